@@ -1,0 +1,391 @@
+"""CPU oracle for elektronn3's 3D U-Net hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module; the product package ``elektronn3_amd`` never does (it fails loudly without its HIP
+library instead of falling back to anything in here).
+
+What is restated (reference file:line, all under /root/reference):
+
+* ``OracleUNet.forward``   <- ``UNet.forward``      elektronn3/models/unet.py:894-916
+* ``_down``                <- ``DownConv.forward``  elektronn3/models/unet.py:244-253
+* ``_up``                  <- ``UpConv.forward``    elektronn3/models/unet.py:384-408
+* ``autocrop``             <- ``autocrop``          elektronn3/models/unet.py:256-325
+* ``tiled_apply``          <- ``tiled_apply``       elektronn3/inference/inference.py:45-199
+* ``predict_tiled``        <- ``Predictor.predict`` elektronn3/inference/inference.py:569-687 (softmax, shape padding)
+
+The arithmetic itself (conv / convT / BN / ReLU / max-pool) lives in torch (third-party,
+``torch>=1.6.0``, requirements.txt:1); it is restated in plain C in ``e3_oracle.c`` and called
+through ctypes.  Pinned by tests/test_oracle_golden.py against tests/golden/*.npz, which were
+generated from the imported reference by tests/golden/make_golden.py.
+"""
+import ctypes
+import itertools
+import os
+import subprocess
+from collections import OrderedDict
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_fp = ctypes.POINTER(ctypes.c_float)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+def build():
+    """Compile oracle/libe3oracle.so with gcc (see oracle/Makefile)."""
+    subprocess.run(['make', '-C', _HERE, '-s'], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, 'libe3oracle.so')
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+    return _LIB
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.dtype == np.float32 and a.flags['C_CONTIGUOUS'], (a.dtype, a.flags)
+    return a.ctypes.data_as(c_fp)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ----------------------------------------------------------------------------- ops
+def conv3d_fwd(x, w, b, pad):
+    x, w = _f32(x), _f32(w)
+    N, Cin, D, H, W = x.shape
+    Cout, _, kd, kh, kw = w.shape
+    y = np.empty((N, Cout, D + 2 * pad[0] - kd + 1, H + 2 * pad[1] - kh + 1, W + 2 * pad[2] - kw + 1), np.float32)
+    lib().orc_conv3d_fwd(_p(x), _p(w), _p(_f32(b)) if b is not None else None, _p(y),
+                         N, Cin, D, H, W, Cout, kd, kh, kw, *pad)
+    return y
+
+
+def conv3d_bwd(x, w, dy, pad, need_dx=True):
+    x, w, dy = _f32(x), _f32(w), _f32(dy)
+    N, Cin, D, H, W = x.shape
+    Cout, _, kd, kh, kw = w.shape
+    dx = None
+    if need_dx:
+        dx = np.empty_like(x)
+        lib().orc_conv3d_bwd_data(_p(dy), _p(w), _p(dx), N, Cin, D, H, W, Cout, kd, kh, kw, *pad)
+    dw = np.empty_like(w)
+    db = np.empty((Cout,), np.float32)
+    lib().orc_conv3d_bwd_weight(_p(x), _p(dy), _p(dw), _p(db), N, Cin, D, H, W, Cout, kd, kh, kw, *pad)
+    return dx, dw, db
+
+
+def convT_fwd(x, w, b):
+    x, w = _f32(x), _f32(w)
+    N, Cin, D, H, W = x.shape
+    _, Cout, sd, sh, sw = w.shape
+    y = np.empty((N, Cout, D * sd, H * sh, W * sw), np.float32)
+    lib().orc_convT_fwd(_p(x), _p(w), _p(_f32(b)) if b is not None else None, _p(y), N, Cin, D, H, W, Cout, sd, sh, sw)
+    return y
+
+
+def convT_bwd(x, w, dy):
+    x, w, dy = _f32(x), _f32(w), _f32(dy)
+    N, Cin, D, H, W = x.shape
+    _, Cout, sd, sh, sw = w.shape
+    dx = np.empty_like(x)
+    dw = np.empty_like(w)
+    db = np.empty((Cout,), np.float32)
+    lib().orc_convT_bwd_data(_p(dy), _p(w), _p(dx), N, Cin, D, H, W, Cout, sd, sh, sw)
+    lib().orc_convT_bwd_weight(_p(x), _p(dy), _p(dw), _p(db), N, Cin, D, H, W, Cout, sd, sh, sw)
+    return dx, dw, db
+
+
+def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
+    """Returns y, save_mean, save_invstd; updates running_* in place (may be None)."""
+    x = _f32(x)
+    N, C = x.shape[:2]
+    S = int(np.prod(x.shape[2:]))
+    y = np.empty_like(x)
+    mean = np.empty((C,), np.float32)
+    invstd = np.empty((C,), np.float32)
+    lib().orc_bn_train_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(invstd),
+                           _p(running_mean), _p(running_var),
+                           ctypes.c_double(momentum), ctypes.c_double(eps), N, C, ctypes.c_size_t(S))
+    return y, mean, invstd
+
+
+def bn_eval_fwd(x, gamma, beta, running_mean, running_var, eps=1e-5):
+    x = _f32(x)
+    N, C = x.shape[:2]
+    S = int(np.prod(x.shape[2:]))
+    y = np.empty_like(x)
+    lib().orc_bn_eval_fwd(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y),
+                          ctypes.c_double(eps), N, C, ctypes.c_size_t(S))
+    return y
+
+
+def bn_train_bwd(dy, x, gamma, mean, invstd):
+    dy, x = _f32(dy), _f32(x)
+    N, C = x.shape[:2]
+    S = int(np.prod(x.shape[2:]))
+    dx = np.empty_like(x)
+    dg = np.empty((C,), np.float32)
+    db = np.empty((C,), np.float32)
+    lib().orc_bn_train_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(invstd), _p(dx), _p(dg), _p(db),
+                           N, C, ctypes.c_size_t(S))
+    return dx, dg, db
+
+
+def relu_fwd(x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().orc_relu_fwd(_p(x), _p(y), ctypes.c_size_t(x.size))
+    return y
+
+
+def relu_bwd(dy, out):
+    dy, out = _f32(dy), _f32(out)
+    dx = np.empty_like(dy)
+    lib().orc_relu_bwd(_p(dy), _p(out), _p(dx), ctypes.c_size_t(dy.size))
+    return dx
+
+
+def maxpool_fwd(x, k):
+    x = _f32(x)
+    N, C, D, H, W = x.shape
+    Do, Ho, Wo = -(-D // k[0]), -(-H // k[1]), -(-W // k[2])
+    y = np.empty((N, C, Do, Ho, Wo), np.float32)
+    idx = np.empty((N, C, Do, Ho, Wo), np.int64)
+    lib().orc_maxpool_fwd(_p(x), _p(y), idx.ctypes.data_as(c_i64p), N, C, D, H, W, *k)
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, in_shape, k):
+    dy = _f32(dy)
+    N, C, D, H, W = in_shape
+    dx = np.empty(in_shape, np.float32)
+    lib().orc_maxpool_bwd(_p(dy), idx.ctypes.data_as(c_i64p), _p(dx), N, C, D, H, W, *k)
+    return dx
+
+
+def softmax_c(x):
+    x = _f32(x)
+    N, C = x.shape[:2]
+    S = int(np.prod(x.shape[2:]))
+    y = np.empty_like(x)
+    lib().orc_softmax_c(_p(x), _p(y), N, C, ctypes.c_size_t(S))
+    return y
+
+
+def autocrop(from_down, from_up):
+    """unet.py:256-325 -- crop decoder output by 1 where (u-d) is odd, centre-crop encoder output."""
+    if from_down.shape[2:] == from_up.shape[2:]:
+        return from_down, from_up, None, None
+    ds, us = from_down.shape[2:], from_up.shape[2:]
+    upcrop = [u - ((u - d) % 2) for d, u in zip(ds, us)]
+    up_sl = (slice(None), slice(None)) + tuple(slice(0, c) for c in upcrop)
+    from_up = from_up[up_sl]
+    us = from_up.shape[2:]
+    assert all(d >= u for d, u in zip(ds, us)), (ds, us)
+    dn_sl = (slice(None), slice(None)) + tuple(slice((d - u) // 2, (d + u) // 2) for d, u in zip(ds, us))
+    from_down = from_down[dn_sl]
+    return from_down, from_up, dn_sl, up_sl
+
+
+# ----------------------------------------------------------------------------- network
+class OracleUNet:
+    """Functional numpy/C restatement of ``UNet(...)`` for the configurations the HIP path supports:
+    dim=3, up_mode='transpose', merge_mode='concat', activation='relu', normalization in
+    {'batch', 'none'}, full_norm=True, conv_mode='same', attention=False, any planar_blocks.
+
+    ``sd`` is a state_dict with the reference's key names (unet.py:832-881); values are numpy arrays.
+    BN running statistics inside ``sd`` are updated in place by a training-mode forward.
+    """
+
+    def __init__(self, sd, n_blocks, planar_blocks=(), normalization='batch', momentum=0.1, eps=1e-5):
+        self.sd = OrderedDict((k, (np.array(v, dtype=np.float32, copy=True) if np.asarray(v).dtype != np.int64
+                                   else np.array(v, copy=True))) for k, v in sd.items())
+        self.n_blocks = n_blocks
+        self.planar = tuple(planar_blocks)
+        self.norm = normalization
+        self.momentum, self.eps = momentum, eps
+        self.training = True
+
+    # -- helpers
+    def _conv(self, name, x, cache):
+        w, b = self.sd[name + '.weight'], self.sd[name + '.bias']
+        pad = tuple((k - 1) // 2 for k in w.shape[2:])
+        cache[name] = (x, pad)
+        return conv3d_fwd(x, w, b, pad)
+
+    def _norm_act(self, name, x, cache):
+        if self.norm == 'batch':
+            g, b = self.sd[name + '.weight'], self.sd[name + '.bias']
+            rm, rv = self.sd[name + '.running_mean'], self.sd[name + '.running_var']
+            if self.training:
+                y, mean, invstd = bn_train_fwd(x, g, b, rm, rv, self.momentum, self.eps)
+                self.sd[name + '.num_batches_tracked'] = self.sd[name + '.num_batches_tracked'] + 1
+                cache[name] = (x, mean, invstd)
+            else:
+                y = bn_eval_fwd(x, g, b, rm, rv, self.eps)
+        else:
+            y = x
+        a = relu_fwd(y)
+        cache[name + '.act'] = a
+        return a
+
+    def forward(self, x):
+        """UNet.forward (unet.py:894-916). Returns logits (N, Cout, D, H, W)."""
+        cache = {}
+        x = _f32(x)
+        enc = []
+        for i in range(self.n_blocks):  # DownConv.forward, unet.py:244-253
+            p = f'down_convs.{i}.'
+            y = self._conv(p + 'conv1', x, cache)
+            y = self._norm_act(p + 'norm0', y, cache)
+            y = self._conv(p + 'conv2', y, cache)
+            y = self._norm_act(p + 'norm1', y, cache)
+            enc.append(y)
+            if i < self.n_blocks - 1:
+                k = (1, 2, 2) if i in self.planar else (2, 2, 2)
+                x, idx = maxpool_fwd(y, k)
+                cache[p + 'pool'] = (idx, y.shape, k)
+            else:
+                x = y
+        for i in range(self.n_blocks - 1):  # UpConv.forward, unet.py:384-408
+            p = f'up_convs.{i}.'
+            before_pool = enc[-(i + 2)]
+            w, b = self.sd[p + 'upconv.weight'], self.sd[p + 'upconv.bias']
+            cache[p + 'upconv'] = x
+            up = convT_fwd(x, w, b)
+            cache[p + 'up_full_shape'] = up.shape
+            before_pool, up, dn_sl, up_sl = autocrop(before_pool, up)
+            cache[p + 'crop'] = (dn_sl, up_sl, enc[-(i + 2)].shape, None)
+            up = self._norm_act(p + 'norm0', np.ascontiguousarray(up), cache)
+            mrg = np.concatenate((up, before_pool), axis=1)
+            y = self._conv(p + 'conv1', mrg, cache)
+            y = self._norm_act(p + 'norm1', y, cache)
+            y = self._conv(p + 'conv2', y, cache)
+            x = self._norm_act(p + 'norm2', y, cache)
+        out = self._conv('conv_final', x, cache)
+        self.cache = cache
+        return out
+
+    # -- backward
+    def _norm_act_bwd(self, name, da, cache, grads):
+        a = cache[name + '.act']
+        dy = relu_bwd(da, a)
+        if self.norm == 'batch':
+            x, mean, invstd = cache[name]
+            dx, dg, db = bn_train_bwd(dy, x, self.sd[name + '.weight'], mean, invstd)
+            grads[name + '.weight'], grads[name + '.bias'] = dg, db
+            return dx
+        return dy
+
+    def _conv_bwd(self, name, dy, cache, grads, need_dx=True):
+        x, pad = cache[name]
+        dx, dw, db = conv3d_bwd(x, self.sd[name + '.weight'], dy, pad, need_dx)
+        grads[name + '.weight'], grads[name + '.bias'] = dw, db
+        return dx
+
+    def backward(self, dout, need_dx=False):
+        """Autograd twin of forward. Returns (grads: name->array, dx or None)."""
+        assert self.training
+        cache, grads = self.cache, OrderedDict()
+        d = self._conv_bwd('conv_final', _f32(dout), cache, grads)
+        enc_grads = [None] * self.n_blocks
+        for i in reversed(range(self.n_blocks - 1)):
+            p = f'up_convs.{i}.'
+            d = self._norm_act_bwd(p + 'norm2', d, cache, grads)
+            d = self._conv_bwd(p + 'conv2', d, cache, grads)
+            d = self._norm_act_bwd(p + 'norm1', d, cache, grads)
+            dmrg = self._conv_bwd(p + 'conv1', d, cache, grads)
+            C = dmrg.shape[1] // 2
+            dup, dskip = np.ascontiguousarray(dmrg[:, :C]), np.ascontiguousarray(dmrg[:, C:])
+            dn_sl, up_sl, enc_shape, _ = cache[p + 'crop']
+            j = self.n_blocks - 2 - i  # encoder block whose before_pool was merged: encoder_outs[-(i+2)]
+            if dn_sl is not None:
+                full = np.zeros(enc_shape, np.float32)
+                full[dn_sl] = dskip
+                dskip = full
+            enc_grads[j] = dskip
+            dup = self._norm_act_bwd(p + 'norm0', dup, cache, grads)
+            if up_sl is not None:
+                full = np.zeros(cache[p + 'up_full_shape'], np.float32)
+                full[up_sl] = dup
+                dup = full
+            xin = cache[p + 'upconv']
+            d, dw, db = convT_bwd(xin, self.sd[p + 'upconv.weight'], dup)
+            grads[p + 'upconv.weight'], grads[p + 'upconv.bias'] = dw, db
+        for i in reversed(range(self.n_blocks)):
+            p = f'down_convs.{i}.'
+            if i < self.n_blocks - 1:
+                idx, shp, k = cache[p + 'pool']
+                d = maxpool_bwd(d, idx, shp, k)
+                d = d + enc_grads[i]
+            d = self._norm_act_bwd(p + 'norm1', d, cache, grads)
+            d = self._conv_bwd(p + 'conv2', d, cache, grads)
+            d = self._norm_act_bwd(p + 'norm0', d, cache, grads)
+            d = self._conv_bwd(p + 'conv1', d, cache, grads, need_dx=(i > 0 or need_dx))
+        return grads, d
+
+
+# ----------------------------------------------------------------------------- tiled inference
+def tile_plan(out_spatial, tile_shape, overlap_shape):
+    """Tile visiting order and coordinates of ``tiled_apply`` (inference.py:153-189): C-order
+    ``itertools.product`` over tile indices; input slab = [tile*pos, tile*(pos+1) + 2*overlap) in
+    padded coordinates; output slab = [tile*pos, tile*(pos+1))."""
+    tile_shape, overlap_shape = np.asarray(tile_shape), np.asarray(overlap_shape)
+    tiles = np.ceil(np.asarray(out_spatial) / tile_shape).astype(int)
+    plan = []
+    for pos in itertools.product(*[range(t) for t in tiles]):
+        pos = np.array(pos)
+        lo, hi = tile_shape * pos, tile_shape * (pos + 1)
+        plan.append((tuple(lo), tuple(hi + 2 * overlap_shape), tuple(lo), tuple(hi)))
+    return plan
+
+
+def tiled_apply(func, inp, tile_shape, overlap_shape, out_shape):
+    """inference.py:45-199 for offset=None ('same' networks): zero-pad by overlap, run ``func`` per
+    tile, keep the central tile_shape region of each result."""
+    inp = _f32(inp)
+    tile_shape, overlap_shape = np.asarray(tile_shape), np.asarray(overlap_shape)
+    if not np.all(np.mod(out_shape[2:], tile_shape) == 0):
+        raise ValueError(f'spatial out shape[2:] {tuple(out_shape[2:])} has to be divisible by tile_shape {tile_shape}.')
+    padded = np.zeros(inp.shape[:2] + tuple(np.asarray(inp.shape[2:]) + 2 * overlap_shape), np.float32)
+    padded[(slice(None), slice(None)) + tuple(slice(o, o + s) for o, s in zip(overlap_shape, inp.shape[2:]))] = inp
+    crop = (slice(None), slice(None)) + tuple(slice(o, o + t) for o, t in zip(overlap_shape, tile_shape))
+    out = None
+    for ilo, ihi, olo, ohi in tile_plan(out_shape[2:], tile_shape, overlap_shape):
+        tile = np.ascontiguousarray(padded[(slice(None), slice(None)) + tuple(slice(l, h) for l, h in zip(ilo, ihi))])
+        res = func(tile)[crop]
+        if out is None:
+            out = np.empty(tuple(out_shape), res.dtype)
+        out[(slice(None), slice(None)) + tuple(slice(l, h) for l, h in zip(olo, ohi))] = res
+    return out
+
+
+def predict_tiled(net, inp, tile_shape, overlap_shape, out_shape, apply_softmax=True):
+    """``Predictor(model, tile_shape=..., overlap_shape=..., out_shape=..., strict_shapes=False).predict``
+    (inference.py:569-687): eval-mode model (+ Softmax(1)), non-divisible out_shape padded up to a tile
+    multiple with zero input (inference.py:645-687), result cropped back to ``out_shape``."""
+    inp = _f32(inp)
+    net.training = False
+    tile_shape = np.asarray(tile_shape)
+    out_shape = np.asarray(out_shape)  # (C, D, H, W)
+    padded_out = out_shape.copy()
+    padded_out[1:] = np.ceil(out_shape[1:] / tile_shape) * tile_shape
+    pin = np.zeros(inp.shape[:2] + tuple(padded_out[1:]), np.float32)
+    pin[(slice(None), slice(None)) + tuple(slice(0, s) for s in inp.shape[2:])] = inp
+
+    def func(tile):
+        y = net.forward(tile)
+        return softmax_c(y) if apply_softmax else y
+
+    out = tiled_apply(func, pin, tile_shape, overlap_shape, (inp.shape[0],) + tuple(padded_out))
+    return out[(slice(None), slice(None)) + tuple(slice(0, s) for s in out_shape[1:])]

@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Runs only in the authoring container (needs /root/reference).  The reference's Python is imported
+by file path (``import elektronn3`` fails here: no colorlog / generated _version.py),
+executed on CPU with torch, and only DATA (inputs, weights, outputs, gradients) is written out as
+.npz.  No reference source text is stored.
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz
+
+Fixtures
+    ops.npz        per-op vectors made with the reference's own layer factories
+                   (unet.py: conv3 :131, upconv2 :152, conv1 :178, get_normalization :77, get_maxpool :67)
+    unet_*.npz     whole-network train step: input, target, state_dict, logits, loss, all parameter
+                   gradients, BN running stats after the step (UNet.forward unet.py:894, Trainer._train_step
+                   trainer.py:509-543 with the example's criterion train_unet_neurodata.py:294-296)
+    predictor.npz  Predictor.predict tiled + padded-shape case (inference.py:569-687)
+    trainsteps.npz 3 AdamW steps: loss trajectory + final weights
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference/elektronn3'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference():
+    """Import unet.py / inference.py / loss.py by path with minimal package stubs."""
+    for pkg in ('elektronn3', 'elektronn3.data', 'elektronn3.modules', 'elektronn3.models'):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = []
+            sys.modules[pkg] = m
+    unet = _load('elektronn3.models.unet', f'{REF}/models/unet.py')
+    # elektronn3.data.utils needs h5py etc.; inference.py only uses utils.calculate_offset, which
+    # needs nothing but torch/numpy -> execute just that file's function in a stub module.
+    utils = types.ModuleType('elektronn3.data.utils')
+    src = open(f'{REF}/data/utils.py').read()
+    start = src.index('def calculate_offset')
+    nxt = src.find('\ndef ', start + 1)
+    src = src[start:nxt if nxt > 0 else None]
+    ns = {'torch': torch, 'np': np, 'logger': __import__('logging').getLogger('golden')}
+    exec(compile(src, f'{REF}/data/utils.py', 'exec'), ns)  # runs reference code in place; nothing is copied
+    utils.calculate_offset = ns['calculate_offset']
+    sys.modules['elektronn3.data.utils'] = utils
+    sys.modules['elektronn3.data'].utils = utils
+    inference = _load('elektronn3.inference.inference', f'{REF}/inference/inference.py')
+    lov = types.ModuleType('elektronn3.modules.lovasz_losses')
+    lov.lovasz_softmax = None
+    sys.modules['elektronn3.modules.lovasz_losses'] = lov
+    loss = _load('elektronn3.modules.loss', f'{REF}/modules/loss.py')
+    return unet, inference, loss
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()  # copy: .numpy() aliases tensors that are later updated in place
+
+
+def make_ops(unet, out):
+    g = torch.Generator().manual_seed(1234)
+    r = lambda *s: torch.randn(*s, generator=g)
+    d = {}
+    # conv 3x3x3, odd sizes, batch 2
+    for tag, cin, cout, shape, planar in (('conv3', 8, 16, (5, 7, 9), False), ('conv3p', 8, 8, (3, 6, 10), True),
+                                          ('conv3c1', 1, 8, (6, 5, 7), False)):
+        m = unet.conv3(cin, cout, planar=planar)
+        with torch.no_grad():
+            m.weight.copy_(r(*m.weight.shape) * 0.2)
+            m.bias.copy_(r(*m.bias.shape))
+        x = r(2, cin, *shape).requires_grad_()
+        y = m(x)
+        dy = r(*y.shape)
+        y.backward(dy)
+        d.update({f'{tag}.x': npy(x), f'{tag}.w': npy(m.weight), f'{tag}.b': npy(m.bias), f'{tag}.y': npy(y),
+                  f'{tag}.dy': npy(dy), f'{tag}.dx': npy(x.grad), f'{tag}.dw': npy(m.weight.grad),
+                  f'{tag}.db': npy(m.bias.grad)})
+    # transposed conv k=s=2 and planar (1,2,2)
+    for tag, cin, cout, shape, planar in (('convT', 16, 8, (3, 4, 5), False), ('convTp', 8, 8, (3, 4, 5), True)):
+        m = unet.upconv2(cin, cout, mode='transpose', planar=planar)
+        with torch.no_grad():
+            m.weight.copy_(r(*m.weight.shape) * 0.2)
+            m.bias.copy_(r(*m.bias.shape))
+        x = r(2, cin, *shape).requires_grad_()
+        y = m(x)
+        dy = r(*y.shape)
+        y.backward(dy)
+        d.update({f'{tag}.x': npy(x), f'{tag}.w': npy(m.weight), f'{tag}.b': npy(m.bias), f'{tag}.y': npy(y),
+                  f'{tag}.dy': npy(dy), f'{tag}.dx': npy(x.grad), f'{tag}.dw': npy(m.weight.grad),
+                  f'{tag}.db': npy(m.bias.grad)})
+    # conv 1x1x1
+    m = unet.conv1(8, 2)
+    with torch.no_grad():
+        m.weight.copy_(r(*m.weight.shape))
+        m.bias.copy_(r(*m.bias.shape))
+    x = r(2, 8, 4, 5, 6).requires_grad_()
+    y = m(x)
+    dy = r(*y.shape)
+    y.backward(dy)
+    d.update({'conv1.x': npy(x), 'conv1.w': npy(m.weight), 'conv1.b': npy(m.bias), 'conv1.y': npy(y),
+              'conv1.dy': npy(dy), 'conv1.dx': npy(x.grad), 'conv1.dw': npy(m.weight.grad), 'conv1.db': npy(m.bias.grad)})
+    # batch norm (train incl. running stats, backward; eval) followed by the reference's ReLU
+    bn = unet.get_normalization('batch', 8)
+    act = unet.get_activation('relu')
+    with torch.no_grad():
+        bn.weight.copy_(r(8) * 0.5 + 1.0)
+        bn.bias.copy_(r(8) * 0.3)
+        bn.running_mean.copy_(r(8) * 0.1)
+        bn.running_var.copy_(torch.rand(8, generator=g) + 0.5)
+    d.update({'bn.gamma': npy(bn.weight), 'bn.beta': npy(bn.bias), 'bn.rm0': npy(bn.running_mean), 'bn.rv0': npy(bn.running_var)})
+    x = (r(2, 8, 5, 6, 7) * 1.7 + 0.4).requires_grad_()
+    bn.train()
+    z = bn(x)
+    a = act(z)
+    da = r(*a.shape)
+    a.backward(da)
+    d.update({'bn.x': npy(x), 'bn.z': npy(z), 'bn.a': npy(a), 'bn.da': npy(da), 'bn.dx': npy(x.grad),
+              'bn.dgamma': npy(bn.weight.grad), 'bn.dbeta': npy(bn.bias.grad), 'bn.rm1': npy(bn.running_mean),
+              'bn.rv1': npy(bn.running_var), 'bn.nbt': npy(bn.num_batches_tracked)})
+    bn.eval()
+    d['bn.z_eval'] = npy(bn(x))
+    # max pool, ceil mode, odd sizes; planar
+    for tag, planar, shape in (('pool', False, (5, 7, 9)), ('poolp', True, (3, 7, 8))):
+        ks = unet.planar_kernel(2) if planar else 2
+        pool = unet.get_maxpool(3)(kernel_size=ks, ceil_mode=True)
+        x = r(2, 8, *shape).requires_grad_()
+        y = pool(x)
+        dy = r(*y.shape)
+        y.backward(dy)
+        d.update({f'{tag}.x': npy(x), f'{tag}.y': npy(y), f'{tag}.dy': npy(dy), f'{tag}.dx': npy(x.grad)})
+    # softmax over C (Predictor wraps model in Sequential(model, Softmax(1)), inference.py:443-444)
+    x = r(2, 2, 3, 4, 5) * 3
+    d.update({'softmax.x': npy(x), 'softmax.y': npy(torch.nn.Softmax(1)(x))})
+    np.savez_compressed(out, **d)
+    print('wrote', out, f'{os.path.getsize(out) / 1e6:.2f} MB')
+
+
+def criterion(loss_mod):
+    """train_unet_neurodata.py:290-296 -- CombinedLoss([CE(w), DiceLoss(softmax, w)], [0.5, 0.5])."""
+    cw = torch.tensor([0.2653, 0.7347])
+    return loss_mod.CombinedLoss([torch.nn.CrossEntropyLoss(weight=cw),
+                                  loss_mod.DiceLoss(apply_softmax=True, weight=cw)], weight=[0.5, 0.5])
+
+
+def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch):
+    torch.manual_seed(seed)
+    model = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
+                      planar_blocks=planar_blocks, activation='relu', normalization='batch')
+    # make BN affine + conv bias non-trivial so that the fixtures exercise them
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if 'norm' in name and name.endswith('weight'):
+                p.copy_(1.0 + 0.2 * torch.randn_like(p))
+            elif name.endswith('bias'):
+                p.copy_(0.1 * torch.randn_like(p))
+    sd0 = {k: npy(v).copy() for k, v in model.state_dict().items()}
+    x = torch.randn(batch, 1, *shape)
+    target = torch.randint(0, 2, (batch, *shape))
+    model.train()
+    crit = criterion(loss_mod)
+    out_t = model(x)
+    loss = crit(out_t, target)
+    dout, = torch.autograd.grad(loss, out_t, retain_graph=True)
+    loss.backward()
+    d = {'cfg.n_blocks': n_blocks, 'cfg.start_filts': start_filts, 'cfg.planar_blocks': np.array(planar_blocks, dtype=np.int64),
+         'x': npy(x), 'target': npy(target), 'logits': npy(out_t), 'loss': npy(loss), 'dlogits': npy(dout)}
+    for k, v in sd0.items():
+        d['sd0/' + k] = v
+    for k, v in model.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            d['sd1/' + k] = npy(v)
+    for k, p in model.named_parameters():
+        d['grad/' + k] = npy(p.grad)
+    model.eval()
+    with torch.no_grad():
+        d['logits_eval'] = npy(model(x))
+    # fp64 reference of the same step (tolerances are stated against it)
+    m64 = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
+                    planar_blocks=planar_blocks, activation='relu', normalization='batch').double()
+    m64.load_state_dict({k: torch.as_tensor(v).double() if v.dtype != np.int64 else torch.as_tensor(v) for k, v in sd0.items()})
+    m64.train()
+    o64 = m64(x.double())
+    crit64 = criterion(loss_mod).double()
+    l64 = crit64(o64, target)
+    l64.backward()
+    d['logits64'] = npy(o64).astype(np.float32)  # fp64 result rounded once to fp32 (keeps the fixture small)
+    for k, p in m64.named_parameters():
+        d['grad64/' + k] = npy(p.grad).astype(np.float32)
+    np.savez_compressed(out, **d)
+    print('wrote', out, f'{os.path.getsize(out) / 1e6:.2f} MB', 'loss', float(loss))
+
+
+def make_predictor(unet, inference, out):
+    torch.manual_seed(7)
+    model = unet.UNet(in_channels=1, out_channels=2, n_blocks=2, start_filts=8, normalization='batch')
+    model.train()
+    with torch.no_grad():
+        for _ in range(3):  # move the running stats off their init values
+            model(torch.randn(2, 1, 8, 16, 16) * 1.5 + 0.3)
+    sd = {k: npy(v).copy() for k, v in model.state_dict().items()}
+    vol = torch.randn(1, 1, 20, 40, 36)
+    tile, overlap, out_shape = (8, 16, 16), (4, 8, 8), (2, 20, 40, 36)
+    pred = inference.Predictor(model, device='cpu', tile_shape=tile, overlap_shape=overlap, offset=(0, 0, 0),
+                               out_shape=out_shape, apply_softmax=True, strict_shapes=False)
+    y = pred.predict(vol)
+    # untiled whole-volume prediction through the same class
+    pred2 = inference.Predictor(model.eval(), device='cpu', apply_softmax=True)
+    y2 = pred2.predict(vol)
+    # divisible case + argmax output
+    vol3 = torch.randn(2, 1, 16, 32, 32)
+    pred3 = inference.Predictor(model, device='cpu', tile_shape=tile, overlap_shape=overlap, offset=(0, 0, 0),
+                                out_shape=(2, 16, 32, 32), apply_softmax=True, apply_argmax=True)
+    y3 = pred3.predict(vol3)
+    d = {'vol': npy(vol), 'tile': np.array(tile), 'overlap': np.array(overlap), 'out_shape': np.array(out_shape),
+         'out_tiled': npy(y), 'out_untiled': npy(y2), 'vol3': npy(vol3), 'out3_argmax': npy(y3)}
+    for k, v in sd.items():
+        d['sd/' + k] = v
+    np.savez_compressed(out, **d)
+    print('wrote', out, f'{os.path.getsize(out) / 1e6:.2f} MB')
+
+
+def make_trainsteps(unet, loss_mod, out):
+    torch.manual_seed(11)
+    model = unet.UNet(in_channels=1, out_channels=2, n_blocks=2, start_filts=8, normalization='batch')
+    sd0 = {k: npy(v).copy() for k, v in model.state_dict().items()}
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.5e-4)  # train_unet_neurodata.py:257-262 (w/o SWA wrapper)
+    crit = criterion(loss_mod)
+    xs = torch.randn(3, 2, 1, 8, 16, 16)
+    ts = torch.randint(0, 2, (3, 2, 8, 16, 16))
+    losses = []
+    model.train()
+    for i in range(3):
+        out_t = model(xs[i])
+        loss = crit(out_t, ts[i])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    d = {'xs': npy(xs), 'ts': npy(ts), 'losses': np.array(losses, dtype=np.float64)}
+    for k, v in sd0.items():
+        d['sd0/' + k] = v
+    for k, v in model.state_dict().items():
+        d['sd3/' + k] = npy(v)
+    np.savez_compressed(out, **d)
+    print('wrote', out, f'{os.path.getsize(out) / 1e6:.2f} MB', losses)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    unet, inference, loss_mod = load_reference()
+    make_ops(unet, f'{HERE}/ops.npz')
+    # cfg 1 of BASELINE.json at a reduced crop: UNet(1,2,n_blocks=2,start_filts=8)
+    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8.npz', seed=0, n_blocks=2, start_filts=8, planar_blocks=(), shape=(16, 24, 24), batch=1)
+    # odd sizes (ceil-mode pooling + autocrop of the up-convolved tensor), batch 2, planar first block
+    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_planar0_odd.npz', seed=1, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 17, 21), batch=2)
+    # the headline depth (n_blocks=4) at start_filts=8, cfg-4 style mixed 3D/2D (planar_blocks=(0,1))
+    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb4_sf8_planar01.npz', seed=2, n_blocks=4, start_filts=8, planar_blocks=(0, 1), shape=(8, 32, 32), batch=2)
+    make_predictor(unet, inference, f'{HERE}/predictor.npz')
+    make_trainsteps(unet, loss_mod, f'{HERE}/trainsteps.npz')

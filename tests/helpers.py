@@ -1,0 +1,56 @@
+"""Shared helpers for the test-suite (test infrastructure)."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_npz(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def sub(npz, prefix):
+    """Entries of an npz whose key starts with 'prefix/' as an OrderedDict without the prefix."""
+    return OrderedDict((k[len(prefix) + 1:], npz[k]) for k in npz.files if k.startswith(prefix + '/'))
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def unet_cfg(npz):
+    return dict(n_blocks=int(npz['cfg.n_blocks']), start_filts=int(npz['cfg.start_filts']),
+                planar_blocks=tuple(int(v) for v in npz['cfg.planar_blocks']))
+
+
+CLASS_WEIGHTS = (0.2653, 0.7347)
+
+
+def combined_loss_np(logits, target, cw=CLASS_WEIGHTS):
+    """0.5*CrossEntropy(weight=cw) + 0.5*Dice(softmax, weight=cw) in float64 numpy and its gradient
+    w.r.t. logits.  Restates the example's criterion (examples/train_unet_neurodata.py:294-296;
+    modules/loss.py:19-49,165-189) for the tests only -- the loss itself stays PyTorch in the product."""
+    z = np.asarray(logits, np.float64)
+    N, C = z.shape[:2]
+    t = np.asarray(target)
+    cw = np.asarray(cw, np.float64)
+    zmax = z.max(axis=1, keepdims=True)
+    e = np.exp(z - zmax)
+    p = e / e.sum(axis=1, keepdims=True)
+    onehot = np.zeros_like(p)
+    np.put_along_axis(onehot, t[:, None], 1.0, axis=1)
+    wmap = cw[t]  # (N, ...)
+    logp = np.log(p)
+    ce = -(wmap * np.take_along_axis(logp, t[:, None], axis=1)[:, 0]).sum() / wmap.sum()
+    dce = (wmap[:, None] * (p - onehot)) / wmap.sum()
+    axes = (0,) + tuple(range(2, z.ndim))
+    num = 2 * (p * onehot).sum(axis=axes)
+    den = (p + onehot).sum(axis=axes) + 1e-4
+    dice = (cw * (1 - num / den)).mean()
+    shp = (1, C) + (1,) * (z.ndim - 2)
+    dL_dp = (cw / C).reshape(shp) * (-(2 * onehot) / den.reshape(shp) + (num / den ** 2).reshape(shp))
+    ddice = p * (dL_dp - (dL_dp * p).sum(axis=1, keepdims=True))
+    return 0.5 * ce + 0.5 * dice, 0.5 * dce + 0.5 * ddice

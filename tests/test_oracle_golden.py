@@ -1,0 +1,130 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the imported reference
+(tests/golden/make_golden.py).  CPU only.
+
+Tolerances: the reference's own fp32-vs-fp64 noise floor is ~5e-6..4e-5 max-abs on
+logits and 2e-4..4e-3 rel-L2 on weight gradients.  The oracle accumulates in double, so it is
+compared (a) against the reference's fp32 results within that floor and (b) against the
+reference's fp64 results, where it must be at least as close as the fp32 reference is.
+"""
+import numpy as np
+import pytest
+
+from helpers import combined_loss_np, load_npz, rel_l2, sub, unet_cfg
+from oracle import unet_oracle as orc
+
+
+@pytest.fixture(scope='module')
+def ops():
+    return load_npz('ops.npz')
+
+
+@pytest.mark.parametrize('tag,pad', [('conv3', (1, 1, 1)), ('conv3p', (0, 1, 1)), ('conv3c1', (1, 1, 1)), ('conv1', (0, 0, 0))])
+def test_conv(ops, tag, pad):
+    x, w, b = ops[f'{tag}.x'], ops[f'{tag}.w'], ops[f'{tag}.b']
+    y = orc.conv3d_fwd(x, w, b, pad)
+    np.testing.assert_allclose(y, ops[f'{tag}.y'], rtol=1e-5, atol=2e-5)
+    dx, dw, db = orc.conv3d_bwd(x, w, ops[f'{tag}.dy'], pad)
+    np.testing.assert_allclose(dx, ops[f'{tag}.dx'], rtol=1e-5, atol=2e-5)
+    assert rel_l2(dw, ops[f'{tag}.dw']) < 1e-5
+    assert rel_l2(db, ops[f'{tag}.db']) < 1e-5
+
+
+@pytest.mark.parametrize('tag', ['convT', 'convTp'])
+def test_convT(ops, tag):
+    x, w, b = ops[f'{tag}.x'], ops[f'{tag}.w'], ops[f'{tag}.b']
+    np.testing.assert_allclose(orc.convT_fwd(x, w, b), ops[f'{tag}.y'], rtol=1e-5, atol=2e-5)
+    dx, dw, db = orc.convT_bwd(x, w, ops[f'{tag}.dy'])
+    np.testing.assert_allclose(dx, ops[f'{tag}.dx'], rtol=1e-5, atol=2e-5)
+    assert rel_l2(dw, ops[f'{tag}.dw']) < 1e-5
+    assert rel_l2(db, ops[f'{tag}.db']) < 1e-5
+
+
+def test_batchnorm_relu(ops):
+    rm, rv = ops['bn.rm0'].copy(), ops['bn.rv0'].copy()
+    z, mean, invstd = orc.bn_train_fwd(ops['bn.x'], ops['bn.gamma'], ops['bn.beta'], rm, rv)
+    np.testing.assert_allclose(z, ops['bn.z'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(rm, ops['bn.rm1'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(rv, ops['bn.rv1'], rtol=1e-6, atol=1e-6)
+    a = orc.relu_fwd(z)
+    np.testing.assert_allclose(a, ops['bn.a'], rtol=1e-5, atol=1e-5)
+    dz = orc.relu_bwd(ops['bn.da'], ops['bn.a'])
+    dx, dg, db = orc.bn_train_bwd(dz, ops['bn.x'], ops['bn.gamma'], mean, invstd)
+    np.testing.assert_allclose(dx, ops['bn.dx'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dg, ops['bn.dgamma'], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db, ops['bn.dbeta'], rtol=1e-4, atol=1e-4)
+    ze = orc.bn_eval_fwd(ops['bn.x'], ops['bn.gamma'], ops['bn.beta'], ops['bn.rm1'], ops['bn.rv1'])
+    np.testing.assert_allclose(ze, ops['bn.z_eval'], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('tag,k', [('pool', (2, 2, 2)), ('poolp', (1, 2, 2))])
+def test_maxpool_ceil(ops, tag, k):
+    x = ops[f'{tag}.x']
+    y, idx = orc.maxpool_fwd(x, k)
+    np.testing.assert_array_equal(y, ops[f'{tag}.y'])  # bit-exact: pure selection
+    dx = orc.maxpool_bwd(ops[f'{tag}.dy'], idx, x.shape, k)
+    np.testing.assert_array_equal(dx, ops[f'{tag}.dx'])
+
+
+def test_softmax(ops):
+    np.testing.assert_allclose(orc.softmax_c(ops['softmax.x']), ops['softmax.y'], rtol=1e-6, atol=1e-7)
+
+
+CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz']
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_unet_train_step(case):
+    g = load_npz(case)
+    cfg = unet_cfg(g)
+    net = orc.OracleUNet(sub(g, 'sd0'), cfg['n_blocks'], cfg['planar_blocks'])
+    logits = net.forward(g['x'])
+    # forward: fp32 reference noise floor is <= 4e-5 max-abs
+    np.testing.assert_allclose(logits, g['logits'], rtol=1e-4, atol=1e-4)
+    assert np.abs(logits - g['logits64']).max() <= max(2 * np.abs(g['logits'] - g['logits64']).max(), 2e-6)
+    # BN running statistics after the step
+    for k, v in sub(g, 'sd1').items():
+        if k.endswith('num_batches_tracked'):
+            assert int(net.sd[k]) == int(v)
+        else:
+            np.testing.assert_allclose(net.sd[k], v, rtol=1e-5, atol=1e-6, err_msg=k)
+    # loss + dlogits restated in numpy (tests/helpers.py) against the reference criterion
+    loss, dlogits = combined_loss_np(logits, g['target'])
+    assert abs(loss - float(g['loss'])) < 1e-5
+    np.testing.assert_allclose(dlogits, g['dlogits'], rtol=1e-3, atol=1e-9)
+    grads, _ = net.backward(g['dlogits'])
+    ref32, ref64 = sub(g, 'grad'), sub(g, 'grad64')
+    assert set(grads) == set(ref32)
+    gnorm = np.sqrt(sum(float(np.sum(v.astype(np.float64) ** 2)) for v in ref64.values()))
+    for k in ref32:
+        is_prebn_bias = k.endswith('.bias') and ('conv1' in k or 'conv2' in k or 'upconv' in k) and k != 'conv_final.bias'
+        if is_prebn_bias:  # analytically zero gradient (bias feeding a train-mode BN): absolute tolerance only
+            assert np.abs(grads[k]).max() <= 1e-5 * gnorm, k
+            continue
+        err_o = rel_l2(grads[k], ref64[k])
+        err_r = rel_l2(ref32[k], ref64[k])
+        assert err_o <= max(3 * err_r, 1e-4), (k, err_o, err_r)
+
+
+def test_unet_eval_forward():
+    g = load_npz('unet_nb2_sf8.npz')
+    cfg = unet_cfg(g)
+    sd = sub(g, 'sd0')
+    sd.update(sub(g, 'sd1'))  # eval logits were produced after the train step updated the running stats
+    net = orc.OracleUNet(sd, cfg['n_blocks'], cfg['planar_blocks'])
+    net.training = False
+    np.testing.assert_allclose(net.forward(g['x']), g['logits_eval'], rtol=1e-4, atol=1e-5)
+
+
+def test_predictor_tiled():
+    g = load_npz('predictor.npz')
+    net = orc.OracleUNet(sub(g, 'sd'), 2)
+    out = orc.predict_tiled(net, g['vol'], g['tile'], g['overlap'], g['out_shape'])
+    assert out.shape == g['out_tiled'].shape
+    np.testing.assert_allclose(out, g['out_tiled'], rtol=1e-4, atol=1e-5)
+    # tiled != untiled by construction (overlap < receptive field), SURVEY.md 8c
+    assert np.abs(g['out_tiled'] - g['out_untiled']).max() > 1e-4
+    plan = orc.tile_plan(np.ceil(g['out_shape'][1:] / g['tile']) * g['tile'], g['tile'], g['overlap'])
+    assert len(plan) == 3 * 3 * 3 and plan[0][0] == (0, 0, 0) and plan[1][0] == (0, 0, 16)
+    out3 = orc.predict_tiled(net, g['vol3'], g['tile'], g['overlap'], (2, 16, 32, 32))
+    am = out3.argmax(axis=1)[:, None].astype(np.uint8)
+    assert (am != g['out3_argmax']).mean() < 1e-4  # argmax may flip only where p0 ~ p1 within fp32 noise
