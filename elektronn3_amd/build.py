@@ -1,0 +1,67 @@
+"""Builds elektronn3_amd/libe3unet.so (hand-written HIP for gfx950) with hipcc, in-tree.
+
+    python -m elektronn3_amd.build        # or: from elektronn3_amd.build import build; build()
+
+The .so is git-ignored but travels with the tree (e.g. to the GPU box); it is rebuilt only when a source is newer.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(HERE, 'libe3unet.so')
+OBJDIR = os.path.join(HERE, 'build')
+SOURCES = ['conv_mfma.hip', 'wgrad_mfma.hip', 'conv_small.hip', 'elementwise.hip', 'api.cpp', 'unet_plan.cpp']
+HEADERS = ['common.h', 'kernels.h', os.path.join('..', '..', 'include', 'e3unet.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-x', 'hip']
+
+
+def _hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found: libe3unet.so cannot be built on this machine')
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    if not force and not _stale(OUT, srcs + hdrs + [os.path.abspath(__file__)]):
+        return OUT
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, os.path.basename(src) + '.o')
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr}')
+            if verbose and r.stderr.strip():
+                print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'link failed:\n{r.stderr}')
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,71 @@
+// Common definitions for libe3unet (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define E3_OK 0
+#define E3_ERR_INVALID 1
+#define E3_ERR_HIP 2
+#define E3_ERR_UNSUPPORTED 3
+#define E3_ERR_WORKSPACE 4
+
+void e3_set_error(const std::string& msg);
+
+#define E3_CHECK_HIP(expr)                                                                     \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            e3_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+            return E3_ERR_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+#define E3_REQUIRE(cond, code, msg)                                                            \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            e3_set_error(std::string(msg) + " [" #cond "]");                                   \
+            return (code);                                                                     \
+        }                                                                                      \
+    } while (0)
+
+// Activations live in HBM as NDHWC fp32.  A view addresses `C` channels starting at `ptr`
+// inside rows of `ldc` floats per voxel, so producers can write straight into one half of a
+// concat buffer (torch.cat disappears, unet.py:398-399).
+struct View {
+    float* ptr;
+    int N, D, H, W, C;
+    int ldc;
+    __host__ __device__ size_t voxels() const { return (size_t)N * D * H * W; }
+};
+
+static inline View make_view(float* p, int N, int D, int H, int W, int C, int ldc = 0) {
+    View v; v.ptr = p; v.N = N; v.D = D; v.H = H; v.W = W; v.C = C; v.ldc = ldc ? ldc : C; return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bijective XCD-aware block remap (cdna guide T1): physical block b runs on XCD b % 8; give each
+// XCD a contiguous range of logical ids so that neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned xcd = bid & 7u, q = nblk >> 3, r = nblk & 7u;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// Chan/Welford merge of (count, mean, M2) records; robust for na == 0 or nb == 0.
+__device__ __forceinline__ void welford_merge(float& na, float& ma, float& sa, float nb, float mb, float sb) {
+    const float n = na + nb;
+    if (n > 0.f) {
+        const float d = mb - ma;
+        const float f = nb / n;
+        ma += d * f;
+        sa += sb + d * d * na * f;
+        na = n;
+    }
+}

@@ -1,0 +1,289 @@
+// Implicit-GEMM 3D convolution on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the ATen/MIOpen kernels behind elektronn3's `conv3()` (nn.Conv3d k=3 / (1,3,3), unet.py:131-149)
+// and, in POINT mode, the GEMM inside `upconv2('transpose')` (nn.ConvTranspose3d k=s=2, unet.py:152-165).
+// The same kernel computes the data gradient (dgrad = conv with flipped, role-swapped weights).
+//
+// GEMM view:  rows  = output voxels (a TDxTHxTW = 256-voxel brick per workgroup, 64 per wave)
+//             cols  = output channels (32*NT per workgroup)
+//             K     = taps x input channels, walked as  [channel chunk CK] x [tap]
+// A operand:  the brick's input halo ((TD+2)x(TH+2)x(TW+2) voxels x CK channels) is staged ONCE per channel
+//             chunk into LDS (zero padding and the optional BN+ReLU prologue applied on the way); every tap
+//             then reads it at a compile-time LDS offset with ds_read_b128 (4 consecutive channels per lane =
+//             the k-slices of 4 consecutive MFMAs).  Voxel stride CK+4 floats keeps those reads conflict-free.
+// B operand:  packed weights [tap][co][ci] are read straight from global memory (L1/L2 resident: every
+//             workgroup walks the same 27*Cin*Cout*4 B), one float4 per lane per 4 MFMAs, register
+//             double-buffered one tap ahead.  No per-tap barrier: the only barriers bracket the halo staging.
+// fp32 MFMA is exact fp32 (an fmaf chain) at 157 TFLOP/s dense; LDS and L1 traffic per MFMA is tiny because a
+// 32x32x2 MFMA takes 64 cycles, so the kernel is matrix-pipe bound, not LDS bound.
+#include "kernels.h"
+
+namespace {
+
+template <int KD, int KHW, int TD, int TH, int TW, int CK>
+struct Geo {
+    static constexpr int PD = KD / 2, PH = KHW / 2;
+    static constexpr int LD = TD + 2 * PD, LH = TH + 2 * PH, LW = TW + 2 * PH;
+    static constexpr int VS = CK + 4;                 // LDS floats per voxel (padded)
+    static constexpr int NVOX = LD * LH * LW;
+    static constexpr int T = KD * KHW * KHW;
+    static constexpr int LDS_BYTES = NVOX * VS * 4;
+    static_assert(TD * TH * TW == 256, "brick must hold 256 voxels (4 waves x 64 rows)");
+    static_assert(TW == 16, "row mapping assumes 16 voxels along W");
+};
+
+template <int KD, int KHW, int TD, int TH, int TW, int CK, int NT>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+    using G = Geo<KD, KHW, TD, TH, TW, CK>;
+    constexpr int VS = G::VS, LH = G::LH, LW = G::LW, PD = G::PD, PH = G::PH, T = G::T, K8 = CK / 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hf = lane >> 5;
+
+    // ---- which brick / column tile (XCD-aware: neighbours in (ntile, w, h, d) order share an L2)
+    const unsigned nblk = gridDim.x;
+    unsigned L = xcd_remap(blockIdx.x, nblk);
+    const int ntile = L % a.ntiles; L /= a.ntiles;
+    const int tw_ = L % a.tilesW; L /= a.tilesW;
+    const int th_ = L % a.tilesH; L /= a.tilesH;
+    const int td_ = L % a.tilesD; const int nb = L / a.tilesD;
+    const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * TW;
+    const int n0 = ntile * 32 * NT;
+    const int mtile = ((nb * a.tilesD + td_) * a.tilesH + th_) * a.tilesW + tw_;
+    const bool gather = (a.flags & CF_GATHER_UP) != 0;
+    const bool scatter = (a.flags & CF_SCATTER_UP) != 0;
+
+    // ---- per-lane LDS base of its two 32-row sub-tiles (rows = voxels)
+    int abase[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int m = wave * 64 + s * 32 + j;
+        const int ww = m & 15, hh = (m >> 4) % TH, dd = (m >> 4) / TH;
+        abase[s] = ((dd * LH + hh) * LW + ww) * VS + 4 * hf;
+    }
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ns = 0; ns < NT; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][ns][r] = 0.f;
+
+    const size_t tapstride = (size_t)a.NPad * a.Cin;
+    const bool pro = a.pro_scale != nullptr;
+
+    for (int g = 0; g < a.G; ++g) {
+        int gtd = 0, gth = 0, gtw = 0;
+        if (gather) { gtw = g & 1; gth = (g >> 1) & 1; gtd = g >> 2; }
+        for (int cb = 0; cb < a.Cin; cb += CK) {
+            __syncthreads();
+            // ---- stage the halo brick of channels [cb, cb+CK) into LDS
+            constexpr int Q = CK / 4;
+            constexpr int ITEMS = G::NVOX * Q;
+#pragma unroll 4
+            for (int idx = tid; idx < ITEMS; idx += 256) {
+                const int v = idx / Q, q = idx % Q;
+                const int zw = v % LW; const int t2 = v / LW; const int zh = t2 % LH; const int zd = t2 / LH;
+                int gd = d0 + zd - PD, gh = h0 + zh - PH, gw = w0 + zw - PH;
+                bool ok = gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+                size_t off;
+                if (gather) {
+                    gd = a.sd * gd + gtd; gh = 2 * gh + gth; gw = 2 * gw + gtw;
+                    ok = ok && gd < a.Do && gh < a.Ho && gw < a.Wo;
+                    off = ((((size_t)nb * a.Do + gd) * a.Ho + gh) * a.Wo + gw) * a.x_ldc + cb + 4 * q;
+                } else {
+                    off = ((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.x_ldc + cb + 4 * q;
+                }
+                f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                if (ok) {
+                    val = *reinterpret_cast<const f32x4*>(a.x + off);
+                    if (pro) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.pro_scale + cb + 4 * q);
+                        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.pro_shift + cb + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) val[e] = fmaxf(__builtin_fmaf(val[e], sc[e], sh[e]), 0.f);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(smem + v * VS + 4 * q) = val;
+            }
+            __syncthreads();
+
+            // ---- walk the taps; B fragments come from global, one tap ahead
+            const float* wl = a.wt + ((size_t)g * T * a.NPad + n0 + j) * a.Cin + cb + 4 * hf;
+            f32x4 bcur[NT][K8];
+#pragma unroll
+            for (int ns = 0; ns < NT; ++ns)
+#pragma unroll
+                for (int k8 = 0; k8 < K8; ++k8)
+                    bcur[ns][k8] = *reinterpret_cast<const f32x4*>(wl + (size_t)ns * 32 * a.Cin + k8 * 8);
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap) {
+                f32x4 bnx[NT][K8];
+                if (tap + 1 < T) {
+                    const float* wn = wl + (size_t)(tap + 1) * tapstride;
+#pragma unroll
+                    for (int ns = 0; ns < NT; ++ns)
+#pragma unroll
+                        for (int k8 = 0; k8 < K8; ++k8)
+                            bnx[ns][k8] = *reinterpret_cast<const f32x4*>(wn + (size_t)ns * 32 * a.Cin + k8 * 8);
+                }
+                const int kd = tap / (KHW * KHW), kh = (tap / KHW) % KHW, kw = tap % KHW;
+                const int tapoff = ((kd * LH + kh) * LW + kw) * VS;
+#pragma unroll
+                for (int k8 = 0; k8 < K8; ++k8) {
+                    f32x4 av[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        av[s] = *reinterpret_cast<const f32x4*>(smem + abase[s] + tapoff + k8 * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int ns = 0; ns < NT; ++ns)
+#pragma unroll
+                            for (int s = 0; s < 2; ++s)
+                                acc[s][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][e], bcur[ns][k8][e], acc[s][ns], 0, 0, 0);
+                }
+                if (tap + 1 < T) {
+#pragma unroll
+                    for (int ns = 0; ns < NT; ++ns)
+#pragma unroll
+                        for (int k8 = 0; k8 < K8; ++k8) bcur[ns][k8] = bnx[ns][k8];
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias (+ folded BN + ReLU in eval mode), store, per-tile channel statistics
+    const bool do_stats = a.stats != nullptr;
+    const bool aff = a.epi_scale != nullptr;
+    if (do_stats) __syncthreads();   // all waves are done reading the halo: LDS is reused as scratch below
+#pragma unroll
+    for (int ns = 0; ns < NT; ++ns) {
+        const int n = n0 + 32 * ns + j;
+        const bool nvalid = n < a.Ncols;
+        int co = n, utd = 0, uth = 0, utw = 0, ut = 0;
+        if (scatter) { ut = n / a.Cout; co = n - ut * a.Cout; utw = ut & 1; uth = (ut >> 1) & 1; utd = ut >> 2; }
+        const float bias = (a.bias && nvalid) ? a.bias[co] : 0.f;
+        float es = 1.f, eh = 0.f;
+        if (aff && nvalid) { es = a.epi_scale[co]; eh = a.epi_shift[co]; }
+        float cnt = 0.f, sum = 0.f;
+        unsigned okmask = 0u;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                const int m = wave * 64 + s * 32 + row;
+                const int gw = w0 + (m & 15), gh = h0 + (m >> 4) % TH, gd = d0 + (m >> 4) / TH;
+                bool ok = nvalid && gd < a.D && gh < a.H && gw < a.W;
+                size_t off;
+                if (scatter) {
+                    const int od = a.sd * gd + utd, oh = 2 * gh + uth, ow = 2 * gw + utw;
+                    ok = ok && od < a.Do && oh < a.Ho && ow < a.Wo;
+                    off = ((((size_t)nb * a.Do + od) * a.Ho + oh) * a.Wo + ow) * a.y_ldc + co;
+                } else {
+                    off = ((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.y_ldc + co;
+                }
+                float v = acc[s][ns][r] + bias;
+                if (aff) v = fmaxf(__builtin_fmaf(v, es, eh), 0.f);
+                acc[s][ns][r] = v;
+                if (ok) {
+                    a.y[off] = v;
+                    cnt += 1.f; sum += v;
+                    okmask |= 1u << (s * 16 + r);
+                }
+            }
+        if (do_stats) {
+            float mean = cnt > 0.f ? sum / cnt : 0.f, m2 = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (okmask & (1u << (s * 16 + r))) { const float d = acc[s][ns][r] - mean; m2 += d * d; }
+            // other half-wave holds the other 32 rows of the same column
+            const float cnt2 = __shfl_xor(cnt, 32), mean2 = __shfl_xor(mean, 32), m22 = __shfl_xor(m2, 32);
+            welford_merge(cnt, mean, m2, cnt2, mean2, m22);
+            if (hf == 0) {
+                float* sc = smem + ((wave * NT + ns) * 32 + j) * 3;
+                sc[0] = cnt; sc[1] = mean; sc[2] = m2;
+            }
+        }
+    }
+    if (do_stats) {
+        __syncthreads();
+        if (tid < 32 * NT) {
+            const int ns = tid >> 5, jj = tid & 31;
+            const int n = n0 + 32 * ns + jj;
+            if (n < a.Ncols) {
+                float cnt = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float* sc = smem + ((w * NT + ns) * 32 + jj) * 3;
+                    welford_merge(cnt, mean, m2, sc[0], sc[1], sc[2]);
+                }
+                int co = n, pidx = mtile;
+                if (scatter) { const int ut = n / a.Cout; co = n - ut * a.Cout; pidx = mtile * (a.Ncols / a.Cout) + ut; }
+                float* o = a.stats + ((size_t)pidx * a.Cout + co) * 3;
+                o[0] = cnt; o[1] = mean; o[2] = m2;
+            }
+        }
+    }
+}
+
+template <int KD, int KHW, int TD, int TH, int TW, int CK, int NT>
+int launch_inst(ConvArgs a, hipStream_t s) {
+    using G = Geo<KD, KHW, TD, TH, TW, CK>;
+    a.tilesD = cdiv(a.D, TD); a.tilesH = cdiv(a.H, TH); a.tilesW = cdiv(a.W, TW);
+    a.ntiles = a.NPad / (32 * NT);
+    const size_t nblk = (size_t)a.N * a.tilesD * a.tilesH * a.tilesW * a.ntiles;
+    E3_REQUIRE(nblk > 0 && nblk < (1u << 31), E3_ERR_INVALID, "conv grid out of range");
+    auto kern = conv_mfma_kernel<KD, KHW, TD, TH, TW, CK, NT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), G::LDS_BYTES, s, a);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+template <int KD, int KHW, int TD, int TH, int TW>
+int dispatch_ck_nt(const ConvArgs& a, hipStream_t s) {
+    const bool ck16 = (a.Cin % 16) == 0;
+    const bool nt2 = conv_col_tile(a.Ncols) == 64;
+    if (ck16) return nt2 ? launch_inst<KD, KHW, TD, TH, TW, 16, 2>(a, s) : launch_inst<KD, KHW, TD, TH, TW, 16, 1>(a, s);
+    return nt2 ? launch_inst<KD, KHW, TD, TH, TW, 8, 2>(a, s) : launch_inst<KD, KHW, TD, TH, TW, 8, 1>(a, s);
+}
+
+}  // namespace
+
+int conv_col_tile(int ncols) { return ncols >= 64 ? 64 : 32; }
+
+static void brick_dims(ConvKind kind, int& TD, int& TH, int& TW) {
+    if (kind == CONV_K3_PLANAR) { TD = 1; TH = 16; TW = 16; } else { TD = 2; TH = 8; TW = 16; }
+}
+
+int conv_stats_parts(ConvKind kind, int flags, int N, int D, int H, int W, int sd) {
+    int TD, TH, TW; brick_dims(kind, TD, TH, TW);
+    int parts = N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, TW);
+    if (flags & CF_SCATTER_UP) parts *= sd * 4;
+    return parts;
+}
+
+int launch_conv_mfma(ConvKind kind, ConvArgs a, hipStream_t s) {
+    E3_REQUIRE(a.Cin % 8 == 0 && a.Cin >= 8, E3_ERR_UNSUPPORTED, "MFMA conv needs input channels to be a multiple of 8");
+    E3_REQUIRE(a.x_ldc % 4 == 0 && ((uintptr_t)a.x % 16) == 0, E3_ERR_INVALID, "conv input view must be 16-byte aligned");
+    E3_REQUIRE(a.NPad % conv_col_tile(a.Ncols) == 0 && a.NPad >= a.Ncols, E3_ERR_INVALID, "bad NPad");
+    if (a.G <= 0) a.G = 1;
+    switch (kind) {
+        case CONV_K3: return dispatch_ck_nt<3, 3, 2, 8, 16>(a, s);
+        case CONV_K3_PLANAR: return dispatch_ck_nt<1, 3, 1, 16, 16>(a, s);
+        case CONV_POINT: return dispatch_ck_nt<1, 1, 2, 8, 16>(a, s);
+    }
+    e3_set_error("unknown conv kind");
+    return E3_ERR_INVALID;
+}

@@ -1,0 +1,389 @@
+// Direct (VALU) kernels for the two HBM-bound convolutions at the ends of the U-Net:
+//   * the first 3x3x3 / 1x3x3 conv, whose input has in_channels (1..7) channels   (unet.py:218-220, SURVEY 8d: 13 FLOP/B)
+//   * the final 1x1x1 conv C -> out_channels (<= 8)                                 (unet.py:178-180,881,912: 0.9 FLOP/B)
+// and their gradients.  Neither has a dense contraction (K = 27 or N = 2), so they do not go to the matrix cores.
+#include "kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------ first conv, forward
+// brick = 256 voxels (2x8x16, planar 1x16x16); thread = (channel quad q = tid%8, voxel group g = tid/8) and
+// computes 8 voxels x 4 channels.  x halo and the [ci][tap][32] weight slab live in LDS; the 27x4 weights of the
+// current input channel are held in registers.
+template <int KD, int TD, int TH>
+__global__ __launch_bounds__(256) void conv_small_fwd_kernel(const ConvSmallArgs a, int tilesD, int tilesH, int tilesW) {
+    constexpr int TW = 16, PD = KD / 2, LD = TD + 2 * PD, LH = TH + 2, LW = TW + 2, NV = LD * LH * LW, T = KD * 9;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                       // [Cin][NV]
+    float* ws = smem + ((a.Cin * NV + 3) & ~3);   // [Cin][T][32]  (current pass)
+    const int tid = threadIdx.x, q = tid & 7, g = tid >> 3;
+    unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tw_ = L % tilesW; L /= tilesW; const int th_ = L % tilesH; L /= tilesH; const int td_ = L % tilesD; const int nb = L / tilesD;
+    const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * TW;
+    const int mtile = blockIdx.x;           // any bijection works for the stats records
+
+    for (int idx = tid; idx < a.Cin * NV; idx += 256) {
+        const int ci = idx / NV, v = idx % NV;
+        const int zw = v % LW, zh = (v / LW) % LH, zd = v / (LW * LH);
+        const int gd = d0 + zd - PD, gh = h0 + zh - 1, gw = w0 + zw - 1;
+        float val = 0.f;
+        if (gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
+            val = a.x[((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.Cin + ci];
+        xs[ci * NV + v] = val;
+    }
+
+    int vbase[8]; bool vok[8]; size_t voff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int v = g + 32 * i;
+        const int ww = v & 15, hh = (v >> 4) % TH, dd = (v >> 4) / TH;
+        vbase[i] = (dd * LH + hh) * LW + ww;
+        const int gd = d0 + dd, gh = h0 + hh, gw = w0 + ww;
+        vok[i] = gd < a.D && gh < a.H && gw < a.W;
+        voff[i] = ((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.y_ldc;
+    }
+
+    for (int pass = 0; pass * 32 < a.Cout; ++pass) {
+        __syncthreads();
+        for (int idx = tid; idx < a.Cin * T * 32; idx += 256) {
+            const int c = idx & 31, t = (idx >> 5) % T, ci = (idx >> 5) / T;
+            const int co = pass * 32 + c;
+            ws[idx] = co < a.Cout ? a.w[((size_t)co * a.Cin + ci) * T + t] : 0.f;
+        }
+        __syncthreads();
+        f32x4 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ci = 0; ci < a.Cin; ++ci) {
+            f32x4 wr[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) wr[t] = *reinterpret_cast<const f32x4*>(ws + (ci * T + t) * 32 + 4 * q);
+            const float* xc = xs + ci * NV;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+                    const float xv = xc[vbase[i] + (kd * LH + kh) * LW + kw];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][e] = __builtin_fmaf(xv, wr[t][e], acc[i][e]);
+                }
+        }
+        const int co0 = pass * 32 + 4 * q;
+        const bool cok = co0 < a.Cout;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f}, es = {1.f, 1.f, 1.f, 1.f}, eh = bias;
+        if (cok && a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + co0);
+        const bool aff = a.epi_scale != nullptr;
+        if (cok && aff) { es = *reinterpret_cast<const f32x4*>(a.epi_scale + co0); eh = *reinterpret_cast<const f32x4*>(a.epi_shift + co0); }
+        f32x4 cnt = {0.f, 0.f, 0.f, 0.f}, sum = cnt;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[i][e] + bias[e];
+                if (aff) v = fmaxf(__builtin_fmaf(v, es[e], eh[e]), 0.f);
+                acc[i][e] = v;
+            }
+            if (vok[i] && cok) {
+                *reinterpret_cast<f32x4*>(a.y + voff[i] + co0) = acc[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cnt[e] += 1.f; sum[e] += acc[i][e]; }
+            }
+        }
+        if (a.stats) {
+            f32x4 mean, m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mean[e] = cnt[e] > 0.f ? sum[e] / cnt[e] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (vok[i] && cok)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = acc[i][e] - mean[e]; m2[e] += d * d; }
+            // lanes with equal q (lane bits 3,4,5) hold the same channels
+#pragma unroll
+            for (int off = 8; off <= 32; off <<= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float c1 = cnt[e], mn1 = mean[e], s1 = m2[e];
+                    const float c2 = __shfl_xor(c1, off), mn2 = __shfl_xor(mn1, off), s2 = __shfl_xor(s1, off);
+                    welford_merge(c1, mn1, s1, c2, mn2, s2);
+                    cnt[e] = c1; mean[e] = mn1; m2[e] = s1;
+                }
+            __syncthreads();   // ws is free now: reuse as scratch [wave][32][3]
+            const int wave = tid >> 6, lane = tid & 63;
+            if (lane < 8)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float* sc = ws + ((wave * 32) + 4 * lane + e) * 3;
+                    sc[0] = cnt[e]; sc[1] = mean[e]; sc[2] = m2[e];
+                }
+            __syncthreads();
+            if (tid < 32 && pass * 32 + tid < a.Cout) {
+                float c = 0.f, mn = 0.f, s = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { const float* sc = ws + (w * 32 + tid) * 3; welford_merge(c, mn, s, sc[0], sc[1], sc[2]); }
+                float* o = a.stats + ((size_t)mtile * a.Cout + pass * 32 + tid) * 3;
+                o[0] = c; o[1] = mn; o[2] = s;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ first conv, weight gradient
+// thread = (tap slot t = tid/8 (27 of 32 used), channel quad cq = tid%8): dW[co][ci][t] partial over the voxels of
+// the bricks owned by this block.  part layout [splits][T][Cout][Cin].
+template <int KD, int TD, int TH>
+__global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __restrict__ x, int Cin, const float* __restrict__ dy, int dy_ldc,
+                                                               float* __restrict__ part, int N, int D, int H, int W, int Cout,
+                                                               int tilesD, int tilesH, int tilesW, int tiles_per_split) {
+    constexpr int TW = 16, PD = KD / 2, LD = TD + 2 * PD, LH = TH + 2, LW = TW + 2, NV = LD * LH * LW, T = KD * 9;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                 // [NV]        one input channel
+    float* gs = smem + ((NV + 3) & ~3);   // [256][32]   dy brick, one pass of 32 output channels
+    const int tid = threadIdx.x, cq = tid & 7, t = tid >> 3;
+    const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+    const int toff = (kd * LH + kh) * LW + kw;
+    const int ntiles = N * tilesD * tilesH * tilesW;
+    const int tile0 = blockIdx.x * tiles_per_split;
+    for (int pass = 0; pass * 32 < Cout; ++pass)
+        for (int ci = 0; ci < Cin; ++ci) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int tile = tile0; tile < tile0 + tiles_per_split && tile < ntiles; ++tile) {
+                int L = tile;
+                const int tw_ = L % tilesW; L /= tilesW; const int th_ = L % tilesH; L /= tilesH; const int td_ = L % tilesD; const int nb = L / tilesD;
+                const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * TW;
+                __syncthreads();
+                for (int v = tid; v < NV; v += 256) {
+                    const int zw = v % LW, zh = (v / LW) % LH, zd = v / (LW * LH);
+                    const int gd = d0 + zd - PD, gh = h0 + zh - 1, gw = w0 + zw - 1;
+                    float val = 0.f;
+                    if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                        val = x[((((size_t)nb * D + gd) * H + gh) * W + gw) * Cin + ci];
+                    xs[v] = val;
+                }
+                for (int idx = tid; idx < 256 * 8; idx += 256) {
+                    const int v = idx >> 3, qq = idx & 7;
+                    const int ww = v & 15, hh = (v >> 4) % TH, dd = (v >> 4) / TH;
+                    const int gd = d0 + dd, gh = h0 + hh, gw = w0 + ww;
+                    f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                    if (gd < D && gh < H && gw < W && pass * 32 + 4 * qq < Cout)
+                        val = *reinterpret_cast<const f32x4*>(dy + ((((size_t)nb * D + gd) * H + gh) * W + gw) * dy_ldc + pass * 32 + 4 * qq);
+                    *reinterpret_cast<f32x4*>(gs + v * 32 + 4 * qq) = val;
+                }
+                __syncthreads();
+                if (t < T) {
+#pragma unroll 8
+                    for (int v = 0; v < 256; ++v) {
+                        const int ww = v & 15, hh = (v >> 4) % TH, dd = (v >> 4) / TH;
+                        const float xv = xs[(dd * LH + hh) * LW + ww + toff];
+                        const f32x4 gv = *reinterpret_cast<const f32x4*>(gs + v * 32 + 4 * cq);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(xv, gv[e], acc[e]);
+                    }
+                }
+            }
+            if (t < T)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = pass * 32 + 4 * cq + e;
+                    if (co < Cout) part[(((size_t)blockIdx.x * T + t) * Cout + co) * Cin + ci] = acc[e];
+                }
+        }
+}
+
+// ------------------------------------------------------------------ final 1x1x1 conv, forward (+ optional softmax)
+template <int COUT>
+__global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, int C, const float* __restrict__ w,
+                                      const float* __restrict__ bias, float* __restrict__ y, size_t S, int N, int lpv, int softmax) {
+    // lpv (1,2,4,8) consecutive lanes share one voxel; each walks every lpv-th channel quad
+    const int Q = C >> 2;
+    const size_t total = (size_t)N * S;
+    const int sub = threadIdx.x % lpv;
+    const size_t vpb = blockDim.x / lpv;
+    for (size_t v = blockIdx.x * vpb + threadIdx.x / lpv; v < (total + vpb - 1) / vpb * vpb; v += (size_t)gridDim.x * vpb) {
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+        const bool ok = v < total;
+        if (ok)
+            for (int q = sub; q < Q; q += lpv) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * q);
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + co * C + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[co] = __builtin_fmaf(av[e], wv[e], acc[co]);
+                }
+            }
+        for (int off = 1; off < lpv; off <<= 1)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[co] += __shfl_xor(acc[co], off);
+        if (ok && sub == 0) {
+            const size_t n = v / S, sp = v % S;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[co] += bias ? bias[co] : 0.f;
+            if (softmax) {
+                float m = acc[0];
+#pragma unroll
+                for (int co = 1; co < COUT; ++co) m = fmaxf(m, acc[co]);
+                float s = 0.f;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) { acc[co] = __expf(acc[co] - m); s += acc[co]; }
+                const float inv = 1.f / s;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] *= inv;
+            }
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) y[(n * COUT + co) * S + sp] = acc[co];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ final conv, backward: da, dW/db partials
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_final_bwd_kernel(const float* __restrict__ a, int a_ldc, int C, const float* __restrict__ w,
+                                                             const float* __restrict__ dy, float* __restrict__ da, int da_ldc,
+                                                             float* __restrict__ part, size_t S, int N) {
+    __shared__ float red[256][4];
+    const int Q = C >> 2;
+    const int BT = (256 / Q) * Q;
+    const size_t total = (size_t)N * S * Q;
+    const int tid = threadIdx.x;
+    const int q = tid % Q;
+    f32x4 wv[COUT], dwacc[COUT];
+    float dbacc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        wv[co] = *reinterpret_cast<const f32x4*>(w + co * C + 4 * q);
+        dwacc[co] = f32x4{0.f, 0.f, 0.f, 0.f}; dbacc[co] = 0.f;
+    }
+    for (size_t i = (size_t)blockIdx.x * BT + tid; tid < BT && i < total; i += (size_t)gridDim.x * BT) {
+        const size_t v = i / Q;
+        const size_t n = v / S, sp = v % S;
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * q);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float g = dy[(n * COUT + co) * S + sp];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = __builtin_fmaf(g, wv[co][e], o[e]); dwacc[co][e] = __builtin_fmaf(g, av[e], dwacc[co][e]); }
+            if (q == 0) dbacc[co] += g;
+        }
+        *reinterpret_cast<f32x4*>(da + v * da_ldc + 4 * q) = o;
+    }
+    // block reduce, one output row (co) at a time
+    const int pstride = COUT * C + COUT;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[tid][e] = tid < BT ? dwacc[co][e] : 0.f;
+        __syncthreads();
+        for (int t = tid; t < Q * 4; t += 256) {
+            const int e = t & 3, qq = t >> 2;
+            float acc = 0.f;
+            for (int k = qq; k < BT; k += Q) acc += red[k][e];
+            part[(size_t)blockIdx.x * pstride + co * C + 4 * qq + e] = acc;
+        }
+        __syncthreads();
+        red[tid][0] = (tid < BT && q == 0) ? dbacc[co] : 0.f;
+        __syncthreads();
+        if (tid == 0) {
+            float acc = 0.f;
+            for (int k = 0; k < BT; k += Q) acc += red[k][0];
+            part[(size_t)blockIdx.x * pstride + COUT * C + co] = acc;
+        }
+    }
+}
+
+}  // namespace
+
+static void small_brick(int planar, int& TD, int& TH) { if (planar) { TD = 1; TH = 16; } else { TD = 2; TH = 8; } }
+
+int conv_small_stats_parts(int N, int D, int H, int W, int planar) {
+    int TD, TH; small_brick(planar, TD, TH);
+    return N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, 16);
+}
+
+int launch_conv_small_fwd(ConvSmallArgs a, hipStream_t s) {
+    E3_REQUIRE(a.Cin >= 1 && a.Cin < 8, E3_ERR_UNSUPPORTED, "direct conv handles 1..7 input channels");
+    E3_REQUIRE(a.Cout % 4 == 0 && a.y_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "output channels must be a multiple of 4");
+    int TD, TH; small_brick(a.planar, TD, TH);
+    const int tD = cdiv(a.D, TD), tH = cdiv(a.H, TH), tW = cdiv(a.W, 16);
+    const int KD = a.planar ? 1 : 3;
+    const int NV = (TD + (a.planar ? 0 : 2)) * (TH + 2) * 18;
+    const size_t lds = (size_t)(((a.Cin * NV + 3) & ~3) + a.Cin * KD * 9 * 32) * 4;
+    const dim3 grid((unsigned)((size_t)a.N * tD * tH * tW)), block(256);
+    if (a.planar) hipLaunchKernelGGL((conv_small_fwd_kernel<1, 1, 16>), grid, block, lds, s, a, tD, tH, tW);
+    else hipLaunchKernelGGL((conv_small_fwd_kernel<3, 2, 8>), grid, block, lds, s, a, tD, tH, tW);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+static int small_wgrad_tiles_per_split(int ntiles) { return cdiv(ntiles, 1024); }
+
+int conv_small_wgrad_splits(int N, int D, int H, int W, int planar) {
+    const int ntiles = conv_small_stats_parts(N, D, H, W, planar);
+    return cdiv(ntiles, small_wgrad_tiles_per_split(ntiles));
+}
+
+int launch_conv_small_wgrad(const float* x, int Cin, const float* dy, int dy_ldc, float* part,
+                            int N, int D, int H, int W, int Cout, int planar, hipStream_t s) {
+    E3_REQUIRE(Cin >= 1 && Cin < 8, E3_ERR_UNSUPPORTED, "direct conv handles 1..7 input channels");
+    int TD, TH; small_brick(planar, TD, TH);
+    const int tD = cdiv(D, TD), tH = cdiv(H, TH), tW = cdiv(W, 16);
+    const int ntiles = N * tD * tH * tW;
+    const int tps = small_wgrad_tiles_per_split(ntiles);
+    const int splits = cdiv(ntiles, tps);
+    const int NV = (TD + (planar ? 0 : 2)) * (TH + 2) * 18;
+    const size_t lds = (size_t)(((NV + 3) & ~3) + 256 * 32) * 4;
+    if (planar) hipLaunchKernelGGL((conv_small_wgrad_kernel<1, 1, 16>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps);
+    else hipLaunchKernelGGL((conv_small_wgrad_kernel<3, 2, 8>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+static int final_lpv(int C) {
+    const int Q = C / 4;
+    int l = 1;
+    while (l < 8 && Q % (l * 2) == 0) l *= 2;
+    return l;
+}
+
+#define E3_COUT_SWITCH(COUT, ...)                         \
+    switch (COUT) {                                       \
+        case 1: { constexpr int CO = 1; __VA_ARGS__; break; } \
+        case 2: { constexpr int CO = 2; __VA_ARGS__; break; } \
+        case 3: { constexpr int CO = 3; __VA_ARGS__; break; } \
+        case 4: { constexpr int CO = 4; __VA_ARGS__; break; } \
+        case 5: { constexpr int CO = 5; __VA_ARGS__; break; } \
+        case 6: { constexpr int CO = 6; __VA_ARGS__; break; } \
+        case 7: { constexpr int CO = 7; __VA_ARGS__; break; } \
+        case 8: { constexpr int CO = 8; __VA_ARGS__; break; } \
+        default: e3_set_error("final 1x1x1 conv supports 1..8 output channels"); return E3_ERR_UNSUPPORTED; \
+    }
+
+int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y,
+                          int Cout, size_t S, int N, int softmax, hipStream_t s) {
+    E3_REQUIRE(C % 4 == 0 && a_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
+    const int lpv = final_lpv(C);
+    const size_t vox = (size_t)N * S;
+    size_t g = (vox * lpv + 255) / 256; if (g > 4096) g = 4096; if (g == 0) g = 1;
+    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_fwd_kernel<CO>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, S, N, lpv, softmax));
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int conv_final_bwd_parts(size_t total_voxels) {
+    size_t g = (total_voxels + 31) / 32; if (g > 1024) g = 1024; if (g == 0) g = 1;
+    return (int)g;
+}
+
+int launch_conv_final_bwd(const float* a, int a_ldc, int C, const float* w, const float* dy, float* da, int da_ldc,
+                          float* part, int Cout, size_t S, int N, hipStream_t s) {
+    E3_REQUIRE(C % 4 == 0 && C <= 1024, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4 and <= 1024");
+    const int parts = conv_final_bwd_parts((size_t)N * S);
+    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_bwd_kernel<CO>), dim3(parts), dim3(256), 0, s, a, a_ldc, C, w, dy, da, da_ldc, part, S, N));
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}

@@ -1,0 +1,394 @@
+// HBM-bound kernels of the U-Net hot path: weight packing, BatchNorm statistics/finalise/apply, ReLU,
+// ceil-mode max-pool, their backward, and layout helpers.  All activations are fp32 NDHWC.
+//
+//   BatchNorm3d (train / eval)  unet.py:77-105   (torch: eps 1e-5, momentum 0.1, biased var for y, unbiased for running_var)
+//   ReLU                        unet.py:183-186
+//   MaxPool3d(k=2|(1,2,2), ceil_mode=True)  unet.py:67-74,225-230
+//
+// Each of these is a pure streaming pass: float4 (4 channels) per lane, consecutive lanes walk consecutive
+// channel quads and then consecutive voxels, so every wave issues full 1 KiB coalesced requests.
+#include "kernels.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+constexpr int EW_MAX_GRID = 256 * 8;   // ~8 resident workgroups per CU, grid-stride beyond that
+
+inline int ew_grid(size_t items) {
+    size_t g = (items + EW_BLOCK - 1) / EW_BLOCK;
+    if (g > (size_t)EW_MAX_GRID) g = EW_MAX_GRID;
+    if (g == 0) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------ weight packing
+__global__ void pack_weights_kernel(int mode, const float* __restrict__ w, float* __restrict__ out,
+                                    int Cout, int Cin, int T, int NPad) {
+    // out index space: [G][Tin][NPad][K]
+    size_t total;
+    int K, G = 1, Tin = T;
+    if (mode == PACK_CONV_FWD) { K = Cin; }
+    else if (mode == PACK_CONV_DGRAD) { K = Cout; }
+    else if (mode == PACK_UP_FWD) { K = Cin; Tin = 1; }
+    else { K = Cout; G = T; Tin = 1; }
+    total = (size_t)G * Tin * NPad * K;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = i % K; size_t r = i / K;
+        const int n = r % NPad; r /= NPad;
+        const int t = r % Tin; const int g = r / Tin;
+        float v = 0.f;
+        if (mode == PACK_CONV_FWD) {            // w[co=n][ci=k][t]
+            if (n < Cout) v = w[((size_t)n * Cin + k) * T + t];
+        } else if (mode == PACK_CONV_DGRAD) {   // column n = ci, k = co, flipped tap
+            if (n < Cin) v = w[((size_t)k * Cin + n) * T + (T - 1 - t)];
+        } else if (mode == PACK_UP_FWD) {       // w[ci=k][co][tap], column n = tap*Cout + co
+            if (n < T * Cout) { const int tap = n / Cout, co = n % Cout; v = w[((size_t)k * Cout + co) * T + tap]; }
+        } else {                                // PACK_UP_DGRAD: gather tap g, column n = ci, k = co
+            if (n < Cin) v = w[((size_t)n * Cout + k) * T + g];
+        }
+        out[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------ BN finalise (one wave per channel)
+__global__ void bn_finalize_kernel(const BnFinalizeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= a.C) return;
+    // Chan merge in double: each lane folds a strided subset, then a butterfly over the wave
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int p = lane; p < a.parts; p += 64) {
+        const float* r = a.stats + ((size_t)p * a.C + c) * 3;
+        const double nb = r[0];
+        if (nb > 0.0) {
+            const double d = (double)r[1] - mean, nn = n + nb;
+            mean += d * nb / nn; m2 += (double)r[2] + d * d * n * nb / nn; n = nn;
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double nb = __shfl_xor(n, off), mb = __shfl_xor(mean, off), sb = __shfl_xor(m2, off);
+        const double nn = n + nb;
+        if (nn > 0.0) {
+            const double d = mb - mean;
+            const double mnew = mean + d * nb / nn;
+            const double snew = m2 + sb + d * d * n * nb / nn;
+            mean = mnew; m2 = snew; n = nn;
+        }
+    }
+    if (lane == 0) {
+        const double var = n > 0.0 ? m2 / n : 0.0;
+        const double invstd = 1.0 / sqrt(var + (double)a.eps);
+        const double g = a.gamma ? (double)a.gamma[c] : 1.0, b = a.beta ? (double)a.beta[c] : 0.0;
+        a.mean[c] = (float)mean;
+        a.invstd[c] = (float)invstd;
+        a.scale[c] = (float)(g * invstd);
+        a.shift[c] = (float)(b - mean * g * invstd);
+        if (a.running_mean) a.running_mean[c] = (float)((1.0 - a.momentum) * a.running_mean[c] + a.momentum * mean);
+        if (a.running_var) {
+            const double unb = n > 1.0 ? m2 / (n - 1.0) : var;
+            a.running_var[c] = (float)((1.0 - a.momentum) * a.running_var[c] + a.momentum * unb);
+        }
+    }
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                               const float* conv_bias, float eps, float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double invstd = 1.0 / sqrt((double)rv[c] + (double)eps);
+    const double s = (gamma ? (double)gamma[c] : 1.0) * invstd;
+    scale[c] = (float)s;
+    shift[c] = (float)((beta ? (double)beta[c] : 0.0) + ((conv_bias ? (double)conv_bias[c] : 0.0) - (double)rm[c]) * s);
+}
+
+// ------------------------------------------------------------------ BN apply + ReLU (+ max-pool)
+__global__ void bn_relu_apply_kernel(const float* __restrict__ x, int x_ldc, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, float* __restrict__ a, int a_ldc,
+                                     size_t voxels, int C) {
+    const int Q = C >> 2;
+    const size_t total = voxels * Q;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = i % Q; const size_t v = i / Q;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + v * x_ldc + 4 * q);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + 4 * q);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + 4 * q);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(__builtin_fmaf(xv[e], sc[e], sh[e]), 0.f);
+        *reinterpret_cast<f32x4*>(a + v * a_ldc + 4 * q) = o;
+    }
+}
+
+// one lane = one pooling window x 4 channels: applies BN+ReLU to the (up to) kd*2*2 voxels of the window,
+// writes them to `a` (the skip connection, possibly a concat-buffer half) and their max to `pooled`.
+// APPLY=false: `x` already holds activations (plain max-pool).
+template <bool APPLY>
+__global__ void bn_relu_pool_kernel(const float* __restrict__ x, int x_ldc, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, float* __restrict__ a, int a_ldc,
+                                    float* __restrict__ pooled, int kd, int N, int D, int H, int W, int C) {
+    const int Q = C >> 2;
+    const int Dp = (D + kd - 1) / kd, Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+    const size_t total = (size_t)N * Dp * Hp * Wp * Q;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = i % Q; size_t r = i / Q;
+        const int pw = r % Wp; r /= Wp; const int ph = r % Hp; r /= Hp; const int pd = r % Dp; const int n = r / Dp;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (APPLY) { sc = *reinterpret_cast<const f32x4*>(scale + 4 * q); sh = *reinterpret_cast<const f32x4*>(shift + 4 * q); }
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int dz = 0; dz < kd; ++dz) {
+            const int d = pd * kd + dz; if (d >= D) break;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int h = ph * 2 + dy; if (h >= H) break;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int w = pw * 2 + dx; if (w >= W) break;
+                    const size_t v = (((size_t)n * D + d) * H + h) * W + w;
+                    f32x4 o = *reinterpret_cast<const f32x4*>(x + v * x_ldc + 4 * q);
+                    if (APPLY) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(__builtin_fmaf(o[e], sc[e], sh[e]), 0.f);
+                        *reinterpret_cast<f32x4*>(a + v * a_ldc + 4 * q) = o;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) best[e] = (o[e] > best[e] || o[e] != o[e]) ? o[e] : best[e];
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(pooled + ((((size_t)n * Dp + pd) * Hp + ph) * Wp + pw) * C + 4 * q) = best;
+    }
+}
+
+// ------------------------------------------------------------------ BN + ReLU (+ pool) backward
+// dA(v) = g1(v) + [v is the first arg-max of its pooling window] * gpool(window)
+// dz = dA * (z > 0),  z = x*scale + shift ;  xhat = (x - mean) * invstd
+// pass 1 (REDUCE): per-channel sum dz, sum dz*xhat.   pass 2 (APPLY): dx = gamma*invstd*(dz - c1 - xhat*c2), sum dx.
+template <bool POOL, bool APPLYPASS>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
+    __shared__ float red[3][256][4];
+    const int Q = a.C >> 2;
+    const int kd = a.kd;
+    const int Dp = POOL ? (a.D + kd - 1) / kd : a.D, Hp = POOL ? (a.H + 1) >> 1 : a.H, Wp = POOL ? (a.W + 1) >> 1 : a.W;
+    // work item = (window or voxel, channel quad); a block always works on channel quad (tid % Q') so that the
+    // in-block reduction is a fixed pattern: items are laid out [unit][Q]
+    const size_t units = (size_t)a.N * Dp * Hp * Wp;
+    const size_t total = units * Q;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
+    // Only BT = floor(256/Q)*Q threads work, so that a thread's channel quad (tid % Q) never changes across its
+    // grid-stride iterations and the in-block reduction below is a fixed pattern.
+    const int BT = (256 / Q) * Q;
+    const size_t stride = (size_t)gridDim.x * BT;
+    for (size_t i = (size_t)blockIdx.x * BT + threadIdx.x; threadIdx.x < BT && i < total; i += stride) {
+        const int q = i % Q; size_t r = i / Q;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + 4 * q);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + 4 * q);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + 4 * q);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(a.invstd + 4 * q);
+        f32x4 c1 = s1, c2 = s1, gi = s1;
+        if (APPLYPASS) {
+            c1 = *reinterpret_cast<const f32x4*>(a.coef + 4 * q);
+            c2 = *reinterpret_cast<const f32x4*>(a.coef + a.C + 4 * q);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gi[e] = gm[e] * is[e];
+        }
+        if (!POOL) {
+            const size_t v = r;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + v * a.x_ldc + 4 * q);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(a.g1 + v * a.g1_ldc + 4 * q);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z = __builtin_fmaf(xv[e], sc[e], sh[e]);   // same expression as the forward apply
+                const float dz = z > 0.f ? g[e] : 0.f;
+                const float xh = (xv[e] - mu[e]) * is[e];
+                if (APPLYPASS) { o[e] = gi[e] * (dz - c1[e] - xh * c2[e]); s3[e] += o[e]; }
+                else { s1[e] += dz; s2[e] += dz * xh; }
+            }
+            if (APPLYPASS) *reinterpret_cast<f32x4*>(a.dx + v * a.dx_ldc + 4 * q) = o;
+        } else {
+            const int pw = r % Wp; r /= Wp; const int ph = r % Hp; r /= Hp; const int pd = r % Dp; const int n = r / Dp;
+            const size_t pidx = ((((size_t)n * Dp + pd) * Hp + ph) * Wp + pw) * a.C + 4 * q;
+            const f32x4 gp = *reinterpret_cast<const f32x4*>(a.gpool + pidx);
+            const f32x4 pm = *reinterpret_cast<const f32x4*>(a.pooled + pidx);
+            bool taken[4] = {false, false, false, false};
+            for (int dz_ = 0; dz_ < kd; ++dz_) {
+                const int d = pd * kd + dz_; if (d >= a.D) break;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    const int h = ph * 2 + dy; if (h >= a.H) break;
+#pragma unroll
+                    for (int dx_ = 0; dx_ < 2; ++dx_) {
+                        const int w = pw * 2 + dx_; if (w >= a.W) break;
+                        const size_t v = (((size_t)n * a.D + d) * a.H + h) * a.W + w;
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + v * a.x_ldc + 4 * q);
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(a.a + v * a.a_ldc + 4 * q);
+                        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                        if (a.g1) g = *reinterpret_cast<const f32x4*>(a.g1 + v * a.g1_ldc + 4 * q);
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float dA = g[e];
+                            if (!taken[e] && av[e] == pm[e]) { dA += gp[e]; taken[e] = true; }   // first arg-max wins (ATen)
+                            const float dz = av[e] > 0.f ? dA : 0.f;
+                            const float xh = (xv[e] - mu[e]) * is[e];
+                            if (APPLYPASS) { o[e] = gi[e] * (dz - c1[e] - xh * c2[e]); s3[e] += o[e]; }
+                            else { s1[e] += dz; s2[e] += dz * xh; }
+                        }
+                        if (APPLYPASS) *reinterpret_cast<f32x4*>(a.dx + v * a.dx_ldc + 4 * q) = o;
+                    }
+                }
+            }
+        }
+    }
+    // ---- block reduction: threads with equal (tid % Q) own the same channel quad
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][tid][e] = APPLYPASS ? s3[e] : s1[e]; red[1][tid][e] = s2[e]; }
+    __syncthreads();
+    const int rows = APPLYPASS ? 1 : 2;
+    for (int t = tid; t < Q * 4 * rows; t += 256) {
+        const int e = t & 3, q = (t >> 2) % Q, which = (t >> 2) / Q;
+        float acc = 0.f;
+        for (int k = q; k < BT; k += Q) acc += red[which][k][e];
+        a.part[((size_t)blockIdx.x * 3 + (APPLYPASS ? 2 : which)) * a.C + 4 * q + e] = acc;   // part layout [parts][3][C]
+    }
+}
+
+// sums part[p][row][c] over p (double accumulate); one thread per (row, c)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int parts, int C, float inv_n,
+                                       float* dgamma, float* dbeta, float* coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < parts; ++p) { s1 += part[((size_t)p * 3 + 0) * C + c]; s2 += part[((size_t)p * 3 + 1) * C + c]; }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    coef[c] = (float)(s1 * inv_n);
+    coef[C + c] = (float)(s2 * inv_n);
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int parts, int part_stride, int offset, int C, float* out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int p = 0; p < parts; ++p) s += part[(size_t)p * part_stride + offset + c];
+    out[c] = (float)s;
+}
+
+// ------------------------------------------------------------------ layout helpers (module boundary only)
+__global__ void ncdhw_to_ndhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, size_t S) {
+    const size_t total = (size_t)N * C * S;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % C; size_t r = i / C; const size_t sp = r % S; const int n = r / S;
+        dst[i] = src[((size_t)n * C + c) * S + sp];
+    }
+}
+__global__ void ndhwc_to_ncdhw_kernel(const float* __restrict__ src, int ldc, float* __restrict__ dst, int N, int C, size_t S) {
+    const size_t total = (size_t)N * C * S;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t sp = i % S; size_t r = i / S; const int c = r % C; const int n = r / C;
+        dst[i] = src[((size_t)n * S + sp) * ldc + c];
+    }
+}
+
+}  // namespace
+
+int launch_pack_weights(PackMode mode, const float* w, float* out, int Cout, int Cin, int T, int NPad, hipStream_t s) {
+    size_t total;
+    if (mode == PACK_CONV_FWD) total = (size_t)T * NPad * Cin;
+    else if (mode == PACK_CONV_DGRAD) total = (size_t)T * NPad * Cout;
+    else if (mode == PACK_UP_FWD) total = (size_t)NPad * Cin;
+    else total = (size_t)T * NPad * Cout;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, s, (int)mode, w, out, Cout, Cin, T, NPad);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_bn_finalize(BnFinalizeArgs a, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a.C, 4)), dim3(256), 0, s, a);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, const float* conv_bias,
+                   float eps, float* scale, float* shift, int C, hipStream_t s) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, gamma, beta, rm, rv, conv_bias, eps, scale, shift, C);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_bn_relu_apply(const float* x, int x_ldc, const float* scale, const float* shift, float* a, int a_ldc,
+                         float* pooled, int kd, int N, int D, int H, int W, int C, hipStream_t s) {
+    E3_REQUIRE(C % 4 == 0 && x_ldc % 4 == 0 && a_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
+    if (!pooled) {
+        const size_t vox = (size_t)N * D * H * W;
+        hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(ew_grid(vox * (C / 4))), dim3(EW_BLOCK), 0, s, x, x_ldc, scale, shift, a, a_ldc, vox, C);
+    } else {
+        const size_t items = (size_t)N * cdiv(D, kd) * cdiv(H, 2) * cdiv(W, 2) * (C / 4);
+        hipLaunchKernelGGL(bn_relu_pool_kernel<true>, dim3(ew_grid(items)), dim3(EW_BLOCK), 0, s, x, x_ldc, scale, shift, a, a_ldc, pooled, kd, N, D, H, W, C);
+    }
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_maxpool(const float* a, int a_ldc, float* pooled, int kd, int N, int D, int H, int W, int C, hipStream_t s) {
+    E3_REQUIRE(C % 4 == 0 && a_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
+    const size_t items = (size_t)N * cdiv(D, kd) * cdiv(H, 2) * cdiv(W, 2) * (C / 4);
+    hipLaunchKernelGGL(bn_relu_pool_kernel<false>, dim3(ew_grid(items)), dim3(EW_BLOCK), 0, s, a, a_ldc,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 0, pooled, kd, N, D, H, W, C);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+// number of partial rows == grid size of the backward kernels
+int bn_bwd_parts(size_t voxels, int C) {
+    const int Q = C / 4;
+    size_t g = (voxels * Q + 255) / 256;
+    if (g > 1024) g = 1024;
+    if (g == 0) g = 1;
+    (void)Q;
+    return (int)g;
+}
+
+static int bn_bwd_launch(BnBwdArgs a, bool apply, hipStream_t s) {
+    const int Q = a.C / 4;
+    E3_REQUIRE(a.C % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
+    E3_REQUIRE(Q >= 1 && Q <= 256, E3_ERR_UNSUPPORTED, "BN backward supports up to 1024 channels");
+    const bool pool = a.gpool != nullptr;
+    const dim3 grid(a.parts), block(256);
+    if (pool) {
+        if (apply) hipLaunchKernelGGL((bn_bwd_kernel<true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((bn_bwd_kernel<true, false>), grid, block, 0, s, a);
+    } else {
+        if (apply) hipLaunchKernelGGL((bn_bwd_kernel<false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((bn_bwd_kernel<false, false>), grid, block, 0, s, a);
+    }
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+int launch_bn_bwd_reduce(BnBwdArgs a, hipStream_t s) { return bn_bwd_launch(a, false, s); }
+int launch_bn_bwd_apply(BnBwdArgs a, hipStream_t s) { return bn_bwd_launch(a, true, s); }
+
+int launch_bn_bwd_finalize(const float* part, int parts, int C, float inv_n, float* dgamma, float* dbeta, float* coef, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, part, parts, C, inv_n, dgamma, dbeta, coef);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_colsum_finalize(const float* part, int parts, int part_stride, int offset, int C, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, part, parts, part_stride, offset, C, out);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_ncdhw_to_ndhwc(const float* src, float* dst, int N, int C, size_t S, hipStream_t s) {
+    hipLaunchKernelGGL(ncdhw_to_ndhwc_kernel, dim3(ew_grid((size_t)N * C * S)), dim3(EW_BLOCK), 0, s, src, dst, N, C, S);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+int launch_ndhwc_to_ncdhw(const float* src, int src_ldc, float* dst, int N, int C, size_t S, hipStream_t s) {
+    hipLaunchKernelGGL(ndhwc_to_ncdhw_kernel, dim3(ew_grid((size_t)N * C * S)), dim3(EW_BLOCK), 0, s, src, src_ldc, dst, N, C, S);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}

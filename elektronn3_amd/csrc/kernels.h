@@ -1,0 +1,135 @@
+// Kernel-launcher interface of libe3unet (internal; the public C ABI is include/e3unet.h).
+// All tensors are fp32 NDHWC in HBM unless stated otherwise.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------- implicit-GEMM conv on f32 MFMA
+enum ConvKind {
+    CONV_K3 = 0,      // 3x3x3, pad 1           (unet.py:131-149 conv3)
+    CONV_K3_PLANAR,   // 1x3x3, pad (0,1,1)     (unet.py:114-128,138-141)
+    CONV_POINT,       // 1x1x1 GEMM over voxels (building block of the transposed conv)
+};
+enum ConvFlags {
+    CF_SCATTER_UP = 1,  // POINT only: columns are (tap, co); row p is written to voxel 2p+tap   (ConvTranspose3d fwd)
+    CF_GATHER_UP = 2,   // POINT only: K runs over (tap, c); row p reads voxel 2p+tap            (ConvTranspose3d dgrad)
+};
+
+struct ConvArgs {
+    const float* x; int x_ldc;   // input view (pointer already offset to its first channel)
+    int Cin;                     // input channels per tap (multiple of 8)
+    const float* wt;             // packed weights [G][T][NPad][Cin]  (see pack_conv_weights)
+    const float* bias;           // [Cout] or null
+    float* y; int y_ldc;         // output view
+    int N, D, H, W;              // dims of the GEMM-row (voxel) space
+    int Do, Ho, Wo;              // SCATTER_UP: dims of y (after autocrop); GATHER_UP: dims of x
+    int sd;                      // up-sampling factor along D (2, or 1 for planar blocks); H and W are always 2
+    int Cout;                    // real output channels
+    int Ncols;                   // GEMM columns: Cout, or taps*Cout for SCATTER_UP
+    int NPad;                    // Ncols rounded up to the block's column tile
+    const float* pro_scale; const float* pro_shift;  // non-null: x := relu(x*scale[c]+shift[c]) while staging
+    const float* epi_scale; const float* epi_shift;  // non-null: y := relu(acc*scale[co]+shift[co])  (bias folded by caller)
+    float* stats;                // non-null: per-(tile,channel) (count, mean, M2) of the stored values
+    int tilesD, tilesH, tilesW, ntiles;
+    int G;                       // gather taps (1 unless GATHER_UP)
+    int flags;
+};
+
+// number of stats records (rows of [Cout][3]) the conv will write
+int conv_stats_parts(ConvKind kind, int flags, int N, int D, int H, int W, int sd);
+int launch_conv_mfma(ConvKind kind, ConvArgs a, hipStream_t s);
+int conv_col_tile(int ncols);  // 32 or 64: column tile the launcher will use for `ncols` GEMM columns
+
+// ---------------------------------------------------------------- weight packing
+enum PackMode {
+    PACK_CONV_FWD = 0,   // torch (Cout,Cin,T)   -> [T][NPad][Cin]         B[k=ci][n=co] of tap t
+    PACK_CONV_DGRAD,     // torch (Cout,Cin,T)   -> [T][NPad(Cin)][Cout]   flipped taps, roles swapped
+    PACK_UP_FWD,         // torch (Cin,Cout,T)   -> [1][NPad(T*Cout)][Cin] column n = t*Cout+co
+    PACK_UP_DGRAD,       // torch (Cin,Cout,T)   -> [T][NPad(Cin)][Cout]   gather tap t, column n = ci
+};
+int launch_pack_weights(PackMode mode, const float* w, float* out, int Cout, int Cin, int T, int NPad, hipStream_t s);
+
+// ---------------------------------------------------------------- small-channel direct convs (HBM-bound)
+// first layer: Cin < 8 (in_channels of the network), K3 or planar; x is NDHWC (== NCDHW when Cin == 1)
+struct ConvSmallArgs {
+    const float* x; int Cin;
+    const float* w;              // torch layout (Cout,Cin,T)
+    const float* bias;
+    float* y; int y_ldc;
+    int N, D, H, W, Cout;        // Cout multiple of 4, <= 256
+    int planar;
+    const float* epi_scale; const float* epi_shift;
+    float* stats;
+};
+int conv_small_stats_parts(int N, int D, int H, int W, int planar);
+int launch_conv_small_fwd(ConvSmallArgs a, hipStream_t s);
+// dW partials for the first layer: part[split][T][CoPad=Cout][CiPad=Cin] ; returns number of splits used
+int conv_small_wgrad_splits(int N, int D, int H, int W, int planar);
+int launch_conv_small_wgrad(const float* x, int Cin, const float* dy, int dy_ldc, float* part,
+                            int N, int D, int H, int W, int Cout, int planar, hipStream_t s);
+
+// final 1x1x1 conv: C (multiple of 4) -> Cout (<= 8); output and its gradient are NCDHW (the module boundary)
+int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y_ncdhw,
+                          int Cout, size_t voxels_per_sample, int N, int softmax, hipStream_t s);
+int conv_final_bwd_parts(size_t total_voxels);
+int launch_conv_final_bwd(const float* a, int a_ldc, int C, const float* w, const float* dy_ncdhw, float* da, int da_ldc,
+                          float* part /*[parts][Cout][C+1]*/, int Cout, size_t voxels_per_sample, int N, hipStream_t s);
+
+// ---------------------------------------------------------------- wgrad on f32 MFMA
+struct WgradArgs {
+    const float* x; int x_ldc; int Cin;     // conv input activation view
+    const float* dy; int dy_ldc; int Cout;  // gradient w.r.t. conv output
+    float* part;                            // [splits][T][CoPad][CiPad]
+    int N, D, H, W;
+    int CoPad, CiPad, splits;
+    // POINT (transposed conv): x has dims (N,D,H,W); dy has dims (N,Do,Ho,Wo), row p pairs with dy voxel 2p+tap
+    int Do, Ho, Wo, sd;
+};
+int wgrad_splits(ConvKind kind, int N, int D, int H, int W, int Cin, int Cout);
+int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s);
+// out (torch layout): transposed==0: (Cout,Cin,T) from part rows=co, cols=ci ; transposed==1: (Cin,Cout,T), part rows=ci, cols=co
+int launch_wgrad_reduce(const float* part, float* out, int splits, int T, int RPad, int CPad, int R, int C, hipStream_t s);
+
+// ---------------------------------------------------------------- batch-norm / relu / pool (HBM-bound elementwise)
+// merges `parts` records of (count, mean, M2) per channel -> mean, invstd, scale, shift; updates running stats
+struct BnFinalizeArgs {
+    const float* stats; int parts; int C;
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var;   // may be null
+    float momentum; float eps;
+    float* mean; float* invstd; float* scale; float* shift;   // each [C]
+};
+int launch_bn_finalize(BnFinalizeArgs a, hipStream_t s);
+// eval mode: scale = gamma/sqrt(rv+eps); shift = beta + (conv_bias - rm)*scale   (BN folded into the conv epilogue)
+int launch_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, const float* conv_bias,
+                   float eps, float* scale, float* shift, int C, hipStream_t s);
+// a = relu(x*scale+shift) written to `a` (any ldc); optionally also p = maxpool_{kd,2,2}(a), ceil mode
+int launch_bn_relu_apply(const float* x, int x_ldc, const float* scale, const float* shift, float* a, int a_ldc,
+                         float* pooled /*null or packed NDHWC (ceil dims)*/, int kd,
+                         int N, int D, int H, int W, int C, hipStream_t s);
+int launch_maxpool(const float* a, int a_ldc, float* pooled, int kd, int N, int D, int H, int W, int C, hipStream_t s);
+
+// backward of x -> (scale,shift) -> relu, with dA = g1 (+ unpool(gpool) through the max-pool of `a`)
+struct BnBwdArgs {
+    const float* x; int x_ldc;            // raw conv output (BN input)
+    const float* mean; const float* invstd; const float* gamma; const float* scale; const float* shift;
+    const float* g1; int g1_ldc;          // gradient w.r.t. relu output (may be null if gpool given)
+    const float* gpool;                   // gradient w.r.t. pooled output (packed, ceil dims) or null
+    const float* a; int a_ldc;            // relu output (needed for the pool arg-max) or null
+    const float* pooled;                  // pooled forward output (packed)
+    int kd;
+    int N, D, H, W, C;
+    float* part;                          // [parts][3][C]: sum dz, sum dz*xhat, (apply pass) sum dx
+    int parts;
+    const float* coef;                    // apply pass: [2][C] = (sum dz / n, sum dz*xhat / n)
+    float* dx; int dx_ldc;                // apply pass output
+};
+int bn_bwd_parts(size_t voxels, int C);
+int launch_bn_bwd_reduce(BnBwdArgs a, hipStream_t s);
+// sums `parts` rows of `rows` x C -> out rows; used for (dgamma,dbeta) + coefficients and for bias grads
+int launch_bn_bwd_finalize(const float* part, int parts, int C, float inv_n, float* dgamma, float* dbeta, float* coef, hipStream_t s);
+int launch_bn_bwd_apply(BnBwdArgs a, hipStream_t s);
+int launch_colsum_finalize(const float* part, int parts, int part_stride, int offset, int C, float* out, hipStream_t s);
+
+// ---------------------------------------------------------------- layout helpers
+int launch_ncdhw_to_ndhwc(const float* src, float* dst, int N, int C, size_t S, hipStream_t s);
+int launch_ndhwc_to_ncdhw(const float* src, int src_ldc, float* dst, int N, int C, size_t S, hipStream_t s);

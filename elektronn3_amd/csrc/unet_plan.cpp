@@ -1,0 +1,528 @@
+// Whole-network executor: UNet.forward and its backward as a fixed sequence of stream-ordered launches.
+//
+// Replaces the nn.Module graph walk + autograd tape of elektronn3/models/unet.py:894-916 (UNet.forward),
+// :244-253 (DownConv.forward), :384-408 (UpConv.forward), :256-325 (autocrop).  Host code only; every launch goes
+// to the caller's HIP stream, nothing synchronises, no device memory is allocated here.
+//
+// Memory plan (fp32 NDHWC, sized for 288 GB HBM: nothing is recomputed, nothing is re-read that need not be):
+//   saved   per conv unit: raw conv output x (BN input), activation a = relu(bn(x)); encoder skip activations are
+//           written straight into the second half of the decoder's concat buffer, the up-convolved activation
+//           into the first half (torch.cat, unet.py:398-399, never runs); pooled outputs; per-BN mean/invstd/
+//           scale/shift vectors.
+//   scratch packed weights, BN statistic records, gradient ping-pong buffers per level, split-K slabs.
+#include <vector>
+
+#include "../../include/e3unet.h"
+#include "kernels.h"
+
+namespace {
+
+struct ParamSlot { std::string name; int64_t numel; int kind; };
+
+struct ConvUnit {           // conv (3x3x3 | 1x3x3 | transposed 2x2x2) followed by BatchNorm + ReLU
+    std::string name;       // e.g. "down_convs.0.conv1"
+    std::string bn_name;    // e.g. "down_convs.0.norm0"
+    int cin, cout, level;   // level = resolution level of the OUTPUT
+    int planar;             // planar block (1x3x3 / (1,2,2))
+    int is_up;              // transposed conv (input at level+1)
+    int p_w, p_b, p_g, p_be, p_rm, p_rv;   // indices into the param table
+    int bn_index;
+};
+
+struct Arena {              // bump allocator used twice: once with base == nullptr to size, once to place
+    char* base; size_t off;
+    explicit Arena(void* b) : base((char*)b), off(0) {}
+    float* take(size_t floats) {
+        float* p = base ? (float*)(base + off) : nullptr;
+        off += align_up(floats * sizeof(float), 256);
+        return p;
+    }
+};
+
+struct LevelDims { int D, H, W; size_t vox; };
+
+}  // namespace
+
+struct e3_unet_plan {
+    e3_unet_cfg cfg;
+    std::vector<ParamSlot> params;
+    std::vector<ConvUnit> units;      // execution order of the forward
+    int p_final_w, p_final_b;
+    int n_bn;
+    // profiling
+    int prof_layer = -1, prof_which = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
+
+    bool planar(int level) const { return (cfg.planar_mask >> level) & 1u; }
+    int chan(int level) const { return cfg.start_filts << level; }
+};
+
+namespace {
+
+int add_param(e3_unet_plan* p, const std::string& name, int64_t numel, int kind) {
+    p->params.push_back({name, numel, kind});
+    return (int)p->params.size() - 1;
+}
+
+void add_unit(e3_unet_plan* p, const std::string& conv, const std::string& bn, int cin, int cout, int level, int planar, int is_up) {
+    ConvUnit u;
+    u.name = conv; u.bn_name = bn; u.cin = cin; u.cout = cout; u.level = level; u.planar = planar; u.is_up = is_up;
+    const int taps = is_up ? (planar ? 4 : 8) : (planar ? 9 : 27);
+    u.p_w = add_param(p, conv + ".weight", (int64_t)cin * cout * taps, 0);
+    u.p_b = add_param(p, conv + ".bias", cout, 0);
+    u.p_g = add_param(p, bn + ".weight", cout, 0);
+    u.p_be = add_param(p, bn + ".bias", cout, 0);
+    u.p_rm = add_param(p, bn + ".running_mean", cout, 1);
+    u.p_rv = add_param(p, bn + ".running_var", cout, 1);
+    u.bn_index = p->n_bn++;
+    p->units.push_back(u);
+}
+
+void level_dims(const e3_unet_plan* p, int N, int D, int H, int W, std::vector<LevelDims>& L) {
+    L.resize(p->cfg.n_blocks);
+    for (int i = 0; i < p->cfg.n_blocks; ++i) {
+        L[i] = {D, H, W, (size_t)N * D * H * W};
+        const int kd = p->planar(i) ? 1 : 2;
+        D = cdiv(D, kd); H = cdiv(H, 2); W = cdiv(W, 2);   // MaxPool3d(ceil_mode=True), unet.py:229
+    }
+}
+
+// ---- buffers -----------------------------------------------------------------------------------------------
+struct UnitBufs { float* raw; float* act; int act_ldc; float* mean; float* invstd; float* scale; float* shift; };
+
+struct Buffers {
+    // saved
+    std::vector<UnitBufs> ub;            // per unit
+    std::vector<float*> cat;             // per level < nb-1: [vox][2C]
+    std::vector<float*> pooled;          // per level < nb-1: [vox(level+1)][C(level)]
+    float* xin;                          // NDHWC copy of the input when in_channels > 1
+    size_t saved_bytes;
+    // scratch
+    float* wpack; float* stats; float* bnpart; float* slab; float* small;   // small: coef / fold vectors
+    std::vector<float*> g1, g2, dcat;    // gradient buffers per level
+    float* evalA; float* evalB;          // inference ping-pong (level-0 sized)
+    size_t scratch_bytes;
+};
+
+size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+int pad_cols(int n) { const int t = conv_col_tile(n); return cdiv(n, t) * t; }
+
+void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool training, void* saved, void* scratch, Buffers& B) {
+    const int nb = p->cfg.n_blocks;
+    std::vector<LevelDims> L; level_dims(p, N, D, H, W, L);
+    Arena S(saved), T(scratch);
+    B.ub.assign(p->units.size(), UnitBufs{});
+    B.cat.assign(nb, nullptr); B.pooled.assign(nb, nullptr);
+    B.g1.assign(nb, nullptr); B.g2.assign(nb, nullptr); B.dcat.assign(nb, nullptr);
+    B.xin = nullptr; B.evalA = B.evalB = nullptr;
+    Arena& A = training ? S : T;   // in inference everything is scratch
+    if (p->cfg.in_channels > 1) B.xin = A.take(L[0].vox * p->cfg.in_channels);
+    for (int j = 0; j + 1 < nb; ++j) {
+        B.cat[j] = A.take(L[j].vox * 2 * p->chan(j));
+        B.pooled[j] = A.take(L[j + 1].vox * p->chan(j));
+    }
+    for (size_t k = 0; k < p->units.size(); ++k) {
+        const ConvUnit& u = p->units[k];
+        UnitBufs& b = B.ub[k];
+        const size_t n = L[u.level].vox * u.cout;
+        b.raw = training ? A.take(n) : nullptr;
+        // where does the activation go?
+        const bool enc_skip = !u.is_up && u.name.find("down_convs") == 0 && u.name.find("conv2") != std::string::npos && u.level < nb - 1;
+        if (enc_skip) { b.act = B.cat[u.level] ? B.cat[u.level] + u.cout : nullptr; b.act_ldc = 2 * u.cout; }
+        else if (u.is_up) { b.act = B.cat[u.level]; b.act_ldc = 2 * u.cout; }
+        else { b.act = A.take(n); b.act_ldc = u.cout; }
+        if (!saved && !scratch) { b.act = nullptr; }
+        b.mean = A.take(u.cout); b.invstd = A.take(u.cout); b.scale = A.take(u.cout); b.shift = A.take(u.cout);
+    }
+    B.saved_bytes = S.off;
+    // scratch
+    size_t wmax = 0, statmax = 0, slabmax = 0, bnpartmax = 0;
+    for (const ConvUnit& u : p->units) {
+        const LevelDims& lo = L[u.level];
+        if (u.is_up) {
+            const int sd = u.planar ? 1 : 2, taps = sd * 4;
+            const LevelDims& li = L[u.level + 1];
+            wmax = max_sz(wmax, max_sz((size_t)pad_cols(taps * u.cout) * u.cin, (size_t)taps * pad_cols(u.cin) * u.cout));
+            statmax = max_sz(statmax, (size_t)conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, li.D, li.H, li.W, sd) * u.cout * 3);
+            if (training) slabmax = max_sz(slabmax, (size_t)wgrad_splits(CONV_POINT, N, li.D, li.H, li.W, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32));
+        } else {
+            const int taps = u.planar ? 9 : 27;
+            const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
+            if (u.cin >= 8) {
+                wmax = max_sz(wmax, max_sz((size_t)taps * pad_cols(u.cout) * u.cin, (size_t)taps * pad_cols(u.cin) * u.cout));
+                statmax = max_sz(statmax, (size_t)conv_stats_parts(kind, 0, N, lo.D, lo.H, lo.W, 2) * u.cout * 3);
+                if (training) slabmax = max_sz(slabmax, (size_t)wgrad_splits(kind, N, lo.D, lo.H, lo.W, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32));
+            } else {
+                wmax = max_sz(wmax, (size_t)taps * pad_cols(u.cin) * u.cout);   // only its dgrad (dx requested) packs weights
+                statmax = max_sz(statmax, (size_t)conv_small_stats_parts(N, lo.D, lo.H, lo.W, u.planar) * u.cout * 3);
+                if (training) slabmax = max_sz(slabmax, (size_t)conv_small_wgrad_splits(N, lo.D, lo.H, lo.W, u.planar) * taps * u.cout * u.cin);
+            }
+        }
+        if (training) bnpartmax = max_sz(bnpartmax, (size_t)bn_bwd_parts(lo.vox, u.cout) * 3 * u.cout);
+    }
+    if (training) {
+        const int C0 = p->chan(0);
+        slabmax = max_sz(slabmax, (size_t)conv_final_bwd_parts(L[0].vox) * (p->cfg.out_channels * C0 + p->cfg.out_channels));
+    }
+    B.wpack = T.take(wmax);
+    B.stats = T.take(statmax);
+    B.small = T.take((size_t)4 * p->chan(nb - 1) + 64);
+    if (training) {
+        B.bnpart = T.take(bnpartmax);
+        B.slab = T.take(slabmax);
+        for (int j = 0; j < nb; ++j) {
+            const size_t n = L[j].vox * p->chan(j);
+            B.g1[j] = T.take(n); B.g2[j] = T.take(n);
+            if (j + 1 < nb) B.dcat[j] = T.take(2 * n);
+        }
+    } else {
+        B.bnpart = B.slab = nullptr;
+    }
+    B.scratch_bytes = T.off;
+}
+
+struct Prof {
+    e3_unet_plan* p; hipStream_t s; bool on;
+    Prof(e3_unet_plan* plan, hipStream_t st, int layer, int which) : p(plan), s(st) {
+        on = plan->prof_layer >= 0 && plan->prof_layer == layer && plan->prof_which == which;
+        if (on) {
+            if (p->prof_used == p->prof_events.size()) {
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+                p->prof_events.push_back({a, b});
+            }
+            (void)hipEventRecord(p->prof_events[p->prof_used].first, s);
+        }
+    }
+    ~Prof() { if (on) { (void)hipEventRecord(p->prof_events[p->prof_used].second, s); p->prof_used++; } }
+};
+
+#define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
+    E3_REQUIRE(cfg && out, E3_ERR_INVALID, "null argument");
+    E3_REQUIRE(cfg->n_blocks >= 1 && cfg->n_blocks <= 8, E3_ERR_INVALID, "n_blocks must be in 1..8");
+    E3_REQUIRE(cfg->in_channels >= 1, E3_ERR_INVALID, "in_channels must be >= 1");
+    E3_REQUIRE(cfg->in_channels < 8 || cfg->in_channels % 8 == 0, E3_ERR_UNSUPPORTED, "in_channels must be < 8 or a multiple of 8");
+    E3_REQUIRE(cfg->out_channels >= 1 && cfg->out_channels <= 8, E3_ERR_UNSUPPORTED, "out_channels must be in 1..8 on the HIP path");
+    E3_REQUIRE(cfg->start_filts >= 8 && cfg->start_filts % 8 == 0, E3_ERR_UNSUPPORTED, "start_filts must be a multiple of 8 on the HIP path");
+    E3_REQUIRE((cfg->start_filts << (cfg->n_blocks - 1)) <= 1024, E3_ERR_UNSUPPORTED, "more than 1024 channels at the bottom level");
+    E3_REQUIRE(cfg->normalization == 1, E3_ERR_UNSUPPORTED, "only normalization='batch' is implemented on the HIP path");
+    e3_unet_plan* p = new e3_unet_plan();
+    p->cfg = *cfg;
+    p->n_bn = 0;
+    const int nb = cfg->n_blocks;
+    for (int i = 0; i < nb; ++i) {   // unet.py:832-850
+        const std::string b = "down_convs." + std::to_string(i) + ".";
+        const int ins = i == 0 ? cfg->in_channels : p->chan(i - 1), outs = p->chan(i);
+        add_unit(p, b + "conv1", b + "norm0", ins, outs, i, p->planar(i), 0);
+        add_unit(p, b + "conv2", b + "norm1", outs, outs, i, p->planar(i), 0);
+    }
+    for (int k = 0; k + 1 < nb; ++k) {   // unet.py:854-879: block k works at level nb-2-k
+        const int j = nb - 2 - k;
+        const std::string b = "up_convs." + std::to_string(k) + ".";
+        const int ins = p->chan(j + 1), outs = p->chan(j);
+        add_unit(p, b + "upconv", b + "norm0", ins, outs, j, p->planar(j), 1);
+        add_unit(p, b + "conv1", b + "norm1", 2 * outs, outs, j, p->planar(j), 0);
+        add_unit(p, b + "conv2", b + "norm2", outs, outs, j, p->planar(j), 0);
+    }
+    p->p_final_w = add_param(p, "conv_final.weight", (int64_t)cfg->out_channels * p->chan(0), 0);
+    p->p_final_b = add_param(p, "conv_final.bias", cfg->out_channels, 0);
+    *out = p;
+    return E3_OK;
+}
+
+void e3_unet_plan_destroy(e3_unet_plan* plan) {
+    if (!plan) return;
+    for (auto& e : plan->prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    delete plan;
+}
+
+int e3_unet_param_count(const e3_unet_plan* plan) { return plan ? (int)plan->params.size() : 0; }
+int e3_unet_bn_count(const e3_unet_plan* plan) { return plan ? plan->n_bn : 0; }
+
+int e3_unet_param_info(const e3_unet_plan* plan, int index, char* name, int name_len, int64_t* numel, int* kind) {
+    E3_REQUIRE(plan && index >= 0 && index < (int)plan->params.size(), E3_ERR_INVALID, "bad param index");
+    const ParamSlot& s = plan->params[index];
+    if (name && name_len > 0) snprintf(name, name_len, "%s", s.name.c_str());
+    if (numel) *numel = s.numel;
+    if (kind) *kind = s.kind;
+    return E3_OK;
+}
+
+int e3_unet_conv_count(const e3_unet_plan* plan) { return plan ? (int)plan->units.size() + 1 : 0; }
+
+int e3_unet_conv_info(const e3_unet_plan* plan, int layer, char* name, int name_len, int* cin, int* cout, int* taps, int* level) {
+    E3_REQUIRE(plan && layer >= 0 && layer <= (int)plan->units.size(), E3_ERR_INVALID, "bad layer index");
+    if (layer == (int)plan->units.size()) {
+        if (name && name_len > 0) snprintf(name, name_len, "conv_final");
+        if (cin) *cin = plan->chan(0);
+        if (cout) *cout = plan->cfg.out_channels;
+        if (taps) *taps = 1;
+        if (level) *level = 0;
+        return E3_OK;
+    }
+    const ConvUnit& u = plan->units[layer];
+    if (name && name_len > 0) snprintf(name, name_len, "%s", u.name.c_str());
+    if (cin) *cin = u.cin;
+    if (cout) *cout = u.cout;
+    if (taps) *taps = u.is_up ? (u.planar ? 4 : 8) : (u.planar ? 9 : 27);
+    if (level) *level = u.level;
+    return E3_OK;
+}
+
+int e3_unet_profile_select(e3_unet_plan* plan, int layer, int which) {
+    E3_REQUIRE(plan, E3_ERR_INVALID, "null plan");
+    plan->prof_layer = layer; plan->prof_which = which; plan->prof_used = 0;
+    return E3_OK;
+}
+
+int e3_unet_profile_read(e3_unet_plan* plan, double* mean_ms, int* launches) {
+    E3_REQUIRE(plan && mean_ms && launches, E3_ERR_INVALID, "null argument");
+    double tot = 0.0; int n = 0;
+    for (size_t i = 0; i < plan->prof_used; ++i) {
+        float ms = 0.f;
+        E3_CHECK_HIP(hipEventSynchronize(plan->prof_events[i].second));
+        E3_CHECK_HIP(hipEventElapsedTime(&ms, plan->prof_events[i].first, plan->prof_events[i].second));
+        tot += ms; ++n;
+    }
+    *mean_ms = n ? tot / n : 0.0; *launches = n;
+    plan->prof_used = 0;
+    return E3_OK;
+}
+
+int e3_unet_sizes(const e3_unet_plan* plan, int N, int D, int H, int W, int training, size_t* saved_bytes, size_t* scratch_bytes) {
+    E3_REQUIRE(plan && N > 0 && D > 0 && H > 0 && W > 0, E3_ERR_INVALID, "bad shape");
+    Buffers B;
+    plan_buffers(plan, N, D, H, W, training != 0, nullptr, nullptr, B);
+    if (saved_bytes) *saved_bytes = B.saved_bytes;
+    if (scratch_bytes) *scratch_bytes = B.scratch_bytes;
+    return E3_OK;
+}
+
+int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
+                    void* const* params, const float* momenta, float* y,
+                    void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags) {
+    E3_REQUIRE(plan && x && y && params && scratch, E3_ERR_INVALID, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const bool training = (flags & E3_FWD_TRAINING) != 0;
+    const e3_unet_cfg& cfg = plan->cfg;
+    const int nb = cfg.n_blocks;
+    E3_REQUIRE(!training || (saved && momenta), E3_ERR_INVALID, "training forward needs `saved` and `momenta`");
+    Buffers B;
+    plan_buffers(plan, N, D, H, W, training, saved, scratch, B);
+    E3_REQUIRE(!training || saved_bytes >= B.saved_bytes, E3_ERR_WORKSPACE, "`saved` buffer too small");
+    E3_REQUIRE(scratch_bytes >= B.scratch_bytes, E3_ERR_WORKSPACE, "`scratch` buffer too small");
+    std::vector<LevelDims> L; level_dims(plan, N, D, H, W, L);
+    auto P = [&](int i) { return (float*)params[i]; };
+
+    const float* cur = x; int cur_ldc = cfg.in_channels;
+    if (cfg.in_channels > 1) { RUN(launch_ncdhw_to_ndhwc(x, B.xin, N, cfg.in_channels, L[0].vox / N, s)); cur = B.xin; }
+
+    for (size_t k = 0; k < plan->units.size(); ++k) {
+        const ConvUnit& u = plan->units[k];
+        UnitBufs& b = B.ub[k];
+        const LevelDims& lo = L[u.level];
+        const bool is_enc_conv2 = !u.is_up && u.name.compare(0, 10, "down_convs") == 0 && u.name.find("conv2") != std::string::npos;
+        const bool pool_after = is_enc_conv2 && u.level < nb - 1;
+        const int kd = u.planar ? 1 : 2;
+        float* dst = training ? b.raw : b.act;           // eval: conv writes the activation directly
+        const int dst_ldc = training ? u.cout : b.act_ldc;
+        const float* es = nullptr; const float* eh = nullptr;
+        if (!training) {   // eval-mode BN folded into the conv epilogue (running stats), SURVEY 8a row a18
+            RUN(launch_bn_fold(P(u.p_g), P(u.p_be), P(u.p_rm), P(u.p_rv), P(u.p_b), cfg.bn_eps, b.scale, b.shift, u.cout, s));
+            es = b.scale; eh = b.shift;
+        }
+        int parts = 0;
+        if (u.is_up) {
+            const LevelDims& li = L[u.level + 1];
+            const int sd = u.planar ? 1 : 2, taps = sd * 4, NPad = pad_cols(taps * u.cout);
+            RUN(launch_pack_weights(PACK_UP_FWD, P(u.p_w), B.wpack, u.cout, u.cin, taps, NPad, s));
+            ConvArgs a{};
+            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpack; a.bias = training ? P(u.p_b) : nullptr;
+            a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = li.D; a.H = li.H; a.W = li.W;
+            a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = sd;   // autocrop of the up-convolved tensor (unet.py:289-299)
+            a.Cout = u.cout; a.Ncols = taps * u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
+            a.stats = training ? B.stats : nullptr; a.G = 1; a.flags = CF_SCATTER_UP;
+            parts = conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, li.D, li.H, li.W, sd);
+            { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(CONV_POINT, a, s)); }
+        } else if (u.cin < 8) {
+            ConvSmallArgs a{};
+            a.x = cur; a.Cin = u.cin; a.w = P(u.p_w); a.bias = training ? P(u.p_b) : nullptr; a.y = dst; a.y_ldc = dst_ldc;
+            a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.Cout = u.cout; a.planar = u.planar;
+            a.epi_scale = es; a.epi_shift = eh; a.stats = training ? B.stats : nullptr;
+            parts = conv_small_stats_parts(N, lo.D, lo.H, lo.W, u.planar);
+            { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_small_fwd(a, s)); }
+        } else {
+            const int taps = u.planar ? 9 : 27, NPad = pad_cols(u.cout);
+            const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
+            RUN(launch_pack_weights(PACK_CONV_FWD, P(u.p_w), B.wpack, u.cout, u.cin, taps, NPad, s));
+            ConvArgs a{};
+            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpack; a.bias = training ? P(u.p_b) : nullptr;
+            a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.sd = 2;
+            a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
+            a.stats = training ? B.stats : nullptr; a.G = 1; a.flags = 0;
+            parts = conv_stats_parts(kind, 0, N, lo.D, lo.H, lo.W, 2);
+            { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(kind, a, s)); }
+        }
+        if (training) {
+            BnFinalizeArgs f{};
+            f.stats = B.stats; f.parts = parts; f.C = u.cout; f.gamma = P(u.p_g); f.beta = P(u.p_be);
+            f.running_mean = P(u.p_rm); f.running_var = P(u.p_rv); f.momentum = momenta[u.bn_index]; f.eps = cfg.bn_eps;
+            f.mean = b.mean; f.invstd = b.invstd; f.scale = b.scale; f.shift = b.shift;
+            RUN(launch_bn_finalize(f, s));
+            RUN(launch_bn_relu_apply(b.raw, u.cout, b.scale, b.shift, b.act, b.act_ldc, pool_after ? B.pooled[u.level] : nullptr, kd,
+                                     N, lo.D, lo.H, lo.W, u.cout, s));
+        } else if (pool_after) {
+            RUN(launch_maxpool(b.act, b.act_ldc, B.pooled[u.level], kd, N, lo.D, lo.H, lo.W, u.cout, s));
+        }
+        // input of the next unit
+        if (pool_after) { cur = B.pooled[u.level]; cur_ldc = u.cout; }
+        else if (u.is_up) { cur = B.cat[u.level]; cur_ldc = 2 * u.cout; }   // conv1 of the UpConv reads the whole concat buffer
+        else { cur = b.act; cur_ldc = b.act_ldc; }
+    }
+    { Prof pr(plan, s, (int)plan->units.size(), 0);
+      RUN(launch_conv_final_fwd(cur, cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y, cfg.out_channels,
+                                L[0].vox / N, N, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s)); }
+    return E3_OK;
+}
+
+int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const float* x, int N, int D, int H, int W,
+                     void* const* params, void* const* grads, float* dx,
+                     void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                     void* bucket_event, int bucket_after_down_block) {
+    E3_REQUIRE(plan && dy && x && params && grads && saved && scratch, E3_ERR_INVALID, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const e3_unet_cfg& cfg = plan->cfg;
+    const int nb = cfg.n_blocks;
+    Buffers B;
+    plan_buffers(plan, N, D, H, W, true, saved, scratch, B);
+    E3_REQUIRE(saved_bytes >= B.saved_bytes, E3_ERR_WORKSPACE, "`saved` buffer too small");
+    E3_REQUIRE(scratch_bytes >= B.scratch_bytes, E3_ERR_WORKSPACE, "`scratch` buffer too small");
+    std::vector<LevelDims> L; level_dims(plan, N, D, H, W, L);
+    auto P = [&](int i) { return (float*)params[i]; };
+    auto G = [&](int i) { return (float*)grads[i]; };
+    const int C0 = plan->chan(0);
+    const int nunits = (int)plan->units.size();
+
+    // ---- conv_final (unet.py:912): da, dW, db
+    const UnitBufs& last = B.ub[nunits - 1 - 0];   // last unit of the forward feeds conv_final
+    {
+        const int parts = conv_final_bwd_parts(L[0].vox);
+        const int ps = cfg.out_channels * C0 + cfg.out_channels;
+        { Prof pr(plan, s, nunits, 1);
+          RUN(launch_conv_final_bwd(last.act, last.act_ldc, C0, P(plan->p_final_w), dy, B.g1[0], C0, B.slab, cfg.out_channels, L[0].vox / N, N, s)); }
+        RUN(launch_colsum_finalize(B.slab, parts, ps, 0, cfg.out_channels * C0, G(plan->p_final_w), s));
+        RUN(launch_colsum_finalize(B.slab, parts, ps, cfg.out_channels * C0, cfg.out_channels, G(plan->p_final_b), s));
+    }
+
+    // ---- walk the units backwards.  `g` = gradient w.r.t. the current unit's activation.
+    const float* g = B.g1[0]; int g_ldc = C0;
+    bool event_done = bucket_event == nullptr;
+    for (int k = nunits - 1; k >= 0; --k) {
+        const ConvUnit& u = plan->units[k];
+        const UnitBufs& b = B.ub[k];
+        const LevelDims& lo = L[u.level];
+        const int j = u.level;
+        const bool is_down = u.name.compare(0, 10, "down_convs") == 0;
+        const bool is_enc_conv2 = is_down && u.name.find("conv2") != std::string::npos;
+        const bool pooled_unit = is_enc_conv2 && j < nb - 1;
+        const int kd = u.planar ? 1 : 2;
+        if (!event_done && is_down) {
+            const int blk = j;   // encoder block index == level
+            if (is_enc_conv2 && blk == bucket_after_down_block - 1) { E3_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_event, s)); event_done = true; }
+        }
+        // -- BN + ReLU (+ pool, + skip) backward -> dxr = gradient w.r.t. the raw conv output
+        float* dxr = B.g2[j];
+        {
+            BnBwdArgs a{};
+            a.x = b.raw; a.x_ldc = u.cout; a.mean = b.mean; a.invstd = b.invstd; a.gamma = P(u.p_g); a.scale = b.scale; a.shift = b.shift;
+            if (pooled_unit) { a.g1 = B.dcat[j] + u.cout; a.g1_ldc = 2 * u.cout; a.gpool = g; a.a = b.act; a.a_ldc = b.act_ldc; a.pooled = B.pooled[j]; }
+            else { a.g1 = g; a.g1_ldc = g_ldc; }
+            a.kd = kd; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.C = u.cout;
+            a.parts = bn_bwd_parts(lo.vox, u.cout); a.part = B.bnpart; a.coef = B.small; a.dx = dxr; a.dx_ldc = u.cout;
+            RUN(launch_bn_bwd_reduce(a, s));
+            RUN(launch_bn_bwd_finalize(B.bnpart, a.parts, u.cout, (float)(1.0 / (double)lo.vox), G(u.p_g), G(u.p_be), B.small, s));
+            RUN(launch_bn_bwd_apply(a, s));
+            RUN(launch_colsum_finalize(B.bnpart, a.parts, 3 * u.cout, 2 * u.cout, u.cout, G(u.p_b), s));
+        }
+        // -- input activation of this conv
+        const float* xin; int xin_ldc;
+        if (k == 0) { xin = cfg.in_channels > 1 ? B.xin : x; xin_ldc = cfg.in_channels; }
+        else {
+            const ConvUnit& pu = plan->units[k - 1];
+            const bool prev_pooled = pu.name.compare(0, 10, "down_convs") == 0 && pu.name.find("conv2") != std::string::npos && pu.level < nb - 1 && is_down;
+            if (prev_pooled) { xin = B.pooled[pu.level]; xin_ldc = pu.cout; }
+            else if (pu.is_up) { xin = B.cat[pu.level]; xin_ldc = 2 * pu.cout; }
+            else { xin = B.ub[k - 1].act; xin_ldc = B.ub[k - 1].act_ldc; }
+            if (u.is_up) {   // input of upconv k-th: activation at level j+1 = output of the previous unit (packed or cat-skip of bottom block)
+                xin = B.ub[k - 1].act; xin_ldc = B.ub[k - 1].act_ldc;
+            }
+        }
+        // -- weight gradient
+        if (u.is_up) {
+            const LevelDims& li = L[j + 1];
+            const int sd = u.planar ? 1 : 2;
+            WgradArgs a{};
+            a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dxr; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = B.slab;
+            a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = sd;
+            a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
+            a.splits = wgrad_splits(CONV_POINT, N, li.D, li.H, li.W, u.cin, u.cout);
+            { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(CONV_POINT, a, s)); }
+            RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, sd * 4, a.CiPad, a.CoPad, u.cin, u.cout, s));
+        } else if (u.cin < 8) {
+            const int taps = u.planar ? 9 : 27;
+            const int splits = conv_small_wgrad_splits(N, lo.D, lo.H, lo.W, u.planar);
+            { Prof pr(plan, s, k, 2); RUN(launch_conv_small_wgrad(xin, u.cin, dxr, u.cout, B.slab, N, lo.D, lo.H, lo.W, u.cout, u.planar, s)); }
+            RUN(launch_wgrad_reduce(B.slab, G(u.p_w), splits, taps, u.cout, u.cin, u.cout, u.cin, s));
+        } else {
+            const int taps = u.planar ? 9 : 27;
+            const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
+            WgradArgs a{};
+            a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dxr; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = B.slab;
+            a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
+            a.splits = wgrad_splits(kind, N, lo.D, lo.H, lo.W, u.cin, u.cout);
+            { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(kind, a, s)); }
+            RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
+        }
+        // -- data gradient -> g for the previous unit
+        if (k == 0 && !dx) break;
+        if (u.is_up) {
+            const LevelDims& li = L[j + 1];
+            const int sd = u.planar ? 1 : 2, taps = sd * 4, NPad = pad_cols(u.cin);
+            RUN(launch_pack_weights(PACK_UP_DGRAD, P(u.p_w), B.wpack, u.cout, u.cin, taps, NPad, s));
+            ConvArgs a{};
+            a.x = dxr; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = B.wpack; a.y = B.g1[j + 1]; a.y_ldc = u.cin;
+            a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = sd;
+            a.Cout = u.cin; a.Ncols = u.cin; a.NPad = NPad; a.G = taps; a.flags = CF_GATHER_UP;
+            { Prof pr(plan, s, k, 1); RUN(launch_conv_mfma(CONV_POINT, a, s)); }
+            g = B.g1[j + 1]; g_ldc = u.cin;
+        } else {
+            const int taps = u.planar ? 9 : 27, NPad = pad_cols(u.cin);
+            const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
+            RUN(launch_pack_weights(PACK_CONV_DGRAD, P(u.p_w), B.wpack, u.cout, u.cin, taps, NPad, s));
+            const bool to_cat = !is_down && u.name.find("conv1") != std::string::npos;   // UpConv.conv1: gradient of the concat buffer
+            float* out; int out_ldc = u.cin;
+            if (k == 0) out = (cfg.in_channels > 1) ? B.g1[0] : dx;   // g1[0] is free by now (C0 >= in_channels)
+            else if (to_cat) out = B.dcat[j];
+            else out = B.g1[j];
+            ConvArgs a{};
+            a.x = dxr; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = B.wpack; a.y = out; a.y_ldc = out_ldc;
+            a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.sd = 2;
+            a.Cout = u.cin; a.Ncols = u.cin; a.NPad = NPad; a.G = 1; a.flags = 0;
+            { Prof pr(plan, s, k, 1); RUN(launch_conv_mfma(kind, a, s)); }
+            if (k == 0) { if (cfg.in_channels > 1) RUN(launch_ndhwc_to_ncdhw(B.g1[0], cfg.in_channels, dx, N, cfg.in_channels, L[0].vox / N, s)); }
+            g = out; g_ldc = to_cat ? 2 * u.cout : u.cin;   // for to_cat the next unit (upconv) reads the first half: ldc = 2*C
+        }
+    }
+    if (!event_done) E3_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_event, s));
+    return E3_OK;
+}
+
+}  // extern "C"

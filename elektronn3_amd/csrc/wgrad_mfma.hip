@@ -1,0 +1,254 @@
+// Weight gradient of the 3x3x3 / 1x3x3 convolutions and of the k=s=2 transposed convolution on the fp32 matrix
+// cores (autograd twin of conv3()/upconv2()).
+//
+//   dW[co][ci][tap] = sum_p dY[p][co] * X[p + off(tap)][ci]
+//
+// GEMM view per tap: D[co][ci] += A[co][k] * B[k][ci] with k = voxel.  A workgroup owns a (32 co x 32 ci) tile of
+// ALL taps and a contiguous range of 128-voxel bricks ("split"); its four waves share the LDS-staged dY brick and X
+// halo brick and split the TAPS (7/7/7/6), so every wave keeps <= 7 accumulator tiles (112 VGPRs) resident over the
+// whole range and the K = N*D*H*W reduction needs no atomics: each split writes one partial slab, a small second
+// kernel sums the slabs in a fixed order (deterministic) straight into torch's (Cout,Cin,kd,kh,kw) layout.
+// Operand fetch is one ds_read_b32 per MFMA (lanes of a half-wave read 32 consecutive channels of one voxel:
+// conflict-free), negligible next to the 64-cycle MFMA.
+#include "kernels.h"
+
+namespace {
+
+template <int KD, int TD, int TH>
+struct WGeo {
+    static constexpr int TW = 16, PD = KD / 2;
+    static constexpr int LD = TD + 2 * PD, LH = TH + 2, LW = TW + 2;
+    static constexpr int NV = LD * LH * LW;          // halo voxels
+    static constexpr int MV = TD * TH * TW;          // brick voxels (128)
+    static constexpr int T = KD * 9;
+    static constexpr int TPW = (T + 3) / 4;          // taps per wave
+    static constexpr int LDS_BYTES = (NV + MV) * 32 * 4;
+    static_assert(MV == 128, "brick must hold 128 voxels");
+};
+
+template <int KD, int TD, int TH>
+__global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WgradArgs a, int tilesD, int tilesH, int tilesW,
+                                                            int tiles_per_split, int co_tiles, int ci_tiles) {
+    using G = WGeo<KD, TD, TH>;
+    constexpr int LH = G::LH, LW = G::LW, NV = G::NV, MV = G::MV, T = G::T, TPW = G::TPW, PD = G::PD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;              // [NV][32]  X halo brick, 32 input channels
+    float* gs = smem + NV * 32;    // [MV][32]  dY brick, 32 output channels
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hf = lane >> 5;
+    unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int ci_t = L % ci_tiles; L /= ci_tiles;
+    const int co_t = L % co_tiles; const int split = L / co_tiles;
+    const int ci0 = ci_t * 32, co0 = co_t * 32;
+    const int ntiles = a.N * tilesD * tilesH * tilesW;
+    const int tile0 = split * tiles_per_split;
+
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+
+    int tapoff[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int tap = wave + 4 * u;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        tapoff[u] = ((kd * LH + kh) * LW + kw) * 32;
+    }
+
+    for (int tile = tile0; tile < tile0 + tiles_per_split && tile < ntiles; ++tile) {
+        int Lt = tile;
+        const int tw_ = Lt % tilesW; Lt /= tilesW; const int th_ = Lt % tilesH; Lt /= tilesH; const int td_ = Lt % tilesD; const int nb = Lt / tilesD;
+        const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * G::TW;
+        __syncthreads();
+        // stage X halo (8 float4 per voxel) and dY brick
+#pragma unroll 4
+        for (int idx = tid; idx < NV * 8; idx += 256) {
+            const int v = idx >> 3, q = idx & 7;
+            const int zw = v % LW, zh = (v / LW) % LH, zd = v / (LW * LH);
+            const int gd = d0 + zd - PD, gh = h0 + zh - 1, gw = w0 + zw - 1;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W && ci0 + 4 * q < a.Cin)
+                val = *reinterpret_cast<const f32x4*>(a.x + ((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.x_ldc + ci0 + 4 * q);
+            *reinterpret_cast<f32x4*>(xs + v * 32 + 4 * q) = val;
+        }
+#pragma unroll 4
+        for (int idx = tid; idx < MV * 8; idx += 256) {
+            const int v = idx >> 3, q = idx & 7;
+            const int ww = v & 15, hh = (v >> 4) % TH, dd = (v >> 4) / TH;
+            const int gd = d0 + dd, gh = h0 + hh, gw = w0 + ww;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (gd < a.D && gh < a.H && gw < a.W && co0 + 4 * q < a.Cout)
+                val = *reinterpret_cast<const f32x4*>(a.dy + ((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.dy_ldc + co0 + 4 * q);
+            *reinterpret_cast<f32x4*>(gs + v * 32 + 4 * q) = val;
+        }
+        __syncthreads();
+        // K loop: MFMA #t consumes voxels (2t, 2t+1): lane half hf takes voxel 2t+hf
+#pragma unroll 1
+        for (int row = 0; row < MV / 16; ++row) {          // one W-row of 16 voxels = 8 MFMA k-steps
+            const int hh = row % TH, dd = row / TH;
+            const int gbase = row * 16 * 32 + hf * 32 + j;
+            const int xbase = ((dd * LH + hh) * LW + hf) * 32 + j;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float av = gs[gbase + t * 64];
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) {
+                    if (wave + 4 * u < T) {
+                        const float bv = xs[xbase + t * 64 + tapoff[u]];
+                        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[u], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // write the partial slab: part[split][tap][co][ci]
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int tap = wave + 4 * u;
+        if (tap < T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                a.part[(((size_t)split * T + tap) * a.CoPad + co0 + row) * a.CiPad + ci0 + j] = acc[u][r];
+            }
+        }
+    }
+}
+
+// Transposed conv (k = s): dW[ci][co][tap] = sum_p X[p][ci] * dY[up(p, tap)][co].  One workgroup = one tap, one
+// (32 ci x 32 co) tile, a range of 256-voxel bricks; the four waves split the voxels and are summed through LDS.
+__global__ __launch_bounds__(256, 2) void wgrad_point_kernel(const WgradArgs a, int tilesD, int tilesH, int tilesW,
+                                                             int tiles_per_split, int T, int co_tiles, int ci_tiles) {
+    constexpr int TD = 2, TH = 8, MV = 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;              // [256][32] X brick (ci)
+    float* gs = smem + MV * 32;    // [256][32] dY gathered at 2p+tap (co)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hf = lane >> 5;
+    unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int co_t = L % co_tiles; L /= co_tiles;
+    const int ci_t = L % ci_tiles; L /= ci_tiles;
+    const int tap = L % T; const int split = L / T;
+    const int ci0 = ci_t * 32, co0 = co_t * 32;
+    const int utw = tap & 1, uth = (tap >> 1) & 1, utd = tap >> 2;
+    const int ntiles = a.N * tilesD * tilesH * tilesW;
+    const int tile0 = split * tiles_per_split;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int tile = tile0; tile < tile0 + tiles_per_split && tile < ntiles; ++tile) {
+        int Lt = tile;
+        const int tw_ = Lt % tilesW; Lt /= tilesW; const int th_ = Lt % tilesH; Lt /= tilesH; const int td_ = Lt % tilesD; const int nb = Lt / tilesD;
+        const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * 16;
+        __syncthreads();
+#pragma unroll 4
+        for (int idx = tid; idx < MV * 8; idx += 256) {
+            const int v = idx >> 3, q = idx & 7;
+            const int gd = d0 + (v >> 4) / TH, gh = h0 + (v >> 4) % TH, gw = w0 + (v & 15);
+            const bool ok = gd < a.D && gh < a.H && gw < a.W;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f}, gv = xv;
+            if (ok && ci0 + 4 * q < a.Cin)
+                xv = *reinterpret_cast<const f32x4*>(a.x + ((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.x_ldc + ci0 + 4 * q);
+            const int od = a.sd * gd + utd, oh = 2 * gh + uth, ow = 2 * gw + utw;
+            if (ok && od < a.Do && oh < a.Ho && ow < a.Wo && co0 + 4 * q < a.Cout)
+                gv = *reinterpret_cast<const f32x4*>(a.dy + ((((size_t)nb * a.Do + od) * a.Ho + oh) * a.Wo + ow) * a.dy_ldc + co0 + 4 * q);
+            *reinterpret_cast<f32x4*>(xs + v * 32 + 4 * q) = xv;
+            *reinterpret_cast<f32x4*>(gs + v * 32 + 4 * q) = gv;
+        }
+        __syncthreads();
+        const int base = (wave * 64 + hf) * 32 + j;
+#pragma unroll 8
+        for (int t = 0; t < 32; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[base + t * 64], gs[base + t * 64], acc, 0, 0, 0);
+    }
+    // sum the four waves' tiles through LDS, then write part[split][tap][ci][co]
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        smem[(wave * 32 + row) * 32 + j] = acc[r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+        const float v = smem[idx] + smem[1024 + idx] + smem[2048 + idx] + smem[3072 + idx];
+        const int row = idx >> 5, col = idx & 31;
+        a.part[(((size_t)split * T + tap) * a.CiPad + ci0 + row) * a.CoPad + co0 + col] = v;
+    }
+}
+
+// out[(r*C + c)*T + t] = sum_s part[((s*T + t)*RPad + r)*CPad + c]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int splits, int T,
+                                    int RPad, int CPad, int R, int C) {
+    const size_t total = (size_t)T * R * C;
+    const size_t slab = (size_t)T * RPad * CPad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % C; size_t rr = i / C; const int r = rr % R; const int t = rr / R;
+        const float* p = part + ((size_t)t * RPad + r) * CPad + c;
+        double s = 0.0;
+        for (int k = 0; k < splits; ++k) s += p[(size_t)k * slab];
+        out[((size_t)r * C + c) * T + t] = (float)s;
+    }
+}
+
+void wgeo(ConvKind kind, int& TD, int& TH) { if (kind == CONV_K3_PLANAR) { TD = 1; TH = 8; } else if (kind == CONV_K3) { TD = 2; TH = 4; } else { TD = 2; TH = 8; } }
+
+int tiles_per_split(int ntiles, int other) {
+    // aim at ~768 workgroups in total (3 per CU) so that partial slabs stay small
+    int want = 768 / (other > 0 ? other : 1);
+    if (want < 1) want = 1;
+    return cdiv(ntiles, want);
+}
+
+}  // namespace
+
+int wgrad_splits(ConvKind kind, int N, int D, int H, int W, int Cin, int Cout) {
+    int TD, TH; wgeo(kind, TD, TH);
+    const int ntiles = N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, 16);
+    const int other = cdiv(Cout, 32) * cdiv(Cin, 32);
+    return cdiv(ntiles, tiles_per_split(ntiles, other));
+}
+
+int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s) {
+    E3_REQUIRE(a.Cin % 4 == 0 && a.Cout % 4 == 0 && a.x_ldc % 4 == 0 && a.dy_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "wgrad needs channel counts that are multiples of 4");
+    int TD, TH; wgeo(kind, TD, TH);
+    const int tD = cdiv(a.D, TD), tH = cdiv(a.H, TH), tW = cdiv(a.W, 16);
+    const int ntiles = a.N * tD * tH * tW;
+    const int co_tiles = cdiv(a.Cout, 32), ci_tiles = cdiv(a.Cin, 32);
+    const int tps = tiles_per_split(ntiles, co_tiles * ci_tiles);
+    const int splits = cdiv(ntiles, tps);
+    E3_REQUIRE(splits == a.splits, E3_ERR_INVALID, "wgrad: splits mismatch");
+    if (kind == CONV_POINT) {
+        const int T = a.sd * 4;
+        const size_t lds = 2 * 256 * 32 * 4;
+        const dim3 grid((unsigned)((size_t)splits * T * co_tiles * ci_tiles));
+        hipLaunchKernelGGL(wgrad_point_kernel, grid, dim3(256), lds, s, a, tD, tH, tW, tps, T, co_tiles, ci_tiles);
+    } else {
+        const dim3 grid((unsigned)((size_t)splits * co_tiles * ci_tiles));
+        if (kind == CONV_K3) {
+            using G = WGeo<3, 2, 4>;
+            auto kern = wgrad_conv_kernel<3, 2, 4>;
+            static bool set = false;
+            if (!set) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES)); set = true; }
+            hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, s, a, tD, tH, tW, tps, co_tiles, ci_tiles);
+        } else {
+            using G = WGeo<1, 1, 8>;
+            auto kern = wgrad_conv_kernel<1, 1, 8>;
+            static bool set = false;
+            if (!set) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES)); set = true; }
+            hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, s, a, tD, tH, tW, tps, co_tiles, ci_tiles);
+        }
+    }
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_wgrad_reduce(const float* part, float* out, int splits, int T, int RPad, int CPad, int R, int C, hipStream_t s) {
+    const size_t total = (size_t)T * R * C;
+    size_t g = (total + 255) / 256; if (g > 2048) g = 2048; if (g == 0) g = 1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, part, out, splits, T, RPad, CPad, R, C);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}

@@ -1,0 +1,188 @@
+/*
+ * e3unet.h -- C ABI of libe3unet.so: the MI355X (gfx950) implementation of elektronn3's 3D U-Net hot path.
+ *
+ * elektronn3 has no FFI or plugin registry: its boundary for this path is Python duck typing on
+ * torch.nn.Module.  This header is what a binding for that boundary calls: plain pointers and
+ * sizes, no torch types.  Every entry point cites the reference code it replaces (paths relative to the
+ * reference repo root).  The reference-side binding (ctypes) is shown in INTEGRATION.md and implemented in
+ * elektronn3_amd/_lib.py.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers owned by the caller (e.g. the torch caching allocator) unless a parameter
+ *     is documented as host memory.  The library never allocates or frees device memory.
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream).  Calls only enqueue work and
+ *     return; they never synchronise.  Results are ordered on that stream.
+ *   - Return value: 0 (E3_OK) on success, otherwise an E3_ERR_* code; e3_last_error() returns a message for the
+ *     calling thread.  No process-global mutable state besides that thread-local string, so replicas driven from
+ *     different Python threads (nn.DataParallel, benchmark/train_benchmark.py:109-110) do not interfere.
+ *   - Activations inside the library are fp32 NDHWC ("channels-last-3d").  Module-boundary tensors (network
+ *     input, logits, their gradients) are contiguous NCDHW like the reference's.
+ *   - "view": (ptr, ldc) addresses C channels at `ptr` inside voxel rows of `ldc` floats, so an op can read or
+ *     write one half of a concat buffer (replaces torch.cat, elektronn3/models/unet.py:398-399).
+ */
+#ifndef E3UNET_H
+#define E3UNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E3_OK 0
+#define E3_ERR_INVALID 1
+#define E3_ERR_HIP 2
+#define E3_ERR_UNSUPPORTED 3
+#define E3_ERR_WORKSPACE 4
+
+/* Message of the last failing call on this thread ("" if none). */
+const char* e3_last_error(void);
+/* Library version string, e.g. "e3unet 0.1 gfx950". */
+const char* e3_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Whole-network API: UNet.forward / its autograd backward
+ *   replaces elektronn3/models/unet.py:894-916 (UNet.forward), :244-253 (DownConv.forward), :384-408
+ *   (UpConv.forward), :256-325 (autocrop) and the autograd graph torch builds for them (Trainer._train_step,
+ *   elektronn3/training/trainer.py:520,539).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct e3_unet_cfg {
+    int32_t in_channels;    /* UNet(in_channels=...)            unet.py:757 */
+    int32_t out_channels;   /* UNet(out_channels=...), 1..8     unet.py:758 */
+    int32_t n_blocks;       /* UNet(n_blocks=...), 1..8         unet.py:759 */
+    int32_t start_filts;    /* UNet(start_filts=...), multiple of 8   unet.py:760 */
+    uint32_t planar_mask;   /* bit i set <=> i in planar_blocks unet.py:763,827 */
+    int32_t normalization;  /* 1 = 'batch' (the only mode on the HIP path this round) unet.py:767 */
+    float bn_eps;           /* nn.BatchNorm3d eps (1e-5) */
+} e3_unet_cfg;
+
+typedef struct e3_unet_plan e3_unet_plan;
+
+int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out);
+void e3_unet_plan_destroy(e3_unet_plan* plan);
+
+/* The parameter table: pointers are passed in THIS order.  Names are the reference's state_dict keys
+ * (e.g. "down_convs.0.conv1.weight", "up_convs.1.norm0.running_var"); num_batches_tracked is not part of the
+ * table (the binding increments it).  kind: 0 = trainable parameter, 1 = buffer (running statistic). */
+int e3_unet_param_count(const e3_unet_plan* plan);
+int e3_unet_param_info(const e3_unet_plan* plan, int index, char* name, int name_len, int64_t* numel, int* kind);
+/* Number of BatchNorm layers, in table order (momenta[] below has one entry per BN). */
+int e3_unet_bn_count(const e3_unet_plan* plan);
+
+/* Bytes of caller-provided device memory needed for an (N, in_channels, D, H, W) batch.
+ *   saved_bytes:   activations kept from a training forward for the backward (0 for inference)
+ *   scratch_bytes: temporaries; may be shared by consecutive calls on one stream */
+int e3_unet_sizes(const e3_unet_plan* plan, int N, int D, int H, int W, int training,
+                  size_t* saved_bytes, size_t* scratch_bytes);
+
+#define E3_FWD_TRAINING 1u  /* batch statistics + running-stat update (module.training) */
+#define E3_FWD_SOFTMAX 2u   /* y = softmax over channels (Predictor's nn.Sequential(model, nn.Softmax(1)), inference.py:443-444) */
+
+/* y[N,out,D,H,W] = UNet(x[N,in,D,H,W]).
+ *   params : e3_unet_param_count() device pointers in table order
+ *   momenta: HOST array, one exponential-average factor per BN (module.momentum at call time; SWA.bn_update
+ *            mutates it, training/swa.py:317-342).  Ignored unless E3_FWD_TRAINING.
+ *   saved  : written when training (needed by e3_unet_backward), may be NULL otherwise */
+int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
+                    void* const* params, const float* momenta, float* y,
+                    void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags);
+
+/* Gradients of a scalar loss w.r.t. every trainable parameter (and optionally x), given dy = dLoss/dy.
+ *   grads : table-ordered device pointers (entries of buffers are ignored, may be NULL); every trainable entry
+ *           is OVERWRITTEN with the gradient (accumulation into .grad stays with autograd)
+ *   dx    : NULL or [N,in,D,H,W]
+ *   bucket_event / bucket_after_down_block: if bucket_event (a hipEvent_t) is non-NULL it is recorded on
+ *           `stream` as soon as the gradients of every layer EXCEPT down_convs[0..bucket_after_down_block-1] are
+ *           complete, so a data-parallel binding can start the RCCL all-reduce of that bucket on a side stream
+ *           while the rest of the backward runs (replaces nn.DataParallel's reduce_add_coalesced,
+ *           benchmark/train_benchmark.py:109-110). */
+int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const float* x, int N, int D, int H, int W,
+                     void* const* params, void* const* grads, float* dx,
+                     void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                     void* bucket_event, int bucket_after_down_block);
+
+/* Per-layer profiling hook used by bench.py for the roofline line: when `layer` >= 0, hipEvents are recorded
+ * around that layer's dominant kernel in every subsequent forward (which=0), dgrad (1) or wgrad (2); read the
+ * mean duration of all recorded launches (and reset) with e3_unet_profile_read.  `layer` indexes the conv list
+ * returned by e3_unet_conv_info. */
+int e3_unet_conv_count(const e3_unet_plan* plan);
+int e3_unet_conv_info(const e3_unet_plan* plan, int layer, char* name, int name_len, int* cin, int* cout, int* taps, int* level);
+int e3_unet_profile_select(e3_unet_plan* plan, int layer, int which);
+int e3_unet_profile_read(e3_unet_plan* plan, double* mean_ms, int* launches);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Per-op API (unit parity against the oracle; also usable on their own).  Tensors are NDHWC views.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* nn.Conv3d(k=3, pad=1) or, planar != 0, nn.Conv3d(k=(1,3,3), pad=(0,1,1))   [unet.py:131-149]
+ *   w: torch layout (Cout, Cin, kd, 3, 3); bias may be NULL.
+ *   pro_scale/pro_shift (NULL or [Cin]):  x := relu(x*scale+shift) applied while loading (fused BN+ReLU of the
+ *       producer layer).
+ *   epi_scale/epi_shift (NULL or [Cout]): y := relu(y*scale+shift) (eval-mode BatchNorm folded; bias is NOT added
+ *       separately in that case -- fold it into epi_shift).
+ *   stats (NULL or [e3_conv3d_stats_parts][Cout][3]): per-tile (count, mean, M2) of y for train-mode BatchNorm.
+ *   workspace: e3_conv3d_workspace_bytes() bytes (packed weights). */
+size_t e3_conv3d_workspace_bytes(int Cin, int Cout, int planar);
+int e3_conv3d_stats_parts(int Cin, int N, int D, int H, int W, int planar);
+int e3_conv3d_fwd(void* stream, const float* x, int x_ldc, int Cin, const float* w, const float* bias,
+                  float* y, int y_ldc, int Cout, int N, int D, int H, int W, int planar,
+                  const float* pro_scale, const float* pro_shift, const float* epi_scale, const float* epi_shift,
+                  float* stats, void* workspace, size_t workspace_bytes);
+/* dx = d/dx of the above (no prologue/epilogue), Cout >= 8. */
+int e3_conv3d_dgrad(void* stream, const float* dy, int dy_ldc, int Cout, const float* w, float* dx, int dx_ldc, int Cin,
+                    int N, int D, int H, int W, int planar, void* workspace, size_t workspace_bytes);
+/* dw (torch layout) = d/dw.  workspace: e3_conv3d_wgrad_workspace_bytes(). */
+size_t e3_conv3d_wgrad_workspace_bytes(int Cin, int Cout, int N, int D, int H, int W, int planar);
+int e3_conv3d_wgrad(void* stream, const float* x, int x_ldc, int Cin, const float* dy, int dy_ldc, int Cout, float* dw,
+                    int N, int D, int H, int W, int planar, void* workspace, size_t workspace_bytes);
+
+/* nn.ConvTranspose3d(Cin, Cout, kernel=stride=(sd,2,2)), sd in {1,2}   [unet.py:152-165]; w: (Cin, Cout, sd, 2, 2).
+ * (D,H,W) are the INPUT dims; the output view has dims (Do,Ho,Wo) <= (sd*D, 2H, 2W): positions beyond are dropped,
+ * which implements autocrop()'s crop of the up-convolved tensor (unet.py:289-299). */
+size_t e3_convT_workspace_bytes(int Cin, int Cout, int sd);
+int e3_convT_stats_parts(int N, int D, int H, int W, int sd);
+int e3_convT_fwd(void* stream, const float* x, int x_ldc, int Cin, const float* w, const float* bias, float* y, int y_ldc,
+                 int Cout, int N, int D, int H, int W, int sd, int Do, int Ho, int Wo, float* stats,
+                 void* workspace, size_t workspace_bytes);
+int e3_convT_dgrad(void* stream, const float* dy, int dy_ldc, int Cout, const float* w, float* dx, int dx_ldc, int Cin,
+                   int N, int D, int H, int W, int sd, int Do, int Ho, int Wo, void* workspace, size_t workspace_bytes);
+size_t e3_convT_wgrad_workspace_bytes(int Cin, int Cout, int N, int D, int H, int W, int sd);
+int e3_convT_wgrad(void* stream, const float* x, int x_ldc, int Cin, const float* dy, int dy_ldc, int Cout, float* dw,
+                   int N, int D, int H, int W, int sd, int Do, int Ho, int Wo, void* workspace, size_t workspace_bytes);
+
+/* nn.BatchNorm3d training statistics from the per-tile records a conv wrote   [unet.py:77-105]:
+ * mean/invstd/scale/shift are [C] outputs (scale = gamma*invstd, shift = beta - mean*scale);
+ * running_mean/var are updated in place with `momentum` (NULL to skip). */
+int e3_bn_finalize(void* stream, const float* stats, int parts, int C, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps,
+                   float* mean, float* invstd, float* scale, float* shift);
+/* a = relu(x*scale + shift); if pooled != NULL also pooled = MaxPool3d(k=(kd,2,2), ceil_mode=True)(a)
+ * [unet.py:183-186, 67-74, 225-230].  pooled is packed NDHWC with ceil dims. */
+int e3_bn_relu_apply(void* stream, const float* x, int x_ldc, const float* scale, const float* shift, float* a, int a_ldc,
+                     float* pooled, int kd, int N, int D, int H, int W, int C);
+int e3_maxpool(void* stream, const float* a, int a_ldc, float* pooled, int kd, int N, int D, int H, int W, int C);
+/* Backward of x -> BatchNorm(train) -> ReLU [-> MaxPool]:
+ *   dA = g1 (may be NULL) + unpool(gpool) (may be NULL; needs a, pooled);  dx, dgamma, dbeta, dxsum (= sum_p dx,
+ *   the gradient of the producing conv's bias) are outputs.  workspace: e3_bn_bwd_workspace_bytes(). */
+size_t e3_bn_bwd_workspace_bytes(int N, int D, int H, int W, int C);
+int e3_bn_relu_bwd(void* stream, const float* x, int x_ldc, const float* mean, const float* invstd, const float* gamma,
+                   const float* scale, const float* shift, const float* g1, int g1_ldc, const float* gpool,
+                   const float* a, int a_ldc, const float* pooled, int kd, int N, int D, int H, int W, int C,
+                   float* dx, int dx_ldc, float* dgamma, float* dbeta, float* dxsum, void* workspace, size_t workspace_bytes);
+
+/* conv_final: nn.Conv3d(C, Cout, 1)   [unet.py:178-180, 881, 912].  y and dy are NCDHW (module boundary). */
+int e3_conv1_fwd(void* stream, const float* a, int a_ldc, int C, const float* w, const float* bias, float* y_ncdhw,
+                 int Cout, int N, int D, int H, int W, int softmax);
+size_t e3_conv1_bwd_workspace_bytes(int C, int Cout, int N, int D, int H, int W);
+int e3_conv1_bwd(void* stream, const float* a, int a_ldc, int C, const float* w, const float* dy_ncdhw, float* da, int da_ldc,
+                 float* dw, float* db, int Cout, int N, int D, int H, int W, void* workspace, size_t workspace_bytes);
+
+/* Layout conversion at the module boundary. */
+int e3_ncdhw_to_ndhwc(void* stream, const float* src, float* dst, int N, int C, int D, int H, int W);
+int e3_ndhwc_to_ncdhw(void* stream, const float* src, int src_ldc, float* dst, int N, int C, int D, int H, int W);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E3UNET_H */

@@ -1,0 +1,84 @@
+"""CPU-only: the C-ABI library builds, loads and exports every symbol include/e3unet.h declares, with the argument
+counts the ctypes binding uses.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, 'include', 'e3unet.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    src = re.sub(r'^\s*#.*$', '', src, flags=re.M)
+    fns = {}
+    for m in re.finditer(r'([A-Za-z_][\w\s\*]*?)\b(e3_\w+)\s*\(([^;{}]*?)\)\s*;', src, flags=re.S):
+        name, args = m.group(2), m.group(3).strip()
+        n = 0 if args in ('', 'void') else len([a for a in args.split(',') if a.strip()])
+        fns[name] = n
+    return fns
+
+
+def test_header_declares_something():
+    fns = header_functions()
+    assert 'e3_unet_forward' in fns and 'e3_conv3d_fwd' in fns and len(fns) >= 30
+
+
+def test_library_exports_all_header_symbols():
+    from elektronn3_amd import _lib
+    lib = _lib.load()
+    fns = header_functions()
+    for name in fns:
+        assert hasattr(lib, name), f'{name} declared in include/e3unet.h but not exported by libe3unet.so'
+    assert lib.e3_version().decode().startswith('e3unet')
+
+
+def test_binding_matches_header_arity():
+    from elektronn3_amd import _lib
+    fns = header_functions()
+    assert set(_lib.EXPORTED_SYMBOLS) == set(fns), set(_lib.EXPORTED_SYMBOLS) ^ set(fns)
+    for name, (_, args) in _lib._SIG.items():
+        assert len(args) == fns[name], (name, len(args), fns[name])
+
+
+def test_plan_param_table_matches_reference_state_dict_names():
+    """Host logic only (no GPU): the plan's parameter table uses the reference's state_dict keys
+    (golden fixture sd0 of an n_blocks=4, planar_blocks=(0,1) model)."""
+    import numpy as np
+    from elektronn3_amd import _lib
+    from helpers import load_npz, sub
+    g = load_npz('unet_nb4_sf8_planar01.npz')
+    sd = sub(g, 'sd0')
+    lib = _lib.load()
+    cfg = _lib.UNetCfg(1, 2, 4, 8, 0b0011, 1, 1e-5)
+    plan = ctypes.c_void_p()
+    _lib.check(lib.e3_unet_plan_create(ctypes.byref(cfg), ctypes.byref(plan)))
+    try:
+        names = []
+        for i in range(lib.e3_unet_param_count(plan)):
+            buf = ctypes.create_string_buffer(128)
+            numel, kind = ctypes.c_int64(), ctypes.c_int()
+            _lib.check(lib.e3_unet_param_info(plan, i, buf, 128, ctypes.byref(numel), ctypes.byref(kind)))
+            name = buf.value.decode()
+            names.append(name)
+            assert name in sd, name
+            assert int(np.prod(sd[name].shape)) == numel.value, name
+        expected = {k for k in sd if not k.endswith('num_batches_tracked')}
+        assert set(names) == expected
+        assert lib.e3_unet_bn_count(plan) == sum(1 for k in sd if k.endswith('running_mean'))
+        saved, scratch = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(lib.e3_unet_sizes(plan, 2, 8, 32, 32, 1, ctypes.byref(saved), ctypes.byref(scratch)))
+        assert saved.value > 0 and scratch.value > 0
+    finally:
+        lib.e3_unet_plan_destroy(plan)
+
+
+def test_unsupported_config_is_reported():
+    from elektronn3_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.UNetCfg(1, 2, 3, 12, 0, 1, 1e-5)   # start_filts not a multiple of 8
+    plan = ctypes.c_void_p()
+    with pytest.raises(NotImplementedError):
+        _lib.check(lib.e3_unet_plan_create(ctypes.byref(cfg), ctypes.byref(plan)))
