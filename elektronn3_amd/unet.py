@@ -1,0 +1,399 @@
+"""``UNet`` -- drop-in for ``elektronn3.models.unet.UNet`` whose forward/backward run in libe3unet (HIP, gfx950).
+
+Mirrors the reference's constructor signature, attribute names, sub-module tree and ``state_dict`` keys
+(elektronn3/models/unet.py:755-883), so ``Trainer``, ``Predictor``, ``torch.save(model)``, ``load_state_dict`` of a
+reference checkpoint, ``SWA.bn_update`` (which walks ``_BatchNorm`` modules and mutates ``momentum``,
+training/swa.py:317-342) and parameter/gradient histograms keep working.  The sub-modules are ordinary
+``nn.Conv3d`` / ``nn.BatchNorm3d`` / ``nn.ConvTranspose3d`` objects that only HOLD parameters and buffers: their
+``forward`` is never called.  ``UNet.forward`` makes ONE native call per pass (``e3_unet_forward`` /
+``e3_unet_backward``) on torch's current HIP stream; parameters, buffers and ``momentum`` are read from the module
+at call time (nothing is cached across calls except scratch memory).
+
+There is no CPU path: a CPU input raises ``RuntimeError``.
+"""
+import ctypes
+import threading
+from typing import Sequence, Union
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import E3_FWD_SOFTMAX, E3_FWD_TRAINING, UNetCfg, c_size_t, c_void_p, check
+
+_plans = {}
+_plans_lock = threading.Lock()
+_scratch = {}
+
+
+class _Plan:
+    """Native plan + the parameter table order (shared by all modules with the same configuration)."""
+
+    def __init__(self, key):
+        lib = _lib.load()
+        cfg = UNetCfg(*key)
+        handle = c_void_p()
+        check(lib.e3_unet_plan_create(ctypes.byref(cfg), ctypes.byref(handle)))
+        self.handle = handle
+        self.names, self.kinds = [], []
+        for i in range(lib.e3_unet_param_count(handle)):
+            buf = ctypes.create_string_buffer(160)
+            numel, kind = ctypes.c_int64(), ctypes.c_int()
+            check(lib.e3_unet_param_info(handle, i, buf, 160, ctypes.byref(numel), ctypes.byref(kind)))
+            self.names.append(buf.value.decode())
+            self.kinds.append(kind.value)
+        self.bn_names = [n[:-len('.running_mean')] for n in self.names if n.endswith('.running_mean')]
+        self.n_bn = lib.e3_unet_bn_count(handle)
+        assert self.n_bn == len(self.bn_names)
+        self.conv_names = []
+        for i in range(lib.e3_unet_conv_count(handle)):
+            buf = ctypes.create_string_buffer(160)
+            ci, co, taps, lvl = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            check(lib.e3_unet_conv_info(handle, i, buf, 160, ctypes.byref(ci), ctypes.byref(co), ctypes.byref(taps), ctypes.byref(lvl)))
+            self.conv_names.append((buf.value.decode(), ci.value, co.value, taps.value, lvl.value))
+
+    def sizes(self, N, D, H, W, training):
+        saved, scratch = c_size_t(), c_size_t()
+        check(_lib.load().e3_unet_sizes(self.handle, N, D, H, W, int(training), ctypes.byref(saved), ctypes.byref(scratch)))
+        return saved.value, scratch.value
+
+
+def _get_plan(key):
+    with _plans_lock:
+        p = _plans.get(key)
+        if p is None:
+            p = _plans[key] = _Plan(key)
+        return p
+
+
+def _get_scratch(device, nbytes):
+    """Per-(device, stream) scratch buffer, grown on demand.  Safe to share between consecutive calls on one stream
+    (everything is stream-ordered)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _scratch.pop(key, None)
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+def release_scratch():
+    """Drop the cached scratch buffers (they are re-created on the next call)."""
+    _scratch.clear()
+
+
+class _UNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, softmax, x, *params):
+        plan = module._plan()
+        lib = _lib.load()
+        dev = x.device
+        in_dtype = x.dtype
+        x32 = x.detach().to(torch.float32).contiguous()
+        N, Cin, D, H, W = x32.shape
+        training = module.training
+        # parameters / buffers at call time, in the plan's table order
+        tens = module._table(plan, params)
+        if any(t.dtype != torch.float32 for t in tens):
+            if training:
+                raise NotImplementedError('training with non-fp32 parameters is not implemented on the HIP path '
+                                          '(use fp32 parameters; autocast inputs are up-cast)')
+            tens = [t.float() for t in tens]   # e.g. Predictor(float16=True): compute in fp32, cast the result
+        tens = [t if t.is_contiguous() else t.contiguous() for t in tens]
+        # (grad mode is off inside Function.forward; needs_input_grad tells whether a backward can follow)
+        need_grad = training and any(ctx.needs_input_grad)
+        ctx.eval_mode = not training
+        saved_bytes, scratch_bytes = plan.sizes(N, D, H, W, training)
+        saved = torch.empty(max(saved_bytes, 256), dtype=torch.uint8, device=dev) if training else None
+        scratch = _get_scratch(dev, max(scratch_bytes, 256))
+        y = torch.empty((N, module.out_channels, D, H, W), dtype=torch.float32, device=dev)
+        ptrs = (c_void_p * len(tens))(*[t.data_ptr() for t in tens])
+        momenta = None
+        if training:
+            moms = module._momenta(plan)
+            momenta = (ctypes.c_float * len(moms))(*moms)
+        flags = (E3_FWD_TRAINING if training else 0) | (E3_FWD_SOFTMAX if softmax else 0)
+        with torch.cuda.device(dev):
+            check(lib.e3_unet_forward(plan.handle, _lib.stream_ptr(dev), c_void_p(x32.data_ptr()), N, D, H, W, ptrs, momenta,
+                                      c_void_p(y.data_ptr()), c_void_p(saved.data_ptr()) if saved is not None else None,
+                                      c_size_t(saved.numel() if saved is not None else 0),
+                                      c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), flags))
+        if training:
+            module._bump_num_batches_tracked(plan)
+        ctx.module, ctx.plan = module, plan
+        ctx.softmax = softmax
+        ctx.shape = (N, D, H, W)
+        ctx.in_dtype = in_dtype
+        if need_grad:
+            ctx.x32, ctx.saved_buf, ctx.tens = x32, saved, tens
+        else:
+            ctx.x32 = ctx.saved_buf = ctx.tens = None
+        return y if in_dtype == torch.float32 else y.to(in_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.saved_buf is None:
+            if ctx.eval_mode:
+                raise NotImplementedError('backward through an eval-mode (running-statistics) forward is not implemented on the HIP path')
+            raise RuntimeError('backward called but the forward did not save activations')
+        if ctx.softmax:
+            raise NotImplementedError('backward through the fused softmax head is not implemented')
+        module, plan = ctx.module, ctx.plan
+        lib = _lib.load()
+        N, D, H, W = ctx.shape
+        dev = dy.device
+        dy32 = dy.detach().to(torch.float32).contiguous()
+        tens = ctx.tens
+        sync = getattr(module, '_grad_sync', None)
+        # one flat gradient buffer; every trainable tensor gets a view (table order)
+        flat, views = (sync.flat_views(plan, tens) if sync is not None else _flat_views(plan, tens, dev))
+        gptrs = (c_void_p * len(tens))(*[(v.data_ptr() if v is not None else None) for v in views])
+        ptrs = (c_void_p * len(tens))(*[t.data_ptr() for t in tens])
+        dx = torch.empty_like(ctx.x32) if ctx.needs_input_grad[2] else None
+        _, scratch_bytes = plan.sizes(N, D, H, W, True)
+        scratch = _get_scratch(dev, max(scratch_bytes, 256))
+        ev, ev_blk = (sync.bucket_event(), sync.bucket_after_down_block) if sync is not None else (None, 0)
+        with torch.cuda.device(dev):
+            check(lib.e3_unet_backward(plan.handle, _lib.stream_ptr(dev), c_void_p(dy32.data_ptr()), c_void_p(ctx.x32.data_ptr()),
+                                       N, D, H, W, ptrs, gptrs, c_void_p(dx.data_ptr()) if dx is not None else None,
+                                       c_void_p(ctx.saved_buf.data_ptr()), c_size_t(ctx.saved_buf.numel()),
+                                       c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), ev, ev_blk))
+        if sync is not None:
+            sync.after_backward(plan)
+        ctx.saved_buf = ctx.x32 = ctx.tens = None   # free the activations now
+        by_name = dict(zip(plan.names, views))
+        grads = []
+        for name, p in module._named_table_params(plan):
+            g = by_name[name].view_as(p)
+            grads.append(g if g.dtype == p.dtype else g.to(p.dtype))
+        if dx is not None and dx.dtype != ctx.in_dtype:
+            dx = dx.to(ctx.in_dtype)
+        return (None, None, dx, *grads)
+
+
+def _flat_views(plan, tens, device):
+    sizes = [t.numel() if k == 0 else 0 for t, k in zip(tens, plan.kinds)]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    views, off = [], 0
+    for n in sizes:
+        views.append(flat[off:off + n] if n else None)
+        off += n
+    return flat, views
+
+
+class DownConv(nn.Module):
+    """Parameter container for one encoder block (two convs, two norms, max-pool) -- reference: unet.py:202-253."""
+
+    def __init__(self, in_channels, out_channels, pooling=True, planar=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.pooling, self.planar = in_channels, out_channels, pooling, planar
+        k, p = ((1, 3, 3), (0, 1, 1)) if planar else (3, 1)
+        self.conv1 = nn.Conv3d(in_channels, out_channels, kernel_size=k, padding=p)
+        self.conv2 = nn.Conv3d(out_channels, out_channels, kernel_size=k, padding=p)
+        if pooling:
+            self.pool = nn.MaxPool3d(kernel_size=(1, 2, 2) if planar else 2, ceil_mode=True)
+        else:
+            self.pool = nn.Identity()
+        self.act1, self.act2 = nn.ReLU(), nn.ReLU()
+        self.norm0, self.norm1 = nn.BatchNorm3d(out_channels), nn.BatchNorm3d(out_channels)
+
+    def forward(self, x):
+        raise RuntimeError('elektronn3_amd sub-modules only hold parameters; call UNet.forward')
+
+
+class UpConv(nn.Module):
+    """Parameter container for one decoder block (transposed conv, two convs, three norms) -- reference: unet.py:328-408."""
+
+    def __init__(self, in_channels, out_channels, planar=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.planar = in_channels, out_channels, planar
+        ks = (1, 2, 2) if planar else 2
+        k, p = ((1, 3, 3), (0, 1, 1)) if planar else (3, 1)
+        self.upconv = nn.ConvTranspose3d(in_channels, out_channels, kernel_size=ks, stride=ks)
+        self.conv1 = nn.Conv3d(2 * out_channels, out_channels, kernel_size=k, padding=p)
+        self.conv2 = nn.Conv3d(out_channels, out_channels, kernel_size=k, padding=p)
+        self.act0, self.act1, self.act2 = nn.ReLU(), nn.ReLU(), nn.ReLU()
+        self.norm0, self.norm1, self.norm2 = (nn.BatchNorm3d(out_channels) for _ in range(3))
+        self.att = None   # Trainer reads model.up_convs[i].att (trainer.py:611-617); always None without attention
+
+    def forward(self, enc, dec):
+        raise RuntimeError('elektronn3_amd sub-modules only hold parameters; call UNet.forward')
+
+
+class UNet(nn.Module):
+    """3D U-Net with the reference's interface (elektronn3/models/unet.py:755-771), executed by hand-written HIP
+    kernels.  Options of the reference that are not yet on the HIP path raise ``NotImplementedError`` at
+    construction: ``dim=2``, ``up_mode != 'transpose'``, ``merge_mode='add'``,
+    ``attention=True``, ``activation != 'relu'``, ``normalization != 'batch'``, ``full_norm=False``,
+    ``conv_mode != 'same'``."""
+
+    def __init__(
+            self,
+            in_channels: int = 1,
+            out_channels: int = 2,
+            n_blocks: int = 3,
+            start_filts: int = 32,
+            up_mode: str = 'transpose',
+            merge_mode: str = 'concat',
+            planar_blocks: Sequence = (),
+            batch_norm: str = 'unset',
+            attention: bool = False,
+            activation: Union[str, nn.Module] = 'relu',
+            normalization: str = 'batch',
+            full_norm: bool = True,
+            dim: int = 3,
+            conv_mode: str = 'same',
+    ):
+        super().__init__()
+        # -- the reference's argument validation (unet.py:774-824), same exception types
+        if n_blocks < 1:
+            raise ValueError('n_blocks must be > 1.')
+        if dim not in {2, 3}:
+            raise ValueError('dim has to be 2 or 3')
+        if dim == 2 and planar_blocks != ():
+            raise ValueError('If dim=2, you can\'t use planar_blocks since everything will be planar (2-dimensional) anyways.\n'
+                             'Either set dim=3 or set planar_blocks=().')
+        if up_mode not in ('transpose', 'upsample', 'resizeconv_nearest', 'resizeconv_linear', 'resizeconv_nearest1', 'resizeconv_linear1'):
+            raise ValueError(f'"{up_mode}" is not a valid mode for upsampling')
+        if merge_mode not in ('concat', 'add'):
+            raise ValueError(f'"{merge_mode}" is not a valid mode for merging up and down paths. Only "concat" and "add" are allowed.')
+        if 'resizeconv' in up_mode and merge_mode == 'add':
+            raise ValueError('up_mode "resizeconv" is incompatible with merge_mode "add" at the moment')
+        if len(planar_blocks) > n_blocks:
+            raise ValueError('planar_blocks can\'t be longer than n_blocks.')
+        if planar_blocks and (max(planar_blocks) >= n_blocks or min(planar_blocks) < 0):
+            raise ValueError('planar_blocks has invalid value range. All values have to be block indices, meaning integers '
+                             'between 0 and (n_blocks - 1).')
+        if batch_norm != 'unset':
+            raise RuntimeError('The `batch_norm` option has been replaced with the more general `normalization` option.\n'
+                               'If you still want to use batch normalization, set `normalization=batch` instead.')
+        # -- what the HIP path implements this round
+        unsupported = []
+        if dim != 3: unsupported.append('dim=2')
+        if up_mode != 'transpose': unsupported.append(f'up_mode={up_mode!r}')
+        if merge_mode != 'concat': unsupported.append(f'merge_mode={merge_mode!r}')
+        if attention: unsupported.append('attention=True')
+        if activation != 'relu': unsupported.append(f'activation={activation!r}')
+        if normalization != 'batch': unsupported.append(f'normalization={normalization!r}')
+        if not full_norm: unsupported.append('full_norm=False')
+        if conv_mode != 'same': unsupported.append(f'conv_mode={conv_mode!r}')
+        if start_filts % 8 != 0: unsupported.append(f'start_filts={start_filts} (must be a multiple of 8)')
+        if not (1 <= out_channels <= 8): unsupported.append(f'out_channels={out_channels} (1..8)')
+        if not (in_channels < 8 or in_channels % 8 == 0): unsupported.append(f'in_channels={in_channels}')
+        if unsupported:
+            raise NotImplementedError('not implemented on the MI355X HIP path yet: ' + ', '.join(unsupported))
+
+        self.out_channels = out_channels
+        self.in_channels = in_channels
+        self.start_filts = start_filts
+        self.n_blocks = n_blocks
+        self.normalization = normalization
+        self.attention = attention
+        self.conv_mode = conv_mode
+        self.activation = activation
+        self.dim = dim
+        self.up_mode = up_mode
+        self.merge_mode = merge_mode
+        self.planar_blocks = tuple(planar_blocks)
+
+        self.down_convs = nn.ModuleList()
+        self.up_convs = nn.ModuleList()
+        outs = in_channels
+        for i in range(n_blocks):
+            ins = in_channels if i == 0 else outs
+            outs = start_filts * (2 ** i)
+            self.down_convs.append(DownConv(ins, outs, pooling=i < n_blocks - 1, planar=i in self.planar_blocks))
+        for i in range(n_blocks - 1):
+            ins = outs
+            outs = ins // 2
+            self.up_convs.append(UpConv(ins, outs, planar=(n_blocks - 2 - i) in self.planar_blocks))
+        self.conv_final = nn.Conv3d(outs, out_channels, kernel_size=1)
+        self.apply(self.weight_init)
+
+    @staticmethod
+    def weight_init(m):
+        """Xavier-normal weights, zero biases for every (transposed) conv -- same scheme as unet.py:885-892."""
+        if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)):
+            nn.init.xavier_normal_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+    # ------------------------------------------------------------------ native plumbing
+    def _plan_key(self):
+        mask = 0
+        for b in self.planar_blocks:
+            mask |= 1 << int(b)
+        return (self.in_channels, self.out_channels, self.n_blocks, self.start_filts, mask, 1, float(self.down_convs[0].norm0.eps))
+
+    def _plan(self):
+        return _get_plan(self._plan_key())
+
+    def _named_table_params(self, plan):
+        """(name, Parameter) for the trainable entries of the plan table, in table order."""
+        for name, kind in zip(plan.names, plan.kinds):
+            if kind == 0:
+                yield name, self.get_parameter(name)
+
+    def _table(self, plan, params):
+        """Tensors for every table slot: trainable ones come from the autograd inputs (same order), buffers from
+        the module (running statistics are read -- and updated -- in place at call time)."""
+        it = iter(params)
+        out = []
+        for name, kind in zip(plan.names, plan.kinds):
+            out.append(next(it).detach() if kind == 0 else self.get_buffer(name))
+        return out
+
+    def _momenta(self, plan):
+        moms = []
+        for bn_name in plan.bn_names:
+            bn = self.get_submodule(bn_name)
+            if bn.momentum is None:   # cumulative moving average (torch semantics)
+                moms.append(1.0 / float(int(bn.num_batches_tracked) + 1))
+            else:
+                moms.append(float(bn.momentum))
+        return moms
+
+    def _bump_num_batches_tracked(self, plan):
+        nbt = [self.get_submodule(n).num_batches_tracked for n in plan.bn_names]
+        torch._foreach_add_(nbt, 1)
+
+    # ------------------------------------------------------------------ public API
+    def forward(self, x):
+        return self._run(x, softmax=False)
+
+    def _run(self, x, softmax=False):
+        if not isinstance(x, torch.Tensor) or x.dim() != 5:
+            raise ValueError('expected a 5D (N, C, D, H, W) tensor')
+        if x.shape[1] != self.in_channels:
+            raise ValueError(f'expected {self.in_channels} input channels, got {x.shape[1]}')
+        if not x.is_cuda:
+            raise RuntimeError('elektronn3_amd.UNet runs only on a ROCm GPU (hand-written HIP kernels); there is no CPU fallback')
+        plan = self._plan()
+        params = [p for _, p in self._named_table_params(plan)]
+        if any(p.device != x.device for p in params):
+            raise RuntimeError('input and parameters are on different devices')
+        return _UNetFunction.apply(self, softmax, x, *params)
+
+    def forward_softmax(self, x):
+        """``softmax(forward(x), dim=1)`` with the softmax fused into the final 1x1x1 conv kernel (used by Predictor)."""
+        return self._run(x, softmax=True)
+
+    @torch.jit.unused
+    def forward_gradcp(self, x):
+        """Same as :meth:`forward` (unet.py:918-935 trades recompute for memory; with 288 GB of HBM nothing needs to be
+        recomputed, so checkpointing is a no-op here)."""
+        return self.forward(x)
+
+    # profiling hook used by bench.py (roofline of a single layer measured with HIP events inside the step)
+    def conv_layers(self):
+        return list(self._plan().conv_names)
+
+    def profile_select(self, layer, which=0):
+        check(_lib.load().e3_unet_profile_select(self._plan().handle, int(layer), int(which)))
+
+    def profile_read(self):
+        ms, n = ctypes.c_double(), ctypes.c_int()
+        check(_lib.load().e3_unet_profile_read(self._plan().handle, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,77 @@
+"""Functional torch restatement of ``UNet.forward`` -- TEST / BASELINE INFRASTRUCTURE ONLY (see oracle/unet_oracle.py
+for who may import this).
+
+It issues exactly the ATen ops the reference's ``nn.Module`` graph issues (elektronn3/models/unet.py:244-253,
+384-408, 894-916): ``conv3d -> batch_norm -> relu -> conv3d -> batch_norm -> relu -> max_pool3d(ceil_mode=True)``
+per encoder block, ``conv_transpose3d -> (autocrop) -> batch_norm -> relu -> cat -> conv3d ...`` per decoder block,
+1x1x1 ``conv3d`` head.  Parameters come from a state_dict with the reference's key names, so the same weights drive
+this, the C oracle and the HIP path.  Used for
+
+* ``bench.py``'s ``cpu_baseline`` leg: "the reference's CPU PyTorch path timed on the host cores" (north_star) --
+  the reference's own Python cannot travel to the GPU box, its ATen call sequence can;
+* full-size parity checks on the GPU box (same ops through PyTorch-ROCm/MIOpen, device='cuda').
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _bn(x, sd, name, training, momentum=0.1, eps=1e-5):
+    return F.batch_norm(x, sd[name + '.running_mean'], sd[name + '.running_var'], sd[name + '.weight'], sd[name + '.bias'],
+                        training=training, momentum=momentum, eps=eps)
+
+
+def _conv(x, sd, name):
+    w = sd[name + '.weight']
+    pad = tuple((k - 1) // 2 for k in w.shape[2:])
+    return F.conv3d(x, w, sd[name + '.bias'], padding=pad)
+
+
+def autocrop(from_down, from_up):
+    """unet.py:256-325 restated for 5D tensors."""
+    if from_down.shape[2:] == from_up.shape[2:]:
+        return from_down, from_up
+    ds, us = from_down.shape[2:], from_up.shape[2:]
+    upcrop = [u - ((u - d) % 2) for d, u in zip(ds, us)]
+    from_up = from_up[:, :, :upcrop[0], :upcrop[1], :upcrop[2]]
+    us = from_up.shape[2:]
+    from_down = from_down[:, :, (ds[0] - us[0]) // 2:(ds[0] + us[0]) // 2, (ds[1] - us[1]) // 2:(ds[1] + us[1]) // 2,
+                          (ds[2] - us[2]) // 2:(ds[2] + us[2]) // 2]
+    return from_down, from_up
+
+
+def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True):
+    """sd: name -> tensor (parameters may require grad; running stats are updated in place when training)."""
+    enc = []
+    for i in range(n_blocks):
+        p = f'down_convs.{i}.'
+        y = F.relu(_bn(_conv(x, sd, p + 'conv1'), sd, p + 'norm0', training))
+        y = F.relu(_bn(_conv(y, sd, p + 'conv2'), sd, p + 'norm1', training))
+        enc.append(y)
+        if i < n_blocks - 1:
+            x = F.max_pool3d(y, kernel_size=(1, 2, 2) if i in planar_blocks else 2, ceil_mode=True)
+        else:
+            x = y
+    for i in range(n_blocks - 1):
+        p = f'up_convs.{i}.'
+        w = sd[p + 'upconv.weight']
+        up = F.conv_transpose3d(x, w, sd[p + 'upconv.bias'], stride=tuple(w.shape[2:]))
+        skip, up = autocrop(enc[-(i + 2)], up)
+        up = F.relu(_bn(up, sd, p + 'norm0', training))
+        y = torch.cat((up, skip), 1)
+        y = F.relu(_bn(_conv(y, sd, p + 'conv1'), sd, p + 'norm1', training))
+        x = F.relu(_bn(_conv(y, sd, p + 'conv2'), sd, p + 'norm2', training))
+    return _conv(x, sd, 'conv_final')
+
+
+def combined_loss(logits, target, class_weights=(0.2653, 0.7347)):
+    """0.5*CrossEntropy(weight) + 0.5*Dice(softmax, weight) -- the example's criterion
+    (examples/train_unet_neurodata.py:294-296; modules/loss.py:19-49,165-189), restated with torch ops."""
+    cw = torch.tensor(class_weights, dtype=logits.dtype, device=logits.device)
+    ce = F.cross_entropy(logits, target, weight=cw)
+    probs = torch.softmax(logits, 1)
+    onehot = torch.zeros_like(probs).scatter_(1, target.unsqueeze(1), 1)
+    dims = (0,) + tuple(range(2, logits.dim()))
+    num = 2 * (probs * onehot).sum(dims)
+    den = (probs + onehot).sum(dims) + 1e-4
+    dice = (cw * (1 - num / den)).mean()
+    return 0.5 * ce + 0.5 * dice
