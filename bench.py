@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: 3D U-Net training step (forward + backward) on synthetic 64x128x128 crops.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (for N > 1 launched by
+``python -m torch.distributed.run --nproc-per-node N``), prints ONE JSON line on rank 0.
+
+Workload = BASELINE.json configs[1]: ``UNet(in=1, out=2, n_blocks=4, start_filts=32, normalization='batch')``, fp32,
+batch 2 per GPU of 1x64x128x128 crops (N > 1: the same per-GPU batch on every rank = weak scaling, gradients
+all-reduced with RCCL on a side stream overlapped with the backward).  A step is forward + loss + backward
+(+ gradient all-reduce); the optimizer is excluded.  Inputs are resident in HBM before the timed region.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel (fp32-MFMA implicit-GEMM conv of the heaviest layer, up_convs.2.conv1 64->32 at full
+                resolution): ALGORITHMIC flops per launch / mean launch time measured with HIP events on the compute
+                stream INSIDE the timed steps (e3_unet_profile_*), against the 157.3 TFLOP/s fp32 matrix peak.
+  cpu_baseline  the reference's ATen op sequence (oracle/torch_ref.py) on the host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CROP = (64, 128, 128)
+BATCH_PER_GPU = 2
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FWD_FLOP_PER_VOXEL = 427.2e3    # SURVEY.md 8d (cfg 2 network)
+FWDBWD_FLOP_PER_VOXEL = 1279.9e3
+
+
+def conv_flops(cin, cout, taps, voxels):
+    return 2.0 * cin * cout * taps * voxels
+
+
+def cpu_baseline(iters=2):
+    """The reference's CPU PyTorch path (same ATen op sequence, oracle/torch_ref.py) timed on this box's host cores."""
+    from oracle.torch_ref import combined_loss, unet_forward
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(0)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=32)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in m.state_dict().items()}
+    x = torch.randn(BATCH_PER_GPU, 1, *CROP)
+    t = torch.randint(0, 2, (BATCH_PER_GPU, *CROP))
+    times = []
+    for i in range(iters + 1):
+        t0 = time.time()
+        out = unet_forward(sd, x, 4, (), training=True)
+        loss = combined_loss(out, t)
+        loss.backward()
+        for v in sd.values():
+            v.grad = None
+        times.append(time.time() - t0)
+    dt = sum(times[1:]) / iters
+    return {'value': x.numel() / dt, 'unit': 'voxels/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'full cfg-2 batch ({BATCH_PER_GPU}x1x{"x".join(map(str, CROP))}) fp32 fwd+bwd, 1 warm-up + {iters} timed iterations '
+                      f'of the reference\'s ATen op sequence (oracle/torch_ref.py) with torch {torch.__version__} on the host CPU',
+            's_per_step': dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-layer', default='up_convs.2.conv1')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm GPU (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from elektronn3_amd.unet import UNet
+    from oracle.torch_ref import combined_loss  # criterion only (stays PyTorch in the product too)
+
+    torch.manual_seed(0)                                   # identical replica on every rank
+    model = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=32, normalization='batch').to(dev).train()
+    sync = None
+    if world > 1:
+        from elektronn3_amd.dataparallel import GradSync
+        sync = GradSync(model)
+    torch.manual_seed(1000 + rank)                         # different synthetic crops per rank
+    x = torch.randn(BATCH_PER_GPU, 1, *CROP, device=dev)
+    tgt = torch.randint(0, 2, (BATCH_PER_GPU, *CROP), device=dev)
+
+    layers = model.conv_layers()
+    names = [l[0] for l in layers]
+    li = names.index(args.profile_layer)
+    _, lcin, lcout, ltaps, llevel = layers[li]
+
+    def step():
+        out = model(x)
+        loss = combined_loss(out, tgt)
+        for p in model.parameters():
+            p.grad = None
+        loss.backward()
+        if sync is not None:
+            sync.wait()
+        return loss
+
+    def timed(nsteps, which):
+        model.profile_select(li, which)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        ms, n = model.profile_read()
+        return dt, ms, n
+
+    for _ in range(args.warmup):
+        step()
+    dt, k_ms, k_n = timed(args.steps, 0)
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = dt / args.steps * 1e3
+    # secondary kernel timings (outside the reported timed region): dgrad and wgrad of the same layer
+    extra = {}
+    for which, tag in ((1, 'dgrad'), (2, 'wgrad')):
+        _, ms, n = timed(2, which)
+        extra[tag] = ms
+
+    if rank == 0:
+        vox_per_step = world * BATCH_PER_GPU * CROP[0] * CROP[1] * CROP[2]
+        lvox = BATCH_PER_GPU * CROP[0] * CROP[1] * CROP[2] // (8 ** llevel)
+        lflops = conv_flops(lcin, lcout, ltaps, lvox)
+        ach = lflops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        res = {
+            'metric': 'voxels/sec (train fwd+bwd) 3D UNet 64x128x128',
+            'value': vox_per_step / (ms_per_step * 1e-3),
+            'unit': 'voxels/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE.json configs[1]: UNet(in=1,out=2,n_blocks=4,start_filts=32,bn) fp32 train fwd+bwd, '
+                                   f'batch {BATCH_PER_GPU}/GPU of 1x64x128x128 random crops, CE+Dice loss, optimizer excluded',
+                       'global_batch': world * BATCH_PER_GPU, 'crop': list(CROP),
+                       'parallelism': f'dp{world}' if world > 1 else 'single',
+                       'step_tflops': FWDBWD_FLOP_PER_VOXEL * vox_per_step / world / (ms_per_step * 1e-3) / 1e12},
+            'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'kernel': f'conv_mfma_kernel fwd of {args.profile_layer} ({lcin}->{lcout}, {ltaps} taps, {lvox} voxels)',
+                         'flops_per_launch': lflops, 'ms_per_launch': k_ms, 'launches_timed': k_n,
+                         'dgrad_ms': extra.get('dgrad'), 'wgrad_ms': extra.get('wgrad'),
+                         'dgrad_tflops': lflops / (extra['dgrad'] * 1e-3) / 1e12 if extra.get('dgrad') else None,
+                         'wgrad_tflops': lflops / (extra['wgrad'] * 1e-3) / 1e12 if extra.get('wgrad') else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res['cpu_baseline'] = cpu_baseline()
+            except Exception as e:  # noqa: BLE001
+                res['cpu_baseline'] = {'value': None, 'unit': 'voxels/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                                       'sample': f'failed: {e}'}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

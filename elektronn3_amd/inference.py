@@ -1,0 +1,408 @@
+"""``Predictor`` / ``tiled_apply`` -- drop-in for ``elektronn3.inference.Predictor`` (elektronn3/inference/inference.py).
+
+Same constructor arguments, option handling, tile order and coordinates, shape padding and return value (a CPU
+tensor) as the reference (inference.py:45-199, 368-687).  What is different is where the data lives:
+
+* the (padded) input volume and the output volume are DEVICE-resident (288 GB of HBM holds cfg 5's 8 GiB volume,
+  its 11 GB zero-padded copy and the 21 GB output at once).  The reference stages every tile through host memory
+  with synchronous H2D/D2H copies per tile (inference.py:189-197) and pads with a float64 ``np.zeros``
+  (inference.py:660); here there is ONE H2D copy of the input and ONE D2H copy of the result.
+* tiles are cut as strided views of the padded device volume; for an :class:`elektronn3_amd.unet.UNet` the model
+  call is the eval-mode native forward (BatchNorm folded into the conv epilogues) with the ``Softmax(1)`` of
+  ``nn.Sequential(model, nn.Softmax(1))`` (inference.py:443-444) fused into the last kernel.
+* tiles are independent (each carries its own halo), so with ``torch.distributed`` initialised the tile list is
+  sharded round-robin over the ranks (``tile_parallel=True``) with no data-path collective; rank 0 collects the
+  disjoint output slabs at the end.
+
+Any other ``nn.Module`` is accepted too and is simply called like the reference calls it.
+"""
+import copy
+import itertools
+import logging
+import os
+import time
+from collections import OrderedDict
+from pathlib import Path
+from typing import Callable, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+logger = logging.getLogger('elektronn3log')
+
+Transform = Callable[[np.ndarray, Optional[np.ndarray]], Tuple[np.ndarray, Optional[np.ndarray]]]
+
+
+def _extend_nc(spatial_slice):
+    return (slice(None), slice(None)) + tuple(spatial_slice)
+
+
+def tile_plan(out_spatial, tile_shape, overlap_shape):
+    """Visiting order and coordinates of the reference's tile loop (inference.py:153-189): C-order product over tile
+    indices; input slab [tile*pos, tile*(pos+1) + 2*overlap) in padded coordinates, output slab [tile*pos, tile*(pos+1))."""
+    tile_shape, overlap_shape = np.asarray(tile_shape), np.asarray(overlap_shape)
+    tiles = np.ceil(np.asarray(out_spatial) / tile_shape).astype(int)
+    plan = []
+    for pos in itertools.product(*[range(int(t)) for t in tiles]):
+        pos = np.array(pos)
+        lo, hi = tile_shape * pos, tile_shape * (pos + 1)
+        plan.append((tuple(int(v) for v in lo), tuple(int(v) for v in hi + 2 * overlap_shape),
+                     tuple(int(v) for v in lo), tuple(int(v) for v in hi)))
+    return plan
+
+
+def tiled_apply(func, inp, tile_shape, overlap_shape, offset, out_shape, verbose=False, device=None,
+                tile_indices=None, out=None):
+    """Splits ``inp`` into overlapping tiles, applies ``func(tile, crop_slice)`` to each and assembles the central
+    regions (inference.py:45-199).  ``inp`` may live on any device; padded input and output are allocated on
+    ``device`` (default: ``inp``'s device).  ``tile_indices`` restricts the loop to a subset (tile-parallel ranks)."""
+    if not (inp.dim() - 2 == len(tile_shape) == len(overlap_shape)):
+        raise ValueError(f'ndims of tile shape ({len(tile_shape)}) and overlap shape ({len(overlap_shape)}) don\'t match input '
+                         f'shape ndim - 2({inp.dim() - 2}).')
+    if not np.all(np.mod(out_shape[2:], tile_shape) == 0):
+        raise ValueError(f'spatial out shape[2:] {tuple(out_shape[2:])} has to be divisible by tile_shape {tile_shape}.')
+    device = torch.device(device) if device is not None else inp.device
+    if offset is not None:
+        offset = np.array(offset)
+    inp_shape = np.array(inp.shape)
+    out_shape = np.array(out_shape)
+    tile_shape = np.array(tile_shape)
+    overlap_shape = np.array(overlap_shape)
+    final_crop_slice = None
+    if not np.array_equal(out_shape[2:], inp_shape[2:]):   # input is already padded (valid-conv networks)
+        inp_padded = inp.to(device)
+    else:
+        padded_shape = inp_shape + np.array((0, 0, *overlap_shape * 2))
+        logger.info(f'additional input padding to {padded_shape}')
+        inp_padded = torch.zeros(tuple(int(v) for v in padded_shape), dtype=inp.dtype, device=device)
+        inp_padded[_extend_nc([slice(int(l), int(h)) for l, h in zip(overlap_shape, padded_shape[2:] - overlap_shape)])] = \
+            inp.to(device, non_blocking=True)
+        final_crop_slice = _extend_nc([slice(int(l), int(h)) for l, h in zip(overlap_shape, tile_shape + overlap_shape)])
+    if offset is not None:   # no cropping necessary for valid conv
+        final_crop_slice = None
+    del inp
+    plan = tile_plan(out_shape[2:], tile_shape, overlap_shape)
+    it = range(len(plan)) if tile_indices is None else tile_indices
+    if verbose:
+        try:
+            from tqdm import tqdm
+            it = tqdm(it, 'Predicting', total=len(plan) if tile_indices is None else len(tile_indices), dynamic_ncols=True)
+        except ImportError:
+            pass
+    for ti in it:
+        ilo, ihi, olo, ohi = plan[ti]
+        assert all(h <= s for h, s in zip(ihi, inp_padded.shape[2:])), ihi
+        inp_tile = inp_padded[_extend_nc([slice(l, h) for l, h in zip(ilo, ihi)])].contiguous()
+        out_tile = func(inp_tile, final_crop_slice)
+        if out is None:
+            out = torch.zeros([int(v) for v in out_shape], dtype=out_tile.dtype, device=device)
+        out[_extend_nc([slice(l, h) for l, h in zip(olo, ohi)])] = out_tile
+    if out is None:
+        out = torch.zeros([int(v) for v in out_shape], dtype=inp_padded.dtype, device=device)
+    return out
+
+
+class Argmax(nn.Module):
+    def __init__(self, dim=1, unsqueeze=True):
+        super().__init__()
+        self.dim, self.unsqueeze = dim, unsqueeze
+
+    def forward(self, x):
+        a = torch.argmax(x, self.dim)
+        return a.unsqueeze(1) if self.unsqueeze else a
+
+
+class FlipAugment:
+    def __init__(self, dims):
+        self.dims = tuple(int(d) + 2 for d in dims)   # skip (N, C)
+
+    def forward(self, inp):
+        return torch.flip(inp, dims=self.dims)
+
+    def backward(self, inp):
+        return self.forward(inp)
+
+
+DEFAULT_AUGMENTATIONS_3D = [FlipAugment(d) for d in [(0,), (1,), (0, 1), (2,), (0, 2), (1, 2), (0, 1, 2)]]
+DEFAULT_AUGMENTATIONS_2D = DEFAULT_AUGMENTATIONS_3D[:3]
+
+
+def calculate_offset(model, tile_shape=None):
+    """Half the spatial shape difference between a model's input and output (elektronn3/data/utils.py:63-78)."""
+    with torch.no_grad():
+        param = next(model.parameters())
+        shapes = [tuple(tile_shape)] if tile_shape else [(90, 90, 90), (186, 186)]
+        last = None
+        for sh in shapes:
+            try:
+                ex = torch.randn(1, param.size()[1], *sh, device=param.device, dtype=param.dtype)
+                out = model.eval().forward(ex)
+                return np.subtract(ex.shape[2:], out.shape[2:]) // 2
+            except RuntimeError as e:
+                last = e
+        raise last
+
+
+def set_state_dict(model, state_dict):
+    """Also accepts state dicts saved from ``nn.DataParallel`` wrappers (inference.py:698-710)."""
+    try:
+        model.load_state_dict(state_dict)
+    except RuntimeError:
+        model.load_state_dict(OrderedDict((k.replace('module.', ''), v) for k, v in state_dict.items()))
+
+
+class Predictor:
+    """Tiled sliding-window inference with the reference's interface (inference.py:368-388)."""
+
+    def __init__(
+            self,
+            model: Union[nn.Module, str, Path],
+            state_dict_src: Optional[Union[str, dict]] = None,
+            device: Optional[Union[torch.device, str]] = None,
+            batch_size: Optional[int] = None,
+            tile_shape: Optional[Tuple[int, ...]] = None,
+            overlap_shape: Optional[Tuple[int, ...]] = None,
+            offset: Optional[Tuple[int, ...]] = None,
+            out_shape: Optional[Tuple[int, ...]] = None,
+            out_dtype: Optional[torch.dtype] = None,
+            float16: bool = False,
+            apply_softmax: bool = True,
+            transform: Optional[Transform] = None,
+            augmentations: Union[int, Optional[Sequence]] = None,
+            strict_shapes: bool = False,
+            apply_argmax: bool = False,
+            argmax_with_threshold: Optional[float] = None,
+            verbose: bool = False,
+            report_inp_stats: bool = False,
+            tile_parallel: bool = False,
+    ):
+        from .unet import UNet
+        if device is None:
+            device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+        elif isinstance(device, str):
+            device = torch.device(device)
+        self.device = device
+        self.batch_size = batch_size
+        self.out_dtype = out_dtype
+        self.float16 = float16
+        if isinstance(model, Path):
+            model = str(model)
+        if float16 and not isinstance(model, str) and not next(model.parameters()).dtype == torch.float16:
+            model = copy.deepcopy(model)   # casting is in-place; keep the caller's fp32 model intact (inference.py:402-407)
+        self.dtype = torch.float16 if float16 else torch.float32
+        self.transform = transform
+        if isinstance(augmentations, int):
+            augmentations = DEFAULT_AUGMENTATIONS_3D[:augmentations]
+        self.augmentations = augmentations
+        self.strict_shapes = strict_shapes
+        self.apply_argmax = apply_argmax
+        self.argmax_with_threshold = argmax_with_threshold
+        self.verbose = verbose
+        self.report_inp_stats = report_inp_stats
+        self.tile_parallel = tile_parallel
+        if isinstance(model, str):
+            if os.path.isfile(model):
+                if model.endswith('.pts'):
+                    model = torch.jit.load(model, map_location=device)
+                elif model.endswith('.pt'):
+                    model = torch.load(model, map_location=device, weights_only=False)
+                else:
+                    raise ValueError(f'{model} has an unkown file extension. Supported are .pt and .pts')
+            else:
+                raise ValueError(f'Model path {model} not found.')
+        self.model = model
+        if isinstance(state_dict_src, str):
+            state_dict = torch.load(state_dict_src)
+            if 'model_state_dict' in state_dict:
+                state_dict = state_dict['model_state_dict']
+        elif isinstance(state_dict_src, dict) or state_dict_src is None:
+            state_dict = state_dict_src
+        else:
+            raise ValueError('"state_dict_src" has to be either a path to a .pth file (str), a state_dict object (dict) or None.')
+        if state_dict is not None:
+            set_state_dict(model, state_dict)
+        if not apply_softmax and augmentations is not None:
+            raise ValueError('When augmentations are enabled, apply_softmax cannot be False.')
+        self._native = isinstance(model, UNet)          # HIP fast path: softmax fused into the network's last kernel
+        self._softmax = bool(apply_softmax or augmentations is not None)
+        if self._softmax and not self._native:
+            self.model = nn.Sequential(self.model, nn.Softmax(1))
+        if float16:
+            self.model.half()
+        self.apply_argmax_after_tta = False
+        self._post = None
+        if apply_argmax or argmax_with_threshold is not None:
+            self.apply_argmax_after_tta = augmentations is not None
+            if not self.apply_argmax_after_tta:
+                layers = [Argmax(dim=1, unsqueeze=True)]
+                if argmax_with_threshold:
+                    layers = [nn.Threshold(argmax_with_threshold, 0)] + layers
+                if self._native:
+                    self._post = nn.Sequential(*layers)
+                else:
+                    self.model = nn.Sequential(self.model, *layers)
+            if self.out_dtype is None:
+                self.out_dtype = torch.uint8
+        self._warn_about_shapes = True
+        # Side effect kept from the reference (inference.py:458): the caller's module is switched to eval mode.
+        self.model.eval()
+        if isinstance(self.model, nn.Module) and device.type == 'cuda':
+            self.model.to(device)
+
+        def is_set(array):
+            return array is not None and np.any(array)
+
+        if is_set(overlap_shape) and is_set(offset):
+            raise ValueError(f'overlap_shape={overlap_shape} and offet={offset} are both specified, but this is not supported.\n'
+                             'Either specify overlap_shape (if the spatial shape of inputs and outputs are the same)\n'
+                             'or offset (if the output is smaller).')
+        if not is_set(tile_shape):
+            assert not (is_set(out_shape) or is_set(overlap_shape) or is_set(offset)), \
+                'If tile_shape is not set, out_shape, overlap_shape and offset should not be set either.'
+            self.enable_tiling = False
+        else:
+            assert is_set(out_shape), 'If tile_shape is set, out_shape is required to be set, too.'
+            self.enable_tiling = True
+            if offset is None:
+                if self._native:
+                    offset = np.zeros(len(tile_shape), dtype=np.int64)   # 'same' convolutions only: known without a probe forward
+                else:
+                    logger.warning('Predictor: offset=None -> Estimating offset from forward pass.')
+                    offset = calculate_offset(self.model)
+            if np.count_nonzero(offset) == 0:
+                offset = None
+            else:
+                offset = np.array(offset)
+                overlap_shape = offset
+                out_shape = np.array([*out_shape[:-len(offset)], *(out_shape[-len(offset):] - 2 * offset)])
+                logger.info(f'Adjusted out_shape: {out_shape}')
+        self.offset = offset
+        self.overlap_shape = np.array(overlap_shape) if overlap_shape is not None else None
+        self.tile_shape = np.array(tile_shape) if tile_shape is not None else None
+        self.out_shape = np.array(out_shape) if out_shape is not None else None
+
+    # ------------------------------------------------------------------ per-tile model call (inference.py:496-525)
+    def _call_model(self, dinp):
+        if self._native:
+            y = self.model.forward_softmax(dinp) if self._softmax else self.model(dinp)
+            return self._post(y) if self._post is not None else y
+        return self.model(dinp)
+
+    @torch.no_grad()
+    def _predict(self, dinp, crop_slice=None):
+        dinp = dinp.to(self.device, dtype=self.dtype)
+        dout = self._call_model(dinp)
+        if crop_slice is not None:
+            dout = dout[crop_slice]
+        if self.augmentations is not None:
+            douts = [dout]
+            for aug in self.augmentations:
+                dout_aug = aug.backward(self._call_model(aug.forward(dinp)))
+                if crop_slice:
+                    dout_aug = dout_aug[crop_slice]
+                douts.append(dout_aug)
+            dout = torch.mean(torch.stack(douts), dim=0)
+        if self.apply_argmax_after_tta:
+            if self.argmax_with_threshold:
+                dout[dout <= self.argmax_with_threshold] = 0
+            dout = dout.argmax(dim=1).to(self.out_dtype)
+        return dout.to(self.out_dtype)
+
+    def _tiled_predict(self, inp, out_shape=None):
+        if not self.enable_tiling:
+            return self._predict(inp)
+        if self.out_shape is None:
+            raise ValueError('If you use tiling, you also need to supply out_shape.')
+        out_shape = (inp.shape[0], *out_shape)
+        tile_indices, world, rank = None, 1, 0
+        if self.tile_parallel and torch.distributed.is_available() and torch.distributed.is_initialized():
+            world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
+            ntiles = int(np.prod(np.ceil(np.asarray(out_shape[2:]) / self.tile_shape)))
+            tile_indices = list(range(rank, ntiles, world))     # static round-robin shard: independent units, no exchange
+        out = tiled_apply(self._predict, inp=inp, tile_shape=self.tile_shape, overlap_shape=self.overlap_shape,
+                          offset=self.offset, out_shape=out_shape, verbose=self.verbose, device=self.device,
+                          tile_indices=tile_indices)
+        if world > 1:   # rank 0 collects the disjoint slabs (zeros elsewhere => a sum assembles them exactly)
+            red = out if out.dtype in (torch.float32, torch.float16, torch.int32, torch.int64) else out.to(torch.int32)
+            torch.distributed.reduce(red, dst=0, op=torch.distributed.ReduceOp.SUM)
+            out = red.to(out.dtype)
+        return out
+
+    def _splitbatch_predict(self, inp, num_batches, out_shape=None):
+        if self.out_shape is None:
+            raise ValueError('If you define a batch_size, you also need to supply out_shape.')
+        outs = []
+        for k in range(num_batches):
+            outs.append(self._tiled_predict(inp[self.batch_size * k:self.batch_size * (k + 1)], out_shape=out_shape))
+        return torch.cat(outs, 0)
+
+    # ------------------------------------------------------------------ public API (inference.py:569-642)
+    def predict(self, inp):
+        if self.transform is not None:
+            if isinstance(inp, torch.Tensor):
+                inp = inp.numpy()
+            transformed = np.empty_like(inp)
+            for i in range(inp.shape[0]):
+                transformed[i], _ = self.transform(inp[i], None)
+            inp = transformed
+        if self.verbose:
+            start = time.time()
+        inp = torch.as_tensor(inp)
+        if self.enable_tiling:
+            inp, out_shape, relevant_slice = self._ensure_matching_shapes(inp)
+        else:
+            relevant_slice, out_shape = None, self.out_shape
+            inp = inp.to(self.device, dtype=self.dtype).contiguous()
+        inp_batch_size = inp.shape[0]
+        spatial_shape = np.array(inp.shape[2:])
+        if self.out_dtype is None:
+            self.out_dtype = torch.uint8 if self.argmax_with_threshold is not None else inp.dtype
+        if out_shape is not None and out_shape[0] > 255 and self.out_dtype == torch.uint8:
+            raise ValueError(f'C = out_shape[0] = {out_shape[0]}, but out_dtype torch.uint8 can only hold values up to 255.')
+        if self.tile_shape is None:
+            self.tile_shape = spatial_shape
+        if self.overlap_shape is None:
+            self.overlap_shape = np.zeros_like(spatial_shape)
+        if self.batch_size is None:
+            self.batch_size = inp_batch_size
+        num_batches = int(np.ceil(inp_batch_size / self.batch_size))
+        if num_batches == 1:
+            out = self._tiled_predict(inp=inp, out_shape=out_shape)
+        else:
+            out = self._splitbatch_predict(inp=inp, num_batches=num_batches, out_shape=out_shape)
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize(self.device)
+        out = out.cpu() if relevant_slice is None else out[relevant_slice].cpu()
+        if self.verbose:
+            dtime = time.time() - start
+            amount = out.numel()
+            if out_shape is not None and np.array_equal(out_shape[2:], inp.shape[2:]):
+                amount = np.prod([*out.shape[:-3], *(out.shape[-3:] - 2 * self.overlap_shape)])
+            print(f'Inference speed: {amount / dtime / 1e6:.2f} MVox/s, time: {dtime:.2f}.')
+        return out
+
+    def _ensure_matching_shapes(self, inp):
+        """Pads the input (with zeros, on the device, in the compute dtype) so that out_shape becomes a multiple of
+        tile_shape, and returns the slice that undoes it (inference.py:645-687)."""
+        inp = inp.to(self.device, dtype=self.dtype)
+        if self.out_shape is not None and np.any(self.out_shape[1:] % self.tile_shape):
+            if self.strict_shapes:
+                raise ValueError('Make sure that out_shape is divisible by tile_shape or relax this constraint by setting '
+                                 'strict_shapes=False.')
+            padded_out_shape = np.array(self.out_shape)
+            padded_out_shape[1:] = np.ceil(self.out_shape[1:] / self.tile_shape) * self.tile_shape
+            offset = np.zeros(len(padded_out_shape) - 1, dtype=np.int64) if self.offset is None else np.array(self.offset)
+            padded_inp = torch.zeros((*inp.shape[:2], *(int(v) for v in padded_out_shape[1:] + 2 * offset)), dtype=self.dtype, device=self.device)
+            padded_inp[_extend_nc([slice(0, d) for d in inp.shape[2:]])] = inp
+            relevant_slice_out = _extend_nc([slice(0, int(d)) for d in self.out_shape[1:]])
+            if self._warn_about_shapes and np.any(padded_out_shape != self.out_shape):
+                logger.info(f'Adapting out_shape {tuple(self.out_shape[1:])} to tile_shape {tuple(self.tile_shape)} by padding '
+                            f'out_shape to {tuple(padded_out_shape[1:])}.\nSuboptimal shapes will reduce execution speed.')
+                self._warn_about_shapes = False
+            return padded_inp, padded_out_shape, relevant_slice_out
+        return inp.contiguous(), self.out_shape, None
+
+    def predict_proba(self, inp):
+        logger.warning('Predictor.predict_proba(inp) is deprecated. Please use Predictor.predict(inp) instead.')
+        return self.predict(inp)

@@ -320,6 +320,13 @@ class UNet(nn.Module):
             if m.bias is not None:
                 nn.init.constant_(m.bias, 0)
 
+    def __getstate__(self):
+        # torch.save(model) / copy.deepcopy(model) (trainer.py:874, inference.py:402-407): never pickle runtime
+        # attachments (streams, events, process groups of a GradSync)
+        state = self.__dict__.copy()
+        state.pop('_grad_sync', None)
+        return state
+
     # ------------------------------------------------------------------ native plumbing
     def _plan_key(self):
         mask = 0

@@ -1,0 +1,83 @@
+"""Data-parallel path on CPU with gloo, world_size 2 (the 8-GPU run is the driver's): bucketed all-reduce of the flat
+gradient buffer (GradSync), batch sharding, tile-parallel Predictor sharding."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tmp):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from elektronn3_amd.dataparallel import GradSync, shard_batch
+        from elektronn3_amd.unet import UNet
+        torch.manual_seed(0)
+        model = UNet(1, 2, n_blocks=3, start_filts=8)          # CPU: parameters only, no forward
+        sync = GradSync(model, bucket_after_down_block=2)
+        plan = model._plan()
+        tens = [model.get_parameter(n) if k == 0 else model.get_buffer(n) for n, k in zip(plan.names, plan.kinds)]
+        flat, views = sync.flat_views(plan, tens)
+        # table order puts the first two encoder blocks in a prefix = bucket B
+        n_prefix = sum(p.numel() for n, p in model.named_parameters() if n.startswith(('down_convs.0.', 'down_convs.1.')))
+        assert sync._split == n_prefix and 0 < sync._split < flat.numel()
+        assert sum(v.numel() for v in views if v is not None) == sum(p.numel() for p in model.parameters()) == flat.numel()
+        # rank-dependent "gradients"
+        g = torch.Generator().manual_seed(100 + rank)
+        local = torch.randn(flat.numel(), generator=g)
+        flat.copy_(local)
+        assert sync.bucket_event() is None                    # CPU: no HIP event
+        sync.after_backward(plan)
+        # expected: mean over ranks
+        exp = sum(torch.randn(flat.numel(), generator=torch.Generator().manual_seed(100 + r)) for r in range(world)) / world
+        assert torch.allclose(flat, exp, atol=1e-6)
+        # views alias the flat buffer
+        k = next(i for i, v in enumerate(views) if v is not None)
+        views[k].zero_()
+        assert float(flat[:views[k].numel()].abs().sum()) == 0.0
+        # batch sharding
+        batch = torch.arange(8).view(8, 1)
+        assert shard_batch(batch, rank, world).flatten().tolist() == list(range(rank * 4, rank * 4 + 4))
+        # parameter broadcast makes replicas identical
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(rank)
+        sync.broadcast_parameters(0)
+        ref = UNet(1, 2, n_blocks=3, start_filts=8)
+        torch.manual_seed(0)
+        ref = UNet(1, 2, n_blocks=3, start_filts=8)
+        for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            assert torch.equal(p, q), n
+        # tile-parallel Predictor: generic module on CPU, tiles sharded round-robin, rank 0 assembles
+        from elektronn3_amd.inference import Predictor
+        conv = torch.nn.Conv3d(1, 2, 3, padding=1)
+        torch.manual_seed(5)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn_like(conv.weight)); conv.bias.copy_(torch.randn_like(conv.bias))
+        vol = torch.randn(1, 1, 8, 16, 16, generator=torch.Generator().manual_seed(9))
+        kw = dict(device='cpu', tile_shape=(4, 8, 8), overlap_shape=(2, 2, 2), offset=(0, 0, 0), out_shape=(2, 8, 16, 16), apply_softmax=True)
+        y_par = Predictor(conv, tile_parallel=True, **kw).predict(vol)
+        y_one = Predictor(conv, tile_parallel=False, **kw).predict(vol)
+        if rank == 0:
+            assert torch.allclose(y_par, y_one, atol=1e-6)
+        open(os.path.join(tmp, f'ok{rank}'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradsync_and_tile_parallel_gloo_world2(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f'ok{r}').exists() for r in range(world))

@@ -1,0 +1,155 @@
+"""Predictor / tiled_apply host logic.
+
+CPU (not gpu): the tiling, padding, cropping, batching and option handling of elektronn3_amd.inference.Predictor,
+driven with a plain torch module built from the oracle's functional network (tests may use the oracle), must
+reproduce the reference's Predictor outputs stored in tests/golden/predictor.npz.
+
+GPU: the same fixtures through the native HIP UNet (eval-mode BN folded, softmax fused into the last kernel).
+"""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from helpers import load_npz, sub
+
+
+class RefModule(nn.Module):
+    """nn.Module around oracle/torch_ref.unet_forward (generic-module path of the Predictor)."""
+
+    def __init__(self, sd, n_blocks):
+        super().__init__()
+        self.sd = nn.ParameterDict()
+        self._names = {}
+        for k, v in sd.items():
+            key = k.replace('.', '__')
+            self._names[k] = key
+            t = torch.from_numpy(np.array(v))
+            if t.is_floating_point():
+                self.sd[key] = nn.Parameter(t, requires_grad=False)
+        self.n_blocks = n_blocks
+
+    def forward(self, x):
+        from oracle.torch_ref import unet_forward
+        sd = {k: self.sd[key] for k, key in self._names.items() if key in self.sd}
+        return unet_forward(sd, x, self.n_blocks, (), training=self.training)
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return load_npz('predictor.npz')
+
+
+def test_tile_plan_matches_reference_order(gold):
+    from elektronn3_amd.inference import tile_plan
+    plan = tile_plan((24, 48, 48), gold['tile'], gold['overlap'])
+    assert len(plan) == 27
+    assert plan[0] == ((0, 0, 0), (16, 32, 32), (0, 0, 0), (8, 16, 16))
+    assert plan[1][0] == (0, 0, 16) and plan[3][0] == (0, 16, 0) and plan[9][0] == (8, 0, 0)   # C-order, W fastest
+
+
+def test_predictor_cpu_generic_module_matches_reference(gold):
+    from elektronn3_amd.inference import Predictor
+    model = RefModule(sub(gold, 'sd'), 2)
+    pred = Predictor(model, device='cpu', tile_shape=tuple(gold['tile']), overlap_shape=tuple(gold['overlap']), offset=(0, 0, 0),
+                     out_shape=tuple(gold['out_shape']), apply_softmax=True, strict_shapes=False)
+    y = pred.predict(gold['vol'])
+    assert not y.is_cuda and tuple(y.shape) == gold['out_tiled'].shape
+    np.testing.assert_allclose(y.numpy(), gold['out_tiled'], rtol=1e-4, atol=1e-5)
+    assert not model.training            # side effect of the reference kept: the caller's module is put in eval mode
+    # untiled
+    y2 = Predictor(model, device='cpu', apply_softmax=True).predict(torch.from_numpy(gold['vol']))
+    np.testing.assert_allclose(y2.numpy(), gold['out_untiled'], rtol=1e-4, atol=1e-5)
+    # argmax + batch splitting
+    pred3 = Predictor(model, device='cpu', tile_shape=tuple(gold['tile']), overlap_shape=tuple(gold['overlap']), offset=(0, 0, 0),
+                      out_shape=(2, 16, 32, 32), apply_softmax=True, apply_argmax=True, batch_size=1)
+    y3 = pred3.predict(gold['vol3'])
+    assert y3.dtype == torch.uint8 and tuple(y3.shape) == gold['out3_argmax'].shape
+    assert (y3.numpy() != gold['out3_argmax']).mean() < 1e-4
+
+
+def test_predictor_argument_validation(gold):
+    from elektronn3_amd.inference import Predictor, tiled_apply
+    model = RefModule(sub(gold, 'sd'), 2)
+    with pytest.raises(ValueError):
+        Predictor(model, device='cpu', tile_shape=(8, 16, 16), overlap_shape=(4, 8, 8), offset=(1, 1, 1), out_shape=(2, 16, 32, 32))
+    with pytest.raises(ValueError):
+        Predictor(model, device='cpu', apply_softmax=False, augmentations=3)
+    with pytest.raises(ValueError):   # strict shapes: non-divisible out_shape
+        Predictor(model, device='cpu', tile_shape=(8, 16, 16), overlap_shape=(4, 8, 8), offset=(0, 0, 0), out_shape=(2, 20, 40, 36),
+                  strict_shapes=True).predict(gold['vol'])
+    with pytest.raises(ValueError):
+        tiled_apply(lambda t, c: t, torch.zeros(1, 1, 8, 8, 8), (3, 3, 3), (1, 1, 1), None, (1, 1, 8, 8, 8))
+    with pytest.raises(ValueError):
+        tiled_apply(lambda t, c: t, torch.zeros(1, 1, 8, 8, 8), (4, 4), (1, 1), None, (1, 1, 8, 8, 8))
+
+
+def test_predictor_tta_cpu(gold):
+    """Flip test-time augmentation (inference.py:507-517): mean over identity + flips equals a manual computation."""
+    from elektronn3_amd.inference import Predictor
+    model = RefModule(sub(gold, 'sd'), 2).eval()
+    x = torch.from_numpy(gold['vol3'][:1, :, :8, :16, :16].copy())
+    y = Predictor(model, device='cpu', apply_softmax=True, augmentations=2).predict(x)
+    with torch.no_grad():
+        f = lambda t: torch.softmax(model(t), 1)
+        manual = (f(x) + torch.flip(f(torch.flip(x, (2,))), (2,)) + torch.flip(f(torch.flip(x, (3,))), (3,))) / 3
+    np.testing.assert_allclose(y.numpy(), manual.numpy(), rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------- GPU
+def native_model(gold):
+    from elektronn3_amd.unet import UNet
+    m = UNet(1, 2, n_blocks=2, start_filts=8)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sub(gold, 'sd').items()})
+    return m.cuda()
+
+
+@pytest.mark.gpu
+def test_predictor_native_matches_reference(gold):
+    from elektronn3_amd.inference import Predictor
+    m = native_model(gold)
+    pred = Predictor(m, device='cuda', tile_shape=tuple(gold['tile']), overlap_shape=tuple(gold['overlap']), offset=None,
+                     out_shape=tuple(gold['out_shape']), apply_softmax=True, strict_shapes=False)
+    y = pred.predict(gold['vol'])
+    assert not y.is_cuda and tuple(y.shape) == gold['out_tiled'].shape
+    np.testing.assert_allclose(y.numpy(), gold['out_tiled'], rtol=1e-4, atol=1e-5)
+    y2 = Predictor(m, device='cuda', apply_softmax=True).predict(gold['vol'])
+    np.testing.assert_allclose(y2.numpy(), gold['out_untiled'], rtol=1e-4, atol=1e-5)
+    pred3 = Predictor(m, device='cuda', tile_shape=tuple(gold['tile']), overlap_shape=tuple(gold['overlap']), offset=(0, 0, 0),
+                      out_shape=(2, 16, 32, 32), apply_softmax=True, apply_argmax=True)
+    y3 = pred3.predict(gold['vol3'])
+    assert y3.dtype == torch.uint8 and (y3.numpy() != gold['out3_argmax']).mean() < 1e-4
+    # logits path (no softmax) + float16 option (computed in fp32, cast on output)
+    y4 = Predictor(m, device='cuda', apply_softmax=False).predict(gold['vol'])
+    y5 = Predictor(m, device='cuda', apply_softmax=True, float16=True).predict(gold['vol'])
+    assert y5.dtype == torch.float16
+    np.testing.assert_allclose(torch.softmax(y4, 1).numpy(), gold['out_untiled'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(y5.float().numpy(), gold['out_untiled'], rtol=2e-2, atol=2e-3)
+    assert next(m.parameters()).dtype == torch.float32    # float16=True deep-copies, the caller's model is untouched
+
+
+@pytest.mark.gpu
+def test_predictor_native_tta_and_cfg5_shaped_tiling(gold):
+    """cfg-5-shaped run at reduced size: tile 96x192x192 / overlap 16 geometry scaled down (non-divisible volume, halo
+    tiles), plus size-independent properties: the tiled result equals running each tile by hand, and the prediction
+    of an all-zero padded region is finite."""
+    from elektronn3_amd.inference import Predictor, tile_plan
+    m = native_model(gold).eval()
+    vol = torch.randn(1, 1, 40, 72, 88)
+    tile, ov = (24, 32, 32), (8, 8, 8)
+    pred = Predictor(m, device='cuda', tile_shape=tile, overlap_shape=ov, offset=None, out_shape=(2, 40, 72, 88), apply_softmax=True)
+    y = pred.predict(vol)
+    assert tuple(y.shape) == (1, 2, 40, 72, 88) and torch.isfinite(y).all()
+    # hand-rolled tiles
+    padded_out = (48, 96, 96)
+    padded = torch.zeros(1, 1, *(p + 2 * o for p, o in zip(padded_out, ov)))
+    padded[:, :, 8:48, 8:80, 8:96] = vol
+    full = torch.zeros(1, 2, *padded_out)
+    with torch.no_grad():
+        for ilo, ihi, olo, ohi in tile_plan(padded_out, tile, ov):
+            t = padded[:, :, ilo[0]:ihi[0], ilo[1]:ihi[1], ilo[2]:ihi[2]].cuda()
+            o = m.forward_softmax(t)[:, :, 8:32, 8:40, 8:40].cpu()
+            full[:, :, olo[0]:ohi[0], olo[1]:ohi[1], olo[2]:ohi[2]] = o
+    assert torch.equal(y, full[:, :, :40, :72, :88])
+    ya = Predictor(m, device='cuda', apply_softmax=True, augmentations=3).predict(vol[:, :, :16, :32, :32])
+    assert torch.allclose(ya.sum(1), torch.ones_like(ya[:, 0]), atol=1e-5)
