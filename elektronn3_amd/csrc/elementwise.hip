@@ -255,25 +255,37 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
     }
 }
 
-// sums part[p][row][c] over p (double accumulate); one thread per (row, c)
+// sums part[p][row][c] over p: one WAVE per channel (lanes stride over the partial rows, butterfly in double)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int parts, int C, float inv_n,
                                        float* dgamma, float* dbeta, float* coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int p = 0; p < parts; ++p) { s1 += part[((size_t)p * 3 + 0) * C + c]; s2 += part[((size_t)p * 3 + 1) * C + c]; }
-    if (dbeta) dbeta[c] = (float)s1;
-    if (dgamma) dgamma[c] = (float)s2;
-    coef[c] = (float)(s1 * inv_n);
-    coef[C + c] = (float)(s2 * inv_n);
+    for (int p = lane; p < parts; p += 64) { s1 += part[((size_t)p * 3 + 0) * C + c]; s2 += part[((size_t)p * 3 + 1) * C + c]; }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) {
+        if (dbeta) dbeta[c] = (float)s1;
+        if (dgamma) dgamma[c] = (float)s2;
+        coef[c] = (float)(s1 * inv_n);
+        coef[C + c] = (float)(s2 * inv_n);
+    }
 }
 
 __global__ void colsum_finalize_kernel(const float* __restrict__ part, int parts, int part_stride, int offset, int C, float* out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= C) return;
     double s = 0.0;
-    for (int p = 0; p < parts; ++p) s += part[(size_t)p * part_stride + offset + c];
-    out[c] = (float)s;
+    for (int p = lane; p < parts; p += 64) s += part[(size_t)p * part_stride + offset + c];
+    s = wave_sum(s);
+    if (lane == 0) out[c] = (float)s;
 }
 
 // ------------------------------------------------------------------ layout helpers (module boundary only)
@@ -371,13 +383,13 @@ int launch_bn_bwd_reduce(BnBwdArgs a, hipStream_t s) { return bn_bwd_launch(a, f
 int launch_bn_bwd_apply(BnBwdArgs a, hipStream_t s) { return bn_bwd_launch(a, true, s); }
 
 int launch_bn_bwd_finalize(const float* part, int parts, int C, float inv_n, float* dgamma, float* dbeta, float* coef, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, part, parts, C, inv_n, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, part, parts, C, inv_n, dgamma, dbeta, coef);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
 
 int launch_colsum_finalize(const float* part, int parts, int part_stride, int offset, int C, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, part, parts, part_stride, offset, C, out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, part, parts, part_stride, offset, C, out);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

@@ -180,24 +180,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_point_kernel(const WgradArgs a, 
 }
 
 // out[(r*C + c)*T + t] = sum_s part[((s*T + t)*RPad + r)*CPad + c]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int splits, int T,
-                                    int RPad, int CPad, int R, int C) {
-    const size_t total = (size_t)T * R * C;
+// block = 32 consecutive outputs (one 128-B row segment of a slab) x 8 groups of splits; fixed summation order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int splits, int T,
+                                                           int RPad, int CPad, int R, int C) {
+    __shared__ double red[8][32];
+    const int ctiles = (C + 31) / 32;
     const size_t slab = (size_t)T * RPad * CPad;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = i % C; size_t rr = i / C; const int r = rr % R; const int t = rr / R;
-        const float* p = part + ((size_t)t * RPad + r) * CPad + c;
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const size_t nrows = (size_t)T * R * ctiles;
+    for (size_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int ct = row % ctiles; size_t rr = row / ctiles; const int r = rr % R; const int t = rr / R;
+        const int c = ct * 32 + lane;
         double s = 0.0;
-        for (int k = 0; k < splits; ++k) s += p[(size_t)k * slab];
-        out[((size_t)r * C + c) * T + t] = (float)s;
+        if (c < C) {
+            const float* p = part + ((size_t)t * RPad + r) * CPad + c;
+            for (int k = grp; k < splits; k += 8) s += p[(size_t)k * slab];
+        }
+        red[grp][lane] = s;
+        __syncthreads();
+        if (grp == 0 && c < C) {
+            double tot = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) tot += red[g][lane];
+            out[((size_t)r * C + c) * T + t] = (float)tot;
+        }
+        __syncthreads();
     }
 }
 
 void wgeo(ConvKind kind, int& TD, int& TH) { if (kind == CONV_K3_PLANAR) { TD = 1; TH = 8; } else if (kind == CONV_K3) { TD = 2; TH = 4; } else { TD = 2; TH = 8; } }
 
 int tiles_per_split(int ntiles, int other) {
-    // aim at ~768 workgroups in total (3 per CU) so that partial slabs stay small
-    int want = 768 / (other > 0 ? other : 1);
+    // Two workgroups fit a CU (LDS), 256 CUs: aim at exactly 512 workgroups in total so the launch is ONE full
+    // residency round (no partially filled tail round) and the partial slabs stay small.
+    int want = 512 / (other > 0 ? other : 1);
     if (want < 1) want = 1;
     return cdiv(ntiles, want);
 }
@@ -207,7 +223,7 @@ int tiles_per_split(int ntiles, int other) {
 int wgrad_splits(ConvKind kind, int N, int D, int H, int W, int Cin, int Cout) {
     int TD, TH; wgeo(kind, TD, TH);
     const int ntiles = N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, 16);
-    const int other = cdiv(Cout, 32) * cdiv(Cin, 32);
+    const int other = cdiv(Cout, 32) * cdiv(Cin, 32) * (kind == CONV_POINT ? 8 : 1);   // POINT: one workgroup per tap too
     return cdiv(ntiles, tiles_per_split(ntiles, other));
 }
 
@@ -217,7 +233,7 @@ int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s) {
     const int tD = cdiv(a.D, TD), tH = cdiv(a.H, TH), tW = cdiv(a.W, 16);
     const int ntiles = a.N * tD * tH * tW;
     const int co_tiles = cdiv(a.Cout, 32), ci_tiles = cdiv(a.Cin, 32);
-    const int tps = tiles_per_split(ntiles, co_tiles * ci_tiles);
+    const int tps = tiles_per_split(ntiles, co_tiles * ci_tiles * (kind == CONV_POINT ? 8 : 1));
     const int splits = cdiv(ntiles, tps);
     E3_REQUIRE(splits == a.splits, E3_ERR_INVALID, "wgrad: splits mismatch");
     if (kind == CONV_POINT) {
@@ -246,8 +262,7 @@ int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s) {
 }
 
 int launch_wgrad_reduce(const float* part, float* out, int splits, int T, int RPad, int CPad, int R, int C, hipStream_t s) {
-    const size_t total = (size_t)T * R * C;
-    size_t g = (total + 255) / 256; if (g > 2048) g = 2048; if (g == 0) g = 1;
+    size_t g = (size_t)T * R * ((C + 31) / 32); if (g > 8192) g = 8192; if (g == 0) g = 1;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, part, out, splits, T, RPad, CPad, R, C);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
