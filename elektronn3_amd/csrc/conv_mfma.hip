@@ -10,7 +10,9 @@
 // A operand:  the brick's input halo ((TD+2)x(TH+2)x(TW+2) voxels x CK channels) is staged ONCE per channel
 //             chunk into LDS (zero padding and the optional BN+ReLU prologue applied on the way); every tap
 //             then reads it at a compile-time LDS offset with ds_read_b128 (4 consecutive channels per lane =
-//             the k-slices of 4 consecutive MFMAs).  Voxel stride CK+4 floats keeps those reads conflict-free.
+//             the k-slices of 4 consecutive MFMAs).  The 16-B chunks of a voxel are XOR-swizzled with the voxel index
+//             so that the 16 voxels a ds_read_b128 lane group touches fall on 16 different 16-B bank slots without
+//             padding: the brick needs 46 KB instead of 57.6 KB and THREE workgroups fit a CU (12 waves).
 // B operand:  packed weights [tap][co][ci] are read straight from global memory (L1/L2 resident: every
 //             workgroup walks the same 27*Cin*Cout*4 B), one float4 per lane per 4 MFMAs, register
 //             double-buffered one tap ahead.  No per-tap barrier: the only barriers bracket the halo staging.
@@ -24,7 +26,9 @@ template <int KD, int KHW, int TD, int TH, int TW, int CK>
 struct Geo {
     static constexpr int PD = KD / 2, PH = KHW / 2;
     static constexpr int LD = TD + 2 * PD, LH = TH + 2 * PH, LW = TW + 2 * PH;
-    static constexpr int VS = CK + 4;                 // LDS floats per voxel (padded)
+    static constexpr int VS = CK;                     // LDS floats per voxel (no padding: 16-B chunks are XOR-swizzled)
+    static constexpr int Q = CK / 4;                  // 16-B chunks per voxel
+    static constexpr int FSH = Q == 4 ? 2 : (Q == 2 ? 3 : 4);   // chunk q of a voxel at halo-W coordinate zw is stored at q ^ ((zw >> FSH) & (Q-1))
     static constexpr int NVOX = LD * LH * LW;
     static constexpr int T = KD * KHW * KHW;
     static constexpr int LDS_BYTES = NVOX * VS * 4;
@@ -33,9 +37,10 @@ struct Geo {
 };
 
 template <int KD, int KHW, int TD, int TH, int TW, int CK, int NT>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_mfma_kernel(const ConvArgs a) {
     using G = Geo<KD, KHW, TD, TH, TW, CK>;
     constexpr int VS = G::VS, LH = G::LH, LW = G::LW, PD = G::PD, PH = G::PH, T = G::T, K8 = CK / 8;
+    static_assert(CK == 8 || CK == 16, "swizzle is derived for CK in {8,16}");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -55,13 +60,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const bool gather = (a.flags & CF_GATHER_UP) != 0;
     const bool scatter = (a.flags & CF_SCATTER_UP) != 0;
 
-    // ---- per-lane LDS base of its two 32-row sub-tiles (rows = voxels)
-    int abase[2];
+    // ---- per-lane LDS byte offsets of its two 32-row sub-tiles (rows = voxels).  The chunk swizzle key depends only on
+    // the voxel's W coordinate inside the halo brick, so for each of the KHW values of kw the (sub-tile, k8) offsets are
+    // lane constants and every tap adds a compile-time immediate: no address arithmetic inside the tap loop.
+    int aoff[KHW][2][K8];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int m = wave * 64 + s * 32 + j;
         const int ww = m & 15, hh = (m >> 4) % TH, dd = (m >> 4) / TH;
-        abase[s] = ((dd * LH + hh) * LW + ww) * VS + 4 * hf;
+        const int vox = (dd * LH + hh) * LW + ww;
+#pragma unroll
+        for (int kw = 0; kw < KHW; ++kw) {
+            const int key = ((ww + kw) >> G::FSH) & (G::Q - 1);
+#pragma unroll
+            for (int k8 = 0; k8 < K8; ++k8) aoff[kw][s][k8] = (vox + kw) * VS + 4 * ((2 * k8 + hf) ^ key);
+        }
     }
 
     f32x16 acc[2][NT];
@@ -107,51 +120,60 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                         for (int e = 0; e < 4; ++e) val[e] = fmaxf(__builtin_fmaf(val[e], sc[e], sh[e]), 0.f);
                     }
                 }
-                *reinterpret_cast<f32x4*>(smem + v * VS + 4 * q) = val;
+                *reinterpret_cast<f32x4*>(smem + v * VS + 4 * (q ^ ((zw >> G::FSH) & (Q - 1)))) = val;
             }
             __syncthreads();
 
-            // ---- walk the taps; B fragments come from global, one tap ahead
+            // ---- walk the taps; B fragments come straight from global memory (L1/L2 resident), prefetched TWO taps
+            // ahead into a 3-deep register ring.  sched_barrier pins each prefetch above the MFMAs it hides behind
+            // (left alone, the scheduler sinks the loads to ~8 MFMAs before their use, which is less than an L2 round
+            // trip when the wave has its SIMD to itself).
             const float* wl = a.wt + ((size_t)g * T * a.NPad + n0 + j) * a.Cin + cb + 4 * hf;
-            f32x4 bcur[NT][K8];
+            f32x4 bq[3][NT][K8];
 #pragma unroll
-            for (int ns = 0; ns < NT; ++ns)
+            for (int pre = 0; pre < 2 && pre < T; ++pre)
 #pragma unroll
-                for (int k8 = 0; k8 < K8; ++k8)
-                    bcur[ns][k8] = *reinterpret_cast<const f32x4*>(wl + (size_t)ns * 32 * a.Cin + k8 * 8);
+                for (int ns = 0; ns < NT; ++ns)
 #pragma unroll
-            for (int tap = 0; tap < T; ++tap) {
-                f32x4 bnx[NT][K8];
-                if (tap + 1 < T) {
-                    const float* wn = wl + (size_t)(tap + 1) * tapstride;
+                    for (int k8 = 0; k8 < K8; ++k8)
+                        bq[pre][ns][k8] = *reinterpret_cast<const f32x4*>(wl + (size_t)pre * tapstride + (size_t)ns * 32 * a.Cin + k8 * 8);
+            // flat software pipeline over steps (tap, k8): A fragments of step i+1 and the B fragments of tap+2 are
+            // requested BEFORE the 8*NT MFMAs of step i; sched_barrier keeps that order in the emitted code.
+            constexpr int S = T * K8;
+            f32x4 av[2][2];
+            {
+                const int tapoff0 = 0;
 #pragma unroll
-                    for (int ns = 0; ns < NT; ++ns)
+                for (int s = 0; s < 2; ++s) av[0][s] = *reinterpret_cast<const f32x4*>(smem + aoff[0][s][0] + tapoff0);
+            }
 #pragma unroll
-                        for (int k8 = 0; k8 < K8; ++k8)
-                            bnx[ns][k8] = *reinterpret_cast<const f32x4*>(wn + (size_t)ns * 32 * a.Cin + k8 * 8);
-                }
-                const int kd = tap / (KHW * KHW), kh = (tap / KHW) % KHW, kw = tap % KHW;
-                const int tapoff = ((kd * LH + kh) * LW + kw) * VS;
-#pragma unroll
-                for (int k8 = 0; k8 < K8; ++k8) {
-                    f32x4 av[2];
+            for (int i = 0; i < S; ++i) {
+                const int tap = i / K8, k8 = i % K8;
+                if (i + 1 < S) {
+                    const int tn = (i + 1) / K8, k8n = (i + 1) % K8;
+                    const int kdn = tn / (KHW * KHW), khn = (tn / KHW) % KHW, kwn = tn % KHW;
+                    const int tapoffn = (kdn * LH + khn) * LW * VS;   // compile-time: folded into the ds_read immediate
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
-                        av[s] = *reinterpret_cast<const f32x4*>(smem + abase[s] + tapoff + k8 * 8);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int ns = 0; ns < NT; ++ns)
-#pragma unroll
-                            for (int s = 0; s < 2; ++s)
-                                acc[s][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][e], bcur[ns][k8][e], acc[s][ns], 0, 0, 0);
+                        av[(i + 1) & 1][s] = *reinterpret_cast<const f32x4*>(smem + aoff[kwn][s][k8n] + tapoffn);
                 }
-                if (tap + 1 < T) {
+                if (k8 == 0 && tap + 2 < T) {
+                    const float* wn = wl + (size_t)(tap + 2) * tapstride;
 #pragma unroll
                     for (int ns = 0; ns < NT; ++ns)
 #pragma unroll
-                        for (int k8 = 0; k8 < K8; ++k8) bcur[ns][k8] = bnx[ns][k8];
+                        for (int kk = 0; kk < K8; ++kk)
+                            bq[(tap + 2) % 3][ns][kk] = *reinterpret_cast<const f32x4*>(wn + (size_t)ns * 32 * a.Cin + kk * 8);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int ns = 0; ns < NT; ++ns)
+#pragma unroll
+                        for (int s = 0; s < 2; ++s)
+                            acc[s][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i & 1][s][e], bq[tap % 3][ns][k8][e], acc[s][ns], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
