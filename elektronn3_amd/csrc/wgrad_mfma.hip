@@ -62,28 +62,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WgradArgs a, i
         int Lt = tile;
         const int tw_ = Lt % tilesW; Lt /= tilesW; const int th_ = Lt % tilesH; Lt /= tilesH; const int td_ = Lt % tilesD; const int nb = Lt / tilesD;
         const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * G::TW;
-        __syncthreads();
-        // stage X halo (8 float4 per voxel) and dY brick
-#pragma unroll 4
-        for (int idx = tid; idx < NV * 8; idx += 256) {
+        // stage X halo (8 float4 per voxel) and dY brick: ALL global loads of the tile are issued back to back into
+        // registers (one HBM/L2 round trip instead of one per unrolled group), then written to LDS after the barrier
+        // that retires the previous tile's reads.
+        constexpr int XI = (NV * 8 + 255) / 256, GI = (MV * 8) / 256;
+        f32x4 xr[XI], gr[GI];
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            const int idx = tid + it * 256;
             const int v = idx >> 3, q = idx & 7;
             const int zw = v % LW, zh = (v / LW) % LH, zd = v / (LW * LH);
             const int gd = d0 + zd - PD, gh = h0 + zh - 1, gw = w0 + zw - 1;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W && ci0 + 4 * q < a.Cin)
-                val = *reinterpret_cast<const f32x4*>(a.x + ((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.x_ldc + ci0 + 4 * q);
-            *reinterpret_cast<f32x4*>(xs + v * 32 + 4 * q) = val;
+            xr[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < NV * 8 && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W && ci0 + 4 * q < a.Cin)
+                xr[it] = *reinterpret_cast<const f32x4*>(a.x + ((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.x_ldc + ci0 + 4 * q);
         }
-#pragma unroll 4
-        for (int idx = tid; idx < MV * 8; idx += 256) {
+#pragma unroll
+        for (int it = 0; it < GI; ++it) {
+            const int idx = tid + it * 256;
             const int v = idx >> 3, q = idx & 7;
             const int ww = v & 15, hh = (v >> 4) % TH, dd = (v >> 4) / TH;
             const int gd = d0 + dd, gh = h0 + hh, gw = w0 + ww;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            gr[it] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (gd < a.D && gh < a.H && gw < a.W && co0 + 4 * q < a.Cout)
-                val = *reinterpret_cast<const f32x4*>(a.dy + ((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.dy_ldc + co0 + 4 * q);
-            *reinterpret_cast<f32x4*>(gs + v * 32 + 4 * q) = val;
+                gr[it] = *reinterpret_cast<const f32x4*>(a.dy + ((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.dy_ldc + co0 + 4 * q);
         }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < NV * 8) *reinterpret_cast<f32x4*>(xs + idx * 4) = xr[it];
+        }
+#pragma unroll
+        for (int it = 0; it < GI; ++it) *reinterpret_cast<f32x4*>(gs + (tid + it * 256) * 4) = gr[it];
         __syncthreads();
         // K loop: MFMA #t consumes voxels (2t, 2t+1): lane half hf takes voxel 2t+hf
 #pragma unroll 1
