@@ -49,13 +49,13 @@ _SIG = {
     'e3_unet_profile_read': (_I, [c_void_p, POINTER(c_double), POINTER(c_int)]),
     # per-op
     'e3_conv3d_workspace_bytes': (c_size_t, [_I, _I, _I]),
-    'e3_conv3d_stats_parts': (_I, [_I, _I, _I, _I, _I, _I]),
+    'e3_conv3d_stats_parts': (_I, [_I, _I, _I, _I, _I, _I, _I]),
     'e3_conv3d_fwd': (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, c_size_t]),
     'e3_conv3d_dgrad': (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, c_size_t]),
     'e3_conv3d_wgrad_workspace_bytes': (c_size_t, [_I, _I, _I, _I, _I, _I, _I]),
     'e3_conv3d_wgrad': (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, c_size_t]),
     'e3_convT_workspace_bytes': (c_size_t, [_I, _I, _I]),
-    'e3_convT_stats_parts': (_I, [_I, _I, _I, _I, _I]),
+    'e3_convT_stats_parts': (_I, [_I, _I, _I, _I, _I, _I, _I]),
     'e3_convT_fwd': (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, c_size_t]),
     'e3_convT_dgrad': (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, c_size_t]),
     'e3_convT_wgrad_workspace_bytes': (c_size_t, [_I, _I, _I, _I, _I, _I, _I]),

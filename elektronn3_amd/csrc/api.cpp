@@ -20,9 +20,9 @@ size_t e3_conv3d_workspace_bytes(int Cin, int Cout, int planar) {
     return align_up((a > b ? a : b) * sizeof(float), 256);
 }
 
-int e3_conv3d_stats_parts(int Cin, int N, int D, int H, int W, int planar) {
+int e3_conv3d_stats_parts(int Cin, int Cout, int N, int D, int H, int W, int planar) {
     if (Cin < 8) return conv_small_stats_parts(N, D, H, W, planar);
-    return conv_stats_parts(kind_of(planar), 0, N, D, H, W, 2);
+    return conv_stats_parts(kind_of(planar), 0, N, D, H, W, 2, Cin, Cout);
 }
 
 int e3_conv3d_fwd(void* stream, const float* x, int x_ldc, int Cin, const float* w, const float* bias,
@@ -100,7 +100,9 @@ size_t e3_convT_workspace_bytes(int Cin, int Cout, int sd) {
     const size_t a = (size_t)pad_cols(T * Cout) * Cin, b = (size_t)T * pad_cols(Cin) * Cout;
     return align_up((a > b ? a : b) * sizeof(float), 256);
 }
-int e3_convT_stats_parts(int N, int D, int H, int W, int sd) { return conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, D, H, W, sd); }
+int e3_convT_stats_parts(int Cin, int Cout, int N, int D, int H, int W, int sd) {
+    return conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, D, H, W, sd, Cin, sd * 4 * Cout);
+}
 
 int e3_convT_fwd(void* stream, const float* x, int x_ldc, int Cin, const float* w, const float* bias, float* y, int y_ldc,
                  int Cout, int N, int D, int H, int W, int sd, int Do, int Ho, int Wo, float* stats,

@@ -4,25 +4,29 @@
 // and, in POINT mode, the GEMM inside `upconv2('transpose')` (nn.ConvTranspose3d k=s=2, unet.py:152-165).
 // The same kernel computes the data gradient (dgrad = conv with flipped, role-swapped weights).
 //
-// GEMM view:  rows  = output voxels (a TDxTHxTW = 256-voxel brick per workgroup, 64 per wave)
-//             cols  = output channels (32*NT per workgroup)
+// GEMM view:  rows  = output voxels, cols = output channels (32*NT per workgroup),
 //             K     = taps x input channels, walked as  [channel chunk CK] x [tap]
 // A operand:  the brick's input halo ((TD+2)x(TH+2)x(TW+2) voxels x CK channels) is staged ONCE per channel
 //             chunk into LDS (zero padding and the optional BN+ReLU prologue applied on the way); every tap
 //             then reads it at a compile-time LDS offset with ds_read_b128 (4 consecutive channels per lane =
-//             the k-slices of 4 consecutive MFMAs).  The 16-B chunks of a voxel are XOR-swizzled with the voxel index
-//             so that the 16 voxels a ds_read_b128 lane group touches fall on 16 different 16-B bank slots without
-//             padding: the brick needs 46 KB instead of 57.6 KB and THREE workgroups fit a CU (12 waves).
+//             the k-slices of 4 consecutive MFMAs).  The 16-B chunks of a voxel are XOR-swizzled with the voxel's W
+//             coordinate so that the 16 voxels a ds_read_b128 lane group touches fall on 16 different 16-B bank slots
+//             without padding: the brick needs 46 KB instead of 57.6 KB and THREE workgroups fit a CU (12 waves).
 // B operand:  packed weights [tap][co][ci] are read straight from global memory (L1/L2 resident: every
-//             workgroup walks the same 27*Cin*Cout*4 B), one float4 per lane per 4 MFMAs, register
-//             double-buffered one tap ahead.  No per-tap barrier: the only barriers bracket the halo staging.
+//             workgroup walks the same 27*Cin*Cout*4 B), one float4 per lane per 4 MFMAs, kept two taps ahead in a
+//             3-deep register ring.  No per-tap barrier: the only barriers bracket the halo staging.
+// Two work decompositions (template KS):
+//   KS = 1  workgroup = 256-voxel brick (2x8x16, planar 1x16x16); each of the 4 waves owns 64 rows, all K.
+//   KS = 4  workgroup =  64-voxel brick (1x4x16); the 4 waves own the SAME 64 rows and split the channel chunks
+//           (intra-workgroup split-K), partial tiles are summed through LDS in a fixed order.  Used for the low-resolution
+//           levels (8x16x16: 4096 voxels) where 256-voxel bricks would leave most of the 256 CUs idle.
 // fp32 MFMA is exact fp32 (an fmaf chain) at 157 TFLOP/s dense; LDS and L1 traffic per MFMA is tiny because a
 // 32x32x2 MFMA takes 64 cycles, so the kernel is matrix-pipe bound, not LDS bound.
 #include "kernels.h"
 
 namespace {
 
-template <int KD, int KHW, int TD, int TH, int TW, int CK>
+template <int KD, int KHW, int TD, int TH, int TW, int CK, int KS>
 struct Geo {
     static constexpr int PD = KD / 2, PH = KHW / 2;
     static constexpr int LD = TD + 2 * PD, LH = TH + 2 * PH, LW = TW + 2 * PH;
@@ -31,21 +35,25 @@ struct Geo {
     static constexpr int FSH = Q == 4 ? 2 : (Q == 2 ? 3 : 4);   // chunk q of a voxel at halo-W coordinate zw is stored at q ^ ((zw >> FSH) & (Q-1))
     static constexpr int NVOX = LD * LH * LW;
     static constexpr int T = KD * KHW * KHW;
-    static constexpr int LDS_BYTES = NVOX * VS * 4;
-    static_assert(TD * TH * TW == 256, "brick must hold 256 voxels (4 waves x 64 rows)");
+    static constexpr int PART = NVOX * VS;            // floats of one staged chunk
+    static constexpr int LDS_FLOATS = PART * KS;
+    static_assert(TD * TH * TW * KS == 256, "brick must hold 256/KS voxels (64 rows per wave)");
     static_assert(TW == 16, "row mapping assumes 16 voxels along W");
 };
 
-template <int KD, int KHW, int TD, int TH, int TW, int CK, int NT>
-__global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_mfma_kernel(const ConvArgs a) {
-    using G = Geo<KD, KHW, TD, TH, TW, CK>;
+template <int KD, int KHW, int TD, int TH, int TW, int CK, int NT, int KS>
+__global__ __launch_bounds__(256, (NT == 2 || KS == 4) ? 2 : 3) void conv_mfma_kernel(const ConvArgs a) {
+    using G = Geo<KD, KHW, TD, TH, TW, CK, KS>;
     constexpr int VS = G::VS, LH = G::LH, LW = G::LW, PD = G::PD, PH = G::PH, T = G::T, K8 = CK / 8;
     static_assert(CK == 8 || CK == 16, "swizzle is derived for CK in {8,16}");
+    static_assert(KS == 1 || KS == 4, "KS in {1,4}");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hf = lane >> 5;
+    const int rowbase = KS == 1 ? wave * 64 : 0;      // first GEMM row (voxel of the brick) this wave owns
+    float* lds = smem + (KS == 1 ? 0 : wave * G::PART);   // this wave's staged chunk
 
     // ---- which brick / column tile (XCD-aware: neighbours in (ntile, w, h, d) order share an L2)
     const unsigned nblk = gridDim.x;
@@ -60,13 +68,13 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_mfma_kernel(const C
     const bool gather = (a.flags & CF_GATHER_UP) != 0;
     const bool scatter = (a.flags & CF_SCATTER_UP) != 0;
 
-    // ---- per-lane LDS byte offsets of its two 32-row sub-tiles (rows = voxels).  The chunk swizzle key depends only on
+    // ---- per-lane LDS offsets of its two 32-row sub-tiles (rows = voxels).  The chunk swizzle key depends only on
     // the voxel's W coordinate inside the halo brick, so for each of the KHW values of kw the (sub-tile, k8) offsets are
     // lane constants and every tap adds a compile-time immediate: no address arithmetic inside the tap loop.
     int aoff[KHW][2][K8];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const int m = wave * 64 + s * 32 + j;
+        const int m = rowbase + s * 32 + j;
         const int ww = m & 15, hh = (m >> 4) % TH, dd = (m >> 4) / TH;
         const int vox = (dd * LH + hh) * LW + ww;
 #pragma unroll
@@ -91,17 +99,20 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_mfma_kernel(const C
     for (int g = 0; g < a.G; ++g) {
         int gtd = 0, gth = 0, gtw = 0;
         if (gather) { gtw = g & 1; gth = (g >> 1) & 1; gtd = g >> 2; }
-        for (int cb = 0; cb < a.Cin; cb += CK) {
+        for (int cb0 = 0; cb0 < a.Cin; cb0 += CK * KS) {
             __syncthreads();
-            // ---- stage the halo brick of channels [cb, cb+CK) into LDS
+            // ---- stage the halo brick(s): KS consecutive channel chunks, one per wave when KS == 4
             constexpr int Q = CK / 4;
-            constexpr int ITEMS = G::NVOX * Q;
+            constexpr int ITEMS = G::NVOX * Q * KS;
 #pragma unroll 4
             for (int idx = tid; idx < ITEMS; idx += 256) {
-                const int v = idx / Q, q = idx % Q;
+                const int part = idx / (G::NVOX * Q);
+                const int rem = idx - part * (G::NVOX * Q);
+                const int v = rem / Q, q = rem % Q;
+                const int cb = cb0 + part * CK;
                 const int zw = v % LW; const int t2 = v / LW; const int zh = t2 % LH; const int zd = t2 / LH;
                 int gd = d0 + zd - PD, gh = h0 + zh - PH, gw = w0 + zw - PH;
-                bool ok = gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+                bool ok = gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W && cb < a.Cin;
                 size_t off;
                 if (gather) {
                     gd = a.sd * gd + gtd; gh = 2 * gh + gth; gw = 2 * gw + gtw;
@@ -120,68 +131,99 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_mfma_kernel(const C
                         for (int e = 0; e < 4; ++e) val[e] = fmaxf(__builtin_fmaf(val[e], sc[e], sh[e]), 0.f);
                     }
                 }
-                *reinterpret_cast<f32x4*>(smem + v * VS + 4 * (q ^ ((zw >> G::FSH) & (Q - 1)))) = val;
+                *reinterpret_cast<f32x4*>(smem + part * G::PART + v * VS + 4 * (q ^ ((zw >> G::FSH) & (Q - 1)))) = val;
             }
             __syncthreads();
 
-            // ---- walk the taps; B fragments come straight from global memory (L1/L2 resident), prefetched TWO taps
-            // ahead into a 3-deep register ring.  sched_barrier pins each prefetch above the MFMAs it hides behind
-            // (left alone, the scheduler sinks the loads to ~8 MFMAs before their use, which is less than an L2 round
-            // trip when the wave has its SIMD to itself).
-            const float* wl = a.wt + ((size_t)g * T * a.NPad + n0 + j) * a.Cin + cb + 4 * hf;
-            f32x4 bq[3][NT][K8];
+            const int cb = cb0 + (KS == 1 ? 0 : wave * CK);      // this wave's channel chunk
+            if (KS == 1 || cb < a.Cin) {
+                // ---- walk the taps; B fragments come straight from global memory (L1/L2 resident), prefetched TWO
+                // taps ahead into a 3-deep register ring.  sched_barrier pins each prefetch above the MFMAs it hides
+                // behind (left alone, the scheduler sinks the loads to ~8 MFMAs before their use, which is less than an
+                // L2 round trip when the wave has its SIMD to itself).
+                const float* wl = a.wt + ((size_t)g * T * a.NPad + n0 + j) * a.Cin + cb + 4 * hf;
+                f32x4 bq[3][NT][K8];
 #pragma unroll
-            for (int pre = 0; pre < 2 && pre < T; ++pre)
-#pragma unroll
-                for (int ns = 0; ns < NT; ++ns)
-#pragma unroll
-                    for (int k8 = 0; k8 < K8; ++k8)
-                        bq[pre][ns][k8] = *reinterpret_cast<const f32x4*>(wl + (size_t)pre * tapstride + (size_t)ns * 32 * a.Cin + k8 * 8);
-            // flat software pipeline over steps (tap, k8): A fragments of step i+1 and the B fragments of tap+2 are
-            // requested BEFORE the 8*NT MFMAs of step i; sched_barrier keeps that order in the emitted code.
-            constexpr int S = T * K8;
-            f32x4 av[2][2];
-            {
-                const int tapoff0 = 0;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) av[0][s] = *reinterpret_cast<const f32x4*>(smem + aoff[0][s][0] + tapoff0);
-            }
-#pragma unroll
-            for (int i = 0; i < S; ++i) {
-                const int tap = i / K8, k8 = i % K8;
-                if (i + 1 < S) {
-                    const int tn = (i + 1) / K8, k8n = (i + 1) % K8;
-                    const int kdn = tn / (KHW * KHW), khn = (tn / KHW) % KHW, kwn = tn % KHW;
-                    const int tapoffn = (kdn * LH + khn) * LW * VS;   // compile-time: folded into the ds_read immediate
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-                        av[(i + 1) & 1][s] = *reinterpret_cast<const f32x4*>(smem + aoff[kwn][s][k8n] + tapoffn);
-                }
-                if (k8 == 0 && tap + 2 < T) {
-                    const float* wn = wl + (size_t)(tap + 2) * tapstride;
+                for (int pre = 0; pre < 2 && pre < T; ++pre)
 #pragma unroll
                     for (int ns = 0; ns < NT; ++ns)
 #pragma unroll
-                        for (int kk = 0; kk < K8; ++kk)
-                            bq[(tap + 2) % 3][ns][kk] = *reinterpret_cast<const f32x4*>(wn + (size_t)ns * 32 * a.Cin + kk * 8);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                        for (int k8 = 0; k8 < K8; ++k8)
+                            bq[pre][ns][k8] = *reinterpret_cast<const f32x4*>(wl + (size_t)pre * tapstride + (size_t)ns * 32 * a.Cin + k8 * 8);
+                // flat software pipeline over steps (tap, k8): A fragments of step i+1 and the B fragments of tap+2 are
+                // requested BEFORE the 8*NT MFMAs of step i; sched_barrier keeps that order in the emitted code.
+                constexpr int S = T * K8;
+                f32x4 av[2][2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int s = 0; s < 2; ++s) av[0][s] = *reinterpret_cast<const f32x4*>(lds + aoff[0][s][0]);
 #pragma unroll
-                    for (int ns = 0; ns < NT; ++ns)
+                for (int i = 0; i < S; ++i) {
+                    const int tap = i / K8, k8 = i % K8;
+                    if (i + 1 < S) {
+                        const int tn = (i + 1) / K8, k8n = (i + 1) % K8;
+                        const int kdn = tn / (KHW * KHW), khn = (tn / KHW) % KHW, kwn = tn % KHW;
+                        const int tapoffn = (kdn * LH + khn) * LW * VS;   // compile-time: folded into the ds_read immediate
 #pragma unroll
                         for (int s = 0; s < 2; ++s)
-                            acc[s][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i & 1][s][e], bq[tap % 3][ns][k8][e], acc[s][ns], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                            av[(i + 1) & 1][s] = *reinterpret_cast<const f32x4*>(lds + aoff[kwn][s][k8n] + tapoffn);
+                    }
+                    if (k8 == 0 && tap + 2 < T) {
+                        const float* wn = wl + (size_t)(tap + 2) * tapstride;
+#pragma unroll
+                        for (int ns = 0; ns < NT; ++ns)
+#pragma unroll
+                            for (int kk = 0; kk < K8; ++kk)
+                                bq[(tap + 2) % 3][ns][kk] = *reinterpret_cast<const f32x4*>(wn + (size_t)ns * 32 * a.Cin + kk * 8);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int ns = 0; ns < NT; ++ns)
+#pragma unroll
+                            for (int s = 0; s < 2; ++s)
+                                acc[s][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i & 1][s][e], bq[tap % 3][ns][k8][e], acc[s][ns], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
+    }
+
+    // ---- KS == 4: sum the four waves' partial tiles through LDS (fixed order); wave t keeps tile t = s*NT + ns
+    constexpr int NTILES = 2 * NT;
+    bool owns[2][NT];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ns = 0; ns < NT; ++ns) owns[s][ns] = KS == 1 ? true : (wave == s * NT + ns);
+    if (KS == 4) {
+        __syncthreads();   // every wave is done with its halo: LDS becomes [wave][tile][reg][lane]
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ns = 0; ns < NT; ++ns)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) smem[((wave * NTILES + s * NT + ns) * 16 + r) * 64 + lane] = acc[s][ns][r];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ns = 0; ns < NT; ++ns)
+                if (owns[s][ns]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) v += smem[((w * NTILES + s * NT + ns) * 16 + r) * 64 + lane];
+                        acc[s][ns][r] = v;
+                    }
+                }
     }
 
     // ---- epilogue: bias (+ folded BN + ReLU in eval mode), store, per-tile channel statistics
     const bool do_stats = a.stats != nullptr;
     const bool aff = a.epi_scale != nullptr;
-    if (do_stats) __syncthreads();   // all waves are done reading the halo: LDS is reused as scratch below
+    if (do_stats) __syncthreads();   // all waves are done reading LDS: it is reused as scratch below
 #pragma unroll
     for (int ns = 0; ns < NT; ++ns) {
         const int n = n0 + 32 * ns + j;
@@ -194,11 +236,12 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_mfma_kernel(const C
         float cnt = 0.f, sum = 0.f;
         unsigned okmask = 0u;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
+            if (!owns[s][ns]) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
-                const int m = wave * 64 + s * 32 + row;
+                const int m = rowbase + s * 32 + row;
                 const int gw = w0 + (m & 15), gh = h0 + (m >> 4) % TH, gd = d0 + (m >> 4) / TH;
                 bool ok = nvalid && gd < a.D && gh < a.H && gw < a.W;
                 size_t off;
@@ -218,6 +261,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_mfma_kernel(const C
                     okmask |= 1u << (s * 16 + r);
                 }
             }
+        }
         if (do_stats) {
             float mean = cnt > 0.f ? sum / cnt : 0.f, m2 = 0.f;
 #pragma unroll
@@ -255,43 +299,70 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_mfma_kernel(const C
     }
 }
 
-template <int KD, int KHW, int TD, int TH, int TW, int CK, int NT>
+template <int KD, int KHW, int TD, int TH, int TW, int CK, int NT, int KS>
 int launch_inst(ConvArgs a, hipStream_t s) {
-    using G = Geo<KD, KHW, TD, TH, TW, CK>;
+    using G = Geo<KD, KHW, TD, TH, TW, CK, KS>;
     a.tilesD = cdiv(a.D, TD); a.tilesH = cdiv(a.H, TH); a.tilesW = cdiv(a.W, TW);
     a.ntiles = a.NPad / (32 * NT);
     const size_t nblk = (size_t)a.N * a.tilesD * a.tilesH * a.tilesW * a.ntiles;
     E3_REQUIRE(nblk > 0 && nblk < (1u << 31), E3_ERR_INVALID, "conv grid out of range");
-    auto kern = conv_mfma_kernel<KD, KHW, TD, TH, TW, CK, NT>;
+    constexpr int scratch = KS == 4 ? 4 * 2 * NT * 16 * 64 : 4 * NT * 32 * 3;
+    constexpr int lds_bytes = (G::LDS_FLOATS > scratch ? G::LDS_FLOATS : scratch) * 4;
+    auto kern = conv_mfma_kernel<KD, KHW, TD, TH, TW, CK, NT, KS>;
     static bool attr_set = false;
     if (!attr_set) {
-        E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, s, a);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
 
-template <int KD, int KHW, int TD, int TH, int TW>
-int dispatch_ck_nt(const ConvArgs& a, hipStream_t s) {
+template <int KD, int KHW, int TD, int TH, int TW, int KS>
+int dispatch_ck_nt(const ConvArgs& a, int NT, hipStream_t s) {
     const bool ck16 = (a.Cin % 16) == 0;
-    const bool nt2 = conv_col_tile(a.Ncols) == 64;
-    if (ck16) return nt2 ? launch_inst<KD, KHW, TD, TH, TW, 16, 2>(a, s) : launch_inst<KD, KHW, TD, TH, TW, 16, 1>(a, s);
-    return nt2 ? launch_inst<KD, KHW, TD, TH, TW, 8, 2>(a, s) : launch_inst<KD, KHW, TD, TH, TW, 8, 1>(a, s);
+    if (ck16) return NT == 2 ? launch_inst<KD, KHW, TD, TH, TW, 16, 2, KS>(a, s) : launch_inst<KD, KHW, TD, TH, TW, 16, 1, KS>(a, s);
+    return NT == 2 ? launch_inst<KD, KHW, TD, TH, TW, 8, 2, KS>(a, s) : launch_inst<KD, KHW, TD, TH, TW, 8, 1, KS>(a, s);
+}
+
+struct Brick { int TD, TH; };
+Brick brick_of(ConvKind kind, int ks) {
+    if (ks == 4) return {1, 4};
+    if (kind == CONV_K3_PLANAR) return {1, 16};
+    return {2, 8};
+}
+
+size_t grid_of(ConvKind kind, int ks, int nt, int N, int D, int H, int W, int ncols) {
+    const Brick b = brick_of(kind, ks);
+    return (size_t)N * cdiv(D, b.TD) * cdiv(H, b.TH) * cdiv(W, 16) * cdiv(ncols, 32 * nt);
 }
 
 }  // namespace
 
-int conv_col_tile(int ncols) { return ncols >= 64 ? 64 : 32; }
-
-static void brick_dims(ConvKind kind, int& TD, int& TH, int& TW) {
-    if (kind == CONV_K3_PLANAR) { TD = 1; TH = 16; TW = 16; } else { TD = 2; TH = 8; TW = 16; }
+// Work decomposition: prefer big tiles (A staged once per 64 columns, all K in one wave), but only if the launch still
+// fills the chip (256 CUs x 2-3 resident workgroups); otherwise narrower column tiles, then intra-workgroup split-K.
+void conv_decomposition(ConvKind kind, int flags, int N, int D, int H, int W, int Cin, int ncols, int* ks, int* nt) {
+    const int nt_max = ncols >= 64 ? 2 : 1;
+    const bool ks_ok = kind != CONV_POINT && flags == 0 && Cin >= 64;
+    const int cand[4][2] = {{1, 2}, {1, 1}, {4, 2}, {4, 1}};
+    int best_ks = 1, best_nt = nt_max; size_t best_grid = 0;
+    for (const auto& c : cand) {
+        if (c[1] > nt_max) continue;
+        if (c[0] == 4 && !ks_ok) continue;
+        const size_t g = grid_of(kind, c[0], c[1], N, D, H, W, ncols);
+        if (g >= 256u) { *ks = c[0]; *nt = c[1]; return; }   // at least one workgroup per CU
+        if (g > best_grid) { best_grid = g; best_ks = c[0]; best_nt = c[1]; }
+    }
+    *ks = best_ks; *nt = best_nt;
 }
 
-int conv_stats_parts(ConvKind kind, int flags, int N, int D, int H, int W, int sd) {
-    int TD, TH, TW; brick_dims(kind, TD, TH, TW);
-    int parts = N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, TW);
+int conv_col_tile(int ncols) { return ncols >= 64 ? 64 : 32; }
+
+int conv_stats_parts(ConvKind kind, int flags, int N, int D, int H, int W, int sd, int Cin, int ncols) {
+    int ks, nt; conv_decomposition(kind, flags, N, D, H, W, Cin, ncols, &ks, &nt);
+    const Brick b = brick_of(kind, ks);
+    int parts = N * cdiv(D, b.TD) * cdiv(H, b.TH) * cdiv(W, 16);
     if (flags & CF_SCATTER_UP) parts *= sd * 4;
     return parts;
 }
@@ -301,10 +372,11 @@ int launch_conv_mfma(ConvKind kind, ConvArgs a, hipStream_t s) {
     E3_REQUIRE(a.x_ldc % 4 == 0 && ((uintptr_t)a.x % 16) == 0, E3_ERR_INVALID, "conv input view must be 16-byte aligned");
     E3_REQUIRE(a.NPad % conv_col_tile(a.Ncols) == 0 && a.NPad >= a.Ncols, E3_ERR_INVALID, "bad NPad");
     if (a.G <= 0) a.G = 1;
+    int ks, nt; conv_decomposition(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols, &ks, &nt);
     switch (kind) {
-        case CONV_K3: return dispatch_ck_nt<3, 3, 2, 8, 16>(a, s);
-        case CONV_K3_PLANAR: return dispatch_ck_nt<1, 3, 1, 16, 16>(a, s);
-        case CONV_POINT: return dispatch_ck_nt<1, 1, 2, 8, 16>(a, s);
+        case CONV_K3: return ks == 4 ? dispatch_ck_nt<3, 3, 1, 4, 16, 4>(a, nt, s) : dispatch_ck_nt<3, 3, 2, 8, 16, 1>(a, nt, s);
+        case CONV_K3_PLANAR: return ks == 4 ? dispatch_ck_nt<1, 3, 1, 4, 16, 4>(a, nt, s) : dispatch_ck_nt<1, 3, 1, 16, 16, 1>(a, nt, s);
+        case CONV_POINT: return dispatch_ck_nt<1, 1, 2, 8, 16, 1>(a, nt, s);
     }
     e3_set_error("unknown conv kind");
     return E3_ERR_INVALID;

@@ -35,7 +35,9 @@ struct ConvArgs {
 };
 
 // number of stats records (rows of [Cout][3]) the conv will write
-int conv_stats_parts(ConvKind kind, int flags, int N, int D, int H, int W, int sd);
+int conv_stats_parts(ConvKind kind, int flags, int N, int D, int H, int W, int sd, int Cin, int ncols);
+// chosen work decomposition: ks = 1 (256-voxel bricks) or 4 (64-voxel bricks, waves split K); nt = 32-column tiles per workgroup
+void conv_decomposition(ConvKind kind, int flags, int N, int D, int H, int W, int Cin, int ncols, int* ks, int* nt);
 int launch_conv_mfma(ConvKind kind, ConvArgs a, hipStream_t s);
 int conv_col_tile(int ncols);  // 32 or 64: column tile the launcher will use for `ncols` GEMM columns
 

@@ -145,14 +145,14 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
             const int sd = u.planar ? 1 : 2, taps = sd * 4;
             const LevelDims& li = L[u.level + 1];
             wmax = max_sz(wmax, max_sz((size_t)pad_cols(taps * u.cout) * u.cin, (size_t)taps * pad_cols(u.cin) * u.cout));
-            statmax = max_sz(statmax, (size_t)conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, li.D, li.H, li.W, sd) * u.cout * 3);
+            statmax = max_sz(statmax, (size_t)conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, li.D, li.H, li.W, sd, u.cin, taps * u.cout) * u.cout * 3);
             if (training) slabmax = max_sz(slabmax, (size_t)wgrad_splits(CONV_POINT, N, li.D, li.H, li.W, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32));
         } else {
             const int taps = u.planar ? 9 : 27;
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             if (u.cin >= 8) {
                 wmax = max_sz(wmax, max_sz((size_t)taps * pad_cols(u.cout) * u.cin, (size_t)taps * pad_cols(u.cin) * u.cout));
-                statmax = max_sz(statmax, (size_t)conv_stats_parts(kind, 0, N, lo.D, lo.H, lo.W, 2) * u.cout * 3);
+                statmax = max_sz(statmax, (size_t)conv_stats_parts(kind, 0, N, lo.D, lo.H, lo.W, 2, u.cin, u.cout) * u.cout * 3);
                 if (training) slabmax = max_sz(slabmax, (size_t)wgrad_splits(kind, N, lo.D, lo.H, lo.W, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32));
             } else {
                 wmax = max_sz(wmax, (size_t)taps * pad_cols(u.cin) * u.cout);   // only its dgrad (dx requested) packs weights
@@ -350,7 +350,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = sd;   // autocrop of the up-convolved tensor (unet.py:289-299)
             a.Cout = u.cout; a.Ncols = taps * u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
             a.stats = training ? B.stats : nullptr; a.G = 1; a.flags = CF_SCATTER_UP;
-            parts = conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, li.D, li.H, li.W, sd);
+            parts = conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, li.D, li.H, li.W, sd, u.cin, taps * u.cout);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(CONV_POINT, a, s)); }
         } else if (u.cin < 8) {
             ConvSmallArgs a{};
@@ -368,7 +368,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.sd = 2;
             a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
             a.stats = training ? B.stats : nullptr; a.G = 1; a.flags = 0;
-            parts = conv_stats_parts(kind, 0, N, lo.D, lo.H, lo.W, 2);
+            parts = conv_stats_parts(kind, 0, N, lo.D, lo.H, lo.W, 2, u.cin, u.cout);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(kind, a, s)); }
         }
         if (training) {

@@ -55,7 +55,7 @@ def conv3d(x, w, bias=None, planar=False, pro=None, epi=None, want_stats=False, 
     ws = _ws(L.e3_conv3d_workspace_bytes(Cin, Cout, int(planar)), x.device)
     stats = None
     if want_stats:
-        parts = L.e3_conv3d_stats_parts(Cin, N, D, H, W, int(planar))
+        parts = L.e3_conv3d_stats_parts(Cin, Cout, N, D, H, W, int(planar))
         stats = torch.zeros((parts, Cout, 3), device=x.device, dtype=torch.float32)
     w = w.contiguous()
     check(L.e3_conv3d_fwd(stream_ptr(x.device), ptr(x), _ldc(x), Cin, ptr(w), ptr(bias), ptr(y), _ldc(y), Cout, N, D, H, W,
@@ -101,7 +101,7 @@ def convT(x, w, bias=None, out_dims=None, want_stats=False, out=None):
     ws = _ws(L.e3_convT_workspace_bytes(Cin, Cout, sd), x.device)
     stats = None
     if want_stats:
-        stats = torch.zeros((L.e3_convT_stats_parts(N, D, H, W, sd), Cout, 3), device=x.device, dtype=torch.float32)
+        stats = torch.zeros((L.e3_convT_stats_parts(Cin, Cout, N, D, H, W, sd), Cout, 3), device=x.device, dtype=torch.float32)
     w = w.contiguous()
     check(L.e3_convT_fwd(stream_ptr(x.device), ptr(x), _ldc(x), Cin, ptr(w), ptr(bias), ptr(y), _ldc(y), Cout, N, D, H, W, sd,
                          Do, Ho, Wo, ptr(stats), ptr(ws), c_size_t(ws.numel())))

@@ -124,7 +124,7 @@ int e3_unet_profile_read(e3_unet_plan* plan, double* mean_ms, int* launches);
  *   stats (NULL or [e3_conv3d_stats_parts][Cout][3]): per-tile (count, mean, M2) of y for train-mode BatchNorm.
  *   workspace: e3_conv3d_workspace_bytes() bytes (packed weights). */
 size_t e3_conv3d_workspace_bytes(int Cin, int Cout, int planar);
-int e3_conv3d_stats_parts(int Cin, int N, int D, int H, int W, int planar);
+int e3_conv3d_stats_parts(int Cin, int Cout, int N, int D, int H, int W, int planar);
 int e3_conv3d_fwd(void* stream, const float* x, int x_ldc, int Cin, const float* w, const float* bias,
                   float* y, int y_ldc, int Cout, int N, int D, int H, int W, int planar,
                   const float* pro_scale, const float* pro_shift, const float* epi_scale, const float* epi_shift,
@@ -141,7 +141,7 @@ int e3_conv3d_wgrad(void* stream, const float* x, int x_ldc, int Cin, const floa
  * (D,H,W) are the INPUT dims; the output view has dims (Do,Ho,Wo) <= (sd*D, 2H, 2W): positions beyond are dropped,
  * which implements autocrop()'s crop of the up-convolved tensor (unet.py:289-299). */
 size_t e3_convT_workspace_bytes(int Cin, int Cout, int sd);
-int e3_convT_stats_parts(int N, int D, int H, int W, int sd);
+int e3_convT_stats_parts(int Cin, int Cout, int N, int D, int H, int W, int sd);
 int e3_convT_fwd(void* stream, const float* x, int x_ldc, int Cin, const float* w, const float* bias, float* y, int y_ldc,
                  int Cout, int N, int D, int H, int W, int sd, int Do, int Ho, int Wo, float* stats,
                  void* workspace, size_t workspace_bytes);
