@@ -42,7 +42,7 @@ struct Geo {
 };
 
 template <int KD, int KHW, int TD, int TH, int TW, int CK, int NT, int KS>
-__global__ __launch_bounds__(256, (NT == 2 || KS == 4) ? 2 : 3) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     using G = Geo<KD, KHW, TD, TH, TW, CK, KS>;
     constexpr int VS = G::VS, LH = G::LH, LW = G::LW, PD = G::PD, PH = G::PH, T = G::T, K8 = CK / 8;
     static_assert(CK == 8 || CK == 16, "swizzle is derived for CK in {8,16}");
@@ -96,42 +96,79 @@ __global__ __launch_bounds__(256, (NT == 2 || KS == 4) ? 2 : 3) void conv_mfma_k
     const size_t tapstride = (size_t)a.NPad * a.Cin;
     const bool pro = a.pro_scale != nullptr;
 
+    // ---- staging plan of this thread: item `it` is one 16-B piece (voxel v, channel quad q [, chunk part]) of the halo
+    // brick(s).  Its global element offset (without the chunk base), LDS offset and validity are lane constants for the
+    // whole workgroup, so the per-chunk staging below is a branch-free burst of loads: out-of-range voxels read a clamped
+    // (valid) address and are zeroed by a select; ALL loads of a chunk are in flight together.
+    constexpr int Q = CK / 4;
+    constexpr int ITEMS = G::NVOX * Q * KS;
+    constexpr int XI = (ITEMS + 255) / 256;
+    int soff[XI], loff[XI];
+    unsigned okbits = 0;
+
     for (int g = 0; g < a.G; ++g) {
         int gtd = 0, gth = 0, gtw = 0;
         if (gather) { gtw = g & 1; gth = (g >> 1) & 1; gtd = g >> 2; }
-        for (int cb0 = 0; cb0 < a.Cin; cb0 += CK * KS) {
-            __syncthreads();
-            // ---- stage the halo brick(s): KS consecutive channel chunks, one per wave when KS == 4
-            constexpr int Q = CK / 4;
-            constexpr int ITEMS = G::NVOX * Q * KS;
-#pragma unroll 4
-            for (int idx = tid; idx < ITEMS; idx += 256) {
+        if (g == 0 || gather) {
+            okbits = 0;
+#pragma unroll
+            for (int it = 0; it < XI; ++it) {
+                const int idx = tid + it * 256;
                 const int part = idx / (G::NVOX * Q);
                 const int rem = idx - part * (G::NVOX * Q);
                 const int v = rem / Q, q = rem % Q;
-                const int cb = cb0 + part * CK;
                 const int zw = v % LW; const int t2 = v / LW; const int zh = t2 % LH; const int zd = t2 / LH;
                 int gd = d0 + zd - PD, gh = h0 + zh - PH, gw = w0 + zw - PH;
-                bool ok = gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W && cb < a.Cin;
-                size_t off;
+                bool ok = idx < ITEMS && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+                int ed = a.D, eh = a.H, ew = a.W;
                 if (gather) {
                     gd = a.sd * gd + gtd; gh = 2 * gh + gth; gw = 2 * gw + gtw;
                     ok = ok && gd < a.Do && gh < a.Ho && gw < a.Wo;
-                    off = ((((size_t)nb * a.Do + gd) * a.Ho + gh) * a.Wo + gw) * a.x_ldc + cb + 4 * q;
-                } else {
-                    off = ((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.x_ldc + cb + 4 * q;
+                    ed = a.Do; eh = a.Ho; ew = a.Wo;
                 }
-                f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                if (ok) {
-                    val = *reinterpret_cast<const f32x4*>(a.x + off);
-                    if (pro) {
-                        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.pro_scale + cb + 4 * q);
-                        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.pro_shift + cb + 4 * q);
+                soff[it] = ok ? ((((nb * ed + gd) * eh + gh) * ew + gw) * a.x_ldc + part * CK + 4 * q) : 0;   // < 2^31 (launcher checks)
+                loff[it] = part * G::PART + v * VS + 4 * (q ^ ((zw >> G::FSH) & (Q - 1)));
+                okbits |= (ok ? 1u : 0u) << it;
+            }
+        }
+        for (int cb0 = 0; cb0 < a.Cin; cb0 += CK * KS) {
+            __syncthreads();
+            if (!(a.flags & 256)) {   // flag 256: timing ablation (skip staging)
+                // every item of a thread is the same channel quad (256 % Q == 0): one scale/shift pair per chunk
+                f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+                if (pro) {
+                    psc = *reinterpret_cast<const f32x4*>(a.pro_scale + cb0 + 4 * (tid % Q));
+                    psh = *reinterpret_cast<const f32x4*>(a.pro_shift + cb0 + 4 * (tid % Q));
+                }
+#ifndef E3_STAGE_BATCH
+#define E3_STAGE_BATCH 6
+#endif
+                constexpr int SB = E3_STAGE_BATCH < XI ? E3_STAGE_BATCH : XI;   // loads in flight per thread and batch
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) val[e] = fmaxf(__builtin_fmaf(val[e], sc[e], sh[e]), 0.f);
+                for (int b0 = 0; b0 < XI; b0 += SB) {
+                    f32x4 xr[SB];
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+                        const int it = b0 + u;
+                        if (it < XI) {
+                            bool ok = (okbits >> it) & 1u;
+                            if (KS > 1) ok = ok && (cb0 + (loff[it] / G::PART) * CK < a.Cin);   // ragged last group of chunks
+                            const int off = ok ? soff[it] + cb0 : 0;
+                            f32x4 val = *reinterpret_cast<const f32x4*>(a.x + off);
+                            if (pro) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) val[e] = fmaxf(__builtin_fmaf(val[e], psc[e], psh[e]), 0.f);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) xr[u][e] = ok ? val[e] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+                        const int it = b0 + u;
+                        if (it < XI && tid + it * 256 < ITEMS) *reinterpret_cast<f32x4*>(smem + loff[it]) = xr[u];
                     }
                 }
-                *reinterpret_cast<f32x4*>(smem + part * G::PART + v * VS + 4 * (q ^ ((zw >> G::FSH) & (Q - 1)))) = val;
             }
             __syncthreads();
 
@@ -142,6 +179,8 @@ __global__ __launch_bounds__(256, (NT == 2 || KS == 4) ? 2 : 3) void conv_mfma_k
                 // behind (left alone, the scheduler sinks the loads to ~8 MFMAs before their use, which is less than an
                 // L2 round trip when the wave has its SIMD to itself).
                 const float* wl = a.wt + ((size_t)g * T * a.NPad + n0 + j) * a.Cin + cb + 4 * hf;
+                // keep the 27 per-tap pointers from being hoisted out of the chunk loop (54+ VGPRs live across everything)
+                asm volatile("" : "+v"(wl));
                 f32x4 bq[3][NT][K8];
 #pragma unroll
                 for (int pre = 0; pre < 2 && pre < T; ++pre)
@@ -255,6 +294,7 @@ __global__ __launch_bounds__(256, (NT == 2 || KS == 4) ? 2 : 3) void conv_mfma_k
                 float v = acc[s][ns][r] + bias;
                 if (aff) v = fmaxf(__builtin_fmaf(v, es, eh), 0.f);
                 acc[s][ns][r] = v;
+                if (ok && (a.flags & 512)) ok = (v == 12345.678f);   // flag 512: timing ablation (skip the stores)
                 if (ok) {
                     a.y[off] = v;
                     cnt += 1.f; sum += v;
@@ -344,7 +384,7 @@ size_t grid_of(ConvKind kind, int ks, int nt, int N, int D, int H, int W, int nc
 // fills the chip (256 CUs x 2-3 resident workgroups); otherwise narrower column tiles, then intra-workgroup split-K.
 void conv_decomposition(ConvKind kind, int flags, int N, int D, int H, int W, int Cin, int ncols, int* ks, int* nt) {
     const int nt_max = ncols >= 64 ? 2 : 1;
-    const bool ks_ok = kind != CONV_POINT && flags == 0 && Cin >= 64;
+    const bool ks_ok = kind != CONV_POINT && flags == 0 && Cin >= 64;   // (callers with a BN prologue pass flags |= CF_NO_KSPLIT)
     const int cand[4][2] = {{1, 2}, {1, 1}, {4, 2}, {4, 1}};
     int best_ks = 1, best_nt = nt_max; size_t best_grid = 0;
     for (const auto& c : cand) {
@@ -371,6 +411,10 @@ int launch_conv_mfma(ConvKind kind, ConvArgs a, hipStream_t s) {
     E3_REQUIRE(a.Cin % 8 == 0 && a.Cin >= 8, E3_ERR_UNSUPPORTED, "MFMA conv needs input channels to be a multiple of 8");
     E3_REQUIRE(a.x_ldc % 4 == 0 && ((uintptr_t)a.x % 16) == 0, E3_ERR_INVALID, "conv input view must be 16-byte aligned");
     E3_REQUIRE(a.NPad % conv_col_tile(a.Ncols) == 0 && a.NPad >= a.Ncols, E3_ERR_INVALID, "bad NPad");
+    {
+        const size_t vin = (a.flags & CF_GATHER_UP) ? (size_t)a.N * a.Do * a.Ho * a.Wo : (size_t)a.N * a.D * a.H * a.W;
+        E3_REQUIRE(vin * (size_t)a.x_ldc < ((size_t)1 << 31), E3_ERR_UNSUPPORTED, "conv input view exceeds 2^31 elements (32-bit offsets)");
+    }
     if (a.G <= 0) a.G = 1;
     int ks, nt; conv_decomposition(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols, &ks, &nt);
     switch (kind) {

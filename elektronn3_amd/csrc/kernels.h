@@ -12,6 +12,7 @@ enum ConvKind {
 enum ConvFlags {
     CF_SCATTER_UP = 1,  // POINT only: columns are (tap, co); row p is written to voxel 2p+tap   (ConvTranspose3d fwd)
     CF_GATHER_UP = 2,   // POINT only: K runs over (tap, c); row p reads voxel 2p+tap            (ConvTranspose3d dgrad)
+    CF_NO_KSPLIT = 4,   // keep the 256-voxel decomposition (required with a BN+ReLU prologue)
 };
 
 struct ConvArgs {
