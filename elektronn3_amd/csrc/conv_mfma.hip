@@ -22,6 +22,8 @@
 //           levels (8x16x16: 4096 voxels) where 256-voxel bricks would leave most of the 256 CUs idle.
 // fp32 MFMA is exact fp32 (an fmaf chain) at 157 TFLOP/s dense; LDS and L1 traffic per MFMA is tiny because a
 // 32x32x2 MFMA takes 64 cycles, so the kernel is matrix-pipe bound, not LDS bound.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace {
@@ -417,6 +419,9 @@ int launch_conv_mfma(ConvKind kind, ConvArgs a, hipStream_t s) {
     }
     if (a.G <= 0) a.G = 1;
     int ks, nt; conv_decomposition(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols, &ks, &nt);
+    static const bool use_v3 = getenv("E3_CONV_NO_V3") == nullptr;
+    if (use_v3 && kind != CONV_POINT && ks == 1 && (a.flags & (CF_SCATTER_UP | CF_GATHER_UP)) == 0)
+        return launch_conv3_v3(kind, a, nt, s);    // both operands in LDS, register-prefetched chunks (conv_v3.hip)
     switch (kind) {
         case CONV_K3: return ks == 4 ? dispatch_ck_nt<3, 3, 1, 4, 16, 4>(a, nt, s) : dispatch_ck_nt<3, 3, 2, 8, 16, 1>(a, nt, s);
         case CONV_K3_PLANAR: return ks == 4 ? dispatch_ck_nt<1, 3, 1, 4, 16, 4>(a, nt, s) : dispatch_ck_nt<1, 3, 1, 16, 16, 1>(a, nt, s);

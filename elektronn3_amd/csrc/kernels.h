@@ -40,6 +40,7 @@ int conv_stats_parts(ConvKind kind, int flags, int N, int D, int H, int W, int s
 // chosen work decomposition: ks = 1 (256-voxel bricks) or 4 (64-voxel bricks, waves split K); nt = 32-column tiles per workgroup
 void conv_decomposition(ConvKind kind, int flags, int N, int D, int H, int W, int Cin, int ncols, int* ks, int* nt);
 int launch_conv_mfma(ConvKind kind, ConvArgs a, hipStream_t s);
+int launch_conv3_v3(ConvKind kind, ConvArgs a, int nt, hipStream_t s);   // conv_v3.hip
 int conv_col_tile(int ncols);  // 32 or 64: column tile the launcher will use for `ncols` GEMM columns
 
 // ---------------------------------------------------------------- weight packing
