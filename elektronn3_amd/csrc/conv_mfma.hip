@@ -419,7 +419,7 @@ int launch_conv_mfma(ConvKind kind, ConvArgs a, hipStream_t s) {
     }
     if (a.G <= 0) a.G = 1;
     int ks, nt; conv_decomposition(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols, &ks, &nt);
-    static const bool use_v3 = getenv("E3_CONV_NO_V3") == nullptr;
+    static const bool use_v3 = getenv("E3_CONV_NO_V3") == nullptr;   // debug switch: fall back to the global-B kernel
     if (use_v3 && kind != CONV_POINT && ks == 1 && (a.flags & (CF_SCATTER_UP | CF_GATHER_UP)) == 0)
         return launch_conv3_v3(kind, a, nt, s);    // both operands in LDS, register-prefetched chunks (conv_v3.hip)
     switch (kind) {

@@ -50,14 +50,14 @@ __global__ void pack_weights_kernel(int mode, const float* __restrict__ w, float
     }
 }
 
-// ------------------------------------------------------------------ BN finalise (one wave per channel)
-__global__ void bn_finalize_kernel(const BnFinalizeArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (c >= a.C) return;
-    // Chan merge in double: each lane folds a strided subset, then a butterfly over the wave
+// ------------------------------------------------------------------ BN finalise (one 256-thread workgroup per channel)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinalizeArgs a) {
+    __shared__ double sh[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x;
+    // Chan merge in double: each thread folds a strided subset of the per-tile records, then butterflies
     double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int p = lane; p < a.parts; p += 64) {
+    for (int p = threadIdx.x; p < a.parts; p += 256) {
         const float* r = a.stats + ((size_t)p * a.C + c) * 3;
         const double nb = r[0];
         if (nb > 0.0) {
@@ -65,8 +65,7 @@ __global__ void bn_finalize_kernel(const BnFinalizeArgs a) {
             mean += d * nb / nn; m2 += (double)r[2] + d * d * n * nb / nn; n = nn;
         }
     }
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double nb = __shfl_xor(n, off), mb = __shfl_xor(mean, off), sb = __shfl_xor(m2, off);
+    auto merge = [&](double nb, double mb, double sb) {
         const double nn = n + nb;
         if (nn > 0.0) {
             const double d = mb - mean;
@@ -74,8 +73,12 @@ __global__ void bn_finalize_kernel(const BnFinalizeArgs a) {
             const double snew = m2 + sb + d * d * n * nb / nn;
             mean = mnew; m2 = snew; n = nn;
         }
-    }
-    if (lane == 0) {
+    };
+    for (int off = 32; off >= 1; off >>= 1) merge(__shfl_xor(n, off), __shfl_xor(mean, off), __shfl_xor(m2, off));
+    if (lane == 0) { sh[wave][0] = n; sh[wave][1] = mean; sh[wave][2] = m2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) merge(sh[w][0], sh[w][1], sh[w][2]);
         const double var = n > 0.0 ? m2 / n : 0.0;
         const double invstd = 1.0 / sqrt(var + (double)a.eps);
         const double g = a.gamma ? (double)a.gamma[c] : 1.0, b = a.beta ? (double)a.beta[c] : 0.0;
@@ -318,7 +321,7 @@ int launch_pack_weights(PackMode mode, const float* w, float* out, int Cout, int
 }
 
 int launch_bn_finalize(BnFinalizeArgs a, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a.C, 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(256), 0, s, a);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

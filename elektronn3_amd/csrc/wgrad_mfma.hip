@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WgradArgs a, i
     float* xs = smem;              // [NV][32]  X halo brick, 32 input channels
     float* gs = smem + NV * 32;    // [MV][32]  dY brick, 32 output channels
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches, SGPR offsets
     const int j = lane & 31, hf = lane >> 5;
     unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const int ci_t = L % ci_tiles; L /= ci_tiles;
@@ -53,7 +54,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WgradArgs a, i
     int tapoff[TPW];
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
-        const int tap = wave + 4 * u;
+        // a wave whose last slot has no tap (wave 3 for 27 taps) recomputes its previous tap into a dummy accumulator:
+        // same latency as the other waves, no divergent-looking control flow in the MFMA loop
+        const int tap = wave + 4 * u < T ? wave + 4 * u : T - 1;
         const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
         tapoff[u] = ((kd * LH + kh) * LW + kw) * 32;
     }
@@ -107,10 +110,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WgradArgs a, i
                 const float av = gs[gbase + t * 64];
 #pragma unroll
                 for (int u = 0; u < TPW; ++u) {
-                    if (wave + 4 * u < T) {
-                        const float bv = xs[xbase + t * 64 + tapoff[u]];
-                        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[u], 0, 0, 0);
-                    }
+                    const float bv = xs[xbase + t * 64 + tapoff[u]];
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[u], 0, 0, 0);
                 }
             }
         }
