@@ -79,7 +79,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:   # launched by torch.distributed.run (also with a single rank)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -91,7 +91,7 @@ def main():
     torch.manual_seed(0)                                   # identical replica on every rank
     model = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=32, normalization='batch').to(dev).train()
     sync = None
-    if world > 1:
+    if world > 1 or (dist is not None):
         from elektronn3_amd.dataparallel import GradSync
         sync = GradSync(model)
     torch.manual_seed(1000 + rank)                         # different synthetic crops per rank

@@ -27,6 +27,8 @@ class GradSync:
         self.average = average
         self.bucket_after_down_block = int(min(bucket_after_down_block, model.n_blocks))
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # world == 1 normally short-circuits; `force` keeps the whole event/side-stream/all-reduce path alive (tests)
+        self.force = bool(int(__import__('os').environ.get('E3_FORCE_GRADSYNC', '0')))
         self._flat = None
         self._views = None
         self._split = 0
@@ -54,7 +56,7 @@ class GradSync:
 
     def bucket_event(self):
         """Raw hipEvent_t (as c_void_p) that libe3unet records when bucket A is complete; None on CPU."""
-        if self._flat is None or not self._flat.is_cuda or self.world == 1:
+        if self._flat is None or not self._flat.is_cuda or (self.world == 1 and not self.force):
             return None
         import ctypes
         if self._event is None:
@@ -64,7 +66,7 @@ class GradSync:
         return ctypes.c_void_p(self._event.cuda_event)
 
     def after_backward(self, plan):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         flat = self._flat
         a, b = flat[self._split:], flat[:self._split]

@@ -259,3 +259,47 @@ def test_cpu_input_fails_loudly():
     m = UNet(n_blocks=2, start_filts=8)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 1, 8, 8, 8))
+
+
+def test_gradsync_rccl_single_rank_path(tmp_path):
+    """The data-parallel path end to end on ONE GPU: torch.distributed.run with one rank, RCCL process group, the HIP
+    event recorded by libe3unet mid-backward, the side-stream all-reduce (AVG over 1 rank = identity).  The gradients
+    must equal the plain single-GPU gradients bit for bit and bench.py must print its JSON line."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, E3_FORCE_GRADSYNC='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    script = tmp_path / 'dp_check.py'
+    script.write_text('''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from elektronn3_amd.unet import UNet
+from elektronn3_amd.dataparallel import GradSync
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+torch.manual_seed(0)
+m = UNet(1, 2, n_blocks=3, start_filts=8).cuda().train()
+x = torch.randn(2, 1, 16, 32, 32, device='cuda')
+out = m(x); out.backward(torch.ones_like(out) * 1e-3)
+ref = [p.grad.clone() for p in m.parameters()]
+sync = GradSync(m, bucket_after_down_block=2)
+for p in m.parameters(): p.grad = None
+m.load_state_dict(m.state_dict())
+out = m(x); out.backward(torch.ones_like(out) * 1e-3)
+torch.cuda.synchronize()
+assert sync._event is not None and sync._split > 0
+bad = [n for (n, p), r in zip(m.named_parameters(), ref) if not torch.equal(p.grad, r)]
+print('BAD', bad)
+dist.destroy_process_group()
+''' % root)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29541', str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'BAD []' in r.stdout, r.stdout[-2000:]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29542', os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--no-cpu-baseline']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    res = json.loads(line)
+    assert res['n_gpus'] == 1 and res['value'] > 1e6 and res['roofline']['achieved'] > 10
