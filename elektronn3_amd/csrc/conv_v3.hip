@@ -93,6 +93,11 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3_v3_kernel(const Co
             for (int r = 0; r < 16; ++r) acc[s][ns][r] = 0.f;
 
     const bool pro = a.pro_scale != nullptr;
+    const bool dbg = (a.flags & 1024) != 0;
+    long long* dbgp = reinterpret_cast<long long*>(a.stats) + (size_t)blockIdx.x * 16;
+    int dbgi = 0;
+    auto stamp = [&]() { if (dbg && tid == 0 && dbgi < 16) dbgp[dbgi++] = (long long)__builtin_amdgcn_s_memtime(); };
+    stamp();
     f32x4 xa[AI], xb[BI];
     auto issue_loads = [&](int cb) {
 #pragma unroll
@@ -109,6 +114,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3_v3_kernel(const Co
     issue_loads(0);
 
     for (int cb = 0; cb < a.Cin; cb += 8) {
+        stamp();
         if (cb > 0) __syncthreads();          // every wave is done reading the previous chunk
         // ---- registers -> LDS (zero padding, optional BN+ReLU prologue on the in-range voxels)
         {
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3_v3_kernel(const Co
                     *reinterpret_cast<f32x4*>(Bs + b_dst0 + it * TAPS_PER_IT * 32 * NT * 8) = xb[it];
         }
         __syncthreads();
+        stamp();
         // in flight during the whole tap loop below (unconditional: the last chunk harmlessly re-loads itself, which
         // keeps the loop body free of a branch/join where the compiler would otherwise drain vmcnt)
         issue_loads(cb + 8 < a.Cin ? cb + 8 : cb);
@@ -169,10 +176,30 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3_v3_kernel(const Co
         }
     }
 
-    // ---- epilogue: bias (+ folded BN + ReLU in eval mode), store, per-tile channel statistics
-    const bool do_stats = a.stats != nullptr;
+    // ---- epilogue: bias (+ folded BN + ReLU in eval mode), per-tile channel statistics, store.
+    // Stores go through LDS: the accumulator layout gives every lane ONE channel of 32 different voxels (32 dword stores
+    // per lane, store-issue bound: ~36k cycles per workgroup measured); transposed through a per-wave 64x32 LDS tile each
+    // lane instead writes 4 consecutive channels of 8 voxels = 8 dwordx4 stores, each wave-instruction covering 1 KB of
+    // whole 128-B voxel rows.
+    const bool do_stats = a.stats != nullptr && !dbg;
     const bool aff = a.epi_scale != nullptr;
-    if (do_stats) __syncthreads();
+    const bool wide = (a.Ncols & 3) == 0 && (a.y_ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
+    __syncthreads();                               // every wave is done with As/Bs: LDS is reused below
+    stamp();
+    float* tile = smem + 4 * NT * 32 * 3 + wave * (64 * 32);   // after the statistics scratch
+    // Row geometry of the accumulator layout (TW = 16): row = (r&3) + 8*(r>>2) + 4*hf (+32 s) -> W coordinate
+    // (r&3) + 4*hf + 8*((r>>2)&1), line (D,H) index wave*4 + 2*s + (r>>3).  Validity is separable, so the per-element
+    // work below is branch-free (the compiler otherwise emits ~6 branches per element).
+    bool oklin[2][2], okw[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int line = wave * 4 + 2 * s + u;
+            oklin[s][u] = (d0 + line / TH) < a.D && (h0 + line % TH) < a.H;
+        }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) okw[u] = (w0 + 4 * hf + 8 * u + 3) < a.W;   // fast path flag: all 4 voxels (r&3) in range
 #pragma unroll
     for (int ns = 0; ns < NT; ++ns) {
         const int n = n0 + 32 * ns + j;
@@ -183,32 +210,52 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3_v3_kernel(const Co
         if (aff && nvalid) { es = a.epi_scale[co]; eh = a.epi_shift[co]; }
         float cnt = 0.f, sum = 0.f;
         unsigned okmask = 0u;
+        if (dbg) { asm volatile("" :: "v"(bias)); stamp(); }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
-                const int m = wave * 64 + s * 32 + row;
-                const int gw = w0 + (m & 15), gh = h0 + (m >> 4) % TH, gd = d0 + (m >> 4) / TH;
-                bool ok = nvalid && gd < a.D && gh < a.H && gw < a.W;
-                const size_t off = ((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.y_ldc + co;
+                const bool ok = nvalid && oklin[s][r >> 3] && (okw[(r >> 2) & 1] || (w0 + (row & 15)) < a.W);
                 float v = acc[s][ns][r] + bias;
                 if (aff) v = fmaxf(__builtin_fmaf(v, es, eh), 0.f);
                 acc[s][ns][r] = v;
-                if (ok && (a.flags & 512)) ok = (v == 12345.678f);   // flag 512: timing ablation (skip the stores)
-                if (ok) {
-                    a.y[off] = v;
-                    cnt += 1.f; sum += v;
-                    okmask |= 1u << (s * 16 + r);
-                }
+                tile[(s * 32 + row) * 32 + j] = v;
+                cnt += ok ? 1.f : 0.f;
+                sum += ok ? v : 0.f;
+                okmask |= (ok ? 1u : 0u) << (s * 16 + r);
             }
+        // same wave wrote the tile: LDS ops of one wave are ordered, no workgroup barrier needed
+        if (dbg) { asm volatile("" :: "v"(sum)); stamp(); }
+        if (wide) {
+            const int c4 = n0 + 32 * ns + 4 * (lane & 7);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int row = 8 * p + (lane >> 3);
+                const int line = wave * 4 + (p >> 1);
+                const int gd = d0 + line / TH, gh = h0 + line % TH, gw = w0 + (row & 15);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * 32 + 4 * (lane & 7));
+                if (c4 < a.Ncols && gd < a.D && gh < a.H && gw < a.W && !(a.flags & 512))
+                    *reinterpret_cast<f32x4*>(a.y + (size_t)(((nb * a.D + gd) * a.H + gh) * a.W + gw) * a.y_ldc + c4) = v;
+            }
+        } else {
+            for (int rr = 0; rr < 32; ++rr) {      // rare fallback (unaligned view / channel count not a multiple of 4)
+                const int row = 2 * rr + hf;
+                const int line = wave * 4 + (row >> 4);
+                const int gd = d0 + line / TH, gh = h0 + line % TH, gw = w0 + (row & 15);
+                if (nvalid && gd < a.D && gh < a.H && gw < a.W && !(a.flags & 512))
+                    a.y[(size_t)(((nb * a.D + gd) * a.H + gh) * a.W + gw) * a.y_ldc + co] = tile[row * 32 + j];
+            }
+        }
         if (do_stats) {
             float mean = cnt > 0.f ? sum / cnt : 0.f, m2 = 0.f;
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (okmask & (1u << (s * 16 + r))) { const float d = acc[s][ns][r] - mean; m2 += d * d; }
+                for (int r = 0; r < 16; ++r) {
+                    const float d = acc[s][ns][r] - mean;
+                    m2 += ((okmask >> (s * 16 + r)) & 1u) ? d * d : 0.f;
+                }
             const float cnt2 = __shfl_xor(cnt, 32), mean2 = __shfl_xor(mean, 32), m22 = __shfl_xor(m2, 32);
             welford_merge(cnt, mean, m2, cnt2, mean2, m22);
             if (hf == 0) {
@@ -234,6 +281,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3_v3_kernel(const Co
             }
         }
     }
+    stamp();   // (no barrier: a workgroup barrier would also wait for the outstanding stores)
 }
 
 template <int KD, int TD, int TH, int NT>
@@ -243,7 +291,9 @@ int launch_v3(ConvArgs a, hipStream_t s) {
     a.ntiles = a.NPad / (32 * NT);
     const size_t nblk = (size_t)a.N * a.tilesD * a.tilesH * a.tilesW * a.ntiles;
     E3_REQUIRE(nblk > 0 && nblk < (1u << 31), E3_ERR_INVALID, "conv grid out of range");
-    constexpr int lds_bytes = (G::A_FLOATS + G::T * 32 * NT * 8) * 4;
+    constexpr int stage_floats = G::A_FLOATS + G::T * 32 * NT * 8;
+    constexpr int epi_floats = 4 * NT * 32 * 3 + 4 * 64 * 32;      // statistics scratch + one 64x32 store tile per wave
+    constexpr int lds_bytes = (stage_floats > epi_floats ? stage_floats : epi_floats) * 4;
     auto kern = conv3_v3_kernel<KD, TD, TH, NT>;
     static bool attr_set = false;
     if (!attr_set) {
