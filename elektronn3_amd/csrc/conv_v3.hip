@@ -96,8 +96,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3_v3_kernel(const Co
     const bool dbg = (a.flags & 1024) != 0;
     long long* dbgp = reinterpret_cast<long long*>(a.stats) + (size_t)blockIdx.x * 16;
     int dbgi = 0;
-    auto stamp = [&]() { if (dbg && tid == 0 && dbgi < 16) dbgp[dbgi++] = (long long)__builtin_amdgcn_s_memtime(); };
+    auto stamp = [&]() { if (dbg && tid == 0 && dbgi < 12) dbgp[dbgi++] = (long long)__builtin_amdgcn_s_memtime(); };
     stamp();
+    if (dbg && tid == 0) { dbgp[12] = (long long)__builtin_amdgcn_s_memtime(); dbgp[14] = (long long)__builtin_amdgcn_s_memrealtime(); }
     f32x4 xa[AI], xb[BI];
     auto issue_loads = [&](int cb) {
 #pragma unroll
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3_v3_kernel(const Co
             }
         }
     }
+    if (dbg && tid == 0) { dbgp[13] = (long long)__builtin_amdgcn_s_memtime(); dbgp[15] = (long long)__builtin_amdgcn_s_memrealtime(); }
     stamp();   // (no barrier: a workgroup barrier would also wait for the outstanding stores)
 }
 

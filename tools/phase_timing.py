@@ -16,3 +16,7 @@ for cin, cout in ((32, 32),):
           'per chunk (wait+LDS write, taps):', [(int(med[1 + 2 * c]), int(med[2 + 2 * c])) for c in range(nch)], f'epi: barrier+setup {med[-4]:.0f} bias load {med[-3]:.0f} tile write+stats {med[-2]:.0f} stores {med[-1]:.0f}; total {np.median(t[:, n-1]-t[:, 0]):.0f}')
     dur = (t[:, n - 1].max() - t[:, 0].min())
     print('  kernel span (memtime ticks)', dur, ' sum of block times / (span*768 slots)=', (t[:, n-1]-t[:, 0]).sum() / (dur * 768.0))
+    rt = (t[:, 15] - t[:, 14]).astype(np.float64)
+    ck = (t[:, n - 1] - t[:, 0]) / np.maximum(rt, 1) * 100.0
+    print(f'  per-block realtime ticks (100 MHz) median {np.median(rt):.0f}; memtime ticks per us -> clock MHz: median {np.median(ck):.0f} p10 {np.percentile(ck,10):.0f} p90 {np.percentile(ck,90):.0f}')
+    print('  kernel wall (realtime, max-min)', (t[:, 15].max() - t[:, 14].min()) / 100.0, 'us')
