@@ -18,7 +18,8 @@ static inline int pad_cols(int n) { const int t = conv_col_tile(n); return cdiv(
 // ---------------------------------------------------------------------------------------------- conv 3x3x3
 size_t e3_conv3d_workspace_bytes(int Cin, int Cout, int planar) {
     const int T = planar ? 9 : 27;
-    const size_t a = (size_t)T * pad_cols(Cout) * Cin, b = (size_t)T * pad_cols(Cin) * Cout;
+    (void)T;
+    const size_t a = conv_packed_floats(kind_of(planar), Cin, Cout), b = conv_packed_floats(kind_of(planar), Cout, Cin);
     return align_up((a > b ? a : b) * sizeof(float), 256);
 }
 
@@ -43,7 +44,8 @@ int e3_conv3d_fwd(void* stream, const float* x, int x_ldc, int Cin, const float*
     }
     E3_REQUIRE(workspace_bytes >= e3_conv3d_workspace_bytes(Cin, Cout, planar), E3_ERR_WORKSPACE, "conv3d workspace too small");
     const int T = planar ? 9 : 27, NPad = pad_cols(Cout);
-    int rc = launch_pack_weights(PACK_CONV_FWD, w, (float*)workspace, Cout, Cin, T, NPad, s);
+    (void)T;
+    int rc = launch_pack_conv_auto(kind_of(planar), 0, w, (float*)workspace, Cout, Cin, N, D, H, W, s);
     if (rc) return rc;
     ConvArgs a{};
     a.x = x; a.x_ldc = x_ldc; a.Cin = Cin; a.wt = (const float*)workspace; a.bias = epi_scale ? nullptr : bias;
@@ -60,7 +62,8 @@ int e3_conv3d_dgrad(void* stream, const float* dy, int dy_ldc, int Cout, const f
     hipStream_t s = (hipStream_t)stream;
     E3_REQUIRE(workspace_bytes >= e3_conv3d_workspace_bytes(Cin, Cout, planar), E3_ERR_WORKSPACE, "conv3d workspace too small");
     const int T = planar ? 9 : 27, NPad = pad_cols(Cin);
-    int rc = launch_pack_weights(PACK_CONV_DGRAD, w, (float*)workspace, Cout, Cin, T, NPad, s);
+    (void)T;
+    int rc = launch_pack_conv_auto(kind_of(planar), 1, w, (float*)workspace, Cout, Cin, N, D, H, W, s);
     if (rc) return rc;
     ConvArgs a{};
     a.x = dy; a.x_ldc = dy_ldc; a.Cin = Cout; a.wt = (const float*)workspace; a.bias = nullptr;

@@ -402,6 +402,7 @@ void conv_decomposition(ConvKind kind, int flags, int N, int D, int H, int W, in
 int conv_col_tile(int ncols) { return ncols >= 64 ? 64 : 32; }
 
 int conv_stats_parts(ConvKind kind, int flags, int N, int D, int H, int W, int sd, int Cin, int ncols) {
+    if (conv_use_wino(kind, flags, N, D, H, W, Cin, ncols)) return wino_bricks(N, D, H, W);
     int ks, nt; conv_decomposition(kind, flags, N, D, H, W, Cin, ncols, &ks, &nt);
     const Brick b = brick_of(kind, ks);
     int parts = N * cdiv(D, b.TD) * cdiv(H, b.TH) * cdiv(W, 16);
@@ -418,6 +419,7 @@ int launch_conv_mfma(ConvKind kind, ConvArgs a, hipStream_t s) {
         E3_REQUIRE(vin * (size_t)a.x_ldc < ((size_t)1 << 31), E3_ERR_UNSUPPORTED, "conv input view exceeds 2^31 elements (32-bit offsets)");
     }
     if (a.G <= 0) a.G = 1;
+    if (conv_use_wino(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols)) return launch_conv3_wino(a, s);   // a.wt packed by launch_pack_conv_auto
     int ks, nt; conv_decomposition(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols, &ks, &nt);
     static const bool use_v3 = getenv("E3_CONV_NO_V3") == nullptr;   // debug switch: fall back to the global-B kernel
     if (use_v3 && kind != CONV_POINT && ks == 1 && (a.flags & (CF_SCATTER_UP | CF_GATHER_UP)) == 0)

@@ -1,0 +1,390 @@
+// 3x3x3 stride-1 convolution as Winograd F(2x2x2, 3x3x3) on the fp32 matrix cores (forward AND dgrad: the packer
+// hands dgrad over as a forward conv with flipped taps and swapped channel roles).
+//
+// Replaces torch.nn.Conv3d(k=3, padding=1) inside elektronn3's conv3 blocks (unet.py:131-149) wherever the grid fills
+// the chip.  64 multiplies per 2x2x2 output tile and (ci, co) pair instead of 216: 3.375x fewer matrix FLOPs than the
+// direct implicit GEMM of conv_v3.hip, with the same fp32 arithmetic (F(2,3) only has 0, +-1, +-1/2 coefficients; the
+// measured error against an fp64 convolution is the same 2-3e-7 rel-L2 as the direct fp32 kernel).
+//
+//   Y = A^T [ sum_ci (G g G^T)(ci,co)  (.)  (B^T d B)(ci) ] A          in each of the three dimensions
+//
+// Work decomposition (one workgroup = 4 waves, one wave per SIMD, 512 registers per lane):
+//   * a brick of 2x2x8 tiles (4x4x16 output voxels, 6x6x18 input halo) x 32 output channels;
+//   * the 64 Winograd positions (pd, ph, pw) are 64 independent GEMMs  M = 32 tiles, N = 32 channels, K = Cin.
+//     Wave w owns the 16 positions with pd = w: 16 accumulator tiles of v_mfma_f32_32x32x2_f32 = 256 registers.
+//   * K is walked in chunks of 8 input channels.  Per chunk the raw halo (648 voxels x 8 channels) is staged in LDS
+//     (double buffered, one barrier per chunk).  Lane (tile i, half hf) reads the 2 d-planes its pd needs of ITS tile
+//     and ITS 4 channels (32 ds_read_b128, parity-split + XOR-swizzled layout = conflict-free), does the B^T d B
+//     transform in registers (the lane that computes a transformed value is the lane that feeds it to the MFMA: the
+//     transformed tile never touches LDS) and issues 64 MFMAs.  The transformed weights U of the wave's 16 positions
+//     come straight from L2 into registers one chunk ahead (they are private to the wave, LDS would buy nothing).
+//   * epilogue: A^T m A over (ph, pw) in registers, over pd through LDS (each wave then owns one (oh, ow) of every
+//     tile), then bias / folded eval-BN + ReLU / per-brick Welford statistics / store as in the direct kernels.
+#include "kernels.h"
+
+namespace {
+
+constexpr int W_LD = 6, W_LH = 6, W_LW = 18;               // halo of a 4x4x16 brick
+constexpr int W_NVOX = W_LD * W_LH * W_LW;                  // 648
+constexpr int W_AI = (W_NVOX * 2 + 255) / 256;              // 16-B pieces per thread and chunk (6)
+constexpr int W_CLASS = 96;                                 // voxel slots per parity class (3 x 32 >= 2*32 + 2*9 + 9)
+constexpr int W_RAW = 8 * W_CLASS * 8;                      // floats of one raw buffer (6144)
+constexpr int W_PADF = (W_AI * 256 - W_NVOX * 2) * 4;       // landing zone of the pieces beyond the halo
+constexpr int W_BUF = W_RAW + W_PADF;                       // floats per buffer incl. pad
+constexpr int W_EX = 4 * 16 * 64 * 4;                       // epilogue exchange [pd][e4][lane][4] floats (64 KB)
+constexpr int W_LDS_FLOATS = (2 * W_BUF > W_EX + 4 * 32 * 3 ? 2 * W_BUF : W_EX + 4 * 32 * 3);
+
+// LDS float offset of halo voxel (zd, zh, zw), 16-B piece q: parity classes keep the stride-2 tile origins contiguous,
+// the piece is XOR-ed with bit 0 of zh/2 so that each ds_read_b128 lane group covers all 64 banks.
+__device__ __forceinline__ int raw_slot(int zd, int zh, int zw, int q) {
+    const int k = (zd & 1) * 4 + (zh & 1) * 2 + (zw & 1);
+    const int slot = k * W_CLASS + (zd >> 1) * 32 + (zh >> 1) * 9 + (zw >> 1);
+    return slot * 8 + 4 * (q ^ ((zh >> 1) & 1));
+}
+
+__global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, hf = lane >> 5;
+
+    unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = L % a.ntiles; L /= a.ntiles;
+    const int tw_ = L % a.tilesW; L /= a.tilesW;
+    const int th_ = L % a.tilesH; L /= a.tilesH;
+    const int td_ = L % a.tilesD; const int nb = L / a.tilesD;
+    const int d0 = td_ * 4, h0 = th_ * 4, w0 = tw_ * 16;
+    const int n0 = ntile * 32;
+    const int mtile = ((nb * a.tilesD + td_) * a.tilesH + th_) * a.tilesW + tw_;
+    const int NCH = a.Cin >> 3;
+
+    // ---- staging plan: piece idx = tid + 256 it -> (halo voxel, 16-B half)
+    int a_src[W_AI], a_dst[W_AI];
+    unsigned a_ok = 0;
+#pragma unroll
+    for (int it = 0; it < W_AI; ++it) {
+        const int idx = tid + it * 256;
+        const int v = idx >> 1, q = idx & 1;
+        const int zw = v % W_LW; const int t2 = v / W_LW; const int zh = t2 % W_LH; const int zd = t2 / W_LH;
+        const int gd = d0 + zd - 1, gh = h0 + zh - 1, gw = w0 + zw - 1;
+        const bool inb = v < W_NVOX;
+        const bool ok = inb && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+        a_src[it] = ok ? ((((nb * a.D + gd) * a.H + gh) * a.W + gw) * a.x_ldc + 4 * q) : 0;
+        a_dst[it] = inb ? raw_slot(zd, zh, zw, q) : W_RAW + (idx - W_NVOX * 2) * 4;
+        a_ok |= (ok ? 1u : 0u) << it;
+    }
+
+    // ---- read plan of lane (tile i = j, half hf): tile (td, th, tw) = (j >> 4, (j >> 3) & 1, j & 7)
+    // D pass of Winograd row pd = wave:  0: x0 - x2   1: x1 + x2   2: x2 - x1   3: x1 - x3
+    const int da = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int db = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sgn = wave == 1 ? 1.f : -1.f;
+    const int ttd = j >> 4, tth = (j >> 3) & 1, ttw = j & 7;
+    const int lbase = (ttd * 32 + tth * 9 + ttw) * 8;
+    const int offA = (((da & 1) * 4) * W_CLASS + (da >> 1) * 32) * 8;
+    const int offB = (((db & 1) * 4) * W_CLASS + (db >> 1) * 32) * 8;
+    // rows h = 0,1 of the tile have zh/2 = th, rows 2,3 have th + 1: the swizzle bit differs between the two
+    int rdA[2], rdB[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int pc = 4 * (hf ^ ((tth + hh) & 1));
+        rdA[hh] = lbase + offA + pc;
+        rdB[hh] = lbase + offB + pc;
+    }
+
+    // ---- transformed weights: U[ntile][chunk][pos 64][hf 2][co 32][4 ci]; wave = pd owns positions 16 pd .. 16 pd + 15
+    const float* bp = a.wt + ((size_t)ntile * NCH * 64 + wave * 16) * 256 + lane * 4;
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    const bool pro = a.pro_scale != nullptr;
+    f32x4 xr[W_AI], Bv[16];
+    auto issue_raw = [&](int cb) {
+#pragma unroll
+        for (int it = 0; it < W_AI; ++it) {
+            const bool ok = (a_ok >> it) & 1u;
+            xr[it] = *reinterpret_cast<const f32x4*>(a.x + (ok ? a_src[it] + cb : 0));
+        }
+    };
+    auto write_raw = [&](float* buf, int cb) {
+        f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+        if (pro) {
+            psc = *reinterpret_cast<const f32x4*>(a.pro_scale + cb + 4 * (tid & 1));
+            psh = *reinterpret_cast<const f32x4*>(a.pro_shift + cb + 4 * (tid & 1));
+        }
+#pragma unroll
+        for (int it = 0; it < W_AI; ++it) {
+            const bool ok = (a_ok >> it) & 1u;
+            f32x4 v = xr[it];
+            if (pro) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(v[e], psc[e], psh[e]), 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+            *reinterpret_cast<f32x4*>(buf + a_dst[it]) = v;
+        }
+    };
+    auto load_B = [&](int c, int g) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            Bv[g * 4 + p] = *reinterpret_cast<const f32x4*>(bp + ((size_t)c * 64 + g * 4 + p) * 256);
+    };
+
+    // one 8-channel chunk: raw halo in `cur`, next chunk's halo goes to `nxt`
+    auto chunk = [&](int c, const float* cur, float* nxt) {
+        const int cn = c + 1 < NCH ? c + 1 : c;     // (the last chunk harmlessly re-stages itself: no branch in the loop body)
+        issue_raw(cn * 8);
+        // ---- B^T d B of this lane's tile, 4 channels at a time (f32x4 = the 4 k-steps of the chunk)
+        f32x4 t[4][4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int imm = (((h & 1) * 2 + (w & 1)) * W_CLASS + (h >> 1) * 9 + (w >> 1)) * 8;
+                const f32x4 xa = *reinterpret_cast<const f32x4*>(cur + rdA[h >> 1] + imm);
+                const f32x4 xb = *reinterpret_cast<const f32x4*>(cur + rdB[h >> 1] + imm);
+                t[h][w] = xa + sgn * xb;
+            }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const f32x4 u0 = t[0][w] - t[2][w], u1 = t[1][w] + t[2][w], u2 = t[2][w] - t[1][w], u3 = t[1][w] - t[3][w];
+            t[0][w] = u0; t[1][w] = u1; t[2][w] = u2; t[3][w] = u3;
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const f32x4 u0 = t[h][0] - t[h][2], u1 = t[h][1] + t[h][2], u2 = t[h][2] - t[h][1], u3 = t[h][1] - t[h][3];
+            t[h][0] = u0; t[h][1] = u1; t[h][2] = u2; t[h][3] = u3;
+        }
+        // ---- 16 positions x 4 k-steps; groups of 4 positions keep 4 independent accumulators in flight
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    acc[g * 4 + p] = __builtin_amdgcn_mfma_f32_32x32x2f32(t[g][p][s], Bv[g * 4 + p][s], acc[g * 4 + p], 0, 0, 0);
+            load_B(cn, g);                           // the group's registers are free again: fetch them for the next chunk
+        }
+        write_raw(nxt, cn * 8);
+        __syncthreads();
+    };
+
+    float* buf0 = smem;
+    float* buf1 = smem + W_BUF;
+    issue_raw(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) load_B(0, g);
+    write_raw(buf0, 0);
+    __syncthreads();
+    for (int c = 0; c < NCH; c += 2) {
+        chunk(c, buf0, buf1);
+        if (c + 1 < NCH) chunk(c + 1, buf1, buf0);
+    }
+
+    // ---- epilogue.  acc[ph*4+pw][r]: position (pd = wave, ph, pw), tile row r -> tile t = (r&3) + 8 (r>>2) + 4 hf, channel j.
+    f32x16 q[2][2];
+    {
+        f32x16 tmp[4][2];
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            tmp[ph][0] = acc[ph * 4 + 0] + acc[ph * 4 + 1] + acc[ph * 4 + 2];
+            tmp[ph][1] = acc[ph * 4 + 1] - acc[ph * 4 + 2] - acc[ph * 4 + 3];
+        }
+#pragma unroll
+        for (int ow = 0; ow < 2; ++ow) {
+            q[0][ow] = tmp[0][ow] + tmp[1][ow] + tmp[2][ow];
+            q[1][ow] = tmp[1][ow] - tmp[2][ow] - tmp[3][ow];
+        }
+    }
+    // (the barrier that ended the last chunk already separates the raw buffers from their reuse below)
+    float* ex = smem;
+#pragma unroll
+    for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+        for (int ow = 0; ow < 2; ++ow)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = q[oh][ow][4 * k + e];
+                *reinterpret_cast<f32x4*>(ex + ((wave * 16 + (oh * 2 + ow) * 4 + k) * 64 + lane) * 4) = v;
+            }
+    __syncthreads();
+    // wave w now owns output offset (oh, ow) = (w >> 1, w & 1) of every tile and sums the pd axis: od = 0, 1
+    const int oh = wave >> 1, ow = wave & 1;
+    float y[2][16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f32x4 m[4];
+#pragma unroll
+        for (int pd = 0; pd < 4; ++pd) m[pd] = *reinterpret_cast<const f32x4*>(ex + ((pd * 16 + wave * 4 + k) * 64 + lane) * 4);
+        const f32x4 y0 = m[0] + m[1] + m[2], y1 = m[1] - m[2] - m[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y[0][4 * k + e] = y0[e]; y[1][4 * k + e] = y1[e]; }
+    }
+
+    const bool do_stats = a.stats != nullptr;
+    const bool aff = a.epi_scale != nullptr;
+    const int n = n0 + j;
+    const bool nvalid = n < a.Ncols;
+    const float bias = (a.bias && nvalid) ? a.bias[n] : 0.f;
+    float es = 1.f, eh = 0.f;
+    if (aff && nvalid) { es = a.epi_scale[n]; eh = a.epi_shift[n]; }
+    float cnt = 0.f, sum = 0.f;
+    unsigned okmask = 0u;
+#pragma unroll
+    for (int od = 0; od < 2; ++od)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // tile t = (r&3) + 8 (r>>2) + 4 hf -> (td, th, tw) = (r >> 3, (r >> 2) & 1, (r & 3) + 4 hf)
+            const int gd = d0 + 2 * (r >> 3) + od, gh = h0 + 2 * ((r >> 2) & 1) + oh, gw = w0 + 2 * ((r & 3) + 4 * hf) + ow;
+            const bool ok = nvalid && gd < a.D && gh < a.H && gw < a.W;
+            float v = y[od][r] + bias;
+            if (aff) v = fmaxf(__builtin_fmaf(v, es, eh), 0.f);
+            y[od][r] = v;
+            if (ok) {
+                a.y[(size_t)(((nb * a.D + gd) * a.H + gh) * a.W + gw) * a.y_ldc + n] = v;
+                cnt += 1.f; sum += v; okmask |= 1u << (od * 16 + r);
+            }
+        }
+    if (do_stats) {
+        float mean = cnt > 0.f ? sum / cnt : 0.f, m2 = 0.f;
+#pragma unroll
+        for (int od = 0; od < 2; ++od)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = y[od][r] - mean;
+                m2 += ((okmask >> (od * 16 + r)) & 1u) ? d * d : 0.f;
+            }
+        const float cnt2 = __shfl_xor(cnt, 32), mean2 = __shfl_xor(mean, 32), m22 = __shfl_xor(m2, 32);
+        welford_merge(cnt, mean, m2, cnt2, mean2, m22);
+        float* scr = smem + W_EX;
+        if (hf == 0) {
+            float* sc = scr + (wave * 32 + j) * 3;
+            sc[0] = cnt; sc[1] = mean; sc[2] = m2;
+        }
+        __syncthreads();
+        if (tid < 32 && n < a.Ncols) {
+            float c0 = 0.f, me = 0.f, mm = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float* sc = scr + (w * 32 + tid) * 3;
+                welford_merge(c0, me, mm, sc[0], sc[1], sc[2]);
+            }
+            float* o = a.stats + ((size_t)mtile * a.Cout + n) * 3;
+            o[0] = c0; o[1] = me; o[2] = mm;
+        }
+    }
+}
+
+// torch weights -> U[ntile][chunk][pos][hf][co32][4]:  U = (G (x) G (x) G) g, evaluated in double.
+//   dgrad == 0:  g[tap][n = co][k = ci] = w[co][ci][tap]           (w is (Cout, Cin, 27))
+//   dgrad == 1:  g[tap][n = ci][k = co] = w[co][ci][26 - tap]      (rows/cols swapped, taps flipped)
+// K = number of GEMM-K channels (multiple of 8), Ncols = real columns, NPad = padded to 32.
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int dgrad, int K, int Ncols, int NPad) {
+    const int NCH = K >> 3;
+    const size_t total = (size_t)(NPad >> 5) * NCH * 256;     // one thread per (ntile, chunk, hf, co, e): all 64 positions
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = i & 3, co = (i >> 2) & 31, hf = (i >> 7) & 1;
+        const size_t r = i >> 8;
+        const int ch = r % NCH, nt = r / NCH;
+        const int n = nt * 32 + co, k = ch * 8 + hf * 4 + e;
+        double g[27];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            float v = 0.f;
+            if (n < Ncols) v = dgrad ? w[((size_t)k * Cin + n) * 27 + (26 - t)] : w[((size_t)n * Cin + k) * 27 + t];
+            g[t] = v;
+        }
+        // separable G: rows [1,0,0], [.5,.5,.5], [.5,-.5,.5], [0,0,1]
+        double u1[4][3][3], u2[4][4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double g0 = g[0 * 9 + b * 3 + c], g1 = g[1 * 9 + b * 3 + c], g2 = g[2 * 9 + b * 3 + c];
+                u1[0][b][c] = g0; u1[1][b][c] = 0.5 * (g0 + g1 + g2); u1[2][b][c] = 0.5 * (g0 - g1 + g2); u1[3][b][c] = g2;
+            }
+#pragma unroll
+        for (int pd = 0; pd < 4; ++pd)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double g0 = u1[pd][0][c], g1 = u1[pd][1][c], g2 = u1[pd][2][c];
+                u2[pd][0][c] = g0; u2[pd][1][c] = 0.5 * (g0 + g1 + g2); u2[pd][2][c] = 0.5 * (g0 - g1 + g2); u2[pd][3][c] = g2;
+            }
+        float* o = out + ((size_t)(nt * NCH + ch) * 64) * 256 + (hf * 32 + co) * 4 + e;
+#pragma unroll
+        for (int pd = 0; pd < 4; ++pd)
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const double g0 = u2[pd][ph][0], g1 = u2[pd][ph][1], g2 = u2[pd][ph][2];
+                const int pos = (pd * 4 + ph) * 4;
+                o[(size_t)(pos + 0) * 256] = (float)g0;
+                o[(size_t)(pos + 1) * 256] = (float)(0.5 * (g0 + g1 + g2));
+                o[(size_t)(pos + 2) * 256] = (float)(0.5 * (g0 - g1 + g2));
+                o[(size_t)(pos + 3) * 256] = (float)g2;
+            }
+    }
+}
+
+}  // namespace
+
+// ---- host side
+size_t wino_packed_floats(int K, int ncols) { return (size_t)64 * K * (size_t)((ncols + 31) / 32 * 32); }
+
+int wino_bricks(int N, int D, int H, int W) { return N * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16); }
+
+bool conv_use_wino(ConvKind kind, int flags, int N, int D, int H, int W, int Cin, int ncols) {
+    static const bool enabled = getenv("E3_CONV_NO_WINO") == nullptr;
+    if (!enabled || kind != CONV_K3 || (flags & (CF_SCATTER_UP | CF_GATHER_UP)) != 0 || Cin < 8 || (Cin & 7)) return false;
+    const size_t grid = (size_t)wino_bricks(N, D, H, W) * ((ncols + 31) / 32);
+    return grid >= 256u;       // one workgroup per CU at least (1 wave per SIMD each)
+}
+
+int launch_wino_pack(const float* w, float* out, int Cout, int Cin, int dgrad, hipStream_t s) {
+    const int K = dgrad ? Cout : Cin, ncols = dgrad ? Cin : Cout;
+    const int NPad = (ncols + 31) / 32 * 32;
+    const size_t total = (size_t)(NPad >> 5) * (K >> 3) * 256;
+    const int grid = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3(grid), dim3(256), 0, s, w, out, Cout, Cin, dgrad, K, ncols, NPad);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+size_t conv_packed_floats(ConvKind kind, int K, int ncols) {
+    const int T = kind == CONV_K3 ? 27 : (kind == CONV_K3_PLANAR ? 9 : 1);
+    const int ct = conv_col_tile(ncols);
+    const size_t direct = (size_t)T * (cdiv(ncols, ct) * ct) * K;
+    const size_t wino = kind == CONV_K3 ? wino_packed_floats(K, ncols) : 0;
+    return direct > wino ? direct : wino;
+}
+
+int launch_pack_conv_auto(ConvKind kind, int dgrad, const float* w, float* out, int Cout, int Cin, int N, int D, int H, int W, hipStream_t s) {
+    const int K = dgrad ? Cout : Cin, ncols = dgrad ? Cin : Cout;
+    if (conv_use_wino(kind, 0, N, D, H, W, K, ncols)) return launch_wino_pack(w, out, Cout, Cin, dgrad, s);
+    const int T = kind == CONV_K3 ? 27 : 9, ct = conv_col_tile(ncols);
+    return launch_pack_weights(dgrad ? PACK_CONV_DGRAD : PACK_CONV_FWD, w, out, Cout, Cin, T, cdiv(ncols, ct) * ct, s);
+}
+
+int launch_conv3_wino(ConvArgs a, hipStream_t s) {
+    a.tilesD = cdiv(a.D, 4); a.tilesH = cdiv(a.H, 4); a.tilesW = cdiv(a.W, 16);
+    a.NPad = (a.Ncols + 31) / 32 * 32;
+    a.ntiles = a.NPad / 32;
+    const size_t nblk = (size_t)a.N * a.tilesD * a.tilesH * a.tilesW * a.ntiles;
+    E3_REQUIRE(nblk > 0 && nblk < (1u << 31), E3_ERR_INVALID, "conv grid out of range");
+    constexpr int lds_bytes = W_LDS_FLOATS * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3_wino_kernel, dim3((unsigned)nblk), dim3(256), lds_bytes, s, a);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}

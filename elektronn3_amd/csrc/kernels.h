@@ -41,6 +41,16 @@ int conv_stats_parts(ConvKind kind, int flags, int N, int D, int H, int W, int s
 void conv_decomposition(ConvKind kind, int flags, int N, int D, int H, int W, int Cin, int ncols, int* ks, int* nt);
 int launch_conv_mfma(ConvKind kind, ConvArgs a, hipStream_t s);
 int launch_conv3_v3(ConvKind kind, ConvArgs a, int nt, hipStream_t s);   // conv_v3.hip
+// Winograd F(2x2x2,3x3x3) path (conv_wino.hip).  conv_use_wino() is THE routing predicate: the weight packer, the
+// statistics sizing and launch_conv_mfma() all ask it, with K = GEMM-K channels and ncols = GEMM columns.
+bool conv_use_wino(ConvKind kind, int flags, int N, int D, int H, int W, int K, int ncols);
+int wino_bricks(int N, int D, int H, int W);
+int launch_conv3_wino(ConvArgs a, hipStream_t s);
+// floats of packed-weight workspace a stride-1 conv (fwd or dgrad) may need, whichever algorithm is chosen
+size_t conv_packed_floats(ConvKind kind, int K, int ncols);
+// packs torch (Cout,Cin,T) weights for the forward (dgrad = 0) or the input-gradient (dgrad = 1) launch of a conv over
+// an (N,D,H,W) grid, in the layout of the algorithm conv_use_wino() selects
+int launch_pack_conv_auto(ConvKind kind, int dgrad, const float* w, float* out, int Cout, int Cin, int N, int D, int H, int W, hipStream_t s);
 int conv_col_tile(int ncols);  // 32 or 64: column tile the launcher will use for `ncols` GEMM columns
 
 // ---------------------------------------------------------------- weight packing

@@ -151,11 +151,11 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
             const int taps = u.planar ? 9 : 27;
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             if (u.cin >= 8) {
-                wmax = max_sz(wmax, max_sz((size_t)taps * pad_cols(u.cout) * u.cin, (size_t)taps * pad_cols(u.cin) * u.cout));
+                wmax = max_sz(wmax, max_sz(conv_packed_floats(kind, u.cin, u.cout), conv_packed_floats(kind, u.cout, u.cin)));
                 statmax = max_sz(statmax, (size_t)conv_stats_parts(kind, 0, N, lo.D, lo.H, lo.W, 2, u.cin, u.cout) * u.cout * 3);
                 if (training) slabmax = max_sz(slabmax, (size_t)wgrad_splits(kind, N, lo.D, lo.H, lo.W, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32));
             } else {
-                wmax = max_sz(wmax, (size_t)taps * pad_cols(u.cin) * u.cout);   // only its dgrad (dx requested) packs weights
+                wmax = max_sz(wmax, conv_packed_floats(kind, u.cout, u.cin));   // only its dgrad (dx requested) packs weights
                 statmax = max_sz(statmax, (size_t)conv_small_stats_parts(N, lo.D, lo.H, lo.W, u.planar) * u.cout * 3);
                 if (training) slabmax = max_sz(slabmax, (size_t)conv_small_wgrad_splits(N, lo.D, lo.H, lo.W, u.planar) * taps * u.cout * u.cin);
             }
@@ -362,7 +362,8 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         } else {
             const int taps = u.planar ? 9 : 27, NPad = pad_cols(u.cout);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
-            RUN(launch_pack_weights(PACK_CONV_FWD, P(u.p_w), B.wpack, u.cout, u.cin, taps, NPad, s));
+            (void)taps;
+            RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, lo.D, lo.H, lo.W, s));
             ConvArgs a{};
             a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpack; a.bias = training ? P(u.p_b) : nullptr;
             a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.sd = 2;
@@ -506,7 +507,8 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         } else {
             const int taps = u.planar ? 9 : 27, NPad = pad_cols(u.cin);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
-            RUN(launch_pack_weights(PACK_CONV_DGRAD, P(u.p_w), B.wpack, u.cout, u.cin, taps, NPad, s));
+            (void)taps;
+            RUN(launch_pack_conv_auto(kind, 1, P(u.p_w), B.wpack, u.cout, u.cin, N, lo.D, lo.H, lo.W, s));
             const bool to_cat = !is_down && u.name.find("conv1") != std::string::npos;   // UpConv.conv1: gradient of the concat buffer
             float* out; int out_ldc = u.cin;
             if (k == 0) out = (cfg.in_channels > 1) ? B.g1[0] : dx;   // g1[0] is free by now (C0 >= in_channels)

@@ -146,6 +146,9 @@ CONV_CASES = [
     (64, 128, (8, 16, 32), False, 2),    # KS=4 with NT=2 (the bottom-level shapes of cfg 2)
     (64, 32, (3, 5, 7), False, 1),       # KS=4, partial 64-voxel bricks in every dim
     (80, 64, (3, 9, 20), True, 1),       # KS=4, planar, 5 channel chunks over 4 waves (ragged split)
+    (32, 64, (14, 30, 50), False, 2),    # Winograd path (>= 256 workgroups), partial 4x4x16 bricks in every dim
+    (40, 24, (16, 32, 64), False, 2),    # Winograd, odd number of 8-channel chunks, partial column tile
+    (8, 8, (9, 33, 33), False, 4),       # Winograd, single chunk, odd extents (partial 2x2x2 tiles)
 ]
 
 
