@@ -42,6 +42,10 @@ __device__ __forceinline__ int raw_slot(int zd, int zh, int zw, int q) {
     return slot * 8 + 4 * (q ^ ((zh >> 1) & 1));
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool PRO>
 __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -58,9 +62,25 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
     const int n0 = ntile * 32;
     const int mtile = ((nb * a.tilesD + td_) * a.tilesH + th_) * a.tilesW + tw_;
     const int NCH = a.Cin >> 3;
+    constexpr unsigned OOB = 0x80000000u;       // buffer offset beyond every descriptor below: loads return 0, stores are dropped
+
+    // ---- buffer descriptors.  The activation descriptors start at the brick's first d-plane so that every offset is a
+    // small non-negative number whatever the size of the tensor; an out-of-volume voxel gets the OOB offset and the
+    // hardware supplies the zero padding (no select, no 64-bit address arithmetic in the loop).
+    const int dlo = d0 > 0 ? d0 - 1 : 0;
+    const size_t plane_x = (size_t)a.H * a.W * a.x_ldc, plane_y = (size_t)a.H * a.W * a.y_ldc;
+    const size_t xrem = (size_t)(a.D - dlo) * plane_x * 4, yrem = (size_t)(a.D - d0) * plane_y * 4;
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x) + ((size_t)nb * a.D + dlo) * plane_x, 0, (int)(xrem < 0x7fffffffu ? xrem : 0x7fffffffu), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(
+        a.y + ((size_t)nb * a.D + d0) * plane_y, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
+    // transformed weights: U[ntile][chunk][pos 64][hf 2][co 32][4 ci]; wave = pd owns positions 16 pd .. 16 pd + 15
+    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.wt) + ((size_t)ntile * NCH * 64 + wave * 16) * 256, 0, NCH * 64 * 1024, 0x00020000);
+    const int b_voff = lane * 16;
 
     // ---- staging plan: piece idx = tid + 256 it -> (halo voxel, 16-B half)
-    int a_src[W_AI], a_dst[W_AI];
+    unsigned a_src[W_AI]; int a_dst[W_AI];
     unsigned a_ok = 0;
 #pragma unroll
     for (int it = 0; it < W_AI; ++it) {
@@ -70,7 +90,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
         const int gd = d0 + zd - 1, gh = h0 + zh - 1, gw = w0 + zw - 1;
         const bool inb = v < W_NVOX;
         const bool ok = inb && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-        a_src[it] = ok ? ((((nb * a.D + gd) * a.H + gh) * a.W + gw) * a.x_ldc + 4 * q) : 0;
+        a_src[it] = ok ? (unsigned)(((((gd - dlo) * a.H + gh) * a.W + gw) * a.x_ldc + 4 * q) * 4) : OOB;
         a_dst[it] = inb ? raw_slot(zd, zh, zw, q) : W_RAW + (idx - W_NVOX * 2) * 4;
         a_ok |= (ok ? 1u : 0u) << it;
     }
@@ -80,6 +100,8 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
     const int da = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int db = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sgn = wave == 1 ? 1.f : -1.f;
+    float m1 = -1.f;
+    asm volatile("" : "+s"(m1));     // opaque -1: a + m1*b becomes v_pk_fma_f32 (hipcc only packs fadd/ffma, never fsub)
     const int ttd = j >> 4, tth = (j >> 3) & 1, ttw = j & 7;
     const int lbase = (ttd * 32 + tth * 9 + ttw) * 8;
     const int offA = (((da & 1) * 4) * W_CLASS + (da >> 1) * 32) * 8;
@@ -93,52 +115,51 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
         rdB[hh] = lbase + offB + pc;
     }
 
-    // ---- transformed weights: U[ntile][chunk][pos 64][hf 2][co 32][4 ci]; wave = pd owns positions 16 pd .. 16 pd + 15
-    const float* bp = a.wt + ((size_t)ntile * NCH * 64 + wave * 16) * 256 + lane * 4;
-
     f32x16 acc[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    const bool pro = a.pro_scale != nullptr;
+    const bool dbg = (a.flags & 1024) != 0;     // timing experiments: s_memtime stamps into the statistics buffer
+    long long* dbgp = reinterpret_cast<long long*>(a.stats) + (size_t)blockIdx.x * 16;
+    int dbgi = 0;
+    auto stamp = [&]() { if (dbg && tid == 0 && dbgi < 14) dbgp[dbgi++] = (long long)__builtin_amdgcn_s_memtime(); };
+    if (dbg && tid == 0) dbgp[14] = (long long)__builtin_amdgcn_s_memrealtime();
+    stamp();
     f32x4 xr[W_AI], Bv[16];
     auto issue_raw = [&](int cb) {
 #pragma unroll
-        for (int it = 0; it < W_AI; ++it) {
-            const bool ok = (a_ok >> it) & 1u;
-            xr[it] = *reinterpret_cast<const f32x4*>(a.x + (ok ? a_src[it] + cb : 0));
-        }
+        for (int it = 0; it < W_AI; ++it)
+            xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, a_src[it], cb * 4, 0));
     };
     auto write_raw = [&](float* buf, int cb) {
         f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
-        if (pro) {
+        if (PRO) {
             psc = *reinterpret_cast<const f32x4*>(a.pro_scale + cb + 4 * (tid & 1));
             psh = *reinterpret_cast<const f32x4*>(a.pro_shift + cb + 4 * (tid & 1));
         }
 #pragma unroll
         for (int it = 0; it < W_AI; ++it) {
-            const bool ok = (a_ok >> it) & 1u;
             f32x4 v = xr[it];
-            if (pro) {
+            if (PRO) {                         // BN + ReLU of the producer applied while staging; the padding stays 0
+                const bool ok = (a_ok >> it) & 1u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(v[e], psc[e], psh[e]), 0.f);
+                for (int e = 0; e < 4; ++e) v[e] = ok ? fmaxf(__builtin_fmaf(v[e], psc[e], psh[e]), 0.f) : 0.f;
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
             *reinterpret_cast<f32x4*>(buf + a_dst[it]) = v;
         }
     };
     auto load_B = [&](int c, int g) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            Bv[g * 4 + p] = *reinterpret_cast<const f32x4*>(bp + ((size_t)c * 64 + g * 4 + p) * 256);
+            Bv[g * 4 + p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_voff + p * 1024, (c * 64 + g * 4) * 1024, 0));
     };
 
     // one 8-channel chunk: raw halo in `cur`, next chunk's halo goes to `nxt`
     auto chunk = [&](int c, const float* cur, float* nxt) {
         const int cn = c + 1 < NCH ? c + 1 : c;     // (the last chunk harmlessly re-stages itself: no branch in the loop body)
+        if (c == 1) stamp();
         issue_raw(cn * 8);
         // ---- B^T d B of this lane's tile, 4 channels at a time (f32x4 = the 4 k-steps of the chunk)
         f32x4 t[4][4];
@@ -153,14 +174,26 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
             }
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const f32x4 u0 = t[0][w] - t[2][w], u1 = t[1][w] + t[2][w], u2 = t[2][w] - t[1][w], u3 = t[1][w] - t[3][w];
+            const f32x4 u0 = t[0][w] + m1 * t[2][w], u1 = t[1][w] + t[2][w], u2 = t[2][w] + m1 * t[1][w], u3 = t[1][w] + m1 * t[3][w];
             t[0][w] = u0; t[1][w] = u1; t[2][w] = u2; t[3][w] = u3;
         }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const f32x4 u0 = t[h][0] - t[h][2], u1 = t[h][1] + t[h][2], u2 = t[h][2] - t[h][1], u3 = t[h][1] - t[h][3];
+            const f32x4 u0 = t[h][0] + m1 * t[h][2], u1 = t[h][1] + t[h][2], u2 = t[h][2] + m1 * t[h][1], u3 = t[h][1] + m1 * t[h][3];
             t[h][0] = u0; t[h][1] = u1; t[h][2] = u2; t[h][3] = u3;
         }
+        // keep the transform packed (2 floats per VALU lane-op): without an opaque use hipcc scalarises every vector op
+        // whose results are only ever extracted element-wise (the MFMA operands below)
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                f32x2 lo = {t[h][w][0], t[h][w][1]}, hi = {t[h][w][2], t[h][w][3]};
+                asm("" : "+v"(lo)); asm("" : "+v"(hi));
+                t[h][w][0] = lo[0]; t[h][w][1] = lo[1]; t[h][w][2] = hi[0]; t[h][w][3] = hi[1];
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == 1) stamp();
         // ---- 16 positions x 4 k-steps; groups of 4 positions keep 4 independent accumulators in flight
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -171,8 +204,13 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
                     acc[g * 4 + p] = __builtin_amdgcn_mfma_f32_32x32x2f32(t[g][p][s], Bv[g * 4 + p][s], acc[g * 4 + p], 0, 0, 0);
             load_B(cn, g);                           // the group's registers are free again: fetch them for the next chunk
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == 1) stamp();
         write_raw(nxt, cn * 8);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == 1) stamp();
         __syncthreads();
+        if (c == 1) stamp();
     };
 
     float* buf0 = smem;
@@ -182,25 +220,24 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
     for (int g = 0; g < 4; ++g) load_B(0, g);
     write_raw(buf0, 0);
     __syncthreads();
-    for (int c = 0; c < NCH; c += 2) {
-        chunk(c, buf0, buf1);
-        if (c + 1 < NCH) chunk(c + 1, buf1, buf0);
+    stamp();
+    chunk(0, buf0, buf1);                   // peeled: the accumulators are known zeros here (MFMA with a literal 0 addend)
+    for (int c = 1; c < NCH; c += 2) {
+        chunk(c, buf1, buf0);
+        if (c + 1 < NCH) chunk(c + 1, buf0, buf1);
     }
+    stamp();
 
     // ---- epilogue.  acc[ph*4+pw][r]: position (pd = wave, ph, pw), tile row r -> tile t = (r&3) + 8 (r>>2) + 4 hf, channel j.
     f32x16 q[2][2];
-    {
-        f32x16 tmp[4][2];
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            tmp[ph][0] = acc[ph * 4 + 0] + acc[ph * 4 + 1] + acc[ph * 4 + 2];
-            tmp[ph][1] = acc[ph * 4 + 1] - acc[ph * 4 + 2] - acc[ph * 4 + 3];
-        }
-#pragma unroll
-        for (int ow = 0; ow < 2; ++ow) {
-            q[0][ow] = tmp[0][ow] + tmp[1][ow] + tmp[2][ow];
-            q[1][ow] = tmp[1][ow] - tmp[2][ow] - tmp[3][ow];
-        }
+    for (int ph = 0; ph < 4; ++ph) {       // incremental: 4 accumulators -> 2 temporaries -> folded into q, low register pressure
+        const f32x16 t0 = acc[ph * 4 + 0] + acc[ph * 4 + 1] + acc[ph * 4 + 2];
+        const f32x16 t1 = acc[ph * 4 + 1] + m1 * acc[ph * 4 + 2] + m1 * acc[ph * 4 + 3];
+        if (ph == 0) { q[0][0] = t0; q[0][1] = t1; }
+        else if (ph == 1) { q[0][0] += t0; q[0][1] += t1; q[1][0] = t0; q[1][1] = t1; }
+        else if (ph == 2) { q[0][0] += t0; q[0][1] += t1; q[1][0] += m1 * t0; q[1][1] += m1 * t1; }
+        else { q[1][0] += m1 * t0; q[1][1] += m1 * t1; }
     }
     // (the barrier that ended the last chunk already separates the raw buffers from their reuse below)
     float* ex = smem;
@@ -216,50 +253,75 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
                 *reinterpret_cast<f32x4*>(ex + ((wave * 16 + (oh * 2 + ow) * 4 + k) * 64 + lane) * 4) = v;
             }
     __syncthreads();
+    stamp();
     // wave w now owns output offset (oh, ow) = (w >> 1, w & 1) of every tile and sums the pd axis: od = 0, 1
     const int oh = wave >> 1, ow = wave & 1;
-    float y[2][16];
+    const int n = n0 + j;
+    const bool nvalid = n < a.Ncols;
+    const bool aff = a.epi_scale != nullptr;
+    const float bias = (a.bias && nvalid) ? a.bias[n] : 0.f;
+    float es = 1.f, eh = 0.f;
+    if (aff && nvalid) { es = a.epi_scale[n]; eh = a.epi_shift[n]; }
+    f32x4 y[2][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         f32x4 m[4];
 #pragma unroll
         for (int pd = 0; pd < 4; ++pd) m[pd] = *reinterpret_cast<const f32x4*>(ex + ((pd * 16 + wave * 4 + k) * 64 + lane) * 4);
-        const f32x4 y0 = m[0] + m[1] + m[2], y1 = m[1] - m[2] - m[3];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { y[0][4 * k + e] = y0[e]; y[1][4 * k + e] = y1[e]; }
+        y[0][k] = m[0] + m[1] + m[2] + bias;
+        y[1][k] = m[1] + m1 * m[2] + m1 * m[3] + bias;
     }
-
-    const bool do_stats = a.stats != nullptr;
-    const bool aff = a.epi_scale != nullptr;
-    const int n = n0 + j;
-    const bool nvalid = n < a.Ncols;
-    const float bias = (a.bias && nvalid) ? a.bias[n] : 0.f;
-    float es = 1.f, eh = 0.f;
-    if (aff && nvalid) { es = a.epi_scale[n]; eh = a.epi_shift[n]; }
+    if (aff) {
+#pragma unroll
+        for (int od = 0; od < 2; ++od)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[od][k][e] = fmaxf(__builtin_fmaf(y[od][k][e], es, eh), 0.f);
+    }
+    // value (od, r = 4k + e): tile t = (r&3) + 8 (r>>2) + 4 hf -> (td, th, tw) = (r >> 3, (r >> 2) & 1, (r & 3) + 4 hf),
+    // voxel (d0 + 2 td + od, h0 + 2 th + oh, w0 + 2 tw + ow).  Lane part of the address in a VGPR, the rest is scalar.
+    const int gw_l = w0 + 8 * hf + ow, gh_l = h0 + oh;
+    const unsigned y_voff = (unsigned)(((gh_l * a.W + gw_l) * a.y_ldc + n) * 4);
+    const bool full = d0 + 4 <= a.D && h0 + 4 <= a.H && w0 + 16 <= a.W && n0 + 32 <= a.Ncols;
+    const bool do_stats = a.stats != nullptr && !dbg;
     float cnt = 0.f, sum = 0.f;
-    unsigned okmask = 0u;
+    unsigned okmask = 0xffffffffu;
+    if (full) {
 #pragma unroll
-    for (int od = 0; od < 2; ++od)
+        for (int od = 0; od < 2; ++od)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // tile t = (r&3) + 8 (r>>2) + 4 hf -> (td, th, tw) = (r >> 3, (r >> 2) & 1, (r & 3) + 4 hf)
-            const int gd = d0 + 2 * (r >> 3) + od, gh = h0 + 2 * ((r >> 2) & 1) + oh, gw = w0 + 2 * ((r & 3) + 4 * hf) + ow;
-            const bool ok = nvalid && gd < a.D && gh < a.H && gw < a.W;
-            float v = y[od][r] + bias;
-            if (aff) v = fmaxf(__builtin_fmaf(v, es, eh), 0.f);
-            y[od][r] = v;
-            if (ok) {
-                a.y[(size_t)(((nb * a.D + gd) * a.H + gh) * a.W + gw) * a.y_ldc + n] = v;
-                cnt += 1.f; sum += v; okmask |= 1u << (od * 16 + r);
+            for (int r = 0; r < 16; ++r) {
+                const int soff = ((((2 * (r >> 3) + od) * a.H + 2 * ((r >> 2) & 1)) * a.W + 2 * (r & 3)) * a.y_ldc) * 4;
+                const float v = y[od][r >> 2][r & 3];   // (bit_cast of a vector-element lvalue reads element 0 with this hipcc)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, y_voff, soff, 0);
+                sum += v;
             }
-        }
+        cnt = 32.f;
+    } else {
+        okmask = 0u;
+#pragma unroll
+        for (int od = 0; od < 2; ++od)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gd = d0 + 2 * (r >> 3) + od, gh = gh_l + 2 * ((r >> 2) & 1), gw = gw_l + 2 * (r & 3);
+                const bool ok = nvalid && gd < a.D && gh < a.H && gw < a.W;
+                const int soff = ((((2 * (r >> 3) + od) * a.H + 2 * ((r >> 2) & 1)) * a.W + 2 * (r & 3)) * a.y_ldc) * 4;
+                const float v = y[od][r >> 2][r & 3];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, ok ? y_voff : OOB, soff, 0);
+                cnt += ok ? 1.f : 0.f;
+                sum += ok ? v : 0.f;
+                okmask |= (ok ? 1u : 0u) << (od * 16 + r);
+            }
+    }
+    if (dbg) { asm volatile("" :: "v"(sum)); stamp(); if (tid == 0) dbgp[15] = (long long)__builtin_amdgcn_s_memrealtime(); }
     if (do_stats) {
         float mean = cnt > 0.f ? sum / cnt : 0.f, m2 = 0.f;
 #pragma unroll
         for (int od = 0; od < 2; ++od)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float d = y[od][r] - mean;
+                const float d = y[od][r >> 2][r & 3] - mean;
                 m2 += ((okmask >> (od * 16 + r)) & 1u) ? d * d : 0.f;
             }
         const float cnt2 = __shfl_xor(cnt, 32), mean2 = __shfl_xor(mean, 32), m22 = __shfl_xor(m2, 32);
@@ -378,13 +440,17 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
     a.ntiles = a.NPad / 32;
     const size_t nblk = (size_t)a.N * a.tilesD * a.tilesH * a.tilesW * a.ntiles;
     E3_REQUIRE(nblk > 0 && nblk < (1u << 31), E3_ERR_INVALID, "conv grid out of range");
+    E3_REQUIRE((size_t)6 * a.H * a.W * (size_t)(a.x_ldc > a.y_ldc ? a.x_ldc : a.y_ldc) * 4 < 0x7fffffffu, E3_ERR_UNSUPPORTED,
+               "six d-planes of the conv input/output view exceed 2^31 bytes (32-bit buffer offsets)");
     constexpr int lds_bytes = W_LDS_FLOATS * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3_wino_kernel, dim3((unsigned)nblk), dim3(256), lds_bytes, s, a);
+    if (a.pro_scale) hipLaunchKernelGGL(conv3_wino_kernel<true>, dim3((unsigned)nblk), dim3(256), lds_bytes, s, a);
+    else hipLaunchKernelGGL(conv3_wino_kernel<false>, dim3((unsigned)nblk), dim3(256), lds_bytes, s, a);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

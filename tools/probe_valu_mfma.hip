@@ -14,6 +14,34 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
         if (!(mode & 1)) return;
         f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
         float a = threadIdx.x * 1e-3f, b = 1.0f;
+        if (mode & 8) {     // same wave: 4 MFMAs interleaved with 16 (mode 8) or 32 (mode 24) independent VALU FMAs
+            float x0 = threadIdx.x, x1 = 1.f, x2 = 2.f, x3 = 3.f, x4 = 4.f, x5 = 5.f, x6 = 6.f, x7 = 7.f;
+            const float m = 1.0001f, q = 0.5f;
+            for (int i = 0; i < iters; ++i) {
+#pragma unroll
+                for (int u = 0; u < ((mode & 16) ? 2 : 1); ++u) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
+                x0 = __builtin_fmaf(x0, m, q); x1 = __builtin_fmaf(x1, m, q); x2 = __builtin_fmaf(x2, m, q); x3 = __builtin_fmaf(x3, m, q);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c1, 0, 0, 0);
+                x4 = __builtin_fmaf(x4, m, q); x5 = __builtin_fmaf(x5, m, q); x6 = __builtin_fmaf(x6, m, q); x7 = __builtin_fmaf(x7, m, q);
+                if (!(mode & 16)) {
+                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c2, 0, 0, 0);
+                x0 = __builtin_fmaf(x0, m, q); x1 = __builtin_fmaf(x1, m, q); x2 = __builtin_fmaf(x2, m, q); x3 = __builtin_fmaf(x3, m, q);
+                c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c3, 0, 0, 0);
+                x4 = __builtin_fmaf(x4, m, q); x5 = __builtin_fmaf(x5, m, q); x6 = __builtin_fmaf(x6, m, q); x7 = __builtin_fmaf(x7, m, q);
+                } else {
+                x0 = __builtin_fmaf(x0, m, q); x1 = __builtin_fmaf(x1, m, q); x2 = __builtin_fmaf(x2, m, q); x3 = __builtin_fmaf(x3, m, q);
+                x4 = __builtin_fmaf(x4, m, q); x5 = __builtin_fmaf(x5, m, q); x6 = __builtin_fmaf(x6, m, q); x7 = __builtin_fmaf(x7, m, q);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c3, 0, 0, 0);
+                }
+                }
+            }
+            float s = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+            for (int r = 0; r < 16; ++r) s += c0[r] + c1[r] + c2[r] + c3[r];
+            out[blockIdx.x * 512 + threadIdx.x] = s;
+            return;
+        }
         bf16x4 ab = {1, 2, 3, 4};
         for (int i = 0; i < iters; ++i) {
             if (mode & 4) {
@@ -50,7 +78,7 @@ int main() {
     float* out; (void)hipMalloc(&out, 4096 * 512 * 4);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int iters = 20000, blocks = 256;
-    for (int mode : {1, 2, 3, 5, 7, 1, 2, 3}) {
+    for (int mode : {1, 2, 3, 5, 7, 9, 25, 1, 2, 3}) {
         auto run = [&]() {
             switch (mode) {
                 case 1: k<1><<<blocks, 512>>>(out, iters); break;
@@ -58,6 +86,8 @@ int main() {
                 case 3: k<3><<<blocks, 512>>>(out, iters); break;
                 case 5: k<5><<<blocks, 512>>>(out, iters); break;
                 case 7: k<7><<<blocks, 512>>>(out, iters); break;
+                case 9: k<9><<<blocks, 512>>>(out, iters); break;
+                case 25: k<25><<<blocks, 512>>>(out, iters); break;
             }
         };
         run(); (void)hipDeviceSynchronize();
