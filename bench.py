@@ -10,9 +10,12 @@ all-reduced with RCCL on a side stream overlapped with the backward).  A step is
 (+ gradient all-reduce); the optimizer is excluded.  Inputs are resident in HBM before the timed region.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel (fp32-MFMA implicit-GEMM conv of the heaviest layer, up_convs.2.conv1 64->32 at full
-                resolution): ALGORITHMIC flops per launch / mean launch time measured with HIP events on the compute
-                stream INSIDE the timed steps (e3_unet_profile_*), against the 157.3 TFLOP/s fp32 matrix peak.
+  roofline      the conv of the heaviest layer (up_convs.2.conv1, 64->32 at full resolution): ALGORITHMIC flops per launch
+                (direct-convolution count 2*Cin*Cout*27 per voxel) / mean launch time measured with HIP
+                events on the compute stream INSIDE the timed steps (e3_unet_profile_*), against the 157.3 TFLOP/s fp32
+                matrix peak.  The forward/dgrad kernel is Winograd F(2x2x2,3x3x3): it EXECUTES 64/216 of those flops on
+                the matrix cores, so `frac` can exceed 1; `mfma_executed` reports the executed matrix flops against
+                the same peak.  wgrad (direct implicit GEMM) executes exactly the algorithmic count.
   cpu_baseline  the reference's ATen op sequence (oracle/torch_ref.py) on the host cores, rank 0, N=1 only.
 """
 import argparse
@@ -162,7 +165,12 @@ def main():
                        'step_tflops': FWDBWD_FLOP_PER_VOXEL * vox_per_step / world / (ms_per_step * 1e-3) / 1e12},
             'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
-                         'kernel': f'conv_mfma_kernel fwd of {args.profile_layer} ({lcin}->{lcout}, {ltaps} taps, {lvox} voxels)',
+                         'kernel': f'conv3_wino_kernel (Winograd F(2x2x2,3x3x3), fp32 MFMA) fwd of {args.profile_layer} '
+                                   f'({lcin}->{lcout}, {ltaps} taps, {lvox} voxels)' if ltaps == 27 else
+                                   f'conv3_v3_kernel fwd of {args.profile_layer} ({lcin}->{lcout}, {ltaps} taps, {lvox} voxels)',
+                         'mfma_executed': {'flops_per_launch': lflops * (64.0 / 216.0 if ltaps == 27 else 1.0),
+                                           'tflops': ach * (64.0 / 216.0 if ltaps == 27 else 1.0),
+                                           'frac': ach * (64.0 / 216.0 if ltaps == 27 else 1.0) / FP32_MFMA_PEAK_TFLOPS},
                          'flops_per_launch': lflops, 'ms_per_launch': k_ms, 'launches_timed': k_n,
                          'dgrad_ms': extra.get('dgrad'), 'wgrad_ms': extra.get('wgrad'),
                          'dgrad_tflops': lflops / (extra['dgrad'] * 1e-3) / 1e12 if extra.get('dgrad') else None,
