@@ -255,6 +255,7 @@ int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s) {
         hipLaunchKernelGGL(wgrad_point_kernel, grid, dim3(256), lds, s, a, tD, tH, tW, tps, T, co_tiles, ci_tiles);
     } else {
         const dim3 grid((unsigned)((size_t)splits * co_tiles * ci_tiles));
+        if (wgrad_use_wino(kind)) return launch_wgrad_wino(a, tD, tH, tW, tps, co_tiles, ci_tiles, splits, s);   // wgrad_wino.hip
         if (kind == CONV_K3) {
             using G = WGeo<3, 2, 4>;
             auto kern = wgrad_conv_kernel<3, 2, 4>;

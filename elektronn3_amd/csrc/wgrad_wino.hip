@@ -1,0 +1,274 @@
+// Weight gradient of the 3x3x3 convolution as Winograd F(3x3x3, 2x2x2) on the fp32 matrix cores.
+//
+//   dW[co][ci][k] = sum over 2x2x2 output tiles t:  sum_o dY[2t + o][co] * X[2t + o + k - 1][ci]        (k in {0,1,2}^3)
+//
+// Per dimension this is F(3, 2): 3 outputs (the taps), a 2-tap "filter" (the dY tile) and a 4-wide input (the X tile),
+// 4 multiplies instead of 6; in 3D 64 instead of 216 per tile and (ci, co) pair, 3.375x fewer matrix FLOPs than the
+// direct wgrad of wgrad_mfma.hip.  With the interpolation points (0, 1, -1, inf):
+//   Xt = B^T x      B^T rows: x0 - x2,  x1 + x2,  x2 - x1,  x1 - x3           (the forward kernel's input transform)
+//   Yt = G y        G rows:   y0,  y0 + y1,  y0 - y1,  y1                     (factors 1/2 moved to the output side)
+//   M_p[co][ci] = sum_tiles Yt_p[tile][co] * Xt_p[tile][ci]                   (64 independent GEMMs, K = all tiles)
+//   dW = A^T M      A^T rows: M0 + M1/2 + M2/2,  M1/2 - M2/2,  M1/2 + M2/2 - M3
+//
+// Work decomposition (same bricks, splits and partial-slab layout as wgrad_conv_kernel, so wgrad_reduce_kernel and all
+// callers are unchanged): a workgroup owns a (32 co x 32 ci) tile and a contiguous range of 2x4x16-voxel bricks
+// (16 tiles each).  Wave w owns the 16 positions with pd = w: 16 accumulators of v_mfma_f32_32x32x2_f32 (K = 2 tiles
+// per instruction), resident over the whole range.  Lane (j, hf) transforms channel co0+j of dY and channel ci0+j of X
+// for the tiles 4 hf + s it feeds to k-step s, straight from an LDS image stored [d][h][channel][w] (w contiguous:
+// one ds_read_b64/b128 serves several overlapping tiles), so the transformed tiles never touch LDS.
+// Epilogue: A^T over (ph, pw) in registers, over pd through LDS, partial slab part[split][tap][co][ci].
+#include "kernels.h"
+
+namespace {
+
+constexpr int G_LH = 6, G_LW = 18;                       // X halo of a 2x4x16 brick: 4 x 6 x 18
+constexpr int G_NV = 4 * G_LH * G_LW;                    // 432 voxels
+constexpr int G_MV = 128;                                // dY brick voxels
+constexpr int G_XS = G_NV * 32;                          // X image [voxel][32 ci] floats
+constexpr int G_GS = G_MV * 32;                          // dY image [voxel][32 co]
+constexpr int G_BUF = G_XS + G_GS;                       // one stage (70 KB)
+constexpr int G_XW = G_NV * 8 / 64;                      // 54 wave-pieces (1 KB each) of X per brick
+constexpr int G_XI = (G_XW + 3) / 4;                     // per wave: 14 (waves 0,1) / 13
+constexpr int G_GI = G_MV * 8 / 64 / 4;                  // 4 wave-pieces of dY per wave
+constexpr int G_EX = 4 * 9 * 4 * 64 * 4;                 // epilogue exchange: [pd][khkw][r/4][lane][4] floats (144 KB)
+constexpr int G_LDS_FLOATS = 2 * G_BUF > G_EX ? 2 * G_BUF : G_EX;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, int tilesD, int tilesH, int tilesW,
+                                                            int tiles_per_split, int co_tiles, int ci_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, hf = lane >> 5;
+    unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int ci_t = L % ci_tiles; L /= ci_tiles;
+    const int co_t = L % co_tiles; const int split = L / co_tiles;
+    const int ci0 = ci_t * 32, co0 = co_t * 32;
+    const int nbricks = a.N * tilesD * tilesH * tilesW;
+    const int brick0 = split * tiles_per_split;
+    const int brick1 = brick0 + tiles_per_split < nbricks ? brick0 + tiles_per_split : nbricks;
+    constexpr unsigned OOB = 0x80000000u;       // buffer offset beyond the descriptors: the DMA writes zeros
+
+    // ---- staging by LDS-DMA (buffer_load_dwordx4 ... lds): a wave-instruction moves 64 x 16 B = 8 voxels x 32 channels
+    // into 1 KB of the [voxel][32] image; no staging registers, no ds_write pass, zero padding by the range check.
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, 0x7fffffff, 0x00020000);
+    // lane constants: wave-piece (it*4 + wave), lane -> piece idx -> (voxel, 4-channel group).  Validity of a halo voxel is
+    // separable, so a brick only needs one 28-bit scalar mask (4 d bits | 6 h bits | 18 w bits) and each piece the
+    // constant pattern of its three bits: 4 VALU per piece and brick, no branches.
+    unsigned xpm[G_XI], xrel[G_XI];
+#pragma unroll
+    for (int it = 0; it < G_XI; ++it) {
+        const int wp = it * 4 + wave < G_XW ? it * 4 + wave : G_XW - 1;     // (waves 2, 3 repeat the last piece in their 14th slot)
+        const int idx = wp * 64 + lane;
+        const int v = idx >> 3, q = idx & 7;
+        const int zw = v % G_LW, zh = (v / G_LW) % G_LH, zd = v / (G_LW * G_LH);
+        const bool cok = ci0 + 4 * q < a.Cin;
+        xpm[it] = cok ? (1u << zd) | (1u << (4 + zh)) | (1u << (10 + zw)) : 0xffffffffu;      // all-ones never matches
+        xrel[it] = (unsigned)((((zd * a.H + zh) * a.W + zw) * a.x_ldc + ci0 + 4 * q) * 4);
+    }
+    unsigned gpm[G_GI], grel[G_GI];
+#pragma unroll
+    for (int it = 0; it < G_GI; ++it) {
+        const int idx = (it * 4 + wave) * 64 + lane;
+        const int v = idx >> 3, q = idx & 7;
+        const int ww = v & 15, hh = (v >> 4) & 3, dd = v >> 6;
+        const bool cok = co0 + 4 * q < a.Cout;
+        gpm[it] = cok ? (1u << dd) | (1u << (4 + hh)) | (1u << (10 + ww)) : 0xffffffffu;
+        grel[it] = (unsigned)((((dd * a.H + hh) * a.W + ww) * a.dy_ldc + co0 + 4 * q) * 4);
+    }
+
+    // ---- read plan.  D pass of Winograd row pd = wave: X: 0: x0 - x2, 1: x1 + x2, 2: x2 - x1, 3: x1 - x3;  Y: y0, y0+y1, y0-y1, y1
+    const int da = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int db = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sgn = wave == 1 ? 1.f : -1.f;
+    const float ya = wave == 3 ? 0.f : 1.f, yb = wave == 0 ? 0.f : (wave == 2 ? -1.f : 1.f);
+    float m1 = -1.f;
+    asm volatile("" : "+s"(m1));                          // opaque -1 (keeps a + m1*b as one fma)
+    const int xrd_a = (da * G_LH * G_LW + 8 * hf) * 32 + j;        // + ((2c + h) * LW + 4 hc + w) * 32
+    const int xrd_b = (db * G_LH * G_LW + 8 * hf) * 32 + j;
+    const int yrd = G_XS + (8 * hf) * 32 + j;                       // + ((dd * 4 + 2c + oh) * 16 + 4 hc + w) * 32
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    auto issue = [&](int brick, float* buf) {
+        int Lt = brick < brick1 ? brick : brick1 - 1;     // (past the end the last brick harmlessly re-stages itself)
+        const int tw_ = Lt % tilesW; Lt /= tilesW; const int th_ = Lt % tilesH; Lt /= tilesH; const int td_ = Lt % tilesD; const int nb = Lt / tilesD;
+        const int d0 = td_ * 2, h0 = th_ * 4, w0 = tw_ * 16;
+        // scalar validity masks of the brick: bit z of a field is set when halo coordinate z is inside the volume
+        auto range_mask = [](int lo, int n, int size) {      // z in [0, n): lo + z in [0, size)
+            const int first = lo < 0 ? -lo : 0, last = size - lo < n ? size - lo : n;     // valid z in [first, last)
+            return last > first ? ((1u << last) - 1u) & ~((1u << first) - 1u) : 0u;
+        };
+        const unsigned xmask = range_mask(d0 - 1, 4, a.D) | (range_mask(h0 - 1, 6, a.H) << 4) | (range_mask(w0 - 1, 18, a.W) << 10);
+        const unsigned gmask = range_mask(d0, 2, a.D) | (range_mask(h0, 4, a.H) << 4) | (range_mask(w0, 16, a.W) << 10);
+        const unsigned xbase = (unsigned)(((((nb * a.D + d0 - 1) * a.H + h0 - 1) * a.W + w0 - 1) * a.x_ldc) * 4);   // wraps at the borders
+        const unsigned gbase = (unsigned)(((((nb * a.D + d0) * a.H + h0) * a.W + w0) * a.dy_ldc) * 4);
+#pragma unroll
+        for (int it = 0; it < G_XI; ++it) {
+            const int wp = it * 4 + wave < G_XW ? it * 4 + wave : G_XW - 1;
+            const bool ok = (xmask & xpm[it]) == xpm[it];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(buf + wp * 256), 16, ok ? xrel[it] + xbase : OOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < G_GI; ++it) {
+            const bool ok = (gmask & gpm[it]) == gpm[it];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rs, (lds_ptr_t)(buf + G_XS + (it * 4 + wave) * 256), 16, ok ? grel[it] + gbase : OOB, 0, 0, 0);
+        }
+    };
+
+    // one brick = 2 tile rows (chunks) x 2 halves of 2 k-steps each
+    auto compute = [&](const float* buf) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int hc = 0; hc < 2; ++hc) {
+                // ---- X: rows h = 0..3 of the tile row, w window 8 hf + 4 hc + [0, 6) serves the lane's tiles 4 hf + 2 hc + {0, 1}
+                float u[4][6];
+#pragma unroll
+                for (int h = 0; h < 4; ++h)
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) {
+                        const int off = ((2 * c + h) * G_LW + 4 * hc + w) * 32;
+                        u[h][w] = buf[xrd_a + off] + sgn * buf[xrd_b + off];
+                    }
+#pragma unroll
+                for (int w = 0; w < 6; ++w) {
+                    const float v0 = u[0][w] + m1 * u[2][w], v1 = u[1][w] + u[2][w], v2 = u[2][w] + m1 * u[1][w], v3 = u[1][w] + m1 * u[3][w];
+                    u[0][w] = v0; u[1][w] = v1; u[2][w] = v2; u[3][w] = v3;
+                }
+                float X[2][4][4];                       // [tile][ph][pw]
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const float* r = &u[h][2 * tl];
+                        X[tl][h][0] = r[0] + m1 * r[2]; X[tl][h][1] = r[1] + r[2]; X[tl][h][2] = r[2] + m1 * r[1]; X[tl][h][3] = r[1] + m1 * r[3];
+                    }
+                // ---- Y: dY rows oh = 0, 1 of the tile row, both d planes, w window 8 hf + 4 hc + [0, 4)
+                float g[2][4];
+#pragma unroll
+                for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int off = ((2 * c + oh) * 16 + 4 * hc + w) * 32;
+                        g[oh][w] = ya * buf[yrd + off] + yb * buf[yrd + off + 4 * 16 * 32];
+                    }
+                float Y[2][4][4];
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    float hrow[4][2];
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const float g0 = g[0][2 * tl + w], g1 = g[1][2 * tl + w];
+                        hrow[0][w] = g0; hrow[1][w] = g0 + g1; hrow[2][w] = g0 + m1 * g1; hrow[3][w] = g1;
+                    }
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        Y[tl][h][0] = hrow[h][0]; Y[tl][h][1] = hrow[h][0] + hrow[h][1]; Y[tl][h][2] = hrow[h][0] + m1 * hrow[h][1]; Y[tl][h][3] = hrow[h][1];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- 16 positions x 2 k-steps (k-step s = 2 hc + tl: lane half hf supplies tile 4 hf + s)
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                    for (int p = 0; p < 16; ++p)
+                        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y[tl][p >> 2][p & 3], X[tl][p >> 2][p & 3], acc[p], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    float* buf0 = smem;
+    float* buf1 = smem + G_BUF;
+    if (brick0 < brick1) {
+        issue(brick0, buf0);
+        __syncthreads();                     // (hipcc drains vmcnt before the barrier: the DMA has landed)
+        for (int b = brick0; b < brick1; b += 2) {
+            issue(b + 1, buf1);
+            compute(buf0);
+            __syncthreads();
+            if (b + 1 < brick1) {
+                issue(b + 2, buf0);
+                compute(buf1);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: A^T over (ph, pw) in registers.  acc[ph*4+pw][r]: row r -> co = (r&3) + 8 (r>>2) + 4 hf, column j = ci.
+    float hlf = 0.5f;
+    asm volatile("" : "+s"(hlf));
+    f32x16 o[3][3];       // [kh][kw]
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+        const f32x16 s12 = hlf * (acc[ph * 4 + 1] + acc[ph * 4 + 2]), d12 = hlf * (acc[ph * 4 + 1] + m1 * acc[ph * 4 + 2]);
+        const f32x16 c0 = acc[ph * 4 + 0] + s12, c1 = d12, c2 = s12 + m1 * acc[ph * 4 + 3];
+        // fold row ph into the kh outputs: kh0 += [1, .5, .5, 0][ph] * c,  kh1 += [0, .5, -.5, 0][ph] * c,  kh2 += [0, .5, .5, -1][ph] * c
+        if (ph == 0) { o[0][0] = c0; o[0][1] = c1; o[0][2] = c2; }
+        else if (ph == 1) {
+            o[0][0] += hlf * c0; o[0][1] += hlf * c1; o[0][2] += hlf * c2;
+            o[1][0] = hlf * c0; o[1][1] = hlf * c1; o[1][2] = hlf * c2;
+            o[2][0] = hlf * c0; o[2][1] = hlf * c1; o[2][2] = hlf * c2;
+        } else if (ph == 2) {
+            o[0][0] += hlf * c0; o[0][1] += hlf * c1; o[0][2] += hlf * c2;
+            o[1][0] += m1 * (hlf * c0); o[1][1] += m1 * (hlf * c1); o[1][2] += m1 * (hlf * c2);
+            o[2][0] += hlf * c0; o[2][1] += hlf * c1; o[2][2] += hlf * c2;
+        } else { o[2][0] += m1 * c0; o[2][1] += m1 * c1; o[2][2] += m1 * c2; }
+    }
+    // (every wave passed the loop's final barrier: the staging buffers are free)
+    float* ex = smem;     // [pd][khkw 9][r/4][lane][4]
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk)
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = o[kk / 3][kk % 3][4 * k4 + e];
+            *reinterpret_cast<f32x4*>(ex + (((wave * 9 + kk) * 4 + k4) * 64 + lane) * 4) = v;
+        }
+    __syncthreads();
+    // wave w sums the pd axis for the (kh, kw) pairs kk = w, w + 4, w + 8 and writes taps (kd, kh, kw), kd = 0..2
+    for (int kk = wave; kk < 9; kk += 4) {
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            f32x4 m[4];
+#pragma unroll
+            for (int pd = 0; pd < 4; ++pd) m[pd] = *reinterpret_cast<const f32x4*>(ex + (((pd * 9 + kk) * 4 + k4) * 64 + lane) * 4);
+            const f32x4 s12 = hlf * (m[1] + m[2]);
+            f32x4 w3[3];
+            w3[0] = m[0] + s12; w3[1] = hlf * (m[1] + m1 * m[2]); w3[2] = s12 + m1 * m[3];
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                const int tap = kd * 9 + kk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * k4 + e;
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                    a.part[(((size_t)split * 27 + tap) * a.CoPad + co0 + row) * a.CiPad + ci0 + j] = w3[kd][e];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool wgrad_use_wino(ConvKind kind) {
+    static const bool enabled = getenv("E3_WGRAD_NO_WINO") == nullptr;
+    return enabled && kind == CONV_K3;
+}
+
+int launch_wgrad_wino(WgradArgs a, int tD, int tH, int tW, int tps, int co_tiles, int ci_tiles, int splits, hipStream_t s) {
+    constexpr int lds_bytes = G_LDS_FLOATS * 4;
+    static bool set = false;
+    if (!set) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); set = true; }
+    const dim3 grid((unsigned)((size_t)splits * co_tiles * ci_tiles));
+    hipLaunchKernelGGL(wgrad_wino_kernel, grid, dim3(256), lds_bytes, s, a, tD, tH, tW, tps, co_tiles, ci_tiles);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
