@@ -406,7 +406,7 @@ bool conv_use_wino(ConvKind kind, int flags, int N, int D, int H, int W, int Cin
     static const bool enabled = getenv("E3_CONV_NO_WINO") == nullptr;
     if (!enabled || kind != CONV_K3 || (flags & (CF_SCATTER_UP | CF_GATHER_UP)) != 0 || Cin < 8 || (Cin & 7)) return false;
     const size_t grid = (size_t)wino_bricks(N, D, H, W) * ((ncols + 31) / 32);
-    return grid >= 256u;       // one workgroup per CU at least (1 wave per SIMD each)
+    return grid >= 128u;       // at least half the CUs busy: a Winograd workgroup does 3.4x less matrix work than a direct one
 }
 
 int launch_wino_pack(const float* w, float* out, int Cout, int Cin, int dgrad, hipStream_t s) {
