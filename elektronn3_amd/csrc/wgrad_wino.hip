@@ -183,20 +183,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
             }
     };
 
-    float* buf0 = smem;
-    float* buf1 = smem + G_BUF;
     if (brick0 < brick1) {
-        issue(brick0, buf0);
+        issue(brick0, smem);
         __syncthreads();                     // (hipcc drains vmcnt before the barrier: the DMA has landed)
-        for (int b = brick0; b < brick1; b += 2) {
-            issue(b + 1, buf1);
-            compute(buf0);
+        int par = 0;
+        for (int b = brick0; b < brick1; ++b) {
+            issue(b + 1, smem + (par ^ 1) * G_BUF);
+            compute(smem + par * G_BUF);
             __syncthreads();
-            if (b + 1 < brick1) {
-                issue(b + 2, buf0);
-                compute(buf1);
-                __syncthreads();
-            }
+            par ^= 1;
         }
     }
 
