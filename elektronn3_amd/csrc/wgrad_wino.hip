@@ -95,7 +95,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    auto issue = [&](int brick, float* buf) {
+    // staging of one brick, split in 4 parts so that the DMA traffic of the NEXT brick can be issued in front of each of the
+    // 4 MFMA blocks of the current one (the texture-address path moves 64 B/clk: 72 KB per brick = 1.1k cycles that would
+    // otherwise sit between the barrier and the first transform)
+    unsigned xmask = 0, gmask = 0, xbase = 0, gbase = 0;
+    auto issue_setup = [&](int brick) {
         int Lt = brick < brick1 ? brick : brick1 - 1;     // (past the end the last brick harmlessly re-stages itself)
         const int tw_ = Lt % tilesW; Lt /= tilesW; const int th_ = Lt % tilesH; Lt /= tilesH; const int td_ = Lt % tilesD; const int nb = Lt / tilesD;
         const int d0 = td_ * 2, h0 = th_ * 4, w0 = tw_ * 16;
@@ -104,92 +108,115 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
             const int first = lo < 0 ? -lo : 0, last = size - lo < n ? size - lo : n;     // valid z in [first, last)
             return last > first ? ((1u << last) - 1u) & ~((1u << first) - 1u) : 0u;
         };
-        const unsigned xmask = range_mask(d0 - 1, 4, a.D) | (range_mask(h0 - 1, 6, a.H) << 4) | (range_mask(w0 - 1, 18, a.W) << 10);
-        const unsigned gmask = range_mask(d0, 2, a.D) | (range_mask(h0, 4, a.H) << 4) | (range_mask(w0, 16, a.W) << 10);
-        const unsigned xbase = (unsigned)(((((nb * a.D + d0 - 1) * a.H + h0 - 1) * a.W + w0 - 1) * a.x_ldc) * 4);   // wraps at the borders
-        const unsigned gbase = (unsigned)(((((nb * a.D + d0) * a.H + h0) * a.W + w0) * a.dy_ldc) * 4);
+        xmask = range_mask(d0 - 1, 4, a.D) | (range_mask(h0 - 1, 6, a.H) << 4) | (range_mask(w0 - 1, 18, a.W) << 10);
+        gmask = range_mask(d0, 2, a.D) | (range_mask(h0, 4, a.H) << 4) | (range_mask(w0, 16, a.W) << 10);
+        xbase = (unsigned)(((((nb * a.D + d0 - 1) * a.H + h0 - 1) * a.W + w0 - 1) * a.x_ldc) * 4);   // wraps at the borders
+        gbase = (unsigned)(((((nb * a.D + d0) * a.H + h0) * a.W + w0) * a.dy_ldc) * 4);
+    };
+    auto issue_part = [&](int part, float* buf) {         // part 0..2: X pieces {0-5, 6-10, 11-13}, dY pieces {0-1, 2, 3}; part 3: nothing
+        // (the last MFMA block keeps the DMA queue draining: everything has landed when the brick's barrier is reached)
+        const int lo = part == 0 ? 0 : (part == 1 ? 6 : (part == 2 ? 11 : 14)), hi = part == 0 ? 6 : (part == 1 ? 11 : 14);
+        const int glo = part == 0 ? 0 : (part == 1 ? 2 : (part == 2 ? 3 : 4)), ghi = part == 0 ? 2 : (part == 1 ? 3 : 4);
 #pragma unroll
         for (int it = 0; it < G_XI; ++it) {
+            if (it < lo || it >= hi) continue;
             const int wp = it * 4 + wave < G_XW ? it * 4 + wave : G_XW - 1;
             const bool ok = (xmask & xpm[it]) == xpm[it];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(buf + wp * 256), 16, ok ? xrel[it] + xbase : OOB, 0, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < G_GI; ++it) {
+            if (it < glo || it >= ghi) continue;
             const bool ok = (gmask & gpm[it]) == gpm[it];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rs, (lds_ptr_t)(buf + G_XS + (it * 4 + wave) * 256), 16, ok ? grel[it] + gbase : OOB, 0, 0, 0);
         }
     };
 
-    // one brick = 2 tile rows (chunks) x 2 halves of 2 k-steps each
-    auto compute = [&](const float* buf) {
+    // one brick = 2 tile rows (chunks) x 2 halves of 2 k-steps each.  The LDS reads of half-chunk q+1 are issued before the
+    // MFMAs of half-chunk q (their latency hides under the matrix pipe), the transforms stay between the MFMA blocks.
+    auto compute = [&](const float* buf, float* nxt) {
+        float ra[4][6], rb[4][6], ry0[2][4], ry1[2][4];
+        auto read_raw = [&](int c, int hc) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int hc = 0; hc < 2; ++hc) {
-                // ---- X: rows h = 0..3 of the tile row, w window 8 hf + 4 hc + [0, 6) serves the lane's tiles 4 hf + 2 hc + {0, 1}
-                float u[4][6];
-#pragma unroll
-                for (int h = 0; h < 4; ++h)
-#pragma unroll
-                    for (int w = 0; w < 6; ++w) {
-                        const int off = ((2 * c + h) * G_LW + 4 * hc + w) * 32;
-                        u[h][w] = buf[xrd_a + off] + sgn * buf[xrd_b + off];
-                    }
+            for (int h = 0; h < 4; ++h)
 #pragma unroll
                 for (int w = 0; w < 6; ++w) {
-                    const float v0 = u[0][w] + m1 * u[2][w], v1 = u[1][w] + u[2][w], v2 = u[2][w] + m1 * u[1][w], v3 = u[1][w] + m1 * u[3][w];
-                    u[0][w] = v0; u[1][w] = v1; u[2][w] = v2; u[3][w] = v3;
+                    const int off = ((2 * c + h) * G_LW + 4 * hc + w) * 32;
+                    ra[h][w] = buf[xrd_a + off]; rb[h][w] = buf[xrd_b + off];
                 }
-                float X[2][4][4];                       // [tile][ph][pw]
 #pragma unroll
-                for (int tl = 0; tl < 2; ++tl)
+            for (int oh = 0; oh < 2; ++oh)
 #pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        const float* r = &u[h][2 * tl];
-                        X[tl][h][0] = r[0] + m1 * r[2]; X[tl][h][1] = r[1] + r[2]; X[tl][h][2] = r[2] + m1 * r[1]; X[tl][h][3] = r[1] + m1 * r[3];
-                    }
-                // ---- Y: dY rows oh = 0, 1 of the tile row, both d planes, w window 8 hf + 4 hc + [0, 4)
-                float g[2][4];
-#pragma unroll
-                for (int oh = 0; oh < 2; ++oh)
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const int off = ((2 * c + oh) * 16 + 4 * hc + w) * 32;
-                        g[oh][w] = ya * buf[yrd + off] + yb * buf[yrd + off + 4 * 16 * 32];
-                    }
-                float Y[2][4][4];
-#pragma unroll
-                for (int tl = 0; tl < 2; ++tl) {
-                    float hrow[4][2];
-#pragma unroll
-                    for (int w = 0; w < 2; ++w) {
-                        const float g0 = g[0][2 * tl + w], g1 = g[1][2 * tl + w];
-                        hrow[0][w] = g0; hrow[1][w] = g0 + g1; hrow[2][w] = g0 + m1 * g1; hrow[3][w] = g1;
-                    }
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        Y[tl][h][0] = hrow[h][0]; Y[tl][h][1] = hrow[h][0] + hrow[h][1]; Y[tl][h][2] = hrow[h][0] + m1 * hrow[h][1]; Y[tl][h][3] = hrow[h][1];
-                    }
+                for (int w = 0; w < 4; ++w) {
+                    const int off = ((2 * c + oh) * 16 + 4 * hc + w) * 32;
+                    ry0[oh][w] = buf[yrd + off]; ry1[oh][w] = buf[yrd + off + 4 * 16 * 32];
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- 16 positions x 2 k-steps (k-step s = 2 hc + tl: lane half hf supplies tile 4 hf + s)
+        };
+        read_raw(0, 0);
 #pragma unroll
-                for (int tl = 0; tl < 2; ++tl)
+        for (int qd = 0; qd < 4; ++qd) {
+            // ---- X: rows h = 0..3 of the tile row, w window 8 hf + 4 hc + [0, 6) serves the lane's tiles 4 hf + 2 hc + {0, 1}
+            float u[4][6];
 #pragma unroll
-                    for (int p = 0; p < 16; ++p)
-                        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y[tl][p >> 2][p & 3], X[tl][p >> 2][p & 3], acc[p], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int h = 0; h < 4; ++h)
+#pragma unroll
+                for (int w = 0; w < 6; ++w) u[h][w] = ra[h][w] + sgn * rb[h][w];
+#pragma unroll
+            for (int w = 0; w < 6; ++w) {
+                const float v0 = u[0][w] + m1 * u[2][w], v1 = u[1][w] + u[2][w], v2 = u[2][w] + m1 * u[1][w], v3 = u[1][w] + m1 * u[3][w];
+                u[0][w] = v0; u[1][w] = v1; u[2][w] = v2; u[3][w] = v3;
             }
+            float X[2][4][4];                       // [tile][ph][pw]
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const float* r = &u[h][2 * tl];
+                    X[tl][h][0] = r[0] + m1 * r[2]; X[tl][h][1] = r[1] + r[2]; X[tl][h][2] = r[2] + m1 * r[1]; X[tl][h][3] = r[1] + m1 * r[3];
+                }
+            // ---- Y: dY rows oh = 0, 1 of the tile row, both d planes, w window 8 hf + 4 hc + [0, 4)
+            float g[2][4];
+#pragma unroll
+            for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) g[oh][w] = ya * ry0[oh][w] + yb * ry1[oh][w];
+            float Y[2][4][4];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                float hrow[4][2];
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const float g0 = g[0][2 * tl + w], g1 = g[1][2 * tl + w];
+                    hrow[0][w] = g0; hrow[1][w] = g0 + g1; hrow[2][w] = g0 + m1 * g1; hrow[3][w] = g1;
+                }
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    Y[tl][h][0] = hrow[h][0]; Y[tl][h][1] = hrow[h][0] + hrow[h][1]; Y[tl][h][2] = hrow[h][0] + m1 * hrow[h][1]; Y[tl][h][3] = hrow[h][1];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            issue_part(qd, nxt);                                     // next brick's DMA and this brick's next LDS reads:
+            if (qd < 3) read_raw((qd + 1) >> 1, (qd + 1) & 1);      // in flight during the 32 MFMAs below
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- 16 positions x 2 k-steps (k-step s = 2 hc + tl: lane half hf supplies tile 4 hf + s)
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int p = 0; p < 16; ++p)
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y[tl][p >> 2][p & 3], X[tl][p >> 2][p & 3], acc[p], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     if (brick0 < brick1) {
-        issue(brick0, smem);
+        issue_setup(brick0);
+#pragma unroll
+        for (int part = 0; part < 4; ++part) issue_part(part, smem);
         __syncthreads();                     // (hipcc drains vmcnt before the barrier: the DMA has landed)
         int par = 0;
         for (int b = brick0; b < brick1; ++b) {
-            issue(b + 1, smem + (par ^ 1) * G_BUF);
-            compute(smem + par * G_BUF);
+            issue_setup(b + 1);
+            compute(smem + par * G_BUF, smem + (par ^ 1) * G_BUF);
             __syncthreads();
             par ^= 1;
         }
