@@ -222,10 +222,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 void wgeo(ConvKind kind, int& TD, int& TH) { if (kind == CONV_K3_PLANAR) { TD = 1; TH = 8; } else if (kind == CONV_K3) { TD = 2; TH = 4; } else { TD = 2; TH = 8; } }
 
-int tiles_per_split(int ntiles, int other) {
+int tiles_per_split(int ntiles, int other, int resident = 512) {
     // Two workgroups fit a CU (LDS), 256 CUs: aim at exactly 512 workgroups in total so the launch is ONE full
-    // residency round (no partially filled tail round) and the partial slabs stay small.
-    int want = 512 / (other > 0 ? other : 1);
+    // residency round (no partially filled tail round) and the partial slabs stay small.  (The Winograd kernel keeps
+    // one workgroup per CU: 256.)
+    int want = resident / (other > 0 ? other : 1);
     if (want < 1) want = 1;
     return cdiv(ntiles, want);
 }
@@ -236,7 +237,7 @@ int wgrad_splits(ConvKind kind, int N, int D, int H, int W, int Cin, int Cout) {
     int TD, TH; wgeo(kind, TD, TH);
     const int ntiles = N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, 16);
     const int other = cdiv(Cout, 32) * cdiv(Cin, 32) * (kind == CONV_POINT ? 8 : 1);   // POINT: one workgroup per tap too
-    return cdiv(ntiles, tiles_per_split(ntiles, other));
+    return cdiv(ntiles, tiles_per_split(ntiles, other, wgrad_use_wino(kind) ? 256 : 512));
 }
 
 int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s) {
@@ -245,7 +246,7 @@ int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s) {
     const int tD = cdiv(a.D, TD), tH = cdiv(a.H, TH), tW = cdiv(a.W, 16);
     const int ntiles = a.N * tD * tH * tW;
     const int co_tiles = cdiv(a.Cout, 32), ci_tiles = cdiv(a.Cin, 32);
-    const int tps = tiles_per_split(ntiles, co_tiles * ci_tiles * (kind == CONV_POINT ? 8 : 1));
+    const int tps = tiles_per_split(ntiles, co_tiles * ci_tiles * (kind == CONV_POINT ? 8 : 1), wgrad_use_wino(kind) ? 256 : 512);
     const int splits = cdiv(ntiles, tps);
     E3_REQUIRE(splits == a.splits, E3_ERR_INVALID, "wgrad: splits mismatch");
     if (kind == CONV_POINT) {
