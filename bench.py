@@ -89,10 +89,11 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from elektronn3_amd.unet import UNet
-    from oracle.torch_ref import combined_loss  # criterion only (stays PyTorch in the product too)
+    from elektronn3_amd.loss import CombinedCEDiceLoss   # the example's criterion (0.5 CE + 0.5 Dice, class weights) on device
 
     torch.manual_seed(0)                                   # identical replica on every rank
     model = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=32, normalization='batch').to(dev).train()
+    criterion = CombinedCEDiceLoss(weight=[0.2653, 0.7347]).to(dev)
     sync = None
     if world > 1 or (dist is not None):
         from elektronn3_amd.dataparallel import GradSync
@@ -108,7 +109,7 @@ def main():
 
     def step():
         out = model(x)
-        loss = combined_loss(out, tgt)
+        loss = criterion(out, tgt)
         for p in model.parameters():
             p.grad = None
         loss.backward()

@@ -30,6 +30,7 @@ class UNetCfg(ctypes.Structure):
 
 _P = c_void_p  # device pointer
 _I = c_int
+_F = c_float
 _SIG = {
     'e3_last_error': (c_char_p, []),
     'e3_version': (c_char_p, []),
@@ -69,6 +70,9 @@ _SIG = {
     'e3_conv1_fwd': (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     'e3_conv1_bwd_workspace_bytes': (c_size_t, [_I, _I, _I, _I, _I, _I]),
     'e3_conv1_bwd': (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, c_size_t]),
+    'e3_ce_dice_workspace_bytes': (c_size_t, [_I]),
+    'e3_ce_dice_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _P, c_size_t, _P]),
+    'e3_ce_dice_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, c_size_t, _P, _P]),
     'e3_ncdhw_to_ndhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
     'e3_ndhwc_to_ncdhw': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I]),
 }

@@ -210,6 +210,21 @@ int e3_bn_relu_bwd(void* stream, const float* x, int x_ldc, const float* mean, c
     return rc;
 }
 
+// ---------------------------------------------------------------------------------------------- criterion
+size_t e3_ce_dice_workspace_bytes(int C) { return align_up(ce_dice_workspace_floats(C) * sizeof(float), 256); }
+
+int e3_ce_dice_fwd(void* stream, const float* logits, const long long* target, const float* w, int C, int N, int D, int H, int W,
+                   float ce_weight, float dice_weight, float eps, float smooth, void* workspace, size_t workspace_bytes, float* loss_out) {
+    E3_REQUIRE(workspace_bytes >= e3_ce_dice_workspace_bytes(C), E3_ERR_WORKSPACE, "ce_dice workspace too small");
+    return launch_ce_dice_fwd(logits, target, w, C, N, (size_t)D * H * W, ce_weight, dice_weight, eps, smooth, (float*)workspace, loss_out, (hipStream_t)stream);
+}
+
+int e3_ce_dice_bwd(void* stream, const float* logits, const long long* target, const float* w, int C, int N, int D, int H, int W,
+                   const void* workspace, size_t workspace_bytes, const float* gout, float* dlogits) {
+    E3_REQUIRE(workspace_bytes >= e3_ce_dice_workspace_bytes(C), E3_ERR_WORKSPACE, "ce_dice workspace too small");
+    return launch_ce_dice_bwd(logits, target, w, C, N, (size_t)D * H * W, (const float*)workspace, gout, dlogits, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------- final 1x1x1 conv
 int e3_conv1_fwd(void* stream, const float* a, int a_ldc, int C, const float* w, const float* bias, float* y_ncdhw,
                  int Cout, int N, int D, int H, int W, int softmax) {

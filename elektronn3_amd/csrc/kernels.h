@@ -88,6 +88,13 @@ int conv_final_bwd_parts(size_t total_voxels);
 int launch_conv_final_bwd(const float* a, int a_ldc, int C, const float* w, const float* dy_ncdhw, float* da, int da_ldc,
                           float* part /*[parts][Cout][C+1]*/, int Cout, size_t voxels_per_sample, int N, hipStream_t s);
 
+// ---------------------------------------------------------------- weighted CE + Dice criterion (loss.hip)
+size_t ce_dice_workspace_floats(int C);
+int launch_ce_dice_fwd(const float* logits, const long long* target, const float* w, int C, int N, size_t vps, float a, float b,
+                       float eps, float smooth, float* workspace, float* loss_out, hipStream_t s);
+int launch_ce_dice_bwd(const float* logits, const long long* target, const float* w, int C, int N, size_t vps,
+                       const float* workspace, const float* gout, float* dlogits, hipStream_t s);
+
 // ---------------------------------------------------------------- wgrad on f32 MFMA
 struct WgradArgs {
     const float* x; int x_ldc; int Cin;     // conv input activation view

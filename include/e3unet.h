@@ -178,6 +178,18 @@ size_t e3_conv1_bwd_workspace_bytes(int C, int Cout, int N, int D, int H, int W)
 int e3_conv1_bwd(void* stream, const float* a, int a_ldc, int C, const float* w, const float* dy_ncdhw, float* da, int da_ldc,
                  float* dw, float* db, int Cout, int N, int D, int H, int W, void* workspace, size_t workspace_bytes);
 
+/* Criterion of the reference's training example on device:
+ *   loss = ce_weight * CrossEntropyLoss(weight=w)(logits, target) + dice_weight * DiceLoss(apply_softmax=True, weight=w, smooth)(logits, target)
+ * [elektronn3/modules/loss.py:19-49 CombinedLoss, :158-189 dice_loss (eps = 1e-4), :192-234 DiceLoss; examples/train_unet_neurodata.py:294-296].
+ * logits/dlogits: fp32 NCDHW (N, C, D, H, W), 2 <= C <= 8; target: int64 (N, D, H, W) class indices; w: [C] or NULL (all ones).
+ * The forward writes the scalar loss to loss_out (device) and leaves the coefficients of the backward in `workspace`
+ * (e3_ce_dice_workspace_bytes(C) bytes, to be passed unchanged to e3_ce_dice_bwd); gout: device scalar dL/dloss or NULL (= 1). */
+size_t e3_ce_dice_workspace_bytes(int C);
+int e3_ce_dice_fwd(void* stream, const float* logits, const long long* target, const float* w, int C, int N, int D, int H, int W,
+                   float ce_weight, float dice_weight, float eps, float smooth, void* workspace, size_t workspace_bytes, float* loss_out);
+int e3_ce_dice_bwd(void* stream, const float* logits, const long long* target, const float* w, int C, int N, int D, int H, int W,
+                   const void* workspace, size_t workspace_bytes, const float* gout, float* dlogits);
+
 /* Layout conversion at the module boundary. */
 int e3_ncdhw_to_ndhwc(void* stream, const float* src, float* dst, int N, int C, int D, int H, int W);
 int e3_ndhwc_to_ncdhw(void* stream, const float* src, int src_ldc, float* dst, int N, int C, int D, int H, int W);

@@ -303,3 +303,44 @@ dist.destroy_process_group()
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     res = json.loads(line)
     assert res['n_gpus'] == 1 and res['value'] > 1e6 and res['roofline']['achieved'] > 10
+
+
+# ------------------------------------------------------------------------------------------------ device criterion
+@pytest.mark.gpu
+@pytest.mark.parametrize('C,shape,weighted', [(2, (2, 9, 17, 21), True), (4, (1, 8, 16, 16), True), (3, (3, 5, 6, 7), False)])
+def test_ce_dice_loss_matches_reference_criterion(C, shape, weighted):
+    """CombinedCEDiceLoss == 0.5*CrossEntropyLoss(w) + 0.5*DiceLoss(softmax, w) of the reference (numpy fp64 restatement
+    tests/helpers.combined_loss_np for the value; PyTorch autograd of the same formula in fp64 for the gradient)."""
+    import torch
+    from elektronn3_amd.loss import CombinedCEDiceLoss
+    from helpers import combined_loss_np
+    rng = np.random.default_rng(7 + C)
+    n = shape[0]
+    z = (rng.standard_normal((n, C) + shape[1:]) * 2).astype(np.float32)
+    t = rng.integers(0, C, (n,) + shape[1:]).astype(np.int64)
+    w = (rng.random(C) + 0.2).astype(np.float32) if weighted else None
+    crit = CombinedCEDiceLoss(weight=w).cuda()
+    zt = torch.from_numpy(z).cuda().requires_grad_(True)
+    loss = crit(zt, torch.from_numpy(t).cuda())
+    (loss * 1.7).backward()
+    # fp64 reference with autograd
+    zr = torch.from_numpy(z).double().requires_grad_(True)
+    tr = torch.from_numpy(t)
+    wr = torch.ones(C, dtype=torch.float64) if w is None else torch.from_numpy(w).double()
+    ce = torch.nn.functional.cross_entropy(zr, tr, weight=wr)
+    p = torch.softmax(zr, 1)
+    oh = torch.zeros_like(p).scatter_(1, tr.unsqueeze(1), 1)
+    dims = (0,) + tuple(range(2, zr.dim()))
+    dice = (wr * (1 - 2 * (p * oh).sum(dims) / ((p + oh).sum(dims) + 1e-4))).mean()
+    lref = 0.5 * ce + 0.5 * dice
+    (lref * 1.7).backward()
+    assert abs(float(loss) - float(lref)) < 2e-6 * max(1.0, abs(float(lref)))
+    g, gr = zt.grad.cpu().numpy(), zr.grad.numpy()
+    assert np.abs(g - gr).max() < 2e-6 * np.abs(gr).max() + 1e-10
+    if w is not None:      # the numpy restatement used by the whole-net tests agrees as well
+        lnp, gnp = combined_loss_np(z, t, w)
+        assert abs(float(loss) - lnp) < 2e-6 * max(1.0, abs(lnp))
+        assert np.abs(g - 1.7 * gnp).max() < 2e-6 * np.abs(gnp).max() * 1.7 + 1e-10
+    # deterministic (fixed reduction order)
+    loss2 = crit(zt.detach(), torch.from_numpy(t).cuda())
+    assert float(loss2) == float(loss)
