@@ -25,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('dirs', nargs='+')
     ap.add_argument('-o', '--out')
-    ap.add_argument('--filter', default='conv_mfma|wgrad_conv|wgrad_point|conv_small|conv_final|bn_')
+    ap.add_argument('--filter', default='conv3_wino|wgrad_wino|conv3_v3|conv_mfma|wgrad_conv|wgrad_point|conv_small|conv_final|bn_')
     a = ap.parse_args()
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in a.dirs:
