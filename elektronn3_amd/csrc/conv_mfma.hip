@@ -264,7 +264,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     // ---- epilogue: bias (+ folded BN + ReLU in eval mode), store, per-tile channel statistics
     const bool do_stats = a.stats != nullptr;
     const bool aff = a.epi_scale != nullptr;
-    if (do_stats) __syncthreads();   // all waves are done reading LDS: it is reused as scratch below
+    // Wide stores (KS == 1): the accumulator layout gives a lane ONE channel of 32 voxels = 32 dword stores per tile, which is
+    // store-issue bound (measured: the transposed-conv forward spent 2/3 of its time here).  Transposed through a per-wave
+    // 64x32 LDS tile each lane instead writes 4 consecutive channels of 8 voxels (8 dwordx4 stores, whole 128-B voxel rows).
+    // Needs a 32-column tile that lies inside one tap's channel range.
+    const bool wide = KS == 1 && (a.Cout & 31) == 0 && (a.y_ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
+    constexpr int EPI_SCR = 4 * NT * 32 * 3;             // statistics scratch floats in front of the store tiles
+    if (do_stats || wide) __syncthreads();   // all waves are done reading LDS: it is reused as scratch below
 #pragma unroll
     for (int ns = 0; ns < NT; ++ns) {
         const int n = n0 + 32 * ns + j;
@@ -276,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         if (aff && nvalid) { es = a.epi_scale[co]; eh = a.epi_shift[co]; }
         float cnt = 0.f, sum = 0.f;
         unsigned okmask = 0u;
+        float* tile = smem + EPI_SCR + wave * (64 * 32);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             if (!owns[s][ns]) continue;
@@ -297,11 +304,35 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                 if (aff) v = fmaxf(__builtin_fmaf(v, es, eh), 0.f);
                 acc[s][ns][r] = v;
                 if (ok && (a.flags & 512)) ok = (v == 12345.678f);   // flag 512: timing ablation (skip the stores)
+                if (wide) tile[(s * 32 + row) * 32 + j] = v;
                 if (ok) {
-                    a.y[off] = v;
+                    if (!wide) a.y[off] = v;
                     cnt += 1.f; sum += v;
                     okmask |= 1u << (s * 16 + r);
                 }
+            }
+        }
+        if (wide) {      // (same wave wrote the tile: LDS operations of one wave are ordered, no barrier needed)
+            const int nt0 = n0 + 32 * ns;                 // first column of the tile (wave-uniform)
+            int c0 = nt0, wtd = 0, wth = 0, wtw = 0;
+            if (scatter) { const int wt = nt0 / a.Cout; c0 = nt0 - wt * a.Cout; wtw = wt & 1; wth = (wt >> 1) & 1; wtd = wt >> 2; }
+            const int c4 = 4 * (lane & 7);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int trow = 8 * p + (lane >> 3);
+                const int m = rowbase + trow;
+                const int gw = w0 + (m & 15), gh = h0 + (m >> 4) % TH, gd = d0 + (m >> 4) / TH;
+                bool ok = nt0 + c4 < a.Ncols && gd < a.D && gh < a.H && gw < a.W && !(a.flags & 512);
+                size_t off;
+                if (scatter) {
+                    const int od = a.sd * gd + wtd, oh = 2 * gh + wth, ow = 2 * gw + wtw;
+                    ok = ok && od < a.Do && oh < a.Ho && ow < a.Wo;
+                    off = ((((size_t)nb * a.Do + od) * a.Ho + oh) * a.Wo + ow) * a.y_ldc + c0 + c4;
+                } else {
+                    off = ((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.y_ldc + c0 + c4;
+                }
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tile + trow * 32 + c4);
+                if (ok) *reinterpret_cast<f32x4*>(a.y + off) = v;
             }
         }
         if (do_stats) {
@@ -348,7 +379,7 @@ int launch_inst(ConvArgs a, hipStream_t s) {
     a.ntiles = a.NPad / (32 * NT);
     const size_t nblk = (size_t)a.N * a.tilesD * a.tilesH * a.tilesW * a.ntiles;
     E3_REQUIRE(nblk > 0 && nblk < (1u << 31), E3_ERR_INVALID, "conv grid out of range");
-    constexpr int scratch = KS == 4 ? 4 * 2 * NT * 16 * 64 : 4 * NT * 32 * 3;
+    constexpr int scratch = KS == 4 ? 4 * 2 * NT * 16 * 64 : 4 * NT * 32 * 3 + 4 * 64 * 32;   // KS == 1: statistics scratch + one 64x32 store tile per wave
     constexpr int lds_bytes = (G::LDS_FLOATS > scratch ? G::LDS_FLOATS : scratch) * 4;
     auto kern = conv_mfma_kernel<KD, KHW, TD, TH, TW, CK, NT, KS>;
     static bool attr_set = false;
@@ -403,6 +434,7 @@ int conv_col_tile(int ncols) { return ncols >= 64 ? 64 : 32; }
 
 int conv_stats_parts(ConvKind kind, int flags, int N, int D, int H, int W, int sd, int Cin, int ncols) {
     if (conv_use_wino(kind, flags, N, D, H, W, Cin, ncols)) return wino_bricks(N, D, H, W);
+    if (kind == CONV_POINT && (flags & CF_SCATTER_UP) && upconv_gemm_ok(flags, Cin, ncols / (sd * 4), ncols)) return upconv_stats_parts(N, D, H, W, sd);
     int ks, nt; conv_decomposition(kind, flags, N, D, H, W, Cin, ncols, &ks, &nt);
     const Brick b = brick_of(kind, ks);
     int parts = N * cdiv(D, b.TD) * cdiv(H, b.TH) * cdiv(W, 16);
@@ -419,6 +451,7 @@ int launch_conv_mfma(ConvKind kind, ConvArgs a, hipStream_t s) {
         E3_REQUIRE(vin * (size_t)a.x_ldc < ((size_t)1 << 31), E3_ERR_UNSUPPORTED, "conv input view exceeds 2^31 elements (32-bit offsets)");
     }
     if (a.G <= 0) a.G = 1;
+    if (kind == CONV_POINT && upconv_gemm_ok(a.flags, a.Cin, a.Cout, a.Ncols)) return launch_upconv_gemm(a, s);   // upconv_gemm.hip
     if (conv_use_wino(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols)) return launch_conv3_wino(a, s);   // a.wt packed by launch_pack_conv_auto
     int ks, nt; conv_decomposition(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols, &ks, &nt);
     static const bool use_v3 = getenv("E3_CONV_NO_V3") == nullptr;   // debug switch: fall back to the global-B kernel

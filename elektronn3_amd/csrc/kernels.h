@@ -51,6 +51,10 @@ size_t conv_packed_floats(ConvKind kind, int K, int ncols);
 // packs torch (Cout,Cin,T) weights for the forward (dgrad = 0) or the input-gradient (dgrad = 1) launch of a conv over
 // an (N,D,H,W) grid, in the layout of the algorithm conv_use_wino() selects
 int launch_pack_conv_auto(ConvKind kind, int dgrad, const float* w, float* out, int Cout, int Cin, int N, int D, int H, int W, hipStream_t s);
+// transposed conv (POINT + SCATTER_UP / GATHER_UP) as a plain LDS-tiled GEMM (upconv_gemm.hip); Cx = channels per voxel of x
+bool upconv_gemm_ok(int flags, int Cx, int Cout, int ncols);
+int upconv_stats_parts(int N, int D, int H, int W, int sd);
+int launch_upconv_gemm(ConvArgs a, hipStream_t s);
 int conv_col_tile(int ncols);  // 32 or 64: column tile the launcher will use for `ncols` GEMM columns
 
 // ---------------------------------------------------------------- weight packing
