@@ -78,10 +78,16 @@ __global__ void ce_dice_finalize_kernel(const float* __restrict__ partial, int b
                                         float a, float b, float eps, float smooth, float* __restrict__ out, float* __restrict__ coef) {
     __shared__ double s[2 + 3 * LOSS_MAXC];
     const int NV = 2 + 3 * C;
-    if ((int)threadIdx.x < NV) {
-        double t = 0.0;
-        for (int k = 0; k < blocks; ++k) t += (double)partial[(size_t)k * NV + threadIdx.x];
-        s[threadIdx.x] = t;
+    // one wave per value (16 waves take the NV <= 26 values in turn): 64 lanes stride over the block partials, fp64 butterfly
+    {
+        const int lane = threadIdx.x & 63;
+        for (int v = threadIdx.x >> 6; v < NV; v += (int)(blockDim.x >> 6)) {
+            double t = 0.0;
+            for (int k = lane; k < blocks; k += 64) t += (double)partial[(size_t)k * NV + v];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+            if (lane == 0) s[v] = t;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -151,7 +157,7 @@ int launch_ce_dice_fwd(const float* logits, const long long* target, const float
     float* partial = workspace;
     float* coef = workspace + (size_t)LOSS_BLOCKS * (2 + 3 * C);
     LOSS_DISPATCH(ce_dice_fwd_kernel, logits, target, w, N, vps, partial)
-    hipLaunchKernelGGL(ce_dice_finalize_kernel, dim3(1), dim3(64), 0, s, partial, LOSS_BLOCKS, C, w, a, b, eps, smooth, loss_out, coef);
+    hipLaunchKernelGGL(ce_dice_finalize_kernel, dim3(1), dim3(1024), 0, s, partial, LOSS_BLOCKS, C, w, a, b, eps, smooth, loss_out, coef);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
