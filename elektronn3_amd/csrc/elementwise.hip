@@ -50,35 +50,44 @@ __global__ void pack_weights_kernel(int mode, const float* __restrict__ w, float
     }
 }
 
-// ------------------------------------------------------------------ BN finalise (one 256-thread workgroup per channel)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const BnFinalizeArgs a) {
-    __shared__ double sh[4][3];
+// ------------------------------------------------------------------ BN finalise (one 1024-thread workgroup per channel)
+// Merges the per-tile (count, mean, M2) records of a channel in fp64, two division-free passes over the (L2-resident)
+// records:  N = sum n_i,  mu = sum n_i mean_i / N;  M2 = sum [ M2_i + n_i (mean_i - mu)^2 ].  Fixed order: deterministic.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const BnFinalizeArgs a) {
+    __shared__ double sh[16][2];
+    __shared__ double bc[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x;
-    // Chan merge in double: each thread folds a strided subset of the per-tile records, then butterflies
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int p = threadIdx.x; p < a.parts; p += 256) {
+    auto block_sum2 = [&](double& x, double& y) {          // sums x and y over the workgroup, result in every thread
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { x += __shfl_xor(x, off); y += __shfl_xor(y, off); }
+        __syncthreads();                                    // (protects sh/bc against the previous use)
+        if (lane == 0) { sh[wave][0] = x; sh[wave][1] = y; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double sx = 0.0, sy = 0.0;
+            for (int w = 0; w < 16; ++w) { sx += sh[w][0]; sy += sh[w][1]; }
+            bc[0] = sx; bc[1] = sy;
+        }
+        __syncthreads();
+        x = bc[0]; y = bc[1];
+    };
+    double n = 0.0, s1 = 0.0;
+    for (int p = threadIdx.x; p < a.parts; p += 1024) {
         const float* r = a.stats + ((size_t)p * a.C + c) * 3;
         const double nb = r[0];
-        if (nb > 0.0) {
-            const double d = (double)r[1] - mean, nn = n + nb;
-            mean += d * nb / nn; m2 += (double)r[2] + d * d * n * nb / nn; n = nn;
-        }
+        n += nb; s1 += nb * (double)r[1];
     }
-    auto merge = [&](double nb, double mb, double sb) {
-        const double nn = n + nb;
-        if (nn > 0.0) {
-            const double d = mb - mean;
-            const double mnew = mean + d * nb / nn;
-            const double snew = m2 + sb + d * d * n * nb / nn;
-            mean = mnew; m2 = snew; n = nn;
-        }
-    };
-    for (int off = 32; off >= 1; off >>= 1) merge(__shfl_xor(n, off), __shfl_xor(mean, off), __shfl_xor(m2, off));
-    if (lane == 0) { sh[wave][0] = n; sh[wave][1] = mean; sh[wave][2] = m2; }
-    __syncthreads();
+    block_sum2(n, s1);
+    const double mean = n > 0.0 ? s1 / n : 0.0;
+    double m2 = 0.0, unused = 0.0;
+    for (int p = threadIdx.x; p < a.parts; p += 1024) {
+        const float* r = a.stats + ((size_t)p * a.C + c) * 3;
+        const double nb = r[0], d = (double)r[1] - mean;
+        m2 += nb > 0.0 ? (double)r[2] + nb * d * d : 0.0;
+    }
+    block_sum2(m2, unused);
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) merge(sh[w][0], sh[w][1], sh[w][2]);
         const double var = n > 0.0 ? m2 / n : 0.0;
         const double invstd = 1.0 / sqrt(var + (double)a.eps);
         const double g = a.gamma ? (double)a.gamma[c] : 1.0, b = a.beta ? (double)a.beta[c] : 0.0;
@@ -321,7 +330,7 @@ int launch_pack_weights(PackMode mode, const float* w, float* out, int Cout, int
 }
 
 int launch_bn_finalize(BnFinalizeArgs a, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(1024), 0, s, a);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
