@@ -26,19 +26,20 @@ namespace {
 
 constexpr int W_LD = 6, W_LH = 6, W_LW = 18;               // halo of a 4x4x16 brick
 constexpr int W_NVOX = W_LD * W_LH * W_LW;                  // 648
-constexpr int W_AI = (W_NVOX * 2 + 255) / 256;              // 16-B pieces per thread and chunk (6)
-constexpr int W_CLASS = 96;                                 // voxel slots per parity class (3 x 32 >= 2*32 + 2*9 + 9)
-constexpr int W_RAW = 8 * W_CLASS * 8;                      // floats of one raw buffer (6144)
-constexpr int W_PADF = (W_AI * 256 - W_NVOX * 2) * 4;       // landing zone of the pieces beyond the halo
-constexpr int W_BUF = W_RAW + W_PADF;                       // floats per buffer incl. pad
+constexpr int W_AI = W_LD;                                  // one thread stages one (zh, zw, 16-B half) column: 6 d-planes
+constexpr int W_CLASS = 32;                                 // slots per (zh, zw) parity class of a plane (3 x 9 = 27 used)
+constexpr int W_PLANE = 4 * W_CLASS * 8;                    // floats of one D-transformed plane (1024)
+constexpr int W_BUF = 8 * W_PLANE;                          // 8 planes (td, pd) per buffer: 32 KB
 constexpr int W_EX = 4 * 16 * 64 * 4;                       // epilogue exchange [pd][e4][lane][4] floats (64 KB)
-constexpr int W_LDS_FLOATS = (2 * W_BUF > W_EX + 4 * 32 * 3 ? 2 * W_BUF : W_EX + 4 * 32 * 3);
+constexpr int W_LDS_FLOATS = (2 * W_BUF > W_EX + 4 * 32 * 3 ? 2 * W_BUF : W_EX + 4 * 32 * 3);   // 64 KB + statistics scratch
 
-// LDS float offset of halo voxel (zd, zh, zw), 16-B piece q: parity classes keep the stride-2 tile origins contiguous,
-// the piece is XOR-ed with bit 0 of zh/2 so that each ds_read_b128 lane group covers all 64 banks.
-__device__ __forceinline__ int raw_slot(int zd, int zh, int zw, int q) {
-    const int k = (zd & 1) * 4 + (zh & 1) * 2 + (zw & 1);
-    const int slot = k * W_CLASS + (zd >> 1) * 32 + (zh >> 1) * 9 + (zw >> 1);
+// The LDS image holds the halo ALREADY TRANSFORMED ALONG D: plane (td, pd) = row pd of B^T applied to the 4 d-planes of
+// tile depth td (the staging thread of a (zh, zw) column has all 6 d-values in registers, so this costs 8 packed ops per
+// column instead of a D pass in every wave, and halves the LDS reads of the transform).  Float offset of (zh, zw), 16-B
+// piece q inside a plane: parity classes keep the stride-2 tile origins contiguous, the piece is XOR-ed with bit 0 of
+// zh/2 so that each ds_read_b128 lane group covers all 64 banks.
+__device__ __forceinline__ int plane_slot(int zh, int zw, int q) {
+    const int slot = ((zh & 1) * 2 + (zw & 1)) * W_CLASS + (zh >> 1) * 9 + (zw >> 1);
     return slot * 8 + 4 * (q ^ ((zh >> 1) & 1));
 }
 
@@ -79,41 +80,31 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
         const_cast<float*>(a.wt) + ((size_t)ntile * NCH * 64 + wave * 16) * 256, 0, NCH * 64 * 1024, 0x00020000);
     const int b_voff = lane * 16;
 
-    // ---- staging plan: piece idx = tid + 256 it -> (halo voxel, 16-B half)
-    unsigned a_src[W_AI]; int a_dst[W_AI];
+    // ---- staging plan: thread -> column (zh, zw, 16-B half q) of the halo, all 6 d-planes (threads 216..255 idle)
+    const bool col_on = tid < W_LH * W_LW * 2;
+    const int cq = tid & 1, czw = (tid >> 1) % W_LW, czh = (tid >> 1) / W_LW;
+    const int cgh = h0 + czh - 1, cgw = w0 + czw - 1;
+    const bool col_ok = col_on && cgh >= 0 && cgh < a.H && cgw >= 0 && cgw < a.W;
+    unsigned a_src[W_AI];
     unsigned a_ok = 0;
 #pragma unroll
-    for (int it = 0; it < W_AI; ++it) {
-        const int idx = tid + it * 256;
-        const int v = idx >> 1, q = idx & 1;
-        const int zw = v % W_LW; const int t2 = v / W_LW; const int zh = t2 % W_LH; const int zd = t2 / W_LH;
-        const int gd = d0 + zd - 1, gh = h0 + zh - 1, gw = w0 + zw - 1;
-        const bool inb = v < W_NVOX;
-        const bool ok = inb && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-        a_src[it] = ok ? (unsigned)(((((gd - dlo) * a.H + gh) * a.W + gw) * a.x_ldc + 4 * q) * 4) : OOB;
-        a_dst[it] = inb ? raw_slot(zd, zh, zw, q) : W_RAW + (idx - W_NVOX * 2) * 4;
-        a_ok |= (ok ? 1u : 0u) << it;
+    for (int zd = 0; zd < W_AI; ++zd) {
+        const int gd = d0 + zd - 1;
+        const bool ok = col_ok && gd >= 0 && gd < a.D;
+        a_src[zd] = ok ? (unsigned)(((((gd - dlo) * a.H + cgh) * a.W + cgw) * a.x_ldc + 4 * cq) * 4) : OOB;
+        a_ok |= (ok ? 1u : 0u) << zd;
     }
+    const int a_dst = col_on ? plane_slot(czh, czw, cq) : 0;
 
-    // ---- read plan of lane (tile i = j, half hf): tile (td, th, tw) = (j >> 4, (j >> 3) & 1, j & 7)
-    // D pass of Winograd row pd = wave:  0: x0 - x2   1: x1 + x2   2: x2 - x1   3: x1 - x3
-    const int da = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
-    const int db = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
-    const float sgn = wave == 1 ? 1.f : -1.f;
+    // ---- read plan of lane (tile i = j, half hf): tile (td, th, tw) = (j >> 4, (j >> 3) & 1, j & 7), plane (td, pd = wave)
     float m1 = -1.f;
     asm volatile("" : "+s"(m1));     // opaque -1: a + m1*b becomes v_pk_fma_f32 (hipcc only packs fadd/ffma, never fsub)
     const int ttd = j >> 4, tth = (j >> 3) & 1, ttw = j & 7;
-    const int lbase = (ttd * 32 + tth * 9 + ttw) * 8;
-    const int offA = (((da & 1) * 4) * W_CLASS + (da >> 1) * 32) * 8;
-    const int offB = (((db & 1) * 4) * W_CLASS + (db >> 1) * 32) * 8;
+    const int lbase = (ttd * 4 + wave) * W_PLANE + (tth * 9 + ttw) * 8;
     // rows h = 0,1 of the tile have zh/2 = th, rows 2,3 have th + 1: the swizzle bit differs between the two
-    int rdA[2], rdB[2];
+    int rdA[2];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        const int pc = 4 * (hf ^ ((tth + hh) & 1));
-        rdA[hh] = lbase + offA + pc;
-        rdB[hh] = lbase + offB + pc;
-    }
+    for (int hh = 0; hh < 2; ++hh) rdA[hh] = lbase + 4 * (hf ^ ((tth + hh) & 1));
 
     f32x16 acc[16];
 #pragma unroll
@@ -134,20 +125,26 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
             xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, a_src[it], cb * 4, 0));
     };
     auto write_raw = [&](float* buf, int cb) {
-        f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
-        if (PRO) {
-            psc = *reinterpret_cast<const f32x4*>(a.pro_scale + cb + 4 * (tid & 1));
-            psh = *reinterpret_cast<const f32x4*>(a.pro_shift + cb + 4 * (tid & 1));
-        }
+        if (PRO) {                             // BN + ReLU of the producer applied while staging; the padding stays 0
+            const f32x4 psc = *reinterpret_cast<const f32x4*>(a.pro_scale + cb + 4 * cq);
+            const f32x4 psh = *reinterpret_cast<const f32x4*>(a.pro_shift + cb + 4 * cq);
 #pragma unroll
-        for (int it = 0; it < W_AI; ++it) {
-            f32x4 v = xr[it];
-            if (PRO) {                         // BN + ReLU of the producer applied while staging; the padding stays 0
-                const bool ok = (a_ok >> it) & 1u;
+            for (int zd = 0; zd < W_AI; ++zd) {
+                const bool ok = (a_ok >> zd) & 1u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ok ? fmaxf(__builtin_fmaf(v[e], psc[e], psh[e]), 0.f) : 0.f;
+                for (int e = 0; e < 4; ++e) xr[zd][e] = ok ? fmaxf(__builtin_fmaf(xr[zd][e], psc[e], psh[e]), 0.f) : 0.f;
             }
-            *reinterpret_cast<f32x4*>(buf + a_dst[it]) = v;
+        }
+        if (col_on) {
+            // D pass of B^T for the two tile depths: rows  x0 - x2,  x1 + x2,  x2 - x1,  x1 - x3  of planes (0..3) and (2..5)
+#pragma unroll
+            for (int td = 0; td < 2; ++td) {
+                const f32x4 x0 = xr[2 * td], x1 = xr[2 * td + 1], x2 = xr[2 * td + 2], x3 = xr[2 * td + 3];
+                *reinterpret_cast<f32x4*>(buf + (td * 4 + 0) * W_PLANE + a_dst) = x0 + m1 * x2;
+                *reinterpret_cast<f32x4*>(buf + (td * 4 + 1) * W_PLANE + a_dst) = x1 + x2;
+                *reinterpret_cast<f32x4*>(buf + (td * 4 + 2) * W_PLANE + a_dst) = x2 + m1 * x1;
+                *reinterpret_cast<f32x4*>(buf + (td * 4 + 3) * W_PLANE + a_dst) = x1 + m1 * x3;
+            }
         }
     };
     auto load_B = [&](int c, int g) {
@@ -161,16 +158,14 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
         const int cn = c + 1 < NCH ? c + 1 : c;     // (the last chunk harmlessly re-stages itself: no branch in the loop body)
         if (c == 1) stamp();
         issue_raw(cn * 8);
-        // ---- B^T d B of this lane's tile, 4 channels at a time (f32x4 = the 4 k-steps of the chunk)
+        // ---- H and W passes of B^T d B on this lane's tile of plane (td, pd), 4 channels at a time (f32x4 = the 4 k-steps)
         f32x4 t[4][4];
 #pragma unroll
         for (int h = 0; h < 4; ++h)
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const int imm = (((h & 1) * 2 + (w & 1)) * W_CLASS + (h >> 1) * 9 + (w >> 1)) * 8;
-                const f32x4 xa = *reinterpret_cast<const f32x4*>(cur + rdA[h >> 1] + imm);
-                const f32x4 xb = *reinterpret_cast<const f32x4*>(cur + rdB[h >> 1] + imm);
-                t[h][w] = xa + sgn * xb;
+                t[h][w] = *reinterpret_cast<const f32x4*>(cur + rdA[h >> 1] + imm);
             }
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
