@@ -312,7 +312,10 @@ int launch_conv_small_fwd(ConvSmallArgs a, hipStream_t s) {
     const int tD = cdiv(a.D, TD), tH = cdiv(a.H, TH), tW = cdiv(a.W, 16);
     const int KD = a.planar ? 1 : 3;
     const int NV = (TD + (a.planar ? 0 : 2)) * (TH + 2) * 18;
-    const size_t lds = (size_t)(((a.Cin * NV + 3) & ~3) + a.Cin * KD * 9 * 32) * 4;
+    // the weight slab is reused as the statistics scratch [4 waves][32][3]: planar convs with one input channel have only
+    // 288 floats of weights (this under-allocation corrupted the BN statistics of a planar first conv with > 16 channels)
+    const int wslab = a.Cin * KD * 9 * 32 > 4 * 32 * 3 ? a.Cin * KD * 9 * 32 : 4 * 32 * 3;
+    const size_t lds = (size_t)(((a.Cin * NV + 3) & ~3) + wslab) * 4;
     const dim3 grid((unsigned)((size_t)a.N * tD * tH * tW)), block(256);
     if (a.planar) hipLaunchKernelGGL((conv_small_fwd_kernel<1, 1, 16>), grid, block, lds, s, a, tD, tH, tW);
     else hipLaunchKernelGGL((conv_small_fwd_kernel<3, 2, 8>), grid, block, lds, s, a, tD, tH, tW);

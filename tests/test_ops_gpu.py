@@ -142,6 +142,7 @@ CONV_CASES = [
     (64, 32, (2, 20, 33), True, 2),      # planar 1x3x3
     (1, 32, (5, 9, 19), False, 2),       # first layer (direct kernel)
     (2, 16, (4, 6, 7), True, 1),         # direct kernel, 2 input channels, planar
+    (1, 64, (3, 20, 33), True, 2),       # direct kernel, planar, 2 passes of 32 channels (statistics scratch > weight slab)
     (128, 64, (4, 8, 16), False, 1),     # small grid -> intra-workgroup split-K (KS=4), NT=1
     (64, 128, (8, 16, 32), False, 2),    # KS=4 with NT=2 (the bottom-level shapes of cfg 2)
     (64, 32, (3, 5, 7), False, 1),       # KS=4, partial 64-voxel bricks in every dim

@@ -210,6 +210,37 @@ def test_full_size_cfg2_against_pytorch_rocm(cfg2):
         assert err < 2e-2, (k, err)
 
 
+def test_full_size_cfg4_anisotropic_against_pytorch_rocm():
+    """BASELINE.json configs[3] (anisotropic UNet, planar_blocks=(0,1), start_filts=64) on a 16x128x128 crop (a quarter of
+    the 32x256x256 of the config in every direction: MIOpen needs minutes to pick kernels for the full size) -- mixed
+    1x3x3 / 3x3x3 convs, (1,2,2) pooling and transposed convs -- vs PyTorch-ROCm on the same weights."""
+    from elektronn3_amd.unet import UNet
+    from oracle.torch_ref import combined_loss, unet_forward
+    torch.manual_seed(3)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=64, planar_blocks=(0, 1), normalization='batch').cuda().train()
+    x = torch.randn(1, 1, 16, 128, 128, device='cuda')
+    t = torch.randint(0, 2, (1, 16, 128, 128), device='cuda')
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    out = m(x)
+    loss = combined_loss(out, t)
+    m.zero_grad(set_to_none=True)
+    loss.backward()
+    sd_ref = {k: v.clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd0.items()}
+    ref = unet_forward(sd_ref, x, 4, (0, 1), training=True)
+    lref = combined_loss(ref, t)
+    lref.backward()
+    assert torch.allclose(out, ref, rtol=1e-3, atol=2e-4), float((out - ref).abs().max())
+    assert abs(float(loss.detach()) - float(lref.detach())) < 1e-5
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))
+    for k, p in m.named_parameters():
+        gr = sd_ref[k].grad
+        if is_prebn_bias(k):
+            assert float(p.grad.abs().max()) <= 1e-5 * float(gn), k
+            continue
+        err = float((p.grad - gr).norm() / gr.norm().clamp_min(1e-30))
+        assert err < 2e-2, (k, err)
+
+
 def test_full_size_properties(cfg2):
     m, x, t = cfg2
     # determinism: two training forwards+backwards from the same state are bit-identical (no atomics anywhere)
