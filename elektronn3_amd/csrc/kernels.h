@@ -150,6 +150,7 @@ struct BnBwdArgs {
     int parts;
     const float* coef;                    // apply pass: [2][C] = (sum dz / n, sum dz*xhat / n)
     float* dx; int dx_ldc;                // apply pass output
+    size_t nt_bytes;                      // set by the launcher: tensors above this size are read with non-temporal loads
 };
 int bn_bwd_parts(size_t voxels, int C);
 int launch_bn_bwd_reduce(BnBwdArgs a, hipStream_t s);
