@@ -337,6 +337,86 @@ class Predictor:
             outs.append(self._tiled_predict(inp[self.batch_size * k:self.batch_size * (k + 1)], out_shape=out_shape))
         return torch.cat(outs, 0)
 
+    # ------------------------------------------------------------------ host <-> device pipeline
+    def _pipeline_applicable(self, inp):
+        return (self.enable_tiling and self.device.type == 'cuda' and isinstance(inp, torch.Tensor) and not inp.is_cuda
+                and self.offset is None and self.out_shape is not None and self.tile_shape is not None
+                and self.overlap_shape is not None and len(self.tile_shape) == 3 and inp.dim() == 5
+                and tuple(inp.shape[2:]) == tuple(int(v) for v in self.out_shape[1:])
+                and (self.batch_size is None or self.batch_size >= inp.shape[0])
+                and not (self.tile_parallel and torch.distributed.is_available() and torch.distributed.is_initialized())
+                and os.environ.get('E3_PREDICTOR_NO_PIPELINE') is None)
+
+    @torch.no_grad()
+    def _pipelined_predict(self, inp):
+        """Same result as the plain path (pad to a multiple of the tile shape, zero halo, tiles in the reference's C order,
+        central crops assembled), but the volume streams through the GPU: the input is uploaded in z slabs just ahead of the
+        tile rows that need them, and every finished row of output tiles goes back to the host (cropped to out_shape) on a
+        side stream while the next rows are computed.  Host copies are done by two worker threads (pageable memory copies
+        block their calling thread, not the GPU); the compute stream only waits on events."""
+        from concurrent.futures import ThreadPoolExecutor
+        dev = self.device
+        N, Cin = int(inp.shape[0]), int(inp.shape[1])
+        real = np.array(self.out_shape[1:], dtype=np.int64)
+        tile, ov = self.tile_shape.astype(np.int64), self.overlap_shape.astype(np.int64)
+        if np.any(real % tile) and self.strict_shapes:
+            raise ValueError('Make sure that out_shape is divisible by tile_shape or relax this constraint by setting '
+                             'strict_shapes=False.')
+        padded = (np.ceil(real / tile) * tile).astype(np.int64)           # spatial shape the tile loop works on
+        ntz, nty, ntx = (int(v) for v in padded // tile)
+        C = int(self.out_shape[0])
+        if self.out_dtype is None:
+            self.out_dtype = torch.uint8 if self.argmax_with_threshold is not None else inp.dtype
+        inp_padded = torch.zeros((N, Cin, *(int(v) for v in padded + 2 * ov)), dtype=self.dtype, device=dev)
+        crop = _extend_nc([slice(int(l), int(h)) for l, h in zip(ov, tile + ov)])
+        plan = tile_plan(padded, tile, ov)
+        main = torch.cuda.current_stream(dev)
+        up_stream, down_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        up_stream.wait_stream(main); down_stream.wait_stream(main)       # (the zero fill of inp_padded precedes every upload)
+        # z rows of the ORIGINAL input that tile row k needs: padded coords [tile*k, tile*(k+1) + 2 ov) = original - ov
+        hi = [int(min(real[0], tile[0] * (k + 1) + ov[0])) for k in range(ntz)]
+        lo = [0] + hi[:-1]
+        up_events = [torch.cuda.Event() for _ in range(ntz)]
+
+        def upload(k):
+            a, b = lo[k], hi[k]
+            with torch.cuda.stream(up_stream):
+                if b > a:
+                    dst = inp_padded[:, :, int(ov[0]) + a:int(ov[0]) + b, int(ov[1]):int(ov[1] + real[1]), int(ov[2]):int(ov[2] + real[2])]
+                    dst.copy_(inp[:, :, a:b].to(self.dtype))
+                up_events[k].record(up_stream)
+
+        host_out = None
+        out_dev = None
+        downs = []
+
+        def download(k, ev, src):
+            with torch.cuda.stream(down_stream):
+                down_stream.wait_event(ev)
+                z0, z1 = int(tile[0] * k), int(min(tile[0] * (k + 1), real[0]))
+                if z1 > z0:
+                    host_out[:, :, z0:z1].copy_(src[:, :, z0:z1, :int(real[1]), :int(real[2])])
+
+        with ThreadPoolExecutor(max_workers=1) as up_pool, ThreadPoolExecutor(max_workers=1) as down_pool:
+            ups = [up_pool.submit(upload, k) for k in range(ntz)]
+            for k in range(ntz):
+                ups[k].result()                       # (the copy has been issued; the stream-side wait is the event)
+                main.wait_event(up_events[k])
+                for ti in range(k * nty * ntx, (k + 1) * nty * ntx):
+                    ilo, ihi, olo, ohi = plan[ti]
+                    inp_tile = inp_padded[_extend_nc([slice(l, h) for l, h in zip(ilo, ihi)])].contiguous()
+                    out_tile = self._predict(inp_tile, crop)
+                    if out_dev is None:
+                        out_dev = torch.zeros((N, *out_tile.shape[1:-3], *(int(v) for v in padded)), dtype=out_tile.dtype, device=dev)
+                        host_out = torch.empty((N, *out_tile.shape[1:-3], *(int(v) for v in real)), dtype=out_tile.dtype)
+                    out_dev[_extend_nc([slice(l, h) for l, h in zip(olo, ohi)])] = out_tile
+                ev = torch.cuda.Event(); ev.record(main)
+                downs.append(down_pool.submit(download, k, ev, out_dev))
+            for d in downs:
+                d.result()
+        torch.cuda.synchronize(dev)
+        return host_out
+
     # ------------------------------------------------------------------ public API (inference.py:569-642)
     def predict(self, inp):
         if self.transform is not None:
@@ -349,6 +429,12 @@ class Predictor:
         if self.verbose:
             start = time.time()
         inp = torch.as_tensor(inp)
+        if self._pipeline_applicable(inp):
+            out = self._pipelined_predict(inp)
+            if self.verbose:
+                dtime = time.time() - start
+                print(f'Inference speed: {out.numel() / dtime / 1e6:.2f} MVox/s, time: {dtime:.2f}.')
+            return out
         if self.enable_tiling:
             inp, out_shape, relevant_slice = self._ensure_matching_shapes(inp)
         else:

@@ -151,5 +151,16 @@ def test_predictor_native_tta_and_cfg5_shaped_tiling(gold):
             o = m.forward_softmax(t)[:, :, 8:32, 8:40, 8:40].cpu()
             full[:, :, olo[0]:ohi[0], olo[1]:ohi[1], olo[2]:ohi[2]] = o
     assert torch.equal(y, full[:, :, :40, :72, :88])
+    # the streaming host<->device pipeline (z slabs up, finished tile rows down on side streams) changes nothing
+    import os
+    os.environ['E3_PREDICTOR_NO_PIPELINE'] = '1'
+    try:
+        y_plain = pred.predict(vol)
+    finally:
+        del os.environ['E3_PREDICTOR_NO_PIPELINE']
+    assert torch.equal(y, y_plain)
+    yb = Predictor(m, device='cuda', tile_shape=tile, overlap_shape=ov, offset=None, out_shape=(2, 40, 72, 88), apply_softmax=True,
+                   apply_argmax=True).predict(torch.cat([vol, vol.flip(2)]))       # batch of 2, uint8 output through the pipeline
+    assert yb.dtype == torch.uint8 and tuple(yb.shape) == (2, 1, 40, 72, 88) and torch.equal(yb[0, 0], y[0].argmax(0).to(torch.uint8))
     ya = Predictor(m, device='cuda', apply_softmax=True, augmentations=3).predict(vol[:, :, :16, :32, :32])
     assert torch.allclose(ya.sum(1), torch.ones_like(ya[:, 0]), atol=1e-5)
