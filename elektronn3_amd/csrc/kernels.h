@@ -55,6 +55,10 @@ int launch_pack_conv_auto(ConvKind kind, int dgrad, const float* w, float* out, 
 bool upconv_gemm_ok(int flags, int Cx, int Cout, int ncols);
 int upconv_stats_parts(int N, int D, int H, int W, int sd);
 int launch_upconv_gemm(ConvArgs a, hipStream_t s);
+struct WgradArgs;
+bool upconv_wgrad_ok(int Cin, int Cout, int sd);                         // weight gradient of the transposed conv, all taps per workgroup
+int upconv_wgrad_splits(int N, int D, int H, int W, int Cin, int Cout);
+int launch_upconv_wgrad(WgradArgs a, hipStream_t s);
 int conv_col_tile(int ncols);  // 32 or 64: column tile the launcher will use for `ncols` GEMM columns
 
 // ---------------------------------------------------------------- weight packing

@@ -239,3 +239,165 @@ int launch_upconv_gemm(ConvArgs a, hipStream_t s) {
     if (gather) return nt4 ? launch_up<true, 4>(a, s) : launch_up<true, 2>(a, s);
     return nt4 ? launch_up<false, 4>(a, s) : launch_up<false, 2>(a, s);
 }
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[ci][co][tap] = sum_p X[p][ci] * dY[2p + tap][co]:  per tap a GEMM with K = input voxels.  One workgroup owns a
+// (64 ci x 32 co) tile of ALL taps (wave w: taps {w*T/4 ...}, 2 ci tiles each = 4 (2 for planar) accumulators) over a
+// contiguous range of 32-voxel bricks (2 h-rows x 16 w), so X is staged once for the 8 taps (the one-tap-per-workgroup
+// kernel in wgrad_mfma.hip re-reads it 8 times and spends most of its time on per-element address arithmetic).
+// Staging by LDS-DMA into [voxel][64 ci] / [tap][voxel][32 co] images, validity as scalar bit masks, zero fill by the buffer
+// range check; single-buffered (40 KB), three workgroups per CU cover each other's staging.  Slab layout as before:
+// part[split][tap][ci][co].
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_u;
+
+// (body as a device function template + two plain __global__ wrappers: hipcc 7.2 fails to emit the host stub of this
+// kernel when it is itself a template)
+template <int NTAPS>
+__device__ __forceinline__ void upconv_wgrad_body(const WgradArgs& a, int tilesH, int tilesW, int bricks_per_split,
+                                                  int co_tiles, int ci_tiles) {
+    constexpr int TPW = NTAPS / 4;                           // taps per wave
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                                    // [32 voxels][64 ci]
+    float* gs = smem + 32 * 64;                          // [NTAPS][32 voxels][32 co]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, hf = lane >> 5;
+    unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int co_t = L % co_tiles; L /= co_tiles;
+    const int ci_t = L % ci_tiles; const int split = L / ci_tiles;
+    const int ci0 = ci_t * 64, co0 = co_t * 32;
+    const int nbricks = a.N * a.D * tilesH * tilesW;
+    const int b0 = split * bricks_per_split;
+    const int b1 = b0 + bricks_per_split < nbricks ? b0 + bricks_per_split : nbricks;
+
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, 0x7fffffff, 0x00020000);
+    // lane constants of the DMA pieces.  X: wave-piece wp = 2*it' + ... (8 per brick, 2 per wave), voxel = idx >> 4, 16-B piece q = idx & 15
+    unsigned xrel[2], xpm[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = (it * 4 + wave) * 64 + lane;
+        const int v = idx >> 4, q = idx & 15;
+        const int vh = v >> 4, vw = v & 15;
+        const bool cok = ci0 + 4 * q < a.Cin;
+        xrel[it] = (unsigned)(((vh * a.W + vw) * a.x_ldc + ci0 + 4 * q) * 4);
+        xpm[it] = cok ? (1u << vh) | (1u << (2 + vw)) : 0xffffffffu;
+    }
+    // dY: per tap 4 wave-pieces (one per wave): voxel = idx >> 3, piece q = idx & 7 of the voxel 2p + tap
+    const int gidx = wave * 64 + lane;
+    const int gv = gidx >> 3, gq = gidx & 7, gvh = gv >> 4, gvw = gv & 15;
+    const bool gcok = co0 + 4 * gq < a.Cout;
+    const unsigned gpm = gcok ? (1u << gvh) | (1u << (2 + gvw)) : 0xffffffffu;
+    unsigned grel[NTAPS];
+#pragma unroll
+    for (int tp = 0; tp < NTAPS; ++tp) {
+        const int utw = tp & 1, uth = (tp >> 1) & 1, utd = tp >> 2;
+        grel[tp] = (unsigned)((((utd * a.Ho + 2 * gvh + uth) * a.Wo + 2 * gvw + utw) * a.dy_ldc + co0 + 4 * gq) * 4);
+    }
+
+    f32x16 acc[TPW][2];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+
+    auto range_mask = [](int lo, int n, int size) {          // bits z in [0, n) with lo + z < size
+        const int last = size - lo < n ? size - lo : n;
+        return last > 0 ? (1u << last) - 1u : 0u;
+    };
+    for (int b = b0; b < b1; ++b) {
+        int Lt = b;
+        const int tw_ = Lt % tilesW; Lt /= tilesW; const int th_ = Lt % tilesH; Lt /= tilesH; const int d = Lt % a.D; const int nb = Lt / a.D;
+        const int h0 = th_ * 2, w0 = tw_ * 16;
+        const unsigned xmask = range_mask(h0, 2, a.H) | (range_mask(w0, 16, a.W) << 2);
+        const unsigned xbase = (unsigned)(((((nb * a.D + d) * a.H + h0) * a.W + w0) * a.x_ldc) * 4);
+        __syncthreads();                                  // every wave is done with the previous brick
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const bool ok = (xmask & xpm[it]) == xpm[it];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_u)(xs + (it * 4 + wave) * 256), 16, ok ? xrel[it] + xbase : OOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int tp = 0; tp < NTAPS; ++tp) {
+            const int utw = tp & 1, uth = (tp >> 1) & 1, utd = tp >> 2;
+            // output rows 2(h0 + vh) + uth < Ho  <=>  vh < (Ho - uth + 1)/2 - h0; likewise along w
+            const unsigned gmask = range_mask(h0, 2, (a.Ho - uth + 1) >> 1) | (range_mask(w0, 16, (a.Wo - utw + 1) >> 1) << 2);
+            const bool dok = a.sd * d + utd < a.Do;
+            const unsigned gbase = (unsigned)(((((nb * a.Do + a.sd * d) * a.Ho + 2 * h0) * a.Wo + 2 * w0) * a.dy_ldc) * 4);
+            const bool ok = dok && (gmask & gpm) == gpm;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rs, (lds_ptr_u)(gs + (tp * 4 + wave) * 256), 16, ok ? grel[tp] + gbase : OOB, 0, 0, 0);
+        }
+        __syncthreads();                                  // (hipcc drains vmcnt in front of the barrier: the images have landed)
+        // K loop: MFMA k-step t consumes voxels (2t, 2t+1): lane half hf takes voxel 2t + hf
+#pragma unroll 4
+        for (int t = 0; t < 16; ++t) {
+            const int v = 2 * t + hf;
+            const float a0 = xs[v * 64 + j], a1 = xs[v * 64 + 32 + j];
+#pragma unroll
+            for (int tp = 0; tp < TPW; ++tp) {
+                const float bv = gs[((wave * TPW + tp) * 32 + v) * 32 + j];
+                acc[tp][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[tp][0], 0, 0, 0);
+                acc[tp][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[tp][1], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                a.part[(((size_t)split * NTAPS + wave * TPW + tp) * a.CiPad + ci0 + 32 * c + row) * a.CoPad + co0 + j] = acc[tp][c][r];
+            }
+}
+
+__global__ __launch_bounds__(256, 3) void upconv_wgrad_kernel8(const WgradArgs a, int tilesH, int tilesW, int bps, int co_tiles, int ci_tiles) {
+    upconv_wgrad_body<8>(a, tilesH, tilesW, bps, co_tiles, ci_tiles);
+}
+__global__ __launch_bounds__(256, 3) void upconv_wgrad_kernel4(const WgradArgs a, int tilesH, int tilesW, int bps, int co_tiles, int ci_tiles) {
+    upconv_wgrad_body<4>(a, tilesH, tilesW, bps, co_tiles, ci_tiles);
+}
+
+}  // namespace
+
+bool upconv_wgrad_ok(int Cin, int Cout, int sd) {
+    static const bool enabled = getenv("E3_UPCONV_NO_GEMM") == nullptr;
+    return enabled && (Cin & 63) == 0 && (Cout & 31) == 0 && (sd == 1 || sd == 2);
+}
+
+static int upconv_wgrad_bricks_per_split(int nbricks, int pairs) {
+    int want = 768 / (pairs > 0 ? pairs : 1);              // three resident workgroups per CU
+    if (want < 1) want = 1;
+    return cdiv(nbricks, want);
+}
+
+int upconv_wgrad_splits(int N, int D, int H, int W, int Cin, int Cout) {
+    const int nbricks = N * D * cdiv(H, 2) * cdiv(W, 16);
+    return cdiv(nbricks, upconv_wgrad_bricks_per_split(nbricks, (Cin / 64) * (Cout / 32)));
+}
+
+int launch_upconv_wgrad(WgradArgs a, hipStream_t s) {
+    E3_REQUIRE((a.x_ldc & 3) == 0 && (a.dy_ldc & 3) == 0 && ((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.dy & 15) == 0, E3_ERR_INVALID,
+               "upconv wgrad views must be 16-byte aligned");
+    E3_REQUIRE((size_t)a.N * a.D * a.H * a.W * a.x_ldc * 4 < 0x7fffffffu && (size_t)a.N * a.Do * a.Ho * a.Wo * a.dy_ldc * 4 < 0x7fffffffu,
+               E3_ERR_UNSUPPORTED, "upconv wgrad: tensors beyond 2 GiB (32-bit buffer offsets)");
+    const int tH = cdiv(a.H, 2), tW = cdiv(a.W, 16);
+    const int nbricks = a.N * a.D * tH * tW;
+    const int ci_tiles = a.Cin / 64, co_tiles = a.Cout / 32;
+    const int bps = upconv_wgrad_bricks_per_split(nbricks, ci_tiles * co_tiles);
+    const int splits = cdiv(nbricks, bps);
+    E3_REQUIRE(splits == a.splits, E3_ERR_INVALID, "upconv wgrad: splits mismatch");
+    const dim3 grid((unsigned)((size_t)splits * ci_tiles * co_tiles));
+    const int ntaps = a.sd * 4;
+    const size_t lds = (size_t)(32 * 64 + ntaps * 32 * 32) * 4;
+    if (ntaps == 8) hipLaunchKernelGGL(upconv_wgrad_kernel8, grid, dim3(256), lds, s, a, tH, tW, bps, co_tiles, ci_tiles);
+    else hipLaunchKernelGGL(upconv_wgrad_kernel4, grid, dim3(256), lds, s, a, tH, tW, bps, co_tiles, ci_tiles);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
