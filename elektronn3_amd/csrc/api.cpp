@@ -25,7 +25,9 @@ size_t e3_conv3d_workspace_bytes(int Cin, int Cout, int planar) {
 
 int e3_conv3d_stats_parts(int Cin, int Cout, int N, int D, int H, int W, int planar) {
     if (Cin < 8) return conv_small_stats_parts(N, D, H, W, planar);
-    return conv_stats_parts(kind_of(planar), 0, N, D, H, W, 2, Cin, Cout);
+    // (a call with a BN prologue uses the direct kernel: report the larger of the two record counts, empty records are neutral)
+    const int p0 = conv_stats_parts(kind_of(planar), 0, N, D, H, W, 2, Cin, Cout), p1 = conv_stats_parts(kind_of(planar), CF_NO_WINO | CF_NO_KSPLIT, N, D, H, W, 2, Cin, Cout);
+    return p0 > p1 ? p0 : p1;
 }
 
 int e3_conv3d_fwd(void* stream, const float* x, int x_ldc, int Cin, const float* w, const float* bias,
@@ -45,14 +47,15 @@ int e3_conv3d_fwd(void* stream, const float* x, int x_ldc, int Cin, const float*
     E3_REQUIRE(workspace_bytes >= e3_conv3d_workspace_bytes(Cin, Cout, planar), E3_ERR_WORKSPACE, "conv3d workspace too small");
     const int T = planar ? 9 : 27, NPad = pad_cols(Cout);
     (void)T;
-    int rc = launch_pack_conv_auto(kind_of(planar), 0, w, (float*)workspace, Cout, Cin, N, D, H, W, s);
+    const int flags0 = pro_scale ? (CF_NO_WINO | CF_NO_KSPLIT) : 0;    // the Winograd kernels have no BN prologue
+    int rc = launch_pack_conv_auto(kind_of(planar), 0, w, (float*)workspace, Cout, Cin, N, D, H, W, flags0, s);
     if (rc) return rc;
     ConvArgs a{};
     a.x = x; a.x_ldc = x_ldc; a.Cin = Cin; a.wt = (const float*)workspace; a.bias = epi_scale ? nullptr : bias;
     a.y = y; a.y_ldc = y_ldc; a.N = N; a.D = D; a.H = H; a.W = W; a.sd = 2;
     a.Cout = Cout; a.Ncols = Cout; a.NPad = NPad;
     a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.epi_scale = epi_scale; a.epi_shift = epi_shift;
-    a.stats = stats; a.G = 1; a.flags = 0;
+    a.stats = stats; a.G = 1; a.flags = flags0;
     if (const char* dbg = getenv("E3_CONV_ABLATE")) a.flags |= atoi(dbg) & (256 | 512 | 1024);   // timing experiments only
     return launch_conv_mfma(kind_of(planar), a, s);
 }
@@ -63,7 +66,7 @@ int e3_conv3d_dgrad(void* stream, const float* dy, int dy_ldc, int Cout, const f
     E3_REQUIRE(workspace_bytes >= e3_conv3d_workspace_bytes(Cin, Cout, planar), E3_ERR_WORKSPACE, "conv3d workspace too small");
     const int T = planar ? 9 : 27, NPad = pad_cols(Cin);
     (void)T;
-    int rc = launch_pack_conv_auto(kind_of(planar), 1, w, (float*)workspace, Cout, Cin, N, D, H, W, s);
+    int rc = launch_pack_conv_auto(kind_of(planar), 1, w, (float*)workspace, Cout, Cin, N, D, H, W, 0, s);
     if (rc) return rc;
     ConvArgs a{};
     a.x = dy; a.x_ldc = dy_ldc; a.Cin = Cout; a.wt = (const float*)workspace; a.bias = nullptr;

@@ -434,6 +434,7 @@ int conv_col_tile(int ncols) { return ncols >= 64 ? 64 : 32; }
 
 int conv_stats_parts(ConvKind kind, int flags, int N, int D, int H, int W, int sd, int Cin, int ncols) {
     if (conv_use_wino(kind, flags, N, D, H, W, Cin, ncols)) return wino_bricks(N, D, H, W);
+    if (conv_use_wino2d(kind, flags, N, D, H, W, Cin, ncols)) return wino2d_bricks(N, D, H, W);
     if (kind == CONV_POINT && (flags & CF_SCATTER_UP) && upconv_gemm_ok(flags, Cin, ncols / (sd * 4), ncols)) return upconv_stats_parts(N, D, H, W, sd);
     int ks, nt; conv_decomposition(kind, flags, N, D, H, W, Cin, ncols, &ks, &nt);
     const Brick b = brick_of(kind, ks);
@@ -453,6 +454,7 @@ int launch_conv_mfma(ConvKind kind, ConvArgs a, hipStream_t s) {
     if (a.G <= 0) a.G = 1;
     if (kind == CONV_POINT && upconv_gemm_ok(a.flags, a.Cin, a.Cout, a.Ncols)) return launch_upconv_gemm(a, s);   // upconv_gemm.hip
     if (conv_use_wino(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols)) return launch_conv3_wino(a, s);   // a.wt packed by launch_pack_conv_auto
+    if (conv_use_wino2d(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols)) return launch_conv2_wino(a, s);
     int ks, nt; conv_decomposition(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols, &ks, &nt);
     static const bool use_v3 = getenv("E3_CONV_NO_V3") == nullptr;   // debug switch: fall back to the global-B kernel
     if (use_v3 && kind != CONV_POINT && ks == 1 && (a.flags & (CF_SCATTER_UP | CF_GATHER_UP)) == 0)

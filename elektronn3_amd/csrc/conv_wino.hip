@@ -407,7 +407,7 @@ int wino_bricks(int N, int D, int H, int W) { return N * cdiv(D, 4) * cdiv(H, 4)
 
 bool conv_use_wino(ConvKind kind, int flags, int N, int D, int H, int W, int Cin, int ncols) {
     static const bool enabled = getenv("E3_CONV_NO_WINO") == nullptr;
-    if (!enabled || kind != CONV_K3 || (flags & (CF_SCATTER_UP | CF_GATHER_UP)) != 0 || Cin < 8 || (Cin & 7)) return false;
+    if (!enabled || kind != CONV_K3 || (flags & (CF_SCATTER_UP | CF_GATHER_UP | CF_NO_WINO)) != 0 || Cin < 8 || (Cin & 7)) return false;
     // decided per SAMPLE (not per batch) so that the algorithm, and with it every rounding, is independent of the batch size:
     // eval-mode outputs of a batch are bit-identical to those of its samples run one by one (tests/test_unet_gpu.py)
     (void)N;
@@ -429,13 +429,14 @@ size_t conv_packed_floats(ConvKind kind, int K, int ncols) {
     const int T = kind == CONV_K3 ? 27 : (kind == CONV_K3_PLANAR ? 9 : 1);
     const int ct = conv_col_tile(ncols);
     const size_t direct = (size_t)T * (cdiv(ncols, ct) * ct) * K;
-    const size_t wino = kind == CONV_K3 ? wino_packed_floats(K, ncols) : 0;
+    const size_t wino = kind == CONV_K3 ? wino_packed_floats(K, ncols) : (kind == CONV_K3_PLANAR ? wino2d_packed_floats(K, ncols) : 0);
     return direct > wino ? direct : wino;
 }
 
-int launch_pack_conv_auto(ConvKind kind, int dgrad, const float* w, float* out, int Cout, int Cin, int N, int D, int H, int W, hipStream_t s) {
+int launch_pack_conv_auto(ConvKind kind, int dgrad, const float* w, float* out, int Cout, int Cin, int N, int D, int H, int W, int flags, hipStream_t s) {
     const int K = dgrad ? Cout : Cin, ncols = dgrad ? Cin : Cout;
-    if (conv_use_wino(kind, 0, N, D, H, W, K, ncols)) return launch_wino_pack(w, out, Cout, Cin, dgrad, s);
+    if (conv_use_wino(kind, flags, N, D, H, W, K, ncols)) return launch_wino_pack(w, out, Cout, Cin, dgrad, s);
+    if (conv_use_wino2d(kind, flags, N, D, H, W, K, ncols)) return launch_wino2d_pack(w, out, Cout, Cin, dgrad, s);
     const int T = kind == CONV_K3 ? 27 : 9, ct = conv_col_tile(ncols);
     return launch_pack_weights(dgrad ? PACK_CONV_DGRAD : PACK_CONV_FWD, w, out, Cout, Cin, T, cdiv(ncols, ct) * ct, s);
 }

@@ -13,6 +13,7 @@ enum ConvFlags {
     CF_SCATTER_UP = 1,  // POINT only: columns are (tap, co); row p is written to voxel 2p+tap   (ConvTranspose3d fwd)
     CF_GATHER_UP = 2,   // POINT only: K runs over (tap, c); row p reads voxel 2p+tap            (ConvTranspose3d dgrad)
     CF_NO_KSPLIT = 4,   // keep the 256-voxel decomposition (required with a BN+ReLU prologue)
+    CF_NO_WINO = 8,     // direct kernels only (set by callers that pass a BN+ReLU prologue)
 };
 
 struct ConvArgs {
@@ -46,11 +47,17 @@ int launch_conv3_v3(ConvKind kind, ConvArgs a, int nt, hipStream_t s);   // conv
 bool conv_use_wino(ConvKind kind, int flags, int N, int D, int H, int W, int K, int ncols);
 int wino_bricks(int N, int D, int H, int W);
 int launch_conv3_wino(ConvArgs a, hipStream_t s);
+// planar 1x3x3: Winograd F(2x2,3x3) (conv_wino2d.hip), same contract
+bool conv_use_wino2d(ConvKind kind, int flags, int N, int D, int H, int W, int K, int ncols);
+int wino2d_bricks(int N, int D, int H, int W);
+size_t wino2d_packed_floats(int K, int ncols);
+int launch_wino2d_pack(const float* w, float* out, int Cout, int Cin, int dgrad, hipStream_t s);
+int launch_conv2_wino(ConvArgs a, hipStream_t s);
 // floats of packed-weight workspace a stride-1 conv (fwd or dgrad) may need, whichever algorithm is chosen
 size_t conv_packed_floats(ConvKind kind, int K, int ncols);
 // packs torch (Cout,Cin,T) weights for the forward (dgrad = 0) or the input-gradient (dgrad = 1) launch of a conv over
 // an (N,D,H,W) grid, in the layout of the algorithm conv_use_wino() selects
-int launch_pack_conv_auto(ConvKind kind, int dgrad, const float* w, float* out, int Cout, int Cin, int N, int D, int H, int W, hipStream_t s);
+int launch_pack_conv_auto(ConvKind kind, int dgrad, const float* w, float* out, int Cout, int Cin, int N, int D, int H, int W, int flags, hipStream_t s);
 // transposed conv (POINT + SCATTER_UP / GATHER_UP) as a plain LDS-tiled GEMM (upconv_gemm.hip); Cx = channels per voxel of x
 bool upconv_gemm_ok(int flags, int Cx, int Cout, int ncols);
 int upconv_stats_parts(int N, int D, int H, int W, int sd);

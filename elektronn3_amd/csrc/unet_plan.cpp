@@ -363,7 +363,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             const int taps = u.planar ? 9 : 27, NPad = pad_cols(u.cout);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             (void)taps;
-            RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, lo.D, lo.H, lo.W, s));
+            RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, lo.D, lo.H, lo.W, 0, s));
             ConvArgs a{};
             a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpack; a.bias = training ? P(u.p_b) : nullptr;
             a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.sd = 2;
@@ -508,7 +508,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             const int taps = u.planar ? 9 : 27, NPad = pad_cols(u.cin);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             (void)taps;
-            RUN(launch_pack_conv_auto(kind, 1, P(u.p_w), B.wpack, u.cout, u.cin, N, lo.D, lo.H, lo.W, s));
+            RUN(launch_pack_conv_auto(kind, 1, P(u.p_w), B.wpack, u.cout, u.cin, N, lo.D, lo.H, lo.W, 0, s));
             const bool to_cat = !is_down && u.name.find("conv1") != std::string::npos;   // UpConv.conv1: gradient of the concat buffer
             float* out; int out_ldc = u.cin;
             if (k == 0) out = (cfg.in_channels > 1) ? B.g1[0] : dx;   // g1[0] is free by now (C0 >= in_channels)

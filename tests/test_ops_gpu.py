@@ -150,6 +150,9 @@ CONV_CASES = [
     (32, 64, (14, 30, 50), False, 2),    # Winograd path (>= 256 workgroups), partial 4x4x16 bricks in every dim
     (40, 24, (16, 32, 64), False, 2),    # Winograd, odd number of 8-channel chunks, partial column tile
     (8, 8, (9, 33, 33), False, 4),       # Winograd, single chunk, odd extents (partial 2x2x2 tiles)
+    (32, 64, (6, 44, 70), True, 1),      # planar Winograd F(2x2,3x3) (>= 128 workgroups per sample), partial 8x16 bricks
+    (40, 24, (8, 64, 64), True, 2),      # planar Winograd, odd number of chunks, partial 64-column tile
+    (8, 72, (5, 33, 65), True, 2),       # planar Winograd, single chunk, odd extents, second column tile nearly empty
 ]
 
 
