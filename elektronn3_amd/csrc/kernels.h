@@ -125,6 +125,10 @@ int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s);
 // Winograd F(3x3x3, 2x2x2) variant for CONV_K3 (wgrad_wino.hip): same bricks, splits and partial-slab layout
 bool wgrad_use_wino(ConvKind kind);
 int launch_wgrad_wino(WgradArgs a, int tD, int tH, int tW, int tps, int co_tiles, int ci_tiles, int splits, hipStream_t s);
+// planar: Winograd F(3x3, 2x2) (wgrad_wino2d.hip); 64-channel granularity on the co side, 32 on the ci side
+bool wgrad_use_wino2d(ConvKind kind, int Cin, int Cout);
+int wgrad_wino2d_splits(int N, int D, int H, int W, int Cin, int Cout);
+int launch_wgrad_wino2d(WgradArgs a, hipStream_t s);
 // out (torch layout): transposed==0: (Cout,Cin,T) from part rows=co, cols=ci ; transposed==1: (Cin,Cout,T), part rows=ci, cols=co
 int launch_wgrad_reduce(const float* part, float* out, int splits, int T, int RPad, int CPad, int R, int C, hipStream_t s);
 

@@ -236,6 +236,7 @@ int tiles_per_split(int ntiles, int other, int resident = 512) {
 int wgrad_splits(ConvKind kind, int N, int D, int H, int W, int Cin, int Cout) {
     // (POINT: D, H, W are the INPUT dims of the transposed conv; sd is not known here, the GEMM kernel serves sd = 1 and 2 alike)
     if (kind == CONV_POINT && upconv_wgrad_ok(Cin, Cout, 2)) return upconv_wgrad_splits(N, D, H, W, Cin, Cout);
+    if (wgrad_use_wino2d(kind, Cin, Cout)) return wgrad_wino2d_splits(N, D, H, W, Cin, Cout);
     int TD, TH; wgeo(kind, TD, TH);
     const int ntiles = N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, 16);
     const int other = cdiv(Cout, 32) * cdiv(Cin, 32) * (kind == CONV_POINT ? 8 : 1);   // POINT: one workgroup per tap too
@@ -245,6 +246,7 @@ int wgrad_splits(ConvKind kind, int N, int D, int H, int W, int Cin, int Cout) {
 int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s) {
     E3_REQUIRE(a.Cin % 4 == 0 && a.Cout % 4 == 0 && a.x_ldc % 4 == 0 && a.dy_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "wgrad needs channel counts that are multiples of 4");
     if (kind == CONV_POINT && upconv_wgrad_ok(a.Cin, a.Cout, a.sd)) return launch_upconv_wgrad(a, s);   // upconv_gemm.hip
+    if (wgrad_use_wino2d(kind, a.Cin, a.Cout)) return launch_wgrad_wino2d(a, s);                        // wgrad_wino2d.hip
     int TD, TH; wgeo(kind, TD, TH);
     const int tD = cdiv(a.D, TD), tH = cdiv(a.H, TH), tW = cdiv(a.W, 16);
     const int ntiles = a.N * tD * tH * tW;

@@ -51,8 +51,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
 
     // ---- staging by LDS-DMA (buffer_load_dwordx4 ... lds): a wave-instruction moves 64 x 16 B = 8 voxels x 32 channels
     // into 1 KB of the [voxel][32] image; no staging registers, no ds_write pass, zero padding by the range check.
-    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, 0x7fffffff, 0x00020000);
+    // one descriptor per sample (rebuilt per brick, scalar work): offsets stay below 2^31 for any batch size
+    __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, 0x7fffffff, 0x00020000);
+    const size_t samp_x = (size_t)a.D * a.H * a.W * a.x_ldc, samp_g = (size_t)a.D * a.H * a.W * a.dy_ldc;
     // lane constants: wave-piece (it*4 + wave), lane -> piece idx -> (voxel, 4-channel group).  Validity of a halo voxel is
     // separable, so a brick only needs one 28-bit scalar mask (4 d bits | 6 h bits | 18 w bits) and each piece the
     // constant pattern of its three bits: 4 VALU per piece and brick, no branches.
@@ -110,8 +112,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
         };
         xmask = range_mask(d0 - 1, 4, a.D) | (range_mask(h0 - 1, 6, a.H) << 4) | (range_mask(w0 - 1, 18, a.W) << 10);
         gmask = range_mask(d0, 2, a.D) | (range_mask(h0, 4, a.H) << 4) | (range_mask(w0, 16, a.W) << 10);
-        xbase = (unsigned)(((((nb * a.D + d0 - 1) * a.H + h0 - 1) * a.W + w0 - 1) * a.x_ldc) * 4);   // wraps at the borders
-        gbase = (unsigned)(((((nb * a.D + d0) * a.H + h0) * a.W + w0) * a.dy_ldc) * 4);
+        x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)nb * samp_x, 0, 0x7fffffff, 0x00020000);
+        g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy) + (size_t)nb * samp_g, 0, 0x7fffffff, 0x00020000);
+        xbase = (unsigned)(((((d0 - 1) * a.H + h0 - 1) * a.W + w0 - 1) * a.x_ldc) * 4);   // relative to the sample; wraps at the borders
+        gbase = (unsigned)((((d0 * a.H + h0) * a.W + w0) * a.dy_ldc) * 4);
     };
     auto issue_part = [&](int part, float* buf) {         // part 0..2: X pieces {0-5, 6-10, 11-13}, dY pieces {0-1, 2, 3}; part 3: nothing
         // (the last MFMA block keeps the DMA queue draining: everything has landed when the brick's barrier is reached)
@@ -286,6 +290,8 @@ bool wgrad_use_wino(ConvKind kind) {
 }
 
 int launch_wgrad_wino(WgradArgs a, int tD, int tH, int tW, int tps, int co_tiles, int ci_tiles, int splits, hipStream_t s) {
+    E3_REQUIRE((size_t)a.D * a.H * a.W * (size_t)(a.x_ldc > a.dy_ldc ? a.x_ldc : a.dy_ldc) * 4 < 0x7fffffffu, E3_ERR_UNSUPPORTED,
+               "Winograd wgrad: one sample beyond 2 GiB (32-bit buffer offsets); set E3_WGRAD_NO_WINO=1");
     constexpr int lds_bytes = G_LDS_FLOATS * 4;
     static bool set = false;
     if (!set) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); set = true; }

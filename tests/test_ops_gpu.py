@@ -153,6 +153,7 @@ CONV_CASES = [
     (32, 64, (6, 44, 70), True, 1),      # planar Winograd F(2x2,3x3) (>= 128 workgroups per sample), partial 8x16 bricks
     (40, 24, (8, 64, 64), True, 2),      # planar Winograd, odd number of chunks, partial 64-column tile
     (8, 72, (5, 33, 65), True, 2),       # planar Winograd, single chunk, odd extents, second column tile nearly empty
+    (64, 128, (3, 13, 37), True, 2),     # planar Winograd wgrad F(3x3,2x2): 2 co x 2 ci tiles, partial 4x16 bricks, odd extents
 ]
 
 
