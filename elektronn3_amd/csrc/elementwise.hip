@@ -56,6 +56,32 @@ __global__ void pack_weights_kernel(int mode, const float* __restrict__ w, float
     }
 }
 
+// ------------------------------------------------------------------ BN statistics: coalesced pre-merge of many records
+// in [parts][C][3] -> out [BN_PRERED][C][3].  Block b merges records [b*chunk, (b+1)*chunk): thread = (channel c, group g)
+// Chan-merges its strided share (adjacent threads read adjacent channels of one record row: coalesced), then the groups of
+// a channel are merged through LDS.  (One block per channel, as in bn_finalize_kernel, reads every 384-B record row
+// 32 times from L2 when there are thousands of records.)
+__global__ __launch_bounds__(1024) void bn_premerge_kernel(const float* __restrict__ in, int parts, int C, float* __restrict__ out) {
+    __shared__ float sh[1024][3];
+    const int chunk = (parts + gridDim.x - 1) / gridDim.x;
+    const int p0 = blockIdx.x * chunk, p1 = p0 + chunk < parts ? p0 + chunk : parts;
+    const int groups = 1024 / C;                       // C <= 1024
+    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (g < groups)
+        for (int p = p0 + g; p < p1; p += groups) {
+            const float* r = in + ((size_t)p * C + c) * 3;
+            welford_merge(n, mean, m2, r[0], r[1], r[2]);
+        }
+    sh[threadIdx.x][0] = n; sh[threadIdx.x][1] = mean; sh[threadIdx.x][2] = m2;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        for (int k = 1; k < groups; ++k) welford_merge(n, mean, m2, sh[k * C + c][0], sh[k * C + c][1], sh[k * C + c][2]);
+        float* o = out + ((size_t)blockIdx.x * C + c) * 3;
+        o[0] = n; o[1] = mean; o[2] = m2;
+    }
+}
+
 // ------------------------------------------------------------------ BN finalise (one 1024-thread workgroup per channel)
 // Merges the per-tile (count, mean, M2) records of a channel in fp64, two division-free passes over the (L2-resident)
 // records:  N = sum n_i,  mu = sum n_i mean_i / N;  M2 = sum [ M2_i + n_i (mean_i - mu)^2 ].  Fixed order: deterministic.
@@ -384,6 +410,10 @@ int launch_pack_weights(PackMode mode, const float* w, float* out, int Cout, int
 }
 
 int launch_bn_finalize(BnFinalizeArgs a, hipStream_t s) {
+    if (a.scratch && a.parts > 4 * BN_PRERED && a.C <= 1024) {
+        hipLaunchKernelGGL(bn_premerge_kernel, dim3(BN_PRERED), dim3(1024), 0, s, a.stats, a.parts, a.C, a.scratch);
+        a.stats = a.scratch; a.parts = BN_PRERED;
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(1024), 0, s, a);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;

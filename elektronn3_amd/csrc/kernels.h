@@ -140,7 +140,9 @@ struct BnFinalizeArgs {
     float* running_mean; float* running_var;   // may be null
     float momentum; float eps;
     float* mean; float* invstd; float* scale; float* shift;   // each [C]
+    float* scratch;                           // optional: BN_PRERED * C * 3 floats; many records are first merged into BN_PRERED coalesced partials
 };
+constexpr int BN_PRERED = 64;
 int launch_bn_finalize(BnFinalizeArgs a, hipStream_t s);
 // eval mode: scale = gamma/sqrt(rv+eps); shift = beta + (conv_bias - rm)*scale   (BN folded into the conv epilogue)
 int launch_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, const float* conv_bias,

@@ -100,6 +100,7 @@ struct Buffers {
     size_t saved_bytes;
     // scratch
     float* wpack; float* stats; float* bnpart; float* slab; float* small;   // small: coef / fold vectors
+    float* bnred;                                                              // pre-merged BN statistic records
     std::vector<float*> g1, g2, dcat;    // gradient buffers per level
     float* evalA; float* evalB;          // inference ping-pong (level-0 sized)
     size_t scratch_bytes;
@@ -169,6 +170,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     B.wpack = T.take(wmax);
     B.stats = T.take(statmax);
     B.small = T.take((size_t)4 * p->chan(nb - 1) + 64);
+    B.bnred = T.take((size_t)BN_PRERED * p->chan(nb - 1) * 3);
     if (training) {
         B.bnpart = T.take(bnpartmax);
         B.slab = T.take(slabmax);
@@ -376,7 +378,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             BnFinalizeArgs f{};
             f.stats = B.stats; f.parts = parts; f.C = u.cout; f.gamma = P(u.p_g); f.beta = P(u.p_be);
             f.running_mean = P(u.p_rm); f.running_var = P(u.p_rv); f.momentum = momenta[u.bn_index]; f.eps = cfg.bn_eps;
-            f.mean = b.mean; f.invstd = b.invstd; f.scale = b.scale; f.shift = b.shift;
+            f.mean = b.mean; f.invstd = b.invstd; f.scale = b.scale; f.shift = b.shift; f.scratch = B.bnred;
             RUN(launch_bn_finalize(f, s));
             RUN(launch_bn_relu_apply(b.raw, u.cout, b.scale, b.shift, b.act, b.act_ldc, pool_after ? B.pooled[u.level] : nullptr, kd,
                                      N, lo.D, lo.H, lo.W, u.cout, s));
