@@ -273,8 +273,8 @@ __device__ __forceinline__ void upconv_wgrad_body(const WgradArgs& a, int tilesH
     const int b0 = split * bricks_per_split;
     const int b1 = b0 + bricks_per_split < nbricks ? b0 + bricks_per_split : nbricks;
 
-    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, 0x7fffffff, 0x00020000);
+    // descriptors are rebuilt per brick for its d-slice (scalar work): offsets stay small whatever the size of the tensors
+    const size_t slice_x = (size_t)a.H * a.W * a.x_ldc, slice_g = (size_t)a.Ho * a.Wo * a.dy_ldc;
     // lane constants of the DMA pieces.  X: wave-piece wp = 2*it' + ... (8 per brick, 2 per wave), voxel = idx >> 4, 16-B piece q = idx & 15
     unsigned xrel[2], xpm[2];
 #pragma unroll
@@ -315,7 +315,9 @@ __device__ __forceinline__ void upconv_wgrad_body(const WgradArgs& a, int tilesH
         const int tw_ = Lt % tilesW; Lt /= tilesW; const int th_ = Lt % tilesH; Lt /= tilesH; const int d = Lt % a.D; const int nb = Lt / a.D;
         const int h0 = th_ * 2, w0 = tw_ * 16;
         const unsigned xmask = range_mask(h0, 2, a.H) | (range_mask(w0, 16, a.W) << 2);
-        const unsigned xbase = (unsigned)(((((nb * a.D + d) * a.H + h0) * a.W + w0) * a.x_ldc) * 4);
+        const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + ((size_t)nb * a.D + d) * slice_x, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy) + ((size_t)nb * a.Do + a.sd * d) * slice_g, 0, 0x7fffffff, 0x00020000);
+        const unsigned xbase = (unsigned)(((h0 * a.W + w0) * a.x_ldc) * 4);
         __syncthreads();                                  // every wave is done with the previous brick
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -328,7 +330,7 @@ __device__ __forceinline__ void upconv_wgrad_body(const WgradArgs& a, int tilesH
             // output rows 2(h0 + vh) + uth < Ho  <=>  vh < (Ho - uth + 1)/2 - h0; likewise along w
             const unsigned gmask = range_mask(h0, 2, (a.Ho - uth + 1) >> 1) | (range_mask(w0, 16, (a.Wo - utw + 1) >> 1) << 2);
             const bool dok = a.sd * d + utd < a.Do;
-            const unsigned gbase = (unsigned)(((((nb * a.Do + a.sd * d) * a.Ho + 2 * h0) * a.Wo + 2 * w0) * a.dy_ldc) * 4);
+            const unsigned gbase = (unsigned)(((2 * h0 * a.Wo + 2 * w0) * a.dy_ldc) * 4);
             const bool ok = dok && (gmask & gpm) == gpm;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rs, (lds_ptr_u)(gs + (tp * 4 + wave) * 256), 16, ok ? grel[tp] + gbase : OOB, 0, 0, 0);
         }
@@ -385,8 +387,8 @@ int upconv_wgrad_splits(int N, int D, int H, int W, int Cin, int Cout) {
 int launch_upconv_wgrad(WgradArgs a, hipStream_t s) {
     E3_REQUIRE((a.x_ldc & 3) == 0 && (a.dy_ldc & 3) == 0 && ((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.dy & 15) == 0, E3_ERR_INVALID,
                "upconv wgrad views must be 16-byte aligned");
-    E3_REQUIRE((size_t)a.N * a.D * a.H * a.W * a.x_ldc * 4 < 0x7fffffffu && (size_t)a.N * a.Do * a.Ho * a.Wo * a.dy_ldc * 4 < 0x7fffffffu,
-               E3_ERR_UNSUPPORTED, "upconv wgrad: tensors beyond 2 GiB (32-bit buffer offsets)");
+    E3_REQUIRE((size_t)a.H * a.W * a.x_ldc * 4 < 0x7fffffffu && (size_t)2 * a.Ho * a.Wo * a.dy_ldc * 4 < 0x7fffffffu,
+               E3_ERR_UNSUPPORTED, "upconv wgrad: a d-slice beyond 2 GiB (32-bit buffer offsets)");
     const int tH = cdiv(a.H, 2), tW = cdiv(a.W, 16);
     const int nbricks = a.N * a.D * tH * tW;
     const int ci_tiles = a.Cin / 64, co_tiles = a.Cout / 32;
