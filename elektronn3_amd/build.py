@@ -42,6 +42,17 @@ def build(force=False, verbose=False):
     if not force and not _stale(OUT, srcs + hdrs + [os.path.abspath(__file__)]):
         return OUT
     os.makedirs(OBJDIR, exist_ok=True)
+    # one builder at a time (several ranks of a torch.distributed launch may import the package at once): the others wait for
+    # the lock and then find the library fresh
+    import fcntl
+    with open(os.path.join(OBJDIR, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale(OUT, srcs + hdrs + [os.path.abspath(__file__)]):
+            return OUT
+        return _build_locked(srcs, hdrs, force, verbose)
+
+
+def _build_locked(srcs, hdrs, force, verbose):
     hipcc = _hipcc()
 
     def compile_one(src):
@@ -59,10 +70,12 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+    tmp = OUT + f'.tmp{os.getpid()}'
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stderr}')
+    os.replace(tmp, OUT)              # atomic: a concurrent dlopen never sees a half-written library
     return OUT
 
 
