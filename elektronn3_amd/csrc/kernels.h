@@ -110,6 +110,13 @@ int launch_ce_dice_fwd(const float* logits, const long long* target, const float
 int launch_ce_dice_bwd(const float* logits, const long long* target, const float* w, int C, int N, size_t vps,
                        const float* workspace, const float* gout, float* dlogits, hipStream_t s);
 
+// ---------------------------------------------------------------- optimizer (optim.hip)
+size_t adamw_state_floats(int n_tensors, const long long* numels);
+size_t adamw_state_offset(int n_tensors, const long long* numels, int tensor);
+int launch_adamw(int n_tensors, void* const* params, void* const* grads, const long long* numels, float* exp_avg, float* exp_avg_sq,
+                 float* step, float* coef, double lr, double beta1, double beta2, double eps, double weight_decay,
+                 const float* grad_scale, const float* found_inf, hipStream_t s);
+
 // ---------------------------------------------------------------- wgrad on f32 MFMA
 struct WgradArgs {
     const float* x; int x_ldc; int Cin;     // conv input activation view

@@ -190,6 +190,22 @@ int e3_ce_dice_fwd(void* stream, const float* logits, const long long* target, c
 int e3_ce_dice_bwd(void* stream, const float* logits, const long long* target, const float* w, int C, int N, int D, int H, int W,
                    const void* workspace, size_t workspace_bytes, const float* gout, float* dlogits);
 
+/* torch.optim.AdamW(model.parameters(), lr, betas, eps, weight_decay) [examples/train_unet_neurodata.py:257-262; stepped by
+ * training/trainer.py:539-542 through GradScaler.step] as ONE launch over all parameter tensors:
+ *   p *= 1 - lr*wd;  m += (1-b1)(g - m);  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
+ * params/grads/numels: HOST arrays of n_tensors device pointers / element counts (fp32 tensors, each with its own
+ * allocation; grads[i] may be NULL = tensor skipped).  exp_avg/exp_avg_sq: flat device buffers of
+ * e3_adamw_state_floats() floats, zero-initialised by the caller; tensor i's moments start at e3_adamw_state_offset(.., i).
+ * step: device float (number of steps taken, incremented here); coef: device scratch of 8 floats.
+ * grad_scale/found_inf: NULL, or the device scalars a torch GradScaler registers on an optimizer with
+ * _step_supports_amp_scaling: gradients are divided by grad_scale[0]; found_inf[0] != 0 skips the whole step (no host sync). */
+size_t e3_adamw_state_floats(int n_tensors, const long long* numels);
+size_t e3_adamw_state_offset(int n_tensors, const long long* numels, int tensor);
+int e3_adamw_step(void* stream, int n_tensors, void* const* params, void* const* grads, const long long* numels,
+                  float* exp_avg, float* exp_avg_sq, float* step, float* coef,
+                  double lr, double beta1, double beta2, double eps, double weight_decay,
+                  const float* grad_scale, const float* found_inf);
+
 /* Layout conversion at the module boundary. */
 int e3_ncdhw_to_ndhwc(void* stream, const float* src, float* dst, int N, int C, int D, int H, int W);
 int e3_ndhwc_to_ncdhw(void* stream, const float* src, int src_ldc, float* dst, int N, int C, int D, int H, int W);

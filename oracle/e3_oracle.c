@@ -15,6 +15,7 @@
  *   orc_relu_*        nn.ReLU()                                          unet.py:183-186
  *   orc_maxpool_*     nn.MaxPool3d(k=2|(1,2,2), ceil_mode=True)          unet.py:67-74,225-230
  *   orc_softmax_c     nn.Softmax(1)                                      inference.py:443-444
+ *   orc_adamw_step    torch.optim.AdamW(lr, weight_decay)                examples/train_unet_neurodata.py:257-262
  *
  * Layout: contiguous NCDHW fp32 exactly like the reference's tensors.  Sums are
  * accumulated in double so that the oracle is at least as accurate as the fp32
@@ -393,4 +394,25 @@ void orc_softmax_c(const float *x, float *y, int N, int C, size_t S)
             for (int c = 0; c < C; ++c)
                 y[((size_t)n * C + c) * S + i] = (float)(exp((double)x[((size_t)n * C + c) * S + i] - m) / s);
         }
+}
+
+/* torch.optim.AdamW single step (decoupled weight decay, no amsgrad), the optimizer of the reference example
+ * (examples/train_unet_neurodata.py:257-262; stepped in training/trainer.py:539-542).  Published semantics
+ * (torch/optim/adamw.py, "_single_tensor_adam" with decoupled_weight_decay):
+ *   p <- p * (1 - lr*wd);  m <- m + (1-b1)(g - m);  v <- b2*v + (1-b2) g*g
+ *   p <- p - lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)            t = step count AFTER the increment
+ * Arithmetic in double, state stored as fp32 like torch's. */
+void orc_adamw_step(float *p, const float *g, float *m, float *v, size_t n, int t,
+                    double lr, double b1, double b2, double eps, double wd)
+{
+    const double bc1 = 1.0 - pow(b1, (double)t), bc2s = sqrt(1.0 - pow(b2, (double)t));
+    for (size_t i = 0; i < n; ++i) {
+        double pi = (double)p[i] * (1.0 - lr * wd);
+        const double gi = g[i];
+        const double mi = (double)m[i] + (1.0 - b1) * (gi - (double)m[i]);
+        const double vi = (double)v[i] * b2 + (1.0 - b2) * gi * gi;
+        m[i] = (float)mi; v[i] = (float)vi;
+        pi -= lr / bc1 * ((double)m[i] / (sqrt((double)v[i]) / bc2s + eps));
+        p[i] = (float)pi;
+    }
 }

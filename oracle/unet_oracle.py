@@ -182,6 +182,15 @@ def softmax_c(x):
     return y
 
 
+def adamw_step(p, g, m, v, t, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    """In-place torch.optim.AdamW step number t (1-based) on fp32 arrays p, m, v (examples/train_unet_neurodata.py:257-262)."""
+    for a in (p, m, v):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    g = _f32(g)
+    lib().orc_adamw_step(_p(p), _p(g), _p(m), _p(v), ctypes.c_size_t(p.size), int(t), ctypes.c_double(lr), ctypes.c_double(betas[0]),
+                         ctypes.c_double(betas[1]), ctypes.c_double(eps), ctypes.c_double(weight_decay))
+
+
 def autocrop(from_down, from_up):
     """unet.py:256-325 -- crop decoder output by 1 where (u-d) is odd, centre-crop encoder output."""
     if from_down.shape[2:] == from_up.shape[2:]:

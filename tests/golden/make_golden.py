@@ -16,6 +16,7 @@ Fixtures
                    trainer.py:509-543 with the example's criterion train_unet_neurodata.py:294-296)
     predictor.npz  Predictor.predict tiled + padded-shape case (inference.py:569-687)
     trainsteps.npz 3 AdamW steps: loss trajectory + final weights
+    adamw.npz      torch.optim.AdamW alone: 5 steps on random tensors with a changing lr (parameters + both moments per step)
 """
 import importlib.util
 import os
@@ -257,7 +258,35 @@ def make_trainsteps(unet, loss_mod, out):
     print('wrote', out, f'{os.path.getsize(out) / 1e6:.2f} MB', losses)
 
 
+def make_adamw(out):
+    """torch.optim.AdamW as the example configures it (train_unet_neurodata.py:257-262), lr varied per step like CyclicLR does."""
+    torch.manual_seed(5)
+    shapes = [(7,), (3, 5), (2, 3, 3, 3, 3), (1030,)]
+    ps = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    opt = torch.optim.AdamW(ps, lr=1e-3, weight_decay=0.5e-4, foreach=False)
+    lrs = [1e-3, 2e-3, 5e-4, 1e-6, 3e-3]
+    d = {'lrs': np.array(lrs), 'n': np.array(len(shapes))}
+    for i, p in enumerate(ps):
+        d[f'p0/{i}'] = npy(p).copy()
+    for t, lr in enumerate(lrs):
+        for grp in opt.param_groups:
+            grp['lr'] = lr
+        for i, p in enumerate(ps):
+            p.grad = torch.randn(p.shape) * (10.0 ** (i - 2))      # gradient scales 1e-2 .. 10
+            d[f'g{t}/{i}'] = npy(p.grad).copy()
+        opt.step()
+        for i, p in enumerate(ps):
+            d[f'p{t + 1}/{i}'] = npy(p).copy()
+            d[f'm{t + 1}/{i}'] = npy(opt.state[p]['exp_avg']).copy()
+            d[f'v{t + 1}/{i}'] = npy(opt.state[p]['exp_avg_sq']).copy()
+    np.savez_compressed(out, **d)
+    print('wrote', out, f'{os.path.getsize(out) / 1e6:.2f} MB')
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'adamw':      # only the optimizer fixture (needs torch, not the reference)
+        make_adamw(f'{HERE}/adamw.npz')
+        sys.exit(0)
     torch.set_num_threads(8)
     unet, inference, loss_mod = load_reference()
     make_ops(unet, f'{HERE}/ops.npz')
@@ -268,4 +297,5 @@ if __name__ == '__main__':
     # the headline depth (n_blocks=4) at start_filts=8, cfg-4 style mixed 3D/2D (planar_blocks=(0,1))
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb4_sf8_planar01.npz', seed=2, n_blocks=4, start_filts=8, planar_blocks=(0, 1), shape=(8, 32, 32), batch=2)
     make_predictor(unet, inference, f'{HERE}/predictor.npz')
+    make_adamw(f'{HERE}/adamw.npz')
     make_trainsteps(unet, loss_mod, f'{HERE}/trainsteps.npz')

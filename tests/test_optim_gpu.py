@@ -1,0 +1,150 @@
+"""GPU parity of elektronn3_amd.optim.AdamW (one HIP launch over all parameter tensors) against
+
+  (a) torch.optim.AdamW's golden 5-step trajectory (tests/golden/adamw.npz) and the CPU oracle's restatement,
+  (b) torch.optim.AdamW running on the same GPU over the real parameter set of cfg 2 (70 tensors, 5.6 M elements),
+  (c) the callers' protocol: lr schedulers, state_dict round trips with the stock optimizer, GradScaler's
+      un-scaling / skip-on-inf (training/trainer.py:539-542), the reference's SWA wrapper semantics (p.data.copy_).
+
+Stated tolerance: parameters and moments rtol 2e-6 (+1e-7 abs) per step -- fp32 round-off of the same formula.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_npz
+
+pytestmark = pytest.mark.gpu
+
+
+def _opt(params, **kw):
+    from elektronn3_amd.optim import AdamW
+    return AdamW(params, **kw)
+
+
+def test_golden_trajectory_and_oracle():
+    from oracle import unet_oracle as orc
+    g = load_npz('adamw.npz')
+    n = int(g['n'])
+    ps = [torch.nn.Parameter(torch.from_numpy(g[f'p0/{i}'].copy()).cuda()) for i in range(n)]
+    opt = _opt(ps, lr=1e-3, weight_decay=0.5e-4)
+    om = [np.zeros_like(g[f'p0/{i}']) for i in range(n)]; ov = [np.zeros_like(a) for a in om]
+    op = [g[f'p0/{i}'].copy() for i in range(n)]
+    for t, lr in enumerate(g['lrs']):
+        for grp in opt.param_groups:
+            grp['lr'] = float(lr)
+        for i, p in enumerate(ps):
+            p.grad = torch.from_numpy(g[f'g{t}/{i}']).cuda()
+            orc.adamw_step(op[i], g[f'g{t}/{i}'], om[i], ov[i], t + 1, lr=float(lr), weight_decay=0.5e-4)
+        opt.step()
+        for i, p in enumerate(ps):
+            st = opt.state[p]
+            # m = m + 0.1 (g - m) cancels where the result crosses zero: absolute slack of a few ulp of the tensor's scale
+            np.testing.assert_allclose(st['exp_avg'].cpu().numpy(), g[f'm{t + 1}/{i}'], rtol=2e-6, atol=3e-7 * np.abs(g[f'm{t + 1}/{i}']).max())
+            np.testing.assert_allclose(st['exp_avg_sq'].cpu().numpy(), g[f'v{t + 1}/{i}'], rtol=2e-6, atol=0)
+            np.testing.assert_allclose(p.detach().cpu().numpy(), g[f'p{t + 1}/{i}'], rtol=2e-6, atol=1e-7)
+            np.testing.assert_allclose(p.detach().cpu().numpy(), op[i], rtol=2e-6, atol=1e-7)
+            assert float(st['step']) == t + 1
+
+
+def test_full_parameter_set_against_torch_adamw():
+    """cfg 2's 70 parameter tensors, 6 steps with a cyclic lr, some tensors without a gradient in some steps."""
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(0)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=32, normalization='batch').cuda()
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in m.parameters()]
+    mine = list(m.parameters())
+    o_ref = torch.optim.AdamW(ref, lr=1e-3, weight_decay=0.5e-4)
+    o_my = _opt(mine, lr=1e-3, weight_decay=0.5e-4)
+    s_ref = torch.optim.lr_scheduler.CyclicLR(o_ref, base_lr=1e-6, max_lr=1e-3, step_size_up=2, step_size_down=3, cycle_momentum=False)
+    s_my = torch.optim.lr_scheduler.CyclicLR(o_my, base_lr=1e-6, max_lr=1e-3, step_size_up=2, step_size_down=3, cycle_momentum=False)
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    for step in range(6):
+        for k, (a, b) in enumerate(zip(mine, ref)):
+            if step == 2 and k % 7 == 3:
+                a.grad = None; b.grad = None       # torch skips parameters without a gradient; so must we
+                continue
+            gr = torch.randn(a.shape, device='cuda', generator=gen) * 10.0 ** ((k % 5) - 3)
+            a.grad = gr.clone(); b.grad = gr.clone()
+        o_ref.step(); o_my.step(); s_ref.step(); s_my.step()
+        assert o_ref.param_groups[0]['lr'] == o_my.param_groups[0]['lr']
+    for k, (a, b) in enumerate(zip(mine, ref)):
+        if k % 7 == 3:
+            continue        # skipped once: torch keeps a per-tensor step count, ours is per group (documented difference)
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=5e-6, atol=2e-7, msg=lambda s: f'param {k}: {s}')
+        torch.testing.assert_close(o_my.state[a]['exp_avg'], o_ref.state[b]['exp_avg'], rtol=5e-6, atol=3e-7 * float(o_ref.state[b]['exp_avg'].abs().max()))
+        torch.testing.assert_close(o_my.state[a]['exp_avg_sq'], o_ref.state[b]['exp_avg_sq'], rtol=5e-6, atol=1e-20)
+
+
+def test_state_dict_round_trip_with_stock_optimizer():
+    torch.manual_seed(3)
+    shapes = [(5, 3), (1025,), (4, 4, 3, 3, 3)]
+    base = [torch.randn(s, device='cuda') for s in shapes]
+    grads = [[torch.randn(s, device='cuda') for s in shapes] for _ in range(4)]
+
+    def run(opt_a, opt_b):
+        """2 steps with optimizer type a, state_dict -> optimizer type b, 2 more steps."""
+        ps = [torch.nn.Parameter(b.clone()) for b in base]
+        oa = opt_a(ps)
+        for t in range(2):
+            for p, g in zip(ps, grads[t]): p.grad = g.clone()
+            oa.step()
+        ob = opt_b(ps)
+        ob.load_state_dict(oa.state_dict())
+        for t in range(2, 4):
+            for p, g in zip(ps, grads[t]): p.grad = g.clone()
+            ob.step()
+        return [p.detach().clone() for p in ps]
+
+    stock = lambda ps: torch.optim.AdamW(ps, lr=2e-3, weight_decay=1e-2)
+    ours = lambda ps: _opt(ps, lr=2e-3, weight_decay=1e-2)
+    want = run(stock, stock)
+    for got in (run(ours, ours), run(ours, stock), run(stock, ours)):
+        for a, b in zip(got, want):
+            torch.testing.assert_close(a, b, rtol=5e-6, atol=2e-7)
+
+
+def test_grad_scaler_unscale_and_skip():
+    """GradScaler.step(optimizer): gradients arrive multiplied by the scale; an inf anywhere vetoes the whole step."""
+    torch.manual_seed(4)
+    ps = [torch.nn.Parameter(torch.randn(300, device='cuda')), torch.nn.Parameter(torch.randn(17, 9, device='cuda'))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    o_my = _opt(ps, lr=1e-3, weight_decay=0.5e-4); o_ref = torch.optim.AdamW(ref, lr=1e-3, weight_decay=0.5e-4)
+    scaler = torch.amp.GradScaler('cuda', init_scale=1024.0)
+    for step in range(3):
+        gs = [torch.randn_like(p) for p in ps]
+        scaler.scale(torch.zeros(1, device='cuda'))                      # what scaler.scale(loss) does first: lazy init of the scale
+        for p, r, g in zip(ps, ref, gs):
+            p.grad = g * scaler.get_scale(); r.grad = g.clone()
+        if step == 1:
+            ps[1].grad[3, 3] = float('inf')
+        before = [p.detach().clone() for p in ps]
+        scaler.step(o_my); scaler.update()
+        if step == 1:
+            for p, b in zip(ps, before):
+                assert torch.equal(p.detach(), b)                       # skipped
+            assert float(o_my.state[ps[0]]['step']) == 1
+            assert scaler.get_scale() == 512.0                           # backoff happened
+        else:
+            o_ref.step()
+    for p, r in zip(ps, ref):
+        torch.testing.assert_close(p.detach(), r.detach(), rtol=5e-6, atol=2e-7)
+
+
+def test_swa_style_parameter_swap_keeps_working():
+    """The reference's SWA wrapper swaps weights with p.data.copy_ (training/swa.py:182-202): pointers stay, state stays."""
+    torch.manual_seed(6)
+    p = torch.nn.Parameter(torch.randn(2000, device='cuda')); r = torch.nn.Parameter(p.detach().clone())
+    o_my = _opt([p], lr=1e-3); o_ref = torch.optim.AdamW([r], lr=1e-3)
+    for step in range(3):
+        g = torch.randn(2000, device='cuda'); p.grad = g.clone(); r.grad = g.clone()
+        o_my.step(); o_ref.step()
+        buf = torch.randn(2000, device='cuda')
+        p.data.copy_(buf); r.data.copy_(buf)
+    torch.testing.assert_close(p.detach(), r.detach(), rtol=5e-6, atol=2e-7)
+
+
+def test_cpu_parameters_raise():
+    o = _opt([torch.nn.Parameter(torch.randn(4))], lr=1e-3)
+    o.param_groups[0]['params'][0].grad = torch.randn(4)
+    with pytest.raises(RuntimeError):
+        o.step()

@@ -128,3 +128,17 @@ def test_predictor_tiled():
     out3 = orc.predict_tiled(net, g['vol3'], g['tile'], g['overlap'], (2, 16, 32, 32))
     am = out3.argmax(axis=1)[:, None].astype(np.uint8)
     assert (am != g['out3_argmax']).mean() < 1e-4  # argmax may flip only where p0 ~ p1 within fp32 noise
+
+
+def test_adamw_trajectory():
+    """orc_adamw_step against torch.optim.AdamW's own 5-step trajectory with a changing lr (tests/golden/adamw.npz)."""
+    g = load_npz('adamw.npz')
+    for i in range(int(g['n'])):
+        p = g[f'p0/{i}'].copy()
+        m = np.zeros_like(p); v = np.zeros_like(p)
+        for t, lr in enumerate(g['lrs']):
+            orc.adamw_step(p, g[f'g{t}/{i}'], m, v, t + 1, lr=float(lr), weight_decay=0.5e-4)
+            # m = m + 0.1 (g - m) cancels where the result crosses zero: absolute slack of a few ulp of the tensor's scale
+            np.testing.assert_allclose(m, g[f'm{t + 1}/{i}'], rtol=2e-6, atol=3e-7 * np.abs(g[f'm{t + 1}/{i}']).max())
+            np.testing.assert_allclose(v, g[f'v{t + 1}/{i}'], rtol=2e-6, atol=0)
+            np.testing.assert_allclose(p, g[f'p{t + 1}/{i}'], rtol=2e-6, atol=1e-7)
