@@ -183,21 +183,28 @@ def _flat_views(plan, tens, device):
     return flat, views
 
 
+# layer types per dimensionality: conv, transposed conv, max-pool, batch norm (unet.py:47-105)
+_LAYERS = {3: (nn.Conv3d, nn.ConvTranspose3d, nn.MaxPool3d, nn.BatchNorm3d),
+           2: (nn.Conv2d, nn.ConvTranspose2d, nn.MaxPool2d, nn.BatchNorm2d)}
+
+
 class DownConv(nn.Module):
     """Parameter container for one encoder block (two convs, two norms, max-pool) -- reference: unet.py:202-253."""
 
-    def __init__(self, in_channels, out_channels, pooling=True, planar=False):
+    def __init__(self, in_channels, out_channels, pooling=True, planar=False, dim=3):
         super().__init__()
         self.in_channels, self.out_channels, self.pooling, self.planar = in_channels, out_channels, pooling, planar
-        k, p = ((1, 3, 3), (0, 1, 1)) if planar else (3, 1)
-        self.conv1 = nn.Conv3d(in_channels, out_channels, kernel_size=k, padding=p)
-        self.conv2 = nn.Conv3d(out_channels, out_channels, kernel_size=k, padding=p)
+        self.dim = dim
+        Conv, Pool, Norm = _LAYERS[dim][0], _LAYERS[dim][2], _LAYERS[dim][3]
+        k, p = ((1, 3, 3), (0, 1, 1)) if (planar and dim == 3) else (3, 1)
+        self.conv1 = Conv(in_channels, out_channels, kernel_size=k, padding=p)
+        self.conv2 = Conv(out_channels, out_channels, kernel_size=k, padding=p)
         if pooling:
-            self.pool = nn.MaxPool3d(kernel_size=(1, 2, 2) if planar else 2, ceil_mode=True)
+            self.pool = Pool(kernel_size=(1, 2, 2) if (planar and dim == 3) else 2, ceil_mode=True)
         else:
             self.pool = nn.Identity()
         self.act1, self.act2 = nn.ReLU(), nn.ReLU()
-        self.norm0, self.norm1 = nn.BatchNorm3d(out_channels), nn.BatchNorm3d(out_channels)
+        self.norm0, self.norm1 = Norm(out_channels), Norm(out_channels)
 
     def forward(self, x):
         raise RuntimeError('elektronn3_amd sub-modules only hold parameters; call UNet.forward')
@@ -206,16 +213,18 @@ class DownConv(nn.Module):
 class UpConv(nn.Module):
     """Parameter container for one decoder block (transposed conv, two convs, three norms) -- reference: unet.py:328-408."""
 
-    def __init__(self, in_channels, out_channels, planar=False):
+    def __init__(self, in_channels, out_channels, planar=False, dim=3):
         super().__init__()
         self.in_channels, self.out_channels, self.planar = in_channels, out_channels, planar
-        ks = (1, 2, 2) if planar else 2
-        k, p = ((1, 3, 3), (0, 1, 1)) if planar else (3, 1)
-        self.upconv = nn.ConvTranspose3d(in_channels, out_channels, kernel_size=ks, stride=ks)
-        self.conv1 = nn.Conv3d(2 * out_channels, out_channels, kernel_size=k, padding=p)
-        self.conv2 = nn.Conv3d(out_channels, out_channels, kernel_size=k, padding=p)
+        self.dim = dim
+        Conv, ConvT, Norm = _LAYERS[dim][0], _LAYERS[dim][1], _LAYERS[dim][3]
+        ks = (1, 2, 2) if (planar and dim == 3) else 2
+        k, p = ((1, 3, 3), (0, 1, 1)) if (planar and dim == 3) else (3, 1)
+        self.upconv = ConvT(in_channels, out_channels, kernel_size=ks, stride=ks)
+        self.conv1 = Conv(2 * out_channels, out_channels, kernel_size=k, padding=p)
+        self.conv2 = Conv(out_channels, out_channels, kernel_size=k, padding=p)
         self.act0, self.act1, self.act2 = nn.ReLU(), nn.ReLU(), nn.ReLU()
-        self.norm0, self.norm1, self.norm2 = (nn.BatchNorm3d(out_channels) for _ in range(3))
+        self.norm0, self.norm1, self.norm2 = (Norm(out_channels) for _ in range(3))
         self.att = None   # Trainer reads model.up_convs[i].att (trainer.py:611-617); always None without attention
 
     def forward(self, enc, dec):
@@ -225,9 +234,10 @@ class UpConv(nn.Module):
 class UNet(nn.Module):
     """3D U-Net with the reference's interface (elektronn3/models/unet.py:755-771), executed by hand-written HIP
     kernels.  Options of the reference that are not yet on the HIP path raise ``NotImplementedError`` at
-    construction: ``dim=2``, ``up_mode != 'transpose'``, ``merge_mode='add'``,
+    construction: ``up_mode != 'transpose'``, ``merge_mode='add'``,
     ``attention=True``, ``activation != 'relu'``, ``normalization != 'batch'``, ``full_norm=False``,
-    ``conv_mode != 'same'``."""
+    ``conv_mode != 'same'``.  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
+    the 3D one with every block planar and a depth of 1."""
 
     def __init__(
             self,
@@ -271,7 +281,6 @@ class UNet(nn.Module):
                                'If you still want to use batch normalization, set `normalization=batch` instead.')
         # -- what the HIP path implements this round
         unsupported = []
-        if dim != 3: unsupported.append('dim=2')
         if up_mode != 'transpose': unsupported.append(f'up_mode={up_mode!r}')
         if merge_mode != 'concat': unsupported.append(f'merge_mode={merge_mode!r}')
         if attention: unsupported.append('attention=True')
@@ -304,18 +313,18 @@ class UNet(nn.Module):
         for i in range(n_blocks):
             ins = in_channels if i == 0 else outs
             outs = start_filts * (2 ** i)
-            self.down_convs.append(DownConv(ins, outs, pooling=i < n_blocks - 1, planar=i in self.planar_blocks))
+            self.down_convs.append(DownConv(ins, outs, pooling=i < n_blocks - 1, planar=i in self.planar_blocks, dim=dim))
         for i in range(n_blocks - 1):
             ins = outs
             outs = ins // 2
-            self.up_convs.append(UpConv(ins, outs, planar=(n_blocks - 2 - i) in self.planar_blocks))
-        self.conv_final = nn.Conv3d(outs, out_channels, kernel_size=1)
+            self.up_convs.append(UpConv(ins, outs, planar=(n_blocks - 2 - i) in self.planar_blocks, dim=dim))
+        self.conv_final = _LAYERS[dim][0](outs, out_channels, kernel_size=1)
         self.apply(self.weight_init)
 
     @staticmethod
     def weight_init(m):
         """Xavier-normal weights, zero biases for every (transposed) conv -- same scheme as unet.py:885-892."""
-        if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)):
+        if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d, nn.Conv2d, nn.ConvTranspose2d)):   # get_conv/get_convtranspose of the model's dim
             nn.init.xavier_normal_(m.weight)
             if m.bias is not None:
                 nn.init.constant_(m.bias, 0)
@@ -330,7 +339,7 @@ class UNet(nn.Module):
     # ------------------------------------------------------------------ native plumbing
     def _plan_key(self):
         mask = 0
-        for b in self.planar_blocks:
+        for b in (range(self.n_blocks) if self.dim == 2 else self.planar_blocks):   # dim=2: every block is planar, depth 1
             mask |= 1 << int(b)
         return (self.in_channels, self.out_channels, self.n_blocks, self.start_filts, mask, 1, float(self.down_convs[0].norm0.eps))
 
@@ -371,6 +380,10 @@ class UNet(nn.Module):
         return self._run(x, softmax=False)
 
     def _run(self, x, softmax=False):
+        if self.dim == 2:
+            if not isinstance(x, torch.Tensor) or x.dim() != 4:
+                raise ValueError('expected a 4D (N, C, H, W) tensor')
+            x = x.unsqueeze(2)
         if not isinstance(x, torch.Tensor) or x.dim() != 5:
             raise ValueError('expected a 5D (N, C, D, H, W) tensor')
         if x.shape[1] != self.in_channels:
@@ -381,7 +394,8 @@ class UNet(nn.Module):
         params = [p for _, p in self._named_table_params(plan)]
         if any(p.device != x.device for p in params):
             raise RuntimeError('input and parameters are on different devices')
-        return _UNetFunction.apply(self, softmax, x, *params)
+        y = _UNetFunction.apply(self, softmax, x, *params)
+        return y.squeeze(2) if self.dim == 2 else y
 
     def forward_softmax(self, x):
         """``softmax(forward(x), dim=1)`` with the softmax fused into the final 1x1x1 conv kernel (used by Predictor)."""

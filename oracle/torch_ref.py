@@ -23,19 +23,18 @@ def _bn(x, sd, name, training, momentum=0.1, eps=1e-5):
 def _conv(x, sd, name):
     w = sd[name + '.weight']
     pad = tuple((k - 1) // 2 for k in w.shape[2:])
-    return F.conv3d(x, w, sd[name + '.bias'], padding=pad)
+    return (F.conv3d if w.dim() == 5 else F.conv2d)(x, w, sd[name + '.bias'], padding=pad)   # get_conv(dim), unet.py:47-54
 
 
 def autocrop(from_down, from_up):
-    """unet.py:256-325 restated for 5D tensors."""
+    """unet.py:256-325 restated (4D and 5D tensors)."""
     if from_down.shape[2:] == from_up.shape[2:]:
         return from_down, from_up
     ds, us = from_down.shape[2:], from_up.shape[2:]
     upcrop = [u - ((u - d) % 2) for d, u in zip(ds, us)]
-    from_up = from_up[:, :, :upcrop[0], :upcrop[1], :upcrop[2]]
+    from_up = from_up[(slice(None), slice(None)) + tuple(slice(0, c) for c in upcrop)]
     us = from_up.shape[2:]
-    from_down = from_down[:, :, (ds[0] - us[0]) // 2:(ds[0] + us[0]) // 2, (ds[1] - us[1]) // 2:(ds[1] + us[1]) // 2,
-                          (ds[2] - us[2]) // 2:(ds[2] + us[2]) // 2]
+    from_down = from_down[(slice(None), slice(None)) + tuple(slice((d - u) // 2, (d + u) // 2) for d, u in zip(ds, us))]
     return from_down, from_up
 
 
@@ -48,13 +47,16 @@ def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True):
         y = F.relu(_bn(_conv(y, sd, p + 'conv2'), sd, p + 'norm1', training))
         enc.append(y)
         if i < n_blocks - 1:
-            x = F.max_pool3d(y, kernel_size=(1, 2, 2) if i in planar_blocks else 2, ceil_mode=True)
+            if y.dim() == 4:
+                x = F.max_pool2d(y, kernel_size=2, ceil_mode=True)
+            else:
+                x = F.max_pool3d(y, kernel_size=(1, 2, 2) if i in planar_blocks else 2, ceil_mode=True)
         else:
             x = y
     for i in range(n_blocks - 1):
         p = f'up_convs.{i}.'
         w = sd[p + 'upconv.weight']
-        up = F.conv_transpose3d(x, w, sd[p + 'upconv.bias'], stride=tuple(w.shape[2:]))
+        up = (F.conv_transpose3d if w.dim() == 5 else F.conv_transpose2d)(x, w, sd[p + 'upconv.bias'], stride=tuple(w.shape[2:]))
         skip, up = autocrop(enc[-(i + 2)], up)
         up = F.relu(_bn(up, sd, p + 'norm0', training))
         y = torch.cat((up, skip), 1)

@@ -155,10 +155,10 @@ def criterion(loss_mod):
                                   loss_mod.DiceLoss(apply_softmax=True, weight=cw)], weight=[0.5, 0.5])
 
 
-def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch):
+def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3):
     torch.manual_seed(seed)
     model = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
-                      planar_blocks=planar_blocks, activation='relu', normalization='batch')
+                      planar_blocks=planar_blocks, activation='relu', normalization='batch', dim=dim)
     # make BN affine + conv bias non-trivial so that the fixtures exercise them
     with torch.no_grad():
         for name, p in model.named_parameters():
@@ -177,6 +177,8 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
     loss.backward()
     d = {'cfg.n_blocks': n_blocks, 'cfg.start_filts': start_filts, 'cfg.planar_blocks': np.array(planar_blocks, dtype=np.int64),
          'x': npy(x), 'target': npy(target), 'logits': npy(out_t), 'loss': npy(loss), 'dlogits': npy(dout)}
+    if dim != 3:
+        d['cfg.dim'] = dim
     for k, v in sd0.items():
         d['sd0/' + k] = v
     for k, v in model.state_dict().items():
@@ -189,7 +191,7 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
         d['logits_eval'] = npy(model(x))
     # fp64 reference of the same step (tolerances are stated against it)
     m64 = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
-                    planar_blocks=planar_blocks, activation='relu', normalization='batch').double()
+                    planar_blocks=planar_blocks, activation='relu', normalization='batch', dim=dim).double()
     m64.load_state_dict({k: torch.as_tensor(v).double() if v.dtype != np.int64 else torch.as_tensor(v) for k, v in sd0.items()})
     m64.train()
     o64 = m64(x.double())
@@ -289,6 +291,9 @@ if __name__ == '__main__':
         sys.exit(0)
     torch.set_num_threads(8)
     unet, inference, loss_mod = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'unet2d':    # only the dim=2 fixture
+        make_unet_case(unet, loss_mod, f'{HERE}/unet2d_nb3_sf8_odd.npz', seed=3, n_blocks=3, start_filts=8, planar_blocks=(), shape=(37, 46), batch=2, dim=2)
+        sys.exit(0)
     make_ops(unet, f'{HERE}/ops.npz')
     # cfg 1 of BASELINE.json at a reduced crop: UNet(1,2,n_blocks=2,start_filts=8)
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8.npz', seed=0, n_blocks=2, start_filts=8, planar_blocks=(), shape=(16, 24, 24), batch=1)
@@ -296,6 +301,8 @@ if __name__ == '__main__':
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_planar0_odd.npz', seed=1, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 17, 21), batch=2)
     # the headline depth (n_blocks=4) at start_filts=8, cfg-4 style mixed 3D/2D (planar_blocks=(0,1))
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb4_sf8_planar01.npz', seed=2, n_blocks=4, start_filts=8, planar_blocks=(0, 1), shape=(8, 32, 32), batch=2)
+    # dim=2 (Conv2d/BatchNorm2d/MaxPool2d/ConvTranspose2d), odd sizes
+    make_unet_case(unet, loss_mod, f'{HERE}/unet2d_nb3_sf8_odd.npz', seed=3, n_blocks=3, start_filts=8, planar_blocks=(), shape=(37, 46), batch=2, dim=2)
     make_predictor(unet, inference, f'{HERE}/predictor.npz')
     make_adamw(f'{HERE}/adamw.npz')
     make_trainsteps(unet, loss_mod, f'{HERE}/trainsteps.npz')

@@ -22,8 +22,17 @@ def rel_l2(a, b):
 
 
 def unet_cfg(npz):
-    return dict(n_blocks=int(npz['cfg.n_blocks']), start_filts=int(npz['cfg.start_filts']),
-                planar_blocks=tuple(int(v) for v in npz['cfg.planar_blocks']))
+    cfg = dict(n_blocks=int(npz['cfg.n_blocks']), start_filts=int(npz['cfg.start_filts']),
+               planar_blocks=tuple(int(v) for v in npz['cfg.planar_blocks']))
+    if 'cfg.dim' in npz.files:
+        cfg['dim'] = int(npz['cfg.dim'])
+    return cfg
+
+
+def embed_2d(sd):
+    """A dim=2 state_dict as the equivalent dim=3 one: (Cout, Cin, kh, kw) conv / transposed-conv weights get a depth-1 kernel
+    axis.  A 2D U-Net IS the 3D one with every block planar on a depth-1 volume (unet.py:47-74,114-128)."""
+    return OrderedDict((k, v[:, :, None] if np.asarray(v).ndim == 4 else v) for k, v in sd.items())
 
 
 CLASS_WEIGHTS = (0.2653, 0.7347)

@@ -9,7 +9,7 @@ reference's fp64 results, where it must be at least as close as the fp32 referen
 import numpy as np
 import pytest
 
-from helpers import combined_loss_np, load_npz, rel_l2, sub, unet_cfg
+from helpers import combined_loss_np, embed_2d, load_npz, rel_l2, sub, unet_cfg
 from oracle import unet_oracle as orc
 
 
@@ -69,15 +69,19 @@ def test_softmax(ops):
     np.testing.assert_allclose(orc.softmax_c(ops['softmax.x']), ops['softmax.y'], rtol=1e-6, atol=1e-7)
 
 
-CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz']
+CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz', 'unet2d_nb3_sf8_odd.npz']
 
 
 @pytest.mark.parametrize('case', CASES)
 def test_unet_train_step(case):
     g = load_npz(case)
     cfg = unet_cfg(g)
-    net = orc.OracleUNet(sub(g, 'sd0'), cfg['n_blocks'], cfg['planar_blocks'])
-    logits = net.forward(g['x'])
+    if cfg.get('dim', 3) == 2:      # dim=2 fixture on the 3D oracle: depth-1 volume, every block planar
+        net = orc.OracleUNet(embed_2d(sub(g, 'sd0')), cfg['n_blocks'], tuple(range(cfg['n_blocks'])))
+        logits = net.forward(g['x'][:, :, None])[:, :, 0]
+    else:
+        net = orc.OracleUNet(sub(g, 'sd0'), cfg['n_blocks'], cfg['planar_blocks'])
+        logits = net.forward(g['x'])
     # forward: fp32 reference noise floor is <= 4e-5 max-abs
     np.testing.assert_allclose(logits, g['logits'], rtol=1e-4, atol=1e-4)
     assert np.abs(logits - g['logits64']).max() <= max(2 * np.abs(g['logits'] - g['logits64']).max(), 2e-6)
@@ -91,7 +95,11 @@ def test_unet_train_step(case):
     loss, dlogits = combined_loss_np(logits, g['target'])
     assert abs(loss - float(g['loss'])) < 1e-5
     np.testing.assert_allclose(dlogits, g['dlogits'], rtol=1e-3, atol=1e-9)
-    grads, _ = net.backward(g['dlogits'])
+    if cfg.get('dim', 3) == 2:
+        grads, _ = net.backward(g['dlogits'][:, :, None])
+        grads = {k: v.reshape(g['grad/' + k].shape) for k, v in grads.items()}
+    else:
+        grads, _ = net.backward(g['dlogits'])
     ref32, ref64 = sub(g, 'grad'), sub(g, 'grad64')
     assert set(grads) == set(ref32)
     gnorm = np.sqrt(sum(float(np.sum(v.astype(np.float64) ** 2)) for v in ref64.values()))

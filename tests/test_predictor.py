@@ -164,3 +164,37 @@ def test_predictor_native_tta_and_cfg5_shaped_tiling(gold):
     assert yb.dtype == torch.uint8 and tuple(yb.shape) == (2, 1, 40, 72, 88) and torch.equal(yb[0, 0], y[0].argmax(0).to(torch.uint8))
     ya = Predictor(m, device='cuda', apply_softmax=True, augmentations=3).predict(vol[:, :, :16, :32, :32])
     assert torch.allclose(ya.sum(1), torch.ones_like(ya[:, 0]), atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_predictor_dim2_native_tiled():
+    """dim=2 model through the same Predictor (tiled_apply is rank-generic, inference.py:115-125): non-divisible image, halo
+    tiles; equals the hand-rolled tiles, and one tile equals the ATen op sequence on PyTorch-ROCm."""
+    from elektronn3_amd.inference import Predictor, tile_plan
+    from elektronn3_amd.unet import UNet
+    from oracle.torch_ref import unet_forward
+    torch.manual_seed(8)
+    m = UNet(1, 2, n_blocks=3, start_filts=16, dim=2).cuda()
+    m.train()
+    with torch.no_grad():
+        for _ in range(2):
+            m(torch.randn(2, 1, 64, 64, device='cuda'))      # non-trivial running statistics
+    m.eval()
+    img = torch.randn(1, 1, 150, 200)
+    tile, ov = (64, 96), (16, 16)
+    y = Predictor(m, device='cuda', tile_shape=tile, overlap_shape=ov, offset=None, out_shape=(2, 150, 200), apply_softmax=True).predict(img)
+    assert tuple(y.shape) == (1, 2, 150, 200) and torch.isfinite(y).all()
+    padded_out = (192, 288)
+    padded = torch.zeros(1, 1, *(p + 2 * o for p, o in zip(padded_out, ov)))
+    padded[:, :, 16:166, 16:216] = img
+    full = torch.zeros(1, 2, *padded_out)
+    sd = {k: v.double() if v.is_floating_point() else v for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        for i, (ilo, ihi, olo, ohi) in enumerate(tile_plan(padded_out, tile, ov)):
+            t = padded[:, :, ilo[0]:ihi[0], ilo[1]:ihi[1]].cuda()
+            o = m.forward_softmax(t)
+            if i == 0:
+                ref = torch.softmax(unet_forward(sd, t.double(), 3, (), training=False), 1)
+                assert torch.allclose(o.double(), ref, rtol=1e-4, atol=1e-5)
+            full[:, :, olo[0]:ohi[0], olo[1]:ohi[1]] = o[:, :, 16:80, 16:112].cpu()
+    assert torch.equal(y, full[:, :, :150, :200])

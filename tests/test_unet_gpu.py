@@ -19,7 +19,7 @@ from helpers import load_npz, rel_l2, sub, unet_cfg
 
 pytestmark = pytest.mark.gpu
 
-CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz']
+CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz', 'unet2d_nb3_sf8_odd.npz']
 
 
 def build(cfg, sd_np):
@@ -239,6 +239,53 @@ def test_full_size_cfg4_anisotropic_against_pytorch_rocm():
             continue
         err = float((p.grad - gr).norm() / gr.norm().clamp_min(1e-30))
         assert err < 2e-2, (k, err)
+
+
+def test_dim2_unet_against_pytorch_rocm():
+    """dim=2 (unet.py:47-74: Conv2d / ConvTranspose2d / MaxPool2d / BatchNorm2d, 4D input) at 2x1x384x512 with the headline
+    widths (n_blocks=4, start_filts=32): runs on the planar kernels incl. the planar Winograd ones; vs the same op sequence
+    on PyTorch-ROCm (fp64, so that its own BN-statistics error does not enter) -- forward, loss, running stats, gradients."""
+    from elektronn3_amd.unet import UNet
+    from oracle.torch_ref import combined_loss, unet_forward
+    torch.manual_seed(5)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=32, normalization='batch', dim=2).cuda().train()
+    assert isinstance(m.down_convs[0].conv1, torch.nn.Conv2d) and isinstance(m.up_convs[0].norm0, torch.nn.BatchNorm2d)
+    x = torch.randn(2, 1, 384, 512, device='cuda')
+    t = torch.randint(0, 2, (2, 384, 512), device='cuda')
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    out = m(x)
+    assert out.shape == (2, 2, 384, 512)
+    loss = combined_loss(out, t)
+    m.zero_grad(set_to_none=True)
+    loss.backward()
+    sd_ref = {k: (v.double() if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k)
+              for k, v in sd0.items()}
+    ref = unet_forward(sd_ref, x.double(), 4, (), training=True)
+    lref = combined_loss(ref, t)
+    lref.backward()
+    assert torch.allclose(out.double(), ref, rtol=1e-4, atol=1e-4), float((out - ref).abs().max())
+    assert abs(float(loss.detach()) - float(lref.detach())) < 1e-5
+    sd1 = m.state_dict()
+    for k in sd0:
+        if 'running' in k:
+            torch.testing.assert_close(sd1[k].double(), sd_ref[k], rtol=1e-5, atol=1e-6, msg=k)
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))
+    for k, p in m.named_parameters():
+        gr = sd_ref[k].grad
+        assert p.grad.shape == p.shape
+        if is_prebn_bias(k):
+            assert float(p.grad.abs().max()) <= 1e-5 * float(gn), k
+            continue
+        err = float((p.grad.double() - gr).norm() / gr.norm().clamp_min(1e-30))
+        assert err < 1e-2, (k, err)
+    # eval mode + the wrong rank fail loudly
+    m.eval()
+    with torch.no_grad():
+        ye = m(x)
+    sd_e = {k: v.double() if v.is_floating_point() else v for k, v in m.state_dict().items()}
+    assert torch.allclose(ye.double(), unet_forward(sd_e, x.double(), 4, (), training=False), rtol=1e-4, atol=1e-4)
+    with pytest.raises(ValueError):
+        m(x.unsqueeze(2))
 
 
 def test_full_size_properties(cfg2):
