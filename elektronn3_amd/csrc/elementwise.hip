@@ -380,6 +380,15 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ part, int parts
     if (lane == 0) out[c] = (float)s;
 }
 
+__global__ void fill_kernel(float* __restrict__ p, float v, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+// conv -> nn.Identity -> ReLU (normalization='none' / full_norm=False): the "folded norm" of the conv epilogue is y = relu(1*acc + bias)
+__global__ void bias_fold_kernel(const float* __restrict__ bias, float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { scale[c] = 1.f; shift[c] = bias ? bias[c] : 0.f; }
+}
+
 // ------------------------------------------------------------------ layout helpers (module boundary only)
 __global__ void ncdhw_to_ndhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, size_t S) {
     const size_t total = (size_t)N * C * S;
@@ -415,6 +424,19 @@ int launch_bn_finalize(BnFinalizeArgs a, hipStream_t s) {
         a.stats = a.scratch; a.parts = BN_PRERED;
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(1024), 0, s, a);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_fill(float* p, float v, size_t n, hipStream_t s) {
+    if (n == 0) return E3_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, p, v, n);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_bias_fold(const float* conv_bias, float* scale, float* shift, int C, hipStream_t s) {
+    hipLaunchKernelGGL(bias_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, conv_bias, scale, shift, C);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

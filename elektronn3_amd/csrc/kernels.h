@@ -110,6 +110,9 @@ int launch_ce_dice_fwd(const float* logits, const long long* target, const float
 int launch_ce_dice_bwd(const float* logits, const long long* target, const float* w, int C, int N, size_t vps,
                        const float* workspace, const float* gout, float* dlogits, hipStream_t s);
 
+int launch_fill(float* p, float v, size_t n, hipStream_t s);
+int launch_bias_fold(const float* conv_bias, float* scale, float* shift, int C, hipStream_t s);   // scale = 1, shift = bias
+
 // ---------------------------------------------------------------- optimizer (optim.hip)
 size_t adamw_state_floats(int n_tensors, const long long* numels);
 size_t adamw_state_offset(int n_tensors, const long long* numels, int tensor);

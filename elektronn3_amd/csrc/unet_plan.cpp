@@ -26,7 +26,8 @@ struct ConvUnit {           // conv (3x3x3 | 1x3x3 | transposed 2x2x2) followed 
     int planar;             // planar block (1x3x3 / (1,2,2))
     int is_up;              // transposed conv (input at level+1)
     int p_w, p_b, p_g, p_be, p_rm, p_rv;   // indices into the param table
-    int bn_index;
+    int bn_index;           // -1: no normalisation after this conv (nn.Identity): conv -> bias -> ReLU
+    bool has_norm() const { return bn_index >= 0; }
 };
 
 struct Arena {              // bump allocator used twice: once with base == nullptr to size, once to place
@@ -65,17 +66,20 @@ int add_param(e3_unet_plan* p, const std::string& name, int64_t numel, int kind)
     return (int)p->params.size() - 1;
 }
 
-void add_unit(e3_unet_plan* p, const std::string& conv, const std::string& bn, int cin, int cout, int level, int planar, int is_up) {
+void add_unit(e3_unet_plan* p, const std::string& conv, const std::string& bn, int cin, int cout, int level, int planar, int is_up, bool norm) {
     ConvUnit u;
     u.name = conv; u.bn_name = bn; u.cin = cin; u.cout = cout; u.level = level; u.planar = planar; u.is_up = is_up;
     const int taps = is_up ? (planar ? 4 : 8) : (planar ? 9 : 27);
     u.p_w = add_param(p, conv + ".weight", (int64_t)cin * cout * taps, 0);
     u.p_b = add_param(p, conv + ".bias", cout, 0);
-    u.p_g = add_param(p, bn + ".weight", cout, 0);
-    u.p_be = add_param(p, bn + ".bias", cout, 0);
-    u.p_rm = add_param(p, bn + ".running_mean", cout, 1);
-    u.p_rv = add_param(p, bn + ".running_var", cout, 1);
-    u.bn_index = p->n_bn++;
+    u.p_g = u.p_be = u.p_rm = u.p_rv = -1; u.bn_index = -1;
+    if (norm) {
+        u.p_g = add_param(p, bn + ".weight", cout, 0);
+        u.p_be = add_param(p, bn + ".bias", cout, 0);
+        u.p_rm = add_param(p, bn + ".running_mean", cout, 1);
+        u.p_rv = add_param(p, bn + ".running_var", cout, 1);
+        u.bn_index = p->n_bn++;
+    }
     p->units.push_back(u);
 }
 
@@ -101,6 +105,7 @@ struct Buffers {
     // scratch
     float* wpack; float* stats; float* bnpart; float* slab; float* small;   // small: coef / fold vectors
     float* bnred;                                                              // pre-merged BN statistic records
+    float* ones; float* zeros;                                                 // [Cmax] / [2*Cmax] constants for units without a norm
     std::vector<float*> g1, g2, dcat;    // gradient buffers per level
     float* evalA; float* evalB;          // inference ping-pong (level-0 sized)
     size_t scratch_bytes;
@@ -128,7 +133,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         const ConvUnit& u = p->units[k];
         UnitBufs& b = B.ub[k];
         const size_t n = L[u.level].vox * u.cout;
-        b.raw = training ? A.take(n) : nullptr;
+        b.raw = (training && u.has_norm()) ? A.take(n) : nullptr;   // without a norm the conv writes relu(acc + bias) directly
         // where does the activation go?
         const bool enc_skip = !u.is_up && u.name.find("down_convs") == 0 && u.name.find("conv2") != std::string::npos && u.level < nb - 1;
         if (enc_skip) { b.act = B.cat[u.level] ? B.cat[u.level] + u.cout : nullptr; b.act_ldc = 2 * u.cout; }
@@ -171,6 +176,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     B.stats = T.take(statmax);
     B.small = T.take((size_t)4 * p->chan(nb - 1) + 64);
     B.bnred = T.take((size_t)BN_PRERED * p->chan(nb - 1) * 3);
+    B.ones = T.take(p->chan(nb - 1)); B.zeros = T.take((size_t)2 * p->chan(nb - 1));
     if (training) {
         B.bnpart = T.take(bnpartmax);
         B.slab = T.take(slabmax);
@@ -215,7 +221,8 @@ int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
     E3_REQUIRE(cfg->out_channels >= 1 && cfg->out_channels <= 8, E3_ERR_UNSUPPORTED, "out_channels must be in 1..8 on the HIP path");
     E3_REQUIRE(cfg->start_filts >= 8 && cfg->start_filts % 8 == 0, E3_ERR_UNSUPPORTED, "start_filts must be a multiple of 8 on the HIP path");
     E3_REQUIRE((cfg->start_filts << (cfg->n_blocks - 1)) <= 1024, E3_ERR_UNSUPPORTED, "more than 1024 channels at the bottom level");
-    E3_REQUIRE(cfg->normalization == 1, E3_ERR_UNSUPPORTED, "only normalization='batch' is implemented on the HIP path");
+    E3_REQUIRE(cfg->normalization == 1 || cfg->normalization == 0, E3_ERR_UNSUPPORTED, "only normalization='batch' and 'none' are implemented on the HIP path");
+    const bool last_norm = cfg->normalization == 1, all_norm = last_norm && cfg->full_norm != 0;
     e3_unet_plan* p = new e3_unet_plan();
     p->cfg = *cfg;
     p->n_bn = 0;
@@ -223,16 +230,16 @@ int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
     for (int i = 0; i < nb; ++i) {   // unet.py:832-850
         const std::string b = "down_convs." + std::to_string(i) + ".";
         const int ins = i == 0 ? cfg->in_channels : p->chan(i - 1), outs = p->chan(i);
-        add_unit(p, b + "conv1", b + "norm0", ins, outs, i, p->planar(i), 0);
-        add_unit(p, b + "conv2", b + "norm1", outs, outs, i, p->planar(i), 0);
+        add_unit(p, b + "conv1", b + "norm0", ins, outs, i, p->planar(i), 0, all_norm);     // unet.py:238-242
+        add_unit(p, b + "conv2", b + "norm1", outs, outs, i, p->planar(i), 0, last_norm);
     }
     for (int k = 0; k + 1 < nb; ++k) {   // unet.py:854-879: block k works at level nb-2-k
         const int j = nb - 2 - k;
         const std::string b = "up_convs." + std::to_string(k) + ".";
         const int ins = p->chan(j + 1), outs = p->chan(j);
-        add_unit(p, b + "upconv", b + "norm0", ins, outs, j, p->planar(j), 1);
-        add_unit(p, b + "conv1", b + "norm1", 2 * outs, outs, j, p->planar(j), 0);
-        add_unit(p, b + "conv2", b + "norm2", outs, outs, j, p->planar(j), 0);
+        add_unit(p, b + "upconv", b + "norm0", ins, outs, j, p->planar(j), 1, all_norm);    // unet.py:369-375
+        add_unit(p, b + "conv1", b + "norm1", 2 * outs, outs, j, p->planar(j), 0, all_norm);
+        add_unit(p, b + "conv2", b + "norm2", outs, outs, j, p->planar(j), 0, last_norm);
     }
     p->p_final_w = add_param(p, "conv_final.weight", (int64_t)cfg->out_channels * p->chan(0), 0);
     p->p_final_b = add_param(p, "conv_final.bias", cfg->out_channels, 0);
@@ -334,10 +341,14 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         const bool is_enc_conv2 = !u.is_up && u.name.compare(0, 10, "down_convs") == 0 && u.name.find("conv2") != std::string::npos;
         const bool pool_after = is_enc_conv2 && u.level < nb - 1;
         const int kd = u.planar ? 1 : 2;
-        float* dst = training ? b.raw : b.act;           // eval: conv writes the activation directly
-        const int dst_ldc = training ? u.cout : b.act_ldc;
+        const bool bn_train = training && u.has_norm();   // batch statistics needed: conv writes the raw output, BN+ReLU is a second pass
+        float* dst = bn_train ? b.raw : b.act;            // otherwise the conv writes the activation directly
+        const int dst_ldc = bn_train ? u.cout : b.act_ldc;
         const float* es = nullptr; const float* eh = nullptr;
-        if (!training) {   // eval-mode BN folded into the conv epilogue (running stats), SURVEY 8a row a18
+        if (!u.has_norm()) {       // nn.Identity: y = relu(acc + bias), in training and in eval mode alike
+            RUN(launch_bias_fold(P(u.p_b), b.scale, b.shift, u.cout, s));
+            es = b.scale; eh = b.shift;
+        } else if (!training) {    // eval-mode BN folded into the conv epilogue (running stats), SURVEY 8a row a18
             RUN(launch_bn_fold(P(u.p_g), P(u.p_be), P(u.p_rm), P(u.p_rv), P(u.p_b), cfg.bn_eps, b.scale, b.shift, u.cout, s));
             es = b.scale; eh = b.shift;
         }
@@ -347,18 +358,18 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             const int sd = u.planar ? 1 : 2, taps = sd * 4, NPad = pad_cols(taps * u.cout);
             RUN(launch_pack_weights(PACK_UP_FWD, P(u.p_w), B.wpack, u.cout, u.cin, taps, NPad, s));
             ConvArgs a{};
-            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpack; a.bias = training ? P(u.p_b) : nullptr;
+            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
             a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = li.D; a.H = li.H; a.W = li.W;
             a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = sd;   // autocrop of the up-convolved tensor (unet.py:289-299)
             a.Cout = u.cout; a.Ncols = taps * u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
-            a.stats = training ? B.stats : nullptr; a.G = 1; a.flags = CF_SCATTER_UP;
+            a.stats = bn_train ? B.stats : nullptr; a.G = 1; a.flags = CF_SCATTER_UP;
             parts = conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, li.D, li.H, li.W, sd, u.cin, taps * u.cout);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(CONV_POINT, a, s)); }
         } else if (u.cin < 8) {
             ConvSmallArgs a{};
-            a.x = cur; a.Cin = u.cin; a.w = P(u.p_w); a.bias = training ? P(u.p_b) : nullptr; a.y = dst; a.y_ldc = dst_ldc;
+            a.x = cur; a.Cin = u.cin; a.w = P(u.p_w); a.bias = bn_train ? P(u.p_b) : nullptr; a.y = dst; a.y_ldc = dst_ldc;
             a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.Cout = u.cout; a.planar = u.planar;
-            a.epi_scale = es; a.epi_shift = eh; a.stats = training ? B.stats : nullptr;
+            a.epi_scale = es; a.epi_shift = eh; a.stats = bn_train ? B.stats : nullptr;
             parts = conv_small_stats_parts(N, lo.D, lo.H, lo.W, u.planar);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_small_fwd(a, s)); }
         } else {
@@ -367,14 +378,14 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             (void)taps;
             RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, lo.D, lo.H, lo.W, 0, s));
             ConvArgs a{};
-            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpack; a.bias = training ? P(u.p_b) : nullptr;
+            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
             a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.sd = 2;
             a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
-            a.stats = training ? B.stats : nullptr; a.G = 1; a.flags = 0;
+            a.stats = bn_train ? B.stats : nullptr; a.G = 1; a.flags = 0;
             parts = conv_stats_parts(kind, 0, N, lo.D, lo.H, lo.W, 2, u.cin, u.cout);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(kind, a, s)); }
         }
-        if (training) {
+        if (bn_train) {
             BnFinalizeArgs f{};
             f.stats = B.stats; f.parts = parts; f.C = u.cout; f.gamma = P(u.p_g); f.beta = P(u.p_be);
             f.running_mean = P(u.p_rm); f.running_var = P(u.p_rv); f.momentum = momenta[u.bn_index]; f.eps = cfg.bn_eps;
@@ -425,6 +436,8 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         RUN(launch_colsum_finalize(B.slab, parts, ps, cfg.out_channels * C0, cfg.out_channels, G(plan->p_final_b), s));
     }
 
+    RUN(launch_fill(B.ones, 1.f, (size_t)plan->chan(nb - 1), s));
+    RUN(launch_fill(B.zeros, 0.f, (size_t)2 * plan->chan(nb - 1), s));
     // ---- walk the units backwards.  `g` = gradient w.r.t. the current unit's activation.
     const float* g = B.g1[0]; int g_ldc = C0;
     bool event_done = bucket_event == nullptr;
@@ -445,13 +458,20 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         float* dxr = B.g2[j];
         {
             BnBwdArgs a{};
-            a.x = b.raw; a.x_ldc = u.cout; a.mean = b.mean; a.invstd = b.invstd; a.gamma = P(u.p_g); a.scale = b.scale; a.shift = b.shift;
+            a.x = b.raw; a.x_ldc = u.cout; a.mean = b.mean; a.invstd = b.invstd; a.scale = b.scale; a.shift = b.shift;
+            if (u.has_norm()) a.gamma = P(u.p_g);
+            else {   // nn.Identity + ReLU: dz = dA * (a > 0) is the APPLY pass with the constants of an identity "norm":
+                     // x := a (mask z = 1*a + 0 > 0), mean 0, invstd 1, gamma 1, c1 = c2 = 0  =>  dx = dz, sum dx = conv-bias gradient
+                a.x = b.act; a.x_ldc = b.act_ldc; a.mean = B.zeros; a.invstd = B.ones; a.gamma = B.ones; a.scale = B.ones; a.shift = B.zeros;
+            }
             if (pooled_unit) { a.g1 = B.dcat[j] + u.cout; a.g1_ldc = 2 * u.cout; a.gpool = g; a.a = b.act; a.a_ldc = b.act_ldc; a.pooled = B.pooled[j]; }
             else { a.g1 = g; a.g1_ldc = g_ldc; }
             a.kd = kd; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.C = u.cout;
             a.parts = bn_bwd_parts(lo.vox, u.cout); a.part = B.bnpart; a.coef = B.small; a.dx = dxr; a.dx_ldc = u.cout;
-            RUN(launch_bn_bwd_reduce(a, s));
-            RUN(launch_bn_bwd_finalize(B.bnpart, a.parts, u.cout, (float)(1.0 / (double)lo.vox), G(u.p_g), G(u.p_be), B.small, s));
+            if (u.has_norm()) {
+                RUN(launch_bn_bwd_reduce(a, s));
+                RUN(launch_bn_bwd_finalize(B.bnpart, a.parts, u.cout, (float)(1.0 / (double)lo.vox), G(u.p_g), G(u.p_be), B.small, s));
+            } else a.coef = B.zeros;
             RUN(launch_bn_bwd_apply(a, s));
             RUN(launch_colsum_finalize(B.bnpart, a.parts, 3 * u.cout, 2 * u.cout, u.cout, G(u.p_b), s));
         }

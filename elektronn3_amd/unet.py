@@ -191,10 +191,11 @@ _LAYERS = {3: (nn.Conv3d, nn.ConvTranspose3d, nn.MaxPool3d, nn.BatchNorm3d),
 class DownConv(nn.Module):
     """Parameter container for one encoder block (two convs, two norms, max-pool) -- reference: unet.py:202-253."""
 
-    def __init__(self, in_channels, out_channels, pooling=True, planar=False, dim=3):
+    def __init__(self, in_channels, out_channels, pooling=True, planar=False, dim=3, normalization='batch', full_norm=True):
         super().__init__()
         self.in_channels, self.out_channels, self.pooling, self.planar = in_channels, out_channels, pooling, planar
         self.dim = dim
+        self.normalization = normalization
         Conv, Pool, Norm = _LAYERS[dim][0], _LAYERS[dim][2], _LAYERS[dim][3]
         k, p = ((1, 3, 3), (0, 1, 1)) if (planar and dim == 3) else (3, 1)
         self.conv1 = Conv(in_channels, out_channels, kernel_size=k, padding=p)
@@ -204,7 +205,9 @@ class DownConv(nn.Module):
         else:
             self.pool = nn.Identity()
         self.act1, self.act2 = nn.ReLU(), nn.ReLU()
-        self.norm0, self.norm1 = Norm(out_channels), Norm(out_channels)
+        norm = (lambda: Norm(out_channels)) if normalization == 'batch' else nn.Identity   # get_normalization, unet.py:77-105
+        self.norm0 = norm() if full_norm else nn.Identity()                                   # unet.py:238-242
+        self.norm1 = norm()
 
     def forward(self, x):
         raise RuntimeError('elektronn3_amd sub-modules only hold parameters; call UNet.forward')
@@ -213,10 +216,11 @@ class DownConv(nn.Module):
 class UpConv(nn.Module):
     """Parameter container for one decoder block (transposed conv, two convs, three norms) -- reference: unet.py:328-408."""
 
-    def __init__(self, in_channels, out_channels, planar=False, dim=3):
+    def __init__(self, in_channels, out_channels, planar=False, dim=3, normalization='batch', full_norm=True):
         super().__init__()
         self.in_channels, self.out_channels, self.planar = in_channels, out_channels, planar
         self.dim = dim
+        self.normalization = normalization
         Conv, ConvT, Norm = _LAYERS[dim][0], _LAYERS[dim][1], _LAYERS[dim][3]
         ks = (1, 2, 2) if (planar and dim == 3) else 2
         k, p = ((1, 3, 3), (0, 1, 1)) if (planar and dim == 3) else (3, 1)
@@ -224,7 +228,10 @@ class UpConv(nn.Module):
         self.conv1 = Conv(2 * out_channels, out_channels, kernel_size=k, padding=p)
         self.conv2 = Conv(out_channels, out_channels, kernel_size=k, padding=p)
         self.act0, self.act1, self.act2 = nn.ReLU(), nn.ReLU(), nn.ReLU()
-        self.norm0, self.norm1, self.norm2 = (Norm(out_channels) for _ in range(3))
+        norm = (lambda: Norm(out_channels)) if normalization == 'batch' else nn.Identity
+        self.norm0 = norm() if full_norm else nn.Identity()                                   # unet.py:369-375
+        self.norm1 = norm() if full_norm else nn.Identity()
+        self.norm2 = norm()
         self.att = None   # Trainer reads model.up_convs[i].att (trainer.py:611-617); always None without attention
 
     def forward(self, enc, dec):
@@ -235,7 +242,7 @@ class UNet(nn.Module):
     """3D U-Net with the reference's interface (elektronn3/models/unet.py:755-771), executed by hand-written HIP
     kernels.  Options of the reference that are not yet on the HIP path raise ``NotImplementedError`` at
     construction: ``up_mode != 'transpose'``, ``merge_mode='add'``,
-    ``attention=True``, ``activation != 'relu'``, ``normalization != 'batch'``, ``full_norm=False``,
+    ``attention=True``, ``activation != 'relu'``, ``normalization`` other than ``'batch'`` / ``'none'``,
     ``conv_mode != 'same'``.  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
     the 3D one with every block planar and a depth of 1."""
 
@@ -285,8 +292,12 @@ class UNet(nn.Module):
         if merge_mode != 'concat': unsupported.append(f'merge_mode={merge_mode!r}')
         if attention: unsupported.append('attention=True')
         if activation != 'relu': unsupported.append(f'activation={activation!r}')
-        if normalization != 'batch': unsupported.append(f'normalization={normalization!r}')
-        if not full_norm: unsupported.append('full_norm=False')
+        if normalization is None:
+            normalization = 'none'
+        if not (normalization in ('none', 'batch', 'instance') or (isinstance(normalization, str) and normalization.startswith('group'))):
+            raise ValueError(f'Unknown normalization type "{normalization}".\nValid choices are "batch", "instance", "group" or "group<G>",'
+                             'where <G> is the number of groups.')      # get_normalization, unet.py:106-111
+        if normalization not in ('batch', 'none'): unsupported.append(f'normalization={normalization!r}')
         if conv_mode != 'same': unsupported.append(f'conv_mode={conv_mode!r}')
         if start_filts % 8 != 0: unsupported.append(f'start_filts={start_filts} (must be a multiple of 8)')
         if not (1 <= out_channels <= 8): unsupported.append(f'out_channels={out_channels} (1..8)')
@@ -299,6 +310,7 @@ class UNet(nn.Module):
         self.start_filts = start_filts
         self.n_blocks = n_blocks
         self.normalization = normalization
+        self.full_norm = full_norm
         self.attention = attention
         self.conv_mode = conv_mode
         self.activation = activation
@@ -313,11 +325,13 @@ class UNet(nn.Module):
         for i in range(n_blocks):
             ins = in_channels if i == 0 else outs
             outs = start_filts * (2 ** i)
-            self.down_convs.append(DownConv(ins, outs, pooling=i < n_blocks - 1, planar=i in self.planar_blocks, dim=dim))
+            self.down_convs.append(DownConv(ins, outs, pooling=i < n_blocks - 1, planar=i in self.planar_blocks, dim=dim,
+                                            normalization=normalization, full_norm=full_norm))
         for i in range(n_blocks - 1):
             ins = outs
             outs = ins // 2
-            self.up_convs.append(UpConv(ins, outs, planar=(n_blocks - 2 - i) in self.planar_blocks, dim=dim))
+            self.up_convs.append(UpConv(ins, outs, planar=(n_blocks - 2 - i) in self.planar_blocks, dim=dim,
+                                        normalization=normalization, full_norm=full_norm))
         self.conv_final = _LAYERS[dim][0](outs, out_channels, kernel_size=1)
         self.apply(self.weight_init)
 
@@ -341,7 +355,9 @@ class UNet(nn.Module):
         mask = 0
         for b in (range(self.n_blocks) if self.dim == 2 else self.planar_blocks):   # dim=2: every block is planar, depth 1
             mask |= 1 << int(b)
-        return (self.in_channels, self.out_channels, self.n_blocks, self.start_filts, mask, 1, float(self.down_convs[0].norm0.eps))
+        eps = next((float(m.eps) for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)), 1e-5)
+        return (self.in_channels, self.out_channels, self.n_blocks, self.start_filts, mask, 1 if self.normalization == 'batch' else 0, eps,
+                1 if getattr(self, 'full_norm', True) else 0)
 
     def _plan(self):
         return _get_plan(self._plan_key())
@@ -373,7 +389,8 @@ class UNet(nn.Module):
 
     def _bump_num_batches_tracked(self, plan):
         nbt = [self.get_submodule(n).num_batches_tracked for n in plan.bn_names]
-        torch._foreach_add_(nbt, 1)
+        if nbt:
+            torch._foreach_add_(nbt, 1)
 
     # ------------------------------------------------------------------ public API
     def forward(self, x):

@@ -53,8 +53,9 @@ typedef struct e3_unet_cfg {
     int32_t n_blocks;       /* UNet(n_blocks=...), 1..8         unet.py:759 */
     int32_t start_filts;    /* UNet(start_filts=...), multiple of 8   unet.py:760 */
     uint32_t planar_mask;   /* bit i set <=> i in planar_blocks unet.py:763,827 */
-    int32_t normalization;  /* 1 = 'batch' (the only mode on the HIP path this round) unet.py:767 */
+    int32_t normalization;  /* 1 = 'batch', 0 = 'none' (nn.Identity, unet.py:77-80); group/instance are not on the HIP path */
     float bn_eps;           /* nn.BatchNorm3d eps (1e-5) */
+    int32_t full_norm;      /* 1: a norm after every (transposed) conv; 0: only after the last conv of a block (unet.py:238-242,369-375) */
 } e3_unet_cfg;
 
 typedef struct e3_unet_plan e3_unet_plan;

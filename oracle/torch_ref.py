@@ -16,6 +16,8 @@ import torch.nn.functional as F
 
 
 def _bn(x, sd, name, training, momentum=0.1, eps=1e-5):
+    if name + '.weight' not in sd:      # nn.Identity: normalization='none' or full_norm=False (unet.py:77-80,238-242,369-375)
+        return x
     return F.batch_norm(x, sd[name + '.running_mean'], sd[name + '.running_var'], sd[name + '.weight'], sd[name + '.bias'],
                         training=training, momentum=momentum, eps=eps)
 

@@ -233,7 +233,8 @@ class OracleUNet:
         return conv3d_fwd(x, w, b, pad)
 
     def _norm_act(self, name, x, cache):
-        if self.norm == 'batch':
+        # a norm layer that is nn.Identity (normalization='none', or full_norm=False: unet.py:238-242,369-375) has no entries in the state_dict
+        if self.norm == 'batch' and (name + '.weight') in self.sd:
             g, b = self.sd[name + '.weight'], self.sd[name + '.bias']
             rm, rv = self.sd[name + '.running_mean'], self.sd[name + '.running_var']
             if self.training:
@@ -289,7 +290,7 @@ class OracleUNet:
     def _norm_act_bwd(self, name, da, cache, grads):
         a = cache[name + '.act']
         dy = relu_bwd(da, a)
-        if self.norm == 'batch':
+        if self.norm == 'batch' and (name + '.weight') in self.sd:
             x, mean, invstd = cache[name]
             dx, dg, db = bn_train_bwd(dy, x, self.sd[name + '.weight'], mean, invstd)
             grads[name + '.weight'], grads[name + '.bias'] = dg, db

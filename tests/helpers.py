@@ -26,7 +26,26 @@ def unet_cfg(npz):
                planar_blocks=tuple(int(v) for v in npz['cfg.planar_blocks']))
     if 'cfg.dim' in npz.files:
         cfg['dim'] = int(npz['cfg.dim'])
+    if 'cfg.normalization' in npz.files:
+        cfg['normalization'] = str(npz['cfg.normalization'])
+    if 'cfg.full_norm' in npz.files:
+        cfg['full_norm'] = bool(int(npz['cfg.full_norm']))
     return cfg
+
+
+def is_prebn_bias(k, names=None):
+    """Bias of a (transposed) conv that feeds a train-mode BatchNorm: analytically zero gradient.  ``names`` (all parameter
+    names) tells whether the norm after that conv exists at all (normalization='none' / full_norm=False make it nn.Identity)."""
+    if not (k.endswith('.bias') and ('conv1' in k or 'conv2' in k or 'upconv' in k) and not k.startswith('conv_final')):
+        return False
+    if names is None:
+        return True
+    block, conv = k[:-len('.bias')].rsplit('.', 1)
+    if block.startswith('down_convs'):
+        norm = {'conv1': 'norm0', 'conv2': 'norm1'}[conv]
+    else:
+        norm = {'upconv': 'norm0', 'conv1': 'norm1', 'conv2': 'norm2'}[conv]
+    return f'{block}.{norm}.weight' in names
 
 
 def embed_2d(sd):

@@ -43,16 +43,19 @@ def test_binding_matches_header_arity():
         assert len(args) == fns[name], (name, len(args), fns[name])
 
 
-def test_plan_param_table_matches_reference_state_dict_names():
-    """Host logic only (no GPU): the plan's parameter table uses the reference's state_dict keys
-    (golden fixture sd0 of an n_blocks=4, planar_blocks=(0,1) model)."""
+@pytest.mark.parametrize('fixture,cfg_args', [('unet_nb4_sf8_planar01.npz', (1, 2, 4, 8, 0b0011, 1, 1e-5, 1)),
+                                              ('unet_nb3_sf8_planar0_sparsenorm.npz', (1, 2, 3, 8, 0b001, 1, 1e-5, 0)),   # full_norm=False
+                                              ('unet_nb2_sf8_nonorm.npz', (1, 2, 2, 8, 0, 0, 1e-5, 1))])                  # normalization='none'
+def test_plan_param_table_matches_reference_state_dict_names(fixture, cfg_args):
+    """Host logic only (no GPU): the plan's parameter table uses the reference's state_dict keys (golden fixtures sd0 of an
+    n_blocks=4, planar_blocks=(0,1) model, a full_norm=False model and a normalization='none' model)."""
     import numpy as np
     from elektronn3_amd import _lib
     from helpers import load_npz, sub
-    g = load_npz('unet_nb4_sf8_planar01.npz')
+    g = load_npz(fixture)
     sd = sub(g, 'sd0')
     lib = _lib.load()
-    cfg = _lib.UNetCfg(1, 2, 4, 8, 0b0011, 1, 1e-5)
+    cfg = _lib.UNetCfg(*cfg_args)
     plan = ctypes.c_void_p()
     _lib.check(lib.e3_unet_plan_create(ctypes.byref(cfg), ctypes.byref(plan)))
     try:

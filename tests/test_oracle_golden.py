@@ -9,7 +9,7 @@ reference's fp64 results, where it must be at least as close as the fp32 referen
 import numpy as np
 import pytest
 
-from helpers import combined_loss_np, embed_2d, load_npz, rel_l2, sub, unet_cfg
+from helpers import combined_loss_np, embed_2d, is_prebn_bias, load_npz, rel_l2, sub, unet_cfg
 from oracle import unet_oracle as orc
 
 
@@ -69,7 +69,8 @@ def test_softmax(ops):
     np.testing.assert_allclose(orc.softmax_c(ops['softmax.x']), ops['softmax.y'], rtol=1e-6, atol=1e-7)
 
 
-CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz', 'unet2d_nb3_sf8_odd.npz']
+CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz', 'unet2d_nb3_sf8_odd.npz',
+         'unet_nb2_sf8_nonorm.npz', 'unet_nb3_sf8_planar0_sparsenorm.npz']
 
 
 @pytest.mark.parametrize('case', CASES)
@@ -104,8 +105,7 @@ def test_unet_train_step(case):
     assert set(grads) == set(ref32)
     gnorm = np.sqrt(sum(float(np.sum(v.astype(np.float64) ** 2)) for v in ref64.values()))
     for k in ref32:
-        is_prebn_bias = k.endswith('.bias') and ('conv1' in k or 'conv2' in k or 'upconv' in k) and k != 'conv_final.bias'
-        if is_prebn_bias:  # analytically zero gradient (bias feeding a train-mode BN): absolute tolerance only
+        if is_prebn_bias(k, set(ref32)):  # analytically zero gradient (bias feeding a train-mode BN): absolute tolerance only
             assert np.abs(grads[k]).max() <= 1e-5 * gnorm, k
             continue
         err_o = rel_l2(grads[k], ref64[k])

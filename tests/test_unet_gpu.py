@@ -15,11 +15,12 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_npz, rel_l2, sub, unet_cfg
+from helpers import is_prebn_bias, load_npz, rel_l2, sub, unet_cfg
 
 pytestmark = pytest.mark.gpu
 
-CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz', 'unet2d_nb3_sf8_odd.npz']
+CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz', 'unet2d_nb3_sf8_odd.npz',
+         'unet_nb2_sf8_nonorm.npz', 'unet_nb3_sf8_planar0_sparsenorm.npz']
 
 
 def build(cfg, sd_np):
@@ -28,10 +29,6 @@ def build(cfg, sd_np):
     sd = {k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}
     m.load_state_dict(sd)           # reference key names and shapes must match exactly
     return m.cuda()
-
-
-def is_prebn_bias(k):
-    return k.endswith('.bias') and ('conv1' in k or 'conv2' in k or 'upconv' in k) and not k.startswith('conv_final')
 
 
 @pytest.mark.parametrize('case', CASES)
@@ -66,7 +63,7 @@ def test_train_step_matches_reference(case):
         errs = {}
         for k in ref32:
             assert gr[k].shape == ref32[k].shape, k
-            if is_prebn_bias(k):    # analytically zero (bias feeding a train-mode BN): absolute tolerance only
+            if is_prebn_bias(k, set(ref32)):    # analytically zero (bias feeding a train-mode BN): absolute tolerance only
                 assert np.abs(gr[k]).max() <= 1e-5 * gnorm, (k, np.abs(gr[k]).max())
                 continue
             errs[k] = (rel_l2(gr[k], ref64[k]), rel_l2(ref32[k], ref64[k]))
@@ -239,6 +236,57 @@ def test_full_size_cfg4_anisotropic_against_pytorch_rocm():
             continue
         err = float((p.grad - gr).norm() / gr.norm().clamp_min(1e-30))
         assert err < 2e-2, (k, err)
+
+
+@pytest.mark.parametrize('kw', [dict(normalization='none'), dict(normalization='batch', full_norm=False, planar_blocks=(0,))],
+                         ids=['nonorm', 'sparsenorm'])
+def test_identity_norm_variants_against_pytorch_rocm(kw):
+    """normalization='none' and full_norm=False (norm layers = nn.Identity, unet.py:77-80,238-242,369-375) at a size that runs the
+    Winograd kernels (conv -> bias -> ReLU fused in their epilogue, also in training): forward, loss, all gradients (conv biases
+    before an Identity have REAL gradients now), running statistics, vs the fp64 ATen op sequence on PyTorch-ROCm."""
+    from elektronn3_amd.unet import UNet
+    from oracle.torch_ref import combined_loss, unet_forward
+    torch.manual_seed(9)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=3, start_filts=32, **kw).cuda().train()
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith('.bias'):
+                p.copy_(0.1 * torch.randn_like(p))
+    x = torch.randn(2, 1, 32, 64, 64, device='cuda')
+    t = torch.randint(0, 2, (2, 32, 64, 64), device='cuda')
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    out = m(x)
+    loss = combined_loss(out, t)
+    m.zero_grad(set_to_none=True)
+    loss.backward()
+    sd_ref = {k: (v.double() if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k)
+              for k, v in sd0.items()}
+    pl = tuple(kw.get('planar_blocks', ()))
+    ref = unet_forward(sd_ref, x.double(), 3, pl, training=True)
+    lref = combined_loss(ref, t)
+    lref.backward()
+    assert torch.allclose(out.double(), ref, rtol=1e-4, atol=1e-4), float((out - ref).abs().max())
+    assert abs(float(loss.detach()) - float(lref.detach())) < 1e-5
+    for k, v in m.state_dict().items():
+        if 'running' in k:
+            torch.testing.assert_close(v.double(), sd_ref[k], rtol=1e-5, atol=1e-6, msg=k)
+    names = {k for k, _ in m.named_parameters()}
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))
+    n_real_bias = 0
+    for k, p in m.named_parameters():
+        gr = sd_ref[k].grad
+        if is_prebn_bias(k, names):
+            assert float(p.grad.abs().max()) <= 1e-5 * float(gn), k
+            continue
+        n_real_bias += k.endswith('.bias') and 'conv' in k and not k.startswith('conv_final')
+        err = float((p.grad.double() - gr).norm() / gr.norm().clamp_min(1e-30))
+        assert err < 1e-2, (k, err)
+    assert n_real_bias >= 3
+    m.eval()
+    with torch.no_grad():
+        ye = m(x)
+    sd_e = {k: v.double() if v.is_floating_point() else v for k, v in m.state_dict().items()}
+    assert torch.allclose(ye.double(), unet_forward(sd_e, x.double(), 3, pl, training=False), rtol=1e-4, atol=1e-4)
 
 
 def test_dim2_unet_against_pytorch_rocm():

@@ -9,6 +9,8 @@ Usage: python tools/fuzz_unet.py [n_cases] [seed]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from elektronn3_amd.unet import UNet
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+from helpers import is_prebn_bias
 import oracle.torch_ref as R
 from oracle.torch_ref import combined_loss, unet_forward
 _relu = torch.nn.functional.relu
@@ -23,12 +25,18 @@ for case in range(n_cases):
     mult = 2 ** (nb - 1)
     D = ri(1, 5) * mult + (ri(0, 3) if ri(0, 1) else 0); H = ri(2, 9) * mult + ri(0, 5); W = ri(2, 10) * mult + ri(0, 5)
     N = ri(1, 3)
+    kw = {}
+    v = ri(0, 5)                                      # option variants: dim=2, normalization='none', full_norm=False
+    if v == 0: kw, planar, D = dict(dim=2), (), None
+    elif v == 1: kw = dict(normalization='none')
+    elif v == 2: kw = dict(full_norm=False)
+    shape = (H, W) if D is None else (D, H, W)
     torch.manual_seed(case)
     try:
-        m = UNet(in_channels=inc, out_channels=outc, n_blocks=nb, start_filts=sf, planar_blocks=planar, normalization='batch').cuda().train()
+        m = UNet(in_channels=inc, out_channels=outc, n_blocks=nb, start_filts=sf, planar_blocks=planar, **kw).cuda().train()
     except Exception as e:
         print('skip (ctor):', nb, sf, planar, e); continue
-    x = torch.randn(N, inc, D, H, W, device='cuda'); t = torch.randint(0, outc, (N, D, H, W), device='cuda')
+    x = torch.randn(N, inc, *shape, device='cuda'); t = torch.randint(0, outc, (N, *shape), device='cuda')
     cw = tuple(float(v) for v in (torch.rand(outc, generator=g) + 0.2))
     sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
     out = m(x); loss = combined_loss(out, t, cw); m.zero_grad(set_to_none=True); loss.backward()
@@ -42,15 +50,16 @@ for case in range(n_cases):
     e_out = float((out - ref).detach().abs().max()) / max(1.0, float(ref.abs().max()))
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
     worst, wk = 0.0, ''
+    names = {k for k, _ in m.named_parameters()}
     for k, p in m.named_parameters():
         gr = sd_ref[k].grad
-        prebn = k.endswith('.bias') and 'norm' not in k and not k.startswith('conv_final')
+        prebn = is_prebn_bias(k, names)
         err = float(p.grad.abs().max()) / gn if prebn else float((p.grad - gr).norm() / gr.norm().clamp_min(1e-30))
         if (not prebn and err > worst): worst, wk = err, k
         if prebn and err > 1e-5: worst, wk = 1.0, k + ' (pre-BN bias not ~0)'
-    e_rs = max(float((m.state_dict()[k] - sd_ref[k]).abs().max()) for k in sd0 if 'running' in k)
+    e_rs = max([float((m.state_dict()[k] - sd_ref[k]).abs().max()) for k in sd0 if 'running' in k] or [0.0])
     ok = e_out < 5e-5 and worst < (3e-2 if margin[0] < 2e-6 else 1e-4) and e_rs < 1e-5
     bad += not ok
-    print(f'{"ok  " if ok else "BAD "} nb={nb} sf={sf} in={inc} out={outc} planar={planar} N={N} {D}x{H}x{W}: out {e_out:.1e} worst grad {worst:.1e} ({wk}) running {e_rs:.1e} relu margin {margin[0]:.0e}', flush=True)
+    print(f'{"ok  " if ok else "BAD "} nb={nb} sf={sf} in={inc} out={outc} planar={planar} {kw} N={N} {"x".join(map(str, shape))}: out {e_out:.1e} worst grad {worst:.1e} ({wk}) running {e_rs:.1e} relu margin {margin[0]:.0e}', flush=True)
 print('BAD CASES:', bad)
 sys.exit(1 if bad else 0)
