@@ -383,6 +383,18 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ part, int parts
 __global__ void fill_kernel(float* __restrict__ p, float v, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
+// merge_mode='add' (unet.py:400-401): out[v][c] = a[v][c] + b[v][c] over channel views
+__global__ void add_views_kernel(const float* __restrict__ a, int a_ldc, const float* __restrict__ b, int b_ldc,
+                                 float* __restrict__ out, int out_ldc, size_t vox, int C) {
+    const int Q = C >> 2;
+    const size_t total = vox * Q;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % Q); const size_t v = i / Q;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * q);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(b + v * b_ldc + 4 * q);
+        *reinterpret_cast<f32x4*>(out + v * out_ldc + 4 * q) = f32x4{x[0] + y[0], x[1] + y[1], x[2] + y[2], x[3] + y[3]};
+    }
+}
 // conv -> nn.Identity -> ReLU (normalization='none' / full_norm=False): the "folded norm" of the conv epilogue is y = relu(1*acc + bias)
 __global__ void bias_fold_kernel(const float* __restrict__ bias, float* __restrict__ scale, float* __restrict__ shift, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -431,6 +443,13 @@ int launch_bn_finalize(BnFinalizeArgs a, hipStream_t s) {
 int launch_fill(float* p, float v, size_t n, hipStream_t s) {
     if (n == 0) return E3_OK;
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, p, v, n);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_add_views(const float* a, int a_ldc, const float* b, int b_ldc, float* out, int out_ldc, size_t vox, int C, hipStream_t s) {
+    E3_REQUIRE(C % 4 == 0 && a_ldc % 4 == 0 && b_ldc % 4 == 0 && out_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
+    hipLaunchKernelGGL(add_views_kernel, dim3(ew_grid(vox * (C / 4))), dim3(EW_BLOCK), 0, s, a, a_ldc, b, b_ldc, out, out_ldc, vox, C);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

@@ -111,6 +111,7 @@ int launch_ce_dice_bwd(const float* logits, const long long* target, const float
                        const float* workspace, const float* gout, float* dlogits, hipStream_t s);
 
 int launch_fill(float* p, float v, size_t n, hipStream_t s);
+int launch_add_views(const float* a, int a_ldc, const float* b, int b_ldc, float* out, int out_ldc, size_t vox, int C, hipStream_t s);   // out = a + b
 int launch_bias_fold(const float* conv_bias, float* scale, float* shift, int C, hipStream_t s);   // scale = 1, shift = bias
 
 // ---------------------------------------------------------------- optimizer (optim.hip)

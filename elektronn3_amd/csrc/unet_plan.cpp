@@ -100,6 +100,7 @@ struct Buffers {
     std::vector<UnitBufs> ub;            // per unit
     std::vector<float*> cat;             // per level < nb-1: [vox][2C]
     std::vector<float*> pooled;          // per level < nb-1: [vox(level+1)][C(level)]
+    std::vector<float*> sum;             // merge_mode='add': per level < nb-1 [vox][C] = up + skip (the two halves of `cat`)
     float* xin;                          // NDHWC copy of the input when in_channels > 1
     size_t saved_bytes;
     // scratch
@@ -120,7 +121,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     std::vector<LevelDims> L; level_dims(p, N, D, H, W, L);
     Arena S(saved), T(scratch);
     B.ub.assign(p->units.size(), UnitBufs{});
-    B.cat.assign(nb, nullptr); B.pooled.assign(nb, nullptr);
+    B.cat.assign(nb, nullptr); B.pooled.assign(nb, nullptr); B.sum.assign(nb, nullptr);
     B.g1.assign(nb, nullptr); B.g2.assign(nb, nullptr); B.dcat.assign(nb, nullptr);
     B.xin = nullptr; B.evalA = B.evalB = nullptr;
     Arena& A = training ? S : T;   // in inference everything is scratch
@@ -128,6 +129,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     for (int j = 0; j + 1 < nb; ++j) {
         B.cat[j] = A.take(L[j].vox * 2 * p->chan(j));
         B.pooled[j] = A.take(L[j + 1].vox * p->chan(j));
+        if (p->cfg.merge_add) B.sum[j] = A.take(L[j].vox * p->chan(j));
     }
     for (size_t k = 0; k < p->units.size(); ++k) {
         const ConvUnit& u = p->units[k];
@@ -238,7 +240,7 @@ int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
         const std::string b = "up_convs." + std::to_string(k) + ".";
         const int ins = p->chan(j + 1), outs = p->chan(j);
         add_unit(p, b + "upconv", b + "norm0", ins, outs, j, p->planar(j), 1, all_norm);    // unet.py:369-375
-        add_unit(p, b + "conv1", b + "norm1", 2 * outs, outs, j, p->planar(j), 0, all_norm);
+        add_unit(p, b + "conv1", b + "norm1", cfg->merge_add ? outs : 2 * outs, outs, j, p->planar(j), 0, all_norm);   // unet.py:352-360
         add_unit(p, b + "conv2", b + "norm2", outs, outs, j, p->planar(j), 0, last_norm);
     }
     p->p_final_w = add_param(p, "conv_final.weight", (int64_t)cfg->out_channels * p->chan(0), 0);
@@ -398,6 +400,10 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         }
         // input of the next unit
         if (pool_after) { cur = B.pooled[u.level]; cur_ldc = u.cout; }
+        else if (u.is_up && cfg.merge_add) {   // mrg = updec + genc (unet.py:400-401): the two halves of the buffer summed
+            RUN(launch_add_views(B.cat[u.level], 2 * u.cout, B.cat[u.level] + u.cout, 2 * u.cout, B.sum[u.level], u.cout, lo.vox, u.cout, s));
+            cur = B.sum[u.level]; cur_ldc = u.cout;
+        }
         else if (u.is_up) { cur = B.cat[u.level]; cur_ldc = 2 * u.cout; }   // conv1 of the UpConv reads the whole concat buffer
         else { cur = b.act; cur_ldc = b.act_ldc; }
     }
@@ -464,7 +470,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
                      // x := a (mask z = 1*a + 0 > 0), mean 0, invstd 1, gamma 1, c1 = c2 = 0  =>  dx = dz, sum dx = conv-bias gradient
                 a.x = b.act; a.x_ldc = b.act_ldc; a.mean = B.zeros; a.invstd = B.ones; a.gamma = B.ones; a.scale = B.ones; a.shift = B.zeros;
             }
-            if (pooled_unit) { a.g1 = B.dcat[j] + u.cout; a.g1_ldc = 2 * u.cout; a.gpool = g; a.a = b.act; a.a_ldc = b.act_ldc; a.pooled = B.pooled[j]; }
+            if (pooled_unit) { a.g1 = cfg.merge_add ? B.dcat[j] : B.dcat[j] + u.cout; a.g1_ldc = cfg.merge_add ? u.cout : 2 * u.cout; a.gpool = g; a.a = b.act; a.a_ldc = b.act_ldc; a.pooled = B.pooled[j]; }
             else { a.g1 = g; a.g1_ldc = g_ldc; }
             a.kd = kd; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.C = u.cout;
             a.parts = bn_bwd_parts(lo.vox, u.cout); a.part = B.bnpart; a.coef = B.small; a.dx = dxr; a.dx_ldc = u.cout;
@@ -482,6 +488,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             const ConvUnit& pu = plan->units[k - 1];
             const bool prev_pooled = pu.name.compare(0, 10, "down_convs") == 0 && pu.name.find("conv2") != std::string::npos && pu.level < nb - 1 && is_down;
             if (prev_pooled) { xin = B.pooled[pu.level]; xin_ldc = pu.cout; }
+            else if (pu.is_up && cfg.merge_add) { xin = B.sum[pu.level]; xin_ldc = pu.cout; }
             else if (pu.is_up) { xin = B.cat[pu.level]; xin_ldc = 2 * pu.cout; }
             else { xin = B.ub[k - 1].act; xin_ldc = B.ub[k - 1].act_ldc; }
             if (u.is_up) {   // input of upconv k-th: activation at level j+1 = output of the previous unit (packed or cat-skip of bottom block)
@@ -542,7 +549,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             a.Cout = u.cin; a.Ncols = u.cin; a.NPad = NPad; a.G = 1; a.flags = 0;
             { Prof pr(plan, s, k, 1); RUN(launch_conv_mfma(kind, a, s)); }
             if (k == 0) { if (cfg.in_channels > 1) RUN(launch_ndhwc_to_ncdhw(B.g1[0], cfg.in_channels, dx, N, cfg.in_channels, L[0].vox / N, s)); }
-            g = out; g_ldc = to_cat ? 2 * u.cout : u.cin;   // for to_cat the next unit (upconv) reads the first half: ldc = 2*C
+            g = out; g_ldc = (to_cat && !cfg.merge_add) ? 2 * u.cout : u.cin;   // concat: the next unit (upconv) reads the first half, ldc = 2*C; add: d(up + skip) goes to both
         }
     }
     if (!event_done) E3_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_event, s));

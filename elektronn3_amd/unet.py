@@ -216,16 +216,17 @@ class DownConv(nn.Module):
 class UpConv(nn.Module):
     """Parameter container for one decoder block (transposed conv, two convs, three norms) -- reference: unet.py:328-408."""
 
-    def __init__(self, in_channels, out_channels, planar=False, dim=3, normalization='batch', full_norm=True):
+    def __init__(self, in_channels, out_channels, planar=False, dim=3, normalization='batch', full_norm=True, merge_mode='concat'):
         super().__init__()
         self.in_channels, self.out_channels, self.planar = in_channels, out_channels, planar
+        self.merge_mode = merge_mode
         self.dim = dim
         self.normalization = normalization
         Conv, ConvT, Norm = _LAYERS[dim][0], _LAYERS[dim][1], _LAYERS[dim][3]
         ks = (1, 2, 2) if (planar and dim == 3) else 2
         k, p = ((1, 3, 3), (0, 1, 1)) if (planar and dim == 3) else (3, 1)
         self.upconv = ConvT(in_channels, out_channels, kernel_size=ks, stride=ks)
-        self.conv1 = Conv(2 * out_channels, out_channels, kernel_size=k, padding=p)
+        self.conv1 = Conv((2 if merge_mode == 'concat' else 1) * out_channels, out_channels, kernel_size=k, padding=p)   # unet.py:352-360
         self.conv2 = Conv(out_channels, out_channels, kernel_size=k, padding=p)
         self.act0, self.act1, self.act2 = nn.ReLU(), nn.ReLU(), nn.ReLU()
         norm = (lambda: Norm(out_channels)) if normalization == 'batch' else nn.Identity
@@ -241,7 +242,7 @@ class UpConv(nn.Module):
 class UNet(nn.Module):
     """3D U-Net with the reference's interface (elektronn3/models/unet.py:755-771), executed by hand-written HIP
     kernels.  Options of the reference that are not yet on the HIP path raise ``NotImplementedError`` at
-    construction: ``up_mode != 'transpose'``, ``merge_mode='add'``,
+    construction: ``up_mode != 'transpose'``,
     ``attention=True``, ``activation != 'relu'``, ``normalization`` other than ``'batch'`` / ``'none'``,
     ``conv_mode != 'same'``.  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
     the 3D one with every block planar and a depth of 1."""
@@ -289,7 +290,6 @@ class UNet(nn.Module):
         # -- what the HIP path implements this round
         unsupported = []
         if up_mode != 'transpose': unsupported.append(f'up_mode={up_mode!r}')
-        if merge_mode != 'concat': unsupported.append(f'merge_mode={merge_mode!r}')
         if attention: unsupported.append('attention=True')
         if activation != 'relu': unsupported.append(f'activation={activation!r}')
         if normalization is None:
@@ -331,7 +331,7 @@ class UNet(nn.Module):
             ins = outs
             outs = ins // 2
             self.up_convs.append(UpConv(ins, outs, planar=(n_blocks - 2 - i) in self.planar_blocks, dim=dim,
-                                        normalization=normalization, full_norm=full_norm))
+                                        normalization=normalization, full_norm=full_norm, merge_mode=merge_mode))
         self.conv_final = _LAYERS[dim][0](outs, out_channels, kernel_size=1)
         self.apply(self.weight_init)
 
@@ -357,7 +357,7 @@ class UNet(nn.Module):
             mask |= 1 << int(b)
         eps = next((float(m.eps) for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)), 1e-5)
         return (self.in_channels, self.out_channels, self.n_blocks, self.start_filts, mask, 1 if self.normalization == 'batch' else 0, eps,
-                1 if getattr(self, 'full_norm', True) else 0)
+                1 if getattr(self, 'full_norm', True) else 0, 1 if self.merge_mode == 'add' else 0)
 
     def _plan(self):
         return _get_plan(self._plan_key())

@@ -56,6 +56,7 @@ typedef struct e3_unet_cfg {
     int32_t normalization;  /* 1 = 'batch', 0 = 'none' (nn.Identity, unet.py:77-80); group/instance are not on the HIP path */
     float bn_eps;           /* nn.BatchNorm3d eps (1e-5) */
     int32_t full_norm;      /* 1: a norm after every (transposed) conv; 0: only after the last conv of a block (unet.py:238-242,369-375) */
+    int32_t merge_add;      /* 0: merge_mode='concat' (torch.cat((up, skip), 1)); 1: merge_mode='add' (up + skip), unet.py:398-401 */
 } e3_unet_cfg;
 
 typedef struct e3_unet_plan e3_unet_plan;

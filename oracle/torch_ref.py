@@ -61,7 +61,8 @@ def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True):
         up = (F.conv_transpose3d if w.dim() == 5 else F.conv_transpose2d)(x, w, sd[p + 'upconv.bias'], stride=tuple(w.shape[2:]))
         skip, up = autocrop(enc[-(i + 2)], up)
         up = F.relu(_bn(up, sd, p + 'norm0', training))
-        y = torch.cat((up, skip), 1)
+        cat = sd[p + 'conv1.weight'].shape[1] == 2 * up.shape[1]      # merge_mode 'concat' vs 'add' (unet.py:398-401) shows in conv1's Cin
+        y = torch.cat((up, skip), 1) if cat else up + skip
         y = F.relu(_bn(_conv(y, sd, p + 'conv1'), sd, p + 'norm1', training))
         x = F.relu(_bn(_conv(y, sd, p + 'conv2'), sd, p + 'norm2', training))
     return _conv(x, sd, 'conv_final')

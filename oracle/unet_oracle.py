@@ -277,7 +277,11 @@ class OracleUNet:
             before_pool, up, dn_sl, up_sl = autocrop(before_pool, up)
             cache[p + 'crop'] = (dn_sl, up_sl, enc[-(i + 2)].shape, None)
             up = self._norm_act(p + 'norm0', np.ascontiguousarray(up), cache)
-            mrg = np.concatenate((up, before_pool), axis=1)
+            # merge_mode (unet.py:398-401): 'concat' -> conv1 has 2C input channels, 'add' -> C
+            if self.sd[p + 'conv1.weight'].shape[1] == 2 * up.shape[1]:
+                mrg = np.concatenate((up, before_pool), axis=1)
+            else:
+                mrg = up + before_pool
             y = self._conv(p + 'conv1', mrg, cache)
             y = self._norm_act(p + 'norm1', y, cache)
             y = self._conv(p + 'conv2', y, cache)
@@ -315,8 +319,11 @@ class OracleUNet:
             d = self._conv_bwd(p + 'conv2', d, cache, grads)
             d = self._norm_act_bwd(p + 'norm1', d, cache, grads)
             dmrg = self._conv_bwd(p + 'conv1', d, cache, grads)
-            C = dmrg.shape[1] // 2
-            dup, dskip = np.ascontiguousarray(dmrg[:, :C]), np.ascontiguousarray(dmrg[:, C:])
+            if self.sd[p + 'conv1.weight'].shape[1] == 2 * self.sd[p + 'conv1.weight'].shape[0]:
+                C = dmrg.shape[1] // 2
+                dup, dskip = np.ascontiguousarray(dmrg[:, :C]), np.ascontiguousarray(dmrg[:, C:])
+            else:       # 'add': the gradient of the sum goes to both operands
+                dup, dskip = dmrg, dmrg.copy()
             dn_sl, up_sl, enc_shape, _ = cache[p + 'crop']
             j = self.n_blocks - 2 - i  # encoder block whose before_pool was merged: encoder_outs[-(i+2)]
             if dn_sl is not None:

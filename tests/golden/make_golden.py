@@ -155,10 +155,10 @@ def criterion(loss_mod):
                                   loss_mod.DiceLoss(apply_softmax=True, weight=cw)], weight=[0.5, 0.5])
 
 
-def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True):
+def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True, merge_mode='concat'):
     torch.manual_seed(seed)
     model = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
-                      planar_blocks=planar_blocks, activation='relu', normalization=normalization, dim=dim, full_norm=full_norm)
+                      planar_blocks=planar_blocks, activation='relu', normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode)
     # make BN affine + conv bias non-trivial so that the fixtures exercise them
     with torch.no_grad():
         for name, p in model.named_parameters():
@@ -183,6 +183,8 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
         d['cfg.normalization'] = np.array(normalization)
     if not full_norm:
         d['cfg.full_norm'] = np.array(0)
+    if merge_mode != 'concat':
+        d['cfg.merge_mode'] = np.array(merge_mode)
     for k, v in sd0.items():
         d['sd0/' + k] = v
     for k, v in model.state_dict().items():
@@ -195,7 +197,7 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
         d['logits_eval'] = npy(model(x))
     # fp64 reference of the same step (tolerances are stated against it)
     m64 = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
-                    planar_blocks=planar_blocks, activation='relu', normalization=normalization, dim=dim, full_norm=full_norm).double()
+                    planar_blocks=planar_blocks, activation='relu', normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode).double()
     m64.load_state_dict({k: torch.as_tensor(v).double() if v.dtype != np.int64 else torch.as_tensor(v) for k, v in sd0.items()})
     m64.train()
     o64 = m64(x.double())
@@ -299,6 +301,9 @@ if __name__ == '__main__':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_nonorm.npz', seed=4, n_blocks=2, start_filts=8, planar_blocks=(), shape=(10, 13, 18), batch=2, normalization='none')
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_planar0_sparsenorm.npz', seed=5, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 18, 21), batch=2, full_norm=False)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'add':
+        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_add_odd.npz', seed=6, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 14, 19), batch=2, merge_mode='add')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'unet2d':    # only the dim=2 fixture
         make_unet_case(unet, loss_mod, f'{HERE}/unet2d_nb3_sf8_odd.npz', seed=3, n_blocks=3, start_filts=8, planar_blocks=(), shape=(37, 46), batch=2, dim=2)
         sys.exit(0)
@@ -314,6 +319,8 @@ if __name__ == '__main__':
     # nn.Identity norms: normalization='none'; full_norm=False ("sparse" normalization scheme of the examples' comments)
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_nonorm.npz', seed=4, n_blocks=2, start_filts=8, planar_blocks=(), shape=(10, 13, 18), batch=2, normalization='none')
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_planar0_sparsenorm.npz', seed=5, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 18, 21), batch=2, full_norm=False)
+    # merge_mode='add' (skip connection summed instead of concatenated), odd sizes, planar middle block
+    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_add_odd.npz', seed=6, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 14, 19), batch=2, merge_mode='add')
     make_predictor(unet, inference, f'{HERE}/predictor.npz')
     make_adamw(f'{HERE}/adamw.npz')
     make_trainsteps(unet, loss_mod, f'{HERE}/trainsteps.npz')

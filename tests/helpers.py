@@ -28,6 +28,8 @@ def unet_cfg(npz):
         cfg['dim'] = int(npz['cfg.dim'])
     if 'cfg.normalization' in npz.files:
         cfg['normalization'] = str(npz['cfg.normalization'])
+    if 'cfg.merge_mode' in npz.files:
+        cfg['merge_mode'] = str(npz['cfg.merge_mode'])
     if 'cfg.full_norm' in npz.files:
         cfg['full_norm'] = bool(int(npz['cfg.full_norm']))
     return cfg

@@ -20,7 +20,7 @@ from helpers import is_prebn_bias, load_npz, rel_l2, sub, unet_cfg
 pytestmark = pytest.mark.gpu
 
 CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz', 'unet2d_nb3_sf8_odd.npz',
-         'unet_nb2_sf8_nonorm.npz', 'unet_nb3_sf8_planar0_sparsenorm.npz']
+         'unet_nb2_sf8_nonorm.npz', 'unet_nb3_sf8_planar0_sparsenorm.npz', 'unet_nb3_sf8_add_odd.npz']
 
 
 def build(cfg, sd_np):
@@ -238,12 +238,14 @@ def test_full_size_cfg4_anisotropic_against_pytorch_rocm():
         assert err < 2e-2, (k, err)
 
 
-@pytest.mark.parametrize('kw', [dict(normalization='none'), dict(normalization='batch', full_norm=False, planar_blocks=(0,))],
-                         ids=['nonorm', 'sparsenorm'])
-def test_identity_norm_variants_against_pytorch_rocm(kw):
+@pytest.mark.parametrize('kw', [dict(normalization='none'), dict(normalization='batch', full_norm=False, planar_blocks=(0,)),
+                                dict(merge_mode='add'), dict(merge_mode='add', normalization='none', planar_blocks=(0,))],
+                         ids=['nonorm', 'sparsenorm', 'add', 'add_nonorm_planar'])
+def test_option_variants_against_pytorch_rocm(kw):
     """normalization='none' and full_norm=False (norm layers = nn.Identity, unet.py:77-80,238-242,369-375) at a size that runs the
-    Winograd kernels (conv -> bias -> ReLU fused in their epilogue, also in training): forward, loss, all gradients (conv biases
-    before an Identity have REAL gradients now), running statistics, vs the fp64 ATen op sequence on PyTorch-ROCm."""
+    Winograd kernels (conv -> bias -> ReLU fused in their epilogue, also in training), and merge_mode='add' (unet.py:398-401: the skip
+    connection is summed, conv1 has C input channels): forward, loss, all gradients (conv biases before an Identity have REAL
+    gradients), running statistics, vs the fp64 ATen op sequence on PyTorch-ROCm."""
     from elektronn3_amd.unet import UNet
     from oracle.torch_ref import combined_loss, unet_forward
     torch.manual_seed(9)
@@ -281,7 +283,7 @@ def test_identity_norm_variants_against_pytorch_rocm(kw):
         n_real_bias += k.endswith('.bias') and 'conv' in k and not k.startswith('conv_final')
         err = float((p.grad.double() - gr).norm() / gr.norm().clamp_min(1e-30))
         assert err < 1e-2, (k, err)
-    assert n_real_bias >= 3
+    assert n_real_bias >= 3 or kw.get('normalization', 'batch') == 'batch' and kw.get('full_norm', True)
     m.eval()
     with torch.no_grad():
         ye = m(x)

@@ -26,10 +26,11 @@ for case in range(n_cases):
     D = ri(1, 5) * mult + (ri(0, 3) if ri(0, 1) else 0); H = ri(2, 9) * mult + ri(0, 5); W = ri(2, 10) * mult + ri(0, 5)
     N = ri(1, 3)
     kw = {}
-    v = ri(0, 5)                                      # option variants: dim=2, normalization='none', full_norm=False
+    v = ri(0, 5)                                      # option variants: dim=2, normalization='none', full_norm=False, merge_mode='add'
     if v == 0: kw, planar, D = dict(dim=2), (), None
     elif v == 1: kw = dict(normalization='none')
     elif v == 2: kw = dict(full_norm=False)
+    if ri(0, 3) == 0: kw['merge_mode'] = 'add'
     shape = (H, W) if D is None else (D, H, W)
     torch.manual_seed(case)
     try:
