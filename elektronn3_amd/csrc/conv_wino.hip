@@ -352,10 +352,9 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
 //   dgrad == 0:  g[tap][n = co][k = ci] = w[co][ci][tap]           (w is (Cout, Cin, 27))
 //   dgrad == 1:  g[tap][n = ci][k = co] = w[co][ci][26 - tap]      (rows/cols swapped, taps flipped)
 // K = number of GEMM-K channels (multiple of 8), Ncols = real columns, NPad = padded to 32.
-__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int dgrad, int K, int Ncols, int NPad) {
+__device__ __forceinline__ void wino_pack_item(const float* __restrict__ w, float* __restrict__ out, int Cin, int dgrad, int K, int Ncols, size_t i) {
     const int NCH = K >> 3;
-    const size_t total = (size_t)(NPad >> 5) * NCH * 256;     // one thread per (ntile, chunk, hf, co, e): all 64 positions
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    {
         const int e = i & 3, co = (i >> 2) & 31, hf = (i >> 7) & 1;
         const size_t r = i >> 8;
         const int ch = r % NCH, nt = r / NCH;
@@ -398,6 +397,31 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int dgrad, int K, int Ncols, int NPad) {
+    const size_t total = (size_t)(NPad >> 5) * (K >> 3) * 256;     // one thread per (ntile, chunk, hf, co, e): all 64 positions
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        wino_pack_item(w, out, Cin, dgrad, K, Ncols, i);
+}
+
+// all layers of a network in ONE launch (each layer alone is a 4..256-workgroup, latency-bound kernel: 25 of them cost
+// 0.19 ms per training step); workgroup -> job by binary search over the block prefix
+struct WinoPackMultiArgs {
+    const float* w[WINO_PACK_MAX_JOBS]; float* out[WINO_PACK_MAX_JOBS];
+    int Cin[WINO_PACK_MAX_JOBS], K[WINO_PACK_MAX_JOBS], Ncols[WINO_PACK_MAX_JOBS], dgrad[WINO_PACK_MAX_JOBS];
+    int bstart[WINO_PACK_MAX_JOBS + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void wino_pack_multi_kernel(const WinoPackMultiArgs a) {
+    const int b = blockIdx.x;
+    int lo = 0, hi = a.n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.bstart[mid] <= b) lo = mid; else hi = mid; }
+    const int j = lo;
+    const int K = a.K[j], Ncols = a.Ncols[j], NPad = (Ncols + 31) / 32 * 32;
+    const size_t total = (size_t)(NPad >> 5) * (K >> 3) * 256;
+    const size_t i = (size_t)(b - a.bstart[j]) * 256 + threadIdx.x;
+    if (i < total) wino_pack_item(a.w[j], a.out[j], a.Cin[j], a.dgrad[j], K, Ncols, i);
+}
+
 }  // namespace
 
 // ---- host side
@@ -413,6 +437,25 @@ bool conv_use_wino(ConvKind kind, int flags, int N, int D, int H, int W, int Cin
     (void)N;
     const size_t grid = (size_t)wino_bricks(1, D, H, W) * ((ncols + 31) / 32);
     return grid >= 64u;        // a Winograd workgroup does 3.4x less matrix work than a direct one: worth it from 1/4 of the CUs
+}
+
+int launch_wino_pack_multi(const WinoPackJob* jobs, int njobs, hipStream_t s) {
+    for (int j0 = 0; j0 < njobs; j0 += WINO_PACK_MAX_JOBS) {
+        WinoPackMultiArgs a;
+        a.n = njobs - j0 < WINO_PACK_MAX_JOBS ? njobs - j0 : WINO_PACK_MAX_JOBS;
+        int b = 0;
+        for (int j = 0; j < a.n; ++j) {
+            const WinoPackJob& q = jobs[j0 + j];
+            const int K = q.dgrad ? q.Cout : q.Cin, ncols = q.dgrad ? q.Cin : q.Cout, NPad = (ncols + 31) / 32 * 32;
+            a.w[j] = q.w; a.out[j] = q.out; a.Cin[j] = q.Cin; a.K[j] = K; a.Ncols[j] = ncols; a.dgrad[j] = q.dgrad;
+            a.bstart[j] = b;
+            b += (int)(((size_t)(NPad >> 5) * (K >> 3) * 256 + 255) / 256);
+        }
+        a.bstart[a.n] = b;
+        if (b > 0) hipLaunchKernelGGL(wino_pack_multi_kernel, dim3(b), dim3(256), 0, s, a);
+        E3_CHECK_HIP(hipGetLastError());
+    }
+    return E3_OK;
 }
 
 int launch_wino_pack(const float* w, float* out, int Cout, int Cin, int dgrad, hipStream_t s) {

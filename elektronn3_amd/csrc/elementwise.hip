@@ -401,6 +401,29 @@ __global__ void bias_fold_kernel(const float* __restrict__ bias, float* __restri
     if (c < C) { scale[c] = 1.f; shift[c] = bias ? bias[c] : 0.f; }
 }
 
+// many column sums in one launch (the conv-bias gradients of all layers: 17 tiny latency-bound launches per step otherwise)
+struct ColsumMultiArgs {
+    const float* part[COLSUM_MAX_JOBS]; float* out[COLSUM_MAX_JOBS];
+    int parts[COLSUM_MAX_JOBS], stride[COLSUM_MAX_JOBS], offset[COLSUM_MAX_JOBS], C[COLSUM_MAX_JOBS];
+    int bstart[COLSUM_MAX_JOBS + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void colsum_multi_kernel(const ColsumMultiArgs a) {
+    const int b = blockIdx.x;
+    int lo = 0, hi = a.n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.bstart[mid] <= b) lo = mid; else hi = mid; }
+    const int j = lo;
+    const int lane = threadIdx.x & 63;
+    const int c = (b - a.bstart[j]) * 4 + (threadIdx.x >> 6);
+    if (c >= a.C[j]) return;
+    const float* __restrict__ part = a.part[j];
+    const int stride = a.stride[j], off = a.offset[j] + c, parts = a.parts[j];
+    double s = 0.0;
+    for (int p = lane; p < parts; p += 64) s += part[(size_t)p * stride + off];   // same order as colsum_finalize_kernel
+    s = wave_sum(s);
+    if (lane == 0) a.out[j][c] = (float)s;
+}
+
 // ------------------------------------------------------------------ layout helpers (module boundary only)
 __global__ void ncdhw_to_ndhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, size_t S) {
     const size_t total = (size_t)N * C * S;
@@ -529,6 +552,24 @@ int launch_bn_bwd_finalize(const float* part, int parts, int C, float inv_n, flo
 int launch_colsum_finalize(const float* part, int parts, int part_stride, int offset, int C, float* out, hipStream_t s) {
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, part, parts, part_stride, offset, C, out);
     E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_colsum_multi(const ColsumJob* jobs, int njobs, hipStream_t s) {
+    for (int j0 = 0; j0 < njobs; j0 += COLSUM_MAX_JOBS) {
+        ColsumMultiArgs a;
+        a.n = njobs - j0 < COLSUM_MAX_JOBS ? njobs - j0 : COLSUM_MAX_JOBS;
+        int b = 0;
+        for (int j = 0; j < a.n; ++j) {
+            const ColsumJob& q = jobs[j0 + j];
+            a.part[j] = q.part; a.out[j] = q.out; a.parts[j] = q.parts; a.stride[j] = q.stride; a.offset[j] = q.offset; a.C[j] = q.C;
+            a.bstart[j] = b;
+            b += cdiv(q.C, 4);
+        }
+        a.bstart[a.n] = b;
+        if (b > 0) hipLaunchKernelGGL(colsum_multi_kernel, dim3(b), dim3(256), 0, s, a);
+        E3_CHECK_HIP(hipGetLastError());
+    }
     return E3_OK;
 }
 

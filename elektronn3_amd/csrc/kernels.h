@@ -45,6 +45,9 @@ int launch_conv3_v3(ConvKind kind, ConvArgs a, int nt, hipStream_t s);   // conv
 // Winograd F(2x2x2,3x3x3) path (conv_wino.hip).  conv_use_wino() is THE routing predicate: the weight packer, the
 // statistics sizing and launch_conv_mfma() all ask it, with K = GEMM-K channels and ncols = GEMM columns.
 bool conv_use_wino(ConvKind kind, int flags, int N, int D, int H, int W, int K, int ncols);
+constexpr int WINO_PACK_MAX_JOBS = 40;
+struct WinoPackJob { const float* w; float* out; int Cout, Cin, dgrad; };
+int launch_wino_pack_multi(const WinoPackJob* jobs, int njobs, hipStream_t s);   // the Winograd weight transforms of many layers in one launch
 int wino_bricks(int N, int D, int H, int W);
 int launch_conv3_wino(ConvArgs a, hipStream_t s);
 // planar 1x3x3: Winograd F(2x2,3x3) (conv_wino2d.hip), same contract
@@ -110,6 +113,9 @@ int launch_ce_dice_fwd(const float* logits, const long long* target, const float
 int launch_ce_dice_bwd(const float* logits, const long long* target, const float* w, int C, int N, size_t vps,
                        const float* workspace, const float* gout, float* dlogits, hipStream_t s);
 
+constexpr int COLSUM_MAX_JOBS = 40;
+struct ColsumJob { const float* part; int parts, stride, offset, C; float* out; };
+int launch_colsum_multi(const ColsumJob* jobs, int njobs, hipStream_t s);   // out[c] = sum_p part[p*stride + offset + c], many at once
 int launch_fill(float* p, float v, size_t n, hipStream_t s);
 int launch_add_views(const float* a, int a_ldc, const float* b, int b_ldc, float* out, int out_ldc, size_t vox, int C, hipStream_t s);   // out = a + b
 int launch_bias_fold(const float* conv_bias, float* scale, float* shift, int C, hipStream_t s);   // scale = 1, shift = bias

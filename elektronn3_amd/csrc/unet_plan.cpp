@@ -107,6 +107,8 @@ struct Buffers {
     float* wpack; float* stats; float* bnpart; float* slab; float* small;   // small: coef / fold vectors
     float* bnred;                                                              // pre-merged BN statistic records
     float* ones; float* zeros;                                                 // [Cmax] / [2*Cmax] constants for units without a norm
+    std::vector<float*> bnpart_u;        // per unit: block partials of the BN backward [parts][3][C]; row 2 (sum dx = conv-bias gradient) is summed for all units at once
+    std::vector<float*> wpk_f, wpk_d;    // per unit: Winograd-transformed weights (forward / dgrad form), all packed by ONE launch; nullptr = packed on the spot into wpack
     std::vector<float*> g1, g2, dcat;    // gradient buffers per level
     float* evalA; float* evalB;          // inference ping-pong (level-0 sized)
     size_t scratch_bytes;
@@ -175,11 +177,22 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         slabmax = max_sz(slabmax, (size_t)conv_final_bwd_parts(L[0].vox) * (p->cfg.out_channels * C0 + p->cfg.out_channels));
     }
     B.wpack = T.take(wmax);
+    B.wpk_f.assign(p->units.size(), nullptr); B.wpk_d.assign(p->units.size(), nullptr);
+    for (size_t k = 0; k < p->units.size(); ++k) {
+        const ConvUnit& u = p->units[k];
+        const LevelDims& lo = L[u.level];
+        if (u.is_up || u.planar || u.cin < 8) continue;
+        if (conv_use_wino(CONV_K3, 0, N, lo.D, lo.H, lo.W, u.cin, u.cout)) B.wpk_f[k] = T.take(conv_packed_floats(CONV_K3, u.cin, u.cout));
+        if (training && conv_use_wino(CONV_K3, 0, N, lo.D, lo.H, lo.W, u.cout, u.cin)) B.wpk_d[k] = T.take(conv_packed_floats(CONV_K3, u.cout, u.cin));
+    }
     B.stats = T.take(statmax);
     B.small = T.take((size_t)4 * p->chan(nb - 1) + 64);
     B.bnred = T.take((size_t)BN_PRERED * p->chan(nb - 1) * 3);
     B.ones = T.take(p->chan(nb - 1)); B.zeros = T.take((size_t)2 * p->chan(nb - 1));
+    B.bnpart_u.assign(p->units.size(), nullptr);
     if (training) {
+        for (size_t k = 0; k < p->units.size(); ++k)
+            B.bnpart_u[k] = T.take((size_t)bn_bwd_parts(L[p->units[k].level].vox, p->units[k].cout) * 3 * p->units[k].cout);
         B.bnpart = T.take(bnpartmax);
         B.slab = T.take(slabmax);
         for (int j = 0; j < nb; ++j) {
@@ -333,6 +346,12 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
     std::vector<LevelDims> L; level_dims(plan, N, D, H, W, L);
     auto P = [&](int i) { return (float*)params[i]; };
 
+    {   // Winograd weight transforms of every layer that uses them, in one launch
+        std::vector<WinoPackJob> jobs;
+        for (size_t k = 0; k < plan->units.size(); ++k)
+            if (B.wpk_f[k]) jobs.push_back({P(plan->units[k].p_w), B.wpk_f[k], plan->units[k].cout, plan->units[k].cin, 0});
+        if (!jobs.empty()) RUN(launch_wino_pack_multi(jobs.data(), (int)jobs.size(), s));
+    }
     const float* cur = x; int cur_ldc = cfg.in_channels;
     if (cfg.in_channels > 1) { RUN(launch_ncdhw_to_ndhwc(x, B.xin, N, cfg.in_channels, L[0].vox / N, s)); cur = B.xin; }
 
@@ -378,9 +397,9 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             const int taps = u.planar ? 9 : 27, NPad = pad_cols(u.cout);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             (void)taps;
-            RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, lo.D, lo.H, lo.W, 0, s));
+            if (!B.wpk_f[k]) RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, lo.D, lo.H, lo.W, 0, s));
             ConvArgs a{};
-            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
+            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpk_f[k] ? B.wpk_f[k] : B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
             a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.sd = 2;
             a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
             a.stats = bn_train ? B.stats : nullptr; a.G = 1; a.flags = 0;
@@ -442,11 +461,18 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         RUN(launch_colsum_finalize(B.slab, parts, ps, cfg.out_channels * C0, cfg.out_channels, G(plan->p_final_b), s));
     }
 
+    {   // dgrad form of the Winograd weights of every layer, in one launch
+        std::vector<WinoPackJob> jobs;
+        for (int k = 0; k < nunits; ++k)
+            if (B.wpk_d[k] && (k > 0 || dx)) jobs.push_back({P(plan->units[k].p_w), B.wpk_d[k], plan->units[k].cout, plan->units[k].cin, 1});
+        if (!jobs.empty()) RUN(launch_wino_pack_multi(jobs.data(), (int)jobs.size(), s));
+    }
     RUN(launch_fill(B.ones, 1.f, (size_t)plan->chan(nb - 1), s));
     RUN(launch_fill(B.zeros, 0.f, (size_t)2 * plan->chan(nb - 1), s));
     // ---- walk the units backwards.  `g` = gradient w.r.t. the current unit's activation.
     const float* g = B.g1[0]; int g_ldc = C0;
     bool event_done = bucket_event == nullptr;
+    std::vector<ColsumJob> bias_jobs;     // conv-bias gradients (column sums of the apply pass' partials), flushed in one launch
     for (int k = nunits - 1; k >= 0; --k) {
         const ConvUnit& u = plan->units[k];
         const UnitBufs& b = B.ub[k];
@@ -458,7 +484,10 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         const int kd = u.planar ? 1 : 2;
         if (!event_done && is_down) {
             const int blk = j;   // encoder block index == level
-            if (is_enc_conv2 && blk == bucket_after_down_block - 1) { E3_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_event, s)); event_done = true; }
+            if (is_enc_conv2 && blk == bucket_after_down_block - 1) {
+                if (!bias_jobs.empty()) { RUN(launch_colsum_multi(bias_jobs.data(), (int)bias_jobs.size(), s)); bias_jobs.clear(); }   // the bucket's gradients must be final
+                E3_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_event, s)); event_done = true;
+            }
         }
         // -- BN + ReLU (+ pool, + skip) backward -> dxr = gradient w.r.t. the raw conv output
         float* dxr = B.g2[j];
@@ -473,13 +502,13 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             if (pooled_unit) { a.g1 = cfg.merge_add ? B.dcat[j] : B.dcat[j] + u.cout; a.g1_ldc = cfg.merge_add ? u.cout : 2 * u.cout; a.gpool = g; a.a = b.act; a.a_ldc = b.act_ldc; a.pooled = B.pooled[j]; }
             else { a.g1 = g; a.g1_ldc = g_ldc; }
             a.kd = kd; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.C = u.cout;
-            a.parts = bn_bwd_parts(lo.vox, u.cout); a.part = B.bnpart; a.coef = B.small; a.dx = dxr; a.dx_ldc = u.cout;
+            a.parts = bn_bwd_parts(lo.vox, u.cout); a.part = B.bnpart_u[k]; a.coef = B.small; a.dx = dxr; a.dx_ldc = u.cout;
             if (u.has_norm()) {
                 RUN(launch_bn_bwd_reduce(a, s));
-                RUN(launch_bn_bwd_finalize(B.bnpart, a.parts, u.cout, (float)(1.0 / (double)lo.vox), G(u.p_g), G(u.p_be), B.small, s));
+                RUN(launch_bn_bwd_finalize(a.part, a.parts, u.cout, (float)(1.0 / (double)lo.vox), G(u.p_g), G(u.p_be), B.small, s));
             } else a.coef = B.zeros;
             RUN(launch_bn_bwd_apply(a, s));
-            RUN(launch_colsum_finalize(B.bnpart, a.parts, 3 * u.cout, 2 * u.cout, u.cout, G(u.p_b), s));
+            bias_jobs.push_back({a.part, a.parts, 3 * u.cout, 2 * u.cout, u.cout, G(u.p_b)});
         }
         // -- input activation of this conv
         const float* xin; int xin_ldc;
@@ -537,14 +566,14 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             const int taps = u.planar ? 9 : 27, NPad = pad_cols(u.cin);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             (void)taps;
-            RUN(launch_pack_conv_auto(kind, 1, P(u.p_w), B.wpack, u.cout, u.cin, N, lo.D, lo.H, lo.W, 0, s));
+            if (!B.wpk_d[k]) RUN(launch_pack_conv_auto(kind, 1, P(u.p_w), B.wpack, u.cout, u.cin, N, lo.D, lo.H, lo.W, 0, s));
             const bool to_cat = !is_down && u.name.find("conv1") != std::string::npos;   // UpConv.conv1: gradient of the concat buffer
             float* out; int out_ldc = u.cin;
             if (k == 0) out = (cfg.in_channels > 1) ? B.g1[0] : dx;   // g1[0] is free by now (C0 >= in_channels)
             else if (to_cat) out = B.dcat[j];
             else out = B.g1[j];
             ConvArgs a{};
-            a.x = dxr; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = B.wpack; a.y = out; a.y_ldc = out_ldc;
+            a.x = dxr; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = B.wpk_d[k] ? B.wpk_d[k] : B.wpack; a.y = out; a.y_ldc = out_ldc;
             a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.sd = 2;
             a.Cout = u.cin; a.Ncols = u.cin; a.NPad = NPad; a.G = 1; a.flags = 0;
             { Prof pr(plan, s, k, 1); RUN(launch_conv_mfma(kind, a, s)); }
@@ -552,6 +581,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             g = out; g_ldc = (to_cat && !cfg.merge_add) ? 2 * u.cout : u.cin;   // concat: the next unit (upconv) reads the first half, ldc = 2*C; add: d(up + skip) goes to both
         }
     }
+    if (!bias_jobs.empty()) RUN(launch_colsum_multi(bias_jobs.data(), (int)bias_jobs.size(), s));
     if (!event_done) E3_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_event, s));
     return E3_OK;
 }
