@@ -354,15 +354,21 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int parts, int C, float inv_n,
-                                       float* dgamma, float* dbeta, float* coef) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (c >= C) return;
+// one WORKGROUP per channel: 256 lanes stride over the partial rows (4 independent loads each for 1024 rows instead of a
+// 16-deep chain per wave), butterfly in double, 4 wave results combined through LDS in a fixed order
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int parts, int C, float inv_n,
+                                                              float* dgamma, float* dbeta, float* coef) {
+    __shared__ double red[2][4];
+    const int c = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double s1 = 0.0, s2 = 0.0;
-    for (int p = lane; p < parts; p += 64) { s1 += part[((size_t)p * 3 + 0) * C + c]; s2 += part[((size_t)p * 3 + 1) * C + c]; }
+    for (int p = tid; p < parts; p += 256) { s1 += part[((size_t)p * 3 + 0) * C + c]; s2 += part[((size_t)p * 3 + 1) * C + c]; }
     s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) {
+    if (lane == 0) { red[0][wv] = s1; red[1][wv] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
         if (dbeta) dbeta[c] = (float)s1;
         if (dgamma) dgamma[c] = (float)s2;
         coef[c] = (float)(s1 * inv_n);
@@ -544,7 +550,7 @@ int launch_bn_bwd_reduce(BnBwdArgs a, hipStream_t s) { return bn_bwd_launch(a, f
 int launch_bn_bwd_apply(BnBwdArgs a, hipStream_t s) { return bn_bwd_launch(a, true, s); }
 
 int launch_bn_bwd_finalize(const float* part, int parts, int C, float inv_n, float* dgamma, float* dbeta, float* coef, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, part, parts, C, inv_n, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, part, parts, C, inv_n, dgamma, dbeta, coef);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
