@@ -65,12 +65,43 @@ def cpu_baseline(iters=2):
             's_per_step': dt}
 
 
+def predictor_leg(dev, shape=(288, 1152, 1152), tile=(96, 192, 192), overlap=(16, 16, 16)):
+    """BASELINE.json's second metric ("Predictor MVox/s", configs[4]) on the cfg-5 geometry -- tile 96x192x192, overlap 16, eval-mode
+    UNet(n_blocks=4, start_filts=32), softmax output, fp32 volume in HOST memory, result back in host memory -- over a
+    288x1152x1152 sub-volume (108 tiles) so that the default bench run stays short; tools/bench_predictor.py runs the full
+    512x2048x2048 volume (726 tiles).  Input voxels / predict() wall time incl. H2D and D2H (benchmark/pred_benchmark.py:101)."""
+    from elektronn3_amd.inference import Predictor
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(0)
+    model = UNet(1, 2, n_blocks=4, start_filts=32).to(dev)
+    model.train()
+    with torch.no_grad():                    # running statistics from 10 warm-up batches (SURVEY 8d cfg 5)
+        for _ in range(10):
+            model(torch.randn(2, 1, 32, 64, 64, device=dev))
+    vol = torch.randn(1, 1, *shape, generator=torch.Generator().manual_seed(0))
+    Predictor(model, device=dev, apply_softmax=True).predict(torch.randn(1, 1, *[t + 2 * o for t, o in zip(tile, overlap)]))   # warm-up tile
+    pred = Predictor(model, device=dev, tile_shape=tile, overlap_shape=overlap, offset=None, out_shape=(2, *shape), apply_softmax=True,
+                     strict_shapes=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = pred.predict(vol)
+    dt = time.perf_counter() - t0
+    ntiles = 1
+    for n, t in zip(shape, tile):
+        ntiles *= -(-n // t)
+    return {'metric': 'Predictor MVox/s', 'value': vol.numel() / dt / 1e6, 'unit': 'MVox/s (input voxels / predict() wall time incl. H2D + D2H)',
+            'seconds': dt, 'volume': list(shape), 'tile': list(tile), 'overlap': list(overlap), 'tiles': ntiles, 'dtype': 'f32',
+            'finite': bool(torch.isfinite(out[..., ::32, ::32]).all()),
+            'note': 'cfg-5 geometry on a sub-volume; the full 512x2048x2048 volume (726 tiles): tools/bench_predictor.py, DESIGN.md section 5'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-predictor', action='store_true', help='skip the Predictor MVox/s leg (N=1 only)')
     ap.add_argument('--profile-layer', default='up_convs.2.conv1')
     args = ap.parse_args()
 
@@ -186,6 +217,13 @@ def main():
             except Exception as e:  # noqa: BLE001
                 res['cpu_baseline'] = {'value': None, 'unit': 'voxels/s', 'cores': torch.get_num_threads(), 'kind': 'port',
                                        'sample': f'failed: {e}'}
+        if world == 1 and dist is None and not args.no_predictor:
+            try:
+                del x, tgt
+                torch.cuda.empty_cache()
+                res['predictor'] = predictor_leg(dev)
+            except Exception as e:  # noqa: BLE001
+                res['predictor'] = {'metric': 'Predictor MVox/s', 'value': None, 'note': f'failed: {e}'}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
