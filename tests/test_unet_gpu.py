@@ -382,6 +382,38 @@ def test_state_dict_roundtrip_pickle_and_reference_keys(tmp_path):
     assert sum(isinstance(mod, nn.modules.batchnorm._BatchNorm) for mod in m.modules()) == 17   # SWA.bn_update walks these
 
 
+def test_trainer_protocol_autocast_gradscaler_dataparallel():
+    """What Trainer._train_step wraps around the model (training/trainer.py:517-543): ``torch.autocast`` (fp16 by default),
+    ``GradScaler.scale(loss).backward()`` + ``scaler.step(optimizer)``, and ``nn.DataParallel`` (benchmark/train_benchmark.py:109-110,
+    one visible GPU here).  The HIP path computes in fp32 whatever the autocast state: same logits/gradients as the plain call."""
+    from elektronn3_amd.loss import CombinedCEDiceLoss
+    from elektronn3_amd.optim import AdamW
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(12)
+    m = UNet(n_blocks=3, start_filts=16, planar_blocks=(0,)).cuda().train()
+    crit = CombinedCEDiceLoss(weight=[0.2653, 0.7347]).cuda()
+    x = torch.randn(2, 1, 12, 40, 48, device='cuda'); t = torch.randint(0, 2, (2, 12, 40, 48), device='cuda')
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    out0 = m(x); crit(out0, t).backward()
+    g0 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.load_state_dict(sd0); m.zero_grad(set_to_none=True)
+    dp = torch.nn.DataParallel(m)
+    opt = AdamW(m.parameters(), lr=1e-3, weight_decay=0.5e-4)
+    scaler = torch.amp.GradScaler('cuda', init_scale=256.0)
+    with torch.autocast('cuda', dtype=torch.float16):
+        out1 = dp(x)
+        loss = crit(out1, t)
+    assert out1.dtype == torch.float32 and torch.equal(out1, out0)       # fp32 compute, bit-identical to the plain call
+    scaler.scale(loss).backward()
+    for k, p in m.named_parameters():
+        torch.testing.assert_close(p.grad / 256.0, g0[k], rtol=1e-5, atol=1e-8, msg=k)   # scaled by a power of two: exact up to underflow
+    before = [p.detach().clone() for p in m.parameters()]
+    scaler.step(opt); scaler.update()
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    assert any(not torch.equal(p.detach(), b) for p, b in zip(m.parameters(), before))
+    assert float(opt.state[next(m.parameters())]['step']) == 1
+
+
 def test_cpu_input_fails_loudly():
     from elektronn3_amd.unet import UNet
     m = UNet(n_blocks=2, start_filts=8)
