@@ -10,9 +10,9 @@ tensor) as the reference (inference.py:45-199, 368-687).  What is different is w
 * tiles are cut as strided views of the padded device volume; for an :class:`elektronn3_amd.unet.UNet` the model
   call is the eval-mode native forward (BatchNorm folded into the conv epilogues) with the ``Softmax(1)`` of
   ``nn.Sequential(model, nn.Softmax(1))`` (inference.py:443-444) fused into the last kernel.
-* tiles are independent (each carries its own halo), so with ``torch.distributed`` initialised the tile list is
-  sharded round-robin over the ranks (``tile_parallel=True``) with no data-path collective; rank 0 collects the
-  disjoint output slabs at the end.
+* tiles are independent (each carries its own halo), so with ``torch.distributed`` initialised (one process per GPU of one
+  node) and ``tile_parallel=True`` the rows of tiles are split over the ranks with no data-path collective; every rank
+  writes its rows into one output buffer in shared host memory.
 
 Any other ``nn.Module`` is accepted too and is simply called like the reference calls it.
 """
@@ -32,6 +32,39 @@ from torch import nn
 logger = logging.getLogger('elektronn3log')
 
 Transform = Callable[[np.ndarray, Optional[np.ndarray]], Tuple[np.ndarray, Optional[np.ndarray]]]
+
+
+class _SharedHostTensor:
+    """A host tensor backed by a file in /dev/shm that the ranks of one node map together (np.memmap): the tile-parallel
+    Predictor's output buffer.  The creator unlinks the name once every rank has finished writing; the mappings stay valid
+    for as long as the tensors live."""
+
+    def __init__(self, name, shape, dtype, create):
+        import tempfile
+        nbytes = max(int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size(), 1)
+        self.owner = create
+        if create:
+            shm_dir = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
+            fd, name = tempfile.mkstemp(prefix='e3pred_', dir=shm_dir)
+            os.close(fd)
+        self.name = name
+        buf = np.memmap(name, dtype=np.uint8, mode='w+' if create else 'r+', shape=(nbytes,))
+        self.tensor = torch.from_numpy(buf).view(dtype).view(*shape)     # (the tensor keeps the mapping alive)
+
+    @classmethod
+    def create(cls, shape, dtype):
+        return cls(None, shape, dtype, True)
+
+    @classmethod
+    def open(cls, name, shape, dtype):
+        return cls(name, shape, dtype, False)
+
+    def unlink_if_owner(self):
+        if self.owner:
+            try:
+                os.unlink(self.name)
+            except FileNotFoundError:
+                pass
 
 
 def _extend_nc(spatial_slice):
@@ -344,8 +377,13 @@ class Predictor:
                 and self.overlap_shape is not None and len(self.tile_shape) == 3 and inp.dim() == 5
                 and tuple(inp.shape[2:]) == tuple(int(v) for v in self.out_shape[1:])
                 and (self.batch_size is None or self.batch_size >= inp.shape[0])
-                and not (self.tile_parallel and torch.distributed.is_available() and torch.distributed.is_initialized())
                 and os.environ.get('E3_PREDICTOR_NO_PIPELINE') is None)
+
+    def _dist(self):
+        """(world, rank) of the tile-parallel run, (1, 0) otherwise."""
+        if self.tile_parallel and torch.distributed.is_available() and torch.distributed.is_initialized():
+            return torch.distributed.get_world_size(), torch.distributed.get_rank()
+        return 1, 0
 
     @torch.no_grad()
     def _pipelined_predict(self, inp):
@@ -353,9 +391,15 @@ class Predictor:
         central crops assembled), but the volume streams through the GPU: the input is uploaded in z slabs just ahead of the
         tile rows that need them, and every finished row of output tiles goes back to the host (cropped to out_shape) on a
         side stream while the next rows are computed.  Host copies are done by two worker threads (pageable memory copies
-        block their calling thread, not the GPU); the compute stream only waits on events."""
+        block their calling thread, not the GPU); the compute stream only waits on events.
+
+        Tile-parallel (``tile_parallel=True`` under torch.distributed, one process per GPU of ONE node): the
+        (z, y) rows of tiles are split into contiguous shares, one per rank; a rank uploads only the z slabs its rows need and
+        writes its finished rows straight into ONE output buffer in POSIX shared memory that all ranks map -- independent
+        units, no data-path collective, eight PCIe links used in parallel.  Every rank returns that (complete) tensor."""
         from concurrent.futures import ThreadPoolExecutor
         dev = self.device
+        world, rank = self._dist()
         N, Cin = int(inp.shape[0]), int(inp.shape[1])
         real = np.array(self.out_shape[1:], dtype=np.int64)
         tile, ov = self.tile_shape.astype(np.int64), self.overlap_shape.astype(np.int64)
@@ -364,7 +408,6 @@ class Predictor:
                              'strict_shapes=False.')
         padded = (np.ceil(real / tile) * tile).astype(np.int64)           # spatial shape the tile loop works on
         ntz, nty, ntx = (int(v) for v in padded // tile)
-        C = int(self.out_shape[0])
         if self.out_dtype is None:
             self.out_dtype = torch.uint8 if self.argmax_with_threshold is not None else inp.dtype
         inp_padded = torch.zeros((N, Cin, *(int(v) for v in padded + 2 * ov)), dtype=self.dtype, device=dev)
@@ -373,49 +416,87 @@ class Predictor:
         main = torch.cuda.current_stream(dev)
         up_stream, down_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         up_stream.wait_stream(main); down_stream.wait_stream(main)       # (the zero fill of inp_padded precedes every upload)
-        # z rows of the ORIGINAL input that tile row k needs: padded coords [tile*k, tile*(k+1) + 2 ov) = original - ov
-        hi = [int(min(real[0], tile[0] * (k + 1) + ov[0])) for k in range(ntz)]
-        lo = [0] + hi[:-1]
-        up_events = [torch.cuda.Event() for _ in range(ntz)]
+        # this rank's share of the (z row k, y row j) rows of tiles, in the reference's visiting order
+        rows = [(k, j) for k in range(ntz) for j in range(nty)]
+        per = -(-len(rows) // world)                                      # contiguous shares; rank 0 always has work
+        mine = rows[min(len(rows), per * rank):min(len(rows), per * (rank + 1))]
+        zrows = sorted({k for k, _ in mine})
+        # z planes of the ORIGINAL input that tile row k needs: padded coords [tile*k, tile*(k+1) + 2 ov) = original - ov
+        need_lo = {k: int(max(0, tile[0] * k - ov[0])) for k in zrows}
+        need_hi = {k: int(min(real[0], tile[0] * (k + 1) + ov[0])) for k in zrows}
+        up_events = {k: torch.cuda.Event() for k in zrows}
+        uploaded = [None]                                                 # z plane up to which the input is on the device
 
         def upload(k):
-            a, b = lo[k], hi[k]
+            a = need_lo[k] if uploaded[0] is None else max(uploaded[0], need_lo[k])
+            b = need_hi[k]
             with torch.cuda.stream(up_stream):
                 if b > a:
                     dst = inp_padded[:, :, int(ov[0]) + a:int(ov[0]) + b, int(ov[1]):int(ov[1] + real[1]), int(ov[2]):int(ov[2] + real[2])]
                     dst.copy_(inp[:, :, a:b].to(self.dtype))
+                uploaded[0] = b if uploaded[0] is None else max(uploaded[0], b)
                 up_events[k].record(up_stream)
 
-        host_out = None
-        out_dev = None
+        state = {'host_out': None, 'out_dev': None, 'shm': None}
         downs = []
 
-        def download(k, ev, src):
+        def make_outputs(out_tile):
+            """Output buffers, once the first tile tells channel layout and dtype (world > 1: every rank calls this exactly once,
+            whether it has tiles or not -- the shared-memory name travels in one broadcast_object_list)."""
+            meta = None
+            if out_tile is not None:
+                meta = (tuple(int(v) for v in out_tile.shape[1:-3]), out_tile.dtype)
+            if world > 1:
+                box = [None]
+                if rank == 0:
+                    assert meta is not None
+                    shape = (N, *meta[0], *(int(v) for v in real))
+                    state['shm'] = _SharedHostTensor.create(shape, meta[1])
+                    box = [(state['shm'].name, shape, meta[1])]
+                torch.distributed.broadcast_object_list(box, src=0)
+                if rank != 0:
+                    state['shm'] = _SharedHostTensor.open(*box[0])
+                    meta = (tuple(box[0][1][1:-3]), box[0][2])
+                state['host_out'] = state['shm'].tensor
+            else:
+                state['host_out'] = torch.empty((N, *meta[0], *(int(v) for v in real)), dtype=meta[1])
+            state['out_dev'] = torch.zeros((N, *meta[0], *(int(v) for v in padded)), dtype=meta[1], device=dev)
+
+        def download(k, j0, j1, ev):
             with torch.cuda.stream(down_stream):
                 down_stream.wait_event(ev)
                 z0, z1 = int(tile[0] * k), int(min(tile[0] * (k + 1), real[0]))
-                if z1 > z0:
-                    host_out[:, :, z0:z1].copy_(src[:, :, z0:z1, :int(real[1]), :int(real[2])])
+                y0, y1 = int(tile[1] * j0), int(min(tile[1] * j1, real[1]))
+                if z1 > z0 and y1 > y0:
+                    state['host_out'][:, :, z0:z1, y0:y1].copy_(state['out_dev'][:, :, z0:z1, y0:y1, :int(real[2])])
 
         with ThreadPoolExecutor(max_workers=1) as up_pool, ThreadPoolExecutor(max_workers=1) as down_pool:
-            ups = [up_pool.submit(upload, k) for k in range(ntz)]
-            for k in range(ntz):
-                ups[k].result()                       # (the copy has been issued; the stream-side wait is the event)
-                main.wait_event(up_events[k])
-                for ti in range(k * nty * ntx, (k + 1) * nty * ntx):
+            ups = {k: up_pool.submit(upload, k) for k in zrows}
+            if not mine:
+                make_outputs(None)
+            for i, (k, j) in enumerate(mine):
+                if i == 0 or mine[i - 1][0] != k:
+                    ups[k].result()                   # (the copy has been issued; the stream-side wait is the event)
+                    main.wait_event(up_events[k])
+                    j_first = j
+                for ti in range((k * nty + j) * ntx, (k * nty + j + 1) * ntx):
                     ilo, ihi, olo, ohi = plan[ti]
                     inp_tile = inp_padded[_extend_nc([slice(l, h) for l, h in zip(ilo, ihi)])].contiguous()
                     out_tile = self._predict(inp_tile, crop)
-                    if out_dev is None:
-                        out_dev = torch.zeros((N, *out_tile.shape[1:-3], *(int(v) for v in padded)), dtype=out_tile.dtype, device=dev)
-                        host_out = torch.empty((N, *out_tile.shape[1:-3], *(int(v) for v in real)), dtype=out_tile.dtype)
-                    out_dev[_extend_nc([slice(l, h) for l, h in zip(olo, ohi)])] = out_tile
-                ev = torch.cuda.Event(); ev.record(main)
-                downs.append(down_pool.submit(download, k, ev, out_dev))
+                    if state['out_dev'] is None:
+                        make_outputs(out_tile)
+                    state['out_dev'][_extend_nc([slice(l, h) for l, h in zip(olo, ohi)])] = out_tile
+                last_of_zrow = i + 1 == len(mine) or mine[i + 1][0] != k
+                if world > 1 or last_of_zrow:         # one rank: whole z rows go back (contiguous in host memory)
+                    ev = torch.cuda.Event(); ev.record(main)
+                    downs.append(down_pool.submit(download, k, j if world > 1 else j_first, j + 1, ev))
             for d in downs:
                 d.result()
         torch.cuda.synchronize(dev)
-        return host_out
+        if world > 1:
+            torch.distributed.barrier()               # every rank's rows are in the shared buffer
+            state['shm'].unlink_if_owner()            # the mapping stays valid; the name disappears
+        return state['host_out']
 
     # ------------------------------------------------------------------ public API (inference.py:569-642)
     def predict(self, inp):

@@ -198,3 +198,42 @@ def test_predictor_dim2_native_tiled():
                 assert torch.allclose(o.double(), ref, rtol=1e-4, atol=1e-5)
             full[:, :, olo[0]:ohi[0], olo[1]:ohi[1]] = o[:, :, 16:80, 16:112].cpu()
     assert torch.equal(y, full[:, :, :150, :200])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world', [3, 7])
+def test_predictor_tile_parallel_ranks_share_one_output(tmp_path, world):
+    """the (z, y) rows of tiles are split over the ranks, every rank writes its rows into ONE output buffer in
+    shared host memory, no data-path collective.  `world` gloo ranks share the one GPU of the test box (the sharding logic does
+    not care which device a rank drives); 7 ranks > 6 rows leaves a rank without work.  Result == single-process result, bit
+    for bit, on every rank; uint8 argmax output too; nothing is left behind in /dev/shm."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'pred_ranks.py'
+    script.write_text('''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from elektronn3_amd.unet import UNet
+from elektronn3_amd.inference import Predictor
+dist.init_process_group('gloo')
+torch.cuda.set_device(0)
+torch.manual_seed(0)
+m = UNet(1, 2, n_blocks=2, start_filts=8).cuda()
+m.train()
+with torch.no_grad():
+    m(torch.randn(2, 1, 16, 32, 32, device='cuda'))
+vol = torch.randn(1, 1, 40, 72, 88, generator=torch.Generator().manual_seed(1))
+kw = dict(device='cuda', tile_shape=(24, 32, 32), overlap_shape=(8, 8, 8), offset=None, out_shape=(2, 40, 72, 88), apply_softmax=True)
+y = Predictor(m, tile_parallel=True, **kw).predict(vol)
+ref = Predictor(m, tile_parallel=False, **kw).predict(vol)
+ya = Predictor(m, tile_parallel=True, apply_argmax=True, **kw).predict(vol)
+ok = torch.equal(y, ref) and ya.dtype == torch.uint8 and torch.equal(ya[0, 0], ref[0].argmax(0).to(torch.uint8))
+left = [f for f in os.listdir('/dev/shm') if f.startswith('e3pred_')]
+dist.barrier()
+print('RANK_OK' if ok and not left else 'RANK_BAD', dist.get_rank(), left, flush=True)
+''' % root)
+    port = 29600 + world
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count('RANK_OK') == world and 'RANK_BAD' not in r.stdout, r.stdout[-2000:]
