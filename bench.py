@@ -65,7 +65,7 @@ def cpu_baseline(iters=2):
             's_per_step': dt}
 
 
-def predictor_leg(dev, shape=(288, 1152, 1152), tile=(96, 192, 192), overlap=(16, 16, 16)):
+def predictor_leg(dev, shape=(288, 1152, 1152), tile=(96, 192, 192), overlap=(16, 16, 16), tile_parallel=False):
     """BASELINE.json's second metric ("Predictor MVox/s", configs[4]) on the cfg-5 geometry -- tile 96x192x192, overlap 16, eval-mode
     UNet(n_blocks=4, start_filts=32), softmax output, fp32 volume in HOST memory, result back in host memory -- over a
     288x1152x1152 sub-volume (108 tiles) so that the default bench run stays short; tools/bench_predictor.py runs the full
@@ -81,7 +81,7 @@ def predictor_leg(dev, shape=(288, 1152, 1152), tile=(96, 192, 192), overlap=(16
     vol = torch.randn(1, 1, *shape, generator=torch.Generator().manual_seed(0))
     Predictor(model, device=dev, apply_softmax=True).predict(torch.randn(1, 1, *[t + 2 * o for t, o in zip(tile, overlap)]))   # warm-up tile
     pred = Predictor(model, device=dev, tile_shape=tile, overlap_shape=overlap, offset=None, out_shape=(2, *shape), apply_softmax=True,
-                     strict_shapes=False)
+                     strict_shapes=False, tile_parallel=tile_parallel)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = pred.predict(vol)
@@ -177,6 +177,11 @@ def main():
         _, ms, n = timed(2, which)
         extra[tag] = ms
 
+    multi_pred = None
+    if dist is not None and world > 1 and os.environ.get('E3_BENCH_PREDICTOR_MULTI') and not args.no_predictor:
+        # opt-in (a collective path that the 1-GPU development box cannot exercise over RCCL): every rank predicts its share of
+        # the tile rows of the same sub-volume; all ranks call this
+        multi_pred = predictor_leg(dev, tile_parallel=True)
     if rank == 0:
         vox_per_step = world * BATCH_PER_GPU * CROP[0] * CROP[1] * CROP[2]
         lvox = BATCH_PER_GPU * CROP[0] * CROP[1] * CROP[2] // (8 ** llevel)
@@ -224,6 +229,8 @@ def main():
                 res['predictor'] = predictor_leg(dev)
             except Exception as e:  # noqa: BLE001
                 res['predictor'] = {'metric': 'Predictor MVox/s', 'value': None, 'note': f'failed: {e}'}
+        elif multi_pred is not None:
+            res['predictor'] = dict(multi_pred, n_gpus=world, parallelism=f'tile-parallel over {world} ranks, shared-memory output')
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

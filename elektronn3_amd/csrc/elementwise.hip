@@ -290,6 +290,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
         const int q = i % Q; size_t r = i / Q;
         const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + 4 * q);
         const f32x4 is = *reinterpret_cast<const f32x4*>(a.invstd + 4 * q);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + 4 * q);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + 4 * q);
         f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = c1, gi = c1;
         if (APPLYPASS) {
             c1 = *reinterpret_cast<const f32x4*>(a.coef + 4 * q);
@@ -314,7 +316,11 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                         const int w = pw * 2 + dx_; if (w >= a.W) break;
                         const size_t v = (((size_t)n * a.D + d) * a.H + h) * a.W + w;
                         const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + v * a.x_ldc + 4 * q);
-                        const f32x4 av = *reinterpret_cast<const f32x4*>(a.a + v * a.a_ldc + 4 * q);
+                        // the activation is recomputed, not re-read (a quarter of this pass' HBM traffic): the same expression as the
+                        // forward apply, so it is bit-identical to the stored tensor the pooled maxima were taken from
+                        f32x4 av;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) av[e] = fmaxf(__builtin_fmaf(xv[e], sc[e], sh[e]), 0.f);
                         f32x4 g = {0.f, 0.f, 0.f, 0.f};
                         if (a.g1) g = *reinterpret_cast<const f32x4*>(a.g1 + v * a.g1_ldc + 4 * q);
                         f32x4 o;
