@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
 // ------------------------------------------------------------------ final 1x1x1 conv, forward (+ optional softmax)
 template <int COUT>
 __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, int C, const float* __restrict__ w,
-                                      const float* __restrict__ bias, float* __restrict__ y, size_t S, int N, int lpv, int softmax) {
+                                      const float* __restrict__ bias, float* __restrict__ y, size_t S, int N, int lpv, int softmax,
+                                      const float* __restrict__ pro_scale, const float* __restrict__ pro_shift) {
+    // pro_scale/pro_shift: `a` is the RAW output of the last conv; its BatchNorm + ReLU, a := relu(a*scale + shift), is applied while
+    // loading (same expression as bn_relu_apply_kernel) -- the last activation of the network is never written or re-read
     // lpv (1,2,4,8) consecutive lanes share one voxel; each walks every lpv-th channel quad
     const int Q = C >> 2;
     const size_t total = (size_t)N * S;
@@ -207,7 +210,12 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
         const bool ok = v < total;
         if (ok)
             for (int q = sub; q < Q; q += lpv) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * q);
+                f32x4 av = *reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * q);
+                if (pro_scale) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(pro_scale + 4 * q), sh = *reinterpret_cast<const f32x4*>(pro_shift + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[e] = fmaxf(__builtin_fmaf(av[e], sc[e], sh[e]), 0.f);
+                }
 #pragma unroll
                 for (int co = 0; co < COUT; ++co) {
                     const f32x4 wv = *reinterpret_cast<const f32x4*>(w + co * C + 4 * q);
@@ -243,7 +251,8 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_final_bwd_kernel(const float* __restrict__ a, int a_ldc, int C, const float* __restrict__ w,
                                                              const float* __restrict__ dy, float* __restrict__ da, int da_ldc,
-                                                             float* __restrict__ part, size_t S, int N) {
+                                                             float* __restrict__ part, size_t S, int N,
+                                                             const float* __restrict__ pro_scale, const float* __restrict__ pro_shift) {
     __shared__ float red[256][4];
     const int Q = C >> 2;
     const int BT = (256 / Q) * Q;
@@ -252,6 +261,8 @@ __global__ __launch_bounds__(256) void conv_final_bwd_kernel(const float* __rest
     const int q = tid % Q;
     f32x4 wv[COUT], dwacc[COUT];
     float dbacc[COUT];
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (pro_scale) { sc = *reinterpret_cast<const f32x4*>(pro_scale + 4 * q); sh = *reinterpret_cast<const f32x4*>(pro_shift + 4 * q); }
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
         wv[co] = *reinterpret_cast<const f32x4*>(w + co * C + 4 * q);
@@ -260,7 +271,11 @@ __global__ __launch_bounds__(256) void conv_final_bwd_kernel(const float* __rest
     for (size_t i = (size_t)blockIdx.x * BT + tid; tid < BT && i < total; i += (size_t)gridDim.x * BT) {
         const size_t v = i / Q;
         const size_t n = v / S, sp = v % S;
-        const f32x4 av = *reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * q);
+        f32x4 av = *reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * q);
+        if (pro_scale) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = fmaxf(__builtin_fmaf(av[e], sc[e], sh[e]), 0.f);
+        }
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
@@ -367,12 +382,12 @@ static int final_lpv(int C) {
     }
 
 int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y,
-                          int Cout, size_t S, int N, int softmax, hipStream_t s) {
+                          int Cout, size_t S, int N, int softmax, hipStream_t s, const float* pro_scale, const float* pro_shift) {
     E3_REQUIRE(C % 4 == 0 && a_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
     const int lpv = final_lpv(C);
     const size_t vox = (size_t)N * S;
     size_t g = (vox * lpv + 255) / 256; if (g > 4096) g = 4096; if (g == 0) g = 1;
-    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_fwd_kernel<CO>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, S, N, lpv, softmax));
+    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_fwd_kernel<CO>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, S, N, lpv, softmax, pro_scale, pro_shift));
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
@@ -383,10 +398,10 @@ int conv_final_bwd_parts(size_t total_voxels) {
 }
 
 int launch_conv_final_bwd(const float* a, int a_ldc, int C, const float* w, const float* dy, float* da, int da_ldc,
-                          float* part, int Cout, size_t S, int N, hipStream_t s) {
+                          float* part, int Cout, size_t S, int N, hipStream_t s, const float* pro_scale, const float* pro_shift) {
     E3_REQUIRE(C % 4 == 0 && C <= 1024, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4 and <= 1024");
     const int parts = conv_final_bwd_parts((size_t)N * S);
-    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_bwd_kernel<CO>), dim3(parts), dim3(256), 0, s, a, a_ldc, C, w, dy, da, da_ldc, part, S, N));
+    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_bwd_kernel<CO>), dim3(parts), dim3(256), 0, s, a, a_ldc, C, w, dy, da, da_ldc, part, S, N, pro_scale, pro_shift));
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

@@ -101,10 +101,12 @@ int launch_conv_small_wgrad(const float* x, int Cin, const float* dy, int dy_ldc
 
 // final 1x1x1 conv: C (multiple of 4) -> Cout (<= 8); output and its gradient are NCDHW (the module boundary)
 int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y_ncdhw,
-                          int Cout, size_t voxels_per_sample, int N, int softmax, hipStream_t s);
+                          int Cout, size_t voxels_per_sample, int N, int softmax, hipStream_t s,
+                          const float* pro_scale = nullptr, const float* pro_shift = nullptr);   // a := relu(a*scale + shift) while loading
 int conv_final_bwd_parts(size_t total_voxels);
 int launch_conv_final_bwd(const float* a, int a_ldc, int C, const float* w, const float* dy_ncdhw, float* da, int da_ldc,
-                          float* part /*[parts][Cout][C+1]*/, int Cout, size_t voxels_per_sample, int N, hipStream_t s);
+                          float* part /*[parts][Cout][C+1]*/, int Cout, size_t voxels_per_sample, int N, hipStream_t s,
+                          const float* pro_scale = nullptr, const float* pro_shift = nullptr);
 
 // ---------------------------------------------------------------- weighted CE + Dice criterion (loss.hip)
 size_t ce_dice_workspace_floats(int C);

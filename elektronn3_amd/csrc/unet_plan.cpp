@@ -412,8 +412,11 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             f.running_mean = P(u.p_rm); f.running_var = P(u.p_rv); f.momentum = momenta[u.bn_index]; f.eps = cfg.bn_eps;
             f.mean = b.mean; f.invstd = b.invstd; f.scale = b.scale; f.shift = b.shift; f.scratch = B.bnred;
             RUN(launch_bn_finalize(f, s));
-            RUN(launch_bn_relu_apply(b.raw, u.cout, b.scale, b.shift, b.act, b.act_ldc, pool_after ? B.pooled[u.level] : nullptr, kd,
-                                     N, lo.D, lo.H, lo.W, u.cout, s));
+            // the last activation of the network only feeds the 1x1x1 head, which applies BN + ReLU while loading the raw tensor
+            // (forward and backward): no apply pass, no activation tensor
+            if (k + 1 < plan->units.size())
+                RUN(launch_bn_relu_apply(b.raw, u.cout, b.scale, b.shift, b.act, b.act_ldc, pool_after ? B.pooled[u.level] : nullptr, kd,
+                                         N, lo.D, lo.H, lo.W, u.cout, s));
         } else if (pool_after) {
             RUN(launch_maxpool(b.act, b.act_ldc, B.pooled[u.level], kd, N, lo.D, lo.H, lo.W, u.cout, s));
         }
@@ -426,9 +429,15 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         else if (u.is_up) { cur = B.cat[u.level]; cur_ldc = 2 * u.cout; }   // conv1 of the UpConv reads the whole concat buffer
         else { cur = b.act; cur_ldc = b.act_ldc; }
     }
-    { Prof pr(plan, s, (int)plan->units.size(), 0);
-      RUN(launch_conv_final_fwd(cur, cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y, cfg.out_channels,
-                                L[0].vox / N, N, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s)); }
+    {
+        const ConvUnit& lu = plan->units.back();
+        const UnitBufs& lb = B.ub.back();
+        const bool fused = training && lu.has_norm();     // see above: head reads the raw conv output + (scale, shift)
+        Prof pr(plan, s, (int)plan->units.size(), 0);
+        RUN(launch_conv_final_fwd(fused ? lb.raw : cur, fused ? lu.cout : cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y,
+                                  cfg.out_channels, L[0].vox / N, N, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s,
+                                  fused ? lb.scale : nullptr, fused ? lb.shift : nullptr));
+    }
     return E3_OK;
 }
 
@@ -456,7 +465,9 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         const int parts = conv_final_bwd_parts(L[0].vox);
         const int ps = cfg.out_channels * C0 + cfg.out_channels;
         { Prof pr(plan, s, nunits, 1);
-          RUN(launch_conv_final_bwd(last.act, last.act_ldc, C0, P(plan->p_final_w), dy, B.g1[0], C0, B.slab, cfg.out_channels, L[0].vox / N, N, s)); }
+          const bool fused = plan->units.back().has_norm();
+          RUN(launch_conv_final_bwd(fused ? last.raw : last.act, fused ? C0 : last.act_ldc, C0, P(plan->p_final_w), dy, B.g1[0], C0, B.slab,
+                                    cfg.out_channels, L[0].vox / N, N, s, fused ? last.scale : nullptr, fused ? last.shift : nullptr)); }
         RUN(launch_colsum_finalize(B.slab, parts, ps, 0, cfg.out_channels * C0, G(plan->p_final_w), s));
         RUN(launch_colsum_finalize(B.slab, parts, ps, cfg.out_channels * C0, cfg.out_channels, G(plan->p_final_b), s));
     }
