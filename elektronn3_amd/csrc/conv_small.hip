@@ -135,7 +135,12 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const ConvSmallArgs
 template <int KD, int TD, int TH>
 __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __restrict__ x, int Cin, const float* __restrict__ dy, int dy_ldc,
                                                                float* __restrict__ part, int N, int D, int H, int W, int Cout,
-                                                               int tilesD, int tilesH, int tilesW, int tiles_per_split) {
+                                                               int tilesD, int tilesH, int tilesW, int tiles_per_split, const SmallWgradFuse f) {
+    // f.x1 != nullptr: `dy` is not given; it is the BN + ReLU backward of this conv's own output, computed while the brick is staged
+    //   dy = gamma*invstd * (dz - c1 - xhat*c2),  dz = g * (x1*scale + shift > 0),  xhat = (x1 - mean)*invstd
+    // (the APPLY pass of bn_bwd_kernel, same expressions) from the raw conv output x1 and the incoming gradient g: the first conv has
+    // no data gradient, so its dy has no other consumer and is never written; the column sums of dy (= conv-bias gradient) go to
+    // f.biaspart [blocks][Cout].
     constexpr int TW = 16, PD = KD / 2, LD = TD + 2 * PD, LH = TH + 2, LW = TW + 2, NV = LD * LH * LW, T = KD * 9;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                 // [NV]        one input channel
@@ -145,7 +150,18 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
     const int toff = (kd * LH + kh) * LW + kw;
     const int ntiles = N * tilesD * tilesH * tilesW;
     const int tile0 = blockIdx.x * tiles_per_split;
-    for (int pass = 0; pass * 32 < Cout; ++pass)
+    for (int pass = 0; pass * 32 < Cout; ++pass) {
+        // per-channel constants of the fused BN backward for the channel quad this thread stages (tid & 7 is fixed across its pieces)
+        f32x4 fsc = {1.f, 1.f, 1.f, 1.f}, fsh = {0.f, 0.f, 0.f, 0.f}, fmu = fsh, fis = fsc, fgi = fsc, fc1 = fsh, fc2 = fsh, bsum = fsh;
+        if (f.x1 && pass * 32 + 4 * (tid & 7) < Cout) {
+            const int c0 = pass * 32 + 4 * (tid & 7);
+            fsc = *reinterpret_cast<const f32x4*>(f.scale + c0); fsh = *reinterpret_cast<const f32x4*>(f.shift + c0);
+            fmu = *reinterpret_cast<const f32x4*>(f.mean + c0); fis = *reinterpret_cast<const f32x4*>(f.invstd + c0);
+            fc1 = *reinterpret_cast<const f32x4*>(f.coef + c0); fc2 = *reinterpret_cast<const f32x4*>(f.coef + Cout + c0);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(f.gamma + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fgi[e] = gm[e] * fis[e];
+        }
         for (int ci = 0; ci < Cin; ++ci) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (int tile = tile0; tile < tile0 + tiles_per_split && tile < ntiles; ++tile) {
@@ -166,8 +182,24 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
                     const int ww = v & 15, hh = (v >> 4) % TH, dd = (v >> 4) / TH;
                     const int gd = d0 + dd, gh = h0 + hh, gw = w0 + ww;
                     f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                    if (gd < D && gh < H && gw < W && pass * 32 + 4 * qq < Cout)
-                        val = *reinterpret_cast<const f32x4*>(dy + ((((size_t)nb * D + gd) * H + gh) * W + gw) * dy_ldc + pass * 32 + 4 * qq);
+                    if (gd < D && gh < H && gw < W && pass * 32 + 4 * qq < Cout) {
+                        const size_t vox = (((size_t)nb * D + gd) * H + gh) * W + gw;
+                        const int c0 = pass * 32 + 4 * qq;
+                        if (f.x1) {
+                            const f32x4 xv = *reinterpret_cast<const f32x4*>(f.x1 + vox * f.x1_ldc + c0);
+                            const f32x4 gv = *reinterpret_cast<const f32x4*>(f.g + vox * f.g_ldc + c0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float z = __builtin_fmaf(xv[e], fsc[e], fsh[e]);
+                                const float dz = z > 0.f ? gv[e] : 0.f;
+                                const float xh = (xv[e] - fmu[e]) * fis[e];
+                                val[e] = fgi[e] * (dz - fc1[e] - xh * fc2[e]);
+                                if (ci == 0) bsum[e] += val[e];
+                            }
+                        } else {
+                            val = *reinterpret_cast<const f32x4*>(dy + vox * dy_ldc + c0);
+                        }
+                    }
                     *reinterpret_cast<f32x4*>(gs + v * 32 + 4 * qq) = val;
                 }
                 __syncthreads();
@@ -189,6 +221,20 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
                     if (co < Cout) part[(((size_t)blockIdx.x * T + t) * Cout + co) * Cin + ci] = acc[e];
                 }
         }
+        if (f.x1) {   // conv-bias gradient partial of this block: threads with equal (tid & 7) staged the same channel quad
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gs[tid * 4 + e] = bsum[e];
+            __syncthreads();
+            if (tid < 32 && pass * 32 + tid < Cout) {
+                const int qq = tid >> 2, e = tid & 3;
+                float sum = 0.f;
+                for (int m = 0; m < 32; ++m) sum += gs[(qq + 8 * m) * 4 + e];
+                f.biaspart[(size_t)blockIdx.x * Cout + pass * 32 + tid] = sum;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // ------------------------------------------------------------------ final 1x1x1 conv, forward (+ optional softmax)
@@ -346,7 +392,9 @@ int conv_small_wgrad_splits(int N, int D, int H, int W, int planar) {
 }
 
 int launch_conv_small_wgrad(const float* x, int Cin, const float* dy, int dy_ldc, float* part,
-                            int N, int D, int H, int W, int Cout, int planar, hipStream_t s) {
+                            int N, int D, int H, int W, int Cout, int planar, hipStream_t s, const SmallWgradFuse* fuse) {
+    SmallWgradFuse f{};
+    if (fuse) { f = *fuse; E3_REQUIRE(Cout % 4 == 0 && f.x1 && f.g && f.biaspart, E3_ERR_INVALID, "bad fused BN-backward arguments"); }
     E3_REQUIRE(Cin >= 1 && Cin < 8, E3_ERR_UNSUPPORTED, "direct conv handles 1..7 input channels");
     int TD, TH; small_brick(planar, TD, TH);
     const int tD = cdiv(D, TD), tH = cdiv(H, TH), tW = cdiv(W, 16);
@@ -355,8 +403,8 @@ int launch_conv_small_wgrad(const float* x, int Cin, const float* dy, int dy_ldc
     const int splits = cdiv(ntiles, tps);
     const int NV = (TD + (planar ? 0 : 2)) * (TH + 2) * 18;
     const size_t lds = (size_t)(((NV + 3) & ~3) + 256 * 32) * 4;
-    if (planar) hipLaunchKernelGGL((conv_small_wgrad_kernel<1, 1, 16>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps);
-    else hipLaunchKernelGGL((conv_small_wgrad_kernel<3, 2, 8>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps);
+    if (planar) hipLaunchKernelGGL((conv_small_wgrad_kernel<1, 1, 16>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
+    else hipLaunchKernelGGL((conv_small_wgrad_kernel<3, 2, 8>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

@@ -96,8 +96,10 @@ int conv_small_stats_parts(int N, int D, int H, int W, int planar);
 int launch_conv_small_fwd(ConvSmallArgs a, hipStream_t s);
 // dW partials for the first layer: part[split][T][CoPad=Cout][CiPad=Cin] ; returns number of splits used
 int conv_small_wgrad_splits(int N, int D, int H, int W, int planar);
+// optional fusion of the BN + ReLU backward (APPLY pass) of the conv's own output into the staging of dy; biaspart [splits][Cout]
+struct SmallWgradFuse { const float* x1; int x1_ldc; const float* g; int g_ldc; const float *scale, *shift, *mean, *invstd, *gamma, *coef; float* biaspart; };
 int launch_conv_small_wgrad(const float* x, int Cin, const float* dy, int dy_ldc, float* part,
-                            int N, int D, int H, int W, int Cout, int planar, hipStream_t s);
+                            int N, int D, int H, int W, int Cout, int planar, hipStream_t s, const SmallWgradFuse* fuse = nullptr);
 
 // final 1x1x1 conv: C (multiple of 4) -> Cout (<= 8); output and its gradient are NCDHW (the module boundary)
 int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y_ncdhw,

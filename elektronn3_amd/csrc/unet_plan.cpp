@@ -10,6 +10,7 @@
 //           into the first half (torch.cat, unet.py:398-399, never runs); pooled outputs; per-BN mean/invstd/
 //           scale/shift vectors.
 //   scratch packed weights, BN statistic records, gradient ping-pong buffers per level, split-K slabs.
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/e3unet.h"
@@ -107,6 +108,7 @@ struct Buffers {
     float* wpack; float* stats; float* bnpart; float* slab; float* small;   // small: coef / fold vectors
     float* bnred;                                                              // pre-merged BN statistic records
     float* ones; float* zeros;                                                 // [Cmax] / [2*Cmax] constants for units without a norm
+    float* biaspart0;                    // [splits][Cout] conv-bias gradient partials of the first conv when its BN backward is fused into its wgrad
     std::vector<float*> bnpart_u;        // per unit: block partials of the BN backward [parts][3][C]; row 2 (sum dx = conv-bias gradient) is summed for all units at once
     std::vector<float*> wpk_f, wpk_d;    // per unit: Winograd-transformed weights (forward / dgrad form), all packed by ONE launch; nullptr = packed on the spot into wpack
     std::vector<float*> g1, g2, dcat;    // gradient buffers per level
@@ -190,7 +192,10 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     B.bnred = T.take((size_t)BN_PRERED * p->chan(nb - 1) * 3);
     B.ones = T.take(p->chan(nb - 1)); B.zeros = T.take((size_t)2 * p->chan(nb - 1));
     B.bnpart_u.assign(p->units.size(), nullptr);
+    B.biaspart0 = nullptr;
     if (training) {
+        if (p->units[0].cin < 8)
+            B.biaspart0 = T.take((size_t)conv_small_wgrad_splits(N, L[0].D, L[0].H, L[0].W, p->units[0].planar) * p->units[0].cout);
         for (size_t k = 0; k < p->units.size(); ++k)
             B.bnpart_u[k] = T.take((size_t)bn_bwd_parts(L[p->units[k].level].vox, p->units[k].cout) * 3 * p->units[k].cout);
         B.bnpart = T.take(bnpartmax);
@@ -502,6 +507,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         }
         // -- BN + ReLU (+ pool, + skip) backward -> dxr = gradient w.r.t. the raw conv output
         float* dxr = B.g2[j];
+        bool fuse_first = false; SmallWgradFuse first_fuse{};
         {
             BnBwdArgs a{};
             a.x = b.raw; a.x_ldc = u.cout; a.mean = b.mean; a.invstd = b.invstd; a.scale = b.scale; a.shift = b.shift;
@@ -518,8 +524,16 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
                 RUN(launch_bn_bwd_reduce(a, s));
                 RUN(launch_bn_bwd_finalize(a.part, a.parts, u.cout, (float)(1.0 / (double)lo.vox), G(u.p_g), G(u.p_be), B.small, s));
             } else a.coef = B.zeros;
-            RUN(launch_bn_bwd_apply(a, s));
-            bias_jobs.push_back({a.part, a.parts, 3 * u.cout, 2 * u.cout, u.cout, G(u.p_b)});
+            // the first conv without a requested input gradient: dxr has a single consumer (its wgrad), which computes it on the fly
+            static const bool no_first_fuse = getenv("E3_NO_FIRST_FUSE") != nullptr;     // A/B switch
+            fuse_first = k == 0 && !dx && u.cin < 8 && !u.is_up && !no_first_fuse;
+            if (fuse_first) {
+                first_fuse = SmallWgradFuse{a.x, a.x_ldc, a.g1, a.g1_ldc, a.scale, a.shift, a.mean, a.invstd, a.gamma, a.coef, B.biaspart0};
+                bias_jobs.push_back({B.biaspart0, conv_small_wgrad_splits(N, lo.D, lo.H, lo.W, u.planar), u.cout, 0, u.cout, G(u.p_b)});
+            } else {
+                RUN(launch_bn_bwd_apply(a, s));
+                bias_jobs.push_back({a.part, a.parts, 3 * u.cout, 2 * u.cout, u.cout, G(u.p_b)});
+            }
         }
         // -- input activation of this conv
         const float* xin; int xin_ldc;
@@ -549,7 +563,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         } else if (u.cin < 8) {
             const int taps = u.planar ? 9 : 27;
             const int splits = conv_small_wgrad_splits(N, lo.D, lo.H, lo.W, u.planar);
-            { Prof pr(plan, s, k, 2); RUN(launch_conv_small_wgrad(xin, u.cin, dxr, u.cout, B.slab, N, lo.D, lo.H, lo.W, u.cout, u.planar, s)); }
+            { Prof pr(plan, s, k, 2); RUN(launch_conv_small_wgrad(xin, u.cin, dxr, u.cout, B.slab, N, lo.D, lo.H, lo.W, u.cout, u.planar, s, fuse_first ? &first_fuse : nullptr)); }
             RUN(launch_wgrad_reduce(B.slab, G(u.p_w), splits, taps, u.cout, u.cin, u.cout, u.cin, s));
         } else {
             const int taps = u.planar ? 9 : 27;

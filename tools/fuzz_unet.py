@@ -59,7 +59,12 @@ for case in range(n_cases):
         if (not prebn and err > worst): worst, wk = err, k
         if prebn and err > 1e-5: worst, wk = 1.0, k + ' (pre-BN bias not ~0)'
     e_rs = max([float((m.state_dict()[k] - sd_ref[k]).abs().max()) for k in sd0 if 'running' in k] or [0.0])
-    ok = e_out < 5e-5 and worst < (3e-2 if margin[0] < 2e-6 else 1e-4) and e_rs < 1e-5
+    # one flipped ReLU mask moves a per-channel sum over n voxels by ~1/sqrt(n): the loose bound follows the smallest level
+    n_bottom = N
+    for i, v in enumerate(shape):
+        n_bottom *= -(-v // (1 if (len(shape) == 3 and i == 0 and all(b in planar for b in range(nb - 1))) else mult))
+    loose = max(3e-2, 1.0 / n_bottom ** 0.5)
+    ok = e_out < 5e-5 and worst < (loose if margin[0] < 2e-6 else 1e-4) and e_rs < 1e-5
     bad += not ok
     print(f'{"ok  " if ok else "BAD "} nb={nb} sf={sf} in={inc} out={outc} planar={planar} {kw} N={N} {"x".join(map(str, shape))}: out {e_out:.1e} worst grad {worst:.1e} ({wk}) running {e_rs:.1e} relu margin {margin[0]:.0e}', flush=True)
 print('BAD CASES:', bad)
