@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void conv_final_bwd_kernel(const float* __rest
             for (int e = 0; e < 4; ++e) { o[e] = __builtin_fmaf(g, wv[co][e], o[e]); dwacc[co][e] = __builtin_fmaf(g, av[e], dwacc[co][e]); }
             if (q == 0) dbacc[co] += g;
         }
-        *reinterpret_cast<f32x4*>(da + v * da_ldc + 4 * q) = o;
+        if (da) *reinterpret_cast<f32x4*>(da + v * da_ldc + 4 * q) = o;     // da == nullptr: the consumer recomputes it (BnBwdArgs::head_dy)
     }
     // block reduce, one output row (co) at a time
     const int pstride = COUT * C + COUT;

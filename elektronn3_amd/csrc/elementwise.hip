@@ -221,7 +221,7 @@ __global__ void bn_relu_pool_kernel(const float* __restrict__ x, int x_ldc, cons
 // dA(v) = g1(v) + [v is the first arg-max of its pooling window] * gpool(window)
 // dz = dA * (z > 0),  z = x*scale + shift ;  xhat = (x - mean) * invstd
 // pass 1 (REDUCE): per-channel sum dz, sum dz*xhat.   pass 2 (APPLY): dx = gamma*invstd*(dz - c1 - xhat*c2), sum dx.
-template <bool POOL, bool APPLYPASS>
+template <bool POOL, bool APPLYPASS, bool HEAD = false>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
     __shared__ float red[3][256][4];
     const int Q = a.C >> 2;
@@ -263,7 +263,19 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                 ok[u] = v < units;
                 // streaming tensors larger than the 256 MB Infinity Cache: non-temporal loads (measured 5.2 -> 6.2 TB/s on the
                 // forward apply); smaller ones were just written by the previous kernel and still sit on-die
-                if (big) {
+                if (HEAD) {
+                    xv[u] = ok[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + v * a.x_ldc + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    g[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ok[u]) {
+                        const size_t n = v / a.head_S, sp = v - n * a.head_S;
+                        for (int co = 0; co < a.head_cout; ++co) {       // same fma order over co as conv_final_bwd_kernel
+                            const float gy = a.head_dy[(n * a.head_cout + co) * a.head_S + sp];
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(a.head_w + co * a.C + 4 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) g[u][e] = __builtin_fmaf(gy, wv[e], g[u][e]);
+                        }
+                    }
+                } else if (big) {
                     xv[u] = ok[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + v * a.x_ldc + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
                     g[u] = ok[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.g1 + v * a.g1_ldc + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
                 } else {
@@ -545,6 +557,10 @@ static int bn_bwd_launch(BnBwdArgs a, bool apply, hipStream_t s) {
     if (pool) {
         if (apply) hipLaunchKernelGGL((bn_bwd_kernel<true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((bn_bwd_kernel<true, false>), grid, block, 0, s, a);
+    } else if (a.g1 == nullptr) {
+        E3_REQUIRE(a.head_dy && a.head_w && a.head_cout > 0 && a.head_S > 0, E3_ERR_INVALID, "BN backward without an incoming gradient");
+        if (apply) hipLaunchKernelGGL((bn_bwd_kernel<false, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((bn_bwd_kernel<false, false, true>), grid, block, 0, s, a);
     } else {
         if (apply) hipLaunchKernelGGL((bn_bwd_kernel<false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((bn_bwd_kernel<false, false>), grid, block, 0, s, a);

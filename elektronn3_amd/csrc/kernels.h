@@ -189,6 +189,9 @@ struct BnBwdArgs {
     const float* coef;                    // apply pass: [2][C] = (sum dz / n, sum dz*xhat / n)
     float* dx; int dx_ldc;                // apply pass output
     size_t nt_bytes;                      // set by the launcher: tensors above this size are read with non-temporal loads
+    // non-pool path, g1 == nullptr: the incoming gradient is that of the 1x1x1 head, g[v][c] = sum_co head_dy[n][co][sp] * head_w[co][c],
+    // recomputed from the (tiny) NCDHW logits gradient instead of being written by conv_final_bwd and re-read twice
+    const float* head_dy; const float* head_w; int head_cout; size_t head_S;
 };
 int bn_bwd_parts(size_t voxels, int C);
 int launch_bn_bwd_reduce(BnBwdArgs a, hipStream_t s);

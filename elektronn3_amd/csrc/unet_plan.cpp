@@ -471,7 +471,9 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         const int ps = cfg.out_channels * C0 + cfg.out_channels;
         { Prof pr(plan, s, nunits, 1);
           const bool fused = plan->units.back().has_norm();
-          RUN(launch_conv_final_bwd(fused ? last.raw : last.act, fused ? C0 : last.act_ldc, C0, P(plan->p_final_w), dy, B.g1[0], C0, B.slab,
+          // the gradient w.r.t. the last activation is not written: the BN backward of the last unit recomputes it from dy and the head's
+          // weights (2 fma per element instead of one 4-byte write and two 4-byte reads)
+          RUN(launch_conv_final_bwd(fused ? last.raw : last.act, fused ? C0 : last.act_ldc, C0, P(plan->p_final_w), dy, nullptr, C0, B.slab,
                                     cfg.out_channels, L[0].vox / N, N, s, fused ? last.scale : nullptr, fused ? last.shift : nullptr)); }
         RUN(launch_colsum_finalize(B.slab, parts, ps, 0, cfg.out_channels * C0, G(plan->p_final_w), s));
         RUN(launch_colsum_finalize(B.slab, parts, ps, cfg.out_channels * C0, cfg.out_channels, G(plan->p_final_b), s));
@@ -516,7 +518,10 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
                      // x := a (mask z = 1*a + 0 > 0), mean 0, invstd 1, gamma 1, c1 = c2 = 0  =>  dx = dz, sum dx = conv-bias gradient
                 a.x = b.act; a.x_ldc = b.act_ldc; a.mean = B.zeros; a.invstd = B.ones; a.gamma = B.ones; a.scale = B.ones; a.shift = B.zeros;
             }
-            if (pooled_unit) { a.g1 = cfg.merge_add ? B.dcat[j] : B.dcat[j] + u.cout; a.g1_ldc = cfg.merge_add ? u.cout : 2 * u.cout; a.gpool = g; a.a = b.act; a.a_ldc = b.act_ldc; a.pooled = B.pooled[j]; }
+            if (k == nunits - 1) {      // incoming gradient = that of the 1x1x1 head, recomputed on the fly
+                a.g1 = nullptr; a.head_dy = dy; a.head_w = P(plan->p_final_w); a.head_cout = cfg.out_channels; a.head_S = L[0].vox / N;
+            }
+            else if (pooled_unit) { a.g1 = cfg.merge_add ? B.dcat[j] : B.dcat[j] + u.cout; a.g1_ldc = cfg.merge_add ? u.cout : 2 * u.cout; a.gpool = g; a.a = b.act; a.a_ldc = b.act_ldc; a.pooled = B.pooled[j]; }
             else { a.g1 = g; a.g1_ldc = g_ldc; }
             a.kd = kd; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.C = u.cout;
             a.parts = bn_bwd_parts(lo.vox, u.cout); a.part = B.bnpart_u[k]; a.coef = B.small; a.dx = dxr; a.dx_ldc = u.cout;
