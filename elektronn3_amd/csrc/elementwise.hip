@@ -267,7 +267,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                     xv[u] = ok[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + v * a.x_ldc + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
                     g[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (ok[u]) {
-                        const size_t n = v / a.head_S, sp = v - n * a.head_S;
+                        // (32-bit division when the voxel index allows it: the 64-bit one costs more than the rest of the item)
+                        const size_t n = units <= 0xffffffffull ? (size_t)((unsigned)v / (unsigned)a.head_S) : v / a.head_S;
+                        const size_t sp = v - n * a.head_S;
                         for (int co = 0; co < a.head_cout; ++co) {       // same fma order over co as conv_final_bwd_kernel
                             const float gy = a.head_dy[(n * a.head_cout + co) * a.head_S + sp];
                             const f32x4 wv = *reinterpret_cast<const f32x4*>(a.head_w + co * a.C + 4 * q);
