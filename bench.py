@@ -117,7 +117,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        # RCCL's kernels must get compute units while the (512-register, one-workgroup-per-CU) conv kernels of the backward own the
+        # chip: run the collectives on a high-priority stream so that they are dispatched first whenever a CU frees up
+        pg_opts = None
+        try:
+            pg_opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        except Exception:  # noqa: BLE001
+            pg_opts = None
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev, **({'pg_options': pg_opts} if pg_opts is not None else {}))
 
     from elektronn3_amd.unet import UNet
     from elektronn3_amd.loss import CombinedCEDiceLoss   # the example's criterion (0.5 CE + 0.5 Dice, class weights) on device

@@ -62,7 +62,7 @@ class GradSync:
         if self._event is None:
             self._event = torch.cuda.Event()
             self._event.record()          # forces creation of the underlying hipEvent_t
-            self._comm_stream = torch.cuda.Stream(device=self._flat.device)
+            self._comm_stream = torch.cuda.Stream(device=self._flat.device, priority=-1)   # collectives ahead of queued compute
         return ctypes.c_void_p(self._event.cuda_event)
 
     def after_backward(self, plan):
