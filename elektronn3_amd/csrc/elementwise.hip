@@ -145,6 +145,26 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
     shift[c] = (float)((beta ? (double)beta[c] : 0.0) + ((conv_bias ? (double)conv_bias[c] : 0.0) - (double)rm[c]) * s);
 }
 
+// every conv unit's epilogue constants in one launch (eval mode folds ~17 BatchNorms per forward; one 5-us launch each otherwise).
+// gamma == nullptr marks a unit without a norm (nn.Identity): scale = 1, shift = conv bias.
+struct FoldMultiArgs {
+    const float* gamma[FOLD_MAX_JOBS]; const float* beta[FOLD_MAX_JOBS]; const float* rm[FOLD_MAX_JOBS]; const float* rv[FOLD_MAX_JOBS];
+    const float* bias[FOLD_MAX_JOBS]; float* scale[FOLD_MAX_JOBS]; float* shift[FOLD_MAX_JOBS];
+    int C[FOLD_MAX_JOBS];
+    int n; float eps;
+};
+__global__ void bn_fold_multi_kernel(const FoldMultiArgs a) {
+    const int j = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.n || c >= a.C[j]) return;
+    const double bias = a.bias[j] ? (double)a.bias[j][c] : 0.0;
+    if (!a.gamma[j]) { a.scale[j][c] = 1.f; a.shift[j][c] = (float)bias; return; }
+    const double invstd = 1.0 / sqrt((double)a.rv[j][c] + (double)a.eps);          // same expressions as bn_fold_kernel
+    const double s = (double)a.gamma[j][c] * invstd;
+    a.scale[j][c] = (float)s;
+    a.shift[j][c] = (float)((double)a.beta[j][c] + (bias - (double)a.rm[j][c]) * s);
+}
+
 // ------------------------------------------------------------------ BN apply + ReLU (+ max-pool)
 __global__ void bn_relu_apply_kernel(const float* __restrict__ x, int x_ldc, const float* __restrict__ scale,
                                      const float* __restrict__ shift, float* __restrict__ a, int a_ldc,
@@ -513,6 +533,22 @@ int launch_bn_fold(const float* gamma, const float* beta, const float* rm, const
                    float eps, float* scale, float* shift, int C, hipStream_t s) {
     hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, gamma, beta, rm, rv, conv_bias, eps, scale, shift, C);
     E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_fold_multi(const FoldJob* jobs, int njobs, float eps, hipStream_t s) {
+    for (int j0 = 0; j0 < njobs; j0 += FOLD_MAX_JOBS) {
+        FoldMultiArgs a;
+        a.n = njobs - j0 < FOLD_MAX_JOBS ? njobs - j0 : FOLD_MAX_JOBS; a.eps = eps;
+        int cmax = 1;
+        for (int j = 0; j < a.n; ++j) {
+            const FoldJob& q = jobs[j0 + j];
+            a.gamma[j] = q.gamma; a.beta[j] = q.beta; a.rm[j] = q.rm; a.rv[j] = q.rv; a.bias[j] = q.bias; a.scale[j] = q.scale; a.shift[j] = q.shift; a.C[j] = q.C;
+            if (q.C > cmax) cmax = q.C;
+        }
+        hipLaunchKernelGGL(bn_fold_multi_kernel, dim3(cdiv(cmax, 256), a.n), dim3(256), 0, s, a);
+        E3_CHECK_HIP(hipGetLastError());
+    }
     return E3_OK;
 }
 

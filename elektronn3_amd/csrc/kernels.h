@@ -117,6 +117,9 @@ int launch_ce_dice_fwd(const float* logits, const long long* target, const float
 int launch_ce_dice_bwd(const float* logits, const long long* target, const float* w, int C, int N, size_t vps,
                        const float* workspace, const float* gout, float* dlogits, hipStream_t s);
 
+constexpr int FOLD_MAX_JOBS = 40;
+struct FoldJob { const float *gamma, *beta, *rm, *rv, *bias; float *scale, *shift; int C; };   // gamma == nullptr: no norm (scale 1, shift bias)
+int launch_fold_multi(const FoldJob* jobs, int njobs, float eps, hipStream_t s);   // eval-mode BN folds / bias folds of all conv units at once
 constexpr int COLSUM_MAX_JOBS = 40;
 struct ColsumJob { const float* part; int parts, stride, offset, C; float* out; };
 int launch_colsum_multi(const ColsumJob* jobs, int njobs, hipStream_t s);   // out[c] = sum_p part[p*stride + offset + c], many at once

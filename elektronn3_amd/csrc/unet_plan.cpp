@@ -357,6 +357,15 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             if (B.wpk_f[k]) jobs.push_back({P(plan->units[k].p_w), B.wpk_f[k], plan->units[k].cout, plan->units[k].cin, 0});
         if (!jobs.empty()) RUN(launch_wino_pack_multi(jobs.data(), (int)jobs.size(), s));
     }
+    {   // epilogue constants of every unit that has them (eval-mode BN fold; bias fold of units without a norm), in one launch
+        std::vector<FoldJob> jobs;
+        for (size_t k = 0; k < plan->units.size(); ++k) {
+            const ConvUnit& u = plan->units[k];
+            if (!u.has_norm()) jobs.push_back({nullptr, nullptr, nullptr, nullptr, P(u.p_b), B.ub[k].scale, B.ub[k].shift, u.cout});
+            else if (!training) jobs.push_back({P(u.p_g), P(u.p_be), P(u.p_rm), P(u.p_rv), P(u.p_b), B.ub[k].scale, B.ub[k].shift, u.cout});
+        }
+        if (!jobs.empty()) RUN(launch_fold_multi(jobs.data(), (int)jobs.size(), cfg.bn_eps, s));
+    }
     const float* cur = x; int cur_ldc = cfg.in_channels;
     if (cfg.in_channels > 1) { RUN(launch_ncdhw_to_ndhwc(x, B.xin, N, cfg.in_channels, L[0].vox / N, s)); cur = B.xin; }
 
@@ -371,12 +380,8 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         float* dst = bn_train ? b.raw : b.act;            // otherwise the conv writes the activation directly
         const int dst_ldc = bn_train ? u.cout : b.act_ldc;
         const float* es = nullptr; const float* eh = nullptr;
-        if (!u.has_norm()) {       // nn.Identity: y = relu(acc + bias), in training and in eval mode alike
-            RUN(launch_bias_fold(P(u.p_b), b.scale, b.shift, u.cout, s));
-            es = b.scale; eh = b.shift;
-        } else if (!training) {    // eval-mode BN folded into the conv epilogue (running stats), SURVEY 8a row a18
-            RUN(launch_bn_fold(P(u.p_g), P(u.p_be), P(u.p_rm), P(u.p_rv), P(u.p_b), cfg.bn_eps, b.scale, b.shift, u.cout, s));
-            es = b.scale; eh = b.shift;
+        if (!u.has_norm() || !training) {   // nn.Identity: y = relu(acc + bias) always; eval-mode BN folded into the conv epilogue
+            es = b.scale; eh = b.shift;     // (running stats) -- constants computed by the one launch above
         }
         int parts = 0;
         if (u.is_up) {
