@@ -20,6 +20,7 @@
 //     come straight from L2 into registers one chunk ahead (they are private to the wave, LDS would buy nothing).
 //   * epilogue: A^T m A over (ph, pw) in registers, over pd through LDS (each wave then owns one (oh, ow) of every
 //     tile), then bias / folded eval-BN + ReLU / per-brick Welford statistics / store as in the direct kernels.
+#include <type_traits>
 #include "kernels.h"
 
 namespace {
@@ -348,6 +349,316 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
     }
 }
 
+// ---- persistent variant: one workgroup per CU walks the bricks bid, bid + grid, ...; the input staging is software-pipelined ACROSS
+// bricks: the last chunk of a brick, whose "next chunk" slot is idle, fetches / D-transforms / stages the first chunk of the next
+// brick into the other LDS buffer, so a brick starts with its first chunk already in LDS (no exposed global-load latency, no
+// wasted re-staging).  Nothing but a few scalars lives across the epilogue, which has its own LDS region (130 KB in total).
+constexpr int W_PLDS_FLOATS = 2 * W_BUF + W_EX + 4 * 32 * 3;
+
+__global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, const unsigned nblk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, hf = lane >> 5;
+    // The arguments are re-read from the kernarg segment (scalar loads) wherever a brick needs them instead of living in ~40 SGPRs
+    // across the whole persistent loop (which made hipcc spill 200+ scalars into vector lanes).
+    typedef const __attribute__((address_space(4))) ConvArgs* KArgs;
+    auto KA = []() -> KArgs { KArgs q = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(q)); return q; };
+    const int NCH = a.Cin >> 3;
+    constexpr unsigned OOB = 0x80000000u;
+
+    // ---- lane constants that do not depend on the brick
+    const bool col_on = tid < W_LH * W_LW * 2;
+    const int cq = tid & 1, czw = (tid >> 1) % W_LW, czh = (tid >> 1) / W_LW;
+    const int a_dst = col_on ? plane_slot(czh, czw, cq) : 0;
+    float m1 = -1.f;
+    asm volatile("" : "+s"(m1));
+    const int ttd = j >> 4, tth = (j >> 3) & 1, ttw = j & 7;
+    const int lbase = (ttd * 4 + wave) * W_PLANE + (tth * 9 + ttw) * 8;
+    int rdA[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) rdA[hh] = lbase + 4 * (hf ^ ((tth + hh) & 1));
+    const int b_voff = lane * 16;
+
+    // ---- per-brick state.  Out: where the brick's results go (scalars).  Stage: where the staging slot reads from -- the current
+    // brick, or already the NEXT one during a brick's last chunk: a descriptor, per-d-plane scalar offsets / validity flags and ONE
+    // vector register (byte offset of the thread's halo column inside a d-plane, OOB outside H x W).
+    struct Out { int d0, h0, w0, nb, n0, ntile, mtile; };
+    struct Stage { __amdgpu_buffer_rsrc_t x_rs; unsigned col_off; unsigned dflag[W_AI]; unsigned dsoff[W_AI]; };
+    auto divmod = [](unsigned& x, int d) {
+        int r;
+        if ((d & (d - 1)) == 0) { r = (int)(x & (unsigned)(d - 1)); x >>= __builtin_ctz((unsigned)d); }
+        else { r = (int)(x % (unsigned)d); x /= (unsigned)d; }
+        return r;
+    };
+    auto make_out = [&](unsigned bid, Out& o) {
+        const KArgs k = KA();
+        unsigned L = xcd_remap(bid, nblk);
+        o.ntile = divmod(L, k->ntiles);
+        const int tw_ = divmod(L, k->tilesW);
+        const int th_ = divmod(L, k->tilesH);
+        const int td_ = divmod(L, k->tilesD); o.nb = (int)L;
+        o.d0 = td_ * 4; o.h0 = th_ * 4; o.w0 = tw_ * 16; o.n0 = o.ntile * 32;
+        o.mtile = ((o.nb * k->tilesD + td_) * k->tilesH + th_) * k->tilesW + tw_;
+    };
+    auto make_stage = [&](const Out& o, bool real, Stage& p) {
+        const KArgs k = KA();
+        const int D = k->D, H = k->H, W = k->W, xl = k->x_ldc;
+        const size_t plane_x = (size_t)H * W * xl;
+        const unsigned plane_xb = (unsigned)(plane_x * 4);
+        const int dlo = o.d0 > 0 ? o.d0 - 1 : 0;
+        const size_t xrem = (size_t)(D - dlo) * plane_x * 4;
+        p.x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(k->x) + ((size_t)o.nb * D + dlo) * plane_x, 0,
+                                                   (int)(xrem < 0x7fffffffu ? xrem : 0x7fffffffu), 0x00020000);
+        const int cgh = o.h0 + czh - 1, cgw = o.w0 + czw - 1;
+        const bool col_ok = real && col_on && cgh >= 0 && cgh < H && cgw >= 0 && cgw < W;
+        p.col_off = col_ok ? (unsigned)(((cgh * W + cgw) * xl + 4 * cq) * 4) : OOB;
+#pragma unroll
+        for (int zd = 0; zd < W_AI; ++zd) {
+            const int gd = o.d0 + zd - 1;
+            const bool ok = gd >= 0 && gd < D;
+            p.dflag[zd] = ok ? 0u : OOB;
+            p.dsoff[zd] = ok ? (unsigned)(gd - dlo) * plane_xb : 0u;
+        }
+    };
+
+    f32x16 acc[16];
+    f32x4 xr[W_AI], Bv[16];
+    Stage S;
+    auto issue_raw = [&](int cb) {
+#pragma unroll
+        for (int it = 0; it < W_AI; ++it)
+            xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(S.x_rs, S.col_off | S.dflag[it], (int)S.dsoff[it] + cb * 4, 0));
+    };
+    auto write_raw = [&](float* buf) {
+        if (col_on) {
+#pragma unroll
+            for (int td = 0; td < 2; ++td) {
+                const f32x4 x0 = xr[2 * td], x1 = xr[2 * td + 1], x2 = xr[2 * td + 2], x3 = xr[2 * td + 3];
+                *reinterpret_cast<f32x4*>(buf + (td * 4 + 0) * W_PLANE + a_dst) = x0 + m1 * x2;
+                *reinterpret_cast<f32x4*>(buf + (td * 4 + 1) * W_PLANE + a_dst) = x1 + x2;
+                *reinterpret_cast<f32x4*>(buf + (td * 4 + 2) * W_PLANE + a_dst) = x2 + m1 * x1;
+                *reinterpret_cast<f32x4*>(buf + (td * 4 + 3) * W_PLANE + a_dst) = x1 + m1 * x3;
+            }
+        }
+    };
+    __amdgpu_buffer_rsrc_t b_rs;
+    auto load_B = [&](int c, int g) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            Bv[g * 4 + p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_voff + p * 1024, (c * 64 + g * 4) * 1024, 0));
+    };
+
+    // one 8-channel chunk of the current brick: transformed halo in `cur`; the chunk staged meanwhile into `nxt` is channel
+    // offset cb_next of stage S (the same brick, or the first chunk of the next brick when this is the brick's last chunk).
+    // `cB` = chunk whose weights are fetched for the next iteration.
+    auto chunk = [&](auto zero_tag, const float* cur, float* nxt, int cb_next, int cB) {
+        constexpr bool ZERO = decltype(zero_tag)::value;
+        issue_raw(cb_next);
+        f32x4 t[4][4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int imm = (((h & 1) * 2 + (w & 1)) * W_CLASS + (h >> 1) * 9 + (w >> 1)) * 8;
+                t[h][w] = *reinterpret_cast<const f32x4*>(cur + rdA[h >> 1] + imm);
+            }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const f32x4 u0 = t[0][w] + m1 * t[2][w], u1 = t[1][w] + t[2][w], u2 = t[2][w] + m1 * t[1][w], u3 = t[1][w] + m1 * t[3][w];
+            t[0][w] = u0; t[1][w] = u1; t[2][w] = u2; t[3][w] = u3;
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const f32x4 u0 = t[h][0] + m1 * t[h][2], u1 = t[h][1] + t[h][2], u2 = t[h][2] + m1 * t[h][1], u3 = t[h][1] + m1 * t[h][3];
+            t[h][0] = u0; t[h][1] = u1; t[h][2] = u2; t[h][3] = u3;
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                f32x2 lo = {t[h][w][0], t[h][w][1]}, hi = {t[h][w][2], t[h][w][3]};
+                asm("" : "+v"(lo)); asm("" : "+v"(hi));
+                t[h][w][0] = lo[0]; t[h][w][1] = lo[1]; t[h][w][2] = hi[0]; t[h][w][3] = hi[1];
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (ZERO && s == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        acc[g * 4 + p] = __builtin_amdgcn_mfma_f32_32x32x2f32(t[g][p][s], Bv[g * 4 + p][s], z, 0, 0, 0);
+                    } else {
+                        acc[g * 4 + p] = __builtin_amdgcn_mfma_f32_32x32x2f32(t[g][p][s], Bv[g * 4 + p][s], acc[g * 4 + p], 0, 0, 0);
+                    }
+                }
+            load_B(cB, g);                            // (unconditional: a branch here makes hipcc drain every memory counter mid-MFMA)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        write_raw(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    };
+
+    float* cur = smem;
+    float* nxt = smem + W_BUF;
+    float* ex = smem + 2 * W_BUF;
+    float* scr = ex + W_EX;
+    unsigned bid = blockIdx.x;
+    Out P;
+    make_out(bid, P);
+    make_stage(P, true, S);
+    issue_raw(0);
+    write_raw(cur);
+    __syncthreads();
+    for (;;) {
+        const unsigned nbid = bid + gridDim.x;
+        const bool has_next = nbid < nblk;
+        b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(KA()->wt) + ((size_t)P.ntile * NCH * 64 + wave * 16) * 256, 0, NCH * 64 * 1024, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) load_B(0, g);
+        auto advance_stage = [&]() {                      // from here on the staging slot works for the NEXT brick (zeros if none)
+            Out on;
+            make_out(has_next ? nbid : bid, on);
+            make_stage(on, has_next, S);
+        };
+        // chunk 0 starts the accumulators from a literal zero; the brick's last chunk stages the next brick's first chunk
+        if (NCH == 1) advance_stage();
+        chunk(std::true_type{}, cur, nxt, NCH == 1 ? 0 : 8, NCH == 1 ? 0 : 1);
+        { float* tsw = cur; cur = nxt; nxt = tsw; }
+        for (int c = 1; c < NCH; ++c) {
+            const bool last = c + 1 == NCH;
+            if (last) advance_stage();
+            chunk(std::false_type{}, cur, nxt, last ? 0 : (c + 1) * 8, last ? 0 : c + 1);   // (last: a harmless re-fetch of chunk 0's weights)
+            { float* tsw = cur; cur = nxt; nxt = tsw; }
+        }
+
+        // ---- epilogue (as in conv3_wino_kernel, with its own LDS region)
+        const KArgs e = KA();
+        const int d0 = P.d0, h0 = P.h0, w0 = P.w0, n0 = P.n0;
+        const int eD = e->D, eH = e->H, eW = e->W, yl = e->y_ldc, eN = e->Ncols;
+        const size_t plane_y = (size_t)eH * eW * yl;
+        const size_t yrem = (size_t)(eD - d0) * plane_y * 4;
+        const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(
+            e->y + ((size_t)P.nb * eD + d0) * plane_y, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
+        f32x16 q[2][2];
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const f32x16 t0 = acc[ph * 4 + 0] + acc[ph * 4 + 1] + acc[ph * 4 + 2];
+            const f32x16 t1 = acc[ph * 4 + 1] + m1 * acc[ph * 4 + 2] + m1 * acc[ph * 4 + 3];
+            if (ph == 0) { q[0][0] = t0; q[0][1] = t1; }
+            else if (ph == 1) { q[0][0] += t0; q[0][1] += t1; q[1][0] = t0; q[1][1] = t1; }
+            else if (ph == 2) { q[0][0] += t0; q[0][1] += t1; q[1][0] += m1 * t0; q[1][1] += m1 * t1; }
+            else { q[1][0] += m1 * t0; q[1][1] += m1 * t1; }
+        }
+#pragma unroll
+        for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+            for (int ow = 0; ow < 2; ++ow)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = q[oh][ow][4 * k + e];
+                    *reinterpret_cast<f32x4*>(ex + ((wave * 16 + (oh * 2 + ow) * 4 + k) * 64 + lane) * 4) = v;
+                }
+        __syncthreads();
+        const int oh = wave >> 1, ow = wave & 1;
+        const int n = n0 + j;
+        const bool nvalid = n < eN;
+        const bool aff = e->epi_scale != nullptr;
+        const float bias = (e->bias && nvalid) ? e->bias[n] : 0.f;
+        float es = 1.f, eh = 0.f;
+        if (aff && nvalid) { es = e->epi_scale[n]; eh = e->epi_shift[n]; }
+        f32x4 y[2][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x4 m[4];
+#pragma unroll
+            for (int pd = 0; pd < 4; ++pd) m[pd] = *reinterpret_cast<const f32x4*>(ex + ((pd * 16 + wave * 4 + k) * 64 + lane) * 4);
+            y[0][k] = m[0] + m[1] + m[2] + bias;
+            y[1][k] = m[1] + m1 * m[2] + m1 * m[3] + bias;
+        }
+        if (aff) {
+#pragma unroll
+            for (int od = 0; od < 2; ++od)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[od][k][e] = fmaxf(__builtin_fmaf(y[od][k][e], es, eh), 0.f);
+        }
+        const int gw_l = w0 + 8 * hf + ow, gh_l = h0 + oh;
+        const unsigned y_voff = (unsigned)(((gh_l * eW + gw_l) * yl + n) * 4);
+        const bool full = d0 + 4 <= eD && h0 + 4 <= eH && w0 + 16 <= eW && n0 + 32 <= eN;
+        const bool do_stats = e->stats != nullptr;
+        float cnt = 0.f, sum = 0.f;
+        unsigned okmask = 0xffffffffu;
+        if (full) {
+#pragma unroll
+            for (int od = 0; od < 2; ++od)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int soff = ((((2 * (r >> 3) + od) * eH + 2 * ((r >> 2) & 1)) * eW + 2 * (r & 3)) * yl) * 4;
+                    const float v = y[od][r >> 2][r & 3];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, y_voff, soff, 0);
+                    sum += v;
+                }
+            cnt = 32.f;
+        } else {
+            okmask = 0u;
+#pragma unroll
+            for (int od = 0; od < 2; ++od)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gd = d0 + 2 * (r >> 3) + od, gh = gh_l + 2 * ((r >> 2) & 1), gw = gw_l + 2 * (r & 3);
+                    const bool ok = nvalid && gd < eD && gh < eH && gw < eW;
+                    const int soff = ((((2 * (r >> 3) + od) * eH + 2 * ((r >> 2) & 1)) * eW + 2 * (r & 3)) * yl) * 4;
+                    const float v = y[od][r >> 2][r & 3];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, ok ? y_voff : OOB, soff, 0);
+                    cnt += ok ? 1.f : 0.f;
+                    sum += ok ? v : 0.f;
+                    okmask |= (ok ? 1u : 0u) << (od * 16 + r);
+                }
+        }
+        if (do_stats) {
+            float mean = cnt > 0.f ? sum / cnt : 0.f, m2 = 0.f;
+#pragma unroll
+            for (int od = 0; od < 2; ++od)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = y[od][r >> 2][r & 3] - mean;
+                    m2 += ((okmask >> (od * 16 + r)) & 1u) ? d * d : 0.f;
+                }
+            const float cnt2 = __shfl_xor(cnt, 32), mean2 = __shfl_xor(mean, 32), m22 = __shfl_xor(m2, 32);
+            welford_merge(cnt, mean, m2, cnt2, mean2, m22);
+            if (hf == 0) {
+                float* sc = scr + (wave * 32 + j) * 3;
+                sc[0] = cnt; sc[1] = mean; sc[2] = m2;
+            }
+            __syncthreads();
+            if (tid < 32 && n < eN) {
+                float c0 = 0.f, me = 0.f, mm = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float* sc = scr + (w * 32 + tid) * 3;
+                    welford_merge(c0, me, mm, sc[0], sc[1], sc[2]);
+                }
+                float* o = e->stats + ((size_t)P.mtile * e->Cout + n) * 3;
+                o[0] = c0; o[1] = me; o[2] = mm;
+            }
+        }
+        if (!has_next) break;
+        bid = nbid;
+        make_out(bid, P);
+    }
+}
+
 // torch weights -> U[ntile][chunk][pos][hf][co32][4]:  U = (G (x) G (x) G) g, evaluated in double.
 //   dgrad == 0:  g[tap][n = co][k = ci] = w[co][ci][tap]           (w is (Cout, Cin, 27))
 //   dgrad == 1:  g[tap][n = ci][k = co] = w[co][ci][26 - tap]      (rows/cols swapped, taps flipped)
@@ -498,6 +809,18 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
         E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
+    }
+    // persistent variant (staging pipelined across bricks) where a CU gets several bricks: it hides the first-chunk load latency of
+    // every brick but the first (-5..10 % on the 32-/64-channel layers at full resolution); with one or two bricks per CU the plain
+    // kernel is as fast or 1-3 % faster.  E3_WINO_NO_PERSIST=1: A/B switch.
+    static const bool persist = getenv("E3_WINO_NO_PERSIST") == nullptr;
+    if (persist && nblk >= 1024 && !a.pro_scale && !(a.flags & 1024)) {
+        constexpr int plds = W_PLDS_FLOATS * 4;
+        static bool pattr = false;
+        if (!pattr) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel), hipFuncAttributeMaxDynamicSharedMemorySize, plds)); pattr = true; }
+        hipLaunchKernelGGL(conv3_wino_pkernel, dim3(256), dim3(256), plds, s, a, (unsigned)nblk);   // 256 = one workgroup per CU, a multiple of the 8 XCDs
+        E3_CHECK_HIP(hipGetLastError());
+        return E3_OK;
     }
     if (a.pro_scale) hipLaunchKernelGGL(conv3_wino_kernel<true>, dim3((unsigned)nblk), dim3(256), lds_bytes, s, a);
     else hipLaunchKernelGGL(conv3_wino_kernel<false>, dim3((unsigned)nblk), dim3(256), lds_bytes, s, a);
