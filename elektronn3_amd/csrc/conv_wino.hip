@@ -814,11 +814,13 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
     // every brick but the first (-5..10 % on the 32-/64-channel layers at full resolution); with one or two bricks per CU the plain
     // kernel is as fast or 1-3 % faster.  E3_WINO_NO_PERSIST=1: A/B switch.
     static const bool persist = getenv("E3_WINO_NO_PERSIST") == nullptr;
-    if (persist && nblk >= 1024 && !a.pro_scale && !(a.flags & 1024)) {
+    static const size_t pmin = getenv("E3_WINO_PERSIST_MIN") ? (size_t)atol(getenv("E3_WINO_PERSIST_MIN")) : 1024;   // (tests force 1: every shape)
+    if (persist && nblk >= pmin && !a.pro_scale && !(a.flags & 1024)) {
         constexpr int plds = W_PLDS_FLOATS * 4;
         static bool pattr = false;
         if (!pattr) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel), hipFuncAttributeMaxDynamicSharedMemorySize, plds)); pattr = true; }
-        hipLaunchKernelGGL(conv3_wino_pkernel, dim3(256), dim3(256), plds, s, a, (unsigned)nblk);   // 256 = one workgroup per CU, a multiple of the 8 XCDs
+        const unsigned pgrid = nblk >= 256 ? 256u : (unsigned)nblk;   // one workgroup per CU (256 is a multiple of the 8 XCDs; smaller grids run one brick each)
+        hipLaunchKernelGGL(conv3_wino_pkernel, dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk);
         E3_CHECK_HIP(hipGetLastError());
         return E3_OK;
     }
