@@ -211,8 +211,8 @@ def main():
                          'frac': ach / FP32_MFMA_PEAK_TFLOPS,
                          # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the gfx950
                          # correction + WRITE_SIZE, profiles/r01_pmc_wino.md); only known for the default layer/config
-                         'traffic': 1.20e9 if (args.profile_layer == 'up_convs.2.conv1' and ltaps == 27) else None,
-                         'kernel': f'conv3_wino_kernel (Winograd F(2x2x2,3x3x3), fp32 MFMA) fwd of {args.profile_layer} '
+                         'traffic': 1.30e9 if (args.profile_layer == 'up_convs.2.conv1' and ltaps == 27) else None,
+                         'kernel': f'conv3_wino_pkernel (persistent Winograd F(2x2x2,3x3x3), fp32 MFMA) fwd of {args.profile_layer} '
                                    f'({lcin}->{lcout}, {ltaps} taps, {lvox} voxels)' if ltaps == 27 else
                                    f'conv3_v3_kernel fwd of {args.profile_layer} ({lcin}->{lcout}, {ltaps} taps, {lvox} voxels)',
                          'mfma_executed': {'flops_per_launch': lflops * (64.0 / 216.0 if ltaps == 27 else 1.0),
