@@ -417,7 +417,7 @@ size_t grid_of(ConvKind kind, int ks, int nt, int N, int D, int H, int W, int nc
 // fills the chip (256 CUs x 2-3 resident workgroups); otherwise narrower column tiles, then intra-workgroup split-K.
 void conv_decomposition(ConvKind kind, int flags, int N, int D, int H, int W, int Cin, int ncols, int* ks, int* nt) {
     const int nt_max = ncols >= 64 ? 2 : 1;
-    const bool ks_ok = kind != CONV_POINT && flags == 0 && Cin >= 64;   // (callers with a BN prologue pass flags |= CF_NO_KSPLIT)
+    const bool ks_ok = kind != CONV_POINT && (flags & ~CF_NO_PERSIST) == 0 && Cin >= 64;   // (callers with a BN prologue pass flags |= CF_NO_KSPLIT)
     const int cand[4][2] = {{1, 2}, {1, 1}, {4, 2}, {4, 1}};
     int best_ks = 1, best_nt = nt_max; size_t best_grid = 0;
     for (const auto& c : cand) {

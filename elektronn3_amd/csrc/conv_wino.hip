@@ -815,7 +815,7 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
     // kernel is as fast or 1-3 % faster.  E3_WINO_NO_PERSIST=1: A/B switch.
     static const bool persist = getenv("E3_WINO_NO_PERSIST") == nullptr;
     static const size_t pmin = getenv("E3_WINO_PERSIST_MIN") ? (size_t)atol(getenv("E3_WINO_PERSIST_MIN")) : 1024;   // (tests force 1: every shape)
-    if (persist && nblk >= pmin && !a.pro_scale && !(a.flags & 1024)) {
+    if (persist && nblk >= pmin && !a.pro_scale && !(a.flags & (1024 | CF_NO_PERSIST))) {
         constexpr int plds = W_PLDS_FLOATS * 4;
         static bool pattr = false;
         if (!pattr) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel), hipFuncAttributeMaxDynamicSharedMemorySize, plds)); pattr = true; }

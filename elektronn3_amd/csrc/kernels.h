@@ -14,6 +14,8 @@ enum ConvFlags {
     CF_GATHER_UP = 2,   // POINT only: K runs over (tap, c); row p reads voxel 2p+tap            (ConvTranspose3d dgrad)
     CF_NO_KSPLIT = 4,   // keep the 256-voxel decomposition (required with a BN+ReLU prologue)
     CF_NO_WINO = 8,     // direct kernels only (set by callers that pass a BN+ReLU prologue)
+    CF_NO_PERSIST = 16, // one brick per workgroup even on large grids: a collective may hold CUs while this kernel runs, and a static
+                        // 256-workgroup kernel that does not get all 256 CUs at once needs a full second round
 };
 
 struct ConvArgs {

@@ -610,7 +610,8 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             ConvArgs a{};
             a.x = dxr; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = B.wpk_d[k] ? B.wpk_d[k] : B.wpack; a.y = out; a.y_ldc = out_ldc;
             a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.sd = 2;
-            a.Cout = u.cin; a.Ncols = u.cin; a.NPad = NPad; a.G = 1; a.flags = 0;
+            a.Cout = u.cin; a.Ncols = u.cin; a.NPad = NPad; a.G = 1;
+            a.flags = (bucket_event != nullptr && event_done) ? CF_NO_PERSIST : 0;   // the gradient all-reduce may be running on some CUs
             { Prof pr(plan, s, k, 1); RUN(launch_conv_mfma(kind, a, s)); }
             if (k == 0) { if (cfg.in_channels > 1) RUN(launch_ndhwc_to_ncdhw(B.g1[0], cfg.in_channels, dx, N, cfg.in_channels, L[0].vox / N, s)); }
             g = out; g_ldc = (to_cat && !cfg.merge_add) ? 2 * u.cout : u.cin;   // concat: the next unit (upconv) reads the first half, ldc = 2*C; add: d(up + skip) goes to both
