@@ -93,7 +93,7 @@ class _UNetFunction(torch.autograd.Function):
         in_dtype = x.dtype
         x32 = x.detach().to(torch.float32).contiguous()
         N, Cin, D, H, W = x32.shape
-        training = module.training
+        training = module.training or module.normalization == 'instance'   # instance statistics also in eval mode
         # parameters / buffers at call time, in the plan's table order
         tens = module._table(plan, params)
         if any(t.dtype != torch.float32 for t in tens):
@@ -188,6 +188,15 @@ _LAYERS = {3: (nn.Conv3d, nn.ConvTranspose3d, nn.MaxPool3d, nn.BatchNorm3d),
            2: (nn.Conv2d, nn.ConvTranspose2d, nn.MaxPool2d, nn.BatchNorm2d)}
 
 
+def _norm_factory(normalization, BatchNorm, dim, channels):
+    """get_normalization (unet.py:77-105) for the modes on the HIP path."""
+    if normalization == 'batch':
+        return lambda: BatchNorm(channels)
+    if normalization == 'instance':
+        return lambda: (nn.InstanceNorm3d if dim == 3 else nn.InstanceNorm2d)(channels)   # affine=False, no running statistics
+    return nn.Identity
+
+
 class DownConv(nn.Module):
     """Parameter container for one encoder block (two convs, two norms, max-pool) -- reference: unet.py:202-253."""
 
@@ -205,7 +214,7 @@ class DownConv(nn.Module):
         else:
             self.pool = nn.Identity()
         self.act1, self.act2 = nn.ReLU(), nn.ReLU()
-        norm = (lambda: Norm(out_channels)) if normalization == 'batch' else nn.Identity   # get_normalization, unet.py:77-105
+        norm = _norm_factory(normalization, Norm, dim, out_channels)                          # get_normalization, unet.py:77-105
         self.norm0 = norm() if full_norm else nn.Identity()                                   # unet.py:238-242
         self.norm1 = norm()
 
@@ -229,7 +238,7 @@ class UpConv(nn.Module):
         self.conv1 = Conv((2 if merge_mode == 'concat' else 1) * out_channels, out_channels, kernel_size=k, padding=p)   # unet.py:352-360
         self.conv2 = Conv(out_channels, out_channels, kernel_size=k, padding=p)
         self.act0, self.act1, self.act2 = nn.ReLU(), nn.ReLU(), nn.ReLU()
-        norm = (lambda: Norm(out_channels)) if normalization == 'batch' else nn.Identity
+        norm = _norm_factory(normalization, Norm, dim, out_channels)
         self.norm0 = norm() if full_norm else nn.Identity()                                   # unet.py:369-375
         self.norm1 = norm() if full_norm else nn.Identity()
         self.norm2 = norm()
@@ -243,7 +252,7 @@ class UNet(nn.Module):
     """3D U-Net with the reference's interface (elektronn3/models/unet.py:755-771), executed by hand-written HIP
     kernels.  Options of the reference that are not yet on the HIP path raise ``NotImplementedError`` at
     construction: ``up_mode != 'transpose'``,
-    ``attention=True``, ``activation != 'relu'``, ``normalization`` other than ``'batch'`` / ``'none'``,
+    ``attention=True``, ``activation != 'relu'``, ``normalization='group*'``,
     ``conv_mode != 'same'``.  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
     the 3D one with every block planar and a depth of 1."""
 
@@ -297,7 +306,7 @@ class UNet(nn.Module):
         if not (normalization in ('none', 'batch', 'instance') or (isinstance(normalization, str) and normalization.startswith('group'))):
             raise ValueError(f'Unknown normalization type "{normalization}".\nValid choices are "batch", "instance", "group" or "group<G>",'
                              'where <G> is the number of groups.')      # get_normalization, unet.py:106-111
-        if normalization not in ('batch', 'none'): unsupported.append(f'normalization={normalization!r}')
+        if normalization not in ('batch', 'none', 'instance'): unsupported.append(f'normalization={normalization!r}')
         if conv_mode != 'same': unsupported.append(f'conv_mode={conv_mode!r}')
         if start_filts % 8 != 0: unsupported.append(f'start_filts={start_filts} (must be a multiple of 8)')
         if not (1 <= out_channels <= 8): unsupported.append(f'out_channels={out_channels} (1..8)')
@@ -348,6 +357,7 @@ class UNet(nn.Module):
         # attachments (streams, events, process groups of a GradSync)
         state = self.__dict__.copy()
         state.pop('_grad_sync', None)
+        state.pop('_inst_consts', None)
         return state
 
     # ------------------------------------------------------------------ native plumbing
@@ -356,7 +366,7 @@ class UNet(nn.Module):
         for b in (range(self.n_blocks) if self.dim == 2 else self.planar_blocks):   # dim=2: every block is planar, depth 1
             mask |= 1 << int(b)
         eps = next((float(m.eps) for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)), 1e-5)
-        return (self.in_channels, self.out_channels, self.n_blocks, self.start_filts, mask, 1 if self.normalization == 'batch' else 0, eps,
+        return (self.in_channels, self.out_channels, self.n_blocks, self.start_filts, mask, 1 if self.normalization in ('batch', 'instance') else 0, eps,
                 1 if getattr(self, 'full_norm', True) else 0, 1 if self.merge_mode == 'add' else 0)
 
     def _plan(self):
@@ -364,8 +374,9 @@ class UNet(nn.Module):
 
     def _named_table_params(self, plan):
         """(name, Parameter) for the trainable entries of the plan table, in table order."""
+        inst = self.normalization == 'instance'
         for name, kind in zip(plan.names, plan.kinds):
-            if kind == 0:
+            if kind == 0 and not (inst and '.norm' in name):    # InstanceNorm has no affine parameters (gamma = 1, beta = 0 constants)
                 yield name, self.get_parameter(name)
 
     def _table(self, plan, params):
@@ -373,12 +384,26 @@ class UNet(nn.Module):
         the module (running statistics are read -- and updated -- in place at call time)."""
         it = iter(params)
         out = []
+        inst = self.normalization == 'instance'
         for name, kind in zip(plan.names, plan.kinds):
-            out.append(next(it).detach() if kind == 0 else self.get_buffer(name))
+            if inst and '.norm' in name:
+                # InstanceNorm = BatchNorm over a batch of one sample with gamma = 1, beta = 0 and throw-away running statistics
+                dev = params[0].device
+                C = self.get_submodule(name.rsplit('.', 1)[0]).num_features
+                key = (name.rsplit('.', 1)[1], C, dev)
+                consts = self.__dict__.setdefault('_inst_consts', {})
+                if key not in consts:
+                    fill = 1.0 if key[0] in ('weight', 'running_var') else 0.0
+                    consts[key] = torch.full((C,), fill, dtype=torch.float32, device=dev)
+                out.append(consts[key])
+            else:
+                out.append(next(it).detach() if kind == 0 else self.get_buffer(name))
         return out
 
     def _momenta(self, plan):
         moms = []
+        if self.normalization == 'instance':
+            return [0.0] * len(plan.bn_names)      # (running statistics are not tracked: nn.InstanceNorm3d defaults)
         for bn_name in plan.bn_names:
             bn = self.get_submodule(bn_name)
             if bn.momentum is None:   # cumulative moving average (torch semantics)
@@ -388,6 +413,8 @@ class UNet(nn.Module):
         return moms
 
     def _bump_num_batches_tracked(self, plan):
+        if self.normalization == 'instance':
+            return
         nbt = [self.get_submodule(n).num_batches_tracked for n in plan.bn_names]
         if nbt:
             torch._foreach_add_(nbt, 1)
@@ -411,7 +438,12 @@ class UNet(nn.Module):
         params = [p for _, p in self._named_table_params(plan)]
         if any(p.device != x.device for p in params):
             raise RuntimeError('input and parameters are on different devices')
-        y = _UNetFunction.apply(self, softmax, x, *params)
+        if self.normalization == 'instance':
+            # per-sample statistics in training AND eval mode (nn.InstanceNorm3d defaults): one native call per sample; autograd
+            # sums the parameter gradients of the calls
+            y = torch.cat([_UNetFunction.apply(self, softmax, x[n:n + 1], *params) for n in range(x.shape[0])], 0)
+        else:
+            y = _UNetFunction.apply(self, softmax, x, *params)
         return y.squeeze(2) if self.dim == 2 else y
 
     def forward_softmax(self, x):

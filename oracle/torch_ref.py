@@ -16,7 +16,9 @@ import torch.nn.functional as F
 
 
 def _bn(x, sd, name, training, momentum=0.1, eps=1e-5):
-    if name + '.weight' not in sd:      # nn.Identity: normalization='none' or full_norm=False (unet.py:77-80,238-242,369-375)
+    if name + '.weight' not in sd:      # no parameters: nn.Identity (normalization='none' / full_norm=False, unet.py:77-80,238-242,
+        if name in sd.get('__instance_norms__', ()):     # 369-375) or nn.InstanceNorm3d (affine=False, instance statistics always)
+            return F.instance_norm(x, eps=eps)
         return x
     return F.batch_norm(x, sd[name + '.running_mean'], sd[name + '.running_var'], sd[name + '.weight'], sd[name + '.bias'],
                         training=training, momentum=momentum, eps=eps)
@@ -38,6 +40,17 @@ def autocrop(from_down, from_up):
     us = from_up.shape[2:]
     from_down = from_down[(slice(None), slice(None)) + tuple(slice((d - u) // 2, (d + u) // 2) for d, u in zip(ds, us))]
     return from_down, from_up
+
+
+def instance_norm_names(n_blocks, full_norm=True):
+    """Names of the norm layers of UNet(normalization='instance') -- they have no state_dict entries; pass the result as
+    sd['__instance_norms__']."""
+    names = []
+    for i in range(n_blocks):
+        names += ([f'down_convs.{i}.norm0'] if full_norm else []) + [f'down_convs.{i}.norm1']
+    for i in range(n_blocks - 1):
+        names += ([f'up_convs.{i}.norm0', f'up_convs.{i}.norm1'] if full_norm else []) + [f'up_convs.{i}.norm2']
+    return tuple(names)
 
 
 def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True):

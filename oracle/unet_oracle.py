@@ -222,6 +222,7 @@ class OracleUNet:
         self.n_blocks = n_blocks
         self.planar = tuple(planar_blocks)
         self.norm = normalization
+        self.instance_norms = ()      # names of the nn.InstanceNorm layers (they have no state_dict entries), set by the caller
         self.momentum, self.eps = momentum, eps
         self.training = True
 
@@ -234,7 +235,18 @@ class OracleUNet:
 
     def _norm_act(self, name, x, cache):
         # a norm layer that is nn.Identity (normalization='none', or full_norm=False: unet.py:238-242,369-375) has no entries in the state_dict
-        if self.norm == 'batch' and (name + '.weight') in self.sd:
+        if self.norm == 'instance' and name in self.instance_norms:
+            # nn.InstanceNorm3d(C): affine=False, no running statistics, biased variance over (D,H,W) of each sample -- also in eval mode
+            # (get_normalization, unet.py:91-97) == the train-mode batch norm of every sample on its own with gamma = 1, beta = 0
+            C = x.shape[1]
+            ones, zeros = np.ones(C, np.float32), np.zeros(C, np.float32)
+            ys, stats = [], []
+            for n in range(x.shape[0]):
+                yn, mean, invstd = bn_train_fwd(x[n:n + 1], ones, zeros, zeros.copy(), ones.copy(), self.momentum, self.eps)
+                ys.append(yn); stats.append((mean, invstd))
+            y = np.concatenate(ys, 0)
+            cache[name] = (x, stats)
+        elif self.norm == 'batch' and (name + '.weight') in self.sd:
             g, b = self.sd[name + '.weight'], self.sd[name + '.bias']
             rm, rv = self.sd[name + '.running_mean'], self.sd[name + '.running_var']
             if self.training:
@@ -294,6 +306,10 @@ class OracleUNet:
     def _norm_act_bwd(self, name, da, cache, grads):
         a = cache[name + '.act']
         dy = relu_bwd(da, a)
+        if self.norm == 'instance' and name in self.instance_norms:
+            x, stats = cache[name]
+            ones = np.ones(x.shape[1], np.float32)
+            return np.concatenate([bn_train_bwd(dy[n:n + 1], x[n:n + 1], ones, *stats[n])[0] for n in range(x.shape[0])], 0)
         if self.norm == 'batch' and (name + '.weight') in self.sd:
             x, mean, invstd = cache[name]
             dx, dg, db = bn_train_bwd(dy, x, self.sd[name + '.weight'], mean, invstd)

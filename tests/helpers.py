@@ -35,7 +35,7 @@ def unet_cfg(npz):
     return cfg
 
 
-def is_prebn_bias(k, names=None):
+def is_prebn_bias(k, names=None, paramless_norms=()):
     """Bias of a (transposed) conv that feeds a train-mode BatchNorm: analytically zero gradient.  ``names`` (all parameter
     names) tells whether the norm after that conv exists at all (normalization='none' / full_norm=False make it nn.Identity)."""
     if not (k.endswith('.bias') and ('conv1' in k or 'conv2' in k or 'upconv' in k) and not k.startswith('conv_final')):
@@ -47,13 +47,26 @@ def is_prebn_bias(k, names=None):
         norm = {'conv1': 'norm0', 'conv2': 'norm1'}[conv]
     else:
         norm = {'upconv': 'norm0', 'conv1': 'norm1', 'conv2': 'norm2'}[conv]
-    return f'{block}.{norm}.weight' in names
+    return f'{block}.{norm}.weight' in names or f'{block}.{norm}' in paramless_norms      # (nn.InstanceNorm has no parameters)
 
 
 def embed_2d(sd):
     """A dim=2 state_dict as the equivalent dim=3 one: (Cout, Cin, kh, kw) conv / transposed-conv weights get a depth-1 kernel
     axis.  A 2D U-Net IS the 3D one with every block planar on a depth-1 volume (unet.py:47-74,114-128)."""
     return OrderedDict((k, v[:, :, None] if np.asarray(v).ndim == 4 else v) for k, v in sd.items())
+
+
+def instance_norm_names(cfg):
+    """Norm layers of a normalization='instance' model (no state_dict entries): every norm slot that full_norm leaves in place."""
+    if cfg.get('normalization') != 'instance':
+        return ()
+    nb, full = cfg['n_blocks'], cfg.get('full_norm', True)
+    names = []
+    for i in range(nb):
+        names += ([f'down_convs.{i}.norm0'] if full else []) + [f'down_convs.{i}.norm1']
+    for i in range(nb - 1):
+        names += ([f'up_convs.{i}.norm0', f'up_convs.{i}.norm1'] if full else []) + [f'up_convs.{i}.norm2']
+    return tuple(names)
 
 
 CLASS_WEIGHTS = (0.2653, 0.7347)

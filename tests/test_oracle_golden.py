@@ -9,7 +9,7 @@ reference's fp64 results, where it must be at least as close as the fp32 referen
 import numpy as np
 import pytest
 
-from helpers import combined_loss_np, embed_2d, is_prebn_bias, load_npz, rel_l2, sub, unet_cfg
+from helpers import combined_loss_np, embed_2d, instance_norm_names, is_prebn_bias, load_npz, rel_l2, sub, unet_cfg
 from oracle import unet_oracle as orc
 
 
@@ -70,7 +70,7 @@ def test_softmax(ops):
 
 
 CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz', 'unet2d_nb3_sf8_odd.npz',
-         'unet_nb2_sf8_nonorm.npz', 'unet_nb3_sf8_planar0_sparsenorm.npz', 'unet_nb3_sf8_add_odd.npz']
+         'unet_nb2_sf8_nonorm.npz', 'unet_nb3_sf8_planar0_sparsenorm.npz', 'unet_nb3_sf8_add_odd.npz', 'unet_nb3_sf8_instance.npz']
 
 
 @pytest.mark.parametrize('case', CASES)
@@ -81,7 +81,8 @@ def test_unet_train_step(case):
         net = orc.OracleUNet(embed_2d(sub(g, 'sd0')), cfg['n_blocks'], tuple(range(cfg['n_blocks'])))
         logits = net.forward(g['x'][:, :, None])[:, :, 0]
     else:
-        net = orc.OracleUNet(sub(g, 'sd0'), cfg['n_blocks'], cfg['planar_blocks'])
+        net = orc.OracleUNet(sub(g, 'sd0'), cfg['n_blocks'], cfg['planar_blocks'], normalization=cfg.get('normalization', 'batch'))
+        net.instance_norms = instance_norm_names(cfg)
         logits = net.forward(g['x'])
     # forward: fp32 reference noise floor is <= 4e-5 max-abs
     np.testing.assert_allclose(logits, g['logits'], rtol=1e-4, atol=1e-4)
@@ -105,7 +106,7 @@ def test_unet_train_step(case):
     assert set(grads) == set(ref32)
     gnorm = np.sqrt(sum(float(np.sum(v.astype(np.float64) ** 2)) for v in ref64.values()))
     for k in ref32:
-        if is_prebn_bias(k, set(ref32)):  # analytically zero gradient (bias feeding a train-mode BN): absolute tolerance only
+        if is_prebn_bias(k, set(ref32), instance_norm_names(cfg)):  # analytically zero gradient (bias feeding a train-mode BN): absolute tolerance only
             assert np.abs(grads[k]).max() <= 1e-5 * gnorm, k
             continue
         err_o = rel_l2(grads[k], ref64[k])

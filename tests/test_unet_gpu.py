@@ -15,12 +15,12 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import is_prebn_bias, load_npz, rel_l2, sub, unet_cfg
+from helpers import instance_norm_names, is_prebn_bias, load_npz, rel_l2, sub, unet_cfg
 
 pytestmark = pytest.mark.gpu
 
 CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz', 'unet2d_nb3_sf8_odd.npz',
-         'unet_nb2_sf8_nonorm.npz', 'unet_nb3_sf8_planar0_sparsenorm.npz', 'unet_nb3_sf8_add_odd.npz']
+         'unet_nb2_sf8_nonorm.npz', 'unet_nb3_sf8_planar0_sparsenorm.npz', 'unet_nb3_sf8_add_odd.npz', 'unet_nb3_sf8_instance.npz']
 
 
 def build(cfg, sd_np):
@@ -63,7 +63,7 @@ def test_train_step_matches_reference(case):
         errs = {}
         for k in ref32:
             assert gr[k].shape == ref32[k].shape, k
-            if is_prebn_bias(k, set(ref32)):    # analytically zero (bias feeding a train-mode BN): absolute tolerance only
+            if is_prebn_bias(k, set(ref32), instance_norm_names(cfg)):    # analytically zero (bias feeding a train-mode BN): absolute tolerance only
                 assert np.abs(gr[k]).max() <= 1e-5 * gnorm, (k, np.abs(gr[k]).max())
                 continue
             errs[k] = (rel_l2(gr[k], ref64[k]), rel_l2(ref32[k], ref64[k]))
@@ -239,16 +239,18 @@ def test_full_size_cfg4_anisotropic_against_pytorch_rocm():
 
 
 @pytest.mark.parametrize('kw', [dict(normalization='none'), dict(normalization='batch', full_norm=False, planar_blocks=(0,)),
-                                dict(merge_mode='add'), dict(merge_mode='add', normalization='none', planar_blocks=(0,))],
-                         ids=['nonorm', 'sparsenorm', 'add', 'add_nonorm_planar'])
+                                dict(merge_mode='add'), dict(merge_mode='add', normalization='none', planar_blocks=(0,)),
+                                dict(normalization='instance', planar_blocks=(0,))],
+                         ids=['nonorm', 'sparsenorm', 'add', 'add_nonorm_planar', 'instance'])
 def test_option_variants_against_pytorch_rocm(kw):
     """normalization='none' and full_norm=False (norm layers = nn.Identity, unet.py:77-80,238-242,369-375) at a size that runs the
     Winograd kernels (conv -> bias -> ReLU fused in their epilogue, also in training), and merge_mode='add' (unet.py:398-401: the skip
     connection is summed, conv1 has C input channels): forward, loss, all gradients (conv biases before an Identity have REAL
     gradients), running statistics, vs the fp64 ATen op sequence on PyTorch-ROCm."""
     from elektronn3_amd.unet import UNet
-    from oracle.torch_ref import combined_loss, unet_forward
+    from oracle.torch_ref import combined_loss, instance_norm_names as inorms, unet_forward
     torch.manual_seed(9)
+    paramless = inorms(3, kw.get('full_norm', True)) if kw.get('normalization') == 'instance' else ()
     m = UNet(in_channels=1, out_channels=2, n_blocks=3, start_filts=32, **kw).cuda().train()
     with torch.no_grad():
         for k, p in m.named_parameters():
@@ -264,6 +266,7 @@ def test_option_variants_against_pytorch_rocm(kw):
     sd_ref = {k: (v.double() if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k)
               for k, v in sd0.items()}
     pl = tuple(kw.get('planar_blocks', ()))
+    sd_ref['__instance_norms__'] = paramless
     ref = unet_forward(sd_ref, x.double(), 3, pl, training=True)
     lref = combined_loss(ref, t)
     lref.backward()
@@ -277,18 +280,22 @@ def test_option_variants_against_pytorch_rocm(kw):
     n_real_bias = 0
     for k, p in m.named_parameters():
         gr = sd_ref[k].grad
-        if is_prebn_bias(k, names):
+        if is_prebn_bias(k, names, paramless):
             assert float(p.grad.abs().max()) <= 1e-5 * float(gn), k
             continue
         n_real_bias += k.endswith('.bias') and 'conv' in k and not k.startswith('conv_final')
         err = float((p.grad.double() - gr).norm() / gr.norm().clamp_min(1e-30))
         assert err < 1e-2, (k, err)
-    assert n_real_bias >= 3 or kw.get('normalization', 'batch') == 'batch' and kw.get('full_norm', True)
+    assert n_real_bias >= 3 or kw.get('normalization', 'batch') in ('batch', 'instance') and kw.get('full_norm', True)
     m.eval()
     with torch.no_grad():
         ye = m(x)
     sd_e = {k: v.double() if v.is_floating_point() else v for k, v in m.state_dict().items()}
+    sd_e['__instance_norms__'] = paramless
     assert torch.allclose(ye.double(), unet_forward(sd_e, x.double(), 3, pl, training=False), rtol=1e-4, atol=1e-4)
+    if paramless:       # instance statistics in eval mode too: eval output == train output, and a batch equals its samples one by one
+        assert torch.equal(ye, out.detach())
+        assert torch.equal(m(x[1:2]), ye[1:2])
 
 
 def test_dim2_unet_against_pytorch_rocm():
