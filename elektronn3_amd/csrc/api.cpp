@@ -184,7 +184,7 @@ int e3_maxpool(void* stream, const float* a, int a_ldc, float* pooled, int kd, i
 
 size_t e3_bn_bwd_workspace_bytes(int N, int D, int H, int W, int C) {
     const int parts = bn_bwd_parts((size_t)N * D * H * W, C);
-    return align_up(((size_t)parts * 3 * C + 2 * C) * sizeof(float), 256);
+    return align_up(((size_t)parts * 3 * C + 4 * C) * sizeof(float), 256);
 }
 
 int e3_bn_relu_bwd(void* stream, const float* x, int x_ldc, const float* mean, const float* invstd, const float* gamma,

@@ -104,17 +104,22 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const BnFinalizeArgs 
         __syncthreads();
         x = bc[0]; y = bc[1];
     };
+    // group = 1: BatchNorm (statistics of channel c).  group > 1: GroupNorm -- the records of all `group` channels of c's group are
+    // merged (nn.GroupNorm normalises over (C/G, D, H, W) of one sample; the caller passes one sample's records)
+    const int gs = a.group > 1 ? a.group : 1;
+    const int c_first = (c / gs) * gs;
+    const int items = a.parts * gs;
     double n = 0.0, s1 = 0.0;
-    for (int p = threadIdx.x; p < a.parts; p += 1024) {
-        const float* r = a.stats + ((size_t)p * a.C + c) * 3;
+    for (int i = threadIdx.x; i < items; i += 1024) {
+        const float* r = a.stats + ((size_t)(i / gs) * a.C + c_first + i % gs) * 3;
         const double nb = r[0];
         n += nb; s1 += nb * (double)r[1];
     }
     block_sum2(n, s1);
     const double mean = n > 0.0 ? s1 / n : 0.0;
     double m2 = 0.0, unused = 0.0;
-    for (int p = threadIdx.x; p < a.parts; p += 1024) {
-        const float* r = a.stats + ((size_t)p * a.C + c) * 3;
+    for (int i = threadIdx.x; i < items; i += 1024) {
+        const float* r = a.stats + ((size_t)(i / gs) * a.C + c_first + i % gs) * 3;
         const double nb = r[0], d = (double)r[1] - mean;
         m2 += nb > 0.0 ? (double)r[2] + nb * d * d : 0.0;
     }
@@ -265,10 +270,12 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
         const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + 4 * q);
         const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + 4 * q);
         const f32x4 is = *reinterpret_cast<const f32x4*>(a.invstd + 4 * q);
-        f32x4 c1 = s1, c2 = s1, gi = s1;
+        f32x4 c1 = s1, c2 = s1, gi = s1, k1 = s1, k2 = s1;
         if (APPLYPASS) {
             c1 = *reinterpret_cast<const f32x4*>(a.coef + 4 * q);
             c2 = *reinterpret_cast<const f32x4*>(a.coef + a.C + 4 * q);
+            k1 = *reinterpret_cast<const f32x4*>(a.coef + 2 * a.C + 4 * q);     // GroupNorm: group-mean terms that do not carry the
+            k2 = *reinterpret_cast<const f32x4*>(a.coef + 3 * a.C + 4 * q);     // channel's gamma (zero for BatchNorm: x - 0 is exact)
             const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + 4 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) gi[e] = gm[e] * is[e];
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                     const float z = __builtin_fmaf(xv[u][e], sc[e], sh[e]);   // same expression as the forward apply
                     const float dz = z > 0.f ? g[u][e] : 0.f;
                     const float xh = (xv[u][e] - mu[e]) * is[e];
-                    if (APPLYPASS) { o[e] = ok[u] ? gi[e] * (dz - c1[e] - xh * c2[e]) : 0.f; s3[e] += o[e]; }
+                    if (APPLYPASS) { o[e] = ok[u] ? gi[e] * (dz - c1[e] - xh * c2[e]) - (k1[e] + xh * k2[e]) : 0.f; s3[e] += o[e]; }
                     else { s1[e] += dz; s2[e] += dz * xh; }
                 }
                 if (APPLYPASS && ok[u]) *reinterpret_cast<f32x4*>(a.dx + (v0 + u * vstride) * a.dx_ldc + 4 * q) = o;
@@ -326,10 +333,12 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
         const f32x4 is = *reinterpret_cast<const f32x4*>(a.invstd + 4 * q);
         const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + 4 * q);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + 4 * q);
-        f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = c1, gi = c1;
+        f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = c1, gi = c1, k1 = c1, k2 = c1;
         if (APPLYPASS) {
             c1 = *reinterpret_cast<const f32x4*>(a.coef + 4 * q);
             c2 = *reinterpret_cast<const f32x4*>(a.coef + a.C + 4 * q);
+            k1 = *reinterpret_cast<const f32x4*>(a.coef + 2 * a.C + 4 * q);
+            k2 = *reinterpret_cast<const f32x4*>(a.coef + 3 * a.C + 4 * q);
             const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + 4 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) gi[e] = gm[e] * is[e];
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                             if (!taken[e] && av[e] == pm[e]) { dA += gp[e]; taken[e] = true; }   // first arg-max wins (ATen)
                             const float dz = av[e] > 0.f ? dA : 0.f;
                             const float xh = (xv[e] - mu[e]) * is[e];
-                            if (APPLYPASS) { o[e] = gi[e] * (dz - c1[e] - xh * c2[e]); s3[e] += o[e]; }
+                            if (APPLYPASS) { o[e] = gi[e] * (dz - c1[e] - xh * c2[e]) - (k1[e] + xh * k2[e]); s3[e] += o[e]; }
                             else { s1[e] += dz; s2[e] += dz * xh; }
                         }
                         if (APPLYPASS) *reinterpret_cast<f32x4*>(a.dx + v * a.dx_ldc + 4 * q) = o;
@@ -413,7 +422,25 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
         if (dgamma) dgamma[c] = (float)s2;
         coef[c] = (float)(s1 * inv_n);
         coef[C + c] = (float)(s2 * inv_n);
+        coef[2 * C + c] = 0.f;
+        coef[3 * C + c] = 0.f;
     }
+}
+
+// GroupNorm backward coefficients (after bn_bwd_finalize wrote dbeta = sum dz, dgamma = sum dz*xhat per channel):
+//   dx_c = invstd_g * [ gamma_c dz - mean_g(gamma dz) - xhat mean_g(gamma dz xhat) ]   (means over the group's channels and voxels)
+// in the apply pass' form  gi*(dz - c1 - xhat*c2) - (k1 + xhat*k2):  c1 = c2 = 0,  k1 = invstd_g * sum_{c' in g} gamma_c' dbeta_c' * inv_n / gs.
+__global__ void gn_bwd_coef_kernel(const float* __restrict__ dgamma, const float* __restrict__ dbeta, const float* __restrict__ gamma,
+                                   const float* __restrict__ invstd, int C, int gs, float inv_n, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int c0 = (c / gs) * gs;
+    double m1 = 0.0, m2 = 0.0;
+    for (int k = 0; k < gs; ++k) { m1 += (double)gamma[c0 + k] * (double)dbeta[c0 + k]; m2 += (double)gamma[c0 + k] * (double)dgamma[c0 + k]; }
+    const double f = (double)invstd[c] * (double)inv_n / (double)gs;
+    coef[c] = 0.f; coef[C + c] = 0.f;
+    coef[2 * C + c] = (float)(m1 * f);
+    coef[3 * C + c] = (float)(m2 * f);
 }
 
 __global__ void colsum_finalize_kernel(const float* __restrict__ part, int parts, int part_stride, int offset, int C, float* out) {
@@ -611,6 +638,14 @@ int launch_bn_bwd_apply(BnBwdArgs a, hipStream_t s) { return bn_bwd_launch(a, tr
 
 int launch_bn_bwd_finalize(const float* part, int parts, int C, float inv_n, float* dgamma, float* dbeta, float* coef, hipStream_t s) {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, part, parts, C, inv_n, dgamma, dbeta, coef);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_gn_bwd_coef(const float* dgamma, const float* dbeta, const float* gamma, const float* invstd, int C, int group, float inv_n,
+                       float* coef, hipStream_t s) {
+    E3_REQUIRE(group >= 1 && C % group == 0, E3_ERR_INVALID, "group size must divide the channel count");
+    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, dgamma, dbeta, gamma, invstd, C, group, inv_n, coef);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

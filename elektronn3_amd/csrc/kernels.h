@@ -125,6 +125,8 @@ int launch_fold_multi(const FoldJob* jobs, int njobs, float eps, hipStream_t s);
 constexpr int COLSUM_MAX_JOBS = 40;
 struct ColsumJob { const float* part; int parts, stride, offset, C; float* out; };
 int launch_colsum_multi(const ColsumJob* jobs, int njobs, hipStream_t s);   // out[c] = sum_p part[p*stride + offset + c], many at once
+int launch_gn_bwd_coef(const float* dgamma, const float* dbeta, const float* gamma, const float* invstd, int C, int group, float inv_n,
+                       float* coef, hipStream_t s);   // GroupNorm: rewrites coef after launch_bn_bwd_finalize
 int launch_fill(float* p, float v, size_t n, hipStream_t s);
 int launch_add_views(const float* a, int a_ldc, const float* b, int b_ldc, float* out, int out_ldc, size_t vox, int C, hipStream_t s);   // out = a + b
 int launch_bias_fold(const float* conv_bias, float* scale, float* shift, int C, hipStream_t s);   // scale = 1, shift = bias
@@ -167,6 +169,7 @@ struct BnFinalizeArgs {
     float momentum; float eps;
     float* mean; float* invstd; float* scale; float* shift;   // each [C]
     float* scratch;                           // optional: BN_PRERED * C * 3 floats; many records are first merged into BN_PRERED coalesced partials
+    int group;                                // 0/1: statistics per channel (BatchNorm); > 1: merged over groups of `group` consecutive channels (GroupNorm)
 };
 constexpr int BN_PRERED = 64;
 int launch_bn_finalize(BnFinalizeArgs a, hipStream_t s);
@@ -191,7 +194,7 @@ struct BnBwdArgs {
     int N, D, H, W, C;
     float* part;                          // [parts][3][C]: sum dz, sum dz*xhat, (apply pass) sum dx
     int parts;
-    const float* coef;                    // apply pass: [2][C] = (sum dz / n, sum dz*xhat / n)
+    const float* coef;                    // apply pass: [4][C] = (c1 = sum dz / n, c2 = sum dz*xhat / n, k1, k2): dx = g*istd*(dz - c1 - xh*c2) - (k1 + xh*k2)
     float* dx; int dx_ldc;                // apply pass output
     size_t nt_bytes;                      // set by the launcher: tensors above this size are read with non-temporal loads
     // non-pool path, g1 == nullptr: the incoming gradient is that of the 1x1x1 head, g[v][c] = sum_co head_dy[n][co][sp] * head_w[co][c],

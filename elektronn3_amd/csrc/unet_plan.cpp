@@ -68,6 +68,7 @@ int add_param(e3_unet_plan* p, const std::string& name, int64_t numel, int kind)
 }
 
 void add_unit(e3_unet_plan* p, const std::string& conv, const std::string& bn, int cin, int cout, int level, int planar, int is_up, bool norm) {
+    const bool group = p->cfg.normalization == 2;    // nn.GroupNorm: weight and bias only, no running statistics
     ConvUnit u;
     u.name = conv; u.bn_name = bn; u.cin = cin; u.cout = cout; u.level = level; u.planar = planar; u.is_up = is_up;
     const int taps = is_up ? (planar ? 4 : 8) : (planar ? 9 : 27);
@@ -77,8 +78,10 @@ void add_unit(e3_unet_plan* p, const std::string& conv, const std::string& bn, i
     if (norm) {
         u.p_g = add_param(p, bn + ".weight", cout, 0);
         u.p_be = add_param(p, bn + ".bias", cout, 0);
-        u.p_rm = add_param(p, bn + ".running_mean", cout, 1);
-        u.p_rv = add_param(p, bn + ".running_var", cout, 1);
+        if (!group) {
+            u.p_rm = add_param(p, bn + ".running_mean", cout, 1);
+            u.p_rv = add_param(p, bn + ".running_var", cout, 1);
+        }
         u.bn_index = p->n_bn++;
     }
     p->units.push_back(u);
@@ -190,7 +193,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     B.stats = T.take(statmax);
     B.small = T.take((size_t)4 * p->chan(nb - 1) + 64);
     B.bnred = T.take((size_t)BN_PRERED * p->chan(nb - 1) * 3);
-    B.ones = T.take(p->chan(nb - 1)); B.zeros = T.take((size_t)2 * p->chan(nb - 1));
+    B.ones = T.take(p->chan(nb - 1)); B.zeros = T.take((size_t)4 * p->chan(nb - 1));
     B.bnpart_u.assign(p->units.size(), nullptr);
     B.biaspart0 = nullptr;
     if (training) {
@@ -241,8 +244,10 @@ int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
     E3_REQUIRE(cfg->out_channels >= 1 && cfg->out_channels <= 8, E3_ERR_UNSUPPORTED, "out_channels must be in 1..8 on the HIP path");
     E3_REQUIRE(cfg->start_filts >= 8 && cfg->start_filts % 8 == 0, E3_ERR_UNSUPPORTED, "start_filts must be a multiple of 8 on the HIP path");
     E3_REQUIRE((cfg->start_filts << (cfg->n_blocks - 1)) <= 1024, E3_ERR_UNSUPPORTED, "more than 1024 channels at the bottom level");
-    E3_REQUIRE(cfg->normalization == 1 || cfg->normalization == 0, E3_ERR_UNSUPPORTED, "only normalization='batch' and 'none' are implemented on the HIP path");
-    const bool last_norm = cfg->normalization == 1, all_norm = last_norm && cfg->full_norm != 0;
+    E3_REQUIRE(cfg->normalization >= 0 && cfg->normalization <= 2, E3_ERR_UNSUPPORTED, "normalization must be 0 (none), 1 (batch) or 2 (group)");
+    if (cfg->normalization == 2)
+        E3_REQUIRE(cfg->num_groups >= 1 && cfg->start_filts % cfg->num_groups == 0, E3_ERR_INVALID, "num_groups must divide every channel count");
+    const bool last_norm = cfg->normalization != 0, all_norm = last_norm && cfg->full_norm != 0;
     e3_unet_plan* p = new e3_unet_plan();
     p->cfg = *cfg;
     p->n_bn = 0;
@@ -344,6 +349,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
     const e3_unet_cfg& cfg = plan->cfg;
     const int nb = cfg.n_blocks;
     E3_REQUIRE(!training || (saved && momenta), E3_ERR_INVALID, "training forward needs `saved` and `momenta`");
+    E3_REQUIRE(training || cfg.normalization != 2, E3_ERR_INVALID, "GroupNorm has no running statistics: pass E3_FWD_TRAINING also for inference");
     Buffers B;
     plan_buffers(plan, N, D, H, W, training, saved, scratch, B);
     E3_REQUIRE(!training || saved_bytes >= B.saved_bytes, E3_ERR_WORKSPACE, "`saved` buffer too small");
@@ -419,7 +425,11 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         if (bn_train) {
             BnFinalizeArgs f{};
             f.stats = B.stats; f.parts = parts; f.C = u.cout; f.gamma = P(u.p_g); f.beta = P(u.p_be);
-            f.running_mean = P(u.p_rm); f.running_var = P(u.p_rv); f.momentum = momenta[u.bn_index]; f.eps = cfg.bn_eps;
+            const bool group = cfg.normalization == 2;
+            if (group) E3_REQUIRE(N == 1, E3_ERR_INVALID, "GroupNorm statistics are per sample: call with N = 1");
+            f.group = group ? u.cout / cfg.num_groups : 1;
+            f.running_mean = group ? nullptr : P(u.p_rm); f.running_var = group ? nullptr : P(u.p_rv);
+            f.momentum = momenta[u.bn_index]; f.eps = cfg.bn_eps;
             f.mean = b.mean; f.invstd = b.invstd; f.scale = b.scale; f.shift = b.shift; f.scratch = B.bnred;
             RUN(launch_bn_finalize(f, s));
             // the last activation of the network only feeds the 1x1x1 head, which applies BN + ReLU while loading the raw tensor
@@ -491,7 +501,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         if (!jobs.empty()) RUN(launch_wino_pack_multi(jobs.data(), (int)jobs.size(), s));
     }
     RUN(launch_fill(B.ones, 1.f, (size_t)plan->chan(nb - 1), s));
-    RUN(launch_fill(B.zeros, 0.f, (size_t)2 * plan->chan(nb - 1), s));
+    RUN(launch_fill(B.zeros, 0.f, (size_t)4 * plan->chan(nb - 1), s));
     // ---- walk the units backwards.  `g` = gradient w.r.t. the current unit's activation.
     const float* g = B.g1[0]; int g_ldc = C0;
     bool event_done = bucket_event == nullptr;
@@ -533,10 +543,12 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             if (u.has_norm()) {
                 RUN(launch_bn_bwd_reduce(a, s));
                 RUN(launch_bn_bwd_finalize(a.part, a.parts, u.cout, (float)(1.0 / (double)lo.vox), G(u.p_g), G(u.p_be), B.small, s));
+                if (cfg.normalization == 2)
+                    RUN(launch_gn_bwd_coef(G(u.p_g), G(u.p_be), P(u.p_g), b.invstd, u.cout, u.cout / cfg.num_groups, (float)(1.0 / (double)lo.vox), B.small, s));
             } else a.coef = B.zeros;
             // the first conv without a requested input gradient: dxr has a single consumer (its wgrad), which computes it on the fly
             static const bool no_first_fuse = getenv("E3_NO_FIRST_FUSE") != nullptr;     // A/B switch
-            fuse_first = k == 0 && !dx && u.cin < 8 && !u.is_up && !no_first_fuse;
+            fuse_first = k == 0 && !dx && u.cin < 8 && !u.is_up && !no_first_fuse && cfg.normalization != 2;   // (the fused staging has no group terms)
             if (fuse_first) {
                 first_fuse = SmallWgradFuse{a.x, a.x_ldc, a.g1, a.g1_ldc, a.scale, a.shift, a.mean, a.invstd, a.gamma, a.coef, B.biaspart0};
                 bias_jobs.push_back({B.biaspart0, conv_small_wgrad_splits(N, lo.D, lo.H, lo.W, u.planar), u.cout, 0, u.cout, G(u.p_b)});

@@ -42,7 +42,7 @@ class _Plan:
             check(lib.e3_unet_param_info(handle, i, buf, 160, ctypes.byref(numel), ctypes.byref(kind)))
             self.names.append(buf.value.decode())
             self.kinds.append(kind.value)
-        self.bn_names = [n[:-len('.running_mean')] for n in self.names if n.endswith('.running_mean')]
+        self.bn_names = [n[:-len('.weight')] for n in self.names if '.norm' in n and n.endswith('.weight')]
         self.n_bn = lib.e3_unet_bn_count(handle)
         assert self.n_bn == len(self.bn_names)
         self.conv_names = []
@@ -93,7 +93,7 @@ class _UNetFunction(torch.autograd.Function):
         in_dtype = x.dtype
         x32 = x.detach().to(torch.float32).contiguous()
         N, Cin, D, H, W = x32.shape
-        training = module.training or module.normalization == 'instance'   # instance statistics also in eval mode
+        training = module.training or module._per_sample_norm()   # instance / group statistics also in eval mode
         # parameters / buffers at call time, in the plan's table order
         tens = module._table(plan, params)
         if any(t.dtype != torch.float32 for t in tens):
@@ -194,7 +194,18 @@ def _norm_factory(normalization, BatchNorm, dim, channels):
         return lambda: BatchNorm(channels)
     if normalization == 'instance':
         return lambda: (nn.InstanceNorm3d if dim == 3 else nn.InstanceNorm2d)(channels)   # affine=False, no running statistics
+    if normalization.startswith('group'):
+        return lambda: nn.GroupNorm(num_groups=_num_groups(normalization), num_channels=channels)
     return nn.Identity
+
+
+def _num_groups(normalization):
+    """'group' -> 8, 'group<G>' -> G (unet.py:81-90)."""
+    if normalization == 'group':
+        return 8
+    if normalization[len('group'):].isdigit():
+        return int(normalization[len('group'):])
+    raise ValueError(f'normtype "{normalization}" not understood. It should be "group<G>", where <G> is the number of groups.')
 
 
 class DownConv(nn.Module):
@@ -252,7 +263,7 @@ class UNet(nn.Module):
     """3D U-Net with the reference's interface (elektronn3/models/unet.py:755-771), executed by hand-written HIP
     kernels.  Options of the reference that are not yet on the HIP path raise ``NotImplementedError`` at
     construction: ``up_mode != 'transpose'``,
-    ``attention=True``, ``activation != 'relu'``, ``normalization='group*'``,
+    ``attention=True``, ``activation != 'relu'``,
     ``conv_mode != 'same'``.  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
     the 3D one with every block planar and a depth of 1."""
 
@@ -306,7 +317,10 @@ class UNet(nn.Module):
         if not (normalization in ('none', 'batch', 'instance') or (isinstance(normalization, str) and normalization.startswith('group'))):
             raise ValueError(f'Unknown normalization type "{normalization}".\nValid choices are "batch", "instance", "group" or "group<G>",'
                              'where <G> is the number of groups.')      # get_normalization, unet.py:106-111
-        if normalization not in ('batch', 'none', 'instance'): unsupported.append(f'normalization={normalization!r}')
+        if normalization.startswith('group'):
+            if start_filts % _num_groups(normalization) != 0:
+                raise ValueError('num_channels must be divisible by num_groups')      # (torch.nn.GroupNorm's own check)
+        elif normalization not in ('batch', 'none', 'instance'): unsupported.append(f'normalization={normalization!r}')
         if conv_mode != 'same': unsupported.append(f'conv_mode={conv_mode!r}')
         if start_filts % 8 != 0: unsupported.append(f'start_filts={start_filts} (must be a multiple of 8)')
         if not (1 <= out_channels <= 8): unsupported.append(f'out_channels={out_channels} (1..8)')
@@ -365,12 +379,16 @@ class UNet(nn.Module):
         mask = 0
         for b in (range(self.n_blocks) if self.dim == 2 else self.planar_blocks):   # dim=2: every block is planar, depth 1
             mask |= 1 << int(b)
-        eps = next((float(m.eps) for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)), 1e-5)
-        return (self.in_channels, self.out_channels, self.n_blocks, self.start_filts, mask, 1 if self.normalization in ('batch', 'instance') else 0, eps,
-                1 if getattr(self, 'full_norm', True) else 0, 1 if self.merge_mode == 'add' else 0)
+        eps = next((float(m.eps) for m in self.modules() if isinstance(m, (nn.modules.batchnorm._BatchNorm, nn.GroupNorm))), 1e-5)
+        return (self.in_channels, self.out_channels, self.n_blocks, self.start_filts, mask, 2 if self.normalization.startswith('group') else (1 if self.normalization in ('batch', 'instance') else 0), eps,
+                1 if getattr(self, 'full_norm', True) else 0, 1 if self.merge_mode == 'add' else 0,
+                _num_groups(self.normalization) if self.normalization.startswith('group') else 0)
 
     def _plan(self):
         return _get_plan(self._plan_key())
+
+    def _per_sample_norm(self):
+        return self.normalization == 'instance' or self.normalization.startswith('group')
 
     def _named_table_params(self, plan):
         """(name, Parameter) for the trainable entries of the plan table, in table order."""
@@ -402,8 +420,8 @@ class UNet(nn.Module):
 
     def _momenta(self, plan):
         moms = []
-        if self.normalization == 'instance':
-            return [0.0] * len(plan.bn_names)      # (running statistics are not tracked: nn.InstanceNorm3d defaults)
+        if self._per_sample_norm():
+            return [0.0] * plan.n_bn               # (no running statistics: nn.InstanceNorm3d defaults / nn.GroupNorm)
         for bn_name in plan.bn_names:
             bn = self.get_submodule(bn_name)
             if bn.momentum is None:   # cumulative moving average (torch semantics)
@@ -413,7 +431,7 @@ class UNet(nn.Module):
         return moms
 
     def _bump_num_batches_tracked(self, plan):
-        if self.normalization == 'instance':
+        if self._per_sample_norm():
             return
         nbt = [self.get_submodule(n).num_batches_tracked for n in plan.bn_names]
         if nbt:
@@ -438,9 +456,9 @@ class UNet(nn.Module):
         params = [p for _, p in self._named_table_params(plan)]
         if any(p.device != x.device for p in params):
             raise RuntimeError('input and parameters are on different devices')
-        if self.normalization == 'instance':
-            # per-sample statistics in training AND eval mode (nn.InstanceNorm3d defaults): one native call per sample; autograd
-            # sums the parameter gradients of the calls
+        if self._per_sample_norm():
+            # per-sample statistics in training AND eval mode (nn.InstanceNorm3d defaults, nn.GroupNorm): one native call per sample;
+            # autograd sums the parameter gradients of the calls
             y = torch.cat([_UNetFunction.apply(self, softmax, x[n:n + 1], *params) for n in range(x.shape[0])], 0)
         else:
             y = _UNetFunction.apply(self, softmax, x, *params)

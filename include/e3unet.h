@@ -53,10 +53,12 @@ typedef struct e3_unet_cfg {
     int32_t n_blocks;       /* UNet(n_blocks=...), 1..8         unet.py:759 */
     int32_t start_filts;    /* UNet(start_filts=...), multiple of 8   unet.py:760 */
     uint32_t planar_mask;   /* bit i set <=> i in planar_blocks unet.py:763,827 */
-    int32_t normalization;  /* 1 = 'batch', 0 = 'none' (nn.Identity, unet.py:77-80); group/instance are not on the HIP path */
+    int32_t normalization;  /* 1 = 'batch', 0 = 'none' (nn.Identity, unet.py:77-80), 2 = 'group<G>' (nn.GroupNorm(num_groups, C): affine, no running
+                             * statistics, per-SAMPLE statistics => call with N = 1; 'instance' = 'batch' with N = 1 and unit affine constants) */
     float bn_eps;           /* nn.BatchNorm3d eps (1e-5) */
     int32_t full_norm;      /* 1: a norm after every (transposed) conv; 0: only after the last conv of a block (unet.py:238-242,369-375) */
     int32_t merge_add;      /* 0: merge_mode='concat' (torch.cat((up, skip), 1)); 1: merge_mode='add' (up + skip), unet.py:398-401 */
+    int32_t num_groups;     /* normalization = 2: number of groups (8 for 'group', G for 'group<G>', unet.py:81-90) */
 } e3_unet_cfg;
 
 typedef struct e3_unet_plan e3_unet_plan;

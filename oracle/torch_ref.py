@@ -20,6 +20,8 @@ def _bn(x, sd, name, training, momentum=0.1, eps=1e-5):
         if name in sd.get('__instance_norms__', ()):     # 369-375) or nn.InstanceNorm3d (affine=False, instance statistics always)
             return F.instance_norm(x, eps=eps)
         return x
+    if name + '.running_mean' not in sd:         # nn.GroupNorm(num_groups, C): affine, no running statistics (unet.py:81-90)
+        return F.group_norm(x, sd['__num_groups__'], sd[name + '.weight'], sd[name + '.bias'], eps=eps)
     return F.batch_norm(x, sd[name + '.running_mean'], sd[name + '.running_var'], sd[name + '.weight'], sd[name + '.bias'],
                         training=training, momentum=momentum, eps=eps)
 

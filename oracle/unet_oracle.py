@@ -182,6 +182,36 @@ def softmax_c(x):
     return y
 
 
+def group_norm_fwd(x, gamma, beta, num_groups, eps=1e-5):
+    """nn.GroupNorm(num_groups, C) (get_normalization, unet.py:81-90): per sample, mean / biased variance over the C/G channels of a
+    group and all voxels, then the per-channel affine map.  float64 arithmetic.  Returns (y, xhat, invstd[N,G])."""
+    x = np.asarray(x, np.float64)
+    N, C = x.shape[:2]
+    xg = x.reshape(N, num_groups, -1)
+    mean = xg.mean(-1, keepdims=True)
+    var = xg.var(-1, keepdims=True)
+    invstd = 1.0 / np.sqrt(var + eps)
+    xhat = ((xg - mean) * invstd).reshape(x.shape)
+    sh = (1, C) + (1,) * (x.ndim - 2)
+    y = xhat * np.asarray(gamma, np.float64).reshape(sh) + np.asarray(beta, np.float64).reshape(sh)
+    return y.astype(np.float32), xhat, invstd[..., 0]
+
+
+def group_norm_bwd(dy, xhat, invstd, gamma, num_groups):
+    """Backward of group_norm_fwd: dgamma_c = sum dy*xhat, dbeta_c = sum dy,
+    dx = invstd_g * (gamma dy - mean_g(gamma dy) - xhat * mean_g(gamma dy xhat))."""
+    dy = np.asarray(dy, np.float64)
+    N, C = dy.shape[:2]
+    red = (0,) + tuple(range(2, dy.ndim))
+    dgamma, dbeta = (dy * xhat).sum(red), dy.sum(red)
+    sh = (1, C) + (1,) * (dy.ndim - 2)
+    gdy = dy * np.asarray(gamma, np.float64).reshape(sh)
+    gg = gdy.reshape(N, num_groups, -1); xg = xhat.reshape(N, num_groups, -1)
+    m1 = gg.mean(-1, keepdims=True); m2 = (gg * xg).mean(-1, keepdims=True)
+    dx = (invstd[..., None] * (gg - m1 - xg * m2)).reshape(dy.shape)
+    return dx.astype(np.float32), dgamma.astype(np.float32), dbeta.astype(np.float32)
+
+
 def adamw_step(p, g, m, v, t, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
     """In-place torch.optim.AdamW step number t (1-based) on fp32 arrays p, m, v (examples/train_unet_neurodata.py:257-262)."""
     for a in (p, m, v):
@@ -222,6 +252,7 @@ class OracleUNet:
         self.n_blocks = n_blocks
         self.planar = tuple(planar_blocks)
         self.norm = normalization
+        self.num_groups = 8 if normalization == 'group' else (int(normalization[5:]) if normalization.startswith('group') else 0)
         self.instance_norms = ()      # names of the nn.InstanceNorm layers (they have no state_dict entries), set by the caller
         self.momentum, self.eps = momentum, eps
         self.training = True
@@ -246,6 +277,9 @@ class OracleUNet:
                 ys.append(yn); stats.append((mean, invstd))
             y = np.concatenate(ys, 0)
             cache[name] = (x, stats)
+        elif self.norm.startswith('group') and (name + '.weight') in self.sd:
+            y, xhat, invstd = group_norm_fwd(x, self.sd[name + '.weight'], self.sd[name + '.bias'], self.num_groups, self.eps)
+            cache[name] = (xhat, invstd)
         elif self.norm == 'batch' and (name + '.weight') in self.sd:
             g, b = self.sd[name + '.weight'], self.sd[name + '.bias']
             rm, rv = self.sd[name + '.running_mean'], self.sd[name + '.running_var']
@@ -310,6 +344,11 @@ class OracleUNet:
             x, stats = cache[name]
             ones = np.ones(x.shape[1], np.float32)
             return np.concatenate([bn_train_bwd(dy[n:n + 1], x[n:n + 1], ones, *stats[n])[0] for n in range(x.shape[0])], 0)
+        if self.norm.startswith('group') and (name + '.weight') in self.sd:
+            xhat, invstd = cache[name]
+            dx, dg, db = group_norm_bwd(dy, xhat, invstd, self.sd[name + '.weight'], self.num_groups)
+            grads[name + '.weight'], grads[name + '.bias'] = dg, db
+            return dx
         if self.norm == 'batch' and (name + '.weight') in self.sd:
             x, mean, invstd = cache[name]
             dx, dg, db = bn_train_bwd(dy, x, self.sd[name + '.weight'], mean, invstd)

@@ -301,6 +301,9 @@ if __name__ == '__main__':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_nonorm.npz', seed=4, n_blocks=2, start_filts=8, planar_blocks=(), shape=(10, 13, 18), batch=2, normalization='none')
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_planar0_sparsenorm.npz', seed=5, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 18, 21), batch=2, full_norm=False)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'group':
+        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_group4_odd.npz', seed=8, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 21), batch=2, normalization='group4')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'instance':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_instance.npz', seed=7, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 17, 20), batch=2, normalization='instance')
         sys.exit(0)
@@ -326,6 +329,8 @@ if __name__ == '__main__':
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_add_odd.npz', seed=6, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 14, 19), batch=2, merge_mode='add')
     # nn.InstanceNorm3d norms (no parameters, per-sample statistics in training and eval mode)
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_instance.npz', seed=7, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 17, 20), batch=2, normalization='instance')
+    # nn.GroupNorm(4, C) norms (affine, per-sample group statistics, no running stats), odd sizes
+    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_group4_odd.npz', seed=8, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 21), batch=2, normalization='group4')
     make_predictor(unet, inference, f'{HERE}/predictor.npz')
     make_adamw(f'{HERE}/adamw.npz')
     make_trainsteps(unet, loss_mod, f'{HERE}/trainsteps.npz')

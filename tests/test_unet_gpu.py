@@ -20,7 +20,8 @@ from helpers import instance_norm_names, is_prebn_bias, load_npz, rel_l2, sub, u
 pytestmark = pytest.mark.gpu
 
 CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz', 'unet2d_nb3_sf8_odd.npz',
-         'unet_nb2_sf8_nonorm.npz', 'unet_nb3_sf8_planar0_sparsenorm.npz', 'unet_nb3_sf8_add_odd.npz', 'unet_nb3_sf8_instance.npz']
+         'unet_nb2_sf8_nonorm.npz', 'unet_nb3_sf8_planar0_sparsenorm.npz', 'unet_nb3_sf8_add_odd.npz', 'unet_nb3_sf8_instance.npz',
+         'unet_nb3_sf8_group4_odd.npz']
 
 
 def build(cfg, sd_np):
@@ -63,7 +64,8 @@ def test_train_step_matches_reference(case):
         errs = {}
         for k in ref32:
             assert gr[k].shape == ref32[k].shape, k
-            if is_prebn_bias(k, set(ref32), instance_norm_names(cfg)):    # analytically zero (bias feeding a train-mode BN): absolute tolerance only
+            # analytically zero (bias feeding a train-mode BN / InstanceNorm; NOT for GroupNorm): absolute tolerance only
+            if is_prebn_bias(k, set() if str(cfg.get('normalization')).startswith('group') else set(ref32), instance_norm_names(cfg)):
                 assert np.abs(gr[k]).max() <= 1e-5 * gnorm, (k, np.abs(gr[k]).max())
                 continue
             errs[k] = (rel_l2(gr[k], ref64[k]), rel_l2(ref32[k], ref64[k]))
@@ -240,8 +242,9 @@ def test_full_size_cfg4_anisotropic_against_pytorch_rocm():
 
 @pytest.mark.parametrize('kw', [dict(normalization='none'), dict(normalization='batch', full_norm=False, planar_blocks=(0,)),
                                 dict(merge_mode='add'), dict(merge_mode='add', normalization='none', planar_blocks=(0,)),
-                                dict(normalization='instance', planar_blocks=(0,))],
-                         ids=['nonorm', 'sparsenorm', 'add', 'add_nonorm_planar', 'instance'])
+                                dict(normalization='instance', planar_blocks=(0,)), dict(normalization='group', planar_blocks=(0,)),
+                                dict(normalization='group16', full_norm=False, merge_mode='add')],
+                         ids=['nonorm', 'sparsenorm', 'add', 'add_nonorm_planar', 'instance', 'group8', 'group16_sparse_add'])
 def test_option_variants_against_pytorch_rocm(kw):
     """normalization='none' and full_norm=False (norm layers = nn.Identity, unet.py:77-80,238-242,369-375) at a size that runs the
     Winograd kernels (conv -> bias -> ReLU fused in their epilogue, also in training), and merge_mode='add' (unet.py:398-401: the skip
@@ -266,7 +269,9 @@ def test_option_variants_against_pytorch_rocm(kw):
     sd_ref = {k: (v.double() if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k)
               for k, v in sd0.items()}
     pl = tuple(kw.get('planar_blocks', ()))
+    group = str(kw.get('normalization', '')).startswith('group')
     sd_ref['__instance_norms__'] = paramless
+    sd_ref['__num_groups__'] = 8 if kw.get('normalization') == 'group' else (int(kw['normalization'][5:]) if group else 0)
     ref = unet_forward(sd_ref, x.double(), 3, pl, training=True)
     lref = combined_loss(ref, t)
     lref.backward()
@@ -280,7 +285,7 @@ def test_option_variants_against_pytorch_rocm(kw):
     n_real_bias = 0
     for k, p in m.named_parameters():
         gr = sd_ref[k].grad
-        if is_prebn_bias(k, names, paramless):
+        if is_prebn_bias(k, set() if group else names, paramless):
             assert float(p.grad.abs().max()) <= 1e-5 * float(gn), k
             continue
         n_real_bias += k.endswith('.bias') and 'conv' in k and not k.startswith('conv_final')
@@ -292,8 +297,9 @@ def test_option_variants_against_pytorch_rocm(kw):
         ye = m(x)
     sd_e = {k: v.double() if v.is_floating_point() else v for k, v in m.state_dict().items()}
     sd_e['__instance_norms__'] = paramless
+    sd_e['__num_groups__'] = sd_ref['__num_groups__']
     assert torch.allclose(ye.double(), unet_forward(sd_e, x.double(), 3, pl, training=False), rtol=1e-4, atol=1e-4)
-    if paramless:       # instance statistics in eval mode too: eval output == train output, and a batch equals its samples one by one
+    if paramless or group:       # instance / group statistics in eval mode too: eval output == train output, and a batch equals its samples one by one
         assert torch.equal(ye, out.detach())
         assert torch.equal(m(x[1:2]), ye[1:2])
 

@@ -26,11 +26,12 @@ for case in range(n_cases):
     D = ri(1, 5) * mult + (ri(0, 3) if ri(0, 1) else 0); H = ri(2, 9) * mult + ri(0, 5); W = ri(2, 10) * mult + ri(0, 5)
     N = ri(1, 3)
     kw = {}
-    v = ri(0, 6)                                      # option variants: dim=2, normalization='none'/'instance', full_norm=False, merge_mode='add'
+    v = ri(0, 7)                                      # option variants: dim=2, normalization='none'/'instance', full_norm=False, merge_mode='add'
     if v == 0: kw, planar, D = dict(dim=2), (), None
     elif v == 1: kw = dict(normalization='none')
     elif v == 2: kw = dict(full_norm=False)
     elif v == 3: kw = dict(normalization='instance', full_norm=bool(ri(0, 1)))
+    elif v == 4: kw = dict(normalization=('group', 'group4', 'group2')[ri(0, 2)], full_norm=bool(ri(0, 1)))
     if ri(0, 3) == 0: kw['merge_mode'] = 'add'
     shape = (H, W) if D is None else (D, H, W)
     torch.manual_seed(case)
@@ -45,6 +46,8 @@ for case in range(n_cases):
     sd_ref = {k: (v.double() if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd0.items()}
     paramless = R.instance_norm_names(nb, kw.get('full_norm', True)) if kw.get('normalization') == 'instance' else ()
     sd_ref['__instance_norms__'] = paramless
+    group = str(kw.get('normalization', '')).startswith('group')
+    sd_ref['__num_groups__'] = (8 if kw['normalization'] == 'group' else int(kw['normalization'][5:])) if group else 0
     margin = [float('inf')]
     def rec_relu(z, *a, **k):
         margin[0] = min(margin[0], float(z.detach().abs().min())); return _relu(z, *a, **k)
@@ -57,7 +60,7 @@ for case in range(n_cases):
     names = {k for k, _ in m.named_parameters()}
     for k, p in m.named_parameters():
         gr = sd_ref[k].grad
-        prebn = is_prebn_bias(k, names, paramless)
+        prebn = is_prebn_bias(k, set() if group else names, paramless)
         err = float(p.grad.abs().max()) / gn if prebn else float((p.grad - gr).norm() / gr.norm().clamp_min(1e-30))
         if (not prebn and err > worst): worst, wk = err, k
         if prebn and err > 1e-5: worst, wk = 1.0, k + ' (pre-BN bias not ~0)'
