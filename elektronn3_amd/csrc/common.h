@@ -58,6 +58,11 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     return base + (bid >> 3);
 }
 
+// The network's activation: ReLU (slope 0), LeakyReLU(slope) [get_activation 'leaky' = 0.1, unet.py:183-199] or identity (slope 1,
+// 'lin').  Written so that slope == 0 reproduces fmaxf(z, 0) bit for bit (+0 + -0 = +0) and the mask form stays sign-of-zero clean.
+__device__ __forceinline__ float act_fwd(float z, float slope) { return fmaxf(z, 0.f) + slope * fminf(z, 0.f); }
+__device__ __forceinline__ float act_bwd(float z, float g, float slope) { return z > 0.f ? g : slope * g + 0.f; }
+
 // Chan/Welford merge of (count, mean, M2) records; robust for na == 0 or nb == 0.
 __device__ __forceinline__ void welford_merge(float& na, float& ma, float& sa, float nb, float mb, float sb) {
     const float n = na + nb;

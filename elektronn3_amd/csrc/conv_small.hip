@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float z = __builtin_fmaf(xv[e], fsc[e], fsh[e]);
-                                const float dz = z > 0.f ? gv[e] : 0.f;
+                                const float dz = act_bwd(z, gv[e], f.slope);
                                 const float xh = (xv[e] - fmu[e]) * fis[e];
                                 val[e] = fgi[e] * (dz - fc1[e] - xh * fc2[e]);
                                 if (ci == 0) bsum[e] += val[e];
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
 template <int COUT>
 __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, int C, const float* __restrict__ w,
                                       const float* __restrict__ bias, float* __restrict__ y, size_t S, int N, int lpv, int softmax,
-                                      const float* __restrict__ pro_scale, const float* __restrict__ pro_shift) {
+                                      const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, float pro_slope) {
     // pro_scale/pro_shift: `a` is the RAW output of the last conv; its BatchNorm + ReLU, a := relu(a*scale + shift), is applied while
     // loading (same expression as bn_relu_apply_kernel) -- the last activation of the network is never written or re-read
     // lpv (1,2,4,8) consecutive lanes share one voxel; each walks every lpv-th channel quad
@@ -260,7 +260,7 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
                 if (pro_scale) {
                     const f32x4 sc = *reinterpret_cast<const f32x4*>(pro_scale + 4 * q), sh = *reinterpret_cast<const f32x4*>(pro_shift + 4 * q);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) av[e] = fmaxf(__builtin_fmaf(av[e], sc[e], sh[e]), 0.f);
+                    for (int e = 0; e < 4; ++e) av[e] = act_fwd(__builtin_fmaf(av[e], sc[e], sh[e]), pro_slope);
                 }
 #pragma unroll
                 for (int co = 0; co < COUT; ++co) {
@@ -298,7 +298,7 @@ template <int COUT>
 __global__ __launch_bounds__(256) void conv_final_bwd_kernel(const float* __restrict__ a, int a_ldc, int C, const float* __restrict__ w,
                                                              const float* __restrict__ dy, float* __restrict__ da, int da_ldc,
                                                              float* __restrict__ part, size_t S, int N,
-                                                             const float* __restrict__ pro_scale, const float* __restrict__ pro_shift) {
+                                                             const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, float pro_slope) {
     __shared__ float red[256][4];
     const int Q = C >> 2;
     const int BT = (256 / Q) * Q;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void conv_final_bwd_kernel(const float* __rest
         f32x4 av = *reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * q);
         if (pro_scale) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) av[e] = fmaxf(__builtin_fmaf(av[e], sc[e], sh[e]), 0.f);
+            for (int e = 0; e < 4; ++e) av[e] = act_fwd(__builtin_fmaf(av[e], sc[e], sh[e]), pro_slope);
         }
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -430,12 +430,12 @@ static int final_lpv(int C) {
     }
 
 int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y,
-                          int Cout, size_t S, int N, int softmax, hipStream_t s, const float* pro_scale, const float* pro_shift) {
+                          int Cout, size_t S, int N, int softmax, hipStream_t s, const float* pro_scale, const float* pro_shift, float pro_slope) {
     E3_REQUIRE(C % 4 == 0 && a_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
     const int lpv = final_lpv(C);
     const size_t vox = (size_t)N * S;
     size_t g = (vox * lpv + 255) / 256; if (g > 4096) g = 4096; if (g == 0) g = 1;
-    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_fwd_kernel<CO>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, S, N, lpv, softmax, pro_scale, pro_shift));
+    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_fwd_kernel<CO>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, S, N, lpv, softmax, pro_scale, pro_shift, pro_slope));
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
@@ -446,10 +446,10 @@ int conv_final_bwd_parts(size_t total_voxels) {
 }
 
 int launch_conv_final_bwd(const float* a, int a_ldc, int C, const float* w, const float* dy, float* da, int da_ldc,
-                          float* part, int Cout, size_t S, int N, hipStream_t s, const float* pro_scale, const float* pro_shift) {
+                          float* part, int Cout, size_t S, int N, hipStream_t s, const float* pro_scale, const float* pro_shift, float pro_slope) {
     E3_REQUIRE(C % 4 == 0 && C <= 1024, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4 and <= 1024");
     const int parts = conv_final_bwd_parts((size_t)N * S);
-    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_bwd_kernel<CO>), dim3(parts), dim3(256), 0, s, a, a_ldc, C, w, dy, da, da_ldc, part, S, N, pro_scale, pro_shift));
+    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_bwd_kernel<CO>), dim3(parts), dim3(256), 0, s, a, a_ldc, C, w, dy, da, da_ldc, part, S, N, pro_scale, pro_shift, pro_slope));
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

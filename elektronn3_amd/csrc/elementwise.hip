@@ -173,7 +173,7 @@ __global__ void bn_fold_multi_kernel(const FoldMultiArgs a) {
 // ------------------------------------------------------------------ BN apply + ReLU (+ max-pool)
 __global__ void bn_relu_apply_kernel(const float* __restrict__ x, int x_ldc, const float* __restrict__ scale,
                                      const float* __restrict__ shift, float* __restrict__ a, int a_ldc,
-                                     size_t voxels, int C, size_t nt_bytes) {
+                                     size_t voxels, int C, size_t nt_bytes, float slope) {
     const int Q = C >> 2;
     const size_t total = voxels * Q;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -196,7 +196,7 @@ __global__ void bn_relu_apply_kernel(const float* __restrict__ x, int x_ldc, con
             const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + 4 * qq[u]);
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fmaxf(__builtin_fmaf(xv[u][e], sc[e], sh[e]), 0.f);
+            for (int e = 0; e < 4; ++e) o[e] = act_fwd(__builtin_fmaf(xv[u][e], sc[e], sh[e]), slope);
             if (ok[u]) *reinterpret_cast<f32x4*>(a + off[u] * a_ldc + 4 * qq[u]) = o;
         }
     }
@@ -208,7 +208,7 @@ __global__ void bn_relu_apply_kernel(const float* __restrict__ x, int x_ldc, con
 template <bool APPLY>
 __global__ void bn_relu_pool_kernel(const float* __restrict__ x, int x_ldc, const float* __restrict__ scale,
                                     const float* __restrict__ shift, float* __restrict__ a, int a_ldc,
-                                    float* __restrict__ pooled, int kd, int N, int D, int H, int W, int C) {
+                                    float* __restrict__ pooled, int kd, int N, int D, int H, int W, int C, float slope) {
     const int Q = C >> 2;
     const int Dp = (D + kd - 1) / kd, Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
     const size_t total = (size_t)N * Dp * Hp * Wp * Q;
@@ -230,7 +230,7 @@ __global__ void bn_relu_pool_kernel(const float* __restrict__ x, int x_ldc, cons
                     f32x4 o = *reinterpret_cast<const f32x4*>(x + v * x_ldc + 4 * q);
                     if (APPLY) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(__builtin_fmaf(o[e], sc[e], sh[e]), 0.f);
+                        for (int e = 0; e < 4; ++e) o[e] = act_fwd(__builtin_fmaf(o[e], sc[e], sh[e]), slope);
                         *reinterpret_cast<f32x4*>(a + v * a_ldc + 4 * q) = o;
                     }
 #pragma unroll
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float z = __builtin_fmaf(xv[u][e], sc[e], sh[e]);   // same expression as the forward apply
-                    const float dz = z > 0.f ? g[u][e] : 0.f;
+                    const float dz = act_bwd(z, g[u][e], a.slope);
                     const float xh = (xv[u][e] - mu[e]) * is[e];
                     if (APPLYPASS) { o[e] = ok[u] ? gi[e] * (dz - c1[e] - xh * c2[e]) - (k1[e] + xh * k2[e]) : 0.f; s3[e] += o[e]; }
                     else { s1[e] += dz; s2[e] += dz * xh; }
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                         // forward apply, so it is bit-identical to the stored tensor the pooled maxima were taken from
                         f32x4 av;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) av[e] = fmaxf(__builtin_fmaf(xv[e], sc[e], sh[e]), 0.f);
+                        for (int e = 0; e < 4; ++e) av[e] = act_fwd(__builtin_fmaf(xv[e], sc[e], sh[e]), a.slope);
                         f32x4 g = {0.f, 0.f, 0.f, 0.f};
                         if (a.g1) g = *reinterpret_cast<const f32x4*>(a.g1 + v * a.g1_ldc + 4 * q);
                         f32x4 o;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                         for (int e = 0; e < 4; ++e) {
                             float dA = g[e];
                             if (!taken[e] && av[e] == pm[e]) { dA += gp[e]; taken[e] = true; }   // first arg-max wins (ATen)
-                            const float dz = av[e] > 0.f ? dA : 0.f;
+                            const float dz = act_bwd(av[e], dA, a.slope);     // (sign(a) == sign(z) for every slope >= 0)
                             const float xh = (xv[e] - mu[e]) * is[e];
                             if (APPLYPASS) { o[e] = gi[e] * (dz - c1[e] - xh * c2[e]) - (k1[e] + xh * k2[e]); s3[e] += o[e]; }
                             else { s1[e] += dz; s2[e] += dz * xh; }
@@ -580,14 +580,14 @@ int launch_fold_multi(const FoldJob* jobs, int njobs, float eps, hipStream_t s) 
 }
 
 int launch_bn_relu_apply(const float* x, int x_ldc, const float* scale, const float* shift, float* a, int a_ldc,
-                         float* pooled, int kd, int N, int D, int H, int W, int C, hipStream_t s) {
+                         float* pooled, int kd, int N, int D, int H, int W, int C, hipStream_t s, float slope) {
     E3_REQUIRE(C % 4 == 0 && x_ldc % 4 == 0 && a_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
     if (!pooled) {
         const size_t vox = (size_t)N * D * H * W;
-        hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(ew_grid(vox * (C / 4))), dim3(EW_BLOCK), 0, s, x, x_ldc, scale, shift, a, a_ldc, vox, C, ew_nt_bytes());
+        hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(ew_grid(vox * (C / 4))), dim3(EW_BLOCK), 0, s, x, x_ldc, scale, shift, a, a_ldc, vox, C, ew_nt_bytes(), slope);
     } else {
         const size_t items = (size_t)N * cdiv(D, kd) * cdiv(H, 2) * cdiv(W, 2) * (C / 4);
-        hipLaunchKernelGGL(bn_relu_pool_kernel<true>, dim3(ew_grid(items)), dim3(EW_BLOCK), 0, s, x, x_ldc, scale, shift, a, a_ldc, pooled, kd, N, D, H, W, C);
+        hipLaunchKernelGGL(bn_relu_pool_kernel<true>, dim3(ew_grid(items)), dim3(EW_BLOCK), 0, s, x, x_ldc, scale, shift, a, a_ldc, pooled, kd, N, D, H, W, C, slope);
     }
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
@@ -597,7 +597,7 @@ int launch_maxpool(const float* a, int a_ldc, float* pooled, int kd, int N, int 
     E3_REQUIRE(C % 4 == 0 && a_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
     const size_t items = (size_t)N * cdiv(D, kd) * cdiv(H, 2) * cdiv(W, 2) * (C / 4);
     hipLaunchKernelGGL(bn_relu_pool_kernel<false>, dim3(ew_grid(items)), dim3(EW_BLOCK), 0, s, a, a_ldc,
-                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 0, pooled, kd, N, D, H, W, C);
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 0, pooled, kd, N, D, H, W, C, 0.f);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

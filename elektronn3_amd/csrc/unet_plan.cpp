@@ -142,7 +142,9 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         const ConvUnit& u = p->units[k];
         UnitBufs& b = B.ub[k];
         const size_t n = L[u.level].vox * u.cout;
-        b.raw = (training && u.has_norm()) ? A.take(n) : nullptr;   // without a norm the conv writes relu(acc + bias) directly
+        // without batch statistics to wait for, the conv writes relu(acc*scale + shift) directly; other activations are not in the conv
+        // epilogues and take the two-pass route (raw tensor, then the apply pass)
+        b.raw = ((training && u.has_norm()) || p->cfg.act_slope != 0.f) ? A.take(n) : nullptr;
         // where does the activation go?
         const bool enc_skip = !u.is_up && u.name.find("down_convs") == 0 && u.name.find("conv2") != std::string::npos && u.level < nb - 1;
         if (enc_skip) { b.act = B.cat[u.level] ? B.cat[u.level] + u.cout : nullptr; b.act_ldc = 2 * u.cout; }
@@ -244,6 +246,7 @@ int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
     E3_REQUIRE(cfg->out_channels >= 1 && cfg->out_channels <= 8, E3_ERR_UNSUPPORTED, "out_channels must be in 1..8 on the HIP path");
     E3_REQUIRE(cfg->start_filts >= 8 && cfg->start_filts % 8 == 0, E3_ERR_UNSUPPORTED, "start_filts must be a multiple of 8 on the HIP path");
     E3_REQUIRE((cfg->start_filts << (cfg->n_blocks - 1)) <= 1024, E3_ERR_UNSUPPORTED, "more than 1024 channels at the bottom level");
+    E3_REQUIRE(cfg->act_slope >= 0.f && cfg->act_slope <= 1.f, E3_ERR_INVALID, "act_slope must be in [0, 1] (0 ReLU, 0.1 LeakyReLU, 1 identity)");
     E3_REQUIRE(cfg->normalization >= 0 && cfg->normalization <= 2, E3_ERR_UNSUPPORTED, "normalization must be 0 (none), 1 (batch) or 2 (group)");
     if (cfg->normalization == 2)
         E3_REQUIRE(cfg->num_groups >= 1 && cfg->start_filts % cfg->num_groups == 0, E3_ERR_INVALID, "num_groups must divide every channel count");
@@ -382,12 +385,14 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         const bool is_enc_conv2 = !u.is_up && u.name.compare(0, 10, "down_convs") == 0 && u.name.find("conv2") != std::string::npos;
         const bool pool_after = is_enc_conv2 && u.level < nb - 1;
         const int kd = u.planar ? 1 : 2;
+        const float slope = cfg.act_slope;
         const bool bn_train = training && u.has_norm();   // batch statistics needed: conv writes the raw output, BN+ReLU is a second pass
-        float* dst = bn_train ? b.raw : b.act;            // otherwise the conv writes the activation directly
-        const int dst_ldc = bn_train ? u.cout : b.act_ldc;
+        const bool two_pass = bn_train || slope != 0.f;   // (non-ReLU activations are not in the conv epilogues)
+        float* dst = two_pass ? b.raw : b.act;            // otherwise the conv writes the activation directly
+        const int dst_ldc = two_pass ? u.cout : b.act_ldc;
         const float* es = nullptr; const float* eh = nullptr;
-        if (!u.has_norm() || !training) {   // nn.Identity: y = relu(acc + bias) always; eval-mode BN folded into the conv epilogue
-            es = b.scale; eh = b.shift;     // (running stats) -- constants computed by the one launch above
+        if ((!u.has_norm() || !training) && !two_pass) {   // nn.Identity: y = relu(acc + bias) always; eval-mode BN folded into the conv
+            es = b.scale; eh = b.shift;                    // epilogue (running stats) -- constants from the launch above
         }
         int parts = 0;
         if (u.is_up) {
@@ -436,7 +441,10 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             // (forward and backward): no apply pass, no activation tensor
             if (k + 1 < plan->units.size())
                 RUN(launch_bn_relu_apply(b.raw, u.cout, b.scale, b.shift, b.act, b.act_ldc, pool_after ? B.pooled[u.level] : nullptr, kd,
-                                         N, lo.D, lo.H, lo.W, u.cout, s));
+                                         N, lo.D, lo.H, lo.W, u.cout, s, slope));
+        } else if (two_pass) {      // raw = pure accumulations; (scale, shift) = folded eval-mode BN, or (1, conv bias) without a norm
+            RUN(launch_bn_relu_apply(b.raw, u.cout, b.scale, b.shift, b.act, b.act_ldc, pool_after ? B.pooled[u.level] : nullptr, kd,
+                                     N, lo.D, lo.H, lo.W, u.cout, s, slope));
         } else if (pool_after) {
             RUN(launch_maxpool(b.act, b.act_ldc, B.pooled[u.level], kd, N, lo.D, lo.H, lo.W, u.cout, s));
         }
@@ -456,7 +464,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         Prof pr(plan, s, (int)plan->units.size(), 0);
         RUN(launch_conv_final_fwd(fused ? lb.raw : cur, fused ? lu.cout : cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y,
                                   cfg.out_channels, L[0].vox / N, N, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s,
-                                  fused ? lb.scale : nullptr, fused ? lb.shift : nullptr));
+                                  fused ? lb.scale : nullptr, fused ? lb.shift : nullptr, cfg.act_slope));
     }
     return E3_OK;
 }
@@ -489,7 +497,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
           // the gradient w.r.t. the last activation is not written: the BN backward of the last unit recomputes it from dy and the head's
           // weights (2 fma per element instead of one 4-byte write and two 4-byte reads)
           RUN(launch_conv_final_bwd(fused ? last.raw : last.act, fused ? C0 : last.act_ldc, C0, P(plan->p_final_w), dy, nullptr, C0, B.slab,
-                                    cfg.out_channels, L[0].vox / N, N, s, fused ? last.scale : nullptr, fused ? last.shift : nullptr)); }
+                                    cfg.out_channels, L[0].vox / N, N, s, fused ? last.scale : nullptr, fused ? last.shift : nullptr, cfg.act_slope)); }
         RUN(launch_colsum_finalize(B.slab, parts, ps, 0, cfg.out_channels * C0, G(plan->p_final_w), s));
         RUN(launch_colsum_finalize(B.slab, parts, ps, cfg.out_channels * C0, cfg.out_channels, G(plan->p_final_b), s));
     }
@@ -528,10 +536,13 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         {
             BnBwdArgs a{};
             a.x = b.raw; a.x_ldc = u.cout; a.mean = b.mean; a.invstd = b.invstd; a.scale = b.scale; a.shift = b.shift;
+            a.slope = cfg.act_slope;
             if (u.has_norm()) a.gamma = P(u.p_g);
-            else {   // nn.Identity + ReLU: dz = dA * (a > 0) is the APPLY pass with the constants of an identity "norm":
-                     // x := a (mask z = 1*a + 0 > 0), mean 0, invstd 1, gamma 1, c1 = c2 = 0  =>  dx = dz, sum dx = conv-bias gradient
-                a.x = b.act; a.x_ldc = b.act_ldc; a.mean = B.zeros; a.invstd = B.ones; a.gamma = B.ones; a.scale = B.ones; a.shift = B.zeros;
+            else {   // nn.Identity + activation: dz = dA * act'(z) is the APPLY pass with the constants of an identity "norm":
+                     // mean 0, invstd 1, gamma 1, c = k = 0  =>  dx = dz, sum dx = conv-bias gradient.  ReLU: x := a (mask 1*a + 0 > 0);
+                     // other activations kept the raw accumulations: z = raw*1 + bias (scale, shift of the forward's bias fold)
+                a.mean = B.zeros; a.invstd = B.ones; a.gamma = B.ones;
+                if (cfg.act_slope == 0.f) { a.x = b.act; a.x_ldc = b.act_ldc; a.scale = B.ones; a.shift = B.zeros; }
             }
             if (k == nunits - 1) {      // incoming gradient = that of the 1x1x1 head, recomputed on the fly
                 a.g1 = nullptr; a.head_dy = dy; a.head_w = P(plan->p_final_w); a.head_cout = cfg.out_channels; a.head_S = L[0].vox / N;
@@ -550,7 +561,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             static const bool no_first_fuse = getenv("E3_NO_FIRST_FUSE") != nullptr;     // A/B switch
             fuse_first = k == 0 && !dx && u.cin < 8 && !u.is_up && !no_first_fuse && cfg.normalization != 2;   // (the fused staging has no group terms)
             if (fuse_first) {
-                first_fuse = SmallWgradFuse{a.x, a.x_ldc, a.g1, a.g1_ldc, a.scale, a.shift, a.mean, a.invstd, a.gamma, a.coef, B.biaspart0};
+                first_fuse = SmallWgradFuse{a.x, a.x_ldc, a.g1, a.g1_ldc, a.scale, a.shift, a.mean, a.invstd, a.gamma, a.coef, B.biaspart0, cfg.act_slope};
                 bias_jobs.push_back({B.biaspart0, conv_small_wgrad_splits(N, lo.D, lo.H, lo.W, u.planar), u.cout, 0, u.cout, G(u.p_b)});
             } else {
                 RUN(launch_bn_bwd_apply(a, s));

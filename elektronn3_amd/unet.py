@@ -188,6 +188,28 @@ _LAYERS = {3: (nn.Conv3d, nn.ConvTranspose3d, nn.MaxPool3d, nn.BatchNorm3d),
            2: (nn.Conv2d, nn.ConvTranspose2d, nn.MaxPool2d, nn.BatchNorm2d)}
 
 
+def _activation_slope(activation):
+    """Negative-side slope of the activations on the HIP path (get_activation, unet.py:183-199): 'relu' 0, 'leaky' 0.1
+    (nn.LeakyReLU(negative_slope=0.1)), 'lin' 1 (nn.Identity); module instances of those types are accepted like the reference does
+    (it deep-copies them).  None = not on the HIP path."""
+    if isinstance(activation, str):
+        return {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0}.get(activation)
+    if isinstance(activation, nn.LeakyReLU):
+        return float(activation.negative_slope) if 0.0 <= activation.negative_slope <= 1.0 else None
+    if isinstance(activation, nn.ReLU):
+        return 0.0
+    if isinstance(activation, nn.Identity):
+        return 1.0
+    return None
+
+
+def _make_activation(activation):
+    if isinstance(activation, str):
+        return {'relu': nn.ReLU, 'leaky': lambda: nn.LeakyReLU(negative_slope=0.1), 'lin': nn.Identity}[activation]()
+    import copy
+    return copy.deepcopy(activation)
+
+
 def _norm_factory(normalization, BatchNorm, dim, channels):
     """get_normalization (unet.py:77-105) for the modes on the HIP path."""
     if normalization == 'batch':
@@ -211,7 +233,7 @@ def _num_groups(normalization):
 class DownConv(nn.Module):
     """Parameter container for one encoder block (two convs, two norms, max-pool) -- reference: unet.py:202-253."""
 
-    def __init__(self, in_channels, out_channels, pooling=True, planar=False, dim=3, normalization='batch', full_norm=True):
+    def __init__(self, in_channels, out_channels, pooling=True, planar=False, dim=3, normalization='batch', full_norm=True, activation='relu'):
         super().__init__()
         self.in_channels, self.out_channels, self.pooling, self.planar = in_channels, out_channels, pooling, planar
         self.dim = dim
@@ -224,7 +246,7 @@ class DownConv(nn.Module):
             self.pool = Pool(kernel_size=(1, 2, 2) if (planar and dim == 3) else 2, ceil_mode=True)
         else:
             self.pool = nn.Identity()
-        self.act1, self.act2 = nn.ReLU(), nn.ReLU()
+        self.act1, self.act2 = _make_activation(activation), _make_activation(activation)
         norm = _norm_factory(normalization, Norm, dim, out_channels)                          # get_normalization, unet.py:77-105
         self.norm0 = norm() if full_norm else nn.Identity()                                   # unet.py:238-242
         self.norm1 = norm()
@@ -236,7 +258,7 @@ class DownConv(nn.Module):
 class UpConv(nn.Module):
     """Parameter container for one decoder block (transposed conv, two convs, three norms) -- reference: unet.py:328-408."""
 
-    def __init__(self, in_channels, out_channels, planar=False, dim=3, normalization='batch', full_norm=True, merge_mode='concat'):
+    def __init__(self, in_channels, out_channels, planar=False, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu'):
         super().__init__()
         self.in_channels, self.out_channels, self.planar = in_channels, out_channels, planar
         self.merge_mode = merge_mode
@@ -248,7 +270,7 @@ class UpConv(nn.Module):
         self.upconv = ConvT(in_channels, out_channels, kernel_size=ks, stride=ks)
         self.conv1 = Conv((2 if merge_mode == 'concat' else 1) * out_channels, out_channels, kernel_size=k, padding=p)   # unet.py:352-360
         self.conv2 = Conv(out_channels, out_channels, kernel_size=k, padding=p)
-        self.act0, self.act1, self.act2 = nn.ReLU(), nn.ReLU(), nn.ReLU()
+        self.act0, self.act1, self.act2 = (_make_activation(activation) for _ in range(3))
         norm = _norm_factory(normalization, Norm, dim, out_channels)
         self.norm0 = norm() if full_norm else nn.Identity()                                   # unet.py:369-375
         self.norm1 = norm() if full_norm else nn.Identity()
@@ -263,7 +285,7 @@ class UNet(nn.Module):
     """3D U-Net with the reference's interface (elektronn3/models/unet.py:755-771), executed by hand-written HIP
     kernels.  Options of the reference that are not yet on the HIP path raise ``NotImplementedError`` at
     construction: ``up_mode != 'transpose'``,
-    ``attention=True``, ``activation != 'relu'``,
+    ``attention=True``, ``activation`` other than ``'relu'`` / ``'leaky'`` / ``'lin'``,
     ``conv_mode != 'same'``.  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
     the 3D one with every block planar and a depth of 1."""
 
@@ -311,7 +333,9 @@ class UNet(nn.Module):
         unsupported = []
         if up_mode != 'transpose': unsupported.append(f'up_mode={up_mode!r}')
         if attention: unsupported.append('attention=True')
-        if activation != 'relu': unsupported.append(f'activation={activation!r}')
+        if isinstance(activation, str) and activation not in ('relu', 'leaky', 'prelu', 'rrelu', 'silu', 'lin'):
+            raise ValueError(f'unknown activation {activation!r}')
+        if _activation_slope(activation) is None: unsupported.append(f'activation={activation!r}')
         if normalization is None:
             normalization = 'none'
         if not (normalization in ('none', 'batch', 'instance') or (isinstance(normalization, str) and normalization.startswith('group'))):
@@ -349,12 +373,12 @@ class UNet(nn.Module):
             ins = in_channels if i == 0 else outs
             outs = start_filts * (2 ** i)
             self.down_convs.append(DownConv(ins, outs, pooling=i < n_blocks - 1, planar=i in self.planar_blocks, dim=dim,
-                                            normalization=normalization, full_norm=full_norm))
+                                            normalization=normalization, full_norm=full_norm, activation=activation))
         for i in range(n_blocks - 1):
             ins = outs
             outs = ins // 2
             self.up_convs.append(UpConv(ins, outs, planar=(n_blocks - 2 - i) in self.planar_blocks, dim=dim,
-                                        normalization=normalization, full_norm=full_norm, merge_mode=merge_mode))
+                                        normalization=normalization, full_norm=full_norm, merge_mode=merge_mode, activation=activation))
         self.conv_final = _LAYERS[dim][0](outs, out_channels, kernel_size=1)
         self.apply(self.weight_init)
 
@@ -382,7 +406,7 @@ class UNet(nn.Module):
         eps = next((float(m.eps) for m in self.modules() if isinstance(m, (nn.modules.batchnorm._BatchNorm, nn.GroupNorm))), 1e-5)
         return (self.in_channels, self.out_channels, self.n_blocks, self.start_filts, mask, 2 if self.normalization.startswith('group') else (1 if self.normalization in ('batch', 'instance') else 0), eps,
                 1 if getattr(self, 'full_norm', True) else 0, 1 if self.merge_mode == 'add' else 0,
-                _num_groups(self.normalization) if self.normalization.startswith('group') else 0)
+                _num_groups(self.normalization) if self.normalization.startswith('group') else 0, float(_activation_slope(self.activation)))
 
     def _plan(self):
         return _get_plan(self._plan_key())

@@ -15,6 +15,12 @@ import torch
 import torch.nn.functional as F
 
 
+def _act(x, sd):
+    """get_activation (unet.py:183-199): ReLU unless sd['__act_slope__'] says LeakyReLU(slope) (1.0 = nn.Identity, 'lin')."""
+    s = sd.get('__act_slope__', 0.0)
+    return F.relu(x) if s == 0.0 else F.leaky_relu(x, negative_slope=s)
+
+
 def _bn(x, sd, name, training, momentum=0.1, eps=1e-5):
     if name + '.weight' not in sd:      # no parameters: nn.Identity (normalization='none' / full_norm=False, unet.py:77-80,238-242,
         if name in sd.get('__instance_norms__', ()):     # 369-375) or nn.InstanceNorm3d (affine=False, instance statistics always)
@@ -60,8 +66,8 @@ def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True):
     enc = []
     for i in range(n_blocks):
         p = f'down_convs.{i}.'
-        y = F.relu(_bn(_conv(x, sd, p + 'conv1'), sd, p + 'norm0', training))
-        y = F.relu(_bn(_conv(y, sd, p + 'conv2'), sd, p + 'norm1', training))
+        y = _act(_bn(_conv(x, sd, p + 'conv1'), sd, p + 'norm0', training), sd)
+        y = _act(_bn(_conv(y, sd, p + 'conv2'), sd, p + 'norm1', training), sd)
         enc.append(y)
         if i < n_blocks - 1:
             if y.dim() == 4:
@@ -75,11 +81,11 @@ def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True):
         w = sd[p + 'upconv.weight']
         up = (F.conv_transpose3d if w.dim() == 5 else F.conv_transpose2d)(x, w, sd[p + 'upconv.bias'], stride=tuple(w.shape[2:]))
         skip, up = autocrop(enc[-(i + 2)], up)
-        up = F.relu(_bn(up, sd, p + 'norm0', training))
+        up = _act(_bn(up, sd, p + 'norm0', training), sd)
         cat = sd[p + 'conv1.weight'].shape[1] == 2 * up.shape[1]      # merge_mode 'concat' vs 'add' (unet.py:398-401) shows in conv1's Cin
         y = torch.cat((up, skip), 1) if cat else up + skip
-        y = F.relu(_bn(_conv(y, sd, p + 'conv1'), sd, p + 'norm1', training))
-        x = F.relu(_bn(_conv(y, sd, p + 'conv2'), sd, p + 'norm2', training))
+        y = _act(_bn(_conv(y, sd, p + 'conv1'), sd, p + 'norm1', training), sd)
+        x = _act(_bn(_conv(y, sd, p + 'conv2'), sd, p + 'norm2', training), sd)
     return _conv(x, sd, 'conv_final')
 
 

@@ -253,6 +253,7 @@ class OracleUNet:
         self.planar = tuple(planar_blocks)
         self.norm = normalization
         self.num_groups = 8 if normalization == 'group' else (int(normalization[5:]) if normalization.startswith('group') else 0)
+        self.act_slope = 0.0          # 0 ReLU, 0.1 'leaky', 1.0 'lin' (set by the caller)
         self.instance_norms = ()      # names of the nn.InstanceNorm layers (they have no state_dict entries), set by the caller
         self.momentum, self.eps = momentum, eps
         self.training = True
@@ -291,7 +292,8 @@ class OracleUNet:
                 y = bn_eval_fwd(x, g, b, rm, rv, self.eps)
         else:
             y = x
-        a = relu_fwd(y)
+        # get_activation (unet.py:183-199): 'relu', or LeakyReLU(0.1) ('leaky') / identity ('lin') via act_slope
+        a = relu_fwd(y) if self.act_slope == 0.0 else np.where(y > 0, y, np.float32(self.act_slope) * y).astype(np.float32)
         cache[name + '.act'] = a
         return a
 
@@ -339,7 +341,10 @@ class OracleUNet:
     # -- backward
     def _norm_act_bwd(self, name, da, cache, grads):
         a = cache[name + '.act']
-        dy = relu_bwd(da, a)
+        if self.act_slope == 0.0:
+            dy = relu_bwd(da, a)
+        else:   # sign(a) == sign(pre-activation) for slope > 0
+            dy = (_f32(da) * np.where(a > 0, np.float32(1), np.float32(self.act_slope))).astype(np.float32)
         if self.norm == 'instance' and name in self.instance_norms:
             x, stats = cache[name]
             ones = np.ones(x.shape[1], np.float32)

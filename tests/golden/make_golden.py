@@ -155,10 +155,10 @@ def criterion(loss_mod):
                                   loss_mod.DiceLoss(apply_softmax=True, weight=cw)], weight=[0.5, 0.5])
 
 
-def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True, merge_mode='concat'):
+def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu'):
     torch.manual_seed(seed)
     model = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
-                      planar_blocks=planar_blocks, activation='relu', normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode)
+                      planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode)
     # make BN affine + conv bias non-trivial so that the fixtures exercise them
     with torch.no_grad():
         for name, p in model.named_parameters():
@@ -185,6 +185,8 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
         d['cfg.full_norm'] = np.array(0)
     if merge_mode != 'concat':
         d['cfg.merge_mode'] = np.array(merge_mode)
+    if activation != 'relu':
+        d['cfg.activation'] = np.array(activation)
     for k, v in sd0.items():
         d['sd0/' + k] = v
     for k, v in model.state_dict().items():
@@ -197,7 +199,7 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
         d['logits_eval'] = npy(model(x))
     # fp64 reference of the same step (tolerances are stated against it)
     m64 = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
-                    planar_blocks=planar_blocks, activation='relu', normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode).double()
+                    planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode).double()
     m64.load_state_dict({k: torch.as_tensor(v).double() if v.dtype != np.int64 else torch.as_tensor(v) for k, v in sd0.items()})
     m64.train()
     o64 = m64(x.double())
@@ -301,6 +303,10 @@ if __name__ == '__main__':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_nonorm.npz', seed=4, n_blocks=2, start_filts=8, planar_blocks=(), shape=(10, 13, 18), batch=2, normalization='none')
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_planar0_sparsenorm.npz', seed=5, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 18, 21), batch=2, full_norm=False)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'act':
+        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_leaky_odd.npz', seed=9, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(10, 13, 19), batch=2, activation='leaky')
+        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_lin_nonorm.npz', seed=10, n_blocks=2, start_filts=8, planar_blocks=(), shape=(6, 10, 12), batch=2, activation='lin', normalization='none')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'group':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_group4_odd.npz', seed=8, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 21), batch=2, normalization='group4')
         sys.exit(0)
@@ -331,6 +337,9 @@ if __name__ == '__main__':
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_instance.npz', seed=7, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 17, 20), batch=2, normalization='instance')
     # nn.GroupNorm(4, C) norms (affine, per-sample group statistics, no running stats), odd sizes
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_group4_odd.npz', seed=8, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 21), batch=2, normalization='group4')
+    # other activations: LeakyReLU(0.1) with BatchNorm, identity ('lin') without a norm
+    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_leaky_odd.npz', seed=9, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(10, 13, 19), batch=2, activation='leaky')
+    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_lin_nonorm.npz', seed=10, n_blocks=2, start_filts=8, planar_blocks=(), shape=(6, 10, 12), batch=2, activation='lin', normalization='none')
     make_predictor(unet, inference, f'{HERE}/predictor.npz')
     make_adamw(f'{HERE}/adamw.npz')
     make_trainsteps(unet, loss_mod, f'{HERE}/trainsteps.npz')

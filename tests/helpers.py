@@ -28,6 +28,8 @@ def unet_cfg(npz):
         cfg['dim'] = int(npz['cfg.dim'])
     if 'cfg.normalization' in npz.files:
         cfg['normalization'] = str(npz['cfg.normalization'])
+    if 'cfg.activation' in npz.files:
+        cfg['activation'] = str(npz['cfg.activation'])
     if 'cfg.merge_mode' in npz.files:
         cfg['merge_mode'] = str(npz['cfg.merge_mode'])
     if 'cfg.full_norm' in npz.files:

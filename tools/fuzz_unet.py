@@ -4,7 +4,8 @@ statistics.  fp64 because PyTorch-ROCm's own fp32 batch-norm statistics are only
 which train-mode normalisation then amplifies to 1e-3 in the output (ours agree with fp64 to 4e-11).
 Gradients are only comparable when no ReLU input sits within fp32 rounding of zero: one voxel whose mask flips changes a BN bias
 gradient of these tiny crops by ~1e-2 (verified: the error equals that voxel's incoming gradient exactly).  The fp64 run records the
-smallest |pre-ReLU value|; cases with a margin < 2e-6 get the loose gradient bound, all others the tight one.
+smallest |pre-ReLU value| and the smallest gap between the two largest values of a max-pool window; cases with a margin < 2e-6 get
+the loose gradient bound, all others the tight one.
 Usage: python tools/fuzz_unet.py [n_cases] [seed]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,6 +34,7 @@ for case in range(n_cases):
     elif v == 3: kw = dict(normalization='instance', full_norm=bool(ri(0, 1)))
     elif v == 4: kw = dict(normalization=('group', 'group4', 'group2')[ri(0, 2)], full_norm=bool(ri(0, 1)))
     if ri(0, 3) == 0: kw['merge_mode'] = 'add'
+    if ri(0, 3) == 0: kw['activation'] = ('leaky', 'lin')[ri(0, 1)]
     shape = (H, W) if D is None else (D, H, W)
     torch.manual_seed(case)
     try:
@@ -46,14 +48,30 @@ for case in range(n_cases):
     sd_ref = {k: (v.double() if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd0.items()}
     paramless = R.instance_norm_names(nb, kw.get('full_norm', True)) if kw.get('normalization') == 'instance' else ()
     sd_ref['__instance_norms__'] = paramless
+    sd_ref['__act_slope__'] = {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0}[kw.get('activation', 'relu')]
     group = str(kw.get('normalization', '')).startswith('group')
     sd_ref['__num_groups__'] = (8 if kw['normalization'] == 'group' else int(kw['normalization'][5:])) if group else 0
     margin = [float('inf')]
     def rec_relu(z, *a, **k):
         margin[0] = min(margin[0], float(z.detach().abs().min())); return _relu(z, *a, **k)
-    R.F.relu = rec_relu
+    _leaky = torch.nn.functional.leaky_relu
+    def rec_leaky(z, *a, **k):                      # (a LeakyReLU mask flip changes the local derivative by 0.9 instead of 1)
+        margin[0] = min(margin[0], float(z.detach().abs().min())); return _leaky(z, *a, **k)
+    _mp3, _mp2 = torch.nn.functional.max_pool3d, torch.nn.functional.max_pool2d
+    def rec_pool(fn):                               # arg-max decisions: smallest non-zero gap between a window's two largest values
+        def f(z, **k):                              # (exact ties, e.g. ReLU zeros, resolve identically in both implementations)
+            m1, idx = fn(z, return_indices=True, **k)
+            z2 = z.detach().clone().flatten(2); z2.scatter_(2, idx.flatten(2), float('-inf'))
+            m2 = fn(z2.view_as(z), **k)
+            gap = (m1.detach() - m2)[torch.isfinite(m2)]
+            gap = gap[gap > 0]
+            if gap.numel(): margin[0] = min(margin[0], float(gap.min()))
+            return m1
+        return f
+    R.F.relu = rec_relu; R.F.max_pool3d = rec_pool(_mp3); R.F.max_pool2d = rec_pool(_mp2)
+    if sd_ref['__act_slope__'] == 0.1: R.F.leaky_relu = rec_leaky
     try: ref = unet_forward(sd_ref, x.double(), nb, planar, training=True)
-    finally: R.F.relu = _relu; lref = combined_loss(ref, t, cw); lref.backward()
+    finally: R.F.relu = _relu; R.F.leaky_relu = _leaky; R.F.max_pool3d = _mp3; R.F.max_pool2d = _mp2; lref = combined_loss(ref, t, cw); lref.backward()
     e_out = float((out - ref).detach().abs().max()) / max(1.0, float(ref.abs().max()))
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
     worst, wk = 0.0, ''
