@@ -58,10 +58,18 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     return base + (bid >> 3);
 }
 
-// The network's activation: ReLU (slope 0), LeakyReLU(slope) [get_activation 'leaky' = 0.1, unet.py:183-199] or identity (slope 1,
-// 'lin').  Written so that slope == 0 reproduces fmaxf(z, 0) bit for bit (+0 + -0 = +0) and the mask form stays sign-of-zero clean.
-__device__ __forceinline__ float act_fwd(float z, float slope) { return fmaxf(z, 0.f) + slope * fminf(z, 0.f); }
-__device__ __forceinline__ float act_bwd(float z, float g, float slope) { return z > 0.f ? g : slope * g + 0.f; }
+// The network's activation: ReLU (slope 0), LeakyReLU(slope) [get_activation 'leaky' = 0.1, unet.py:183-199], identity (slope 1,
+// 'lin') or SiLU (ACT_SILU).  Written so that slope == 0 reproduces fmaxf(z, 0) bit for bit (+0 + -0 = +0) and the mask form stays sign-of-zero clean.
+// slope == ACT_SILU selects nn.SiLU ('silu'): z * sigmoid(z), derivative sig * (1 + z * (1 - sig)).
+constexpr float ACT_SILU = 2.f;
+__device__ __forceinline__ float act_fwd(float z, float slope) {
+    if (slope == ACT_SILU) return z / (1.f + expf(-z));
+    return fmaxf(z, 0.f) + slope * fminf(z, 0.f);
+}
+__device__ __forceinline__ float act_bwd(float z, float g, float slope) {     // z = PRE-activation value
+    if (slope == ACT_SILU) { const float sg = 1.f / (1.f + expf(-z)); return g * (sg * (1.f + z * (1.f - sg))); }
+    return z > 0.f ? g : slope * g + 0.f;
+}
 
 // Chan/Welford merge of (count, mean, M2) records; robust for na == 0 or nb == 0.
 __device__ __forceinline__ void welford_merge(float& na, float& ma, float& sa, float nb, float mb, float sb) {

@@ -362,8 +362,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                         // the activation is recomputed, not re-read (a quarter of this pass' HBM traffic): the same expression as the
                         // forward apply, so it is bit-identical to the stored tensor the pooled maxima were taken from
                         f32x4 av;
+                        f32x4 zv;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) av[e] = act_fwd(__builtin_fmaf(xv[e], sc[e], sh[e]), a.slope);
+                        for (int e = 0; e < 4; ++e) { zv[e] = __builtin_fmaf(xv[e], sc[e], sh[e]); av[e] = act_fwd(zv[e], a.slope); }
                         f32x4 g = {0.f, 0.f, 0.f, 0.f};
                         if (a.g1) g = *reinterpret_cast<const f32x4*>(a.g1 + v * a.g1_ldc + 4 * q);
                         f32x4 o;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                         for (int e = 0; e < 4; ++e) {
                             float dA = g[e];
                             if (!taken[e] && av[e] == pm[e]) { dA += gp[e]; taken[e] = true; }   // first arg-max wins (ATen)
-                            const float dz = act_bwd(av[e], dA, a.slope);     // (sign(a) == sign(z) for every slope >= 0)
+                            const float dz = act_bwd(zv[e], dA, a.slope);
                             const float xh = (xv[e] - mu[e]) * is[e];
                             if (APPLYPASS) { o[e] = gi[e] * (dz - c1[e] - xh * c2[e]) - (k1[e] + xh * k2[e]); s3[e] += o[e]; }
                             else { s1[e] += dz; s2[e] += dz * xh; }

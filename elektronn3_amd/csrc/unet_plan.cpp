@@ -246,7 +246,8 @@ int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
     E3_REQUIRE(cfg->out_channels >= 1 && cfg->out_channels <= 8, E3_ERR_UNSUPPORTED, "out_channels must be in 1..8 on the HIP path");
     E3_REQUIRE(cfg->start_filts >= 8 && cfg->start_filts % 8 == 0, E3_ERR_UNSUPPORTED, "start_filts must be a multiple of 8 on the HIP path");
     E3_REQUIRE((cfg->start_filts << (cfg->n_blocks - 1)) <= 1024, E3_ERR_UNSUPPORTED, "more than 1024 channels at the bottom level");
-    E3_REQUIRE(cfg->act_slope >= 0.f && cfg->act_slope <= 1.f, E3_ERR_INVALID, "act_slope must be in [0, 1] (0 ReLU, 0.1 LeakyReLU, 1 identity)");
+    E3_REQUIRE((cfg->act_slope >= 0.f && cfg->act_slope <= 1.f) || cfg->act_slope == ACT_SILU, E3_ERR_INVALID,
+               "act_slope must be in [0, 1] (0 ReLU, 0.1 LeakyReLU, 1 identity) or 2 (SiLU)");
     E3_REQUIRE(cfg->normalization >= 0 && cfg->normalization <= 2, E3_ERR_UNSUPPORTED, "normalization must be 0 (none), 1 (batch) or 2 (group)");
     if (cfg->normalization == 2)
         E3_REQUIRE(cfg->num_groups >= 1 && cfg->start_filts % cfg->num_groups == 0, E3_ERR_INVALID, "num_groups must divide every channel count");

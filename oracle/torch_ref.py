@@ -16,8 +16,10 @@ import torch.nn.functional as F
 
 
 def _act(x, sd):
-    """get_activation (unet.py:183-199): ReLU unless sd['__act_slope__'] says LeakyReLU(slope) (1.0 = nn.Identity, 'lin')."""
+    """get_activation (unet.py:183-199): ReLU unless sd['__act_slope__'] says LeakyReLU(slope) (1.0 = nn.Identity, 'lin'; 2.0 = nn.SiLU)."""
     s = sd.get('__act_slope__', 0.0)
+    if s == 2.0:
+        return F.silu(x)
     return F.relu(x) if s == 0.0 else F.leaky_relu(x, negative_slope=s)
 
 

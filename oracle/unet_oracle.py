@@ -293,7 +293,12 @@ class OracleUNet:
         else:
             y = x
         # get_activation (unet.py:183-199): 'relu', or LeakyReLU(0.1) ('leaky') / identity ('lin') via act_slope
-        a = relu_fwd(y) if self.act_slope == 0.0 else np.where(y > 0, y, np.float32(self.act_slope) * y).astype(np.float32)
+        if self.act_slope == 2.0:      # nn.SiLU: y * sigmoid(y); the backward needs the pre-activation
+            y64 = np.asarray(y, np.float64)
+            a = (y64 / (1.0 + np.exp(-y64))).astype(np.float32)
+            cache[name + '.pre'] = y64
+        else:
+            a = relu_fwd(y) if self.act_slope == 0.0 else np.where(y > 0, y, np.float32(self.act_slope) * y).astype(np.float32)
         cache[name + '.act'] = a
         return a
 
@@ -341,7 +346,10 @@ class OracleUNet:
     # -- backward
     def _norm_act_bwd(self, name, da, cache, grads):
         a = cache[name + '.act']
-        if self.act_slope == 0.0:
+        if self.act_slope == 2.0:
+            z = cache[name + '.pre']; sg = 1.0 / (1.0 + np.exp(-z))
+            dy = (np.asarray(da, np.float64) * sg * (1.0 + z * (1.0 - sg))).astype(np.float32)
+        elif self.act_slope == 0.0:
             dy = relu_bwd(da, a)
         else:   # sign(a) == sign(pre-activation) for slope > 0
             dy = (_f32(da) * np.where(a > 0, np.float32(1), np.float32(self.act_slope))).astype(np.float32)

@@ -307,6 +307,9 @@ if __name__ == '__main__':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_leaky_odd.npz', seed=9, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(10, 13, 19), batch=2, activation='leaky')
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_lin_nonorm.npz', seed=10, n_blocks=2, start_filts=8, planar_blocks=(), shape=(6, 10, 12), batch=2, activation='lin', normalization='none')
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'silu':
+        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_silu_odd.npz', seed=11, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 15, 18), batch=2, activation='silu')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'group':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_group4_odd.npz', seed=8, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 21), batch=2, normalization='group4')
         sys.exit(0)
@@ -340,6 +343,7 @@ if __name__ == '__main__':
     # other activations: LeakyReLU(0.1) with BatchNorm, identity ('lin') without a norm
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_leaky_odd.npz', seed=9, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(10, 13, 19), batch=2, activation='leaky')
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_lin_nonorm.npz', seed=10, n_blocks=2, start_filts=8, planar_blocks=(), shape=(6, 10, 12), batch=2, activation='lin', normalization='none')
+    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_silu_odd.npz', seed=11, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 15, 18), batch=2, activation='silu')
     make_predictor(unet, inference, f'{HERE}/predictor.npz')
     make_adamw(f'{HERE}/adamw.npz')
     make_trainsteps(unet, loss_mod, f'{HERE}/trainsteps.npz')
