@@ -237,3 +237,22 @@ print('RANK_OK' if ok and not left else 'RANK_BAD', dist.get_rank(), left, flush
                         '--master-port', str(port), str(script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count('RANK_OK') == world and 'RANK_BAD' not in r.stdout, r.stdout[-2000:]
+
+
+def test_shared_host_tensor_roundtrip():
+    """The tile-parallel Predictor's shared output buffer (host logic, no GPU): a second mapping of the same /dev/shm file sees the
+    writes of the first, the name can be unlinked while mappings live, dtype/shape views are exact."""
+    import os
+    from elektronn3_amd.inference import _SharedHostTensor
+    a = _SharedHostTensor.create((2, 3, 4, 5, 6), torch.float32)
+    b = _SharedHostTensor.open(a.name, (2, 3, 4, 5, 6), torch.float32)
+    a.tensor.zero_()
+    b.tensor[1, 2, 3] = 7.5
+    assert float(a.tensor[1, 2, 3, 4, 5]) == 7.5 and float(a.tensor.sum()) == 7.5 * 30
+    a.unlink_if_owner(); b.unlink_if_owner()
+    assert not os.path.exists(a.name)
+    a.tensor[0, 0, 0, 0, 0] = 1.0
+    assert float(b.tensor[0, 0, 0, 0, 0]) == 1.0          # mappings outlive the name
+    u = _SharedHostTensor.create((1, 1, 7, 9, 11), torch.uint8)
+    assert u.tensor.dtype == torch.uint8 and tuple(u.tensor.shape) == (1, 1, 7, 9, 11)
+    u.unlink_if_owner()
