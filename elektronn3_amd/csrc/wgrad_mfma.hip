@@ -192,31 +192,86 @@ __global__ __launch_bounds__(256, 2) void wgrad_point_kernel(const WgradArgs a, 
 }
 
 // out[(r*C + c)*T + t] = sum_s part[((s*T + t)*RPad + r)*CPad + c]
-// block = 32 consecutive outputs (one 128-B row segment of a slab) x 8 groups of splits; fixed summation order.
+// thread = (output quad of 4 consecutive c, split group g of G): 16-B loads, 8 of them in flight, double accumulation in a fixed
+// order (k = g, g + G, ... then the G partial sums in order through LDS) => bit-reproducible.  G (a power of two <= 64) is chosen by
+// the launcher so that small layers (27 x 32 x 32 outputs, 256 slabs) still spread over the chip.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int splits, int T,
-                                                           int RPad, int CPad, int R, int C) {
-    __shared__ double red[8][32];
-    const int ctiles = (C + 31) / 32;
+                                                           int RPad, int CPad, int R, int C, int G, int lgG) {
+    __shared__ double red[256][4];
+    const int cq = (C + 3) >> 2;                       // quads per row
     const size_t slab = (size_t)T * RPad * CPad;
-    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const size_t nrows = (size_t)T * R * ctiles;
-    for (size_t row = blockIdx.x; row < nrows; row += gridDim.x) {
-        const int ct = row % ctiles; size_t rr = row / ctiles; const int r = rr % R; const int t = rr / R;
-        const int c = ct * 32 + lane;
-        double s = 0.0;
-        if (c < C) {
-            const float* p = part + ((size_t)t * RPad + r) * CPad + c;
-            for (int k = grp; k < splits; k += 8) s += p[(size_t)k * slab];
-        }
-        red[grp][lane] = s;
-        __syncthreads();
-        if (grp == 0 && c < C) {
-            double tot = 0.0;
+    const size_t nquads = (size_t)T * R * cq;
+    const int g = threadIdx.x & (G - 1);
+    const int qpb = 256 >> lgG;                        // quads per block
+    const size_t quad = (size_t)blockIdx.x * qpb + (threadIdx.x >> lgG);
+    const bool on = quad < nquads;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int c0 = 0, r = 0, t = 0;
+    if (on) {
+        c0 = (int)(quad % cq) * 4; size_t rr = quad / cq; r = (int)(rr % R); t = (int)(rr / R);
+        const float* p = part + ((size_t)t * RPad + r) * CPad + c0;
+        int k = g;
+        for (; k + 7 * G < splits; k += 8 * G) {
+            f32x4 v[8];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) tot += red[g][lane];
-            out[((size_t)r * C + c) * T + t] = (float)tot;
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(k + u * G) * slab);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += (double)v[u][e];
         }
+        for (; k < splits; k += G) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + (size_t)k * slab);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += (double)v[e];
+        }
+    }
+    if (G > 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[threadIdx.x][e] = acc[e];
         __syncthreads();
+        if (g == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { double tot = 0.0; for (int i = 0; i < G; ++i) tot += red[threadIdx.x + i][e]; acc[e] = tot; }
+        }
+    }
+    if (on && g == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c0 + e < C) out[((size_t)r * C + c0 + e) * T + t] = (float)acc[e];
+    }
+}
+
+// rows that are not a multiple of 4 floats (first conv: CPad = in_channels): same scheme with one element per thread; a slab is
+// one contiguous run of T*RPad*CPad floats, so consecutive threads read consecutive addresses
+__global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* __restrict__ part, float* __restrict__ out, int splits, int T,
+                                                                  int RPad, int CPad, int R, int C, int G, int lgG) {
+    __shared__ double red[256];
+    const size_t slab = (size_t)T * RPad * CPad;
+    const int g = threadIdx.x & (G - 1);
+    const size_t i = (size_t)blockIdx.x * (256 >> lgG) + (threadIdx.x >> lgG);     // element of the slab
+    const bool on = i < slab;
+    double acc = 0.0;
+    if (on) {
+        const float* p = part + i;
+        int k = g;
+        for (; k + 7 * G < splits; k += 8 * G) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u * G) * slab];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)v[u];
+        }
+        for (; k < splits; k += G) acc += (double)p[(size_t)k * slab];
+    }
+    if (G > 1) {
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (g == 0) { double tot = 0.0; for (int j = 0; j < G; ++j) tot += red[threadIdx.x + j]; acc = tot; }
+    }
+    if (on && g == 0) {
+        const int c = (int)(i % CPad); const size_t rr = i / CPad; const int r = (int)(rr % RPad); const int t = (int)(rr / RPad);
+        if (c < C && r < R) out[((size_t)r * C + c) * T + t] = (float)acc;
     }
 }
 
@@ -281,8 +336,15 @@ int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s) {
 }
 
 int launch_wgrad_reduce(const float* part, float* out, int splits, int T, int RPad, int CPad, int R, int C, hipStream_t s) {
-    size_t g = (size_t)T * R * ((C + 31) / 32); if (g > 8192) g = 8192; if (g == 0) g = 1;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, part, out, splits, T, RPad, CPad, R, C);
+    const bool vec = CPad % 4 == 0;
+    const size_t items = vec ? (size_t)T * R * ((C + 3) / 4) : (size_t)T * RPad * CPad;     // output quads / slab elements
+    if (items == 0) return E3_OK;
+    int G = 1, lg = 0;                                  // threads per item: enough for ~64 K threads, never more than the splits
+    while (G < 64 && (size_t)G * items < 65536 && 2 * G <= splits) { G *= 2; ++lg; }
+    const size_t ipb = 256 >> lg;
+    const dim3 grid((unsigned)((items + ipb - 1) / ipb));
+    if (vec) hipLaunchKernelGGL(wgrad_reduce_kernel, grid, dim3(256), 0, s, part, out, splits, T, RPad, CPad, R, C, G, lg);
+    else hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, grid, dim3(256), 0, s, part, out, splits, T, RPad, CPad, R, C, G, lg);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
