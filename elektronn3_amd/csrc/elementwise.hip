@@ -498,6 +498,83 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(const ColsumMultiArgs
     if (lane == 0) a.out[j][c] = (float)s;
 }
 
+// ------------------------------------------------------------------ up_mode='resizeconv_nearest' (ResizeConv, unet.py:411-449)
+// nn.Upsample(scale_factor=(sd,2,2), mode='nearest'): out[n, d, h, w] = x[n, d / sd, h >> 1, w >> 1]
+__global__ void upsample_nearest_kernel(const float* __restrict__ x, int x_ldc, float* __restrict__ out, int C, int N, int Di, int Hi, int Wi, int sd) {
+    const int Q = C >> 2, Do = Di * sd, Ho = Hi * 2, Wo = Wi * 2;
+    const size_t total = (size_t)N * Do * Ho * Wo * Q;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % Q); size_t r = i / Q;
+        const int w = (int)(r % Wo); r /= Wo; const int h = (int)(r % Ho); r /= Ho; const int d = (int)(r % Do); const int n = (int)(r / Do);
+        const size_t vi = (((size_t)n * Di + d / sd) * Hi + (h >> 1)) * Wi + (w >> 1);
+        *reinterpret_cast<f32x4*>(out + (i / Q) * C + 4 * q) = *reinterpret_cast<const f32x4*>(x + vi * x_ldc + 4 * q);
+    }
+}
+// its backward: dx[n, d, h, w] = sum of g over the (sd x 2 x 2) block it was copied to, in a fixed order
+__global__ void downsample_sum_kernel(const float* __restrict__ g, float* __restrict__ dx, int dx_ldc, int C, int N, int Di, int Hi, int Wi, int sd) {
+    const int Q = C >> 2, Ho = Hi * 2, Wo = Wi * 2;
+    const size_t total = (size_t)N * Di * Hi * Wi * Q;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % Q); size_t r = i / Q;
+        const int w = (int)(r % Wi); r /= Wi; const int h = (int)(r % Hi); r /= Hi; const int d = (int)(r % Di); const int n = (int)(r / Di);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < sd; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const size_t vo = (((size_t)n * (Di * sd) + d * sd + a) * Ho + 2 * h + b) * Wo + 2 * w + c;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(g + vo * C + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += v[e];
+                }
+        *reinterpret_cast<f32x4*>(dx + (i / Q) * dx_ldc + 4 * q) = acc;
+    }
+}
+// autocrop of the up-convolved tensor (unet.py:289-299: one voxel at the high end where the skip has an odd size), together with the
+// BatchNorm statistics of the CROPPED tensor: src [N, Ds, Hs, Ws, C] -> dst [N, Dd, Hd, Wd, C] (leading box) + one (count, mean, M2)
+// record per workgroup and channel.  Same fixed-pattern block reduction as bn_bwd_kernel.
+__global__ __launch_bounds__(256) void crop_stats_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int N,
+                                                         int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, float* __restrict__ stats) {
+    __shared__ float red[256][3][4];
+    const int Q = C >> 2;
+    const int BT = (256 / Q) * Q;
+    const size_t units = (size_t)N * Dd * Hd * Wd, total = units * Q;
+    const size_t stride = (size_t)gridDim.x * BT;
+    f32x4 cn = {0.f, 0.f, 0.f, 0.f}, mean = cn, m2 = cn;
+    for (size_t i = (size_t)blockIdx.x * BT + threadIdx.x; threadIdx.x < BT && i < total; i += stride) {
+        const int q = (int)(i % Q); size_t r = i / Q;
+        const int w = (int)(r % Wd); r /= Wd; const int h = (int)(r % Hd); r /= Hd; const int d = (int)(r % Dd); const int n = (int)(r / Dd);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((((size_t)n * Ds + d) * Hs + h) * Ws + w) * C + 4 * q);
+        *reinterpret_cast<f32x4*>(dst + (i / Q) * C + 4 * q) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cn[e] += 1.f; const float dl = v[e] - mean[e]; mean[e] += dl / cn[e]; m2[e] += dl * (v[e] - mean[e]); }
+    }
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[tid][0][e] = cn[e]; red[tid][1][e] = mean[e]; red[tid][2][e] = m2[e]; }
+    __syncthreads();
+    for (int t = tid; t < Q * 4; t += 256) {
+        const int e = t & 3, q = t >> 2;
+        float n = 0.f, mu = 0.f, s = 0.f;
+        for (int k = q; k < BT; k += Q) welford_merge(n, mu, s, red[k][0][e], red[k][1][e], red[k][2][e]);
+        float* o = stats + ((size_t)blockIdx.x * C + 4 * q + e) * 3;
+        o[0] = n; o[1] = mu; o[2] = s;
+    }
+}
+// backward of the crop: dst [N, Dd, Hd, Wd, C] = src inside the leading box [Ds, Hs, Ws], zero elsewhere
+__global__ void pad_box_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd) {
+    const int Q = C >> 2;
+    const size_t total = (size_t)N * Dd * Hd * Wd * Q;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % Q); size_t r = i / Q;
+        const int w = (int)(r % Wd); r /= Wd; const int h = (int)(r % Hd); r /= Hd; const int d = (int)(r % Dd); const int n = (int)(r / Dd);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (d < Ds && h < Hs && w < Ws) v = *reinterpret_cast<const f32x4*>(src + ((((size_t)n * Ds + d) * Hs + h) * Ws + w) * C + 4 * q);
+        *reinterpret_cast<f32x4*>(dst + (i / Q) * C + 4 * q) = v;
+    }
+}
+
 // ------------------------------------------------------------------ layout helpers (module boundary only)
 __global__ void ncdhw_to_ndhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, size_t S) {
     const size_t total = (size_t)N * C * S;
@@ -672,6 +749,34 @@ int launch_colsum_multi(const ColsumJob* jobs, int njobs, hipStream_t s) {
         if (b > 0) hipLaunchKernelGGL(colsum_multi_kernel, dim3(b), dim3(256), 0, s, a);
         E3_CHECK_HIP(hipGetLastError());
     }
+    return E3_OK;
+}
+
+int launch_upsample_nearest(const float* x, int x_ldc, float* out, int C, int N, int Di, int Hi, int Wi, int sd, hipStream_t s) {
+    E3_REQUIRE(C % 4 == 0 && x_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
+    hipLaunchKernelGGL(upsample_nearest_kernel, dim3(ew_grid((size_t)N * Di * sd * Hi * 2 * Wi * 2 * (C / 4))), dim3(EW_BLOCK), 0, s, x, x_ldc, out, C, N, Di, Hi, Wi, sd);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+int launch_downsample_sum(const float* g, float* dx, int dx_ldc, int C, int N, int Di, int Hi, int Wi, int sd, hipStream_t s) {
+    E3_REQUIRE(C % 4 == 0 && dx_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
+    hipLaunchKernelGGL(downsample_sum_kernel, dim3(ew_grid((size_t)N * Di * Hi * Wi * (C / 4))), dim3(EW_BLOCK), 0, s, g, dx, dx_ldc, C, N, Di, Hi, Wi, sd);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+int crop_stats_parts(size_t voxels, int C) { return bn_bwd_parts(voxels, C); }
+int launch_crop_stats(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, float* stats, hipStream_t s) {
+    E3_REQUIRE(C % 4 == 0 && C <= 1024, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4, at most 1024");
+    E3_REQUIRE(Dd <= Ds && Hd <= Hs && Wd <= Ws, E3_ERR_INVALID, "crop box larger than the source");
+    const int parts = crop_stats_parts((size_t)N * Dd * Hd * Wd, C);
+    hipLaunchKernelGGL(crop_stats_kernel, dim3(parts), dim3(256), 0, s, src, dst, C, N, Ds, Hs, Ws, Dd, Hd, Wd, stats);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+int launch_pad_box(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, hipStream_t s) {
+    E3_REQUIRE(C % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
+    hipLaunchKernelGGL(pad_box_kernel, dim3(ew_grid((size_t)N * Dd * Hd * Wd * (C / 4))), dim3(EW_BLOCK), 0, s, src, dst, C, N, Ds, Hs, Ws, Dd, Hd, Wd);
+    E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
 

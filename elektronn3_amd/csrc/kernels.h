@@ -119,6 +119,13 @@ int launch_ce_dice_fwd(const float* logits, const long long* target, const float
 int launch_ce_dice_bwd(const float* logits, const long long* target, const float* w, int C, int N, size_t vps,
                        const float* workspace, const float* gout, float* dlogits, hipStream_t s);
 
+// up_mode='resizeconv_*' building blocks (elementwise.hip): nearest up-sampling by (sd,2,2) and its backward, the autocrop of the
+// up-convolved tensor fused with the statistics of the cropped tensor (records [crop_stats_parts][C][3]) and its backward
+int launch_upsample_nearest(const float* x, int x_ldc, float* out, int C, int N, int Di, int Hi, int Wi, int sd, hipStream_t s);
+int launch_downsample_sum(const float* g, float* dx, int dx_ldc, int C, int N, int Di, int Hi, int Wi, int sd, hipStream_t s);
+int crop_stats_parts(size_t voxels, int C);
+int launch_crop_stats(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, float* stats, hipStream_t s);
+int launch_pad_box(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, hipStream_t s);
 constexpr int FOLD_MAX_JOBS = 40;
 struct FoldJob { const float *gamma, *beta, *rm, *rv, *bias; float *scale, *shift; int C; };   // gamma == nullptr: no norm (scale 1, shift bias)
 int launch_fold_multi(const FoldJob* jobs, int njobs, float eps, hipStream_t s);   // eval-mode BN folds / bias folds of all conv units at once

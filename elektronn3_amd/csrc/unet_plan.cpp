@@ -25,7 +25,7 @@ struct ConvUnit {           // conv (3x3x3 | 1x3x3 | transposed 2x2x2) followed 
     std::string bn_name;    // e.g. "down_convs.0.norm0"
     int cin, cout, level;   // level = resolution level of the OUTPUT
     int planar;             // planar block (1x3x3 / (1,2,2))
-    int is_up;              // transposed conv (input at level+1)
+    int is_up;              // 1: transposed conv, 2: ResizeConv = nearest up-sampling + 3x3x3 conv (input at level+1); 0: plain conv
     int p_w, p_b, p_g, p_be, p_rm, p_rv;   // indices into the param table
     int bn_index;           // -1: no normalisation after this conv (nn.Identity): conv -> bias -> ReLU
     bool has_norm() const { return bn_index >= 0; }
@@ -71,7 +71,7 @@ void add_unit(e3_unet_plan* p, const std::string& conv, const std::string& bn, i
     const bool group = p->cfg.normalization == 2;    // nn.GroupNorm: weight and bias only, no running statistics
     ConvUnit u;
     u.name = conv; u.bn_name = bn; u.cin = cin; u.cout = cout; u.level = level; u.planar = planar; u.is_up = is_up;
-    const int taps = is_up ? (planar ? 4 : 8) : (planar ? 9 : 27);
+    const int taps = is_up == 1 ? (planar ? 4 : 8) : (planar ? 9 : 27);
     u.p_w = add_param(p, conv + ".weight", (int64_t)cin * cout * taps, 0);
     u.p_b = add_param(p, conv + ".bias", cout, 0);
     u.p_g = u.p_be = u.p_rm = u.p_rv = -1; u.bn_index = -1;
@@ -111,6 +111,8 @@ struct Buffers {
     float* wpack; float* stats; float* bnpart; float* slab; float* small;   // small: coef / fold vectors
     float* bnred;                                                              // pre-merged BN statistic records
     float* ones; float* zeros;                                                 // [Cmax] / [2*Cmax] constants for units without a norm
+    std::vector<float*> ups;             // ResizeConv units: the up-sampled input [N, sd*D', 2H', 2W', Cin] (kept for the weight gradient)
+    float* rtmp; float* rpad; float* rdu; // ResizeConv scratch: conv output / padded gradient at the up-sampled size, gradient of the up-sampled input
     float* biaspart0;                    // [splits][Cout] conv-bias gradient partials of the first conv when its BN backward is fused into its wgrad
     std::vector<float*> bnpart_u;        // per unit: block partials of the BN backward [parts][3][C]; row 2 (sum dx = conv-bias gradient) is summed for all units at once
     std::vector<float*> wpk_f, wpk_d;    // per unit: Winograd-transformed weights (forward / dgrad form), all packed by ONE launch; nullptr = packed on the spot into wpack
@@ -129,6 +131,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     Arena S(saved), T(scratch);
     B.ub.assign(p->units.size(), UnitBufs{});
     B.cat.assign(nb, nullptr); B.pooled.assign(nb, nullptr); B.sum.assign(nb, nullptr);
+    B.ups.assign(p->units.size(), nullptr); B.rtmp = B.rpad = B.rdu = nullptr;
     B.g1.assign(nb, nullptr); B.g2.assign(nb, nullptr); B.dcat.assign(nb, nullptr);
     B.xin = nullptr; B.evalA = B.evalB = nullptr;
     Arena& A = training ? S : T;   // in inference everything is scratch
@@ -144,7 +147,11 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         const size_t n = L[u.level].vox * u.cout;
         // without batch statistics to wait for, the conv writes relu(acc*scale + shift) directly; other activations are not in the conv
         // epilogues and take the two-pass route (raw tensor, then the apply pass)
-        b.raw = ((training && u.has_norm()) || p->cfg.act_slope != 0.f) ? A.take(n) : nullptr;
+        b.raw = ((training && u.has_norm()) || p->cfg.act_slope != 0.f || u.is_up == 2) ? A.take(n) : nullptr;
+        if (u.is_up == 2) {
+            const LevelDims& li = L[u.level + 1];
+            B.ups[k] = A.take((size_t)N * li.D * (u.planar ? 1 : 2) * li.H * 2 * li.W * 2 * u.cin);
+        }
         // where does the activation go?
         const bool enc_skip = !u.is_up && u.name.find("down_convs") == 0 && u.name.find("conv2") != std::string::npos && u.level < nb - 1;
         if (enc_skip) { b.act = B.cat[u.level] ? B.cat[u.level] + u.cout : nullptr; b.act_ldc = 2 * u.cout; }
@@ -155,10 +162,20 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     }
     B.saved_bytes = S.off;
     // scratch
-    size_t wmax = 0, statmax = 0, slabmax = 0, bnpartmax = 0;
+    size_t wmax = 0, statmax = 0, slabmax = 0, bnpartmax = 0, rtmpmax = 0, rdumax = 0;
     for (const ConvUnit& u : p->units) {
         const LevelDims& lo = L[u.level];
-        if (u.is_up) {
+        if (u.is_up == 2) {      // ResizeConv: a 3x3x3 / 1x3x3 conv on the up-sampled grid
+            const LevelDims& li = L[u.level + 1];
+            const int Ud = li.D * (u.planar ? 1 : 2), Uh = li.H * 2, Uw = li.W * 2, taps = u.planar ? 9 : 27;
+            const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
+            const size_t uvox = (size_t)N * Ud * Uh * Uw;
+            wmax = max_sz(wmax, max_sz(conv_packed_floats(kind, u.cin, u.cout), conv_packed_floats(kind, u.cout, u.cin)));
+            statmax = max_sz(statmax, (size_t)conv_stats_parts(kind, 0, N, Ud, Uh, Uw, 2, u.cin, u.cout) * u.cout * 3);
+            statmax = max_sz(statmax, (size_t)crop_stats_parts(lo.vox, u.cout) * u.cout * 3);
+            rtmpmax = max_sz(rtmpmax, uvox * u.cout); rdumax = max_sz(rdumax, uvox * u.cin);
+            if (training) slabmax = max_sz(slabmax, (size_t)wgrad_splits(kind, N, Ud, Uh, Uw, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32));
+        } else if (u.is_up) {
             const int sd = u.planar ? 1 : 2, taps = sd * 4;
             const LevelDims& li = L[u.level + 1];
             wmax = max_sz(wmax, max_sz((size_t)pad_cols(taps * u.cout) * u.cin, (size_t)taps * pad_cols(u.cin) * u.cout));
@@ -184,6 +201,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         slabmax = max_sz(slabmax, (size_t)conv_final_bwd_parts(L[0].vox) * (p->cfg.out_channels * C0 + p->cfg.out_channels));
     }
     B.wpack = T.take(wmax);
+    if (rtmpmax) { B.rtmp = T.take(rtmpmax); if (training) { B.rpad = T.take(rtmpmax); B.rdu = T.take(rdumax); } }
     B.wpk_f.assign(p->units.size(), nullptr); B.wpk_d.assign(p->units.size(), nullptr);
     for (size_t k = 0; k < p->units.size(); ++k) {
         const ConvUnit& u = p->units[k];
@@ -266,7 +284,7 @@ int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
         const int j = nb - 2 - k;
         const std::string b = "up_convs." + std::to_string(k) + ".";
         const int ins = p->chan(j + 1), outs = p->chan(j);
-        add_unit(p, b + "upconv", b + "norm0", ins, outs, j, p->planar(j), 1, all_norm);    // unet.py:369-375
+        add_unit(p, b + (cfg->up_resize ? "upconv.conv" : "upconv"), b + "norm0", ins, outs, j, p->planar(j), cfg->up_resize ? 2 : 1, all_norm);   // unet.py:152-176,369-375
         add_unit(p, b + "conv1", b + "norm1", cfg->merge_add ? outs : 2 * outs, outs, j, p->planar(j), 0, all_norm);   // unet.py:352-360
         add_unit(p, b + "conv2", b + "norm2", outs, outs, j, p->planar(j), 0, last_norm);
     }
@@ -310,7 +328,7 @@ int e3_unet_conv_info(const e3_unet_plan* plan, int layer, char* name, int name_
     if (name && name_len > 0) snprintf(name, name_len, "%s", u.name.c_str());
     if (cin) *cin = u.cin;
     if (cout) *cout = u.cout;
-    if (taps) *taps = u.is_up ? (u.planar ? 4 : 8) : (u.planar ? 9 : 27);
+    if (taps) *taps = u.is_up == 1 ? (u.planar ? 4 : 8) : (u.planar ? 9 : 27);
     if (level) *level = u.level;
     return E3_OK;
 }
@@ -388,7 +406,8 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         const int kd = u.planar ? 1 : 2;
         const float slope = cfg.act_slope;
         const bool bn_train = training && u.has_norm();   // batch statistics needed: conv writes the raw output, BN+ReLU is a second pass
-        const bool two_pass = bn_train || slope != 0.f;   // (non-ReLU activations are not in the conv epilogues)
+        const bool two_pass = bn_train || slope != 0.f || u.is_up == 2;   // (non-ReLU activations are not in the conv epilogues; the
+                                                                           // ResizeConv output may need the autocrop before the norm)
         float* dst = two_pass ? b.raw : b.act;            // otherwise the conv writes the activation directly
         const int dst_ldc = two_pass ? u.cout : b.act_ldc;
         const float* es = nullptr; const float* eh = nullptr;
@@ -396,7 +415,25 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             es = b.scale; eh = b.shift;                    // epilogue (running stats) -- constants from the launch above
         }
         int parts = 0;
-        if (u.is_up) {
+        if (u.is_up == 2) {      // ResizeConv (unet.py:411-449): nn.Upsample(nearest) then conv3 on the up-sampled grid, autocrop afterwards
+            const LevelDims& li = L[u.level + 1];
+            const int sd = u.planar ? 1 : 2, Ud = li.D * sd, Uh = li.H * 2, Uw = li.W * 2, NPad = pad_cols(u.cout);
+            const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
+            const bool same = Ud == lo.D && Uh == lo.H && Uw == lo.W;
+            RUN(launch_upsample_nearest(cur, cur_ldc, B.ups[k], u.cin, N, li.D, li.H, li.W, sd, s));
+            RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, Ud, Uh, Uw, 0, s));
+            ConvArgs a{};
+            a.x = B.ups[k]; a.x_ldc = u.cin; a.Cin = u.cin; a.wt = B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
+            a.y = same ? b.raw : B.rtmp; a.y_ldc = u.cout; a.N = N; a.D = Ud; a.H = Uh; a.W = Uw; a.sd = 2;
+            a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.G = 1; a.flags = 0;
+            a.stats = (bn_train && same) ? B.stats : nullptr;
+            parts = conv_stats_parts(kind, 0, N, Ud, Uh, Uw, 2, u.cin, u.cout);
+            { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(kind, a, s)); }
+            if (!same) {             // crop one voxel at the high end where the skip has an odd size (unet.py:289-299) + statistics
+                RUN(launch_crop_stats(B.rtmp, b.raw, u.cout, N, Ud, Uh, Uw, lo.D, lo.H, lo.W, B.stats, s));
+                parts = crop_stats_parts(lo.vox, u.cout);
+            }
+        } else if (u.is_up) {
             const LevelDims& li = L[u.level + 1];
             const int sd = u.planar ? 1 : 2, taps = sd * 4, NPad = pad_cols(taps * u.cout);
             RUN(launch_pack_weights(PACK_UP_FWD, P(u.p_w), B.wpack, u.cout, u.cin, taps, NPad, s));
@@ -584,7 +621,22 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             }
         }
         // -- weight gradient
-        if (u.is_up) {
+        const float* dyu = dxr;      // ResizeConv: gradient of the conv output on the up-sampled grid (zero in the cropped-away voxels)
+        if (u.is_up == 2) {
+            const LevelDims& li = L[j + 1];
+            const int Ud = li.D * (u.planar ? 1 : 2), Uh = li.H * 2, Uw = li.W * 2, taps = u.planar ? 9 : 27;
+            const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
+            if (!(Ud == lo.D && Uh == lo.H && Uw == lo.W)) {
+                RUN(launch_pad_box(dxr, B.rpad, u.cout, N, lo.D, lo.H, lo.W, Ud, Uh, Uw, s));
+                dyu = B.rpad;
+            }
+            WgradArgs a{};
+            a.x = B.ups[k]; a.x_ldc = u.cin; a.Cin = u.cin; a.dy = dyu; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = B.slab;
+            a.N = N; a.D = Ud; a.H = Uh; a.W = Uw; a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
+            a.splits = wgrad_splits(kind, N, Ud, Uh, Uw, u.cin, u.cout);
+            { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(kind, a, s)); }
+            RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
+        } else if (u.is_up) {
             const LevelDims& li = L[j + 1];
             const int sd = u.planar ? 1 : 2;
             WgradArgs a{};
@@ -611,7 +663,20 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         }
         // -- data gradient -> g for the previous unit
         if (k == 0 && !dx) break;
-        if (u.is_up) {
+        if (u.is_up == 2) {      // conv dgrad on the up-sampled grid, then the sum over each (sd x 2 x 2) block = backward of nn.Upsample(nearest)
+            const LevelDims& li = L[j + 1];
+            const int sd = u.planar ? 1 : 2, Ud = li.D * sd, Uh = li.H * 2, Uw = li.W * 2, NPad = pad_cols(u.cin);
+            const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
+            RUN(launch_pack_conv_auto(kind, 1, P(u.p_w), B.wpack, u.cout, u.cin, N, Ud, Uh, Uw, 0, s));
+            ConvArgs a{};
+            a.x = dyu; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = B.wpack; a.y = B.rdu; a.y_ldc = u.cin;
+            a.N = N; a.D = Ud; a.H = Uh; a.W = Uw; a.sd = 2;
+            a.Cout = u.cin; a.Ncols = u.cin; a.NPad = NPad; a.G = 1;
+            a.flags = (bucket_event != nullptr && event_done) ? CF_NO_PERSIST : 0;
+            { Prof pr(plan, s, k, 1); RUN(launch_conv_mfma(kind, a, s)); }
+            RUN(launch_downsample_sum(B.rdu, B.g1[j + 1], u.cin, u.cin, N, li.D, li.H, li.W, sd, s));
+            g = B.g1[j + 1]; g_ldc = u.cin;
+        } else if (u.is_up) {
             const LevelDims& li = L[j + 1];
             const int sd = u.planar ? 1 : 2, taps = sd * 4, NPad = pad_cols(u.cin);
             RUN(launch_pack_weights(PACK_UP_DGRAD, P(u.p_w), B.wpack, u.cout, u.cin, taps, NPad, s));

@@ -80,8 +80,13 @@ def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True):
             x = y
     for i in range(n_blocks - 1):
         p = f'up_convs.{i}.'
-        w = sd[p + 'upconv.weight']
-        up = (F.conv_transpose3d if w.dim() == 5 else F.conv_transpose2d)(x, w, sd[p + 'upconv.bias'], stride=tuple(w.shape[2:]))
+        if p + 'upconv.conv.weight' in sd:      # up_mode='resizeconv_nearest': ResizeConv = nn.Upsample(nearest) + conv3 (unet.py:411-449)
+            w = sd[p + 'upconv.conv.weight']
+            scale = (1, 2, 2) if (w.dim() == 5 and w.shape[2] == 1) else 2
+            up = _conv(F.interpolate(x, scale_factor=scale, mode='nearest'), sd, p + 'upconv.conv')
+        else:
+            w = sd[p + 'upconv.weight']
+            up = (F.conv_transpose3d if w.dim() == 5 else F.conv_transpose2d)(x, w, sd[p + 'upconv.bias'], stride=tuple(w.shape[2:]))
         skip, up = autocrop(enc[-(i + 2)], up)
         up = _act(_bn(up, sd, p + 'norm0', training), sd)
         cat = sd[p + 'conv1.weight'].shape[1] == 2 * up.shape[1]      # merge_mode 'concat' vs 'add' (unet.py:398-401) shows in conv1's Cin

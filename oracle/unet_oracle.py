@@ -323,9 +323,19 @@ class OracleUNet:
         for i in range(self.n_blocks - 1):  # UpConv.forward, unet.py:384-408
             p = f'up_convs.{i}.'
             before_pool = enc[-(i + 2)]
-            w, b = self.sd[p + 'upconv.weight'], self.sd[p + 'upconv.bias']
-            cache[p + 'upconv'] = x
-            up = convT_fwd(x, w, b)
+            if (p + 'upconv.conv.weight') in self.sd:
+                # up_mode='resizeconv_nearest' (ResizeConv, unet.py:411-449): nn.Upsample(scale_factor, 'nearest') = every voxel
+                # repeated (sd, 2, 2) times, then a 'same' 3x3x3 / 1x3x3 convolution on the up-sampled grid
+                w, b = self.sd[p + 'upconv.conv.weight'], self.sd[p + 'upconv.conv.bias']
+                sd_ = 1 if w.shape[2] == 1 else 2
+                xu = np.ascontiguousarray(x.repeat(sd_, axis=2).repeat(2, axis=3).repeat(2, axis=4))
+                pad = tuple((k - 1) // 2 for k in w.shape[2:])
+                cache[p + 'upconv'] = (xu, pad, sd_)
+                up = conv3d_fwd(xu, w, b, pad)
+            else:
+                w, b = self.sd[p + 'upconv.weight'], self.sd[p + 'upconv.bias']
+                cache[p + 'upconv'] = x
+                up = convT_fwd(x, w, b)
             cache[p + 'up_full_shape'] = up.shape
             before_pool, up, dn_sl, up_sl = autocrop(before_pool, up)
             cache[p + 'crop'] = (dn_sl, up_sl, enc[-(i + 2)].shape, None)
@@ -404,9 +414,16 @@ class OracleUNet:
                 full = np.zeros(cache[p + 'up_full_shape'], np.float32)
                 full[up_sl] = dup
                 dup = full
-            xin = cache[p + 'upconv']
-            d, dw, db = convT_bwd(xin, self.sd[p + 'upconv.weight'], dup)
-            grads[p + 'upconv.weight'], grads[p + 'upconv.bias'] = dw, db
+            if (p + 'upconv.conv.weight') in self.sd:
+                xu, pad, sd_ = cache[p + 'upconv']
+                dxu, dw, db = conv3d_bwd(xu, self.sd[p + 'upconv.conv.weight'], np.ascontiguousarray(dup), pad, True)
+                grads[p + 'upconv.conv.weight'], grads[p + 'upconv.conv.bias'] = dw, db
+                N_, C_, D_, H_, W_ = dxu.shape     # backward of the nearest up-sampling: sum over each (sd, 2, 2) block
+                d = dxu.astype(np.float64).reshape(N_, C_, D_ // sd_, sd_, H_ // 2, 2, W_ // 2, 2).sum(axis=(3, 5, 7)).astype(np.float32)
+            else:
+                xin = cache[p + 'upconv']
+                d, dw, db = convT_bwd(xin, self.sd[p + 'upconv.weight'], dup)
+                grads[p + 'upconv.weight'], grads[p + 'upconv.bias'] = dw, db
         for i in reversed(range(self.n_blocks)):
             p = f'down_convs.{i}.'
             if i < self.n_blocks - 1:

@@ -155,10 +155,10 @@ def criterion(loss_mod):
                                   loss_mod.DiceLoss(apply_softmax=True, weight=cw)], weight=[0.5, 0.5])
 
 
-def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu'):
+def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu', up_mode='transpose'):
     torch.manual_seed(seed)
     model = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
-                      planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode)
+                      planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode)
     # make BN affine + conv bias non-trivial so that the fixtures exercise them
     with torch.no_grad():
         for name, p in model.named_parameters():
@@ -187,6 +187,8 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
         d['cfg.merge_mode'] = np.array(merge_mode)
     if activation != 'relu':
         d['cfg.activation'] = np.array(activation)
+    if up_mode != 'transpose':
+        d['cfg.up_mode'] = np.array(up_mode)
     for k, v in sd0.items():
         d['sd0/' + k] = v
     for k, v in model.state_dict().items():
@@ -199,7 +201,7 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
         d['logits_eval'] = npy(model(x))
     # fp64 reference of the same step (tolerances are stated against it)
     m64 = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
-                    planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode).double()
+                    planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode).double()
     m64.load_state_dict({k: torch.as_tensor(v).double() if v.dtype != np.int64 else torch.as_tensor(v) for k, v in sd0.items()})
     m64.train()
     o64 = m64(x.double())
@@ -307,6 +309,9 @@ if __name__ == '__main__':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_leaky_odd.npz', seed=9, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(10, 13, 19), batch=2, activation='leaky')
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_lin_nonorm.npz', seed=10, n_blocks=2, start_filts=8, planar_blocks=(), shape=(6, 10, 12), batch=2, activation='lin', normalization='none')
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'resize':
+        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizeconv_odd.npz', seed=12, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 19), batch=2, up_mode='resizeconv_nearest')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'silu':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_silu_odd.npz', seed=11, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 15, 18), batch=2, activation='silu')
         sys.exit(0)
@@ -344,6 +349,8 @@ if __name__ == '__main__':
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_leaky_odd.npz', seed=9, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(10, 13, 19), batch=2, activation='leaky')
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_lin_nonorm.npz', seed=10, n_blocks=2, start_filts=8, planar_blocks=(), shape=(6, 10, 12), batch=2, activation='lin', normalization='none')
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_silu_odd.npz', seed=11, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 15, 18), batch=2, activation='silu')
+    # up_mode='resizeconv_nearest' (nearest up-sampling + conv3 instead of the transposed conv), odd sizes, planar first block
+    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizeconv_odd.npz', seed=12, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 19), batch=2, up_mode='resizeconv_nearest')
     make_predictor(unet, inference, f'{HERE}/predictor.npz')
     make_adamw(f'{HERE}/adamw.npz')
     make_trainsteps(unet, loss_mod, f'{HERE}/trainsteps.npz')

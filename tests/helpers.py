@@ -28,6 +28,8 @@ def unet_cfg(npz):
         cfg['dim'] = int(npz['cfg.dim'])
     if 'cfg.normalization' in npz.files:
         cfg['normalization'] = str(npz['cfg.normalization'])
+    if 'cfg.up_mode' in npz.files:
+        cfg['up_mode'] = str(npz['cfg.up_mode'])
     if 'cfg.activation' in npz.files:
         cfg['activation'] = str(npz['cfg.activation'])
     if 'cfg.merge_mode' in npz.files:
@@ -44,7 +46,10 @@ def is_prebn_bias(k, names=None, paramless_norms=()):
         return False
     if names is None:
         return True
-    block, conv = k[:-len('.bias')].rsplit('.', 1)
+    stem = k[:-len('.bias')]
+    if stem.endswith('.upconv.conv'):           # ResizeConv (up_mode='resizeconv_*'): the conv lives one level deeper
+        stem = stem[:-len('.conv')]
+    block, conv = stem.rsplit('.', 1)
     if block.startswith('down_convs'):
         norm = {'conv1': 'norm0', 'conv2': 'norm1'}[conv]
     else:

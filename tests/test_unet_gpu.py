@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz', 'unet2d_nb3_sf8_odd.npz',
          'unet_nb2_sf8_nonorm.npz', 'unet_nb3_sf8_planar0_sparsenorm.npz', 'unet_nb3_sf8_add_odd.npz', 'unet_nb3_sf8_instance.npz',
          'unet_nb3_sf8_group4_odd.npz', 'unet_nb3_sf8_leaky_odd.npz', 'unet_nb2_sf8_lin_nonorm.npz',
-         'unet_nb3_sf8_silu_odd.npz']
+         'unet_nb3_sf8_silu_odd.npz', 'unet_nb3_sf8_resizeconv_odd.npz']
 
 
 def build(cfg, sd_np):
@@ -247,9 +247,10 @@ def test_full_size_cfg4_anisotropic_against_pytorch_rocm():
                                 dict(normalization='group16', full_norm=False, merge_mode='add'),
                                 dict(activation='leaky'), dict(activation='leaky', normalization='none', planar_blocks=(0,)),
                                 dict(activation='lin', normalization='group', full_norm=False),
-                                dict(activation='silu', planar_blocks=(0,)), dict(activation='silu', normalization='none')],
+                                dict(activation='silu', planar_blocks=(0,)), dict(activation='silu', normalization='none'),
+                                dict(up_mode='resizeconv_nearest'), dict(up_mode='resizeconv_nearest', planar_blocks=(0,), normalization='group', full_norm=False)],
                          ids=['nonorm', 'sparsenorm', 'add', 'add_nonorm_planar', 'instance', 'group8', 'group16_sparse_add',
-                              'leaky', 'leaky_nonorm_planar', 'lin_group', 'silu_planar', 'silu_nonorm'])
+                              'leaky', 'leaky_nonorm_planar', 'lin_group', 'silu_planar', 'silu_nonorm', 'resizeconv', 'resizeconv_planar_group_sparse'])
 def test_option_variants_against_pytorch_rocm(kw):
     """normalization='none' and full_norm=False (norm layers = nn.Identity, unet.py:77-80,238-242,369-375) at a size that runs the
     Winograd kernels (conv -> bias -> ReLU fused in their epilogue, also in training), and merge_mode='add' (unet.py:398-401: the skip

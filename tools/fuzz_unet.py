@@ -34,6 +34,7 @@ for case in range(n_cases):
     elif v == 3: kw = dict(normalization='instance', full_norm=bool(ri(0, 1)))
     elif v == 4: kw = dict(normalization=('group', 'group4', 'group2')[ri(0, 2)], full_norm=bool(ri(0, 1)))
     if ri(0, 3) == 0: kw['merge_mode'] = 'add'
+    if ri(0, 3) == 0: kw['up_mode'] = 'resizeconv_nearest'
     if ri(0, 3) == 0: kw['activation'] = ('leaky', 'lin', 'silu')[ri(0, 2)]
     shape = (H, W) if D is None else (D, H, W)
     torch.manual_seed(case)
