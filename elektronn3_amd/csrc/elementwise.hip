@@ -531,6 +531,76 @@ __global__ void downsample_sum_kernel(const float* __restrict__ g, float* __rest
         *reinterpret_cast<f32x4*>(dx + (i / Q) * dx_ldc + 4 * q) = acc;
     }
 }
+// nn.Upsample(scale_factor=(sd,2,2), mode='trilinear' / 'bilinear', align_corners=False): per axis with scale 2 the source coordinate of
+// output o is max((o + 0.5)/2 - 0.5, 0); i0 = floor, i1 = min(i0 + 1, n - 1), weights (1 - l, l): out[0] = x[0], out[2i+1] = .75 x[i] + .25 x[i+1],
+// out[2i] = .25 x[i-1] + .75 x[i], clamped at the high end.  An axis with scale 1 is the identity.
+__device__ __forceinline__ void lin_src(int o, int n, int scale, int& i0, int& i1, float& l) {
+    if (scale == 1) { i0 = i1 = o; l = 0.f; return; }
+    const float src = fmaxf(((float)o + 0.5f) * 0.5f - 0.5f, 0.f);
+    i0 = (int)src; i1 = i0 + 1 < n ? i0 + 1 : n - 1; l = src - (float)i0;
+}
+__global__ void upsample_linear_kernel(const float* __restrict__ x, int x_ldc, float* __restrict__ out, int C, int N, int Di, int Hi, int Wi, int sd) {
+    const int Q = C >> 2, Do = Di * sd, Ho = Hi * 2, Wo = Wi * 2;
+    const size_t total = (size_t)N * Do * Ho * Wo * Q;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % Q); size_t r = i / Q;
+        const int w = (int)(r % Wo); r /= Wo; const int h = (int)(r % Ho); r /= Ho; const int d = (int)(r % Do); const int n = (int)(r / Do);
+        int d0, d1, h0, h1, w0, w1; float ld, lh, lw;
+        lin_src(d, Di, sd, d0, d1, ld); lin_src(h, Hi, 2, h0, h1, lh); lin_src(w, Wi, 2, w0, w1, lw);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float wt = (a ? ld : 1.f - ld) * (b ? lh : 1.f - lh) * (c ? lw : 1.f - lw);
+                    const size_t vi = (((size_t)n * Di + (a ? d1 : d0)) * Hi + (b ? h1 : h0)) * Wi + (c ? w1 : w0);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + vi * x_ldc + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(wt, v[e], acc[e]);
+                }
+        *reinterpret_cast<f32x4*>(out + (i / Q) * C + 4 * q) = acc;
+    }
+}
+// its backward as a GATHER (fixed order, no atomics): input voxel i is referenced only by outputs 2i-1 .. 2i+2 of an axis
+__global__ void downsample_linear_kernel(const float* __restrict__ g, float* __restrict__ dx, int dx_ldc, int C, int N, int Di, int Hi, int Wi, int sd) {
+    const int Q = C >> 2, Do = Di * sd, Ho = Hi * 2, Wo = Wi * 2;
+    const size_t total = (size_t)N * Di * Hi * Wi * Q;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % Q); size_t r = i / Q;
+        const int w = (int)(r % Wi); r /= Wi; const int h = (int)(r % Hi); r /= Hi; const int d = (int)(r % Di); const int n = (int)(r / Di);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int nd = sd == 1 ? 1 : 4;
+        for (int a = 0; a < nd; ++a) {
+            const int od = sd == 1 ? d : 2 * d - 1 + a;
+            if (od < 0 || od >= Do) continue;
+            int i0, i1; float l; lin_src(od, Di, sd, i0, i1, l);
+            const float wd = (i0 == d ? 1.f - l : 0.f) + (i1 == d ? l : 0.f);
+            if (wd == 0.f) continue;
+            for (int b = 0; b < 4; ++b) {
+                const int oh = 2 * h - 1 + b;
+                if (oh < 0 || oh >= Ho) continue;
+                lin_src(oh, Hi, 2, i0, i1, l);
+                const float wh = (i0 == h ? 1.f - l : 0.f) + (i1 == h ? l : 0.f);
+                if (wh == 0.f) continue;
+                for (int c = 0; c < 4; ++c) {
+                    const int ow = 2 * w - 1 + c;
+                    if (ow < 0 || ow >= Wo) continue;
+                    lin_src(ow, Wi, 2, i0, i1, l);
+                    const float ww = (i0 == w ? 1.f - l : 0.f) + (i1 == w ? l : 0.f);
+                    if (ww == 0.f) continue;
+                    const size_t vo = (((size_t)n * Do + od) * Ho + oh) * Wo + ow;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(g + vo * C + 4 * q);
+                    const float wt = wd * wh * ww;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(wt, v[e], acc[e]);
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + (i / Q) * dx_ldc + 4 * q) = acc;
+    }
+}
 // autocrop of the up-convolved tensor (unet.py:289-299: one voxel at the high end where the skip has an odd size), together with the
 // BatchNorm statistics of the CROPPED tensor: src [N, Ds, Hs, Ws, C] -> dst [N, Dd, Hd, Wd, C] (leading box) + one (count, mean, M2)
 // record per workgroup and channel.  Same fixed-pattern block reduction as bn_bwd_kernel.
@@ -752,14 +822,24 @@ int launch_colsum_multi(const ColsumJob* jobs, int njobs, hipStream_t s) {
     return E3_OK;
 }
 
-int launch_upsample_nearest(const float* x, int x_ldc, float* out, int C, int N, int Di, int Hi, int Wi, int sd, hipStream_t s) {
+int launch_upsample_nearest(const float* x, int x_ldc, float* out, int C, int N, int Di, int Hi, int Wi, int sd, hipStream_t s, int linear) {
     E3_REQUIRE(C % 4 == 0 && x_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
+    if (linear) {
+        hipLaunchKernelGGL(upsample_linear_kernel, dim3(ew_grid((size_t)N * Di * sd * Hi * 2 * Wi * 2 * (C / 4))), dim3(EW_BLOCK), 0, s, x, x_ldc, out, C, N, Di, Hi, Wi, sd);
+        E3_CHECK_HIP(hipGetLastError());
+        return E3_OK;
+    }
     hipLaunchKernelGGL(upsample_nearest_kernel, dim3(ew_grid((size_t)N * Di * sd * Hi * 2 * Wi * 2 * (C / 4))), dim3(EW_BLOCK), 0, s, x, x_ldc, out, C, N, Di, Hi, Wi, sd);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
-int launch_downsample_sum(const float* g, float* dx, int dx_ldc, int C, int N, int Di, int Hi, int Wi, int sd, hipStream_t s) {
+int launch_downsample_sum(const float* g, float* dx, int dx_ldc, int C, int N, int Di, int Hi, int Wi, int sd, hipStream_t s, int linear) {
     E3_REQUIRE(C % 4 == 0 && dx_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
+    if (linear) {
+        hipLaunchKernelGGL(downsample_linear_kernel, dim3(ew_grid((size_t)N * Di * Hi * Wi * (C / 4))), dim3(EW_BLOCK), 0, s, g, dx, dx_ldc, C, N, Di, Hi, Wi, sd);
+        E3_CHECK_HIP(hipGetLastError());
+        return E3_OK;
+    }
     hipLaunchKernelGGL(downsample_sum_kernel, dim3(ew_grid((size_t)N * Di * Hi * Wi * (C / 4))), dim3(EW_BLOCK), 0, s, g, dx, dx_ldc, C, N, Di, Hi, Wi, sd);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;

@@ -121,8 +121,8 @@ int launch_ce_dice_bwd(const float* logits, const long long* target, const float
 
 // up_mode='resizeconv_*' building blocks (elementwise.hip): nearest up-sampling by (sd,2,2) and its backward, the autocrop of the
 // up-convolved tensor fused with the statistics of the cropped tensor (records [crop_stats_parts][C][3]) and its backward
-int launch_upsample_nearest(const float* x, int x_ldc, float* out, int C, int N, int Di, int Hi, int Wi, int sd, hipStream_t s);
-int launch_downsample_sum(const float* g, float* dx, int dx_ldc, int C, int N, int Di, int Hi, int Wi, int sd, hipStream_t s);
+int launch_upsample_nearest(const float* x, int x_ldc, float* out, int C, int N, int Di, int Hi, int Wi, int sd, hipStream_t s, int linear = 0);   // linear: tri-/bilinear, align_corners=False
+int launch_downsample_sum(const float* g, float* dx, int dx_ldc, int C, int N, int Di, int Hi, int Wi, int sd, hipStream_t s, int linear = 0);
 int crop_stats_parts(size_t voxels, int C);
 int launch_crop_stats(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, float* stats, hipStream_t s);
 int launch_pad_box(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, hipStream_t s);

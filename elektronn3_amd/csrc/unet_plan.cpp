@@ -420,7 +420,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             const int sd = u.planar ? 1 : 2, Ud = li.D * sd, Uh = li.H * 2, Uw = li.W * 2, NPad = pad_cols(u.cout);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             const bool same = Ud == lo.D && Uh == lo.H && Uw == lo.W;
-            RUN(launch_upsample_nearest(cur, cur_ldc, B.ups[k], u.cin, N, li.D, li.H, li.W, sd, s));
+            RUN(launch_upsample_nearest(cur, cur_ldc, B.ups[k], u.cin, N, li.D, li.H, li.W, sd, s, cfg.up_resize == 2));
             RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, Ud, Uh, Uw, 0, s));
             ConvArgs a{};
             a.x = B.ups[k]; a.x_ldc = u.cin; a.Cin = u.cin; a.wt = B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
@@ -674,7 +674,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             a.Cout = u.cin; a.Ncols = u.cin; a.NPad = NPad; a.G = 1;
             a.flags = (bucket_event != nullptr && event_done) ? CF_NO_PERSIST : 0;
             { Prof pr(plan, s, k, 1); RUN(launch_conv_mfma(kind, a, s)); }
-            RUN(launch_downsample_sum(B.rdu, B.g1[j + 1], u.cin, u.cin, N, li.D, li.H, li.W, sd, s));
+            RUN(launch_downsample_sum(B.rdu, B.g1[j + 1], u.cin, u.cin, N, li.D, li.H, li.W, sd, s, cfg.up_resize == 2));
             g = B.g1[j + 1]; g_ldc = u.cin;
         } else if (u.is_up) {
             const LevelDims& li = L[j + 1];

@@ -83,7 +83,10 @@ def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True):
         if p + 'upconv.conv.weight' in sd:      # up_mode='resizeconv_nearest': ResizeConv = nn.Upsample(nearest) + conv3 (unet.py:411-449)
             w = sd[p + 'upconv.conv.weight']
             scale = (1, 2, 2) if (w.dim() == 5 and w.shape[2] == 1) else 2
-            up = _conv(F.interpolate(x, scale_factor=scale, mode='nearest'), sd, p + 'upconv.conv')
+            lin = sd.get('__up_linear__', False)      # 'resizeconv_linear': nn.Upsample(mode='trilinear' | 'bilinear'), align_corners=False
+            xu = F.interpolate(x, scale_factor=scale, mode=('trilinear' if w.dim() == 5 else 'bilinear'), align_corners=False) if lin \
+                else F.interpolate(x, scale_factor=scale, mode='nearest')
+            up = _conv(xu, sd, p + 'upconv.conv')
         else:
             w = sd[p + 'upconv.weight']
             up = (F.conv_transpose3d if w.dim() == 5 else F.conv_transpose2d)(x, w, sd[p + 'upconv.bias'], stride=tuple(w.shape[2:]))

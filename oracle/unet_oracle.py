@@ -182,6 +182,17 @@ def softmax_c(x):
     return y
 
 
+def linear_upsample_matrix(n, scale):
+    """(scale*n, n) matrix of nn.Upsample(scale_factor=scale, mode='linear'-family, align_corners=False) along one axis: source
+    coordinate max((o + 0.5)/scale - 0.5, 0), taps floor / min(floor + 1, n - 1) with weights (1 - l, l).  scale 1 = identity."""
+    M = np.zeros((scale * n, n), np.float64)
+    for o in range(scale * n):
+        src = max((o + 0.5) / scale - 0.5, 0.0)
+        i0 = int(np.floor(src)); i1 = min(i0 + 1, n - 1); l = src - i0
+        M[o, i0] += 1.0 - l; M[o, i1] += l
+    return M
+
+
 def group_norm_fwd(x, gamma, beta, num_groups, eps=1e-5):
     """nn.GroupNorm(num_groups, C) (get_normalization, unet.py:81-90): per sample, mean / biased variance over the C/G channels of a
     group and all voxels, then the per-channel affine map.  float64 arithmetic.  Returns (y, xhat, invstd[N,G])."""
@@ -253,6 +264,7 @@ class OracleUNet:
         self.planar = tuple(planar_blocks)
         self.norm = normalization
         self.num_groups = 8 if normalization == 'group' else (int(normalization[5:]) if normalization.startswith('group') else 0)
+        self.up_linear = False        # up_mode='resizeconv_linear' (set by the caller)
         self.act_slope = 0.0          # 0 ReLU, 0.1 'leaky', 1.0 'lin' (set by the caller)
         self.instance_norms = ()      # names of the nn.InstanceNorm layers (they have no state_dict entries), set by the caller
         self.momentum, self.eps = momentum, eps
@@ -328,7 +340,12 @@ class OracleUNet:
                 # repeated (sd, 2, 2) times, then a 'same' 3x3x3 / 1x3x3 convolution on the up-sampled grid
                 w, b = self.sd[p + 'upconv.conv.weight'], self.sd[p + 'upconv.conv.bias']
                 sd_ = 1 if w.shape[2] == 1 else 2
-                xu = np.ascontiguousarray(x.repeat(sd_, axis=2).repeat(2, axis=3).repeat(2, axis=4))
+                if self.up_linear:     # 'resizeconv_linear': separable tri-linear interpolation, align_corners=False
+                    Ms = [linear_upsample_matrix(x.shape[2], sd_), linear_upsample_matrix(x.shape[3], 2), linear_upsample_matrix(x.shape[4], 2)]
+                    xu = np.einsum('ad,bh,cw,nkdhw->nkabc', *Ms, x.astype(np.float64)).astype(np.float32)
+                    xu = np.ascontiguousarray(xu)
+                else:
+                    xu = np.ascontiguousarray(x.repeat(sd_, axis=2).repeat(2, axis=3).repeat(2, axis=4))
                 pad = tuple((k - 1) // 2 for k in w.shape[2:])
                 cache[p + 'upconv'] = (xu, pad, sd_)
                 up = conv3d_fwd(xu, w, b, pad)
@@ -419,7 +436,11 @@ class OracleUNet:
                 dxu, dw, db = conv3d_bwd(xu, self.sd[p + 'upconv.conv.weight'], np.ascontiguousarray(dup), pad, True)
                 grads[p + 'upconv.conv.weight'], grads[p + 'upconv.conv.bias'] = dw, db
                 N_, C_, D_, H_, W_ = dxu.shape     # backward of the nearest up-sampling: sum over each (sd, 2, 2) block
-                d = dxu.astype(np.float64).reshape(N_, C_, D_ // sd_, sd_, H_ // 2, 2, W_ // 2, 2).sum(axis=(3, 5, 7)).astype(np.float32)
+                if self.up_linear:     # transpose of the interpolation
+                    Ms = [linear_upsample_matrix(D_ // sd_, sd_), linear_upsample_matrix(H_ // 2, 2), linear_upsample_matrix(W_ // 2, 2)]
+                    d = np.einsum('ad,bh,cw,nkabc->nkdhw', *Ms, dxu.astype(np.float64)).astype(np.float32)
+                else:
+                    d = dxu.astype(np.float64).reshape(N_, C_, D_ // sd_, sd_, H_ // 2, 2, W_ // 2, 2).sum(axis=(3, 5, 7)).astype(np.float32)
             else:
                 xin = cache[p + 'upconv']
                 d, dw, db = convT_bwd(xin, self.sd[p + 'upconv.weight'], dup)

@@ -22,7 +22,8 @@ pytestmark = pytest.mark.gpu
 CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_planar01.npz', 'unet2d_nb3_sf8_odd.npz',
          'unet_nb2_sf8_nonorm.npz', 'unet_nb3_sf8_planar0_sparsenorm.npz', 'unet_nb3_sf8_add_odd.npz', 'unet_nb3_sf8_instance.npz',
          'unet_nb3_sf8_group4_odd.npz', 'unet_nb3_sf8_leaky_odd.npz', 'unet_nb2_sf8_lin_nonorm.npz',
-         'unet_nb3_sf8_silu_odd.npz', 'unet_nb3_sf8_resizeconv_odd.npz']
+         'unet_nb3_sf8_silu_odd.npz', 'unet_nb3_sf8_resizeconv_odd.npz',
+         'unet_nb3_sf8_resizelinear_odd.npz']
 
 
 def build(cfg, sd_np):
@@ -248,9 +249,10 @@ def test_full_size_cfg4_anisotropic_against_pytorch_rocm():
                                 dict(activation='leaky'), dict(activation='leaky', normalization='none', planar_blocks=(0,)),
                                 dict(activation='lin', normalization='group', full_norm=False),
                                 dict(activation='silu', planar_blocks=(0,)), dict(activation='silu', normalization='none'),
-                                dict(up_mode='resizeconv_nearest'), dict(up_mode='resizeconv_nearest', planar_blocks=(0,), normalization='group', full_norm=False)],
+                                dict(up_mode='resizeconv_nearest'), dict(up_mode='resizeconv_nearest', planar_blocks=(0,), normalization='group', full_norm=False),
+                                dict(up_mode='resizeconv_linear', planar_blocks=(0,))],
                          ids=['nonorm', 'sparsenorm', 'add', 'add_nonorm_planar', 'instance', 'group8', 'group16_sparse_add',
-                              'leaky', 'leaky_nonorm_planar', 'lin_group', 'silu_planar', 'silu_nonorm', 'resizeconv', 'resizeconv_planar_group_sparse'])
+                              'leaky', 'leaky_nonorm_planar', 'lin_group', 'silu_planar', 'silu_nonorm', 'resizeconv', 'resizeconv_planar_group_sparse', 'resizelinear_planar'])
 def test_option_variants_against_pytorch_rocm(kw):
     """normalization='none' and full_norm=False (norm layers = nn.Identity, unet.py:77-80,238-242,369-375) at a size that runs the
     Winograd kernels (conv -> bias -> ReLU fused in their epilogue, also in training), and merge_mode='add' (unet.py:398-401: the skip
@@ -276,6 +278,7 @@ def test_option_variants_against_pytorch_rocm(kw):
               for k, v in sd0.items()}
     pl = tuple(kw.get('planar_blocks', ()))
     group = str(kw.get('normalization', '')).startswith('group')
+    sd_ref['__up_linear__'] = kw.get('up_mode') == 'resizeconv_linear'
     sd_ref['__act_slope__'] = {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0}[kw.get('activation', 'relu')]
     sd_ref['__instance_norms__'] = paramless
     sd_ref['__num_groups__'] = 8 if kw.get('normalization') == 'group' else (int(kw['normalization'][5:]) if group else 0)
@@ -306,6 +309,7 @@ def test_option_variants_against_pytorch_rocm(kw):
     sd_e['__instance_norms__'] = paramless
     sd_e['__num_groups__'] = sd_ref['__num_groups__']
     sd_e['__act_slope__'] = sd_ref['__act_slope__']
+    sd_e['__up_linear__'] = sd_ref['__up_linear__']
     assert torch.allclose(ye.double(), unet_forward(sd_e, x.double(), 3, pl, training=False), rtol=1e-4, atol=1e-4)
     if paramless or group:       # instance / group statistics in eval mode too: eval output == train output, and a batch equals its samples one by one
         assert torch.equal(ye, out.detach())
