@@ -81,6 +81,8 @@ for case in range(n_cases):
     for k, p in m.named_parameters():
         gr = sd_ref[k].grad
         prebn = is_prebn_bias(k, set() if group else names, paramless)
+        if group and p.numel() == sd_ref['__num_groups__'] and is_prebn_bias(k, names, paramless):
+            prebn = True        # groups of ONE channel: GroupNorm removes the channel's own mean, the bias gradient is analytically zero
         err = float(p.grad.abs().max()) / gn if prebn else float((p.grad - gr).norm() / gr.norm().clamp_min(1e-30))
         if (not prebn and err > worst): worst, wk = err, k
         if prebn and err > 1e-5: worst, wk = 1.0, k + ' (pre-BN bias not ~0)'
