@@ -601,6 +601,16 @@ __global__ void downsample_linear_kernel(const float* __restrict__ g, float* __r
         *reinterpret_cast<f32x4*>(dx + (i / Q) * dx_ldc + 4 * q) = acc;
     }
 }
+// ResizeConv(kernel_size=1) ('resizeconv_*1'): the 1x1x1 weights as the centre tap of an otherwise zero T-tap kernel, so that the
+// layer runs on the 3x3x3 / 1x3x3 conv kernels (correct, 27x / 9x more multiplies than a pointwise GEMM needs), and back
+__global__ void embed_center_tap_kernel(const float* __restrict__ w1, float* __restrict__ wT, size_t pairs, int T) {
+    const size_t total = pairs * T;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        wT[i] = (int)(i % T) == T / 2 ? w1[i / T] : 0.f;
+}
+__global__ void extract_center_tap_kernel(const float* __restrict__ gT, float* __restrict__ g1, size_t pairs, int T) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) g1[i] = gT[i * T + T / 2];
+}
 // autocrop of the up-convolved tensor (unet.py:289-299: one voxel at the high end where the skip has an odd size), together with the
 // BatchNorm statistics of the CROPPED tensor: src [N, Ds, Hs, Ws, C] -> dst [N, Dd, Hd, Wd, C] (leading box) + one (count, mean, M2)
 // record per workgroup and channel.  Same fixed-pattern block reduction as bn_bwd_kernel.
@@ -841,6 +851,16 @@ int launch_downsample_sum(const float* g, float* dx, int dx_ldc, int C, int N, i
         return E3_OK;
     }
     hipLaunchKernelGGL(downsample_sum_kernel, dim3(ew_grid((size_t)N * Di * Hi * Wi * (C / 4))), dim3(EW_BLOCK), 0, s, g, dx, dx_ldc, C, N, Di, Hi, Wi, sd);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+int launch_embed_center_tap(const float* w1, float* wT, size_t pairs, int T, hipStream_t s) {
+    hipLaunchKernelGGL(embed_center_tap_kernel, dim3(ew_grid(pairs * T)), dim3(EW_BLOCK), 0, s, w1, wT, pairs, T);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+int launch_extract_center_tap(const float* gT, float* g1, size_t pairs, int T, hipStream_t s) {
+    hipLaunchKernelGGL(extract_center_tap_kernel, dim3(ew_grid(pairs)), dim3(EW_BLOCK), 0, s, gT, g1, pairs, T);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

@@ -123,6 +123,8 @@ int launch_ce_dice_bwd(const float* logits, const long long* target, const float
 // up-convolved tensor fused with the statistics of the cropped tensor (records [crop_stats_parts][C][3]) and its backward
 int launch_upsample_nearest(const float* x, int x_ldc, float* out, int C, int N, int Di, int Hi, int Wi, int sd, hipStream_t s, int linear = 0);   // linear: tri-/bilinear, align_corners=False
 int launch_downsample_sum(const float* g, float* dx, int dx_ldc, int C, int N, int Di, int Hi, int Wi, int sd, hipStream_t s, int linear = 0);
+int launch_embed_center_tap(const float* w1, float* wT, size_t pairs, int T, hipStream_t s);     // (Cout*Cin) 1x1x1 weights -> centre tap of T-tap kernels
+int launch_extract_center_tap(const float* gT, float* g1, size_t pairs, int T, hipStream_t s);
 int crop_stats_parts(size_t voxels, int C);
 int launch_crop_stats(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, float* stats, hipStream_t s);
 int launch_pad_box(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, hipStream_t s);

@@ -72,7 +72,8 @@ void add_unit(e3_unet_plan* p, const std::string& conv, const std::string& bn, i
     ConvUnit u;
     u.name = conv; u.bn_name = bn; u.cin = cin; u.cout = cout; u.level = level; u.planar = planar; u.is_up = is_up;
     const int taps = is_up == 1 ? (planar ? 4 : 8) : (planar ? 9 : 27);
-    u.p_w = add_param(p, conv + ".weight", (int64_t)cin * cout * taps, 0);
+    const bool k1 = is_up == 2 && p->cfg.up_resize >= 3;      // ResizeConv(kernel_size=1): 'resizeconv_nearest1' / 'resizeconv_linear1'
+    u.p_w = add_param(p, conv + ".weight", (int64_t)cin * cout * (k1 ? 1 : taps), 0);
     u.p_b = add_param(p, conv + ".bias", cout, 0);
     u.p_g = u.p_be = u.p_rm = u.p_rv = -1; u.bn_index = -1;
     if (norm) {
@@ -112,6 +113,7 @@ struct Buffers {
     float* bnred;                                                              // pre-merged BN statistic records
     float* ones; float* zeros;                                                 // [Cmax] / [2*Cmax] constants for units without a norm
     std::vector<float*> ups;             // ResizeConv units: the up-sampled input [N, sd*D', 2H', 2W', Cin] (kept for the weight gradient)
+    float* wemb; float* gemb;            // ResizeConv(kernel_size=1): weights / weight gradient embedded as the centre tap of a 27-tap kernel
     float* rtmp; float* rpad; float* rdu; // ResizeConv scratch: conv output / padded gradient at the up-sampled size, gradient of the up-sampled input
     float* biaspart0;                    // [splits][Cout] conv-bias gradient partials of the first conv when its BN backward is fused into its wgrad
     std::vector<float*> bnpart_u;        // per unit: block partials of the BN backward [parts][3][C]; row 2 (sum dx = conv-bias gradient) is summed for all units at once
@@ -201,6 +203,8 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         slabmax = max_sz(slabmax, (size_t)conv_final_bwd_parts(L[0].vox) * (p->cfg.out_channels * C0 + p->cfg.out_channels));
     }
     B.wpack = T.take(wmax);
+    B.wemb = B.gemb = nullptr;
+    if (p->cfg.up_resize >= 3) { const size_t e = (size_t)p->chan(nb - 1) * p->chan(nb - 1) / 2 * 27; B.wemb = T.take(e); if (training) B.gemb = T.take(e); }
     if (rtmpmax) { B.rtmp = T.take(rtmpmax); if (training) { B.rpad = T.take(rtmpmax); B.rdu = T.take(rdumax); } }
     B.wpk_f.assign(p->units.size(), nullptr); B.wpk_d.assign(p->units.size(), nullptr);
     for (size_t k = 0; k < p->units.size(); ++k) {
@@ -420,8 +424,11 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             const int sd = u.planar ? 1 : 2, Ud = li.D * sd, Uh = li.H * 2, Uw = li.W * 2, NPad = pad_cols(u.cout);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             const bool same = Ud == lo.D && Uh == lo.H && Uw == lo.W;
-            RUN(launch_upsample_nearest(cur, cur_ldc, B.ups[k], u.cin, N, li.D, li.H, li.W, sd, s, cfg.up_resize == 2));
-            RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, Ud, Uh, Uw, 0, s));
+            const bool lin = cfg.up_resize == 2 || cfg.up_resize == 4, k1 = cfg.up_resize >= 3;
+            RUN(launch_upsample_nearest(cur, cur_ldc, B.ups[k], u.cin, N, li.D, li.H, li.W, sd, s, lin));
+            const float* wsrc = P(u.p_w);
+            if (k1) { RUN(launch_embed_center_tap(P(u.p_w), B.wemb, (size_t)u.cout * u.cin, u.planar ? 9 : 27, s)); wsrc = B.wemb; }
+            RUN(launch_pack_conv_auto(kind, 0, wsrc, B.wpack, u.cout, u.cin, N, Ud, Uh, Uw, 0, s));
             ConvArgs a{};
             a.x = B.ups[k]; a.x_ldc = u.cin; a.Cin = u.cin; a.wt = B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
             a.y = same ? b.raw : B.rtmp; a.y_ldc = u.cout; a.N = N; a.D = Ud; a.H = Uh; a.W = Uw; a.sd = 2;
@@ -635,7 +642,10 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             a.N = N; a.D = Ud; a.H = Uh; a.W = Uw; a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
             a.splits = wgrad_splits(kind, N, Ud, Uh, Uw, u.cin, u.cout);
             { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(kind, a, s)); }
-            RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
+            if (cfg.up_resize >= 3) {      // kernel_size = 1: only the centre tap of the 27-tap gradient is the parameter's
+                RUN(launch_wgrad_reduce(B.slab, B.gemb, a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
+                RUN(launch_extract_center_tap(B.gemb, G(u.p_w), (size_t)u.cout * u.cin, taps, s));
+            } else RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
         } else if (u.is_up) {
             const LevelDims& li = L[j + 1];
             const int sd = u.planar ? 1 : 2;
@@ -667,14 +677,16 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             const LevelDims& li = L[j + 1];
             const int sd = u.planar ? 1 : 2, Ud = li.D * sd, Uh = li.H * 2, Uw = li.W * 2, NPad = pad_cols(u.cin);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
-            RUN(launch_pack_conv_auto(kind, 1, P(u.p_w), B.wpack, u.cout, u.cin, N, Ud, Uh, Uw, 0, s));
+            const float* wsrc = P(u.p_w);
+            if (cfg.up_resize >= 3) { RUN(launch_embed_center_tap(P(u.p_w), B.wemb, (size_t)u.cout * u.cin, u.planar ? 9 : 27, s)); wsrc = B.wemb; }
+            RUN(launch_pack_conv_auto(kind, 1, wsrc, B.wpack, u.cout, u.cin, N, Ud, Uh, Uw, 0, s));
             ConvArgs a{};
             a.x = dyu; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = B.wpack; a.y = B.rdu; a.y_ldc = u.cin;
             a.N = N; a.D = Ud; a.H = Uh; a.W = Uw; a.sd = 2;
             a.Cout = u.cin; a.Ncols = u.cin; a.NPad = NPad; a.G = 1;
             a.flags = (bucket_event != nullptr && event_done) ? CF_NO_PERSIST : 0;
             { Prof pr(plan, s, k, 1); RUN(launch_conv_mfma(kind, a, s)); }
-            RUN(launch_downsample_sum(B.rdu, B.g1[j + 1], u.cin, u.cin, N, li.D, li.H, li.W, sd, s, cfg.up_resize == 2));
+            RUN(launch_downsample_sum(B.rdu, B.g1[j + 1], u.cin, u.cin, N, li.D, li.H, li.W, sd, s, cfg.up_resize == 2 || cfg.up_resize == 4));
             g = B.g1[j + 1]; g_ldc = u.cin;
         } else if (u.is_up) {
             const LevelDims& li = L[j + 1];

@@ -236,10 +236,12 @@ class ResizeConv(nn.Module):
     """Parameter container of the reference's ResizeConv (unet.py:411-449): ``nn.Upsample(scale_factor, mode='nearest')`` followed by a
     3x3x3 (planar: 1x3x3; dim=2: 3x3) convolution -- ``up_mode='resizeconv_nearest'``.  state_dict keys: ``conv.weight``, ``conv.bias``."""
 
-    def __init__(self, in_channels, out_channels, planar=False, dim=3, upsampling_mode='nearest'):
+    def __init__(self, in_channels, out_channels, planar=False, dim=3, upsampling_mode='nearest', kernel_size=3):
         super().__init__()
         Conv = _LAYERS[dim][0]
         k, p = ((1, 3, 3), (0, 1, 1)) if (planar and dim == 3) else (3, 1)
+        if kernel_size == 1:        # conv1(), unet.py:178-180,443-444
+            k, p = 1, 0
         self.upsampling_mode = upsampling_mode          # 'nearest', or 'trilinear' / 'bilinear' (upconv2, unet.py:166-170)
         self.scale_factor = (1, 2, 2) if (planar and dim == 3) else 2
         self.dim = dim
@@ -293,7 +295,8 @@ class UpConv(nn.Module):
             self.upconv = ConvT(in_channels, out_channels, kernel_size=ks, stride=ks)
         else:       # 'resizeconv_nearest' / 'resizeconv_linear' (upconv2, unet.py:152-176)
             mode = 'nearest' if 'nearest' in up_mode else ('trilinear' if dim == 3 else 'bilinear')
-            self.upconv = ResizeConv(in_channels, out_channels, planar=planar, dim=dim, upsampling_mode=mode)
+            self.upconv = ResizeConv(in_channels, out_channels, planar=planar, dim=dim, upsampling_mode=mode,
+                                     kernel_size=1 if up_mode.endswith('1') else 3)
         self.conv1 = Conv((2 if merge_mode == 'concat' else 1) * out_channels, out_channels, kernel_size=k, padding=p)   # unet.py:352-360
         self.conv2 = Conv(out_channels, out_channels, kernel_size=k, padding=p)
         self.act0, self.act1, self.act2 = (_make_activation(activation) for _ in range(3))
@@ -310,7 +313,7 @@ class UpConv(nn.Module):
 class UNet(nn.Module):
     """3D U-Net with the reference's interface (elektronn3/models/unet.py:755-771), executed by hand-written HIP
     kernels.  Options of the reference that are not yet on the HIP path raise ``NotImplementedError`` at
-    construction: ``up_mode`` other than ``'transpose'`` / ``'resizeconv_nearest'`` / ``'resizeconv_linear'``,
+    construction: ``up_mode='upsample'``,
     ``attention=True``, ``activation`` other than ``'relu'`` / ``'leaky'`` / ``'lin'`` / ``'silu'``,
     ``conv_mode != 'same'``.  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
     the 3D one with every block planar and a depth of 1."""
@@ -357,7 +360,7 @@ class UNet(nn.Module):
                                'If you still want to use batch normalization, set `normalization=batch` instead.')
         # -- what the HIP path implements this round
         unsupported = []
-        if up_mode not in ('transpose', 'resizeconv_nearest', 'resizeconv_linear'): unsupported.append(f'up_mode={up_mode!r}')
+        if up_mode == 'upsample': unsupported.append("up_mode='upsample' (upconv2 has no branch for it in the reference either)")
         if attention: unsupported.append('attention=True')
         if isinstance(activation, str) and activation not in ('relu', 'leaky', 'prelu', 'rrelu', 'silu', 'lin'):
             raise ValueError(f'unknown activation {activation!r}')
@@ -433,7 +436,8 @@ class UNet(nn.Module):
         return (self.in_channels, self.out_channels, self.n_blocks, self.start_filts, mask, 2 if self.normalization.startswith('group') else (1 if self.normalization in ('batch', 'instance') else 0), eps,
                 1 if getattr(self, 'full_norm', True) else 0, 1 if self.merge_mode == 'add' else 0,
                 _num_groups(self.normalization) if self.normalization.startswith('group') else 0,
-                {'transpose': 0, 'resizeconv_nearest': 1, 'resizeconv_linear': 2}[self.up_mode], float(_activation_slope(self.activation)))
+                {'transpose': 0, 'resizeconv_nearest': 1, 'resizeconv_linear': 2, 'resizeconv_nearest1': 3, 'resizeconv_linear1': 4}[self.up_mode],
+                float(_activation_slope(self.activation)))
 
     def _plan(self):
         return _get_plan(self._plan_key())

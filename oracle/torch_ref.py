@@ -82,7 +82,7 @@ def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True):
         p = f'up_convs.{i}.'
         if p + 'upconv.conv.weight' in sd:      # up_mode='resizeconv_nearest': ResizeConv = nn.Upsample(nearest) + conv3 (unet.py:411-449)
             w = sd[p + 'upconv.conv.weight']
-            scale = (1, 2, 2) if (w.dim() == 5 and w.shape[2] == 1) else 2
+            scale = (1, 2, 2) if (w.dim() == 5 and (n_blocks - 2 - i) in planar_blocks) else 2      # planar decoder block: only (H, W) grow
             lin = sd.get('__up_linear__', False)      # 'resizeconv_linear': nn.Upsample(mode='trilinear' | 'bilinear'), align_corners=False
             xu = F.interpolate(x, scale_factor=scale, mode=('trilinear' if w.dim() == 5 else 'bilinear'), align_corners=False) if lin \
                 else F.interpolate(x, scale_factor=scale, mode='nearest')

@@ -339,7 +339,7 @@ class OracleUNet:
                 # up_mode='resizeconv_nearest' (ResizeConv, unet.py:411-449): nn.Upsample(scale_factor, 'nearest') = every voxel
                 # repeated (sd, 2, 2) times, then a 'same' 3x3x3 / 1x3x3 convolution on the up-sampled grid
                 w, b = self.sd[p + 'upconv.conv.weight'], self.sd[p + 'upconv.conv.bias']
-                sd_ = 1 if w.shape[2] == 1 else 2
+                sd_ = 1 if (self.n_blocks - 2 - i) in self.planar else 2      # planar decoder block: only (H, W) grow
                 if self.up_linear:     # 'resizeconv_linear': separable tri-linear interpolation, align_corners=False
                     Ms = [linear_upsample_matrix(x.shape[2], sd_), linear_upsample_matrix(x.shape[3], 2), linear_upsample_matrix(x.shape[4], 2)]
                     xu = np.einsum('ad,bh,cw,nkdhw->nkabc', *Ms, x.astype(np.float64)).astype(np.float32)

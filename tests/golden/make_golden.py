@@ -312,6 +312,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'resize':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizeconv_odd.npz', seed=12, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 19), batch=2, up_mode='resizeconv_nearest')
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'resize1':
+        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizenearest1_odd.npz', seed=14, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 13, 18), batch=2, up_mode='resizeconv_nearest1')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'resizelin':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizelinear_odd.npz', seed=13, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(7, 15, 18), batch=2, up_mode='resizeconv_linear')
         sys.exit(0)
@@ -355,6 +358,7 @@ if __name__ == '__main__':
     # up_mode='resizeconv_nearest' (nearest up-sampling + conv3 instead of the transposed conv), odd sizes, planar first block
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizeconv_odd.npz', seed=12, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 19), batch=2, up_mode='resizeconv_nearest')
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizelinear_odd.npz', seed=13, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(7, 15, 18), batch=2, up_mode='resizeconv_linear')
+    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizenearest1_odd.npz', seed=14, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 13, 18), batch=2, up_mode='resizeconv_nearest1')
     make_predictor(unet, inference, f'{HERE}/predictor.npz')
     make_adamw(f'{HERE}/adamw.npz')
     make_trainsteps(unet, loss_mod, f'{HERE}/trainsteps.npz')

@@ -34,7 +34,7 @@ for case in range(n_cases):
     elif v == 3: kw = dict(normalization='instance', full_norm=bool(ri(0, 1)))
     elif v == 4: kw = dict(normalization=('group', 'group4', 'group2')[ri(0, 2)], full_norm=bool(ri(0, 1)))
     if ri(0, 3) == 0: kw['merge_mode'] = 'add'
-    if ri(0, 3) == 0 and 'merge_mode' not in kw: kw['up_mode'] = ('resizeconv_nearest', 'resizeconv_linear')[ri(0, 1)]
+    if ri(0, 3) == 0 and 'merge_mode' not in kw: kw['up_mode'] = ('resizeconv_nearest', 'resizeconv_linear', 'resizeconv_nearest1', 'resizeconv_linear1')[ri(0, 3)]
     if ri(0, 3) == 0: kw['activation'] = ('leaky', 'lin', 'silu')[ri(0, 2)]
     shape = (H, W) if D is None else (D, H, W)
     torch.manual_seed(case)
@@ -49,7 +49,7 @@ for case in range(n_cases):
     sd_ref = {k: (v.double() if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd0.items()}
     paramless = R.instance_norm_names(nb, kw.get('full_norm', True)) if kw.get('normalization') == 'instance' else ()
     sd_ref['__instance_norms__'] = paramless
-    sd_ref['__up_linear__'] = kw.get('up_mode') == 'resizeconv_linear'
+    sd_ref['__up_linear__'] = str(kw.get('up_mode')).startswith('resizeconv_linear')
     sd_ref['__act_slope__'] = {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0}[kw.get('activation', 'relu')]
     group = str(kw.get('normalization', '')).startswith('group')
     sd_ref['__num_groups__'] = (8 if kw['normalization'] == 'group' else int(kw['normalization'][5:])) if group else 0
