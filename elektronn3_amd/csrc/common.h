@@ -60,8 +60,18 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 
 // The network's activation: ReLU (slope 0), LeakyReLU(slope) [get_activation 'leaky' = 0.1, unet.py:183-199], identity (slope 1,
 // 'lin') or SiLU (ACT_SILU).  Written so that slope == 0 reproduces fmaxf(z, 0) bit for bit (+0 + -0 = +0) and the mask form stays sign-of-zero clean.
+// Activation argument of the kernels: a constant slope, or -- nn.PReLU(num_parameters=1), 'prelu' -- a learnable slope read from
+// device memory (no host sync).  Implicitly constructible from a float, so constant-slope call sites stay as they are.
+struct ActArg {
+    float slope; const float* ptr;
+    __host__ __device__ ActArg(float s = 0.f) : slope(s), ptr(nullptr) {}
+    __host__ __device__ ActArg(float s, const float* p) : slope(s), ptr(p) {}
+    // (a learned slope that is exactly 2.0f must not be mistaken for the ACT_SILU code below: moved by one ulp)
+    __device__ __forceinline__ float get() const { if (!ptr) return slope; const float v = *ptr; return v == 2.f ? 2.0000002f : v; }
+};
 // slope == ACT_SILU selects nn.SiLU ('silu'): z * sigmoid(z), derivative sig * (1 + z * (1 - sig)).
 constexpr float ACT_SILU = 2.f;
+constexpr float ACT_PRELU = 3.f;     // (plan-level code only: the kernels see the learnable slope through ActArg::ptr)
 __device__ __forceinline__ float act_fwd(float z, float slope) {
     if (slope == ACT_SILU) return z / (1.f + expf(-z));
     return fmaxf(z, 0.f) + slope * fminf(z, 0.f);

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
     const int toff = (kd * LH + kh) * LW + kw;
     const int ntiles = N * tilesD * tilesH * tilesW;
     const int tile0 = blockIdx.x * tiles_per_split;
+    const float fslope = f.act.get();
     for (int pass = 0; pass * 32 < Cout; ++pass) {
         // per-channel constants of the fused BN backward for the channel quad this thread stages (tid & 7 is fixed across its pieces)
         f32x4 fsc = {1.f, 1.f, 1.f, 1.f}, fsh = {0.f, 0.f, 0.f, 0.f}, fmu = fsh, fis = fsc, fgi = fsc, fc1 = fsh, fc2 = fsh, bsum = fsh;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float z = __builtin_fmaf(xv[e], fsc[e], fsh[e]);
-                                const float dz = act_bwd(z, gv[e], f.slope);
+                                const float dz = act_bwd(z, gv[e], fslope);
                                 const float xh = (xv[e] - fmu[e]) * fis[e];
                                 val[e] = fgi[e] * (dz - fc1[e] - xh * fc2[e]);
                                 if (ci == 0) bsum[e] += val[e];
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
 template <int COUT>
 __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, int C, const float* __restrict__ w,
                                       const float* __restrict__ bias, float* __restrict__ y, size_t S, int N, int lpv, int softmax,
-                                      const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, float pro_slope) {
+                                      const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, ActArg pro_act) {
+    const float pro_slope = pro_act.get();
     // pro_scale/pro_shift: `a` is the RAW output of the last conv; its BatchNorm + ReLU, a := relu(a*scale + shift), is applied while
     // loading (same expression as bn_relu_apply_kernel) -- the last activation of the network is never written or re-read
     // lpv (1,2,4,8) consecutive lanes share one voxel; each walks every lpv-th channel quad
@@ -298,8 +300,9 @@ template <int COUT>
 __global__ __launch_bounds__(256) void conv_final_bwd_kernel(const float* __restrict__ a, int a_ldc, int C, const float* __restrict__ w,
                                                              const float* __restrict__ dy, float* __restrict__ da, int da_ldc,
                                                              float* __restrict__ part, size_t S, int N,
-                                                             const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, float pro_slope) {
+                                                             const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, ActArg pro_act) {
     __shared__ float red[256][4];
+    const float pro_slope = pro_act.get();
     const int Q = C >> 2;
     const int BT = (256 / Q) * Q;
     const size_t total = (size_t)N * S * Q;
@@ -430,7 +433,7 @@ static int final_lpv(int C) {
     }
 
 int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y,
-                          int Cout, size_t S, int N, int softmax, hipStream_t s, const float* pro_scale, const float* pro_shift, float pro_slope) {
+                          int Cout, size_t S, int N, int softmax, hipStream_t s, const float* pro_scale, const float* pro_shift, ActArg pro_slope) {
     E3_REQUIRE(C % 4 == 0 && a_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
     const int lpv = final_lpv(C);
     const size_t vox = (size_t)N * S;
@@ -446,7 +449,7 @@ int conv_final_bwd_parts(size_t total_voxels) {
 }
 
 int launch_conv_final_bwd(const float* a, int a_ldc, int C, const float* w, const float* dy, float* da, int da_ldc,
-                          float* part, int Cout, size_t S, int N, hipStream_t s, const float* pro_scale, const float* pro_shift, float pro_slope) {
+                          float* part, int Cout, size_t S, int N, hipStream_t s, const float* pro_scale, const float* pro_shift, ActArg pro_slope) {
     E3_REQUIRE(C % 4 == 0 && C <= 1024, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4 and <= 1024");
     const int parts = conv_final_bwd_parts((size_t)N * S);
     E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_bwd_kernel<CO>), dim3(parts), dim3(256), 0, s, a, a_ldc, C, w, dy, da, da_ldc, part, S, N, pro_scale, pro_shift, pro_slope));

@@ -173,7 +173,8 @@ __global__ void bn_fold_multi_kernel(const FoldMultiArgs a) {
 // ------------------------------------------------------------------ BN apply + ReLU (+ max-pool)
 __global__ void bn_relu_apply_kernel(const float* __restrict__ x, int x_ldc, const float* __restrict__ scale,
                                      const float* __restrict__ shift, float* __restrict__ a, int a_ldc,
-                                     size_t voxels, int C, size_t nt_bytes, float slope) {
+                                     size_t voxels, int C, size_t nt_bytes, ActArg act) {
+    const float slope = act.get();
     const int Q = C >> 2;
     const size_t total = voxels * Q;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -208,7 +209,8 @@ __global__ void bn_relu_apply_kernel(const float* __restrict__ x, int x_ldc, con
 template <bool APPLY>
 __global__ void bn_relu_pool_kernel(const float* __restrict__ x, int x_ldc, const float* __restrict__ scale,
                                     const float* __restrict__ shift, float* __restrict__ a, int a_ldc,
-                                    float* __restrict__ pooled, int kd, int N, int D, int H, int W, int C, float slope) {
+                                    float* __restrict__ pooled, int kd, int N, int D, int H, int W, int C, ActArg act) {
+    const float slope = act.get();
     const int Q = C >> 2;
     const int Dp = (D + kd - 1) / kd, Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
     const size_t total = (size_t)N * Dp * Hp * Wp * Q;
@@ -257,6 +259,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
     const size_t units = (size_t)a.N * Dp * Hp * Wp;
     const size_t total = units * Q;
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
+    const float slope = a.act.get();
+    const bool prelu = a.act.ptr != nullptr;       // REDUCE pass: also sum dA * min(z, 0) = d(activation)/d(slope) contributions
     // Only BT = floor(256/Q)*Q threads work, so that a thread's channel quad (tid % Q) never changes across its
     // grid-stride iterations and the in-block reduction below is a fixed pattern.
     const int BT = (256 / Q) * Q;
@@ -318,7 +322,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float z = __builtin_fmaf(xv[u][e], sc[e], sh[e]);   // same expression as the forward apply
-                    const float dz = act_bwd(z, g[u][e], a.slope);
+                    const float dz = act_bwd(z, g[u][e], slope);
+                    if (!APPLYPASS && prelu) s3[e] += g[u][e] * fminf(z, 0.f);
                     const float xh = (xv[u][e] - mu[e]) * is[e];
                     if (APPLYPASS) { o[e] = ok[u] ? gi[e] * (dz - c1[e] - xh * c2[e]) - (k1[e] + xh * k2[e]) : 0.f; s3[e] += o[e]; }
                     else { s1[e] += dz; s2[e] += dz * xh; }
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                         f32x4 av;
                         f32x4 zv;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { zv[e] = __builtin_fmaf(xv[e], sc[e], sh[e]); av[e] = act_fwd(zv[e], a.slope); }
+                        for (int e = 0; e < 4; ++e) { zv[e] = __builtin_fmaf(xv[e], sc[e], sh[e]); av[e] = act_fwd(zv[e], slope); }
                         f32x4 g = {0.f, 0.f, 0.f, 0.f};
                         if (a.g1) g = *reinterpret_cast<const f32x4*>(a.g1 + v * a.g1_ldc + 4 * q);
                         f32x4 o;
@@ -372,7 +377,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                         for (int e = 0; e < 4; ++e) {
                             float dA = g[e];
                             if (!taken[e] && av[e] == pm[e]) { dA += gp[e]; taken[e] = true; }   // first arg-max wins (ATen)
-                            const float dz = act_bwd(zv[e], dA, a.slope);
+                            const float dz = act_bwd(zv[e], dA, slope);
+                            if (!APPLYPASS && prelu) s3[e] += dA * fminf(zv[e], 0.f);
                             const float xh = (xv[e] - mu[e]) * is[e];
                             if (APPLYPASS) { o[e] = gi[e] * (dz - c1[e] - xh * c2[e]) - (k1[e] + xh * k2[e]); s3[e] += o[e]; }
                             else { s1[e] += dz; s2[e] += dz * xh; }
@@ -386,9 +392,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
     // ---- block reduction: threads with equal (tid % Q) own the same channel quad
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { red[0][tid][e] = APPLYPASS ? s3[e] : s1[e]; red[1][tid][e] = s2[e]; }
+    for (int e = 0; e < 4; ++e) { red[0][tid][e] = APPLYPASS ? s3[e] : s1[e]; red[1][tid][e] = s2[e]; red[2][tid][e] = s3[e]; }
     __syncthreads();
-    const int rows = APPLYPASS ? 1 : 2;
+    const int rows = APPLYPASS ? 1 : (prelu ? 3 : 2);
     for (int t = tid; t < Q * 4 * rows; t += 256) {
         const int e = t & 3, q = (t >> 2) % Q, which = (t >> 2) / Q;
         float acc = 0.f;
@@ -738,7 +744,7 @@ int launch_fold_multi(const FoldJob* jobs, int njobs, float eps, hipStream_t s) 
 }
 
 int launch_bn_relu_apply(const float* x, int x_ldc, const float* scale, const float* shift, float* a, int a_ldc,
-                         float* pooled, int kd, int N, int D, int H, int W, int C, hipStream_t s, float slope) {
+                         float* pooled, int kd, int N, int D, int H, int W, int C, hipStream_t s, ActArg slope) {
     E3_REQUIRE(C % 4 == 0 && x_ldc % 4 == 0 && a_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
     if (!pooled) {
         const size_t vox = (size_t)N * D * H * W;
@@ -755,7 +761,7 @@ int launch_maxpool(const float* a, int a_ldc, float* pooled, int kd, int N, int 
     E3_REQUIRE(C % 4 == 0 && a_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
     const size_t items = (size_t)N * cdiv(D, kd) * cdiv(H, 2) * cdiv(W, 2) * (C / 4);
     hipLaunchKernelGGL(bn_relu_pool_kernel<false>, dim3(ew_grid(items)), dim3(EW_BLOCK), 0, s, a, a_ldc,
-                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 0, pooled, kd, N, D, H, W, C, 0.f);
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 0, pooled, kd, N, D, H, W, C, ActArg(0.f));
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
@@ -796,6 +802,30 @@ int launch_bn_bwd_apply(BnBwdArgs a, hipStream_t s) { return bn_bwd_launch(a, tr
 
 int launch_bn_bwd_finalize(const float* part, int parts, int C, float inv_n, float* dgamma, float* dbeta, float* coef, hipStream_t s) {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, part, parts, C, inv_n, dgamma, dbeta, coef);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+// PReLU slope gradient: sum of row 2 of the REDUCE pass' partials over rows and channels, fixed order
+__global__ __launch_bounds__(256) void prelu_dslope_kernel(const float* __restrict__ part, int parts, int C, float* __restrict__ tmp, float* __restrict__ dslope) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c = wv; c < C; c += 4) {                    // one wave per channel at a time
+        double s = 0.0;
+        for (int p = lane; p < parts; p += 64) s += part[((size_t)p * 3 + 2) * C + c];
+        s = wave_sum(s);
+        if (lane == 0) tmp[c] = (float)s;
+    }
+    __syncthreads();
+    double t = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) t += (double)tmp[c];
+    t = wave_sum(t);
+    if (lane == 0) red[wv] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) dslope[0] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+int launch_prelu_dslope(const float* part, int parts, int C, float* tmp, float* dslope, hipStream_t s) {
+    hipLaunchKernelGGL(prelu_dslope_kernel, dim3(1), dim3(256), 0, s, part, parts, C, tmp, dslope);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

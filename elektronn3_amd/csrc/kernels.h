@@ -99,18 +99,18 @@ int launch_conv_small_fwd(ConvSmallArgs a, hipStream_t s);
 // dW partials for the first layer: part[split][T][CoPad=Cout][CiPad=Cin] ; returns number of splits used
 int conv_small_wgrad_splits(int N, int D, int H, int W, int planar);
 // optional fusion of the BN + ReLU backward (APPLY pass) of the conv's own output into the staging of dy; biaspart [splits][Cout]
-struct SmallWgradFuse { const float* x1; int x1_ldc; const float* g; int g_ldc; const float *scale, *shift, *mean, *invstd, *gamma, *coef; float* biaspart; float slope; };
+struct SmallWgradFuse { const float* x1; int x1_ldc; const float* g; int g_ldc; const float *scale, *shift, *mean, *invstd, *gamma, *coef; float* biaspart; ActArg act; };
 int launch_conv_small_wgrad(const float* x, int Cin, const float* dy, int dy_ldc, float* part,
                             int N, int D, int H, int W, int Cout, int planar, hipStream_t s, const SmallWgradFuse* fuse = nullptr);
 
 // final 1x1x1 conv: C (multiple of 4) -> Cout (<= 8); output and its gradient are NCDHW (the module boundary)
 int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y_ncdhw,
                           int Cout, size_t voxels_per_sample, int N, int softmax, hipStream_t s,
-                          const float* pro_scale = nullptr, const float* pro_shift = nullptr, float pro_slope = 0.f);   // a := act(a*scale + shift) while loading
+                          const float* pro_scale = nullptr, const float* pro_shift = nullptr, ActArg pro_act = ActArg(0.f));   // a := act(a*scale + shift) while loading
 int conv_final_bwd_parts(size_t total_voxels);
 int launch_conv_final_bwd(const float* a, int a_ldc, int C, const float* w, const float* dy_ncdhw, float* da, int da_ldc,
                           float* part /*[parts][Cout][C+1]*/, int Cout, size_t voxels_per_sample, int N, hipStream_t s,
-                          const float* pro_scale = nullptr, const float* pro_shift = nullptr, float pro_slope = 0.f);
+                          const float* pro_scale = nullptr, const float* pro_shift = nullptr, ActArg pro_act = ActArg(0.f));
 
 // ---------------------------------------------------------------- weighted CE + Dice criterion (loss.hip)
 size_t ce_dice_workspace_floats(int C);
@@ -134,6 +134,8 @@ int launch_fold_multi(const FoldJob* jobs, int njobs, float eps, hipStream_t s);
 constexpr int COLSUM_MAX_JOBS = 40;
 struct ColsumJob { const float* part; int parts, stride, offset, C; float* out; };
 int launch_colsum_multi(const ColsumJob* jobs, int njobs, hipStream_t s);   // out[c] = sum_p part[p*stride + offset + c], many at once
+// PReLU: dslope[0] = sum over channels and partial rows of row 2 of the REDUCE pass' `part` (fixed order); tmp: [C] floats
+int launch_prelu_dslope(const float* part, int parts, int C, float* tmp, float* dslope, hipStream_t s);
 int launch_gn_bwd_coef(const float* dgamma, const float* dbeta, const float* gamma, const float* invstd, int C, int group, float inv_n,
                        float* coef, hipStream_t s);   // GroupNorm: rewrites coef after launch_bn_bwd_finalize
 int launch_fill(float* p, float v, size_t n, hipStream_t s);
@@ -188,7 +190,7 @@ int launch_bn_fold(const float* gamma, const float* beta, const float* rm, const
 // a = relu(x*scale+shift) written to `a` (any ldc); optionally also p = maxpool_{kd,2,2}(a), ceil mode
 int launch_bn_relu_apply(const float* x, int x_ldc, const float* scale, const float* shift, float* a, int a_ldc,
                          float* pooled /*null or packed NDHWC (ceil dims)*/, int kd,
-                         int N, int D, int H, int W, int C, hipStream_t s, float slope = 0.f);   // slope: 0 ReLU, 0.1 LeakyReLU, 1 identity
+                         int N, int D, int H, int W, int C, hipStream_t s, ActArg slope = ActArg(0.f));   // slope: 0 ReLU, 0.1 LeakyReLU, 1 identity, ...
 int launch_maxpool(const float* a, int a_ldc, float* pooled, int kd, int N, int D, int H, int W, int C, hipStream_t s);
 
 // backward of x -> (scale,shift) -> relu, with dA = g1 (+ unpool(gpool) through the max-pool of `a`)
@@ -209,7 +211,8 @@ struct BnBwdArgs {
     // non-pool path, g1 == nullptr: the incoming gradient is that of the 1x1x1 head, g[v][c] = sum_co head_dy[n][co][sp] * head_w[co][c],
     // recomputed from the (tiny) NCDHW logits gradient instead of being written by conv_final_bwd and re-read twice
     const float* head_dy; const float* head_w; int head_cout; size_t head_S;
-    float slope;                          // activation: 0 = ReLU, > 0 = LeakyReLU(slope), 1 = identity
+    ActArg act;                           // activation: slope 0 = ReLU, > 0 = LeakyReLU(slope), 1 = identity, ACT_SILU; or a PReLU pointer
+    // PReLU: the REDUCE pass also writes sum dA*min(z,0) per channel into row 2 of `part` (the APPLY pass overwrites it later)
 };
 int bn_bwd_parts(size_t voxels, int C);
 int launch_bn_bwd_reduce(BnBwdArgs a, hipStream_t s);

@@ -27,6 +27,7 @@ struct ConvUnit {           // conv (3x3x3 | 1x3x3 | transposed 2x2x2) followed 
     int planar;             // planar block (1x3x3 / (1,2,2))
     int is_up;              // 1: transposed conv, 2: ResizeConv = nearest up-sampling + 3x3x3 conv (input at level+1); 0: plain conv
     int p_w, p_b, p_g, p_be, p_rm, p_rv;   // indices into the param table
+    int p_a;                // nn.PReLU weight of the activation after this conv ('prelu'), -1 otherwise
     int bn_index;           // -1: no normalisation after this conv (nn.Identity): conv -> bias -> ReLU
     bool has_norm() const { return bn_index >= 0; }
 };
@@ -67,7 +68,8 @@ int add_param(e3_unet_plan* p, const std::string& name, int64_t numel, int kind)
     return (int)p->params.size() - 1;
 }
 
-void add_unit(e3_unet_plan* p, const std::string& conv, const std::string& bn, int cin, int cout, int level, int planar, int is_up, bool norm) {
+void add_unit(e3_unet_plan* p, const std::string& conv, const std::string& bn, int cin, int cout, int level, int planar, int is_up, bool norm,
+              const std::string& act = "") {
     const bool group = p->cfg.normalization == 2;    // nn.GroupNorm: weight and bias only, no running statistics
     ConvUnit u;
     u.name = conv; u.bn_name = bn; u.cin = cin; u.cout = cout; u.level = level; u.planar = planar; u.is_up = is_up;
@@ -85,6 +87,7 @@ void add_unit(e3_unet_plan* p, const std::string& conv, const std::string& bn, i
         }
         u.bn_index = p->n_bn++;
     }
+    u.p_a = (p->cfg.act_slope == ACT_PRELU && !act.empty()) ? add_param(p, act + ".weight", 1, 0) : -1;
     p->units.push_back(u);
 }
 
@@ -215,7 +218,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         if (training && conv_use_wino(CONV_K3, 0, N, lo.D, lo.H, lo.W, u.cout, u.cin)) B.wpk_d[k] = T.take(conv_packed_floats(CONV_K3, u.cout, u.cin));
     }
     B.stats = T.take(statmax);
-    B.small = T.take((size_t)4 * p->chan(nb - 1) + 64);
+    B.small = T.take((size_t)5 * p->chan(nb - 1) + 64);   // [4][C] backward coefficients + [C] PReLU scratch
     B.bnred = T.take((size_t)BN_PRERED * p->chan(nb - 1) * 3);
     B.ones = T.take(p->chan(nb - 1)); B.zeros = T.take((size_t)4 * p->chan(nb - 1));
     B.bnpart_u.assign(p->units.size(), nullptr);
@@ -268,8 +271,8 @@ int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
     E3_REQUIRE(cfg->out_channels >= 1 && cfg->out_channels <= 8, E3_ERR_UNSUPPORTED, "out_channels must be in 1..8 on the HIP path");
     E3_REQUIRE(cfg->start_filts >= 8 && cfg->start_filts % 8 == 0, E3_ERR_UNSUPPORTED, "start_filts must be a multiple of 8 on the HIP path");
     E3_REQUIRE((cfg->start_filts << (cfg->n_blocks - 1)) <= 1024, E3_ERR_UNSUPPORTED, "more than 1024 channels at the bottom level");
-    E3_REQUIRE((cfg->act_slope >= 0.f && cfg->act_slope <= 1.f) || cfg->act_slope == ACT_SILU, E3_ERR_INVALID,
-               "act_slope must be in [0, 1] (0 ReLU, 0.1 LeakyReLU, 1 identity) or 2 (SiLU)");
+    E3_REQUIRE((cfg->act_slope >= 0.f && cfg->act_slope <= 1.f) || cfg->act_slope == ACT_SILU || cfg->act_slope == ACT_PRELU, E3_ERR_INVALID,
+               "act_slope must be in [0, 1] (0 ReLU, 0.1 LeakyReLU, 1 identity), 2 (SiLU) or 3 (PReLU: learnable slopes in the parameter table)");
     E3_REQUIRE(cfg->normalization >= 0 && cfg->normalization <= 2, E3_ERR_UNSUPPORTED, "normalization must be 0 (none), 1 (batch) or 2 (group)");
     if (cfg->normalization == 2)
         E3_REQUIRE(cfg->num_groups >= 1 && cfg->start_filts % cfg->num_groups == 0, E3_ERR_INVALID, "num_groups must divide every channel count");
@@ -281,16 +284,16 @@ int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
     for (int i = 0; i < nb; ++i) {   // unet.py:832-850
         const std::string b = "down_convs." + std::to_string(i) + ".";
         const int ins = i == 0 ? cfg->in_channels : p->chan(i - 1), outs = p->chan(i);
-        add_unit(p, b + "conv1", b + "norm0", ins, outs, i, p->planar(i), 0, all_norm);     // unet.py:238-242
-        add_unit(p, b + "conv2", b + "norm1", outs, outs, i, p->planar(i), 0, last_norm);
+        add_unit(p, b + "conv1", b + "norm0", ins, outs, i, p->planar(i), 0, all_norm, b + "act1");     // unet.py:235-242
+        add_unit(p, b + "conv2", b + "norm1", outs, outs, i, p->planar(i), 0, last_norm, b + "act2");
     }
     for (int k = 0; k + 1 < nb; ++k) {   // unet.py:854-879: block k works at level nb-2-k
         const int j = nb - 2 - k;
         const std::string b = "up_convs." + std::to_string(k) + ".";
         const int ins = p->chan(j + 1), outs = p->chan(j);
-        add_unit(p, b + (cfg->up_resize ? "upconv.conv" : "upconv"), b + "norm0", ins, outs, j, p->planar(j), cfg->up_resize ? 2 : 1, all_norm);   // unet.py:152-176,369-375
-        add_unit(p, b + "conv1", b + "norm1", cfg->merge_add ? outs : 2 * outs, outs, j, p->planar(j), 0, all_norm);   // unet.py:352-360
-        add_unit(p, b + "conv2", b + "norm2", outs, outs, j, p->planar(j), 0, last_norm);
+        add_unit(p, b + (cfg->up_resize ? "upconv.conv" : "upconv"), b + "norm0", ins, outs, j, p->planar(j), cfg->up_resize ? 2 : 1, all_norm, b + "act0");   // unet.py:152-176,365-375
+        add_unit(p, b + "conv1", b + "norm1", cfg->merge_add ? outs : 2 * outs, outs, j, p->planar(j), 0, all_norm, b + "act1");   // unet.py:352-360
+        add_unit(p, b + "conv2", b + "norm2", outs, outs, j, p->planar(j), 0, last_norm, b + "act2");
     }
     p->p_final_w = add_param(p, "conv_final.weight", (int64_t)cfg->out_channels * p->chan(0), 0);
     p->p_final_b = add_param(p, "conv_final.bias", cfg->out_channels, 0);
@@ -409,6 +412,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         const bool pool_after = is_enc_conv2 && u.level < nb - 1;
         const int kd = u.planar ? 1 : 2;
         const float slope = cfg.act_slope;
+        const ActArg act = u.p_a >= 0 ? ActArg(0.f, P(u.p_a)) : ActArg(slope);
         const bool bn_train = training && u.has_norm();   // batch statistics needed: conv writes the raw output, BN+ReLU is a second pass
         const bool two_pass = bn_train || slope != 0.f || u.is_up == 2;   // (non-ReLU activations are not in the conv epilogues; the
                                                                            // ResizeConv output may need the autocrop before the norm)
@@ -486,10 +490,10 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             // (forward and backward): no apply pass, no activation tensor
             if (k + 1 < plan->units.size())
                 RUN(launch_bn_relu_apply(b.raw, u.cout, b.scale, b.shift, b.act, b.act_ldc, pool_after ? B.pooled[u.level] : nullptr, kd,
-                                         N, lo.D, lo.H, lo.W, u.cout, s, slope));
+                                         N, lo.D, lo.H, lo.W, u.cout, s, act));
         } else if (two_pass) {      // raw = pure accumulations; (scale, shift) = folded eval-mode BN, or (1, conv bias) without a norm
             RUN(launch_bn_relu_apply(b.raw, u.cout, b.scale, b.shift, b.act, b.act_ldc, pool_after ? B.pooled[u.level] : nullptr, kd,
-                                     N, lo.D, lo.H, lo.W, u.cout, s, slope));
+                                     N, lo.D, lo.H, lo.W, u.cout, s, act));
         } else if (pool_after) {
             RUN(launch_maxpool(b.act, b.act_ldc, B.pooled[u.level], kd, N, lo.D, lo.H, lo.W, u.cout, s));
         }
@@ -509,7 +513,8 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         Prof pr(plan, s, (int)plan->units.size(), 0);
         RUN(launch_conv_final_fwd(fused ? lb.raw : cur, fused ? lu.cout : cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y,
                                   cfg.out_channels, L[0].vox / N, N, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s,
-                                  fused ? lb.scale : nullptr, fused ? lb.shift : nullptr, cfg.act_slope));
+                                  fused ? lb.scale : nullptr, fused ? lb.shift : nullptr,
+                                  lu.p_a >= 0 ? ActArg(0.f, P(lu.p_a)) : ActArg(cfg.act_slope)));
     }
     return E3_OK;
 }
@@ -542,7 +547,8 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
           // the gradient w.r.t. the last activation is not written: the BN backward of the last unit recomputes it from dy and the head's
           // weights (2 fma per element instead of one 4-byte write and two 4-byte reads)
           RUN(launch_conv_final_bwd(fused ? last.raw : last.act, fused ? C0 : last.act_ldc, C0, P(plan->p_final_w), dy, nullptr, C0, B.slab,
-                                    cfg.out_channels, L[0].vox / N, N, s, fused ? last.scale : nullptr, fused ? last.shift : nullptr, cfg.act_slope)); }
+                                    cfg.out_channels, L[0].vox / N, N, s, fused ? last.scale : nullptr, fused ? last.shift : nullptr,
+                                    plan->units.back().p_a >= 0 ? ActArg(0.f, P(plan->units.back().p_a)) : ActArg(cfg.act_slope))); }
         RUN(launch_colsum_finalize(B.slab, parts, ps, 0, cfg.out_channels * C0, G(plan->p_final_w), s));
         RUN(launch_colsum_finalize(B.slab, parts, ps, cfg.out_channels * C0, cfg.out_channels, G(plan->p_final_b), s));
     }
@@ -581,7 +587,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         {
             BnBwdArgs a{};
             a.x = b.raw; a.x_ldc = u.cout; a.mean = b.mean; a.invstd = b.invstd; a.scale = b.scale; a.shift = b.shift;
-            a.slope = cfg.act_slope;
+            a.act = u.p_a >= 0 ? ActArg(0.f, P(u.p_a)) : ActArg(cfg.act_slope);
             if (u.has_norm()) a.gamma = P(u.p_g);
             else {   // nn.Identity + activation: dz = dA * act'(z) is the APPLY pass with the constants of an identity "norm":
                      // mean 0, invstd 1, gamma 1, c = k = 0  =>  dx = dz, sum dx = conv-bias gradient.  ReLU: x := a (mask 1*a + 0 > 0);
@@ -596,8 +602,13 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             else { a.g1 = g; a.g1_ldc = g_ldc; }
             a.kd = kd; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.C = u.cout;
             a.parts = bn_bwd_parts(lo.vox, u.cout); a.part = B.bnpart_u[k]; a.coef = B.small; a.dx = dxr; a.dx_ldc = u.cout;
+            if (!u.has_norm() && u.p_a >= 0) {   // no norm, but the PReLU slope gradient needs the REDUCE pass (its row 2)
+                RUN(launch_bn_bwd_reduce(a, s));
+                RUN(launch_prelu_dslope(a.part, a.parts, u.cout, B.small + 4 * u.cout, G(u.p_a), s));
+            }
             if (u.has_norm()) {
                 RUN(launch_bn_bwd_reduce(a, s));
+                if (u.p_a >= 0) RUN(launch_prelu_dslope(a.part, a.parts, u.cout, B.small + 4 * u.cout, G(u.p_a), s));
                 RUN(launch_bn_bwd_finalize(a.part, a.parts, u.cout, (float)(1.0 / (double)lo.vox), G(u.p_g), G(u.p_be), B.small, s));
                 if (cfg.normalization == 2)
                     RUN(launch_gn_bwd_coef(G(u.p_g), G(u.p_be), P(u.p_g), b.invstd, u.cout, u.cout / cfg.num_groups, (float)(1.0 / (double)lo.vox), B.small, s));
@@ -606,7 +617,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             static const bool no_first_fuse = getenv("E3_NO_FIRST_FUSE") != nullptr;     // A/B switch
             fuse_first = k == 0 && !dx && u.cin < 8 && !u.is_up && !no_first_fuse && cfg.normalization != 2;   // (the fused staging has no group terms)
             if (fuse_first) {
-                first_fuse = SmallWgradFuse{a.x, a.x_ldc, a.g1, a.g1_ldc, a.scale, a.shift, a.mean, a.invstd, a.gamma, a.coef, B.biaspart0, cfg.act_slope};
+                first_fuse = SmallWgradFuse{a.x, a.x_ldc, a.g1, a.g1_ldc, a.scale, a.shift, a.mean, a.invstd, a.gamma, a.coef, B.biaspart0, a.act};
                 bias_jobs.push_back({B.biaspart0, conv_small_wgrad_splits(N, lo.D, lo.H, lo.W, u.planar), u.cout, 0, u.cout, G(u.p_b)});
             } else {
                 RUN(launch_bn_bwd_apply(a, s));

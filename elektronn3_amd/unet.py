@@ -193,7 +193,7 @@ def _activation_slope(activation):
     (nn.LeakyReLU(negative_slope=0.1)), 'lin' 1 (nn.Identity); module instances of those types are accepted like the reference does
     (it deep-copies them).  None = not on the HIP path."""
     if isinstance(activation, str):
-        return {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0}.get(activation)     # (2.0 = ACT_SILU in csrc/common.h)
+        return {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0, 'prelu': 3.0}.get(activation)     # (2.0 = ACT_SILU, 3.0 = ACT_PRELU in csrc/common.h)
     if isinstance(activation, nn.LeakyReLU):
         return float(activation.negative_slope) if 0.0 <= activation.negative_slope <= 1.0 else None
     if isinstance(activation, nn.ReLU):
@@ -202,12 +202,15 @@ def _activation_slope(activation):
         return 1.0
     if isinstance(activation, nn.SiLU):
         return 2.0
+    if isinstance(activation, nn.PReLU) and activation.num_parameters == 1:
+        return 3.0
     return None
 
 
 def _make_activation(activation):
     if isinstance(activation, str):
-        return {'relu': nn.ReLU, 'leaky': lambda: nn.LeakyReLU(negative_slope=0.1), 'lin': nn.Identity, 'silu': nn.SiLU}[activation]()
+        return {'relu': nn.ReLU, 'leaky': lambda: nn.LeakyReLU(negative_slope=0.1), 'lin': nn.Identity, 'silu': nn.SiLU,
+                'prelu': lambda: nn.PReLU(num_parameters=1)}[activation]()
     import copy
     return copy.deepcopy(activation)
 
@@ -314,7 +317,7 @@ class UNet(nn.Module):
     """3D U-Net with the reference's interface (elektronn3/models/unet.py:755-771), executed by hand-written HIP
     kernels.  Options of the reference that are not yet on the HIP path raise ``NotImplementedError`` at
     construction: ``up_mode='upsample'``,
-    ``attention=True``, ``activation`` other than ``'relu'`` / ``'leaky'`` / ``'lin'`` / ``'silu'``,
+    ``attention=True``, ``activation='rrelu'`` (random slopes),
     ``conv_mode != 'same'``.  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
     the 3D one with every block planar and a depth of 1."""
 

@@ -61,7 +61,8 @@ typedef struct e3_unet_cfg {
     int32_t num_groups;     /* normalization = 2: number of groups (8 for 'group', G for 'group<G>', unet.py:81-90) */
     int32_t up_resize;      /* 0: up_mode='transpose' (nn.ConvTranspose3d k=s=2); 1: 'resizeconv_nearest', 2: 'resizeconv_linear', 3 / 4: the same with a 1x1x1 conv ('resizeconv_nearest1' / 'resizeconv_linear1') (ResizeConv: nn.Upsample(nearest | tri-/bilinear, align_corners=False) + conv3,
                              * unet.py:152-176,411-449; parameters 'up_convs.i.upconv.conv.weight/bias') */
-    float act_slope;        /* activation (get_activation, unet.py:183-199): 0 = 'relu', 0.1 = 'leaky' (LeakyReLU(0.1)), 1 = 'lin' (identity), 2 = 'silu' */
+    float act_slope;        /* activation (get_activation, unet.py:183-199): 0 = 'relu', 0.1 = 'leaky' (LeakyReLU(0.1)), 1 = 'lin' (identity), 2 = 'silu',
+                             * 3 = 'prelu' (nn.PReLU(1) per activation: parameters '<block>.act<k>.weight' join the table) */
 } e3_unet_cfg;
 
 typedef struct e3_unet_plan e3_unet_plan;

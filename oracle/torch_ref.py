@@ -15,8 +15,10 @@ import torch
 import torch.nn.functional as F
 
 
-def _act(x, sd):
+def _act(x, sd, name=None):
     """get_activation (unet.py:183-199): ReLU unless sd['__act_slope__'] says LeakyReLU(slope) (1.0 = nn.Identity, 'lin'; 2.0 = nn.SiLU)."""
+    if name is not None and name + '.weight' in sd:      # nn.PReLU(num_parameters=1): learnable slope of THIS activation module
+        return F.prelu(x, sd[name + '.weight'])
     s = sd.get('__act_slope__', 0.0)
     if s == 2.0:
         return F.silu(x)
@@ -68,8 +70,8 @@ def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True):
     enc = []
     for i in range(n_blocks):
         p = f'down_convs.{i}.'
-        y = _act(_bn(_conv(x, sd, p + 'conv1'), sd, p + 'norm0', training), sd)
-        y = _act(_bn(_conv(y, sd, p + 'conv2'), sd, p + 'norm1', training), sd)
+        y = _act(_bn(_conv(x, sd, p + 'conv1'), sd, p + 'norm0', training), sd, p + 'act1')
+        y = _act(_bn(_conv(y, sd, p + 'conv2'), sd, p + 'norm1', training), sd, p + 'act2')
         enc.append(y)
         if i < n_blocks - 1:
             if y.dim() == 4:
@@ -91,11 +93,11 @@ def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True):
             w = sd[p + 'upconv.weight']
             up = (F.conv_transpose3d if w.dim() == 5 else F.conv_transpose2d)(x, w, sd[p + 'upconv.bias'], stride=tuple(w.shape[2:]))
         skip, up = autocrop(enc[-(i + 2)], up)
-        up = _act(_bn(up, sd, p + 'norm0', training), sd)
+        up = _act(_bn(up, sd, p + 'norm0', training), sd, p + 'act0')
         cat = sd[p + 'conv1.weight'].shape[1] == 2 * up.shape[1]      # merge_mode 'concat' vs 'add' (unet.py:398-401) shows in conv1's Cin
         y = torch.cat((up, skip), 1) if cat else up + skip
-        y = _act(_bn(_conv(y, sd, p + 'conv1'), sd, p + 'norm1', training), sd)
-        x = _act(_bn(_conv(y, sd, p + 'conv2'), sd, p + 'norm2', training), sd)
+        y = _act(_bn(_conv(y, sd, p + 'conv1'), sd, p + 'norm1', training), sd, p + 'act1')
+        x = _act(_bn(_conv(y, sd, p + 'conv2'), sd, p + 'norm2', training), sd, p + 'act2')
     return _conv(x, sd, 'conv_final')
 
 

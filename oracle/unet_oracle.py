@@ -271,6 +271,14 @@ class OracleUNet:
         self.training = True
 
     # -- helpers
+    @staticmethod
+    def _act_name(norm_name):
+        """Activation module that follows a norm slot: DownConv norm0/norm1 -> act1/act2 (unet.py:244-253), UpConv norm0/1/2 -> act0/1/2
+        (unet.py:396-407)."""
+        block, norm = norm_name.rsplit('.', 1)
+        k = int(norm[-1])
+        return f'{block}.act{k + 1 if block.startswith("down_convs") else k}'
+
     def _conv(self, name, x, cache):
         w, b = self.sd[name + '.weight'], self.sd[name + '.bias']
         pad = tuple((k - 1) // 2 for k in w.shape[2:])
@@ -305,7 +313,12 @@ class OracleUNet:
         else:
             y = x
         # get_activation (unet.py:183-199): 'relu', or LeakyReLU(0.1) ('leaky') / identity ('lin') via act_slope
-        if self.act_slope == 2.0:      # nn.SiLU: y * sigmoid(y); the backward needs the pre-activation
+        aname = self._act_name(name)
+        if (aname + '.weight') in self.sd:      # nn.PReLU(num_parameters=1): max(y, 0) + w * min(y, 0) with this module's learnable w
+            w = np.float32(self.sd[aname + '.weight'].reshape(-1)[0])
+            a = np.where(y > 0, y, w * y).astype(np.float32)
+            cache[name + '.pre'] = y
+        elif self.act_slope == 2.0:      # nn.SiLU: y * sigmoid(y); the backward needs the pre-activation
             y64 = np.asarray(y, np.float64)
             a = (y64 / (1.0 + np.exp(-y64))).astype(np.float32)
             cache[name + '.pre'] = y64
@@ -373,7 +386,13 @@ class OracleUNet:
     # -- backward
     def _norm_act_bwd(self, name, da, cache, grads):
         a = cache[name + '.act']
-        if self.act_slope == 2.0:
+        aname = self._act_name(name)
+        if (aname + '.weight') in self.sd:
+            y = cache[name + '.pre']; w = np.float32(self.sd[aname + '.weight'].reshape(-1)[0])
+            da64 = np.asarray(da, np.float64)
+            grads[aname + '.weight'] = np.array([(da64 * np.minimum(np.asarray(y, np.float64), 0.0)).sum()], np.float32)
+            dy = (_f32(da) * np.where(y > 0, np.float32(1), w)).astype(np.float32)
+        elif self.act_slope == 2.0:
             z = cache[name + '.pre']; sg = 1.0 / (1.0 + np.exp(-z))
             dy = (np.asarray(da, np.float64) * sg * (1.0 + z * (1.0 - sg))).astype(np.float32)
         elif self.act_slope == 0.0:

@@ -166,6 +166,8 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
                 p.copy_(1.0 + 0.2 * torch.randn_like(p))
             elif name.endswith('bias'):
                 p.copy_(0.1 * torch.randn_like(p))
+            elif '.act' in name:                     # nn.PReLU slopes: distinct values, also negative ones
+                p.copy_(0.25 + 0.3 * torch.randn_like(p))
     sd0 = {k: npy(v).copy() for k, v in model.state_dict().items()}
     x = torch.randn(batch, 1, *shape)
     target = torch.randint(0, 2, (batch, *shape))
@@ -318,6 +320,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'resizelin':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizelinear_odd.npz', seed=13, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(7, 15, 18), batch=2, up_mode='resizeconv_linear')
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'prelu':
+        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_prelu_odd.npz', seed=15, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 15, 19), batch=2, activation='prelu', full_norm=False)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'silu':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_silu_odd.npz', seed=11, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 15, 18), batch=2, activation='silu')
         sys.exit(0)
@@ -359,6 +364,8 @@ if __name__ == '__main__':
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizeconv_odd.npz', seed=12, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 19), batch=2, up_mode='resizeconv_nearest')
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizelinear_odd.npz', seed=13, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(7, 15, 18), batch=2, up_mode='resizeconv_linear')
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizenearest1_odd.npz', seed=14, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 13, 18), batch=2, up_mode='resizeconv_nearest1')
+    # nn.PReLU(1) activations (learnable slopes) with the sparse norm scheme: slopes behind a norm and behind nn.Identity
+    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_prelu_odd.npz', seed=15, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 15, 19), batch=2, activation='prelu', full_norm=False)
     make_predictor(unet, inference, f'{HERE}/predictor.npz')
     make_adamw(f'{HERE}/adamw.npz')
     make_trainsteps(unet, loss_mod, f'{HERE}/trainsteps.npz')

@@ -73,7 +73,8 @@ CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_plana
          'unet_nb2_sf8_nonorm.npz', 'unet_nb3_sf8_planar0_sparsenorm.npz', 'unet_nb3_sf8_add_odd.npz', 'unet_nb3_sf8_instance.npz',
          'unet_nb3_sf8_group4_odd.npz', 'unet_nb3_sf8_leaky_odd.npz', 'unet_nb2_sf8_lin_nonorm.npz',
          'unet_nb3_sf8_silu_odd.npz', 'unet_nb3_sf8_resizeconv_odd.npz',
-         'unet_nb3_sf8_resizelinear_odd.npz', 'unet_nb3_sf8_resizenearest1_odd.npz']
+         'unet_nb3_sf8_resizelinear_odd.npz', 'unet_nb3_sf8_resizenearest1_odd.npz',
+         'unet_nb3_sf8_prelu_odd.npz']
 
 
 @pytest.mark.parametrize('case', CASES)
@@ -87,7 +88,7 @@ def test_unet_train_step(case):
         net = orc.OracleUNet(sub(g, 'sd0'), cfg['n_blocks'], cfg['planar_blocks'], normalization=cfg.get('normalization', 'batch'))
         net.instance_norms = instance_norm_names(cfg)
         net.up_linear = str(cfg.get('up_mode')).startswith('resizeconv_linear')
-        net.act_slope = {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0}[cfg.get('activation', 'relu')]
+        net.act_slope = {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0, 'prelu': 3.0}[cfg.get('activation', 'relu')]
         logits = net.forward(g['x'])
     # forward: fp32 reference noise floor is <= 4e-5 max-abs
     np.testing.assert_allclose(logits, g['logits'], rtol=1e-4, atol=1e-4)

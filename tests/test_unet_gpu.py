@@ -23,7 +23,8 @@ CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_plana
          'unet_nb2_sf8_nonorm.npz', 'unet_nb3_sf8_planar0_sparsenorm.npz', 'unet_nb3_sf8_add_odd.npz', 'unet_nb3_sf8_instance.npz',
          'unet_nb3_sf8_group4_odd.npz', 'unet_nb3_sf8_leaky_odd.npz', 'unet_nb2_sf8_lin_nonorm.npz',
          'unet_nb3_sf8_silu_odd.npz', 'unet_nb3_sf8_resizeconv_odd.npz',
-         'unet_nb3_sf8_resizelinear_odd.npz', 'unet_nb3_sf8_resizenearest1_odd.npz']
+         'unet_nb3_sf8_resizelinear_odd.npz', 'unet_nb3_sf8_resizenearest1_odd.npz',
+         'unet_nb3_sf8_prelu_odd.npz']
 
 
 def build(cfg, sd_np):
@@ -249,10 +250,11 @@ def test_full_size_cfg4_anisotropic_against_pytorch_rocm():
                                 dict(activation='leaky'), dict(activation='leaky', normalization='none', planar_blocks=(0,)),
                                 dict(activation='lin', normalization='group', full_norm=False),
                                 dict(activation='silu', planar_blocks=(0,)), dict(activation='silu', normalization='none'),
+                                dict(activation='prelu', planar_blocks=(0,)), dict(activation='prelu', normalization='none'),
                                 dict(up_mode='resizeconv_nearest'), dict(up_mode='resizeconv_nearest', planar_blocks=(0,), normalization='group', full_norm=False),
                                 dict(up_mode='resizeconv_linear', planar_blocks=(0,)), dict(up_mode='resizeconv_linear1', planar_blocks=(0,))],
                          ids=['nonorm', 'sparsenorm', 'add', 'add_nonorm_planar', 'instance', 'group8', 'group16_sparse_add',
-                              'leaky', 'leaky_nonorm_planar', 'lin_group', 'silu_planar', 'silu_nonorm', 'resizeconv', 'resizeconv_planar_group_sparse', 'resizelinear_planar', 'resizelinear1_planar'])
+                              'leaky', 'leaky_nonorm_planar', 'lin_group', 'silu_planar', 'silu_nonorm', 'prelu_planar', 'prelu_nonorm', 'resizeconv', 'resizeconv_planar_group_sparse', 'resizelinear_planar', 'resizelinear1_planar'])
 def test_option_variants_against_pytorch_rocm(kw):
     """normalization='none' and full_norm=False (norm layers = nn.Identity, unet.py:77-80,238-242,369-375) at a size that runs the
     Winograd kernels (conv -> bias -> ReLU fused in their epilogue, also in training), and merge_mode='add' (unet.py:398-401: the skip
@@ -267,6 +269,8 @@ def test_option_variants_against_pytorch_rocm(kw):
         for k, p in m.named_parameters():
             if k.endswith('.bias'):
                 p.copy_(0.1 * torch.randn_like(p))
+            elif '.act' in k:
+                p.copy_(0.25 + 0.3 * torch.randn_like(p))
     x = torch.randn(2, 1, 32, 64, 64, device='cuda')
     t = torch.randint(0, 2, (2, 32, 64, 64), device='cuda')
     sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
@@ -279,7 +283,7 @@ def test_option_variants_against_pytorch_rocm(kw):
     pl = tuple(kw.get('planar_blocks', ()))
     group = str(kw.get('normalization', '')).startswith('group')
     sd_ref['__up_linear__'] = str(kw.get('up_mode')).startswith('resizeconv_linear')
-    sd_ref['__act_slope__'] = {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0}[kw.get('activation', 'relu')]
+    sd_ref['__act_slope__'] = {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0, 'prelu': 3.0}[kw.get('activation', 'relu')]
     sd_ref['__instance_norms__'] = paramless
     sd_ref['__num_groups__'] = 8 if kw.get('normalization') == 'group' else (int(kw['normalization'][5:]) if group else 0)
     ref = unet_forward(sd_ref, x.double(), 3, pl, training=True)

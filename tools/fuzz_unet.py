@@ -35,7 +35,7 @@ for case in range(n_cases):
     elif v == 4: kw = dict(normalization=('group', 'group4', 'group2')[ri(0, 2)], full_norm=bool(ri(0, 1)))
     if ri(0, 3) == 0: kw['merge_mode'] = 'add'
     if ri(0, 3) == 0 and 'merge_mode' not in kw: kw['up_mode'] = ('resizeconv_nearest', 'resizeconv_linear', 'resizeconv_nearest1', 'resizeconv_linear1')[ri(0, 3)]
-    if ri(0, 3) == 0: kw['activation'] = ('leaky', 'lin', 'silu')[ri(0, 2)]
+    if ri(0, 3) == 0: kw['activation'] = ('leaky', 'lin', 'silu', 'prelu')[ri(0, 3)]
     shape = (H, W) if D is None else (D, H, W)
     torch.manual_seed(case)
     try:
@@ -44,13 +44,16 @@ for case in range(n_cases):
         print('skip (ctor):', nb, sf, planar, e); continue
     x = torch.randn(N, inc, *shape, device='cuda'); t = torch.randint(0, outc, (N, *shape), device='cuda')
     cw = tuple(float(v) for v in (torch.rand(outc, generator=g) + 0.2))
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if '.act' in k: p.copy_(0.25 + 0.3 * torch.randn_like(p))      # PReLU slopes: distinct, some negative
     sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
     out = m(x); loss = combined_loss(out, t, cw); m.zero_grad(set_to_none=True); loss.backward()
     sd_ref = {k: (v.double() if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd0.items()}
     paramless = R.instance_norm_names(nb, kw.get('full_norm', True)) if kw.get('normalization') == 'instance' else ()
     sd_ref['__instance_norms__'] = paramless
     sd_ref['__up_linear__'] = str(kw.get('up_mode')).startswith('resizeconv_linear')
-    sd_ref['__act_slope__'] = {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0}[kw.get('activation', 'relu')]
+    sd_ref['__act_slope__'] = {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0, 'prelu': 3.0}[kw.get('activation', 'relu')]
     group = str(kw.get('normalization', '')).startswith('group')
     sd_ref['__num_groups__'] = (8 if kw['normalization'] == 'group' else int(kw['normalization'][5:])) if group else 0
     margin = [float('inf')]
@@ -70,10 +73,14 @@ for case in range(n_cases):
             if gap.numel(): margin[0] = min(margin[0], float(gap.min()))
             return m1
         return f
+    _prelu = torch.nn.functional.prelu
+    def rec_prelu(z, *a, **k):
+        margin[0] = min(margin[0], float(z.detach().abs().min())); return _prelu(z, *a, **k)
+    R.F.prelu = rec_prelu
     R.F.relu = rec_relu; R.F.max_pool3d = rec_pool(_mp3); R.F.max_pool2d = rec_pool(_mp2)
     if sd_ref['__act_slope__'] == 0.1: R.F.leaky_relu = rec_leaky
     try: ref = unet_forward(sd_ref, x.double(), nb, planar, training=True)
-    finally: R.F.relu = _relu; R.F.leaky_relu = _leaky; R.F.max_pool3d = _mp3; R.F.max_pool2d = _mp2; lref = combined_loss(ref, t, cw); lref.backward()
+    finally: R.F.relu = _relu; R.F.prelu = _prelu; R.F.leaky_relu = _leaky; R.F.max_pool3d = _mp3; R.F.max_pool2d = _mp2; lref = combined_loss(ref, t, cw); lref.backward()
     e_out = float((out - ref).detach().abs().max()) / max(1.0, float(ref.abs().max()))
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
     worst, wk = 0.0, ''
