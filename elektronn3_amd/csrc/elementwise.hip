@@ -621,7 +621,8 @@ __global__ void extract_center_tap_kernel(const float* __restrict__ gT, float* _
 // BatchNorm statistics of the CROPPED tensor: src [N, Ds, Hs, Ws, C] -> dst [N, Dd, Hd, Wd, C] (leading box) + one (count, mean, M2)
 // record per workgroup and channel.  Same fixed-pattern block reduction as bn_bwd_kernel.
 __global__ __launch_bounds__(256) void crop_stats_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int N,
-                                                         int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, float* __restrict__ stats) {
+                                                         int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, float* __restrict__ stats,
+                                                         int od, int oh, int ow) {   // (od, oh, ow): position of the box inside src
     __shared__ float red[256][3][4];
     const int Q = C >> 2;
     const int BT = (256 / Q) * Q;
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(256) void crop_stats_kernel(const float* __restrict
     for (size_t i = (size_t)blockIdx.x * BT + threadIdx.x; threadIdx.x < BT && i < total; i += stride) {
         const int q = (int)(i % Q); size_t r = i / Q;
         const int w = (int)(r % Wd); r /= Wd; const int h = (int)(r % Hd); r /= Hd; const int d = (int)(r % Dd); const int n = (int)(r / Dd);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((((size_t)n * Ds + d) * Hs + h) * Ws + w) * C + 4 * q);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((((size_t)n * Ds + d + od) * Hs + h + oh) * Ws + w + ow) * C + 4 * q);
         *reinterpret_cast<f32x4*>(dst + (i / Q) * C + 4 * q) = v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { cn[e] += 1.f; const float dl = v[e] - mean[e]; mean[e] += dl / cn[e]; m2[e] += dl * (v[e] - mean[e]); }
@@ -648,15 +649,30 @@ __global__ __launch_bounds__(256) void crop_stats_kernel(const float* __restrict
         o[0] = n; o[1] = mu; o[2] = s;
     }
 }
+// centre crop of the skip connection in conv_mode='valid' (autocrop, unet.py:300-325): dst view (ldc) [N, Dd, Hd, Wd] = src box at (od, oh, ow)
+__global__ void crop_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int dst_ldc, int C, int N, int Ds, int Hs, int Ws,
+                                 int Dd, int Hd, int Wd, int od, int oh, int ow) {
+    const int Q = C >> 2;
+    const size_t total = (size_t)N * Dd * Hd * Wd * Q;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % Q); size_t r = i / Q;
+        const int w = (int)(r % Wd); r /= Wd; const int h = (int)(r % Hd); r /= Hd; const int d = (int)(r % Dd); const int n = (int)(r / Dd);
+        *reinterpret_cast<f32x4*>(dst + (i / Q) * dst_ldc + 4 * q) =
+            *reinterpret_cast<const f32x4*>(src + ((((size_t)n * Ds + d + od) * Hs + h + oh) * Ws + w + ow) * C + 4 * q);
+    }
+}
 // backward of the crop: dst [N, Dd, Hd, Wd, C] = src inside the leading box [Ds, Hs, Ws], zero elsewhere
-__global__ void pad_box_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd) {
+__global__ void pad_box_kernel(const float* __restrict__ src, int src_ldc, float* __restrict__ dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd,
+                               int od, int oh, int ow) {   // src sits at (od, oh, ow) inside dst
     const int Q = C >> 2;
     const size_t total = (size_t)N * Dd * Hd * Wd * Q;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int q = (int)(i % Q); size_t r = i / Q;
         const int w = (int)(r % Wd); r /= Wd; const int h = (int)(r % Hd); r /= Hd; const int d = (int)(r % Dd); const int n = (int)(r / Dd);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (d < Ds && h < Hs && w < Ws) v = *reinterpret_cast<const f32x4*>(src + ((((size_t)n * Ds + d) * Hs + h) * Ws + w) * C + 4 * q);
+        const int sd_ = d - od, sh_ = h - oh, sw_ = w - ow;
+        if (sd_ >= 0 && sd_ < Ds && sh_ >= 0 && sh_ < Hs && sw_ >= 0 && sw_ < Ws)
+            v = *reinterpret_cast<const f32x4*>(src + ((((size_t)n * Ds + sd_) * Hs + sh_) * Ws + sw_) * src_ldc + 4 * q);
         *reinterpret_cast<f32x4*>(dst + (i / Q) * C + 4 * q) = v;
     }
 }
@@ -895,17 +911,26 @@ int launch_extract_center_tap(const float* gT, float* g1, size_t pairs, int T, h
     return E3_OK;
 }
 int crop_stats_parts(size_t voxels, int C) { return bn_bwd_parts(voxels, C); }
-int launch_crop_stats(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, float* stats, hipStream_t s) {
+int launch_crop_stats(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, float* stats, hipStream_t s,
+                      int od, int oh, int ow) {
     E3_REQUIRE(C % 4 == 0 && C <= 1024, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4, at most 1024");
-    E3_REQUIRE(Dd <= Ds && Hd <= Hs && Wd <= Ws, E3_ERR_INVALID, "crop box larger than the source");
+    E3_REQUIRE(od >= 0 && oh >= 0 && ow >= 0 && Dd + od <= Ds && Hd + oh <= Hs && Wd + ow <= Ws, E3_ERR_INVALID, "crop box outside the source");
     const int parts = crop_stats_parts((size_t)N * Dd * Hd * Wd, C);
-    hipLaunchKernelGGL(crop_stats_kernel, dim3(parts), dim3(256), 0, s, src, dst, C, N, Ds, Hs, Ws, Dd, Hd, Wd, stats);
+    hipLaunchKernelGGL(crop_stats_kernel, dim3(parts), dim3(256), 0, s, src, dst, C, N, Ds, Hs, Ws, Dd, Hd, Wd, stats, od, oh, ow);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
-int launch_pad_box(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, hipStream_t s) {
+int launch_crop_copy(const float* src, float* dst, int dst_ldc, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, int od, int oh, int ow, hipStream_t s) {
+    E3_REQUIRE(C % 4 == 0 && dst_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
+    E3_REQUIRE(od >= 0 && oh >= 0 && ow >= 0 && Dd + od <= Ds && Hd + oh <= Hs && Wd + ow <= Ws, E3_ERR_INVALID, "crop box outside the source");
+    hipLaunchKernelGGL(crop_copy_kernel, dim3(ew_grid((size_t)N * Dd * Hd * Wd * (C / 4))), dim3(EW_BLOCK), 0, s, src, dst, dst_ldc, C, N, Ds, Hs, Ws, Dd, Hd, Wd, od, oh, ow);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+int launch_pad_box(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, hipStream_t s, int od, int oh, int ow, int src_ldc) {
     E3_REQUIRE(C % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
-    hipLaunchKernelGGL(pad_box_kernel, dim3(ew_grid((size_t)N * Dd * Hd * Wd * (C / 4))), dim3(EW_BLOCK), 0, s, src, dst, C, N, Ds, Hs, Ws, Dd, Hd, Wd);
+    if (src_ldc == 0) src_ldc = C;
+    hipLaunchKernelGGL(pad_box_kernel, dim3(ew_grid((size_t)N * Dd * Hd * Wd * (C / 4))), dim3(EW_BLOCK), 0, s, src, src_ldc, dst, C, N, Ds, Hs, Ws, Dd, Hd, Wd, od, oh, ow);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

@@ -126,8 +126,11 @@ int launch_downsample_sum(const float* g, float* dx, int dx_ldc, int C, int N, i
 int launch_embed_center_tap(const float* w1, float* wT, size_t pairs, int T, hipStream_t s);     // (Cout*Cin) 1x1x1 weights -> centre tap of T-tap kernels
 int launch_extract_center_tap(const float* gT, float* g1, size_t pairs, int T, hipStream_t s);
 int crop_stats_parts(size_t voxels, int C);
-int launch_crop_stats(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, float* stats, hipStream_t s);
-int launch_pad_box(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, hipStream_t s);
+int launch_crop_stats(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, float* stats, hipStream_t s,
+                      int od = 0, int oh = 0, int ow = 0);            // box at (od, oh, ow) inside src
+int launch_pad_box(const float* src, float* dst, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, hipStream_t s,
+                   int od = 0, int oh = 0, int ow = 0, int src_ldc = 0);  // src at (od, oh, ow) inside dst, zeros elsewhere
+int launch_crop_copy(const float* src, float* dst, int dst_ldc, int C, int N, int Ds, int Hs, int Ws, int Dd, int Hd, int Wd, int od, int oh, int ow, hipStream_t s);
 constexpr int FOLD_MAX_JOBS = 40;
 struct FoldJob { const float *gamma, *beta, *rm, *rv, *bias; float *scale, *shift; int C; };   // gamma == nullptr: no norm (scale 1, shift bias)
 int launch_fold_multi(const FoldJob* jobs, int njobs, float eps, hipStream_t s);   // eval-mode BN folds / bias folds of all conv units at once
