@@ -4,7 +4,7 @@ statistics.  fp64 because PyTorch-ROCm's own fp32 batch-norm statistics are only
 which train-mode normalisation then amplifies to 1e-3 in the output (ours agree with fp64 to 4e-11).
 Gradients are only comparable when no ReLU input sits within fp32 rounding of zero: one voxel whose mask flips changes a BN bias
 gradient of these tiny crops by ~1e-2 (verified: the error equals that voxel's incoming gradient exactly).  The fp64 run records the
-smallest |pre-ReLU value| and the smallest gap between the two largest values of a max-pool window; cases with a margin < 2e-6 get
+smallest |pre-ReLU value| and the smallest gap between the two largest values of a max-pool window; cases with a margin < 1e-5 get
 the loose gradient bound, all others the tight one.
 Usage: python tools/fuzz_unet.py [n_cases] [seed]"""
 import os, sys, torch
@@ -90,7 +90,8 @@ for case in range(n_cases):
         prebn = is_prebn_bias(k, set() if group else names, paramless)
         if group and p.numel() == sd_ref['__num_groups__'] and is_prebn_bias(k, names, paramless):
             prebn = True        # groups of ONE channel: GroupNorm removes the channel's own mean, the bias gradient is analytically zero
-        err = float(p.grad.abs().max()) / gn if prebn else float((p.grad - gr).norm() / gr.norm().clamp_min(1e-30))
+        err = float(p.grad.abs().max()) / gn if prebn else float((p.grad - gr).norm() / gr.norm().clamp_min(1e-4 * gn))     # (gradients that are analytically ~0, e.g. a norm bias whose
+                                                                                       # shift the next norm removes entirely, are judged against the global scale)
         if (not prebn and err > worst): worst, wk = err, k
         if prebn and err > 1e-5: worst, wk = 1.0, k + ' (pre-BN bias not ~0)'
     e_rs = max([float((m.state_dict()[k] - sd_ref[k]).abs().max()) for k in sd0 if 'running' in k] or [0.0])
@@ -99,7 +100,7 @@ for case in range(n_cases):
     for i, v in enumerate(shape):
         n_bottom *= -(-v // (1 if (len(shape) == 3 and i == 0 and all(b in planar for b in range(nb - 1))) else mult))
     loose = max(3e-2, 1.0 / n_bottom ** 0.5)
-    ok = e_out < 5e-5 and worst < (loose if margin[0] < 2e-6 else 1e-4) and e_rs < 1e-5
+    ok = e_out < 5e-5 and worst < (loose if margin[0] < 1e-5 else 1e-4) and e_rs < 1e-5
     bad += not ok
     print(f'{"ok  " if ok else "BAD "} nb={nb} sf={sf} in={inc} out={outc} planar={planar} {kw} N={N} {"x".join(map(str, shape))}: out {e_out:.1e} worst grad {worst:.1e} ({wk}) running {e_rs:.1e} relu margin {margin[0]:.0e}', flush=True)
 print('BAD CASES:', bad)
