@@ -25,7 +25,7 @@ class E3Error(RuntimeError):
 
 class UNetCfg(ctypes.Structure):
     _fields_ = [('in_channels', c_int32), ('out_channels', c_int32), ('n_blocks', c_int32), ('start_filts', c_int32),
-                ('planar_mask', c_uint32), ('normalization', c_int32), ('bn_eps', c_float), ('full_norm', c_int32), ('merge_add', c_int32), ('num_groups', c_int32), ('up_resize', c_int32), ('act_slope', c_float)]
+                ('planar_mask', c_uint32), ('normalization', c_int32), ('bn_eps', c_float), ('full_norm', c_int32), ('merge_add', c_int32), ('num_groups', c_int32), ('up_resize', c_int32), ('conv_valid', c_int32), ('act_slope', c_float)]
 
 
 _P = c_void_p  # device pointer
@@ -39,6 +39,7 @@ _SIG = {
     'e3_unet_param_count': (_I, [c_void_p]),
     'e3_unet_param_info': (_I, [c_void_p, _I, c_char_p, _I, POINTER(c_int64), POINTER(c_int)]),
     'e3_unet_bn_count': (_I, [c_void_p]),
+    'e3_unet_out_dims': (_I, [c_void_p, _I, _I, _I, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     'e3_unet_sizes': (_I, [c_void_p, _I, _I, _I, _I, _I, POINTER(c_size_t), POINTER(c_size_t)]),
     'e3_unet_forward': (_I, [c_void_p, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), POINTER(c_float), _P,
                              _P, c_size_t, _P, c_size_t, c_uint32]),

@@ -91,13 +91,60 @@ void add_unit(e3_unet_plan* p, const std::string& conv, const std::string& bn, i
     p->units.push_back(u);
 }
 
-void level_dims(const e3_unet_plan* p, int N, int D, int H, int W, std::vector<LevelDims>& L) {
-    L.resize(p->cfg.n_blocks);
-    for (int i = 0; i < p->cfg.n_blocks; ++i) {
-        L[i] = {D, H, W, (size_t)N * D * H * W};
-        const int kd = p->planar(i) ? 1 : 2;
-        D = cdiv(D, kd); H = cdiv(H, 2); W = cdiv(W, 2);   // MaxPool3d(ceil_mode=True), unet.py:229
+// Dimensions of every tensor of the network for an (N, D, H, W) input.  conv_mode='same': one size per resolution level.
+// conv_mode='valid' (padding 0, unet.py:217,347): every 3x3x3 conv shrinks its grid by 2 (planar: H and W only), so each unit has its own
+// input / output size; the up-convolved tensor is cropped by one voxel where its size differs from the skip's by an odd amount and the
+// skip is centre-cropped to it (autocrop, unet.py:256-325).
+struct UnitDims { LevelDims in, out; int od, oh, ow; };   // in: the unit's input tensor = the grid its conv kernel runs on (transposed conv /
+                                                          // ResizeConv: the LOW-resolution input); out: its output tensor; (od, oh, ow): where
+                                                          // `out` sits inside the conv grid (valid convs: 1 voxel in, 0 along D for planar)
+struct NetDims {
+    std::vector<UnitDims> u;
+    std::vector<LevelDims> E, X;       // per level: the encoder's skip activation (before the pool), the level's input
+    std::vector<int> sd_, sh_, sw_;    // per level: offset of the centre crop of the skip inside E
+    LevelDims Y;                       // output of the last unit = grid of the logits
+    bool ok;
+};
+
+LevelDims mkdims(int N, int D, int H, int W) { return {D, H, W, (size_t)N * (size_t)(D > 0 ? D : 0) * (size_t)(H > 0 ? H : 0) * (size_t)(W > 0 ? W : 0)}; }
+
+void net_dims(const e3_unet_plan* p, int N, int D, int H, int W, NetDims& nd) {
+    const int nb = p->cfg.n_blocks;
+    const bool valid = p->cfg.conv_valid != 0;
+    nd.u.assign(p->units.size(), UnitDims{});
+    nd.E.assign(nb, LevelDims{}); nd.X.assign(nb, LevelDims{});
+    nd.sd_.assign(nb, 0); nd.sh_.assign(nb, 0); nd.sw_.assign(nb, 0);
+    nd.ok = true;
+    auto pymod2 = [](int a) { return ((a % 2) + 2) % 2; };
+    LevelDims cur = mkdims(N, D, H, W);
+    size_t k = 0;
+    auto plain = [&](int planar) {
+        UnitDims& ud = nd.u[k++];
+        ud.in = cur;
+        const int m = planar ? 0 : 1;
+        ud.od = valid ? m : 0; ud.oh = ud.ow = valid ? 1 : 0;
+        ud.out = valid ? mkdims(N, cur.D - 2 * m, cur.H - 2, cur.W - 2) : cur;
+        cur = ud.out;
+        if (cur.D < 1 || cur.H < 1 || cur.W < 1) nd.ok = false;
+    };
+    for (int i = 0; i < nb; ++i) {
+        nd.X[i] = cur;
+        plain(p->planar(i)); plain(p->planar(i));
+        nd.E[i] = cur;
+        if (i + 1 < nb) cur = mkdims(N, cdiv(cur.D, p->planar(i) ? 1 : 2), cdiv(cur.H, 2), cdiv(cur.W, 2));   // MaxPool3d(ceil_mode=True), unet.py:229
     }
+    for (int j = nb - 2; j >= 0; --j) {
+        UnitDims& ud = nd.u[k++];
+        ud.in = cur; ud.od = ud.oh = ud.ow = 0;
+        const int fd = cur.D * (p->planar(j) ? 1 : 2), fh = cur.H * 2, fw = cur.W * 2;      // full size of the up-convolved tensor
+        const LevelDims& e = nd.E[j];
+        ud.out = mkdims(N, fd - pymod2(fd - e.D), fh - pymod2(fh - e.H), fw - pymod2(fw - e.W));
+        if (ud.out.D > e.D || ud.out.H > e.H || ud.out.W > e.W || ud.out.D < 1 || ud.out.H < 1 || ud.out.W < 1) nd.ok = false;
+        nd.sd_[j] = (e.D - ud.out.D) / 2; nd.sh_[j] = (e.H - ud.out.H) / 2; nd.sw_[j] = (e.W - ud.out.W) / 2;
+        cur = ud.out;
+        plain(p->planar(j)); plain(p->planar(j));
+    }
+    nd.Y = cur;
 }
 
 // ---- buffers -----------------------------------------------------------------------------------------------
@@ -122,6 +169,7 @@ struct Buffers {
     std::vector<float*> bnpart_u;        // per unit: block partials of the BN backward [parts][3][C]; row 2 (sum dx = conv-bias gradient) is summed for all units at once
     std::vector<float*> wpk_f, wpk_d;    // per unit: Winograd-transformed weights (forward / dgrad form), all packed by ONE launch; nullptr = packed on the spot into wpack
     std::vector<float*> g1, g2, dcat;    // gradient buffers per level
+    std::vector<float*> gskip;           // conv_mode='valid': gradient of the (un-cropped) skip activation per level
     float* evalA; float* evalB;          // inference ping-pong (level-0 sized)
     size_t scratch_bytes;
 };
@@ -132,34 +180,38 @@ int pad_cols(int n) { const int t = conv_col_tile(n); return cdiv(n, t) * t; }
 
 void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool training, void* saved, void* scratch, Buffers& B) {
     const int nb = p->cfg.n_blocks;
-    std::vector<LevelDims> L; level_dims(p, N, D, H, W, L);
+    NetDims ND; net_dims(p, N, D, H, W, ND);
+    const bool valid = p->cfg.conv_valid != 0;
+    auto up_unit = [&](int j) { return (size_t)(2 * nb + 3 * (nb - 2 - j)); };      // index of the up-conv unit whose output is level j
     Arena S(saved), T(scratch);
     B.ub.assign(p->units.size(), UnitBufs{});
     B.cat.assign(nb, nullptr); B.pooled.assign(nb, nullptr); B.sum.assign(nb, nullptr);
     B.ups.assign(p->units.size(), nullptr); B.rtmp = B.rpad = B.rdu = nullptr;
-    B.g1.assign(nb, nullptr); B.g2.assign(nb, nullptr); B.dcat.assign(nb, nullptr);
+    B.g1.assign(nb, nullptr); B.g2.assign(nb, nullptr); B.dcat.assign(nb, nullptr); B.gskip.assign(nb, nullptr);
     B.xin = nullptr; B.evalA = B.evalB = nullptr;
     Arena& A = training ? S : T;   // in inference everything is scratch
-    if (p->cfg.in_channels > 1) B.xin = A.take(L[0].vox * p->cfg.in_channels);
+    if (p->cfg.in_channels > 1) B.xin = A.take(ND.X[0].vox * p->cfg.in_channels);
     for (int j = 0; j + 1 < nb; ++j) {
-        B.cat[j] = A.take(L[j].vox * 2 * p->chan(j));
-        B.pooled[j] = A.take(L[j + 1].vox * p->chan(j));
-        if (p->cfg.merge_add) B.sum[j] = A.take(L[j].vox * p->chan(j));
+        const size_t cvox = ND.u[up_unit(j)].out.vox;            // the decoder works on the (cropped) up-convolved grid
+        B.cat[j] = A.take(cvox * 2 * p->chan(j));
+        B.pooled[j] = A.take(ND.X[j + 1].vox * p->chan(j));
+        if (p->cfg.merge_add) B.sum[j] = A.take(cvox * p->chan(j));
     }
     for (size_t k = 0; k < p->units.size(); ++k) {
         const ConvUnit& u = p->units[k];
         UnitBufs& b = B.ub[k];
-        const size_t n = L[u.level].vox * u.cout;
+        const size_t n = ND.u[k].out.vox * u.cout;
         // without batch statistics to wait for, the conv writes relu(acc*scale + shift) directly; other activations are not in the conv
         // epilogues and take the two-pass route (raw tensor, then the apply pass)
-        b.raw = ((training && u.has_norm()) || p->cfg.act_slope != 0.f || u.is_up == 2) ? A.take(n) : nullptr;
+        b.raw = ((training && u.has_norm()) || p->cfg.act_slope != 0.f || u.is_up == 2 || (valid && !u.is_up)) ? A.take(n) : nullptr;
         if (u.is_up == 2) {
-            const LevelDims& li = L[u.level + 1];
+            const LevelDims& li = ND.u[k].in;
             B.ups[k] = A.take((size_t)N * li.D * (u.planar ? 1 : 2) * li.H * 2 * li.W * 2 * u.cin);
         }
         // where does the activation go?
         const bool enc_skip = !u.is_up && u.name.find("down_convs") == 0 && u.name.find("conv2") != std::string::npos && u.level < nb - 1;
-        if (enc_skip) { b.act = B.cat[u.level] ? B.cat[u.level] + u.cout : nullptr; b.act_ldc = 2 * u.cout; }
+        // ('valid': the skip is larger than the decoder's grid and gets centre-cropped into the concat buffer by a copy)
+        if (enc_skip && !valid) { b.act = B.cat[u.level] ? B.cat[u.level] + u.cout : nullptr; b.act_ldc = 2 * u.cout; }
         else if (u.is_up) { b.act = B.cat[u.level]; b.act_ldc = 2 * u.cout; }
         else { b.act = A.take(n); b.act_ldc = u.cout; }
         if (!saved && !scratch) { b.act = nullptr; }
@@ -168,10 +220,12 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     B.saved_bytes = S.off;
     // scratch
     size_t wmax = 0, statmax = 0, slabmax = 0, bnpartmax = 0, rtmpmax = 0, rdumax = 0;
-    for (const ConvUnit& u : p->units) {
-        const LevelDims& lo = L[u.level];
+    for (size_t k = 0; k < p->units.size(); ++k) {
+        const ConvUnit& u = p->units[k];
+        const LevelDims& lo = ND.u[k].out;
+        const LevelDims& ci = ND.u[k].in;          // plain convs: the grid the conv kernel runs on
         if (u.is_up == 2) {      // ResizeConv: a 3x3x3 / 1x3x3 conv on the up-sampled grid
-            const LevelDims& li = L[u.level + 1];
+            const LevelDims& li = ND.u[k].in;
             const int Ud = li.D * (u.planar ? 1 : 2), Uh = li.H * 2, Uw = li.W * 2, taps = u.planar ? 9 : 27;
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             const size_t uvox = (size_t)N * Ud * Uh * Uw;
@@ -182,7 +236,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
             if (training) slabmax = max_sz(slabmax, (size_t)wgrad_splits(kind, N, Ud, Uh, Uw, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32));
         } else if (u.is_up) {
             const int sd = u.planar ? 1 : 2, taps = sd * 4;
-            const LevelDims& li = L[u.level + 1];
+            const LevelDims& li = ND.u[k].in;
             wmax = max_sz(wmax, max_sz((size_t)pad_cols(taps * u.cout) * u.cin, (size_t)taps * pad_cols(u.cin) * u.cout));
             statmax = max_sz(statmax, (size_t)conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, li.D, li.H, li.W, sd, u.cin, taps * u.cout) * u.cout * 3);
             if (training) slabmax = max_sz(slabmax, (size_t)wgrad_splits(CONV_POINT, N, li.D, li.H, li.W, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32));
@@ -191,28 +245,32 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             if (u.cin >= 8) {
                 wmax = max_sz(wmax, max_sz(conv_packed_floats(kind, u.cin, u.cout), conv_packed_floats(kind, u.cout, u.cin)));
-                statmax = max_sz(statmax, (size_t)conv_stats_parts(kind, 0, N, lo.D, lo.H, lo.W, 2, u.cin, u.cout) * u.cout * 3);
-                if (training) slabmax = max_sz(slabmax, (size_t)wgrad_splits(kind, N, lo.D, lo.H, lo.W, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32));
+                statmax = max_sz(statmax, (size_t)conv_stats_parts(kind, 0, N, ci.D, ci.H, ci.W, 2, u.cin, u.cout) * u.cout * 3);
+                if (training) slabmax = max_sz(slabmax, (size_t)wgrad_splits(kind, N, ci.D, ci.H, ci.W, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32));
             } else {
                 wmax = max_sz(wmax, conv_packed_floats(kind, u.cout, u.cin));   // only its dgrad (dx requested) packs weights
-                statmax = max_sz(statmax, (size_t)conv_small_stats_parts(N, lo.D, lo.H, lo.W, u.planar) * u.cout * 3);
-                if (training) slabmax = max_sz(slabmax, (size_t)conv_small_wgrad_splits(N, lo.D, lo.H, lo.W, u.planar) * taps * u.cout * u.cin);
+                statmax = max_sz(statmax, (size_t)conv_small_stats_parts(N, ci.D, ci.H, ci.W, u.planar) * u.cout * 3);
+                if (training) slabmax = max_sz(slabmax, (size_t)conv_small_wgrad_splits(N, ci.D, ci.H, ci.W, u.planar) * taps * u.cout * u.cin);
             }
+        }
+        if (valid && !u.is_up) {     // conv on the input grid into a temporary, crop + statistics into the unit's tensor; padded gradient back
+            statmax = max_sz(statmax, (size_t)crop_stats_parts(lo.vox, u.cout) * u.cout * 3);
+            rtmpmax = max_sz(rtmpmax, ci.vox * u.cout);
         }
         if (training) bnpartmax = max_sz(bnpartmax, (size_t)bn_bwd_parts(lo.vox, u.cout) * 3 * u.cout);
     }
     if (training) {
         const int C0 = p->chan(0);
-        slabmax = max_sz(slabmax, (size_t)conv_final_bwd_parts(L[0].vox) * (p->cfg.out_channels * C0 + p->cfg.out_channels));
+        slabmax = max_sz(slabmax, (size_t)conv_final_bwd_parts(ND.Y.vox) * (p->cfg.out_channels * C0 + p->cfg.out_channels));
     }
     B.wpack = T.take(wmax);
     B.wemb = B.gemb = nullptr;
     if (p->cfg.up_resize >= 3) { const size_t e = (size_t)p->chan(nb - 1) * p->chan(nb - 1) / 2 * 27; B.wemb = T.take(e); if (training) B.gemb = T.take(e); }
-    if (rtmpmax) { B.rtmp = T.take(rtmpmax); if (training) { B.rpad = T.take(rtmpmax); B.rdu = T.take(rdumax); } }
+    if (rtmpmax) { B.rtmp = T.take(rtmpmax); if (training) { B.rpad = T.take(rtmpmax); if (rdumax) B.rdu = T.take(rdumax); } }
     B.wpk_f.assign(p->units.size(), nullptr); B.wpk_d.assign(p->units.size(), nullptr);
     for (size_t k = 0; k < p->units.size(); ++k) {
         const ConvUnit& u = p->units[k];
-        const LevelDims& lo = L[u.level];
+        const LevelDims& lo = ND.u[k].in;          // (the conv grid)
         if (u.is_up || u.planar || u.cin < 8) continue;
         if (conv_use_wino(CONV_K3, 0, N, lo.D, lo.H, lo.W, u.cin, u.cout)) B.wpk_f[k] = T.take(conv_packed_floats(CONV_K3, u.cin, u.cout));
         if (training && conv_use_wino(CONV_K3, 0, N, lo.D, lo.H, lo.W, u.cout, u.cin)) B.wpk_d[k] = T.take(conv_packed_floats(CONV_K3, u.cout, u.cin));
@@ -225,15 +283,16 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     B.biaspart0 = nullptr;
     if (training) {
         if (p->units[0].cin < 8)
-            B.biaspart0 = T.take((size_t)conv_small_wgrad_splits(N, L[0].D, L[0].H, L[0].W, p->units[0].planar) * p->units[0].cout);
+            B.biaspart0 = T.take((size_t)conv_small_wgrad_splits(N, ND.X[0].D, ND.X[0].H, ND.X[0].W, p->units[0].planar) * p->units[0].cout);
         for (size_t k = 0; k < p->units.size(); ++k)
-            B.bnpart_u[k] = T.take((size_t)bn_bwd_parts(L[p->units[k].level].vox, p->units[k].cout) * 3 * p->units[k].cout);
+            B.bnpart_u[k] = T.take((size_t)bn_bwd_parts(ND.u[k].out.vox, p->units[k].cout) * 3 * p->units[k].cout);
         B.bnpart = T.take(bnpartmax);
         B.slab = T.take(slabmax);
         for (int j = 0; j < nb; ++j) {
-            const size_t n = L[j].vox * p->chan(j);
+            const size_t n = ND.X[j].vox * p->chan(j);        // the level's input grid is its largest
             B.g1[j] = T.take(n); B.g2[j] = T.take(n);
             if (j + 1 < nb) B.dcat[j] = T.take(2 * n);
+            if (valid && j + 1 < nb) B.gskip[j] = T.take(ND.E[j].vox * p->chan(j));
         }
     } else {
         B.bnpart = B.slab = nullptr;
@@ -360,6 +419,14 @@ int e3_unet_profile_read(e3_unet_plan* plan, double* mean_ms, int* launches) {
     return E3_OK;
 }
 
+int e3_unet_out_dims(const e3_unet_plan* plan, int D, int H, int W, int* Do, int* Ho, int* Wo) {
+    E3_REQUIRE(plan && D > 0 && H > 0 && W > 0 && Do && Ho && Wo, E3_ERR_INVALID, "bad argument");
+    NetDims nd; net_dims(plan, 1, D, H, W, nd);
+    E3_REQUIRE(nd.ok, E3_ERR_INVALID, "input too small for this network (conv_mode='valid' shrinks every conv by 2)");
+    *Do = nd.Y.D; *Ho = nd.Y.H; *Wo = nd.Y.W;
+    return E3_OK;
+}
+
 int e3_unet_sizes(const e3_unet_plan* plan, int N, int D, int H, int W, int training, size_t* saved_bytes, size_t* scratch_bytes) {
     E3_REQUIRE(plan && N > 0 && D > 0 && H > 0 && W > 0, E3_ERR_INVALID, "bad shape");
     Buffers B;
@@ -383,7 +450,9 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
     plan_buffers(plan, N, D, H, W, training, saved, scratch, B);
     E3_REQUIRE(!training || saved_bytes >= B.saved_bytes, E3_ERR_WORKSPACE, "`saved` buffer too small");
     E3_REQUIRE(scratch_bytes >= B.scratch_bytes, E3_ERR_WORKSPACE, "`scratch` buffer too small");
-    std::vector<LevelDims> L; level_dims(plan, N, D, H, W, L);
+    NetDims ND; net_dims(plan, N, D, H, W, ND);
+    E3_REQUIRE(ND.ok, E3_ERR_INVALID, "input too small for this network (conv_mode='valid' shrinks every conv by 2)");
+    const bool valid = cfg.conv_valid != 0;
     auto P = [&](int i) { return (float*)params[i]; };
 
     {   // Winograd weight transforms of every layer that uses them, in one launch
@@ -402,19 +471,21 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         if (!jobs.empty()) RUN(launch_fold_multi(jobs.data(), (int)jobs.size(), cfg.bn_eps, s));
     }
     const float* cur = x; int cur_ldc = cfg.in_channels;
-    if (cfg.in_channels > 1) { RUN(launch_ncdhw_to_ndhwc(x, B.xin, N, cfg.in_channels, L[0].vox / N, s)); cur = B.xin; }
+    if (cfg.in_channels > 1) { RUN(launch_ncdhw_to_ndhwc(x, B.xin, N, cfg.in_channels, ND.X[0].vox / N, s)); cur = B.xin; }
 
     for (size_t k = 0; k < plan->units.size(); ++k) {
         const ConvUnit& u = plan->units[k];
         UnitBufs& b = B.ub[k];
-        const LevelDims& lo = L[u.level];
+        const LevelDims& lo = ND.u[k].out;         // the unit's output tensor
+        const LevelDims& ci = ND.u[k].in;          // plain convs: the grid the conv kernel runs on (== lo unless conv_mode='valid')
+        const bool vcrop = valid && !u.is_up;      // 'valid' conv = the 'same' conv on the input grid, cropped by the padding
         const bool is_enc_conv2 = !u.is_up && u.name.compare(0, 10, "down_convs") == 0 && u.name.find("conv2") != std::string::npos;
         const bool pool_after = is_enc_conv2 && u.level < nb - 1;
         const int kd = u.planar ? 1 : 2;
         const float slope = cfg.act_slope;
         const ActArg act = u.p_a >= 0 ? ActArg(0.f, P(u.p_a)) : ActArg(slope);
         const bool bn_train = training && u.has_norm();   // batch statistics needed: conv writes the raw output, BN+ReLU is a second pass
-        const bool two_pass = bn_train || slope != 0.f || u.is_up == 2;   // (non-ReLU activations are not in the conv epilogues; the
+        const bool two_pass = bn_train || slope != 0.f || u.is_up == 2 || vcrop;   // (non-ReLU activations are not in the conv epilogues; the
                                                                            // ResizeConv output may need the autocrop before the norm)
         float* dst = two_pass ? b.raw : b.act;            // otherwise the conv writes the activation directly
         const int dst_ldc = two_pass ? u.cout : b.act_ldc;
@@ -424,7 +495,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         }
         int parts = 0;
         if (u.is_up == 2) {      // ResizeConv (unet.py:411-449): nn.Upsample(nearest) then conv3 on the up-sampled grid, autocrop afterwards
-            const LevelDims& li = L[u.level + 1];
+            const LevelDims& li = ND.u[k].in;
             const int sd = u.planar ? 1 : 2, Ud = li.D * sd, Uh = li.H * 2, Uw = li.W * 2, NPad = pad_cols(u.cout);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             const bool same = Ud == lo.D && Uh == lo.H && Uw == lo.W;
@@ -445,7 +516,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
                 parts = crop_stats_parts(lo.vox, u.cout);
             }
         } else if (u.is_up) {
-            const LevelDims& li = L[u.level + 1];
+            const LevelDims& li = ND.u[k].in;
             const int sd = u.planar ? 1 : 2, taps = sd * 4, NPad = pad_cols(taps * u.cout);
             RUN(launch_pack_weights(PACK_UP_FWD, P(u.p_w), B.wpack, u.cout, u.cin, taps, NPad, s));
             ConvArgs a{};
@@ -458,23 +529,27 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(CONV_POINT, a, s)); }
         } else if (u.cin < 8) {
             ConvSmallArgs a{};
-            a.x = cur; a.Cin = u.cin; a.w = P(u.p_w); a.bias = bn_train ? P(u.p_b) : nullptr; a.y = dst; a.y_ldc = dst_ldc;
-            a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.Cout = u.cout; a.planar = u.planar;
-            a.epi_scale = es; a.epi_shift = eh; a.stats = bn_train ? B.stats : nullptr;
-            parts = conv_small_stats_parts(N, lo.D, lo.H, lo.W, u.planar);
+            a.x = cur; a.Cin = u.cin; a.w = P(u.p_w); a.bias = bn_train ? P(u.p_b) : nullptr; a.y = vcrop ? B.rtmp : dst; a.y_ldc = dst_ldc;
+            a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.Cout = u.cout; a.planar = u.planar;
+            a.epi_scale = es; a.epi_shift = eh; a.stats = (bn_train && !vcrop) ? B.stats : nullptr;
+            parts = conv_small_stats_parts(N, ci.D, ci.H, ci.W, u.planar);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_small_fwd(a, s)); }
         } else {
             const int taps = u.planar ? 9 : 27, NPad = pad_cols(u.cout);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             (void)taps;
-            if (!B.wpk_f[k]) RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, lo.D, lo.H, lo.W, 0, s));
+            if (!B.wpk_f[k]) RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, ci.D, ci.H, ci.W, 0, s));
             ConvArgs a{};
             a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpk_f[k] ? B.wpk_f[k] : B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
-            a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.sd = 2;
+            a.y = vcrop ? B.rtmp : dst; a.y_ldc = dst_ldc; a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.sd = 2;
             a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
-            a.stats = bn_train ? B.stats : nullptr; a.G = 1; a.flags = 0;
-            parts = conv_stats_parts(kind, 0, N, lo.D, lo.H, lo.W, 2, u.cin, u.cout);
+            a.stats = (bn_train && !vcrop) ? B.stats : nullptr; a.G = 1; a.flags = 0;
+            parts = conv_stats_parts(kind, 0, N, ci.D, ci.H, ci.W, 2, u.cin, u.cout);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(kind, a, s)); }
+        }
+        if (vcrop) {        // the interior of the 'same' result is the 'valid' result (no tap of an interior voxel touches the padding)
+            RUN(launch_crop_stats(B.rtmp, b.raw, u.cout, N, ci.D, ci.H, ci.W, lo.D, lo.H, lo.W, B.stats, s, ND.u[k].od, ND.u[k].oh, ND.u[k].ow));
+            parts = crop_stats_parts(lo.vox, u.cout);
         }
         if (bn_train) {
             BnFinalizeArgs f{};
@@ -497,6 +572,12 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         } else if (pool_after) {
             RUN(launch_maxpool(b.act, b.act_ldc, B.pooled[u.level], kd, N, lo.D, lo.H, lo.W, u.cout, s));
         }
+        if (u.is_up && valid) {      // centre-crop the encoder's skip activation into the second half of the concat buffer (unet.py:300-325)
+            const int j = u.level;
+            const LevelDims& e = ND.E[j];
+            const UnitBufs& eb = B.ub[2 * j + 1];
+            RUN(launch_crop_copy(eb.act, B.cat[j] + u.cout, 2 * u.cout, u.cout, N, e.D, e.H, e.W, lo.D, lo.H, lo.W, ND.sd_[j], ND.sh_[j], ND.sw_[j], s));
+        }
         // input of the next unit
         if (pool_after) { cur = B.pooled[u.level]; cur_ldc = u.cout; }
         else if (u.is_up && cfg.merge_add) {   // mrg = updec + genc (unet.py:400-401): the two halves of the buffer summed
@@ -512,7 +593,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         const bool fused = training && lu.has_norm();     // see above: head reads the raw conv output + (scale, shift)
         Prof pr(plan, s, (int)plan->units.size(), 0);
         RUN(launch_conv_final_fwd(fused ? lb.raw : cur, fused ? lu.cout : cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y,
-                                  cfg.out_channels, L[0].vox / N, N, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s,
+                                  cfg.out_channels, ND.Y.vox / N, N, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s,
                                   fused ? lb.scale : nullptr, fused ? lb.shift : nullptr,
                                   lu.p_a >= 0 ? ActArg(0.f, P(lu.p_a)) : ActArg(cfg.act_slope)));
     }
@@ -531,7 +612,9 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
     plan_buffers(plan, N, D, H, W, true, saved, scratch, B);
     E3_REQUIRE(saved_bytes >= B.saved_bytes, E3_ERR_WORKSPACE, "`saved` buffer too small");
     E3_REQUIRE(scratch_bytes >= B.scratch_bytes, E3_ERR_WORKSPACE, "`scratch` buffer too small");
-    std::vector<LevelDims> L; level_dims(plan, N, D, H, W, L);
+    NetDims ND; net_dims(plan, N, D, H, W, ND);
+    E3_REQUIRE(ND.ok, E3_ERR_INVALID, "input too small for this network");
+    const bool valid = cfg.conv_valid != 0;
     auto P = [&](int i) { return (float*)params[i]; };
     auto G = [&](int i) { return (float*)grads[i]; };
     const int C0 = plan->chan(0);
@@ -540,14 +623,14 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
     // ---- conv_final (unet.py:912): da, dW, db
     const UnitBufs& last = B.ub[nunits - 1 - 0];   // last unit of the forward feeds conv_final
     {
-        const int parts = conv_final_bwd_parts(L[0].vox);
+        const int parts = conv_final_bwd_parts(ND.Y.vox);
         const int ps = cfg.out_channels * C0 + cfg.out_channels;
         { Prof pr(plan, s, nunits, 1);
           const bool fused = plan->units.back().has_norm();
           // the gradient w.r.t. the last activation is not written: the BN backward of the last unit recomputes it from dy and the head's
           // weights (2 fma per element instead of one 4-byte write and two 4-byte reads)
           RUN(launch_conv_final_bwd(fused ? last.raw : last.act, fused ? C0 : last.act_ldc, C0, P(plan->p_final_w), dy, nullptr, C0, B.slab,
-                                    cfg.out_channels, L[0].vox / N, N, s, fused ? last.scale : nullptr, fused ? last.shift : nullptr,
+                                    cfg.out_channels, ND.Y.vox / N, N, s, fused ? last.scale : nullptr, fused ? last.shift : nullptr,
                                     plan->units.back().p_a >= 0 ? ActArg(0.f, P(plan->units.back().p_a)) : ActArg(cfg.act_slope))); }
         RUN(launch_colsum_finalize(B.slab, parts, ps, 0, cfg.out_channels * C0, G(plan->p_final_w), s));
         RUN(launch_colsum_finalize(B.slab, parts, ps, cfg.out_channels * C0, cfg.out_channels, G(plan->p_final_b), s));
@@ -568,7 +651,9 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
     for (int k = nunits - 1; k >= 0; --k) {
         const ConvUnit& u = plan->units[k];
         const UnitBufs& b = B.ub[k];
-        const LevelDims& lo = L[u.level];
+        const LevelDims& lo = ND.u[k].out;         // the unit's output tensor (BatchNorm / activation / pool work on it)
+        const LevelDims& ci = ND.u[k].in;          // plain convs: the grid the conv kernels run on
+        const bool vcrop = valid && !u.is_up;
         const int j = u.level;
         const bool is_down = u.name.compare(0, 10, "down_convs") == 0;
         const bool is_enc_conv2 = is_down && u.name.find("conv2") != std::string::npos;
@@ -596,7 +681,13 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
                 if (cfg.act_slope == 0.f) { a.x = b.act; a.x_ldc = b.act_ldc; a.scale = B.ones; a.shift = B.zeros; }
             }
             if (k == nunits - 1) {      // incoming gradient = that of the 1x1x1 head, recomputed on the fly
-                a.g1 = nullptr; a.head_dy = dy; a.head_w = P(plan->p_final_w); a.head_cout = cfg.out_channels; a.head_S = L[0].vox / N;
+                a.g1 = nullptr; a.head_dy = dy; a.head_w = P(plan->p_final_w); a.head_cout = cfg.out_channels; a.head_S = ND.Y.vox / N;
+            }
+            else if (pooled_unit && valid) {   // the skip was centre-cropped: its gradient is zero outside that box
+                const LevelDims& dc = ND.u[2 * nb + 3 * (nb - 2 - j)].out;
+                RUN(launch_pad_box(cfg.merge_add ? B.dcat[j] : B.dcat[j] + u.cout, B.gskip[j], u.cout, N, dc.D, dc.H, dc.W, lo.D, lo.H, lo.W, s,
+                                   ND.sd_[j], ND.sh_[j], ND.sw_[j], cfg.merge_add ? u.cout : 2 * u.cout));
+                a.g1 = B.gskip[j]; a.g1_ldc = u.cout; a.gpool = g; a.a = b.act; a.a_ldc = b.act_ldc; a.pooled = B.pooled[j];
             }
             else if (pooled_unit) { a.g1 = cfg.merge_add ? B.dcat[j] : B.dcat[j] + u.cout; a.g1_ldc = cfg.merge_add ? u.cout : 2 * u.cout; a.gpool = g; a.a = b.act; a.a_ldc = b.act_ldc; a.pooled = B.pooled[j]; }
             else { a.g1 = g; a.g1_ldc = g_ldc; }
@@ -615,10 +706,10 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             } else a.coef = B.zeros;
             // the first conv without a requested input gradient: dxr has a single consumer (its wgrad), which computes it on the fly
             static const bool no_first_fuse = getenv("E3_NO_FIRST_FUSE") != nullptr;     // A/B switch
-            fuse_first = k == 0 && !dx && u.cin < 8 && !u.is_up && !no_first_fuse && cfg.normalization != 2;   // (the fused staging has no group terms)
+            fuse_first = k == 0 && !dx && u.cin < 8 && !u.is_up && !no_first_fuse && cfg.normalization != 2 && !valid;   // (the fused staging has no group terms)
             if (fuse_first) {
                 first_fuse = SmallWgradFuse{a.x, a.x_ldc, a.g1, a.g1_ldc, a.scale, a.shift, a.mean, a.invstd, a.gamma, a.coef, B.biaspart0, a.act};
-                bias_jobs.push_back({B.biaspart0, conv_small_wgrad_splits(N, lo.D, lo.H, lo.W, u.planar), u.cout, 0, u.cout, G(u.p_b)});
+                bias_jobs.push_back({B.biaspart0, conv_small_wgrad_splits(N, ci.D, ci.H, ci.W, u.planar), u.cout, 0, u.cout, G(u.p_b)});
             } else {
                 RUN(launch_bn_bwd_apply(a, s));
                 bias_jobs.push_back({a.part, a.parts, 3 * u.cout, 2 * u.cout, u.cout, G(u.p_b)});
@@ -639,9 +730,13 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             }
         }
         // -- weight gradient
-        const float* dyu = dxr;      // ResizeConv: gradient of the conv output on the up-sampled grid (zero in the cropped-away voxels)
+        const float* dyu = dxr;      // gradient of the conv output on the grid the conv kernels run on: zero in cropped-away voxels
+        if (vcrop) {                 // ('valid' plain conv: dxr sits at (od, oh, ow) inside the input grid)
+            RUN(launch_pad_box(dxr, B.rpad, u.cout, N, lo.D, lo.H, lo.W, ci.D, ci.H, ci.W, s, ND.u[k].od, ND.u[k].oh, ND.u[k].ow));
+            dyu = B.rpad;
+        }
         if (u.is_up == 2) {
-            const LevelDims& li = L[j + 1];
+            const LevelDims& li = ND.u[k].in;
             const int Ud = li.D * (u.planar ? 1 : 2), Uh = li.H * 2, Uw = li.W * 2, taps = u.planar ? 9 : 27;
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             if (!(Ud == lo.D && Uh == lo.H && Uw == lo.W)) {
@@ -658,7 +753,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
                 RUN(launch_extract_center_tap(B.gemb, G(u.p_w), (size_t)u.cout * u.cin, taps, s));
             } else RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
         } else if (u.is_up) {
-            const LevelDims& li = L[j + 1];
+            const LevelDims& li = ND.u[k].in;
             const int sd = u.planar ? 1 : 2;
             WgradArgs a{};
             a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dxr; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = B.slab;
@@ -669,23 +764,23 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, sd * 4, a.CiPad, a.CoPad, u.cin, u.cout, s));
         } else if (u.cin < 8) {
             const int taps = u.planar ? 9 : 27;
-            const int splits = conv_small_wgrad_splits(N, lo.D, lo.H, lo.W, u.planar);
-            { Prof pr(plan, s, k, 2); RUN(launch_conv_small_wgrad(xin, u.cin, dxr, u.cout, B.slab, N, lo.D, lo.H, lo.W, u.cout, u.planar, s, fuse_first ? &first_fuse : nullptr)); }
+            const int splits = conv_small_wgrad_splits(N, ci.D, ci.H, ci.W, u.planar);
+            { Prof pr(plan, s, k, 2); RUN(launch_conv_small_wgrad(xin, u.cin, dyu, u.cout, B.slab, N, ci.D, ci.H, ci.W, u.cout, u.planar, s, fuse_first ? &first_fuse : nullptr)); }
             RUN(launch_wgrad_reduce(B.slab, G(u.p_w), splits, taps, u.cout, u.cin, u.cout, u.cin, s));
         } else {
             const int taps = u.planar ? 9 : 27;
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             WgradArgs a{};
-            a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dxr; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = B.slab;
-            a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
-            a.splits = wgrad_splits(kind, N, lo.D, lo.H, lo.W, u.cin, u.cout);
+            a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dyu; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = B.slab;
+            a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
+            a.splits = wgrad_splits(kind, N, ci.D, ci.H, ci.W, u.cin, u.cout);
             { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(kind, a, s)); }
             RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
         }
         // -- data gradient -> g for the previous unit
         if (k == 0 && !dx) break;
         if (u.is_up == 2) {      // conv dgrad on the up-sampled grid, then the sum over each (sd x 2 x 2) block = backward of nn.Upsample(nearest)
-            const LevelDims& li = L[j + 1];
+            const LevelDims& li = ND.u[k].in;
             const int sd = u.planar ? 1 : 2, Ud = li.D * sd, Uh = li.H * 2, Uw = li.W * 2, NPad = pad_cols(u.cin);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             const float* wsrc = P(u.p_w);
@@ -700,7 +795,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             RUN(launch_downsample_sum(B.rdu, B.g1[j + 1], u.cin, u.cin, N, li.D, li.H, li.W, sd, s, cfg.up_resize == 2 || cfg.up_resize == 4));
             g = B.g1[j + 1]; g_ldc = u.cin;
         } else if (u.is_up) {
-            const LevelDims& li = L[j + 1];
+            const LevelDims& li = ND.u[k].in;
             const int sd = u.planar ? 1 : 2, taps = sd * 4, NPad = pad_cols(u.cin);
             RUN(launch_pack_weights(PACK_UP_DGRAD, P(u.p_w), B.wpack, u.cout, u.cin, taps, NPad, s));
             ConvArgs a{};
@@ -713,19 +808,19 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             const int taps = u.planar ? 9 : 27, NPad = pad_cols(u.cin);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             (void)taps;
-            if (!B.wpk_d[k]) RUN(launch_pack_conv_auto(kind, 1, P(u.p_w), B.wpack, u.cout, u.cin, N, lo.D, lo.H, lo.W, 0, s));
+            if (!B.wpk_d[k]) RUN(launch_pack_conv_auto(kind, 1, P(u.p_w), B.wpack, u.cout, u.cin, N, ci.D, ci.H, ci.W, 0, s));
             const bool to_cat = !is_down && u.name.find("conv1") != std::string::npos;   // UpConv.conv1: gradient of the concat buffer
             float* out; int out_ldc = u.cin;
             if (k == 0) out = (cfg.in_channels > 1) ? B.g1[0] : dx;   // g1[0] is free by now (C0 >= in_channels)
             else if (to_cat) out = B.dcat[j];
             else out = B.g1[j];
             ConvArgs a{};
-            a.x = dxr; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = B.wpk_d[k] ? B.wpk_d[k] : B.wpack; a.y = out; a.y_ldc = out_ldc;
-            a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.sd = 2;
+            a.x = dyu; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = B.wpk_d[k] ? B.wpk_d[k] : B.wpack; a.y = out; a.y_ldc = out_ldc;
+            a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.sd = 2;
             a.Cout = u.cin; a.Ncols = u.cin; a.NPad = NPad; a.G = 1;
             a.flags = (bucket_event != nullptr && event_done) ? CF_NO_PERSIST : 0;   // the gradient all-reduce may be running on some CUs
             { Prof pr(plan, s, k, 1); RUN(launch_conv_mfma(kind, a, s)); }
-            if (k == 0) { if (cfg.in_channels > 1) RUN(launch_ndhwc_to_ncdhw(B.g1[0], cfg.in_channels, dx, N, cfg.in_channels, L[0].vox / N, s)); }
+            if (k == 0) { if (cfg.in_channels > 1) RUN(launch_ndhwc_to_ncdhw(B.g1[0], cfg.in_channels, dx, N, cfg.in_channels, ND.X[0].vox / N, s)); }
             g = out; g_ldc = (to_cat && !cfg.merge_add) ? 2 * u.cout : u.cin;   // concat: the next unit (upconv) reads the first half, ldc = 2*C; add: d(up + skip) goes to both
         }
     }

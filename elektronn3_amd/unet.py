@@ -440,7 +440,7 @@ class UNet(nn.Module):
                 1 if getattr(self, 'full_norm', True) else 0, 1 if self.merge_mode == 'add' else 0,
                 _num_groups(self.normalization) if self.normalization.startswith('group') else 0,
                 {'transpose': 0, 'resizeconv_nearest': 1, 'resizeconv_linear': 2, 'resizeconv_nearest1': 3, 'resizeconv_linear1': 4}[self.up_mode],
-                float(_activation_slope(self.activation)))
+                1 if self.conv_mode == 'valid' else 0, float(_activation_slope(self.activation)))
 
     def _plan(self):
         return _get_plan(self._plan_key())

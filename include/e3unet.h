@@ -61,6 +61,8 @@ typedef struct e3_unet_cfg {
     int32_t num_groups;     /* normalization = 2: number of groups (8 for 'group', G for 'group<G>', unet.py:81-90) */
     int32_t up_resize;      /* 0: up_mode='transpose' (nn.ConvTranspose3d k=s=2); 1: 'resizeconv_nearest', 2: 'resizeconv_linear', 3 / 4: the same with a 1x1x1 conv ('resizeconv_nearest1' / 'resizeconv_linear1') (ResizeConv: nn.Upsample(nearest | tri-/bilinear, align_corners=False) + conv3,
                              * unet.py:152-176,411-449; parameters 'up_convs.i.upconv.conv.weight/bias') */
+    int32_t conv_valid;     /* 0: conv_mode='same' (padding 1); 1: conv_mode='valid' (padding 0 in the 3x3x3 convs of the blocks, unet.py:217,347: the
+                             * output is smaller than the input, see e3_unet_out_dims) */
     float act_slope;        /* activation (get_activation, unet.py:183-199): 0 = 'relu', 0.1 = 'leaky' (LeakyReLU(0.1)), 1 = 'lin' (identity), 2 = 'silu',
                              * 3 = 'prelu' (nn.PReLU(1) per activation: parameters '<block>.act<k>.weight' join the table) */
 } e3_unet_cfg;
@@ -81,6 +83,8 @@ int e3_unet_bn_count(const e3_unet_plan* plan);
 /* Bytes of caller-provided device memory needed for an (N, in_channels, D, H, W) batch.
  *   saved_bytes:   activations kept from a training forward for the backward (0 for inference)
  *   scratch_bytes: temporaries; may be shared by consecutive calls on one stream */
+/* Spatial size of the logits for a (D, H, W) input: equal to the input with conv_mode='same'; smaller with 'valid'. */
+int e3_unet_out_dims(const e3_unet_plan* plan, int D, int H, int W, int* Do, int* Ho, int* Wo);
 int e3_unet_sizes(const e3_unet_plan* plan, int N, int D, int H, int W, int training,
                   size_t* saved_bytes, size_t* scratch_bytes);
 
