@@ -429,6 +429,8 @@ int e3_unet_out_dims(const e3_unet_plan* plan, int D, int H, int W, int* Do, int
 
 int e3_unet_sizes(const e3_unet_plan* plan, int N, int D, int H, int W, int training, size_t* saved_bytes, size_t* scratch_bytes) {
     E3_REQUIRE(plan && N > 0 && D > 0 && H > 0 && W > 0, E3_ERR_INVALID, "bad shape");
+    { NetDims nd; net_dims(plan, N, D, H, W, nd);
+      E3_REQUIRE(nd.ok, E3_ERR_INVALID, "input too small for this network (conv_mode='valid' shrinks every conv by 2)"); }
     Buffers B;
     plan_buffers(plan, N, D, H, W, training != 0, nullptr, nullptr, B);
     if (saved_bytes) *saved_bytes = B.saved_bytes;
@@ -444,6 +446,8 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
     const bool training = (flags & E3_FWD_TRAINING) != 0;
     const e3_unet_cfg& cfg = plan->cfg;
     const int nb = cfg.n_blocks;
+    { NetDims nd0; net_dims(plan, N, D, H, W, nd0);
+      E3_REQUIRE(N > 0 && nd0.ok, E3_ERR_INVALID, "input too small for this network (conv_mode='valid' shrinks every conv by 2)"); }
     E3_REQUIRE(!training || (saved && momenta), E3_ERR_INVALID, "training forward needs `saved` and `momenta`");
     E3_REQUIRE(training || cfg.normalization != 2, E3_ERR_INVALID, "GroupNorm has no running statistics: pass E3_FWD_TRAINING also for inference");
     Buffers B;
@@ -608,6 +612,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
     hipStream_t s = (hipStream_t)stream;
     const e3_unet_cfg& cfg = plan->cfg;
     const int nb = cfg.n_blocks;
+    { NetDims nd0; net_dims(plan, N, D, H, W, nd0); E3_REQUIRE(N > 0 && nd0.ok, E3_ERR_INVALID, "input too small for this network"); }
     Buffers B;
     plan_buffers(plan, N, D, H, W, true, saved, scratch, B);
     E3_REQUIRE(saved_bytes >= B.saved_bytes, E3_ERR_WORKSPACE, "`saved` buffer too small");

@@ -172,7 +172,7 @@ def calculate_offset(model, tile_shape=None):
                 ex = torch.randn(1, param.size()[1], *sh, device=param.device, dtype=param.dtype)
                 out = model.eval().forward(ex)
                 return np.subtract(ex.shape[2:], out.shape[2:]) // 2
-            except RuntimeError as e:
+            except (RuntimeError, ValueError) as e:      # (wrong rank for this model: try the next probe shape)
                 last = e
         raise last
 
@@ -298,8 +298,8 @@ class Predictor:
             assert is_set(out_shape), 'If tile_shape is set, out_shape is required to be set, too.'
             self.enable_tiling = True
             if offset is None:
-                if self._native:
-                    offset = np.zeros(len(tile_shape), dtype=np.int64)   # 'same' convolutions only: known without a probe forward
+                if self._native and getattr(self.model if not isinstance(self.model, nn.Sequential) else self.model[0], 'conv_mode', 'same') == 'same':
+                    offset = np.zeros(len(tile_shape), dtype=np.int64)   # 'same' convolutions: known without a probe forward
                 else:
                     logger.warning('Predictor: offset=None -> Estimating offset from forward pass.')
                     offset = calculate_offset(self.model)

@@ -52,6 +52,11 @@ class _Plan:
             check(lib.e3_unet_conv_info(handle, i, buf, 160, ctypes.byref(ci), ctypes.byref(co), ctypes.byref(taps), ctypes.byref(lvl)))
             self.conv_names.append((buf.value.decode(), ci.value, co.value, taps.value, lvl.value))
 
+    def out_dims(self, D, H, W):
+        do, ho, wo = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(_lib.load().e3_unet_out_dims(self.handle, D, H, W, ctypes.byref(do), ctypes.byref(ho), ctypes.byref(wo)))
+        return do.value, ho.value, wo.value
+
     def sizes(self, N, D, H, W, training):
         saved, scratch = c_size_t(), c_size_t()
         check(_lib.load().e3_unet_sizes(self.handle, N, D, H, W, int(training), ctypes.byref(saved), ctypes.byref(scratch)))
@@ -108,7 +113,8 @@ class _UNetFunction(torch.autograd.Function):
         saved_bytes, scratch_bytes = plan.sizes(N, D, H, W, training)
         saved = torch.empty(max(saved_bytes, 256), dtype=torch.uint8, device=dev) if training else None
         scratch = _get_scratch(dev, max(scratch_bytes, 256))
-        y = torch.empty((N, module.out_channels, D, H, W), dtype=torch.float32, device=dev)
+        Do, Ho, Wo = plan.out_dims(D, H, W)      # == (D, H, W) unless conv_mode='valid'
+        y = torch.empty((N, module.out_channels, Do, Ho, Wo), dtype=torch.float32, device=dev)
         ptrs = (c_void_p * len(tens))(*[t.data_ptr() for t in tens])
         momenta = None
         if training:
@@ -258,13 +264,16 @@ class ResizeConv(nn.Module):
 class DownConv(nn.Module):
     """Parameter container for one encoder block (two convs, two norms, max-pool) -- reference: unet.py:202-253."""
 
-    def __init__(self, in_channels, out_channels, pooling=True, planar=False, dim=3, normalization='batch', full_norm=True, activation='relu'):
+    def __init__(self, in_channels, out_channels, pooling=True, planar=False, dim=3, normalization='batch', full_norm=True, activation='relu',
+                 conv_mode='same'):
         super().__init__()
         self.in_channels, self.out_channels, self.pooling, self.planar = in_channels, out_channels, pooling, planar
         self.dim = dim
         self.normalization = normalization
         Conv, Pool, Norm = _LAYERS[dim][0], _LAYERS[dim][2], _LAYERS[dim][3]
         k, p = ((1, 3, 3), (0, 1, 1)) if (planar and dim == 3) else (3, 1)
+        if 'same' not in conv_mode:      # padding = 1 if 'same' in conv_mode else 0 (unet.py:217)
+            p = (0, 0, 0) if (planar and dim == 3) else 0
         self.conv1 = Conv(in_channels, out_channels, kernel_size=k, padding=p)
         self.conv2 = Conv(out_channels, out_channels, kernel_size=k, padding=p)
         if pooling:
@@ -284,7 +293,7 @@ class UpConv(nn.Module):
     """Parameter container for one decoder block (transposed conv, two convs, three norms) -- reference: unet.py:328-408."""
 
     def __init__(self, in_channels, out_channels, planar=False, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu',
-                 up_mode='transpose'):
+                 up_mode='transpose', conv_mode='same'):
         super().__init__()
         self.in_channels, self.out_channels, self.planar = in_channels, out_channels, planar
         self.merge_mode = merge_mode
@@ -293,6 +302,8 @@ class UpConv(nn.Module):
         Conv, ConvT, Norm = _LAYERS[dim][0], _LAYERS[dim][1], _LAYERS[dim][3]
         ks = (1, 2, 2) if (planar and dim == 3) else 2
         k, p = ((1, 3, 3), (0, 1, 1)) if (planar and dim == 3) else (3, 1)
+        if 'same' not in conv_mode:      # (unet.py:347; the ResizeConv's own conv keeps padding 1)
+            p = (0, 0, 0) if (planar and dim == 3) else 0
         self.up_mode = up_mode
         if up_mode == 'transpose':
             self.upconv = ConvT(in_channels, out_channels, kernel_size=ks, stride=ks)
@@ -318,7 +329,7 @@ class UNet(nn.Module):
     kernels.  Options of the reference that are not yet on the HIP path raise ``NotImplementedError`` at
     construction: ``up_mode='upsample'``,
     ``attention=True``, ``activation='rrelu'`` (random slopes),
-    ``conv_mode != 'same'``.  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
+    ``conv_mode`` other than ``'same'`` / ``'valid'``.  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
     the 3D one with every block planar and a depth of 1."""
 
     def __init__(
@@ -377,7 +388,7 @@ class UNet(nn.Module):
             if start_filts % _num_groups(normalization) != 0:
                 raise ValueError('num_channels must be divisible by num_groups')      # (torch.nn.GroupNorm's own check)
         elif normalization not in ('batch', 'none', 'instance'): unsupported.append(f'normalization={normalization!r}')
-        if conv_mode != 'same': unsupported.append(f'conv_mode={conv_mode!r}')
+        if conv_mode not in ('same', 'valid'): unsupported.append(f'conv_mode={conv_mode!r}')
         if start_filts % 8 != 0: unsupported.append(f'start_filts={start_filts} (must be a multiple of 8)')
         if not (1 <= out_channels <= 8): unsupported.append(f'out_channels={out_channels} (1..8)')
         if not (in_channels < 8 or in_channels % 8 == 0): unsupported.append(f'in_channels={in_channels}')
@@ -405,12 +416,12 @@ class UNet(nn.Module):
             ins = in_channels if i == 0 else outs
             outs = start_filts * (2 ** i)
             self.down_convs.append(DownConv(ins, outs, pooling=i < n_blocks - 1, planar=i in self.planar_blocks, dim=dim,
-                                            normalization=normalization, full_norm=full_norm, activation=activation))
+                                            normalization=normalization, full_norm=full_norm, activation=activation, conv_mode=conv_mode))
         for i in range(n_blocks - 1):
             ins = outs
             outs = ins // 2
             self.up_convs.append(UpConv(ins, outs, planar=(n_blocks - 2 - i) in self.planar_blocks, dim=dim,
-                                        normalization=normalization, full_norm=full_norm, merge_mode=merge_mode, activation=activation, up_mode=up_mode))
+                                        normalization=normalization, full_norm=full_norm, merge_mode=merge_mode, activation=activation, up_mode=up_mode, conv_mode=conv_mode))
         self.conv_final = _LAYERS[dim][0](outs, out_channels, kernel_size=1)
         self.apply(self.weight_init)
 

@@ -39,6 +39,8 @@ def _bn(x, sd, name, training, momentum=0.1, eps=1e-5):
 def _conv(x, sd, name):
     w = sd[name + '.weight']
     pad = tuple((k - 1) // 2 for k in w.shape[2:])
+    if sd.get('__valid__', False) and (name.endswith('.conv1') or name.endswith('.conv2')):
+        pad = tuple(0 for _ in pad)             # conv_mode='valid': padding 0 in the convs of the blocks (unet.py:217,347)
     return (F.conv3d if w.dim() == 5 else F.conv2d)(x, w, sd[name + '.bias'], padding=pad)   # get_conv(dim), unet.py:47-54
 
 

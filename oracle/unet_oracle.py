@@ -264,6 +264,7 @@ class OracleUNet:
         self.planar = tuple(planar_blocks)
         self.norm = normalization
         self.num_groups = 8 if normalization == 'group' else (int(normalization[5:]) if normalization.startswith('group') else 0)
+        self.valid = False            # conv_mode='valid' (set by the caller)
         self.up_linear = False        # up_mode='resizeconv_linear' (set by the caller)
         self.act_slope = 0.0          # 0 ReLU, 0.1 'leaky', 1.0 'lin' (set by the caller)
         self.instance_norms = ()      # names of the nn.InstanceNorm layers (they have no state_dict entries), set by the caller
@@ -282,6 +283,8 @@ class OracleUNet:
     def _conv(self, name, x, cache):
         w, b = self.sd[name + '.weight'], self.sd[name + '.bias']
         pad = tuple((k - 1) // 2 for k in w.shape[2:])
+        if self.valid and (name.endswith('.conv1') or name.endswith('.conv2')):
+            pad = (0, 0, 0)                     # conv_mode='valid': padding 0 in the convs of the blocks (unet.py:217,347)
         cache[name] = (x, pad)
         return conv3d_fwd(x, w, b, pad)
 

@@ -155,10 +155,10 @@ def criterion(loss_mod):
                                   loss_mod.DiceLoss(apply_softmax=True, weight=cw)], weight=[0.5, 0.5])
 
 
-def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu', up_mode='transpose'):
+def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu', up_mode='transpose', conv_mode='same'):
     torch.manual_seed(seed)
     model = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
-                      planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode)
+                      planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode, conv_mode=conv_mode)
     # make BN affine + conv bias non-trivial so that the fixtures exercise them
     with torch.no_grad():
         for name, p in model.named_parameters():
@@ -170,10 +170,10 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
                 p.copy_(0.25 + 0.3 * torch.randn_like(p))
     sd0 = {k: npy(v).copy() for k, v in model.state_dict().items()}
     x = torch.randn(batch, 1, *shape)
-    target = torch.randint(0, 2, (batch, *shape))
     model.train()
     crit = criterion(loss_mod)
     out_t = model(x)
+    target = torch.randint(0, 2, (batch, *out_t.shape[2:]))      # (conv_mode='valid': the output is smaller than the input)
     loss = crit(out_t, target)
     dout, = torch.autograd.grad(loss, out_t, retain_graph=True)
     loss.backward()
@@ -191,6 +191,8 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
         d['cfg.activation'] = np.array(activation)
     if up_mode != 'transpose':
         d['cfg.up_mode'] = np.array(up_mode)
+    if conv_mode != 'same':
+        d['cfg.conv_mode'] = np.array(conv_mode)
     for k, v in sd0.items():
         d['sd0/' + k] = v
     for k, v in model.state_dict().items():
@@ -203,7 +205,7 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
         d['logits_eval'] = npy(model(x))
     # fp64 reference of the same step (tolerances are stated against it)
     m64 = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
-                    planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode).double()
+                    planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode, conv_mode=conv_mode).double()
     m64.load_state_dict({k: torch.as_tensor(v).double() if v.dtype != np.int64 else torch.as_tensor(v) for k, v in sd0.items()})
     m64.train()
     o64 = m64(x.double())
@@ -320,6 +322,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'resizelin':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizelinear_odd.npz', seed=13, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(7, 15, 18), batch=2, up_mode='resizeconv_linear')
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'valid':
+        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_valid.npz', seed=16, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(21, 45, 47), batch=2, conv_mode='valid')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'prelu':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_prelu_odd.npz', seed=15, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 15, 19), batch=2, activation='prelu', full_norm=False)
         sys.exit(0)
@@ -366,6 +371,8 @@ if __name__ == '__main__':
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizenearest1_odd.npz', seed=14, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 13, 18), batch=2, up_mode='resizeconv_nearest1')
     # nn.PReLU(1) activations (learnable slopes) with the sparse norm scheme: slopes behind a norm and behind nn.Identity
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_prelu_odd.npz', seed=15, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 15, 19), batch=2, activation='prelu', full_norm=False)
+    # conv_mode='valid' (padding 0: shrinking grids, centre-cropped skips), planar first block, odd sizes
+    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_valid.npz', seed=16, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(21, 45, 47), batch=2, conv_mode='valid')
     make_predictor(unet, inference, f'{HERE}/predictor.npz')
     make_adamw(f'{HERE}/adamw.npz')
     make_trainsteps(unet, loss_mod, f'{HERE}/trainsteps.npz')

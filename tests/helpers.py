@@ -28,6 +28,8 @@ def unet_cfg(npz):
         cfg['dim'] = int(npz['cfg.dim'])
     if 'cfg.normalization' in npz.files:
         cfg['normalization'] = str(npz['cfg.normalization'])
+    if 'cfg.conv_mode' in npz.files:
+        cfg['conv_mode'] = str(npz['cfg.conv_mode'])
     if 'cfg.up_mode' in npz.files:
         cfg['up_mode'] = str(npz['cfg.up_mode'])
     if 'cfg.activation' in npz.files:

@@ -74,7 +74,7 @@ CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_plana
          'unet_nb3_sf8_group4_odd.npz', 'unet_nb3_sf8_leaky_odd.npz', 'unet_nb2_sf8_lin_nonorm.npz',
          'unet_nb3_sf8_silu_odd.npz', 'unet_nb3_sf8_resizeconv_odd.npz',
          'unet_nb3_sf8_resizelinear_odd.npz', 'unet_nb3_sf8_resizenearest1_odd.npz',
-         'unet_nb3_sf8_prelu_odd.npz']
+         'unet_nb3_sf8_prelu_odd.npz', 'unet_nb3_sf8_valid.npz']
 
 
 @pytest.mark.parametrize('case', CASES)
@@ -87,6 +87,7 @@ def test_unet_train_step(case):
     else:
         net = orc.OracleUNet(sub(g, 'sd0'), cfg['n_blocks'], cfg['planar_blocks'], normalization=cfg.get('normalization', 'batch'))
         net.instance_norms = instance_norm_names(cfg)
+        net.valid = cfg.get('conv_mode') == 'valid'
         net.up_linear = str(cfg.get('up_mode')).startswith('resizeconv_linear')
         net.act_slope = {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0, 'prelu': 3.0}[cfg.get('activation', 'relu')]
         logits = net.forward(g['x'])

@@ -256,3 +256,43 @@ def test_shared_host_tensor_roundtrip():
     u = _SharedHostTensor.create((1, 1, 7, 9, 11), torch.uint8)
     assert u.tensor.dtype == torch.uint8 and tuple(u.tensor.shape) == (1, 1, 7, 9, 11)
     u.unlink_if_owner()
+
+
+@pytest.mark.gpu
+def test_predictor_valid_conv_model_offset_path():
+    """conv_mode='valid' model through the Predictor's offset logic (inference.py:476-494, tiled_apply without padding): the output is
+    smaller than the input by 2*offset, tiles of the OUTPUT grid, each fed its input tile incl. the offset border; equals the
+    hand-rolled tiles and the untiled forward of the whole volume (valid convs see no padding, so tiling is exact here)."""
+    from elektronn3_amd.inference import Predictor, calculate_offset
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(21)
+    m = UNet(1, 2, n_blocks=2, start_filts=8, conv_mode='valid').cuda()
+    m.train()
+    with torch.no_grad():
+        m(torch.randn(2, 1, 40, 40, 40, device='cuda'))
+    m.eval()
+    off = calculate_offset(m, tile_shape=(48, 48, 48))
+    assert (off > 0).all()
+    tile = np.array([8, 12, 16])
+    S = 2 * tile + 2 * off                                    # 2 x 2 x 2 output tiles
+    vol = torch.randn(1, 1, *S)
+    pred = Predictor(m, device='cuda', tile_shape=tuple(tile), offset=tuple(off), out_shape=(2, *S), apply_softmax=True)
+    y = pred.predict(vol)
+    assert tuple(y.shape) == (1, 2, *(2 * tile))
+    with torch.no_grad():
+        whole = torch.softmax(m(vol.cuda()), 1).cpu()
+        assert tuple(whole.shape) == tuple(y.shape)
+        full = torch.zeros_like(y)
+        for iz in range(2):
+            for iy in range(2):
+                for ix in range(2):
+                    lo = tile * np.array([iz, iy, ix]); hi = lo + tile + 2 * off
+                    t = vol[:, :, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].cuda()
+                    o = torch.softmax(m(t), 1).cpu()
+                    assert tuple(o.shape[2:]) == tuple(tile)
+                    full[:, :, lo[0]:lo[0] + tile[0], lo[1]:lo[1] + tile[1], lo[2]:lo[2] + tile[2]] = o
+    assert torch.allclose(y, full, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(y, whole, rtol=1e-4, atol=1e-5)
+    # offset=None: estimated by a probe forward, like the reference does for unknown models
+    y2 = Predictor(m, device='cuda', tile_shape=tuple(tile), offset=None, out_shape=(2, *S), apply_softmax=True).predict(vol)
+    assert torch.equal(y2, y)

@@ -24,7 +24,7 @@ CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_plana
          'unet_nb3_sf8_group4_odd.npz', 'unet_nb3_sf8_leaky_odd.npz', 'unet_nb2_sf8_lin_nonorm.npz',
          'unet_nb3_sf8_silu_odd.npz', 'unet_nb3_sf8_resizeconv_odd.npz',
          'unet_nb3_sf8_resizelinear_odd.npz', 'unet_nb3_sf8_resizenearest1_odd.npz',
-         'unet_nb3_sf8_prelu_odd.npz']
+         'unet_nb3_sf8_prelu_odd.npz', 'unet_nb3_sf8_valid.npz']
 
 
 def build(cfg, sd_np):
@@ -252,9 +252,11 @@ def test_full_size_cfg4_anisotropic_against_pytorch_rocm():
                                 dict(activation='silu', planar_blocks=(0,)), dict(activation='silu', normalization='none'),
                                 dict(activation='prelu', planar_blocks=(0,)), dict(activation='prelu', normalization='none'),
                                 dict(up_mode='resizeconv_nearest'), dict(up_mode='resizeconv_nearest', planar_blocks=(0,), normalization='group', full_norm=False),
-                                dict(up_mode='resizeconv_linear', planar_blocks=(0,)), dict(up_mode='resizeconv_linear1', planar_blocks=(0,))],
+                                dict(up_mode='resizeconv_linear', planar_blocks=(0,)), dict(up_mode='resizeconv_linear1', planar_blocks=(0,)),
+                                dict(conv_mode='valid'), dict(conv_mode='valid', planar_blocks=(0,), merge_mode='add', normalization='group'),
+                                dict(conv_mode='valid', up_mode='resizeconv_nearest', activation='leaky', full_norm=False)],
                          ids=['nonorm', 'sparsenorm', 'add', 'add_nonorm_planar', 'instance', 'group8', 'group16_sparse_add',
-                              'leaky', 'leaky_nonorm_planar', 'lin_group', 'silu_planar', 'silu_nonorm', 'prelu_planar', 'prelu_nonorm', 'resizeconv', 'resizeconv_planar_group_sparse', 'resizelinear_planar', 'resizelinear1_planar'])
+                              'leaky', 'leaky_nonorm_planar', 'lin_group', 'silu_planar', 'silu_nonorm', 'prelu_planar', 'prelu_nonorm', 'resizeconv', 'resizeconv_planar_group_sparse', 'resizelinear_planar', 'resizelinear1_planar', 'valid', 'valid_planar_add_group', 'valid_resizeconv_leaky_sparse'])
 def test_option_variants_against_pytorch_rocm(kw):
     """normalization='none' and full_norm=False (norm layers = nn.Identity, unet.py:77-80,238-242,369-375) at a size that runs the
     Winograd kernels (conv -> bias -> ReLU fused in their epilogue, also in training), and merge_mode='add' (unet.py:398-401: the skip
@@ -271,10 +273,12 @@ def test_option_variants_against_pytorch_rocm(kw):
                 p.copy_(0.1 * torch.randn_like(p))
             elif '.act' in k:
                 p.copy_(0.25 + 0.3 * torch.randn_like(p))
-    x = torch.randn(2, 1, 32, 64, 64, device='cuda')
-    t = torch.randint(0, 2, (2, 32, 64, 64), device='cuda')
+    valid = kw.get('conv_mode') == 'valid'
+    x = torch.randn(2, 1, *((44, 76, 76) if valid else (32, 64, 64)), device='cuda')      # ('valid' shrinks every conv by 2)
     sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
     out = m(x)
+    assert valid == (out.shape[2:] != x.shape[2:])
+    t = torch.randint(0, 2, (2, *out.shape[2:]), device='cuda')
     loss = combined_loss(out, t)
     m.zero_grad(set_to_none=True)
     loss.backward()
@@ -282,6 +286,7 @@ def test_option_variants_against_pytorch_rocm(kw):
               for k, v in sd0.items()}
     pl = tuple(kw.get('planar_blocks', ()))
     group = str(kw.get('normalization', '')).startswith('group')
+    sd_ref['__valid__'] = valid
     sd_ref['__up_linear__'] = str(kw.get('up_mode')).startswith('resizeconv_linear')
     sd_ref['__act_slope__'] = {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0, 'prelu': 3.0}[kw.get('activation', 'relu')]
     sd_ref['__instance_norms__'] = paramless
@@ -314,6 +319,7 @@ def test_option_variants_against_pytorch_rocm(kw):
     sd_e['__num_groups__'] = sd_ref['__num_groups__']
     sd_e['__act_slope__'] = sd_ref['__act_slope__']
     sd_e['__up_linear__'] = sd_ref['__up_linear__']
+    sd_e['__valid__'] = valid
     assert torch.allclose(ye.double(), unet_forward(sd_e, x.double(), 3, pl, training=False), rtol=1e-4, atol=1e-4)
     if paramless or group:       # instance / group statistics in eval mode too: eval output == train output, and a batch equals its samples one by one
         assert torch.equal(ye, out.detach())

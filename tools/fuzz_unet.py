@@ -35,14 +35,24 @@ for case in range(n_cases):
     elif v == 4: kw = dict(normalization=('group', 'group4', 'group2')[ri(0, 2)], full_norm=bool(ri(0, 1)))
     if ri(0, 3) == 0: kw['merge_mode'] = 'add'
     if ri(0, 3) == 0 and 'merge_mode' not in kw: kw['up_mode'] = ('resizeconv_nearest', 'resizeconv_linear', 'resizeconv_nearest1', 'resizeconv_linear1')[ri(0, 3)]
+    if ri(0, 3) == 0:
+        kw['conv_mode'] = 'valid'          # every conv shrinks the grid by 2: needs a larger input
     if ri(0, 3) == 0: kw['activation'] = ('leaky', 'lin', 'silu', 'prelu')[ri(0, 3)]
     shape = (H, W) if D is None else (D, H, W)
+    if kw.get('conv_mode') == 'valid':
+        shape = tuple(s_ + 4 * (2 ** nb) for s_ in shape)
     torch.manual_seed(case)
+    print(f'case {case}: nb={nb} sf={sf} in={inc} out={outc} planar={planar} {kw} N={N} shape={shape}', flush=True)
     try:
         m = UNet(in_channels=inc, out_channels=outc, n_blocks=nb, start_filts=sf, planar_blocks=planar, **kw).cuda().train()
     except Exception as e:
         print('skip (ctor):', nb, sf, planar, e); continue
-    x = torch.randn(N, inc, *shape, device='cuda'); t = torch.randint(0, outc, (N, *shape), device='cuda')
+    x = torch.randn(N, inc, *shape, device='cuda')
+    try:
+        with torch.no_grad(): oshape = tuple(m.eval()(x[:1]).shape[2:]); m.train()
+    except ValueError as e:
+        print('skip (too small for valid):', shape, e); continue
+    t = torch.randint(0, outc, (N, *oshape), device='cuda')
     cw = tuple(float(v) for v in (torch.rand(outc, generator=g) + 0.2))
     with torch.no_grad():
         for k, p in m.named_parameters():
@@ -52,6 +62,7 @@ for case in range(n_cases):
     sd_ref = {k: (v.double() if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd0.items()}
     paramless = R.instance_norm_names(nb, kw.get('full_norm', True)) if kw.get('normalization') == 'instance' else ()
     sd_ref['__instance_norms__'] = paramless
+    sd_ref['__valid__'] = kw.get('conv_mode') == 'valid'
     sd_ref['__up_linear__'] = str(kw.get('up_mode')).startswith('resizeconv_linear')
     sd_ref['__act_slope__'] = {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0, 'prelu': 3.0}[kw.get('activation', 'relu')]
     group = str(kw.get('normalization', '')).startswith('group')
