@@ -101,11 +101,13 @@ class _UNetFunction(torch.autograd.Function):
         training = module.training or module._per_sample_norm()   # instance / group statistics also in eval mode
         # parameters / buffers at call time, in the plan's table order
         tens = module._table(plan, params)
+        lowp = None
         if any(t.dtype != torch.float32 for t in tens):
-            if training:
-                raise NotImplementedError('training with non-fp32 parameters is not implemented on the HIP path '
-                                          '(use fp32 parameters; autocast inputs are up-cast)')
-            tens = [t.float() for t in tens]   # e.g. Predictor(float16=True): compute in fp32, cast the result
+            # model.half() / model.bfloat16() (Predictor(float16=True), BASELINE cfg 3's bf16 storage): the kernels compute in fp32 on
+            # up-cast copies -- at least the reference's precision -- and results are cast back (the output below, gradients in backward,
+            # the running statistics right after the call)
+            lowp = tens
+            tens = [t.float() for t in tens]
         tens = [t if t.is_contiguous() else t.contiguous() for t in tens]
         # (grad mode is off inside Function.forward; needs_input_grad tells whether a backward can follow)
         need_grad = training and any(ctx.needs_input_grad)
@@ -128,6 +130,10 @@ class _UNetFunction(torch.autograd.Function):
                                       c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), flags))
         if training:
             module._bump_num_batches_tracked(plan)
+            if lowp is not None:         # running statistics were updated in the fp32 copies
+                for kind, lo_t, hi_t in zip(plan.kinds, lowp, tens):
+                    if kind != 0 and lo_t.dtype != torch.float32:
+                        lo_t.copy_(hi_t)
         ctx.module, ctx.plan = module, plan
         ctx.softmax = softmax
         ctx.shape = (N, D, H, W)

@@ -539,3 +539,34 @@ def test_ce_dice_loss_matches_reference_criterion(C, shape, weighted):
     # deterministic (fixed reduction order)
     loss2 = crit(zt.detach(), torch.from_numpy(t).cuda())
     assert float(loss2) == float(loss)
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_low_precision_module_trains_with_fp32_compute(dt):
+    """model.bfloat16() / model.half() (BASELINE configs[2] stores the model in bf16; Predictor(float16=True)): parameters, input and
+    output keep the low-precision dtype, the kernels compute in fp32 on up-cast copies.  One training step must equal the fp32 model
+    loaded with the SAME (rounded) parameters, up to the rounding of the results to the storage dtype."""
+    from elektronn3_amd.unet import UNet
+    from oracle.torch_ref import combined_loss
+    torch.manual_seed(31)
+    m = UNet(1, 2, n_blocks=3, start_filts=16, planar_blocks=(0,)).cuda().to(dt).train()
+    ref = UNet(1, 2, n_blocks=3, start_filts=16, planar_blocks=(0,)).cuda().train()
+    ref.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
+    x = torch.randn(2, 1, 12, 40, 48, device='cuda').to(dt)
+    t = torch.randint(0, 2, (2, 12, 40, 48), device='cuda')
+    out = m(x)
+    assert out.dtype == dt
+    out_ref = ref(x.float())
+    eps = torch.finfo(dt).eps
+    torch.testing.assert_close(out.float(), out_ref, rtol=2 * eps, atol=2 * eps)
+    combined_loss(out.float(), t).backward()
+    combined_loss(out_ref, t).backward()
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.grad.dtype == dt
+        # (the low-precision run back-propagates through the rounded logits: allow the storage rounding on top)
+        assert float((p.grad.float() - q.grad).norm()) <= 3e-2 * float(q.grad.norm()) + 1e-6, k
+    for (k, b), (_, c) in zip(m.named_buffers(), ref.named_buffers()):
+        if 'running' in k:
+            torch.testing.assert_close(b.float(), c, rtol=2 * eps, atol=2 * eps, msg=k)
+            assert b.dtype == dt
+    assert not torch.equal(m.down_convs[0].norm0.running_mean.float(), torch.zeros(16, device='cuda'))
