@@ -204,7 +204,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         // without batch statistics to wait for, the conv writes relu(acc*scale + shift) directly; other activations are not in the conv
         // epilogues and take the two-pass route (raw tensor, then the apply pass)
         b.raw = ((training && u.has_norm()) || p->cfg.act_slope != 0.f || u.is_up == 2 || (valid && !u.is_up)) ? A.take(n) : nullptr;
-        if (u.is_up == 2) {
+        if (u.is_up == 2 && p->cfg.up_resize < 3) {       // (the 1x1x1 variants convolve at low resolution: no up-sampled input)
             const LevelDims& li = ND.u[k].in;
             B.ups[k] = A.take((size_t)N * li.D * (u.planar ? 1 : 2) * li.H * 2 * li.W * 2 * u.cin);
         }
@@ -233,6 +233,10 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
             statmax = max_sz(statmax, (size_t)conv_stats_parts(kind, 0, N, Ud, Uh, Uw, 2, u.cin, u.cout) * u.cout * 3);
             statmax = max_sz(statmax, (size_t)crop_stats_parts(lo.vox, u.cout) * u.cout * 3);
             rtmpmax = max_sz(rtmpmax, uvox * u.cout); rdumax = max_sz(rdumax, uvox * u.cin);
+            if (p->cfg.up_resize >= 3) {   // 1x1x1 variants: centre tap of a 1x3x3 kernel on the LOW-resolution grid
+                wmax = max_sz(wmax, max_sz(conv_packed_floats(CONV_K3_PLANAR, u.cin, u.cout), conv_packed_floats(CONV_K3_PLANAR, u.cout, u.cin)));
+                if (training) slabmax = max_sz(slabmax, (size_t)wgrad_splits(CONV_K3_PLANAR, N, li.D, li.H, li.W, u.cin, u.cout) * 9 * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32));
+            }
             if (training) slabmax = max_sz(slabmax, (size_t)wgrad_splits(kind, N, Ud, Uh, Uw, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32));
         } else if (u.is_up) {
             const int sd = u.planar ? 1 : 2, taps = sd * 4;
@@ -266,7 +270,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     B.wpack = T.take(wmax);
     B.wemb = B.gemb = nullptr;
     if (p->cfg.up_resize >= 3) { const size_t e = (size_t)p->chan(nb - 1) * p->chan(nb - 1) / 2 * 27; B.wemb = T.take(e); if (training) B.gemb = T.take(e); }
-    if (rtmpmax) { B.rtmp = T.take(rtmpmax); if (training) { B.rpad = T.take(rtmpmax); if (rdumax) B.rdu = T.take(rdumax); } }
+    if (rtmpmax) { B.rtmp = T.take(rtmpmax); if (rdumax) B.rdu = T.take(rdumax); if (training) B.rpad = T.take(rtmpmax); }
     B.wpk_f.assign(p->units.size(), nullptr); B.wpk_d.assign(p->units.size(), nullptr);
     for (size_t k = 0; k < p->units.size(); ++k) {
         const ConvUnit& u = p->units[k];
@@ -498,16 +502,30 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             es = b.scale; eh = b.shift;                    // epilogue (running stats) -- constants from the launch above
         }
         int parts = 0;
-        if (u.is_up == 2) {      // ResizeConv (unet.py:411-449): nn.Upsample(nearest) then conv3 on the up-sampled grid, autocrop afterwards
+        if (u.is_up == 2 && cfg.up_resize >= 3) {
+            // ResizeConv(kernel_size=1): a 1x1x1 conv commutes with the up-sampling (nearest copies voxels; the linear weights sum to 1, so
+            // the bias passes through), so it runs at LOW resolution -- as the centre tap of a 1x3x3 kernel on the planar conv kernels
+            // (9 instead of 8*27 multiplies per low-resolution voxel) -- and its Cout-channel result is up-sampled, cropped, measured.
+            const LevelDims& li = ND.u[k].in;
+            const int sd = u.planar ? 1 : 2, Ud = li.D * sd, Uh = li.H * 2, Uw = li.W * 2, NPad = pad_cols(u.cout);
+            const bool lin = cfg.up_resize == 4;
+            RUN(launch_embed_center_tap(P(u.p_w), B.wemb, (size_t)u.cout * u.cin, 9, s));
+            RUN(launch_pack_conv_auto(CONV_K3_PLANAR, 0, B.wemb, B.wpack, u.cout, u.cin, N, li.D, li.H, li.W, 0, s));
+            ConvArgs a{};
+            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
+            a.y = B.rdu; a.y_ldc = u.cout; a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.sd = 2;
+            a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.G = 1; a.flags = 0; a.stats = nullptr;
+            { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(CONV_K3_PLANAR, a, s)); }
+            RUN(launch_upsample_nearest(B.rdu, u.cout, B.rtmp, u.cout, N, li.D, li.H, li.W, sd, s, lin));
+            RUN(launch_crop_stats(B.rtmp, b.raw, u.cout, N, Ud, Uh, Uw, lo.D, lo.H, lo.W, B.stats, s));
+            parts = crop_stats_parts(lo.vox, u.cout);
+        } else if (u.is_up == 2) {      // ResizeConv (unet.py:411-449): nn.Upsample(nearest) then conv3 on the up-sampled grid, autocrop afterwards
             const LevelDims& li = ND.u[k].in;
             const int sd = u.planar ? 1 : 2, Ud = li.D * sd, Uh = li.H * 2, Uw = li.W * 2, NPad = pad_cols(u.cout);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             const bool same = Ud == lo.D && Uh == lo.H && Uw == lo.W;
-            const bool lin = cfg.up_resize == 2 || cfg.up_resize == 4, k1 = cfg.up_resize >= 3;
-            RUN(launch_upsample_nearest(cur, cur_ldc, B.ups[k], u.cin, N, li.D, li.H, li.W, sd, s, lin));
-            const float* wsrc = P(u.p_w);
-            if (k1) { RUN(launch_embed_center_tap(P(u.p_w), B.wemb, (size_t)u.cout * u.cin, u.planar ? 9 : 27, s)); wsrc = B.wemb; }
-            RUN(launch_pack_conv_auto(kind, 0, wsrc, B.wpack, u.cout, u.cin, N, Ud, Uh, Uw, 0, s));
+            RUN(launch_upsample_nearest(cur, cur_ldc, B.ups[k], u.cin, N, li.D, li.H, li.W, sd, s, cfg.up_resize == 2));
+            RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, Ud, Uh, Uw, 0, s));
             ConvArgs a{};
             a.x = B.ups[k]; a.x_ldc = u.cin; a.Cin = u.cin; a.wt = B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
             a.y = same ? b.raw : B.rtmp; a.y_ldc = u.cout; a.N = N; a.D = Ud; a.H = Uh; a.W = Uw; a.sd = 2;
@@ -740,7 +758,24 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             RUN(launch_pad_box(dxr, B.rpad, u.cout, N, lo.D, lo.H, lo.W, ci.D, ci.H, ci.W, s, ND.u[k].od, ND.u[k].oh, ND.u[k].ow));
             dyu = B.rpad;
         }
-        if (u.is_up == 2) {
+        if (u.is_up == 2 && cfg.up_resize >= 3) {
+            // backward of (1x1x1 conv at low resolution -> up-sampling -> crop): pad, transpose of the up-sampling, then the conv's gradients
+            const LevelDims& li = ND.u[k].in;
+            const int sd = u.planar ? 1 : 2, Ud = li.D * sd, Uh = li.H * 2, Uw = li.W * 2;
+            if (!(Ud == lo.D && Uh == lo.H && Uw == lo.W)) {
+                RUN(launch_pad_box(dxr, B.rpad, u.cout, N, lo.D, lo.H, lo.W, Ud, Uh, Uw, s));
+                dyu = B.rpad;
+            }
+            RUN(launch_downsample_sum(dyu, B.rdu, u.cout, u.cout, N, li.D, li.H, li.W, sd, s, cfg.up_resize == 4));
+            dyu = B.rdu;             // gradient of the low-resolution conv output [N, li, Cout]
+            WgradArgs a{};
+            a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dyu; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = B.slab;
+            a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
+            a.splits = wgrad_splits(CONV_K3_PLANAR, N, li.D, li.H, li.W, u.cin, u.cout);
+            { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(CONV_K3_PLANAR, a, s)); }
+            RUN(launch_wgrad_reduce(B.slab, B.gemb, a.splits, 9, a.CoPad, a.CiPad, u.cout, u.cin, s));
+            RUN(launch_extract_center_tap(B.gemb, G(u.p_w), (size_t)u.cout * u.cin, 9, s));
+        } else if (u.is_up == 2) {
             const LevelDims& li = ND.u[k].in;
             const int Ud = li.D * (u.planar ? 1 : 2), Uh = li.H * 2, Uw = li.W * 2, taps = u.planar ? 9 : 27;
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
@@ -753,10 +788,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             a.N = N; a.D = Ud; a.H = Uh; a.W = Uw; a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
             a.splits = wgrad_splits(kind, N, Ud, Uh, Uw, u.cin, u.cout);
             { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(kind, a, s)); }
-            if (cfg.up_resize >= 3) {      // kernel_size = 1: only the centre tap of the 27-tap gradient is the parameter's
-                RUN(launch_wgrad_reduce(B.slab, B.gemb, a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
-                RUN(launch_extract_center_tap(B.gemb, G(u.p_w), (size_t)u.cout * u.cin, taps, s));
-            } else RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
+            RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
         } else if (u.is_up) {
             const LevelDims& li = ND.u[k].in;
             const int sd = u.planar ? 1 : 2;
@@ -784,20 +816,30 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         }
         // -- data gradient -> g for the previous unit
         if (k == 0 && !dx) break;
-        if (u.is_up == 2) {      // conv dgrad on the up-sampled grid, then the sum over each (sd x 2 x 2) block = backward of nn.Upsample(nearest)
+        if (u.is_up == 2 && cfg.up_resize >= 3) {      // dgrad of the low-resolution 1x1x1 conv: directly the gradient of the previous unit's output
+            const LevelDims& li = ND.u[k].in;
+            const int NPad = pad_cols(u.cin);
+            RUN(launch_embed_center_tap(P(u.p_w), B.wemb, (size_t)u.cout * u.cin, 9, s));
+            RUN(launch_pack_conv_auto(CONV_K3_PLANAR, 1, B.wemb, B.wpack, u.cout, u.cin, N, li.D, li.H, li.W, 0, s));
+            ConvArgs a{};
+            a.x = dyu; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = B.wpack; a.y = B.g1[j + 1]; a.y_ldc = u.cin;
+            a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.sd = 2;
+            a.Cout = u.cin; a.Ncols = u.cin; a.NPad = NPad; a.G = 1;
+            a.flags = (bucket_event != nullptr && event_done) ? CF_NO_PERSIST : 0;
+            { Prof pr(plan, s, k, 1); RUN(launch_conv_mfma(CONV_K3_PLANAR, a, s)); }
+            g = B.g1[j + 1]; g_ldc = u.cin;
+        } else if (u.is_up == 2) {      // conv dgrad on the up-sampled grid, then the sum over each (sd x 2 x 2) block = backward of nn.Upsample(nearest)
             const LevelDims& li = ND.u[k].in;
             const int sd = u.planar ? 1 : 2, Ud = li.D * sd, Uh = li.H * 2, Uw = li.W * 2, NPad = pad_cols(u.cin);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
-            const float* wsrc = P(u.p_w);
-            if (cfg.up_resize >= 3) { RUN(launch_embed_center_tap(P(u.p_w), B.wemb, (size_t)u.cout * u.cin, u.planar ? 9 : 27, s)); wsrc = B.wemb; }
-            RUN(launch_pack_conv_auto(kind, 1, wsrc, B.wpack, u.cout, u.cin, N, Ud, Uh, Uw, 0, s));
+            RUN(launch_pack_conv_auto(kind, 1, P(u.p_w), B.wpack, u.cout, u.cin, N, Ud, Uh, Uw, 0, s));
             ConvArgs a{};
             a.x = dyu; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = B.wpack; a.y = B.rdu; a.y_ldc = u.cin;
             a.N = N; a.D = Ud; a.H = Uh; a.W = Uw; a.sd = 2;
             a.Cout = u.cin; a.Ncols = u.cin; a.NPad = NPad; a.G = 1;
             a.flags = (bucket_event != nullptr && event_done) ? CF_NO_PERSIST : 0;
             { Prof pr(plan, s, k, 1); RUN(launch_conv_mfma(kind, a, s)); }
-            RUN(launch_downsample_sum(B.rdu, B.g1[j + 1], u.cin, u.cin, N, li.D, li.H, li.W, sd, s, cfg.up_resize == 2 || cfg.up_resize == 4));
+            RUN(launch_downsample_sum(B.rdu, B.g1[j + 1], u.cin, u.cin, N, li.D, li.H, li.W, sd, s, cfg.up_resize == 2));
             g = B.g1[j + 1]; g_ldc = u.cin;
         } else if (u.is_up) {
             const LevelDims& li = ND.u[k].in;
