@@ -23,6 +23,8 @@ def main():
     ap.add_argument('db')
     ap.add_argument('-o', '--out')
     ap.add_argument('--title', default='')
+    ap.add_argument('--by-position', default='', help='kernel-name substring: also list its dispatches by position within a step')
+    ap.add_argument('--steps', type=int, default=0, help='number of identical steps in the trace (for --by-position)')
     a = ap.parse_args()
     path = a.db
     if os.path.isdir(path):
@@ -39,6 +41,17 @@ def main():
     lines.append('|---|---|---|---|---|---|---|---|---|---|---|---|---|')
     for n, c, tot, avg, mn, mx, g, wg, lds, v, ag, sg in rows:
         lines.append(f'| `{short(n)}` | {c} | {tot / 1e6:.3f} | {avg / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | {100 * tot / total:.1f} | {g} | {wg} | {lds} | {v} | {ag} | {sg} |')
+    if a.by_position and a.steps:
+        # one kernel name serves many layers: split its dispatches by their position inside a step (every step launches the same
+        # sequence), so that a single layer's launch can be compared with the HIP-event timing bench.py reports for it
+        d = db.execute('select duration from kernels where name like ? order by start', (f'%{a.by_position}%',)).fetchall()
+        per = len(d) // a.steps
+        lines.append(f'\n`{a.by_position}` by position within a step ({len(d)} dispatches = {a.steps} steps x {per}):\n')
+        lines.append('| position | avg us | min us | max us |')
+        lines.append('|---|---|---|---|')
+        for i in range(per):
+            v = [d[k * per + i][0] / 1e3 for k in range(a.steps)]
+            lines.append(f'| {i} | {sum(v) / len(v):.1f} | {min(v):.1f} | {max(v):.1f} |')
     text = '\n'.join(lines) + '\n'
     if a.out:
         os.makedirs(os.path.dirname(a.out) or '.', exist_ok=True)
