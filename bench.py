@@ -131,7 +131,9 @@ def main():
 
     torch.manual_seed(0)                                   # identical replica on every rank
     model = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=32, normalization='batch').to(dev).train()
-    criterion = CombinedCEDiceLoss(weight=[0.2653, 0.7347]).to(dev)
+    # N > 1: ONE loss over the global minibatch, as the reference computes on the batch nn.DataParallel gathers (trainer.py:520-524):
+    # the ranks exchange the criterion's 2 + 3C sums (one all-reduce of 8 doubles) between forward and backward
+    criterion = CombinedCEDiceLoss(weight=[0.2653, 0.7347], global_batch=dist is not None).to(dev)
     sync = None
     if world > 1 or (dist is not None):
         from elektronn3_amd.dataparallel import GradSync

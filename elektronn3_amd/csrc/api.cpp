@@ -222,6 +222,20 @@ int e3_ce_dice_fwd(void* stream, const float* logits, const long long* target, c
     return launch_ce_dice_fwd(logits, target, w, C, N, (size_t)D * H * W, ce_weight, dice_weight, eps, smooth, (float*)workspace, loss_out, (hipStream_t)stream);
 }
 
+int e3_ce_dice_sums(void* stream, const float* logits, const long long* target, const float* w, int C, int N, int D, int H, int W,
+                    void* workspace, size_t workspace_bytes, double* sums) {
+    E3_REQUIRE(workspace_bytes >= e3_ce_dice_workspace_bytes(C), E3_ERR_WORKSPACE, "ce_dice workspace too small");
+    E3_REQUIRE(sums != nullptr, E3_ERR_INVALID, "ce_dice_sums: sums is NULL");
+    return launch_ce_dice_sums(logits, target, w, C, N, (size_t)D * H * W, (float*)workspace, sums, (hipStream_t)stream);
+}
+
+int e3_ce_dice_from_sums(void* stream, const double* sums, const float* w, int C, float ce_weight, float dice_weight, float eps, float smooth,
+                         void* workspace, size_t workspace_bytes, float* loss_out) {
+    E3_REQUIRE(workspace_bytes >= e3_ce_dice_workspace_bytes(C), E3_ERR_WORKSPACE, "ce_dice workspace too small");
+    E3_REQUIRE(sums != nullptr, E3_ERR_INVALID, "ce_dice_from_sums: sums is NULL");
+    return launch_ce_dice_from_sums(sums, w, C, ce_weight, dice_weight, eps, smooth, (float*)workspace, loss_out, (hipStream_t)stream);
+}
+
 int e3_ce_dice_bwd(void* stream, const float* logits, const long long* target, const float* w, int C, int N, int D, int H, int W,
                    const void* workspace, size_t workspace_bytes, const float* gout, float* dlogits) {
     E3_REQUIRE(workspace_bytes >= e3_ce_dice_workspace_bytes(C), E3_ERR_WORKSPACE, "ce_dice workspace too small");

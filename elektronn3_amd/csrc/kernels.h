@@ -116,6 +116,10 @@ int launch_conv_final_bwd(const float* a, int a_ldc, int C, const float* w, cons
 size_t ce_dice_workspace_floats(int C);
 int launch_ce_dice_fwd(const float* logits, const long long* target, const float* w, int C, int N, size_t vps, float a, float b,
                        float eps, float smooth, float* workspace, float* loss_out, hipStream_t s);
+int launch_ce_dice_sums(const float* logits, const long long* target, const float* w, int C, int N, size_t vps, float* workspace,
+                        double* sums, hipStream_t s);
+int launch_ce_dice_from_sums(const double* sums, const float* w, int C, float a, float b, float eps, float smooth, float* workspace,
+                             float* loss_out, hipStream_t s);
 int launch_ce_dice_bwd(const float* logits, const long long* target, const float* w, int C, int N, size_t vps,
                        const float* workspace, const float* gout, float* dlogits, hipStream_t s);
 

@@ -73,37 +73,56 @@ __global__ __launch_bounds__(256) void ce_dice_fwd_kernel(const float* __restric
     if (threadIdx.x < NV) partial[(size_t)blockIdx.x * NV + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// Sums over the block partials (fixed order, fp64): one wave per value (16 waves take the NV <= 26 values in turn), 64 lanes stride
+// over the blocks, fp64 butterfly.
+__device__ __forceinline__ void ce_dice_reduce(const float* __restrict__ partial, int blocks, int NV, double* s) {
+    const int lane = threadIdx.x & 63;
+    for (int v = threadIdx.x >> 6; v < NV; v += (int)(blockDim.x >> 6)) {
+        double t = 0.0;
+        for (int k = lane; k < blocks; k += 64) t += (double)partial[(size_t)k * NV + v];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (lane == 0) s[v] = t;
+    }
+}
+
 // out[0] = loss; coef: [0] = a / Ws, [1 + k] = (b/C) w_k num_k / den_k^2, [1 + C + k] = (b/C) w_k 2 / den_k
+__device__ __forceinline__ void ce_dice_coefs(const double* s, int C, const float* __restrict__ w, float a, float b, float eps, float smooth,
+                                              float* __restrict__ out, float* __restrict__ coef) {
+    const double ce = s[1] > 0.0 ? s[0] / s[1] : 0.0;
+    double dice = 0.0;
+    for (int k = 0; k < C; ++k) {
+        const double wk = w ? (double)w[k] : 1.0;
+        const double num = 2.0 * s[2 + k] + smooth, den = s[2 + C + k] + s[2 + 2 * C + k] + smooth + eps;
+        dice += wk * (1.0 - num / den);
+        coef[1 + k] = (float)((double)b / C * wk * num / (den * den));
+        coef[1 + C + k] = (float)((double)b / C * wk * 2.0 / den);
+    }
+    dice /= C;
+    out[0] = (float)((double)a * ce + (double)b * dice);
+    coef[0] = s[1] > 0.0 ? (float)((double)a / s[1]) : 0.f;
+}
+
 __global__ void ce_dice_finalize_kernel(const float* __restrict__ partial, int blocks, int C, const float* __restrict__ w,
                                         float a, float b, float eps, float smooth, float* __restrict__ out, float* __restrict__ coef) {
     __shared__ double s[2 + 3 * LOSS_MAXC];
-    const int NV = 2 + 3 * C;
-    // one wave per value (16 waves take the NV <= 26 values in turn): 64 lanes stride over the block partials, fp64 butterfly
-    {
-        const int lane = threadIdx.x & 63;
-        for (int v = threadIdx.x >> 6; v < NV; v += (int)(blockDim.x >> 6)) {
-            double t = 0.0;
-            for (int k = lane; k < blocks; k += 64) t += (double)partial[(size_t)k * NV + v];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-            if (lane == 0) s[v] = t;
-        }
-    }
+    ce_dice_reduce(partial, blocks, 2 + 3 * C, s);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const double ce = s[1] > 0.0 ? s[0] / s[1] : 0.0;
-        double dice = 0.0;
-        for (int k = 0; k < C; ++k) {
-            const double wk = w ? (double)w[k] : 1.0;
-            const double num = 2.0 * s[2 + k] + smooth, den = s[2 + C + k] + s[2 + 2 * C + k] + smooth + eps;
-            dice += wk * (1.0 - num / den);
-            coef[1 + k] = (float)((double)b / C * wk * num / (den * den));
-            coef[1 + C + k] = (float)((double)b / C * wk * 2.0 / den);
-        }
-        dice /= C;
-        out[0] = (float)((double)a * ce + (double)b * dice);
-        coef[0] = s[1] > 0.0 ? (float)((double)a / s[1]) : 0.f;
-    }
+    if (threadIdx.x == 0) ce_dice_coefs(s, C, w, a, b, eps, smooth, out, coef);
+}
+
+// The two halves of the finaliser as separate launches, for a criterion over a minibatch that is sharded over ranks: the 2 + 3C sums
+// are what the ranks exchange (one all-reduce of <= 26 doubles) between them.
+__global__ void ce_dice_sums_kernel(const float* __restrict__ partial, int blocks, int C, double* __restrict__ sums) {
+    __shared__ double s[2 + 3 * LOSS_MAXC];
+    ce_dice_reduce(partial, blocks, 2 + 3 * C, s);
+    __syncthreads();
+    if ((int)threadIdx.x < 2 + 3 * C) sums[threadIdx.x] = s[threadIdx.x];
+}
+
+__global__ void ce_dice_from_sums_kernel(const double* __restrict__ sums, int C, const float* __restrict__ w,
+                                         float a, float b, float eps, float smooth, float* __restrict__ out, float* __restrict__ coef) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ce_dice_coefs(sums, C, w, a, b, eps, smooth, out, coef);
 }
 
 template <int C>
@@ -158,6 +177,24 @@ int launch_ce_dice_fwd(const float* logits, const long long* target, const float
     float* coef = workspace + (size_t)LOSS_BLOCKS * (2 + 3 * C);
     LOSS_DISPATCH(ce_dice_fwd_kernel, logits, target, w, N, vps, partial)
     hipLaunchKernelGGL(ce_dice_finalize_kernel, dim3(1), dim3(1024), 0, s, partial, LOSS_BLOCKS, C, w, a, b, eps, smooth, loss_out, coef);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_ce_dice_sums(const float* logits, const long long* target, const float* w, int C, int N, size_t vps, float* workspace,
+                        double* sums, hipStream_t s) {
+    float* partial = workspace;
+    LOSS_DISPATCH(ce_dice_fwd_kernel, logits, target, w, N, vps, partial)
+    hipLaunchKernelGGL(ce_dice_sums_kernel, dim3(1), dim3(1024), 0, s, partial, LOSS_BLOCKS, C, sums);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_ce_dice_from_sums(const double* sums, const float* w, int C, float a, float b, float eps, float smooth, float* workspace,
+                             float* loss_out, hipStream_t s) {
+    if (C < 2 || C > LOSS_MAXC) { e3_set_error("ce_dice: 2 <= C <= 8 classes supported"); return E3_ERR_UNSUPPORTED; }
+    float* coef = workspace + (size_t)LOSS_BLOCKS * (2 + 3 * C);
+    hipLaunchKernelGGL(ce_dice_from_sums_kernel, dim3(1), dim3(64), 0, s, sums, C, w, a, b, eps, smooth, loss_out, coef);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

@@ -199,6 +199,16 @@ int e3_conv1_bwd(void* stream, const float* a, int a_ldc, int C, const float* w,
 size_t e3_ce_dice_workspace_bytes(int C);
 int e3_ce_dice_fwd(void* stream, const float* logits, const long long* target, const float* w, int C, int N, int D, int H, int W,
                    float ce_weight, float dice_weight, float eps, float smooth, void* workspace, size_t workspace_bytes, float* loss_out);
+/* The same criterion over a minibatch that is sharded over ranks (the reference computes ONE loss over the batch that
+ * nn.DataParallel gathers on GPU 0, training/trainer.py:520-524; weighted CE and Dice are ratios of batch-wide sums, modules/loss.py:181-186,
+ * so per-rank losses do not average to it).  e3_ce_dice_sums writes this rank's 2 + 3C sums (fp64, device):
+ *   [0] sum_v w[t_v] (-log p[t_v]), [1] sum_v w[t_v], [2 + c] sum p_c [t = c], [2 + C + c] sum p_c, [2 + 2C + c] sum [t = c];
+ * the caller adds them over ranks (one all-reduce) and e3_ce_dice_from_sums turns the totals into the loss and the backward's
+ * coefficients in `workspace`; e3_ce_dice_bwd then gives d(global loss)/d(local logits). */
+int e3_ce_dice_sums(void* stream, const float* logits, const long long* target, const float* w, int C, int N, int D, int H, int W,
+                    void* workspace, size_t workspace_bytes, double* sums);
+int e3_ce_dice_from_sums(void* stream, const double* sums, const float* w, int C, float ce_weight, float dice_weight, float eps, float smooth,
+                         void* workspace, size_t workspace_bytes, float* loss_out);
 int e3_ce_dice_bwd(void* stream, const float* logits, const long long* target, const float* w, int C, int N, int D, int H, int W,
                    const void* workspace, size_t workspace_bytes, const float* gout, float* dlogits);
 

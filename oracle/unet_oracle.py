@@ -232,6 +232,38 @@ def adamw_step(p, g, m, v, t, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_deca
                          ctypes.c_double(betas[1]), ctypes.c_double(eps), ctypes.c_double(weight_decay))
 
 
+def ce_dice_sums(logits, target, w=None):
+    """The 2 + 3C batch sums the example's criterion is a function of (modules/loss.py:158-189 dice_loss: intersection / denominator
+    summed over batch and space; F.cross_entropy(weight): sum of w[t] * nll over sum of w[t]), in fp64:
+    [0] sum w[t](-log p[t]), [1] sum w[t], [2+c] sum p_c[t=c], [2+C+c] sum p_c, [2+2C+c] sum [t=c].  logits (N,C,*sp), target (N,*sp)."""
+    z = np.asarray(logits, np.float64)
+    t = np.asarray(target)
+    C = z.shape[1]
+    w = np.ones(C) if w is None else np.asarray(w, np.float64)
+    m = z.max(1, keepdims=True)
+    lse = m + np.log(np.exp(z - m).sum(1, keepdims=True))
+    p = np.exp(z - lse)
+    onehot = (t[:, None] == np.arange(C).reshape((1, C) + (1,) * (z.ndim - 2)))
+    ax = (0,) + tuple(range(2, z.ndim))
+    s = np.zeros(2 + 3 * C)
+    s[0] = (w[t] * -(np.log(p) * onehot).sum(1)).sum()
+    s[1] = w[t].sum()
+    s[2:2 + C] = (p * onehot).sum(ax)
+    s[2 + C:2 + 2 * C] = p.sum(ax)
+    s[2 + 2 * C:] = onehot.sum(ax)
+    return s
+
+
+def ce_dice_from_sums(s, w=None, ce_weight=0.5, dice_weight=0.5, eps=1e-4, smooth=0.0):
+    """CombinedLoss([CrossEntropyLoss(w), DiceLoss(softmax, w)], (a, b)) (modules/loss.py:19-49,192-234) from the batch sums."""
+    C = (len(s) - 2) // 3
+    w = np.ones(C) if w is None else np.asarray(w, np.float64)
+    ce = s[0] / s[1] if s[1] > 0 else 0.0
+    num = 2 * s[2:2 + C] + smooth
+    den = s[2 + C:2 + 2 * C] + s[2 + 2 * C:] + smooth + eps
+    return ce_weight * ce + dice_weight * float((w * (1 - num / den)).mean())
+
+
 def autocrop(from_down, from_up):
     """unet.py:256-325 -- crop decoder output by 1 where (u-d) is odd, centre-crop encoder output."""
     if from_down.shape[2:] == from_up.shape[2:]:

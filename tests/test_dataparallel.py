@@ -71,6 +71,24 @@ def _worker(rank, world, port, tmp):
         y_one = Predictor(conv, tile_parallel=False, **kw).predict(vol)
         if rank == 0:
             assert torch.allclose(y_par, y_one, atol=1e-6)
+        # the criterion over a sharded minibatch: per-rank sums + ONE all-reduce = the loss of the gathered batch
+        # (what the reference computes on GPU 0), which the mean of the per-rank losses is not
+        import oracle.unet_oracle as O
+        from oracle.torch_ref import combined_loss
+        gen = torch.Generator().manual_seed(3)
+        logits = torch.randn(4, 2, 3, 5, 6, generator=gen, dtype=torch.float64) * 2
+        target = (torch.rand(4, 3, 5, 6, generator=gen) < torch.tensor([0.1, 0.3, 0.6, 0.9]).view(4, 1, 1, 1)).long()   # unbalanced shards
+        logits[:2, 1] += 3 * target[:2]                      # shard 0 predicts well, shard 1 does not
+        cw = (0.2653, 0.7347)
+        sums = torch.from_numpy(O.ce_dice_sums(shard_batch(logits, rank, world).numpy(), shard_batch(target, rank, world).numpy(), cw))
+        local = O.ce_dice_from_sums(sums.numpy(), cw)
+        dist.all_reduce(sums)
+        glob = O.ce_dice_from_sums(sums.numpy(), cw)
+        want = float(combined_loss(logits, target, cw))
+        assert abs(glob - want) < 1e-12, (glob, want)
+        locs = [None] * world
+        dist.all_gather_object(locs, local)
+        assert abs(sum(locs) / world - want) > 1e-4           # the difference the sharded mode removes
         open(os.path.join(tmp, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()

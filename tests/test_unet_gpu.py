@@ -541,6 +541,62 @@ def test_ce_dice_loss_matches_reference_criterion(C, shape, weighted):
     assert float(loss2) == float(loss)
 
 
+@pytest.mark.gpu
+def test_ce_dice_loss_over_sharded_minibatch_equals_gathered_batch():
+    """CombinedCEDiceLoss(global_batch=True): two 'ranks' each hold half of the minibatch; with their 2+3C sums added
+    (the all-reduce, emulated in-process) both return the loss of the GATHERED batch -- what the reference computes on GPU 0 behind
+    nn.DataParallel (training/trainer.py:520-524) -- and their logit gradients, scaled back by the world size the mode pre-multiplies
+    for gradient AVERAGING, concatenate to the gradient of that loss.  Checked against the unsharded HIP criterion, the fp64 oracle sums
+    (oracle/unet_oracle.ce_dice_sums) and PyTorch autograd in fp64."""
+    import oracle.unet_oracle as O
+    from oracle.torch_ref import combined_loss
+    from elektronn3_amd.loss import CombinedCEDiceLoss
+    from elektronn3_amd import _lib
+    from elektronn3_amd._lib import c_size_t, check, ptr, stream_ptr
+    rng = np.random.default_rng(11)
+    C, shape, world = 3, (4, 5, 9, 11), 2
+    z = (rng.standard_normal((shape[0], C) + shape[1:]) * 2).astype(np.float32)
+    t = (rng.random(shape) < np.array([0.1, 0.3, 0.6, 0.9]).reshape(4, 1, 1, 1)).astype(np.int64) * 2      # unbalanced shards
+    z[:2, 2] += 3 * (t[:2] == 2)
+    w = np.array([0.2, 0.5, 0.3], np.float32)
+    zs = [torch.from_numpy(z[r * 2:(r + 1) * 2]).cuda().requires_grad_(True) for r in range(world)]
+    ts = [torch.from_numpy(t[r * 2:(r + 1) * 2]).cuda() for r in range(world)]
+    # each rank's sums through the C ABI; their total = the all-reduce
+    L = _lib.load()
+    nbytes = L.e3_ce_dice_workspace_bytes(C)
+    wt = torch.from_numpy(w).cuda()
+    local = []
+    for zr, tr in zip(zs, ts):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda'); sm = torch.empty(2 + 3 * C, dtype=torch.float64, device='cuda')
+        check(L.e3_ce_dice_sums(stream_ptr(zr.device), ptr(zr.detach()), ptr(tr), ptr(wt), C, 2, *shape[1:], ptr(ws), c_size_t(nbytes), ptr(sm)))
+        want = O.ce_dice_sums(zr.detach().cpu().numpy(), tr.cpu().numpy(), w)
+        assert np.abs(sm.cpu().numpy() - want).max() < 3e-6 * np.abs(want).max()
+        local.append(sm)
+    total = local[0] + local[1]
+
+    class Sharded(CombinedCEDiceLoss):
+        def _world(self): return world
+        def _reduce_sums(self, sums): return total.clone()
+
+    crit = Sharded(weight=w, global_batch=True).cuda()
+    losses = [crit(zr, tr) for zr, tr in zip(zs, ts)]
+    for l in losses: (l * 1.3).backward()
+    # unsharded HIP criterion and fp64 autograd on the gathered batch
+    zf = torch.from_numpy(z).cuda().requires_grad_(True)
+    lf = CombinedCEDiceLoss(weight=w).cuda()(zf, torch.from_numpy(t).cuda()); (lf * 1.3).backward()
+    zd = torch.from_numpy(z).double().requires_grad_(True)
+    ld = combined_loss(zd, torch.from_numpy(t), tuple(float(v) for v in w)); (ld * 1.3).backward()
+    assert float(losses[0]) == float(losses[1])
+    assert abs(float(losses[0]) - float(ld)) < 2e-6 and abs(float(lf) - float(ld)) < 2e-6
+    g = torch.cat([zr.grad for zr in zs]).cpu().numpy() / world
+    gd = zd.grad.numpy()
+    assert np.abs(g - gd).max() < 2e-6 * np.abs(gd).max() + 1e-10
+    assert np.abs(g - zf.grad.cpu().numpy()).max() < 1e-6 * np.abs(gd).max() + 1e-10
+    # the mean of per-shard losses is something else
+    per = [float(CombinedCEDiceLoss(weight=w).cuda()(zr.detach(), tr)) for zr, tr in zip(zs, ts)]
+    assert abs(sum(per) / world - float(ld)) > 1e-4
+
+
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
 def test_low_precision_module_trains_with_fp32_compute(dt):
     """model.bfloat16() / model.half() (BASELINE configs[2] stores the model in bf16; Predictor(float16=True)): parameters, input and
