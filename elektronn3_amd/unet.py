@@ -205,7 +205,10 @@ def _activation_slope(activation):
     (nn.LeakyReLU(negative_slope=0.1)), 'lin' 1 (nn.Identity); module instances of those types are accepted like the reference does
     (it deep-copies them).  None = not on the HIP path."""
     if isinstance(activation, str):
-        return {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0, 'prelu': 3.0}.get(activation)     # (2.0 = ACT_SILU, 3.0 = ACT_PRELU in csrc/common.h)
+        return {'relu': 0.0, 'leaky': 0.1, 'lin': 1.0, 'silu': 2.0, 'prelu': 3.0,     # (2.0 = ACT_SILU, 3.0 = ACT_PRELU in csrc/common.h)
+                'rrelu': (1.0 / 8 + 1.0 / 3) / 2}.get(activation)                     # nn.RReLU() in eval mode: slope (lower + upper) / 2
+    if isinstance(activation, nn.RReLU):
+        return (float(activation.lower) + float(activation.upper)) / 2 if 0.0 <= activation.lower <= activation.upper <= 1.0 else None
     if isinstance(activation, nn.LeakyReLU):
         return float(activation.negative_slope) if 0.0 <= activation.negative_slope <= 1.0 else None
     if isinstance(activation, nn.ReLU):
@@ -222,7 +225,7 @@ def _activation_slope(activation):
 def _make_activation(activation):
     if isinstance(activation, str):
         return {'relu': nn.ReLU, 'leaky': lambda: nn.LeakyReLU(negative_slope=0.1), 'lin': nn.Identity, 'silu': nn.SiLU,
-                'prelu': lambda: nn.PReLU(num_parameters=1)}[activation]()
+                'prelu': lambda: nn.PReLU(num_parameters=1), 'rrelu': nn.RReLU}[activation]()
     import copy
     return copy.deepcopy(activation)
 
@@ -334,8 +337,9 @@ class UNet(nn.Module):
     """3D U-Net with the reference's interface (elektronn3/models/unet.py:755-771), executed by hand-written HIP
     kernels.  Options of the reference that are not yet on the HIP path raise ``NotImplementedError`` at
     construction: ``up_mode='upsample'``,
-    ``attention=True``, ``activation='rrelu'`` (random slopes),
-    ``conv_mode`` other than ``'same'`` / ``'valid'``.  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
+    ``attention=True``,
+    ``conv_mode`` other than ``'same'`` / ``'valid'``.  ``activation='rrelu'`` runs in eval mode only (the fixed slope (1/8 + 1/3)/2 of
+    ``nn.RReLU``; a train-mode forward, which draws a random slope per element, raises ``NotImplementedError``).  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
     the 3D one with every block planar and a depth of 1."""
 
     def __init__(
@@ -527,6 +531,8 @@ class UNet(nn.Module):
             raise ValueError(f'expected {self.in_channels} input channels, got {x.shape[1]}')
         if not x.is_cuda:
             raise RuntimeError('elektronn3_amd.UNet runs only on a ROCm GPU (hand-written HIP kernels); there is no CPU fallback')
+        if self.training and (self.activation == 'rrelu' or isinstance(self.activation, nn.RReLU)):
+            raise NotImplementedError("activation='rrelu' in train mode (a random slope per element) is not on the HIP path; eval mode is")
         plan = self._plan()
         params = [p for _, p in self._named_table_params(plan)]
         if any(p.device != x.device for p in params):

@@ -155,6 +155,33 @@ def criterion(loss_mod):
                                   loss_mod.DiceLoss(apply_softmax=True, weight=cw)], weight=[0.5, 0.5])
 
 
+def make_rrelu_eval(unet, out, seed=17):
+    """activation='rrelu' in EVAL mode (nn.RReLU(): the fixed slope (1/8 + 1/3)/2; train mode draws random slopes and cannot be pinned):
+    eval-mode logits of the reference with non-trivial running statistics."""
+    torch.manual_seed(seed)
+    model = unet.UNet(in_channels=1, out_channels=2, n_blocks=3, start_filts=8, planar_blocks=(0,), activation='rrelu')
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if 'norm' in name and name.endswith('weight'):
+                p.copy_(1.0 + 0.2 * torch.randn_like(p))
+            elif name.endswith('bias'):
+                p.copy_(0.1 * torch.randn_like(p))
+        for name, b in model.named_buffers():
+            if name.endswith('running_mean'):
+                b.copy_(0.3 * torch.randn_like(b))
+            elif name.endswith('running_var'):
+                b.copy_(0.5 + torch.rand_like(b))
+    x = torch.randn(2, 1, 9, 14, 19)
+    model.eval()
+    with torch.no_grad():
+        y = model(x)
+    d = {'cfg.n_blocks': 3, 'cfg.start_filts': 8, 'cfg.planar_blocks': np.array((0,), dtype=np.int64), 'cfg.activation': np.array('rrelu'),
+         'x': npy(x), 'logits_eval': npy(y)}
+    for k, v in model.state_dict().items():
+        d['sd0/' + k] = npy(v).copy()
+    np.savez_compressed(out, **d)
+
+
 def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu', up_mode='transpose', conv_mode='same'):
     torch.manual_seed(seed)
     model = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
@@ -313,6 +340,9 @@ if __name__ == '__main__':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_leaky_odd.npz', seed=9, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(10, 13, 19), batch=2, activation='leaky')
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_lin_nonorm.npz', seed=10, n_blocks=2, start_filts=8, planar_blocks=(), shape=(6, 10, 12), batch=2, activation='lin', normalization='none')
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'rrelu':
+        make_rrelu_eval(unet, f'{HERE}/unet_nb3_sf8_rrelu_eval.npz')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'resize':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizeconv_odd.npz', seed=12, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 19), batch=2, up_mode='resizeconv_nearest')
         sys.exit(0)
@@ -373,6 +403,7 @@ if __name__ == '__main__':
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_prelu_odd.npz', seed=15, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 15, 19), batch=2, activation='prelu', full_norm=False)
     # conv_mode='valid' (padding 0: shrinking grids, centre-cropped skips), planar first block, odd sizes
     make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_valid.npz', seed=16, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(21, 45, 47), batch=2, conv_mode='valid')
+    make_rrelu_eval(unet, f'{HERE}/unet_nb3_sf8_rrelu_eval.npz')
     make_predictor(unet, inference, f'{HERE}/predictor.npz')
     make_adamw(f'{HERE}/adamw.npz')
     make_trainsteps(unet, loss_mod, f'{HERE}/trainsteps.npz')

@@ -132,6 +132,16 @@ def test_unet_eval_forward():
     np.testing.assert_allclose(net.forward(g['x']), g['logits_eval'], rtol=1e-4, atol=1e-5)
 
 
+def test_unet_eval_forward_rrelu():
+    """activation='rrelu' in eval mode: nn.RReLU's fixed slope (lower + upper) / 2 = (1/8 + 1/3) / 2 (get_activation, unet.py:183-199)."""
+    g = load_npz('unet_nb3_sf8_rrelu_eval.npz')
+    cfg = unet_cfg(g)
+    net = orc.OracleUNet(sub(g, 'sd0'), cfg['n_blocks'], cfg['planar_blocks'])
+    net.act_slope = (1.0 / 8 + 1.0 / 3) / 2
+    net.training = False
+    np.testing.assert_allclose(net.forward(g['x']), g['logits_eval'], rtol=1e-4, atol=1e-5)
+
+
 def test_predictor_tiled():
     g = load_npz('predictor.npz')
     net = orc.OracleUNet(sub(g, 'sd'), 2)

@@ -105,6 +105,17 @@ def test_eval_forward_matches_reference():
     np.testing.assert_allclose(y.cpu().numpy(), g['logits_eval'], rtol=1e-4, atol=1e-5)
 
 
+def test_rrelu_eval_forward_matches_reference_and_train_mode_fails_loudly():
+    g = load_npz('unet_nb3_sf8_rrelu_eval.npz')
+    m = build(unet_cfg(g), sub(g, 'sd0')).eval()
+    x = torch.from_numpy(g['x']).cuda()
+    with torch.no_grad():
+        y = m(x)
+    np.testing.assert_allclose(y.cpu().numpy(), g['logits_eval'], rtol=1e-4, atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        m.train()(x)
+
+
 def test_three_adamw_steps_match_reference_trajectory():
     """Trainer._train_step (trainer.py:509-543) with the example's optimizer/criterion: 3 steps, loss trajectory and
     final weights against the reference run (tests/golden/trainsteps.npz)."""
