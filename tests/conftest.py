@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
+# Several GPU tests run the reference's op sequence with PyTorch-ROCm (MIOpen) as a second opinion.  MIOpen's default exhaustive
+# kernel search costs minutes on a fresh box (no find-db persists); the fast mode keeps the whole -m gpu suite under a minute.
+# (libe3unet itself never calls MIOpen.)
+os.environ.setdefault('MIOPEN_FIND_MODE', '2')
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: test needs a real MI355X (run with -m gpu on the GPU box)')
