@@ -243,6 +243,16 @@ int e3_ce_dice_bwd(void* stream, const float* logits, const long long* target, c
 }
 
 // ---------------------------------------------------------------------------------------------- optimizer
+int e3_swa_update(void* stream, int n_tensors, void* const* params, void* const* swa_buffers, const long long* numels, long long n_avg) {
+    E3_REQUIRE(n_tensors >= 0 && n_avg >= 0 && (n_tensors == 0 || (params && swa_buffers && numels)), E3_ERR_INVALID, "swa_update: bad arguments");
+    return launch_swa(n_tensors, params, swa_buffers, numels, 1.0 / (double)(n_avg + 1), 0, (hipStream_t)stream);
+}
+
+int e3_swa_swap(void* stream, int n_tensors, void* const* params, void* const* swa_buffers, const long long* numels) {
+    E3_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (params && swa_buffers && numels)), E3_ERR_INVALID, "swa_swap: bad arguments");
+    return launch_swa(n_tensors, params, swa_buffers, numels, 0.0, 1, (hipStream_t)stream);
+}
+
 size_t e3_adamw_state_floats(int n_tensors, const long long* numels) {
     return (n_tensors > 0 && numels) ? adamw_state_floats(n_tensors, numels) : 0;
 }

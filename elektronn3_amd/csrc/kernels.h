@@ -150,6 +150,7 @@ int launch_add_views(const float* a, int a_ldc, const float* b, int b_ldc, float
 int launch_bias_fold(const float* conv_bias, float* scale, float* shift, int C, hipStream_t s);   // scale = 1, shift = bias
 
 // ---------------------------------------------------------------- optimizer (optim.hip)
+int launch_swa(int n_tensors, void* const* params, void* const* bufs, const long long* numels, double decay, int swap, hipStream_t s);
 size_t adamw_state_floats(int n_tensors, const long long* numels);
 size_t adamw_state_offset(int n_tensors, const long long* numels, int tensor);
 int launch_adamw(int n_tensors, void* const* params, void* const* grads, const long long* numels, float* exp_avg, float* exp_avg_sq,

@@ -89,7 +89,58 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamWArgs a) {
     }
 }
 
+// Stochastic weight averaging over all parameter tensors in one launch: the running average the reference's SWA wrapper keeps per
+// parameter (training/swa.py:145-176 update_swa_group: buf += (p - buf) * (1 / (n_avg + 1)), two rounded fp32 operations -- kept
+// un-fused here so that the averages are bit-identical) and the exchange of parameters and averages (swa.py:184-202 swap_swa_sgd).
+struct SwaArgs {
+    float* p[OPT_MAX_T];
+    float* b[OPT_MAX_T];
+    int cstart[OPT_MAX_T + 1];
+    int numel[OPT_MAX_T];
+    int nt;
+    float decay;                          // 1 / (n_avg + 1)
+    int swap;                             // 0: update the average, 1: exchange p and buf
+};
+
+__global__ __launch_bounds__(256) void swa_kernel(const SwaArgs a) {
+#pragma clang fp contract(off)            // (hipcc contracts a*b+c into an fma by default, also through __fmul_rn/__fadd_rn)
+    const int b = blockIdx.x;
+    int lo = 0, hi = a.nt;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.cstart[mid] <= b) lo = mid; else hi = mid; }
+    const int t = lo, n = a.numel[t];
+    float* __restrict__ p = a.p[t];
+    float* __restrict__ buf = a.b[t];
+    const int e0 = (b - a.cstart[t]) * OPT_CHUNK + 4 * (int)threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = e0 + e;
+        if (i >= n) break;
+        const float pv = p[i], bv = buf[i];
+        if (a.swap) { p[i] = bv; buf[i] = pv; }
+        else { const float diff = (pv - bv) * a.decay; buf[i] = bv + diff; }
+    }
+}
+
 }  // namespace
+
+int launch_swa(int n_tensors, void* const* params, void* const* bufs, const long long* numels, double decay, int swap, hipStream_t s) {
+    for (int t0 = 0; t0 < n_tensors; t0 += OPT_MAX_T) {
+        SwaArgs a;
+        a.nt = n_tensors - t0 < OPT_MAX_T ? n_tensors - t0 : OPT_MAX_T;
+        int c = 0;
+        for (int t = 0; t < a.nt; ++t) {
+            E3_REQUIRE(numels[t0 + t] >= 0 && numels[t0 + t] < (1ll << 31), E3_ERR_UNSUPPORTED, "parameter tensor too large");
+            E3_REQUIRE(params[t0 + t] && bufs[t0 + t], E3_ERR_INVALID, "swa: NULL tensor pointer");
+            a.p[t] = (float*)params[t0 + t]; a.b[t] = (float*)bufs[t0 + t];
+            a.cstart[t] = c; a.numel[t] = (int)numels[t0 + t];
+            c += (int)((numels[t0 + t] + OPT_CHUNK - 1) / OPT_CHUNK);
+        }
+        a.cstart[a.nt] = c; a.decay = (float)decay; a.swap = swap;
+        if (c > 0) hipLaunchKernelGGL(swa_kernel, dim3(c), dim3(256), 0, s, a);
+        E3_CHECK_HIP(hipGetLastError());
+    }
+    return E3_OK;
+}
 
 size_t adamw_state_floats(int n_tensors, const long long* numels) {
     size_t chunks = 0;

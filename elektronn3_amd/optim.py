@@ -127,3 +127,167 @@ class AdamW(torch.optim.Optimizer):
 
 
 __all__ = ['AdamW']
+
+
+class SWA(torch.optim.Optimizer):
+    """Stochastic weight averaging around any optimizer, with the interface of the reference's ``SWA`` wrapper
+    (elektronn3/training/swa.py:11-345, vendored torchcontrib; used by ``Trainer`` as ``SWA(optimizer)`` +
+    ``update_swa()`` / ``swap_swa_sgd()`` / ``bn_update``): automatic mode (``swa_start``, ``swa_freq``, optional ``swa_lr``) or manual
+    mode (``update_swa`` / ``update_swa_group``), ``swap_swa_sgd``, ``state_dict`` with ``opt_state`` / ``swa_state`` / ``param_groups``.
+
+    The running averages live in ``state[p]['swa_buffer']`` like the reference's, but one group is averaged (or swapped) by ONE HIP
+    launch over all of its tensors (libe3unet ``e3_swa_update`` / ``e3_swa_swap``) instead of 3-4 ATen kernels per tensor; the
+    arithmetic is the reference's (two rounded fp32 operations), so the averages are bit-identical.  GPU only."""
+
+    def __init__(self, optimizer, swa_start=None, swa_freq=None, swa_lr=None):
+        import warnings
+        from collections import defaultdict
+        given = [v is not None for v in (swa_start, swa_freq)]
+        self._auto_mode = all(given)
+        if any(given) and not all(given):
+            warnings.warn('Some of swa_start, swa_freq is None, ignoring other')
+        if self._auto_mode:
+            if not isinstance(swa_start, int) or not isinstance(swa_freq, int):
+                warnings.warn('Casting swa_start, swa_freq to int')
+                swa_start, swa_freq = int(swa_start), int(swa_freq)
+            if swa_start < 0:
+                raise ValueError(f'Invalid swa_start: {swa_start}')
+            if swa_freq < 1:
+                raise ValueError(f'Invalid swa_freq: {swa_freq}')
+        else:
+            if swa_lr is not None:
+                warnings.warn('Some of swa_start, swa_freq is None, ignoring swa_lr')
+            swa_start = swa_freq = swa_lr = None
+        if swa_lr is not None and swa_lr < 0:
+            raise ValueError(f'Invalid SWA learning rate: {swa_lr}')
+        self.swa_start, self.swa_freq, self.swa_lr = swa_start, swa_freq, swa_lr
+        self.optimizer = optimizer
+        self.defaults = optimizer.defaults
+        self.param_groups = optimizer.param_groups       # shared: LR schedulers acting on either see the same groups
+        self.state = defaultdict(dict)
+        self.opt_state = optimizer.state
+        for group in self.param_groups:
+            group['n_avg'] = 0
+            group['step_counter'] = 0
+
+    # ------------------------------------------------------------------ one launch over a list of (parameter, buffer) pairs
+    @staticmethod
+    def _launch(pairs, n_avg=None):
+        if not pairs:
+            return
+        dev = pairs[0][0].device
+        for p, b in pairs:
+            if p.device.type != 'cuda':
+                raise RuntimeError('elektronn3_amd.optim.SWA runs on the GPU only (there is no CPU path)')
+            if p.dtype != torch.float32 or p.device != dev or not p.data.is_contiguous() or not b.is_contiguous():
+                raise NotImplementedError('SWA on the HIP path needs contiguous fp32 parameters on one device')
+        n = len(pairs)
+        pp = (ctypes.c_void_p * n)(*[p.data.data_ptr() for p, _ in pairs])
+        bp = (ctypes.c_void_p * n)(*[b.data_ptr() for _, b in pairs])
+        numels = (ctypes.c_int64 * n)(*[p.numel() for p, _ in pairs])
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            if n_avg is None:
+                check(lib.e3_swa_swap(stream_ptr(dev), n, pp, bp, numels))
+            else:
+                check(lib.e3_swa_update(stream_ptr(dev), n, pp, bp, numels, int(n_avg)))
+
+    @torch.no_grad()
+    def update_swa_group(self, group):
+        """Folds the group's current parameters into their running averages (swa.py:145-176)."""
+        pairs = []
+        for p in group['params']:
+            st = self.state[p]
+            if 'swa_buffer' not in st:
+                st['swa_buffer'] = torch.zeros_like(p.data)
+            pairs.append((p, st['swa_buffer']))
+        self._launch(pairs, group['n_avg'])
+        group['n_avg'] += 1
+
+    def update_swa(self):
+        for group in self.param_groups:
+            self.update_swa_group(group)
+
+    @torch.no_grad()
+    def swap_swa_sgd(self):
+        """Exchanges the optimized variables and their running averages (swa.py:184-202); call it again to continue training."""
+        import warnings
+        for group in self.param_groups:
+            pairs = []
+            for p in group['params']:
+                st = self.state[p]
+                if 'swa_buffer' not in st:
+                    warnings.warn(f"SWA wasn't applied to param {p}; skipping it")
+                    continue
+                pairs.append((p, st['swa_buffer']))
+            self._launch(pairs)
+
+    def step(self, closure=None):
+        if self.swa_lr is not None:
+            for group in self.param_groups:
+                if group['step_counter'] >= self.swa_start:
+                    group['lr'] = self.swa_lr
+        loss = self.optimizer.step(closure)
+        for group in self.param_groups:
+            group['step_counter'] += 1
+            if self._auto_mode and group['step_counter'] > self.swa_start and group['step_counter'] % self.swa_freq == 0:
+                self.update_swa_group(group)
+        return loss
+
+    def zero_grad(self, set_to_none=True):
+        self.optimizer.zero_grad(set_to_none=set_to_none)
+
+    def add_param_group(self, param_group):
+        param_group['n_avg'] = 0
+        param_group['step_counter'] = 0
+        self.optimizer.add_param_group(param_group)
+
+    # ------------------------------------------------------------------ checkpoints (layout of swa.py:221-258)
+    def state_dict(self):
+        inner = self.optimizer.state_dict()
+        order = [p for g in self.param_groups for p in g['params']]
+        swa_state = {i: dict(self.state[p]) for i, p in enumerate(order) if p in self.state and self.state[p]}
+        return {'opt_state': inner['state'], 'swa_state': swa_state, 'param_groups': inner['param_groups']}
+
+    def load_state_dict(self, state_dict):
+        self.optimizer.load_state_dict({'state': state_dict['opt_state'], 'param_groups': state_dict['param_groups']})
+        self.param_groups = self.optimizer.param_groups
+        self.opt_state = self.optimizer.state
+        order = [p for g in self.param_groups for p in g['params']]
+        self.state.clear()
+        for i, st in state_dict['swa_state'].items():
+            p = order[int(i)]
+            self.state[p] = {k: (v.to(device=p.device, dtype=p.dtype).clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+
+    # ------------------------------------------------------------------ BatchNorm statistics of the averaged weights
+    @staticmethod
+    def bn_update(loader, model, device=None):
+        """One pass over ``loader`` that re-estimates the running statistics of every ``_BatchNorm`` module as the cumulative average over
+        the batches (swa.py:262-306): statistics reset, momentum of batch k = b_k / (n_seen + b_k), train-mode forwards, momenta and
+        the training flag restored.  Batches may be tensors, (tensor, ...) sequences or the Trainer's dicts (key ``'inp'``)."""
+        bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+        if not bns:
+            return
+        was_training = model.training
+        model.train()
+        saved = [m.momentum for m in bns]
+        for m in bns:
+            m.running_mean = torch.zeros_like(m.running_mean)
+            m.running_var = torch.ones_like(m.running_var)
+        seen = 0
+        with torch.no_grad():
+            for batch in loader:
+                if isinstance(batch, (list, tuple)):
+                    batch = batch[0]
+                elif isinstance(batch, dict):
+                    batch = batch['inp']
+                b = batch.size(0)
+                for m in bns:
+                    m.momentum = b / float(seen + b)
+                if device is not None:
+                    batch = batch.to(device)
+                model(batch)
+                seen += b
+        for m, mom in zip(bns, saved):
+            m.momentum = mom
+        model.train(was_training)

@@ -228,6 +228,14 @@ int e3_adamw_step(void* stream, int n_tensors, void* const* params, void* const*
                   double lr, double beta1, double beta2, double eps, double weight_decay,
                   const float* grad_scale, const float* found_inf);
 
+/* Stochastic weight averaging of the reference's SWA(optimizer) wrapper [elektronn3/training/swa.py:145-176 update_swa_group,
+ * :184-202 swap_swa_sgd; driven by training/trainer.py:681-700] as ONE launch over all parameter tensors:
+ *   e3_swa_update:  swa_buffer += (p - swa_buffer) * (1 / (n_avg + 1))   (fp32, the reference's two rounded operations: bit-identical)
+ *   e3_swa_swap:    exchanges every parameter with its running average.
+ * params / swa_buffers: host arrays of n_tensors device pointers (contiguous fp32, numels[i] elements each). */
+int e3_swa_update(void* stream, int n_tensors, void* const* params, void* const* swa_buffers, const long long* numels, long long n_avg);
+int e3_swa_swap(void* stream, int n_tensors, void* const* params, void* const* swa_buffers, const long long* numels);
+
 /* Layout conversion at the module boundary. */
 int e3_ncdhw_to_ndhwc(void* stream, const float* src, float* dst, int N, int C, int D, int H, int W);
 int e3_ndhwc_to_ncdhw(void* stream, const float* src, int src_ldc, float* dst, int N, int C, int D, int H, int W);

@@ -264,6 +264,13 @@ def ce_dice_from_sums(s, w=None, ce_weight=0.5, dice_weight=0.5, eps=1e-4, smoot
     return ce_weight * ce + dice_weight * float((w * (1 - num / den)).mean())
 
 
+def swa_update(buf, p, n_avg):
+    """One running-average update of the reference's SWA wrapper (training/swa.py:169-175): buf + (p - buf) * (1 / (n_avg + 1)), each
+    operation rounded to fp32 (the scalar is a Python float that ATen casts to fp32 for an fp32 tensor)."""
+    buf, p = _f32(buf), _f32(p)
+    return (buf + ((p - buf) * np.float32(1.0 / float(n_avg + 1))).astype(np.float32)).astype(np.float32)
+
+
 def autocrop(from_down, from_up):
     """unet.py:256-325 -- crop decoder output by 1 where (u-d) is odd, centre-crop encoder output."""
     if from_down.shape[2:] == from_up.shape[2:]:

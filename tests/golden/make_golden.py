@@ -326,7 +326,40 @@ def make_adamw(out):
     print('wrote', out, f'{os.path.getsize(out) / 1e6:.2f} MB')
 
 
+def make_swa(out):
+    """The reference's SWA wrapper (training/swa.py, imported by path: it needs torch only) around torch.optim.SGD on CPU: automatic mode
+    (swa_start=2, swa_freq=2) over 8 steps, then swap_swa_sgd.  Pins the running-average arithmetic (two rounded fp32 operations per
+    update), the update schedule and the swap."""
+    swa = _load('e3ref_swa', f'{REF}/training/swa.py')
+    torch.manual_seed(6)
+    shapes = [(5,), (3, 4), (2, 3, 3, 3, 3), (1027,)]
+    ps = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    opt = swa.SWA(torch.optim.SGD(ps, lr=0.1), swa_start=2, swa_freq=2)
+    d = {'n': np.array(len(shapes)), 'steps': np.array(8), 'swa_start': np.array(2), 'swa_freq': np.array(2), 'lr': np.array(0.1)}
+    for i, p in enumerate(ps):
+        d[f'p0/{i}'] = npy(p).copy()
+    for t in range(8):
+        for i, p in enumerate(ps):
+            p.grad = torch.randn(p.shape)
+            d[f'g{t}/{i}'] = npy(p.grad).copy()
+        opt.step()
+        for i, p in enumerate(ps):
+            d[f'p{t + 1}/{i}'] = npy(p).copy()
+            if 'swa_buffer' in opt.state[p]:
+                d[f'b{t + 1}/{i}'] = npy(opt.state[p]['swa_buffer']).copy()
+        d[f'n_avg{t + 1}'] = np.array(opt.param_groups[0]['n_avg'])
+    opt.swap_swa_sgd()
+    for i, p in enumerate(ps):
+        d[f'p_swapped/{i}'] = npy(p).copy()
+        d[f'b_swapped/{i}'] = npy(opt.state[p]['swa_buffer']).copy()
+    np.savez_compressed(out, **d)
+    print('wrote', out, f'{os.path.getsize(out) / 1e6:.2f} MB')
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'swa':
+        make_swa(f'{HERE}/swa.npz')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'adamw':      # only the optimizer fixture (needs torch, not the reference)
         make_adamw(f'{HERE}/adamw.npz')
         sys.exit(0)
@@ -406,4 +439,5 @@ if __name__ == '__main__':
     make_rrelu_eval(unet, f'{HERE}/unet_nb3_sf8_rrelu_eval.npz')
     make_predictor(unet, inference, f'{HERE}/predictor.npz')
     make_adamw(f'{HERE}/adamw.npz')
+    make_swa(f'{HERE}/swa.npz')
     make_trainsteps(unet, loss_mod, f'{HERE}/trainsteps.npz')

@@ -148,3 +148,92 @@ def test_cpu_parameters_raise():
     o.param_groups[0]['params'][0].grad = torch.randn(4)
     with pytest.raises(RuntimeError):
         o.step()
+
+
+# ------------------------------------------------------------------------------------------------ SWA
+def test_swa_golden_trajectory_bit_exact():
+    """elektronn3_amd.optim.SWA around torch.optim.SGD on the GPU, fed the gradients of tests/golden/swa.npz (the reference's SWA wrapper
+    around SGD on CPU, automatic mode swa_start=2 / swa_freq=2, 8 steps, then swap_swa_sgd): the running averages are a function of
+    the parameter trajectory only, and the kernel keeps the reference's two rounded operations -> BIT-identical buffers given the
+    golden parameters; the SGD trajectory itself is compared to rounding (the GPU's fused multiply-add in torch's own SGD kernel)."""
+    from elektronn3_amd.optim import SWA
+    g = load_npz('swa.npz')
+    n, steps = int(g['n']), int(g['steps'])
+    ps = [torch.nn.Parameter(torch.from_numpy(g[f'p0/{i}'].copy()).cuda()) for i in range(n)]
+    opt = SWA(torch.optim.SGD(ps, lr=float(g['lr'])), swa_start=int(g['swa_start']), swa_freq=int(g['swa_freq']))
+    for t in range(steps):
+        for i, p in enumerate(ps):
+            p.grad = torch.from_numpy(g[f'g{t}/{i}']).cuda()
+        opt.step()
+        assert opt.param_groups[0]['n_avg'] == int(g[f'n_avg{t + 1}'])
+        for i, p in enumerate(ps):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), g[f'p{t + 1}/{i}'], rtol=2e-6, atol=1e-7)
+            with torch.no_grad():
+                p.copy_(torch.from_numpy(g[f'p{t + 1}/{i}']))        # continue from the golden parameters: buffers must then match exactly
+            if f'b{t + 1}/{i}' in g.files:       # (built from GPU parameters that differ from the golden ones by rounding)
+                np.testing.assert_allclose(opt.state[p]['swa_buffer'].cpu().numpy(), g[f'b{t + 1}/{i}'], rtol=2e-6, atol=1e-7)
+    # the averages were built from GPU parameters that differ from the golden ones by rounding until the copy above: rebuild them
+    # from the golden trajectory through the manual-mode API and require bit equality
+    ps2 = [torch.nn.Parameter(torch.from_numpy(g[f'p0/{i}'].copy()).cuda()) for i in range(n)]
+    man = SWA(torch.optim.SGD(ps2, lr=0.1))
+    for t in range(1, steps + 1):
+        if t > int(g['swa_start']) and t % int(g['swa_freq']) == 0:
+            with torch.no_grad():
+                for i, p in enumerate(ps2):
+                    p.copy_(torch.from_numpy(g[f'p{t}/{i}']))
+            man.update_swa()
+            for i, p in enumerate(ps2):
+                np.testing.assert_array_equal(man.state[p]['swa_buffer'].cpu().numpy(), g[f'b{t}/{i}'])
+    with torch.no_grad():
+        for i, p in enumerate(ps2):
+            p.copy_(torch.from_numpy(g[f'p{steps}/{i}']))
+    man.swap_swa_sgd()
+    for i, p in enumerate(ps2):
+        np.testing.assert_array_equal(p.detach().cpu().numpy(), g[f'p_swapped/{i}'])
+        np.testing.assert_array_equal(man.state[p]['swa_buffer'].cpu().numpy(), g[f'b_swapped/{i}'])
+
+
+def test_swa_over_cfg2_parameters_with_hip_adamw_and_bn_update():
+    """The Trainer's use (SWA(AdamW(model.parameters())), update_swa at epoch end, swap + bn_update for validation) on the real parameter set:
+    one launch averages all 70 tensors, bit-identical to the reference's per-tensor formula run by torch on the same GPU; state_dict round
+    trip; bn_update re-estimates the running statistics as the cumulative average over the loader's batches."""
+    from elektronn3_amd.optim import AdamW, SWA
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(0)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=3, start_filts=16).cuda().train()
+    opt = SWA(AdamW(m.parameters(), lr=1e-3, weight_decay=0.5e-4))
+    ref_buf = [torch.zeros_like(p) for p in m.parameters()]
+    x = torch.randn(2, 1, 16, 32, 32, device='cuda')
+    for k in range(3):
+        m(x).square().mean().backward()
+        opt.step(); opt.zero_grad()
+        opt.update_swa()
+        for b, p in zip(ref_buf, m.parameters()):
+            b.add_((p.data - b) * (1 / float(k + 1)))
+    for b, p in zip(ref_buf, m.parameters()):
+        assert torch.equal(opt.state[p]['swa_buffer'], b)
+    sd = opt.state_dict()
+    assert set(sd) == {'opt_state', 'swa_state', 'param_groups'} and len(sd['swa_state']) == len(ref_buf)
+    opt2 = SWA(AdamW(m.parameters(), lr=1e-3, weight_decay=0.5e-4)); opt2.load_state_dict(sd)
+    assert opt2.param_groups[0]['n_avg'] == 3
+    for p in m.parameters():
+        assert torch.equal(opt2.state[p]['swa_buffer'], opt.state[p]['swa_buffer'])
+    before = [p.detach().clone() for p in m.parameters()]
+    opt.swap_swa_sgd()
+    for b, p, q in zip(ref_buf, m.parameters(), before):
+        assert torch.equal(p.data, b) and torch.equal(opt.state[p]['swa_buffer'], q)
+    # bn_update: cumulative average of the batch statistics == statistics of the two batches taken with momentum 1/1, 1/2
+    loader = [torch.randn(2, 1, 16, 32, 32), {'inp': torch.randn(2, 1, 16, 32, 32)}]
+    SWA.bn_update(loader, m, device='cuda')
+    assert m.training and all(mod.momentum == 0.1 for mod in m.modules() if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm))
+    rm = m.down_convs[0].norm0.running_mean.clone()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+            mod.reset_running_stats(); mod.momentum = None        # torch's own cumulative moving average
+    with torch.no_grad():
+        for b in loader:
+            m((b['inp'] if isinstance(b, dict) else b).cuda())
+    np.testing.assert_allclose(rm.cpu().numpy(), m.down_convs[0].norm0.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    opt.swap_swa_sgd()
+    for p, q in zip(m.parameters(), before):
+        assert torch.equal(p.data, q)

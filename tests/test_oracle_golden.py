@@ -169,3 +169,22 @@ def test_adamw_trajectory():
             np.testing.assert_allclose(m, g[f'm{t + 1}/{i}'], rtol=2e-6, atol=3e-7 * np.abs(g[f'm{t + 1}/{i}']).max())
             np.testing.assert_allclose(v, g[f'v{t + 1}/{i}'], rtol=2e-6, atol=0)
             np.testing.assert_allclose(p, g[f'p{t + 1}/{i}'], rtol=2e-6, atol=1e-7)
+
+
+def test_swa_running_average():
+    """oracle.swa_update against the reference SWA wrapper's buffers (tests/golden/swa.npz: automatic mode, swa_start=2, swa_freq=2)."""
+    g = load_npz('swa.npz')
+    n, steps, start, freq = int(g['n']), int(g['steps']), int(g['swa_start']), int(g['swa_freq'])
+    bufs = [np.zeros_like(g[f'p0/{i}']) for i in range(n)]
+    n_avg = 0
+    for t in range(1, steps + 1):
+        if t > start and t % freq == 0:
+            bufs = [orc.swa_update(bufs[i], g[f'p{t}/{i}'], n_avg) for i in range(n)]
+            n_avg += 1
+        assert n_avg == int(g[f'n_avg{t}'])
+        for i in range(n):
+            if f'b{t}/{i}' in g.files:
+                np.testing.assert_array_equal(bufs[i], g[f'b{t}/{i}'])
+    for i in range(n):      # swap_swa_sgd
+        np.testing.assert_array_equal(g[f'p_swapped/{i}'], bufs[i])
+        np.testing.assert_array_equal(g[f'b_swapped/{i}'], g[f'p{steps}/{i}'])
