@@ -453,7 +453,7 @@ int launch_conv_mfma(ConvKind kind, ConvArgs a, hipStream_t s) {
     }
     if (a.G <= 0) a.G = 1;
     if (kind == CONV_POINT && upconv_gemm_ok(a.flags, a.Cin, a.Cout, a.Ncols)) return launch_upconv_gemm(a, s);   // upconv_gemm.hip
-    if (conv_use_wino(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols)) return launch_conv3_wino(a, s);   // a.wt packed by launch_pack_conv_auto
+    if (a.splitk > 1 || conv_use_wino(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols)) return launch_conv3_wino(a, s);   // a.wt packed by launch_pack_conv_auto
     if (conv_use_wino2d(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols)) return launch_conv2_wino(a, s);
     int ks, nt; conv_decomposition(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols, &ks, &nt);
     static const bool use_v3 = getenv("E3_CONV_NO_V3") == nullptr;   // debug switch: fall back to the global-B kernel

@@ -57,7 +57,13 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
 
     // block index -> (sample, brick, column tile).  The tile counts are powers of two for the usual crop sizes: shifts
     // instead of four scalar divisions (~200 SALU instructions of an otherwise latency-bound prologue).
-    unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    unsigned bid = blockIdx.x, nbricks = gridDim.x, split = 0;
+    if (a.splitk > 1) {          // split-K: grid = splits x bricks, every split walks its own share of the input channels
+        nbricks = gridDim.x / (unsigned)a.splitk;
+        split = bid / nbricks;
+        bid -= split * nbricks;
+    }
+    unsigned L = xcd_remap(bid, nbricks);
     auto divmod = [](unsigned& x, int d) {
         int r;
         if ((d & (d - 1)) == 0) { r = (int)(x & (unsigned)(d - 1)); x >>= __builtin_ctz((unsigned)d); }
@@ -81,12 +87,12 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
     const size_t plane_x = (size_t)a.H * a.W * a.x_ldc, plane_y = (size_t)a.H * a.W * a.y_ldc;
     const size_t xrem = (size_t)(a.D - dlo) * plane_x * 4, yrem = (size_t)(a.D - d0) * plane_y * 4;
     const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.x) + ((size_t)nb * a.D + dlo) * plane_x, 0, (int)(xrem < 0x7fffffffu ? xrem : 0x7fffffffu), 0x00020000);
+        const_cast<float*>(a.x) + ((size_t)nb * a.D + dlo) * plane_x + split * (unsigned)a.sk_x, 0, (int)(xrem < 0x7fffffffu ? xrem : 0x7fffffffu), 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(
-        a.y + ((size_t)nb * a.D + d0) * plane_y, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
+        a.y + ((size_t)nb * a.D + d0) * plane_y + split * a.sk_y, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
     // transformed weights: U[ntile][chunk][pos 64][hf 2][co 32][4 ci]; wave = pd owns positions 16 pd .. 16 pd + 15
     const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.wt) + ((size_t)ntile * NCH * 64 + wave * 16) * 256, 0, NCH * 64 * 1024, 0x00020000);
+        const_cast<float*>(a.wt) + ((size_t)ntile * NCH * 64 + wave * 16) * 256 + (size_t)split * a.sk_w, 0, NCH * 64 * 1024, 0x00020000);
     const int b_voff = lane * 16;
 
     // ---- staging plan: thread -> column (zh, zw, 16-B half q) of the halo, all 6 d-planes (threads 216..255 idle)
@@ -740,14 +746,30 @@ size_t wino_packed_floats(int K, int ncols) { return (size_t)64 * K * (size_t)((
 
 int wino_bricks(int N, int D, int H, int W) { return N * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16); }
 
+// The bottom level of a U-Net has few bricks (cfg 2: 2 x 8 x 16 x 16 voxels = 16 bricks x Cout/32 column tiles = 64..128 workgroups for 256 CUs)
+// but many input channels, walked serially by each workgroup: split the channels over 2 or 4 workgroups per brick (partial sums to a
+// scratch tensor, fixed-order reduction by splitk_reduce_kernel).  Per SAMPLE, like conv_use_wino: independent of the batch size.
+static int splitk_factor(size_t nblk1, int K) {
+    static const bool enabled = getenv("E3_NO_SPLITK") == nullptr;
+    int S = 1;
+    while (enabled && S < 4 && nblk1 * S < 256 && K / (2 * S) >= 64 && K % (16 * S) == 0) S *= 2;
+    return S;
+}
+
 bool conv_use_wino(ConvKind kind, int flags, int N, int D, int H, int W, int Cin, int ncols) {
     static const bool enabled = getenv("E3_CONV_NO_WINO") == nullptr;
     if (!enabled || kind != CONV_K3 || (flags & (CF_SCATTER_UP | CF_GATHER_UP | CF_NO_WINO)) != 0 || Cin < 8 || (Cin & 7)) return false;
     // decided per SAMPLE (not per batch) so that the algorithm, and with it every rounding, is independent of the batch size:
     // eval-mode outputs of a batch are bit-identical to those of its samples run one by one (tests/test_unet_gpu.py)
     (void)N;
-    const size_t grid = (size_t)wino_bricks(1, D, H, W) * ((ncols + 31) / 32);
+    size_t grid = (size_t)wino_bricks(1, D, H, W) * ((ncols + 31) / 32);
+    if (flags & CF_SPLITK_OK) grid *= splitk_factor(grid, Cin);
     return grid >= 64u;        // a Winograd workgroup does 3.4x less matrix work than a direct one: worth it from 1/4 of the CUs
+}
+
+int conv_wino_splitk(int D, int H, int W, int K, int ncols) {
+    if (!conv_use_wino(CONV_K3, CF_SPLITK_OK, 1, D, H, W, K, ncols)) return 0;
+    return splitk_factor((size_t)wino_bricks(1, D, H, W) * ((ncols + 31) / 32), K);
 }
 
 int launch_wino_pack_multi(const WinoPackJob* jobs, int njobs, hipStream_t s) {
@@ -757,8 +779,14 @@ int launch_wino_pack_multi(const WinoPackJob* jobs, int njobs, hipStream_t s) {
         int b = 0;
         for (int j = 0; j < a.n; ++j) {
             const WinoPackJob& q = jobs[j0 + j];
-            const int K = q.dgrad ? q.Cout : q.Cin, ncols = q.dgrad ? q.Cin : q.Cout, NPad = (ncols + 31) / 32 * 32;
-            a.w[j] = q.w; a.out[j] = q.out; a.Cin[j] = q.Cin; a.K[j] = K; a.Ncols[j] = ncols; a.dgrad[j] = q.dgrad;
+            int K = q.dgrad ? q.Cout : q.Cin;
+            const int ncols = q.dgrad ? q.Cin : q.Cout, NPad = (ncols + 31) / 32 * 32;
+            const float* w = q.w;
+            if (q.kn > 0) {      // a share of the GEMM-K channels: w is [Cout][Cin][27], K runs over Cin (forward) or Cout (dgrad)
+                w += (size_t)q.k0 * 27 * (q.dgrad ? q.Cin : 1);
+                K = q.kn;
+            }
+            a.w[j] = w; a.out[j] = q.out; a.Cin[j] = q.Cin; a.K[j] = K; a.Ncols[j] = ncols; a.dgrad[j] = q.dgrad;
             a.bstart[j] = b;
             b += (int)(((size_t)(NPad >> 5) * (K >> 3) * 256 + 255) / 256);
         }
@@ -815,7 +843,9 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
     // kernel is as fast or 1-3 % faster.  E3_WINO_NO_PERSIST=1: A/B switch.
     static const bool persist = getenv("E3_WINO_NO_PERSIST") == nullptr;
     static const size_t pmin = getenv("E3_WINO_PERSIST_MIN") ? (size_t)atol(getenv("E3_WINO_PERSIST_MIN")) : 1024;   // (tests force 1: every shape)
-    if (persist && nblk >= pmin && !a.pro_scale && !(a.flags & (1024 | CF_NO_PERSIST))) {
+    const unsigned splits = a.splitk > 1 ? (unsigned)a.splitk : 1u;
+    if (splits > 1) E3_REQUIRE(!a.bias && !a.stats && !a.epi_scale && !a.pro_scale && a.Cin == a.sk_x, E3_ERR_INVALID, "split-K conv: bias / statistics / fused prologue or epilogue are not available");
+    if (persist && splits == 1 && nblk >= pmin && !a.pro_scale && !(a.flags & (1024 | CF_NO_PERSIST))) {
         constexpr int plds = W_PLDS_FLOATS * 4;
         static bool pattr = false;
         if (!pattr) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel), hipFuncAttributeMaxDynamicSharedMemorySize, plds)); pattr = true; }
@@ -825,7 +855,7 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
         return E3_OK;
     }
     if (a.pro_scale) hipLaunchKernelGGL(conv3_wino_kernel<true>, dim3((unsigned)nblk), dim3(256), lds_bytes, s, a);
-    else hipLaunchKernelGGL(conv3_wino_kernel<false>, dim3((unsigned)nblk), dim3(256), lds_bytes, s, a);
+    else hipLaunchKernelGGL(conv3_wino_kernel<false>, dim3((unsigned)nblk * splits), dim3(256), lds_bytes, s, a);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

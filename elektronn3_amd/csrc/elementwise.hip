@@ -649,6 +649,41 @@ __global__ __launch_bounds__(256) void crop_stats_kernel(const float* __restrict
         o[0] = n; o[1] = mu; o[2] = s;
     }
 }
+// Reduction of a split-K convolution (conv_wino_splitk): dst[u][c] = src_0[u][c] + src_1[u][c] (+ ...) + bias[c] in that fixed order, plus
+// (optionally) the BatchNorm statistics of the result -- one (count, mean, M2) record per workgroup and channel, as crop_stats_kernel.
+template <bool STATS>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ src, int nsrc, size_t src_stride, const float* __restrict__ bias,
+                                                            float* __restrict__ dst, int dst_ldc, int C, size_t units, float* __restrict__ stats) {
+    __shared__ float red[STATS ? 256 : 1][3][4];
+    const int Q = C >> 2;
+    const int BT = (256 / Q) * Q;
+    const size_t total = units * Q, stride = (size_t)gridDim.x * BT;
+    f32x4 cn = {0.f, 0.f, 0.f, 0.f}, mean = cn, m2 = cn;
+    for (size_t i = (size_t)blockIdx.x * BT + threadIdx.x; threadIdx.x < BT && i < total; i += stride) {
+        const int q = (int)(i % Q); const size_t u = i / Q;
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + u * C + 4 * q);
+        for (int k = 1; k < nsrc; ++k) v += *reinterpret_cast<const f32x4*>(src + k * src_stride + u * C + 4 * q);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + 4 * q);
+        *reinterpret_cast<f32x4*>(dst + u * dst_ldc + 4 * q) = v;
+        if (STATS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cn[e] += 1.f; const float dl = v[e] - mean[e]; mean[e] += dl / cn[e]; m2[e] += dl * (v[e] - mean[e]); }
+        }
+    }
+    if (STATS) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[tid][0][e] = cn[e]; red[tid][1][e] = mean[e]; red[tid][2][e] = m2[e]; }
+        __syncthreads();
+        for (int t = tid; t < Q * 4; t += 256) {
+            const int e = t & 3, q = t >> 2;
+            float n = 0.f, mu = 0.f, sq = 0.f;
+            for (int k = q; k < BT; k += Q) welford_merge(n, mu, sq, red[k][0][e], red[k][1][e], red[k][2][e]);
+            float* o = stats + ((size_t)blockIdx.x * C + 4 * q + e) * 3;
+            o[0] = n; o[1] = mu; o[2] = sq;
+        }
+    }
+}
 // centre crop of the skip connection in conv_mode='valid' (autocrop, unet.py:300-325): dst view (ldc) [N, Dd, Hd, Wd] = src box at (od, oh, ow)
 __global__ void crop_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int dst_ldc, int C, int N, int Ds, int Hs, int Ws,
                                  int Dd, int Hd, int Wd, int od, int oh, int ow) {
@@ -917,6 +952,15 @@ int launch_crop_stats(const float* src, float* dst, int C, int N, int Ds, int Hs
     E3_REQUIRE(od >= 0 && oh >= 0 && ow >= 0 && Dd + od <= Ds && Hd + oh <= Hs && Wd + ow <= Ws, E3_ERR_INVALID, "crop box outside the source");
     const int parts = crop_stats_parts((size_t)N * Dd * Hd * Wd, C);
     hipLaunchKernelGGL(crop_stats_kernel, dim3(parts), dim3(256), 0, s, src, dst, C, N, Ds, Hs, Ws, Dd, Hd, Wd, stats, od, oh, ow);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+int launch_splitk_reduce(const float* src, int nsrc, size_t src_stride, const float* bias, float* dst, int dst_ldc, int C, size_t units,
+                         float* stats, hipStream_t s) {
+    E3_REQUIRE(C % 4 == 0 && C <= 1024 && dst_ldc % 4 == 0 && nsrc >= 1, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4, at most 1024");
+    const int parts = crop_stats_parts(units, C);
+    if (stats) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(parts), dim3(256), 0, s, src, nsrc, src_stride, bias, dst, dst_ldc, C, units, stats);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(parts), dim3(256), 0, s, src, nsrc, src_stride, bias, dst, dst_ldc, C, units, stats);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

@@ -16,6 +16,8 @@ enum ConvFlags {
     CF_NO_WINO = 8,     // direct kernels only (set by callers that pass a BN+ReLU prologue)
     CF_NO_PERSIST = 16, // one brick per workgroup even on large grids: a collective may hold CUs while this kernel runs, and a static
                         // 256-workgroup kernel that does not get all 256 CUs at once needs a full second round
+    CF_SPLITK_OK = 32,  // the caller can run the conv split over its input channels (conv_wino_splitk): count the splits when deciding
+                        // whether the Winograd grid is large enough
 };
 
 struct ConvArgs {
@@ -36,6 +38,9 @@ struct ConvArgs {
     int tilesD, tilesH, tilesW, ntiles;
     int G;                       // gather taps (1 unless GATHER_UP)
     int flags;
+    // split-K (Winograd 3x3x3 only, conv_wino_splitk()): the grid is splitk x the bricks; split s reads the channels [s * sk_x, (s + 1) * sk_x)
+    // (Cin = sk_x), its own packed weights (wt + s * sk_w) and writes its partial sums to y + s * sk_y.  bias / stats / epilogue must be off.
+    int splitk; int sk_x; unsigned sk_w; size_t sk_y;
 };
 
 // number of stats records (rows of [Cout][3]) the conv will write
@@ -48,7 +53,12 @@ int launch_conv3_v3(ConvKind kind, ConvArgs a, int nt, hipStream_t s);   // conv
 // statistics sizing and launch_conv_mfma() all ask it, with K = GEMM-K channels and ncols = GEMM columns.
 bool conv_use_wino(ConvKind kind, int flags, int N, int D, int H, int W, int K, int ncols);
 constexpr int WINO_PACK_MAX_JOBS = 40;
-struct WinoPackJob { const float* w; float* out; int Cout, Cin, dgrad; };
+struct WinoPackJob { const float* w; float* out; int Cout, Cin, dgrad; int k0 = 0, kn = 0; };   // kn > 0: only the GEMM-K channels [k0, k0 + kn)
+// split-K factor (1, 2 or 4) of a Winograd 3x3x3 conv whose bricks cannot fill the chip (decided per sample, like conv_use_wino)
+int conv_wino_splitk(int D, int H, int W, int K, int ncols);   // (0 if the conv does not use the Winograd kernel even with the splits)
+// dst[u][c] (ldc) = sum_s src[s * src_stride + u * C + c] (+ bias[c]); stats (optional): crop_stats_parts(units, C) records per channel
+int launch_splitk_reduce(const float* src, int nsrc, size_t src_stride, const float* bias, float* dst, int dst_ldc, int C, size_t units,
+                         float* stats, hipStream_t s);
 int launch_wino_pack_multi(const WinoPackJob* jobs, int njobs, hipStream_t s);   // the Winograd weight transforms of many layers in one launch
 int wino_bricks(int N, int D, int H, int W);
 int launch_conv3_wino(ConvArgs a, hipStream_t s);

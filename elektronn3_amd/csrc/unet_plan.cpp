@@ -164,6 +164,7 @@ struct Buffers {
     float* ones; float* zeros;                                                 // [Cmax] / [2*Cmax] constants for units without a norm
     std::vector<float*> ups;             // ResizeConv units: the up-sampled input [N, sd*D', 2H', 2W', Cin] (kept for the weight gradient)
     float* wemb; float* gemb;            // ResizeConv(kernel_size=1): weights / weight gradient embedded as the centre tap of a 27-tap kernel
+    float* skws = nullptr;               // split-K partial sums of the bottom-level convs (training only)
     float* rtmp; float* rpad; float* rdu; // ResizeConv scratch: conv output / padded gradient at the up-sampled size, gradient of the up-sampled input
     float* biaspart0;                    // [splits][Cout] conv-bias gradient partials of the first conv when its BN backward is fused into its wgrad
     std::vector<float*> bnpart_u;        // per unit: block partials of the BN backward [parts][3][C]; row 2 (sum dx = conv-bias gradient) is summed for all units at once
@@ -272,13 +273,26 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     if (p->cfg.up_resize >= 3) { const size_t e = (size_t)p->chan(nb - 1) * p->chan(nb - 1) / 2 * 27; B.wemb = T.take(e); if (training) B.gemb = T.take(e); }
     if (rtmpmax) { B.rtmp = T.take(rtmpmax); if (rdumax) B.rdu = T.take(rdumax); if (training) B.rpad = T.take(rtmpmax); }
     B.wpk_f.assign(p->units.size(), nullptr); B.wpk_d.assign(p->units.size(), nullptr);
+    size_t skmax = 0;
     for (size_t k = 0; k < p->units.size(); ++k) {
         const ConvUnit& u = p->units[k];
         const LevelDims& lo = ND.u[k].in;          // (the conv grid)
         if (u.is_up || u.planar || u.cin < 8) continue;
-        if (conv_use_wino(CONV_K3, 0, N, lo.D, lo.H, lo.W, u.cin, u.cout)) B.wpk_f[k] = T.take(conv_packed_floats(CONV_K3, u.cin, u.cout));
-        if (training && conv_use_wino(CONV_K3, 0, N, lo.D, lo.H, lo.W, u.cout, u.cin)) B.wpk_d[k] = T.take(conv_packed_floats(CONV_K3, u.cout, u.cin));
+        // split-K (training only; forward: units with batch statistics, 'same' convs): the splits count when the Winograd grid is sized
+        const bool skf = training && u.has_norm() && !valid, skd = training && !valid;
+        const int sf = skf ? conv_wino_splitk(lo.D, lo.H, lo.W, u.cin, u.cout) : 0, sd = skd ? conv_wino_splitk(lo.D, lo.H, lo.W, u.cout, u.cin) : 0;
+        const bool wf = sf > 0 || conv_use_wino(CONV_K3, 0, N, lo.D, lo.H, lo.W, u.cin, u.cout);
+        const bool wd = training && (sd > 0 || conv_use_wino(CONV_K3, 0, N, lo.D, lo.H, lo.W, u.cout, u.cin));
+        if (wf) B.wpk_f[k] = T.take(conv_packed_floats(CONV_K3, u.cin, u.cout));
+        if (wd) B.wpk_d[k] = T.take(conv_packed_floats(CONV_K3, u.cout, u.cin));
+        if (training) {      // split-K partial sums (forward: [S][vox][cout], dgrad: [S][vox][cin])
+            const size_t vox = (size_t)N * lo.D * lo.H * lo.W;
+            if (sf > 1) skmax = max_sz(skmax, sf * vox * u.cout);
+            if (sd > 1) skmax = max_sz(skmax, sd * vox * u.cin);
+            if (sf > 1) statmax = max_sz(statmax, (size_t)crop_stats_parts(vox, u.cout) * u.cout * 3);
+        }
     }
+    if (skmax) B.skws = T.take(skmax);
     B.stats = T.take(statmax);
     B.small = T.take((size_t)5 * p->chan(nb - 1) + 64);   // [4][C] backward coefficients + [C] PReLU scratch
     B.bnred = T.take((size_t)BN_PRERED * p->chan(nb - 1) * 3);
@@ -463,10 +477,24 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
     const bool valid = cfg.conv_valid != 0;
     auto P = [&](int i) { return (float*)params[i]; };
 
+    // split-K of a bottom-level conv (conv_wino_splitk): training forward of units with batch statistics only (their raw output and its
+    // statistics come from the reduction pass; the eval / no-norm paths keep the fused epilogues)
+    auto fwd_split = [&](size_t k) -> int {
+        const ConvUnit& u = plan->units[k];
+        if (!(training && u.has_norm()) || valid || !B.wpk_f[k] || !B.skws) return 1;
+        const int S = conv_wino_splitk(ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cin, u.cout);
+        return S > 1 ? S : 1;
+    };
     {   // Winograd weight transforms of every layer that uses them, in one launch
         std::vector<WinoPackJob> jobs;
-        for (size_t k = 0; k < plan->units.size(); ++k)
-            if (B.wpk_f[k]) jobs.push_back({P(plan->units[k].p_w), B.wpk_f[k], plan->units[k].cout, plan->units[k].cin, 0});
+        for (size_t k = 0; k < plan->units.size(); ++k) {
+            if (!B.wpk_f[k]) continue;
+            const ConvUnit& u = plan->units[k];
+            const int S = fwd_split(k);
+            if (S == 1) { jobs.push_back({P(u.p_w), B.wpk_f[k], u.cout, u.cin, 0}); continue; }
+            for (int sp = 0; sp < S; ++sp)     // one packed weight set per share of the input channels
+                jobs.push_back({P(u.p_w), B.wpk_f[k] + sp * conv_packed_floats(CONV_K3, u.cin / S, u.cout), u.cout, u.cin, 0, sp * (u.cin / S), u.cin / S});
+        }
         if (!jobs.empty()) RUN(launch_wino_pack_multi(jobs.data(), (int)jobs.size(), s));
     }
     {   // epilogue constants of every unit that has them (eval-mode BN fold; bias fold of units without a norm), in one launch
@@ -567,7 +595,16 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
             a.stats = (bn_train && !vcrop) ? B.stats : nullptr; a.G = 1; a.flags = 0;
             parts = conv_stats_parts(kind, 0, N, ci.D, ci.H, ci.W, 2, u.cin, u.cout);
+            const int S = (kind == CONV_K3) ? fwd_split(k) : 1;
+            if (S > 1) {         // partial sums per share of the input channels, then sum + bias + statistics in one small pass
+                a.splitk = S; a.sk_x = u.cin / S; a.Cin = u.cin / S; a.sk_w = (unsigned)conv_packed_floats(CONV_K3, u.cin / S, u.cout);
+                a.sk_y = lo.vox * u.cout; a.y = B.skws; a.y_ldc = u.cout; a.bias = nullptr; a.stats = nullptr;
+            }
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(kind, a, s)); }
+            if (S > 1) {
+                RUN(launch_splitk_reduce(B.skws, S, lo.vox * u.cout, P(u.p_b), dst, dst_ldc, u.cout, lo.vox, B.stats, s));
+                parts = crop_stats_parts(lo.vox, u.cout);
+            }
         }
         if (vcrop) {        // the interior of the 'same' result is the 'valid' result (no tap of an interior voxel touches the padding)
             RUN(launch_crop_stats(B.rtmp, b.raw, u.cout, N, ci.D, ci.H, ci.W, lo.D, lo.H, lo.W, B.stats, s, ND.u[k].od, ND.u[k].oh, ND.u[k].ow));
@@ -659,10 +696,22 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         RUN(launch_colsum_finalize(B.slab, parts, ps, cfg.out_channels * C0, cfg.out_channels, G(plan->p_final_b), s));
     }
 
+    auto bwd_split = [&](int k) -> int {      // split-K of the data-gradient conv of a bottom-level unit
+        const ConvUnit& u = plan->units[k];
+        if (cfg.conv_valid || !B.wpk_d[k] || !B.skws) return 1;
+        const int S = conv_wino_splitk(ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cout, u.cin);
+        return S > 1 ? S : 1;
+    };
     {   // dgrad form of the Winograd weights of every layer, in one launch
         std::vector<WinoPackJob> jobs;
-        for (int k = 0; k < nunits; ++k)
-            if (B.wpk_d[k] && (k > 0 || dx)) jobs.push_back({P(plan->units[k].p_w), B.wpk_d[k], plan->units[k].cout, plan->units[k].cin, 1});
+        for (int k = 0; k < nunits; ++k) {
+            if (!(B.wpk_d[k] && (k > 0 || dx))) continue;
+            const ConvUnit& u = plan->units[k];
+            const int S = bwd_split(k);
+            if (S == 1) { jobs.push_back({P(u.p_w), B.wpk_d[k], u.cout, u.cin, 1}); continue; }
+            for (int sp = 0; sp < S; ++sp)     // dgrad: the GEMM-K channels are the conv's OUTPUT channels
+                jobs.push_back({P(u.p_w), B.wpk_d[k] + sp * conv_packed_floats(CONV_K3, u.cout / S, u.cin), u.cout, u.cin, 1, sp * (u.cout / S), u.cout / S});
+        }
         if (!jobs.empty()) RUN(launch_wino_pack_multi(jobs.data(), (int)jobs.size(), s));
     }
     RUN(launch_fill(B.ones, 1.f, (size_t)plan->chan(nb - 1), s));
@@ -866,7 +915,14 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.sd = 2;
             a.Cout = u.cin; a.Ncols = u.cin; a.NPad = NPad; a.G = 1;
             a.flags = (bucket_event != nullptr && event_done) ? CF_NO_PERSIST : 0;   // the gradient all-reduce may be running on some CUs
+            const int S = (kind == CONV_K3) ? bwd_split(k) : 1;
+            const size_t gvox = (size_t)N * ci.D * ci.H * ci.W;
+            if (S > 1) {
+                a.splitk = S; a.sk_x = u.cout / S; a.Cin = u.cout / S; a.sk_w = (unsigned)conv_packed_floats(CONV_K3, u.cout / S, u.cin);
+                a.sk_y = gvox * u.cin; a.y = B.skws; a.y_ldc = u.cin;
+            }
             { Prof pr(plan, s, k, 1); RUN(launch_conv_mfma(kind, a, s)); }
+            if (S > 1) RUN(launch_splitk_reduce(B.skws, S, gvox * u.cin, nullptr, out, out_ldc, u.cin, gvox, nullptr, s));
             if (k == 0) { if (cfg.in_channels > 1) RUN(launch_ndhwc_to_ncdhw(B.g1[0], cfg.in_channels, dx, N, cfg.in_channels, ND.X[0].vox / N, s)); }
             g = out; g_ldc = (to_cat && !cfg.merge_add) ? 2 * u.cout : u.cin;   // concat: the next unit (upconv) reads the first half, ldc = 2*C; add: d(up + skip) goes to both
         }

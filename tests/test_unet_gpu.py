@@ -193,7 +193,7 @@ def cfg2():
     return m, x, t
 
 
-def _train_step_vs_pytorch_rocm(m, x, t, dt=torch.float32, atol=2e-4):
+def _train_step_vs_pytorch_rocm(m, x, t, dt=torch.float32, atol=2e-4, nb=4):
     from oracle.torch_ref import combined_loss, unet_forward
     m.train()
     sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
@@ -202,7 +202,7 @@ def _train_step_vs_pytorch_rocm(m, x, t, dt=torch.float32, atol=2e-4):
     m.zero_grad(set_to_none=True)
     loss.backward()
     sd_ref = {k: (v.to(dt) if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd0.items()}
-    ref = unet_forward(sd_ref, x.to(dt), 4, (), training=True)
+    ref = unet_forward(sd_ref, x.to(dt), nb, (), training=True)
     lref = combined_loss(ref, t)
     lref.backward()
     ref = ref.float()
@@ -238,6 +238,25 @@ def test_full_size_ragged_crop_against_pytorch_rocm(cfg2):
     x = torch.randn(2, 1, 61, 131, 125, device='cuda', generator=g)
     t = (torch.rand(2, 61, 131, 125, device='cuda', generator=g) < 0.3).long()
     _train_step_vs_pytorch_rocm(m, x, t, dt=torch.float64, atol=1e-4)
+
+
+def test_split_k_bottom_level_against_fp64():
+    """Few bricks, many channels: UNet(n_blocks=2, start_filts=64) on 2 x 16x32x64 has a bottom level of 8x16x32 voxels (16 bricks per
+    sample) with 64->128 and 128->128 convs -- the Winograd kernels split the input channels over two workgroups per brick and a
+    reduction pass adds the partial sums, the bias and takes the statistics (conv_wino_splitk; forward AND data gradient).  Same
+    weights, same input, the reference's op sequence in fp64."""
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(4)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=2, start_filts=64).cuda()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if 'norm' in n and n.endswith('weight'):
+                p.copy_(1 + 0.2 * torch.randn_like(p))
+            elif n.endswith('bias'):
+                p.copy_(0.1 * torch.randn_like(p))
+    x = torch.randn(2, 1, 16, 32, 64, device='cuda')
+    t = torch.randint(0, 2, (2, 16, 32, 64), device='cuda')
+    _train_step_vs_pytorch_rocm(m, x, t, dt=torch.float64, atol=1e-4, nb=2)
 
 
 def test_full_size_cfg4_anisotropic_against_pytorch_rocm():
@@ -330,6 +349,8 @@ def test_option_variants_against_pytorch_rocm(kw):
     names = {k for k, _ in m.named_parameters()}
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))
     n_real_bias = 0
+    ref32 = None
+    act_gmax = max([float(sd_ref[k].grad.norm()) for k, _ in m.named_parameters() if '.act' in k] or [0.0])
     for k, p in m.named_parameters():
         gr = sd_ref[k].grad
         if is_prebn_bias(k, set() if group else names, paramless):
@@ -337,7 +358,19 @@ def test_option_variants_against_pytorch_rocm(kw):
             continue
         n_real_bias += k.endswith('.bias') and 'conv' in k and not k.startswith('conv_final')
         err = float((p.grad.double() - gr).norm() / gr.norm().clamp_min(1e-30))
-        assert err < 1e-2, (k, err)
+        bound = 1e-2
+        if '.act' in k:      # (scalars: judged against at least 1e-3 of the largest slope gradient of the network)
+            err = float((p.grad.double() - gr).norm() / gr.norm().clamp_min(1e-3 * act_gmax))
+        if '.act' in k and err >= bound:
+            # a PReLU slope gradient is ONE scalar, a sum over the whole tensor with heavy cancellation (|g| ~ 1e-4 of the layer's other
+            # gradients): SURVEY 8c's budget of 3 x the error of the reference's own fp32 run applies (tools/prelu_diag.py: MIOpen fp32 is
+            # 2.9e-2 off fp64 on down_convs.2.act2 of this very case, the HIP path 0.7e-2 .. 1.7e-2 depending on the conv algorithm)
+            if ref32 is None:
+                sd32 = {k2: (v.float().detach().clone().requires_grad_(v.requires_grad) if torch.is_tensor(v) and v.is_floating_point() else v) for k2, v in sd_ref.items()}
+                combined_loss(unet_forward(sd32, x, 3, pl, training=True), t).backward()
+                ref32 = sd32
+            bound = max(bound, 3 * float((ref32[k].grad.double() - gr).norm() / gr.norm().clamp_min(1e-30)))
+        assert err < bound, (k, err, bound)
     assert n_real_bias >= 3 or kw.get('normalization', 'batch') in ('batch', 'instance') and kw.get('full_norm', True)
     m.eval()
     with torch.no_grad():
