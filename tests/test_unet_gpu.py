@@ -359,8 +359,8 @@ def test_option_variants_against_pytorch_rocm(kw):
         n_real_bias += k.endswith('.bias') and 'conv' in k and not k.startswith('conv_final')
         err = float((p.grad.double() - gr).norm() / gr.norm().clamp_min(1e-30))
         bound = 1e-2
-        if '.act' in k:      # (scalars: judged against at least 1e-3 of the largest slope gradient of the network)
-            err = float((p.grad.double() - gr).norm() / gr.norm().clamp_min(1e-3 * act_gmax))
+        if '.act' in k:      # (scalars: judged against at least 1e-2 of the largest slope gradient of the network)
+            err = float((p.grad.double() - gr).norm() / gr.norm().clamp_min(1e-2 * act_gmax))
         if '.act' in k and err >= bound:
             # a PReLU slope gradient is ONE scalar, a sum over the whole tensor with heavy cancellation (|g| ~ 1e-4 of the layer's other
             # gradients): SURVEY 8c's budget of 3 x the error of the reference's own fp32 run applies (tools/prelu_diag.py: MIOpen fp32 is
