@@ -1,6 +1,6 @@
 // Direct (VALU) kernels for the two HBM-bound convolutions at the ends of the U-Net:
 //   * the first 3x3x3 / 1x3x3 conv, whose input has in_channels (1..7) channels   (unet.py:218-220, SURVEY 8d: 13 FLOP/B)
-//   * the final 1x1x1 conv C -> out_channels (<= 8)                                 (unet.py:178-180,881,912: 0.9 FLOP/B)
+//   * the final 1x1x1 conv C -> out_channels (<= 16)                                (unet.py:178-180,881,912: 0.9 FLOP/B)
 // and their gradients.  Neither has a dense contraction (K = 27 or N = 2), so they do not go to the matrix cores.
 #include "kernels.h"
 
@@ -429,7 +429,15 @@ static int final_lpv(int C) {
         case 6: { constexpr int CO = 6; __VA_ARGS__; break; } \
         case 7: { constexpr int CO = 7; __VA_ARGS__; break; } \
         case 8: { constexpr int CO = 8; __VA_ARGS__; break; } \
-        default: e3_set_error("final 1x1x1 conv supports 1..8 output channels"); return E3_ERR_UNSUPPORTED; \
+        case 9: { constexpr int CO = 9; __VA_ARGS__; break; } \
+        case 10: { constexpr int CO = 10; __VA_ARGS__; break; } \
+        case 11: { constexpr int CO = 11; __VA_ARGS__; break; } \
+        case 12: { constexpr int CO = 12; __VA_ARGS__; break; } \
+        case 13: { constexpr int CO = 13; __VA_ARGS__; break; } \
+        case 14: { constexpr int CO = 14; __VA_ARGS__; break; } \
+        case 15: { constexpr int CO = 15; __VA_ARGS__; break; } \
+        case 16: { constexpr int CO = 16; __VA_ARGS__; break; } \
+        default: e3_set_error("final 1x1x1 conv supports 1..16 output channels"); return E3_ERR_UNSUPPORTED; \
     }
 
 int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y,

@@ -113,7 +113,7 @@ struct SmallWgradFuse { const float* x1; int x1_ldc; const float* g; int g_ldc; 
 int launch_conv_small_wgrad(const float* x, int Cin, const float* dy, int dy_ldc, float* part,
                             int N, int D, int H, int W, int Cout, int planar, hipStream_t s, const SmallWgradFuse* fuse = nullptr);
 
-// final 1x1x1 conv: C (multiple of 4) -> Cout (<= 8); output and its gradient are NCDHW (the module boundary)
+// final 1x1x1 conv: C (multiple of 4) -> Cout (<= 16); output and its gradient are NCDHW (the module boundary)
 int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y_ncdhw,
                           int Cout, size_t voxels_per_sample, int N, int softmax, hipStream_t s,
                           const float* pro_scale = nullptr, const float* pro_shift = nullptr, ActArg pro_act = ActArg(0.f));   // a := act(a*scale + shift) while loading

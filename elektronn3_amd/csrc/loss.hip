@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int LOSS_MAXC = 8;
+constexpr int LOSS_MAXC = 16;
 constexpr int LOSS_BLOCKS = 1024;
 
 template <int C>
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void ce_dice_fwd_kernel(const float* __restric
     if (threadIdx.x < NV) partial[(size_t)blockIdx.x * NV + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// Sums over the block partials (fixed order, fp64): one wave per value (16 waves take the NV <= 26 values in turn), 64 lanes stride
+// Sums over the block partials (fixed order, fp64): one wave per value (16 waves take the NV <= 50 values in turn), 64 lanes stride
 // over the blocks, fp64 butterfly.
 __device__ __forceinline__ void ce_dice_reduce(const float* __restrict__ partial, int blocks, int NV, double* s) {
     const int lane = threadIdx.x & 63;
@@ -167,7 +167,15 @@ size_t ce_dice_workspace_floats(int C) { return (size_t)LOSS_BLOCKS * (2 + 3 * C
         case 6: hipLaunchKernelGGL(KERNEL<6>, dim3(LOSS_BLOCKS), dim3(256), 0, s, __VA_ARGS__); break;                    \
         case 7: hipLaunchKernelGGL(KERNEL<7>, dim3(LOSS_BLOCKS), dim3(256), 0, s, __VA_ARGS__); break;                    \
         case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(LOSS_BLOCKS), dim3(256), 0, s, __VA_ARGS__); break;                    \
-        default: e3_set_error("ce_dice: 2 <= C <= 8 classes supported"); return E3_ERR_UNSUPPORTED;                       \
+        case 9: hipLaunchKernelGGL(KERNEL<9>, dim3(LOSS_BLOCKS), dim3(256), 0, s, __VA_ARGS__); break;                   \
+        case 10: hipLaunchKernelGGL(KERNEL<10>, dim3(LOSS_BLOCKS), dim3(256), 0, s, __VA_ARGS__); break;                   \
+        case 11: hipLaunchKernelGGL(KERNEL<11>, dim3(LOSS_BLOCKS), dim3(256), 0, s, __VA_ARGS__); break;                   \
+        case 12: hipLaunchKernelGGL(KERNEL<12>, dim3(LOSS_BLOCKS), dim3(256), 0, s, __VA_ARGS__); break;                   \
+        case 13: hipLaunchKernelGGL(KERNEL<13>, dim3(LOSS_BLOCKS), dim3(256), 0, s, __VA_ARGS__); break;                   \
+        case 14: hipLaunchKernelGGL(KERNEL<14>, dim3(LOSS_BLOCKS), dim3(256), 0, s, __VA_ARGS__); break;                   \
+        case 15: hipLaunchKernelGGL(KERNEL<15>, dim3(LOSS_BLOCKS), dim3(256), 0, s, __VA_ARGS__); break;                   \
+        case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(LOSS_BLOCKS), dim3(256), 0, s, __VA_ARGS__); break;                   \
+        default: e3_set_error("ce_dice: 2 <= C <= 16 classes supported"); return E3_ERR_UNSUPPORTED;                       \
     }
 
 // workspace: [LOSS_BLOCKS][2+3C] partial sums, then the 1 + 2C backward coefficients (kept for the backward call)
@@ -192,7 +200,7 @@ int launch_ce_dice_sums(const float* logits, const long long* target, const floa
 
 int launch_ce_dice_from_sums(const double* sums, const float* w, int C, float a, float b, float eps, float smooth, float* workspace,
                              float* loss_out, hipStream_t s) {
-    if (C < 2 || C > LOSS_MAXC) { e3_set_error("ce_dice: 2 <= C <= 8 classes supported"); return E3_ERR_UNSUPPORTED; }
+    if (C < 2 || C > LOSS_MAXC) { e3_set_error("ce_dice: 2 <= C <= 16 classes supported"); return E3_ERR_UNSUPPORTED; }
     float* coef = workspace + (size_t)LOSS_BLOCKS * (2 + 3 * C);
     hipLaunchKernelGGL(ce_dice_from_sums_kernel, dim3(1), dim3(64), 0, s, sums, C, w, a, b, eps, smooth, loss_out, coef);
     E3_CHECK_HIP(hipGetLastError());

@@ -345,7 +345,7 @@ int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
     E3_REQUIRE(cfg->n_blocks >= 1 && cfg->n_blocks <= 8, E3_ERR_INVALID, "n_blocks must be in 1..8");
     E3_REQUIRE(cfg->in_channels >= 1, E3_ERR_INVALID, "in_channels must be >= 1");
     E3_REQUIRE(cfg->in_channels < 8 || cfg->in_channels % 8 == 0, E3_ERR_UNSUPPORTED, "in_channels must be < 8 or a multiple of 8");
-    E3_REQUIRE(cfg->out_channels >= 1 && cfg->out_channels <= 8, E3_ERR_UNSUPPORTED, "out_channels must be in 1..8 on the HIP path");
+    E3_REQUIRE(cfg->out_channels >= 1 && cfg->out_channels <= 16, E3_ERR_UNSUPPORTED, "out_channels must be in 1..16 on the HIP path");
     E3_REQUIRE(cfg->start_filts >= 8 && cfg->start_filts % 8 == 0, E3_ERR_UNSUPPORTED, "start_filts must be a multiple of 8 on the HIP path");
     E3_REQUIRE((cfg->start_filts << (cfg->n_blocks - 1)) <= 1024, E3_ERR_UNSUPPORTED, "more than 1024 channels at the bottom level");
     E3_REQUIRE((cfg->act_slope >= 0.f && cfg->act_slope <= 1.f) || cfg->act_slope == ACT_SILU || cfg->act_slope == ACT_PRELU, E3_ERR_INVALID,

@@ -400,7 +400,7 @@ class UNet(nn.Module):
         elif normalization not in ('batch', 'none', 'instance'): unsupported.append(f'normalization={normalization!r}')
         if conv_mode not in ('same', 'valid'): unsupported.append(f'conv_mode={conv_mode!r}')
         if start_filts % 8 != 0: unsupported.append(f'start_filts={start_filts} (must be a multiple of 8)')
-        if not (1 <= out_channels <= 8): unsupported.append(f'out_channels={out_channels} (1..8)')
+        if not (1 <= out_channels <= 16): unsupported.append(f'out_channels={out_channels} (1..16)')
         if not (in_channels < 8 or in_channels % 8 == 0): unsupported.append(f'in_channels={in_channels}')
         if unsupported:
             raise NotImplementedError('not implemented on the MI355X HIP path yet: ' + ', '.join(unsupported))

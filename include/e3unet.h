@@ -49,7 +49,7 @@ const char* e3_version(void);
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct e3_unet_cfg {
     int32_t in_channels;    /* UNet(in_channels=...)            unet.py:757 */
-    int32_t out_channels;   /* UNet(out_channels=...), 1..8     unet.py:758 */
+    int32_t out_channels;   /* UNet(out_channels=...), 1..16    unet.py:758 */
     int32_t n_blocks;       /* UNet(n_blocks=...), 1..8         unet.py:759 */
     int32_t start_filts;    /* UNet(start_filts=...), multiple of 8   unet.py:760 */
     uint32_t planar_mask;   /* bit i set <=> i in planar_blocks unet.py:763,827 */
@@ -193,7 +193,7 @@ int e3_conv1_bwd(void* stream, const float* a, int a_ldc, int C, const float* w,
 /* Criterion of the reference's training example on device:
  *   loss = ce_weight * CrossEntropyLoss(weight=w)(logits, target) + dice_weight * DiceLoss(apply_softmax=True, weight=w, smooth)(logits, target)
  * [elektronn3/modules/loss.py:19-49 CombinedLoss, :158-189 dice_loss (eps = 1e-4), :192-234 DiceLoss; examples/train_unet_neurodata.py:294-296].
- * logits/dlogits: fp32 NCDHW (N, C, D, H, W), 2 <= C <= 8; target: int64 (N, D, H, W) class indices; w: [C] or NULL (all ones).
+ * logits/dlogits: fp32 NCDHW (N, C, D, H, W), 2 <= C <= 16; target: int64 (N, D, H, W) class indices; w: [C] or NULL (all ones).
  * The forward writes the scalar loss to loss_out (device) and leaves the coefficients of the backward in `workspace`
  * (e3_ce_dice_workspace_bytes(C) bytes, to be passed unchanged to e3_ce_dice_bwd); gout: device scalar dL/dloss or NULL (= 1). */
 size_t e3_ce_dice_workspace_bytes(int C);

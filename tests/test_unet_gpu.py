@@ -259,6 +259,37 @@ def test_split_k_bottom_level_against_fp64():
     _train_step_vs_pytorch_rocm(m, x, t, dt=torch.float64, atol=1e-4, nb=2)
 
 
+def test_many_classes_against_fp64():
+    """out_channels = 12 (the head, its fused backward and the criterion are compiled for 1..16 classes): train step vs the fp64 op sequence."""
+    from elektronn3_amd.unet import UNet
+    from oracle.torch_ref import combined_loss, unet_forward
+    torch.manual_seed(6)
+    m = UNet(in_channels=1, out_channels=12, n_blocks=2, start_filts=16).cuda().train()
+    x = torch.randn(2, 1, 12, 24, 40, device='cuda')
+    t = torch.randint(0, 12, (2, 12, 24, 40), device='cuda')
+    cw = tuple(float(v) for v in (torch.rand(12) + 0.2))
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    out = m(x); loss = combined_loss(out, t, cw); loss.backward()
+    from elektronn3_amd.loss import CombinedCEDiceLoss
+    assert abs(float(CombinedCEDiceLoss(weight=cw).cuda()(out.detach(), t)) - float(loss.detach())) < 2e-6
+    sd = {k: (v.double() if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd0.items()}
+    ref = unet_forward(sd, x.double(), 2, (), training=True)
+    lref = combined_loss(ref, t, cw); lref.backward()
+    assert torch.allclose(out.double(), ref, rtol=1e-4, atol=1e-4) and abs(float(loss.detach()) - float(lref.detach())) < 1e-5
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))
+    for k, p in m.named_parameters():
+        if is_prebn_bias(k):
+            assert float(p.grad.abs().max()) <= 1e-5 * float(gn), k
+            continue
+        err = float((p.grad.double() - sd[k].grad).norm() / sd[k].grad.norm().clamp_min(1e-30))
+        assert err < 1e-2, (k, err)
+    m.eval()
+    with torch.no_grad():
+        ye = m(x)
+        sde = {k: v.double() if v.is_floating_point() else v for k, v in m.state_dict().items()}
+        assert torch.allclose(ye.double(), unet_forward(sde, x.double(), 2, (), training=False), rtol=1e-4, atol=1e-4)
+
+
 def test_full_size_cfg4_anisotropic_against_pytorch_rocm():
     """BASELINE.json configs[3] (anisotropic UNet, planar_blocks=(0,1), start_filts=64) on a 16x128x128 crop (a quarter of
     the 32x256x256 of the config in every direction: MIOpen needs minutes to pick kernels for the full size) -- mixed
@@ -563,7 +594,7 @@ dist.destroy_process_group()
 
 # ------------------------------------------------------------------------------------------------ device criterion
 @pytest.mark.gpu
-@pytest.mark.parametrize('C,shape,weighted', [(2, (2, 9, 17, 21), True), (4, (1, 8, 16, 16), True), (3, (3, 5, 6, 7), False)])
+@pytest.mark.parametrize('C,shape,weighted', [(2, (2, 9, 17, 21), True), (4, (1, 8, 16, 16), True), (3, (3, 5, 6, 7), False), (11, (2, 6, 9, 10), True), (16, (1, 4, 8, 12), False)])
 def test_ce_dice_loss_matches_reference_criterion(C, shape, weighted):
     """CombinedCEDiceLoss == 0.5*CrossEntropyLoss(w) + 0.5*DiceLoss(softmax, w) of the reference (numpy fp64 restatement
     tests/helpers.combined_loss_np for the value; PyTorch autograd of the same formula in fp64 for the gradient)."""
