@@ -187,6 +187,8 @@ bool wgrad_use_wino2d(ConvKind kind, int Cin, int Cout);
 int wgrad_wino2d_splits(int N, int D, int H, int W, int Cin, int Cout);
 int launch_wgrad_wino2d(WgradArgs a, hipStream_t s);
 // out (torch layout): transposed==0: (Cout,Cin,T) from part rows=co, cols=ci ; transposed==1: (Cin,Cout,T), part rows=ci, cols=co
+struct WgradReduceJob { const float* part; float* out; int splits, T, RPad, CPad, R, C; };
+int launch_wgrad_reduce_multi(const WgradReduceJob* jobs, int njobs, hipStream_t s);   // many slab reductions in one launch (same results)
 int launch_wgrad_reduce(const float* part, float* out, int splits, int T, int RPad, int CPad, int R, int C, hipStream_t s);
 
 // ---------------------------------------------------------------- batch-norm / relu / pool (HBM-bound elementwise)

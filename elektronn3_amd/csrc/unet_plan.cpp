@@ -164,6 +164,7 @@ struct Buffers {
     float* ones; float* zeros;                                                 // [Cmax] / [2*Cmax] constants for units without a norm
     std::vector<float*> ups;             // ResizeConv units: the up-sampled input [N, sd*D', 2H', 2W', Cin] (kept for the weight gradient)
     float* wemb; float* gemb;            // ResizeConv(kernel_size=1): weights / weight gradient embedded as the centre tap of a 27-tap kernel
+    std::vector<float*> slab_u;          // per unit: own wgrad slab where the slab reduction is deferred to ONE launch (nullptr: B.slab, reduced on the spot)
     float* skws = nullptr;               // split-K partial sums of the bottom-level convs (training only)
     float* rtmp; float* rpad; float* rdu; // ResizeConv scratch: conv output / padded gradient at the up-sampled size, gradient of the up-sampled input
     float* biaspart0;                    // [splits][Cout] conv-bias gradient partials of the first conv when its BN backward is fused into its wgrad
@@ -221,6 +222,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     B.saved_bytes = S.off;
     // scratch
     size_t wmax = 0, statmax = 0, slabmax = 0, bnpartmax = 0, rtmpmax = 0, rdumax = 0;
+    std::vector<size_t> slab_own(p->units.size(), 0);     // slab of a unit whose reduction can be deferred (transposed conv, plain conv with cin >= 8)
     for (size_t k = 0; k < p->units.size(); ++k) {
         const ConvUnit& u = p->units[k];
         const LevelDims& lo = ND.u[k].out;
@@ -244,14 +246,14 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
             const LevelDims& li = ND.u[k].in;
             wmax = max_sz(wmax, max_sz((size_t)pad_cols(taps * u.cout) * u.cin, (size_t)taps * pad_cols(u.cin) * u.cout));
             statmax = max_sz(statmax, (size_t)conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, li.D, li.H, li.W, sd, u.cin, taps * u.cout) * u.cout * 3);
-            if (training) slabmax = max_sz(slabmax, (size_t)wgrad_splits(CONV_POINT, N, li.D, li.H, li.W, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32));
+            if (training) { slab_own[k] = (size_t)wgrad_splits(CONV_POINT, N, li.D, li.H, li.W, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32); slabmax = max_sz(slabmax, slab_own[k]); }
         } else {
             const int taps = u.planar ? 9 : 27;
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             if (u.cin >= 8) {
                 wmax = max_sz(wmax, max_sz(conv_packed_floats(kind, u.cin, u.cout), conv_packed_floats(kind, u.cout, u.cin)));
                 statmax = max_sz(statmax, (size_t)conv_stats_parts(kind, 0, N, ci.D, ci.H, ci.W, 2, u.cin, u.cout) * u.cout * 3);
-                if (training) slabmax = max_sz(slabmax, (size_t)wgrad_splits(kind, N, ci.D, ci.H, ci.W, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32));
+                if (training) { slab_own[k] = (size_t)wgrad_splits(kind, N, ci.D, ci.H, ci.W, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32); slabmax = max_sz(slabmax, slab_own[k]); }
             } else {
                 wmax = max_sz(wmax, conv_packed_floats(kind, u.cout, u.cin));   // only its dgrad (dx requested) packs weights
                 statmax = max_sz(statmax, (size_t)conv_small_stats_parts(N, ci.D, ci.H, ci.W, u.planar) * u.cout * 3);
@@ -306,6 +308,10 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
             B.bnpart_u[k] = T.take((size_t)bn_bwd_parts(ND.u[k].out.vox, p->units[k].cout) * 3 * p->units[k].cout);
         B.bnpart = T.take(bnpartmax);
         B.slab = T.take(slabmax);
+        static const bool batch_reduce = getenv("E3_NO_REDUCE_BATCH") == nullptr;
+        B.slab_u.assign(p->units.size(), nullptr);
+        for (size_t k = 0; batch_reduce && k < p->units.size(); ++k)
+            if (slab_own[k]) B.slab_u[k] = T.take(slab_own[k]);
         for (int j = 0; j < nb; ++j) {
             const size_t n = ND.X[j].vox * p->chan(j);        // the level's input grid is its largest
             B.g1[j] = T.take(n); B.g2[j] = T.take(n);
@@ -719,6 +725,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
     // ---- walk the units backwards.  `g` = gradient w.r.t. the current unit's activation.
     const float* g = B.g1[0]; int g_ldc = C0;
     bool event_done = bucket_event == nullptr;
+    std::vector<WgradReduceJob> wred_jobs;   // slab reductions of the weight gradients (units with their own slab), flushed in one launch
     std::vector<ColsumJob> bias_jobs;     // conv-bias gradients (column sums of the apply pass' partials), flushed in one launch
     for (int k = nunits - 1; k >= 0; --k) {
         const ConvUnit& u = plan->units[k];
@@ -735,6 +742,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             const int blk = j;   // encoder block index == level
             if (is_enc_conv2 && blk == bucket_after_down_block - 1) {
                 if (!bias_jobs.empty()) { RUN(launch_colsum_multi(bias_jobs.data(), (int)bias_jobs.size(), s)); bias_jobs.clear(); }   // the bucket's gradients must be final
+                if (!wred_jobs.empty()) { RUN(launch_wgrad_reduce_multi(wred_jobs.data(), (int)wred_jobs.size(), s)); wred_jobs.clear(); }
                 E3_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_event, s)); event_done = true;
             }
         }
@@ -842,12 +850,13 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             const LevelDims& li = ND.u[k].in;
             const int sd = u.planar ? 1 : 2;
             WgradArgs a{};
-            a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dxr; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = B.slab;
+            a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dxr; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = B.slab_u[k] ? B.slab_u[k] : B.slab;
             a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = sd;
             a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
             a.splits = wgrad_splits(CONV_POINT, N, li.D, li.H, li.W, u.cin, u.cout);
             { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(CONV_POINT, a, s)); }
-            RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, sd * 4, a.CiPad, a.CoPad, u.cin, u.cout, s));
+            if (B.slab_u[k]) wred_jobs.push_back({a.part, G(u.p_w), a.splits, sd * 4, a.CiPad, a.CoPad, u.cin, u.cout});
+            else RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, sd * 4, a.CiPad, a.CoPad, u.cin, u.cout, s));
         } else if (u.cin < 8) {
             const int taps = u.planar ? 9 : 27;
             const int splits = conv_small_wgrad_splits(N, ci.D, ci.H, ci.W, u.planar);
@@ -857,11 +866,12 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             const int taps = u.planar ? 9 : 27;
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             WgradArgs a{};
-            a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dyu; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = B.slab;
+            a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dyu; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = B.slab_u[k] ? B.slab_u[k] : B.slab;
             a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
             a.splits = wgrad_splits(kind, N, ci.D, ci.H, ci.W, u.cin, u.cout);
             { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(kind, a, s)); }
-            RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
+            if (B.slab_u[k]) wred_jobs.push_back({a.part, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin});
+            else RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
         }
         // -- data gradient -> g for the previous unit
         if (k == 0 && !dx) break;
@@ -928,6 +938,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
         }
     }
     if (!bias_jobs.empty()) RUN(launch_colsum_multi(bias_jobs.data(), (int)bias_jobs.size(), s));
+    if (!wred_jobs.empty()) RUN(launch_wgrad_reduce_multi(wred_jobs.data(), (int)wred_jobs.size(), s));
     if (!event_done) E3_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_event, s));
     return E3_OK;
 }

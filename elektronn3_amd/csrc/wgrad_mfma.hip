@@ -195,15 +195,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_point_kernel(const WgradArgs a, 
 // thread = (output quad of 4 consecutive c, split group g of G): 16-B loads, 8 of them in flight, double accumulation in a fixed
 // order (k = g, g + G, ... then the G partial sums in order through LDS) => bit-reproducible.  G (a power of two <= 64) is chosen by
 // the launcher so that small layers (27 x 32 x 32 outputs, 256 slabs) still spread over the chip.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int splits, int T,
-                                                           int RPad, int CPad, int R, int C, int G, int lgG) {
-    __shared__ double red[256][4];
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ out, int splits, int T,
+                                                  int RPad, int CPad, int R, int C, int G, int lgG, unsigned block, double (*red)[4]) {
     const int cq = (C + 3) >> 2;                       // quads per row
     const size_t slab = (size_t)T * RPad * CPad;
     const size_t nquads = (size_t)T * R * cq;
     const int g = threadIdx.x & (G - 1);
     const int qpb = 256 >> lgG;                        // quads per block
-    const size_t quad = (size_t)blockIdx.x * qpb + (threadIdx.x >> lgG);
+    const size_t quad = (size_t)block * qpb + (threadIdx.x >> lgG);
     const bool on = quad < nquads;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     int c0 = 0, r = 0, t = 0;
@@ -240,6 +239,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         for (int e = 0; e < 4; ++e)
             if (c0 + e < C) out[((size_t)r * C + c0 + e) * T + t] = (float)acc[e];
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int splits, int T,
+                                                           int RPad, int CPad, int R, int C, int G, int lgG) {
+    __shared__ double red[256][4];
+    wgrad_reduce_body(part, out, splits, T, RPad, CPad, R, C, G, lgG, blockIdx.x, red);
+}
+
+// the reductions of many layers in ONE launch (each alone is a latency-bound 5..9 us kernel between two big ones: 16 per training step);
+// workgroup -> job by binary search over the block prefix.  Same arithmetic and order per output as wgrad_reduce_kernel.
+constexpr int WRED_MAX_JOBS = 32;
+struct WgradReduceMultiArgs {
+    const float* part[WRED_MAX_JOBS]; float* out[WRED_MAX_JOBS];
+    int splits[WRED_MAX_JOBS], T[WRED_MAX_JOBS], RPad[WRED_MAX_JOBS], CPad[WRED_MAX_JOBS], R[WRED_MAX_JOBS], C[WRED_MAX_JOBS];
+    signed char lg[WRED_MAX_JOBS];
+    int bstart[WRED_MAX_JOBS + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WgradReduceMultiArgs a) {
+    __shared__ double red[256][4];
+    const int b = blockIdx.x;
+    int lo = 0, hi = a.n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.bstart[mid] <= b) lo = mid; else hi = mid; }
+    const int j = lo;
+    wgrad_reduce_body(a.part[j], a.out[j], a.splits[j], a.T[j], a.RPad[j], a.CPad[j], a.R[j], a.C[j], 1 << a.lg[j], a.lg[j], (unsigned)(b - a.bstart[j]), red);
 }
 
 // rows that are not a multiple of 4 floats (first conv: CPad = in_channels): same scheme with one element per thread; a slab is
@@ -332,6 +356,34 @@ int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s) {
         }
     }
     E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+static void wgrad_reduce_shape(size_t items, int splits, int& lg, size_t& blocks) {
+    int G = 1; lg = 0;                                  // threads per item: enough for ~64 K threads, never more than the splits
+    while (G < 64 && (size_t)G * items < 65536 && 2 * G <= splits) { G *= 2; ++lg; }
+    const size_t ipb = 256 >> lg;
+    blocks = (items + ipb - 1) / ipb;
+}
+
+int launch_wgrad_reduce_multi(const WgradReduceJob* jobs, int njobs, hipStream_t s) {
+    for (int j0 = 0; j0 < njobs; j0 += WRED_MAX_JOBS) {
+        WgradReduceMultiArgs a;
+        a.n = njobs - j0 < WRED_MAX_JOBS ? njobs - j0 : WRED_MAX_JOBS;
+        size_t b = 0;
+        for (int j = 0; j < a.n; ++j) {
+            const WgradReduceJob& q = jobs[j0 + j];
+            E3_REQUIRE(q.CPad % 4 == 0, E3_ERR_INVALID, "wgrad_reduce_multi: rows must be multiples of 4 floats");
+            int lg; size_t blocks;
+            wgrad_reduce_shape((size_t)q.T * q.R * ((q.C + 3) / 4), q.splits, lg, blocks);
+            a.part[j] = q.part; a.out[j] = q.out; a.splits[j] = q.splits; a.T[j] = q.T; a.RPad[j] = q.RPad; a.CPad[j] = q.CPad; a.R[j] = q.R; a.C[j] = q.C;
+            a.lg[j] = (signed char)lg; a.bstart[j] = (int)b;
+            b += blocks;
+        }
+        a.bstart[a.n] = (int)b;
+        if (b > 0) hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)b), dim3(256), 0, s, a);
+        E3_CHECK_HIP(hipGetLastError());
+    }
     return E3_OK;
 }
 

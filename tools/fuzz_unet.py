@@ -115,6 +115,8 @@ for case in range(n_cases):
         prebn = is_prebn_bias(k, set() if group else names, paramless)
         if group and p.numel() == sd_ref['__num_groups__'] and is_prebn_bias(k, names, paramless):
             prebn = True        # groups of ONE channel: GroupNorm removes the channel's own mean, the bias gradient is analytically zero
+        if float(gr.norm()) < 1e-10 * gn:
+            prebn = True        # analytically zero in fp64 (e.g. a norm bias whose shift the next norm removes through an identity activation): absolute tolerance
         floor = 1e-4 * gn
         if '.act' in k:     # a PReLU slope gradient is ONE scalar (a sum over the tensor with heavy cancellation): judged against at least
             floor = max(floor, (1e-1 if margin[0] < FLIP else 1e-3) * act_gmax)     # 1e-3 of the largest slope gradient of the network (as tests/test_unet_gpu.py does);
