@@ -725,7 +725,17 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
     // ---- walk the units backwards.  `g` = gradient w.r.t. the current unit's activation.
     const float* g = B.g1[0]; int g_ldc = C0;
     bool event_done = bucket_event == nullptr;
-    std::vector<WgradReduceJob> wred_jobs;   // slab reductions of the weight gradients (units with their own slab), flushed in one launch
+    std::vector<WgradReduceJob> wred_jobs;   // slab reductions of the weight gradients (units with their own slab), several per launch
+    size_t wred_bytes = 0;                   // pending slab bytes (E3_REDUCE_BATCH_MB: flush earlier; measured 48/96/160 MB: no better than one launch)
+    static const size_t wred_limit = getenv("E3_REDUCE_BATCH_MB") ? (size_t)atol(getenv("E3_REDUCE_BATCH_MB")) << 20 : ~(size_t)0;
+    auto wred_push = [&](const WgradReduceJob& j) -> int {
+        wred_jobs.push_back(j);
+        wred_bytes += (size_t)j.splits * j.T * j.RPad * j.CPad * 4;
+        if (wred_bytes < wred_limit) return E3_OK;
+        const int rc = launch_wgrad_reduce_multi(wred_jobs.data(), (int)wred_jobs.size(), s);
+        wred_jobs.clear(); wred_bytes = 0;
+        return rc;
+    };
     std::vector<ColsumJob> bias_jobs;     // conv-bias gradients (column sums of the apply pass' partials), flushed in one launch
     for (int k = nunits - 1; k >= 0; --k) {
         const ConvUnit& u = plan->units[k];
@@ -742,7 +752,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             const int blk = j;   // encoder block index == level
             if (is_enc_conv2 && blk == bucket_after_down_block - 1) {
                 if (!bias_jobs.empty()) { RUN(launch_colsum_multi(bias_jobs.data(), (int)bias_jobs.size(), s)); bias_jobs.clear(); }   // the bucket's gradients must be final
-                if (!wred_jobs.empty()) { RUN(launch_wgrad_reduce_multi(wred_jobs.data(), (int)wred_jobs.size(), s)); wred_jobs.clear(); }
+                if (!wred_jobs.empty()) { RUN(launch_wgrad_reduce_multi(wred_jobs.data(), (int)wred_jobs.size(), s)); wred_jobs.clear(); wred_bytes = 0; }
                 E3_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_event, s)); event_done = true;
             }
         }
@@ -855,7 +865,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
             a.splits = wgrad_splits(CONV_POINT, N, li.D, li.H, li.W, u.cin, u.cout);
             { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(CONV_POINT, a, s)); }
-            if (B.slab_u[k]) wred_jobs.push_back({a.part, G(u.p_w), a.splits, sd * 4, a.CiPad, a.CoPad, u.cin, u.cout});
+            if (B.slab_u[k]) RUN(wred_push({a.part, G(u.p_w), a.splits, sd * 4, a.CiPad, a.CoPad, u.cin, u.cout}));
             else RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, sd * 4, a.CiPad, a.CoPad, u.cin, u.cout, s));
         } else if (u.cin < 8) {
             const int taps = u.planar ? 9 : 27;
@@ -870,7 +880,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
             a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
             a.splits = wgrad_splits(kind, N, ci.D, ci.H, ci.W, u.cin, u.cout);
             { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(kind, a, s)); }
-            if (B.slab_u[k]) wred_jobs.push_back({a.part, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin});
+            if (B.slab_u[k]) RUN(wred_push({a.part, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin}));
             else RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
         }
         // -- data gradient -> g for the previous unit
