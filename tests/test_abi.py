@@ -85,3 +85,32 @@ def test_unsupported_config_is_reported():
     plan = ctypes.c_void_p()
     with pytest.raises(NotImplementedError):
         _lib.check(lib.e3_unet_plan_create(ctypes.byref(cfg), ctypes.byref(plan)))
+
+
+def test_optimizer_and_criterion_host_logic_fails_loudly_without_a_gpu():
+    """Host side of elektronn3_amd.optim.SWA / AdamW and the criterion: the reference wrapper's argument validation (training/swa.py:88-112)
+    and NO CPU path -- CPU tensors raise instead of silently computing somewhere else."""
+    import pytest
+    import torch
+    from elektronn3_amd.loss import CombinedCEDiceLoss
+    from elektronn3_amd.optim import SWA, AdamW
+    p = torch.nn.Parameter(torch.randn(5))
+    with pytest.raises(ValueError):
+        SWA(torch.optim.SGD([p], lr=0.1), swa_start=-1, swa_freq=2)
+    with pytest.raises(ValueError):
+        SWA(torch.optim.SGD([p], lr=0.1), swa_start=1, swa_freq=0)
+    with pytest.raises(ValueError):
+        SWA(torch.optim.SGD([p], lr=0.1), swa_start=1, swa_freq=2, swa_lr=-0.1)
+    with pytest.warns(UserWarning):
+        manual = SWA(torch.optim.SGD([p], lr=0.1), swa_start=3)          # only one of the two given: manual mode
+    assert not manual._auto_mode and manual.swa_start is None and manual.param_groups[0]['n_avg'] == 0
+    auto = SWA(torch.optim.SGD([p], lr=0.1), swa_start=1, swa_freq=1)
+    p.grad = torch.ones(5)
+    auto.step()                                      # step 1: not yet averaging (steps > swa_start)
+    assert auto.param_groups[0]['step_counter'] == 1 and 'swa_buffer' not in auto.state[p]
+    with pytest.raises(RuntimeError):
+        auto.step()                                  # step 2 averages: CPU parameters have no path
+    with pytest.raises(RuntimeError):
+        opt = AdamW([p]); opt.step()
+    with pytest.raises(ValueError):
+        CombinedCEDiceLoss(weight=[0.3, 0.7])(torch.randn(1, 2, 4, 4, 4), torch.zeros(1, 4, 4, 4, dtype=torch.int64))
