@@ -89,6 +89,13 @@ def _worker(rank, world, port, tmp):
         locs = [None] * world
         dist.all_gather_object(locs, local)
         assert abs(sum(locs) / world - want) > 1e-4           # the difference the sharded mode removes
+        # the module's own hooks for that exchange (the device kernels around them are covered by the GPU tests)
+        from elektronn3_amd.loss import CombinedCEDiceLoss
+        crit = CombinedCEDiceLoss(weight=cw, global_batch=True)
+        assert crit._world() == world and crit.grads_averaged
+        mine = torch.arange(8, dtype=torch.float64) + 10 * rank
+        assert torch.equal(crit._reduce_sums(mine.clone()), sum(torch.arange(8, dtype=torch.float64) + 10 * r for r in range(world)))
+        assert CombinedCEDiceLoss(weight=cw)._world() == world and not CombinedCEDiceLoss(weight=cw).global_batch
         open(os.path.join(tmp, f'ok{rank}'), 'w').write('ok')
     finally:
         dist.destroy_process_group()
