@@ -40,18 +40,21 @@ class GradSync:
 
     # -- called from _UNetFunction.backward ------------------------------------------------------------------
     def flat_views(self, plan, tens):
+        # A FRESH flat buffer per backward (the caching allocator makes that free): autograd keeps the returned views by reference
+        # (InputBuffer of a parameter fed by several Function nodes -- one native call per sample with instance / group norm -- and
+        # AccumulateGrad, which may adopt a view as p.grad when gradients are accumulated over several backward passes), so a
+        # persistent buffer would be overwritten under them.
         dev = tens[0].device
-        if self._flat is None or self._flat.device != dev:
-            sizes = [t.numel() if k == 0 else 0 for t, k in zip(tens, plan.kinds)]
-            self._flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-            self._views, off, split = [], 0, 0
-            prefixes = tuple(f'down_convs.{i}.' for i in range(self.bucket_after_down_block))
-            for name, n in zip(plan.names, sizes):
-                self._views.append(self._flat[off:off + n] if n else None)
-                off += n
-                if prefixes and name.startswith(prefixes):
-                    split = off          # table order == forward order: the first encoder blocks are a prefix
-            self._split = split
+        sizes = [t.numel() if k == 0 else 0 for t, k in zip(tens, plan.kinds)]
+        self._flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        self._views, off, split = [], 0, 0
+        prefixes = tuple(f'down_convs.{i}.' for i in range(self.bucket_after_down_block))
+        for name, n in zip(plan.names, sizes):
+            self._views.append(self._flat[off:off + n] if n else None)
+            off += n
+            if prefixes and name.startswith(prefixes):
+                split = off          # table order == forward order: the first encoder blocks are a prefix
+        self._split = split
         return self._flat, self._views
 
     def bucket_event(self):
@@ -85,7 +88,9 @@ class GradSync:
         for w in works:                                    # stream-level wait: `cur` resumes after the collectives
             if w is not None:
                 w.wait()
-        a.record_stream(self._comm_stream)
+        if any(w is None for w in works):                  # (non-RCCL backends: the average's division ran on the side stream)
+            cur.wait_stream(self._comm_stream)
+        flat.record_stream(self._comm_stream)
 
     # -- helpers -----------------------------------------------------------------------------------------------
     def _allreduce(self, t, async_op=False):

@@ -80,7 +80,10 @@ class AdamW(torch.optim.Optimizer):
     def state_dict(self):
         sd = super().state_dict()
         # the live 'step' entries are views of ONE device counter per group; a stock torch.optim.AdamW that loads this dict
-        # increments every parameter's step tensor on its own, so hand out independent CPU scalars (torch's default layout)
+        # increments every parameter's step tensor on its own, so hand out independent CPU scalars (torch's default layout).
+        # super().state_dict() returns the LIVE per-parameter dicts: edit shallow copies, never self.state itself (a second
+        # state_dict() call must read the device counter again, not the scalar of the first one)
+        sd['state'] = {k: dict(v) for k, v in sd['state'].items()}
         for st in sd['state'].values():
             if 'step' in st:
                 st['step'] = torch.tensor(float(st['step']), dtype=torch.float32)

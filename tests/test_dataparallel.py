@@ -33,6 +33,10 @@ def _worker(rank, world, port, tmp):
         n_prefix = sum(p.numel() for n, p in model.named_parameters() if n.startswith(('down_convs.0.', 'down_convs.1.')))
         assert sync._split == n_prefix and 0 < sync._split < flat.numel()
         assert sum(v.numel() for v in views if v is not None) == sum(p.numel() for p in model.parameters()) == flat.numel()
+        # every backward gets its own buffer (autograd may keep views of the previous one: per-sample norms, gradient accumulation)
+        flat_prev = flat
+        flat, views = sync.flat_views(plan, tens)
+        assert flat.data_ptr() != flat_prev.data_ptr()
         # rank-dependent "gradients"
         g = torch.Generator().manual_seed(100 + rank)
         local = torch.randn(flat.numel(), generator=g)

@@ -103,6 +103,25 @@ def test_state_dict_round_trip_with_stock_optimizer():
             torch.testing.assert_close(a, b, rtol=5e-6, atol=2e-7)
 
 
+def test_state_dict_reads_the_live_step_every_time():
+    """state_dict() must not replace the live device step counter by the scalar of the first call: periodic checkpoints each record
+    their own step, and the optimizer keeps counting."""
+    torch.manual_seed(5)
+    ps = [torch.nn.Parameter(torch.randn(33, device='cuda')), torch.nn.Parameter(torch.randn(4, 5, device='cuda'))]
+    opt = _opt(ps, lr=1e-3)
+    seen = []
+    for t in range(1, 6):
+        for p in ps: p.grad = torch.randn_like(p)
+        opt.step()
+        if t in (2, 3, 5):
+            sd = opt.state_dict()
+            seen.append((t, [float(st['step']) for st in sd['state'].values()]))
+    for t, steps in seen:
+        assert steps == [float(t)] * len(ps), (t, steps)
+    assert all(float(opt.state[p]['step']) == 5.0 for p in ps)          # the live state is still the device counter
+    assert all(opt.state[p]['step'].is_cuda for p in ps)
+
+
 def test_grad_scaler_unscale_and_skip():
     """GradScaler.step(optimizer): gradients arrive multiplied by the scale; an inf anywhere vetoes the whole step."""
     torch.manual_seed(4)
