@@ -1,27 +1,33 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: 3D U-Net training step (forward + backward) on synthetic 64x128x128 crops.
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (for N > 1 launched by
-``python -m torch.distributed.run --nproc-per-node N``), prints ONE JSON line on rank 0.
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.  For N > 1 the driver launches
+it under ``python -m torch.distributed.run --nproc-per-node N``; called directly with ``--gpus N`` (no WORLD_SIZE in the
+environment) it re-executes itself under that launcher, so ``python bench.py --gpus 8`` never silently benches one GPU.
 
-Workload = BASELINE.json configs[1]: ``UNet(in=1, out=2, n_blocks=4, start_filts=32, normalization='batch')``, fp32,
-batch 2 per GPU of 1x64x128x128 crops (N > 1: the same per-GPU batch on every rank = weak scaling, gradients
-all-reduced with RCCL on a side stream overlapped with the backward).  A step is forward + loss + backward
-(+ gradient all-reduce); the optimizer is excluded.  Inputs are resident in HBM before the timed region.
+Workload = BASELINE.json configs[1]: ``UNet(in=1, out=2, n_blocks=4, start_filts=32, normalization='batch')``, fp32, batch 2 per
+GPU of 1x64x128x128 crops (N > 1: the same per-GPU batch on every rank = weak scaling, gradients all-reduced with RCCL on a side
+stream overlapped with the backward).  ``--dtype bf16`` runs configs[2]'s per-GPU workload instead: the same module cast with
+``.to(torch.bfloat16)``, bf16 crops, native bf16 kernels.  A step is forward + loss + backward (+ gradient all-reduce); the
+optimizer is excluded.  Inputs are resident in HBM before the timed region.
 
 Extra objects on the JSON line:
-  roofline      the conv of the heaviest layer (up_convs.2.conv1, 64->32 at full resolution): ALGORITHMIC flops per launch
-                (direct-convolution count 2*Cin*Cout*27 per voxel) / mean launch time measured with HIP
-                events on the compute stream INSIDE the timed steps (e3_unet_profile_*), against the 157.3 TFLOP/s fp32
-                matrix peak.  The forward/dgrad kernel is Winograd F(2x2x2,3x3x3): it EXECUTES 64/216 of those flops on
-                the matrix cores, so `frac` can exceed 1; `mfma_executed` reports the executed matrix flops against
-                the same peak.  wgrad (direct implicit GEMM) executes exactly the algorithmic count.
-  cpu_baseline  the reference's ATen op sequence (oracle/torch_ref.py) on the host cores, rank 0, N=1 only.
+  roofline      the forward conv of the heaviest layer (up_convs.2.conv1, 64->32 at full resolution), timed with HIP events on the
+                compute stream INSIDE the timed steps (e3_unet_profile_*).  `achieved` = EXECUTED matrix TFLOP/s and `frac` =
+                achieved / dense MFMA peak of the dtype (fp32: the Winograd F(2x2x2,3x3x3) kernel executes 64/216 of the direct
+                convolution's multiplies; bf16: direct implicit GEMM, executed == algorithmic).  `algorithmic_tflops` (SURVEY 8d's
+                2*Cin*Cout*27 per voxel / time) and `hbm_frac` (SURVEY 8d's layer bytes / time / 8 TB/s) are flat keys beside it.
+                `traffic` = HBM bytes per launch from the rocprofv3 PMC passes recorded in the file `traffic_source` names.
+  cpu_baseline  the reference's ATen op sequence (oracle/torch_ref.py) on the host cores, rank 0, N = 1 only: BASELINE.md section 3's
+                protocol (one cfg-2 sample, 1 warm-up + 3 timed forward+backward iterations).
+  predictor     BASELINE's second metric ("Predictor MVox/s", configs[4]): N = 1: the FULL 512x2048x2048 volume (726 tiles);
+                N > 1: tile-parallel over the ranks on a 288x1152x1152 sub-volume.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import torch
@@ -31,24 +37,21 @@ sys.path.insert(0, ROOT)
 
 CROP = (64, 128, 128)
 BATCH_PER_GPU = 2
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-FWD_FLOP_PER_VOXEL = 427.2e3    # SURVEY.md 8d (cfg 2 network)
-FWDBWD_FLOP_PER_VOXEL = 1279.9e3
+MFMA_PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16, dense
+HBM_PEAK = 8.0e12                                    # B/s (spec)
+FWDBWD_FLOP_PER_VOXEL = 1279.9e3                     # SURVEY.md 8d (cfg 2 network)
+PMC_FILE = os.path.join('profiles', 'r02_pmc_roofline.json')
 
 
-def conv_flops(cin, cout, taps, voxels):
-    return 2.0 * cin * cout * taps * voxels
-
-
-def cpu_baseline(iters=2):
+def cpu_baseline(iters=3):
     """The reference's CPU PyTorch path (same ATen op sequence, oracle/torch_ref.py) timed on this box's host cores."""
     from oracle.torch_ref import combined_loss, unet_forward
     from elektronn3_amd.unet import UNet
     torch.manual_seed(0)
     m = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=32)
     sd = {k: v.clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in m.state_dict().items()}
-    x = torch.randn(BATCH_PER_GPU, 1, *CROP)
-    t = torch.randint(0, 2, (BATCH_PER_GPU, *CROP))
+    x = torch.randn(1, 1, *CROP)
+    t = torch.randint(0, 2, (1, *CROP))
     times = []
     for i in range(iters + 1):
         t0 = time.time()
@@ -60,16 +63,16 @@ def cpu_baseline(iters=2):
         times.append(time.time() - t0)
     dt = sum(times[1:]) / iters
     return {'value': x.numel() / dt, 'unit': 'voxels/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'full cfg-2 batch ({BATCH_PER_GPU}x1x{"x".join(map(str, CROP))}) fp32 fwd+bwd, 1 warm-up + {iters} timed iterations '
-                      f'of the reference\'s ATen op sequence (oracle/torch_ref.py) with torch {torch.__version__} on the host CPU',
+            'sample': f'one cfg-2 sample (1x1x{"x".join(map(str, CROP))}) fp32 fwd+bwd, 1 warm-up + {iters} timed iterations (BASELINE.md section 3) '
+                      f'of the reference\'s ATen op sequence (oracle/torch_ref.py) with torch {torch.__version__} on the host CPU '
+                      f'({os.cpu_count()} logical cores)',
             's_per_step': dt}
 
 
-def predictor_leg(dev, shape=(288, 1152, 1152), tile=(96, 192, 192), overlap=(16, 16, 16), tile_parallel=False):
-    """BASELINE.json's second metric ("Predictor MVox/s", configs[4]) on the cfg-5 geometry -- tile 96x192x192, overlap 16, eval-mode
-    UNet(n_blocks=4, start_filts=32), softmax output, fp32 volume in HOST memory, result back in host memory -- over a
-    288x1152x1152 sub-volume (108 tiles) so that the default bench run stays short; tools/bench_predictor.py runs the full
-    512x2048x2048 volume (726 tiles).  Input voxels / predict() wall time incl. H2D and D2H (benchmark/pred_benchmark.py:101)."""
+def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_parallel=False):
+    """BASELINE.json's second metric ("Predictor MVox/s", configs[4]): tile 96x192x192, overlap 16, eval-mode UNet(n_blocks=4,
+    start_filts=32), softmax output, fp32 volume in HOST memory, result back in host memory.  Input voxels / predict() wall time
+    incl. H2D and D2H (benchmark/pred_benchmark.py:101)."""
     from elektronn3_amd.inference import Predictor
     from elektronn3_amd.unet import UNet
     torch.manual_seed(0)
@@ -78,7 +81,10 @@ def predictor_leg(dev, shape=(288, 1152, 1152), tile=(96, 192, 192), overlap=(16
     with torch.no_grad():                    # running statistics from 10 warm-up batches (SURVEY 8d cfg 5)
         for _ in range(10):
             model(torch.randn(2, 1, 32, 64, 64, device=dev))
-    vol = torch.randn(1, 1, *shape, generator=torch.Generator().manual_seed(0))
+    vol = torch.empty(1, 1, *shape)
+    gen = torch.Generator().manual_seed(0)
+    for z in range(0, shape[0], 32):         # per-slab generation
+        vol[0, 0, z:z + 32].normal_(generator=gen)
     Predictor(model, device=dev, apply_softmax=True).predict(torch.randn(1, 1, *[t + 2 * o for t, o in zip(tile, overlap)]))   # warm-up tile
     pred = Predictor(model, device=dev, tile_shape=tile, overlap_shape=overlap, offset=None, out_shape=(2, *shape), apply_softmax=True,
                      strict_shapes=False, tile_parallel=tile_parallel)
@@ -89,10 +95,26 @@ def predictor_leg(dev, shape=(288, 1152, 1152), tile=(96, 192, 192), overlap=(16
     ntiles = 1
     for n, t in zip(shape, tile):
         ntiles *= -(-n // t)
+    tile_in = [t + 2 * o for t, o in zip(tile, overlap)]
+    tile_flop = 427.2e3 * tile_in[0] * tile_in[1] * tile_in[2]            # forward FLOP per tile incl. halo (2744 GFLOP)
     return {'metric': 'Predictor MVox/s', 'value': vol.numel() / dt / 1e6, 'unit': 'MVox/s (input voxels / predict() wall time incl. H2D + D2H)',
             'seconds': dt, 'volume': list(shape), 'tile': list(tile), 'overlap': list(overlap), 'tiles': ntiles, 'dtype': 'f32',
             'finite': bool(torch.isfinite(out[..., ::32, ::32]).all()),
-            'note': 'cfg-5 geometry on a sub-volume; the full 512x2048x2048 volume (726 tiles): tools/bench_predictor.py, DESIGN.md section 5'}
+            'algorithmic_tflops': ntiles * tile_flop / dt / 1e12,
+            'mfma_executed_frac': ntiles * tile_flop * (64.0 / 216.0) / dt / 1e12 / MFMA_PEAK_TFLOPS['f32'],
+            'note': 'executed fraction = Winograd-executed matrix FLOP (64/216 of the algorithmic count) / wall time incl. PCIe / fp32 MFMA peak'}
+
+
+def respawn_under_launcher(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: run the same command one process per GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.execv(sys.executable, cmd)
 
 
 def main():
@@ -100,14 +122,20 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32', help='f32 = BASELINE configs[1] (the metric\'s config); bf16 = configs[2] per-GPU workload')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-predictor', action='store_true', help='skip the Predictor MVox/s leg (N=1 only)')
+    ap.add_argument('--no-predictor', action='store_true', help='skip the Predictor MVox/s leg')
+    ap.add_argument('--predictor-volume', choices=('full', 'sub'), default=None, help='full = 512x2048x2048 (default for N = 1), sub = 288x1152x1152')
     ap.add_argument('--profile-layer', default='up_convs.2.conv1')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        respawn_under_launcher(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); pass the same N to both')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
@@ -129,8 +157,13 @@ def main():
     from elektronn3_amd.unet import UNet
     from elektronn3_amd.loss import CombinedCEDiceLoss   # the example's criterion (0.5 CE + 0.5 Dice, class weights) on device
 
+    bf16 = args.dtype == 'bf16'
     torch.manual_seed(0)                                   # identical replica on every rank
     model = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=32, normalization='batch').to(dev).train()
+    if bf16:
+        model = model.to(torch.bfloat16)                   # BASELINE configs[2]: "same UNet bf16" (whole-module cast)
+        if not model._plan().bf16_supported():
+            raise SystemExit('bench.py --dtype bf16: configuration not on the native bf16 path')
     # N > 1: ONE loss over the global minibatch, as the reference computes on the batch nn.DataParallel gathers (trainer.py:520-524):
     # the ranks exchange the criterion's 2 + 3C sums (one all-reduce of 8 doubles) between forward and backward
     criterion = CombinedCEDiceLoss(weight=[0.2653, 0.7347], global_batch=dist is not None).to(dev)
@@ -140,6 +173,8 @@ def main():
         sync = GradSync(model)
     torch.manual_seed(1000 + rank)                         # different synthetic crops per rank
     x = torch.randn(BATCH_PER_GPU, 1, *CROP, device=dev)
+    if bf16:
+        x = x.to(torch.bfloat16)
     tgt = torch.randint(0, 2, (BATCH_PER_GPU, *CROP), device=dev)
 
     layers = model.conv_layers()
@@ -186,44 +221,52 @@ def main():
         _, ms, n = timed(2, which)
         extra[tag] = ms
 
-    multi_pred = None
-    if dist is not None and world > 1 and os.environ.get('E3_BENCH_PREDICTOR_MULTI') and not args.no_predictor:
-        # opt-in (a collective path that the 1-GPU development box cannot exercise over RCCL): every rank predicts its share of
-        # the tile rows of the same sub-volume; all ranks call this
-        multi_pred = predictor_leg(dev, tile_parallel=True)
+    res = None
     if rank == 0:
         vox_per_step = world * BATCH_PER_GPU * CROP[0] * CROP[1] * CROP[2]
         lvox = BATCH_PER_GPU * CROP[0] * CROP[1] * CROP[2] // (8 ** llevel)
-        lflops = conv_flops(lcin, lcout, ltaps, lvox)
-        ach = lflops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        lflops = 2.0 * lcin * lcout * ltaps * lvox                         # algorithmic (direct-convolution) count, SURVEY 8d
+        esz = 2 if bf16 else 4
+        lbytes = (lvox * (lcin + lcout) + lcin * lcout * ltaps) * esz + lcout * 4   # x + y + w (+ b), SURVEY 8d's per-layer bytes
+        wino = (not bf16) and ltaps == 27                                  # fp32 3x3x3: Winograd F(2x2x2,3x3x3) executes 64/216 of the multiplies
+        exec_flops = lflops * (64.0 / 216.0 if wino else 1.0)
+        sec = k_ms * 1e-3
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        ach = exec_flops / sec / 1e12 if sec > 0 else 0.0
+        traffic, tsrc = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))
+            ent = pmc.get(args.dtype, {}).get(args.profile_layer)
+            if ent:
+                traffic, tsrc = float(ent['hbm_bytes_per_launch']), PMC_FILE
+        except Exception:  # noqa: BLE001
+            pass
+        kern = ('conv_b16_kernel (direct implicit GEMM, v_mfma_f32_32x32x16_bf16)' if bf16 else
+                ('conv3_wino_pkernel (persistent Winograd F(2x2x2,3x3x3), v_mfma_f32_32x32x2_f32)' if wino else 'conv3_v3_kernel (direct, fp32 MFMA)'))
         res = {
             'metric': 'voxels/sec (train fwd+bwd) 3D UNet 64x128x128',
             'value': vox_per_step / (ms_per_step * 1e-3),
             'unit': 'voxels/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': world, 'rccl_ranks': (dist.get_world_size() if dist is not None else 0), 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE.json configs[1]: UNet(in=1,out=2,n_blocks=4,start_filts=32,bn) fp32 train fwd+bwd, '
-                                   f'batch {BATCH_PER_GPU}/GPU of 1x64x128x128 random crops, CE+Dice loss, optimizer excluded',
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': (f'BASELINE.json configs[{2 if bf16 else 1}]: UNet(in=1,out=2,n_blocks=4,start_filts=32,bn) '
+                                    f'{"bf16 (model.to(bfloat16), bf16 crops, native bf16 kernels)" if bf16 else "fp32"} train fwd+bwd, '
+                                    f'batch {BATCH_PER_GPU}/GPU of 1x64x128x128 random crops, CE+Dice loss, optimizer excluded'),
                        'global_batch': world * BATCH_PER_GPU, 'crop': list(CROP),
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'step_tflops': FWDBWD_FLOP_PER_VOXEL * vox_per_step / world / (ms_per_step * 1e-3) / 1e12},
-            'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': ach / FP32_MFMA_PEAK_TFLOPS,
-                         # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the gfx950
-                         # correction + WRITE_SIZE, profiles/r01_pmc_wino.md); only known for the default layer/config
-                         'traffic': 1.30e9 if (args.profile_layer == 'up_convs.2.conv1' and ltaps == 27) else None,
-                         'kernel': f'conv3_wino_pkernel (persistent Winograd F(2x2x2,3x3x3), fp32 MFMA) fwd of {args.profile_layer} '
-                                   f'({lcin}->{lcout}, {ltaps} taps, {lvox} voxels)' if ltaps == 27 else
-                                   f'conv3_v3_kernel fwd of {args.profile_layer} ({lcin}->{lcout}, {ltaps} taps, {lvox} voxels)',
-                         'mfma_executed': {'flops_per_launch': lflops * (64.0 / 216.0 if ltaps == 27 else 1.0),
-                                           'tflops': ach * (64.0 / 216.0 if ltaps == 27 else 1.0),
-                                           'frac': ach * (64.0 / 216.0 if ltaps == 27 else 1.0) / FP32_MFMA_PEAK_TFLOPS},
-                         'flops_per_launch': lflops, 'ms_per_launch': k_ms, 'launches_timed': k_n,
+            'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                         'traffic': traffic, 'traffic_source': tsrc,
+                         'kernel': f'{kern} fwd of {args.profile_layer} ({lcin}->{lcout}, {ltaps} taps, {lvox} voxels)',
+                         'executed_flops_per_launch': exec_flops, 'algorithmic_flops_per_launch': lflops,
+                         'algorithmic_tflops': lflops / sec / 1e12 if sec > 0 else 0.0,
+                         'algorithmic_bytes_per_launch': lbytes, 'hbm_frac': lbytes / sec / HBM_PEAK if sec > 0 else 0.0,
+                         'ms_per_launch': k_ms, 'launches_timed': k_n,
                          'dgrad_ms': extra.get('dgrad'), 'wgrad_ms': extra.get('wgrad'),
-                         'dgrad_tflops': lflops / (extra['dgrad'] * 1e-3) / 1e12 if extra.get('dgrad') else None,
-                         'wgrad_tflops': lflops / (extra['wgrad'] * 1e-3) / 1e12 if extra.get('wgrad') else None},
+                         'dgrad_algorithmic_tflops': lflops / (extra['dgrad'] * 1e-3) / 1e12 if extra.get('dgrad') else None,
+                         'wgrad_algorithmic_tflops': lflops / (extra['wgrad'] * 1e-3) / 1e12 if extra.get('wgrad') else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -231,16 +274,44 @@ def main():
             except Exception as e:  # noqa: BLE001
                 res['cpu_baseline'] = {'value': None, 'unit': 'voxels/s', 'cores': torch.get_num_threads(), 'kind': 'port',
                                        'sample': f'failed: {e}'}
-        if world == 1 and dist is None and not args.no_predictor:
-            try:
-                del x, tgt
-                torch.cuda.empty_cache()
-                res['predictor'] = predictor_leg(dev)
-            except Exception as e:  # noqa: BLE001
+
+    # ---- Predictor leg (all ranks take part when N > 1)
+    done = threading.Event()
+
+    def emit():
+        if rank == 0 and not done.is_set():
+            done.set()
+            print(json.dumps(res), flush=True)
+
+    if not args.no_predictor and os.environ.get('E3_BENCH_NO_PREDICTOR') is None:
+        del x, tgt
+        torch.cuda.empty_cache()
+        vol_kind = args.predictor_volume or ('full' if world == 1 else 'sub')
+        shape = (512, 2048, 2048) if vol_kind == 'full' else (288, 1152, 1152)
+        # the tile-parallel leg has a control-plane exchange (shared-memory name, closing barrier): a rank that dies in it must not
+        # take the training line down with it -- after 300 s rank 0 prints what it has and every rank leaves
+        watchdog = None
+        if world > 1:
+            def bail():
+                if rank == 0 and res is not None:
+                    res['predictor'] = {'metric': 'Predictor MVox/s', 'value': None, 'note': 'tile-parallel leg did not finish within 300 s'}
+                emit()
+                os._exit(0)
+            watchdog = threading.Timer(300.0, bail)
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            p = predictor_leg(dev, shape, tile_parallel=world > 1)
+            if rank == 0:
+                if world > 1:
+                    p.update(n_gpus=world, parallelism=f'tile-parallel over {world} ranks, shared-memory output')
+                res['predictor'] = p
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
                 res['predictor'] = {'metric': 'Predictor MVox/s', 'value': None, 'note': f'failed: {e}'}
-        elif multi_pred is not None:
-            res['predictor'] = dict(multi_pred, n_gpus=world, parallelism=f'tile-parallel over {world} ranks, shared-memory output')
-        print(json.dumps(res), flush=True)
+        if watchdog is not None:
+            watchdog.cancel()
+    emit()
     if dist is not None:
         dist.destroy_process_group()
 

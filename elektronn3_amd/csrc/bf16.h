@@ -1,0 +1,125 @@
+// Launcher interface of the native bf16 path (BASELINE.json configs[2]: the same U-Net with bf16 storage).
+//
+// Activations and their gradients live in HBM as bf16 NDHWC (same (ptr, ldc) views as the fp32 path), weights are packed to bf16
+// per call, every accumulation is fp32 (v_mfma_f32_32x32x16_bf16), BatchNorm statistics / coefficients / parameter gradients are
+// fp32.  Like a `model.to(torch.bfloat16)` reference module, every op rounds its result to bf16 once (the conv output incl. bias,
+// the normalised activation, every gradient tensor); the statistics are those of the ROUNDED conv output, as nn.BatchNorm3d sees it.
+// Reference: the reduced-precision switches of elektronn3 are Trainer(mixed_precision) (training/trainer.py:367,519) and
+// Predictor(float16=True) / model.half() (inference/inference.py:445-446, benchmark/pred_benchmark.py:55,71).
+#pragma once
+#include "common.h"
+
+typedef unsigned short bf16_t;                                   // storage type (raw bits)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {                 // round to nearest even (NaN stays NaN)
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+__device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
+
+// ---------------------------------------------------------------- 3x3x3 / 1x3x3 conv, stride 1, 'same' padding (bf16_conv.hip)
+// y[v][co] = bf16( sum_{tap, ci} x[v + tap][ci] * w[co][ci][tap] (+ bias[co]) )      forward (unet.py:131-149) and, with the flipped /
+// transposed packing, the data gradient.  Cin % 32 == 0, Cout % 32 == 0.
+struct ConvB16Args {
+    const bf16_t* x; int x_ldc; int Cin;
+    const bf16_t* wt;                      // packed by launch_pack_conv_b16: [tap][Cin/32][2][CoPad][2][8]
+    const float* bias;                     // [Cout] fp32 or null
+    bf16_t* y; int y_ldc;
+    int N, D, H, W, Cout;
+    int planar;                            // 1: 1x3x3 taps (planar blocks, unet.py:114-128)
+    const float* epi_scale; const float* epi_shift;   // non-null: y = bf16(relu(acc * scale[co] + shift[co]))   (eval mode: folded BN)
+    float* stats;                          // non-null: records [conv_b16_stats_parts][Cout][3] = (n, mean, M2) of the stored values
+    float* partial;                        // scratch of conv_b16_partial_floats() floats (split-K of the low-resolution levels; may be null if 0)
+};
+int conv_b16_stats_parts(int N, int D, int H, int W, int Cin, int Cout, int planar);
+size_t conv_b16_partial_floats(int N, int D, int H, int W, int Cin, int Cout);
+size_t conv_b16_packed_elems(int Cin, int Cout, int planar);
+// torch (Cout, Cin, T) fp32 weights -> packed bf16; dgrad = 1: the data-gradient form (taps flipped, roles of Cin / Cout swapped)
+int launch_pack_conv_b16(const float* w, bf16_t* out, int Cout, int Cin, int planar, int dgrad, hipStream_t s);
+int launch_conv_b16(ConvB16Args a, hipStream_t s);
+// every weight packing of a pass in one launch.  mode: 0 conv forward, 1 conv data-gradient, 2 transposed-conv forward, 3 its data gradient;
+// w: torch layout (conv (Cout, Cin, T), transposed conv (Cin, Cout, T)); out: the layout the respective kernel reads
+constexpr int PACK_B16_MAX_JOBS = 40;
+struct PackB16Job { const float* w; bf16_t* out; int Cout, Cin, T, mode; };
+int launch_pack_multi_b16(const PackB16Job* jobs, int njobs, hipStream_t s);
+
+// ---------------------------------------------------------------- weight gradient of the same convs (bf16_wgrad.hip)
+// part[split][tap][CoPad][CiPad] fp32 (the slab layout of the fp32 path: launch_wgrad_reduce* finish it)
+struct WgradB16Args {
+    const bf16_t* x; int x_ldc; int Cin;
+    const bf16_t* dy; int dy_ldc; int Cout;
+    float* part;
+    int N, D, H, W;
+    int planar;
+    int splits;
+};
+int wgrad_b16_splits(int N, int D, int H, int W, int Cin, int Cout, int planar);
+int launch_wgrad_b16(WgradB16Args a, hipStream_t s);
+
+// ---------------------------------------------------------------- transposed conv k = s = (sd, 2, 2) (bf16_upconv.hip)
+// forward: y[(sd d + kd, 2h + kh, 2w + kw)][co] = bf16(bias[co] + sum_ci x[(d,h,w)][ci] * w[ci][co][tap]) for output voxels inside
+// (Do, Ho, Wo) (autocrop of the up-convolved tensor, unet.py:289-299); data gradient: the gather form; weight gradient: slab partials.
+struct UpconvB16Args {
+    const bf16_t* x; int x_ldc; int Cin;          // low-resolution side (N, D, H, W)
+    bf16_t* y; int y_ldc; int Cout;               // high-resolution side (N, Do, Ho, Wo)
+    const bf16_t* wt;                              // packed by launch_pack_upconv_b16
+    const float* bias;
+    int N, D, H, W, Do, Ho, Wo, sd;
+    const float* epi_scale; const float* epi_shift;
+    float* stats;                                  // forward: (n, mean, M2) records of the stored values
+};
+int upconv_b16_stats_parts(int N, int D, int H, int W, int sd);
+size_t upconv_b16_packed_elems(int Cin, int Cout, int sd);
+int launch_pack_upconv_b16(const float* w /*torch (Cin, Cout, T)*/, bf16_t* out, int Cin, int Cout, int sd, int dgrad, hipStream_t s);
+int launch_upconv_b16_fwd(UpconvB16Args a, hipStream_t s);
+// dx[(d,h,w)][ci] = bf16(sum_{tap, co} dy[(sd d + kd, ...)][co] * w[ci][co][tap]); here x/Cin describe dx, y/Cout describe dy
+int launch_upconv_b16_dgrad(UpconvB16Args a, hipStream_t s);
+int upconv_b16_wgrad_splits(int N, int D, int H, int W);
+// part[split][tap][CiPad][CoPad] fp32 (rows = ci: the transposed = 1 form of launch_wgrad_reduce*)
+int launch_upconv_b16_wgrad(const bf16_t* x, int x_ldc, int Cin, const bf16_t* dy, int dy_ldc, int Cout, float* part,
+                            int N, int D, int H, int W, int Do, int Ho, int Wo, int sd, int splits, hipStream_t s);
+
+// ---------------------------------------------------------------- HBM-bound passes on bf16 tensors (bf16_ew.hip)
+// a = bf16(relu(x * scale + shift)) (+ pooled = maxpool_{kd,2,2}(a), ceil mode); x == a-typed raw conv output
+int launch_bn_relu_apply_b16(const bf16_t* x, int x_ldc, const float* scale, const float* shift, bf16_t* a, int a_ldc,
+                             bf16_t* pooled, int kd, int N, int D, int H, int W, int C, hipStream_t s);
+int launch_maxpool_b16(const bf16_t* a, int a_ldc, bf16_t* pooled, int kd, int N, int D, int H, int W, int C, hipStream_t s);
+struct BnBwdB16Args {
+    const bf16_t* x; int x_ldc;             // raw conv output (BN input)
+    const float *mean, *invstd, *gamma, *scale, *shift;
+    const bf16_t* g1; int g1_ldc;           // gradient w.r.t. the activation (null: only gpool)
+    const bf16_t* gpool;                    // gradient w.r.t. the pooled output (packed, ceil dims) or null
+    const bf16_t* pooled;                   // pooled forward output
+    int kd, N, D, H, W, C;
+    float* part; int parts;                 // [parts][3][C]: sum dz, sum dz*xhat, (apply) sum dx
+    const float* coef;                      // apply: [2][C] = (sum dz / n, sum dz*xhat / n)
+    bf16_t* dx; int dx_ldc;
+    // the last unit: dA is recomputed from the head's (fp32, NCDHW) logits gradient and weights instead of being read
+    const float* head_dy; const float* head_w; int head_cout; size_t head_S;
+};
+int bn_bwd_b16_parts(size_t voxels, int C);
+int launch_bn_bwd_b16_reduce(BnBwdB16Args a, hipStream_t s);
+int launch_bn_bwd_b16_apply(BnBwdB16Args a, hipStream_t s);
+
+// first conv (Cin = in_channels < 8): x is the module's bf16 input (NDHWC == NCDHW for one channel); direct VALU conv
+int conv_small_b16_stats_parts(int N, int D, int H, int W);
+int launch_conv_small_b16_fwd(const bf16_t* x, int Cin, const float* w /*torch (Cout,Cin,T) fp32*/, const float* bias, bf16_t* y, int y_ldc,
+                              int N, int D, int H, int W, int Cout, int planar, const float* epi_scale, const float* epi_shift, float* stats, hipStream_t s);
+int conv_small_b16_wgrad_splits(int N, int D, int H, int W);
+int launch_conv_small_b16_wgrad(const bf16_t* x, int Cin, const bf16_t* dy, int dy_ldc, float* part /*[splits][T][Cout][Cin]*/,
+                                int N, int D, int H, int W, int Cout, int planar, hipStream_t s);
+// 1x1x1 head: a (bf16, optionally BN+ReLU applied while loading) -> fp32 NCDHW logits (+ softmax); backward: dW/db partials (+ da)
+int launch_conv_final_b16_fwd(const bf16_t* a, int a_ldc, int C, const float* w, const float* bias, float* y_ncdhw, int Cout,
+                              size_t voxels_per_sample, int N, int softmax, const float* pro_scale, const float* pro_shift, hipStream_t s);
+int conv_final_b16_bwd_parts(size_t total_voxels);
+int launch_conv_final_b16_bwd(const bf16_t* a, int a_ldc, int C, const float* w, const float* dy_ncdhw, bf16_t* da, int da_ldc,
+                              float* part /*[parts][Cout][C+1]*/, int Cout, size_t voxels_per_sample, int N,
+                              const float* pro_scale, const float* pro_shift, hipStream_t s);
+// module boundary
+int launch_ncdhw_to_ndhwc_b16(const bf16_t* src, bf16_t* dst, int N, int C, size_t S, hipStream_t s);
+int launch_ndhwc_to_ncdhw_b16(const bf16_t* src, int src_ldc, bf16_t* dst, int N, int C, size_t S, hipStream_t s);
+int launch_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s);

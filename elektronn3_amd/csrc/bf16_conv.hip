@@ -1,0 +1,436 @@
+// 3x3x3 / 1x3x3 convolution (stride 1, zero padding 1) on the bf16 matrix cores: forward and data gradient of nn.Conv3d as the
+// reference's conv3() builds it (elektronn3/models/unet.py:131-149, planar form :114-128), for bf16 NDHWC tensors.
+//
+// Implicit GEMM, no im2col buffer:  Y^T[co][v] = sum_tap sum_ci W_tap[co][ci] * X[v + tap][ci]
+//   A operand (rows = output channels)  = the packed weights, straight from L2 into a register ring several taps deep
+//   B operand (columns = voxels)        = the input brick's halo, staged ONCE per 32-channel chunk into LDS by LDS-DMA
+//                                         (buffer_load_dwordx4 ... lds, zero padding = the descriptor's range check)
+//   v_mfma_f32_32x32x16_bf16, fp32 accumulators.  The result tile has a VOXEL per lane and 16 output channels in registers
+//   (4 consecutive ones per register quad), which is exactly the NDHWC store pattern: bias, bf16 rounding, 8-byte stores, no
+//   transposition.  BatchNorm statistics (of the rounded values, shifted by the bias) are summed per lane and reduced through LDS.
+//
+// Workgroup = brick of BD x 8 x 16 voxels x (32 * CO_T) output channels, 4 waves; wave w owns BD tiles of 2 x 16 voxels.
+// LDS image: [halo voxel][32 channels] = 64-byte rows, the four 16-byte pieces of a row XOR-swizzled by bits 2..3 of the voxel's
+// w coordinate (applied to the SOURCE address of the DMA: the LDS side of a DMA is lane-linear), so that a wave's ds_read_b128 of
+// 16 consecutive voxels covers all 64 banks; every (tile, kd, kh) is an immediate offset on one of 6 lane addresses (3 kw x 2 k-steps).
+// One LDS buffer per workgroup, 2-3 workgroups per CU: one workgroup's staging overlaps the others' MFMA phases.
+#include "bf16.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// (a plain function: called straight from a kernel TEMPLATE, hipcc's host pass drops the kernel's stub)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, lds_ptr_t dst, int, unsigned voff, int, int, int) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, 0, 0, 0);
+}
+constexpr int HH = 10, HW = 18;
+constexpr unsigned OOB = 0x80000000u;
+
+template <int BD, int KD>
+struct Geo {
+    static constexpr int HD = BD + (KD == 3 ? 2 : 0);
+    static constexpr int HV = HD * HH * HW;              // halo voxels
+    static constexpr int NI = (HV * 4 + 63) / 64;        // 1 KB wave-pieces per chunk
+    static constexpr int NIW = (NI + 3) / 4;             // per wave
+    static constexpr int IMG = NI * 1024;                // bytes
+    static constexpr int NV = BD;                        // 2x16-voxel tiles per wave
+    static constexpr int TAPS = KD * 9;
+};
+
+template <int BD, int CO_T, int KD>
+__global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const ConvB16Args a, int tilesD, int tilesH, int tilesW, int cgroups, int ksplit) {
+    using G = Geo<BD, KD>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, g = lane >> 5;
+    unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int cg = L % cgroups; L /= cgroups;
+    const int ksp = L % ksplit; L /= ksplit;            // split-K: this workgroup sums the channel chunks [ch0, ch1) into partial[ksp]
+    const int brick = (int)L;
+    const int tw = L % tilesW; L /= tilesW; const int th = L % tilesH; L /= tilesH; const int td = L % tilesD; const int n = L / tilesD;
+    const int d0 = td * BD, h0 = th * 8, w0 = tw * 16;
+    const int co0 = cg * 32 * CO_T;
+    constexpr int PD = KD == 3 ? 1 : 0;
+    const int nch = a.Cin >> 5;
+    const int ch0 = ksp * (nch / ksplit), ch1 = ch0 + nch / ksplit;
+
+    // ---- staging plan: wave-piece wi = it * 4 + wave, lane -> (halo voxel, LDS piece); source piece = LDS piece ^ swizzle
+    const size_t samp = (size_t)a.D * a.H * a.W * a.x_ldc;
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x) + (size_t)n * samp, 0, 0x7fffffff, 0x00020000);
+    unsigned rel[G::NIW]; unsigned okmask = 0;
+#pragma unroll
+    for (int it = 0; it < G::NIW; ++it) {
+        const int idx = (it * 4 + wave) * 64 + lane;
+        const int v = idx >> 2, qp = idx & 3;
+        const int zw = v % HW, zh = (v / HW) % HH, zd = v / (HW * HH);
+        const int q = qp ^ ((zw >> 2) & 3);
+        const int gd = d0 - PD + zd, gh = h0 - 1 + zh, gw = w0 - 1 + zw;
+        const bool ok = v < G::HV && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+        rel[it] = (unsigned)((((gd * a.H + gh) * a.W + gw) * a.x_ldc) * 2 + q * 16);
+        okmask |= ok ? (1u << it) : 0u;
+    }
+
+    // ---- lane read addresses (tap kd = kh = 0, tile 0 of the wave): 3 kw x 2 k-steps
+    const int r = j >> 4, c = j & 15;
+    const int T0 = wave * G::NV, dT0 = T0 >> 2, hp0 = T0 & 3;
+    unsigned rd[3][2];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int hw = c + kw, sw = (hw >> 2) & 3;
+        const int row = (dT0 * HH + 2 * hp0 + r) * HW + hw;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) rd[kw][ks] = (unsigned)(row * 64 + (((2 * ks + g) ^ sw) << 4));
+    }
+    // ---- weights: packed [tap][chunk][k-step][CoPad][2][8]; lane (j, g) reads 16 B of row co0 + ct*32 + j
+    const size_t wstep = (size_t)a.Cout * 16;                          // elements per (tap, chunk, k-step)
+    const bf16_t* wlane = a.wt + (size_t)(co0 + j) * 16 + g * 8;
+
+    f32x16 acc[CO_T][G::NV];
+#pragma unroll
+    for (int ct = 0; ct < CO_T; ++ct)
+#pragma unroll
+        for (int t = 0; t < G::NV; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ct][t][e] = 0.f;
+
+    for (int ch = ch0; ch < ch1; ++ch) {
+        constexpr int RING = CO_T == 1 ? 6 : 4;      // taps of weights in flight (L2 latency under load is several MFMA taps)
+        bf16x8 wf[RING][CO_T][2];
+#define E3_LOAD_W(TAP, SLOT)                                                                                                        \
+    _Pragma("unroll") for (int ct_ = 0; ct_ < CO_T; ++ct_)                                                                          \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                                                         \
+            wf[SLOT][ct_][ks_] = *reinterpret_cast<const bf16x8*>(wlane + ((size_t)((TAP) * nch + ch) * 2 + ks_) * wstep + ct_ * 512)
+#pragma unroll
+        for (int t0 = 0; t0 < RING - 1; ++t0) { E3_LOAD_W(t0, t0); }
+#pragma unroll
+        for (int it = 0; it < G::NIW; ++it) {
+            const int wi = it * 4 + wave;
+            if (wi < G::NI)
+                dma16(x_rs, (lds_ptr_t)(smem + wi * 1024), 16,
+                                                         ((okmask >> it) & 1u) ? rel[it] + (unsigned)ch * 64u : OOB, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < G::TAPS; ++tap) {
+            if (tap + RING - 1 < G::TAPS) { E3_LOAD_W(tap + RING - 1, (tap + RING - 1) % RING); }
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < G::NV; ++t) {
+                    const int imm = ((kd * HH + 2 * t + kh) * HW) * 64;
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + rd[kw][ks] + imm);
+#pragma unroll
+                    for (int ct = 0; ct < CO_T; ++ct)
+                        acc[ct][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap % RING][ct][ks], b, acc[ct][t], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+#undef E3_LOAD_W
+    }
+
+    // ---- epilogue: lane (j, g) holds, for tile t and register e, the output of voxel j and channel (e&3) + 8*(e>>2) + 4*g
+    if (ksplit > 1) {           // fp32 partial sums [split][voxel][Cout]; bias, rounding and statistics happen in splitk_reduce_b16_kernel
+        const size_t vox = (size_t)a.N * a.D * a.H * a.W;
+#pragma unroll
+        for (int ct = 0; ct < CO_T; ++ct)
+#pragma unroll
+            for (int t = 0; t < G::NV; ++t) {
+                const int d = d0 + dT0, h = h0 + 2 * (hp0 + t) + r, w = w0 + c;
+                if (d < a.D && h < a.H && w < a.W) {
+                    float* prow = a.partial + ((size_t)ksp * vox + (((size_t)n * a.D + d) * a.H + h) * a.W + w) * a.Cout + co0 + ct * 32 + 4 * g;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<f32x4*>(prow + 8 * q) = f32x4{acc[ct][t][4 * q], acc[ct][t][4 * q + 1], acc[ct][t][4 * q + 2], acc[ct][t][4 * q + 3]};
+                }
+            }
+        return;
+    }
+    float ssum[CO_T][16], ssq[CO_T][16];
+    const bool want_stats = a.stats != nullptr;
+#pragma unroll
+    for (int ct = 0; ct < CO_T; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { ssum[ct][e] = 0.f; ssq[ct][e] = 0.f; }
+#pragma unroll
+    for (int ct = 0; ct < CO_T; ++ct) {
+        f32x4 bq[4], sq[4], hq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cb = co0 + ct * 32 + 8 * q + 4 * g;
+            bq[q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.epi_scale) { sq[q] = *reinterpret_cast<const f32x4*>(a.epi_scale + cb); hq[q] = *reinterpret_cast<const f32x4*>(a.epi_shift + cb); }
+        }
+#pragma unroll
+        for (int t = 0; t < G::NV; ++t) {
+            const int d = d0 + dT0, h = h0 + 2 * (hp0 + t) + r, w = w0 + c;
+            const bool valid = d < a.D && h < a.H && w < a.W;
+            bf16_t* yrow = a.y + ((((size_t)n * a.D + d) * a.H + h) * a.W + w) * a.y_ldc + co0 + ct * 32 + 4 * g;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float val = acc[ct][t][4 * q + e];
+                    if (a.epi_scale) val = fmaxf(__builtin_fmaf(val, sq[q][e], hq[q][e]), 0.f);
+                    else val += bq[q][e];
+                    const bf16_t rb = f2bf(val);
+                    o[e] = rb;
+                    if (want_stats) {
+                        const float dv = valid ? bf2f(rb) - bq[q][e] : 0.f;
+                        ssum[ct][4 * q + e] += dv; ssq[ct][4 * q + e] = __builtin_fmaf(dv, dv, ssq[ct][4 * q + e]);
+                    }
+                }
+                if (valid) *reinterpret_cast<u16x4*>(yrow + 8 * q) = o;
+            }
+        }
+    }
+    if (!want_stats) return;
+    // ---- statistics: S[wave][quantity][channel][33] floats in the (now free) image, column sums, (n, mean, M2) record per brick
+    float* S = reinterpret_cast<float*>(smem);
+    float* R = S + 4 * 2 * 32 * 33;                    // [2][4][32]
+    const int nd = a.D - d0 < BD ? a.D - d0 : BD, nh = a.H - h0 < 8 ? a.H - h0 : 8, nw = a.W - w0 < 16 ? a.W - w0 : 16;
+    const float cnt = (float)(nd * nh * nw);
+#pragma unroll
+    for (int ct = 0; ct < CO_T; ++ct) {
+        if (ct) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int col = (e & 3) + 8 * (e >> 2) + 4 * g;
+            S[((wave * 2 + 0) * 32 + col) * 33 + j] = ssum[ct][e];
+            S[((wave * 2 + 1) * 32 + col) * 33 + j] = ssq[ct][e];
+        }
+        __syncthreads();
+        {
+            const int col = tid & 31, qn = (tid >> 5) & 1, wv = tid >> 6;
+            const float* row = S + ((wv * 2 + qn) * 32 + col) * 33;
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) s += row[k];
+            R[(qn * 4 + wv) * 32 + col] = s;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const float s = (R[0 * 32 + tid] + R[1 * 32 + tid]) + (R[2 * 32 + tid] + R[3 * 32 + tid]);
+            const float q2 = (R[4 * 32 + tid] + R[5 * 32 + tid]) + (R[6 * 32 + tid] + R[7 * 32 + tid]);
+            const int co = co0 + ct * 32 + tid;
+            const float b = a.bias ? a.bias[co] : 0.f;
+            const float m = s / cnt;
+            float* rec = a.stats + ((size_t)brick * a.Cout + co) * 3;
+            rec[0] = cnt; rec[1] = b + m; rec[2] = fmaxf(q2 - s * m, 0.f);
+        }
+    }
+}
+
+// torch (Cout, Cin, T) fp32 -> packed bf16 [tap][chunk][k-step][Cg][2][8], Cg = GEMM rows (output channels of THIS launch)
+__global__ void pack_conv_b16_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int T, int dgrad) {
+    const int Kg = dgrad ? Cout : Cin, Cg = dgrad ? Cin : Cout;       // GEMM-K channels, GEMM rows
+    const size_t total = (size_t)T * Kg * Cg;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int e = r & 7; r >>= 3; const int g = r & 1; r >>= 1; const int row = r % Cg; r /= Cg;
+        const int ks = r & 1; r >>= 1; const int ch = r % (Kg >> 5); const int tap = (int)(r / (Kg >> 5));
+        const int k = ch * 32 + ks * 16 + g * 8 + e;
+        const float v = dgrad ? w[((size_t)k * Cin + row) * T + (T - 1 - tap)] : w[((size_t)row * Cin + k) * T + tap];
+        out[i] = f2bf(v);
+    }
+}
+
+// split-K epilogue: y[v][c] = bf16(sum_s partial[s][v][c] + bias[c]) (or relu(sum * scale + shift)), statistics of the stored values
+// (shifted by the bias) as one (n, mean, M2) record per workgroup and channel.  Thread = 8 channels; the threads of a channel octet
+// walk the voxels with a fixed stride, fixed summation order.
+__global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(const float* __restrict__ partial, int S, size_t vox, int C, const float* __restrict__ bias,
+                                                                const float* __restrict__ epi_scale, const float* __restrict__ epi_shift,
+                                                                bf16_t* __restrict__ y, int y_ldc, float* __restrict__ stats) {
+    __shared__ float red[2][256][8];
+    const int Q = C >> 3;
+    const int BT = (256 / Q) * Q;
+    const int tid = threadIdx.x;
+    const bool active = tid < BT;
+    const size_t i00 = (size_t)blockIdx.x * BT + tid;
+    const int q = (int)(i00 % Q);
+    const size_t vstride = (size_t)gridDim.x * BT / Q;
+    float bs[8], sc[8], sh[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bs[e] = bias ? bias[8 * q + e] : 0.f;
+        sc[e] = epi_scale ? epi_scale[8 * q + e] : 1.f; sh[e] = epi_scale ? epi_shift[8 * q + e] : 0.f;
+        s1[e] = 0.f; s2[e] = 0.f;
+    }
+    float cnt = 0.f;
+    for (size_t v = i00 / Q; active && v < vox; v += vstride) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int sp = 0; sp < S; ++sp) {
+            const float* p = partial + ((size_t)sp * vox + v) * C + 8 * q;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(p), a1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] += a0[e]; acc[4 + e] += a1[e]; }
+        }
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float val = epi_scale ? fmaxf(__builtin_fmaf(acc[e], sc[e], sh[e]), 0.f) : acc[e] + bs[e];
+            o[e] = f2bf(val);
+            const float dv = bf2f(o[e]) - bs[e];
+            s1[e] += dv; s2[e] = __builtin_fmaf(dv, dv, s2[e]);
+        }
+        *reinterpret_cast<u16x8*>(y + v * y_ldc + 8 * q) = o;
+        cnt += 1.f;
+    }
+    if (!stats) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][tid][e] = active ? s1[e] : 0.f; red[1][tid][e] = active ? s2[e] : 0.f; }
+    __shared__ float cn[256];
+    cn[tid] = active ? cnt : 0.f;
+    __syncthreads();
+    for (int t = tid; t < Q * 8; t += 256) {
+        const int e = t & 7, qq = t >> 3;
+        float a1 = 0.f, a2 = 0.f, n = 0.f;
+        for (int k = qq; k < BT; k += Q) { a1 += red[0][k][e]; a2 += red[1][k][e]; n += cn[k]; }
+        const float b = bias ? bias[8 * qq + e] : 0.f;
+        const float m = n > 0.f ? a1 / n : 0.f;
+        float* rec = stats + ((size_t)blockIdx.x * C + 8 * qq + e) * 3;
+        rec[0] = n; rec[1] = b + m; rec[2] = fmaxf(a2 - a1 * m, 0.f);
+    }
+}
+
+// all weight packings of a pass in ONE launch (a dozen 5-us launches otherwise): block -> job by a prefix table in the kernel arguments
+struct PackMultiArgs { PackB16Job job[PACK_B16_MAX_JOBS]; unsigned first_block[PACK_B16_MAX_JOBS + 1]; int njobs; };
+__global__ void pack_multi_b16_kernel(const PackMultiArgs a) {
+    int jb = 0;
+    while (jb + 1 < a.njobs && blockIdx.x >= a.first_block[jb + 1]) ++jb;
+    const PackB16Job J = a.job[jb];
+    const size_t total = (size_t)J.T * J.Cin * J.Cout;
+    const unsigned nblk = a.first_block[jb + 1] - a.first_block[jb];
+    for (size_t i = (size_t)(blockIdx.x - a.first_block[jb]) * blockDim.x + threadIdx.x; i < total; i += (size_t)nblk * blockDim.x) {
+        size_t r = i;
+        const int e = r & 7; r >>= 3; const int g = r & 1; r >>= 1;
+        float v;
+        if (J.mode < 2) {           // conv: [tap][chunk][k-step][Cg][2][8]
+            const int dgrad = J.mode;
+            const int Kg = dgrad ? J.Cout : J.Cin, Cg = dgrad ? J.Cin : J.Cout;
+            const int row = r % Cg; r /= Cg;
+            const int ks = r & 1; r >>= 1; const int ch = r % (Kg >> 5); const int tap = (int)(r / (Kg >> 5));
+            const int k = ch * 32 + ks * 16 + g * 8 + e;
+            v = dgrad ? J.w[((size_t)k * J.Cin + row) * J.T + (J.T - 1 - tap)] : J.w[((size_t)row * J.Cin + k) * J.T + tap];
+        } else {                    // transposed conv: [row tile][k-step][32][2][8]; torch (Cin, Cout, T)
+            const int dgrad = J.mode - 2;
+            const int K = dgrad ? J.T * J.Cout : J.Cin;
+            const int rr = r & 31; r >>= 5;
+            const int ks = r % (K >> 4); const int rt = (int)(r / (K >> 4));
+            const int row = rt * 32 + rr, k = ks * 16 + g * 8 + e;
+            int ci, co, tap;
+            if (dgrad) { ci = row; tap = k / J.Cout; co = k % J.Cout; } else { tap = rt % J.T; co = (rt / J.T) * 32 + rr; ci = k; }
+            v = J.w[((size_t)ci * J.Cout + co) * J.T + tap];
+        }
+        J.out[i] = f2bf(v);
+    }
+}
+
+template <int BD, int CO_T, int KD>
+int launch_t(const ConvB16Args& a, int ksplit, hipStream_t s) {
+    using G = Geo<BD, KD>;
+    const int tD = cdiv(a.D, BD), tH = cdiv(a.H, 8), tW = cdiv(a.W, 16);
+    const int cgroups = a.Cout / (32 * CO_T);
+    const size_t grid = (size_t)a.N * tD * tH * tW * cgroups * ksplit;
+    const int lds = G::IMG > 4 * 2 * 32 * 33 * 4 + 1024 ? G::IMG : 4 * 2 * 32 * 33 * 4 + 1024;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)conv_b16_kernel<BD, CO_T, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
+    hipLaunchKernelGGL((conv_b16_kernel<BD, CO_T, KD>), dim3((unsigned)grid), dim3(256), lds, s, a, tD, tH, tW, cgroups, ksplit);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+// Work decomposition of one launch: brick depth (4x8x16 bricks -- each weight fragment feeds 4 tiles per wave, halo overhead 2.1x
+// instead of 2.8x -- where they still fill the chip), output-channel tiles per workgroup, and for the low-resolution levels (a few
+// dozen bricks for 256 CUs) a split of the input channels over several workgroups (fp32 partial sums, splitk_reduce_b16_kernel).
+struct Decomp { int bd, co_t, ksplit; long bricks; };
+Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout) {
+    static const int forced = getenv("E3_B16_BD") ? atoi(getenv("E3_B16_BD")) : 0;
+    static const bool no_split = getenv("E3_B16_NO_SPLITK") != nullptr;
+    Decomp d;
+    const long b4 = (long)N * cdiv(D, 4) * cdiv(H, 8) * cdiv(W, 16);
+    d.bd = (forced == 2 || forced == 4) ? forced : (b4 >= 512 ? 4 : 2);
+    d.bricks = (long)N * cdiv(D, d.bd) * cdiv(H, 8) * cdiv(W, 16);
+    d.co_t = (Cout % 64 == 0 && d.bricks * (Cout / 64) >= 256) ? 2 : 1;
+    const long wgs = d.bricks * (Cout / (32 * d.co_t));
+    const int nch = Cin / 32;
+    d.ksplit = 1;
+    while (!no_split && wgs * d.ksplit < 512 && nch % (2 * d.ksplit) == 0 && d.ksplit < 8) d.ksplit *= 2;
+    return d;
+}
+int reduce_blocks(size_t vox, int C) {
+    size_t g = (vox * (size_t)(C / 8) + 255) / 256;
+    if (g > 512) g = 512;
+    if (g == 0) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+int conv_b16_stats_parts(int N, int D, int H, int W, int Cin, int Cout, int planar) {
+    (void)planar;
+    const Decomp d = conv_b16_decomp(N, D, H, W, Cin, Cout);
+    return d.ksplit > 1 ? reduce_blocks((size_t)N * D * H * W, Cout) : (int)d.bricks;
+}
+
+size_t conv_b16_partial_floats(int N, int D, int H, int W, int Cin, int Cout) {
+    const Decomp d = conv_b16_decomp(N, D, H, W, Cin, Cout);
+    return d.ksplit > 1 ? (size_t)d.ksplit * N * D * H * W * Cout : 0;
+}
+
+size_t conv_b16_packed_elems(int Cin, int Cout, int planar) { return (size_t)(planar ? 9 : 27) * Cin * Cout; }
+
+int launch_pack_conv_b16(const float* w, bf16_t* out, int Cout, int Cin, int planar, int dgrad, hipStream_t s) {
+    const int T = planar ? 9 : 27;
+    const size_t total = (size_t)T * Cin * Cout;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_conv_b16_kernel, dim3(grid), dim3(256), 0, s, w, out, Cout, Cin, T, dgrad);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_pack_multi_b16(const PackB16Job* jobs, int njobs, hipStream_t s) {
+    E3_REQUIRE(njobs >= 0 && njobs <= PACK_B16_MAX_JOBS, E3_ERR_INVALID, "too many weight-packing jobs");
+    if (njobs == 0) return E3_OK;
+    PackMultiArgs a{};
+    unsigned nb = 0;
+    for (int i = 0; i < njobs; ++i) {
+        a.job[i] = jobs[i];
+        a.first_block[i] = nb;
+        const size_t total = (size_t)jobs[i].T * jobs[i].Cin * jobs[i].Cout;
+        size_t b = (total + 2047) / 2048; if (b > 256) b = 256; if (b == 0) b = 1;
+        nb += (unsigned)b;
+    }
+    a.first_block[njobs] = nb; a.njobs = njobs;
+    hipLaunchKernelGGL(pack_multi_b16_kernel, dim3(nb), dim3(256), 0, s, a);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_conv_b16(ConvB16Args a, hipStream_t s) {
+    E3_REQUIRE(a.Cin % 32 == 0 && a.Cout % 32 == 0, E3_ERR_UNSUPPORTED, "bf16 conv: channel counts must be multiples of 32");
+    E3_REQUIRE(a.x_ldc % 8 == 0 && a.y_ldc % 4 == 0, E3_ERR_INVALID, "bf16 conv: misaligned view");
+    E3_REQUIRE((size_t)a.D * a.H * a.W * a.x_ldc < (1ull << 30), E3_ERR_UNSUPPORTED, "bf16 conv: sample larger than 2 GB");
+    const Decomp d = conv_b16_decomp(a.N, a.D, a.H, a.W, a.Cin, a.Cout);
+    E3_REQUIRE(d.ksplit == 1 || a.partial, E3_ERR_INVALID, "bf16 conv: this shape needs the split-K scratch (conv_b16_partial_floats)");
+    const bool two = d.co_t == 2;
+    int rc;
+    if (a.planar) {
+        if (d.bd == 4) rc = two ? launch_t<4, 2, 1>(a, d.ksplit, s) : launch_t<4, 1, 1>(a, d.ksplit, s);
+        else rc = two ? launch_t<2, 2, 1>(a, d.ksplit, s) : launch_t<2, 1, 1>(a, d.ksplit, s);
+    } else {
+        if (d.bd == 4) rc = two ? launch_t<4, 2, 3>(a, d.ksplit, s) : launch_t<4, 1, 3>(a, d.ksplit, s);
+        else rc = two ? launch_t<2, 2, 3>(a, d.ksplit, s) : launch_t<2, 1, 3>(a, d.ksplit, s);
+    }
+    if (rc || d.ksplit == 1) return rc;
+    const size_t vox = (size_t)a.N * a.D * a.H * a.W;
+    hipLaunchKernelGGL(splitk_reduce_b16_kernel, dim3(reduce_blocks(vox, a.Cout)), dim3(256), 0, s, a.partial, d.ksplit, vox, a.Cout, a.bias,
+                       a.epi_scale, a.epi_shift, a.y, a.y_ldc, a.stats);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}

@@ -1,0 +1,182 @@
+// Weight gradient of the 3x3x3 / 1x3x3 convolution on the bf16 matrix cores (autograd's dW of nn.Conv3d as conv3() builds it,
+// elektronn3/models/unet.py:131-149):
+//
+//   dW[co][ci][tap] = sum over voxels v:  dY[v][co] * X[v + tap][ci]
+//
+// A GEMM whose contraction index is the VOXEL, while both tensors are stored channel-contiguous (NDHWC).  gfx950's transposing LDS
+// read (ds_read_b64_tr_b16) delivers exactly the k-major fragments v_mfma_f32_32x32x16_bf16 wants from [voxel][32 channels] images:
+// within a 16-lane group, lane t supplies the address of 4 consecutive channels of voxel row t/4 and receives channel t of the
+// four rows.  64-byte rows make those reads conflict-free at any tap shift, and let the LDS-DMA staging
+// (buffer_load_dwordx4 ... lds) copy whole 64-byte row segments with no swizzle.
+//
+// Workgroup = (32 co x 32 ci) tile x ALL taps over a contiguous range of 2x8x16-voxel bricks; the 4 waves split the taps
+// (7/7/7/6 accumulator tiles, resident over the whole range: no atomics, fixed summation order).  A k-step = the 16 voxels of one
+// w-row; the dY fragment of a k-step is shared by the wave's taps.  Result: fp32 partial slabs part[split][tap][co][ci] in the
+// layout of the fp32 path, finished by wgrad_reduce_kernel.
+#include "bf16.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// (a plain function: called straight from a kernel TEMPLATE, hipcc's host pass drops the kernel's stub)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, lds_ptr_t dst, int, unsigned voff, int, int, int) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, 0, 0, 0);
+}
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr unsigned OOB = 0x80000000u;
+constexpr int HH = 10, HW = 18;
+
+__device__ __forceinline__ bf16x8 tr_frag(unsigned addr) {       // 8 k-values: rows 0..3 (addr) and 4..7 (addr + 4 rows)
+    typedef s16x4 __attribute__((address_space(3))) * lp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)addr);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(addr + 256));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ unsigned range_mask(int lo, int n, int size) {      // bit z set: lo + z in [0, size), z in [0, n)
+    const int first = lo < 0 ? -lo : 0, last = size - lo < n ? size - lo : n;
+    return last > first ? (unsigned)(((1ull << last) - 1ull) & ~((1ull << first) - 1ull)) : 0u;
+}
+
+template <int KD>
+__global__ __launch_bounds__(256, 2) void wgrad_b16_kernel(const WgradB16Args a, int tilesD, int tilesH, int tilesW, int bricks_per_split,
+                                                           int co_tiles, int ci_tiles) {
+    constexpr int HD = 2 + (KD == 3 ? 2 : 0), PD = KD == 3 ? 1 : 0;
+    constexpr int HV = HD * HH * HW;
+    constexpr int XP = (HV * 4 + 63) / 64;        // 1 KB pieces of the X image (45 / 23)
+    constexpr int XI = (XP + 3) / 4;
+    constexpr int XIMG = XP * 1024;
+    constexpr int TAPS = KD * 9, TPW = (TAPS + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int ci_t = L % ci_tiles; L /= ci_tiles;
+    const int co_t = L % co_tiles; const int split = L / co_tiles;
+    const int ci0 = ci_t * 32, co0 = co_t * 32;
+    const int nbricks = a.N * tilesD * tilesH * tilesW;
+    const int brick0 = split * bricks_per_split;
+    const int brick1 = brick0 + bricks_per_split < nbricks ? brick0 + bricks_per_split : nbricks;
+
+    // ---- staging plan.  Validity of a halo voxel is separable: one scalar mask per brick (4 d | 10 h | 18 w bits), one constant
+    // 3-bit pattern per lane and piece
+    unsigned xpm[XI], xrel[XI];
+#pragma unroll
+    for (int it = 0; it < XI; ++it) {
+        const int idx = (it * 4 + wave) * 64 + lane;
+        const int v = idx >> 2, q = idx & 3;
+        const int zw = v % HW, zh = (v / HW) % HH, zd = v / (HW * HH);
+        xpm[it] = v < HV ? (1u << zd) | (1u << (4 + zh)) | (1u << (14 + zw)) : 0xffffffffu;
+        xrel[it] = (unsigned)((((zd * a.H + zh) * a.W + zw) * a.x_ldc + ci0) * 2 + q * 16);
+    }
+    unsigned gpm[4], grel[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = (it * 4 + wave) * 64 + lane;
+        const int v = idx >> 2, q = idx & 3;
+        const int ww = v & 15, hh = (v >> 4) & 7, dd = v >> 7;
+        gpm[it] = (1u << dd) | (1u << (4 + hh)) | (1u << (14 + ww));
+        grel[it] = (unsigned)((((dd * a.H + hh) * a.W + ww) * a.dy_ldc + co0) * 2 + q * 16);
+    }
+    const size_t samp_x = (size_t)a.D * a.H * a.W * a.x_ldc, samp_g = (size_t)a.D * a.H * a.W * a.dy_ldc;
+
+    // ---- fragment addresses
+    const int G = lane >> 4, t = lane & 15;
+    const int krow = 8 * (G >> 1) + (t >> 2), chb = (16 * (G & 1) + 4 * (t & 3)) * 2;
+    const unsigned ybase = (unsigned)(XIMG + krow * 64 + chb);                  // + k-step * 1024
+    unsigned xt[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        int tap = wave * TPW + i; tap = tap < TAPS ? tap : TAPS - 1;            // (the last wave repeats a tap in its spare slot)
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        xt[i] = (unsigned)((((kd * HH + kh) * HW + kw) + krow) * 64 + chb);     // + ((dd * HH + hh) * HW) * 64
+    }
+
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    for (int brick = brick0; brick < brick1; ++brick) {
+        int Lt = brick;
+        const int tw_ = Lt % tilesW; Lt /= tilesW; const int th_ = Lt % tilesH; Lt /= tilesH; const int td_ = Lt % tilesD; const int nb = Lt / tilesD;
+        const int d0 = td_ * 2, h0 = th_ * 8, w0 = tw_ * 16;
+        const unsigned xmask = range_mask(d0 - PD, HD, a.D) | (range_mask(h0 - 1, HH, a.H) << 4) | (range_mask(w0 - 1, HW, a.W) << 14);
+        const unsigned gmask = range_mask(d0, 2, a.D) | (range_mask(h0, 8, a.H) << 4) | (range_mask(w0, 16, a.W) << 14);
+        const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x) + (size_t)nb * samp_x, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.dy) + (size_t)nb * samp_g, 0, 0x7fffffff, 0x00020000);
+        const unsigned xbase = (unsigned)(((((d0 - PD) * a.H + h0 - 1) * a.W + w0 - 1) * a.x_ldc) * 2);   // wraps at the borders
+        const unsigned gbase = (unsigned)((((d0 * a.H + h0) * a.W + w0) * a.dy_ldc) * 2);
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            const int wi = it * 4 + wave;
+            if (wi < XP) {
+                const bool ok = (xmask & xpm[it]) == xpm[it];
+                dma16(x_rs, (lds_ptr_t)(smem + wi * 1024), 16, ok ? xrel[it] + xbase : OOB, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const bool ok = (gmask & gpm[it]) == gpm[it];
+            dma16(g_rs, (lds_ptr_t)(smem + XIMG + (it * 4 + wave) * 1024), 16, ok ? grel[it] + gbase : OOB, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int dd = s >> 3, hh = s & 7;
+            const bf16x8 af = tr_frag(ybase + s * 1024);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const bf16x8 bfr = tr_frag(xt[i] + ((dd * HH + hh) * HW) * 64);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- slab: part[split][tap][CoPad][CiPad]; lane holds column ci = lane & 31, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const int CoPad = co_tiles * 32, CiPad = ci_tiles * 32;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int tap = wave * TPW + i;
+        if (tap >= TAPS) continue;
+        float* dst = a.part + (((size_t)split * TAPS + tap) * CoPad + co0) * CiPad + ci0 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dst[(size_t)((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * CiPad] = acc[i][e];
+    }
+}
+
+}  // namespace
+
+int wgrad_b16_splits(int N, int D, int H, int W, int Cin, int Cout, int planar) {
+    (void)planar;
+    const int nbricks = N * cdiv(D, 2) * cdiv(H, 8) * cdiv(W, 16);
+    const int tiles = (Cin / 32) * (Cout / 32);
+    int splits = cdiv(512, tiles);
+    if (splits > nbricks) splits = nbricks;
+    if (splits < 1) splits = 1;
+    const int per = cdiv(nbricks, splits);
+    return cdiv(nbricks, per);                 // no empty split
+}
+
+int launch_wgrad_b16(WgradB16Args a, hipStream_t s) {
+    E3_REQUIRE(a.Cin % 32 == 0 && a.Cout % 32 == 0, E3_ERR_UNSUPPORTED, "bf16 wgrad: channel counts must be multiples of 32");
+    E3_REQUIRE(a.x_ldc % 8 == 0 && a.dy_ldc % 8 == 0, E3_ERR_INVALID, "bf16 wgrad: misaligned view");
+    const int tD = cdiv(a.D, 2), tH = cdiv(a.H, 8), tW = cdiv(a.W, 16);
+    const int nbricks = a.N * tD * tH * tW;
+    const int per = cdiv(nbricks, a.splits);
+    const int co_tiles = a.Cout / 32, ci_tiles = a.Cin / 32;
+    const unsigned grid = (unsigned)(a.splits * co_tiles * ci_tiles);
+    if (a.planar) {
+        constexpr int lds = ((2 * HH * HW * 4 + 63) / 64) * 1024 + 16384;
+        hipLaunchKernelGGL(wgrad_b16_kernel<1>, dim3(grid), dim3(256), lds, s, a, tD, tH, tW, per, co_tiles, ci_tiles);
+    } else {
+        constexpr int lds = ((4 * HH * HW * 4 + 63) / 64) * 1024 + 16384;
+        hipLaunchKernelGGL(wgrad_b16_kernel<3>, dim3(grid), dim3(256), lds, s, a, tD, tH, tW, per, co_tiles, ci_tiles);
+    }
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}

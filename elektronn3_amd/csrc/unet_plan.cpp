@@ -13,53 +13,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../../include/e3unet.h"
-#include "kernels.h"
-
-namespace {
-
-struct ParamSlot { std::string name; int64_t numel; int kind; };
-
-struct ConvUnit {           // conv (3x3x3 | 1x3x3 | transposed 2x2x2) followed by BatchNorm + ReLU
-    std::string name;       // e.g. "down_convs.0.conv1"
-    std::string bn_name;    // e.g. "down_convs.0.norm0"
-    int cin, cout, level;   // level = resolution level of the OUTPUT
-    int planar;             // planar block (1x3x3 / (1,2,2))
-    int is_up;              // 1: transposed conv, 2: ResizeConv = nearest up-sampling + 3x3x3 conv (input at level+1); 0: plain conv
-    int p_w, p_b, p_g, p_be, p_rm, p_rv;   // indices into the param table
-    int p_a;                // nn.PReLU weight of the activation after this conv ('prelu'), -1 otherwise
-    int bn_index;           // -1: no normalisation after this conv (nn.Identity): conv -> bias -> ReLU
-    bool has_norm() const { return bn_index >= 0; }
-};
-
-struct Arena {              // bump allocator used twice: once with base == nullptr to size, once to place
-    char* base; size_t off;
-    explicit Arena(void* b) : base((char*)b), off(0) {}
-    float* take(size_t floats) {
-        float* p = base ? (float*)(base + off) : nullptr;
-        off += align_up(floats * sizeof(float), 256);
-        return p;
-    }
-};
-
-struct LevelDims { int D, H, W; size_t vox; };
-
-}  // namespace
-
-struct e3_unet_plan {
-    e3_unet_cfg cfg;
-    std::vector<ParamSlot> params;
-    std::vector<ConvUnit> units;      // execution order of the forward
-    int p_final_w, p_final_b;
-    int n_bn;
-    // profiling
-    int prof_layer = -1, prof_which = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
-    size_t prof_used = 0;
-
-    bool planar(int level) const { return (cfg.planar_mask >> level) & 1u; }
-    int chan(int level) const { return cfg.start_filts << level; }
-};
+#include "plan_internal.h"
 
 namespace {
 
@@ -91,22 +45,9 @@ void add_unit(e3_unet_plan* p, const std::string& conv, const std::string& bn, i
     p->units.push_back(u);
 }
 
-// Dimensions of every tensor of the network for an (N, D, H, W) input.  conv_mode='same': one size per resolution level.
-// conv_mode='valid' (padding 0, unet.py:217,347): every 3x3x3 conv shrinks its grid by 2 (planar: H and W only), so each unit has its own
-// input / output size; the up-convolved tensor is cropped by one voxel where its size differs from the skip's by an odd amount and the
-// skip is centre-cropped to it (autocrop, unet.py:256-325).
-struct UnitDims { LevelDims in, out; int od, oh, ow; };   // in: the unit's input tensor = the grid its conv kernel runs on (transposed conv /
-                                                          // ResizeConv: the LOW-resolution input); out: its output tensor; (od, oh, ow): where
-                                                          // `out` sits inside the conv grid (valid convs: 1 voxel in, 0 along D for planar)
-struct NetDims {
-    std::vector<UnitDims> u;
-    std::vector<LevelDims> E, X;       // per level: the encoder's skip activation (before the pool), the level's input
-    std::vector<int> sd_, sh_, sw_;    // per level: offset of the centre crop of the skip inside E
-    LevelDims Y;                       // output of the last unit = grid of the logits
-    bool ok;
-};
-
 LevelDims mkdims(int N, int D, int H, int W) { return {D, H, W, (size_t)N * (size_t)(D > 0 ? D : 0) * (size_t)(H > 0 ? H : 0) * (size_t)(W > 0 ? W : 0)}; }
+
+}  // namespace
 
 void net_dims(const e3_unet_plan* p, int N, int D, int H, int W, NetDims& nd) {
     const int nb = p->cfg.n_blocks;
@@ -146,6 +87,8 @@ void net_dims(const e3_unet_plan* p, int N, int D, int H, int W, NetDims& nd) {
     }
     nd.Y = cur;
 }
+
+namespace {
 
 // ---- buffers -----------------------------------------------------------------------------------------------
 struct UnitBufs { float* raw; float* act; int act_ldc; float* mean; float* invstd; float* scale; float* shift; };

@@ -102,6 +102,10 @@ class CombinedCEDiceLoss(torch.nn.Module):
         return sums
 
     def forward(self, output, target):
+        if output.dtype in (torch.bfloat16, torch.float16):
+            # logits of a low-precision module (model.bfloat16(), autocast): the criterion's sums are fp32 either way (ATen's
+            # cross_entropy accumulates bf16 inputs in fp32 too); autograd casts the logits gradient back
+            output = output.float()
         reduce_sums, scale = None, 1.0
         if self.global_batch:
             world = self._world()

@@ -224,3 +224,96 @@ def to_ncdhw(x_ndhwc):
     out = torch.empty((N, C, D, H, W), device=x_ndhwc.device, dtype=torch.float32)
     check(L.e3_ndhwc_to_ncdhw(stream_ptr(x_ndhwc.device), ptr(x_ndhwc), _ldc(x_ndhwc), ptr(out), N, C, D, H, W))
     return out
+
+
+# ---------------------------------------------------------------------------------------------- native bf16 ops
+def _chk16(t, name):
+    if not (t.is_cuda and t.dtype == torch.bfloat16):
+        raise ValueError(f'{name}: expected a bfloat16 CUDA tensor')
+    if t.dim() == 5:
+        _ldc(t)
+    return t
+
+
+def conv3d_bf16(x, w, bias=None, planar=False, epi=None, want_stats=False, out=None):
+    """bf16 3x3x3 / 1x3x3 'same' conv on the bf16 matrix cores. x: (N,D,H,W,Cin) bf16; w: fp32 torch layout (rounded to bf16 when packed)."""
+    L = _lib.load()
+    _chk16(x, 'x')
+    N, D, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    y = out if out is not None else torch.empty((N, D, H, W, Cout), device=x.device, dtype=torch.bfloat16)
+    ws = _ws(L.e3_conv3d_workspace_bytes_bf16(Cin, Cout, N, D, H, W, int(planar)), x.device)
+    stats = None
+    if want_stats:
+        stats = torch.zeros((L.e3_conv3d_stats_parts_bf16(Cin, Cout, N, D, H, W, int(planar)), Cout, 3), device=x.device, dtype=torch.float32)
+    w = w.float().contiguous()
+    check(L.e3_conv3d_fwd_bf16(stream_ptr(x.device), ptr(x), _ldc(x), Cin, ptr(w), ptr(bias), ptr(y), _ldc(y), Cout, N, D, H, W, int(planar),
+                               ptr(epi[0]) if epi else None, ptr(epi[1]) if epi else None, ptr(stats), ptr(ws), c_size_t(ws.numel())))
+    return (y, stats) if want_stats else y
+
+
+def conv3d_dgrad_bf16(dy, w, planar=False):
+    L = _lib.load()
+    _chk16(dy, 'dy')
+    N, D, H, W, Cout = dy.shape
+    Cin = w.shape[1]
+    dx = torch.empty((N, D, H, W, Cin), device=dy.device, dtype=torch.bfloat16)
+    ws = _ws(L.e3_conv3d_workspace_bytes_bf16(Cin, Cout, N, D, H, W, int(planar)), dy.device)
+    w = w.float().contiguous()
+    check(L.e3_conv3d_dgrad_bf16(stream_ptr(dy.device), ptr(dy), _ldc(dy), Cout, ptr(w), ptr(dx), Cin, Cin, N, D, H, W, int(planar),
+                                 ptr(ws), c_size_t(ws.numel())))
+    return dx
+
+
+def conv3d_wgrad_bf16(x, dy, planar=False):
+    L = _lib.load()
+    _chk16(x, 'x'); _chk16(dy, 'dy')
+    N, D, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    dw = torch.empty((Cout, Cin, 1 if planar else 3, 3, 3), device=x.device, dtype=torch.float32)
+    ws = _ws(L.e3_conv3d_workspace_bytes_bf16(Cin, Cout, N, D, H, W, int(planar)), x.device)
+    check(L.e3_conv3d_wgrad_bf16(stream_ptr(x.device), ptr(x), _ldc(x), Cin, ptr(dy), _ldc(dy), Cout, ptr(dw), N, D, H, W, int(planar),
+                                 ptr(ws), c_size_t(ws.numel())))
+    return dw
+
+
+def convT_bf16(x, w, bias=None, out_dims=None, want_stats=False, out=None):
+    """bf16 ConvTranspose3d(kernel = stride = 2). x: (N,D,H,W,Cin) bf16; w: (Cin,Cout,2,2,2) fp32."""
+    L = _lib.load()
+    _chk16(x, 'x')
+    N, D, H, W, Cin = x.shape
+    Cout = w.shape[1]
+    Do, Ho, Wo = out_dims if out_dims is not None else (2 * D, 2 * H, 2 * W)
+    y = out if out is not None else torch.empty((N, Do, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16)
+    ws = _ws(L.e3_convT_workspace_bytes_bf16(Cin, Cout, N, D, H, W), x.device)
+    stats = torch.zeros((L.e3_convT_stats_parts_bf16(N, D, H, W), Cout, 3), device=x.device, dtype=torch.float32) if want_stats else None
+    w = w.float().contiguous()
+    check(L.e3_convT_fwd_bf16(stream_ptr(x.device), ptr(x), _ldc(x), Cin, ptr(w), ptr(bias), ptr(y), _ldc(y), Cout, N, D, H, W, Do, Ho, Wo,
+                              ptr(stats), ptr(ws), c_size_t(ws.numel())))
+    return (y, stats) if want_stats else y
+
+
+def convT_dgrad_bf16(dy, w, in_dims):
+    L = _lib.load()
+    _chk16(dy, 'dy')
+    N, Do, Ho, Wo, Cout = dy.shape
+    Cin = w.shape[0]
+    D, H, W = in_dims
+    dx = torch.empty((N, D, H, W, Cin), device=dy.device, dtype=torch.bfloat16)
+    ws = _ws(L.e3_convT_workspace_bytes_bf16(Cin, Cout, N, D, H, W), dy.device)
+    w = w.float().contiguous()
+    check(L.e3_convT_dgrad_bf16(stream_ptr(dy.device), ptr(dy), _ldc(dy), Cout, ptr(w), ptr(dx), Cin, Cin, N, D, H, W, Do, Ho, Wo,
+                                ptr(ws), c_size_t(ws.numel())))
+    return dx
+
+
+def convT_wgrad_bf16(x, dy):
+    L = _lib.load()
+    _chk16(x, 'x'); _chk16(dy, 'dy')
+    N, D, H, W, Cin = x.shape
+    _, Do, Ho, Wo, Cout = dy.shape
+    dw = torch.empty((Cin, Cout, 2, 2, 2), device=x.device, dtype=torch.float32)
+    ws = _ws(L.e3_convT_workspace_bytes_bf16(Cin, Cout, N, D, H, W), x.device)
+    check(L.e3_convT_wgrad_bf16(stream_ptr(x.device), ptr(x), _ldc(x), Cin, ptr(dy), _ldc(dy), Cout, ptr(dw), N, D, H, W, Do, Ho, Wo,
+                                ptr(ws), c_size_t(ws.numel())))
+    return dw

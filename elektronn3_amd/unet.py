@@ -24,6 +24,7 @@ from ._lib import E3_FWD_SOFTMAX, E3_FWD_TRAINING, UNetCfg, c_size_t, c_void_p, 
 _plans = {}
 _plans_lock = threading.Lock()
 _scratch = {}
+_NO_BF16 = bool(int(__import__('os').environ.get('E3_NO_BF16', '0')))      # A/B switch: low-precision modules on the fp32 kernels
 
 
 class _Plan:
@@ -57,10 +58,16 @@ class _Plan:
         check(_lib.load().e3_unet_out_dims(self.handle, D, H, W, ctypes.byref(do), ctypes.byref(ho), ctypes.byref(wo)))
         return do.value, ho.value, wo.value
 
-    def sizes(self, N, D, H, W, training):
+    def sizes(self, N, D, H, W, training, bf16=False):
         saved, scratch = c_size_t(), c_size_t()
-        check(_lib.load().e3_unet_sizes(self.handle, N, D, H, W, int(training), ctypes.byref(saved), ctypes.byref(scratch)))
+        fn = _lib.load().e3_unet_sizes_bf16 if bf16 else _lib.load().e3_unet_sizes
+        check(fn(self.handle, N, D, H, W, int(training), ctypes.byref(saved), ctypes.byref(scratch)))
         return saved.value, scratch.value
+
+    def bf16_supported(self):
+        """True when the native bf16 kernels cover this configuration (csrc/unet_bf16.cpp); otherwise low-precision modules compute in
+        fp32 on up-cast copies."""
+        return bool(_lib.load().e3_unet_bf16_supported(self.handle))
 
 
 def _get_plan(key):
@@ -89,30 +96,54 @@ def release_scratch():
     _scratch.clear()
 
 
+def _fp32_table(module, tens):
+    """fp32 copies of a low-precision module's table tensors in ONE persistent flat buffer, refreshed with a single multi-tensor copy
+    (121 separate `.float()` launches would cost more than the forward's convolutions)."""
+    cache = module.__dict__.get('_fp32_cache')
+    key = tuple((t.data_ptr(), t.numel(), t.dtype) for t in tens)
+    if cache is None or cache[0] != key:
+        sizes = [(t.numel() + 63) // 64 * 64 for t in tens]        # 256-byte aligned slots
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=tens[0].device)
+        views, off = [], 0
+        for t, n in zip(tens, sizes):
+            views.append(flat[off:off + t.numel()].view(t.shape))
+            off += n
+        cache = (key, flat, views)
+        module.__dict__['_fp32_cache'] = cache
+    torch._foreach_copy_(cache[2], list(tens))
+    return cache[2]
+
+
 class _UNetFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, softmax, x, *params):
+    def forward(ctx, module, softmax, want_bf16, x, *params):
         plan = module._plan()
         lib = _lib.load()
         dev = x.device
         in_dtype = x.dtype
-        x32 = x.detach().to(torch.float32).contiguous()
-        N, Cin, D, H, W = x32.shape
+        N, Cin, D, H, W = x.shape
         training = module.training or module._per_sample_norm()   # instance / group statistics also in eval mode
         # parameters / buffers at call time, in the plan's table order
         tens = module._table(plan, params)
         lowp = None
         if any(t.dtype != torch.float32 for t in tens):
-            # model.half() / model.bfloat16() (Predictor(float16=True), BASELINE cfg 3's bf16 storage): the kernels compute in fp32 on
-            # up-cast copies -- at least the reference's precision -- and results are cast back (the output below, gradients in backward,
-            # the running statistics right after the call)
+            # model.half() / model.bfloat16() (Predictor(float16=True), BASELINE cfg 3's bf16 storage): the parameter table handed to the
+            # library is fp32 (up-cast copies; results are cast back: the output below, gradients in backward, the running statistics
+            # right after the call).  bf16 modules on a covered configuration COMPUTE in bf16 (native kernels, see below).
             lowp = tens
-            tens = [t.float() for t in tens]
+            tens = _fp32_table(module, tens)
         tens = [t if t.is_contiguous() else t.contiguous() for t in tens]
+        # native bf16 compute (csrc/unet_bf16.cpp): bf16 module + bf16 input, or torch.autocast(dtype=bfloat16) around any module
+        all_bf16 = lowp is not None and all(t.dtype == torch.bfloat16 for t in lowp if t.is_floating_point())
+        b16 = (want_bf16 or (all_bf16 and in_dtype == torch.bfloat16)) and not ctx.needs_input_grad[3] and plan.bf16_supported() \
+            and not _NO_BF16
+        ctx.b16 = b16
+        xin = x.detach().to(torch.bfloat16 if b16 else torch.float32).contiguous()
+        out_dtype = torch.bfloat16 if (b16 and want_bf16) else in_dtype
         # (grad mode is off inside Function.forward; needs_input_grad tells whether a backward can follow)
         need_grad = training and any(ctx.needs_input_grad)
         ctx.eval_mode = not training
-        saved_bytes, scratch_bytes = plan.sizes(N, D, H, W, training)
+        saved_bytes, scratch_bytes = plan.sizes(N, D, H, W, training, bf16=b16)
         saved = torch.empty(max(saved_bytes, 256), dtype=torch.uint8, device=dev) if training else None
         scratch = _get_scratch(dev, max(scratch_bytes, 256))
         Do, Ho, Wo = plan.out_dims(D, H, W)      # == (D, H, W) unless conv_mode='valid'
@@ -123,26 +154,29 @@ class _UNetFunction(torch.autograd.Function):
             moms = module._momenta(plan)
             momenta = (ctypes.c_float * len(moms))(*moms)
         flags = (E3_FWD_TRAINING if training else 0) | (E3_FWD_SOFTMAX if softmax else 0)
+        fwd = lib.e3_unet_forward_bf16 if b16 else lib.e3_unet_forward
         with torch.cuda.device(dev):
-            check(lib.e3_unet_forward(plan.handle, _lib.stream_ptr(dev), c_void_p(x32.data_ptr()), N, D, H, W, ptrs, momenta,
-                                      c_void_p(y.data_ptr()), c_void_p(saved.data_ptr()) if saved is not None else None,
-                                      c_size_t(saved.numel() if saved is not None else 0),
-                                      c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), flags))
+            check(fwd(plan.handle, _lib.stream_ptr(dev), c_void_p(xin.data_ptr()), N, D, H, W, ptrs, momenta,
+                      c_void_p(y.data_ptr()), c_void_p(saved.data_ptr()) if saved is not None else None,
+                      c_size_t(saved.numel() if saved is not None else 0),
+                      c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), flags))
         if training:
             module._bump_num_batches_tracked(plan)
             if lowp is not None:         # running statistics were updated in the fp32 copies
-                for kind, lo_t, hi_t in zip(plan.kinds, lowp, tens):
-                    if kind != 0 and lo_t.dtype != torch.float32:
-                        lo_t.copy_(hi_t)
+                pairs = [(lo_t, hi_t) for kind, lo_t, hi_t in zip(plan.kinds, lowp, tens) if kind != 0 and lo_t.dtype != torch.float32]
+                if pairs:
+                    torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])
         ctx.module, ctx.plan = module, plan
         ctx.softmax = softmax
         ctx.shape = (N, D, H, W)
         ctx.in_dtype = in_dtype
         if need_grad:
-            ctx.x32, ctx.saved_buf, ctx.tens = x32, saved, tens
+            # (a low-precision module's fp32 table is a cache that the next forward refreshes with the same parameter values:
+            # the backward only reads weights and affine parameters from it, never the running statistics)
+            ctx.x32, ctx.saved_buf, ctx.tens = xin, saved, tens
         else:
             ctx.x32 = ctx.saved_buf = ctx.tens = None
-        return y if in_dtype == torch.float32 else y.to(in_dtype)
+        return y if out_dtype == torch.float32 else y.to(out_dtype)
 
     @staticmethod
     def backward(ctx, dy):
@@ -163,26 +197,39 @@ class _UNetFunction(torch.autograd.Function):
         flat, views = (sync.flat_views(plan, tens) if sync is not None else _flat_views(plan, tens, dev))
         gptrs = (c_void_p * len(tens))(*[(v.data_ptr() if v is not None else None) for v in views])
         ptrs = (c_void_p * len(tens))(*[t.data_ptr() for t in tens])
-        dx = torch.empty_like(ctx.x32) if ctx.needs_input_grad[2] else None
-        _, scratch_bytes = plan.sizes(N, D, H, W, True)
+        dx = torch.empty_like(ctx.x32) if ctx.needs_input_grad[3] else None
+        _, scratch_bytes = plan.sizes(N, D, H, W, True, bf16=ctx.b16)
         scratch = _get_scratch(dev, max(scratch_bytes, 256))
         ev, ev_blk = (sync.bucket_event(), sync.bucket_after_down_block) if sync is not None else (None, 0)
+        bwd = lib.e3_unet_backward_bf16 if ctx.b16 else lib.e3_unet_backward
         with torch.cuda.device(dev):
-            check(lib.e3_unet_backward(plan.handle, _lib.stream_ptr(dev), c_void_p(dy32.data_ptr()), c_void_p(ctx.x32.data_ptr()),
-                                       N, D, H, W, ptrs, gptrs, c_void_p(dx.data_ptr()) if dx is not None else None,
-                                       c_void_p(ctx.saved_buf.data_ptr()), c_size_t(ctx.saved_buf.numel()),
-                                       c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), ev, ev_blk))
+            check(bwd(plan.handle, _lib.stream_ptr(dev), c_void_p(dy32.data_ptr()), c_void_p(ctx.x32.data_ptr()),
+                      N, D, H, W, ptrs, gptrs, c_void_p(dx.data_ptr()) if dx is not None else None,
+                      c_void_p(ctx.saved_buf.data_ptr()), c_size_t(ctx.saved_buf.numel()),
+                      c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), ev, ev_blk))
         if sync is not None:
             sync.after_backward(plan)
         ctx.saved_buf = ctx.x32 = ctx.tens = None   # free the activations now
+        named = list(module._named_table_params(plan))
+        lowp_dtype = next((p.dtype for _, p in named if p.dtype != torch.float32), None)
+        if lowp_dtype is not None and all(p.dtype == lowp_dtype for _, p in named):
+            # one cast of the whole flat buffer instead of one launch per parameter
+            flat_lo = flat.to(lowp_dtype)
+            off_of = {}
+            off = 0
+            for v in views:
+                if v is not None:
+                    off_of[v.data_ptr()] = off
+                    off += v.numel()
+            views = [flat_lo[off_of[v.data_ptr()]:off_of[v.data_ptr()] + v.numel()] if v is not None else None for v in views]
         by_name = dict(zip(plan.names, views))
         grads = []
-        for name, p in module._named_table_params(plan):
+        for name, p in named:
             g = by_name[name].view_as(p)
             grads.append(g if g.dtype == p.dtype else g.to(p.dtype))
         if dx is not None and dx.dtype != ctx.in_dtype:
             dx = dx.to(ctx.in_dtype)
-        return (None, None, dx, *grads)
+        return (None, None, None, dx, *grads)
 
 
 def _flat_views(plan, tens, device):
@@ -449,6 +496,7 @@ class UNet(nn.Module):
         state = self.__dict__.copy()
         state.pop('_grad_sync', None)
         state.pop('_inst_consts', None)
+        state.pop('_fp32_cache', None)
         return state
 
     # ------------------------------------------------------------------ native plumbing
@@ -535,14 +583,18 @@ class UNet(nn.Module):
             raise NotImplementedError("activation='rrelu' in train mode (a random slope per element) is not on the HIP path; eval mode is")
         plan = self._plan()
         params = [p for _, p in self._named_table_params(plan)]
+        # torch.autocast('cuda', dtype=torch.bfloat16) around the call (the bf16 counterpart of Trainer(mixed_precision=True),
+        # trainer.py:519), or module.compute_dtype = torch.bfloat16: bf16 compute with the module's own (fp32 master) parameters
+        want_bf16 = (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16) \
+            or getattr(self, 'compute_dtype', None) == torch.bfloat16
         if any(p.device != x.device for p in params):
             raise RuntimeError('input and parameters are on different devices')
         if self._per_sample_norm():
             # per-sample statistics in training AND eval mode (nn.InstanceNorm3d defaults, nn.GroupNorm): one native call per sample;
             # autograd sums the parameter gradients of the calls
-            y = torch.cat([_UNetFunction.apply(self, softmax, x[n:n + 1], *params) for n in range(x.shape[0])], 0)
+            y = torch.cat([_UNetFunction.apply(self, softmax, want_bf16, x[n:n + 1], *params) for n in range(x.shape[0])], 0)
         else:
-            y = _UNetFunction.apply(self, softmax, x, *params)
+            y = _UNetFunction.apply(self, softmax, want_bf16, x, *params)
         return y.squeeze(2) if self.dim == 2 else y
 
     def forward_softmax(self, x):

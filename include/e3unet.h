@@ -236,6 +236,51 @@ int e3_adamw_step(void* stream, int n_tensors, void* const* params, void* const*
 int e3_swa_update(void* stream, int n_tensors, void* const* params, void* const* swa_buffers, const long long* numels, long long n_avg);
 int e3_swa_swap(void* stream, int n_tensors, void* const* params, void* const* swa_buffers, const long long* numels);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Native bf16 path (BASELINE.json configs[2]: the same U-Net with bf16 storage).
+ *   The reference's reduced-precision switches are Trainer(mixed_precision=True) (torch.cuda.amp.autocast,
+ *   elektronn3/training/trainer.py:367,519), Predictor(float16=True) / model.half() (elektronn3/inference/inference.py:408,445-446)
+ *   and pred_benchmark's model.to(device, dtype) (benchmark/pred_benchmark.py:55,71); their bf16 counterpart is
+ *   model.to(torch.bfloat16) with bf16 inputs, or torch.autocast('cuda', dtype=torch.bfloat16) around a fp32 module.
+ *   Activations and their gradients are bf16 NDHWC in HBM, convolutions run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation,
+ *   BatchNorm statistics / coefficients / parameter gradients are fp32; like a bf16 torch module every op rounds its result once.
+ *   x: [N,in,D,H,W] bf16 NCDHW; params / grads: the SAME fp32 tables as e3_unet_forward / e3_unet_backward (conv weights are
+ *   rounded to bf16 while they are packed); y / dy: fp32 NCDHW logits (values representable in bf16) and their gradient.
+ *   dx must be NULL (no input gradient on this path).  e3_unet_bf16_supported(): 1 when the plan's configuration is covered
+ *   (dim 3, no planar blocks, 'batch' norm with full_norm, ReLU, 'transpose', 'concat', 'same', in_channels < 8,
+ *   start_filts % 32 == 0, out_channels <= 8); other configurations compute in fp32 on up-cast copies.
+ * ---------------------------------------------------------------------------------------------------------- */
+int e3_unet_bf16_supported(const e3_unet_plan* plan);
+int e3_unet_sizes_bf16(const e3_unet_plan* plan, int N, int D, int H, int W, int training, size_t* saved_bytes, size_t* scratch_bytes);
+int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N, int D, int H, int W,
+                         void* const* params, const float* momenta, float* y,
+                         void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags);
+int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, const void* x, int N, int D, int H, int W,
+                          void* const* params, void* const* grads, void* dx,
+                          void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                          void* bucket_event, int bucket_after_down_block);
+/* Per-op entry points of the bf16 path (unit parity tests): bf16 NDHWC views, fp32 torch-layout weights / weight gradients.
+ *   e3_conv3d_*_bf16    nn.Conv3d k=3 (planar: (1,3,3)), stride 1, padding 1            [unet.py:131-149]; Cin, Cout multiples of 32
+ *   e3_convT_*_bf16     nn.ConvTranspose3d k = s = 2 with the autocrop box (Do,Ho,Wo)   [unet.py:152-165,289-299]
+ * stats: NULL or e3_*_stats_parts_bf16() records of (count, mean, M2) per channel of the stored (rounded) output. */
+size_t e3_conv3d_workspace_bytes_bf16(int Cin, int Cout, int N, int D, int H, int W, int planar);
+int e3_conv3d_stats_parts_bf16(int Cin, int Cout, int N, int D, int H, int W, int planar);
+int e3_conv3d_fwd_bf16(void* stream, const void* x, int x_ldc, int Cin, const float* w, const float* bias, void* y, int y_ldc, int Cout,
+                       int N, int D, int H, int W, int planar, const float* epi_scale, const float* epi_shift, float* stats,
+                       void* workspace, size_t workspace_bytes);
+int e3_conv3d_dgrad_bf16(void* stream, const void* dy, int dy_ldc, int Cout, const float* w, void* dx, int dx_ldc, int Cin,
+                         int N, int D, int H, int W, int planar, void* workspace, size_t workspace_bytes);
+int e3_conv3d_wgrad_bf16(void* stream, const void* x, int x_ldc, int Cin, const void* dy, int dy_ldc, int Cout, float* dw,
+                         int N, int D, int H, int W, int planar, void* workspace, size_t workspace_bytes);
+size_t e3_convT_workspace_bytes_bf16(int Cin, int Cout, int N, int D, int H, int W);
+int e3_convT_stats_parts_bf16(int N, int D, int H, int W);
+int e3_convT_fwd_bf16(void* stream, const void* x, int x_ldc, int Cin, const float* w, const float* bias, void* y, int y_ldc, int Cout,
+                      int N, int D, int H, int W, int Do, int Ho, int Wo, float* stats, void* workspace, size_t workspace_bytes);
+int e3_convT_dgrad_bf16(void* stream, const void* dy, int dy_ldc, int Cout, const float* w, void* dx, int dx_ldc, int Cin,
+                        int N, int D, int H, int W, int Do, int Ho, int Wo, void* workspace, size_t workspace_bytes);
+int e3_convT_wgrad_bf16(void* stream, const void* x, int x_ldc, int Cin, const void* dy, int dy_ldc, int Cout, float* dw,
+                        int N, int D, int H, int W, int Do, int Ho, int Wo, void* workspace, size_t workspace_bytes);
+
 /* Layout conversion at the module boundary. */
 int e3_ncdhw_to_ndhwc(void* stream, const float* src, float* dst, int N, int C, int D, int H, int W);
 int e3_ndhwc_to_ncdhw(void* stream, const float* src, int src_ldc, float* dst, int N, int C, int D, int H, int W);

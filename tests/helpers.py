@@ -106,3 +106,18 @@ def combined_loss_np(logits, target, cw=CLASS_WEIGHTS):
     dL_dp = (cw / C).reshape(shp) * (-(2 * onehot) / den.reshape(shp) + (num / den ** 2).reshape(shp))
     ddice = p * (dL_dp - (dL_dp * p).sum(axis=1, keepdims=True))
     return 0.5 * ce + 0.5 * dice, 0.5 * dce + 0.5 * ddice
+
+
+def load_bf16_fixture(path):
+    """npz -> {key: fp32 tensor}; keys ending in ':bf16' hold bf16 values as their 16-bit patterns (tests/golden/make_golden.py)."""
+    import numpy as np
+    import torch
+    g = np.load(path)
+    out = {}
+    for k in g.files:
+        a = np.array(g[k])
+        if k.endswith(':bf16'):
+            out[k[:-5]] = torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16).float()
+        else:
+            out[k] = torch.from_numpy(a) if a.ndim else torch.tensor(a.item())
+    return out

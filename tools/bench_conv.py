@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--layers', default=','.join(LAYERS))
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--what', default='fwd,dgrad,wgrad')
+    ap.add_argument('--dtype', default='f32', choices=('f32', 'bf16'))
     a = ap.parse_args()
     what = a.what.split(',')
     tot = {w: [0.0, 0.0] for w in what}
@@ -41,15 +42,20 @@ def main():
         dy = torch.randn(N, D, H, W, cout, device='cuda')
         w = torch.randn(cout, cin, 3, 3, 3, device='cuda') * 0.05
         b = torch.zeros(cout, device='cuda')
+        if a.dtype == 'bf16':
+            x, dy = x.bfloat16(), dy.bfloat16()
+            conv, dgrad, wgrad = ops.conv3d_bf16, ops.conv3d_dgrad_bf16, ops.conv3d_wgrad_bf16
+        else:
+            conv, dgrad, wgrad = ops.conv3d, ops.conv3d_dgrad, ops.conv3d_wgrad
         fl = 2.0 * cin * cout * 27 * N * D * H * W
         line = f'{name:12s} {fl / 1e9:7.1f} GF '
         for wh in what:
             if wh == 'fwd':
-                ms = timeit(lambda: ops.conv3d(x, w, b, want_stats=True), a.iters)
+                ms = timeit(lambda: conv(x, w, b, want_stats=True), a.iters)
             elif wh == 'dgrad':
-                ms = timeit(lambda: ops.conv3d_dgrad(dy, w), a.iters)
+                ms = timeit(lambda: dgrad(dy, w), a.iters)
             else:
-                ms = timeit(lambda: ops.conv3d_wgrad(x, dy), a.iters)
+                ms = timeit(lambda: wgrad(x, dy), a.iters)
             tot[wh][0] += fl; tot[wh][1] += ms
             line += f'| {wh} {ms * 1e3:8.1f} us {fl / ms / 1e9:6.1f} TF '
         print(line, flush=True)
