@@ -57,7 +57,7 @@ _SIG = {
     'e3_conv3d_dgrad_bf16': (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, c_size_t]),
     'e3_conv3d_wgrad_bf16': (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, c_size_t]),
     'e3_convT_workspace_bytes_bf16': (c_size_t, [_I, _I, _I, _I, _I, _I]),
-    'e3_convT_stats_parts_bf16': (_I, [_I, _I, _I, _I]),
+    'e3_convT_stats_parts_bf16': (_I, [_I, _I, _I, _I, _I]),
     'e3_convT_fwd_bf16': (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, c_size_t]),
     'e3_convT_dgrad_bf16': (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, c_size_t]),
     'e3_convT_wgrad_bf16': (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, c_size_t]),

@@ -69,7 +69,7 @@ size_t e3_convT_workspace_bytes_bf16(int Cin, int Cout, int N, int D, int H, int
     const size_t slab = (size_t)upconv_b16_wgrad_splits(N, D, H, W) * 8 * Cin * Cout * 4;
     return pack > slab ? pack : align_up(slab, 256);
 }
-int e3_convT_stats_parts_bf16(int N, int D, int H, int W) { return upconv_b16_stats_parts(N, D, H, W, 2); }
+int e3_convT_stats_parts_bf16(int Cin, int N, int D, int H, int W) { return upconv_b16_stats_parts(N, D, H, W, 2, Cin); }
 
 int e3_convT_fwd_bf16(void* stream, const void* x, int x_ldc, int Cin, const float* w, const float* bias, void* y, int y_ldc, int Cout,
                       int N, int D, int H, int W, int Do, int Ho, int Wo, float* stats, void* workspace, size_t workspace_bytes) {

@@ -72,7 +72,7 @@ struct UpconvB16Args {
     const float* epi_scale; const float* epi_shift;
     float* stats;                                  // forward: (n, mean, M2) records of the stored values
 };
-int upconv_b16_stats_parts(int N, int D, int H, int W, int sd);
+int upconv_b16_stats_parts(int N, int D, int H, int W, int sd, int Cin);
 size_t upconv_b16_packed_elems(int Cin, int Cout, int sd);
 int launch_pack_upconv_b16(const float* w /*torch (Cin, Cout, T)*/, bf16_t* out, int Cin, int Cout, int sd, int dgrad, hipStream_t s);
 int launch_upconv_b16_fwd(UpconvB16Args a, hipStream_t s);

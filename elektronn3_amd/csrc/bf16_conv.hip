@@ -320,9 +320,11 @@ __global__ void pack_multi_b16_kernel(const PackMultiArgs a) {
         } else {                    // transposed conv: [row tile][k-step][32][2][8]; torch (Cin, Cout, T)
             const int dgrad = J.mode - 2;
             const int K = dgrad ? J.T * J.Cout : J.Cin;
-            const int rr = r & 31; r >>= 5;
+            // (e and g were peeled off above as if g were the second index; the transposed-conv layout is [..][2][32][8])
+            const size_t q5 = (r << 1) | g;
+            const int rr = q5 & 31, gg = (q5 >> 5) & 1; r = q5 >> 6;
             const int ks = r % (K >> 4); const int rt = (int)(r / (K >> 4));
-            const int row = rt * 32 + rr, k = ks * 16 + g * 8 + e;
+            const int row = rt * 32 + rr, k = ks * 16 + gg * 8 + e;
             int ci, co, tap;
             if (dgrad) { ci = row; tap = k / J.Cout; co = k % J.Cout; } else { tap = rt % J.T; co = (rt / J.T) * 32 + rr; ci = k; }
             v = J.w[((size_t)ci * J.Cout + co) * J.T + tap];

@@ -21,14 +21,15 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 constexpr unsigned OOB = 0x80000000u;
 
-// packed weights: [row tile][k-step][32 rows][2][8] bf16
+// packed weights: [row tile][k-step][2][32 rows][8] bf16 (k-group major: a wave's fragment is 1 KB, read lane-linearly from LDS or L2)
 //   forward: rows = (co tile, tap, 32 channels), K = ci;   dgrad: rows = ci, K = (tap, co)
 __global__ void pack_upconv_b16_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cin, int Cout, int T, int dgrad) {
     const int rows = dgrad ? Cin : T * Cout, K = dgrad ? T * Cout : Cin;
     const size_t total = (size_t)rows * K;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         size_t r = i;
-        const int e = r & 7; r >>= 3; const int g = r & 1; r >>= 1; const int rr = r & 31; r >>= 5;
+        const int e = r & 7; r >>= 3;
+        const int rr = r & 31; r >>= 5; const int g = r & 1; r >>= 1;
         const int ks = r % (K >> 4); const int rt = (int)(r / (K >> 4));
         const int row = rt * 32 + rr, k = ks * 16 + g * 8 + e;
         int ci, co, tap;
@@ -41,7 +42,7 @@ __global__ void pack_upconv_b16_kernel(const float* __restrict__ w, bf16_t* __re
 // from L2, feeds NVT MFMAs), RT row tiles per pass.  Results leave through a per-wave LDS tile so that 4 consecutive lanes write the
 // 64 contiguous bytes of a voxel's 32 channels (16-byte stores) instead of every lane scattering 8 bytes into its own row.
 template <bool GATHER, int RT, int NVT>
-__global__ __launch_bounds__(256) void upconv_b16_kernel(const UpconvB16Args a, size_t nvox, int abl) {
+__global__ __launch_bounds__(256) void upconv_b16_kernel(const UpconvB16Args a, size_t nvox) {
     __shared__ float S[4][2][33];                                   // statistics exchange (forward only)
     __shared__ __attribute__((aligned(16))) unsigned char xp[4][32 * 80];   // per-wave transposition tile: [32 voxels][64 B + 16 pad]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,7 +73,10 @@ __global__ __launch_bounds__(256) void upconv_b16_kernel(const UpconvB16Args a, 
     };
     float ssum[16], ssq[16], cntl = 0.f;                  // forward statistics of the current co tile, summed over its taps and tiles
 
-    for (int rt0 = 0; rt0 < nrt; rt0 += RT) {
+    // blockIdx.y splits the row tiles (forward: one co tile = T row tiles per y; dgrad: RT ci tiles per y): more workgroups for the
+    // low-resolution layers, whose few voxel tiles cannot fill the chip
+    const int rt_lo = GATHER ? blockIdx.y * RT : blockIdx.y * T, rt_hi = GATHER ? rt_lo + RT : rt_lo + T;
+    for (int rt0 = rt_lo; rt0 < rt_hi && rt0 < nrt; rt0 += RT) {
         f32x16 acc[RT][NVT];
 #pragma unroll
         for (int q = 0; q < RT; ++q)
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void upconv_b16_kernel(const UpconvB16Args a, 
 #pragma unroll
             for (int q = 0; q < RT; ++q) {
                 if (rt0 + q < nrt) {
-                    const bf16x8 af = (abl & 2) ? b[0] : *reinterpret_cast<const bf16x8*>(a.wt + (((size_t)(rt0 + q) * nks + ks) * 32 + j) * 16 + g * 8);
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(a.wt + ((size_t)(rt0 + q) * nks + ks) * 512 + g * 256 + j * 8);
 #pragma unroll
                     for (int t = 0; t < NVT; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b[t], acc[q][t], 0, 0, 0);
                 }
@@ -145,16 +149,16 @@ __global__ __launch_bounds__(256) void upconv_b16_kernel(const UpconvB16Args a, 
                     if constexpr (GATHER) {
                         const unsigned xo = __shfl(xoff[t], jj);
                         const int vj = __shfl((int)vin[t], jj);
-                        if (vj && !(abl & 1)) *reinterpret_cast<u16x8*>(const_cast<bf16_t*>(a.x) + xo + cb + piece * 8) = row;
+                        if (vj) *reinterpret_cast<u16x8*>(const_cast<bf16_t*>(a.x) + xo + cb + piece * 8) = row;
                     } else {
                         const unsigned ob = __shfl(obase[t], jj), om = __shfl(okm[t], jj);
-                        if (((om >> tap) & 1u) && !(abl & 1)) *reinterpret_cast<u16x8*>(a.y + ob + tapoff(tap) + cb + piece * 8) = row;
+                        if ((om >> tap) & 1u) *reinterpret_cast<u16x8*>(a.y + ob + tapoff(tap) + cb + piece * 8) = row;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
             if constexpr (!GATHER) {
-                if (a.stats && tap == T - 1 && !(abl & 4)) {
+                if (a.stats && tap == T - 1) {
                     // one record per (workgroup, channel): count, mean, M2 over the workgroup's (voxel, tap) outputs
                     float cw = cntl;
 #pragma unroll
@@ -187,6 +191,216 @@ __global__ __launch_bounds__(256) void upconv_b16_kernel(const UpconvB16Args a, 
                 }
             }
         }
+    }
+}
+
+// Forward, the HBM-bound case (Cin = 64 or 128): persistent workgroups.  The weights of one 32-channel output tile (all taps, all of
+// K: T x Cin x 32 bf16 = 32 / 64 KB) are staged into LDS ONCE per workgroup; the workgroup then walks 128-voxel tiles of the
+// low-resolution grid, each staged by LDS-DMA (whole 128-byte row segments, double-buffered: the next tile's loads are in flight
+// during the current tile's MFMAs and stores) and read back as conflict-free ds_read_b128 fragments (16-byte pieces of a row
+// XOR-swizzled by bits 1..3 of the row).  8 accumulator tiles per wave (one per tap); stores leave through the transposition tile.
+template <int CH>      // 64-channel chunks of K
+__global__ __launch_bounds__(256, 2) void upconv_fwd_b16_kernel(const UpconvB16Args a, size_t nvox, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = 8;
+    constexpr int WB = T * CH * 4 * 1024;                 // weights [tap][chunk][k-step][1 KB]
+    constexpr int XB = CH * 128 * 128;                    // one X buffer [chunk][128 rows][128 B]
+    unsigned char* xs = smem + WB;
+    unsigned char* xp = smem + WB + 2 * XB;               // [4 waves][32 * 80]
+    float* S = reinterpret_cast<float*>(xp + 4 * 32 * 80);   // [4][2][33]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, g = lane >> 5;
+    const int cot = blockIdx.y, cb = cot * 32;
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wt), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, 0x7fffffff, 0x00020000);
+    // weights: packed [rt = cot*T + tap][ks over Cin/16][1 KB]; here [tap][chunk][ks] = the same order (ks = chunk*4 + ks4)
+    for (int p = wave; p < T * CH * 4; p += 4)
+        dma16(w_rs, (lds_ptr_t)(smem + p * 1024), 16, (unsigned)(((size_t)cot * T * CH * 4 + p) * 1024 + lane * 16), 0, 0, 0);
+    auto stage = [&](int tile, int buf) {
+        // piece index within the tile: [chunk][row][8 pieces]; 64 lanes = 8 rows
+        for (int p = wave; p < CH * 16; p += 4) {
+            const int c = p >> 4, row = ((p & 15) << 3) + (lane >> 3), pp = lane & 7;
+            const int sp = pp ^ ((row >> 1) & 7);
+            const size_t v = (size_t)tile * 128 + row;
+            dma16(x_rs, (lds_ptr_t)(xs + buf * XB + p * 1024), 16, v < nvox ? (unsigned)(v * a.x_ldc * 2 + c * 128 + sp * 16) : OOB, 0, 0, 0);
+        }
+    };
+    float ssum[16], ssq[16], cntl = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+    f32x4 bq[4], sq[4], hq[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        const int c0 = cb + 8 * qq + 4 * g;
+        bq[qq] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.epi_scale) { sq[qq] = *reinterpret_cast<const f32x4*>(a.epi_scale + c0); hq[qq] = *reinterpret_cast<const f32x4*>(a.epi_shift + c0); }
+    }
+    const int row = wave * 32 + j;
+    const unsigned xrd = (unsigned)(row * 128), xsw = (unsigned)((row >> 1) & 7);
+    const unsigned wrd = (unsigned)(g * 512 + j * 16);
+
+    int it = 0;
+    if ((int)blockIdx.x < ntiles) stage(blockIdx.x, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+        const int buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) stage(tile + gridDim.x, buf ^ 1);
+        // this lane's voxel
+        const size_t v = (size_t)tile * 128 + row;
+        const bool vin = v < nvox;
+        size_t r = vin ? v : 0;
+        const int w = r % a.W; r /= a.W; const int h = r % a.H; r /= a.H; const int d = r % a.D; const int n = (int)(r / a.D);
+        const unsigned obase = (unsigned)(((((size_t)n * a.Do + 2 * d) * a.Ho + 2 * h) * a.Wo + 2 * w) * a.y_ldc);
+        unsigned okm = 0;
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap)
+            if (vin && 2 * d + (tap >> 2) < a.Do && 2 * h + ((tap >> 1) & 1) < a.Ho && 2 * w + (tap & 1) < a.Wo) okm |= 1u << tap;
+        f32x16 acc[T];
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[tap][e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(xs + buf * XB + c * 16384 + xrd + (((2 * ks + g) ^ xsw) << 4));
+#pragma unroll
+                for (int tap = 0; tap < T; ++tap) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(smem + ((tap * CH + c) * 4 + ks) * 1024 + wrd);
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b, acc[tap], 0, 0, 0);
+                }
+            }
+        // epilogue: bias / folded BN, rounding, statistics, transposed 16-byte stores
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+            const bool ok = ((okm >> tap) & 1u) != 0;
+            cntl += ok ? 1.f : 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                u16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float val = acc[tap][4 * qq + e];
+                    if (a.epi_scale) val = fmaxf(__builtin_fmaf(val, sq[qq][e], hq[qq][e]), 0.f);
+                    else val += bq[qq][e];
+                    const bf16_t rb = f2bf(val);
+                    o[e] = rb;
+                    const float dv = ok ? bf2f(rb) - bq[qq][e] : 0.f;
+                    ssum[4 * qq + e] += dv; ssq[4 * qq + e] = __builtin_fmaf(dv, dv, ssq[4 * qq + e]);
+                }
+                *reinterpret_cast<u16x4*>(xp + wave * (32 * 80) + j * 80 + (8 * qq + 4 * g) * 2) = o;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const unsigned toff = (unsigned)((((tap >> 2) * a.Ho + ((tap >> 1) & 1)) * a.Wo + (tap & 1)) * a.y_ldc);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int jj = p * 16 + (lane >> 2), piece = lane & 3;
+                const u16x8 rowv = *reinterpret_cast<const u16x8*>(xp + wave * (32 * 80) + jj * 80 + piece * 16);
+                const unsigned ob = __shfl(obase, jj), om = __shfl(okm, jj);
+                if ((om >> tap) & 1u) *reinterpret_cast<u16x8*>(a.y + ob + toff + cb + piece * 8) = rowv;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (!a.stats) return;
+    // one record per (workgroup, channel): count, mean, M2 over all (voxel, tap) outputs this workgroup produced
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) cntl += __shfl_xor(cntl, off);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) { ssum[e] += __shfl_xor(ssum[e], off); ssq[e] += __shfl_xor(ssq[e], off); }
+    }
+    if (j == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int col = (e & 3) + 8 * (e >> 2) + 4 * g;
+            S[(wave * 2 + 0) * 33 + col] = ssum[e]; S[(wave * 2 + 1) * 33 + col] = ssq[e];
+        }
+        if (g == 0) S[(wave * 2 + 0) * 33 + 32] = cntl;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const float s = (S[0 * 33 + tid] + S[2 * 33 + tid]) + (S[4 * 33 + tid] + S[6 * 33 + tid]);
+        const float q2 = (S[1 * 33 + tid] + S[3 * 33 + tid]) + (S[5 * 33 + tid] + S[7 * 33 + tid]);
+        const float cnt = (S[0 * 33 + 32] + S[2 * 33 + 32]) + (S[4 * 33 + 32] + S[6 * 33 + 32]);
+        const int co = cb + tid;
+        const float bias = a.bias ? a.bias[co] : 0.f;
+        const float m = cnt > 0.f ? s / cnt : 0.f;
+        float* rec = a.stats + ((size_t)blockIdx.x * a.Cout + co) * 3;
+        rec[0] = cnt; rec[1] = bias + m; rec[2] = fmaxf(q2 - s * m, 0.f);
+    }
+}
+
+// Data gradient, the HBM-bound case (Cin = 64, Cout = 32: the full-resolution transposed conv of a start_filts = 32 network):
+// persistent workgroups, the whole weight matrix (64 x 256 bf16 = 32 KB) in LDS, 64-voxel tiles of the LOW-resolution grid whose
+// 8 x 64 gathered dY rows (64 B each) are staged by LDS-DMA (a lane always fetches the same voxel, one tap per instruction),
+// double-buffered.  Wave (vt, rt) owns voxel tile vt and ci tile rt: 16 MFMAs per tile; 16-byte stores through the transposition tile.
+__global__ __launch_bounds__(256, 1) void upconv_dgrad_b16_kernel(const UpconvB16Args a, size_t nvox, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int T = 8, WB = 2 * 16 * 1024, YB = T * 64 * 64;        // weights [rt][ks][1 KB]; one dY buffer [tap][64 voxels][64 B]
+    unsigned char* ys = smem + WB;
+    unsigned char* xp = smem + WB + 2 * YB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, g = lane >> 5;
+    const int vt = wave & 1, rt = wave >> 1;
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wt), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0x7fffffff, 0x00020000);
+    for (int p = wave; p < 32; p += 4) dma16(w_rs, (lds_ptr_t)(smem + p * 1024), 16, (unsigned)(p * 1024 + lane * 16), 0, 0, 0);
+    // staging: instruction k of a wave = tap k of the 16 voxels [16 wave, 16 wave + 16), lane = (voxel, 16-byte piece)
+    const int sv = 16 * wave + (lane >> 2), sp = (lane & 3) ^ ((sv >> 2) & 3);
+    auto stage = [&](int tile, int buf) {
+        const size_t v = (size_t)tile * 64 + sv;
+        const bool vin = v < nvox;
+        size_t r = vin ? v : 0;
+        const int w = r % a.W; r /= a.W; const int h = r % a.H; r /= a.H; const int d = r % a.D; const int n = (int)(r / a.D);
+        const unsigned ob = (unsigned)((((((size_t)n * a.Do + 2 * d) * a.Ho + 2 * h) * a.Wo + 2 * w) * a.y_ldc) * 2 + sp * 16);
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+            const bool ok = vin && 2 * d + (tap >> 2) < a.Do && 2 * h + ((tap >> 1) & 1) < a.Ho && 2 * w + (tap & 1) < a.Wo;
+            const unsigned toff = (unsigned)(((((tap >> 2) * a.Ho + ((tap >> 1) & 1)) * a.Wo + (tap & 1)) * a.y_ldc) * 2);
+            dma16(y_rs, (lds_ptr_t)(ys + buf * YB + (tap * 64 + 16 * wave) * 64), 16, ok ? ob + toff : OOB, 0, 0, 0);
+        }
+    };
+    const int row = vt * 32 + j;
+    const unsigned yrd = (unsigned)(row * 64), ysw = (unsigned)((row >> 2) & 3);
+    const unsigned wrd = (unsigned)(rt * 16 * 1024 + g * 512 + j * 16);
+    int it = 0;
+    if ((int)blockIdx.x < ntiles) stage(blockIdx.x, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+        const int buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) stage(tile + gridDim.x, buf ^ 1);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {           // k = (tap = ks / 2, 16 channels of dY)
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(ys + buf * YB + (ks >> 1) * 4096 + yrd + (((2 * (ks & 1) + g) ^ ysw) << 4));
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(smem + ks * 1024 + wrd);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[4 * qq + e]);
+            *reinterpret_cast<u16x4*>(xp + wave * (32 * 80) + j * 80 + (8 * qq + 4 * g) * 2) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int jj = p * 16 + (lane >> 2), piece = lane & 3;
+            const u16x8 rowv = *reinterpret_cast<const u16x8*>(xp + wave * (32 * 80) + jj * 80 + piece * 16);
+            const size_t v = (size_t)tile * 64 + vt * 32 + jj;
+            if (v < nvox) *reinterpret_cast<u16x8*>(const_cast<bf16_t*>(a.x) + v * a.x_ldc + rt * 32 + piece * 8) = rowv;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -289,8 +503,15 @@ __global__ __launch_bounds__(256, 3) void upconv_wgrad_b16_kernel(const bf16_t* 
 
 }  // namespace
 
-constexpr int UP_NVT = 1;     // 32-voxel tiles per wave
-int upconv_b16_stats_parts(int N, int D, int H, int W, int sd) { (void)sd; return (int)(((size_t)N * D * H * W + 128 * UP_NVT - 1) / (128 * UP_NVT)); }   // one record per workgroup
+constexpr int UP_NVT = 1;     // 32-voxel tiles per wave (generic kernel)
+static bool upconv_fwd_persistent(int Cin, int sd) {
+    static const bool off = getenv("E3_B16_UP_GENERIC") != nullptr;      // A/B switch
+    return !off && sd == 2 && (Cin == 64 || Cin == 128);
+}
+int upconv_b16_stats_parts(int N, int D, int H, int W, int sd, int Cin) {      // one record per workgroup
+    const int tiles = (int)(((size_t)N * D * H * W + 128 * UP_NVT - 1) / (128 * UP_NVT));
+    return upconv_fwd_persistent(Cin, sd) ? (tiles < 512 ? tiles : 512) : tiles;
+}
 
 size_t upconv_b16_packed_elems(int Cin, int Cout, int sd) { return (size_t)sd * 4 * Cin * Cout; }
 
@@ -307,8 +528,25 @@ int launch_upconv_b16_fwd(UpconvB16Args a, hipStream_t s) {
     E3_REQUIRE(a.Cin % 32 == 0 && a.Cout % 32 == 0, E3_ERR_UNSUPPORTED, "bf16 transposed conv: channel counts must be multiples of 32");
     E3_REQUIRE(a.x_ldc % 8 == 0 && a.y_ldc % 4 == 0, E3_ERR_INVALID, "bf16 transposed conv: misaligned view");
     const size_t nvox = (size_t)a.N * a.D * a.H * a.W;
-    E3_REQUIRE((size_t)a.N * a.Do * a.Ho * a.Wo * a.y_ldc < (1ull << 32) && nvox * a.x_ldc < (1ull << 32), E3_ERR_UNSUPPORTED, "bf16 transposed conv: tensor too large for 32-bit element offsets");
-    hipLaunchKernelGGL((upconv_b16_kernel<false, 4, UP_NVT>), dim3((unsigned)((nvox + 128 * UP_NVT - 1) / (128 * UP_NVT))), dim3(256), 0, s, a, nvox, getenv("E3_UP_ABL") ? atoi(getenv("E3_UP_ABL")) : 0);
+    E3_REQUIRE((size_t)a.N * a.Do * a.Ho * a.Wo * a.y_ldc < (1ull << 32) && nvox * a.x_ldc < (1ull << 31), E3_ERR_UNSUPPORTED, "bf16 transposed conv: tensor too large for 32-bit element offsets");
+    if (upconv_fwd_persistent(a.Cin, a.sd)) {
+        const int tiles = (int)((nvox + 127) / 128);
+        const int gx = tiles < 512 ? tiles : 512;
+        const int CH = a.Cin / 64;
+        const int lds = 8 * CH * 4 * 1024 + 2 * CH * 16384 + 4 * 32 * 80 + 4 * 2 * 33 * 4;
+        if (CH == 1) {
+            static bool done = false;
+            if (!done) { (void)hipFuncSetAttribute((const void*)upconv_fwd_b16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+            hipLaunchKernelGGL(upconv_fwd_b16_kernel<1>, dim3(gx, a.Cout / 32), dim3(256), lds, s, a, nvox, tiles);
+        } else {
+            static bool done = false;
+            if (!done) { (void)hipFuncSetAttribute((const void*)upconv_fwd_b16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+            hipLaunchKernelGGL(upconv_fwd_b16_kernel<2>, dim3(gx, a.Cout / 32), dim3(256), lds, s, a, nvox, tiles);
+        }
+        E3_CHECK_HIP(hipGetLastError());
+        return E3_OK;
+    }
+    hipLaunchKernelGGL((upconv_b16_kernel<false, 4, UP_NVT>), dim3((unsigned)((nvox + 128 * UP_NVT - 1) / (128 * UP_NVT)), a.Cout / 32), dim3(256), 0, s, a, nvox);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
@@ -318,7 +556,18 @@ int launch_upconv_b16_dgrad(UpconvB16Args a, hipStream_t s) {
     E3_REQUIRE(a.y_ldc % 8 == 0 && a.x_ldc % 4 == 0, E3_ERR_INVALID, "bf16 transposed conv: misaligned view");
     const size_t nvox = (size_t)a.N * a.D * a.H * a.W;
     E3_REQUIRE((size_t)a.N * a.Do * a.Ho * a.Wo * a.y_ldc < (1ull << 32) && nvox * a.x_ldc < (1ull << 32), E3_ERR_UNSUPPORTED, "bf16 transposed conv: tensor too large for 32-bit element offsets");
-    hipLaunchKernelGGL((upconv_b16_kernel<true, 4, UP_NVT>), dim3((unsigned)((nvox + 128 * UP_NVT - 1) / (128 * UP_NVT))), dim3(256), 0, s, a, nvox, getenv("E3_UP_ABL") ? atoi(getenv("E3_UP_ABL")) : 0);
+    static const bool generic = getenv("E3_B16_UP_GENERIC") != nullptr;
+    if (!generic && a.sd == 2 && a.Cin == 64 && a.Cout == 32 && (size_t)a.N * a.Do * a.Ho * a.Wo * a.y_ldc < (1ull << 30)) {
+        const int tiles = (int)((nvox + 63) / 64);
+        const int gx = tiles < 256 ? tiles : 256;
+        constexpr int lds = 2 * 16 * 1024 + 2 * 8 * 64 * 64 + 4 * 32 * 80;
+        static bool done = false;
+        if (!done) { (void)hipFuncSetAttribute((const void*)upconv_dgrad_b16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+        hipLaunchKernelGGL(upconv_dgrad_b16_kernel, dim3(gx), dim3(256), lds, s, a, nvox, tiles);
+        E3_CHECK_HIP(hipGetLastError());
+        return E3_OK;
+    }
+    hipLaunchKernelGGL((upconv_b16_kernel<true, 4, UP_NVT>), dim3((unsigned)((nvox + 128 * UP_NVT - 1) / (128 * UP_NVT)), cdiv(a.Cin / 32, 4)), dim3(256), 0, s, a, nvox);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

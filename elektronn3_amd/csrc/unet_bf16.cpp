@@ -77,7 +77,7 @@ void plan_b16(const e3_unet_plan* p, int N, int D, int H, int W, bool training, 
         size_t own = 0;
         if (u.is_up) {
             wmax = max(wmax, upconv_b16_packed_elems(u.cin, u.cout, 2));
-            statmax = max(statmax, (size_t)upconv_b16_stats_parts(N, li.D, li.H, li.W, 2) * u.cout * 3);
+            statmax = max(statmax, (size_t)upconv_b16_stats_parts(N, li.D, li.H, li.W, 2, u.cin) * u.cout * 3);
             own = (size_t)upconv_b16_wgrad_splits(N, li.D, li.H, li.W) * 8 * u.cin * u.cout;
         } else if (u.cin < 8) {
             statmax = max(statmax, (size_t)conv_small_b16_stats_parts(N, li.D, li.H, li.W) * u.cout * 3);
@@ -210,7 +210,7 @@ int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N,
             a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.y = dst; a.y_ldc = dst_ldc; a.Cout = u.cout; a.wt = b.wpk_f;
             a.bias = training ? P(u.p_b) : nullptr; a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = 2;
             a.epi_scale = es; a.epi_shift = eh; a.stats = training ? B.stats : nullptr;
-            parts = upconv_b16_stats_parts(N, li.D, li.H, li.W, 2);
+            parts = upconv_b16_stats_parts(N, li.D, li.H, li.W, 2, u.cin);
             { ProfB pr(plan, s, (int)k, 0); RUN(launch_upconv_b16_fwd(a, s)); }
         } else if (u.cin < 8) {
             parts = conv_small_b16_stats_parts(N, li.D, li.H, li.W);

@@ -286,7 +286,7 @@ def convT_bf16(x, w, bias=None, out_dims=None, want_stats=False, out=None):
     Do, Ho, Wo = out_dims if out_dims is not None else (2 * D, 2 * H, 2 * W)
     y = out if out is not None else torch.empty((N, Do, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16)
     ws = _ws(L.e3_convT_workspace_bytes_bf16(Cin, Cout, N, D, H, W), x.device)
-    stats = torch.zeros((L.e3_convT_stats_parts_bf16(N, D, H, W), Cout, 3), device=x.device, dtype=torch.float32) if want_stats else None
+    stats = torch.zeros((L.e3_convT_stats_parts_bf16(Cin, N, D, H, W), Cout, 3), device=x.device, dtype=torch.float32) if want_stats else None
     w = w.float().contiguous()
     check(L.e3_convT_fwd_bf16(stream_ptr(x.device), ptr(x), _ldc(x), Cin, ptr(w), ptr(bias), ptr(y), _ldc(y), Cout, N, D, H, W, Do, Ho, Wo,
                               ptr(stats), ptr(ws), c_size_t(ws.numel())))

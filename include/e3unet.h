@@ -273,7 +273,7 @@ int e3_conv3d_dgrad_bf16(void* stream, const void* dy, int dy_ldc, int Cout, con
 int e3_conv3d_wgrad_bf16(void* stream, const void* x, int x_ldc, int Cin, const void* dy, int dy_ldc, int Cout, float* dw,
                          int N, int D, int H, int W, int planar, void* workspace, size_t workspace_bytes);
 size_t e3_convT_workspace_bytes_bf16(int Cin, int Cout, int N, int D, int H, int W);
-int e3_convT_stats_parts_bf16(int N, int D, int H, int W);
+int e3_convT_stats_parts_bf16(int Cin, int N, int D, int H, int W);
 int e3_convT_fwd_bf16(void* stream, const void* x, int x_ldc, int Cin, const float* w, const float* bias, void* y, int y_ldc, int Cout,
                       int N, int D, int H, int W, int Do, int Ho, int Wo, float* stats, void* workspace, size_t workspace_bytes);
 int e3_convT_dgrad_bf16(void* stream, const void* dy, int dy_ldc, int Cout, const float* w, void* dx, int dx_ldc, int Cin,
