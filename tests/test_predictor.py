@@ -118,7 +118,15 @@ def test_predictor_native_matches_reference(gold):
     pred3 = Predictor(m, device='cuda', tile_shape=tuple(gold['tile']), overlap_shape=tuple(gold['overlap']), offset=(0, 0, 0),
                       out_shape=(2, 16, 32, 32), apply_softmax=True, apply_argmax=True)
     y3 = pred3.predict(gold['vol3'])
-    assert y3.dtype == torch.uint8 and (y3.numpy() != gold['out3_argmax']).mean() < 1e-4
+    assert y3.dtype == torch.uint8
+    # integer output: bit-exact wherever the decision is not a tie -- a voxel may only differ from the reference's argmax if the
+    # two class probabilities are within the fp32 forward tolerance of each other there
+    y3p = Predictor(m, device='cuda', tile_shape=tuple(gold['tile']), overlap_shape=tuple(gold['overlap']), offset=(0, 0, 0),
+                    out_shape=(2, 16, 32, 32), apply_softmax=True).predict(gold['vol3']).numpy()
+    diff = y3.numpy() != gold['out3_argmax']
+    margin = np.broadcast_to(np.abs(y3p[:, 0] - y3p[:, 1])[:, None], diff.shape)     # (the reference's argmax output keeps out_shape's channel axis)
+    assert not diff[margin > 1e-5].any(), f'{int(diff[margin > 1e-5].sum())} argmax voxels differ away from ties'
+    assert diff.mean() < 1e-4
     # logits path (no softmax) + float16 option (computed in fp32, cast on output)
     y4 = Predictor(m, device='cuda', apply_softmax=False).predict(gold['vol'])
     y5 = Predictor(m, device='cuda', apply_softmax=True, float16=True).predict(gold['vol'])

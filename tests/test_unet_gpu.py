@@ -193,7 +193,11 @@ def cfg2():
     return m, x, t
 
 
-def _train_step_vs_pytorch_rocm(m, x, t, dt=torch.float32, atol=2e-4, nb=4):
+def _train_step_vs_pytorch_rocm(m, x, t, dt=torch.float32, atol=2e-4, nb=4, planar=(), budget=False):
+    """One train step of the HIP path against the reference's ATen op sequence (oracle/torch_ref.py) run by PyTorch-ROCm on this GPU in
+    `dt`.  budget=True: `dt` must be fp64, and the SAME op sequence is run a second time in fp32 (MIOpen): every gradient tensor of
+    the HIP path must then be within max(3 x the fp32 reference's own distance from fp64, 1e-2) rel-L2 of the fp64 result -- SURVEY.md
+    8c's stated budget (a single flipped ReLU / arg-max decision moves a gradient tensor by up to 4e-3, DESIGN.md section 5, hence the floor)."""
     from oracle.torch_ref import combined_loss, unet_forward
     m.train()
     sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
@@ -201,31 +205,56 @@ def _train_step_vs_pytorch_rocm(m, x, t, dt=torch.float32, atol=2e-4, nb=4):
     loss = combined_loss(out, t)
     m.zero_grad(set_to_none=True)
     loss.backward()
-    sd_ref = {k: (v.to(dt) if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd0.items()}
-    ref = unet_forward(sd_ref, x.to(dt), nb, (), training=True)
-    lref = combined_loss(ref, t)
-    lref.backward()
-    ref = ref.float()
-    assert torch.allclose(out, ref, rtol=1e-3, atol=atol), float((out - ref).abs().max())
-    assert abs(float(loss.detach()) - float(lref.detach())) < 1e-5
+
+    def run_ref(dtype):
+        sd_ref = {k: (v.to(dtype) if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd0.items()}
+        ref = unet_forward(sd_ref, x.to(dtype), nb, planar, training=True)
+        lref = combined_loss(ref, t)
+        lref.backward()
+        return sd_ref, ref.detach(), float(lref.detach())
+
+    sd_ref, ref, lref = run_ref(dt)
+    assert torch.allclose(out.double(), ref.double(), rtol=1e-3, atol=atol), float((out.double() - ref.double()).abs().max())
+    assert abs(float(loss.detach()) - lref) < 1e-5
     for k in sd0:
         if 'running' in k:
             assert torch.allclose(m.state_dict()[k], sd_ref[k].float(), rtol=1e-4, atol=1e-6), k
+    err_ref = {}
+    if budget:
+        assert dt == torch.float64
+        grads64 = {k: sd_ref[k].grad.clone() for k, _ in m.named_parameters()}
+        sd32, ref32, _ = run_ref(torch.float32)
+        err_ref = {k: float((sd32[k].grad.double() - grads64[k]).norm() / grads64[k].norm().clamp_min(1e-30)) for k in grads64}
+        e_out_ref = float((ref32.double() - ref.double()).abs().max())
+        assert float((out.double() - ref.double()).abs().max()) <= max(3 * e_out_ref, 1e-4)
+        del sd32, ref32
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))
+    worst = (0.0, 0.0, '')
     for k, p in m.named_parameters():
-        gr = sd_ref[k].grad.float()
+        gr = sd_ref[k].grad
         if is_prebn_bias(k):
             assert float(p.grad.abs().max()) <= 1e-5 * float(gn), k
             continue
-        err = float((p.grad - gr).norm() / gr.norm().clamp_min(1e-30))
-        assert err < 2e-2, (k, err)
+        err = float((p.grad.to(gr.dtype) - gr).norm() / gr.norm().clamp_min(1e-30))
+        bound = max(3 * err_ref[k], 1e-2) if budget else 2e-2
+        assert err < bound, (k, err, err_ref.get(k))
+        if err > worst[0]:
+            worst = (err, err_ref.get(k, float('nan')), k)
     m.load_state_dict(sd0)
+    return worst
 
 
 def test_full_size_cfg2_against_pytorch_rocm(cfg2):
     """BASELINE.json configs[1] at full size: same weights, same input, the reference's ATen op sequence executed by
     PyTorch-ROCm (MIOpen) on this GPU vs the HIP path."""
     _train_step_vs_pytorch_rocm(*cfg2)
+
+
+def test_full_size_cfg2_gradient_budget_against_fp64(cfg2):
+    """BASELINE.json configs[1] at full size with SURVEY.md 8c's stated budget: logits and every gradient tensor against the fp64 run
+    of the reference's op sequence, each allowed max(3 x the fp32 reference's own error, 1e-2)."""
+    worst = _train_step_vs_pytorch_rocm(*cfg2, dt=torch.float64, atol=1e-4, budget=True)
+    print(f'cfg 2 full size: worst gradient rel-L2 vs fp64 {worst[0]:.2e} (fp32 reference: {worst[1]:.2e}) at {worst[2]}')
 
 
 def test_full_size_ragged_crop_against_pytorch_rocm(cfg2):
@@ -319,6 +348,42 @@ def test_full_size_cfg4_anisotropic_against_pytorch_rocm():
             continue
         err = float((p.grad - gr).norm() / gr.norm().clamp_min(1e-30))
         assert err < 2e-2, (k, err)
+
+
+def test_full_size_cfg4_at_its_own_size_against_fp64():
+    """BASELINE.json configs[3] at ITS size: anisotropic UNet(planar_blocks=(0,1), start_filts=64), one 32x256x256 crop (the per-GPU
+    shard of the 4-GPU config), against the fp64 op sequence (torch's fp64 convolutions, no MIOpen kernel search) with the 8c budget."""
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(3)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=64, planar_blocks=(0, 1), normalization='batch').cuda()
+    x = torch.randn(1, 1, 32, 256, 256, device='cuda')
+    t = torch.randint(0, 2, (1, 32, 256, 256), device='cuda')
+    worst = _train_step_vs_pytorch_rocm(m, x, t, dt=torch.float64, atol=1e-4, nb=4, planar=(0, 1), budget=True)
+    print(f'cfg 4 full size: worst gradient rel-L2 vs fp64 {worst[0]:.2e} (fp32 reference: {worst[1]:.2e}) at {worst[2]}')
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_cfg5_tile_eval_softmax_against_fp64():
+    """BASELINE.json configs[4]'s model and tile: eval-mode UNet(n_blocks=4, start_filts=32) (running statistics from a few train
+    batches, BN folded into the conv epilogues, softmax fused into the head) on ONE 128x224x224 input tile (tile 96x192x192 + overlap 16)
+    against the fp64 op sequence + softmax."""
+    from elektronn3_amd.unet import UNet
+    from oracle.torch_ref import unet_forward
+    torch.manual_seed(0)
+    m = UNet(1, 2, n_blocks=4, start_filts=32).cuda().train()
+    with torch.no_grad():
+        for _ in range(4):
+            m(torch.randn(2, 1, 32, 64, 64, device='cuda'))
+    m.eval()
+    x = torch.randn(1, 1, 128, 224, 224, device='cuda', generator=torch.Generator(device='cuda').manual_seed(7))
+    with torch.no_grad():
+        y = m.forward_softmax(x)
+        sd = {k: v.double() if v.is_floating_point() else v for k, v in m.state_dict().items()}
+        ref = torch.softmax(unet_forward(sd, x.double(), 4, (), training=False), 1)
+    err = float((y.double() - ref).abs().max())
+    assert err < 1e-4, err
+    assert float((y.sum(1) - 1).abs().max()) < 1e-5
 
 
 @pytest.mark.parametrize('kw', [dict(normalization='none'), dict(normalization='batch', full_norm=False, planar_blocks=(0,)),
