@@ -185,6 +185,87 @@ def set_state_dict(model, state_dict):
         model.load_state_dict(OrderedDict((k.replace('module.', ''), v) for k, v in state_dict.items()))
 
 
+def _open_model(model, device):
+    """A module as given, or loaded from a TorchScript archive (.pts) / a pickled module (.pt) -- the three forms
+    ``Predictor(model=...)`` accepts (inference.py:421-433)."""
+    if isinstance(model, Path):
+        model = str(model)
+    if not isinstance(model, str):
+        return model
+    if not os.path.isfile(model):
+        raise ValueError(f'Model path {model} not found.')
+    loaders = {'.pts': lambda f: torch.jit.load(f, map_location=device),
+               '.pt': lambda f: torch.load(f, map_location=device, weights_only=False)}
+    ext = os.path.splitext(model)[1]
+    if ext not in loaders:
+        raise ValueError(f'{model} has an unkown file extension. Supported are .pt and .pts')     # (sic: the reference's message)
+    return loaders[ext](model)
+
+
+def _resolve_state_dict(src):
+    """None, a state_dict, or a path to a checkpoint that is one or contains one under 'model_state_dict' (inference.py:434-441)."""
+    if src is None or isinstance(src, dict):
+        return src
+    if isinstance(src, str):
+        loaded = torch.load(src)
+        return loaded.get('model_state_dict', loaded)
+    raise ValueError('"state_dict_src" has to be either a path to a .pth file (str), a state_dict object (dict) or None.')
+
+
+class _OutputStages:
+    """What happens to the network's logits before a tile is stored: softmax, test-time-augmentation mean, threshold + argmax.
+    The reference expresses this by wrapping the model in nn.Sequential layers (inference.py:443-456); for the native UNet the softmax
+    is a flag of the last kernel and the remaining stages run on its output."""
+
+    def __init__(self, apply_softmax, augmentations, apply_argmax, threshold):
+        if not apply_softmax and augmentations is not None:
+            raise ValueError('When augmentations are enabled, apply_softmax cannot be False.')
+        self.softmax = bool(apply_softmax or augmentations is not None)
+        self.wants_argmax = bool(apply_argmax or threshold is not None)
+        self.threshold = threshold
+        # with test-time augmentation the arg-max is taken of the MEAN of the augmented predictions, i.e. after the model
+        self.argmax_after_tta = self.wants_argmax and augmentations is not None
+
+    def layers_after_softmax(self):
+        if not self.wants_argmax or self.argmax_after_tta:
+            return []
+        stages = [Argmax(dim=1, unsqueeze=True)]
+        if self.threshold:
+            stages.insert(0, nn.Threshold(self.threshold, 0))
+        return stages
+
+
+class _Tiling:
+    """tile_shape / overlap_shape / offset / out_shape as one consistent set (inference.py:460-494): either all unset (whole input in
+    one call), or a tile grid with a zero-padded overlap ('same' networks) or an offset (networks whose output is smaller)."""
+
+    def __init__(self, tile_shape, overlap_shape, offset, out_shape, estimate_offset):
+        given = lambda a: a is not None and np.any(a)
+        if given(overlap_shape) and given(offset):
+            raise ValueError(f'overlap_shape={overlap_shape} and offet={offset} are both specified, but this is not supported.\n'
+                             'Either specify overlap_shape (if the spatial shape of inputs and outputs are the same)\n'
+                             'or offset (if the output is smaller).')
+        self.enabled = bool(given(tile_shape))
+        if not self.enabled:
+            assert not (given(out_shape) or given(overlap_shape) or given(offset)), \
+                'If tile_shape is not set, out_shape, overlap_shape and offset should not be set either.'
+        else:
+            assert given(out_shape), 'If tile_shape is set, out_shape is required to be set, too.'
+            if offset is None:
+                offset = estimate_offset(len(tile_shape))
+            if np.count_nonzero(offset) == 0:
+                offset = None
+            else:          # the halo a tile needs IS the offset, and the output volume shrinks by it on every side
+                offset = np.array(offset)
+                overlap_shape = offset
+                nsp = len(offset)
+                out_shape = np.array([*out_shape[:-nsp], *(out_shape[-nsp:] - 2 * offset)])
+                logger.info(f'Adjusted out_shape: {out_shape}')
+        as_array = lambda a: np.array(a) if a is not None else None
+        self.offset = offset
+        self.tile_shape, self.overlap_shape, self.out_shape = as_array(tile_shape), as_array(overlap_shape), as_array(out_shape)
+
+
 class Predictor:
     """Tiled sliding-window inference with the reference's interface (inference.py:368-388)."""
 
@@ -211,109 +292,54 @@ class Predictor:
             tile_parallel: bool = False,
     ):
         from .unet import UNet
-        if device is None:
-            device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
-        elif isinstance(device, str):
-            device = torch.device(device)
-        self.device = device
-        self.batch_size = batch_size
-        self.out_dtype = out_dtype
-        self.float16 = float16
-        if isinstance(model, Path):
-            model = str(model)
-        if float16 and not isinstance(model, str) and not next(model.parameters()).dtype == torch.float16:
-            model = copy.deepcopy(model)   # casting is in-place; keep the caller's fp32 model intact (inference.py:402-407)
+        self.device = torch.device(device) if device is not None else torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+        self.batch_size, self.out_dtype, self.float16 = batch_size, out_dtype, float16
         self.dtype = torch.float16 if float16 else torch.float32
-        self.transform = transform
-        if isinstance(augmentations, int):
-            augmentations = DEFAULT_AUGMENTATIONS_3D[:augmentations]
-        self.augmentations = augmentations
-        self.strict_shapes = strict_shapes
-        self.apply_argmax = apply_argmax
-        self.argmax_with_threshold = argmax_with_threshold
-        self.verbose = verbose
-        self.report_inp_stats = report_inp_stats
-        self.tile_parallel = tile_parallel
-        if isinstance(model, str):
-            if os.path.isfile(model):
-                if model.endswith('.pts'):
-                    model = torch.jit.load(model, map_location=device)
-                elif model.endswith('.pt'):
-                    model = torch.load(model, map_location=device, weights_only=False)
-                else:
-                    raise ValueError(f'{model} has an unkown file extension. Supported are .pt and .pts')
-            else:
-                raise ValueError(f'Model path {model} not found.')
-        self.model = model
-        if isinstance(state_dict_src, str):
-            state_dict = torch.load(state_dict_src)
-            if 'model_state_dict' in state_dict:
-                state_dict = state_dict['model_state_dict']
-        elif isinstance(state_dict_src, dict) or state_dict_src is None:
-            state_dict = state_dict_src
+        self.transform, self.strict_shapes, self.verbose = transform, strict_shapes, verbose
+        self.apply_argmax, self.argmax_with_threshold = apply_argmax, argmax_with_threshold
+        self.report_inp_stats, self.tile_parallel = report_inp_stats, tile_parallel
+        self.augmentations = DEFAULT_AUGMENTATIONS_3D[:augmentations] if isinstance(augmentations, int) else augmentations
+        self._warn_about_shapes = True
+
+        # ---- the network: a module (possibly from a file), optionally other weights, optionally cast to half precision
+        net = _open_model(model, self.device)
+        if float16 and isinstance(net, nn.Module) and not isinstance(model, (str, Path)) and next(net.parameters()).dtype != torch.float16:
+            net = copy.deepcopy(net)       # .half() is in-place: the caller's fp32 module stays intact (inference.py:402-407)
+        weights = _resolve_state_dict(state_dict_src)
+        if weights is not None:
+            set_state_dict(net, weights)
+
+        # ---- output stages.  Native UNet: softmax inside the last kernel, the rest as a small post-module; any other module is wrapped
+        # the way the reference wraps it
+        stages = _OutputStages(apply_softmax, self.augmentations, apply_argmax, argmax_with_threshold)
+        self._native = isinstance(net, UNet)
+        self._softmax = stages.softmax
+        self.apply_argmax_after_tta = stages.argmax_after_tta
+        tail = stages.layers_after_softmax()
+        self._post = nn.Sequential(*tail) if (self._native and tail) else None
+        if self._native:
+            self.model = net
         else:
-            raise ValueError('"state_dict_src" has to be either a path to a .pth file (str), a state_dict object (dict) or None.')
-        if state_dict is not None:
-            set_state_dict(model, state_dict)
-        if not apply_softmax and augmentations is not None:
-            raise ValueError('When augmentations are enabled, apply_softmax cannot be False.')
-        self._native = isinstance(model, UNet)          # HIP fast path: softmax fused into the network's last kernel
-        self._softmax = bool(apply_softmax or augmentations is not None)
-        if self._softmax and not self._native:
-            self.model = nn.Sequential(self.model, nn.Softmax(1))
+            wrapped = [net] + ([nn.Softmax(1)] if stages.softmax else []) + tail
+            self.model = net if len(wrapped) == 1 else nn.Sequential(*wrapped)
+        if stages.wants_argmax and self.out_dtype is None:
+            self.out_dtype = torch.uint8
         if float16:
             self.model.half()
-        self.apply_argmax_after_tta = False
-        self._post = None
-        if apply_argmax or argmax_with_threshold is not None:
-            self.apply_argmax_after_tta = augmentations is not None
-            if not self.apply_argmax_after_tta:
-                layers = [Argmax(dim=1, unsqueeze=True)]
-                if argmax_with_threshold:
-                    layers = [nn.Threshold(argmax_with_threshold, 0)] + layers
-                if self._native:
-                    self._post = nn.Sequential(*layers)
-                else:
-                    self.model = nn.Sequential(self.model, *layers)
-            if self.out_dtype is None:
-                self.out_dtype = torch.uint8
-        self._warn_about_shapes = True
-        # Side effect kept from the reference (inference.py:458): the caller's module is switched to eval mode.
-        self.model.eval()
-        if isinstance(self.model, nn.Module) and device.type == 'cuda':
-            self.model.to(device)
+        self.model.eval()                  # (side effect of the reference, inference.py:458: the caller's module leaves train mode)
+        if isinstance(self.model, nn.Module) and self.device.type == 'cuda':
+            self.model.to(self.device)
 
-        def is_set(array):
-            return array is not None and np.any(array)
+        # ---- tiling geometry
+        def estimate_offset(ndim):
+            if self._native and getattr(net, 'conv_mode', 'same') == 'same':
+                return np.zeros(ndim, dtype=np.int64)           # 'same' convolutions: known without a probe forward
+            logger.warning('Predictor: offset=None -> Estimating offset from forward pass.')
+            return calculate_offset(self.model)
 
-        if is_set(overlap_shape) and is_set(offset):
-            raise ValueError(f'overlap_shape={overlap_shape} and offet={offset} are both specified, but this is not supported.\n'
-                             'Either specify overlap_shape (if the spatial shape of inputs and outputs are the same)\n'
-                             'or offset (if the output is smaller).')
-        if not is_set(tile_shape):
-            assert not (is_set(out_shape) or is_set(overlap_shape) or is_set(offset)), \
-                'If tile_shape is not set, out_shape, overlap_shape and offset should not be set either.'
-            self.enable_tiling = False
-        else:
-            assert is_set(out_shape), 'If tile_shape is set, out_shape is required to be set, too.'
-            self.enable_tiling = True
-            if offset is None:
-                if self._native and getattr(self.model if not isinstance(self.model, nn.Sequential) else self.model[0], 'conv_mode', 'same') == 'same':
-                    offset = np.zeros(len(tile_shape), dtype=np.int64)   # 'same' convolutions: known without a probe forward
-                else:
-                    logger.warning('Predictor: offset=None -> Estimating offset from forward pass.')
-                    offset = calculate_offset(self.model)
-            if np.count_nonzero(offset) == 0:
-                offset = None
-            else:
-                offset = np.array(offset)
-                overlap_shape = offset
-                out_shape = np.array([*out_shape[:-len(offset)], *(out_shape[-len(offset):] - 2 * offset)])
-                logger.info(f'Adjusted out_shape: {out_shape}')
-        self.offset = offset
-        self.overlap_shape = np.array(overlap_shape) if overlap_shape is not None else None
-        self.tile_shape = np.array(tile_shape) if tile_shape is not None else None
-        self.out_shape = np.array(out_shape) if out_shape is not None else None
+        geo = _Tiling(tile_shape, overlap_shape, offset, out_shape, estimate_offset)
+        self.enable_tiling = geo.enabled
+        self.offset, self.tile_shape, self.overlap_shape, self.out_shape = geo.offset, geo.tile_shape, geo.overlap_shape, geo.out_shape
 
     # ------------------------------------------------------------------ per-tile model call (inference.py:496-525)
     def _call_model(self, dinp):
@@ -324,22 +350,17 @@ class Predictor:
 
     @torch.no_grad()
     def _predict(self, dinp, crop_slice=None):
+        """One tile: model call (+ test-time augmentation mean, + arg-max) and the central crop (inference.py:496-525)."""
         dinp = dinp.to(self.device, dtype=self.dtype)
-        dout = self._call_model(dinp)
-        if crop_slice is not None:
-            dout = dout[crop_slice]
-        if self.augmentations is not None:
-            douts = [dout]
-            for aug in self.augmentations:
-                dout_aug = aug.backward(self._call_model(aug.forward(dinp)))
-                if crop_slice:
-                    dout_aug = dout_aug[crop_slice]
-                douts.append(dout_aug)
-            dout = torch.mean(torch.stack(douts), dim=0)
+        crop = (lambda t: t[crop_slice]) if crop_slice is not None else (lambda t: t)
+        dout = crop(self._call_model(dinp))
+        if self.augmentations is not None:       # mean over the identity and every flip (prediction of the flipped tile, flipped back)
+            votes = [dout] + [crop(aug.backward(self._call_model(aug.forward(dinp)))) for aug in self.augmentations]
+            dout = torch.stack(votes).mean(dim=0)
         if self.apply_argmax_after_tta:
             if self.argmax_with_threshold:
                 dout[dout <= self.argmax_with_threshold] = 0
-            dout = dout.argmax(dim=1).to(self.out_dtype)
+            dout = dout.argmax(dim=1)
         return dout.to(self.out_dtype)
 
     def _tiled_predict(self, inp, out_shape=None):
@@ -500,75 +521,73 @@ class Predictor:
 
     # ------------------------------------------------------------------ public API (inference.py:569-642)
     def predict(self, inp):
-        if self.transform is not None:
-            if isinstance(inp, torch.Tensor):
-                inp = inp.numpy()
-            transformed = np.empty_like(inp)
-            for i in range(inp.shape[0]):
-                transformed[i], _ = self.transform(inp[i], None)
-            inp = transformed
-        if self.verbose:
-            start = time.time()
-        inp = torch.as_tensor(inp)
-        if self._pipeline_applicable(inp):
+        """``inp``: ndarray or tensor (N, C, *spatial) -> CPU tensor (inference.py:569-642)."""
+        t_start = time.time()
+        inp = torch.as_tensor(self._transformed(inp))
+        if self._pipeline_applicable(inp):                       # host volume streamed through the GPU in rows of tiles
             out = self._pipelined_predict(inp)
-            if self.verbose:
-                dtime = time.time() - start
-                print(f'Inference speed: {out.numel() / dtime / 1e6:.2f} MVox/s, time: {dtime:.2f}.')
+            self._report(t_start, out.numel())
             return out
+        # device-resident path: (padded) input and output live in HBM, one upload and one download
         if self.enable_tiling:
-            inp, out_shape, relevant_slice = self._ensure_matching_shapes(inp)
+            dev_inp, work_out_shape, keep = self._ensure_matching_shapes(inp)
         else:
-            relevant_slice, out_shape = None, self.out_shape
-            inp = inp.to(self.device, dtype=self.dtype).contiguous()
-        inp_batch_size = inp.shape[0]
-        spatial_shape = np.array(inp.shape[2:])
+            dev_inp, work_out_shape, keep = inp.to(self.device, dtype=self.dtype).contiguous(), self.out_shape, None
+        n_samples, spatial = dev_inp.shape[0], np.array(dev_inp.shape[2:])
         if self.out_dtype is None:
-            self.out_dtype = torch.uint8 if self.argmax_with_threshold is not None else inp.dtype
-        if out_shape is not None and out_shape[0] > 255 and self.out_dtype == torch.uint8:
-            raise ValueError(f'C = out_shape[0] = {out_shape[0]}, but out_dtype torch.uint8 can only hold values up to 255.')
-        if self.tile_shape is None:
-            self.tile_shape = spatial_shape
-        if self.overlap_shape is None:
-            self.overlap_shape = np.zeros_like(spatial_shape)
-        if self.batch_size is None:
-            self.batch_size = inp_batch_size
-        num_batches = int(np.ceil(inp_batch_size / self.batch_size))
-        if num_batches == 1:
-            out = self._tiled_predict(inp=inp, out_shape=out_shape)
-        else:
-            out = self._splitbatch_predict(inp=inp, num_batches=num_batches, out_shape=out_shape)
+            self.out_dtype = torch.uint8 if self.argmax_with_threshold is not None else dev_inp.dtype      # (the compute dtype)
+        if work_out_shape is not None and work_out_shape[0] > 255 and self.out_dtype == torch.uint8:
+            raise ValueError(f'C = out_shape[0] = {work_out_shape[0]}, but out_dtype torch.uint8 can only hold values up to 255.')
+        # unset geometry means "the whole input in one piece"
+        self.tile_shape = spatial if self.tile_shape is None else self.tile_shape
+        self.overlap_shape = np.zeros_like(spatial) if self.overlap_shape is None else self.overlap_shape
+        self.batch_size = n_samples if self.batch_size is None else self.batch_size
+        n_chunks = -(-n_samples // self.batch_size)
+        out = self._tiled_predict(dev_inp, work_out_shape) if n_chunks == 1 else self._splitbatch_predict(dev_inp, n_chunks, work_out_shape)
         if self.device.type == 'cuda':
             torch.cuda.synchronize(self.device)
-        out = out.cpu() if relevant_slice is None else out[relevant_slice].cpu()
-        if self.verbose:
-            dtime = time.time() - start
-            amount = out.numel()
-            if out_shape is not None and np.array_equal(out_shape[2:], inp.shape[2:]):
-                amount = np.prod([*out.shape[:-3], *(out.shape[-3:] - 2 * self.overlap_shape)])
-            print(f'Inference speed: {amount / dtime / 1e6:.2f} MVox/s, time: {dtime:.2f}.')
+        out = (out if keep is None else out[keep]).cpu()
+        counted = out.numel()
+        if work_out_shape is not None and np.array_equal(work_out_shape[2:], dev_inp.shape[2:]):      # (the reference's voxel count, :637-640)
+            counted = np.prod([*out.shape[:-3], *(out.shape[-3:] - 2 * self.overlap_shape)])
+        self._report(t_start, counted)
         return out
 
+    def _transformed(self, inp):
+        if self.transform is None:
+            return inp
+        arr = inp.numpy() if isinstance(inp, torch.Tensor) else inp
+        res = np.empty_like(arr)
+        for n in range(arr.shape[0]):
+            res[n], _ = self.transform(arr[n], None)
+        return res
+
+    def _report(self, t_start, voxels):
+        if self.verbose:
+            dtime = time.time() - t_start
+            print(f'Inference speed: {voxels / dtime / 1e6:.2f} MVox/s, time: {dtime:.2f}.')
+
     def _ensure_matching_shapes(self, inp):
-        """Pads the input (with zeros, on the device, in the compute dtype) so that out_shape becomes a multiple of
-        tile_shape, and returns the slice that undoes it (inference.py:645-687)."""
+        """(device input, out_shape to work on, slice that undoes the padding or None).  Where out_shape is not a multiple of tile_shape
+        the input is zero-padded on the device, in the compute dtype, up to the next multiple (the reference pads on the host through a
+        float64 array, inference.py:645-687)."""
         inp = inp.to(self.device, dtype=self.dtype)
-        if self.out_shape is not None and np.any(self.out_shape[1:] % self.tile_shape):
-            if self.strict_shapes:
-                raise ValueError('Make sure that out_shape is divisible by tile_shape or relax this constraint by setting '
-                                 'strict_shapes=False.')
-            padded_out_shape = np.array(self.out_shape)
-            padded_out_shape[1:] = np.ceil(self.out_shape[1:] / self.tile_shape) * self.tile_shape
-            offset = np.zeros(len(padded_out_shape) - 1, dtype=np.int64) if self.offset is None else np.array(self.offset)
-            padded_inp = torch.zeros((*inp.shape[:2], *(int(v) for v in padded_out_shape[1:] + 2 * offset)), dtype=self.dtype, device=self.device)
-            padded_inp[_extend_nc([slice(0, d) for d in inp.shape[2:]])] = inp
-            relevant_slice_out = _extend_nc([slice(0, int(d)) for d in self.out_shape[1:]])
-            if self._warn_about_shapes and np.any(padded_out_shape != self.out_shape):
-                logger.info(f'Adapting out_shape {tuple(self.out_shape[1:])} to tile_shape {tuple(self.tile_shape)} by padding '
-                            f'out_shape to {tuple(padded_out_shape[1:])}.\nSuboptimal shapes will reduce execution speed.')
-                self._warn_about_shapes = False
-            return padded_inp, padded_out_shape, relevant_slice_out
-        return inp.contiguous(), self.out_shape, None
+        ragged = self.out_shape is not None and np.any(self.out_shape[1:] % self.tile_shape)
+        if not ragged:
+            return inp.contiguous(), self.out_shape, None
+        if self.strict_shapes:
+            raise ValueError('Make sure that out_shape is divisible by tile_shape or relax this constraint by setting '
+                             'strict_shapes=False.')
+        full = np.array(self.out_shape)
+        full[1:] = -(-self.out_shape[1:] // self.tile_shape) * self.tile_shape
+        halo = 0 if self.offset is None else 2 * np.array(self.offset)
+        grown = torch.zeros((*inp.shape[:2], *(int(v) for v in full[1:] + halo)), dtype=self.dtype, device=self.device)
+        grown[_extend_nc([slice(0, d) for d in inp.shape[2:]])] = inp
+        if self._warn_about_shapes:
+            logger.info(f'Adapting out_shape {tuple(self.out_shape[1:])} to tile_shape {tuple(self.tile_shape)} by padding '
+                        f'out_shape to {tuple(full[1:])}.\nSuboptimal shapes will reduce execution speed.')
+            self._warn_about_shapes = False
+        return grown, full, _extend_nc([slice(0, int(d)) for d in self.out_shape[1:]])
 
     def predict_proba(self, inp):
         logger.warning('Predictor.predict_proba(inp) is deprecated. Please use Predictor.predict(inp) instead.')

@@ -13,7 +13,7 @@ There is no CPU path: a CPU input raises ``RuntimeError``.
 """
 import ctypes
 import threading
-from typing import Sequence, Union
+from typing import List, Sequence, Union
 
 import torch
 from torch import nn
@@ -45,6 +45,7 @@ class _Plan:
             self.kinds.append(kind.value)
         self.bn_names = [n[:-len('.weight')] for n in self.names if '.norm' in n and n.endswith('.weight')]
         self.n_bn = lib.e3_unet_bn_count(handle)
+        self.out_channels = int(key[1])
         assert self.n_bn == len(self.bn_names)
         self.conv_names = []
         for i in range(lib.e3_unet_conv_count(handle)):
@@ -114,14 +115,61 @@ def _fp32_table(module, tens):
     return cache[2]
 
 
+def _native_forward(module, plan, x, tens, softmax, want_bf16, x_needs_grad, training, momenta):
+    """One call of e3_unet_forward / e3_unet_forward_bf16.  `tens`: fp32 table tensors (contiguous), `lowp_bf16`: the module stores
+    bf16.  Returns (y fp32, saved buffer or None, the input as handed to the library, bf16 path taken)."""
+    lib = _lib.load()
+    dev = x.device
+    N, Cin, D, H, W = x.shape
+    b16 = want_bf16 and not x_needs_grad and plan.bf16_supported() and not _NO_BF16
+    xin = x.detach().to(torch.bfloat16 if b16 else torch.float32).contiguous()
+    saved_bytes, scratch_bytes = plan.sizes(N, D, H, W, training, bf16=b16)
+    saved = torch.empty(max(saved_bytes, 256), dtype=torch.uint8, device=dev) if training else None
+    scratch = _get_scratch(dev, max(scratch_bytes, 256))
+    Do, Ho, Wo = plan.out_dims(D, H, W)      # == (D, H, W) unless conv_mode='valid'
+    y = torch.empty((N, plan.out_channels, Do, Ho, Wo), dtype=torch.float32, device=dev)
+    ptrs = (c_void_p * len(tens))(*[t.data_ptr() for t in tens])
+    cmom = (ctypes.c_float * len(momenta))(*momenta) if training else None
+    flags = (E3_FWD_TRAINING if training else 0) | (E3_FWD_SOFTMAX if softmax else 0)
+    fwd = lib.e3_unet_forward_bf16 if b16 else lib.e3_unet_forward
+    with torch.cuda.device(dev):
+        check(fwd(plan.handle, _lib.stream_ptr(dev), c_void_p(xin.data_ptr()), N, D, H, W, ptrs, cmom,
+                  c_void_p(y.data_ptr()), c_void_p(saved.data_ptr()) if saved is not None else None,
+                  c_size_t(saved.numel() if saved is not None else 0),
+                  c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), flags))
+    return y, saved, xin, b16
+
+
+def _native_backward(plan, dy, xin, tens, saved, b16, want_dx, sync=None):
+    """One call of e3_unet_backward / _bf16: (flat fp32 gradient buffer, its per-table-entry views, dx or None)."""
+    lib = _lib.load()
+    N, _, D, H, W = xin.shape
+    dev = dy.device
+    dy32 = dy.detach().to(torch.float32).contiguous()
+    # one flat gradient buffer; every trainable tensor gets a view (table order)
+    flat, views = (sync.flat_views(plan, tens) if sync is not None else _flat_views(plan, tens, dev))
+    gptrs = (c_void_p * len(tens))(*[(v.data_ptr() if v is not None else None) for v in views])
+    ptrs = (c_void_p * len(tens))(*[t.data_ptr() for t in tens])
+    dx = torch.empty_like(xin) if want_dx else None
+    _, scratch_bytes = plan.sizes(N, D, H, W, True, bf16=b16)
+    scratch = _get_scratch(dev, max(scratch_bytes, 256))
+    ev, ev_blk = (sync.bucket_event(), sync.bucket_after_down_block) if sync is not None else (None, 0)
+    bwd = lib.e3_unet_backward_bf16 if b16 else lib.e3_unet_backward
+    with torch.cuda.device(dev):
+        check(bwd(plan.handle, _lib.stream_ptr(dev), c_void_p(dy32.data_ptr()), c_void_p(xin.data_ptr()),
+                  N, D, H, W, ptrs, gptrs, c_void_p(dx.data_ptr()) if dx is not None else None,
+                  c_void_p(saved.data_ptr()), c_size_t(saved.numel()),
+                  c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), ev, ev_blk))
+    if sync is not None:
+        sync.after_backward(plan)
+    return flat, views, dx
+
+
 class _UNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, softmax, want_bf16, x, *params):
         plan = module._plan()
-        lib = _lib.load()
-        dev = x.device
         in_dtype = x.dtype
-        N, Cin, D, H, W = x.shape
         training = module.training or module._per_sample_norm()   # instance / group statistics also in eval mode
         # parameters / buffers at call time, in the plan's table order
         tens = module._table(plan, params)
@@ -129,53 +177,27 @@ class _UNetFunction(torch.autograd.Function):
         if any(t.dtype != torch.float32 for t in tens):
             # model.half() / model.bfloat16() (Predictor(float16=True), BASELINE cfg 3's bf16 storage): the parameter table handed to the
             # library is fp32 (up-cast copies; results are cast back: the output below, gradients in backward, the running statistics
-            # right after the call).  bf16 modules on a covered configuration COMPUTE in bf16 (native kernels, see below).
+            # right after the call).  bf16 modules on a covered configuration COMPUTE in bf16 (native kernels, csrc/unet_bf16.cpp).
             lowp = tens
             tens = _fp32_table(module, tens)
         tens = [t if t.is_contiguous() else t.contiguous() for t in tens]
-        # native bf16 compute (csrc/unet_bf16.cpp): bf16 module + bf16 input, or torch.autocast(dtype=bfloat16) around any module
         all_bf16 = lowp is not None and all(t.dtype == torch.bfloat16 for t in lowp if t.is_floating_point())
-        b16 = (want_bf16 or (all_bf16 and in_dtype == torch.bfloat16)) and not ctx.needs_input_grad[3] and plan.bf16_supported() \
-            and not _NO_BF16
-        ctx.b16 = b16
-        xin = x.detach().to(torch.bfloat16 if b16 else torch.float32).contiguous()
-        out_dtype = torch.bfloat16 if (b16 and want_bf16) else in_dtype
         # (grad mode is off inside Function.forward; needs_input_grad tells whether a backward can follow)
         need_grad = training and any(ctx.needs_input_grad)
-        ctx.eval_mode = not training
-        saved_bytes, scratch_bytes = plan.sizes(N, D, H, W, training, bf16=b16)
-        saved = torch.empty(max(saved_bytes, 256), dtype=torch.uint8, device=dev) if training else None
-        scratch = _get_scratch(dev, max(scratch_bytes, 256))
-        Do, Ho, Wo = plan.out_dims(D, H, W)      # == (D, H, W) unless conv_mode='valid'
-        y = torch.empty((N, module.out_channels, Do, Ho, Wo), dtype=torch.float32, device=dev)
-        ptrs = (c_void_p * len(tens))(*[t.data_ptr() for t in tens])
-        momenta = None
-        if training:
-            moms = module._momenta(plan)
-            momenta = (ctypes.c_float * len(moms))(*moms)
-        flags = (E3_FWD_TRAINING if training else 0) | (E3_FWD_SOFTMAX if softmax else 0)
-        fwd = lib.e3_unet_forward_bf16 if b16 else lib.e3_unet_forward
-        with torch.cuda.device(dev):
-            check(fwd(plan.handle, _lib.stream_ptr(dev), c_void_p(xin.data_ptr()), N, D, H, W, ptrs, momenta,
-                      c_void_p(y.data_ptr()), c_void_p(saved.data_ptr()) if saved is not None else None,
-                      c_size_t(saved.numel() if saved is not None else 0),
-                      c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), flags))
+        y, saved, xin, b16 = _native_forward(module, plan, x, tens, softmax, want_bf16 or (all_bf16 and in_dtype == torch.bfloat16),
+                                             ctx.needs_input_grad[3], training, module._momenta(plan) if training else None)
+        out_dtype = torch.bfloat16 if (b16 and want_bf16) else in_dtype
         if training:
             module._bump_num_batches_tracked(plan)
             if lowp is not None:         # running statistics were updated in the fp32 copies
                 pairs = [(lo_t, hi_t) for kind, lo_t, hi_t in zip(plan.kinds, lowp, tens) if kind != 0 and lo_t.dtype != torch.float32]
                 if pairs:
                     torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])
-        ctx.module, ctx.plan = module, plan
-        ctx.softmax = softmax
-        ctx.shape = (N, D, H, W)
-        ctx.in_dtype = in_dtype
-        if need_grad:
-            # (a low-precision module's fp32 table is a cache that the next forward refreshes with the same parameter values:
-            # the backward only reads weights and affine parameters from it, never the running statistics)
-            ctx.x32, ctx.saved_buf, ctx.tens = xin, saved, tens
-        else:
-            ctx.x32 = ctx.saved_buf = ctx.tens = None
+        ctx.module, ctx.plan, ctx.b16 = module, plan, b16
+        ctx.softmax, ctx.eval_mode, ctx.in_dtype = softmax, not training, in_dtype
+        # (a low-precision module's fp32 table is a cache that the next forward refreshes with the same parameter values:
+        # the backward only reads weights and affine parameters from it, never the running statistics)
+        ctx.x32, ctx.saved_buf, ctx.tens = (xin, saved, tens) if need_grad else (None, None, None)
         return y if out_dtype == torch.float32 else y.to(out_dtype)
 
     @staticmethod
@@ -187,41 +209,19 @@ class _UNetFunction(torch.autograd.Function):
         if ctx.softmax:
             raise NotImplementedError('backward through the fused softmax head is not implemented')
         module, plan = ctx.module, ctx.plan
-        lib = _lib.load()
-        N, D, H, W = ctx.shape
-        dev = dy.device
-        dy32 = dy.detach().to(torch.float32).contiguous()
-        tens = ctx.tens
-        sync = getattr(module, '_grad_sync', None)
-        # one flat gradient buffer; every trainable tensor gets a view (table order)
-        flat, views = (sync.flat_views(plan, tens) if sync is not None else _flat_views(plan, tens, dev))
-        gptrs = (c_void_p * len(tens))(*[(v.data_ptr() if v is not None else None) for v in views])
-        ptrs = (c_void_p * len(tens))(*[t.data_ptr() for t in tens])
-        dx = torch.empty_like(ctx.x32) if ctx.needs_input_grad[3] else None
-        _, scratch_bytes = plan.sizes(N, D, H, W, True, bf16=ctx.b16)
-        scratch = _get_scratch(dev, max(scratch_bytes, 256))
-        ev, ev_blk = (sync.bucket_event(), sync.bucket_after_down_block) if sync is not None else (None, 0)
-        bwd = lib.e3_unet_backward_bf16 if ctx.b16 else lib.e3_unet_backward
-        with torch.cuda.device(dev):
-            check(bwd(plan.handle, _lib.stream_ptr(dev), c_void_p(dy32.data_ptr()), c_void_p(ctx.x32.data_ptr()),
-                      N, D, H, W, ptrs, gptrs, c_void_p(dx.data_ptr()) if dx is not None else None,
-                      c_void_p(ctx.saved_buf.data_ptr()), c_size_t(ctx.saved_buf.numel()),
-                      c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), ev, ev_blk))
-        if sync is not None:
-            sync.after_backward(plan)
+        flat, views, dx = _native_backward(plan, dy, ctx.x32, ctx.tens, ctx.saved_buf, ctx.b16, ctx.needs_input_grad[3],
+                                           getattr(module, '_grad_sync', None))
         ctx.saved_buf = ctx.x32 = ctx.tens = None   # free the activations now
         named = list(module._named_table_params(plan))
         lowp_dtype = next((p.dtype for _, p in named if p.dtype != torch.float32), None)
         if lowp_dtype is not None and all(p.dtype == lowp_dtype for _, p in named):
             # one cast of the whole flat buffer instead of one launch per parameter
             flat_lo = flat.to(lowp_dtype)
-            off_of = {}
-            off = 0
+            off, lo_views = 0, []
             for v in views:
-                if v is not None:
-                    off_of[v.data_ptr()] = off
-                    off += v.numel()
-            views = [flat_lo[off_of[v.data_ptr()]:off_of[v.data_ptr()] + v.numel()] if v is not None else None for v in views]
+                lo_views.append(flat_lo[off:off + v.numel()] if v is not None else None)
+                off += v.numel() if v is not None else 0
+            views = lo_views
         by_name = dict(zip(plan.names, views))
         grads = []
         for name, p in named:
@@ -240,6 +240,84 @@ def _flat_views(plan, tens, device):
         views.append(flat[off:off + n] if n else None)
         off += n
     return flat, views
+
+
+# ---------------------------------------------------------------------------------------------------------------- TorchScript boundary
+# `torch.jit.script(model)` is what the reference's training script does by default (examples/train_unet_neurodata.py:110-113, --jit
+# onsave; Trainer._save_model scripts and saves again, training/trainer.py:876-881).  A scripted UNet.forward gathers the module's
+# tensors in table order and calls ONE registered operator; the operator (and its autograd formula) run the same native entry points as
+# the eager path.  Functional by construction: the updated running statistics are RETURNED and copied back by the scripted code.
+def _plan_key_from_floats(key: List[float]):
+    ints = (0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11)
+    return tuple(int(round(v)) if i in ints else float(v) for i, v in enumerate(key))
+
+
+@torch.library.custom_op('e3unet::unet_fwd', mutates_args=())
+def _op_unet_fwd(x: torch.Tensor, tensors: List[torch.Tensor], key: List[float], momenta: List[float], training: bool,
+                 softmax: bool) -> List[torch.Tensor]:
+    """-> [logits, saved activations (empty unless training), updated running statistics in table order]"""
+    if not x.is_cuda:
+        raise RuntimeError('elektronn3_amd.UNet runs only on a ROCm GPU (hand-written HIP kernels); there is no CPU fallback')
+    if x.dtype != torch.float32 or any(t.dtype != torch.float32 for t in tensors):
+        raise NotImplementedError('the scripted UNet supports fp32 modules (cast the eager module for reduced precision)')
+    plan = _get_plan(_plan_key_from_floats(key))
+    tens = [t.detach().contiguous() for t in tensors]
+    new_bufs = []
+    if training:
+        for i, kind in enumerate(plan.kinds):
+            if kind != 0:
+                tens[i] = tens[i].clone()
+                new_bufs.append(tens[i])
+    y, saved, _, _ = _native_forward(None, plan, x, tens, softmax, False, False, training, list(momenta) if training else None)
+    return [y, saved if saved is not None else x.new_empty(0, dtype=torch.uint8)] + new_bufs
+
+
+@_op_unet_fwd.register_fake
+def _(x, tensors, key, momenta, training, softmax):
+    plan = _get_plan(_plan_key_from_floats(key))
+    N, _, D, H, W = x.shape
+    Do, Ho, Wo = plan.out_dims(D, H, W)
+    saved_bytes = plan.sizes(N, D, H, W, True)[0] if training else 0
+    bufs = [torch.empty_like(t) for t, k in zip(tensors, plan.kinds) if k != 0] if training else []
+    return [x.new_empty((N, plan.out_channels, Do, Ho, Wo)), x.new_empty(max(saved_bytes, 256) if training else 0, dtype=torch.uint8)] + bufs
+
+
+@torch.library.custom_op('e3unet::unet_bwd', mutates_args=())
+def _op_unet_bwd(dy: torch.Tensor, x: torch.Tensor, tensors: List[torch.Tensor], saved: torch.Tensor, key: List[float]) -> List[torch.Tensor]:
+    """-> gradients of the trainable table entries, in table order"""
+    plan = _get_plan(_plan_key_from_floats(key))
+    tens = [t.detach().contiguous() for t in tensors]
+    _, views, _ = _native_backward(plan, dy, x.detach().contiguous(), tens, saved, False, False)
+    return [v.view_as(t).clone() for v, t in zip(views, tens) if v is not None]     # (operator outputs must not alias each other)
+
+
+@_op_unet_bwd.register_fake
+def _(dy, x, tensors, saved, key):
+    plan = _get_plan(_plan_key_from_floats(key))
+    return [torch.empty_like(t) for t, k in zip(tensors, plan.kinds) if k == 0]
+
+
+def _unet_fwd_setup(ctx, inputs, output):
+    x, tensors, key, momenta, training, softmax = inputs
+    ctx.key, ctx.training, ctx.softmax, ctx.n_mom = key, training, softmax, len(momenta)
+    # (the running statistics are overwritten right after the call and never read by the backward: placeholders keep the table's shape)
+    kinds = _get_plan(_plan_key_from_floats(key)).kinds
+    ctx.save_for_backward(x, output[1], *[t if k == 0 else torch.empty_like(t) for t, k in zip(tensors, kinds)])
+
+
+def _unet_fwd_backward(ctx, grads):
+    if not ctx.training:
+        raise NotImplementedError('backward through an eval-mode (running-statistics) forward is not implemented on the HIP path')
+    if ctx.softmax:
+        raise NotImplementedError('backward through the fused softmax head is not implemented')
+    x, saved, *tensors = ctx.saved_tensors
+    plan = _get_plan(_plan_key_from_floats(ctx.key))
+    g = iter(torch.ops.e3unet.unet_bwd(grads[0], x, tensors, saved, ctx.key))
+    # (one entry per operator argument; an EMPTY list argument -- no BatchNorm momenta -- flattens to zero leaves, not to one)
+    return None, [next(g) if k == 0 else None for k in plan.kinds], None, (None if ctx.n_mom else []), None, None
+
+
+_op_unet_fwd.register_autograd(_unet_fwd_backward, setup_context=_unet_fwd_setup)
 
 
 # layer types per dimensionality: conv, transposed conv, max-pool, batch norm (unet.py:47-105)
@@ -389,6 +467,8 @@ class UNet(nn.Module):
     ``nn.RReLU``; a train-mode forward, which draws a random slope per element, raises ``NotImplementedError``).  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
     the 3D one with every block planar and a depth of 1."""
 
+    _script_key: List[float]
+
     def __init__(
             self,
             in_channels: int = 1,
@@ -481,6 +561,8 @@ class UNet(nn.Module):
                                         normalization=normalization, full_norm=full_norm, merge_mode=merge_mode, activation=activation, up_mode=up_mode, conv_mode=conv_mode))
         self.conv_final = _LAYERS[dim][0](outs, out_channels, kernel_size=1)
         self.apply(self.weight_init)
+        self._script_key = [float(v) for v in self._plan_key()]      # (read by the scripted forward)
+        self._script_ok = normalization != 'instance' and dim == 3
 
     @staticmethod
     def weight_init(m):
@@ -566,8 +648,106 @@ class UNet(nn.Module):
 
     # ------------------------------------------------------------------ public API
     def forward(self, x):
+        if torch.jit.is_scripting():
+            return self._scripted_forward(x)
         return self._run(x, softmax=False)
 
+    def _scripted_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """UNet.forward as TorchScript sees it: the module's tensors in the native parameter-table order (per unit: conv weight, conv
+        bias, [norm weight, norm bias, [running_mean, running_var]], [PReLU slope]; units in execution order; conv_final last), ONE call
+        of the registered operator e3unet::unet_fwd, the returned running statistics copied back."""
+        if not self._script_ok:
+            raise RuntimeError('scripted elektronn3_amd.UNet: dim=3 with batch / group / no normalization only')
+        t: List[torch.Tensor] = []
+        bufs: List[torch.Tensor] = []
+        counters: List[torch.Tensor] = []
+        mom: List[float] = []
+        for blk in self.down_convs:
+            t.append(blk.conv1.weight)
+            b1 = blk.conv1.bias
+            assert b1 is not None
+            t.append(b1)
+            if hasattr(blk.norm0, 'weight'):
+                t.append(blk.norm0.weight); t.append(blk.norm0.bias)
+                if hasattr(blk.norm0, 'running_mean'):
+                    rm, rv, nb, mo = blk.norm0.running_mean, blk.norm0.running_var, blk.norm0.num_batches_tracked, blk.norm0.momentum
+                    assert rm is not None and rv is not None and nb is not None and mo is not None
+                    t.append(rm); t.append(rv); bufs.append(rm); bufs.append(rv); counters.append(nb); mom.append(mo)
+            if hasattr(blk.act1, 'weight'):
+                t.append(blk.act1.weight)
+            t.append(blk.conv2.weight)
+            b2 = blk.conv2.bias
+            assert b2 is not None
+            t.append(b2)
+            if hasattr(blk.norm1, 'weight'):
+                t.append(blk.norm1.weight); t.append(blk.norm1.bias)
+                if hasattr(blk.norm1, 'running_mean'):
+                    rm, rv, nb, mo = blk.norm1.running_mean, blk.norm1.running_var, blk.norm1.num_batches_tracked, blk.norm1.momentum
+                    assert rm is not None and rv is not None and nb is not None and mo is not None
+                    t.append(rm); t.append(rv); bufs.append(rm); bufs.append(rv); counters.append(nb); mom.append(mo)
+            if hasattr(blk.act2, 'weight'):
+                t.append(blk.act2.weight)
+        for ub in self.up_convs:
+            if hasattr(ub.upconv, 'conv'):
+                t.append(ub.upconv.conv.weight)
+                b0 = ub.upconv.conv.bias
+            else:
+                t.append(ub.upconv.weight)
+                b0 = ub.upconv.bias
+            assert b0 is not None
+            t.append(b0)
+            if hasattr(ub.norm0, 'weight'):
+                t.append(ub.norm0.weight); t.append(ub.norm0.bias)
+                if hasattr(ub.norm0, 'running_mean'):
+                    rm, rv, nb, mo = ub.norm0.running_mean, ub.norm0.running_var, ub.norm0.num_batches_tracked, ub.norm0.momentum
+                    assert rm is not None and rv is not None and nb is not None and mo is not None
+                    t.append(rm); t.append(rv); bufs.append(rm); bufs.append(rv); counters.append(nb); mom.append(mo)
+            if hasattr(ub.act0, 'weight'):
+                t.append(ub.act0.weight)
+            t.append(ub.conv1.weight)
+            b1 = ub.conv1.bias
+            assert b1 is not None
+            t.append(b1)
+            if hasattr(ub.norm1, 'weight'):
+                t.append(ub.norm1.weight); t.append(ub.norm1.bias)
+                if hasattr(ub.norm1, 'running_mean'):
+                    rm, rv, nb, mo = ub.norm1.running_mean, ub.norm1.running_var, ub.norm1.num_batches_tracked, ub.norm1.momentum
+                    assert rm is not None and rv is not None and nb is not None and mo is not None
+                    t.append(rm); t.append(rv); bufs.append(rm); bufs.append(rv); counters.append(nb); mom.append(mo)
+            if hasattr(ub.act1, 'weight'):
+                t.append(ub.act1.weight)
+            t.append(ub.conv2.weight)
+            b2 = ub.conv2.bias
+            assert b2 is not None
+            t.append(b2)
+            if hasattr(ub.norm2, 'weight'):
+                t.append(ub.norm2.weight); t.append(ub.norm2.bias)
+                if hasattr(ub.norm2, 'running_mean'):
+                    rm, rv, nb, mo = ub.norm2.running_mean, ub.norm2.running_var, ub.norm2.num_batches_tracked, ub.norm2.momentum
+                    assert rm is not None and rv is not None and nb is not None and mo is not None
+                    t.append(rm); t.append(rv); bufs.append(rm); bufs.append(rv); counters.append(nb); mom.append(mo)
+            if hasattr(ub.act2, 'weight'):
+                t.append(ub.act2.weight)
+        t.append(self.conv_final.weight)
+        bf = self.conv_final.bias
+        assert bf is not None
+        t.append(bf)
+        # nn.GroupNorm keeps no running statistics: its statistics are per sample in training and eval mode alike
+        if self._script_key[5] == 2.0:
+            # nn.GroupNorm: statistics per sample in training and eval mode alike, no running statistics: one call per sample
+            ys: List[torch.Tensor] = []
+            for n in range(x.shape[0]):
+                ys.append(torch.ops.e3unet.unet_fwd(x[n:n + 1], t, self._script_key, mom, True, False)[0])
+            return torch.cat(ys, 0)
+        outs = torch.ops.e3unet.unet_fwd(x, t, self._script_key, mom, self.training, False)
+        if self.training:
+            for i in range(len(bufs)):
+                bufs[i].copy_(outs[2 + i])
+            for c in counters:
+                c.add_(1)
+        return outs[0]
+
+    @torch.jit.unused
     def _run(self, x, softmax=False):
         if self.dim == 2:
             if not isinstance(x, torch.Tensor) or x.dim() != 4:
@@ -597,6 +777,7 @@ class UNet(nn.Module):
             y = _UNetFunction.apply(self, softmax, want_bf16, x, *params)
         return y.squeeze(2) if self.dim == 2 else y
 
+    @torch.jit.unused
     def forward_softmax(self, x):
         """``softmax(forward(x), dim=1)`` with the softmax fused into the final 1x1x1 conv kernel (used by Predictor)."""
         return self._run(x, softmax=True)
