@@ -17,6 +17,8 @@ _LIB_PATH = os.path.join(_HERE, 'libe3unet.so')
 
 E3_FWD_TRAINING = 1
 E3_FWD_SOFTMAX = 2
+E3_FWD_FROZEN_BN = 4
+E3_BWD_FROZEN_BN = 1
 
 
 class E3Error(RuntimeError):
@@ -61,6 +63,8 @@ _SIG = {
     'e3_convT_fwd_bf16': (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, c_size_t]),
     'e3_convT_dgrad_bf16': (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, c_size_t]),
     'e3_convT_wgrad_bf16': (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, c_size_t]),
+    'e3_unet_backward2': (_I, [c_void_p, _P, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), POINTER(c_void_p), _P,
+                               _P, c_size_t, _P, c_size_t, _P, _I, c_uint32]),
     'e3_unet_conv_count': (_I, [c_void_p]),
     'e3_unet_conv_info': (_I, [c_void_p, _I, c_char_p, _I, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     'e3_unet_profile_select': (_I, [c_void_p, _I, _I]),
@@ -153,4 +157,4 @@ def ptr(t):
 
 
 __all__ = ['load', 'check', 'ptr', 'stream_ptr', 'UNetCfg', 'E3Error', 'EXPORTED_SYMBOLS', 'E3_FWD_TRAINING',
-           'E3_FWD_SOFTMAX', 'byref', 'c_size_t', 'c_void_p', 'c_float', 'c_int', 'c_int64', 'c_double', 'POINTER']
+           'E3_FWD_SOFTMAX', 'E3_FWD_FROZEN_BN', 'E3_BWD_FROZEN_BN', 'byref', 'c_size_t', 'c_void_p', 'c_float', 'c_int', 'c_int64', 'c_double', 'POINTER']

@@ -771,6 +771,22 @@ int launch_bias_fold(const float* conv_bias, float* scale, float* shift, int C, 
     return E3_OK;
 }
 
+// frozen statistics (a forward in eval mode that a backward will follow): the normalisation uses the RUNNING statistics, written in the
+// four per-channel vectors the train-mode passes read (mean, invstd, scale, shift); nothing is updated
+__global__ void bn_frozen_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                 float* mean, float* invstd, float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double is = 1.0 / sqrt((double)rv[c] + (double)eps), g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
+    mean[c] = rm[c]; invstd[c] = (float)is; scale[c] = (float)(g * is); shift[c] = (float)(b - (double)rm[c] * g * is);
+}
+int launch_bn_frozen(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                     float* mean, float* invstd, float* scale, float* shift, int C, hipStream_t s) {
+    hipLaunchKernelGGL(bn_frozen_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, gamma, beta, rm, rv, eps, mean, invstd, scale, shift, C);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
 int launch_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, const float* conv_bias,
                    float eps, float* scale, float* shift, int C, hipStream_t s) {
     hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, gamma, beta, rm, rv, conv_bias, eps, scale, shift, C);

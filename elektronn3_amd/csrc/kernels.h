@@ -207,6 +207,8 @@ int launch_bn_finalize(BnFinalizeArgs a, hipStream_t s);
 // eval mode: scale = gamma/sqrt(rv+eps); shift = beta + (conv_bias - rm)*scale   (BN folded into the conv epilogue)
 int launch_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, const float* conv_bias,
                    float eps, float* scale, float* shift, int C, hipStream_t s);
+int launch_bn_frozen(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                     float* mean, float* invstd, float* scale, float* shift, int C, hipStream_t s);   // running statistics as (mean, invstd, scale, shift)
 // a = relu(x*scale+shift) written to `a` (any ldc); optionally also p = maxpool_{kd,2,2}(a), ceil mode
 int launch_bn_relu_apply(const float* x, int x_ldc, const float* scale, const float* shift, float* a, int a_ldc,
                          float* pooled /*null or packed NDHWC (ceil dims)*/, int kd,

@@ -411,6 +411,9 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
     E3_REQUIRE(plan && x && y && params && scratch, E3_ERR_INVALID, "null argument");
     hipStream_t s = (hipStream_t)stream;
     const bool training = (flags & E3_FWD_TRAINING) != 0;
+    // frozen BatchNorm: the training-mode data flow (raw tensors and activations are saved for a backward) with the RUNNING statistics
+    // in place of batch statistics and no update of them -- what autograd does for a module in eval mode
+    const bool frozen = training && (flags & E3_FWD_FROZEN_BN) != 0 && plan->cfg.normalization == 1;
     const e3_unet_cfg& cfg = plan->cfg;
     const int nb = cfg.n_blocks;
     { NetDims nd0; net_dims(plan, N, D, H, W, nd0);
@@ -470,6 +473,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         const float slope = cfg.act_slope;
         const ActArg act = u.p_a >= 0 ? ActArg(0.f, P(u.p_a)) : ActArg(slope);
         const bool bn_train = training && u.has_norm();   // batch statistics needed: conv writes the raw output, BN+ReLU is a second pass
+        float* const stat_buf = frozen ? nullptr : B.stats;   // (frozen statistics: nothing to measure)
         const bool two_pass = bn_train || slope != 0.f || u.is_up == 2 || vcrop;   // (non-ReLU activations are not in the conv epilogues; the
                                                                            // ResizeConv output may need the autocrop before the norm)
         float* dst = two_pass ? b.raw : b.act;            // otherwise the conv writes the activation directly
@@ -507,7 +511,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             a.x = B.ups[k]; a.x_ldc = u.cin; a.Cin = u.cin; a.wt = B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
             a.y = same ? b.raw : B.rtmp; a.y_ldc = u.cout; a.N = N; a.D = Ud; a.H = Uh; a.W = Uw; a.sd = 2;
             a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.G = 1; a.flags = 0;
-            a.stats = (bn_train && same) ? B.stats : nullptr;
+            a.stats = (bn_train && same) ? stat_buf : nullptr;
             parts = conv_stats_parts(kind, 0, N, Ud, Uh, Uw, 2, u.cin, u.cout);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(kind, a, s)); }
             if (!same) {             // crop one voxel at the high end where the skip has an odd size (unet.py:289-299) + statistics
@@ -523,14 +527,14 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = li.D; a.H = li.H; a.W = li.W;
             a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = sd;   // autocrop of the up-convolved tensor (unet.py:289-299)
             a.Cout = u.cout; a.Ncols = taps * u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
-            a.stats = bn_train ? B.stats : nullptr; a.G = 1; a.flags = CF_SCATTER_UP;
+            a.stats = bn_train ? stat_buf : nullptr; a.G = 1; a.flags = CF_SCATTER_UP;
             parts = conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, li.D, li.H, li.W, sd, u.cin, taps * u.cout);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(CONV_POINT, a, s)); }
         } else if (u.cin < 8) {
             ConvSmallArgs a{};
             a.x = cur; a.Cin = u.cin; a.w = P(u.p_w); a.bias = bn_train ? P(u.p_b) : nullptr; a.y = vcrop ? B.rtmp : dst; a.y_ldc = dst_ldc;
             a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.Cout = u.cout; a.planar = u.planar;
-            a.epi_scale = es; a.epi_shift = eh; a.stats = (bn_train && !vcrop) ? B.stats : nullptr;
+            a.epi_scale = es; a.epi_shift = eh; a.stats = (bn_train && !vcrop) ? stat_buf : nullptr;
             parts = conv_small_stats_parts(N, ci.D, ci.H, ci.W, u.planar);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_small_fwd(a, s)); }
         } else {
@@ -542,7 +546,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpk_f[k] ? B.wpk_f[k] : B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
             a.y = vcrop ? B.rtmp : dst; a.y_ldc = dst_ldc; a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.sd = 2;
             a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
-            a.stats = (bn_train && !vcrop) ? B.stats : nullptr; a.G = 1; a.flags = 0;
+            a.stats = (bn_train && !vcrop) ? stat_buf : nullptr; a.G = 1; a.flags = 0;
             parts = conv_stats_parts(kind, 0, N, ci.D, ci.H, ci.W, 2, u.cin, u.cout);
             const int S = (kind == CONV_K3) ? fwd_split(k) : 1;
             if (S > 1) {         // partial sums per share of the input channels, then sum + bias + statistics in one small pass
@@ -551,7 +555,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             }
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(kind, a, s)); }
             if (S > 1) {
-                RUN(launch_splitk_reduce(B.skws, S, lo.vox * u.cout, P(u.p_b), dst, dst_ldc, u.cout, lo.vox, B.stats, s));
+                RUN(launch_splitk_reduce(B.skws, S, lo.vox * u.cout, P(u.p_b), dst, dst_ldc, u.cout, lo.vox, stat_buf, s));
                 parts = crop_stats_parts(lo.vox, u.cout);
             }
         }
@@ -559,7 +563,12 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             RUN(launch_crop_stats(B.rtmp, b.raw, u.cout, N, ci.D, ci.H, ci.W, lo.D, lo.H, lo.W, B.stats, s, ND.u[k].od, ND.u[k].oh, ND.u[k].ow));
             parts = crop_stats_parts(lo.vox, u.cout);
         }
-        if (bn_train) {
+        if (bn_train && frozen) {
+            RUN(launch_bn_frozen(P(u.p_g), P(u.p_be), P(u.p_rm), P(u.p_rv), cfg.bn_eps, b.mean, b.invstd, b.scale, b.shift, u.cout, s));
+            if (k + 1 < plan->units.size())
+                RUN(launch_bn_relu_apply(b.raw, u.cout, b.scale, b.shift, b.act, b.act_ldc, pool_after ? B.pooled[u.level] : nullptr, kd,
+                                         N, lo.D, lo.H, lo.W, u.cout, s, act));
+        } else if (bn_train) {
             BnFinalizeArgs f{};
             f.stats = B.stats; f.parts = parts; f.C = u.cout; f.gamma = P(u.p_g); f.beta = P(u.p_be);
             const bool group = cfg.normalization == 2;
@@ -612,7 +621,17 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
                      void* const* params, void* const* grads, float* dx,
                      void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
                      void* bucket_event, int bucket_after_down_block) {
+    return e3_unet_backward2(plan, stream, dy, x, N, D, H, W, params, grads, dx, saved, saved_bytes, scratch, scratch_bytes, bucket_event,
+                             bucket_after_down_block, 0);
+}
+
+int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const float* x, int N, int D, int H, int W,
+                      void* const* params, void* const* grads, float* dx,
+                      void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                      void* bucket_event, int bucket_after_down_block, uint32_t flags) {
     E3_REQUIRE(plan && dy && x && params && grads && saved && scratch, E3_ERR_INVALID, "null argument");
+    // the forward ran with E3_FWD_FROZEN_BN: the statistics are constants, so dx = gamma * invstd * dz (no mean / variance terms)
+    const bool frozen = (flags & E3_BWD_FROZEN_BN) != 0 && plan->cfg.normalization == 1;
     hipStream_t s = (hipStream_t)stream;
     const e3_unet_cfg& cfg = plan->cfg;
     const int nb = cfg.n_blocks;
@@ -734,6 +753,7 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
                 RUN(launch_bn_bwd_reduce(a, s));
                 if (u.p_a >= 0) RUN(launch_prelu_dslope(a.part, a.parts, u.cout, B.small + 4 * u.cout, G(u.p_a), s));
                 RUN(launch_bn_bwd_finalize(a.part, a.parts, u.cout, (float)(1.0 / (double)lo.vox), G(u.p_g), G(u.p_be), B.small, s));
+                if (frozen) a.coef = B.zeros;      // (dgamma = sum dz*xhat and dbeta = sum dz stand; the correction terms vanish)
                 if (cfg.normalization == 2)
                     RUN(launch_gn_bwd_coef(G(u.p_g), G(u.p_be), P(u.p_g), b.invstd, u.cout, u.cout / cfg.num_groups, (float)(1.0 / (double)lo.vox), B.small, s));
             } else a.coef = B.zeros;

@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import E3_FWD_SOFTMAX, E3_FWD_TRAINING, UNetCfg, c_size_t, c_void_p, check
+from ._lib import E3_BWD_FROZEN_BN, E3_FWD_FROZEN_BN, E3_FWD_SOFTMAX, E3_FWD_TRAINING, UNetCfg, c_size_t, c_void_p, check
 
 _plans = {}
 _plans_lock = threading.Lock()
@@ -115,13 +115,13 @@ def _fp32_table(module, tens):
     return cache[2]
 
 
-def _native_forward(module, plan, x, tens, softmax, want_bf16, x_needs_grad, training, momenta):
+def _native_forward(module, plan, x, tens, softmax, want_bf16, x_needs_grad, training, momenta, frozen=False):
     """One call of e3_unet_forward / e3_unet_forward_bf16.  `tens`: fp32 table tensors (contiguous), `lowp_bf16`: the module stores
     bf16.  Returns (y fp32, saved buffer or None, the input as handed to the library, bf16 path taken)."""
     lib = _lib.load()
     dev = x.device
     N, Cin, D, H, W = x.shape
-    b16 = want_bf16 and not x_needs_grad and plan.bf16_supported() and not _NO_BF16
+    b16 = want_bf16 and not x_needs_grad and not frozen and plan.bf16_supported() and not _NO_BF16
     xin = x.detach().to(torch.bfloat16 if b16 else torch.float32).contiguous()
     saved_bytes, scratch_bytes = plan.sizes(N, D, H, W, training, bf16=b16)
     saved = torch.empty(max(saved_bytes, 256), dtype=torch.uint8, device=dev) if training else None
@@ -130,7 +130,7 @@ def _native_forward(module, plan, x, tens, softmax, want_bf16, x_needs_grad, tra
     y = torch.empty((N, plan.out_channels, Do, Ho, Wo), dtype=torch.float32, device=dev)
     ptrs = (c_void_p * len(tens))(*[t.data_ptr() for t in tens])
     cmom = (ctypes.c_float * len(momenta))(*momenta) if training else None
-    flags = (E3_FWD_TRAINING if training else 0) | (E3_FWD_SOFTMAX if softmax else 0)
+    flags = (E3_FWD_TRAINING if training else 0) | (E3_FWD_SOFTMAX if softmax else 0) | (E3_FWD_FROZEN_BN if frozen else 0)
     fwd = lib.e3_unet_forward_bf16 if b16 else lib.e3_unet_forward
     with torch.cuda.device(dev):
         check(fwd(plan.handle, _lib.stream_ptr(dev), c_void_p(xin.data_ptr()), N, D, H, W, ptrs, cmom,
@@ -140,7 +140,7 @@ def _native_forward(module, plan, x, tens, softmax, want_bf16, x_needs_grad, tra
     return y, saved, xin, b16
 
 
-def _native_backward(plan, dy, xin, tens, saved, b16, want_dx, sync=None):
+def _native_backward(plan, dy, xin, tens, saved, b16, want_dx, sync=None, frozen=False):
     """One call of e3_unet_backward / _bf16: (flat fp32 gradient buffer, its per-table-entry views, dx or None)."""
     lib = _lib.load()
     N, _, D, H, W = xin.shape
@@ -154,12 +154,14 @@ def _native_backward(plan, dy, xin, tens, saved, b16, want_dx, sync=None):
     _, scratch_bytes = plan.sizes(N, D, H, W, True, bf16=b16)
     scratch = _get_scratch(dev, max(scratch_bytes, 256))
     ev, ev_blk = (sync.bucket_event(), sync.bucket_after_down_block) if sync is not None else (None, 0)
-    bwd = lib.e3_unet_backward_bf16 if b16 else lib.e3_unet_backward
+    args = (plan.handle, _lib.stream_ptr(dev), c_void_p(dy32.data_ptr()), c_void_p(xin.data_ptr()),
+            N, D, H, W, ptrs, gptrs, c_void_p(dx.data_ptr()) if dx is not None else None,
+            c_void_p(saved.data_ptr()), c_size_t(saved.numel()), c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), ev, ev_blk)
     with torch.cuda.device(dev):
-        check(bwd(plan.handle, _lib.stream_ptr(dev), c_void_p(dy32.data_ptr()), c_void_p(xin.data_ptr()),
-                  N, D, H, W, ptrs, gptrs, c_void_p(dx.data_ptr()) if dx is not None else None,
-                  c_void_p(saved.data_ptr()), c_size_t(saved.numel()),
-                  c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), ev, ev_blk))
+        if b16:
+            check(lib.e3_unet_backward_bf16(*args))
+        else:
+            check(lib.e3_unet_backward2(*args, E3_BWD_FROZEN_BN if frozen else 0))
     if sync is not None:
         sync.after_backward(plan)
     return flat, views, dx
@@ -183,18 +185,25 @@ class _UNetFunction(torch.autograd.Function):
         tens = [t if t.is_contiguous() else t.contiguous() for t in tens]
         all_bf16 = lowp is not None and all(t.dtype == torch.bfloat16 for t in lowp if t.is_floating_point())
         # (grad mode is off inside Function.forward; needs_input_grad tells whether a backward can follow)
-        need_grad = training and any(ctx.needs_input_grad)
+        need_grad = any(ctx.needs_input_grad) and not softmax
+        # a module in eval mode that a backward will follow (frozen-BatchNorm fine-tuning, training/recalibration.py:53-73 style uses):
+        # the training data flow with the running statistics as constants
+        frozen = need_grad and not training and module.normalization == 'batch'
+        if need_grad and not training and not frozen:
+            training = True            # (normalization='none': train and eval mode are the same function; take the flow that saves)
         y, saved, xin, b16 = _native_forward(module, plan, x, tens, softmax, want_bf16 or (all_bf16 and in_dtype == torch.bfloat16),
-                                             ctx.needs_input_grad[3], training, module._momenta(plan) if training else None)
+                                             ctx.needs_input_grad[3], training or frozen,
+                                             module._momenta(plan) if (training or frozen) else None, frozen=frozen)
+        ctx.frozen = frozen
         out_dtype = torch.bfloat16 if (b16 and want_bf16) else in_dtype
-        if training:
+        if training and not frozen and module.training:
             module._bump_num_batches_tracked(plan)
             if lowp is not None:         # running statistics were updated in the fp32 copies
                 pairs = [(lo_t, hi_t) for kind, lo_t, hi_t in zip(plan.kinds, lowp, tens) if kind != 0 and lo_t.dtype != torch.float32]
                 if pairs:
                     torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])
         ctx.module, ctx.plan, ctx.b16 = module, plan, b16
-        ctx.softmax, ctx.eval_mode, ctx.in_dtype = softmax, not training, in_dtype
+        ctx.softmax, ctx.eval_mode, ctx.in_dtype = softmax, not (training or frozen), in_dtype
         # (a low-precision module's fp32 table is a cache that the next forward refreshes with the same parameter values:
         # the backward only reads weights and affine parameters from it, never the running statistics)
         ctx.x32, ctx.saved_buf, ctx.tens = (xin, saved, tens) if need_grad else (None, None, None)
@@ -210,7 +219,7 @@ class _UNetFunction(torch.autograd.Function):
             raise NotImplementedError('backward through the fused softmax head is not implemented')
         module, plan = ctx.module, ctx.plan
         flat, views, dx = _native_backward(plan, dy, ctx.x32, ctx.tens, ctx.saved_buf, ctx.b16, ctx.needs_input_grad[3],
-                                           getattr(module, '_grad_sync', None))
+                                           getattr(module, '_grad_sync', None), frozen=ctx.frozen)
         ctx.saved_buf = ctx.x32 = ctx.tens = None   # free the activations now
         named = list(module._named_table_params(plan))
         lowp_dtype = next((p.dtype for _, p in named if p.dtype != torch.float32), None)

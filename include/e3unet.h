@@ -90,6 +90,9 @@ int e3_unet_sizes(const e3_unet_plan* plan, int N, int D, int H, int W, int trai
 
 #define E3_FWD_TRAINING 1u  /* batch statistics + running-stat update (module.training) */
 #define E3_FWD_SOFTMAX 2u   /* y = softmax over channels (Predictor's nn.Sequential(model, nn.Softmax(1)), inference.py:443-444) */
+#define E3_FWD_FROZEN_BN 4u /* with E3_FWD_TRAINING: save activations for a backward, but normalise with the RUNNING statistics and leave them
+                             * untouched -- autograd through a module in eval mode (frozen-BN fine-tuning, training/recalibration.py:53-73) */
+#define E3_BWD_FROZEN_BN 1u /* e3_unet_backward2: the matching backward (BatchNorm statistics are constants) */
 
 /* y[N,out,D,H,W] = UNet(x[N,in,D,H,W]).
  *   params : e3_unet_param_count() device pointers in table order
@@ -113,6 +116,12 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
                      void* const* params, void* const* grads, float* dx,
                      void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
                      void* bucket_event, int bucket_after_down_block);
+
+/* e3_unet_backward with flags (E3_BWD_FROZEN_BN). */
+int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const float* x, int N, int D, int H, int W,
+                      void* const* params, void* const* grads, float* dx,
+                      void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                      void* bucket_event, int bucket_after_down_block, uint32_t flags);
 
 /* Per-layer profiling hook used by bench.py for the roofline line: when `layer` >= 0, hipEvents are recorded
  * around that layer's dominant kernel in every subsequent forward (which=0), dgrad (1) or wgrad (2); read the

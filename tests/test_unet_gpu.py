@@ -783,3 +783,46 @@ def test_low_precision_module_trains_with_fp32_compute(dt):
             torch.testing.assert_close(b.float(), c, rtol=2 * eps, atol=2 * eps, msg=k)
             assert b.dtype == dt
     assert not torch.equal(m.down_convs[0].norm0.running_mean.float(), torch.zeros(16, device='cuda'))
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(planar_blocks=(0,), full_norm=False), dict(normalization='none')])
+def test_backward_through_eval_mode_forward_against_fp64(kw):
+    """Autograd through a module in eval mode (frozen-BatchNorm fine-tuning; the reference's autograd supports it, e.g. around
+    training/recalibration.py:53-73): BatchNorm uses the running statistics as constants, which stay untouched.  Against the fp64 op
+    sequence in eval mode; the split-K bottom level and odd sizes included."""
+    from elektronn3_amd.unet import UNet
+    from oracle.torch_ref import combined_loss, unet_forward
+    torch.manual_seed(11)
+    planar = kw.get('planar_blocks', ())
+    m = UNet(1, 2, n_blocks=3, start_filts=16, **kw).cuda()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if 'norm' in n and n.endswith('weight'):
+                p.copy_(1 + 0.2 * torch.randn_like(p))
+            elif n.endswith('bias'):
+                p.copy_(0.1 * torch.randn_like(p))
+    x = torch.randn(2, 1, 13, 30, 36, device='cuda')
+    t = torch.randint(0, 2, (2, 13, 30, 36), device='cuda')
+    m.train()
+    with torch.no_grad():
+        for _ in range(3):
+            m(torch.randn(2, 1, 13, 30, 36, device='cuda'))      # non-trivial running statistics
+    m.eval()
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.zero_grad(set_to_none=True)
+    out = m(x)
+    loss = combined_loss(out, t)
+    loss.backward()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd0[k]), k                            # eval mode: no buffer moves
+    sd = {k: (v.double() if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd0.items()}
+    ref = unet_forward(sd, x.double(), 3, planar, training=False)
+    lref = combined_loss(ref, t)
+    lref.backward()
+    assert torch.allclose(out.double(), ref, rtol=1e-4, atol=1e-4), float((out.double() - ref).abs().max())
+    with torch.no_grad():
+        assert torch.allclose(m(x), out, rtol=1e-5, atol=1e-5)       # the inference path (folded BN) computes the same function
+    for k, p in m.named_parameters():
+        g = sd[k].grad
+        err = float((p.grad.double() - g).norm() / g.norm().clamp_min(1e-30))
+        assert err < 5e-3, (k, err)
