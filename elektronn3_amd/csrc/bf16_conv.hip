@@ -48,7 +48,19 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
     const int cg = L % cgroups; L /= cgroups;
     const int ksp = L % ksplit; L /= ksplit;            // split-K: this workgroup sums the channel chunks [ch0, ch1) into partial[ksp]
     const int brick = (int)L;
-    const int tw = L % tilesW; L /= tilesW; const int th = L % tilesH; L /= tilesH; const int td = L % tilesD; const int n = L / tilesD;
+    // brick order: the bricks an XCD works on at the same time (64 of them: 32 CUs x 2) should be neighbours in all three dimensions, so
+    // that their shared halo planes are L2 hits -- all tilesD bricks of a 2 x 2 (h, w) column before the next column, instead of whole
+    // d-slabs (whose 128 bricks x 140 KB outlive the 4 MB L2 before the next slab asks for the shared planes again)
+    int tw, th, td, n;
+    if (((tilesH | tilesW) & 1) == 0) {
+        const unsigned per = (unsigned)tilesD * 4;
+        const unsigned col = L / per, r = L % per;
+        const unsigned ncol = (unsigned)(tilesH >> 1) * (tilesW >> 1);
+        n = col / ncol; const unsigned c2 = col % ncol;
+        td = r >> 2; th = 2 * (c2 / (tilesW >> 1)) + ((r >> 1) & 1); tw = 2 * (c2 % (tilesW >> 1)) + (r & 1);
+    } else {
+        tw = L % tilesW; L /= tilesW; th = L % tilesH; L /= tilesH; td = L % tilesD; n = L / tilesD;
+    }
     const int d0 = td * BD, h0 = th * 8, w0 = tw * 16;
     const int co0 = cg * 32 * CO_T;
     constexpr int PD = KD == 3 ? 1 : 0;
