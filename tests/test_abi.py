@@ -43,6 +43,23 @@ def test_binding_matches_header_arity():
         assert len(args) == fns[name], (name, len(args), fns[name])
 
 
+def test_integration_doc_struct_matches_the_binding():
+    """The ctypes `UNetCfg` a maintainer would copy from INTEGRATION.md has the fields, order and types of the real binding (a stale,
+    shorter struct makes the library read `act_slope` past its end) and the header's e3_unet_cfg."""
+    from elektronn3_amd import _lib
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    block = doc[doc.index('class UNetCfg(ctypes.Structure)'):doc.index('plan = ctypes.c_void_p()')]
+    fields = re.findall(r"\('(\w+)',\s*ctypes\.(c_\w+)\)", block)
+    want = [(n, t.__name__) for n, t in _lib.UNetCfg._fields_]
+    norm = lambda t: {'c_int': 'c_int32', 'c_uint': 'c_uint32'}.get(t, t)      # (ctypes aliases c_int32 to c_int on this platform)
+    assert [(n, norm(t)) for n, t in fields] == [(n, norm(t)) for n, t in want], (fields, want)
+    hdr = open(os.path.join(ROOT, 'include', 'e3unet.h')).read()
+    struct = hdr[hdr.index('typedef struct e3_unet_cfg {'):hdr.index('} e3_unet_cfg;')]
+    assert re.findall(r'^\s*(?:u?int32_t|float)\s+(\w+);', struct, flags=re.M) == [n for n, _ in want]
+    call = re.search(r'cfg = UNetCfg\(([^)]*)\)', doc).group(1)
+    assert len([a for a in call.split(',') if a.strip()]) == len(want)
+
+
 @pytest.mark.parametrize('fixture,cfg_args', [('unet_nb4_sf8_planar01.npz', (1, 2, 4, 8, 0b0011, 1, 1e-5, 1)),
                                               ('unet_nb3_sf8_planar0_sparsenorm.npz', (1, 2, 3, 8, 0b001, 1, 1e-5, 0)),   # full_norm=False
                                               ('unet_nb2_sf8_nonorm.npz', (1, 2, 2, 8, 0, 0, 1e-5, 1))])                  # normalization='none'
