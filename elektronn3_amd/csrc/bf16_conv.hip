@@ -19,15 +19,22 @@
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 // (a plain function: called straight from a kernel TEMPLATE, hipcc's host pass drops the kernel's stub)
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, lds_ptr_t dst, int, unsigned voff, int, int, int) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, 0, 0, 0);
 }
-constexpr int HH = 10, HW = 18;
 constexpr unsigned OOB = 0x80000000u;
 
-template <int BD, int KD>
+// Brick = BD x BH x BW voxels = BD x 4 tiles of 32 voxels per d-slice.  TW = 16: tile = 2 h-rows x 16 w (brick BD x 8 x 16; works for any
+// W); TW = 32: tile = 1 h-row x 32 w (brick BD x 4 x 32): the 16 lanes of a ds_read_b128 group then read 16 CONSECUTIVE voxels of one
+// row at any tap shift, which the swizzle maps to 16 distinct bank slots -- no conflicts (the 2 x 16 tile straddles two rows 18 voxels
+// apart: a quarter more LDS cycles, measured 22 % of the LDS-active cycles of the 64->32 layer).
+template <int BD, int KD, int TW>
 struct Geo {
+    static constexpr int RPT = 32 / TW;                   // h-rows per tile
+    static constexpr int BH = 4 * RPT, BW = TW;
+    static constexpr int HH = BH + 2, HW = BW + 2;
     static constexpr int HD = BD + (KD == 3 ? 2 : 0);
     static constexpr int HV = HD * HH * HW;              // halo voxels
     static constexpr int NI = (HV * 4 + 63) / 64;        // 1 KB wave-pieces per chunk
@@ -37,9 +44,10 @@ struct Geo {
     static constexpr int TAPS = KD * 9;
 };
 
-template <int BD, int CO_T, int KD>
+template <int BD, int CO_T, int KD, int TW>
 __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const ConvB16Args a, int tilesD, int tilesH, int tilesW, int cgroups, int ksplit) {
-    using G = Geo<BD, KD>;
+    using G = Geo<BD, KD, TW>;
+    constexpr int HH = G::HH, HW = G::HW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
     } else {
         tw = L % tilesW; L /= tilesW; th = L % tilesH; L /= tilesH; td = L % tilesD; n = L / tilesD;
     }
-    const int d0 = td * BD, h0 = th * 8, w0 = tw * 16;
+    const int d0 = td * BD, h0 = th * G::BH, w0 = tw * G::BW;
     const int co0 = cg * 32 * CO_T;
     constexpr int PD = KD == 3 ? 1 : 0;
     const int nch = a.Cin >> 5;
@@ -84,13 +92,13 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
     }
 
     // ---- lane read addresses (tap kd = kh = 0, tile 0 of the wave): 3 kw x 2 k-steps
-    const int r = j >> 4, c = j & 15;
+    const int r = TW == 16 ? j >> 4 : 0, c = TW == 16 ? j & 15 : j;
     const int T0 = wave * G::NV, dT0 = T0 >> 2, hp0 = T0 & 3;
     unsigned rd[3][2];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
         const int hw = c + kw, sw = (hw >> 2) & 3;
-        const int row = (dT0 * HH + 2 * hp0 + r) * HW + hw;
+        const int row = (dT0 * HH + G::RPT * hp0 + r) * HW + hw;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) rd[kw][ks] = (unsigned)(row * 64 + (((2 * ks + g) ^ sw) << 4));
     }
@@ -124,6 +132,40 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (TW == 32 && CO_T == 1) {
+            // the three kw taps of a (kd, kh) pair read the same voxel row shifted by one voxel = by one LANE: two LDS reads (kw = 0 and
+            // kw = 2), the middle fragment from lane shifts (DPP wave_shl / wave_shr; VALU work is free beside bf16 MFMAs): a third fewer
+            // LDS reads -- with one output-channel tile per workgroup every fragment feeds a single MFMA and the LDS is the busiest unit
+            const bool edge = j == 31;
+#pragma unroll
+            for (int pr = 0; pr < G::TAPS / 3; ++pr) {
+#pragma unroll
+                for (int q3 = 0; q3 < 3; ++q3)
+                    if (pr * 3 + q3 + RING - 3 >= RING - 1 && pr * 3 + q3 + RING - 3 < G::TAPS) { E3_LOAD_W(pr * 3 + q3 + RING - 3, (pr * 3 + q3 + RING - 3) % RING); }
+                const int kd = pr / 3, kh = pr % 3;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int t = 0; t < G::NV; ++t) {
+                        const int imm = ((kd * HH + G::RPT * t + kh) * HW) * 64;
+                        const i32x4 f0 = *reinterpret_cast<const i32x4*>(smem + rd[0][ks] + imm);
+                        const i32x4 f2 = *reinterpret_cast<const i32x4*>(smem + rd[2][ks] + imm);
+                        i32x4 f1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int up = __builtin_amdgcn_update_dpp(0, f0[e], 0x130, 0xf, 0xf, false);      // wave_shl:1  lane l <- lane l+1
+                            const int dn = __builtin_amdgcn_update_dpp(0, f2[e], 0x138, 0xf, 0xf, false);      // wave_shr:1  lane l <- lane l-1
+                            f1[e] = edge ? dn : up;
+                        }
+#pragma unroll
+                        for (int ct = 0; ct < CO_T; ++ct) {
+                            acc[ct][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(pr * 3) % RING][ct][ks], __builtin_bit_cast(bf16x8, f0), acc[ct][t], 0, 0, 0);
+                            acc[ct][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(pr * 3 + 1) % RING][ct][ks], __builtin_bit_cast(bf16x8, f1), acc[ct][t], 0, 0, 0);
+                            acc[ct][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(pr * 3 + 2) % RING][ct][ks], __builtin_bit_cast(bf16x8, f2), acc[ct][t], 0, 0, 0);
+                        }
+                    }
+            }
+        } else {
 #pragma unroll
         for (int tap = 0; tap < G::TAPS; ++tap) {
             if (tap + RING - 1 < G::TAPS) { E3_LOAD_W(tap + RING - 1, (tap + RING - 1) % RING); }
@@ -132,12 +174,13 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int t = 0; t < G::NV; ++t) {
-                    const int imm = ((kd * HH + 2 * t + kh) * HW) * 64;
+                    const int imm = ((kd * HH + G::RPT * t + kh) * HW) * 64;
                     const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + rd[kw][ks] + imm);
 #pragma unroll
                     for (int ct = 0; ct < CO_T; ++ct)
                         acc[ct][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap % RING][ct][ks], b, acc[ct][t], 0, 0, 0);
                 }
+        }
         }
         __syncthreads();
 #undef E3_LOAD_W
@@ -150,7 +193,7 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
         for (int ct = 0; ct < CO_T; ++ct)
 #pragma unroll
             for (int t = 0; t < G::NV; ++t) {
-                const int d = d0 + dT0, h = h0 + 2 * (hp0 + t) + r, w = w0 + c;
+                const int d = d0 + dT0, h = h0 + G::RPT * (hp0 + t) + r, w = w0 + c;
                 if (d < a.D && h < a.H && w < a.W) {
                     float* prow = a.partial + ((size_t)ksp * vox + (((size_t)n * a.D + d) * a.H + h) * a.W + w) * a.Cout + co0 + ct * 32 + 4 * g;
 #pragma unroll
@@ -177,7 +220,7 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
         }
 #pragma unroll
         for (int t = 0; t < G::NV; ++t) {
-            const int d = d0 + dT0, h = h0 + 2 * (hp0 + t) + r, w = w0 + c;
+            const int d = d0 + dT0, h = h0 + G::RPT * (hp0 + t) + r, w = w0 + c;
             const bool valid = d < a.D && h < a.H && w < a.W;
             bf16_t* yrow = a.y + ((((size_t)n * a.D + d) * a.H + h) * a.W + w) * a.y_ldc + co0 + ct * 32 + 4 * g;
 #pragma unroll
@@ -203,7 +246,7 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
     // ---- statistics: S[wave][quantity][channel][33] floats in the (now free) image, column sums, (n, mean, M2) record per brick
     float* S = reinterpret_cast<float*>(smem);
     float* R = S + 4 * 2 * 32 * 33;                    // [2][4][32]
-    const int nd = a.D - d0 < BD ? a.D - d0 : BD, nh = a.H - h0 < 8 ? a.H - h0 : 8, nw = a.W - w0 < 16 ? a.W - w0 : 16;
+    const int nd = a.D - d0 < BD ? a.D - d0 : BD, nh = a.H - h0 < G::BH ? a.H - h0 : G::BH, nw = a.W - w0 < G::BW ? a.W - w0 : G::BW;
     const float cnt = (float)(nd * nh * nw);
 #pragma unroll
     for (int ct = 0; ct < CO_T; ++ct) {
@@ -345,16 +388,16 @@ __global__ void pack_multi_b16_kernel(const PackMultiArgs a) {
     }
 }
 
-template <int BD, int CO_T, int KD>
+template <int BD, int CO_T, int KD, int TW>
 int launch_t(const ConvB16Args& a, int ksplit, hipStream_t s) {
-    using G = Geo<BD, KD>;
-    const int tD = cdiv(a.D, BD), tH = cdiv(a.H, 8), tW = cdiv(a.W, 16);
+    using G = Geo<BD, KD, TW>;
+    const int tD = cdiv(a.D, BD), tH = cdiv(a.H, G::BH), tW = cdiv(a.W, G::BW);
     const int cgroups = a.Cout / (32 * CO_T);
     const size_t grid = (size_t)a.N * tD * tH * tW * cgroups * ksplit;
     const int lds = G::IMG > 4 * 2 * 32 * 33 * 4 + 1024 ? G::IMG : 4 * 2 * 32 * 33 * 4 + 1024;
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)conv_b16_kernel<BD, CO_T, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
-    hipLaunchKernelGGL((conv_b16_kernel<BD, CO_T, KD>), dim3((unsigned)grid), dim3(256), lds, s, a, tD, tH, tW, cgroups, ksplit);
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)conv_b16_kernel<BD, CO_T, KD, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
+    hipLaunchKernelGGL((conv_b16_kernel<BD, CO_T, KD, TW>), dim3((unsigned)grid), dim3(256), lds, s, a, tD, tH, tW, cgroups, ksplit);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
@@ -362,14 +405,18 @@ int launch_t(const ConvB16Args& a, int ksplit, hipStream_t s) {
 // Work decomposition of one launch: brick depth (4x8x16 bricks -- each weight fragment feeds 4 tiles per wave, halo overhead 2.1x
 // instead of 2.8x -- where they still fill the chip), output-channel tiles per workgroup, and for the low-resolution levels (a few
 // dozen bricks for 256 CUs) a split of the input channels over several workgroups (fp32 partial sums, splitk_reduce_b16_kernel).
-struct Decomp { int bd, co_t, ksplit; long bricks; };
+struct Decomp { int bd, co_t, ksplit, tw; long bricks; };
 Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout) {
     static const int forced = getenv("E3_B16_BD") ? atoi(getenv("E3_B16_BD")) : 0;
     static const bool no_split = getenv("E3_B16_NO_SPLITK") != nullptr;
+    static const int forced_tw = getenv("E3_B16_TW") ? atoi(getenv("E3_B16_TW")) : 0;
     Decomp d;
-    const long b4 = (long)N * cdiv(D, 4) * cdiv(H, 8) * cdiv(W, 16);
+    // 1 x 32-voxel tiles (conflict-free LDS reads) where the rows are long enough to fill them, 2 x 16 otherwise
+    d.tw = (forced_tw == 16 || forced_tw == 32) ? forced_tw : (W % 32 == 0 || W >= 96 ? 32 : 16);
+    const int bh = d.tw == 32 ? 4 : 8;
+    const long b4 = (long)N * cdiv(D, 4) * cdiv(H, bh) * cdiv(W, d.tw);
     d.bd = (forced == 2 || forced == 4) ? forced : (b4 >= 512 ? 4 : 2);
-    d.bricks = (long)N * cdiv(D, d.bd) * cdiv(H, 8) * cdiv(W, 16);
+    d.bricks = (long)N * cdiv(D, d.bd) * cdiv(H, bh) * cdiv(W, d.tw);
     d.co_t = (Cout % 64 == 0 && d.bricks * (Cout / 64) >= 256) ? 2 : 1;
     const long wgs = d.bricks * (Cout / (32 * d.co_t));
     const int nch = Cin / 32;
@@ -434,13 +481,12 @@ int launch_conv_b16(ConvB16Args a, hipStream_t s) {
     E3_REQUIRE(d.ksplit == 1 || a.partial, E3_ERR_INVALID, "bf16 conv: this shape needs the split-K scratch (conv_b16_partial_floats)");
     const bool two = d.co_t == 2;
     int rc;
-    if (a.planar) {
-        if (d.bd == 4) rc = two ? launch_t<4, 2, 1>(a, d.ksplit, s) : launch_t<4, 1, 1>(a, d.ksplit, s);
-        else rc = two ? launch_t<2, 2, 1>(a, d.ksplit, s) : launch_t<2, 1, 1>(a, d.ksplit, s);
-    } else {
-        if (d.bd == 4) rc = two ? launch_t<4, 2, 3>(a, d.ksplit, s) : launch_t<4, 1, 3>(a, d.ksplit, s);
-        else rc = two ? launch_t<2, 2, 3>(a, d.ksplit, s) : launch_t<2, 1, 3>(a, d.ksplit, s);
-    }
+#define E3_B16_LAUNCH(KD_, TW_)                                                                                              \
+    (d.bd == 4 ? (two ? launch_t<4, 2, KD_, TW_>(a, d.ksplit, s) : launch_t<4, 1, KD_, TW_>(a, d.ksplit, s))                 \
+               : (two ? launch_t<2, 2, KD_, TW_>(a, d.ksplit, s) : launch_t<2, 1, KD_, TW_>(a, d.ksplit, s)))
+    if (a.planar) rc = d.tw == 32 ? E3_B16_LAUNCH(1, 32) : E3_B16_LAUNCH(1, 16);
+    else rc = d.tw == 32 ? E3_B16_LAUNCH(3, 32) : E3_B16_LAUNCH(3, 16);
+#undef E3_B16_LAUNCH
     if (rc || d.ksplit == 1) return rc;
     const size_t vox = (size_t)a.N * a.D * a.H * a.W;
     hipLaunchKernelGGL(splitk_reduce_b16_kernel, dim3(reduce_blocks(vox, a.Cout)), dim3(256), 0, s, a.partial, d.ksplit, vox, a.Cout, a.bias,

@@ -48,7 +48,7 @@ __global__ void bn_relu_apply_b16_kernel(const bf16_t* __restrict__ x, int x_ldc
             const size_t i = i0 + u * stride;
             ok[u] = i < total;
             const size_t v = ok[u] ? i / Q : 0; qq[u] = ok[u] ? (int)(i - v * Q) : 0; vv[u] = v;
-            xv[u] = ld8(x + v * x_ldc + 8 * qq[u]);
+            xv[u] = ld8nt(x + v * x_ldc + 8 * qq[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -128,10 +128,11 @@ __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const BnBwdB16Args a) {
     }
     const size_t vstride = stride / Q;
     if (!POOL) {
-        for (size_t v0 = i00 / Q; active && v0 < units; v0 += 2 * vstride) {
-            f8 xv[2], g[2]; bool ok[2];
+        constexpr int U = HEAD ? 2 : 4;          // independent (x, g) pairs in flight per lane
+        for (size_t v0 = i00 / Q; active && v0 < units; v0 += U * vstride) {
+            f8 xv[U], g[U]; bool ok[U];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const size_t v = v0 + u * vstride;
                 ok[u] = v < units;
                 const size_t vs = ok[u] ? v : 0;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const BnBwdB16Args a) {
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 f8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {

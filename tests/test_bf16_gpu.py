@@ -49,7 +49,8 @@ CONV_CASES = [
     (2, 5, 11, 21, 64, 32),         # ragged edges in every dimension, two channel chunks
     (1, 6, 16, 32, 32, 64),         # two column tiles per workgroup
     (1, 3, 9, 17, 128, 64),         # few bricks: the input channels are split over workgroups (fp32 partial sums + reduce pass)
-    (2, 32, 64, 64, 32, 32),        # enough bricks for the 4x8x16-voxel decomposition
+    (2, 32, 64, 64, 32, 32),        # enough bricks for the 4-deep bricks; W % 32 == 0: 1x32-voxel tiles
+    (1, 9, 13, 100, 64, 64),        # 1x32 tiles with ragged rows (W = 100), two column tiles, odd D / H
 ]
 
 
