@@ -9,7 +9,7 @@
 //   (4 consecutive ones per register quad), which is exactly the NDHWC store pattern: bias, bf16 rounding, 8-byte stores, no
 //   transposition.  BatchNorm statistics (of the rounded values, shifted by the bias) are summed per lane and reduced through LDS.
 //
-// Workgroup = brick of BD x 8 x 16 voxels x (32 * CO_T) output channels, 4 waves; wave w owns BD tiles of 2 x 16 voxels.
+// Workgroup = brick of BD x 8 x 16 (or BD x 4 x 32) voxels x (32 * CO_T) output channels, 4 waves; a wave owns BD tiles of 32 voxels.
 // LDS image: [halo voxel][32 channels] = 64-byte rows, the four 16-byte pieces of a row XOR-swizzled by bits 2..3 of the voxel's
 // w coordinate (applied to the SOURCE address of the DMA: the LDS side of a DMA is lane-linear), so that a wave's ds_read_b128 of
 // 16 consecutive voxels covers all 64 banks; every (tile, kd, kh) is an immediate offset on one of 6 lane addresses (3 kw x 2 k-steps).
@@ -19,7 +19,6 @@
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 // (a plain function: called straight from a kernel TEMPLATE, hipcc's host pass drops the kernel's stub)
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, lds_ptr_t dst, int, unsigned voff, int, int, int) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, 0, 0, 0);
@@ -44,6 +43,13 @@ struct Geo {
     static constexpr int TAPS = KD * 9;
 };
 
+#ifdef E3_CONV_TIMING
+__device__ unsigned long long* g_timing = nullptr;       // phase timestamps (tools/conv_phases.py): [workgroup][16]
+#define E3_TICK(k) do { if (threadIdx.x == 0 && g_timing && blockIdx.x < 8192) g_timing[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define E3_TICK(k)
+#endif
+
 template <int BD, int CO_T, int KD, int TW>
 __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const ConvB16Args a, int tilesD, int tilesH, int tilesW, int cgroups, int ksplit) {
     using G = Geo<BD, KD, TW>;
@@ -52,6 +58,7 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, g = lane >> 5;
+    E3_TICK(0);
     unsigned L = xcd_remap(blockIdx.x, gridDim.x);
     const int cg = L % cgroups; L /= cgroups;
     const int ksp = L % ksplit; L /= ksplit;            // split-K: this workgroup sums the channel chunks [ch0, ch1) into partial[ksp]
@@ -130,59 +137,42 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
                 dma16(x_rs, (lds_ptr_t)(smem + wi * 1024), 16,
                                                          ((okmask >> it) & 1u) ? rel[it] + (unsigned)ch * 64u : OOB, 0, 0, 0);
         }
+        E3_TICK(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        E3_TICK(2);
         __syncthreads();
-        if constexpr (TW == 32 && CO_T == 1) {
-            // the three kw taps of a (kd, kh) pair read the same voxel row shifted by one voxel = by one LANE: two LDS reads (kw = 0 and
-            // kw = 2), the middle fragment from lane shifts (DPP wave_shl / wave_shr; VALU work is free beside bf16 MFMAs): a third fewer
-            // LDS reads -- with one output-channel tile per workgroup every fragment feeds a single MFMA and the LDS is the busiest unit
-            const bool edge = j == 31;
+        E3_TICK(3);
+        {
+            // (tap, k-step) steps; the wave's NV fragments of step s+1 are requested before the MFMAs of step s (a ds_read_b128 takes ~130
+            // cycles, the compiler's own order puts two MFMAs = 64 cycles between a read and its use: taps 10.0 -> 5.5 us per brick of the
+            // 32 -> 32 layer, tools/conv_phases.py), MFMAs tile-innermost (consecutive MFMAs never share an accumulator)
+            constexpr int NSTEP = G::TAPS * 2;
+            bf16x8 b[2][G::NV];
 #pragma unroll
-            for (int pr = 0; pr < G::TAPS / 3; ++pr) {
+            for (int t = 0; t < G::NV; ++t) b[0][t] = *reinterpret_cast<const bf16x8*>(smem + rd[0][0] + (G::RPT * t * HW) * 64);
 #pragma unroll
-                for (int q3 = 0; q3 < 3; ++q3)
-                    if (pr * 3 + q3 + RING - 3 >= RING - 1 && pr * 3 + q3 + RING - 3 < G::TAPS) { E3_LOAD_W(pr * 3 + q3 + RING - 3, (pr * 3 + q3 + RING - 3) % RING); }
-                const int kd = pr / 3, kh = pr % 3;
+            for (int st = 0; st < NSTEP; ++st) {
+                const int tap = st >> 1, ks = st & 1;
+                if (ks == 0 && tap + RING - 1 < G::TAPS) { E3_LOAD_W(tap + RING - 1, (tap + RING - 1) % RING); }
+                if (st + 1 < NSTEP) {
+                    const int tn = (st + 1) >> 1, kn = (st + 1) & 1;
+                    const int kd = tn / 9, kh = (tn / 3) % 3, kw = tn % 3;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int t = 0; t < G::NV; ++t) {
-                        const int imm = ((kd * HH + G::RPT * t + kh) * HW) * 64;
-                        const i32x4 f0 = *reinterpret_cast<const i32x4*>(smem + rd[0][ks] + imm);
-                        const i32x4 f2 = *reinterpret_cast<const i32x4*>(smem + rd[2][ks] + imm);
-                        i32x4 f1;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int up = __builtin_amdgcn_update_dpp(0, f0[e], 0x130, 0xf, 0xf, false);      // wave_shl:1  lane l <- lane l+1
-                            const int dn = __builtin_amdgcn_update_dpp(0, f2[e], 0x138, 0xf, 0xf, false);      // wave_shr:1  lane l <- lane l-1
-                            f1[e] = edge ? dn : up;
-                        }
-#pragma unroll
-                        for (int ct = 0; ct < CO_T; ++ct) {
-                            acc[ct][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(pr * 3) % RING][ct][ks], __builtin_bit_cast(bf16x8, f0), acc[ct][t], 0, 0, 0);
-                            acc[ct][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(pr * 3 + 1) % RING][ct][ks], __builtin_bit_cast(bf16x8, f1), acc[ct][t], 0, 0, 0);
-                            acc[ct][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(pr * 3 + 2) % RING][ct][ks], __builtin_bit_cast(bf16x8, f2), acc[ct][t], 0, 0, 0);
-                        }
-                    }
-            }
-        } else {
-#pragma unroll
-        for (int tap = 0; tap < G::TAPS; ++tap) {
-            if (tap + RING - 1 < G::TAPS) { E3_LOAD_W(tap + RING - 1, (tap + RING - 1) % RING); }
-            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int t = 0; t < G::NV; ++t) {
-                    const int imm = ((kd * HH + G::RPT * t + kh) * HW) * 64;
-                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + rd[kw][ks] + imm);
-#pragma unroll
-                    for (int ct = 0; ct < CO_T; ++ct)
-                        acc[ct][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap % RING][ct][ks], b, acc[ct][t], 0, 0, 0);
+                    for (int t = 0; t < G::NV; ++t)
+                        b[(st + 1) & 1][t] = *reinterpret_cast<const bf16x8*>(smem + rd[kw][kn] + ((kd * HH + G::RPT * t + kh) * HW) * 64);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = 0; ct < CO_T; ++ct)
+#pragma unroll
+                    for (int t = 0; t < G::NV; ++t)
+                        acc[ct][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap % RING][ct][ks], b[st & 1][t], acc[ct][t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        }
+        E3_TICK(4);
         __syncthreads();
+        E3_TICK(5);
 #undef E3_LOAD_W
     }
 
@@ -201,6 +191,7 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
                         *reinterpret_cast<f32x4*>(prow + 8 * q) = f32x4{acc[ct][t][4 * q], acc[ct][t][4 * q + 1], acc[ct][t][4 * q + 2], acc[ct][t][4 * q + 3]};
                 }
             }
+        E3_TICK(6);
         return;
     }
     float ssum[CO_T][16], ssq[CO_T][16];
@@ -242,7 +233,8 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
             }
         }
     }
-    if (!want_stats) return;
+    E3_TICK(6);
+    if (!want_stats) { E3_TICK(7); return; }
     // ---- statistics: S[wave][quantity][channel][33] floats in the (now free) image, column sums, (n, mean, M2) record per brick
     float* S = reinterpret_cast<float*>(smem);
     float* R = S + 4 * 2 * 32 * 33;                    // [2][4][32]
@@ -277,7 +269,9 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
             rec[0] = cnt; rec[1] = b + m; rec[2] = fmaxf(q2 - s * m, 0.f);
         }
     }
+    E3_TICK(7);
 }
+#undef E3_TICK
 
 // torch (Cout, Cin, T) fp32 -> packed bf16 [tap][chunk][k-step][Cg][2][8], Cg = GEMM rows (output channels of THIS launch)
 __global__ void pack_conv_b16_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int T, int dgrad) {
@@ -432,6 +426,10 @@ int reduce_blocks(size_t vox, int C) {
 }
 
 }  // namespace
+
+#ifdef E3_CONV_TIMING
+extern "C" int e3_debug_conv_timing(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_timing), &buf, sizeof(buf)) == hipSuccess ? 0 : 1; }
+#endif
 
 int conv_b16_stats_parts(int N, int D, int H, int W, int Cin, int Cout, int planar) {
     (void)planar;

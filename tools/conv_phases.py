@@ -1,0 +1,39 @@
+"""Phase timing inside the persistent bf16 conv kernel (debug build only):
+
+    E3_HIPCC_EXTRA=-DE3_CONV_TIMING python -c "from elektronn3_amd.build import build; build(force=True)"
+    python tools/conv_phases.py [Cin Cout]          # on the GPU box
+
+Thread 0 of every workgroup stamps s_memrealtime (100 MHz) at: start, DMA issued, DMA landed, barrier passed, taps done, barrier passed,
+stores done, statistics done.  Prints the mean duration of every phase."""
+import ctypes
+import sys
+
+import numpy as np
+import torch
+
+from elektronn3_amd import _lib, ops
+
+cin, cout = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (32, 32)
+if len(sys.argv) > 3:            # another build of the library (experiments)
+    _lib._LIB_PATH = sys.argv[3]
+    print('library', sys.argv[3])
+L = _lib.load(build_if_missing=False)
+dev = torch.device('cuda:0')
+buf = torch.zeros(8192 * 16, dtype=torch.int64, device=dev)
+fn = L.e3_debug_conv_timing
+fn.argtypes = [ctypes.c_void_p]
+assert fn(buf.data_ptr()) == 0
+x = torch.randn(2, 64, 128, 128, cin, device=dev).bfloat16()
+w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
+b = torch.randn(cout, device=dev)
+for mode in ('stats',):
+    for _ in range(3):
+        buf.zero_()
+        ops.conv3d_bf16(x, w, b, want_stats=(mode == 'stats'))
+        torch.cuda.synchronize()
+    t = buf.cpu().numpy().reshape(8192, 16).astype(np.int64)
+    used = t[:, 0] > 0
+    d = np.diff(t[:, :8], axis=1) * 10.0 / 1e3      # us
+    names = ['decode + weight prefetch + DMA issue', 'DMA wait', 'barrier', 'taps (last chunk)', 'barrier', 'stores', 'statistics']
+    print(f'{cin}->{cout} {mode}: {int(used.sum())} workgroups; per brick (us): ' + ', '.join(f'{n} {d[:, i][used].mean():.2f}' for i, n in enumerate(names))
+          + f'; total {(t[:, 7] - t[:, 0])[used].mean() * 10.0 / 1e3:.2f}; kernel span {(t[:, 7].max() - t[:, 0][used].min()) * 10.0 / 1e3:.1f} us')
