@@ -84,24 +84,50 @@ __global__ __launch_bounds__(256) void upconv_b16_kernel(const UpconvB16Args a, 
             for (int t = 0; t < NVT; ++t)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[q][t][e] = 0.f;
-        for (int ks = 0; ks < nks; ++ks) {
-            bf16x8 b[NVT];
+        // K loop, two k-steps per pass, the operands of the next pass requested before the MFMAs of this one (both operands come
+        // straight from global memory / L2: unpipelined, every k-step waited a full round trip -- 108 us for a 2 GFLOP layer)
+        constexpr int U = 2;
+        bf16x8 b[2][U][NVT], af[2][U][RT];
+        auto fetch = [&](int ks0, bf16x8 (&bb)[U][NVT], bf16x8 (&aa)[U][RT]) {
 #pragma unroll
-            for (int t = 0; t < NVT; ++t) {
-                if constexpr (!GATHER) {
-                    b[t] = vin[t] ? *reinterpret_cast<const bf16x8*>(a.x + xoff[t] + ks * 16 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                } else {
-                    const int kk = ks * 16, tap = kk / a.Cout, co = kk % a.Cout;
-                    b[t] = ((okm[t] >> tap) & 1u) ? *reinterpret_cast<const bf16x8*>(a.y + obase[t] + tapoff(tap) + co + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            for (int u = 0; u < U; ++u) {
+                const int ks = ks0 + u < nks ? ks0 + u : nks - 1;
+#pragma unroll
+                for (int t = 0; t < NVT; ++t) {
+                    if constexpr (!GATHER) {
+                        bb[u][t] = vin[t] ? *reinterpret_cast<const bf16x8*>(a.x + xoff[t] + ks * 16 + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    } else {
+                        const int kk = ks * 16, tap = kk / a.Cout, co = kk % a.Cout;
+                        bb[u][t] = ((okm[t] >> tap) & 1u) ? *reinterpret_cast<const bf16x8*>(a.y + obase[t] + tapoff(tap) + co + g * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < RT; ++q) {
+                    const int rt = rt0 + q < nrt ? rt0 + q : nrt - 1;
+                    aa[u][q] = *reinterpret_cast<const bf16x8*>(a.wt + ((size_t)rt * nks + ks) * 512 + g * 256 + j * 8);
                 }
             }
+        };
+        fetch(0, b[0], af[0]);
+        for (int ks0 = 0, par = 0; ks0 < nks; ks0 += U, par ^= 1) {
+            if (par == 0) {
+                if (ks0 + U < nks) fetch(ks0 + U, b[1], af[1]);
 #pragma unroll
-            for (int q = 0; q < RT; ++q) {
-                if (rt0 + q < nrt) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(a.wt + ((size_t)(rt0 + q) * nks + ks) * 512 + g * 256 + j * 8);
+                for (int u = 0; u < U; ++u)
+                    if (ks0 + u < nks)
 #pragma unroll
-                    for (int t = 0; t < NVT; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b[t], acc[q][t], 0, 0, 0);
-                }
+                        for (int q = 0; q < RT; ++q)
+#pragma unroll
+                            for (int t = 0; t < NVT; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][u][q], b[0][u][t], acc[q][t], 0, 0, 0);
+            } else {
+                if (ks0 + U < nks) fetch(ks0 + U, b[0], af[0]);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (ks0 + u < nks)
+#pragma unroll
+                        for (int q = 0; q < RT; ++q)
+#pragma unroll
+                            for (int t = 0; t < NVT; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][u][q], b[1][u][t], acc[q][t], 0, 0, 0);
             }
         }
         // ---- epilogue of this group of row tiles

@@ -125,15 +125,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_b16_kernel(const WgradB16Args a,
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // the fragments of k-step s+1 (one dY fragment, one X fragment per tap) are requested before the MFMAs of step s: a transposing
+        // read takes ~130 cycles, and left to the compiler every MFMA waits for its own read (lgkmcnt(0) in front of each of them)
+        bf16x8 af[2], bfr[2][TPW];
+        af[0] = tr_frag(ybase);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) bfr[0][i] = tr_frag(xt[i]);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int dd = s >> 3, hh = s & 7;
-            const bf16x8 af = tr_frag(ybase + s * 1024);
+            if (s + 1 < 16) {
+                const int dd = (s + 1) >> 3, hh = (s + 1) & 7;
+                af[(s + 1) & 1] = tr_frag(ybase + (s + 1) * 1024);
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                const bf16x8 bfr = tr_frag(xt[i] + ((dd * HH + hh) * HW) * 64);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
+                for (int i = 0; i < TPW; ++i) bfr[(s + 1) & 1][i] = tr_frag(xt[i] + ((dd * HH + hh) * HW) * 64);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1], bfr[s & 1][i], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
