@@ -106,6 +106,12 @@ int launch_bn_bwd_b16_reduce(BnBwdB16Args a, hipStream_t s);
 int launch_bn_bwd_b16_apply(BnBwdB16Args a, hipStream_t s);
 
 // first conv (Cin = in_channels < 8): x is the module's bf16 input (NDHWC == NCDHW for one channel); direct VALU conv
+// first conv with ONE input channel on the matrix cores (bf16_first.hip); same bricks, records and slab as the conv_small_* kernels
+bool conv_first_b16_supported(int Cin, int Cout, int planar);
+int launch_conv_first_b16_fwd(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int y_ldc, int N, int D, int H, int W, int Cout,
+                              const float* epi_scale, const float* epi_shift, float* stats, hipStream_t s);
+int launch_conv_first_b16_wgrad(const bf16_t* x, const bf16_t* dy, int dy_ldc, float* part, int N, int D, int H, int W, int Cout, int tiles_per_split, int splits,
+                                hipStream_t s);
 int conv_small_b16_stats_parts(int N, int D, int H, int W);
 int launch_conv_small_b16_fwd(const bf16_t* x, int Cin, const float* w /*torch (Cout,Cin,T) fp32*/, const float* bias, bf16_t* y, int y_ldc,
                               int N, int D, int H, int W, int Cout, int planar, const float* epi_scale, const float* epi_shift, float* stats, hipStream_t s);

@@ -612,6 +612,7 @@ int launch_conv_small_b16_fwd(const bf16_t* x, int Cin, const float* w, const fl
                               int N, int D, int H, int W, int Cout, int planar, const float* epi_scale, const float* epi_shift, float* stats, hipStream_t s) {
     E3_REQUIRE(Cin >= 1 && Cin < 8 && !planar, E3_ERR_UNSUPPORTED, "bf16 first conv: 1..7 input channels, 3x3x3");
     E3_REQUIRE(Cout % 4 == 0 && y_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "output channels must be a multiple of 4");
+    if (conv_first_b16_supported(Cin, Cout, planar)) return launch_conv_first_b16_fwd(x, w, bias, y, y_ldc, N, D, H, W, Cout, epi_scale, epi_shift, stats, s);
     const int tD = cdiv(D, 2), tH = cdiv(H, 8), tW = cdiv(W, 16);
     const int NV = 4 * 10 * 18;
     const int wslab = Cin * 27 * 32 > 4 * 32 * 3 ? Cin * 27 * 32 : 4 * 32 * 3;
@@ -635,6 +636,7 @@ int launch_conv_small_b16_wgrad(const bf16_t* x, int Cin, const bf16_t* dy, int 
     const int ntiles = N * tD * tH * tW;
     const int tps = small_b16_tps(ntiles);
     const int splits = cdiv(ntiles, tps);
+    if (conv_first_b16_supported(Cin, Cout, planar)) return launch_conv_first_b16_wgrad(x, dy, dy_ldc, part, N, D, H, W, Cout, tps, splits, s);
     const int NV = 4 * 10 * 18;
     const size_t lds = (size_t)(((NV + 3) & ~3) + 256 * 32) * 4;
     hipLaunchKernelGGL((conv_small_b16_wgrad_kernel<3, 2, 8>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps);
