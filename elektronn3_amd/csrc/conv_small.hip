@@ -132,7 +132,11 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const ConvSmallArgs
 // ------------------------------------------------------------------ first conv, weight gradient
 // thread = (tap slot t = tid/8 (27 of 32 used), channel quad cq = tid%8): dW[co][ci][t] partial over the voxels of
 // the bricks owned by this block.  part layout [splits][T][Cout][Cin].
-template <int KD, int TD, int TH>
+// MFMA (one input channel, 3x3x3, Cout % 32 == 0): the sum over the brick's voxels is the K of v_mfma_f32_32x32x2_f32 -- dW[co][tap] =
+// sum_v dY[v][co] * X[v + tap], A = dY^T (lane = channel, straight LDS rows), B = patches (lane = tap); wave w takes the rows 4w..4w+3 of
+// the brick, the four partial tiles meet in LDS.  The VALU form spends 2 LDS reads per 4 FMAs: ~90 us of a 180 us kernel whose traffic
+// (the fused BN backward reads the raw output and the incoming gradient) needs ~100 us.
+template <int KD, int TD, int TH, bool MFMA>
 __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __restrict__ x, int Cin, const float* __restrict__ dy, int dy_ldc,
                                                                float* __restrict__ part, int N, int D, int H, int W, int Cout,
                                                                int tilesD, int tilesH, int tilesW, int tiles_per_split, const SmallWgradFuse f) {
@@ -165,6 +169,11 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
         }
         for (int ci = 0; ci < Cin; ++ci) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x16 macc;
+            if constexpr (MFMA) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) macc[e] = 0.f;
+            }
             for (int tile = tile0; tile < tile0 + tiles_per_split && tile < ntiles; ++tile) {
                 int L = tile;
                 const int tw_ = L % tilesW; L /= tilesW; const int th_ = L % tilesH; L /= tilesH; const int td_ = L % tilesD; const int nb = L / tilesD;
@@ -178,33 +187,56 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
                         val = x[((((size_t)nb * D + gd) * H + gh) * W + gw) * Cin + ci];
                     xs[v] = val;
                 }
-                for (int idx = tid; idx < 256 * 8; idx += 256) {
-                    const int v = idx >> 3, qq = idx & 7;
-                    const int ww = v & 15, hh = (v >> 4) % TH, dd = (v >> 4) / TH;
-                    const int gd = d0 + dd, gh = h0 + hh, gw = w0 + ww;
-                    f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                    if (gd < D && gh < H && gw < W && pass * 32 + 4 * qq < Cout) {
-                        const size_t vox = (((size_t)nb * D + gd) * H + gh) * W + gw;
-                        const int c0 = pass * 32 + 4 * qq;
-                        if (f.x1) {
-                            const f32x4 xv = *reinterpret_cast<const f32x4*>(f.x1 + vox * f.x1_ldc + c0);
-                            const f32x4 gv = *reinterpret_cast<const f32x4*>(f.g + vox * f.g_ldc + c0);
+                // the brick of dY (or of the tensors it is computed from): all 8 (16) loads of a thread in flight before the first use
+                // (rolled, every pass of this loop waited a memory round trip: 180 -> 128 us with the MFMAs alone, -> ? with this)
+                {
+                    f32x4 xv[8], gv[8]; bool ok[8];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float z = __builtin_fmaf(xv[e], fsc[e], fsh[e]);
-                                const float dz = act_bwd(z, gv[e], fslope);
-                                const float xh = (xv[e] - fmu[e]) * fis[e];
-                                val[e] = fgi[e] * (dz - fc1[e] - xh * fc2[e]);
-                                if (ci == 0) bsum[e] += val[e];
-                            }
-                        } else {
-                            val = *reinterpret_cast<const f32x4*>(dy + vox * dy_ldc + c0);
-                        }
+                    for (int it = 0; it < 8; ++it) {
+                        const int idx = tid + 256 * it;
+                        const int v = idx >> 3, qq = idx & 7;
+                        const int ww = v & 15, hh = (v >> 4) % TH, dd = (v >> 4) / TH;
+                        const int gd = d0 + dd, gh = h0 + hh, gw = w0 + ww;
+                        ok[it] = gd < D && gh < H && gw < W && pass * 32 + 4 * qq < Cout;
+                        const size_t vox = ok[it] ? (((size_t)nb * D + gd) * H + gh) * W + gw : 0;
+                        const int c0 = ok[it] ? pass * 32 + 4 * qq : 0;
+                        if (f.x1) { xv[it] = *reinterpret_cast<const f32x4*>(f.x1 + vox * f.x1_ldc + c0); gv[it] = *reinterpret_cast<const f32x4*>(f.g + vox * f.g_ldc + c0); }
+                        else gv[it] = *reinterpret_cast<const f32x4*>(dy + vox * dy_ldc + c0);
                     }
-                    *reinterpret_cast<f32x4*>(gs + v * 32 + 4 * qq) = val;
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int idx = tid + 256 * it;
+                        const int v = idx >> 3, qq = idx & 7;
+                        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                        if (ok[it]) {
+                            if (f.x1) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float z = __builtin_fmaf(xv[it][e], fsc[e], fsh[e]);
+                                    const float dz = act_bwd(z, gv[it][e], fslope);
+                                    const float xh = (xv[it][e] - fmu[e]) * fis[e];
+                                    val[e] = fgi[e] * (dz - fc1[e] - xh * fc2[e]);
+                                    if (ci == 0) bsum[e] += val[e];
+                                }
+                            } else val = gv[it];
+                        }
+                        *reinterpret_cast<f32x4*>(gs + v * 32 + 4 * qq) = val;
+                    }
                 }
                 __syncthreads();
-                if (t < T) {
+                if constexpr (MFMA) {
+                    const int lane = tid & 63, wave = tid >> 6, jj = lane & 31, kk = lane >> 5;
+                    const int tj = jj < T ? jj : T - 1;                                  // (columns 27..31 of the tap tile are never stored)
+                    const int tofs = ((tj / 9) * LH + (tj / 3) % 3) * LW + tj % 3 + kk;
+#pragma unroll
+                    for (int rw = 0; rw < 4; ++rw) {
+                        const int row = 4 * wave + rw, dd = row / TH, hh = row % TH;     // 16 voxels of one w-row = 8 k-steps
+                        const float* xr = xs + (dd * LH + hh) * LW + tofs;
+                        const float* gr = gs + (row * 16 + kk) * 32 + jj;
+#pragma unroll
+                        for (int st = 0; st < 8; ++st) macc = __builtin_amdgcn_mfma_f32_32x32x2f32(gr[st * 64], xr[2 * st], macc, 0, 0, 0);
+                    }
+                } else if (t < T) {
 #pragma unroll 8
                     for (int v = 0; v < 256; ++v) {
                         const int ww = v & 15, hh = (v >> 4) % TH, dd = (v >> 4) / TH;
@@ -215,7 +247,17 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
                     }
                 }
             }
-            if (t < T)
+            if constexpr (MFMA) {     // lane holds column tap = lane & 31, rows co = (e&3) + 8*(e>>2) + 4*(lane>>5); the waves' tiles meet in `gs`
+                const int lane = tid & 63, wave = tid >> 6;
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 16; ++e) gs[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = macc[e];
+                __syncthreads();
+                for (int idx = tid; idx < 32 * 32; idx += 256) {
+                    const int co = idx >> 5, tap = idx & 31;
+                    if (tap < T) part[(((size_t)blockIdx.x * T + tap) * Cout + pass * 32 + co) * Cin + ci] = (gs[idx] + gs[1024 + idx]) + (gs[2048 + idx] + gs[3072 + idx]);
+                }
+            } else if (t < T)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int co = pass * 32 + 4 * cq + e;
@@ -406,8 +448,11 @@ int launch_conv_small_wgrad(const float* x, int Cin, const float* dy, int dy_ldc
     const int splits = cdiv(ntiles, tps);
     const int NV = (TD + (planar ? 0 : 2)) * (TH + 2) * 18;
     const size_t lds = (size_t)(((NV + 3) & ~3) + 256 * 32) * 4;
-    if (planar) hipLaunchKernelGGL((conv_small_wgrad_kernel<1, 1, 16>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
-    else hipLaunchKernelGGL((conv_small_wgrad_kernel<3, 2, 8>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
+    static const bool no_mfma = getenv("E3_FIRST_WGRAD_VALU") != nullptr;
+    if (planar) hipLaunchKernelGGL((conv_small_wgrad_kernel<1, 1, 16, false>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
+    else if (Cin == 1 && Cout % 32 == 0 && !no_mfma)
+        hipLaunchKernelGGL((conv_small_wgrad_kernel<3, 2, 8, true>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
+    else hipLaunchKernelGGL((conv_small_wgrad_kernel<3, 2, 8, false>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
