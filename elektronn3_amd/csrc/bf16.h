@@ -34,6 +34,11 @@ struct ConvB16Args {
     const float* epi_scale; const float* epi_shift;   // non-null: y = bf16(relu(acc * scale[co] + shift[co]))   (eval mode: folded BN)
     float* stats;                          // non-null: records [conv_b16_stats_parts][Cout][3] = (n, mean, M2) of the stored values
     float* partial;                        // scratch of conv_b16_partial_floats() floats (split-K of the low-resolution levels; may be null if 0)
+    // concat without a concat buffer, halves kept as two tensors (64-byte rows at 32 channels: a chunk of one half then reads whole
+    // rows instead of half of every 128-byte row): input channels >= x_split come from x2 (same x_ldc), output channels >= y_split go
+    // to y2 (same y_ldc).  x_split / y_split are multiples of 32; 0 = single tensor.
+    const bf16_t* x2; int x_split;
+    bf16_t* y2; int y_split;
 };
 int conv_b16_stats_parts(int N, int D, int H, int W, int Cin, int Cout, int planar);
 size_t conv_b16_partial_floats(int N, int D, int H, int W, int Cin, int Cout);
@@ -56,6 +61,7 @@ struct WgradB16Args {
     int N, D, H, W;
     int planar;
     int splits;
+    const bf16_t* x2; int x_split;         // input channels >= x_split come from x2 (same x_ldc); 0 = single tensor
 };
 int wgrad_b16_splits(int N, int D, int H, int W, int Cin, int Cout, int planar);
 int launch_wgrad_b16(WgradB16Args a, hipStream_t s);

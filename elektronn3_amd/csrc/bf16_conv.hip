@@ -85,6 +85,8 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
     // ---- staging plan: wave-piece wi = it * 4 + wave, lane -> (halo voxel, LDS piece); source piece = LDS piece ^ swizzle
     const size_t samp = (size_t)a.D * a.H * a.W * a.x_ldc;
     const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x) + (size_t)n * samp, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x2_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x2 ? a.x2 : a.x) + (size_t)n * samp, 0, 0x7fffffff, 0x00020000);
+    const int xsplit_ch = a.x2 ? a.x_split >> 5 : nch;                  // chunks [0, xsplit_ch) from x, the rest from x2
     unsigned rel[G::NIW]; unsigned okmask = 0;
 #pragma unroll
     for (int it = 0; it < G::NIW; ++it) {
@@ -134,8 +136,8 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
         for (int it = 0; it < G::NIW; ++it) {
             const int wi = it * 4 + wave;
             if (wi < G::NI)
-                dma16(x_rs, (lds_ptr_t)(smem + wi * 1024), 16,
-                                                         ((okmask >> it) & 1u) ? rel[it] + (unsigned)ch * 64u : OOB, 0, 0, 0);
+                dma16(ch < xsplit_ch ? x_rs : x2_rs, (lds_ptr_t)(smem + wi * 1024), 16,
+                                                         ((okmask >> it) & 1u) ? rel[it] + (unsigned)(ch < xsplit_ch ? ch : ch - xsplit_ch) * 64u : OOB, 0, 0, 0);
         }
         E3_TICK(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -213,7 +215,8 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
         for (int t = 0; t < G::NV; ++t) {
             const int d = d0 + dT0, h = h0 + G::RPT * (hp0 + t) + r, w = w0 + c;
             const bool valid = d < a.D && h < a.H && w < a.W;
-            bf16_t* yrow = a.y + ((((size_t)n * a.D + d) * a.H + h) * a.W + w) * a.y_ldc + co0 + ct * 32 + 4 * g;
+            const int cot = co0 + ct * 32;
+            bf16_t* yrow = (a.y2 && cot >= a.y_split ? a.y2 + (cot - a.y_split) : a.y + cot) + ((((size_t)n * a.D + d) * a.H + h) * a.W + w) * a.y_ldc + 4 * g;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 u16x4 o;
@@ -292,7 +295,7 @@ __global__ void pack_conv_b16_kernel(const float* __restrict__ w, bf16_t* __rest
 // walk the voxels with a fixed stride, fixed summation order.
 __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(const float* __restrict__ partial, int S, size_t vox, int C, const float* __restrict__ bias,
                                                                 const float* __restrict__ epi_scale, const float* __restrict__ epi_shift,
-                                                                bf16_t* __restrict__ y, int y_ldc, float* __restrict__ stats) {
+                                                                bf16_t* __restrict__ y, int y_ldc, float* __restrict__ stats, bf16_t* __restrict__ y2, int y_split) {
     __shared__ float red[2][256][8];
     const int Q = C >> 3;
     const int BT = (256 / Q) * Q;
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_b16_kernel(const float* __r
             const float dv = bf2f(o[e]) - bs[e];
             s1[e] += dv; s2[e] = __builtin_fmaf(dv, dv, s2[e]);
         }
-        *reinterpret_cast<u16x8*>(y + v * y_ldc + 8 * q) = o;
+        *reinterpret_cast<u16x8*>((y2 && 8 * q >= y_split ? y2 + (8 * q - y_split) : y + 8 * q) + v * y_ldc) = o;
         cnt += 1.f;
     }
     if (!stats) return;
@@ -474,6 +477,8 @@ int launch_pack_multi_b16(const PackB16Job* jobs, int njobs, hipStream_t s) {
 int launch_conv_b16(ConvB16Args a, hipStream_t s) {
     E3_REQUIRE(a.Cin % 32 == 0 && a.Cout % 32 == 0, E3_ERR_UNSUPPORTED, "bf16 conv: channel counts must be multiples of 32");
     E3_REQUIRE(a.x_ldc % 8 == 0 && a.y_ldc % 4 == 0, E3_ERR_INVALID, "bf16 conv: misaligned view");
+    E3_REQUIRE((!a.x2 || (a.x_split % 32 == 0 && a.x_split > 0 && a.x_split < a.Cin)) && (!a.y2 || (a.y_split % 32 == 0 && a.y_split > 0 && a.y_split < a.Cout)),
+               E3_ERR_INVALID, "bf16 conv: a two-tensor operand splits at a multiple of 32 channels");
     E3_REQUIRE((size_t)a.D * a.H * a.W * a.x_ldc < (1ull << 30), E3_ERR_UNSUPPORTED, "bf16 conv: sample larger than 2 GB");
     const Decomp d = conv_b16_decomp(a.N, a.D, a.H, a.W, a.Cin, a.Cout);
     E3_REQUIRE(d.ksplit == 1 || a.partial, E3_ERR_INVALID, "bf16 conv: this shape needs the split-K scratch (conv_b16_partial_floats)");
@@ -488,7 +493,7 @@ int launch_conv_b16(ConvB16Args a, hipStream_t s) {
     if (rc || d.ksplit == 1) return rc;
     const size_t vox = (size_t)a.N * a.D * a.H * a.W;
     hipLaunchKernelGGL(splitk_reduce_b16_kernel, dim3(reduce_blocks(vox, a.Cout)), dim3(256), 0, s, a.partial, d.ksplit, vox, a.Cout, a.bias,
-                       a.epi_scale, a.epi_shift, a.y, a.y_ldc, a.stats);
+                       a.epi_scale, a.epi_shift, a.y, a.y_ldc, a.stats, a.y2, a.y_split);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

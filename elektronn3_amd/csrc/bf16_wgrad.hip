@@ -56,6 +56,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_b16_kernel(const WgradB16Args a,
     const int ci_t = L % ci_tiles; L /= ci_tiles;
     const int co_t = L % co_tiles; const int split = L / co_tiles;
     const int ci0 = ci_t * 32, co0 = co_t * 32;
+    const bool second = a.x2 && ci0 >= a.x_split;                       // this tile's input channels live in the second tensor
+    const bf16_t* xsrc = second ? a.x2 : a.x;
+    const int cisrc = second ? ci0 - a.x_split : ci0;
     const int nbricks = a.N * tilesD * tilesH * tilesW;
     const int brick0 = split * bricks_per_split;
     const int brick1 = brick0 + bricks_per_split < nbricks ? brick0 + bricks_per_split : nbricks;
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_b16_kernel(const WgradB16Args a,
         const int v = idx >> 2, q = idx & 3;
         const int zw = v % HW, zh = (v / HW) % HH, zd = v / (HW * HH);
         xpm[it] = v < HV ? (1u << zd) | (1u << (4 + zh)) | (1u << (14 + zw)) : 0xffffffffu;
-        xrel[it] = (unsigned)((((zd * a.H + zh) * a.W + zw) * a.x_ldc + ci0) * 2 + q * 16);
+        xrel[it] = (unsigned)((((zd * a.H + zh) * a.W + zw) * a.x_ldc + cisrc) * 2 + q * 16);
     }
     unsigned gpm[4], grel[4];
 #pragma unroll
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_b16_kernel(const WgradB16Args a,
         const int d0 = td_ * 2, h0 = th_ * 8, w0 = tw_ * 16;
         const unsigned xmask = range_mask(d0 - PD, HD, a.D) | (range_mask(h0 - 1, HH, a.H) << 4) | (range_mask(w0 - 1, HW, a.W) << 14);
         const unsigned gmask = range_mask(d0, 2, a.D) | (range_mask(h0, 8, a.H) << 4) | (range_mask(w0, 16, a.W) << 14);
-        const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x) + (size_t)nb * samp_x, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xsrc) + (size_t)nb * samp_x, 0, 0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.dy) + (size_t)nb * samp_g, 0, 0x7fffffff, 0x00020000);
         const unsigned xbase = (unsigned)(((((d0 - PD) * a.H + h0 - 1) * a.W + w0 - 1) * a.x_ldc) * 2);   // wraps at the borders
         const unsigned gbase = (unsigned)((((d0 * a.H + h0) * a.W + w0) * a.dy_ldc) * 2);

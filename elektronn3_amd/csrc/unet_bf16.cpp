@@ -34,7 +34,7 @@ struct UnitB { bf16_t* raw; bf16_t* act; int act_ldc; float *mean, *invstd, *sca
 
 struct BufB {
     std::vector<UnitB> ub;
-    std::vector<bf16_t*> cat, pooled, g1, g2, dcat;
+    std::vector<bf16_t*> catA, catB, pooled, g1, g2, dcatA, dcatB;     // concat halves as separate tensors: A = transposed-conv output, B = encoder skip
     bf16_t* xin; bf16_t* wpack; bf16_t* evalA;
     float *stats, *small, *slab, *bnred, *skws;
     size_t saved_bytes, scratch_bytes;
@@ -49,10 +49,12 @@ void plan_b16(const e3_unet_plan* p, int N, int D, int H, int W, bool training, 
     ArenaB& A = training ? S : T;
     const size_t nu = p->units.size();
     B.ub.assign(nu, UnitB{});
-    B.cat.assign(nb, nullptr); B.pooled.assign(nb, nullptr); B.g1.assign(nb, nullptr); B.g2.assign(nb, nullptr); B.dcat.assign(nb, nullptr);
+    B.catA.assign(nb, nullptr); B.catB.assign(nb, nullptr); B.pooled.assign(nb, nullptr); B.g1.assign(nb, nullptr); B.g2.assign(nb, nullptr);
+    B.dcatA.assign(nb, nullptr); B.dcatB.assign(nb, nullptr);
     B.xin = p->cfg.in_channels > 1 ? A.take_h(ND.X[0].vox * p->cfg.in_channels) : nullptr;
     for (int j = 0; j + 1 < nb; ++j) {
-        B.cat[j] = A.take_h(ND.u[up_unit_of(nb, j)].out.vox * 2 * p->chan(j));
+        B.catA[j] = A.take_h(ND.u[up_unit_of(nb, j)].out.vox * p->chan(j));
+        B.catB[j] = A.take_h(ND.u[up_unit_of(nb, j)].out.vox * p->chan(j));
         B.pooled[j] = A.take_h(ND.X[j + 1].vox * p->chan(j));
     }
     for (size_t k = 0; k < nu; ++k) {
@@ -61,8 +63,8 @@ void plan_b16(const e3_unet_plan* p, int N, int D, int H, int W, bool training, 
         const size_t n = ND.u[k].out.vox * u.cout;
         b.raw = training ? A.take_h(n) : nullptr;
         const bool enc_skip = !u.is_up && u.name.compare(0, 10, "down_convs") == 0 && u.name.find("conv2") != std::string::npos && u.level < nb - 1;
-        if (enc_skip) { b.act = B.cat[u.level] ? B.cat[u.level] + u.cout : nullptr; b.act_ldc = 2 * u.cout; }
-        else if (u.is_up) { b.act = B.cat[u.level]; b.act_ldc = 2 * u.cout; }
+        if (enc_skip) { b.act = B.catB[u.level]; b.act_ldc = u.cout; }
+        else if (u.is_up) { b.act = B.catA[u.level]; b.act_ldc = u.cout; }
         else if (training && k + 1 == nu) { b.act = nullptr; b.act_ldc = u.cout; }      // the head applies BN + ReLU while loading `raw`
         else { b.act = A.take_h(n); b.act_ldc = u.cout; }
         b.mean = A.take_f(u.cout); b.invstd = A.take_f(u.cout); b.scale = A.take_f(u.cout); b.shift = A.take_f(u.cout);
@@ -111,7 +113,7 @@ void plan_b16(const e3_unet_plan* p, int N, int D, int H, int W, bool training, 
         for (int j = 0; j < nb; ++j) {
             const size_t n = ND.X[j].vox * p->chan(j);
             B.g1[j] = T.take_h(n); B.g2[j] = T.take_h(n);
-            if (j + 1 < nb) B.dcat[j] = T.take_h(2 * n);
+            if (j + 1 < nb) { B.dcatA[j] = T.take_h(n); B.dcatB[j] = T.take_h(n); }
         }
     }
     B.scratch_bytes = T.off;
@@ -192,6 +194,7 @@ int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N,
         RUN(launch_pack_multi_b16(jobs.data(), (int)jobs.size(), s));
     }
     const bf16_t* cur = (const bf16_t*)x; int cur_ldc = cfg.in_channels;
+    const bf16_t* cur2 = nullptr;                        // second half of a concatenated input (the encoder skip), or null
     if (cfg.in_channels > 1) { RUN(launch_ncdhw_to_ndhwc_b16((const bf16_t*)x, B.xin, N, cfg.in_channels, ND.X[0].vox / N, s)); cur = B.xin; }
 
     for (size_t k = 0; k < nu; ++k) {
@@ -220,6 +223,7 @@ int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N,
         } else {
             ConvB16Args a{};
             a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = b.wpk_f; a.bias = training ? P(u.p_b) : nullptr;
+            a.x2 = cur2; a.x_split = cur2 ? u.cin / 2 : 0;
             a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Cout = u.cout; a.planar = 0;
             a.epi_scale = es; a.epi_shift = eh; a.stats = training ? B.stats : nullptr; a.partial = B.skws;
             parts = conv_b16_stats_parts(N, li.D, li.H, li.W, u.cin, u.cout, 0);
@@ -237,8 +241,9 @@ int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N,
         } else if (pool_after) {
             RUN(launch_maxpool_b16(b.act, b.act_ldc, B.pooled[u.level], 2, N, lo.D, lo.H, lo.W, u.cout, s));
         }
+        cur2 = nullptr;
         if (pool_after) { cur = B.pooled[u.level]; cur_ldc = u.cout; }
-        else if (u.is_up) { cur = B.cat[u.level]; cur_ldc = 2 * u.cout; }
+        else if (u.is_up) { cur = B.catA[u.level]; cur2 = B.catB[u.level]; cur_ldc = u.cout; }
         else { cur = b.act; cur_ldc = b.act_ldc; }
     }
     {
@@ -314,7 +319,7 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
             BnBwdB16Args a{};
             a.x = b.raw; a.x_ldc = u.cout; a.mean = b.mean; a.invstd = b.invstd; a.gamma = P(u.p_g); a.scale = b.scale; a.shift = b.shift;
             if (k == nunits - 1) { a.g1 = nullptr; a.head_dy = dy; a.head_w = P(plan->p_final_w); a.head_cout = cfg.out_channels; a.head_S = ND.Y.vox / N; }
-            else if (pooled_unit) { a.g1 = B.dcat[j] + u.cout; a.g1_ldc = 2 * u.cout; a.gpool = g; a.pooled = B.pooled[j]; }
+            else if (pooled_unit) { a.g1 = B.dcatB[j]; a.g1_ldc = u.cout; a.gpool = g; a.pooled = B.pooled[j]; }
             else { a.g1 = g; a.g1_ldc = g_ldc; }
             a.kd = 2; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.C = u.cout;
             a.parts = bn_bwd_b16_parts(lo.vox, u.cout); a.part = b.bnpart; a.coef = B.small; a.dx = dxr; a.dx_ldc = u.cout;
@@ -324,15 +329,15 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
             bias_jobs.push_back({a.part, a.parts, 3 * u.cout, 2 * u.cout, u.cout, G(u.p_b)});
         }
         // ---- input activation of this conv
-        const bf16_t* xin; int xin_ldc;
+        const bf16_t* xin; int xin_ldc; const bf16_t* xin2 = nullptr;
         if (k == 0) { xin = cfg.in_channels > 1 ? B.xin : (const bf16_t*)x; xin_ldc = cfg.in_channels; }
         else {
             const ConvUnit& pu = plan->units[k - 1];
             const bool prev_pooled = pu.name.compare(0, 10, "down_convs") == 0 && pu.name.find("conv2") != std::string::npos && pu.level < nb - 1 && is_down;
             if (prev_pooled) { xin = B.pooled[pu.level]; xin_ldc = pu.cout; }
-            else if (pu.is_up) { xin = B.cat[pu.level]; xin_ldc = 2 * pu.cout; }
+            else if (pu.is_up) { xin = B.catA[pu.level]; xin2 = B.catB[pu.level]; xin_ldc = pu.cout; }
             else { xin = B.ub[k - 1].act; xin_ldc = B.ub[k - 1].act_ldc; }
-            if (u.is_up) { xin = B.ub[k - 1].act; xin_ldc = B.ub[k - 1].act_ldc; }
+            if (u.is_up) { xin = B.ub[k - 1].act; xin_ldc = B.ub[k - 1].act_ldc; xin2 = nullptr; }
         }
         // ---- weight gradient
         if (u.is_up) {
@@ -347,6 +352,7 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
         } else {
             WgradB16Args a{};
             a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dxr; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = b.slab;
+            a.x2 = xin2; a.x_split = xin2 ? u.cin / 2 : 0;
             a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.planar = 0;
             a.splits = wgrad_b16_splits(N, li.D, li.H, li.W, u.cin, u.cout, 0);
             { ProfB pr(plan, s, k, 2); RUN(launch_wgrad_b16(a, s)); }
@@ -362,12 +368,13 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
             g = B.g1[j + 1]; g_ldc = u.cin;
         } else {
             const bool to_cat = !is_down && u.name.find("conv1") != std::string::npos;     // UpConv.conv1: gradient of the concat buffer
-            bf16_t* out = to_cat ? B.dcat[j] : B.g1[j];
+            bf16_t* out = to_cat ? B.dcatA[j] : B.g1[j];
             ConvB16Args a{};
-            a.x = dxr; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = b.wpk_d; a.bias = nullptr; a.y = out; a.y_ldc = u.cin;
+            a.x = dxr; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = b.wpk_d; a.bias = nullptr; a.y = out; a.y_ldc = to_cat ? u.cin / 2 : u.cin;
+            if (to_cat) { a.y2 = B.dcatB[j]; a.y_split = u.cin / 2; }
             a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Cout = u.cin; a.planar = 0; a.partial = B.skws;
             { ProfB pr(plan, s, k, 1); RUN(launch_conv_b16(a, s)); }
-            g = out; g_ldc = to_cat ? 2 * u.cout : u.cin;     // concat: the next unit (upconv) reads the first half, ldc = 2C
+            g = out; g_ldc = to_cat ? u.cin / 2 : u.cin;      // concat: the next unit (upconv) reads the first half
         }
     }
     if (!bias_jobs.empty()) RUN(launch_colsum_multi(bias_jobs.data(), (int)bias_jobs.size(), s));
