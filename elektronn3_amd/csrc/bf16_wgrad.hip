@@ -40,6 +40,13 @@ __device__ __forceinline__ unsigned range_mask(int lo, int n, int size) {      /
     return last > first ? (unsigned)(((1ull << last) - 1ull) & ~((1ull << first) - 1ull)) : 0u;
 }
 
+#ifdef E3_CONV_TIMING
+__device__ unsigned long long* g_wtiming = nullptr;      // phase timestamps (tools/conv_phases.py --wgrad): [workgroup][brick < 8][4]
+#define E3_WTICK(k) do { if (threadIdx.x == 0 && g_wtiming && brick - brick0 < 8 && blockIdx.x < 1024) g_wtiming[((size_t)blockIdx.x * 8 + (brick - brick0)) * 4 + (k)] = wall_clock64(); } while (0)
+#else
+#define E3_WTICK(k)
+#endif
+
 template <int KD>
 __global__ __launch_bounds__(256, 2) void wgrad_b16_kernel(const WgradB16Args a, int tilesD, int tilesH, int tilesW, int bricks_per_split,
                                                            int co_tiles, int ci_tiles) {
@@ -104,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_b16_kernel(const WgradB16Args a,
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
     for (int brick = brick0; brick < brick1; ++brick) {
+        E3_WTICK(0);
         int Lt = brick;
         const int tw_ = Lt % tilesW; Lt /= tilesW; const int th_ = Lt % tilesH; Lt /= tilesH; const int td_ = Lt % tilesD; const int nb = Lt / tilesD;
         const int d0 = td_ * 2, h0 = th_ * 8, w0 = tw_ * 16;
@@ -126,8 +134,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_b16_kernel(const WgradB16Args a,
             const bool ok = (gmask & gpm[it]) == gpm[it];
             dma16(g_rs, (lds_ptr_t)(smem + XIMG + (it * 4 + wave) * 1024), 16, ok ? grel[it] + gbase : OOB, 0, 0, 0);
         }
+        E3_WTICK(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        E3_WTICK(2);
         // the fragments of k-step s+1 (one dY fragment, one X fragment per tap) are requested before the MFMAs of step s: a transposing
         // read takes ~130 cycles, and left to the compiler every MFMA waits for its own read (lgkmcnt(0) in front of each of them)
         bf16x8 af[2], bfr[2][TPW];
@@ -147,6 +157,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_b16_kernel(const WgradB16Args a,
             for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1], bfr[s & 1][i], acc[i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        E3_WTICK(3);
         __syncthreads();
     }
     // ---- slab: part[split][tap][CoPad][CiPad]; lane holds column ci = lane & 31, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -162,6 +173,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_b16_kernel(const WgradB16Args a,
 }
 
 }  // namespace
+
+#ifdef E3_CONV_TIMING
+extern "C" int e3_debug_wgrad_timing(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_wtiming), &buf, sizeof(buf)) == hipSuccess ? 0 : 1; }
+#endif
 
 int wgrad_b16_splits(int N, int D, int H, int W, int Cin, int Cout, int planar) {
     (void)planar;

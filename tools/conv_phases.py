@@ -37,3 +37,20 @@ for mode in ('stats',):
     names = ['decode + weight prefetch + DMA issue', 'DMA wait', 'barrier', 'taps (last chunk)', 'barrier', 'stores', 'statistics']
     print(f'{cin}->{cout} {mode}: {int(used.sum())} workgroups; per brick (us): ' + ', '.join(f'{n} {d[:, i][used].mean():.2f}' for i, n in enumerate(names))
           + f'; total {(t[:, 7] - t[:, 0])[used].mean() * 10.0 / 1e3:.2f}; kernel span {(t[:, 7].max() - t[:, 0][used].min()) * 10.0 / 1e3:.1f} us')
+
+# ---- weight gradient (same debug build): python tools/conv_phases.py 32 32  prints this after the forward's phases
+fnw = getattr(L, 'e3_debug_wgrad_timing', None)
+if fnw is not None:
+    fnw.argtypes = [ctypes.c_void_p]
+    wbuf = torch.zeros(1024 * 8 * 4, dtype=torch.int64, device=dev)
+    assert fnw(wbuf.data_ptr()) == 0
+    dy = torch.randn(2, 64, 128, 128, cout, device=dev).bfloat16()
+    for _ in range(3):
+        wbuf.zero_()
+        ops.conv3d_wgrad_bf16(x, dy)
+        torch.cuda.synchronize()
+    t = wbuf.cpu().numpy().reshape(1024, 8, 4).astype(np.int64)
+    used = t[:, :, 0] > 0
+    d = np.diff(t, axis=2) * 10.0 / 1e3
+    print(f'wgrad {cin}->{cout}: {int(used.sum())} bricks timed; per brick (us): decode + DMA issue {d[:, :, 0][used].mean():.2f}, DMA wait + barrier {d[:, :, 1][used].mean():.2f}, '
+          f'MFMA loop {d[:, :, 2][used].mean():.2f}; brick to brick {np.diff(t[:, :, 0], axis=1)[used[:, 1:] & used[:, :-1]].mean() * 10.0 / 1e3:.2f}')
