@@ -14,6 +14,7 @@
 // w coordinate (applied to the SOURCE address of the DMA: the LDS side of a DMA is lane-linear), so that a wave's ds_read_b128 of
 // 16 consecutive voxels covers all 64 banks; every (tile, kd, kh) is an immediate offset on one of 6 lane addresses (3 kw x 2 k-steps).
 // One LDS buffer per workgroup, 2-3 workgroups per CU: one workgroup's staging overlaps the others' MFMA phases.
+// Channels of the input may come from two tensors (x2 / x_split) and go to two (y2 / y_split): the halves of a U-Net concatenation.
 #include "bf16.h"
 
 namespace {
