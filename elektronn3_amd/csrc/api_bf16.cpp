@@ -8,6 +8,7 @@ extern "C" {
 
 size_t e3_conv3d_workspace_bytes_bf16(int Cin, int Cout, int N, int D, int H, int W, int planar) {
     const int T = planar ? 9 : 27;
+    if (Cin < 8) return align_up((size_t)conv_small_b16_wgrad_splits(N, D, H, W) * T * Cout * Cin * 4 + 256, 256);      // first conv: only the wgrad slab
     const size_t pack = align_up(conv_b16_packed_elems(Cin, Cout, planar) * 2, 256);
     const size_t slab = Cin % 32 == 0 && Cout % 32 == 0 ? (size_t)wgrad_b16_splits(N, D, H, W, Cin, Cout, planar) * T * Cin * Cout * 4 : 0;
     // forward / dgrad: packed weights, then (low-resolution shapes) the split-K partial sums of either direction
@@ -16,7 +17,9 @@ size_t e3_conv3d_workspace_bytes_bf16(int Cin, int Cout, int N, int D, int H, in
     return fwd > slab ? fwd : align_up(slab, 256);
 }
 
-int e3_conv3d_stats_parts_bf16(int Cin, int Cout, int N, int D, int H, int W, int planar) { return conv_b16_stats_parts(N, D, H, W, Cin, Cout, planar); }
+int e3_conv3d_stats_parts_bf16(int Cin, int Cout, int N, int D, int H, int W, int planar) {
+    return Cin < 8 ? conv_small_b16_stats_parts(N, D, H, W) : conv_b16_stats_parts(N, D, H, W, Cin, Cout, planar);
+}
 
 int e3_conv3d_fwd_bf16(void* stream, const void* x, int x_ldc, int Cin, const float* w, const float* bias, void* y, int y_ldc, int Cout,
                        int N, int D, int H, int W, int planar, const float* epi_scale, const float* epi_shift, float* stats,
@@ -24,6 +27,8 @@ int e3_conv3d_fwd_bf16(void* stream, const void* x, int x_ldc, int Cin, const fl
     hipStream_t s = (hipStream_t)stream;
     E3_REQUIRE(x && w && y && workspace, E3_ERR_INVALID, "null argument");
     E3_REQUIRE(workspace_bytes >= e3_conv3d_workspace_bytes_bf16(Cin, Cout, N, D, H, W, planar), E3_ERR_WORKSPACE, "conv3d bf16 workspace too small");
+    if (Cin < 8)        // the network's first conv (x dense [voxel][Cin]): matrix-core kernel for one input channel, VALU kernel otherwise
+        return launch_conv_small_b16_fwd((const bf16_t*)x, Cin, w, epi_scale ? nullptr : bias, (bf16_t*)y, y_ldc, N, D, H, W, Cout, planar, epi_scale, epi_shift, stats, s);
     int rc = launch_pack_conv_b16(w, (bf16_t*)workspace, Cout, Cin, planar, 0, s);
     if (rc) return rc;
     ConvB16Args a{};
@@ -52,8 +57,15 @@ int e3_conv3d_wgrad_bf16(void* stream, const void* x, int x_ldc, int Cin, const 
                          int N, int D, int H, int W, int planar, void* workspace, size_t workspace_bytes) {
     hipStream_t s = (hipStream_t)stream;
     E3_REQUIRE(x && dy && dw && workspace, E3_ERR_INVALID, "null argument");
-    E3_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, E3_ERR_UNSUPPORTED, "bf16 wgrad: channel counts must be multiples of 32");
     const int T = planar ? 9 : 27;
+    if (Cin < 8) {
+        const int splits = conv_small_b16_wgrad_splits(N, D, H, W);
+        E3_REQUIRE(workspace_bytes >= (size_t)splits * T * Cout * Cin * 4, E3_ERR_WORKSPACE, "wgrad bf16 workspace too small");
+        int rc1 = launch_conv_small_b16_wgrad((const bf16_t*)x, Cin, (const bf16_t*)dy, dy_ldc, (float*)workspace, N, D, H, W, Cout, planar, s);
+        if (rc1) return rc1;
+        return launch_wgrad_reduce((float*)workspace, dw, splits, T, Cout, Cin, Cout, Cin, s);
+    }
+    E3_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, E3_ERR_UNSUPPORTED, "bf16 wgrad: channel counts must be multiples of 32");
     WgradB16Args a{};
     a.x = (const bf16_t*)x; a.x_ldc = x_ldc; a.Cin = Cin; a.dy = (const bf16_t*)dy; a.dy_ldc = dy_ldc; a.Cout = Cout; a.part = (float*)workspace;
     a.N = N; a.D = D; a.H = H; a.W = W; a.planar = planar;

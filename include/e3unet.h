@@ -269,7 +269,8 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
                           void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
                           void* bucket_event, int bucket_after_down_block);
 /* Per-op entry points of the bf16 path (unit parity tests): bf16 NDHWC views, fp32 torch-layout weights / weight gradients.
- *   e3_conv3d_*_bf16    nn.Conv3d k=3 (planar: (1,3,3)), stride 1, padding 1            [unet.py:131-149]; Cin, Cout multiples of 32
+ *   e3_conv3d_*_bf16    nn.Conv3d k=3 (planar: (1,3,3)), stride 1, padding 1            [unet.py:131-149]; Cin, Cout multiples of 32, or -- the
+ *                       network's first conv, fwd / wgrad only -- Cin < 8 with a dense [voxel][Cin] input (x_ldc = Cin), 3x3x3, Cout % 4 == 0
  *   e3_convT_*_bf16     nn.ConvTranspose3d k = s = 2 with the autocrop box (Do,Ho,Wo)   [unet.py:152-165,289-299]
  * stats: NULL or e3_*_stats_parts_bf16() records of (count, mean, M2) per channel of the stored (rounded) output. */
 size_t e3_conv3d_workspace_bytes_bf16(int Cin, int Cout, int N, int D, int H, int W, int planar);

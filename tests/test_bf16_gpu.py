@@ -92,6 +92,38 @@ def test_conv3d_bf16_forward_dgrad_wgrad_vs_fp64(N, D, H, W, Cin, Cout):
     assert rel < 2e-6, f'conv wgrad rel-L2 {rel}'
 
 
+@pytest.mark.parametrize('N,D,H,W,Cin,Cout', [(1, 4, 8, 16, 1, 32), (2, 5, 11, 21, 1, 32), (2, 16, 32, 32, 1, 64), (1, 6, 9, 17, 3, 32)])
+def test_first_conv_bf16_forward_and_wgrad_vs_fp64(N, D, H, W, Cin, Cout):
+    """The network's first conv (few input channels, dense [voxel][Cin] input): one input channel runs on the matrix cores (taps as the
+    GEMM-K of the forward, voxels as the K of the weight gradient: bf16_first.hip), 2..7 channels on the VALU kernels; same C entry points."""
+    from elektronn3_amd import ops
+    x = _bfvals(N, Cin, D, H, W, seed=11)
+    w = _bfvals(Cout, Cin, 3, 3, 3, seed=12, scale=0.2)
+    b = torch.randn(Cout, generator=torch.Generator().manual_seed(13))
+    dy = _bfvals(N, Cout, D, H, W, seed=14)
+    xd, wd, dyd = x.to(DEV), w.to(DEV), dy.to(DEV)
+    y, stats = ops.conv3d_bf16(_ndhwc(xd), wd.float(), b.to(DEV), want_stats=True)
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), b.double(), padding=1)
+    _close_bf16(_ncdhw(y), ref, 'first conv forward')
+    st = stats.double().cpu()
+    n = st[:, :, 0].sum(0); mean = (st[:, :, 0] * st[:, :, 1]).sum(0) / n
+    m2 = (st[:, :, 2] + st[:, :, 0] * (st[:, :, 1] - mean) ** 2).sum(0)
+    yv = _ncdhw(y).double().cpu()
+    assert float(n.min()) == float(n.max()) == N * D * H * W
+    torch.testing.assert_close(mean, yv.mean((0, 2, 3, 4)), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(m2 / n, yv.var((0, 2, 3, 4), unbiased=False), rtol=2e-3, atol=1e-5)
+    sc = torch.rand(Cout, generator=torch.Generator().manual_seed(15)) + 0.5
+    sh = torch.randn(Cout, generator=torch.Generator().manual_seed(16))
+    ye = ops.conv3d_bf16(_ndhwc(xd), wd.float(), None, epi=(sc.to(DEV), sh.to(DEV)))
+    acc = torch.nn.functional.conv3d(x.double(), w.double(), None, padding=1)
+    refe = torch.relu(acc * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1))
+    _close_bf16(_ncdhw(ye), refe, 'first conv eval epilogue', atol=2e-2 * 2.0 ** -8 * float(acc.abs().max()) + 1e-6)
+    dw = ops.conv3d_wgrad_bf16(_ndhwc(xd), _ndhwc(dyd))
+    refdw = torch.nn.grad.conv3d_weight(x.double(), w.shape, dy.double(), padding=1)
+    rel = float((dw.double().cpu() - refdw).norm() / refdw.norm())
+    assert rel < 2e-6, f'first conv wgrad rel-L2 {rel}'
+
+
 def test_conv3d_bf16_reads_and_writes_concat_views():
     """(ptr, ldc) views: the conv reads one half of a concat buffer and writes into a half of another (torch.cat never runs)."""
     from elektronn3_amd import ops
