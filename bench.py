@@ -69,10 +69,11 @@ def cpu_baseline(iters=3):
             's_per_step': dt}
 
 
-def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_parallel=False):
+def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_parallel=False, bf16=False):
     """BASELINE.json's second metric ("Predictor MVox/s", configs[4]): tile 96x192x192, overlap 16, eval-mode UNet(n_blocks=4,
     start_filts=32), softmax output, fp32 volume in HOST memory, result back in host memory.  Input voxels / predict() wall time
-    incl. H2D and D2H (benchmark/pred_benchmark.py:101)."""
+    incl. H2D and D2H (benchmark/pred_benchmark.py:101).  bf16 (`--dtype bf16`): the module is cast with model.to(torch.bfloat16) after its
+    running statistics are set -- the bf16 counterpart of pred_benchmark.py's float16 switch: bf16 tiles, native bf16 kernels, bf16 result volume."""
     from elektronn3_amd.inference import Predictor
     from elektronn3_amd.unet import UNet
     torch.manual_seed(0)
@@ -81,6 +82,8 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
     with torch.no_grad():                    # running statistics from 10 warm-up batches (SURVEY 8d cfg 5)
         for _ in range(10):
             model(torch.randn(2, 1, 32, 64, 64, device=dev))
+    if bf16:
+        model = model.to(torch.bfloat16)
     vol = torch.empty(1, 1, *shape)
     gen = torch.Generator().manual_seed(0)
     for z in range(0, shape[0], 32):         # per-slab generation
@@ -98,11 +101,13 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
     tile_in = [t + 2 * o for t, o in zip(tile, overlap)]
     tile_flop = 427.2e3 * tile_in[0] * tile_in[1] * tile_in[2]            # forward FLOP per tile incl. halo (2744 GFLOP)
     return {'metric': 'Predictor MVox/s', 'value': vol.numel() / dt / 1e6, 'unit': 'MVox/s (input voxels / predict() wall time incl. H2D + D2H)',
-            'seconds': dt, 'volume': list(shape), 'tile': list(tile), 'overlap': list(overlap), 'tiles': ntiles, 'dtype': 'f32',
-            'finite': bool(torch.isfinite(out[..., ::32, ::32]).all()),
+            'seconds': dt, 'volume': list(shape), 'tile': list(tile), 'overlap': list(overlap), 'tiles': ntiles, 'dtype': 'bf16' if bf16 else 'f32',
+            'out_dtype': str(out.dtype).replace('torch.', ''),
+            'finite': bool(torch.isfinite(out[..., ::32, ::32].float()).all()),
             'algorithmic_tflops': ntiles * tile_flop / dt / 1e12,
-            'mfma_executed_frac': ntiles * tile_flop * (64.0 / 216.0) / dt / 1e12 / MFMA_PEAK_TFLOPS['f32'],
-            'note': 'executed fraction = Winograd-executed matrix FLOP (64/216 of the algorithmic count) / wall time incl. PCIe / fp32 MFMA peak'}
+            'mfma_executed_frac': ntiles * tile_flop * (1.0 if bf16 else 64.0 / 216.0) / dt / 1e12 / MFMA_PEAK_TFLOPS['bf16' if bf16 else 'f32'],
+            'note': ('executed fraction = matrix FLOP of the direct bf16 convs (= the algorithmic count) / wall time incl. PCIe / dense bf16 MFMA peak' if bf16 else
+                     'executed fraction = Winograd-executed matrix FLOP (64/216 of the algorithmic count) / wall time incl. PCIe / fp32 MFMA peak')}
 
 
 def respawn_under_launcher(args):
@@ -301,7 +306,7 @@ def main():
             watchdog.daemon = True
             watchdog.start()
         try:
-            p = predictor_leg(dev, shape, tile_parallel=world > 1)
+            p = predictor_leg(dev, shape, tile_parallel=world > 1, bf16=(args.dtype == 'bf16'))
             if rank == 0:
                 if world > 1:
                     p.update(n_gpus=world, parallelism=f'tile-parallel over {world} ranks, shared-memory output')

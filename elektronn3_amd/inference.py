@@ -308,6 +308,13 @@ class Predictor:
         weights = _resolve_state_dict(state_dict_src)
         if weights is not None:
             set_state_dict(net, weights)
+        # a module that already lives in bfloat16 (model.to(torch.bfloat16), BASELINE cfg 3's storage type) gets bfloat16 tiles: the
+        # reference would feed it fp32 tiles and fail in the first conv; here it selects the native bf16 kernels (the bf16 counterpart of
+        # float16=True).  Outputs default to bfloat16 like float16=True defaults to float16; pass out_dtype=torch.float32 for fp32 volumes.
+        if not float16 and isinstance(net, nn.Module):
+            p0 = next(net.parameters(), None)
+            if p0 is not None and p0.dtype == torch.bfloat16:
+                self.dtype = torch.bfloat16
 
         # ---- output stages.  Native UNet: softmax inside the last kernel, the rest as a small post-module; any other module is wrapped
         # the way the reference wraps it
@@ -430,7 +437,7 @@ class Predictor:
         padded = (np.ceil(real / tile) * tile).astype(np.int64)           # spatial shape the tile loop works on
         ntz, nty, ntx = (int(v) for v in padded // tile)
         if self.out_dtype is None:
-            self.out_dtype = torch.uint8 if self.argmax_with_threshold is not None else inp.dtype
+            self.out_dtype = torch.uint8 if self.argmax_with_threshold is not None else self.dtype      # (inp is cast to the compute dtype first, inference.py:606-614)
         inp_padded = torch.zeros((N, Cin, *(int(v) for v in padded + 2 * ov)), dtype=self.dtype, device=dev)
         crop = _extend_nc([slice(int(l), int(h)) for l, h in zip(ov, tile + ov)])
         plan = tile_plan(padded, tile, ov)

@@ -304,3 +304,34 @@ def test_predictor_valid_conv_model_offset_path():
     # offset=None: estimated by a probe forward, like the reference does for unknown models
     y2 = Predictor(m, device='cuda', tile_shape=tuple(tile), offset=None, out_shape=(2, *S), apply_softmax=True).predict(vol)
     assert torch.equal(y2, y)
+
+
+@pytest.mark.gpu
+def test_predictor_bf16_module_runs_the_native_bf16_kernels_and_tracks_fp32():
+    """A module that lives in bfloat16 (model.to(torch.bfloat16): the bf16 counterpart of Predictor(float16=True), inference.py:445-446) gets
+    bfloat16 tiles, i.e. the native bf16 eval path (BN folded into the conv epilogues, softmax fused into the head); the tiled softmax volume
+    stays within bf16 accumulation noise of the fp32 Predictor's and the default result dtype is the compute dtype."""
+    import copy
+    from elektronn3_amd.inference import Predictor
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(3)
+    m = UNet(1, 2, n_blocks=3, start_filts=32).to('cuda:0')
+    m.train()
+    with torch.no_grad():
+        for _ in range(3):
+            m(torch.randn(2, 1, 16, 32, 32, device='cuda:0'))
+    m.eval()
+    vol = torch.randn(1, 1, 40, 72, 88)
+    kw = dict(device='cuda:0', tile_shape=(16, 32, 32), overlap_shape=(8, 8, 8), out_shape=(2, 40, 72, 88), apply_softmax=True, strict_shapes=False)
+    y32 = Predictor(m, **kw).predict(vol)
+    mb = copy.deepcopy(m).to(torch.bfloat16)
+    pb = Predictor(mb, **kw)
+    assert pb.dtype == torch.bfloat16
+    yb = pb.predict(vol)
+    assert yb.dtype == torch.bfloat16 and tuple(yb.shape) == tuple(y32.shape)
+    err = (yb.float() - y32.float()).abs()
+    assert float(err.max()) < 4e-2 and float(err.mean()) < 4e-3, (float(err.max()), float(err.mean()))
+    yf = Predictor(mb, out_dtype=torch.float32, **kw).predict(vol)
+    assert yf.dtype == torch.float32 and float((yf - yb.float()).abs().max()) < 8e-3
+    # the fp32 module is untouched and a float16 request still takes the reference's half-precision path
+    assert next(m.parameters()).dtype == torch.float32
