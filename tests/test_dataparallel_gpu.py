@@ -24,17 +24,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _make(seed=0):
+def _make(seed=0, bf16=False):
     from elektronn3_amd.unet import UNet
     torch.manual_seed(seed)
-    m = UNet(1, 2, n_blocks=3, start_filts=16)
+    m = UNet(1, 2, n_blocks=3, start_filts=32 if bf16 else 16)        # (the native bf16 kernels need multiples of 32 channels)
     with torch.no_grad():
         for n, p in m.named_parameters():
             if 'norm' in n and n.endswith('weight'):
                 p.copy_(1 + 0.2 * torch.randn_like(p))
             elif n.endswith('bias'):
                 p.copy_(0.1 * torch.randn_like(p))
-    return m
+    return m.to(torch.bfloat16) if bf16 else m
 
 
 def _batch():
@@ -44,7 +44,7 @@ def _batch():
     return x, t
 
 
-def _worker(rank, world, port, backend, tmp):
+def _worker(rank, world, port, backend, tmp, bf16=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -55,37 +55,39 @@ def _worker(rank, world, port, backend, tmp):
     try:
         from elektronn3_amd.dataparallel import GradSync, shard_batch
         from elektronn3_amd.loss import CombinedCEDiceLoss
-        model = _make().to(dev).train()
+        model = _make(bf16=bf16).to(dev).train()
         sync = GradSync(model, bucket_after_down_block=2)
         crit = CombinedCEDiceLoss(weight=CW, global_batch=True).to(dev)
         x, t = _batch()
         xr, tr = shard_batch(x, rank, world).to(dev), shard_batch(t, rank, world).to(dev)
+        if bf16:
+            xr = xr.to(torch.bfloat16)
         for step in range(2):                 # twice: the second backward must not be disturbed by the first one's buffers
             model.zero_grad(set_to_none=True)
             loss = crit(model(xr), tr)
             loss.backward()
             sync.wait()
         torch.cuda.synchronize()
-        torch.save({'loss': float(loss), 'grads': {k: p.grad.cpu() for k, p in model.named_parameters()}}, os.path.join(tmp, f'dp{rank}.pt'))
+        torch.save({'loss': float(loss), 'grads': {k: p.grad.float().cpu() for k, p in model.named_parameters()}}, os.path.join(tmp, f'dp{rank}.pt'))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def _reference():
+def _reference(bf16=False):
     """One process, both shards through the same replica (per-shard BatchNorm statistics), ONE loss over the gathered logits."""
     from elektronn3_amd.loss import CombinedCEDiceLoss
     dev = torch.device('cuda', 0)
-    model = _make().to(dev).train()
+    model = _make(bf16=bf16).to(dev).train()
     crit = CombinedCEDiceLoss(weight=CW).to(dev)
     x, t = _batch()
     for step in range(2):
         model.zero_grad(set_to_none=True)
-        outs = [model(x[r * 2:(r + 1) * 2].to(dev)) for r in range(2)]
+        outs = [model(x[r * 2:(r + 1) * 2].to(dev).to(torch.bfloat16 if bf16 else torch.float32)) for r in range(2)]
         loss = crit(torch.cat(outs, 0), t.to(dev))
         loss.backward()
     torch.cuda.synchronize()
-    return float(loss), {k: p.grad.cpu() for k, p in model.named_parameters()}
+    return float(loss), {k: p.grad.float().cpu() for k, p in model.named_parameters()}
 
 
 @pytest.mark.parametrize('backend', ['gloo', 'nccl'])
@@ -106,3 +108,22 @@ def test_two_rank_train_step_equals_gathered_batch(backend, tmp_path):
     # every rank holds the same averaged gradients
     for k in g_ref:
         assert torch.allclose(res[0]['grads'][k], res[1]['grads'][k], rtol=0, atol=1e-6 * gscale), k
+
+
+def test_two_rank_train_step_bf16_module(tmp_path):
+    """BASELINE configs[2]'s combination: a bfloat16 module (native bf16 kernels) under GradSync.  The native backward hands fp32 parameter
+    gradients to the buckets, the all-reduce averages them in fp32 and each parameter's .grad is rounded to bf16 once; the one-process
+    reference accumulates the two shards' bf16 gradients in bf16, so the comparison is at bf16 resolution."""
+    world = 2
+    backend = 'nccl' if torch.cuda.device_count() >= 2 else 'gloo'
+    mp.spawn(_worker, args=(world, _free_port(), backend, str(tmp_path), True), nprocs=world, join=True)
+    loss_ref, g_ref = _reference(bf16=True)
+    res = [torch.load(tmp_path / f'dp{r}.pt') for r in range(world)]
+    gscale = max(float(g.norm()) for g in g_ref.values())
+    for r in range(world):
+        assert abs(res[r]['loss'] - loss_ref) < 2e-3 * max(1.0, abs(loss_ref)), (r, res[r]['loss'], loss_ref)
+        for k, g in g_ref.items():
+            err = float((res[r]['grads'][k] - g).norm()) / max(float(g.norm()), 1e-3 * gscale)
+            assert err < 2e-2, (r, k, err)
+    for k in g_ref:
+        assert torch.equal(res[0]['grads'][k], res[1]['grads'][k]), k        # identical replicas after the all-reduce
