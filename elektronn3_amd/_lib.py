@@ -102,6 +102,8 @@ _SIG = {
     'e3_adamw_state_offset': (c_size_t, [_I, POINTER(c_int64), _I]),
     'e3_adamw_step': (_I, [_P, _I, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), _P, _P, _P, _P,
                            c_double, c_double, c_double, c_double, c_double, _P, _P]),
+    'e3_adamw_step_bf16': (_I, [_P, _I, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), _P, _P, _P, _P,
+                                c_double, c_double, c_double, c_double, c_double, _P, _P]),
     'e3_ncdhw_to_ndhwc': (_I, [_P, _P, _P, _I, _I, _I, _I, _I]),
     'e3_ndhwc_to_ncdhw': (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I]),
 }

@@ -272,6 +272,18 @@ int e3_adamw_step(void* stream, int n_tensors, void* const* params, void* const*
                         grad_scale, found_inf, (hipStream_t)stream);
 }
 
+int e3_adamw_step_bf16(void* stream, int n_tensors, void* const* params, void* const* grads, const long long* numels,
+                       float* exp_avg, float* exp_avg_sq, float* step, float* coef,
+                       double lr, double beta1, double beta2, double eps, double weight_decay,
+                       const float* grad_scale, const float* found_inf) {
+    E3_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (params && grads && numels)), E3_ERR_INVALID, "null tensor table");
+    E3_REQUIRE(exp_avg && exp_avg_sq && step && coef, E3_ERR_INVALID, "null optimizer state");
+    E3_REQUIRE(lr >= 0.0 && eps >= 0.0 && weight_decay >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0,
+               E3_ERR_INVALID, "invalid AdamW hyper-parameter");
+    return launch_adamw(n_tensors, params, grads, numels, exp_avg, exp_avg_sq, step, coef, lr, beta1, beta2, eps, weight_decay,
+                        grad_scale, found_inf, (hipStream_t)stream, 1);
+}
+
 // ---------------------------------------------------------------------------------------------- final 1x1x1 conv
 int e3_conv1_fwd(void* stream, const float* a, int a_ldc, int C, const float* w, const float* bias, float* y_ncdhw,
                  int Cout, int N, int D, int H, int W, int softmax) {

@@ -165,7 +165,7 @@ size_t adamw_state_floats(int n_tensors, const long long* numels);
 size_t adamw_state_offset(int n_tensors, const long long* numels, int tensor);
 int launch_adamw(int n_tensors, void* const* params, void* const* grads, const long long* numels, float* exp_avg, float* exp_avg_sq,
                  float* step, float* coef, double lr, double beta1, double beta2, double eps, double weight_decay,
-                 const float* grad_scale, const float* found_inf, hipStream_t s);
+                 const float* grad_scale, const float* found_inf, hipStream_t s, int bf16 = 0);
 
 // ---------------------------------------------------------------- wgrad on f32 MFMA
 struct WgradArgs {

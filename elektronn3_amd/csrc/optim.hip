@@ -41,6 +41,9 @@ __global__ void adamw_prepare_kernel(float* step, const float* grad_scale, const
     coef[4] = skip ? 1.f : 0.f;
 }
 
+// B16: parameters and gradients are bfloat16 (a module cast with .to(torch.bfloat16)); the moments and all arithmetic stay fp32, the
+// parameter is rounded to bf16 once per step.
+template <bool B16>
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamWArgs a) {
     if (a.coef[4] != 0.f) return;                                    // GradScaler found inf/nan: parameters and moments stay
     const int b = blockIdx.x;
@@ -50,15 +53,25 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamWArgs a) {
     const int e0 = (b - a.cstart[t]) * OPT_CHUNK + 4 * (int)threadIdx.x;
     const int n = a.numel[t];
     if (e0 >= n || a.g[t] == nullptr) return;                        // no gradient this step: tensor untouched (as torch)
-    float* __restrict__ p = a.p[t] + e0;
-    const float* __restrict__ g = a.g[t] + e0;
+    typedef unsigned short u16;
+    float* __restrict__ p = B16 ? nullptr : a.p[t] + e0;
+    const float* __restrict__ g = B16 ? nullptr : a.g[t] + e0;
+    u16* __restrict__ p16 = B16 ? reinterpret_cast<u16*>(a.p[t]) + e0 : nullptr;
+    const u16* __restrict__ g16 = B16 ? reinterpret_cast<const u16*>(a.g[t]) + e0 : nullptr;
     const size_t so = (size_t)(a.chunk0 + b) * OPT_CHUNK + 4 * threadIdx.x;
     float* __restrict__ m = a.m + so; float* __restrict__ v = a.v + so;
     const float step_size = a.coef[0], bc2s = a.coef[1], decay = a.coef[2], inv_scale = a.coef[3];
     const float b2 = a.beta2, w1 = a.w1, w2 = a.w2;
-    const bool vec = e0 + 4 <= n && ((((size_t)p | (size_t)g) & 15) == 0);
+    const bool vec = !B16 && e0 + 4 <= n && ((((size_t)p | (size_t)g) & 15) == 0);
     float pv[4], gv[4], mv[4], vv[4];
-    if (vec) {
+    if (B16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = e0 + e < n;
+            pv[e] = ok ? __uint_as_float((unsigned)p16[e] << 16) : 0.f; gv[e] = ok ? __uint_as_float((unsigned)g16[e] << 16) : 0.f;
+            mv[e] = ok ? m[e] : 0.f; vv[e] = ok ? v[e] : 0.f;
+        }
+    } else if (vec) {
         const f32x4 P = *reinterpret_cast<const f32x4*>(p), G = *reinterpret_cast<const f32x4*>(g);
         const f32x4 M = *reinterpret_cast<const f32x4*>(m), V = *reinterpret_cast<const f32x4*>(v);
 #pragma unroll
@@ -79,7 +92,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamWArgs a) {
         const float denom = __builtin_sqrtf(vv[e]) / bc2s + a.eps;    // sqrt(v) / sqrt(bias_correction2) + eps
         pv[e] = pv[e] - step_size * (mv[e] / denom);
     }
-    if (vec) {
+    if (B16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e0 + e < n) { p16[e] = __builtin_bit_cast(unsigned short, (__bf16)pv[e]); m[e] = mv[e]; v[e] = vv[e]; }
+    } else if (vec) {
         *reinterpret_cast<f32x4*>(p) = f32x4{pv[0], pv[1], pv[2], pv[3]};
         *reinterpret_cast<f32x4*>(m) = f32x4{mv[0], mv[1], mv[2], mv[3]};
         *reinterpret_cast<f32x4*>(v) = f32x4{vv[0], vv[1], vv[2], vv[3]};
@@ -156,7 +172,7 @@ size_t adamw_state_offset(int n_tensors, const long long* numels, int tensor) {
 
 int launch_adamw(int n_tensors, void* const* params, void* const* grads, const long long* numels, float* exp_avg, float* exp_avg_sq,
                  float* step, float* coef, double lr, double beta1, double beta2, double eps, double weight_decay,
-                 const float* grad_scale, const float* found_inf, hipStream_t s) {
+                 const float* grad_scale, const float* found_inf, hipStream_t s, int bf16) {
     hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(1), 0, s, step, grad_scale, found_inf, lr, beta1, beta2, weight_decay, coef);
     E3_CHECK_HIP(hipGetLastError());
     long long chunk0 = 0;
@@ -173,7 +189,10 @@ int launch_adamw(int n_tensors, void* const* params, void* const* grads, const l
         a.cstart[a.nt] = c;
         a.chunk0 = chunk0; a.m = exp_avg; a.v = exp_avg_sq; a.coef = coef;
         a.beta2 = (float)beta2; a.w1 = (float)(1.0 - beta1); a.w2 = (float)(1.0 - beta2); a.eps = (float)eps;
-        if (c > 0) hipLaunchKernelGGL(adamw_kernel, dim3(c), dim3(256), 0, s, a);
+        if (c > 0) {
+            if (bf16) hipLaunchKernelGGL(adamw_kernel<true>, dim3(c), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(adamw_kernel<false>, dim3(c), dim3(256), 0, s, a);
+        }
         E3_CHECK_HIP(hipGetLastError());
         chunk0 += c;
     }

@@ -53,8 +53,8 @@ class AdamW(torch.optim.Optimizer):
         for p in params:
             if p.device.type != 'cuda':
                 raise RuntimeError('elektronn3_amd.optim.AdamW runs on the GPU only (there is no CPU path)')
-            if p.dtype != torch.float32 or p.device != dev or not p.is_contiguous():
-                raise NotImplementedError('AdamW on the HIP path needs contiguous fp32 parameters on one device')
+            if p.dtype not in (torch.float32, torch.bfloat16) or p.dtype != params[0].dtype or p.device != dev or not p.is_contiguous():
+                raise NotImplementedError('AdamW on the HIP path needs contiguous parameters of one dtype (fp32 or bf16) on one device')
         n = len(params)
         numels = (ctypes.c_int64 * n)(*[p.numel() for p in params])
         lib = _lib.load()
@@ -67,12 +67,12 @@ class AdamW(torch.optim.Optimizer):
         for p, o in zip(params, offs):
             st = self.state.get(p)
             if st:
-                m[o:o + p.numel()].copy_(st['exp_avg'].reshape(-1))
-                v[o:o + p.numel()].copy_(st['exp_avg_sq'].reshape(-1))
+                m[o:o + p.numel()].copy_(st['exp_avg'].reshape(-1).float())
+                v[o:o + p.numel()].copy_(st['exp_avg_sq'].reshape(-1).float())
                 step.fill_(float(st['step']))
         for p, o in zip(params, offs):   # torch.optim.AdamW-shaped per-parameter state: views into the flat buffers
             self.state[p] = {'step': step[0], 'exp_avg': m[o:o + p.numel()].view_as(p), 'exp_avg_sq': v[o:o + p.numel()].view_as(p)}
-        fs = dict(key=key, m=m, v=v, step=step, coef=torch.zeros(8, dtype=torch.float32, device=dev), numels=numels,
+        fs = dict(key=key, m=m, v=v, step=step, coef=torch.zeros(8, dtype=torch.float32, device=dev), numels=numels, bf16=params[0].dtype == torch.bfloat16,
                   pp=(ctypes.c_void_p * n)(*[p.data_ptr() for p in params]), gp=(ctypes.c_void_p * n)(), n=n, dev=dev)
         self._flat[gi] = fs
         return fs
@@ -113,15 +113,16 @@ class AdamW(torch.optim.Optimizer):
                     continue
                 if g.is_sparse:
                     raise RuntimeError('AdamW does not support sparse gradients')
-                if g.dtype != torch.float32 or not g.is_contiguous():
-                    g = g.float().contiguous(); p.grad = g
+                if g.dtype != p.dtype or not g.is_contiguous():
+                    g = g.to(p.dtype).contiguous(); p.grad = g
                 fs['gp'][i] = g.data_ptr()
                 any_grad = True
             if not any_grad:
                 continue
             b1, b2 = group['betas']
             with torch.cuda.device(fs['dev']):
-                check(lib.e3_adamw_step(stream_ptr(fs['dev']), fs['n'], fs['pp'], fs['gp'], fs['numels'], ptr(fs['m']), ptr(fs['v']),
+                step_fn = lib.e3_adamw_step_bf16 if fs['bf16'] else lib.e3_adamw_step      # bf16 parameters: fp32 moments, one rounding per step
+                check(step_fn(stream_ptr(fs['dev']), fs['n'], fs['pp'], fs['gp'], fs['numels'], ptr(fs['m']), ptr(fs['v']),
                                         ptr(fs['step']), ptr(fs['coef']), float(group['lr']), float(b1), float(b2), float(group['eps']),
                                         float(group['weight_decay']),
                                         ptr(grad_scale.float()) if grad_scale is not None else None,

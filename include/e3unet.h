@@ -236,6 +236,12 @@ int e3_adamw_step(void* stream, int n_tensors, void* const* params, void* const*
                   float* exp_avg, float* exp_avg_sq, float* step, float* coef,
                   double lr, double beta1, double beta2, double eps, double weight_decay,
                   const float* grad_scale, const float* found_inf);
+/* The same step for a module whose parameters (and therefore gradients) are bfloat16 (model.to(torch.bfloat16), BASELINE configs[2]'s
+ * storage): params / grads point to bf16 tensors, the moments stay fp32, every parameter is rounded to bf16 once per step. */
+int e3_adamw_step_bf16(void* stream, int n_tensors, void* const* params, void* const* grads, const long long* numels,
+                  float* exp_avg, float* exp_avg_sq, float* step, float* coef,
+                  double lr, double beta1, double beta2, double eps, double weight_decay,
+                  const float* grad_scale, const float* found_inf);
 
 /* Stochastic weight averaging of the reference's SWA(optimizer) wrapper [elektronn3/training/swa.py:145-176 update_swa_group,
  * :184-202 swap_swa_sgd; driven by training/trainer.py:681-700] as ONE launch over all parameter tensors:

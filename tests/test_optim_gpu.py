@@ -256,3 +256,35 @@ def test_swa_over_cfg2_parameters_with_hip_adamw_and_bn_update():
     opt.swap_swa_sgd()
     for p, q in zip(m.parameters(), before):
         assert torch.equal(p.data, q)
+
+
+def test_bf16_parameters_follow_an_fp32_master_copy():
+    """A module cast with .to(torch.bfloat16) (BASELINE configs[2]'s storage): parameters and gradients are bf16, the moments and the arithmetic
+    fp32, one rounding of the parameter per step.  Reference: the fp32 kernel on an fp32 copy that is rounded to bf16 after every step, fed the
+    same bf16 gradients -- the bf16 run must reproduce it (same arithmetic, same single rounding)."""
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(0)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=3, start_filts=32).cuda().to(torch.bfloat16)
+    mine = list(m.parameters())
+    ref = [torch.nn.Parameter(p.detach().float().clone()) for p in mine]
+    o_my = _opt(mine, lr=1e-3, weight_decay=0.5e-4)
+    o_ref = _opt(ref, lr=1e-3, weight_decay=0.5e-4)
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    for step in range(5):
+        for k, (a, b) in enumerate(zip(mine, ref)):
+            gr = (torch.randn(a.shape, device='cuda', generator=gen) * 10.0 ** ((k % 4) - 2)).to(torch.bfloat16)
+            a.grad = gr.clone(); b.grad = gr.float()
+        o_my.step(); o_ref.step()
+        with torch.no_grad():
+            for b in ref:
+                b.copy_(b.to(torch.bfloat16).float())
+    for k, (a, b) in enumerate(zip(mine, ref)):
+        assert a.dtype == torch.bfloat16 and o_my.state[a]['exp_avg'].dtype == torch.float32
+        # same arithmetic up to the compiler's choice of fused multiply-adds in the two instantiations: the fp32 values agree to an ulp, so
+        # the bf16 roundings differ in at most a few elements, by one bf16 ulp
+        d = (a.detach().float() - b.detach()).abs()
+        assert float((d > 0).float().mean()) < 2e-3 and bool((d <= 2.0 ** -6 * b.detach().abs() + 1e-30).all()), f'param {k}'
+        torch.testing.assert_close(o_my.state[a]['exp_avg'], o_ref.state[b]['exp_avg'], rtol=1e-5, atol=1e-7 * float(o_ref.state[b]['exp_avg'].abs().max()))
+    # mixed dtypes in one group are refused
+    with pytest.raises(NotImplementedError):
+        _opt([mine[0], ref[0]], lr=1e-3).step()
