@@ -98,6 +98,7 @@ _SIG = {
     'e3_ce_dice_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, c_size_t, _P, _P]),
     'e3_swa_update': (_I, [_P, _I, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int64]),
     'e3_swa_swap': (_I, [_P, _I, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64)]),
+    'e3_unet_set_rrelu': (_I, [_P, c_double, c_double, c_uint32]),
     'e3_adamw_state_floats': (c_size_t, [_I, POINTER(c_int64)]),
     'e3_adamw_state_offset': (c_size_t, [_I, POINTER(c_int64), _I]),
     'e3_adamw_step': (_I, [_P, _I, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), _P, _P, _P, _P,

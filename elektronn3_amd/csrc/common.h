@@ -64,14 +64,26 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
 // device memory (no host sync).  Implicitly constructible from a float, so constant-slope call sites stay as they are.
 struct ActArg {
     float slope; const float* ptr;
-    __host__ __device__ ActArg(float s = 0.f) : slope(s), ptr(nullptr) {}
-    __host__ __device__ ActArg(float s, const float* p) : slope(s), ptr(p) {}
+    // nn.RReLU in TRAIN mode (get_activation 'rrelu', unet.py:183-199 -> nn.RReLU(1/8, 1/3)): the slope of a negative input is drawn per
+    // element from U(lo, hi).  seed != 0 selects it; the draw is a counter-based hash of (seed, element index), so the backward pass
+    // recomputes the forward's slopes instead of storing a noise tensor.
+    unsigned seed; float lo, hi;
+    __host__ __device__ ActArg(float s = 0.f) : slope(s), ptr(nullptr), seed(0u), lo(0.f), hi(0.f) {}
+    __host__ __device__ ActArg(float s, const float* p) : slope(s), ptr(p), seed(0u), lo(0.f), hi(0.f) {}
+    __host__ __device__ ActArg rrelu(unsigned sd, float l, float h) const { ActArg a = *this; a.seed = sd; a.lo = l; a.hi = h; return a; }
     // (a learned slope that is exactly 2.0f must not be mistaken for the ACT_SILU code below: moved by one ulp)
     __device__ __forceinline__ float get() const { if (!ptr) return slope; const float v = *ptr; return v == 2.f ? 2.0000002f : v; }
 };
 // slope == ACT_SILU selects nn.SiLU ('silu'): z * sigmoid(z), derivative sig * (1 + z * (1 - sig)).
 constexpr float ACT_SILU = 2.f;
 constexpr float ACT_PRELU = 3.f;     // (plan-level code only: the kernels see the learnable slope through ActArg::ptr)
+// slope of element idx (= voxel * C + channel of the activation's tensor): the uniform one, or the train-mode RReLU draw
+__device__ __forceinline__ float act_slope_at(const ActArg& a, float slope, unsigned idx) {
+    if (a.seed == 0u) return slope;
+    unsigned h = idx * 747796405u + a.seed;
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return a.lo + (a.hi - a.lo) * ((float)(h >> 8) * 5.9604645e-8f);
+}
 __device__ __forceinline__ float act_fwd(float z, float slope) {
     if (slope == ACT_SILU) return z / (1.f + expf(-z));
     return fmaxf(z, 0.f) + slope * fminf(z, 0.f);

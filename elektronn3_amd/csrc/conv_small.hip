@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
                 // the brick of dY (or of the tensors it is computed from): all 8 (16) loads of a thread in flight before the first use
                 // (rolled, every pass of this loop waited a memory round trip: 180 -> 128 us with the MFMAs alone, -> ? with this)
                 {
-                    f32x4 xv[8], gv[8]; bool ok[8];
+                    f32x4 xv[8], gv[8]; bool ok[8]; unsigned eidx[8];
 #pragma unroll
                     for (int it = 0; it < 8; ++it) {
                         const int idx = tid + 256 * it;
@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
                         ok[it] = gd < D && gh < H && gw < W && pass * 32 + 4 * qq < Cout;
                         const size_t vox = ok[it] ? (((size_t)nb * D + gd) * H + gh) * W + gw : 0;
                         const int c0 = ok[it] ? pass * 32 + 4 * qq : 0;
+                        eidx[it] = (unsigned)(vox * Cout + c0);
                         if (f.x1) { xv[it] = *reinterpret_cast<const f32x4*>(f.x1 + vox * f.x1_ldc + c0); gv[it] = *reinterpret_cast<const f32x4*>(f.g + vox * f.g_ldc + c0); }
                         else gv[it] = *reinterpret_cast<const f32x4*>(dy + vox * dy_ldc + c0);
                     }
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     const float z = __builtin_fmaf(xv[it][e], fsc[e], fsh[e]);
-                                    const float dz = act_bwd(z, gv[it][e], fslope);
+                                    const float dz = act_bwd(z, gv[it][e], act_slope_at(f.act, fslope, eidx[it] + e));
                                     const float xh = (xv[it][e] - fmu[e]) * fis[e];
                                     val[e] = fgi[e] * (dz - fc1[e] - xh * fc2[e]);
                                     if (ci == 0) bsum[e] += val[e];
@@ -304,7 +305,7 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
                 if (pro_scale) {
                     const f32x4 sc = *reinterpret_cast<const f32x4*>(pro_scale + 4 * q), sh = *reinterpret_cast<const f32x4*>(pro_shift + 4 * q);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) av[e] = act_fwd(__builtin_fmaf(av[e], sc[e], sh[e]), pro_slope);
+                    for (int e = 0; e < 4; ++e) av[e] = act_fwd(__builtin_fmaf(av[e], sc[e], sh[e]), act_slope_at(pro_act, pro_slope, (unsigned)(v * C + 4 * q + e)));
                 }
 #pragma unroll
                 for (int co = 0; co < COUT; ++co) {
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void conv_final_bwd_kernel(const float* __rest
         f32x4 av = *reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * q);
         if (pro_scale) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) av[e] = act_fwd(__builtin_fmaf(av[e], sc[e], sh[e]), pro_slope);
+            for (int e = 0; e < 4; ++e) av[e] = act_fwd(__builtin_fmaf(av[e], sc[e], sh[e]), act_slope_at(pro_act, pro_slope, (unsigned)(v * C + 4 * q + e)));
         }
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -197,7 +197,7 @@ __global__ void bn_relu_apply_kernel(const float* __restrict__ x, int x_ldc, con
             const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + 4 * qq[u]);
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = act_fwd(__builtin_fmaf(xv[u][e], sc[e], sh[e]), slope);
+            for (int e = 0; e < 4; ++e) o[e] = act_fwd(__builtin_fmaf(xv[u][e], sc[e], sh[e]), act_slope_at(act, slope, (unsigned)(off[u] * C + 4 * qq[u] + e)));
             if (ok[u]) *reinterpret_cast<f32x4*>(a + off[u] * a_ldc + 4 * qq[u]) = o;
         }
     }
@@ -232,7 +232,7 @@ __global__ void bn_relu_pool_kernel(const float* __restrict__ x, int x_ldc, cons
                     f32x4 o = *reinterpret_cast<const f32x4*>(x + v * x_ldc + 4 * q);
                     if (APPLY) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = act_fwd(__builtin_fmaf(o[e], sc[e], sh[e]), slope);
+                        for (int e = 0; e < 4; ++e) o[e] = act_fwd(__builtin_fmaf(o[e], sc[e], sh[e]), act_slope_at(act, slope, (unsigned)(v * C + 4 * q + e)));
                         *reinterpret_cast<f32x4*>(a + v * a_ldc + 4 * q) = o;
                     }
 #pragma unroll
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float z = __builtin_fmaf(xv[u][e], sc[e], sh[e]);   // same expression as the forward apply
-                    const float dz = act_bwd(z, g[u][e], slope);
+                    const float dz = act_bwd(z, g[u][e], act_slope_at(a.act, slope, (unsigned)((v0 + u * vstride) * a.C + 4 * q + e)));
                     if (!APPLYPASS && prelu) s3[e] += g[u][e] * fminf(z, 0.f);
                     const float xh = (xv[u][e] - mu[e]) * is[e];
                     if (APPLYPASS) { o[e] = ok[u] ? gi[e] * (dz - c1[e] - xh * c2[e]) - (k1[e] + xh * k2[e]) : 0.f; s3[e] += o[e]; }
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                         f32x4 av;
                         f32x4 zv;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { zv[e] = __builtin_fmaf(xv[e], sc[e], sh[e]); av[e] = act_fwd(zv[e], slope); }
+                        for (int e = 0; e < 4; ++e) { zv[e] = __builtin_fmaf(xv[e], sc[e], sh[e]); av[e] = act_fwd(zv[e], act_slope_at(a.act, slope, (unsigned)(v * a.C + 4 * q + e))); }
                         f32x4 g = {0.f, 0.f, 0.f, 0.f};
                         if (a.g1) g = *reinterpret_cast<const f32x4*>(a.g1 + v * a.g1_ldc + 4 * q);
                         f32x4 o;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                         for (int e = 0; e < 4; ++e) {
                             float dA = g[e];
                             if (!taken[e] && av[e] == pm[e]) { dA += gp[e]; taken[e] = true; }   // first arg-max wins (ATen)
-                            const float dz = act_bwd(zv[e], dA, slope);
+                            const float dz = act_bwd(zv[e], dA, act_slope_at(a.act, slope, (unsigned)(v * a.C + 4 * q + e)));
                             if (!APPLYPASS && prelu) s3[e] += dA * fminf(zv[e], 0.f);
                             const float xh = (xv[e] - mu[e]) * is[e];
                             if (APPLYPASS) { o[e] = gi[e] * (dz - c1[e] - xh * c2[e]) - (k1[e] + xh * k2[e]); s3[e] += o[e]; }

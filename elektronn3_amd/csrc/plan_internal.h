@@ -38,6 +38,13 @@ struct e3_unet_plan {
     std::vector<ConvUnit> units;      // execution order of the forward
     int p_final_w, p_final_b;
     int n_bn;
+    // nn.RReLU in train mode: per-call seed (0 = off: fixed slope cfg.act_slope) and the slope interval (e3_unet_set_rrelu)
+    unsigned rrelu_seed = 0; float rrelu_lo = 0.125f, rrelu_hi = 1.f / 3.f;
+    ActArg rrelu_of(ActArg a, int unit) const {           // unit's activation with its own stream of slopes
+        if (!rrelu_seed) return a;
+        const unsigned sd = (rrelu_seed * 0x9E3779B1u) ^ ((unsigned)(unit + 1) * 0x85EBCA77u);
+        return a.rrelu(sd | 1u, rrelu_lo, rrelu_hi);
+    }
     // profiling
     int prof_layer = -1, prof_which = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

@@ -366,6 +366,13 @@ int e3_unet_conv_info(const e3_unet_plan* plan, int layer, char* name, int name_
     return E3_OK;
 }
 
+int e3_unet_set_rrelu(e3_unet_plan* plan, double lower, double upper, unsigned seed) {
+    E3_REQUIRE(plan, E3_ERR_INVALID, "null plan");
+    E3_REQUIRE(seed == 0 || (lower >= 0.0 && lower <= upper && upper <= 1.0), E3_ERR_INVALID, "RReLU needs 0 <= lower <= upper <= 1");
+    plan->rrelu_seed = seed; plan->rrelu_lo = (float)lower; plan->rrelu_hi = (float)upper;
+    return E3_OK;
+}
+
 int e3_unet_profile_select(e3_unet_plan* plan, int layer, int which) {
     E3_REQUIRE(plan, E3_ERR_INVALID, "null plan");
     plan->prof_layer = layer; plan->prof_which = which; plan->prof_used = 0;
@@ -471,7 +478,8 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         const bool pool_after = is_enc_conv2 && u.level < nb - 1;
         const int kd = u.planar ? 1 : 2;
         const float slope = cfg.act_slope;
-        const ActArg act = u.p_a >= 0 ? ActArg(0.f, P(u.p_a)) : ActArg(slope);
+        ActArg act = u.p_a >= 0 ? ActArg(0.f, P(u.p_a)) : ActArg(slope);
+        if (training && !frozen) act = plan->rrelu_of(act, (int)k);      // train-mode RReLU: random slopes (the backward recomputes them)
         const bool bn_train = training && u.has_norm();   // batch statistics needed: conv writes the raw output, BN+ReLU is a second pass
         float* const stat_buf = frozen ? nullptr : B.stats;   // (frozen statistics: nothing to measure)
         const bool two_pass = bn_train || slope != 0.f || u.is_up == 2 || vcrop;   // (non-ReLU activations are not in the conv epilogues; the
@@ -612,7 +620,8 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         RUN(launch_conv_final_fwd(fused ? lb.raw : cur, fused ? lu.cout : cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y,
                                   cfg.out_channels, ND.Y.vox / N, N, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s,
                                   fused ? lb.scale : nullptr, fused ? lb.shift : nullptr,
-                                  lu.p_a >= 0 ? ActArg(0.f, P(lu.p_a)) : ActArg(cfg.act_slope)));
+                                  (training && !frozen) ? plan->rrelu_of(lu.p_a >= 0 ? ActArg(0.f, P(lu.p_a)) : ActArg(cfg.act_slope), (int)plan->units.size() - 1)
+                                                        : (lu.p_a >= 0 ? ActArg(0.f, P(lu.p_a)) : ActArg(cfg.act_slope))));
     }
     return E3_OK;
 }
@@ -659,7 +668,7 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
           // weights (2 fma per element instead of one 4-byte write and two 4-byte reads)
           RUN(launch_conv_final_bwd(fused ? last.raw : last.act, fused ? C0 : last.act_ldc, C0, P(plan->p_final_w), dy, nullptr, C0, B.slab,
                                     cfg.out_channels, ND.Y.vox / N, N, s, fused ? last.scale : nullptr, fused ? last.shift : nullptr,
-                                    plan->units.back().p_a >= 0 ? ActArg(0.f, P(plan->units.back().p_a)) : ActArg(cfg.act_slope))); }
+                                    plan->rrelu_of(plan->units.back().p_a >= 0 ? ActArg(0.f, P(plan->units.back().p_a)) : ActArg(cfg.act_slope), nunits - 1))); }
         RUN(launch_colsum_finalize(B.slab, parts, ps, 0, cfg.out_channels * C0, G(plan->p_final_w), s));
         RUN(launch_colsum_finalize(B.slab, parts, ps, cfg.out_channels * C0, cfg.out_channels, G(plan->p_final_b), s));
     }
@@ -724,7 +733,7 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
         {
             BnBwdArgs a{};
             a.x = b.raw; a.x_ldc = u.cout; a.mean = b.mean; a.invstd = b.invstd; a.scale = b.scale; a.shift = b.shift;
-            a.act = u.p_a >= 0 ? ActArg(0.f, P(u.p_a)) : ActArg(cfg.act_slope);
+            a.act = plan->rrelu_of(u.p_a >= 0 ? ActArg(0.f, P(u.p_a)) : ActArg(cfg.act_slope), k);
             if (u.has_norm()) a.gamma = P(u.p_g);
             else {   // nn.Identity + activation: dz = dA * act'(z) is the APPLY pass with the constants of an identity "norm":
                      // mean 0, invstd 1, gamma 1, c = k = 0  =>  dx = dz, sum dx = conv-bias gradient.  ReLU: x := a (mask 1*a + 0 > 0);

@@ -191,6 +191,13 @@ class _UNetFunction(torch.autograd.Function):
         frozen = need_grad and not training and module.normalization == 'batch'
         if need_grad and not training and not frozen:
             training = True            # (normalization='none': train and eval mode are the same function; take the flow that saves)
+        # nn.RReLU in train mode: one seed per native call from torch's default generator (torch.manual_seed makes runs repeatable); the
+        # backward re-arms the same seed, the kernels recompute the slopes
+        rr = module._rrelu_interval() if (module.training and not frozen) else None
+        ctx.rrelu = None
+        if rr is not None:
+            ctx.rrelu = (rr[0], rr[1], int(torch.randint(1, 2 ** 31 - 1, (1,)).item()))
+        check(_lib.load().e3_unet_set_rrelu(plan.handle, *(ctx.rrelu if ctx.rrelu is not None else (0.0, 0.0, 0))))
         y, saved, xin, b16 = _native_forward(module, plan, x, tens, softmax, want_bf16 or (all_bf16 and in_dtype == torch.bfloat16),
                                              ctx.needs_input_grad[3], training or frozen,
                                              module._momenta(plan) if (training or frozen) else None, frozen=frozen)
@@ -218,6 +225,7 @@ class _UNetFunction(torch.autograd.Function):
         if ctx.softmax:
             raise NotImplementedError('backward through the fused softmax head is not implemented')
         module, plan = ctx.module, ctx.plan
+        check(_lib.load().e3_unet_set_rrelu(plan.handle, *(ctx.rrelu if ctx.rrelu is not None else (0.0, 0.0, 0))))
         flat, views, dx = _native_backward(plan, dy, ctx.x32, ctx.tens, ctx.saved_buf, ctx.b16, ctx.needs_input_grad[3],
                                            getattr(module, '_grad_sync', None), frozen=ctx.frozen)
         ctx.saved_buf = ctx.x32 = ctx.tens = None   # free the activations now
@@ -277,6 +285,7 @@ def _op_unet_fwd(x: torch.Tensor, tensors: List[torch.Tensor], key: List[float],
             if kind != 0:
                 tens[i] = tens[i].clone()
                 new_bufs.append(tens[i])
+    check(_lib.load().e3_unet_set_rrelu(plan.handle, 0.0, 0.0, 0))     # (scripted modules: RReLU with its eval-mode slope; see _script_ok)
     y, saved, _, _ = _native_forward(None, plan, x, tens, softmax, False, False, training, list(momenta) if training else None)
     return [y, saved if saved is not None else x.new_empty(0, dtype=torch.uint8)] + new_bufs
 
@@ -296,6 +305,7 @@ def _op_unet_bwd(dy: torch.Tensor, x: torch.Tensor, tensors: List[torch.Tensor],
     """-> gradients of the trainable table entries, in table order"""
     plan = _get_plan(_plan_key_from_floats(key))
     tens = [t.detach().contiguous() for t in tensors]
+    check(_lib.load().e3_unet_set_rrelu(plan.handle, 0.0, 0.0, 0))
     _, views, _ = _native_backward(plan, dy, x.detach().contiguous(), tens, saved, False, False)
     return [v.view_as(t).clone() for v, t in zip(views, tens) if v is not None]     # (operator outputs must not alias each other)
 
@@ -472,8 +482,9 @@ class UNet(nn.Module):
     kernels.  Options of the reference that are not yet on the HIP path raise ``NotImplementedError`` at
     construction: ``up_mode='upsample'``,
     ``attention=True``,
-    ``conv_mode`` other than ``'same'`` / ``'valid'``.  ``activation='rrelu'`` runs in eval mode only (the fixed slope (1/8 + 1/3)/2 of
-    ``nn.RReLU``; a train-mode forward, which draws a random slope per element, raises ``NotImplementedError``).  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
+    ``conv_mode`` other than ``'same'`` / ``'valid'``.  ``activation='rrelu'``: eval mode uses the fixed slope (1/8 + 1/3)/2 of
+    ``nn.RReLU``; a train-mode forward draws a slope per negative element from U(1/8, 1/3) inside the kernels (a hash of a per-call seed taken
+    from torch's generator, the unit and the element index; the backward recomputes it).  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
     the 3D one with every block planar and a depth of 1."""
 
     _script_key: List[float]
@@ -571,7 +582,7 @@ class UNet(nn.Module):
         self.conv_final = _LAYERS[dim][0](outs, out_channels, kernel_size=1)
         self.apply(self.weight_init)
         self._script_key = [float(v) for v in self._plan_key()]      # (read by the scripted forward)
-        self._script_ok = normalization != 'instance' and dim == 3
+        self._script_ok = normalization != 'instance' and dim == 3 and self._rrelu_interval() is None     # (train-mode RReLU needs a per-call seed)
 
     @staticmethod
     def weight_init(m):
@@ -666,7 +677,7 @@ class UNet(nn.Module):
         bias, [norm weight, norm bias, [running_mean, running_var]], [PReLU slope]; units in execution order; conv_final last), ONE call
         of the registered operator e3unet::unet_fwd, the returned running statistics copied back."""
         if not self._script_ok:
-            raise RuntimeError('scripted elektronn3_amd.UNet: dim=3 with batch / group / no normalization only')
+            raise RuntimeError('scripted elektronn3_amd.UNet: dim=3 with batch / group / no normalization, activations other than rrelu')
         t: List[torch.Tensor] = []
         bufs: List[torch.Tensor] = []
         counters: List[torch.Tensor] = []
@@ -757,6 +768,15 @@ class UNet(nn.Module):
         return outs[0]
 
     @torch.jit.unused
+    def _rrelu_interval(self):
+        """(lower, upper) of nn.RReLU if that is the network's activation (train mode draws a slope per element), else None."""
+        a = self.activation
+        if a == 'rrelu':
+            return (1.0 / 8, 1.0 / 3)
+        if isinstance(a, nn.RReLU):
+            return (float(a.lower), float(a.upper))
+        return None
+
     def _run(self, x, softmax=False):
         if self.dim == 2:
             if not isinstance(x, torch.Tensor) or x.dim() != 4:
@@ -768,8 +788,6 @@ class UNet(nn.Module):
             raise ValueError(f'expected {self.in_channels} input channels, got {x.shape[1]}')
         if not x.is_cuda:
             raise RuntimeError('elektronn3_amd.UNet runs only on a ROCm GPU (hand-written HIP kernels); there is no CPU fallback')
-        if self.training and (self.activation == 'rrelu' or isinstance(self.activation, nn.RReLU)):
-            raise NotImplementedError("activation='rrelu' in train mode (a random slope per element) is not on the HIP path; eval mode is")
         plan = self._plan()
         params = [p for _, p in self._named_table_params(plan)]
         # torch.autocast('cuda', dtype=torch.bfloat16) around the call (the bf16 counterpart of Trainer(mixed_precision=True),

@@ -129,6 +129,11 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
  * returned by e3_unet_conv_info. */
 int e3_unet_conv_count(const e3_unet_plan* plan);
 int e3_unet_conv_info(const e3_unet_plan* plan, int layer, char* name, int name_len, int* cin, int* cout, int* taps, int* level);
+/* nn.RReLU in TRAIN mode (activation='rrelu', unet.py:183-199 get_activation -> nn.RReLU(): lower 1/8, upper 1/3): the slope of every
+ * negative pre-activation is drawn from U(lower, upper).  seed != 0 arms it for the following TRAINING forwards of this plan (fp32 path;
+ * every unit derives its own stream, the draw is a hash of (seed, unit, element index)); the backward of such a forward must run with the SAME
+ * seed set (the slopes are recomputed, no noise tensor is stored).  seed == 0: the fixed slope cfg.act_slope (eval mode: (lower+upper)/2). */
+int e3_unet_set_rrelu(e3_unet_plan* plan, double lower, double upper, unsigned seed);
 int e3_unet_profile_select(e3_unet_plan* plan, int layer, int which);
 int e3_unet_profile_read(e3_unet_plan* plan, double* mean_ms, int* launches);
 
