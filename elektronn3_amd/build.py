@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libe3unet.so')
 OBJDIR = os.path.join(HERE, 'build')
 SOURCES = ['conv_mfma.hip', 'conv_v3.hip', 'conv_wino.hip', 'conv_wino2d.hip', 'upconv_gemm.hip', 'wgrad_mfma.hip', 'wgrad_wino.hip', 'wgrad_wino2d.hip', 'conv_small.hip', 'elementwise.hip', 'loss.hip', 'optim.hip', 'api.cpp', 'unet_plan.cpp',
-           'bf16_conv.hip', 'bf16_wgrad.hip', 'bf16_upconv.hip', 'bf16_ew.hip', 'bf16_first.hip', 'api_bf16.cpp', 'unet_bf16.cpp']
+           'attention.hip', 'bf16_conv.hip', 'bf16_wgrad.hip', 'bf16_upconv.hip', 'bf16_ew.hip', 'bf16_first.hip', 'api_bf16.cpp', 'unet_bf16.cpp']
 HEADERS = ['common.h', 'kernels.h', 'bf16.h', 'plan_internal.h', os.path.join('..', '..', 'include', 'e3unet.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-x', 'hip'] + os.environ.get('E3_HIPCC_EXTRA', '').split()
 # per-file extras.  wgrad_wino: the SLP vectoriser turns its scalar transforms into v_pk_* ops plus ~200 v_mov per brick

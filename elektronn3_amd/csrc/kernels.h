@@ -243,6 +243,26 @@ int launch_bn_bwd_finalize(const float* part, int parts, int C, float inv_n, flo
 int launch_bn_bwd_apply(BnBwdArgs a, hipStream_t s);
 int launch_colsum_finalize(const float* part, int parts, int part_stride, int offset, int C, float* out, hipStream_t s);
 
+// ---------------------------------------------------------------- GridAttention of the decoder blocks (attention.hip; unet.py:452-541)
+struct AttDims {
+    int N, C;               // batch, channels of the skip tensor x (the gating signal g has 2C, the gate works on C/2)
+    int D, H, W;            // grid of x (after autocrop)
+    int d, h, w;            // grid of theta(x): floor(D / sd), H / 2, W / 2
+    int gd, gh, gw;         // grid of g
+    int sd;                 // depth stride of theta: 2 (dim=3) or 1 (dim=2: 2x2 kernel on a depth-1 volume)
+};
+struct AttParams { float *w_w, *w_b, *theta_w, *phi_w, *phi_b, *psi_w, *psi_b; };   // torch layouts; also used for the gradients
+bool att_resized(const AttDims& d);           // phi(g) needs the linear resize (the grids of theta(x) and g differ)
+size_t att_part_floats(const AttDims& d);     // scratch for the split partial sums of the weight gradients
+int launch_att_gate_fwd(const AttDims& d, const float* x, int ldx, const float* g, int ldg, const AttParams& p, float* f, float* sgm, float* att,
+                        float* phi_tmp, float* phi_res, hipStream_t s);
+int launch_att_out_fwd(const AttDims& d, const float* x, int ldx, const float* att, const AttParams& p, const float* epi_scale, const float* epi_shift,
+                       float* out, int ldo, hipStream_t s);
+int launch_att_bwd(const AttDims& d, const float* dz, const float* x, int ldx, const float* g, int ldg, const float* f, const float* sgm, const float* att,
+                   const AttParams& p, const AttParams& grad, float* dx, float* dphi, float* tmp_fine, float* tmp_coarse, float* df, float* part,
+                   hipStream_t s);
+int launch_att_bwd_gate_input(const AttDims& d, const float* dphi, const AttParams& p, float* dg, int ldg, hipStream_t s);
+
 // ---------------------------------------------------------------- layout helpers
 int launch_ncdhw_to_ndhwc(const float* src, float* dst, int N, int C, size_t S, hipStream_t s);
 int launch_ndhwc_to_ncdhw(const float* src, int src_ldc, float* dst, int N, int C, size_t S, hipStream_t s);

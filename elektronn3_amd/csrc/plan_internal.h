@@ -20,6 +20,9 @@ struct ConvUnit {           // conv (3x3x3 | 1x3x3 | transposed 2x2x2) followed 
     bool has_norm() const { return bn_index >= 0; }
 };
 
+// GridAttention of a decoder block (UNet(attention=True), unet.py:376-379,452-541): indices into the param table
+struct AttUnit { int p_ww, p_wb, p_g, p_be, p_rm, p_rv, p_theta, p_phi_w, p_phi_b, p_psi_w, p_psi_b, bn_index; };
+
 struct Arena {              // bump allocator used twice: once with base == nullptr to size, once to place
     char* base; size_t off;
     explicit Arena(void* b) : base((char*)b), off(0) {}
@@ -38,6 +41,7 @@ struct e3_unet_plan {
     std::vector<ConvUnit> units;      // execution order of the forward
     int p_final_w, p_final_b;
     int n_bn;
+    std::vector<AttUnit> att;         // per level < n_blocks - 1 (cfg.attention != 0)
     // nn.RReLU in train mode: per-call seed (0 = off: fixed slope cfg.act_slope) and the slope interval (e3_unet_set_rrelu)
     unsigned rrelu_seed = 0; float rrelu_lo = 0.125f, rrelu_hi = 1.f / 3.f;
     ActArg rrelu_of(ActArg a, int unit) const {           // unit's activation with its own stream of slopes

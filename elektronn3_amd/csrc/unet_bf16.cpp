@@ -139,7 +139,7 @@ struct ProfB {      // same per-layer HIP-event profiling hook as the fp32 execu
 
 bool supported(const e3_unet_cfg& c) {
     return c.normalization == 1 && c.full_norm && c.act_slope == 0.f && c.up_resize == 0 && !c.merge_add && !c.conv_valid &&
-           c.planar_mask == 0 && c.in_channels < 8 && c.start_filts % 32 == 0 && c.out_channels <= 8;
+           c.planar_mask == 0 && c.in_channels < 8 && c.start_filts % 32 == 0 && c.out_channels <= 8 && !c.attention;
 }
 
 }  // namespace

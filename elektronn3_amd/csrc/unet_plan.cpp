@@ -114,7 +114,12 @@ struct Buffers {
     std::vector<float*> bnpart_u;        // per unit: block partials of the BN backward [parts][3][C]; row 2 (sum dx = conv-bias gradient) is summed for all units at once
     std::vector<float*> wpk_f, wpk_d;    // per unit: Winograd-transformed weights (forward / dgrad form), all packed by ONE launch; nullptr = packed on the spot into wpack
     std::vector<float*> g1, g2, dcat;    // gradient buffers per level
-    std::vector<float*> gskip;           // conv_mode='valid': gradient of the (un-cropped) skip activation per level
+    std::vector<float*> gskip;           // conv_mode='valid' / attention: gradient of the (un-cropped) skip activation per level
+    // GridAttention (cfg.attention): per level the saved gate tensors; shared scratch sized for the largest level
+    struct AttBufs { float *f, *sgm, *att, *raw, *mean, *invstd, *scale, *shift, *x, *bnpart, *gx; };   // x: centre-cropped skip ('valid'); gx: its gradient
+    std::vector<AttBufs> att;
+    float *att_phi = nullptr, *att_phires = nullptr, *att_tmp = nullptr, *att_tf = nullptr, *att_tc = nullptr, *att_df = nullptr, *att_dphi = nullptr,
+          *att_part = nullptr;
     float* evalA; float* evalB;          // inference ping-pong (level-0 sized)
     size_t scratch_bytes;
 };
@@ -122,6 +127,21 @@ struct Buffers {
 size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 
 int pad_cols(int n) { const int t = conv_col_tile(n); return cdiv(n, t) * t; }
+
+// grids of the GridAttention of the decoder block whose output is level j (unit index `up`): x = the skip cropped to the block's grid
+AttDims att_dims(const e3_unet_plan* p, const NetDims& ND, int N, int j, size_t up) {
+    AttDims d{};
+    const LevelDims& lo = ND.u[up].out; const LevelDims& li = ND.u[up].in;
+    d.N = N; d.C = p->chan(j); d.D = lo.D; d.H = lo.H; d.W = lo.W;
+    d.sd = p->cfg.attention == 2 ? 1 : 2;
+    d.d = lo.D / d.sd; d.h = lo.H / 2; d.w = lo.W / 2;        // theta: kernel = stride = 2, no padding
+    d.gd = li.D; d.gh = li.H; d.gw = li.W;
+    return d;
+}
+AttParams att_params(void* const* t, const AttUnit& au) {
+    auto P = [&](int i) { return (float*)t[i]; };
+    return AttParams{P(au.p_ww), P(au.p_wb), P(au.p_theta), P(au.p_phi_w), P(au.p_phi_b), P(au.p_psi_w), P(au.p_psi_b)};
+}
 
 void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool training, void* saved, void* scratch, Buffers& B) {
     const int nb = p->cfg.n_blocks;
@@ -156,11 +176,26 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         // where does the activation go?
         const bool enc_skip = !u.is_up && u.name.find("down_convs") == 0 && u.name.find("conv2") != std::string::npos && u.level < nb - 1;
         // ('valid': the skip is larger than the decoder's grid and gets centre-cropped into the concat buffer by a copy)
-        if (enc_skip && !valid) { b.act = B.cat[u.level] ? B.cat[u.level] + u.cout : nullptr; b.act_ldc = 2 * u.cout; }
+        if (enc_skip && !valid && !p->cfg.attention) { b.act = B.cat[u.level] ? B.cat[u.level] + u.cout : nullptr; b.act_ldc = 2 * u.cout; }
         else if (u.is_up) { b.act = B.cat[u.level]; b.act_ldc = 2 * u.cout; }
         else { b.act = A.take(n); b.act_ldc = u.cout; }
         if (!saved && !scratch) { b.act = nullptr; }
         b.mean = A.take(u.cout); b.invstd = A.take(u.cout); b.scale = A.take(u.cout); b.shift = A.take(u.cout);
+    }
+    const int att_on = p->cfg.attention;
+    B.att.assign(att_on ? nb : 0, Buffers::AttBufs{});
+    size_t att_fine = 0, att_coarse = 0, att_dec = 0, att_cf = 0, att_partmax = 0;      // maxima over the levels (voxels; att_cf: fine voxels x C)
+    for (int j = 0; att_on && j + 1 < nb; ++j) {
+        const AttDims ad = att_dims(p, ND, N, j, up_unit(j));
+        const size_t fine = ND.u[up_unit(j)].out.vox, coarse = (size_t)N * (ad.d > 0 ? ad.d : 0) * ad.h * ad.w, dec = ND.u[up_unit(j)].in.vox;
+        const int C = ad.C, Ci = C / 2;
+        Buffers::AttBufs& ab = B.att[j];
+        ab.f = A.take(coarse * Ci); ab.sgm = A.take(coarse); ab.att = A.take(fine);
+        ab.raw = training ? A.take(fine * C) : nullptr;
+        ab.mean = A.take(C); ab.invstd = A.take(C); ab.scale = A.take(C); ab.shift = A.take(C);
+        ab.x = valid ? A.take(fine * C) : nullptr;
+        att_fine = max_sz(att_fine, fine); att_coarse = max_sz(att_coarse, coarse); att_dec = max_sz(att_dec, dec * Ci); att_cf = max_sz(att_cf, fine * C);
+        if (training && ad.d > 0 && ad.h > 0 && ad.w > 0) att_partmax = max_sz(att_partmax, att_part_floats(ad));
     }
     B.saved_bytes = S.off;
     // scratch
@@ -238,7 +273,26 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         }
     }
     if (skmax) B.skws = T.take(skmax);
+    for (int j = 0; att_on && j + 1 < nb; ++j) {
+        const LevelDims& lo = ND.u[up_unit(j)].out;
+        statmax = max_sz(statmax, (size_t)crop_stats_parts(lo.vox, p->chan(j)) * p->chan(j) * 3);
+    }
     B.stats = T.take(statmax);
+    if (att_on) {
+        B.att_phi = T.take(att_dec);
+        size_t cc = 0;      // coarse voxels x C/2, maximum over the levels
+        for (int j = 0; j + 1 < nb; ++j) { const AttDims ad = att_dims(p, ND, N, j, up_unit(j)); cc = max_sz(cc, (size_t)N * (ad.d > 0 ? ad.d : 0) * ad.h * ad.w * (ad.C / 2)); }
+        B.att_phires = T.take(cc);
+        if (training) {
+            B.att_tmp = T.take(att_cf);
+            B.att_tf = T.take(att_fine); B.att_tc = T.take(2 * att_coarse); B.att_df = T.take(cc); B.att_dphi = T.take(att_dec);
+            B.att_part = T.take(att_partmax);
+            for (int j = 0; j + 1 < nb; ++j) {
+                const LevelDims& lo = ND.u[up_unit(j)].out;
+                B.att[j].bnpart = T.take((size_t)bn_bwd_parts(lo.vox, p->chan(j)) * 3 * p->chan(j));
+            }
+        }
+    }
     B.small = T.take((size_t)5 * p->chan(nb - 1) + 64);   // [4][C] backward coefficients + [C] PReLU scratch
     B.bnred = T.take((size_t)BN_PRERED * p->chan(nb - 1) * 3);
     B.ones = T.take(p->chan(nb - 1)); B.zeros = T.take((size_t)4 * p->chan(nb - 1));
@@ -259,7 +313,9 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
             const size_t n = ND.X[j].vox * p->chan(j);        // the level's input grid is its largest
             B.g1[j] = T.take(n); B.g2[j] = T.take(n);
             if (j + 1 < nb) B.dcat[j] = T.take(2 * n);
-            if (valid && j + 1 < nb) B.gskip[j] = T.take(ND.E[j].vox * p->chan(j));
+            if ((valid || att_on) && j + 1 < nb) B.gskip[j] = T.take(ND.E[j].vox * p->chan(j));
+            // attention: gradient of the (cropped) skip as the gate sees it; 'same' convs: that IS the skip's gradient
+            if (att_on && j + 1 < nb) B.att[j].gx = valid ? T.take(ND.u[up_unit(j)].out.vox * p->chan(j)) : B.gskip[j];
         }
     } else {
         B.bnpart = B.slab = nullptr;
@@ -302,11 +358,13 @@ int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
     E3_REQUIRE(cfg->normalization >= 0 && cfg->normalization <= 2, E3_ERR_UNSUPPORTED, "normalization must be 0 (none), 1 (batch) or 2 (group)");
     if (cfg->normalization == 2)
         E3_REQUIRE(cfg->num_groups >= 1 && cfg->start_filts % cfg->num_groups == 0, E3_ERR_INVALID, "num_groups must divide every channel count");
+    E3_REQUIRE(cfg->attention >= 0 && cfg->attention <= 2, E3_ERR_INVALID, "attention must be 0 (off), 1 (dim=3) or 2 (dim=2)");
     const bool last_norm = cfg->normalization != 0, all_norm = last_norm && cfg->full_norm != 0;
     e3_unet_plan* p = new e3_unet_plan();
     p->cfg = *cfg;
     p->n_bn = 0;
     const int nb = cfg->n_blocks;
+    p->att.assign(cfg->attention ? nb : 0, AttUnit{});
     for (int i = 0; i < nb; ++i) {   // unet.py:832-850
         const std::string b = "down_convs." + std::to_string(i) + ".";
         const int ins = i == 0 ? cfg->in_channels : p->chan(i - 1), outs = p->chan(i);
@@ -318,6 +376,23 @@ int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
         const std::string b = "up_convs." + std::to_string(k) + ".";
         const int ins = p->chan(j + 1), outs = p->chan(j);
         add_unit(p, b + (cfg->up_resize ? "upconv.conv" : "upconv"), b + "norm0", ins, outs, j, p->planar(j), cfg->up_resize ? 2 : 1, all_norm, b + "act0");   // unet.py:152-176,365-375
+        if (cfg->attention) {            // GridAttention(in_channels=outs, gating_channels=ins) (unet.py:376-379,452-505); inter_channels = outs / 2
+            const std::string a = b + "attention.";
+            const int T = cfg->attention == 2 ? 4 : 8, ci = outs / 2;
+            AttUnit& au = p->att[j];
+            au.p_ww = add_param(p, a + "w.0.weight", (int64_t)outs * outs, 0);
+            au.p_wb = add_param(p, a + "w.0.bias", outs, 0);
+            au.p_g = add_param(p, a + "w.1.weight", outs, 0);
+            au.p_be = add_param(p, a + "w.1.bias", outs, 0);
+            au.p_rm = add_param(p, a + "w.1.running_mean", outs, 1);
+            au.p_rv = add_param(p, a + "w.1.running_var", outs, 1);
+            au.bn_index = p->n_bn++;
+            au.p_theta = add_param(p, a + "theta.weight", (int64_t)ci * outs * T, 0);
+            au.p_phi_w = add_param(p, a + "phi.weight", (int64_t)ci * ins, 0);
+            au.p_phi_b = add_param(p, a + "phi.bias", ci, 0);
+            au.p_psi_w = add_param(p, a + "psi.weight", ci, 0);
+            au.p_psi_b = add_param(p, a + "psi.bias", 1, 0);
+        }
         add_unit(p, b + "conv1", b + "norm1", cfg->merge_add ? outs : 2 * outs, outs, j, p->planar(j), 0, all_norm, b + "act1");   // unet.py:352-360
         add_unit(p, b + "conv2", b + "norm2", outs, outs, j, p->planar(j), 0, last_norm, b + "act2");
     }
@@ -474,6 +549,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         const LevelDims& lo = ND.u[k].out;         // the unit's output tensor
         const LevelDims& ci = ND.u[k].in;          // plain convs: the grid the conv kernel runs on (== lo unless conv_mode='valid')
         const bool vcrop = valid && !u.is_up;      // 'valid' conv = the 'same' conv on the input grid, cropped by the padding
+        const float* const unit_in = cur; const int unit_in_ldc = cur_ldc;      // (the gating signal of the block's GridAttention)
         const bool is_enc_conv2 = !u.is_up && u.name.compare(0, 10, "down_convs") == 0 && u.name.find("conv2") != std::string::npos;
         const bool pool_after = is_enc_conv2 && u.level < nb - 1;
         const int kd = u.planar ? 1 : 2;
@@ -597,7 +673,43 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         } else if (pool_after) {
             RUN(launch_maxpool(b.act, b.act_ldc, B.pooled[u.level], kd, N, lo.D, lo.H, lo.W, u.cout, s));
         }
-        if (u.is_up && valid) {      // centre-crop the encoder's skip activation into the second half of the concat buffer (unet.py:300-325)
+        if (u.is_up && cfg.attention) {
+            // genc = GridAttention(enc, dec) (unet.py:393): the (cropped) skip, gated by the block's INPUT, goes through W + BatchNorm into the
+            // second half of the concat buffer
+            const int j = u.level, C = u.cout;
+            const LevelDims& e = ND.E[j];
+            const UnitBufs& eb = B.ub[2 * j + 1];
+            const AttUnit& au = plan->att[j];
+            Buffers::AttBufs& ab = B.att[j];
+            const AttDims ad = att_dims(plan, ND, N, j, k);
+            E3_REQUIRE(ad.d >= 1 && ad.h >= 1 && ad.w >= 1, E3_ERR_INVALID, "attention: a skip tensor is smaller than theta's 2x2x2 kernel");
+            const AttParams ap = att_params(params, au);
+            const float* xs = eb.act; int ldx = eb.act_ldc;
+            if (valid) {
+                RUN(launch_crop_copy(eb.act, ab.x, C, C, N, e.D, e.H, e.W, lo.D, lo.H, lo.W, ND.sd_[j], ND.sh_[j], ND.sw_[j], s));
+                xs = ab.x; ldx = C;
+            }
+            RUN(launch_att_gate_fwd(ad, xs, ldx, unit_in, unit_in_ldc, ap, ab.f, ab.sgm, ab.att, B.att_phi, B.att_phires, s));
+            float* const half = B.cat[j] + C;
+            if (!training) {      // eval: the BatchNorm (running statistics) folds into W's epilogue
+                RUN(launch_bn_fold(P(au.p_g), P(au.p_be), P(au.p_rm), P(au.p_rv), P(au.p_wb), cfg.bn_eps, ab.scale, ab.shift, C, s));
+                RUN(launch_att_out_fwd(ad, xs, ldx, ab.att, ap, ab.scale, ab.shift, half, 2 * C, s));
+            } else {
+                if (frozen) {
+                    RUN(launch_att_out_fwd(ad, xs, ldx, ab.att, ap, nullptr, nullptr, ab.raw, C, s));
+                    RUN(launch_bn_frozen(P(au.p_g), P(au.p_be), P(au.p_rm), P(au.p_rv), cfg.bn_eps, ab.mean, ab.invstd, ab.scale, ab.shift, C, s));
+                } else {
+                    RUN(launch_att_out_fwd(ad, xs, ldx, ab.att, ap, nullptr, nullptr, B.att_tmp, C, s));
+                    RUN(launch_splitk_reduce(B.att_tmp, 1, 0, nullptr, ab.raw, C, C, lo.vox, B.stats, s));      // copy + batch statistics
+                    BnFinalizeArgs f{};
+                    f.stats = B.stats; f.parts = crop_stats_parts(lo.vox, C); f.C = C; f.gamma = P(au.p_g); f.beta = P(au.p_be); f.group = 1;
+                    f.running_mean = P(au.p_rm); f.running_var = P(au.p_rv); f.momentum = momenta[au.bn_index]; f.eps = cfg.bn_eps;
+                    f.mean = ab.mean; f.invstd = ab.invstd; f.scale = ab.scale; f.shift = ab.shift; f.scratch = B.bnred;
+                    RUN(launch_bn_finalize(f, s));
+                }
+                RUN(launch_bn_relu_apply(ab.raw, C, ab.scale, ab.shift, half, 2 * C, nullptr, 2, N, lo.D, lo.H, lo.W, C, s, ActArg(1.f)));   // (no activation)
+            }
+        } else if (u.is_up && valid) {      // centre-crop the encoder's skip activation into the second half of the concat buffer (unet.py:300-325)
             const int j = u.level;
             const LevelDims& e = ND.E[j];
             const UnitBufs& eb = B.ub[2 * j + 1];
@@ -727,6 +839,32 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
                 E3_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_event, s)); event_done = true;
             }
         }
+        AttDims att_d{}; AttParams att_p{};
+        if (u.is_up && cfg.attention) {
+            // GridAttention backward (unet.py:393,509-530): the gradient of the concat buffer's second half -> BatchNorm -> W -> gate; the
+            // gradients of x (the skip) and, after this unit's data gradient below, of the gating signal
+            const int C = u.cout;
+            const AttUnit& au = plan->att[j];
+            Buffers::AttBufs& ab = B.att[j];
+            att_d = att_dims(plan, ND, N, j, (size_t)k); att_p = att_params(params, au);
+            const AttParams ag = att_params(grads, au);
+            const UnitBufs& eb = B.ub[2 * j + 1];
+            const float* xs = valid ? ab.x : eb.act; const int ldx = valid ? C : eb.act_ldc;
+            float* dz = B.g1[j];                 // (free: the gradient of this unit's activation sits in dcat)
+            BnBwdArgs a{};
+            a.x = ab.raw; a.x_ldc = C; a.mean = ab.mean; a.invstd = ab.invstd; a.scale = ab.scale; a.shift = ab.shift; a.gamma = P(au.p_g);
+            a.act = ActArg(1.f);
+            a.g1 = cfg.merge_add ? B.dcat[j] : B.dcat[j] + C; a.g1_ldc = cfg.merge_add ? C : 2 * C;
+            a.kd = 2; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.C = C;
+            a.parts = bn_bwd_parts(lo.vox, C); a.part = ab.bnpart; a.coef = B.small; a.dx = dz; a.dx_ldc = C;
+            RUN(launch_bn_bwd_reduce(a, s));
+            RUN(launch_bn_bwd_finalize(a.part, a.parts, C, (float)(1.0 / (double)lo.vox), G(au.p_g), G(au.p_be), B.small, s));
+            if (frozen) a.coef = B.zeros;
+            RUN(launch_bn_bwd_apply(a, s));
+            bias_jobs.push_back({a.part, a.parts, 3 * C, 2 * C, C, G(au.p_wb)});
+            RUN(launch_att_bwd(att_d, dz, xs, ldx, B.ub[k - 1].act, B.ub[k - 1].act_ldc, ab.f, ab.sgm, ab.att, att_p, ag, ab.gx, B.att_dphi, B.att_tf,
+                               B.att_tc, B.att_df, B.att_part, s));
+        }
         // -- BN + ReLU (+ pool, + skip) backward -> dxr = gradient w.r.t. the raw conv output
         float* dxr = B.g2[j];
         bool fuse_first = false; SmallWgradFuse first_fuse{};
@@ -744,8 +882,13 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
             if (k == nunits - 1) {      // incoming gradient = that of the 1x1x1 head, recomputed on the fly
                 a.g1 = nullptr; a.head_dy = dy; a.head_w = P(plan->p_final_w); a.head_cout = cfg.out_channels; a.head_S = ND.Y.vox / N;
             }
+            else if (pooled_unit && cfg.attention && !valid) {   // the GridAttention's backward wrote the skip's gradient
+                a.g1 = B.gskip[j]; a.g1_ldc = u.cout; a.gpool = g; a.a = b.act; a.a_ldc = b.act_ldc; a.pooled = B.pooled[j];
+            }
             else if (pooled_unit && valid) {   // the skip was centre-cropped: its gradient is zero outside that box
                 const LevelDims& dc = ND.u[2 * nb + 3 * (nb - 2 - j)].out;
+                if (cfg.attention) RUN(launch_pad_box(B.att[j].gx, B.gskip[j], u.cout, N, dc.D, dc.H, dc.W, lo.D, lo.H, lo.W, s, ND.sd_[j], ND.sh_[j], ND.sw_[j], u.cout));
+                else
                 RUN(launch_pad_box(cfg.merge_add ? B.dcat[j] : B.dcat[j] + u.cout, B.gskip[j], u.cout, N, dc.D, dc.H, dc.W, lo.D, lo.H, lo.W, s,
                                    ND.sd_[j], ND.sh_[j], ND.sw_[j], cfg.merge_add ? u.cout : 2 * u.cout));
                 a.g1 = B.gskip[j]; a.g1_ldc = u.cout; a.gpool = g; a.a = b.act; a.a_ldc = b.act_ldc; a.pooled = B.pooled[j];
@@ -918,6 +1061,8 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
             if (k == 0) { if (cfg.in_channels > 1) RUN(launch_ndhwc_to_ncdhw(B.g1[0], cfg.in_channels, dx, N, cfg.in_channels, ND.X[0].vox / N, s)); }
             g = out; g_ldc = (to_cat && !cfg.merge_add) ? 2 * u.cout : u.cin;   // concat: the next unit (upconv) reads the first half, ldc = 2*C; add: d(up + skip) goes to both
         }
+        if (u.is_up && cfg.attention)      // the block's input is also the gate's gating signal: + dphi . phi_w
+            RUN(launch_att_bwd_gate_input(att_d, att_resized(att_d) ? B.att_dphi : B.att_df, att_p, B.g1[j + 1], u.cin, s));
     }
     if (!bias_jobs.empty()) RUN(launch_colsum_multi(bias_jobs.data(), (int)bias_jobs.size(), s));
     if (!wred_jobs.empty()) RUN(launch_wgrad_reduce_multi(wred_jobs.data(), (int)wred_jobs.size(), s));

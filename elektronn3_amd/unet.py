@@ -43,7 +43,9 @@ class _Plan:
             check(lib.e3_unet_param_info(handle, i, buf, 160, ctypes.byref(numel), ctypes.byref(kind)))
             self.names.append(buf.value.decode())
             self.kinds.append(kind.value)
-        self.bn_names = [n[:-len('.weight')] for n in self.names if '.norm' in n and n.endswith('.weight')]
+        # BatchNorm layers in table order (momenta are passed in this order): the blocks' norms and, with attention=True, the BatchNorm
+        # behind each GridAttention's output transform ('up_convs.i.attention.w.1')
+        self.bn_names = [n[:-len('.weight')] for n in self.names if ('.norm' in n or '.attention.w.1.' in n) and n.endswith('.weight')]
         self.n_bn = lib.e3_unet_bn_count(handle)
         self.out_channels = int(key[1])
         assert self.n_bn == len(self.bn_names)
@@ -265,7 +267,7 @@ def _flat_views(plan, tens, device):
 # tensors in table order and calls ONE registered operator; the operator (and its autograd formula) run the same native entry points as
 # the eager path.  Functional by construction: the updated running statistics are RETURNED and copied back by the scripted code.
 def _plan_key_from_floats(key: List[float]):
-    ints = (0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11)
+    ints = (0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 13)
     return tuple(int(round(v)) if i in ints else float(v) for i, v in enumerate(key))
 
 
@@ -414,6 +416,52 @@ class ResizeConv(nn.Module):
         raise RuntimeError('elektronn3_amd sub-modules only hold parameters; call UNet.forward')
 
 
+class GridAttention(nn.Module):
+    """Parameter container of the reference's GridAttention (unet.py:452-541; Attention U-Net, arXiv:1804.03999): ``theta`` (k = s = 2 conv
+    of the skip, no bias), ``phi`` (1x1x1 conv of the gating signal), ``psi`` (1x1x1 conv to one channel) and the output transform
+    ``w = Sequential(conv 1x1x1, BatchNorm)``.  Same state_dict keys and the same initialisation (unet.py:532-541)."""
+
+    def __init__(self, in_channels, gating_channels, inter_channels=None, dim=3, sub_sample_factor=2):
+        super().__init__()
+        assert dim in [2, 3]
+        if sub_sample_factor not in (2, (2,) * dim, [2] * dim):
+            raise NotImplementedError('GridAttention on the HIP path: sub_sample_factor=2 (what UpConvBlock passes, unet.py:377-379)')
+        self.dim = dim
+        self.sub_sample_factor = (2,) * dim
+        self.sub_sample_kernel_size = self.sub_sample_factor
+        self.in_channels, self.gating_channels = in_channels, gating_channels
+        self.inter_channels = inter_channels if inter_channels is not None else max(in_channels // 2, 1)
+        if self.inter_channels != in_channels // 2:
+            raise NotImplementedError('GridAttention on the HIP path: inter_channels = in_channels // 2 (the default, unet.py:475-478)')
+        Conv, Norm = _LAYERS[dim][0], _LAYERS[dim][3]
+        self.upsample_mode = 'trilinear' if dim == 3 else 'bilinear'
+        self.w = nn.Sequential(Conv(in_channels, in_channels, kernel_size=1), Norm(in_channels))
+        self.theta = Conv(in_channels, self.inter_channels, kernel_size=self.sub_sample_kernel_size, stride=self.sub_sample_factor, bias=False)
+        self.phi = Conv(gating_channels, self.inter_channels, kernel_size=1, stride=1, padding=0, bias=True)
+        self.psi = Conv(self.inter_channels, 1, kernel_size=1, stride=1, bias=True)
+        self.init_weights()
+
+    def init_weights(self):
+        def weight_init(m):
+            name = m.__class__.__name__
+            if name.find('Conv') != -1 or name.find('Linear') != -1:
+                nn.init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
+            elif name.find('BatchNorm') != -1:
+                nn.init.normal_(m.weight.data, 1.0, 0.02)
+                nn.init.constant_(m.bias.data, 0.0)
+        self.apply(weight_init)
+
+    def forward(self, x, g):
+        raise RuntimeError('elektronn3_amd sub-modules only hold parameters; call UNet.forward')
+
+
+class DummyAttention(nn.Module):
+    """attention=False (unet.py:544-546): the skip passes through."""
+
+    def forward(self, x, g):
+        return x, None
+
+
 class DownConv(nn.Module):
     """Parameter container for one encoder block (two convs, two norms, max-pool) -- reference: unet.py:202-253."""
 
@@ -446,7 +494,7 @@ class UpConv(nn.Module):
     """Parameter container for one decoder block (transposed conv, two convs, three norms) -- reference: unet.py:328-408."""
 
     def __init__(self, in_channels, out_channels, planar=False, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu',
-                 up_mode='transpose', conv_mode='same'):
+                 up_mode='transpose', conv_mode='same', attention=False):
         super().__init__()
         self.in_channels, self.out_channels, self.planar = in_channels, out_channels, planar
         self.merge_mode = merge_mode
@@ -471,7 +519,9 @@ class UpConv(nn.Module):
         self.norm0 = norm() if full_norm else nn.Identity()                                   # unet.py:369-375
         self.norm1 = norm() if full_norm else nn.Identity()
         self.norm2 = norm()
-        self.att = None   # Trainer reads model.up_convs[i].att (trainer.py:611-617); always None without attention
+        # unet.py:376-382: the gate sees the skip (in_channels // 2 channels) and the block's input as the gating signal
+        self.attention = GridAttention(in_channels=in_channels // 2, gating_channels=in_channels, dim=dim) if attention else DummyAttention()
+        self.att = None   # Trainer reads model.up_convs[i].att (trainer.py:611-617); None without attention
 
     def forward(self, enc, dec):
         raise RuntimeError('elektronn3_amd sub-modules only hold parameters; call UNet.forward')
@@ -532,7 +582,6 @@ class UNet(nn.Module):
         # -- what the HIP path implements this round
         unsupported = []
         if up_mode == 'upsample': unsupported.append("up_mode='upsample' (upconv2 has no branch for it in the reference either)")
-        if attention: unsupported.append('attention=True')
         if isinstance(activation, str) and activation not in ('relu', 'leaky', 'prelu', 'rrelu', 'silu', 'lin'):
             raise ValueError(f'unknown activation {activation!r}')
         if _activation_slope(activation) is None: unsupported.append(f'activation={activation!r}')
@@ -546,6 +595,9 @@ class UNet(nn.Module):
                 raise ValueError('num_channels must be divisible by num_groups')      # (torch.nn.GroupNorm's own check)
         elif normalization not in ('batch', 'none', 'instance'): unsupported.append(f'normalization={normalization!r}')
         if conv_mode not in ('same', 'valid'): unsupported.append(f'conv_mode={conv_mode!r}')
+        if attention and (normalization == 'instance' or normalization.startswith('group')):
+            # (the gate's own nn.BatchNorm needs the whole batch; these norms run one native call per sample)
+            unsupported.append(f'attention=True with normalization={normalization!r}')
         if start_filts % 8 != 0: unsupported.append(f'start_filts={start_filts} (must be a multiple of 8)')
         if not (1 <= out_channels <= 16): unsupported.append(f'out_channels={out_channels} (1..16)')
         if not (in_channels < 8 or in_channels % 8 == 0): unsupported.append(f'in_channels={in_channels}')
@@ -578,11 +630,12 @@ class UNet(nn.Module):
             ins = outs
             outs = ins // 2
             self.up_convs.append(UpConv(ins, outs, planar=(n_blocks - 2 - i) in self.planar_blocks, dim=dim,
-                                        normalization=normalization, full_norm=full_norm, merge_mode=merge_mode, activation=activation, up_mode=up_mode, conv_mode=conv_mode))
+                                        normalization=normalization, full_norm=full_norm, merge_mode=merge_mode, activation=activation, up_mode=up_mode, conv_mode=conv_mode,
+                                        attention=attention))
         self.conv_final = _LAYERS[dim][0](outs, out_channels, kernel_size=1)
         self.apply(self.weight_init)
         self._script_key = [float(v) for v in self._plan_key()]      # (read by the scripted forward)
-        self._script_ok = normalization != 'instance' and dim == 3 and self._rrelu_interval() is None     # (train-mode RReLU needs a per-call seed)
+        self._script_ok = normalization != 'instance' and dim == 3 and self._rrelu_interval() is None and not attention     # (train-mode RReLU needs a per-call seed)
 
     @staticmethod
     def weight_init(m):
@@ -611,7 +664,8 @@ class UNet(nn.Module):
                 1 if getattr(self, 'full_norm', True) else 0, 1 if self.merge_mode == 'add' else 0,
                 _num_groups(self.normalization) if self.normalization.startswith('group') else 0,
                 {'transpose': 0, 'resizeconv_nearest': 1, 'resizeconv_linear': 2, 'resizeconv_nearest1': 3, 'resizeconv_linear1': 4}[self.up_mode],
-                1 if self.conv_mode == 'valid' else 0, float(_activation_slope(self.activation)))
+                1 if self.conv_mode == 'valid' else 0, float(_activation_slope(self.activation)),
+                (2 if self.dim == 2 else 1) if getattr(self, 'attention', False) else 0)
 
     def _plan(self):
         return _get_plan(self._plan_key())

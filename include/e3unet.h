@@ -65,6 +65,9 @@ typedef struct e3_unet_cfg {
                              * output is smaller than the input, see e3_unet_out_dims) */
     float act_slope;        /* activation (get_activation, unet.py:183-199): 0 = 'relu', 0.1 = 'leaky' (LeakyReLU(0.1)), 1 = 'lin' (identity), 2 = 'silu',
                              * 3 = 'prelu' (nn.PReLU(1) per activation: parameters '<block>.act<k>.weight' join the table) */
+    int32_t attention;      /* 0: attention=False (DummyAttention); 1: attention=True, dim=3 (GridAttention with a 2x2x2 theta, unet.py:376-379,452-541);
+                             * 2: attention=True, dim=2 (2x2 theta on the depth-1 volume).  Parameters 'up_convs.i.attention.{w.0,w.1,theta,phi,psi}.*'
+                             * join the table after the block's up-convolution; fp32 path only */
 } e3_unet_cfg;
 
 typedef struct e3_unet_plan e3_unet_plan;

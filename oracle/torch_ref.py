@@ -56,6 +56,22 @@ def autocrop(from_down, from_up):
     return from_down, from_up
 
 
+def grid_attention(sd, p, x, g, training, momentum=0.1, eps=1e-5):
+    """GridAttention.forward (unet.py:509-530) restated with ATen ops; p = 'up_convs.i.attention.'.  Returns (W(att * x) through its BatchNorm, att)."""
+    nd = x.dim() - 2
+    conv = F.conv3d if nd == 3 else F.conv2d
+    mode = 'trilinear' if nd == 3 else 'bilinear'
+    theta_x = conv(x, sd[p + 'theta.weight'], None, stride=2)
+    phi_g = F.interpolate(conv(g, sd[p + 'phi.weight'], sd[p + 'phi.bias']), size=theta_x.shape[2:], mode=mode, align_corners=False)
+    f = F.relu(theta_x + phi_g)
+    att = torch.sigmoid(conv(f, sd[p + 'psi.weight'], sd[p + 'psi.bias']))
+    att = F.interpolate(att, size=x.shape[2:], mode=mode, align_corners=False)
+    wy = conv(att.expand_as(x) * x, sd[p + 'w.0.weight'], sd[p + 'w.0.bias'])
+    wy = F.batch_norm(wy, sd[p + 'w.1.running_mean'], sd[p + 'w.1.running_var'], sd[p + 'w.1.weight'], sd[p + 'w.1.bias'],
+                      training=training, momentum=momentum, eps=eps)
+    return wy, att
+
+
 def instance_norm_names(n_blocks, full_norm=True):
     """Names of the norm layers of UNet(normalization='instance') -- they have no state_dict entries; pass the result as
     sd['__instance_norms__']."""
@@ -95,6 +111,8 @@ def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True):
             w = sd[p + 'upconv.weight']
             up = (F.conv_transpose3d if w.dim() == 5 else F.conv_transpose2d)(x, w, sd[p + 'upconv.bias'], stride=tuple(w.shape[2:]))
         skip, up = autocrop(enc[-(i + 2)], up)
+        if p + 'attention.theta.weight' in sd:      # attention=True: the (cropped) skip is gated by the block's input (unet.py:391-393)
+            skip, _ = grid_attention(sd, p + 'attention.', skip, x, training)
         up = _act(_bn(up, sd, p + 'norm0', training), sd, p + 'act0')
         cat = sd[p + 'conv1.weight'].shape[1] == 2 * up.shape[1]      # merge_mode 'concat' vs 'add' (unet.py:398-401) shows in conv1's Cin
         y = torch.cat((up, skip), 1) if cat else up + skip

@@ -183,10 +183,10 @@ def make_rrelu_eval(unet, out, seed=17):
     np.savez_compressed(out, **d)
 
 
-def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu', up_mode='transpose', conv_mode='same'):
+def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu', up_mode='transpose', conv_mode='same', attention=False):
     torch.manual_seed(seed)
     model = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
-                      planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode, conv_mode=conv_mode)
+                      planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode, conv_mode=conv_mode, attention=attention)
     # make BN affine + conv bias non-trivial so that the fixtures exercise them
     with torch.no_grad():
         for name, p in model.named_parameters():
@@ -221,6 +221,8 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
         d['cfg.up_mode'] = np.array(up_mode)
     if conv_mode != 'same':
         d['cfg.conv_mode'] = np.array(conv_mode)
+    if attention:
+        d['cfg.attention'] = np.array(1)
     for k, v in sd0.items():
         d['sd0/' + k] = v
     for k, v in model.state_dict().items():
@@ -233,7 +235,7 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
         d['logits_eval'] = npy(model(x))
     # fp64 reference of the same step (tolerances are stated against it)
     m64 = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
-                    planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode, conv_mode=conv_mode).double()
+                    planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode, conv_mode=conv_mode, attention=attention).double()
     m64.load_state_dict({k: torch.as_tensor(v).double() if v.dtype != np.int64 else torch.as_tensor(v) for k, v in sd0.items()})
     m64.train()
     o64 = m64(x.double())
@@ -459,6 +461,13 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'add':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_add_odd.npz', seed=6, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 14, 19), batch=2, merge_mode='add')
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'attention':     # attention=True (GridAttention, unet.py:452-541): odd sizes (phi(g) and the gate are resized),
+        # dim=2, conv_mode='valid' + a planar block (theta halves the depth the pooling kept), merge_mode='add'
+        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_attention_odd.npz', seed=17, n_blocks=3, start_filts=8, planar_blocks=(), shape=(9, 14, 19), batch=2, attention=True)
+        make_unet_case(unet, loss_mod, f'{HERE}/unet2d_nb3_sf8_attention.npz', seed=18, n_blocks=3, start_filts=8, planar_blocks=(), shape=(37, 46), batch=2, dim=2, attention=True)
+        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_attention_valid_planar0.npz', seed=19, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(22, 45, 47), batch=2, conv_mode='valid', attention=True)
+        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_attention_add.npz', seed=20, n_blocks=3, start_filts=8, planar_blocks=(), shape=(8, 12, 16), batch=2, merge_mode='add', activation='leaky', attention=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'unet2d':    # only the dim=2 fixture
         make_unet_case(unet, loss_mod, f'{HERE}/unet2d_nb3_sf8_odd.npz', seed=3, n_blocks=3, start_filts=8, planar_blocks=(), shape=(37, 46), batch=2, dim=2)

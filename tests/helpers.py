@@ -36,6 +36,8 @@ def unet_cfg(npz):
         cfg['activation'] = str(npz['cfg.activation'])
     if 'cfg.merge_mode' in npz.files:
         cfg['merge_mode'] = str(npz['cfg.merge_mode'])
+    if 'cfg.attention' in npz.files:
+        cfg['attention'] = bool(int(npz['cfg.attention']))
     if 'cfg.full_norm' in npz.files:
         cfg['full_norm'] = bool(int(npz['cfg.full_norm']))
     return cfg
@@ -44,6 +46,8 @@ def unet_cfg(npz):
 def is_prebn_bias(k, names=None, paramless_norms=()):
     """Bias of a (transposed) conv that feeds a train-mode BatchNorm: analytically zero gradient.  ``names`` (all parameter
     names) tells whether the norm after that conv exists at all (normalization='none' / full_norm=False make it nn.Identity)."""
+    if k.endswith('.attention.w.0.bias'):       # GridAttention's output transform: 1x1x1 conv -> nn.BatchNorm, always (unet.py:488-491)
+        return True
     if not (k.endswith('.bias') and ('conv1' in k or 'conv2' in k or 'upconv' in k) and not k.startswith('conv_final')):
         return False
     if names is None:

@@ -122,6 +122,37 @@ def test_unet_train_step(case):
         assert err_o <= max(3 * err_r, 1e-4), (k, err_o, err_r)
 
 
+@pytest.mark.parametrize('case', ['unet_nb3_sf8_attention_odd.npz', 'unet2d_nb3_sf8_attention.npz', 'unet_nb3_sf8_attention_valid_planar0.npz',
+                                  'unet_nb3_sf8_attention_add.npz'])
+def test_torch_restatement_of_grid_attention_train_step(case):
+    """attention=True is outside the C oracle; its checker is oracle/torch_ref.py's ATen restatement of GridAttention.forward
+    (unet.py:509-530).  Pinned here: logits, loss, every gradient and the running statistics of the reference's own train step."""
+    import torch
+    from oracle.torch_ref import combined_loss, unet_forward
+    g = load_npz(case)
+    cfg = unet_cfg(g)
+    sd = {k: torch.from_numpy(np.array(v)).clone() for k, v in sub(g, 'sd0').items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running' not in k:
+            v.requires_grad_(True)
+    if cfg.get('conv_mode') == 'valid':
+        sd['__valid__'] = True
+    if cfg.get('activation') == 'leaky':
+        sd['__act_slope__'] = 0.1
+    out = unet_forward(sd, torch.from_numpy(g['x']), cfg['n_blocks'], cfg['planar_blocks'], training=True)
+    np.testing.assert_allclose(out.detach().numpy(), g['logits'], rtol=1e-5, atol=1e-6)
+    loss = combined_loss(out, torch.from_numpy(g['target']))
+    assert abs(float(loss) - float(g['loss'])) < 1e-6
+    loss.backward()
+    ref = sub(g, 'grad')
+    gnorm = np.sqrt(sum(float(np.sum(v.astype(np.float64) ** 2)) for v in ref.values()))
+    for k, v in ref.items():
+        assert np.abs(sd[k].grad.numpy() - v).max() <= 1e-5 * gnorm, k
+    for k, v in sub(g, 'sd1').items():
+        if 'running' in k:
+            np.testing.assert_allclose(sd[k].numpy(), v, rtol=1e-5, atol=1e-7, err_msg=k)
+
+
 def test_unet_eval_forward():
     g = load_npz('unet_nb2_sf8.npz')
     cfg = unet_cfg(g)

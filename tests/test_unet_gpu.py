@@ -24,7 +24,10 @@ CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_plana
          'unet_nb3_sf8_group4_odd.npz', 'unet_nb3_sf8_leaky_odd.npz', 'unet_nb2_sf8_lin_nonorm.npz',
          'unet_nb3_sf8_silu_odd.npz', 'unet_nb3_sf8_resizeconv_odd.npz',
          'unet_nb3_sf8_resizelinear_odd.npz', 'unet_nb3_sf8_resizenearest1_odd.npz',
-         'unet_nb3_sf8_prelu_odd.npz', 'unet_nb3_sf8_valid.npz']
+         'unet_nb3_sf8_prelu_odd.npz', 'unet_nb3_sf8_valid.npz',
+         # attention=True (GridAttention): odd sizes (both resizes are real interpolations), dim=2, conv_mode='valid' + planar block, merge 'add'
+         'unet_nb3_sf8_attention_odd.npz', 'unet2d_nb3_sf8_attention.npz', 'unet_nb3_sf8_attention_valid_planar0.npz',
+         'unet_nb3_sf8_attention_add.npz']
 
 
 def build(cfg, sd_np):
@@ -68,7 +71,11 @@ def test_train_step_matches_reference(case):
         for k in ref32:
             assert gr[k].shape == ref32[k].shape, k
             # analytically zero (bias feeding a train-mode BN / InstanceNorm; NOT for GroupNorm): absolute tolerance only
-            if is_prebn_bias(k, set() if str(cfg.get('normalization')).startswith('group') else set(ref32), instance_norm_names(cfg)):
+            # (conv_mode='valid' + attention: the gate's BatchNorm shift is a per-channel constant that an un-padded conv1 hands to a
+            # train-mode norm1, which removes it -- also analytically zero)
+            att_beta_zero = (cfg.get('conv_mode') == 'valid' and k.endswith('.attention.w.1.bias')
+                             and k.replace('attention.w.1.bias', 'norm1.weight') in ref32)
+            if att_beta_zero or is_prebn_bias(k, set() if str(cfg.get('normalization')).startswith('group') else set(ref32), instance_norm_names(cfg)):
                 assert np.abs(gr[k]).max() <= 1e-5 * gnorm, (k, np.abs(gr[k]).max())
                 continue
             errs[k] = (rel_l2(gr[k], ref64[k]), rel_l2(ref32[k], ref64[k]))
