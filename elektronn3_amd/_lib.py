@@ -99,6 +99,7 @@ _SIG = {
     'e3_swa_update': (_I, [_P, _I, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int64]),
     'e3_swa_swap': (_I, [_P, _I, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64)]),
     'e3_unet_set_rrelu': (_I, [_P, c_double, c_double, c_uint32]),
+    'e3_unet_attention_map': (_I, [c_void_p, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     'e3_adamw_state_floats': (c_size_t, [_I, POINTER(c_int64)]),
     'e3_adamw_state_offset': (c_size_t, [_I, POINTER(c_int64), _I]),
     'e3_adamw_step': (_I, [_P, _I, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), _P, _P, _P, _P,

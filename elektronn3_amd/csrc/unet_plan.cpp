@@ -448,6 +448,27 @@ int e3_unet_set_rrelu(e3_unet_plan* plan, double lower, double upper, unsigned s
     return E3_OK;
 }
 
+int e3_unet_attention_map(const e3_unet_plan* plan, void* stream, int N, int D, int H, int W, int training, void* saved, void* scratch,
+                          int block, float* out, int* Do, int* Ho, int* Wo) {
+    E3_REQUIRE(plan && N > 0 && D > 0 && H > 0 && W > 0, E3_ERR_INVALID, "bad argument");
+    E3_REQUIRE(plan->cfg.attention, E3_ERR_INVALID, "the plan was built with attention = 0");
+    const int nb = plan->cfg.n_blocks;
+    E3_REQUIRE(block >= 0 && block < nb - 1, E3_ERR_INVALID, "block must index a decoder block");
+    NetDims ND; net_dims(plan, N, D, H, W, ND);
+    E3_REQUIRE(ND.ok, E3_ERR_INVALID, "input too small for this network");
+    const int j = nb - 2 - block;                                  // up_convs[block] works at level nb - 2 - block
+    const LevelDims& lo = ND.u[(size_t)(2 * nb + 3 * block)].out;
+    if (Do) *Do = lo.D;
+    if (Ho) *Ho = lo.H;
+    if (Wo) *Wo = lo.W;
+    if (!out) return E3_OK;
+    E3_REQUIRE(scratch && (saved || !training), E3_ERR_INVALID, "the forward's workspaces are needed");
+    Buffers B;
+    plan_buffers(plan, N, D, H, W, training != 0, saved, scratch, B);
+    E3_CHECK_HIP(hipMemcpyAsync(out, B.att[j].att, lo.vox * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return E3_OK;
+}
+
 int e3_unet_profile_select(e3_unet_plan* plan, int layer, int which) {
     E3_REQUIRE(plan, E3_ERR_INVALID, "null plan");
     plan->prof_layer = layer; plan->prof_which = which; plan->prof_used = 0;
@@ -495,7 +516,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
     const bool training = (flags & E3_FWD_TRAINING) != 0;
     // frozen BatchNorm: the training-mode data flow (raw tensors and activations are saved for a backward) with the RUNNING statistics
     // in place of batch statistics and no update of them -- what autograd does for a module in eval mode
-    const bool frozen = training && (flags & E3_FWD_FROZEN_BN) != 0 && plan->cfg.normalization == 1;
+    const bool frozen = training && (flags & E3_FWD_FROZEN_BN) != 0 && (plan->cfg.normalization == 1 || plan->cfg.attention);
     const e3_unet_cfg& cfg = plan->cfg;
     const int nb = cfg.n_blocks;
     { NetDims nd0; net_dims(plan, N, D, H, W, nd0);
@@ -752,7 +773,7 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
                       void* bucket_event, int bucket_after_down_block, uint32_t flags) {
     E3_REQUIRE(plan && dy && x && params && grads && saved && scratch, E3_ERR_INVALID, "null argument");
     // the forward ran with E3_FWD_FROZEN_BN: the statistics are constants, so dx = gamma * invstd * dz (no mean / variance terms)
-    const bool frozen = (flags & E3_BWD_FROZEN_BN) != 0 && plan->cfg.normalization == 1;
+    const bool frozen = (flags & E3_BWD_FROZEN_BN) != 0 && (plan->cfg.normalization == 1 || plan->cfg.attention);
     hipStream_t s = (hipStream_t)stream;
     const e3_unet_cfg& cfg = plan->cfg;
     const int nb = cfg.n_blocks;

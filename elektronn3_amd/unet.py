@@ -169,9 +169,27 @@ def _native_backward(plan, dy, xin, tens, saved, b16, want_dx, sync=None, frozen
     return flat, views, dx
 
 
+def _store_attention_maps(module, plan, x, training, saved):
+    """up_convs[i].att = the block's attention map (N, 1, D, H, W) of this forward, as the reference's UpConvBlock keeps it for later
+    analysis (unet.py:382,394-395; plotted by the Trainer, trainer.py:611-617).  Copied out of the forward's workspaces on its stream."""
+    lib = _lib.load()
+    N, _, D, H, W = x.shape
+    dev = x.device
+    scratch = _get_scratch(dev, 256)
+    with torch.cuda.device(dev):
+        for i, blk in enumerate(module.up_convs):
+            do, ho, wo = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            args = (plan.handle, _lib.stream_ptr(dev), N, D, H, W, int(training), c_void_p(saved.data_ptr()) if saved is not None else None,
+                    c_void_p(scratch.data_ptr()), i)
+            check(lib.e3_unet_attention_map(*args, None, ctypes.byref(do), ctypes.byref(ho), ctypes.byref(wo)))
+            att = torch.empty((N, 1, do.value, ho.value, wo.value), dtype=torch.float32, device=dev)
+            check(lib.e3_unet_attention_map(*args, c_void_p(att.data_ptr()), None, None, None))
+            blk.att = att.squeeze(2) if module.dim == 2 else att
+
+
 class _UNetFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, softmax, want_bf16, x, *params):
+    def forward(ctx, module, mode, want_bf16, x, *params):
         plan = module._plan()
         in_dtype = x.dtype
         training = module.training or module._per_sample_norm()   # instance / group statistics also in eval mode
@@ -187,10 +205,14 @@ class _UNetFunction(torch.autograd.Function):
         tens = [t if t.is_contiguous() else t.contiguous() for t in tens]
         all_bf16 = lowp is not None and all(t.dtype == torch.bfloat16 for t in lowp if t.is_floating_point())
         # (grad mode is off inside Function.forward; needs_input_grad tells whether a backward can follow)
-        need_grad = any(ctx.needs_input_grad) and not softmax
+        # (needs_input_grad mirrors requires_grad of the inputs whatever the grad mode: `mode` carries torch.is_grad_enabled() of the caller,
+        # so that validation under torch.no_grad() takes the inference path instead of saving activations nobody will use)
+        softmax, grad_on = bool(mode & 1), bool(mode & 2)
+        need_grad = grad_on and any(ctx.needs_input_grad) and not softmax
         # a module in eval mode that a backward will follow (frozen-BatchNorm fine-tuning, training/recalibration.py:53-73 style uses):
         # the training data flow with the running statistics as constants
-        frozen = need_grad and not training and module.normalization == 'batch'
+        # (attention=True: the gates' own nn.BatchNorm layers are there whatever `normalization` says)
+        frozen = need_grad and not training and (module.normalization == 'batch' or bool(getattr(module, 'attention', False)))
         if need_grad and not training and not frozen:
             training = True            # (normalization='none': train and eval mode are the same function; take the flow that saves)
         # nn.RReLU in train mode: one seed per native call from torch's default generator (torch.manual_seed makes runs repeatable); the
@@ -203,6 +225,8 @@ class _UNetFunction(torch.autograd.Function):
         y, saved, xin, b16 = _native_forward(module, plan, x, tens, softmax, want_bf16 or (all_bf16 and in_dtype == torch.bfloat16),
                                              ctx.needs_input_grad[3], training or frozen,
                                              module._momenta(plan) if (training or frozen) else None, frozen=frozen)
+        if getattr(module, 'attention', False) and not b16:
+            _store_attention_maps(module, plan, x, training or frozen, saved)
         ctx.frozen = frozen
         out_dtype = torch.bfloat16 if (b16 and want_bf16) else in_dtype
         if training and not frozen and module.training:
@@ -850,12 +874,13 @@ class UNet(nn.Module):
             or getattr(self, 'compute_dtype', None) == torch.bfloat16
         if any(p.device != x.device for p in params):
             raise RuntimeError('input and parameters are on different devices')
+        mode = (1 if softmax else 0) | (2 if torch.is_grad_enabled() else 0)
         if self._per_sample_norm():
             # per-sample statistics in training AND eval mode (nn.InstanceNorm3d defaults, nn.GroupNorm): one native call per sample;
             # autograd sums the parameter gradients of the calls
-            y = torch.cat([_UNetFunction.apply(self, softmax, want_bf16, x[n:n + 1], *params) for n in range(x.shape[0])], 0)
+            y = torch.cat([_UNetFunction.apply(self, mode, want_bf16, x[n:n + 1], *params) for n in range(x.shape[0])], 0)
         else:
-            y = _UNetFunction.apply(self, softmax, want_bf16, x, *params)
+            y = _UNetFunction.apply(self, mode, want_bf16, x, *params)
         return y.squeeze(2) if self.dim == 2 else y
 
     @torch.jit.unused

@@ -137,6 +137,12 @@ int e3_unet_conv_info(const e3_unet_plan* plan, int layer, char* name, int name_
  * every unit derives its own stream, the draw is a hash of (seed, unit, element index)); the backward of such a forward must run with the SAME
  * seed set (the slopes are recomputed, no noise tensor is stored).  seed == 0: the fixed slope cfg.act_slope (eval mode: (lower+upper)/2). */
 int e3_unet_set_rrelu(e3_unet_plan* plan, double lower, double upper, unsigned seed);
+/* attention=True: the attention map of decoder block `block` (= index into UNet.up_convs) as the last e3_unet_forward left it in its
+ * workspaces -- `sigm_psi_f` of GridAttention.forward (unet.py:521-525), what UpConvBlock stores as `self.att` (unet.py:394-395) and the
+ * Trainer plots.  Same (N, D, H, W, training) and the same `saved` / `scratch` buffers as that forward; call it on the forward's stream before
+ * anything else reuses `scratch`.  out: (N, 1, Do, Ho, Wo) floats, or NULL to query the size only. */
+int e3_unet_attention_map(const e3_unet_plan* plan, void* stream, int N, int D, int H, int W, int training, void* saved, void* scratch,
+                          int block, float* out, int* Do, int* Ho, int* Wo);
 int e3_unet_profile_select(e3_unet_plan* plan, int layer, int which);
 int e3_unet_profile_read(e3_unet_plan* plan, double* mean_ms, int* launches);
 

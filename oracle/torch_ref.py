@@ -83,8 +83,9 @@ def instance_norm_names(n_blocks, full_norm=True):
     return tuple(names)
 
 
-def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True):
-    """sd: name -> tensor (parameters may require grad; running stats are updated in place when training)."""
+def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True, atts=None):
+    """sd: name -> tensor (parameters may require grad; running stats are updated in place when training).  atts: optional list that
+    receives the attention map of every decoder block (UpConvBlock.att, unet.py:394-395)."""
     enc = []
     for i in range(n_blocks):
         p = f'down_convs.{i}.'
@@ -112,7 +113,9 @@ def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True):
             up = (F.conv_transpose3d if w.dim() == 5 else F.conv_transpose2d)(x, w, sd[p + 'upconv.bias'], stride=tuple(w.shape[2:]))
         skip, up = autocrop(enc[-(i + 2)], up)
         if p + 'attention.theta.weight' in sd:      # attention=True: the (cropped) skip is gated by the block's input (unet.py:391-393)
-            skip, _ = grid_attention(sd, p + 'attention.', skip, x, training)
+            skip, att = grid_attention(sd, p + 'attention.', skip, x, training)
+            if atts is not None:
+                atts.append(att)
         up = _act(_bn(up, sd, p + 'norm0', training), sd, p + 'act0')
         cat = sd[p + 'conv1.weight'].shape[1] == 2 * up.shape[1]      # merge_mode 'concat' vs 'add' (unet.py:398-401) shows in conv1's Cin
         y = torch.cat((up, skip), 1) if cat else up + skip

@@ -112,6 +112,50 @@ def test_eval_forward_matches_reference():
     np.testing.assert_allclose(y.cpu().numpy(), g['logits_eval'], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('case', [c for c in CASES if 'attention' in c])
+def test_attention_eval_forward_matches_reference(case):
+    """attention=True in eval mode (the gate's BatchNorm folds into its 1x1x1 conv): the reference's own eval output."""
+    g = load_npz(case)
+    sd = sub(g, 'sd0'); sd.update(sub(g, 'sd1'))          # (the fixture's eval output follows its train step)
+    m = build(unet_cfg(g), sd).eval()
+    with torch.no_grad():
+        out = m(torch.from_numpy(g['x']).cuda())
+    np.testing.assert_allclose(out.cpu().numpy(), g['logits_eval'], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw', [dict(), dict(dim=2), dict(conv_mode='valid', planar_blocks=(0,))], ids=['3d_odd', '2d', 'valid_planar'])
+def test_attention_maps_are_kept_on_the_blocks(kw):
+    """UpConvBlock.att (unet.py:382,394-395; the Trainer plots it, trainer.py:611-617): after a forward every decoder block holds its attention
+    map (N, 1, *spatial of the skip), in train and in eval mode; values against the fp64 op sequence.  None without attention."""
+    from elektronn3_amd.unet import UNet
+    from oracle.torch_ref import unet_forward
+    torch.manual_seed(5)
+    m = UNet(1, 2, n_blocks=3, start_filts=16, attention=True, **kw).cuda()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith('bias'):
+                p.copy_(0.1 * torch.randn_like(p))
+    shape = (37, 50) if kw.get('dim') == 2 else ((30, 53, 55) if kw.get('conv_mode') == 'valid' else (11, 22, 27))
+    x = torch.randn(2, 1, *shape, device='cuda')
+    for train in (True, False):
+        m.train(train)
+        sd = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in m.state_dict().items()}
+        sd['__valid__'] = kw.get('conv_mode') == 'valid'
+        with torch.no_grad():
+            y = m(x)
+        atts = []
+        ref = unet_forward(sd, x.double(), 3, tuple(kw.get('planar_blocks', ())), training=train, atts=atts)
+        assert torch.allclose(y.double(), ref, rtol=1e-4, atol=1e-4)
+        assert len(atts) == len(m.up_convs) == 2
+        for blk, a in zip(m.up_convs, atts):
+            assert blk.att.shape == a.shape and blk.att.dtype == torch.float32
+            assert float((blk.att.double() - a).abs().max()) < 1e-5
+            assert 0.0 <= float(blk.att.min()) and float(blk.att.max()) <= 1.0
+    assert all(b.att is None for b in UNet(1, 2, n_blocks=2, start_filts=8).up_convs)
+
+
+@pytest.mark.gpu
 def test_rrelu_eval_forward_matches_reference_and_train_mode_runs():
     g = load_npz('unet_nb3_sf8_rrelu_eval.npz')
     m = build(unet_cfg(g), sub(g, 'sd0')).eval()
@@ -406,9 +450,13 @@ def test_cfg5_tile_eval_softmax_against_fp64():
                                 dict(up_mode='resizeconv_nearest'), dict(up_mode='resizeconv_nearest', planar_blocks=(0,), normalization='group', full_norm=False),
                                 dict(up_mode='resizeconv_linear', planar_blocks=(0,)), dict(up_mode='resizeconv_linear1', planar_blocks=(0,)),
                                 dict(conv_mode='valid'), dict(conv_mode='valid', planar_blocks=(0,), merge_mode='add', normalization='group'),
-                                dict(conv_mode='valid', up_mode='resizeconv_nearest', activation='leaky', full_norm=False)],
+                                dict(conv_mode='valid', up_mode='resizeconv_nearest', activation='leaky', full_norm=False),
+                                dict(attention=True), dict(attention=True, planar_blocks=(0,), merge_mode='add'),
+                                dict(attention=True, conv_mode='valid', activation='leaky', full_norm=False),
+                                dict(attention=True, normalization='none', up_mode='resizeconv_nearest')],
                          ids=['nonorm', 'sparsenorm', 'add', 'add_nonorm_planar', 'instance', 'group8', 'group16_sparse_add',
-                              'leaky', 'leaky_nonorm_planar', 'lin_group', 'silu_planar', 'silu_nonorm', 'prelu_planar', 'prelu_nonorm', 'resizeconv', 'resizeconv_planar_group_sparse', 'resizelinear_planar', 'resizelinear1_planar', 'valid', 'valid_planar_add_group', 'valid_resizeconv_leaky_sparse'])
+                              'leaky', 'leaky_nonorm_planar', 'lin_group', 'silu_planar', 'silu_nonorm', 'prelu_planar', 'prelu_nonorm', 'resizeconv', 'resizeconv_planar_group_sparse', 'resizelinear_planar', 'resizelinear1_planar', 'valid', 'valid_planar_add_group', 'valid_resizeconv_leaky_sparse',
+                              'attention', 'attention_planar_add', 'attention_valid_leaky_sparse', 'attention_nonorm_resizeconv'])
 def test_option_variants_against_pytorch_rocm(kw):
     """normalization='none' and full_norm=False (norm layers = nn.Identity, unet.py:77-80,238-242,369-375) at a size that runs the
     Winograd kernels (conv -> bias -> ReLU fused in their epilogue, also in training), and merge_mode='add' (unet.py:398-401: the skip
@@ -794,7 +842,8 @@ def test_low_precision_module_trains_with_fp32_compute(dt):
     assert not torch.equal(m.down_convs[0].norm0.running_mean.float(), torch.zeros(16, device='cuda'))
 
 
-@pytest.mark.parametrize('kw', [dict(), dict(planar_blocks=(0,), full_norm=False), dict(normalization='none')])
+@pytest.mark.parametrize('kw', [dict(), dict(planar_blocks=(0,), full_norm=False), dict(normalization='none'), dict(attention=True),
+                                dict(attention=True, normalization='none')])      # (the gates' BatchNorm layers are frozen also when the blocks have no norm)
 def test_backward_through_eval_mode_forward_against_fp64(kw):
     """Autograd through a module in eval mode (frozen-BatchNorm fine-tuning; the reference's autograd supports it, e.g. around
     training/recalibration.py:53-73): BatchNorm uses the running statistics as constants, which stay untouched.  Against the fp64 op
