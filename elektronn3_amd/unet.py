@@ -554,9 +554,9 @@ class UpConv(nn.Module):
 class UNet(nn.Module):
     """3D U-Net with the reference's interface (elektronn3/models/unet.py:755-771), executed by hand-written HIP
     kernels.  Options of the reference that are not yet on the HIP path raise ``NotImplementedError`` at
-    construction: ``up_mode='upsample'``,
-    ``attention=True``,
-    ``conv_mode`` other than ``'same'`` / ``'valid'``.  ``activation='rrelu'``: eval mode uses the fixed slope (1/8 + 1/3)/2 of
+    construction: ``up_mode='upsample'`` (the reference's ``upconv2`` has no branch for it either),
+    ``conv_mode`` other than ``'same'`` / ``'valid'``.  ``attention=True`` puts a ``GridAttention`` gate on every decoder block (fp32 kernels;
+    not with per-sample norms); ``up_convs[i].att`` holds the attention map of the last forward.  ``activation='rrelu'``: eval mode uses the fixed slope (1/8 + 1/3)/2 of
     ``nn.RReLU``; a train-mode forward draws a slope per negative element from U(1/8, 1/3) inside the kernels (a hash of a per-call seed taken
     from torch's generator, the unit and the element index; the backward recomputes it).  ``dim=2`` (Conv2d/BatchNorm2d/... parameters, 4D input) runs on the planar kernels: a 2D U-Net is
     the 3D one with every block planar and a depth of 1."""
