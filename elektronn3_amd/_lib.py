@@ -27,7 +27,7 @@ class E3Error(RuntimeError):
 
 class UNetCfg(ctypes.Structure):
     _fields_ = [('in_channels', c_int32), ('out_channels', c_int32), ('n_blocks', c_int32), ('start_filts', c_int32),
-                ('planar_mask', c_uint32), ('normalization', c_int32), ('bn_eps', c_float), ('full_norm', c_int32), ('merge_add', c_int32), ('num_groups', c_int32), ('up_resize', c_int32), ('conv_valid', c_int32), ('act_slope', c_float), ('attention', c_int32)]
+                ('planar_mask', c_uint32), ('normalization', c_int32), ('bn_eps', c_float), ('full_norm', c_int32), ('merge_add', c_int32), ('num_groups', c_int32), ('up_resize', c_int32), ('conv_valid', c_int32), ('act_slope', c_float), ('attention', c_int32), ('resunet', c_int32), ('enc_res_blocks', c_int32), ('dec_res_blocks', c_int32)]
 
 
 _P = c_void_p  # device pointer

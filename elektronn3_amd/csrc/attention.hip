@@ -486,3 +486,26 @@ int launch_att_bwd_gate_input(const AttDims& d, const float* dphi, const AttPara
     a.out = dg; a.ldo = ldg; a.accumulate = 1; a.rows = (size_t)d.N * d.gd * d.gh * d.gw; a.g = grid5(d);
     return run_rowgemm(a, s);
 }
+
+// ---- plain 1x1x1 convolutions over voxel rows (the ResUNet's shortcut projections, resunet.py:247-251); w is torch's (Cout, Cin)
+size_t pw_part_floats(size_t rows, int Cout, int Cin) { return (size_t)red_splits(rows, Cout, Cin + 1) * Cout * (Cin + 1); }
+
+int launch_pw_fwd(const float* x, int ldx, int Cin, const float* w, const float* b, float* out, int ldo, int Cout, size_t rows, hipStream_t s) {
+    RowGemmArgs a{};
+    a.A = x; a.lda = ldx; a.Ck = Cin; a.Tk = 1; a.W = w; a.wst = 0; a.wsc = 1; a.wsn = Cin; a.Cn = Cout; a.Tn = 1; a.bias = b;
+    a.out = out; a.ldo = ldo; a.rows = rows;
+    return run_rowgemm(a, s);
+}
+// dx += dy . w
+int launch_pw_dgrad_acc(const float* dy, int ldy, int Cout, const float* w, float* dx, int ldx, int Cin, size_t rows, hipStream_t s) {
+    RowGemmArgs a{};
+    a.A = dy; a.lda = ldy; a.Ck = Cout; a.Tk = 1; a.W = w; a.wst = 0; a.wsc = Cin; a.wsn = 1; a.Cn = Cin; a.Tn = 1;
+    a.out = dx; a.ldo = ldx; a.accumulate = 1; a.rows = rows;
+    return run_rowgemm(a, s);
+}
+// dw = dy^T x, db = column sums of dy; part: pw_part_floats(rows, Cout, Cin) floats
+int launch_pw_wgrad(const float* dy, int ldy, int Cout, const float* x, int ldx, int Cin, float* part, float* dw, float* db, size_t rows, hipStream_t s) {
+    RedGemmArgs a{};
+    a.L = dy; a.ldl = ldy; a.M = Cout; a.A = x; a.lda = ldx; a.Ck = Cin; a.Tk = 1; a.ones = 1; a.part = part; a.rows = rows;
+    return run_redgemm(a, dw, Cin, 1, 0, db, s);
+}

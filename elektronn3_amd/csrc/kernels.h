@@ -262,6 +262,11 @@ int launch_att_bwd(const AttDims& d, const float* dz, const float* x, int ldx, c
                    const AttParams& p, const AttParams& grad, float* dx, float* dphi, float* tmp_fine, float* tmp_coarse, float* df, float* part,
                    hipStream_t s);
 int launch_att_bwd_gate_input(const AttDims& d, const float* dphi, const AttParams& p, float* dg, int ldg, hipStream_t s);
+// plain 1x1x1 convolutions over voxel rows on the same GEMM kernels (ResUNet shortcut projections); w: torch (Cout, Cin)
+size_t pw_part_floats(size_t rows, int Cout, int Cin);
+int launch_pw_fwd(const float* x, int ldx, int Cin, const float* w, const float* b, float* out, int ldo, int Cout, size_t rows, hipStream_t s);
+int launch_pw_dgrad_acc(const float* dy, int ldy, int Cout, const float* w, float* dx, int ldx, int Cin, size_t rows, hipStream_t s);   // dx += dy . w
+int launch_pw_wgrad(const float* dy, int ldy, int Cout, const float* x, int ldx, int Cin, float* part, float* dw, float* db, size_t rows, hipStream_t s);
 
 // ---------------------------------------------------------------- layout helpers
 int launch_ncdhw_to_ndhwc(const float* src, float* dst, int N, int C, size_t S, hipStream_t s);

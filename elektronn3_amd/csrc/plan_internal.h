@@ -18,6 +18,14 @@ struct ConvUnit {           // conv (3x3x3 | 1x3x3 | transposed 2x2x2) followed 
     int p_a;                // nn.PReLU weight of the activation after this conv ('prelu'), -1 otherwise
     int bn_index;           // -1: no normalisation after this conv (nn.Identity): conv -> bias -> ReLU
     bool has_norm() const { return bn_index >= 0; }
+    // role in the network (set by the plan builder; the executors never parse names)
+    bool is_down = false;   // encoder unit
+    bool enc_last = false;  // last unit of an encoder block: its activation is the skip connection (and is pooled below the last level)
+    bool to_cat = false;    // first conv of a decoder block: its input is the merged (concat / add) tensor
+    // ResUNet (models/resunet.py:212-262): the second conv of a residual ConvBlock adds the block's input -- through a 1x1x1 projection when the
+    // channel counts differ -- BEFORE its norm:  y = conv2(..); y += proj(inp); norm2; act2
+    int res_in = -1;        // index of the ConvBlock's first conv unit (whose input is `inp`), -1: no residual
+    int p_pw = -1, p_pb = -1;   // projection parameters, -1: identity shortcut
 };
 
 // GridAttention of a decoder block (UNet(attention=True), unet.py:376-379,452-541): indices into the param table
@@ -42,6 +50,9 @@ struct e3_unet_plan {
     int p_final_w, p_final_b;
     int n_bn;
     std::vector<AttUnit> att;         // per level < n_blocks - 1 (cfg.attention != 0)
+    std::vector<int> enc_last_unit;   // per level: index of the encoder block's last unit
+    std::vector<int> up_unit;         // per level < n_blocks - 1: index of the decoder block's up-convolution unit
+    int enc_convs = 2, dec_convs = 2; // plain conv units per encoder / decoder block (UNet: 2; ResUNet: 2 per ConvBlock)
     // nn.RReLU in train mode: per-call seed (0 = off: fixed slope cfg.act_slope) and the slope interval (e3_unet_set_rrelu)
     unsigned rrelu_seed = 0; float rrelu_lo = 0.125f, rrelu_hi = 1.f / 3.f;
     ActArg rrelu_of(ActArg a, int unit) const {           // unit's activation with its own stream of slopes

@@ -62,7 +62,7 @@ void plan_b16(const e3_unet_plan* p, int N, int D, int H, int W, bool training, 
         UnitB& b = B.ub[k];
         const size_t n = ND.u[k].out.vox * u.cout;
         b.raw = training ? A.take_h(n) : nullptr;
-        const bool enc_skip = !u.is_up && u.name.compare(0, 10, "down_convs") == 0 && u.name.find("conv2") != std::string::npos && u.level < nb - 1;
+        const bool enc_skip = u.enc_last && u.level < nb - 1;
         if (enc_skip) { b.act = B.catB[u.level]; b.act_ldc = u.cout; }
         else if (u.is_up) { b.act = B.catA[u.level]; b.act_ldc = u.cout; }
         else if (training && k + 1 == nu) { b.act = nullptr; b.act_ldc = u.cout; }      // the head applies BN + ReLU while loading `raw`
@@ -139,7 +139,7 @@ struct ProfB {      // same per-layer HIP-event profiling hook as the fp32 execu
 
 bool supported(const e3_unet_cfg& c) {
     return c.normalization == 1 && c.full_norm && c.act_slope == 0.f && c.up_resize == 0 && !c.merge_add && !c.conv_valid &&
-           c.planar_mask == 0 && c.in_channels < 8 && c.start_filts % 32 == 0 && c.out_channels <= 8 && !c.attention;
+           c.planar_mask == 0 && c.in_channels < 8 && c.start_filts % 32 == 0 && c.out_channels <= 8 && !c.attention && !c.resunet;
 }
 
 }  // namespace
@@ -202,7 +202,7 @@ int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N,
         UnitB& b = B.ub[k];
         const LevelDims& lo = ND.u[k].out;
         const LevelDims& li = ND.u[k].in;
-        const bool is_enc_conv2 = !u.is_up && u.name.compare(0, 10, "down_convs") == 0 && u.name.find("conv2") != std::string::npos;
+        const bool is_enc_conv2 = u.enc_last;
         const bool pool_after = is_enc_conv2 && u.level < nb - 1;
         bf16_t* dst = training ? b.raw : b.act;
         const int dst_ldc = training ? u.cout : b.act_ldc;
@@ -305,8 +305,8 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
         const LevelDims& lo = ND.u[k].out;
         const LevelDims& li = ND.u[k].in;
         const int j = u.level;
-        const bool is_down = u.name.compare(0, 10, "down_convs") == 0;
-        const bool is_enc_conv2 = is_down && u.name.find("conv2") != std::string::npos;
+        const bool is_down = u.is_down;
+        const bool is_enc_conv2 = u.enc_last;
         const bool pooled_unit = is_enc_conv2 && j < nb - 1;
         if (!event_done && is_down && is_enc_conv2 && j == bucket_after_down_block - 1) {
             if (!bias_jobs.empty()) { RUN(launch_colsum_multi(bias_jobs.data(), (int)bias_jobs.size(), s)); bias_jobs.clear(); }
@@ -333,7 +333,7 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
         if (k == 0) { xin = cfg.in_channels > 1 ? B.xin : (const bf16_t*)x; xin_ldc = cfg.in_channels; }
         else {
             const ConvUnit& pu = plan->units[k - 1];
-            const bool prev_pooled = pu.name.compare(0, 10, "down_convs") == 0 && pu.name.find("conv2") != std::string::npos && pu.level < nb - 1 && is_down;
+            const bool prev_pooled = pu.enc_last && pu.level < nb - 1 && is_down;
             if (prev_pooled) { xin = B.pooled[pu.level]; xin_ldc = pu.cout; }
             else if (pu.is_up) { xin = B.catA[pu.level]; xin2 = B.catB[pu.level]; xin_ldc = pu.cout; }
             else { xin = B.ub[k - 1].act; xin_ldc = B.ub[k - 1].act_ldc; }
@@ -367,7 +367,7 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
             { ProfB pr(plan, s, k, 1); RUN(launch_upconv_b16_dgrad(a, s)); }
             g = B.g1[j + 1]; g_ldc = u.cin;
         } else {
-            const bool to_cat = !is_down && u.name.find("conv1") != std::string::npos;     // UpConv.conv1: gradient of the concat buffer
+            const bool to_cat = u.to_cat;     // UpConv.conv1: gradient of the concat buffer
             bf16_t* out = to_cat ? B.dcatA[j] : B.g1[j];
             ConvB16Args a{};
             a.x = dxr; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = b.wpk_d; a.bias = nullptr; a.y = out; a.y_ldc = to_cat ? u.cin / 2 : u.cin;

@@ -70,7 +70,7 @@ void net_dims(const e3_unet_plan* p, int N, int D, int H, int W, NetDims& nd) {
     };
     for (int i = 0; i < nb; ++i) {
         nd.X[i] = cur;
-        plain(p->planar(i)); plain(p->planar(i));
+        for (int c = 0; c < p->enc_convs; ++c) plain(p->planar(i));
         nd.E[i] = cur;
         if (i + 1 < nb) cur = mkdims(N, cdiv(cur.D, p->planar(i) ? 1 : 2), cdiv(cur.H, 2), cdiv(cur.W, 2));   // MaxPool3d(ceil_mode=True), unet.py:229
     }
@@ -83,7 +83,7 @@ void net_dims(const e3_unet_plan* p, int N, int D, int H, int W, NetDims& nd) {
         if (ud.out.D > e.D || ud.out.H > e.H || ud.out.W > e.W || ud.out.D < 1 || ud.out.H < 1 || ud.out.W < 1) nd.ok = false;
         nd.sd_[j] = (e.D - ud.out.D) / 2; nd.sh_[j] = (e.H - ud.out.H) / 2; nd.sw_[j] = (e.W - ud.out.W) / 2;
         cur = ud.out;
-        plain(p->planar(j)); plain(p->planar(j));
+        for (int c = 0; c < p->dec_convs; ++c) plain(p->planar(j));
     }
     nd.Y = cur;
 }
@@ -118,6 +118,9 @@ struct Buffers {
     // GridAttention (cfg.attention): per level the saved gate tensors; shared scratch sized for the largest level
     struct AttBufs { float *f, *sgm, *att, *raw, *mean, *invstd, *scale, *shift, *x, *bnpart, *gx; };   // x: centre-cropped skip ('valid'); gx: its gradient
     std::vector<AttBufs> att;
+    // ResUNet residual units: [2][vox][C] = (conv accumulations, shortcut) summed by the statistics pass; per level the gradient of such a sum
+    float* res2 = nullptr;
+    std::vector<float*> gres;
     float *att_phi = nullptr, *att_phires = nullptr, *att_tmp = nullptr, *att_tf = nullptr, *att_tc = nullptr, *att_df = nullptr, *att_dphi = nullptr,
           *att_part = nullptr;
     float* evalA; float* evalB;          // inference ping-pong (level-0 sized)
@@ -147,12 +150,12 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     const int nb = p->cfg.n_blocks;
     NetDims ND; net_dims(p, N, D, H, W, ND);
     const bool valid = p->cfg.conv_valid != 0;
-    auto up_unit = [&](int j) { return (size_t)(2 * nb + 3 * (nb - 2 - j)); };      // index of the up-conv unit whose output is level j
+    auto up_unit = [&](int j) { return (size_t)p->up_unit[j]; };      // index of the up-conv unit whose output is level j
     Arena S(saved), T(scratch);
     B.ub.assign(p->units.size(), UnitBufs{});
     B.cat.assign(nb, nullptr); B.pooled.assign(nb, nullptr); B.sum.assign(nb, nullptr);
     B.ups.assign(p->units.size(), nullptr); B.rtmp = B.rpad = B.rdu = nullptr;
-    B.g1.assign(nb, nullptr); B.g2.assign(nb, nullptr); B.dcat.assign(nb, nullptr); B.gskip.assign(nb, nullptr);
+    B.g1.assign(nb, nullptr); B.g2.assign(nb, nullptr); B.dcat.assign(nb, nullptr); B.gskip.assign(nb, nullptr); B.gres.assign(nb, nullptr);
     B.xin = nullptr; B.evalA = B.evalB = nullptr;
     Arena& A = training ? S : T;   // in inference everything is scratch
     if (p->cfg.in_channels > 1) B.xin = A.take(ND.X[0].vox * p->cfg.in_channels);
@@ -168,13 +171,13 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         const size_t n = ND.u[k].out.vox * u.cout;
         // without batch statistics to wait for, the conv writes relu(acc*scale + shift) directly; other activations are not in the conv
         // epilogues and take the two-pass route (raw tensor, then the apply pass)
-        b.raw = ((training && u.has_norm()) || p->cfg.act_slope != 0.f || u.is_up == 2 || (valid && !u.is_up)) ? A.take(n) : nullptr;
+        b.raw = ((training && u.has_norm()) || p->cfg.act_slope != 0.f || u.is_up == 2 || (valid && !u.is_up) || u.res_in >= 0) ? A.take(n) : nullptr;
         if (u.is_up == 2 && p->cfg.up_resize < 3) {       // (the 1x1x1 variants convolve at low resolution: no up-sampled input)
             const LevelDims& li = ND.u[k].in;
             B.ups[k] = A.take((size_t)N * li.D * (u.planar ? 1 : 2) * li.H * 2 * li.W * 2 * u.cin);
         }
         // where does the activation go?
-        const bool enc_skip = !u.is_up && u.name.find("down_convs") == 0 && u.name.find("conv2") != std::string::npos && u.level < nb - 1;
+        const bool enc_skip = u.enc_last && u.level < nb - 1;
         // ('valid': the skip is larger than the decoder's grid and gets centre-cropped into the concat buffer by a copy)
         if (enc_skip && !valid && !p->cfg.attention) { b.act = B.cat[u.level] ? B.cat[u.level] + u.cout : nullptr; b.act_ldc = 2 * u.cout; }
         else if (u.is_up) { b.act = B.cat[u.level]; b.act_ldc = 2 * u.cout; }
@@ -277,7 +280,18 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         const LevelDims& lo = ND.u[up_unit(j)].out;
         statmax = max_sz(statmax, (size_t)crop_stats_parts(lo.vox, p->chan(j)) * p->chan(j) * 3);
     }
+    size_t res2max = 0;
+    for (size_t k = 0; k < p->units.size(); ++k) {
+        const ConvUnit& u = p->units[k];
+        if (u.res_in < 0) continue;
+        const size_t vox = ND.u[k].out.vox;
+        res2max = max_sz(res2max, 2 * vox * u.cout);
+        statmax = max_sz(statmax, (size_t)crop_stats_parts(vox, u.cout) * u.cout * 3);
+        if (training && u.p_pw >= 0) att_partmax = max_sz(att_partmax, pw_part_floats(vox, u.cout, p->units[u.res_in].cin));
+    }
+    if (res2max) B.res2 = T.take(res2max);
     B.stats = T.take(statmax);
+    if (!att_on && training && att_partmax) B.att_part = T.take(att_partmax);
     if (att_on) {
         B.att_phi = T.take(att_dec);
         size_t cc = 0;      // coarse voxels x C/2, maximum over the levels
@@ -313,6 +327,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
             const size_t n = ND.X[j].vox * p->chan(j);        // the level's input grid is its largest
             B.g1[j] = T.take(n); B.g2[j] = T.take(n);
             if (j + 1 < nb) B.dcat[j] = T.take(2 * n);
+            if (res2max) B.gres[j] = T.take(n);
             if ((valid || att_on) && j + 1 < nb) B.gskip[j] = T.take(ND.E[j].vox * p->chan(j));
             // attention: gradient of the (cropped) skip as the gate sees it; 'same' convs: that IS the skip's gradient
             if (att_on && j + 1 < nb) B.att[j].gx = valid ? T.take(ND.u[up_unit(j)].out.vox * p->chan(j)) : B.gskip[j];
@@ -359,42 +374,98 @@ int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
     if (cfg->normalization == 2)
         E3_REQUIRE(cfg->num_groups >= 1 && cfg->start_filts % cfg->num_groups == 0, E3_ERR_INVALID, "num_groups must divide every channel count");
     E3_REQUIRE(cfg->attention >= 0 && cfg->attention <= 2, E3_ERR_INVALID, "attention must be 0 (off), 1 (dim=3) or 2 (dim=2)");
+    E3_REQUIRE(cfg->resunet == 0 || cfg->resunet == 1, E3_ERR_INVALID, "resunet must be 0 or 1");
+    E3_REQUIRE(cfg->resunet || (cfg->enc_res_blocks == 0 && cfg->dec_res_blocks == 0), E3_ERR_INVALID, "res_blocks belong to the ResUNet");
+    E3_REQUIRE(cfg->enc_res_blocks >= 0 && cfg->enc_res_blocks <= 8 && cfg->dec_res_blocks >= 0 && cfg->dec_res_blocks <= 8, E3_ERR_INVALID, "res_blocks must be in 0..8");
+    E3_REQUIRE(!(cfg->conv_valid && (cfg->enc_res_blocks || cfg->dec_res_blocks)), E3_ERR_UNSUPPORTED,
+               "residual shortcuts need conv_mode='same' (a 'valid' conv2 is smaller than the block input it would be added to)");
     const bool last_norm = cfg->normalization != 0, all_norm = last_norm && cfg->full_norm != 0;
     e3_unet_plan* p = new e3_unet_plan();
     p->cfg = *cfg;
     p->n_bn = 0;
     const int nb = cfg->n_blocks;
     p->att.assign(cfg->attention ? nb : 0, AttUnit{});
-    for (int i = 0; i < nb; ++i) {   // unet.py:832-850
-        const std::string b = "down_convs." + std::to_string(i) + ".";
-        const int ins = i == 0 ? cfg->in_channels : p->chan(i - 1), outs = p->chan(i);
-        add_unit(p, b + "conv1", b + "norm0", ins, outs, i, p->planar(i), 0, all_norm, b + "act1");     // unet.py:235-242
-        add_unit(p, b + "conv2", b + "norm1", outs, outs, i, p->planar(i), 0, last_norm, b + "act2");
-    }
-    for (int k = 0; k + 1 < nb; ++k) {   // unet.py:854-879: block k works at level nb-2-k
-        const int j = nb - 2 - k;
-        const std::string b = "up_convs." + std::to_string(k) + ".";
-        const int ins = p->chan(j + 1), outs = p->chan(j);
-        add_unit(p, b + (cfg->up_resize ? "upconv.conv" : "upconv"), b + "norm0", ins, outs, j, p->planar(j), cfg->up_resize ? 2 : 1, all_norm, b + "act0");   // unet.py:152-176,365-375
-        if (cfg->attention) {            // GridAttention(in_channels=outs, gating_channels=ins) (unet.py:376-379,452-505); inter_channels = outs / 2
-            const std::string a = b + "attention.";
-            const int T = cfg->attention == 2 ? 4 : 8, ci = outs / 2;
-            AttUnit& au = p->att[j];
-            au.p_ww = add_param(p, a + "w.0.weight", (int64_t)outs * outs, 0);
-            au.p_wb = add_param(p, a + "w.0.bias", outs, 0);
-            au.p_g = add_param(p, a + "w.1.weight", outs, 0);
-            au.p_be = add_param(p, a + "w.1.bias", outs, 0);
-            au.p_rm = add_param(p, a + "w.1.running_mean", outs, 1);
-            au.p_rv = add_param(p, a + "w.1.running_var", outs, 1);
-            au.bn_index = p->n_bn++;
-            au.p_theta = add_param(p, a + "theta.weight", (int64_t)ci * outs * T, 0);
-            au.p_phi_w = add_param(p, a + "phi.weight", (int64_t)ci * ins, 0);
-            au.p_phi_b = add_param(p, a + "phi.bias", ci, 0);
-            au.p_psi_w = add_param(p, a + "psi.weight", ci, 0);
-            au.p_psi_b = add_param(p, a + "psi.bias", 1, 0);
+    p->enc_last_unit.assign(nb, -1); p->up_unit.assign(nb, -1);
+    auto attention_params = [&](const std::string& b, int j, int ins, int outs) {
+        // GridAttention(in_channels=outs, gating_channels=ins) (unet.py:376-379,452-505); inter_channels = outs / 2
+        const std::string a = b + "attention.";
+        const int T = cfg->attention == 2 ? 4 : 8, ci = outs / 2;
+        AttUnit& au = p->att[j];
+        au.p_ww = add_param(p, a + "w.0.weight", (int64_t)outs * outs, 0);
+        au.p_wb = add_param(p, a + "w.0.bias", outs, 0);
+        au.p_g = add_param(p, a + "w.1.weight", outs, 0);
+        au.p_be = add_param(p, a + "w.1.bias", outs, 0);
+        au.p_rm = add_param(p, a + "w.1.running_mean", outs, 1);
+        au.p_rv = add_param(p, a + "w.1.running_var", outs, 1);
+        au.bn_index = p->n_bn++;
+        au.p_theta = add_param(p, a + "theta.weight", (int64_t)ci * outs * T, 0);
+        au.p_phi_w = add_param(p, a + "phi.weight", (int64_t)ci * ins, 0);
+        au.p_phi_b = add_param(p, a + "phi.bias", ci, 0);
+        au.p_psi_w = add_param(p, a + "psi.weight", ci, 0);
+        au.p_psi_b = add_param(p, a + "psi.bias", 1, 0);
+    };
+    if (!cfg->resunet) {
+        for (int i = 0; i < nb; ++i) {   // unet.py:832-850
+            const std::string b = "down_convs." + std::to_string(i) + ".";
+            const int ins = i == 0 ? cfg->in_channels : p->chan(i - 1), outs = p->chan(i);
+            add_unit(p, b + "conv1", b + "norm0", ins, outs, i, p->planar(i), 0, all_norm, b + "act1");     // unet.py:235-242
+            p->units.back().is_down = true;
+            add_unit(p, b + "conv2", b + "norm1", outs, outs, i, p->planar(i), 0, last_norm, b + "act2");
+            p->units.back().is_down = true; p->units.back().enc_last = true;
+            p->enc_last_unit[i] = (int)p->units.size() - 1;
         }
-        add_unit(p, b + "conv1", b + "norm1", cfg->merge_add ? outs : 2 * outs, outs, j, p->planar(j), 0, all_norm, b + "act1");   // unet.py:352-360
-        add_unit(p, b + "conv2", b + "norm2", outs, outs, j, p->planar(j), 0, last_norm, b + "act2");
+        for (int k = 0; k + 1 < nb; ++k) {   // unet.py:854-879: block k works at level nb-2-k
+            const int j = nb - 2 - k;
+            const std::string b = "up_convs." + std::to_string(k) + ".";
+            const int ins = p->chan(j + 1), outs = p->chan(j);
+            add_unit(p, b + (cfg->up_resize ? "upconv.conv" : "upconv"), b + "norm0", ins, outs, j, p->planar(j), cfg->up_resize ? 2 : 1, all_norm, b + "act0");   // unet.py:152-176,365-375
+            p->up_unit[j] = (int)p->units.size() - 1;
+            if (cfg->attention) attention_params(b, j, ins, outs);
+            add_unit(p, b + "conv1", b + "norm1", cfg->merge_add ? outs : 2 * outs, outs, j, p->planar(j), 0, all_norm, b + "act1");   // unet.py:352-360
+            p->units.back().to_cat = true;
+            add_unit(p, b + "conv2", b + "norm2", outs, outs, j, p->planar(j), 0, last_norm, b + "act2");
+        }
+    } else {
+        // elektronn3.models.resunet.UNet (resunet.py:888-934): DownBlock / UpBlock = a Sequential of ConvBlocks (conv1-norm1-act1-conv2-[+ proj(inp)]-
+        // norm2-act2, resunet.py:212-262), max(1, res_blocks) of them; res_blocks >= 1 turns the shortcuts on, except from the input image
+        // (skip_first_residual, resunet.py:906).  A norm follows every conv (full_norm only reaches norm0, which is always built: resunet.py:411).
+        p->enc_convs = 2 * (cfg->enc_res_blocks > 1 ? cfg->enc_res_blocks : 1);
+        p->dec_convs = 2 * (cfg->dec_res_blocks > 1 ? cfg->dec_res_blocks : 1);
+        auto conv_block = [&](const std::string& cb, int ins, int outs, int level, bool residual, bool down, bool first_of_up) {
+            add_unit(p, cb + "conv1", cb + "norm1", ins, outs, level, p->planar(level), 0, last_norm, cb + "act1");
+            p->units.back().is_down = down; p->units.back().to_cat = first_of_up;
+            const int first = (int)p->units.size() - 1;
+            add_unit(p, cb + "conv2", cb + "norm2", outs, outs, level, p->planar(level), 0, last_norm, cb + "act2");
+            ConvUnit& u2 = p->units.back();
+            u2.is_down = down;
+            if (residual) {
+                u2.res_in = first;
+                if (ins != outs) {       // "projection" to match the channel counts (resunet.py:247-251)
+                    const int pw = add_param(p, cb + "proj.weight", (int64_t)ins * outs, 0), pb = add_param(p, cb + "proj.bias", outs, 0);
+                    p->units.back().p_pw = pw; p->units.back().p_pb = pb;
+                }
+            }
+        };
+        for (int i = 0; i < nb; ++i) {
+            const std::string b = "down_convs." + std::to_string(i) + ".convs.";
+            const int ins = i == 0 ? cfg->in_channels : p->chan(i - 1), outs = p->chan(i);
+            const bool res = cfg->enc_res_blocks >= 1;
+            for (int c = 0; c < p->enc_convs / 2; ++c)
+                conv_block(b + std::to_string(c) + ".", c == 0 ? ins : outs, outs, i, res && !(c == 0 && i == 0), true, false);
+            p->units.back().enc_last = true;
+            p->enc_last_unit[i] = (int)p->units.size() - 1;
+        }
+        for (int k = 0; k + 1 < nb; ++k) {
+            const int j = nb - 2 - k;
+            const std::string b = "up_convs." + std::to_string(k) + ".";
+            const int ins = p->chan(j + 1), outs = p->chan(j);
+            add_unit(p, b + (cfg->up_resize ? "upconv.conv" : "upconv"), b + "norm0", ins, outs, j, p->planar(j), cfg->up_resize ? 2 : 1, last_norm, b + "act0");
+            p->up_unit[j] = (int)p->units.size() - 1;
+            if (cfg->attention) attention_params(b, j, ins, outs);
+            const bool res = cfg->dec_res_blocks >= 1;
+            for (int c = 0; c < p->dec_convs / 2; ++c)
+                conv_block(b + "convs." + std::to_string(c) + ".", c == 0 ? (cfg->merge_add ? outs : 2 * outs) : outs, outs, j, res, false, c == 0);
+        }
     }
     p->p_final_w = add_param(p, "conv_final.weight", (int64_t)cfg->out_channels * p->chan(0), 0);
     p->p_final_b = add_param(p, "conv_final.bias", cfg->out_channels, 0);
@@ -457,7 +528,7 @@ int e3_unet_attention_map(const e3_unet_plan* plan, void* stream, int N, int D, 
     NetDims ND; net_dims(plan, N, D, H, W, ND);
     E3_REQUIRE(ND.ok, E3_ERR_INVALID, "input too small for this network");
     const int j = nb - 2 - block;                                  // up_convs[block] works at level nb - 2 - block
-    const LevelDims& lo = ND.u[(size_t)(2 * nb + 3 * block)].out;
+    const LevelDims& lo = ND.u[(size_t)plan->up_unit[j]].out;
     if (Do) *Do = lo.D;
     if (Ho) *Ho = lo.H;
     if (Wo) *Wo = lo.W;
@@ -536,7 +607,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
     // statistics come from the reduction pass; the eval / no-norm paths keep the fused epilogues)
     auto fwd_split = [&](size_t k) -> int {
         const ConvUnit& u = plan->units[k];
-        if (!(training && u.has_norm()) || valid || !B.wpk_f[k] || !B.skws) return 1;
+        if (!(training && u.has_norm()) || valid || !B.wpk_f[k] || !B.skws || u.res_in >= 0) return 1;
         const int S = conv_wino_splitk(ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cin, u.cout);
         return S > 1 ? S : 1;
     };
@@ -564,6 +635,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
     const float* cur = x; int cur_ldc = cfg.in_channels;
     if (cfg.in_channels > 1) { RUN(launch_ncdhw_to_ndhwc(x, B.xin, N, cfg.in_channels, ND.X[0].vox / N, s)); cur = B.xin; }
 
+    std::vector<std::pair<const float*, int>> unit_ins(plan->units.size());      // input view of every unit (shortcut source of the ResUNet's ConvBlocks)
     for (size_t k = 0; k < plan->units.size(); ++k) {
         const ConvUnit& u = plan->units[k];
         UnitBufs& b = B.ub[k];
@@ -571,7 +643,8 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         const LevelDims& ci = ND.u[k].in;          // plain convs: the grid the conv kernel runs on (== lo unless conv_mode='valid')
         const bool vcrop = valid && !u.is_up;      // 'valid' conv = the 'same' conv on the input grid, cropped by the padding
         const float* const unit_in = cur; const int unit_in_ldc = cur_ldc;      // (the gating signal of the block's GridAttention)
-        const bool is_enc_conv2 = !u.is_up && u.name.compare(0, 10, "down_convs") == 0 && u.name.find("conv2") != std::string::npos;
+        unit_ins[k] = {cur, cur_ldc};
+        const bool is_enc_conv2 = u.enc_last;
         const bool pool_after = is_enc_conv2 && u.level < nb - 1;
         const int kd = u.planar ? 1 : 2;
         const float slope = cfg.act_slope;
@@ -579,7 +652,8 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         if (training && !frozen) act = plan->rrelu_of(act, (int)k);      // train-mode RReLU: random slopes (the backward recomputes them)
         const bool bn_train = training && u.has_norm();   // batch statistics needed: conv writes the raw output, BN+ReLU is a second pass
         float* const stat_buf = frozen ? nullptr : B.stats;   // (frozen statistics: nothing to measure)
-        const bool two_pass = bn_train || slope != 0.f || u.is_up == 2 || vcrop;   // (non-ReLU activations are not in the conv epilogues; the
+        const bool residual = u.res_in >= 0;        // y = conv2(..) + proj(inp) before the norm (resunet.py:254-262)
+        const bool two_pass = bn_train || slope != 0.f || u.is_up == 2 || vcrop || residual;   // (non-ReLU activations are not in the conv epilogues; the
                                                                            // ResizeConv output may need the autocrop before the norm)
         float* dst = two_pass ? b.raw : b.act;            // otherwise the conv writes the activation directly
         const int dst_ldc = two_pass ? u.cout : b.act_ldc;
@@ -652,6 +726,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             a.y = vcrop ? B.rtmp : dst; a.y_ldc = dst_ldc; a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.sd = 2;
             a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
             a.stats = (bn_train && !vcrop) ? stat_buf : nullptr; a.G = 1; a.flags = 0;
+            if (residual) { a.y = B.res2; a.y_ldc = u.cout; a.bias = nullptr; a.stats = nullptr; }      // pure accumulations; bias + shortcut + statistics below
             parts = conv_stats_parts(kind, 0, N, ci.D, ci.H, ci.W, 2, u.cin, u.cout);
             const int S = (kind == CONV_K3) ? fwd_split(k) : 1;
             if (S > 1) {         // partial sums per share of the input channels, then sum + bias + statistics in one small pass
@@ -663,6 +738,20 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
                 RUN(launch_splitk_reduce(B.skws, S, lo.vox * u.cout, P(u.p_b), dst, dst_ldc, u.cout, lo.vox, stat_buf, s));
                 parts = crop_stats_parts(lo.vox, u.cout);
             }
+        }
+        if (residual) {
+            E3_REQUIRE(!u.is_up && u.cin >= 8 && !vcrop, E3_ERR_INVALID, "residual unit: plain 'same' conv expected");
+            const std::pair<const float*, int>& in = unit_ins[(size_t)u.res_in];
+            const int cin0 = plan->units[(size_t)u.res_in].cin;
+            float* const slot1 = B.res2 + lo.vox * u.cout;
+            if (u.p_pw >= 0) RUN(launch_pw_fwd(in.first, in.second, cin0, P(u.p_pw), P(u.p_pb), slot1, u.cout, u.cout, lo.vox, s));
+            else {
+                E3_REQUIRE(in.second == u.cout && cin0 == u.cout, E3_ERR_INVALID, "identity shortcut: packed input with the block's channel count expected");
+                E3_CHECK_HIP(hipMemcpyAsync(slot1, in.first, lo.vox * u.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+            }
+            RUN(launch_splitk_reduce(B.res2, 2, lo.vox * u.cout, bn_train ? P(u.p_b) : nullptr, b.raw, u.cout, u.cout, lo.vox,
+                                     (bn_train && !frozen) ? B.stats : nullptr, s));
+            parts = crop_stats_parts(lo.vox, u.cout);
         }
         if (vcrop) {        // the interior of the 'same' result is the 'valid' result (no tap of an interior voxel touches the padding)
             RUN(launch_crop_stats(B.rtmp, b.raw, u.cout, N, ci.D, ci.H, ci.W, lo.D, lo.H, lo.W, B.stats, s, ND.u[k].od, ND.u[k].oh, ND.u[k].ow));
@@ -699,7 +788,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
             // second half of the concat buffer
             const int j = u.level, C = u.cout;
             const LevelDims& e = ND.E[j];
-            const UnitBufs& eb = B.ub[2 * j + 1];
+            const UnitBufs& eb = B.ub[(size_t)plan->enc_last_unit[j]];
             const AttUnit& au = plan->att[j];
             Buffers::AttBufs& ab = B.att[j];
             const AttDims ad = att_dims(plan, ND, N, j, k);
@@ -733,7 +822,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         } else if (u.is_up && valid) {      // centre-crop the encoder's skip activation into the second half of the concat buffer (unet.py:300-325)
             const int j = u.level;
             const LevelDims& e = ND.E[j];
-            const UnitBufs& eb = B.ub[2 * j + 1];
+            const UnitBufs& eb = B.ub[(size_t)plan->enc_last_unit[j]];
             RUN(launch_crop_copy(eb.act, B.cat[j] + u.cout, 2 * u.cout, u.cout, N, e.D, e.H, e.W, lo.D, lo.H, lo.W, ND.sd_[j], ND.sh_[j], ND.sw_[j], s));
         }
         // input of the next unit
@@ -841,6 +930,7 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
         return rc;
     };
     std::vector<ColsumJob> bias_jobs;     // conv-bias gradients (column sums of the apply pass' partials), flushed in one launch
+    int pending_res = -1;                  // residual unit whose shortcut gradient still has to reach its ConvBlock's input
     for (int k = nunits - 1; k >= 0; --k) {
         const ConvUnit& u = plan->units[k];
         const UnitBufs& b = B.ub[k];
@@ -848,8 +938,8 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
         const LevelDims& ci = ND.u[k].in;          // plain convs: the grid the conv kernels run on
         const bool vcrop = valid && !u.is_up;
         const int j = u.level;
-        const bool is_down = u.name.compare(0, 10, "down_convs") == 0;
-        const bool is_enc_conv2 = is_down && u.name.find("conv2") != std::string::npos;
+        const bool is_down = u.is_down;
+        const bool is_enc_conv2 = u.enc_last;
         const bool pooled_unit = is_enc_conv2 && j < nb - 1;
         const int kd = u.planar ? 1 : 2;
         if (!event_done && is_down) {
@@ -869,7 +959,7 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
             Buffers::AttBufs& ab = B.att[j];
             att_d = att_dims(plan, ND, N, j, (size_t)k); att_p = att_params(params, au);
             const AttParams ag = att_params(grads, au);
-            const UnitBufs& eb = B.ub[2 * j + 1];
+            const UnitBufs& eb = B.ub[(size_t)plan->enc_last_unit[j]];
             const float* xs = valid ? ab.x : eb.act; const int ldx = valid ? C : eb.act_ldc;
             float* dz = B.g1[j];                 // (free: the gradient of this unit's activation sits in dcat)
             BnBwdArgs a{};
@@ -887,7 +977,8 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
                                B.att_tc, B.att_df, B.att_part, s));
         }
         // -- BN + ReLU (+ pool, + skip) backward -> dxr = gradient w.r.t. the raw conv output
-        float* dxr = B.g2[j];
+        // (residual unit: the raw tensor is conv2(..) + shortcut; its gradient also feeds the shortcut and must outlive the ConvBlock's first conv)
+        float* dxr = u.res_in >= 0 ? B.gres[j] : B.g2[j];
         bool fuse_first = false; SmallWgradFuse first_fuse{};
         {
             BnBwdArgs a{};
@@ -907,7 +998,7 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
                 a.g1 = B.gskip[j]; a.g1_ldc = u.cout; a.gpool = g; a.a = b.act; a.a_ldc = b.act_ldc; a.pooled = B.pooled[j];
             }
             else if (pooled_unit && valid) {   // the skip was centre-cropped: its gradient is zero outside that box
-                const LevelDims& dc = ND.u[2 * nb + 3 * (nb - 2 - j)].out;
+                const LevelDims& dc = ND.u[(size_t)plan->up_unit[j]].out;
                 if (cfg.attention) RUN(launch_pad_box(B.att[j].gx, B.gskip[j], u.cout, N, dc.D, dc.H, dc.W, lo.D, lo.H, lo.W, s, ND.sd_[j], ND.sh_[j], ND.sw_[j], u.cout));
                 else
                 RUN(launch_pad_box(cfg.merge_add ? B.dcat[j] : B.dcat[j] + u.cout, B.gskip[j], u.cout, N, dc.D, dc.H, dc.W, lo.D, lo.H, lo.W, s,
@@ -942,18 +1033,29 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
             }
         }
         // -- input activation of this conv
-        const float* xin; int xin_ldc;
-        if (k == 0) { xin = cfg.in_channels > 1 ? B.xin : x; xin_ldc = cfg.in_channels; }
-        else {
-            const ConvUnit& pu = plan->units[k - 1];
-            const bool prev_pooled = pu.name.compare(0, 10, "down_convs") == 0 && pu.name.find("conv2") != std::string::npos && pu.level < nb - 1 && is_down;
-            if (prev_pooled) { xin = B.pooled[pu.level]; xin_ldc = pu.cout; }
-            else if (pu.is_up && cfg.merge_add) { xin = B.sum[pu.level]; xin_ldc = pu.cout; }
-            else if (pu.is_up) { xin = B.cat[pu.level]; xin_ldc = 2 * pu.cout; }
-            else { xin = B.ub[k - 1].act; xin_ldc = B.ub[k - 1].act_ldc; }
-            if (u.is_up) {   // input of upconv k-th: activation at level j+1 = output of the previous unit (packed or cat-skip of bottom block)
-                xin = B.ub[k - 1].act; xin_ldc = B.ub[k - 1].act_ldc;
+        auto input_of = [&](int q, const float*& xi, int& xi_ldc) {
+            const ConvUnit& uq = plan->units[q];
+            if (q == 0) { xi = cfg.in_channels > 1 ? B.xin : x; xi_ldc = cfg.in_channels; return; }
+            const ConvUnit& pu = plan->units[q - 1];
+            const bool prev_pooled = pu.enc_last && pu.level < nb - 1 && uq.is_down;
+            if (prev_pooled) { xi = B.pooled[pu.level]; xi_ldc = pu.cout; }
+            else if (pu.is_up && cfg.merge_add) { xi = B.sum[pu.level]; xi_ldc = pu.cout; }
+            else if (pu.is_up) { xi = B.cat[pu.level]; xi_ldc = 2 * pu.cout; }
+            else { xi = B.ub[q - 1].act; xi_ldc = B.ub[q - 1].act_ldc; }
+            if (uq.is_up) {   // input of upconv k-th: activation at level j+1 = output of the previous unit (packed or cat-skip of bottom block)
+                xi = B.ub[q - 1].act; xi_ldc = B.ub[q - 1].act_ldc;
             }
+        };
+        const float* xin; int xin_ldc;
+        input_of(k, xin, xin_ldc);
+        if (u.res_in >= 0) {      // shortcut: projection gradients now (dxr and the ConvBlock's input are at hand); its input gradient joins the
+                                  // data gradient of the ConvBlock's first conv below
+            if (u.p_pw >= 0) {
+                const float* xr; int xr_ldc;
+                input_of(u.res_in, xr, xr_ldc);
+                RUN(launch_pw_wgrad(dxr, u.cout, u.cout, xr, xr_ldc, plan->units[u.res_in].cin, B.att_part, G(u.p_pw), G(u.p_pb), lo.vox, s));
+            }
+            pending_res = k;
         }
         // -- weight gradient
         const float* dyu = dxr;      // gradient of the conv output on the grid the conv kernels run on: zero in cropped-away voxels
@@ -1061,7 +1163,7 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             (void)taps;
             if (!B.wpk_d[k]) RUN(launch_pack_conv_auto(kind, 1, P(u.p_w), B.wpack, u.cout, u.cin, N, ci.D, ci.H, ci.W, 0, s));
-            const bool to_cat = !is_down && u.name.find("conv1") != std::string::npos;   // UpConv.conv1: gradient of the concat buffer
+            const bool to_cat = u.to_cat;   // UpConv.conv1: gradient of the concat buffer
             float* out; int out_ldc = u.cin;
             if (k == 0) out = (cfg.in_channels > 1) ? B.g1[0] : dx;   // g1[0] is free by now (C0 >= in_channels)
             else if (to_cat) out = B.dcat[j];
@@ -1080,6 +1182,13 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
             { Prof pr(plan, s, k, 1); RUN(launch_conv_mfma(kind, a, s)); }
             if (S > 1) RUN(launch_splitk_reduce(B.skws, S, gvox * u.cin, nullptr, out, out_ldc, u.cin, gvox, nullptr, s));
             if (k == 0) { if (cfg.in_channels > 1) RUN(launch_ndhwc_to_ncdhw(B.g1[0], cfg.in_channels, dx, N, cfg.in_channels, ND.X[0].vox / N, s)); }
+            if (pending_res >= 0 && plan->units[pending_res].res_in == k) {      // + the shortcut's share: d inp += proj^T dsum (or dsum itself)
+                const ConvUnit& ru = plan->units[pending_res];
+                const size_t rvox = ND.u[pending_res].out.vox;
+                if (ru.p_pw >= 0) RUN(launch_pw_dgrad_acc(B.gres[j], ru.cout, ru.cout, P(ru.p_pw), out, out_ldc, u.cin, rvox, s));
+                else RUN(launch_add_views(out, out_ldc, B.gres[j], ru.cout, out, out_ldc, rvox, u.cin, s));
+                pending_res = -1;
+            }
             g = out; g_ldc = (to_cat && !cfg.merge_add) ? 2 * u.cout : u.cin;   // concat: the next unit (upconv) reads the first half, ldc = 2*C; add: d(up + skip) goes to both
         }
         if (u.is_up && cfg.attention)      // the block's input is also the gate's gating signal: + dphi . phi_w

@@ -291,7 +291,7 @@ def _flat_views(plan, tens, device):
 # tensors in table order and calls ONE registered operator; the operator (and its autograd formula) run the same native entry points as
 # the eager path.  Functional by construction: the updated running statistics are RETURNED and copied back by the scripted code.
 def _plan_key_from_floats(key: List[float]):
-    ints = (0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 13)
+    ints = (0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 13, 14, 15, 16)
     return tuple(int(round(v)) if i in ints else float(v) for i, v in enumerate(key))
 
 
@@ -581,6 +581,12 @@ class UNet(nn.Module):
             conv_mode: str = 'same',
     ):
         super().__init__()
+        self._setup(in_channels, out_channels, n_blocks, start_filts, up_mode, merge_mode, planar_blocks, batch_norm, attention, activation,
+                    normalization, full_norm, dim, conv_mode)
+
+    def _setup(self, in_channels, out_channels, n_blocks, start_filts, up_mode, merge_mode, planar_blocks, batch_norm, attention, activation,
+               normalization, full_norm, dim, conv_mode, res_blocks=None):
+        """Argument checks and module tree; res_blocks = (enc_res_blocks, dec_res_blocks) builds the ResUNet's blocks (elektronn3_amd/resunet.py)."""
         # -- the reference's argument validation (unet.py:774-824), same exception types
         if n_blocks < 1:
             raise ValueError('n_blocks must be > 1.')
@@ -625,6 +631,11 @@ class UNet(nn.Module):
         if start_filts % 8 != 0: unsupported.append(f'start_filts={start_filts} (must be a multiple of 8)')
         if not (1 <= out_channels <= 16): unsupported.append(f'out_channels={out_channels} (1..16)')
         if not (in_channels < 8 or in_channels % 8 == 0): unsupported.append(f'in_channels={in_channels}')
+        if res_blocks is not None:
+            if dim != 3: unsupported.append('ResUNet with dim=2 (the reference builds its ConvBlocks with Conv3d whatever dim says, resunet.py:289-299)')
+            if conv_mode != 'same' and (res_blocks[0] or res_blocks[1]):
+                unsupported.append("residual blocks with conv_mode='valid' (the shortcut and the conv output differ in size)")
+            if not all(isinstance(r, int) and 0 <= r <= 8 for r in res_blocks): unsupported.append(f'res_blocks={res_blocks} (0..8)')
         if unsupported:
             raise NotImplementedError('not implemented on the MI355X HIP path yet: ' + ', '.join(unsupported))
 
@@ -645,12 +656,15 @@ class UNet(nn.Module):
         self.down_convs = nn.ModuleList()
         self.up_convs = nn.ModuleList()
         outs = in_channels
-        for i in range(n_blocks):
+        if res_blocks is not None:
+            self.enc_res_blocks, self.dec_res_blocks = res_blocks
+            outs = self._build_blocks()
+        for i in range(n_blocks if res_blocks is None else 0):
             ins = in_channels if i == 0 else outs
             outs = start_filts * (2 ** i)
             self.down_convs.append(DownConv(ins, outs, pooling=i < n_blocks - 1, planar=i in self.planar_blocks, dim=dim,
                                             normalization=normalization, full_norm=full_norm, activation=activation, conv_mode=conv_mode))
-        for i in range(n_blocks - 1):
+        for i in range(n_blocks - 1 if res_blocks is None else 0):
             ins = outs
             outs = ins // 2
             self.up_convs.append(UpConv(ins, outs, planar=(n_blocks - 2 - i) in self.planar_blocks, dim=dim,
@@ -659,11 +673,14 @@ class UNet(nn.Module):
         self.conv_final = _LAYERS[dim][0](outs, out_channels, kernel_size=1)
         self.apply(self.weight_init)
         self._script_key = [float(v) for v in self._plan_key()]      # (read by the scripted forward)
-        self._script_ok = normalization != 'instance' and dim == 3 and self._rrelu_interval() is None and not attention     # (train-mode RReLU needs a per-call seed)
+        self._script_ok = (normalization != 'instance' and dim == 3 and self._rrelu_interval() is None and not attention     # (train-mode RReLU needs a per-call seed)
+                           and res_blocks is None)
 
     @staticmethod
     def weight_init(m):
         """Xavier-normal weights, zero biases for every (transposed) conv -- same scheme as unet.py:885-892."""
+        if isinstance(m, GridAttention):      # (as the reference: only the container is skipped, `apply` still reaches its convs)
+            return
         if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d, nn.Conv2d, nn.ConvTranspose2d)):   # get_conv/get_convtranspose of the model's dim
             nn.init.xavier_normal_(m.weight)
             if m.bias is not None:
@@ -689,7 +706,11 @@ class UNet(nn.Module):
                 _num_groups(self.normalization) if self.normalization.startswith('group') else 0,
                 {'transpose': 0, 'resizeconv_nearest': 1, 'resizeconv_linear': 2, 'resizeconv_nearest1': 3, 'resizeconv_linear1': 4}[self.up_mode],
                 1 if self.conv_mode == 'valid' else 0, float(_activation_slope(self.activation)),
-                (2 if self.dim == 2 else 1) if getattr(self, 'attention', False) else 0)
+                (2 if self.dim == 2 else 1) if getattr(self, 'attention', False) else 0) + self._variant_key()
+
+    def _variant_key(self):
+        """(resunet, enc_res_blocks, dec_res_blocks) of e3_unet_cfg."""
+        return (0, 0, 0)
 
     def _plan(self):
         return _get_plan(self._plan_key())

@@ -68,6 +68,10 @@ typedef struct e3_unet_cfg {
     int32_t attention;      /* 0: attention=False (DummyAttention); 1: attention=True, dim=3 (GridAttention with a 2x2x2 theta, unet.py:376-379,452-541);
                              * 2: attention=True, dim=2 (2x2 theta on the depth-1 volume).  Parameters 'up_convs.i.attention.{w.0,w.1,theta,phi,psi}.*'
                              * join the table after the block's up-convolution; fp32 path only */
+    int32_t resunet;        /* 0: elektronn3.models.unet.UNet; 1: elektronn3.models.resunet.UNet (ConvBlock / DownBlock / UpBlock, resunet.py:212-457:
+                             * parameters '<block>.convs.<k>.{conv1,norm1,act1,conv2,norm2,act2,proj}.*', a norm after every conv, full_norm ignored) */
+    int32_t enc_res_blocks; /* resunet: ConvBlocks per encoder block = max(1, enc_res_blocks); >= 1: with residual shortcuts (not from the input image) */
+    int32_t dec_res_blocks; /* resunet: the same for the decoder blocks (resunet.py:705-707,809-810) */
 } e3_unet_cfg;
 
 typedef struct e3_unet_plan e3_unet_plan;

@@ -124,6 +124,48 @@ def unet_forward(sd, x, n_blocks, planar_blocks=(), training=True, atts=None):
     return _conv(x, sd, 'conv_final')
 
 
+def resunet_forward(sd, x, n_blocks, planar_blocks=(), training=True, enc_res_blocks=0, dec_res_blocks=0, atts=None):
+    """elektronn3.models.resunet.UNet.forward (resunet.py:944-967) restated with ATen ops: DownBlock / UpBlock = Sequential of ConvBlocks
+    (resunet.py:254-262: conv1-norm1-act1-conv2-[+ proj(inp)]-norm2-act2), max(1, res_blocks) per block; shortcuts when res_blocks >= 1, none
+    from the input image (resunet.py:287-299,906).  dim=3 only (the reference's ConvBlocks are Conv3d whatever `dim` says)."""
+    def conv_block(p, inp, residual):
+        y = _act(_bn(_conv(inp, sd, p + 'conv1'), sd, p + 'norm1', training), sd, p + 'act1')
+        y = _conv(y, sd, p + 'conv2')
+        if residual:
+            y = y + (F.conv3d(inp, sd[p + 'proj.weight'], sd[p + 'proj.bias']) if p + 'proj.weight' in sd else inp)
+        return _act(_bn(y, sd, p + 'norm2', training), sd, p + 'act2')
+
+    enc = []
+    for i in range(n_blocks):
+        y = x
+        for c in range(max(1, enc_res_blocks)):
+            y = conv_block(f'down_convs.{i}.convs.{c}.', y, enc_res_blocks >= 1 and not (c == 0 and i == 0))
+        enc.append(y)
+        x = F.max_pool3d(y, kernel_size=(1, 2, 2) if i in planar_blocks else 2, ceil_mode=True) if i < n_blocks - 1 else y
+    for i in range(n_blocks - 1):
+        p = f'up_convs.{i}.'
+        if p + 'upconv.conv.weight' in sd:
+            scale = (1, 2, 2) if (n_blocks - 2 - i) in planar_blocks else 2
+            xu = F.interpolate(x, scale_factor=scale, mode='trilinear', align_corners=False) if sd.get('__up_linear__', False) \
+                else F.interpolate(x, scale_factor=scale, mode='nearest')
+            up = _conv(xu, sd, p + 'upconv.conv')
+        else:
+            w = sd[p + 'upconv.weight']
+            up = F.conv_transpose3d(x, w, sd[p + 'upconv.bias'], stride=tuple(w.shape[2:]))
+        skip, up = autocrop(enc[-(i + 2)], up)
+        if p + 'attention.theta.weight' in sd:
+            skip, att = grid_attention(sd, p + 'attention.', skip, x, training)
+            if atts is not None:
+                atts.append(att)
+        up = _act(_bn(up, sd, p + 'norm0', training), sd, p + 'act0')
+        cat = sd[p + 'convs.0.conv1.weight'].shape[1] == 2 * up.shape[1]
+        y = torch.cat((up, skip), 1) if cat else up + skip
+        for c in range(max(1, dec_res_blocks)):
+            y = conv_block(p + f'convs.{c}.', y, dec_res_blocks >= 1)
+        x = y
+    return _conv(x, sd, 'conv_final')
+
+
 def combined_loss(logits, target, class_weights=(0.2653, 0.7347)):
     """0.5*CrossEntropy(weight) + 0.5*Dice(softmax, weight) -- the example's criterion
     (examples/train_unet_neurodata.py:294-296; modules/loss.py:19-49,165-189), restated with torch ops."""

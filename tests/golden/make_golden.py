@@ -183,10 +183,12 @@ def make_rrelu_eval(unet, out, seed=17):
     np.savez_compressed(out, **d)
 
 
-def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu', up_mode='transpose', conv_mode='same', attention=False):
+def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu', up_mode='transpose', conv_mode='same', attention=False, res_blocks=None):
+    # res_blocks = (enc_res_blocks, dec_res_blocks): `unet` is then the reference's models/resunet.py module
+    extra = {} if res_blocks is None else dict(enc_res_blocks=res_blocks[0], dec_res_blocks=res_blocks[1])
     torch.manual_seed(seed)
     model = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
-                      planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode, conv_mode=conv_mode, attention=attention)
+                      planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode, conv_mode=conv_mode, attention=attention, **extra)
     # make BN affine + conv bias non-trivial so that the fixtures exercise them
     with torch.no_grad():
         for name, p in model.named_parameters():
@@ -223,6 +225,9 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
         d['cfg.conv_mode'] = np.array(conv_mode)
     if attention:
         d['cfg.attention'] = np.array(1)
+    if res_blocks is not None:
+        d['cfg.resunet'] = np.array(1)
+        d['cfg.enc_res_blocks'] = np.array(res_blocks[0]); d['cfg.dec_res_blocks'] = np.array(res_blocks[1])
     for k, v in sd0.items():
         d['sd0/' + k] = v
     for k, v in model.state_dict().items():
@@ -235,7 +240,7 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
         d['logits_eval'] = npy(model(x))
     # fp64 reference of the same step (tolerances are stated against it)
     m64 = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
-                    planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode, conv_mode=conv_mode, attention=attention).double()
+                    planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode, conv_mode=conv_mode, attention=attention, **extra).double()
     m64.load_state_dict({k: torch.as_tensor(v).double() if v.dtype != np.int64 else torch.as_tensor(v) for k, v in sd0.items()})
     m64.train()
     o64 = m64(x.double())
@@ -461,6 +466,14 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'add':
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_add_odd.npz', seed=6, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 14, 19), batch=2, merge_mode='add')
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'resunet':     # elektronn3.models.resunet.UNet (resunet.py:598-934): plain ConvBlocks, residual ones
+        # (identity and projected shortcuts, several per block), with planar blocks / attention / merge 'add' / no norm
+        resunet = _load('elektronn3.models.resunet', f'{REF}/models/resunet.py')
+        make_unet_case(resunet, loss_mod, f'{HERE}/resunet_nb3_sf8_res00.npz', seed=21, n_blocks=3, start_filts=8, planar_blocks=(), shape=(8, 12, 16), batch=2, res_blocks=(0, 0))
+        make_unet_case(resunet, loss_mod, f'{HERE}/resunet_nb3_sf8_res21_odd.npz', seed=22, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 19), batch=2, res_blocks=(2, 1))
+        make_unet_case(resunet, loss_mod, f'{HERE}/resunet_nb3_sf8_res12_add_attention.npz', seed=23, n_blocks=3, start_filts=8, planar_blocks=(), shape=(9, 13, 18), batch=2, merge_mode='add', activation='leaky', attention=True, res_blocks=(1, 2))
+        make_unet_case(resunet, loss_mod, f'{HERE}/resunet_nb2_sf8_res11_nonorm.npz', seed=24, n_blocks=2, start_filts=8, planar_blocks=(), shape=(10, 12, 14), batch=2, normalization='none', res_blocks=(1, 1))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'attention':     # attention=True (GridAttention, unet.py:452-541): odd sizes (phi(g) and the gate are resized),
         # dim=2, conv_mode='valid' + a planar block (theta halves the depth the pooling kept), merge_mode='add'

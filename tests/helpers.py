@@ -36,6 +36,8 @@ def unet_cfg(npz):
         cfg['activation'] = str(npz['cfg.activation'])
     if 'cfg.merge_mode' in npz.files:
         cfg['merge_mode'] = str(npz['cfg.merge_mode'])
+    if 'cfg.resunet' in npz.files:       # elektronn3.models.resunet.UNet: build with elektronn3_amd.resunet.UNet
+        cfg['enc_res_blocks'] = int(npz['cfg.enc_res_blocks']); cfg['dec_res_blocks'] = int(npz['cfg.dec_res_blocks'])
     if 'cfg.attention' in npz.files:
         cfg['attention'] = bool(int(npz['cfg.attention']))
     if 'cfg.full_norm' in npz.files:
@@ -48,6 +50,12 @@ def is_prebn_bias(k, names=None, paramless_norms=()):
     names) tells whether the norm after that conv exists at all (normalization='none' / full_norm=False make it nn.Identity)."""
     if k.endswith('.attention.w.0.bias'):       # GridAttention's output transform: 1x1x1 conv -> nn.BatchNorm, always (unet.py:488-491)
         return True
+    if '.convs.' in k:       # ResUNet ConvBlock (resunet.py:212-262): conv1 -> norm1, conv2 (+ proj) -> norm2
+        if not k.endswith(('.conv1.bias', '.conv2.bias', '.proj.bias')):
+            return False
+        block = k.rsplit('.', 2)[0]
+        norm = 'norm1' if k.endswith('.conv1.bias') else 'norm2'
+        return names is None or f'{block}.{norm}.weight' in names or f'{block}.{norm}' in paramless_norms
     if not (k.endswith('.bias') and ('conv1' in k or 'conv2' in k or 'upconv' in k) and not k.startswith('conv_final')):
         return False
     if names is None:

@@ -153,6 +153,51 @@ def test_torch_restatement_of_grid_attention_train_step(case):
             np.testing.assert_allclose(sd[k].numpy(), v, rtol=1e-5, atol=1e-7, err_msg=k)
 
 
+@pytest.mark.parametrize('case', ['resunet_nb3_sf8_res00.npz', 'resunet_nb3_sf8_res21_odd.npz', 'resunet_nb3_sf8_res12_add_attention.npz',
+                                  'resunet_nb2_sf8_res11_nonorm.npz'])
+def test_torch_restatement_of_resunet_train_step(case):
+    """elektronn3.models.resunet.UNet is outside the C oracle; its checker is oracle/torch_ref.py::resunet_forward (resunet.py:254-262,944-967
+    restated with ATen ops).  Pinned here by the reference's own train step: logits, loss, every gradient, the running statistics."""
+    import torch
+    from oracle.torch_ref import combined_loss, resunet_forward
+    g = load_npz(case)
+    cfg = unet_cfg(g)
+    sd = {k: torch.from_numpy(np.array(v)).clone() for k, v in sub(g, 'sd0').items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running' not in k:
+            v.requires_grad_(True)
+    if cfg.get('activation') == 'leaky':
+        sd['__act_slope__'] = 0.1
+    out = resunet_forward(sd, torch.from_numpy(g['x']), cfg['n_blocks'], cfg['planar_blocks'], True, cfg['enc_res_blocks'], cfg['dec_res_blocks'])
+    np.testing.assert_allclose(out.detach().numpy(), g['logits'], rtol=1e-5, atol=1e-6)
+    loss = combined_loss(out, torch.from_numpy(g['target']))
+    assert abs(float(loss) - float(g['loss'])) < 1e-6
+    loss.backward()
+    ref = sub(g, 'grad')
+    gnorm = np.sqrt(sum(float(np.sum(v.astype(np.float64) ** 2)) for v in ref.values()))
+    for k, v in ref.items():
+        assert np.abs(sd[k].grad.numpy() - v).max() <= 1e-5 * gnorm, k
+    for k, v in sub(g, 'sd1').items():
+        if 'running' in k:
+            np.testing.assert_allclose(sd[k].numpy(), v, rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+def test_resunet_parameter_table_matches_the_reference_state_dict():
+    """Host logic: elektronn3_amd.resunet.UNet has the reference's state_dict keys in the reference's order, and the native plan's table
+    names every one of them (residual blocks with identity and projected shortcuts, attention)."""
+    import torch
+    from elektronn3_amd.resunet import UNet
+    for case in ['resunet_nb3_sf8_res21_odd.npz', 'resunet_nb3_sf8_res12_add_attention.npz']:
+        g = load_npz(case)
+        sd = {k: torch.from_numpy(np.array(v)) for k, v in sub(g, 'sd0').items()}
+        m = UNet(1, 2, **unet_cfg(g))
+        m.load_state_dict(sd)
+        assert list(m.state_dict().keys()) == list(sd.keys())
+        plan = m._plan()
+        assert set(plan.names) == {k for k in sd if not k.endswith('num_batches_tracked')}
+        assert any(n.endswith('.proj.weight') for n in plan.names)
+
+
 def test_unet_eval_forward():
     g = load_npz('unet_nb2_sf8.npz')
     cfg = unet_cfg(g)

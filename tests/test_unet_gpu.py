@@ -27,11 +27,15 @@ CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_plana
          'unet_nb3_sf8_prelu_odd.npz', 'unet_nb3_sf8_valid.npz',
          # attention=True (GridAttention): odd sizes (both resizes are real interpolations), dim=2, conv_mode='valid' + planar block, merge 'add'
          'unet_nb3_sf8_attention_odd.npz', 'unet2d_nb3_sf8_attention.npz', 'unet_nb3_sf8_attention_valid_planar0.npz',
-         'unet_nb3_sf8_attention_add.npz']
+         'unet_nb3_sf8_attention_add.npz',
+         # elektronn3.models.resunet.UNet: plain ConvBlocks; residual ones (2 per encoder block + planar + odd; with attention, 'add', leaky; no norm)
+         'resunet_nb3_sf8_res00.npz', 'resunet_nb3_sf8_res21_odd.npz', 'resunet_nb3_sf8_res12_add_attention.npz', 'resunet_nb2_sf8_res11_nonorm.npz']
 
 
 def build(cfg, sd_np):
     from elektronn3_amd.unet import UNet
+    if 'enc_res_blocks' in cfg:         # fixture of the reference's models/resunet.py
+        from elektronn3_amd.resunet import UNet
     m = UNet(in_channels=1, out_channels=2, **cfg)
     sd = {k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}
     m.load_state_dict(sd)           # reference key names and shapes must match exactly
