@@ -3,6 +3,7 @@
 Host-side mirror of the reference interface for that path only:
 
 * :class:`elektronn3_amd.unet.UNet`            <- ``elektronn3.models.unet.UNet``
+* :class:`elektronn3_amd.resunet.UNet`         <- ``elektronn3.models.resunet.UNet`` (the same network built from residual ConvBlocks)
 * :class:`elektronn3_amd.inference.Predictor`  <- ``elektronn3.inference.Predictor`` / ``tiled_apply``
 * :class:`elektronn3_amd.dataparallel.GradSync` (one process per GPU, RCCL all-reduce of the flat gradient)
 

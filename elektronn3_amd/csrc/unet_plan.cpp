@@ -262,7 +262,8 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         const LevelDims& lo = ND.u[k].in;          // (the conv grid)
         if (u.is_up || u.planar || u.cin < 8) continue;
         // split-K (training only; forward: units with batch statistics, 'same' convs): the splits count when the Winograd grid is sized
-        const bool skf = training && u.has_norm() && !valid, skd = training && !valid;
+        // (a residual unit's conv writes plain accumulations next to its shortcut: no split-K in its forward)
+        const bool skf = training && u.has_norm() && !valid && u.res_in < 0, skd = training && !valid;
         const int sf = skf ? conv_wino_splitk(lo.D, lo.H, lo.W, u.cin, u.cout) : 0, sd = skd ? conv_wino_splitk(lo.D, lo.H, lo.W, u.cout, u.cin) : 0;
         const bool wf = sf > 0 || conv_use_wino(CONV_K3, 0, N, lo.D, lo.H, lo.W, u.cin, u.cout);
         const bool wd = training && (sd > 0 || conv_use_wino(CONV_K3, 0, N, lo.D, lo.H, lo.W, u.cout, u.cin));

@@ -209,6 +209,40 @@ def test_predictor_dim2_native_tiled():
 
 
 @pytest.mark.gpu
+def test_predictor_resunet_with_attention_native_tiled():
+    """The Predictor is model-agnostic in the reference; here a ``resunet.UNet`` with residual blocks and attention gates goes through the
+    native path (fused softmax, pipelined tiles): equals the hand-rolled tiles, and one tile equals the fp64 op sequence."""
+    from elektronn3_amd.inference import Predictor, tile_plan
+    from elektronn3_amd.resunet import UNet
+    from oracle.torch_ref import resunet_forward
+    torch.manual_seed(18)
+    m = UNet(1, 2, n_blocks=3, start_filts=16, enc_res_blocks=2, dec_res_blocks=1, attention=True).cuda()
+    m.train()
+    with torch.no_grad():
+        for _ in range(2):
+            m(torch.randn(2, 1, 16, 32, 32, device='cuda'))      # non-trivial running statistics
+    m.eval()
+    vol = torch.randn(1, 1, 20, 70, 90)
+    tile, ov = (16, 32, 48), (4, 8, 8)
+    y = Predictor(m, device='cuda', tile_shape=tile, overlap_shape=ov, offset=None, out_shape=(2, 20, 70, 90), apply_softmax=True).predict(vol)
+    assert tuple(y.shape) == (1, 2, 20, 70, 90) and torch.isfinite(y).all()
+    padded_out = (32, 96, 96)
+    padded = torch.zeros(1, 1, *(p + 2 * o for p, o in zip(padded_out, ov)))
+    padded[:, :, 4:24, 8:78, 8:98] = vol
+    full = torch.zeros(1, 2, *padded_out)
+    sd = {k: v.double() if v.is_floating_point() else v for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        for i, (ilo, ihi, olo, ohi) in enumerate(tile_plan(padded_out, tile, ov)):
+            t = padded[:, :, ilo[0]:ihi[0], ilo[1]:ihi[1], ilo[2]:ihi[2]].cuda()
+            o = m.forward_softmax(t)
+            if i == 0:
+                ref = torch.softmax(resunet_forward(sd, t.double(), 3, (), False, 2, 1), 1)
+                assert torch.allclose(o.double(), ref, rtol=1e-4, atol=1e-5)
+            full[:, :, olo[0]:ohi[0], olo[1]:ohi[1], olo[2]:ohi[2]] = o[:, :, 4:20, 8:40, 8:56].cpu()
+    assert torch.equal(y, full[:, :, :20, :70, :90])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('world', [3, 7])
 def test_predictor_tile_parallel_ranks_share_one_output(tmp_path, world):
     """the (z, y) rows of tiles are split over the ranks, every rank writes its rows into ONE output buffer in

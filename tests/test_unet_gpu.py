@@ -544,6 +544,77 @@ def test_option_variants_against_pytorch_rocm(kw):
         assert torch.equal(m(x[1:2]), ye[1:2])
 
 
+@pytest.mark.parametrize('kw', [dict(enc_res_blocks=1, dec_res_blocks=1), dict(enc_res_blocks=2, dec_res_blocks=2, planar_blocks=(0,)),
+                                dict(enc_res_blocks=0, dec_res_blocks=0, activation='leaky'),
+                                dict(enc_res_blocks=1, dec_res_blocks=0, attention=True, merge_mode='add'),
+                                dict(enc_res_blocks=2, dec_res_blocks=1, normalization='none', up_mode='resizeconv_nearest'),
+                                dict(enc_res_blocks=1, dec_res_blocks=1, normalization='group', activation='silu')],
+                         ids=['res11', 'res22_planar', 'res00_leaky', 'res10_attention_add', 'res21_nonorm_resizeconv', 'res11_group_silu'])
+def test_resunet_variants_against_pytorch_rocm(kw):
+    """elektronn3.models.resunet.UNet (resunet.py:598-934) at a size that runs the Winograd kernels (2 x 32 x 64 x 64, start_filts 32): residual
+    ConvBlocks with identity and projected shortcuts, several per block; forward, loss, every gradient (projection weights and biases included),
+    running statistics, the eval-mode forward, and the backward through the eval-mode forward -- against the fp64 op sequence on PyTorch-ROCm."""
+    from elektronn3_amd.resunet import UNet
+    from oracle.torch_ref import combined_loss, resunet_forward
+    torch.manual_seed(13)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=3, start_filts=32, **kw).cuda().train()
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith('.bias'):
+                p.copy_(0.1 * torch.randn_like(p))
+    group = str(kw.get('normalization', '')).startswith('group')
+    pl = tuple(kw.get('planar_blocks', ()))
+    e, d = kw['enc_res_blocks'], kw['dec_res_blocks']
+    flags = {'__act_slope__': {'relu': 0.0, 'leaky': 0.1, 'silu': 2.0}[kw.get('activation', 'relu')], '__num_groups__': 8 if group else 0}
+    x = torch.randn(2, 1, 32, 64, 64, device='cuda')
+    t = torch.randint(0, 2, (2, 32, 64, 64), device='cuda')
+
+    def reference(sd0, training):
+        sd = {k: (v.double() if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd0.items()}
+        sd.update(flags)
+        out = resunet_forward(sd, x.double(), 3, pl, training, e, d)
+        loss = combined_loss(out, t)
+        loss.backward()
+        return sd, out, loss
+
+    def check_grads(sd, zero_bias_ok, bound):
+        names = {k for k, _ in m.named_parameters()}
+        gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))
+        for k, p in m.named_parameters():
+            gr = sd[k].grad
+            if zero_bias_ok and is_prebn_bias(k, set() if group else names):
+                assert float(p.grad.abs().max()) <= 1e-5 * float(gn), k
+                continue
+            err = float((p.grad.double() - gr).norm() / gr.norm().clamp_min(1e-30))
+            assert err < bound, (k, err)
+
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    out = m(x)
+    loss = combined_loss(out, t)
+    m.zero_grad(set_to_none=True)
+    loss.backward()
+    sd, ref, lref = reference(sd0, True)
+    assert torch.allclose(out.double(), ref, rtol=1e-4, atol=1e-4), float((out - ref).abs().max())
+    assert abs(float(loss.detach()) - float(lref.detach())) < 1e-5
+    for k, v in m.state_dict().items():
+        if 'running' in k:
+            torch.testing.assert_close(v.double(), sd[k], rtol=1e-5, atol=1e-6, msg=k)
+    assert any(k.endswith('.proj.weight') for k, _ in m.named_parameters()) == (e >= 1 or d >= 1)
+    check_grads(sd, True, 1e-2)
+    # eval mode: inference path, then a backward through it (frozen statistics; GroupNorm has none: same function as above)
+    m.eval()
+    sd1 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ye = m(x)
+    m.zero_grad(set_to_none=True)
+    oe = m(x)
+    combined_loss(oe, t).backward()
+    sde, refe, _ = reference(sd1, False)
+    assert torch.allclose(ye.double(), refe, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(oe.double(), refe, rtol=1e-4, atol=1e-4)
+    check_grads(sde, group, 1e-2)
+
+
 def test_dim2_unet_against_pytorch_rocm():
     """dim=2 (unet.py:47-74: Conv2d / ConvTranspose2d / MaxPool2d / BatchNorm2d, 4D input) at 2x1x384x512 with the headline
     widths (n_blocks=4, start_filts=32): runs on the planar kernels incl. the planar Winograd ones; vs the same op sequence
