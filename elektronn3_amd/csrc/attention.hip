@@ -8,7 +8,7 @@
 //   out     = BatchNorm(W(att * x))         1x1x1 conv + bias, then nn.BatchNorm
 //
 // The block is off the headline configuration (attention=False everywhere in the reference's examples), so it is built from a few
-// general fp32 building blocks rather than per-shape MFMA kernels: an LDS-tiled row GEMM (rows = voxels; optional 2x2x2 gather on the
+// general fp32 building blocks rather than per-shape kernels: an LDS-tiled row GEMM on the fp32 matrix cores (rows = voxels; optional 2x2x2 gather on the
 // K side or scatter on the N side, per-row scales, bias / affine epilogue, fused row dot product), its reduction-over-voxels
 // counterpart for the weight gradients (fixed split order -> deterministic), a general linear resize and its adjoint in gather form,
 // and the two elementwise gate kernels.  Everything is NDHWC fp32; channel counts are multiples of 4.
@@ -23,6 +23,15 @@ __device__ __forceinline__ size_t tap_voxel(const Grid5& g, size_t r, int t) {
     const int tx = t & 1, ty = (t >> 1) & 1, tz = t >> 2;            // torch kernel order (kd, kh, kw); sd == 1: four taps, tz = 0
     return ((n * g.D + (size_t)(g.sd * z + tz)) * g.H + (size_t)(2 * y + ty)) * g.W + (size_t)(2 * x + tx);
 }
+
+// the same split in two: tap 0's voxel of row r (32-bit divisions: rows < 2^32 is checked by the launchers) + the tap's offset
+__device__ __forceinline__ size_t row_base(const Grid5& g, size_t r) {
+    unsigned q = (unsigned)r;
+    const unsigned x = q % (unsigned)g.w; q /= (unsigned)g.w; const unsigned y = q % (unsigned)g.h; q /= (unsigned)g.h;
+    const unsigned z = q % (unsigned)g.d; const unsigned n = q / (unsigned)g.d;
+    return (((size_t)n * g.D + (size_t)(g.sd * z)) * g.H + (size_t)(2 * y)) * g.W + (size_t)(2 * x);
+}
+__device__ __forceinline__ unsigned tap_off(const Grid5& g, int t) { return (unsigned)(((t >> 2) * g.H + ((t >> 1) & 1)) * g.W + (t & 1)); }
 
 }  // namespace
 
@@ -181,17 +190,211 @@ __global__ __launch_bounds__(256) void att_redgemm_kernel(RedGemmArgs a) {
         }
 }
 
-// out[m * osm + c * osc + t * ost] = sum_s part[s][m][t * Ck + c]; bias_out[m] = sum_s part[s][m][K] (fixed order)
-__global__ void att_red_reduce_kernel(const float* __restrict__ part, int S, int M, int Ck, int Tk, int ones, float* __restrict__ out,
-                                      int osm, int osc, int ost, float* __restrict__ bias_out) {
+// ---- the same two GEMMs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: lane l holds A[row l & 31][k = l >> 5], B[k = l >> 5][col l & 31];
+// the 16 accumulators of a lane are col = l & 31, rows (e & 3) + 8 (e >> 2) + 4 (l >> 5)).  The VALU kernels above stay as the A/B
+// reference (E3_ATT_VALU=1).
+// NT column tiles of 32 per pass: a 128-row block keeps NT x 16 accumulators per lane and reads its A rows once.  SC: scattered output rows
+// (Tn > 1); DOT: the row dot product / output row scale of the gate's backward (compiled out elsewhere: they cost registers)
+template <int NT, bool SC, bool DOT>
+__global__ __launch_bounds__(256) void att_rowgemm_mfma_kernel(RowGemmArgs a) {
+    __shared__ float As[16][129];              // [k][row]
+    __shared__ float Bs[16][NT * 32 + 1];      // [k][col]
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+    const size_t row0 = (size_t)blockIdx.x * 128;
+    const int K = a.Tk * a.Ck, Nc = a.Tn * a.Cn;
+    const int lr = tid >> 1, ko = (tid & 1) * 8;                  // staging role on the A side: one row, eight consecutive k
+    const size_t r = row0 + lr; const bool rok = r < a.rows;
+    const float rsin = (rok && a.rs_in) ? a.rs_in[r] : 1.f;
+    const size_t abase = (rok && a.Tk > 1) ? row_base(a.g, r) : r;      // voxel of the staged row (tap 0)
+    unsigned obase[SC ? 16 : 1];                                         // voxels of this lane's 16 output rows (tap 0)
+    if (SC) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const size_t rr = row0 + w * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            obase[SC ? e : 0] = rr < a.rows ? (unsigned)row_base(a.g, rr) : 0u;
+        }
+    }
+    float dotacc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dotacc[e] = 0.f;
+    for (int n0 = 0; n0 < Nc; n0 += NT * 32) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = k0 + ko + 4 * h;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (rok && k < K) {
+                    const int t = k / a.Ck, c = k - t * a.Ck;
+                    const size_t vi = a.Tk > 1 ? abase + tap_off(a.g, t) : r;
+                    v = *reinterpret_cast<const f32x4*>(a.A + vi * a.lda + c) * rsin;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[ko + 4 * h + e][lr] = v[e];
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * NT; ++i) {
+                const int e = tid + 256 * i, kb = e / (NT * 32), nn = e - kb * (NT * 32);
+                const int kk = k0 + kb, n = n0 + nn;
+                float wv = 0.f;
+                if (kk < K && n < Nc) {
+                    const int tk = kk / a.Ck, ck = kk - tk * a.Ck, tn = n / a.Cn, cn = n - tn * a.Cn;
+                    wv = a.W[(size_t)a.wst * (tk + tn) + (size_t)a.wsc * ck + (size_t)a.wsn * cn];
+                }
+                Bs[kb][nn] = wv;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float av = As[2 * kk + hi][w * 32 + lo];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bs[2 * kk + hi][t * 32 + lo], acc[t], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = n0 + t * 32 + lo;
+            if (n >= Nc) continue;
+            const float bq = a.bias ? a.bias[n] : 0.f, sc = a.epi_scale ? a.epi_scale[n] : 1.f, sh = a.epi_scale ? a.epi_shift[n] : 0.f;
+            const int tn = n / a.Cn, cn = n - tn * a.Cn;
+            const unsigned toff = a.Tn > 1 ? tap_off(a.g, tn) : 0u;
+            // all loads of the tile first (old values, dot operands, row scales), then the stores: a store between two loads would serialise them
+            float oldv[16], dv[DOT ? 16 : 1], rs[DOT ? 16 : 1];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const size_t rr = row0 + w * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                const bool ok = rr < a.rows;
+                const size_t vi = SC ? (size_t)obase[SC ? e : 0] + toff : rr;
+                oldv[e] = (ok && a.accumulate) ? a.out[vi * a.ldo + cn] : 0.f;
+                if (DOT) {
+                    dv[DOT ? e : 0] = (ok && a.rowdot) ? a.dotsrc[rr * a.ld_dot + n] : 0.f;
+                    rs[DOT ? e : 0] = (ok && a.rs_out) ? a.rs_out[rr] : 1.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const size_t rr = row0 + w * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (rr >= a.rows) continue;
+                const size_t vi = SC ? (size_t)obase[SC ? e : 0] + toff : rr;
+                const float v = (acc[t][e] + bq) * sc + sh;
+                if (DOT) { dotacc[e] = fmaf(v, dv[DOT ? e : 0], dotacc[e]); a.out[vi * a.ldo + cn] = fmaf(v, rs[DOT ? e : 0], oldv[e]); }
+                else a.out[vi * a.ldo + cn] = v + oldv[e];
+            }
+        }
+    }
+    if (DOT && a.rowdot) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float v = dotacc[e];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            const size_t rr = row0 + w * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (lo == 0 && rr < a.rows) a.rowdot[rr] = v;
+        }
+    }
+}
+
+template <int NT>      // block tile: 32 rows of L^T (m) x NT * 32 columns (k); the four waves split each 64-voxel stage and are summed at the end
+__global__ __launch_bounds__(256) void att_redgemm_mfma_kernel(RedGemmArgs a) {
+    __shared__ float Ls[64][33];               // [voxel][m]
+    __shared__ float Rs[64][NT * 32 + 1];      // [voxel][k]
+    __shared__ float red[4][32][33];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+    const int m0 = blockIdx.z * 32, k0 = blockIdx.y * (NT * 32), K = a.Tk * a.Ck, Kp = K + a.ones;
+    size_t chunk = (a.rows + a.S - 1) / a.S; chunk = (chunk + 63) / 64 * 64;
+    const size_t vbeg = (size_t)blockIdx.x * chunk;
+    const size_t vend = vbeg + chunk < a.rows ? vbeg + chunk : a.rows;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const int lv = tid >> 2, q = tid & 3;          // staging role: one voxel, a quarter of the m / k range
+    const bool lvec = (a.ldl % 4 == 0) && (a.M % 4 == 0);
+    for (size_t vb = vbeg; vb < vend; vb += 64) {
+        const size_t v = vb + lv;
+        const bool vok = v < vend;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = m0 + q * 8 + 4 * h;
+            f32x4 lvv = {0.f, 0.f, 0.f, 0.f};
+            if (vok) {
+                if (lvec) { if (m < a.M) lvv = *reinterpret_cast<const f32x4*>(a.L + v * a.ldl + m); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (m + e < a.M) lvv[e] = a.L[v * a.ldl + m + e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ls[lv][q * 8 + 4 * h + e] = lvv[e];
+        }
+        const float rsv = (vok && a.rs) ? a.rs[v] : 1.f;
+        const size_t vbase = (vok && a.Tk > 1) ? row_base(a.g, v) : v;
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {
+            const int kq = q * (NT * 8) + 4 * i, k = k0 + kq;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (vok) {
+                if (k < K) {
+                    const int t = k / a.Ck, c = k - t * a.Ck;
+                    const size_t vi = a.Tk > 1 ? vbase + tap_off(a.g, t) : v;
+                    val = *reinterpret_cast<const f32x4*>(a.A + vi * a.lda + c) * rsv;
+                } else if (a.ones && k == K) val[0] = 1.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Rs[lv][kq + e] = val[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const int vv = 16 * w + 2 * st + hi;
+            const float av = Ls[vv][lo];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Rs[vv][t * 32 + lo], acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[w][(e & 3) + 8 * (e >> 2) + 4 * hi][lo] = acc[t][e];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = tid + 256 * i, mr = o >> 5, kc = o & 31;
+            const float sum = (red[0][mr][kc] + red[1][mr][kc]) + (red[2][mr][kc] + red[3][mr][kc]);
+            const int m = m0 + mr, k = k0 + t * 32 + kc;
+            if (m < a.M && k < Kp) a.part[((size_t)blockIdx.x * a.M + m) * Kp + k] = sum;
+        }
+        __syncthreads();
+    }
+}
+
+// out = sum over the S splits: 16 outputs per workgroup, 16 partial sums per output, then a fixed-order tree (deterministic; replaces the
+// one-thread-per-output loop, which is latency-bound when S is in the hundreds)
+__global__ __launch_bounds__(256) void att_red_reduce16_kernel(const float* __restrict__ part, int S, int M, int Ck, int Tk, int ones, float* __restrict__ out,
+                                                               int osm, int osc, int ost, float* __restrict__ bias_out) {
+    __shared__ float ps[16][17];
     const int K = Tk * Ck, Kp = K + ones;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M * Kp) return;
-    const int m = i / Kp, k = i - m * Kp;
+    const int oi = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + oi;
     float sum = 0.f;
-    for (int s = 0; s < S; ++s) sum += part[((size_t)s * M + m) * Kp + k];
-    if (k < K) { const int t = k / Ck, c = k - t * Ck; out[(size_t)m * osm + (size_t)c * osc + (size_t)t * ost] = sum; }
-    else if (bias_out) bias_out[m] = sum;
+    if (i < M * Kp) for (int s = q; s < S; s += 16) sum += part[(size_t)s * M * Kp + i];
+    ps[q][oi] = sum;
+    __syncthreads();
+    if (q == 0 && i < M * Kp) {
+        float t8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t8[j] = ps[2 * j][oi] + ps[2 * j + 1][oi];
+        const float tot = ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
+        const int m = i / Kp, k = i - m * Kp;
+        if (k < K) { const int t = k / Ck, c = k - t * Ck; out[(size_t)m * osm + (size_t)c * osc + (size_t)t * ost] = tot; }
+        else if (bias_out) bias_out[m] = tot;
+    }
 }
 
 namespace {
@@ -324,19 +527,40 @@ inline int grid_for(size_t items) { size_t g = (items + 255) / 256; return (int)
 
 Grid5 grid5(const AttDims& d) { return Grid5{d.N, d.d, d.h, d.w, d.D, d.H, d.W, d.sd}; }
 
+const bool g_att_valu = getenv("E3_ATT_VALU") != nullptr;      // A/B switch: the VALU GEMMs instead of the matrix-core ones
+
 int run_rowgemm(RowGemmArgs a, hipStream_t s) {
     E3_REQUIRE(a.Ck % 4 == 0 && a.Cn % 4 == 0 && a.lda % 4 == 0 && a.ldo % 4 == 0, E3_ERR_UNSUPPORTED, "attention: channel counts must be multiples of 4");
     E3_REQUIRE(a.Tk == 1 || a.Tn == 1, E3_ERR_INVALID, "attention GEMM: taps on one side only");
+    E3_REQUIRE(a.rows < ((size_t)1 << 32), E3_ERR_UNSUPPORTED, "attention GEMM: more than 2^32 voxel rows");
     if (a.rows == 0) return E3_OK;
-    hipLaunchKernelGGL(att_rowgemm_kernel, dim3((unsigned)((a.rows + 63) / 64)), dim3(256), 0, s, a);
+    if (g_att_valu) hipLaunchKernelGGL(att_rowgemm_kernel, dim3((unsigned)((a.rows + 63) / 64)), dim3(256), 0, s, a);
+    else {
+        const dim3 g((unsigned)((a.rows + 127) / 128)), b(256);
+        const int tiles = cdiv(a.Tn * a.Cn, 32);
+        const bool sc = a.Tn > 1, dot = a.rowdot != nullptr || a.rs_out != nullptr;
+        E3_REQUIRE(!(sc && dot), E3_ERR_INVALID, "attention GEMM: scatter and row dot product are separate launches");
+#define E3_ROWGEMM(NT)                                                                                         \
+        do {                                                                                                   \
+            if (sc) hipLaunchKernelGGL((att_rowgemm_mfma_kernel<NT, true, false>), g, b, 0, s, a);           \
+            else if (dot) hipLaunchKernelGGL((att_rowgemm_mfma_kernel<NT, false, true>), g, b, 0, s, a);     \
+            else hipLaunchKernelGGL((att_rowgemm_mfma_kernel<NT, false, false>), g, b, 0, s, a);             \
+        } while (0)
+        if (tiles <= 1) E3_ROWGEMM(1);
+        else if (tiles <= 2) E3_ROWGEMM(2);
+        else E3_ROWGEMM(4);      // (8 tiles per pass cost 350-400 registers: one wave per SIMD; two passes over L2-resident rows are faster)
+#undef E3_ROWGEMM
+    }
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
 
+int red_nt(int Kp) { return Kp <= 32 ? 1 : (Kp <= 64 ? 2 : 4); }      // column tiles of 32 per block of the matrix-core reduce GEMM
+
 int red_splits(size_t rows, int M, int Kp) {
-    const int tiles = cdiv(Kp, 64) * cdiv(M, 32);
-    int S = 512 / tiles; if (S < 1) S = 1;
-    const size_t cap = (rows + 127) / 128;
+    const int tiles = g_att_valu ? cdiv(Kp, 64) * cdiv(M, 32) : cdiv(Kp, red_nt(Kp) * 32) * cdiv(M, 32);
+    int S = 1024 / tiles; if (S < 1) S = 1;
+    const size_t cap = (rows + 255) / 256;
     if ((size_t)S > cap) S = (int)(cap < 1 ? 1 : cap);
     return S;
 }
@@ -346,9 +570,16 @@ int run_redgemm(RedGemmArgs a, float* out, int osm, int osc, int ost, float* bia
     E3_REQUIRE(a.Ck % 4 == 0 && a.lda % 4 == 0, E3_ERR_UNSUPPORTED, "attention: channel counts must be multiples of 4");
     const int K = a.Tk * a.Ck, Kp = K + a.ones;
     a.S = red_splits(a.rows, a.M, Kp);
-    hipLaunchKernelGGL(att_redgemm_kernel, dim3(a.S, cdiv(Kp, 64), cdiv(a.M, 32)), dim3(256), 0, s, a);
+    if (g_att_valu) hipLaunchKernelGGL(att_redgemm_kernel, dim3(a.S, cdiv(Kp, 64), cdiv(a.M, 32)), dim3(256), 0, s, a);
+    else {
+        const int nt = red_nt(Kp);
+        const dim3 g(a.S, cdiv(Kp, nt * 32), cdiv(a.M, 32)), b(256);
+        if (nt == 1) hipLaunchKernelGGL(att_redgemm_mfma_kernel<1>, g, b, 0, s, a);
+        else if (nt == 2) hipLaunchKernelGGL(att_redgemm_mfma_kernel<2>, g, b, 0, s, a);
+        else hipLaunchKernelGGL(att_redgemm_mfma_kernel<4>, g, b, 0, s, a);
+    }
     E3_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(att_red_reduce_kernel, dim3(cdiv(a.M * Kp, 256)), dim3(256), 0, s, a.part, a.S, a.M, a.Ck, a.Tk, a.ones, out, osm, osc, ost, bias_out);
+    hipLaunchKernelGGL(att_red_reduce16_kernel, dim3(cdiv(a.M * Kp, 16)), dim3(256), 0, s, a.part, a.S, a.M, a.Ck, a.Tk, a.ones, out, osm, osc, ost, bias_out);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
