@@ -1,4 +1,4 @@
-"""Randomised whole-network fuzzing: UNet configs / crop sizes (odd extents, planar blocks, batch sizes) against the reference's
+"""Randomised whole-network fuzzing: UNet / ResUNet configs (attention gates, residual blocks included) / crop sizes (odd extents, planar blocks, batch sizes) against the reference's
 ATen op sequence run by PyTorch-ROCm IN FP64 (oracle/torch_ref.py) -- train-mode forward, loss, all gradients, running
 statistics.  fp64 because PyTorch-ROCm's own fp32 batch-norm statistics are only good to ~4e-6 for channel counts such as 24/48/96,
 which train-mode normalisation then amplifies to 1e-3 in the output (ours agree with fp64 to 4e-11).
@@ -40,13 +40,24 @@ for case in range(n_cases):
     if ri(0, 3) == 0:
         kw['conv_mode'] = 'valid'          # every conv shrinks the grid by 2: needs a larger input
     if ri(0, 3) == 0: kw['activation'] = ('leaky', 'lin', 'silu', 'prelu')[ri(0, 3)]
+    per_sample = kw.get('normalization', 'batch') == 'instance' or str(kw.get('normalization', '')).startswith('group')
+    if ri(0, 3) == 0 and not per_sample: kw['attention'] = True          # GridAttention gates (their BatchNorm needs the whole batch)
+    res = None
+    if ri(0, 3) == 0 and D is not None and kw.get('normalization') != 'instance':      # elektronn3.models.resunet.UNet
+        res = (ri(0, 2), ri(0, 2))
+        kw.pop('full_norm', None)
+        if res[0] or res[1]: kw.pop('conv_mode', None)
     shape = (H, W) if D is None else (D, H, W)
     if kw.get('conv_mode') == 'valid':
         shape = tuple(s_ + 4 * (2 ** nb) for s_ in shape)
     torch.manual_seed(case)
-    print(f'case {case}: nb={nb} sf={sf} in={inc} out={outc} planar={planar} {kw} N={N} shape={shape}', flush=True)
+    print(f'case {case}: nb={nb} sf={sf} in={inc} out={outc} planar={planar} {kw} res={res} N={N} shape={shape}', flush=True)
     try:
-        m = UNet(in_channels=inc, out_channels=outc, n_blocks=nb, start_filts=sf, planar_blocks=planar, **kw).cuda().train()
+        if res is not None:
+            from elektronn3_amd.resunet import UNet as ResUNet
+            m = ResUNet(in_channels=inc, out_channels=outc, n_blocks=nb, start_filts=sf, planar_blocks=planar, enc_res_blocks=res[0], dec_res_blocks=res[1], **kw).cuda().train()
+        else:
+            m = UNet(in_channels=inc, out_channels=outc, n_blocks=nb, start_filts=sf, planar_blocks=planar, **kw).cuda().train()
     except Exception as e:
         print('skip (ctor):', nb, sf, planar, e); continue
     x = torch.randn(N, inc, *shape, device='cuda')
@@ -92,7 +103,8 @@ for case in range(n_cases):
     R.F.prelu = rec_prelu
     R.F.relu = rec_relu; R.F.max_pool3d = rec_pool(_mp3); R.F.max_pool2d = rec_pool(_mp2)
     if sd_ref['__act_slope__'] == 0.1: R.F.leaky_relu = rec_leaky
-    try: ref = unet_forward(sd_ref, x.double(), nb, planar, training=True)
+    fwd = (lambda sd_, x_: R.resunet_forward(sd_, x_, nb, planar, True, res[0], res[1])) if res is not None else (lambda sd_, x_: unet_forward(sd_, x_, nb, planar, training=True))
+    try: ref = fwd(sd_ref, x.double())
     finally: R.F.relu = _relu; R.F.prelu = _prelu; R.F.leaky_relu = _leaky; R.F.max_pool3d = _mp3; R.F.max_pool2d = _mp2; lref = combined_loss(ref, t, cw); lref.backward()
     e_out = float((out - ref).detach().abs().max()) / max(1.0, float(ref.abs().max()))
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
@@ -106,7 +118,7 @@ for case in range(n_cases):
         for trial in range(4):
             sd2 = {k: (v.detach().clone().requires_grad_(v.requires_grad) if torch.is_tensor(v) else v) for k, v in sd_ref.items()}
             xd = x.double() * (1 + 3e-6 * torch.randn(x.shape, device=x.device, dtype=torch.float64, generator=torch.Generator(device=x.device).manual_seed(77 + trial)))
-            combined_loss(unet_forward(sd2, xd, nb, planar, training=True), t, cw).backward()
+            combined_loss(fwd(sd2, xd), t, cw).backward()
             for k in names:
                 sens[k] = max(sens.get(k, 0.0), float((sd2[k].grad - sd_ref[k].grad).norm()))
     act_gmax = max([float(sd_ref[k].grad.norm()) for k in names if '.act' in k] or [0.0])
@@ -134,7 +146,7 @@ for case in range(n_cases):
     loose = max(3e-2, 1.0 / n_bottom ** 0.5)
     ok = e_out < 5e-5 and worst < (loose if margin[0] < FLIP else 1e-4) and e_rs < 1e-5
     bad += not ok
-    print(f'{"ok  " if ok else "BAD "} nb={nb} sf={sf} in={inc} out={outc} planar={planar} {kw} N={N} {"x".join(map(str, shape))}: out {e_out:.1e} worst grad {worst:.1e} ({wk}) running {e_rs:.1e} relu margin {margin[0]:.0e}', flush=True)
+    print(f'{"ok  " if ok else "BAD "} nb={nb} sf={sf} in={inc} out={outc} planar={planar} {kw} res={res} N={N} {"x".join(map(str, shape))}: out {e_out:.1e} worst grad {worst:.1e} ({wk}) running {e_rs:.1e} relu margin {margin[0]:.0e}', flush=True)
     if not ok and os.environ.get('FUZZ_VERBOSE'):
         for e_, k_, a_, b_ in sorted(detail, reverse=True)[:8]: print(f'      {k_:34s} err {e_:.2e} |ref| {a_:.3e} |ours| {b_:.3e}  (global {gn:.3e}, act max {act_gmax:.3e})')
 print('BAD CASES:', bad)
