@@ -13,12 +13,16 @@ from elektronn3_amd.unet import UNet
 from elektronn3_amd.loss import CombinedCEDiceLoss
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+BF16 = len(sys.argv) > 2 and sys.argv[2] == 'bf16'          # native bf16 path (BASELINE configs[2]): 2-byte tensors, 2.5 PFLOP/s dense bf16 MFMA peak
+ESZ, PEAK, PEAKNAME = (2.0, 2500.0, 'bf16') if BF16 else (4.0, 157.3, 'fp32')
 N, CROP = 2, (64, 128, 128)
 dev = torch.device('cuda')
 torch.manual_seed(0)
 model = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=32, normalization='batch').to(dev).train()
 crit = CombinedCEDiceLoss(weight=[0.2653, 0.7347]).to(dev)
 x = torch.randn(N, 1, *CROP, device=dev); t = torch.randint(0, 2, (N, *CROP), device=dev)
+if BF16:
+    model = model.to(torch.bfloat16); x = x.to(torch.bfloat16)
 
 
 def step():
@@ -37,7 +41,7 @@ for li, (name, cin, cout, taps, level) in enumerate(model.conv_layers()):
     vin = vox_lvl // 8 if up else vox_lvl                            # transposed conv reads the coarser level
     vout = vox_lvl
     flops = 2.0 * cin * cout * taps * (vin if up else vout)
-    byts = 4.0 * (cin * vin + cout * vout + cin * cout * taps)
+    byts = ESZ * (cin * vin + cout * vout + cin * cout * taps)
     ms = []
     for which in (0, 1, 2):
         if which == 1 and li == 0: ms.append(None); continue        # no dx for the network input
@@ -50,13 +54,13 @@ for li, (name, cin, cout, taps, level) in enumerate(model.conv_layers()):
     rows.append((name, cin, cout, taps, vout, flops, byts, ms))
 model.profile_select(-1, 0)
 
-print('# Round 1: per-conv-layer roofline, cfg 2 (UNet n_blocks=4 start_filts=32, batch 2 of 64x128x128, fp32), one MI355X')
+print(f'# Round 2: per-conv-layer roofline, cfg 2 (UNet n_blocks=4 start_filts=32, batch 2 of 64x128x128, {"bf16 (native path)" if BF16 else "fp32"}), one MI355X')
 print()
 print(f'HIP events around each layer\'s dominant kernel inside full training steps (`tools/layer_table.py`, mean of {steps} steps per cell). '
-      'HBM = algorithmic bytes / t / 8 TB/s; fp32 = algorithmic FLOPs / t / 157.3 TFLOP/s (Winograd kernels execute 64/216 of the '
-      '3x3x3 multiplies, so their algorithmic fraction can exceed 1). Bytes/FLOPs per SURVEY.md section 8(d).')
+      f'HBM = algorithmic bytes / t / 8 TB/s; {PEAKNAME} = algorithmic FLOPs / t / {PEAK} TFLOP/s' + ('' if BF16 else ' (Winograd kernels execute 64/216 of the '
+      '3x3x3 multiplies, so their algorithmic fraction can exceed 1)') + '. Bytes/FLOPs per SURVEY.md section 8(d).')
 print()
-print('| layer | Cin→Cout | taps | voxels out | GFLOP | MB | fwd µs | fwd TF/s | fwd fp32 frac | fwd HBM frac | dgrad µs | dgrad TF/s | dgrad HBM frac | wgrad µs | wgrad TF/s | wgrad HBM frac |')
+print(f'| layer | Cin→Cout | taps | voxels out | GFLOP | MB | fwd µs | fwd TF/s | fwd {PEAKNAME} frac | fwd HBM frac | dgrad µs | dgrad TF/s | dgrad HBM frac | wgrad µs | wgrad TF/s | wgrad HBM frac |')
 print('|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|')
 for name, cin, cout, taps, vout, flops, byts, ms in rows:
     cells = [name, f'{cin}→{cout}', str(taps), str(vout), f'{flops / 1e9:.2f}', f'{byts / 1e6:.1f}']
@@ -65,7 +69,7 @@ for name, cin, cout, taps, vout, flops, byts, ms in rows:
             cells += ['—'] * (4 if k == 0 else 3); continue
         tf = flops / (m * 1e-3) / 1e12
         hb = byts / (m * 1e-3) / 8e12
-        cells += [f'{m * 1e3:.0f}', f'{tf:.1f}'] + ([f'{tf / 157.3:.2f}'] if k == 0 else []) + [f'{hb:.3f}']
+        cells += [f'{m * 1e3:.0f}', f'{tf:.1f}'] + ([f'{tf / PEAK:.3f}'] if k == 0 else []) + [f'{hb:.3f}']
     print('| ' + ' | '.join(cells) + ' |')
 print()
 print(f'Sum of the timed kernels per step: forward {tot[0]:.2f} ms, dgrad {tot[1]:.2f} ms, wgrad {tot[2]:.2f} ms '
