@@ -294,46 +294,85 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
     const size_t total = (size_t)N * S;
     const int sub = threadIdx.x % lpv;
     const size_t vpb = blockDim.x / lpv;
-    for (size_t v = blockIdx.x * vpb + threadIdx.x / lpv; v < (total + vpb - 1) / vpb * vpb; v += (size_t)gridDim.x * vpb) {
-        float acc[COUT];
+    const size_t gstride = (size_t)gridDim.x * vpb;
+    const size_t vend = (total + vpb - 1) / vpb * vpb;
+    // U voxels per thread and iteration, their loads issued together (a single 16-byte load per lane and voxel leaves the memory system with
+    // too little in flight: 81 -> 5x us on the 268 MB head of cfg 2); `a` is streamed once: non-temporal.  Same summation order per voxel.
+    constexpr int U = 4;
+    const bool one = Q <= lpv;          // at most one channel quad per lane (the usual head: C = 32, eight lanes per voxel)
+    for (size_t v0 = blockIdx.x * vpb + threadIdx.x / lpv; v0 < vend; v0 += (one ? U : 1) * gstride) {
+        float acc[U][COUT];
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-        const bool ok = v < total;
-        if (ok)
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[u][co] = 0.f;
+        if (one) {
+            f32x4 av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t v = v0 + u * gstride;
+                av[u] = (v < total && sub < Q) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * sub)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (sub < Q) {
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                if (pro_scale) { sc = *reinterpret_cast<const f32x4*>(pro_scale + 4 * sub); sh = *reinterpret_cast<const f32x4*>(pro_shift + 4 * sub); }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const size_t v = v0 + u * gstride;
+                    if (v >= total) continue;
+                    if (pro_scale) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) av[u][e] = act_fwd(__builtin_fmaf(av[u][e], sc[e], sh[e]), act_slope_at(pro_act, pro_slope, (unsigned)(v * C + 4 * sub + e)));
+                    }
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + co * C + 4 * sub);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[u][co] = __builtin_fmaf(av[u][e], wv[e], acc[u][co]);
+                    }
+                }
+            }
+        } else if (v0 < total) {
             for (int q = sub; q < Q; q += lpv) {
-                f32x4 av = *reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * q);
+                f32x4 xv = *reinterpret_cast<const f32x4*>(a + v0 * a_ldc + 4 * q);
                 if (pro_scale) {
                     const f32x4 sc = *reinterpret_cast<const f32x4*>(pro_scale + 4 * q), sh = *reinterpret_cast<const f32x4*>(pro_shift + 4 * q);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) av[e] = act_fwd(__builtin_fmaf(av[e], sc[e], sh[e]), act_slope_at(pro_act, pro_slope, (unsigned)(v * C + 4 * q + e)));
+                    for (int e = 0; e < 4; ++e) xv[e] = act_fwd(__builtin_fmaf(xv[e], sc[e], sh[e]), act_slope_at(pro_act, pro_slope, (unsigned)(v0 * C + 4 * q + e)));
                 }
 #pragma unroll
                 for (int co = 0; co < COUT; ++co) {
                     const f32x4 wv = *reinterpret_cast<const f32x4*>(w + co * C + 4 * q);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[co] = __builtin_fmaf(av[e], wv[e], acc[co]);
+                    for (int e = 0; e < 4; ++e) acc[0][co] = __builtin_fmaf(xv[e], wv[e], acc[0][co]);
                 }
             }
-        for (int off = 1; off < lpv; off <<= 1)
+        }
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) acc[co] += __shfl_xor(acc[co], off);
-        if (ok && sub == 0) {
-            const size_t n = v / S, sp = v % S;
+        for (int u = 0; u < U; ++u) {
+            if (u > 0 && !one) break;
+            const size_t v = v0 + u * gstride;
+            for (int off = 1; off < lpv; off <<= 1)
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) acc[co] += bias ? bias[co] : 0.f;
-            if (softmax) {
-                float m = acc[0];
+                for (int co = 0; co < COUT; ++co) acc[u][co] += __shfl_xor(acc[u][co], off);
+            if (v < total && sub == 0) {
+                const size_t n = v / S, sp = v % S;
 #pragma unroll
-                for (int co = 1; co < COUT; ++co) m = fmaxf(m, acc[co]);
-                float s = 0.f;
+                for (int co = 0; co < COUT; ++co) acc[u][co] += bias ? bias[co] : 0.f;
+                if (softmax) {
+                    float m = acc[u][0];
 #pragma unroll
-                for (int co = 0; co < COUT; ++co) { acc[co] = __expf(acc[co] - m); s += acc[co]; }
-                const float inv = 1.f / s;
+                    for (int co = 1; co < COUT; ++co) m = fmaxf(m, acc[u][co]);
+                    float s = 0.f;
 #pragma unroll
-                for (int co = 0; co < COUT; ++co) acc[co] *= inv;
+                    for (int co = 0; co < COUT; ++co) { acc[u][co] = __expf(acc[u][co] - m); s += acc[u][co]; }
+                    const float inv = 1.f / s;
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[u][co] *= inv;
+                }
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) y[(n * COUT + co) * S + sp] = acc[u][co];
             }
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) y[(n * COUT + co) * S + sp] = acc[co];
         }
     }
 }
@@ -360,23 +399,38 @@ __global__ __launch_bounds__(256) void conv_final_bwd_kernel(const float* __rest
         wv[co] = *reinterpret_cast<const f32x4*>(w + co * C + 4 * q);
         dwacc[co] = f32x4{0.f, 0.f, 0.f, 0.f}; dbacc[co] = 0.f;
     }
-    for (size_t i = (size_t)blockIdx.x * BT + tid; tid < BT && i < total; i += (size_t)gridDim.x * BT) {
-        const size_t v = i / Q;
-        const size_t n = v / S, sp = v % S;
-        f32x4 av = *reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * q);
-        if (pro_scale) {
+    // two items per iteration with all their loads issued first (`a` streamed once: non-temporal)
+    const size_t istride = (size_t)gridDim.x * BT;
+    for (size_t i0 = (size_t)blockIdx.x * BT + tid; tid < BT && i0 < total; i0 += 2 * istride) {
+        f32x4 av[2]; float g[2][COUT]; size_t vv[2]; bool ok[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) av[e] = act_fwd(__builtin_fmaf(av[e], sc[e], sh[e]), act_slope_at(pro_act, pro_slope, (unsigned)(v * C + 4 * q + e)));
+        for (int u = 0; u < 2; ++u) {
+            const size_t i = i0 + u * istride;
+            ok[u] = i < total;
+            const size_t v = ok[u] ? i / Q : 0;
+            vv[u] = v;
+            const size_t n = v / S, sp = v % S;
+            av[u] = ok[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) g[u][co] = ok[u] ? dy[(n * COUT + co) * S + sp] : 0.f;
         }
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) {
-            const float g = dy[(n * COUT + co) * S + sp];
+        for (int u = 0; u < 2; ++u) {
+            if (!ok[u]) continue;
+            const size_t v = vv[u];
+            if (pro_scale) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { o[e] = __builtin_fmaf(g, wv[co][e], o[e]); dwacc[co][e] = __builtin_fmaf(g, av[e], dwacc[co][e]); }
-            if (q == 0) dbacc[co] += g;
+                for (int e = 0; e < 4; ++e) av[u][e] = act_fwd(__builtin_fmaf(av[u][e], sc[e], sh[e]), act_slope_at(pro_act, pro_slope, (unsigned)(v * C + 4 * q + e)));
+            }
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = __builtin_fmaf(g[u][co], wv[co][e], o[e]); dwacc[co][e] = __builtin_fmaf(g[u][co], av[u][e], dwacc[co][e]); }
+                if (q == 0) dbacc[co] += g[u][co];
+            }
+            if (da) *reinterpret_cast<f32x4*>(da + v * da_ldc + 4 * q) = o;     // da == nullptr: the consumer recomputes it (BnBwdArgs::head_dy)
         }
-        if (da) *reinterpret_cast<f32x4*>(da + v * da_ldc + 4 * q) = o;     // da == nullptr: the consumer recomputes it (BnBwdArgs::head_dy)
     }
     // block reduce, one output row (co) at a time
     const int pstride = COUT * C + COUT;
@@ -498,7 +552,7 @@ int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, cons
 }
 
 int conv_final_bwd_parts(size_t total_voxels) {
-    size_t g = (total_voxels + 31) / 32; if (g > 1024) g = 1024; if (g == 0) g = 1;
+    size_t g = (total_voxels + 31) / 32; if (g > 2048) g = 2048; if (g == 0) g = 1;
     return (int)g;
 }
 
