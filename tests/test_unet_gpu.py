@@ -662,6 +662,37 @@ def test_dim2_unet_against_pytorch_rocm():
         m(x.unsqueeze(2))
 
 
+@pytest.mark.parametrize('variant', ['attention', 'resunet'])
+def test_attention_and_residual_steps_are_deterministic_and_batch_independent_in_eval(variant):
+    """The gates' and the shortcuts' GEMMs reduce over voxels in a fixed split order (no atomics): two training steps from the same state are
+    bit-identical, odd sizes included; eval mode treats the samples of a batch independently."""
+    from elektronn3_amd import resunet, unet
+    torch.manual_seed(21)
+    if variant == 'attention':
+        m = unet.UNet(1, 2, n_blocks=3, start_filts=16, attention=True).cuda()
+    else:
+        m = resunet.UNet(1, 2, n_blocks=3, start_filts=16, enc_res_blocks=2, dec_res_blocks=1, attention=True).cuda()
+    x = torch.randn(2, 1, 21, 38, 45, device='cuda')
+    m.train()
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    outs, grads, atts = [], [], []
+    for _ in range(2):
+        m.load_state_dict(sd0)
+        m.zero_grad(set_to_none=True)
+        o = m(x)
+        o.backward(torch.ones_like(o) * 1e-3 + 1e-4 * torch.sign(o.detach()))
+        outs.append(o.detach().clone())
+        grads.append([p.grad.clone() for p in m.parameters()])
+        atts.append([b.att.clone() for b in m.up_convs])
+    assert torch.equal(outs[0], outs[1])
+    assert all(torch.equal(a, b) for a, b in zip(*grads))
+    assert all(torch.equal(a, b) for a, b in zip(*atts))
+    m.eval()
+    with torch.no_grad():
+        y2 = m(x)
+        assert torch.equal(y2[:1], m(x[:1])) and torch.equal(y2[1:], m(x[1:]))
+
+
 def test_full_size_properties(cfg2):
     m, x, t = cfg2
     # determinism: two training forwards+backwards from the same state are bit-identical (no atomics anywhere)
