@@ -693,6 +693,65 @@ def test_attention_and_residual_steps_are_deterministic_and_batch_independent_in
         assert torch.equal(y2[:1], m(x[:1])) and torch.equal(y2[1:], m(x[1:]))
 
 
+def _minimal_case(n_blocks, planar, dim, resunet_blocks=None):
+    import itertools  # noqa: F401
+    from elektronn3_amd import resunet, unet
+    from oracle.torch_ref import resunet_forward, unet_forward
+    torch.manual_seed(100 * n_blocks + len(planar) + (7 if dim == 2 else 0))
+    if resunet_blocks is None:
+        m = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, planar_blocks=planar, dim=dim).cuda().train()
+    else:
+        m = resunet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, planar_blocks=planar, dim=dim, enc_res_blocks=resunet_blocks[0],
+                         dec_res_blocks=resunet_blocks[1]).cuda().train()
+    side = 2 ** n_blocks
+    shape = (side, side) if dim == 2 else (side // (2 ** len(planar)), side, side)
+    x = torch.randn(1, 1, *shape, device='cuda')
+    sd = {k: (v.detach().double() if v.is_floating_point() else v.clone()).requires_grad_(v.is_floating_point() and 'running' not in k)
+          for k, v in m.state_dict().items()}
+    out = m(x)
+    assert tuple(out.shape) == (1, 2, *shape)
+    out.sum().backward()
+    if resunet_blocks is None:
+        ref = unet_forward(sd, x.double(), n_blocks, planar, training=True)
+    else:
+        ref = resunet_forward(sd, x.double(), n_blocks, planar, True, *resunet_blocks)
+    ref.sum().backward()
+    assert torch.allclose(out.double(), ref, rtol=1e-3, atol=1e-3), float((out.double() - ref).abs().max())
+    gn = float(torch.sqrt(sum((v.grad ** 2).sum() for v in sd.values() if v.grad is not None)))
+    for k, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        # (a handful of voxels per BatchNorm channel at the bottom levels: statistics of 4..8 values amplify fp32 rounding; judged against the
+        # gradient's global scale)
+        assert float((p.grad.double() - sd[k].grad).abs().max()) <= 2e-2 * gn + 1e-6, (k, float((p.grad.double() - sd[k].grad).abs().max()), gn)
+
+
+def test_reference_self_test_sweep_2d():
+    """The reference's own inline self-test (`python unet.py`: test_2d_config, unet.py:997-1000): n_blocks 1..4 on the minimal 2**n_blocks input,
+    out.sum().backward(), output shape -- here with values and gradients against the fp64 op sequence as well."""
+    for n_blocks in range(1, 5):
+        _minimal_case(n_blocks, (), 2)
+
+
+def test_reference_self_test_sweep_planar_configs():
+    """test_planar_configs (unet.py:1003-1013): n_blocks 1..4 x EVERY subset of planar blocks on the minimal input
+    (depth 2**n_blocks // 2**len(planar_blocks))."""
+    import itertools
+    for n_blocks in range(1, 5):
+        for r in range(n_blocks + 1):
+            for planar in itertools.combinations(range(n_blocks), r):
+                _minimal_case(n_blocks, planar, 3)
+
+
+def test_resunet_self_test_sweep():
+    """The same sweep for the ResUNet (resunet.py:990-1079), plain and residual ConvBlocks."""
+    import itertools
+    for n_blocks in range(1, 4):
+        for r in range(n_blocks + 1):
+            for planar in itertools.combinations(range(n_blocks), r):
+                _minimal_case(n_blocks, planar, 3, (0, 0) if (n_blocks + r) % 2 else (1, 1))
+    _minimal_case(4, (0, 1), 3, (2, 1))
+
+
 def test_full_size_properties(cfg2):
     m, x, t = cfg2
     # determinism: two training forwards+backwards from the same state are bit-identical (no atomics anywhere)
