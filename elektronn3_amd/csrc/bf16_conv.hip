@@ -30,14 +30,17 @@ constexpr unsigned OOB = 0x80000000u;
 // W); TW = 32: tile = 1 h-row x 32 w (brick BD x 4 x 32): the 16 lanes of a ds_read_b128 group then read 16 CONSECUTIVE voxels of one
 // row at any tap shift, which the swizzle maps to 16 distinct bank slots -- no conflicts (the 2 x 16 tile straddles two rows 18 voxels
 // apart: a quarter more LDS cycles, measured 22 % of the LDS-active cycles of the 64->32 layer).
-template <int BD, int KD, int TW>
+template <int BD, int KD, int TW, int CH = 32>
 struct Geo {
     static constexpr int RPT = 32 / TW;                   // h-rows per tile
     static constexpr int BH = 4 * RPT, BW = TW;
     static constexpr int HH = BH + 2, HW = BW + 2;
     static constexpr int HD = BD + (KD == 3 ? 2 : 0);
     static constexpr int HV = HD * HH * HW;              // halo voxels
-    static constexpr int NI = (HV * 4 + 63) / 64;        // 1 KB wave-pieces per chunk
+    static constexpr int RB = CH * 2;                    // bytes of a voxel's row in the LDS image (CH channels per chunk: 32, or 16 = one k-step)
+    static constexpr int PPV = RB / 16;                  // 16-byte pieces per voxel
+    static constexpr int KS = CH / 16;                   // MFMA k-steps per chunk
+    static constexpr int NI = (HV * PPV + 63) / 64;      // 1 KB wave-pieces per chunk
     static constexpr int NIW = (NI + 3) / 4;             // per wave
     static constexpr int IMG = NI * 1024;                // bytes
     static constexpr int NV = BD;                        // 2x16-voxel tiles per wave
@@ -51,9 +54,13 @@ __device__ unsigned long long* g_timing = nullptr;       // phase timestamps (to
 #define E3_TICK(k)
 #endif
 
-template <int BD, int CO_T, int KD, int TW>
-__global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const ConvB16Args a, int tilesD, int tilesH, int tilesW, int cgroups, int ksplit) {
-    using G = Geo<BD, KD, TW>;
+// CH = 16: the image holds ONE k-step of channels (half the LDS), so that three workgroups instead of two share a CU (a fourth does not fit the
+// register file: 64 accumulators + weight ring + fragments need > 128 registers) and a workgroup's staging meets two others' MFMA / store
+// phases (same bricks, same halo traffic, twice the barriers)
+template <int BD, int CO_T, int KD, int TW, int CH = 32>
+__global__ __launch_bounds__(256, (CH == 16 || BD == 2) ? 3 : 2) void conv_b16_kernel(const ConvB16Args a, int tilesD, int tilesH, int tilesW, int cgroups, int ksplit) {
+    using G = Geo<BD, KD, TW, CH>;
+    constexpr int RB = G::RB, PPV = G::PPV, KS = G::KS;
     constexpr int HH = G::HH, HW = G::HW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -80,21 +87,21 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
     const int d0 = td * BD, h0 = th * G::BH, w0 = tw * G::BW;
     const int co0 = cg * 32 * CO_T;
     constexpr int PD = KD == 3 ? 1 : 0;
-    const int nch = a.Cin >> 5;
+    const int nch = a.Cin / CH;
     const int ch0 = ksp * (nch / ksplit), ch1 = ch0 + nch / ksplit;
 
     // ---- staging plan: wave-piece wi = it * 4 + wave, lane -> (halo voxel, LDS piece); source piece = LDS piece ^ swizzle
     const size_t samp = (size_t)a.D * a.H * a.W * a.x_ldc;
     const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x) + (size_t)n * samp, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t x2_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x2 ? a.x2 : a.x) + (size_t)n * samp, 0, 0x7fffffff, 0x00020000);
-    const int xsplit_ch = a.x2 ? a.x_split >> 5 : nch;                  // chunks [0, xsplit_ch) from x, the rest from x2
+    const int xsplit_ch = a.x2 ? a.x_split / CH : nch;                  // chunks [0, xsplit_ch) from x, the rest from x2
     unsigned rel[G::NIW]; unsigned okmask = 0;
 #pragma unroll
     for (int it = 0; it < G::NIW; ++it) {
         const int idx = (it * 4 + wave) * 64 + lane;
-        const int v = idx >> 2, qp = idx & 3;
+        const int v = idx / PPV, qp = idx % PPV;
         const int zw = v % HW, zh = (v / HW) % HH, zd = v / (HW * HH);
-        const int q = qp ^ ((zw >> 2) & 3);
+        const int q = PPV == 4 ? qp ^ ((zw >> 2) & 3) : qp ^ ((zw >> 3) & 1);      // (32-byte rows: 16 consecutive voxels x 2 pieces = all 64 banks)
         const int gd = d0 - PD + zd, gh = h0 - 1 + zh, gw = w0 - 1 + zw;
         const bool ok = v < G::HV && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
         rel[it] = (unsigned)((((gd * a.H + gh) * a.W + gw) * a.x_ldc) * 2 + q * 16);
@@ -104,13 +111,13 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
     // ---- lane read addresses (tap kd = kh = 0, tile 0 of the wave): 3 kw x 2 k-steps
     const int r = TW == 16 ? j >> 4 : 0, c = TW == 16 ? j & 15 : j;
     const int T0 = wave * G::NV, dT0 = T0 >> 2, hp0 = T0 & 3;
-    unsigned rd[3][2];
+    unsigned rd[3][KS];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-        const int hw = c + kw, sw = (hw >> 2) & 3;
+        const int hw = c + kw, sw = PPV == 4 ? (hw >> 2) & 3 : (hw >> 3) & 1;
         const int row = (dT0 * HH + G::RPT * hp0 + r) * HW + hw;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) rd[kw][ks] = (unsigned)(row * 64 + (((2 * ks + g) ^ sw) << 4));
+        for (int ks = 0; ks < KS; ++ks) rd[kw][ks] = (unsigned)(row * RB + (((2 * ks + g) ^ sw) << 4));
     }
     // ---- weights: packed [tap][chunk][k-step][CoPad][2][8]; lane (j, g) reads 16 B of row co0 + ct*32 + j
     const size_t wstep = (size_t)a.Cout * 16;                          // elements per (tap, chunk, k-step)
@@ -126,11 +133,11 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
 
     for (int ch = ch0; ch < ch1; ++ch) {
         constexpr int RING = CO_T == 1 ? 6 : 4;      // taps of weights in flight (L2 latency under load is several MFMA taps)
-        bf16x8 wf[RING][CO_T][2];
+        bf16x8 wf[RING][CO_T][KS];
 #define E3_LOAD_W(TAP, SLOT)                                                                                                        \
     _Pragma("unroll") for (int ct_ = 0; ct_ < CO_T; ++ct_)                                                                          \
-        _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                                                         \
-            wf[SLOT][ct_][ks_] = *reinterpret_cast<const bf16x8*>(wlane + ((size_t)((TAP) * nch + ch) * 2 + ks_) * wstep + ct_ * 512)
+        _Pragma("unroll") for (int ks_ = 0; ks_ < KS; ++ks_)                                                                        \
+            wf[SLOT][ct_][ks_] = *reinterpret_cast<const bf16x8*>(wlane + ((size_t)((TAP) * nch + ch) * KS + ks_) * wstep + ct_ * 512)
 #pragma unroll
         for (int t0 = 0; t0 < RING - 1; ++t0) { E3_LOAD_W(t0, t0); }
 #pragma unroll
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
             const int wi = it * 4 + wave;
             if (wi < G::NI)
                 dma16(ch < xsplit_ch ? x_rs : x2_rs, (lds_ptr_t)(smem + wi * 1024), 16,
-                                                         ((okmask >> it) & 1u) ? rel[it] + (unsigned)(ch < xsplit_ch ? ch : ch - xsplit_ch) * 64u : OOB, 0, 0, 0);
+                                                         ((okmask >> it) & 1u) ? rel[it] + (unsigned)(ch < xsplit_ch ? ch : ch - xsplit_ch) * (unsigned)RB : OOB, 0, 0, 0);
         }
         E3_TICK(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -149,20 +156,20 @@ __global__ __launch_bounds__(256, BD == 2 ? 3 : 2) void conv_b16_kernel(const Co
             // (tap, k-step) steps; the wave's NV fragments of step s+1 are requested before the MFMAs of step s (a ds_read_b128 takes ~130
             // cycles, the compiler's own order puts two MFMAs = 64 cycles between a read and its use: taps 10.0 -> 5.5 us per brick of the
             // 32 -> 32 layer, tools/conv_phases.py), MFMAs tile-innermost (consecutive MFMAs never share an accumulator)
-            constexpr int NSTEP = G::TAPS * 2;
+            constexpr int NSTEP = G::TAPS * KS;
             bf16x8 b[2][G::NV];
 #pragma unroll
-            for (int t = 0; t < G::NV; ++t) b[0][t] = *reinterpret_cast<const bf16x8*>(smem + rd[0][0] + (G::RPT * t * HW) * 64);
+            for (int t = 0; t < G::NV; ++t) b[0][t] = *reinterpret_cast<const bf16x8*>(smem + rd[0][0] + (G::RPT * t * HW) * RB);
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
-                const int tap = st >> 1, ks = st & 1;
+                const int tap = st / KS, ks = st % KS;
                 if (ks == 0 && tap + RING - 1 < G::TAPS) { E3_LOAD_W(tap + RING - 1, (tap + RING - 1) % RING); }
                 if (st + 1 < NSTEP) {
-                    const int tn = (st + 1) >> 1, kn = (st + 1) & 1;
+                    const int tn = (st + 1) / KS, kn = (st + 1) % KS;
                     const int kd = tn / 9, kh = (tn / 3) % 3, kw = tn % 3;
 #pragma unroll
                     for (int t = 0; t < G::NV; ++t)
-                        b[(st + 1) & 1][t] = *reinterpret_cast<const bf16x8*>(smem + rd[kw][kn] + ((kd * HH + G::RPT * t + kh) * HW) * 64);
+                        b[(st + 1) & 1][t] = *reinterpret_cast<const bf16x8*>(smem + rd[kw][kn] + ((kd * HH + G::RPT * t + kh) * HW) * RB);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -386,16 +393,16 @@ __global__ void pack_multi_b16_kernel(const PackMultiArgs a) {
     }
 }
 
-template <int BD, int CO_T, int KD, int TW>
+template <int BD, int CO_T, int KD, int TW, int CH = 32>
 int launch_t(const ConvB16Args& a, int ksplit, hipStream_t s) {
-    using G = Geo<BD, KD, TW>;
+    using G = Geo<BD, KD, TW, CH>;
     const int tD = cdiv(a.D, BD), tH = cdiv(a.H, G::BH), tW = cdiv(a.W, G::BW);
     const int cgroups = a.Cout / (32 * CO_T);
     const size_t grid = (size_t)a.N * tD * tH * tW * cgroups * ksplit;
     const int lds = G::IMG > 4 * 2 * 32 * 33 * 4 + 1024 ? G::IMG : 4 * 2 * 32 * 33 * 4 + 1024;
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)conv_b16_kernel<BD, CO_T, KD, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
-    hipLaunchKernelGGL((conv_b16_kernel<BD, CO_T, KD, TW>), dim3((unsigned)grid), dim3(256), lds, s, a, tD, tH, tW, cgroups, ksplit);
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)conv_b16_kernel<BD, CO_T, KD, TW, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
+    hipLaunchKernelGGL((conv_b16_kernel<BD, CO_T, KD, TW, CH>), dim3((unsigned)grid), dim3(256), lds, s, a, tD, tH, tW, cgroups, ksplit);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
@@ -488,7 +495,11 @@ int launch_conv_b16(ConvB16Args a, hipStream_t s) {
 #define E3_B16_LAUNCH(KD_, TW_)                                                                                              \
     (d.bd == 4 ? (two ? launch_t<4, 2, KD_, TW_>(a, d.ksplit, s) : launch_t<4, 1, KD_, TW_>(a, d.ksplit, s))                 \
                : (two ? launch_t<2, 2, KD_, TW_>(a, d.ksplit, s) : launch_t<2, 1, KD_, TW_>(a, d.ksplit, s)))
-    if (a.planar) rc = d.tw == 32 ? E3_B16_LAUNCH(1, 32) : E3_B16_LAUNCH(1, 16);
+    // 16-channel LDS images, three workgroups per CU, where the shape allows (BD = 4, 3x3x3, 32-voxel rows, one 32-channel output tile, no split-K):
+    // 150 -> 133, 247 -> 227, 154 -> 138 us on the level-0 forward convs of cfg 2, 5.89 -> 5.76 ms per step (E3_B16_CH32=1 restores 32-channel images)
+    static const bool ch16 = getenv("E3_B16_CH32") == nullptr;
+    if (ch16 && d.bd == 4 && !a.planar && d.tw == 32 && d.ksplit == 1 && !two) rc = launch_t<4, 1, 3, 32, 16>(a, d.ksplit, s);
+    else if (a.planar) rc = d.tw == 32 ? E3_B16_LAUNCH(1, 32) : E3_B16_LAUNCH(1, 16);
     else rc = d.tw == 32 ? E3_B16_LAUNCH(3, 32) : E3_B16_LAUNCH(3, 16);
 #undef E3_B16_LAUNCH
     if (rc || d.ksplit == 1) return rc;
