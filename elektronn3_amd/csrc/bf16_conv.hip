@@ -422,7 +422,11 @@ Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout) {
     const long b4 = (long)N * cdiv(D, 4) * cdiv(H, bh) * cdiv(W, d.tw);
     d.bd = (forced == 2 || forced == 4) ? forced : (b4 >= 512 ? 4 : 2);
     d.bricks = (long)N * cdiv(D, d.bd) * cdiv(H, bh) * cdiv(W, d.tw);
-    d.co_t = (Cout % 64 == 0 && d.bricks * (Cout / 64) >= 256) ? 2 : 1;
+    // two output tiles per workgroup halve the staging per FLOP but cost a workgroup per CU (256 registers) and, on small grids, force a
+    // split-K pass: measured on cfg 2, they pay at level 1 (512 bricks: 69 vs 71, 118 vs 120 us) but neither at level 2 (128 bricks: one tile
+    // fills the chip without split-K, 54 -> 39, 77 -> 67 us) nor at level 0 (4096 bricks: the three-workgroup 16-channel form wins, 264 -> 249 us)
+    static const int cot = getenv("E3_B16_COT") ? atoi(getenv("E3_B16_COT")) : 0;      // A/B switch: 1 / 2 = always that many tiles where legal
+    d.co_t = (Cout % 64 == 0 && (cot == 2 ? d.bricks * (Cout / 64) >= 256 : (cot != 1 && d.bricks * (Cout / 64) >= 512 && d.bricks <= 1024))) ? 2 : 1;
     const long wgs = d.bricks * (Cout / (32 * d.co_t));
     const int nch = Cin / 32;
     d.ksplit = 1;
