@@ -539,6 +539,7 @@ int run_rowgemm(RowGemmArgs a, hipStream_t s) {
         const dim3 g((unsigned)((a.rows + 127) / 128)), b(256);
         const int tiles = cdiv(a.Tn * a.Cn, 32);
         const bool sc = a.Tn > 1, dot = a.rowdot != nullptr || a.rs_out != nullptr;
+        E3_REQUIRE(!sc || (size_t)a.g.N * a.g.D * a.g.H * a.g.W < ((size_t)1 << 32), E3_ERR_UNSUPPORTED, "attention GEMM: more than 2^32 scattered voxels");
         E3_REQUIRE(!(sc && dot), E3_ERR_INVALID, "attention GEMM: scatter and row dot product are separate launches");
 #define E3_ROWGEMM(NT)                                                                                         \
         do {                                                                                                   \
