@@ -100,11 +100,62 @@ __global__ void bn_relu_pool_b16_kernel(const bf16_t* __restrict__ x, int x_ldc,
     }
 }
 
+// the same with a window's two w-columns on two lanes (lane ^ Q; Q a power of two <= 32): 2Q consecutive lanes read / write 2 voxels x C
+// channels as one contiguous run (whole 128-byte lines at C = 32, see bn_bwd_b16_kernel); the pair's maxima meet through one shuffle
+template <bool APPLY>
+__global__ __launch_bounds__(256) void bn_relu_pool2_b16_kernel(const bf16_t* __restrict__ x, int x_ldc, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                bf16_t* __restrict__ a, int a_ldc, bf16_t* __restrict__ pooled, int kd, int N, int D, int H, int W, int C) {
+    const int Q = C >> 3;
+    const int Dp = (D + kd - 1) / kd, Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+    const size_t units = (size_t)N * Dp * Hp * Wp, total = units * 2 * Q;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (total + stride - 1) / stride * stride; i += stride) {     // (pairs iterate together)
+        const bool uok = i < total;
+        const int q = (int)(i % Q), dxl = (int)((i / Q) & 1);
+        size_t r = uok ? i / (2 * Q) : 0;
+        const int pw = r % Wp; r /= Wp; const int ph = r % Hp; r /= Hp; const int pd = r % Dp; const int n = r / Dp;
+        const int w = pw * 2 + dxl;
+        f8 sc, sh;
+        if (APPLY) { sc = ldf8(scale + 8 * q); sh = ldf8(shift + 8 * q); }
+        f8 o[4]; bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int d = pd * kd + (k >> 1), h = ph * 2 + (k & 1);
+            ok[k] = uok && (k >> 1) < kd && d < D && h < H && w < W;
+            const size_t v = ok[k] ? (((size_t)n * D + d) * H + h) * W + w : 0;
+            o[k] = ld8(x + v * x_ldc + 8 * q);
+        }
+        f8 best;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) best.v[e] = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+            const int d = pd * kd + (k >> 1), h = ph * 2 + (k & 1);
+            const size_t v = (((size_t)n * D + d) * H + h) * W + w;
+            if (APPLY) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[k].v[e] = round_bf(fmaxf(__builtin_fmaf(o[k].v[e], sc.v[e], sh.v[e]), 0.f));
+                st8(a + v * a_ldc + 8 * q, o[k]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) best.v[e] = (o[k].v[e] > best.v[e] || o[k].v[e] != o[k].v[e]) ? o[k].v[e] : best.v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float other = __shfl_xor(best.v[e], Q);           // the other column's maximum (-inf when that column is outside the tensor)
+            best.v[e] = (other > best.v[e] || other != other) ? other : best.v[e];     // NaN propagates, as in nn.MaxPool3d
+        }
+        if (uok && dxl == 0) st8(pooled + ((((size_t)n * Dp + pd) * Hp + ph) * Wp + pw) * C + 8 * q, best);
+    }
+}
+
 // ------------------------------------------------------------------ BN + ReLU (+ pool, + skip) backward
 // dA(v) = g1(v) + [v is the first arg-max of its window] * gpool(window);  dz = dA * (z > 0), z = x*scale + shift
 // REDUCE: per-channel sum dz, sum dz*xhat.  APPLY: dx = bf16(gamma*invstd*(dz - c1 - xhat*c2)), sum dx (conv-bias gradient).
 template <bool POOL, bool APPLYPASS, bool HEAD>
 __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const BnBwdB16Args a) {
+    const bool g_pool_rows = a.pool_one_lane != 0;        // A/B switch (E3_B16_POOL_ONE_LANE): the one-lane-per-window form
     __shared__ float red[2][256][8];
     const int Q = a.C >> 3;
     const int kd = a.kd;
@@ -165,6 +216,64 @@ __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const BnBwdB16Args a) {
                     else { s1.v[e] += dz; s2.v[e] = __builtin_fmaf(dz, xh, s2.v[e]); }
                 }
                 if (APPLYPASS && ok[u]) st8(a.dx + (v0 + u * vstride) * a.dx_ldc + 8 * q, o);
+            }
+        }
+    } else if ((Q & (Q - 1)) == 0 && Q <= 32 && !g_pool_rows) {
+        // A window's two w-columns go to two lanes (lane ^ Q): 2Q consecutive lanes then read 2 voxels x C channels = ONE contiguous run
+        // (128 bytes at C = 32) per (dz, dy), where the one-lane-per-window form asks for half cache lines at a 128-byte stride -- the
+        // fp32 kernel, whose voxels are whole lines, runs the same loop at 5 TB/s, this one ran at 1.7-2.2.  "First arg-max wins" across
+        // the pair: each lane finds its first match (dz, dy), the pair compares 2 * k + dx through one shuffle.
+        const int dxl = (int)((i00 / Q) & 1);
+        for (size_t u0 = i00 / (2 * Q); u0 < (units + vstride / 2 - 1) / (vstride / 2) * (vstride / 2); u0 += vstride / 2) {     // (all lanes of a pair iterate together)
+            const bool uok = active && u0 < units;
+            size_t r = uok ? u0 : 0;
+            const int pw = r % Wp; r /= Wp; const int ph = r % Hp; r /= Hp; const int pd = r % Dp; const int n = r / Dp;
+            const size_t pidx = ((((size_t)n * Dp + pd) * Hp + ph) * Wp + pw) * a.C + 8 * q;
+            const int w = pw * 2 + dxl;
+            f8 gp, pm, xv[4], g[4]; bool ok[4];
+            gp = ld8(a.gpool + pidx); pm = ld8(a.pooled + pidx);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int d = pd * kd + (k >> 1), h = ph * 2 + (k & 1);
+                ok[k] = uok && (k >> 1) < kd && d < a.D && h < a.H && w < a.W;
+                const size_t v = ok[k] ? (((size_t)n * a.D + d) * a.H + h) * a.W + w : 0;
+                xv[k] = ld8(a.x + v * a.x_ldc + 8 * q);
+                if (a.g1) g[k] = ld8(a.g1 + v * a.g1_ldc + 8 * q);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[k].v[e] = 0.f;
+                }
+            }
+            unsigned code = 0;                       // per channel: 2 * (first matching k) + dx, 15 = no match in this column
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                unsigned c = 15u;
+#pragma unroll
+                for (int k = 3; k >= 0; --k) {
+                    const float av = round_bf(fmaxf(__builtin_fmaf(xv[k].v[e], sc.v[e], sh.v[e]), 0.f));
+                    if (ok[k] && av == pm.v[e]) c = (unsigned)(2 * k + dxl);
+                }
+                code |= c << (4 * e);
+            }
+            const unsigned other = (unsigned)__shfl_xor((int)code, Q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!ok[k]) continue;
+                const int d = pd * kd + (k >> 1), h = ph * 2 + (k & 1);
+                const size_t v = (((size_t)n * a.D + d) * a.H + h) * a.W + w;
+                f8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float z = __builtin_fmaf(xv[k].v[e], sc.v[e], sh.v[e]);
+                    const unsigned mine = (code >> (4 * e)) & 15u, theirs = (other >> (4 * e)) & 15u;
+                    float dA = g[k].v[e];
+                    if (mine == (unsigned)(2 * k + dxl) && mine < theirs) dA += gp.v[e];     // first arg-max of the window wins (ATen)
+                    const float dz = z > 0.f ? dA : 0.f;
+                    const float xh = (xv[k].v[e] - mu.v[e]) * is.v[e];
+                    if (APPLYPASS) { o.v[e] = round_bf(gi.v[e] * (dz - c1.v[e] - xh * c2.v[e])); s1.v[e] += o.v[e]; }
+                    else { s1.v[e] += dz; s2.v[e] = __builtin_fmaf(dz, xh, s2.v[e]); }
+                }
+                if (APPLYPASS) st8(a.dx + v * a.dx_ldc + 8 * q, o);
             }
         }
     } else {
@@ -554,6 +663,13 @@ int final_lpv8(int C) {
     return l;
 }
 
+// a pooling window's two w-columns on two lanes: needs lane ^ Q inside the wave (E3_B16_POOL_ONE_LANE=1: the one-lane form, A/B switch)
+bool pool_pairs(int C) {
+    static const bool one_lane = getenv("E3_B16_POOL_ONE_LANE") != nullptr;
+    const int Q = C / 8;
+    return !one_lane && (Q & (Q - 1)) == 0 && Q <= 32;
+}
+
 }  // namespace
 
 int launch_bn_relu_apply_b16(const bf16_t* x, int x_ldc, const float* scale, const float* shift, bf16_t* a, int a_ldc,
@@ -562,6 +678,8 @@ int launch_bn_relu_apply_b16(const bf16_t* x, int x_ldc, const float* scale, con
     const size_t vox = (size_t)N * D * H * W;
     if (pooled) {
         const size_t items = (size_t)N * cdiv(D, kd) * cdiv(H, 2) * cdiv(W, 2) * (C / 8);
+        if (pool_pairs(C)) hipLaunchKernelGGL(bn_relu_pool2_b16_kernel<true>, dim3(ew_grid(2 * items)), dim3(EW_BLOCK), 0, s, x, x_ldc, scale, shift, a, a_ldc, pooled, kd, N, D, H, W, C);
+        else
         hipLaunchKernelGGL(bn_relu_pool_b16_kernel<true>, dim3(ew_grid(items)), dim3(EW_BLOCK), 0, s, x, x_ldc, scale, shift, a, a_ldc, pooled, kd, N, D, H, W, C);
     } else {
         hipLaunchKernelGGL(bn_relu_apply_b16_kernel, dim3(ew_grid((vox * (C / 8) + 3) / 4)), dim3(EW_BLOCK), 0, s, x, x_ldc, scale, shift, a, a_ldc, vox, C);
@@ -573,6 +691,8 @@ int launch_bn_relu_apply_b16(const bf16_t* x, int x_ldc, const float* scale, con
 int launch_maxpool_b16(const bf16_t* a, int a_ldc, bf16_t* pooled, int kd, int N, int D, int H, int W, int C, hipStream_t s) {
     E3_REQUIRE(C % 8 == 0 && a_ldc % 8 == 0, E3_ERR_UNSUPPORTED, "bf16 passes need channel counts that are multiples of 8");
     const size_t items = (size_t)N * cdiv(D, kd) * cdiv(H, 2) * cdiv(W, 2) * (C / 8);
+    if (pool_pairs(C)) hipLaunchKernelGGL(bn_relu_pool2_b16_kernel<false>, dim3(ew_grid(2 * items)), dim3(EW_BLOCK), 0, s, a, a_ldc, nullptr, nullptr, nullptr, 0, pooled, kd, N, D, H, W, C);
+    else
     hipLaunchKernelGGL(bn_relu_pool_b16_kernel<false>, dim3(ew_grid(items)), dim3(EW_BLOCK), 0, s, a, a_ldc, nullptr, nullptr, nullptr, 0, pooled, kd, N, D, H, W, C);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
@@ -586,6 +706,8 @@ int bn_bwd_b16_parts(size_t voxels, int C) {
 }
 
 static int bn_bwd_b16_launch(BnBwdB16Args a, bool apply, hipStream_t s) {
+    static const bool one_lane = getenv("E3_B16_POOL_ONE_LANE") != nullptr;
+    a.pool_one_lane = one_lane ? 1 : 0;
     E3_REQUIRE(a.C % 8 == 0 && a.C <= 2048 && a.x_ldc % 8 == 0, E3_ERR_UNSUPPORTED, "bf16 passes need channel counts that are multiples of 8");
     const dim3 grid(a.parts), block(256);
     const bool pool = a.gpool != nullptr, head = a.g1 == nullptr && !pool;
