@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 CROP = (64, 128, 128)
 BATCH_PER_GPU = 2
-MFMA_PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16, dense
+MFMA_PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0, 'f16': 2500.0}   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16, dense
 HBM_PEAK = 8.0e12                                    # B/s (spec)
 FWDBWD_FLOP_PER_VOXEL = 1279.9e3                     # SURVEY.md 8d (cfg 2 network)
 PMC_FILE = os.path.join('profiles', 'r02_pmc_roofline.json')
@@ -83,7 +83,7 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
         for _ in range(10):
             model(torch.randn(2, 1, 32, 64, 64, device=dev))
     if bf16:
-        model = model.to(torch.bfloat16)
+        model = model.to(torch.float16 if bf16 == 'f16' else torch.bfloat16)
     vol = torch.empty(1, 1, *shape)
     gen = torch.Generator().manual_seed(0)
     for z in range(0, shape[0], 32):         # per-slab generation
@@ -101,7 +101,7 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
     tile_in = [t + 2 * o for t, o in zip(tile, overlap)]
     tile_flop = 427.2e3 * tile_in[0] * tile_in[1] * tile_in[2]            # forward FLOP per tile incl. halo (2744 GFLOP)
     return {'metric': 'Predictor MVox/s', 'value': vol.numel() / dt / 1e6, 'unit': 'MVox/s (input voxels / predict() wall time incl. H2D + D2H)',
-            'seconds': dt, 'volume': list(shape), 'tile': list(tile), 'overlap': list(overlap), 'tiles': ntiles, 'dtype': 'bf16' if bf16 else 'f32',
+            'seconds': dt, 'volume': list(shape), 'tile': list(tile), 'overlap': list(overlap), 'tiles': ntiles, 'dtype': (bf16 if isinstance(bf16, str) else 'bf16') if bf16 else 'f32',
             'out_dtype': str(out.dtype).replace('torch.', ''),
             'finite': bool(torch.isfinite(out[..., ::32, ::32].float()).all()),
             'algorithmic_tflops': ntiles * tile_flop / dt / 1e12,
@@ -127,7 +127,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32', help='f32 = BASELINE configs[1] (the metric\'s config); bf16 = configs[2] per-GPU workload')
+    ap.add_argument('--dtype', choices=('f32', 'bf16', 'f16'), default='f32', help='f32 = BASELINE configs[1] (the metric\'s config); bf16 = configs[2] per-GPU workload; f16 = the same with model.half() (the reference\'s own mixed-precision type)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-predictor', action='store_true', help='skip the Predictor MVox/s leg')
     ap.add_argument('--predictor-volume', choices=('full', 'sub'), default=None, help='full = 512x2048x2048 (default for N = 1), sub = 288x1152x1152')
@@ -162,11 +162,12 @@ def main():
     from elektronn3_amd.unet import UNet
     from elektronn3_amd.loss import CombinedCEDiceLoss   # the example's criterion (0.5 CE + 0.5 Dice, class weights) on device
 
-    bf16 = args.dtype == 'bf16'
+    bf16 = args.dtype in ('bf16', 'f16')
+    t16 = torch.float16 if args.dtype == 'f16' else torch.bfloat16
     torch.manual_seed(0)                                   # identical replica on every rank
     model = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=32, normalization='batch').to(dev).train()
     if bf16:
-        model = model.to(torch.bfloat16)                   # BASELINE configs[2]: "same UNet bf16" (whole-module cast)
+        model = model.to(t16)                              # BASELINE configs[2]: "same UNet bf16" (whole-module cast); f16: model.half()
         if not model._plan().bf16_supported():
             raise SystemExit('bench.py --dtype bf16: configuration not on the native bf16 path')
     # N > 1: ONE loss over the global minibatch, as the reference computes on the batch nn.DataParallel gathers (trainer.py:520-524):
@@ -179,7 +180,7 @@ def main():
     torch.manual_seed(1000 + rank)                         # different synthetic crops per rank
     x = torch.randn(BATCH_PER_GPU, 1, *CROP, device=dev)
     if bf16:
-        x = x.to(torch.bfloat16)
+        x = x.to(t16)
     tgt = torch.randint(0, 2, (BATCH_PER_GPU, *CROP), device=dev)
 
     layers = model.conv_layers()
@@ -257,7 +258,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': (f'BASELINE.json configs[{2 if bf16 else 1}]: UNet(in=1,out=2,n_blocks=4,start_filts=32,bn) '
-                                    f'{"bf16 (model.to(bfloat16), bf16 crops, native bf16 kernels)" if bf16 else "fp32"} train fwd+bwd, '
+                                    f'{("float16 (model.half(), float16 crops, native f16 kernels)" if args.dtype == "f16" else "bf16 (model.to(bfloat16), bf16 crops, native bf16 kernels)") if bf16 else "fp32"} train fwd+bwd, '
                                     f'batch {BATCH_PER_GPU}/GPU of 1x64x128x128 random crops, CE+Dice loss, optimizer excluded'),
                        'global_batch': world * BATCH_PER_GPU, 'crop': list(CROP),
                        'parallelism': f'dp{world}' if world > 1 else 'single',
@@ -306,7 +307,7 @@ def main():
             watchdog.daemon = True
             watchdog.start()
         try:
-            p = predictor_leg(dev, shape, tile_parallel=world > 1, bf16=(args.dtype == 'bf16'))
+            p = predictor_leg(dev, shape, tile_parallel=world > 1, bf16=(args.dtype if args.dtype in ('bf16', 'f16') else False))
             if rank == 0:
                 if world > 1:
                     p.update(n_gpus=world, parallelism=f'tile-parallel over {world} ranks, shared-memory output')

@@ -63,6 +63,22 @@ _SIG = {
     'e3_convT_fwd_bf16': (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, c_size_t]),
     'e3_convT_dgrad_bf16': (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, c_size_t]),
     'e3_convT_wgrad_bf16': (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, c_size_t]),
+    'e3_unet_f16_supported': (_I, [c_void_p]),
+    'e3_unet_sizes_f16': (_I, [c_void_p, _I, _I, _I, _I, _I, POINTER(c_size_t), POINTER(c_size_t)]),
+    'e3_unet_forward_f16': (_I, [c_void_p, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), POINTER(c_float), _P,
+                                  _P, c_size_t, _P, c_size_t, c_uint32]),
+    'e3_unet_backward_f16': (_I, [c_void_p, _P, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), POINTER(c_void_p), _P,
+                                   _P, c_size_t, _P, c_size_t, _P, _I]),
+    'e3_conv3d_workspace_bytes_f16': (c_size_t, [_I, _I, _I, _I, _I, _I, _I]),
+    'e3_conv3d_stats_parts_f16': (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    'e3_conv3d_fwd_f16': (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, c_size_t]),
+    'e3_conv3d_dgrad_f16': (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, c_size_t]),
+    'e3_conv3d_wgrad_f16': (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, c_size_t]),
+    'e3_convT_workspace_bytes_f16': (c_size_t, [_I, _I, _I, _I, _I, _I]),
+    'e3_convT_stats_parts_f16': (_I, [_I, _I, _I, _I, _I]),
+    'e3_convT_fwd_f16': (_I, [_P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, c_size_t]),
+    'e3_convT_dgrad_f16': (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, c_size_t]),
+    'e3_convT_wgrad_f16': (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, c_size_t]),
     'e3_unet_backward2': (_I, [c_void_p, _P, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), POINTER(c_void_p), _P,
                                _P, c_size_t, _P, c_size_t, _P, _I, c_uint32]),
     'e3_unet_conv_count': (_I, [c_void_p]),

@@ -16,7 +16,9 @@ OUT = os.path.join(HERE, 'libe3unet.so')
 OBJDIR = os.path.join(HERE, 'build')
 SOURCES = ['conv_mfma.hip', 'conv_v3.hip', 'conv_wino.hip', 'conv_wino2d.hip', 'upconv_gemm.hip', 'wgrad_mfma.hip', 'wgrad_wino.hip', 'wgrad_wino2d.hip', 'conv_small.hip', 'elementwise.hip', 'loss.hip', 'optim.hip', 'api.cpp', 'unet_plan.cpp',
            'attention.hip', 'bf16_conv.hip', 'bf16_wgrad.hip', 'bf16_upconv.hip', 'bf16_ew.hip', 'bf16_first.hip', 'api_bf16.cpp', 'unet_bf16.cpp']
-HEADERS = ['common.h', 'kernels.h', 'bf16.h', 'plan_internal.h', os.path.join('..', '..', 'include', 'e3unet.h')]
+# the 16-bit path is compiled a second time for IEEE half (-DE3_F16, external symbols renamed by f16_names.h; see csrc/bf16.h)
+F16_SOURCES = ['bf16_conv.hip', 'bf16_wgrad.hip', 'bf16_upconv.hip', 'bf16_ew.hip', 'bf16_first.hip', 'api_bf16.cpp', 'unet_bf16.cpp']
+HEADERS = ['common.h', 'kernels.h', 'bf16.h', 'f16_names.h', 'plan_internal.h', os.path.join('..', '..', 'include', 'e3unet.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-x', 'hip'] + os.environ.get('E3_HIPCC_EXTRA', '').split()
 # per-file extras.  wgrad_wino: the SLP vectoriser turns its scalar transforms into v_pk_* ops plus ~200 v_mov per brick
 # to pair the operands up; packed fp32 is not faster than two scalar ops on gfx950 (7 vs 2 x 4.5 cycles), the moves are pure loss.
@@ -56,10 +58,12 @@ def build(force=False, verbose=False):
 def _build_locked(srcs, hdrs, force, verbose):
     hipcc = _hipcc()
 
-    def compile_one(src):
-        obj = os.path.join(OBJDIR, os.path.basename(src) + '.o')
+    def compile_one(job):
+        src, f16 = job
+        obj = os.path.join(OBJDIR, os.path.basename(src) + ('.f16.o' if f16 else '.o'))
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
+            extra = ['-DE3_F16', '-include', os.path.join(CSRC, 'f16_names.h')] if f16 else []
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + extra + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -69,8 +73,9 @@ def _build_locked(srcs, hdrs, force, verbose):
                 print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(compile_one, srcs))
+    jobs = [(src, False) for src in srcs] + [(os.path.join(CSRC, f), True) for f in F16_SOURCES]
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        objs = list(ex.map(compile_one, jobs))
     tmp = OUT + f'.tmp{os.getpid()}'
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)

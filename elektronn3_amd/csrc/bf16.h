@@ -10,15 +10,27 @@
 #include "common.h"
 
 typedef unsigned short bf16_t;                                   // storage type (raw bits)
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-
+// The whole 16-bit path is compiled twice: as is for bfloat16, and with -DE3_F16 -include f16_names.h for IEEE half (the reference's own
+// reduced-precision mode: torch.cuda.amp.autocast defaults to float16, trainer.py:367,519; Predictor(float16=True) = model.half(),
+// inference.py:445-446).  Only the element type, its conversions and the matrix instruction differ; f16_names.h renames every external
+// symbol of these translation units (launch_*_b16 -> launch_*_f16, e3_*_bf16 -> e3_*_f16).
+#ifdef E3_F16
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }     // round to nearest even, overflow -> inf (as torch)
+#define E3_MFMA16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {                 // round to nearest even (NaN stays NaN)
     return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
+#define E3_MFMA16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
 __device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
 
 // ---------------------------------------------------------------- 3x3x3 / 1x3x3 conv, stride 1, 'same' padding (bf16_conv.hip)

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, (CH == 16 || BD == 2) ? 3 : 2) void conv_b16_k
                 for (int ct = 0; ct < CO_T; ++ct)
 #pragma unroll
                     for (int t = 0; t < G::NV; ++t)
-                        acc[ct][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap % RING][ct][ks], b[st & 1][t], acc[ct][t], 0, 0, 0);
+                        acc[ct][t] = E3_MFMA16(wf[tap % RING][ct][ks], b[st & 1][t], acc[ct][t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void conv_first_b16_fwd_kernel(const bf16_t* _
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[t][0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[t][1], acc[t], 0, 0, 0);
+            acc[t] = E3_MFMA16(af[0], bfr[t][0], acc[t], 0, 0, 0);
+            acc[t] = E3_MFMA16(af[1], bfr[t][1], acc[t], 0, 0, 0);
         }
         // lane (voxel j, half g) holds channels (e&3) + 8*(e>>2) + 4*g of its voxel: bias, rounding, 8-byte stores, lane sums
         float ssum[16], ssq[16];
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_first_b16_wgrad_kernel(const bf16_t*
                 u16x8 v;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = xs[(dd * LH + hh) * LW + 8 * g + e + toffj];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, v), acc, 0, 0, 0);
+                acc = E3_MFMA16(af, __builtin_bit_cast(bf16x8, v), acc, 0, 0, 0);
             }
         }
         // the four waves' partial sums -> slab.  lane holds column tap = j, rows co = (e&3) + 8*(e>>2) + 4*g

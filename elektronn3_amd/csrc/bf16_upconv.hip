@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void upconv_b16_kernel(const UpconvB16Args a, 
 #pragma unroll
                         for (int q = 0; q < RT; ++q)
 #pragma unroll
-                            for (int t = 0; t < NVT; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][u][q], b[0][u][t], acc[q][t], 0, 0, 0);
+                            for (int t = 0; t < NVT; ++t) acc[q][t] = E3_MFMA16(af[0][u][q], b[0][u][t], acc[q][t], 0, 0, 0);
             } else {
                 if (ks0 + U < nks) fetch(ks0 + U, b[0], af[0]);
 #pragma unroll
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void upconv_b16_kernel(const UpconvB16Args a, 
 #pragma unroll
                         for (int q = 0; q < RT; ++q)
 #pragma unroll
-                            for (int t = 0; t < NVT; ++t) acc[q][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][u][q], b[1][u][t], acc[q][t], 0, 0, 0);
+                            for (int t = 0; t < NVT; ++t) acc[q][t] = E3_MFMA16(af[1][u][q], b[1][u][t], acc[q][t], 0, 0, 0);
             }
         }
         // ---- epilogue of this group of row tiles
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fwd_b16_kernel(const UpconvB16A
 #pragma unroll
                 for (int tap = 0; tap < T; ++tap) {
                     const bf16x8 af = *reinterpret_cast<const bf16x8*>(smem + ((tap * CH + c) * 4 + ks) * 1024 + wrd);
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b, acc[tap], 0, 0, 0);
+                    acc[tap] = E3_MFMA16(af, b, acc[tap], 0, 0, 0);
                 }
             }
         // epilogue: bias / folded BN, rounding, statistics, transposed 16-byte stores
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_b16_kernel(const UpconvB1
         for (int ks = 0; ks < 16; ++ks) {           // k = (tap = ks / 2, 16 channels of dY)
             const bf16x8 b = *reinterpret_cast<const bf16x8*>(ys + buf * YB + (ks >> 1) * 4096 + yrd + (((2 * (ks & 1) + g) ^ ysw) << 4));
             const bf16x8 af = *reinterpret_cast<const bf16x8*>(smem + ks * 1024 + wrd);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b, acc, 0, 0, 0);
+            acc = E3_MFMA16(af, b, acc, 0, 0, 0);
         }
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256, 3) void upconv_wgrad_b16_kernel(const bf16_t* 
                 if (tap < T) {
                     const bf16x8 bfr = tr_frag((unsigned)(XIMG + ((tap * 64 + s * 16 + krow) * 64) + chb));
 #pragma unroll
-                    for (int c = 0; c < CIT; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c], bfr, acc[i][c], 0, 0, 0);
+                    for (int c = 0; c < CIT; ++c) acc[i][c] = E3_MFMA16(af[c], bfr, acc[i][c], 0, 0, 0);
                 }
             }
         }

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_b16_kernel(const WgradB16Args a,
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1], bfr[s & 1][i], acc[i], 0, 0, 0);
+            for (int i = 0; i < TPW; ++i) acc[i] = E3_MFMA16(af[s & 1], bfr[s & 1][i], acc[i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         E3_WTICK(3);

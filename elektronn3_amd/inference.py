@@ -313,8 +313,8 @@ class Predictor:
         # float16=True).  Outputs default to bfloat16 like float16=True defaults to float16; pass out_dtype=torch.float32 for fp32 volumes.
         if not float16 and isinstance(net, nn.Module):
             p0 = next(net.parameters(), None)
-            if p0 is not None and p0.dtype == torch.bfloat16:
-                self.dtype = torch.bfloat16
+            if p0 is not None and p0.dtype in (torch.bfloat16, torch.float16):      # (a module already in half precision: same as float16=True)
+                self.dtype = p0.dtype
 
         # ---- output stages.  Native UNet: softmax inside the last kernel, the rest as a small post-module; any other module is wrapped
         # the way the reference wraps it

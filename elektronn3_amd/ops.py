@@ -227,9 +227,19 @@ def to_ncdhw(x_ndhwc):
 
 
 # ---------------------------------------------------------------------------------------------- native bf16 ops
+class _L16:
+    """The per-op entry points of the 16-bit path for a tensor's element type: `.e3_conv3d_fwd_bf16` resolves to the `_f16` twin for float16."""
+
+    def __init__(self, t):
+        self._lib, self._f16 = _lib.load(), t.dtype == torch.float16
+
+    def __getattr__(self, name):
+        return getattr(self._lib, name.replace('_bf16', '_f16') if self._f16 else name)
+
+
 def _chk16(t, name):
-    if not (t.is_cuda and t.dtype == torch.bfloat16):
-        raise ValueError(f'{name}: expected a bfloat16 CUDA tensor')
+    if not (t.is_cuda and t.dtype in (torch.bfloat16, torch.float16)):
+        raise ValueError(f'{name}: expected a bfloat16 / float16 CUDA tensor')
     if t.dim() == 5:
         _ldc(t)
     return t
@@ -237,11 +247,11 @@ def _chk16(t, name):
 
 def conv3d_bf16(x, w, bias=None, planar=False, epi=None, want_stats=False, out=None):
     """bf16 3x3x3 / 1x3x3 'same' conv on the bf16 matrix cores. x: (N,D,H,W,Cin) bf16; w: fp32 torch layout (rounded to bf16 when packed)."""
-    L = _lib.load()
+    L = _L16(x)
     _chk16(x, 'x')
     N, D, H, W, Cin = x.shape
     Cout = w.shape[0]
-    y = out if out is not None else torch.empty((N, D, H, W, Cout), device=x.device, dtype=torch.bfloat16)
+    y = out if out is not None else torch.empty((N, D, H, W, Cout), device=x.device, dtype=x.dtype)
     ws = _ws(L.e3_conv3d_workspace_bytes_bf16(Cin, Cout, N, D, H, W, int(planar)), x.device)
     stats = None
     if want_stats:
@@ -253,11 +263,11 @@ def conv3d_bf16(x, w, bias=None, planar=False, epi=None, want_stats=False, out=N
 
 
 def conv3d_dgrad_bf16(dy, w, planar=False):
-    L = _lib.load()
+    L = _L16(dy)
     _chk16(dy, 'dy')
     N, D, H, W, Cout = dy.shape
     Cin = w.shape[1]
-    dx = torch.empty((N, D, H, W, Cin), device=dy.device, dtype=torch.bfloat16)
+    dx = torch.empty((N, D, H, W, Cin), device=dy.device, dtype=dy.dtype)
     ws = _ws(L.e3_conv3d_workspace_bytes_bf16(Cin, Cout, N, D, H, W, int(planar)), dy.device)
     w = w.float().contiguous()
     check(L.e3_conv3d_dgrad_bf16(stream_ptr(dy.device), ptr(dy), _ldc(dy), Cout, ptr(w), ptr(dx), Cin, Cin, N, D, H, W, int(planar),
@@ -266,7 +276,7 @@ def conv3d_dgrad_bf16(dy, w, planar=False):
 
 
 def conv3d_wgrad_bf16(x, dy, planar=False):
-    L = _lib.load()
+    L = _L16(x)
     _chk16(x, 'x'); _chk16(dy, 'dy')
     N, D, H, W, Cin = x.shape
     Cout = dy.shape[-1]
@@ -279,12 +289,12 @@ def conv3d_wgrad_bf16(x, dy, planar=False):
 
 def convT_bf16(x, w, bias=None, out_dims=None, want_stats=False, out=None):
     """bf16 ConvTranspose3d(kernel = stride = 2). x: (N,D,H,W,Cin) bf16; w: (Cin,Cout,2,2,2) fp32."""
-    L = _lib.load()
+    L = _L16(x)
     _chk16(x, 'x')
     N, D, H, W, Cin = x.shape
     Cout = w.shape[1]
     Do, Ho, Wo = out_dims if out_dims is not None else (2 * D, 2 * H, 2 * W)
-    y = out if out is not None else torch.empty((N, Do, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16)
+    y = out if out is not None else torch.empty((N, Do, Ho, Wo, Cout), device=x.device, dtype=x.dtype)
     ws = _ws(L.e3_convT_workspace_bytes_bf16(Cin, Cout, N, D, H, W), x.device)
     stats = torch.zeros((L.e3_convT_stats_parts_bf16(Cin, N, D, H, W), Cout, 3), device=x.device, dtype=torch.float32) if want_stats else None
     w = w.float().contiguous()
@@ -294,12 +304,12 @@ def convT_bf16(x, w, bias=None, out_dims=None, want_stats=False, out=None):
 
 
 def convT_dgrad_bf16(dy, w, in_dims):
-    L = _lib.load()
+    L = _L16(dy)
     _chk16(dy, 'dy')
     N, Do, Ho, Wo, Cout = dy.shape
     Cin = w.shape[0]
     D, H, W = in_dims
-    dx = torch.empty((N, D, H, W, Cin), device=dy.device, dtype=torch.bfloat16)
+    dx = torch.empty((N, D, H, W, Cin), device=dy.device, dtype=dy.dtype)
     ws = _ws(L.e3_convT_workspace_bytes_bf16(Cin, Cout, N, D, H, W), dy.device)
     w = w.float().contiguous()
     check(L.e3_convT_dgrad_bf16(stream_ptr(dy.device), ptr(dy), _ldc(dy), Cout, ptr(w), ptr(dx), Cin, Cin, N, D, H, W, Do, Ho, Wo,
@@ -308,7 +318,7 @@ def convT_dgrad_bf16(dy, w, in_dims):
 
 
 def convT_wgrad_bf16(x, dy):
-    L = _lib.load()
+    L = _L16(x)
     _chk16(x, 'x'); _chk16(dy, 'dy')
     N, D, H, W, Cin = x.shape
     _, Do, Ho, Wo, Cout = dy.shape

@@ -61,9 +61,11 @@ class _Plan:
         check(_lib.load().e3_unet_out_dims(self.handle, D, H, W, ctypes.byref(do), ctypes.byref(ho), ctypes.byref(wo)))
         return do.value, ho.value, wo.value
 
-    def sizes(self, N, D, H, W, training, bf16=False):
+    def sizes(self, N, D, H, W, training, bf16=None):
+        """bf16: None / False = fp32 path; torch.bfloat16 (or True) / torch.float16 = the native 16-bit path of that type."""
         saved, scratch = c_size_t(), c_size_t()
-        fn = _lib.load().e3_unet_sizes_bf16 if bf16 else _lib.load().e3_unet_sizes
+        lib = _lib.load()
+        fn = lib.e3_unet_sizes_f16 if bf16 is torch.float16 else (lib.e3_unet_sizes_bf16 if bf16 else lib.e3_unet_sizes)
         check(fn(self.handle, N, D, H, W, int(training), ctypes.byref(saved), ctypes.byref(scratch)))
         return saved.value, scratch.value
 
@@ -117,14 +119,15 @@ def _fp32_table(module, tens):
     return cache[2]
 
 
-def _native_forward(module, plan, x, tens, softmax, want_bf16, x_needs_grad, training, momenta, frozen=False):
-    """One call of e3_unet_forward / e3_unet_forward_bf16.  `tens`: fp32 table tensors (contiguous), `lowp_bf16`: the module stores
-    bf16.  Returns (y fp32, saved buffer or None, the input as handed to the library, bf16 path taken)."""
+def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, training, momenta, frozen=False):
+    """One call of e3_unet_forward / e3_unet_forward_bf16 / e3_unet_forward_f16.  `tens`: fp32 table tensors (contiguous); `want16`: None, or
+    the 16-bit type to compute in (torch.bfloat16 / torch.float16).  Returns (y fp32, saved buffer or None, the input as handed to the
+    library, the 16-bit type of the native path taken or None)."""
     lib = _lib.load()
     dev = x.device
     N, Cin, D, H, W = x.shape
-    b16 = want_bf16 and not x_needs_grad and not frozen and plan.bf16_supported() and not _NO_BF16
-    xin = x.detach().to(torch.bfloat16 if b16 else torch.float32).contiguous()
+    b16 = want16 if (want16 and not x_needs_grad and not frozen and plan.bf16_supported() and not _NO_BF16) else None
+    xin = x.detach().to(b16 if b16 is not None else torch.float32).contiguous()
     saved_bytes, scratch_bytes = plan.sizes(N, D, H, W, training, bf16=b16)
     saved = torch.empty(max(saved_bytes, 256), dtype=torch.uint8, device=dev) if training else None
     scratch = _get_scratch(dev, max(scratch_bytes, 256))
@@ -133,7 +136,7 @@ def _native_forward(module, plan, x, tens, softmax, want_bf16, x_needs_grad, tra
     ptrs = (c_void_p * len(tens))(*[t.data_ptr() for t in tens])
     cmom = (ctypes.c_float * len(momenta))(*momenta) if training else None
     flags = (E3_FWD_TRAINING if training else 0) | (E3_FWD_SOFTMAX if softmax else 0) | (E3_FWD_FROZEN_BN if frozen else 0)
-    fwd = lib.e3_unet_forward_bf16 if b16 else lib.e3_unet_forward
+    fwd = lib.e3_unet_forward_f16 if b16 is torch.float16 else (lib.e3_unet_forward_bf16 if b16 is not None else lib.e3_unet_forward)
     with torch.cuda.device(dev):
         check(fwd(plan.handle, _lib.stream_ptr(dev), c_void_p(xin.data_ptr()), N, D, H, W, ptrs, cmom,
                   c_void_p(y.data_ptr()), c_void_p(saved.data_ptr()) if saved is not None else None,
@@ -160,7 +163,9 @@ def _native_backward(plan, dy, xin, tens, saved, b16, want_dx, sync=None, frozen
             N, D, H, W, ptrs, gptrs, c_void_p(dx.data_ptr()) if dx is not None else None,
             c_void_p(saved.data_ptr()), c_size_t(saved.numel()), c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), ev, ev_blk)
     with torch.cuda.device(dev):
-        if b16:
+        if b16 is torch.float16:
+            check(lib.e3_unet_backward_f16(*args))
+        elif b16:
             check(lib.e3_unet_backward_bf16(*args))
         else:
             check(lib.e3_unet_backward2(*args, E3_BWD_FROZEN_BN if frozen else 0))
@@ -189,7 +194,7 @@ def _store_attention_maps(module, plan, x, training, saved):
 
 class _UNetFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, mode, want_bf16, x, *params):
+    def forward(ctx, module, mode, want16, x, *params):
         plan = module._plan()
         in_dtype = x.dtype
         training = module.training or module._per_sample_norm()   # instance / group statistics also in eval mode
@@ -203,7 +208,12 @@ class _UNetFunction(torch.autograd.Function):
             lowp = tens
             tens = _fp32_table(module, tens)
         tens = [t if t.is_contiguous() else t.contiguous() for t in tens]
-        all_bf16 = lowp is not None and all(t.dtype == torch.bfloat16 for t in lowp if t.is_floating_point())
+        # a module stored entirely in one 16-bit type (model.to(torch.bfloat16) / model.half()) computes natively in that type
+        all16 = None
+        if lowp is not None:
+            kinds = {t.dtype for t in lowp if t.is_floating_point()}
+            if len(kinds) == 1 and next(iter(kinds)) in (torch.bfloat16, torch.float16):
+                all16 = next(iter(kinds))
         # (grad mode is off inside Function.forward; needs_input_grad tells whether a backward can follow)
         # (needs_input_grad mirrors requires_grad of the inputs whatever the grad mode: `mode` carries torch.is_grad_enabled() of the caller,
         # so that validation under torch.no_grad() takes the inference path instead of saving activations nobody will use)
@@ -222,13 +232,13 @@ class _UNetFunction(torch.autograd.Function):
         if rr is not None:
             ctx.rrelu = (rr[0], rr[1], int(torch.randint(1, 2 ** 31 - 1, (1,)).item()))
         check(_lib.load().e3_unet_set_rrelu(plan.handle, *(ctx.rrelu if ctx.rrelu is not None else (0.0, 0.0, 0))))
-        y, saved, xin, b16 = _native_forward(module, plan, x, tens, softmax, want_bf16 or (all_bf16 and in_dtype == torch.bfloat16),
+        y, saved, xin, b16 = _native_forward(module, plan, x, tens, softmax, want16 if want16 else (all16 if in_dtype == all16 else None),
                                              ctx.needs_input_grad[3], training or frozen,
                                              module._momenta(plan) if (training or frozen) else None, frozen=frozen)
-        if getattr(module, 'attention', False) and not b16:
+        if getattr(module, 'attention', False) and b16 is None:
             _store_attention_maps(module, plan, x, training or frozen, saved)
         ctx.frozen = frozen
-        out_dtype = torch.bfloat16 if (b16 and want_bf16) else in_dtype
+        out_dtype = want16 if (b16 is not None and want16) else in_dtype
         if training and not frozen and module.training:
             module._bump_num_batches_tracked(plan)
             if lowp is not None:         # running statistics were updated in the fp32 copies
@@ -891,17 +901,21 @@ class UNet(nn.Module):
         params = [p for _, p in self._named_table_params(plan)]
         # torch.autocast('cuda', dtype=torch.bfloat16) around the call (the bf16 counterpart of Trainer(mixed_precision=True),
         # trainer.py:519), or module.compute_dtype = torch.bfloat16: bf16 compute with the module's own (fp32 master) parameters
-        want_bf16 = (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16) \
-            or getattr(self, 'compute_dtype', None) == torch.bfloat16
+        # ... and the reference's own default, float16 autocast (torch.cuda.amp.autocast(), trainer.py:519): float16 compute (native f16 kernels)
+        want16 = None
+        if torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in (torch.bfloat16, torch.float16):
+            want16 = torch.get_autocast_dtype('cuda')
+        elif getattr(self, 'compute_dtype', None) in (torch.bfloat16, torch.float16):
+            want16 = self.compute_dtype
         if any(p.device != x.device for p in params):
             raise RuntimeError('input and parameters are on different devices')
         mode = (1 if softmax else 0) | (2 if torch.is_grad_enabled() else 0)
         if self._per_sample_norm():
             # per-sample statistics in training AND eval mode (nn.InstanceNorm3d defaults, nn.GroupNorm): one native call per sample;
             # autograd sums the parameter gradients of the calls
-            y = torch.cat([_UNetFunction.apply(self, mode, want_bf16, x[n:n + 1], *params) for n in range(x.shape[0])], 0)
+            y = torch.cat([_UNetFunction.apply(self, mode, want16, x[n:n + 1], *params) for n in range(x.shape[0])], 0)
         else:
-            y = _UNetFunction.apply(self, mode, want_bf16, x, *params)
+            y = _UNetFunction.apply(self, mode, want16, x, *params)
         return y.squeeze(2) if self.dim == 2 else y
 
     @torch.jit.unused

@@ -315,6 +315,37 @@ int e3_convT_dgrad_bf16(void* stream, const void* dy, int dy_ldc, int Cout, cons
 int e3_convT_wgrad_bf16(void* stream, const void* x, int x_ldc, int Cin, const void* dy, int dy_ldc, int Cout, float* dw,
                         int N, int D, int H, int W, int Do, int Ho, int Wo, void* workspace, size_t workspace_bytes);
 
+/* The same path compiled for IEEE half (float16): the reference's OWN reduced-precision mode -- torch.cuda.amp.autocast defaults to
+ * float16 (Trainer(mixed_precision=True), elektronn3/training/trainer.py:367,519) and Predictor(float16=True) calls model.half()
+ * (elektronn3/inference/inference.py:445-446).  Same signatures and semantics with float16 in place of bfloat16 (v_mfma_f32_32x32x16_f16,
+ * overflow -> inf as in torch); gradients of a float16 net want a scaled loss (torch.cuda.amp.GradScaler, trainer.py:368,539-542). */
+int e3_unet_f16_supported(const e3_unet_plan* plan);
+int e3_unet_sizes_f16(const e3_unet_plan* plan, int N, int D, int H, int W, int training, size_t* saved_bytes, size_t* scratch_bytes);
+int e3_unet_forward_f16(e3_unet_plan* plan, void* stream, const void* x, int N, int D, int H, int W,
+                         void* const* params, const float* momenta, float* y,
+                         void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags);
+int e3_unet_backward_f16(e3_unet_plan* plan, void* stream, const float* dy, const void* x, int N, int D, int H, int W,
+                          void* const* params, void* const* grads, void* dx,
+                          void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                          void* bucket_event, int bucket_after_down_block);
+size_t e3_conv3d_workspace_bytes_f16(int Cin, int Cout, int N, int D, int H, int W, int planar);
+int e3_conv3d_stats_parts_f16(int Cin, int Cout, int N, int D, int H, int W, int planar);
+int e3_conv3d_fwd_f16(void* stream, const void* x, int x_ldc, int Cin, const float* w, const float* bias, void* y, int y_ldc, int Cout,
+                       int N, int D, int H, int W, int planar, const float* epi_scale, const float* epi_shift, float* stats,
+                       void* workspace, size_t workspace_bytes);
+int e3_conv3d_dgrad_f16(void* stream, const void* dy, int dy_ldc, int Cout, const float* w, void* dx, int dx_ldc, int Cin,
+                         int N, int D, int H, int W, int planar, void* workspace, size_t workspace_bytes);
+int e3_conv3d_wgrad_f16(void* stream, const void* x, int x_ldc, int Cin, const void* dy, int dy_ldc, int Cout, float* dw,
+                         int N, int D, int H, int W, int planar, void* workspace, size_t workspace_bytes);
+size_t e3_convT_workspace_bytes_f16(int Cin, int Cout, int N, int D, int H, int W);
+int e3_convT_stats_parts_f16(int Cin, int N, int D, int H, int W);
+int e3_convT_fwd_f16(void* stream, const void* x, int x_ldc, int Cin, const float* w, const float* bias, void* y, int y_ldc, int Cout,
+                      int N, int D, int H, int W, int Do, int Ho, int Wo, float* stats, void* workspace, size_t workspace_bytes);
+int e3_convT_dgrad_f16(void* stream, const void* dy, int dy_ldc, int Cout, const float* w, void* dx, int dx_ldc, int Cin,
+                        int N, int D, int H, int W, int Do, int Ho, int Wo, void* workspace, size_t workspace_bytes);
+int e3_convT_wgrad_f16(void* stream, const void* x, int x_ldc, int Cin, const void* dy, int dy_ldc, int Cout, float* dw,
+                        int N, int D, int H, int W, int Do, int Ho, int Wo, void* workspace, size_t workspace_bytes);
+
 /* Layout conversion at the module boundary. */
 int e3_ncdhw_to_ndhwc(void* stream, const float* src, float* dst, int N, int C, int D, int H, int W);
 int e3_ndhwc_to_ncdhw(void* stream, const float* src, int src_ldc, float* dst, int N, int C, int D, int H, int W);
