@@ -364,11 +364,13 @@ def make_swa(out):
     print('wrote', out, f'{os.path.getsize(out) / 1e6:.2f} MB')
 
 
-def make_unet_bf16(unet, out, seed=21, n_blocks=2, start_filts=32, shape=(9, 18, 20), batch=2):
-    """BASELINE configs[2] ("same UNet bf16"): the reference module cast with model.to(torch.bfloat16) and fed a bf16 input (the style of
+def make_unet_bf16(unet, out, seed=21, n_blocks=2, start_filts=32, shape=(9, 18, 20), batch=2, lowp=torch.bfloat16, dl_scale=1e-3):
+    """BASELINE configs[2] ("same UNet bf16"): the reference module cast with model.to(lowp) and fed a bf16 input (the style of
     benchmark/pred_benchmark.py:55,71 and Predictor(float16=True), inference.py:445-446 -- the reference has no bf16 switch of its own,
     SURVEY 0.6), one train step with a given logits gradient; beside it the fp32 run of the SAME bf16-valued weights and input, so that
-    a test can state its error relative to the reference's own bf16-vs-fp32 distance."""
+    a test can state its error relative to the reference's own bf16-vs-fp32 distance.  lowp=torch.float16: the same in IEEE half (model.half())."""
+    NAME = 'f16' if lowp == torch.float16 else 'bf16'
+    TAG = ':' + NAME      # 16-bit values are stored as their bit patterns under keys with this suffix
     torch.manual_seed(seed)
     model = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts)
     with torch.no_grad():
@@ -378,15 +380,15 @@ def make_unet_bf16(unet, out, seed=21, n_blocks=2, start_filts=32, shape=(9, 18,
             elif name.endswith('bias'):
                 p.copy_(0.1 * torch.randn_like(p))
         for p in model.parameters():
-            p.copy_(p.to(torch.bfloat16).float())             # bf16-valued parameters: both runs start from identical numbers
-    bits = lambda t: npy(t.detach().to(torch.bfloat16).view(torch.int16)).view(np.uint16)     # bf16 values as their 16-bit patterns (half the file)
+            p.copy_(p.to(lowp).float())             # bf16-valued parameters: both runs start from identical numbers
+    bits = lambda t: npy(t.detach().to(lowp).view(torch.int16)).view(np.uint16)     # bf16 values as their 16-bit patterns (half the file)
     sd0 = {k: npy(v).copy() for k, v in model.state_dict().items()}
-    x = torch.randn(batch, 1, *shape).to(torch.bfloat16)
-    dl = (torch.randn(batch, 2, *shape) * 1e-3).to(torch.bfloat16)
-    d = {'cfg.n_blocks': n_blocks, 'cfg.start_filts': start_filts, 'x:bf16': bits(x), 'dlogits:bf16': bits(dl)}
+    x = torch.randn(batch, 1, *shape).to(lowp)
+    dl = (torch.randn(batch, 2, *shape) * dl_scale).to(lowp)
+    d = {'cfg.n_blocks': n_blocks, 'cfg.start_filts': start_filts, 'x' + TAG: bits(x), 'dlogits' + TAG: bits(dl)}
     for k, v in model.state_dict().items():
-        if v.is_floating_point() and float((v - v.to(torch.bfloat16).float()).abs().max()) == 0.0:
-            d['sd0/' + k + ':bf16'] = bits(v)
+        if v.is_floating_point() and float((v - v.to(lowp).float()).abs().max()) == 0.0:
+            d['sd0/' + k + TAG] = bits(v)
         else:
             d['sd0/' + k] = npy(v)
     model.train()
@@ -400,22 +402,27 @@ def make_unet_bf16(unet, out, seed=21, n_blocks=2, start_filts=32, shape=(9, 18,
             d['sd1_fp32/' + k] = npy(v)
     m16 = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts)
     m16.load_state_dict({k: torch.as_tensor(v) for k, v in sd0.items()})
-    m16 = m16.to(torch.bfloat16).train()
+    m16 = m16.to(lowp).train()
     y16 = m16(x)
-    assert y16.dtype == torch.bfloat16
+    assert y16.dtype == lowp
     y16.backward(dl)
-    d['logits_bf16:bf16'] = bits(y16)
+    d['logits_' + NAME + TAG] = bits(y16)
     for k, p in m16.named_parameters():
-        d['grad16/' + k + ':bf16'] = bits(p.grad)
+        d['grad16/' + k + TAG] = bits(p.grad)
     for k, v in m16.state_dict().items():
         if 'running' in k:
-            d['sd1_bf16/' + k + ':bf16'] = bits(v)
+            d['sd1_' + NAME + '/' + k + TAG] = bits(v)
     np.savez_compressed(out, **d)
     e = float((y16.float() - y32).abs().max()), float(y32.abs().max())
     print('wrote', out, f'{os.path.getsize(out) / 1e6:.2f} MB', 'reference bf16 vs fp32 logits: max err %.3e at scale %.2f' % e)
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'f16':      # the reference in float16 (model.half(), inference.py:445-446): O(1) incoming gradient, as GradScaler provides
+        torch.set_num_threads(8)
+        unet, _, _ = load_reference()
+        make_unet_bf16(unet, f'{HERE}/unet_nb2_sf32_f16.npz', lowp=torch.float16, dl_scale=1.0)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'bf16':
         torch.set_num_threads(8)
         unet, _, _ = load_reference()

@@ -130,6 +130,8 @@ def load_bf16_fixture(path):
         a = np.array(g[k])
         if k.endswith(':bf16'):
             out[k[:-5]] = torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16).float()
+        elif k.endswith(':f16'):            # IEEE half fixtures (tests/golden/unet_nb2_sf32_f16.npz)
+            out[k[:-4]] = torch.from_numpy(a.view(np.int16).copy()).view(torch.float16).float()
         else:
             out[k] = torch.from_numpy(a) if a.ndim else torch.tensor(a.item())
     return out

@@ -5,9 +5,13 @@ Same kernels as the bfloat16 path (tests/test_bf16_gpu.py), different element ty
 op in fp64 on the SAME float16-valued inputs (what is left is the fp32 accumulation order and the final rounding, half an ulp = 2^-11 relative).
 Whole network: a ``model.half()`` module against the fp32 HIP path on the same float16-valued parameters; float16 autocast with GradScaler.
 """
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
+
+from helpers import GOLDEN, load_bf16_fixture
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -202,3 +206,33 @@ def test_predictor_float16_switch_runs_the_native_f16_kernels():
     assert y16.dtype == HF and y32.dtype == torch.float32
     assert next(m.parameters()).dtype == torch.float32            # the caller's module is left in fp32 (inference.py:402-407)
     assert float((y16.float() - y32).abs().max()) < 5e-3
+
+
+def test_unet_f16_against_reference_fixture():
+    """The imported reference in float16 (model.half() on CPU, tests/golden/make_golden.py f16) on a committed fixture: one train step with an
+    O(1) logits gradient; beside it the reference's fp32 run of the same float16-valued weights and input.  The native path must be as close
+    to the fp32 run as the reference's own float16 run is (x3), logits and every gradient tensor."""
+    from elektronn3_amd.unet import UNet
+    g = load_bf16_fixture(os.path.join(GOLDEN, 'unet_nb2_sf32_f16.npz'))
+    sd = {k[4:]: v for k, v in g.items() if k.startswith('sd0/')}
+    m = UNet(1, 2, n_blocks=int(g['cfg.n_blocks']), start_filts=int(g['cfg.start_filts']))
+    m.load_state_dict(sd)
+    m = m.to(DEV).half().train()
+    y = m(g['x'].half().to(DEV))
+    y.backward(g['dlogits'].half().to(DEV))
+    torch.cuda.synchronize()
+    ref16, ref32 = g['logits_f16'], g['logits_fp32']
+    scale = float(ref32.abs().max())
+    err_ref = float((ref16 - ref32).abs().max())
+    err = float((y.float().cpu() - ref32).abs().max())
+    assert err < max(3e-3 * scale, 2 * err_ref), f'logits: {err} (reference float16 vs fp32: {err_ref}, scale {scale})'
+    for k, p in m.named_parameters():
+        if k.endswith('.bias') and 'norm' not in k and not k.startswith('conv_final'):
+            continue
+        r32, r16 = g['grad32/' + k], g['grad16/' + k]
+        e_ref = float((r16 - r32).norm() / r32.norm())
+        e = float((p.grad.float().cpu() - r32).norm() / r32.norm())
+        assert e < max(3 * e_ref, 1e-2), f'{k}: rel-L2 {e} (reference float16: {e_ref})'
+    for k, v in m.state_dict().items():
+        if 'running' in k:
+            torch.testing.assert_close(v.float().cpu(), g['sd1_f16/' + k], rtol=4e-3, atol=4e-3 * float(g['sd1_f16/' + k].abs().max()), msg=lambda s: f'{k}: {s}')
