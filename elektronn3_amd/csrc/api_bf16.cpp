@@ -8,7 +8,7 @@ extern "C" {
 
 size_t e3_conv3d_workspace_bytes_bf16(int Cin, int Cout, int N, int D, int H, int W, int planar) {
     const int T = planar ? 9 : 27;
-    if (Cin < 8) return align_up((size_t)conv_small_b16_wgrad_splits(N, D, H, W) * T * Cout * Cin * 4 + 256, 256);      // first conv: only the wgrad slab
+    if (Cin < 8) return align_up((size_t)conv_small_b16_wgrad_splits(N, D, H, W, planar) * T * Cout * Cin * 4 + 256, 256);      // first conv: only the wgrad slab
     const size_t pack = align_up(conv_b16_packed_elems(Cin, Cout, planar) * 2, 256);
     const size_t slab = Cin % 32 == 0 && Cout % 32 == 0 ? (size_t)wgrad_b16_splits(N, D, H, W, Cin, Cout, planar) * T * Cin * Cout * 4 : 0;
     // forward / dgrad: packed weights, then (low-resolution shapes) the split-K partial sums of either direction
@@ -18,7 +18,7 @@ size_t e3_conv3d_workspace_bytes_bf16(int Cin, int Cout, int N, int D, int H, in
 }
 
 int e3_conv3d_stats_parts_bf16(int Cin, int Cout, int N, int D, int H, int W, int planar) {
-    return Cin < 8 ? conv_small_b16_stats_parts(N, D, H, W) : conv_b16_stats_parts(N, D, H, W, Cin, Cout, planar);
+    return Cin < 8 ? conv_small_b16_stats_parts(N, D, H, W, planar) : conv_b16_stats_parts(N, D, H, W, Cin, Cout, planar);
 }
 
 int e3_conv3d_fwd_bf16(void* stream, const void* x, int x_ldc, int Cin, const float* w, const float* bias, void* y, int y_ldc, int Cout,
@@ -59,7 +59,7 @@ int e3_conv3d_wgrad_bf16(void* stream, const void* x, int x_ldc, int Cin, const 
     E3_REQUIRE(x && dy && dw && workspace, E3_ERR_INVALID, "null argument");
     const int T = planar ? 9 : 27;
     if (Cin < 8) {
-        const int splits = conv_small_b16_wgrad_splits(N, D, H, W);
+        const int splits = conv_small_b16_wgrad_splits(N, D, H, W, planar);
         E3_REQUIRE(workspace_bytes >= (size_t)splits * T * Cout * Cin * 4, E3_ERR_WORKSPACE, "wgrad bf16 workspace too small");
         int rc1 = launch_conv_small_b16_wgrad((const bf16_t*)x, Cin, (const bf16_t*)dy, dy_ldc, (float*)workspace, N, D, H, W, Cout, planar, s);
         if (rc1) return rc1;

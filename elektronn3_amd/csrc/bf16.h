@@ -131,10 +131,10 @@ int launch_conv_first_b16_fwd(const bf16_t* x, const float* w, const float* bias
                               const float* epi_scale, const float* epi_shift, float* stats, hipStream_t s);
 int launch_conv_first_b16_wgrad(const bf16_t* x, const bf16_t* dy, int dy_ldc, float* part, int N, int D, int H, int W, int Cout, int tiles_per_split, int splits,
                                 hipStream_t s);
-int conv_small_b16_stats_parts(int N, int D, int H, int W);
+int conv_small_b16_stats_parts(int N, int D, int H, int W, int planar = 0);
 int launch_conv_small_b16_fwd(const bf16_t* x, int Cin, const float* w /*torch (Cout,Cin,T) fp32*/, const float* bias, bf16_t* y, int y_ldc,
                               int N, int D, int H, int W, int Cout, int planar, const float* epi_scale, const float* epi_shift, float* stats, hipStream_t s);
-int conv_small_b16_wgrad_splits(int N, int D, int H, int W);
+int conv_small_b16_wgrad_splits(int N, int D, int H, int W, int planar = 0);
 int launch_conv_small_b16_wgrad(const bf16_t* x, int Cin, const bf16_t* dy, int dy_ldc, float* part /*[splits][T][Cout][Cin]*/,
                                 int N, int D, int H, int W, int Cout, int planar, hipStream_t s);
 // 1x1x1 head: a (bf16, optionally BN+ReLU applied while loading) -> fp32 NCDHW logits (+ softmax); backward: dW/db partials (+ da)

@@ -728,40 +728,44 @@ static int bn_bwd_b16_launch(BnBwdB16Args a, bool apply, hipStream_t s) {
 int launch_bn_bwd_b16_reduce(BnBwdB16Args a, hipStream_t s) { return bn_bwd_b16_launch(a, false, s); }
 int launch_bn_bwd_b16_apply(BnBwdB16Args a, hipStream_t s) { return bn_bwd_b16_launch(a, true, s); }
 
-int conv_small_b16_stats_parts(int N, int D, int H, int W) { return N * cdiv(D, 2) * cdiv(H, 8) * cdiv(W, 16); }
+// brick of the first conv: 2 x 8 x 16 voxels, planar (1x3x3 taps, unet.py:114-128) 1 x 16 x 16
+int conv_small_b16_stats_parts(int N, int D, int H, int W, int planar) { return planar ? N * D * cdiv(H, 16) * cdiv(W, 16) : N * cdiv(D, 2) * cdiv(H, 8) * cdiv(W, 16); }
 
 int launch_conv_small_b16_fwd(const bf16_t* x, int Cin, const float* w, const float* bias, bf16_t* y, int y_ldc,
                               int N, int D, int H, int W, int Cout, int planar, const float* epi_scale, const float* epi_shift, float* stats, hipStream_t s) {
-    E3_REQUIRE(Cin >= 1 && Cin < 8 && !planar, E3_ERR_UNSUPPORTED, "bf16 first conv: 1..7 input channels, 3x3x3");
+    E3_REQUIRE(Cin >= 1 && Cin < 8, E3_ERR_UNSUPPORTED, "bf16 first conv: 1..7 input channels");
     E3_REQUIRE(Cout % 4 == 0 && y_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "output channels must be a multiple of 4");
     if (conv_first_b16_supported(Cin, Cout, planar)) return launch_conv_first_b16_fwd(x, w, bias, y, y_ldc, N, D, H, W, Cout, epi_scale, epi_shift, stats, s);
-    const int tD = cdiv(D, 2), tH = cdiv(H, 8), tW = cdiv(W, 16);
-    const int NV = 4 * 10 * 18;
-    const int wslab = Cin * 27 * 32 > 4 * 32 * 3 ? Cin * 27 * 32 : 4 * 32 * 3;
+    const int T = planar ? 9 : 27;
+    const int tD = planar ? D : cdiv(D, 2), tH = cdiv(H, planar ? 16 : 8), tW = cdiv(W, 16);
+    const int NV = planar ? 1 * 18 * 18 : 4 * 10 * 18;
+    const int wslab = Cin * T * 32 > 4 * 32 * 3 ? Cin * T * 32 : 4 * 32 * 3;
     const size_t lds = (size_t)(((Cin * NV + 3) & ~3) + wslab) * 4;
-    hipLaunchKernelGGL((conv_small_b16_fwd_kernel<3, 2, 8>), dim3((unsigned)((size_t)N * tD * tH * tW)), dim3(256), lds, s, x, Cin, w, bias, y, y_ldc,
-                       N, D, H, W, Cout, epi_scale, epi_shift, stats, tD, tH, tW);
+    const dim3 grid((unsigned)((size_t)N * tD * tH * tW));
+    if (planar) hipLaunchKernelGGL((conv_small_b16_fwd_kernel<1, 1, 16>), grid, dim3(256), lds, s, x, Cin, w, bias, y, y_ldc, N, D, H, W, Cout, epi_scale, epi_shift, stats, tD, tH, tW);
+    else hipLaunchKernelGGL((conv_small_b16_fwd_kernel<3, 2, 8>), grid, dim3(256), lds, s, x, Cin, w, bias, y, y_ldc, N, D, H, W, Cout, epi_scale, epi_shift, stats, tD, tH, tW);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
 
 static int small_b16_tps(int ntiles) { return cdiv(ntiles, 1024); }
-int conv_small_b16_wgrad_splits(int N, int D, int H, int W) {
-    const int ntiles = conv_small_b16_stats_parts(N, D, H, W);
+int conv_small_b16_wgrad_splits(int N, int D, int H, int W, int planar) {
+    const int ntiles = conv_small_b16_stats_parts(N, D, H, W, planar);
     return cdiv(ntiles, small_b16_tps(ntiles));
 }
 
 int launch_conv_small_b16_wgrad(const bf16_t* x, int Cin, const bf16_t* dy, int dy_ldc, float* part,
                                 int N, int D, int H, int W, int Cout, int planar, hipStream_t s) {
-    E3_REQUIRE(Cin >= 1 && Cin < 8 && !planar, E3_ERR_UNSUPPORTED, "bf16 first conv: 1..7 input channels, 3x3x3");
-    const int tD = cdiv(D, 2), tH = cdiv(H, 8), tW = cdiv(W, 16);
+    E3_REQUIRE(Cin >= 1 && Cin < 8, E3_ERR_UNSUPPORTED, "bf16 first conv: 1..7 input channels");
+    const int tD = planar ? D : cdiv(D, 2), tH = cdiv(H, planar ? 16 : 8), tW = cdiv(W, 16);
     const int ntiles = N * tD * tH * tW;
     const int tps = small_b16_tps(ntiles);
     const int splits = cdiv(ntiles, tps);
     if (conv_first_b16_supported(Cin, Cout, planar)) return launch_conv_first_b16_wgrad(x, dy, dy_ldc, part, N, D, H, W, Cout, tps, splits, s);
-    const int NV = 4 * 10 * 18;
+    const int NV = planar ? 1 * 18 * 18 : 4 * 10 * 18;
     const size_t lds = (size_t)(((NV + 3) & ~3) + 256 * 32) * 4;
-    hipLaunchKernelGGL((conv_small_b16_wgrad_kernel<3, 2, 8>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps);
+    if (planar) hipLaunchKernelGGL((conv_small_b16_wgrad_kernel<1, 1, 16>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps);
+    else hipLaunchKernelGGL((conv_small_b16_wgrad_kernel<3, 2, 8>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

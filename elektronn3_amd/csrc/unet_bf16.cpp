@@ -4,7 +4,7 @@
 // coefficients and parameter gradients.  The parameter table stays fp32 (the Python side hands over up-cast copies of a bf16
 // module's parameters: 22 MB for cfg 2); conv weights are rounded to bf16 when they are packed, once per call.
 //
-// Covers the configuration BASELINE names (and its siblings): dim = 3 without planar blocks, normalization='batch' with
+// Covers the configuration BASELINE names (and its siblings): dim = 3 / 2 with any planar blocks, normalization='batch' with
 // full_norm, ReLU, up_mode='transpose', merge_mode='concat', conv_mode='same', in_channels < 8, start_filts % 32 == 0.
 // e3_unet_bf16_supported() says so; everything else keeps the fp32 kernels on up-cast copies.
 #include <algorithm>
@@ -77,22 +77,23 @@ void plan_b16(const e3_unet_plan* p, int N, int D, int H, int W, bool training, 
         const LevelDims& li = ND.u[k].in;
         UnitB& b = B.ub[k];
         size_t own = 0;
+        const int pl = u.planar, sd = pl ? 1 : 2, taps = pl ? 9 : 27;      // planar block (unet.py:114-128): 1x3x3 convs, (1,2,2) pooling / up-convolution
         if (u.is_up) {
-            wmax = max(wmax, upconv_b16_packed_elems(u.cin, u.cout, 2));
-            statmax = max(statmax, (size_t)upconv_b16_stats_parts(N, li.D, li.H, li.W, 2, u.cin) * u.cout * 3);
-            own = (size_t)upconv_b16_wgrad_splits(N, li.D, li.H, li.W) * 8 * u.cin * u.cout;
+            wmax = max(wmax, upconv_b16_packed_elems(u.cin, u.cout, sd));
+            statmax = max(statmax, (size_t)upconv_b16_stats_parts(N, li.D, li.H, li.W, sd, u.cin) * u.cout * 3);
+            own = (size_t)upconv_b16_wgrad_splits(N, li.D, li.H, li.W) * sd * 4 * u.cin * u.cout;
         } else if (u.cin < 8) {
-            statmax = max(statmax, (size_t)conv_small_b16_stats_parts(N, li.D, li.H, li.W) * u.cout * 3);
-            slabmax = max(slabmax, (size_t)conv_small_b16_wgrad_splits(N, li.D, li.H, li.W) * 27 * u.cout * u.cin);
+            statmax = max(statmax, (size_t)conv_small_b16_stats_parts(N, li.D, li.H, li.W, pl) * u.cout * 3);
+            slabmax = max(slabmax, (size_t)conv_small_b16_wgrad_splits(N, li.D, li.H, li.W, pl) * taps * u.cout * u.cin);
         } else {
-            wmax = max(wmax, conv_b16_packed_elems(u.cin, u.cout, 0));
-            statmax = max(statmax, (size_t)conv_b16_stats_parts(N, li.D, li.H, li.W, u.cin, u.cout, 0) * u.cout * 3);
+            wmax = max(wmax, conv_b16_packed_elems(u.cin, u.cout, pl));
+            statmax = max(statmax, (size_t)conv_b16_stats_parts(N, li.D, li.H, li.W, u.cin, u.cout, pl) * u.cout * 3);
             skmax = max(skmax, conv_b16_partial_floats(N, li.D, li.H, li.W, u.cin, u.cout));
             if (training) skmax = max(skmax, conv_b16_partial_floats(N, li.D, li.H, li.W, u.cout, u.cin));
-            own = (size_t)wgrad_b16_splits(N, li.D, li.H, li.W, u.cin, u.cout, 0) * 27 * u.cin * u.cout;
+            own = (size_t)wgrad_b16_splits(N, li.D, li.H, li.W, u.cin, u.cout, pl) * taps * u.cin * u.cout;
         }
         if (u.is_up || u.cin >= 8) {          // packed bf16 weights: forward form, data-gradient form (all packed by one launch per pass)
-            const size_t pe = u.is_up ? upconv_b16_packed_elems(u.cin, u.cout, 2) : conv_b16_packed_elems(u.cin, u.cout, 0);
+            const size_t pe = u.is_up ? upconv_b16_packed_elems(u.cin, u.cout, sd) : conv_b16_packed_elems(u.cin, u.cout, pl);
             b.wpk_f = T.take_h(pe);
             b.wpk_d = training ? T.take_h(pe) : nullptr;
         }
@@ -139,7 +140,7 @@ struct ProfB {      // same per-layer HIP-event profiling hook as the fp32 execu
 
 bool supported(const e3_unet_cfg& c) {
     return c.normalization == 1 && c.full_norm && c.act_slope == 0.f && c.up_resize == 0 && !c.merge_add && !c.conv_valid &&
-           c.planar_mask == 0 && c.in_channels < 8 && c.start_filts % 32 == 0 && c.out_channels <= 8 && !c.attention && !c.resunet;
+           c.in_channels < 8 && c.start_filts % 32 == 0 && c.out_channels <= 8 && !c.attention && !c.resunet;
 }
 
 }  // namespace
@@ -189,7 +190,7 @@ int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N,
         std::vector<PackB16Job> jobs;
         for (size_t k = 0; k < nu; ++k) {
             const ConvUnit& u = plan->units[k];
-            if (B.ub[k].wpk_f) jobs.push_back({P(u.p_w), B.ub[k].wpk_f, u.cout, u.cin, u.is_up ? 8 : 27, u.is_up ? 2 : 0});
+            if (B.ub[k].wpk_f) jobs.push_back({P(u.p_w), B.ub[k].wpk_f, u.cout, u.cin, u.is_up ? (u.planar ? 4 : 8) : (u.planar ? 9 : 27), u.is_up ? 2 : 0});
         }
         RUN(launch_pack_multi_b16(jobs.data(), (int)jobs.size(), s));
     }
@@ -204,6 +205,7 @@ int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N,
         const LevelDims& li = ND.u[k].in;
         const bool is_enc_conv2 = u.enc_last;
         const bool pool_after = is_enc_conv2 && u.level < nb - 1;
+        const int pl = u.planar, sd = pl ? 1 : 2;
         bf16_t* dst = training ? b.raw : b.act;
         const int dst_ldc = training ? u.cout : b.act_ldc;
         const float* es = training ? nullptr : b.scale; const float* eh = training ? nullptr : b.shift;
@@ -211,22 +213,22 @@ int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N,
         if (u.is_up) {
             UpconvB16Args a{};
             a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.y = dst; a.y_ldc = dst_ldc; a.Cout = u.cout; a.wt = b.wpk_f;
-            a.bias = training ? P(u.p_b) : nullptr; a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = 2;
+            a.bias = training ? P(u.p_b) : nullptr; a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = sd;
             a.epi_scale = es; a.epi_shift = eh; a.stats = training ? B.stats : nullptr;
-            parts = upconv_b16_stats_parts(N, li.D, li.H, li.W, 2, u.cin);
+            parts = upconv_b16_stats_parts(N, li.D, li.H, li.W, sd, u.cin);
             { ProfB pr(plan, s, (int)k, 0); RUN(launch_upconv_b16_fwd(a, s)); }
         } else if (u.cin < 8) {
-            parts = conv_small_b16_stats_parts(N, li.D, li.H, li.W);
+            parts = conv_small_b16_stats_parts(N, li.D, li.H, li.W, pl);
             ProfB pr(plan, s, (int)k, 0);
-            RUN(launch_conv_small_b16_fwd(cur, u.cin, P(u.p_w), training ? P(u.p_b) : nullptr, dst, dst_ldc, N, li.D, li.H, li.W, u.cout, 0, es, eh,
+            RUN(launch_conv_small_b16_fwd(cur, u.cin, P(u.p_w), training ? P(u.p_b) : nullptr, dst, dst_ldc, N, li.D, li.H, li.W, u.cout, pl, es, eh,
                                           training ? B.stats : nullptr, s));
         } else {
             ConvB16Args a{};
             a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = b.wpk_f; a.bias = training ? P(u.p_b) : nullptr;
             a.x2 = cur2; a.x_split = cur2 ? u.cin / 2 : 0;
-            a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Cout = u.cout; a.planar = 0;
+            a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Cout = u.cout; a.planar = pl;
             a.epi_scale = es; a.epi_shift = eh; a.stats = training ? B.stats : nullptr; a.partial = B.skws;
-            parts = conv_b16_stats_parts(N, li.D, li.H, li.W, u.cin, u.cout, 0);
+            parts = conv_b16_stats_parts(N, li.D, li.H, li.W, u.cin, u.cout, pl);
             { ProfB pr(plan, s, (int)k, 0); RUN(launch_conv_b16(a, s)); }
         }
         if (training) {
@@ -236,10 +238,10 @@ int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N,
             f.mean = b.mean; f.invstd = b.invstd; f.scale = b.scale; f.shift = b.shift; f.scratch = B.bnred;
             RUN(launch_bn_finalize(f, s));
             if (k + 1 < nu)
-                RUN(launch_bn_relu_apply_b16(b.raw, u.cout, b.scale, b.shift, b.act, b.act_ldc, pool_after ? B.pooled[u.level] : nullptr, 2,
+                RUN(launch_bn_relu_apply_b16(b.raw, u.cout, b.scale, b.shift, b.act, b.act_ldc, pool_after ? B.pooled[u.level] : nullptr, sd,
                                              N, lo.D, lo.H, lo.W, u.cout, s));
         } else if (pool_after) {
-            RUN(launch_maxpool_b16(b.act, b.act_ldc, B.pooled[u.level], 2, N, lo.D, lo.H, lo.W, u.cout, s));
+            RUN(launch_maxpool_b16(b.act, b.act_ldc, B.pooled[u.level], sd, N, lo.D, lo.H, lo.W, u.cout, s));
         }
         cur2 = nullptr;
         if (pool_after) { cur = B.pooled[u.level]; cur_ldc = u.cout; }
@@ -291,7 +293,7 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
         std::vector<PackB16Job> jobs;
         for (int k = 1; k < nunits; ++k) {
             const ConvUnit& u = plan->units[k];
-            if (B.ub[k].wpk_d) jobs.push_back({P(u.p_w), B.ub[k].wpk_d, u.cout, u.cin, u.is_up ? 8 : 27, u.is_up ? 3 : 1});
+            if (B.ub[k].wpk_d) jobs.push_back({P(u.p_w), B.ub[k].wpk_d, u.cout, u.cin, u.is_up ? (u.planar ? 4 : 8) : (u.planar ? 9 : 27), u.is_up ? 3 : 1});
         }
         RUN(launch_pack_multi_b16(jobs.data(), (int)jobs.size(), s));
     }
@@ -308,6 +310,7 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
         const bool is_down = u.is_down;
         const bool is_enc_conv2 = u.enc_last;
         const bool pooled_unit = is_enc_conv2 && j < nb - 1;
+        const int pl = u.planar, sd = pl ? 1 : 2, taps = pl ? 9 : 27;
         if (!event_done && is_down && is_enc_conv2 && j == bucket_after_down_block - 1) {
             if (!bias_jobs.empty()) { RUN(launch_colsum_multi(bias_jobs.data(), (int)bias_jobs.size(), s)); bias_jobs.clear(); }
             if (!wred.empty()) { RUN(launch_wgrad_reduce_multi(wred.data(), (int)wred.size(), s)); wred.clear(); }
@@ -321,7 +324,7 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
             if (k == nunits - 1) { a.g1 = nullptr; a.head_dy = dy; a.head_w = P(plan->p_final_w); a.head_cout = cfg.out_channels; a.head_S = ND.Y.vox / N; }
             else if (pooled_unit) { a.g1 = B.dcatB[j]; a.g1_ldc = u.cout; a.gpool = g; a.pooled = B.pooled[j]; }
             else { a.g1 = g; a.g1_ldc = g_ldc; }
-            a.kd = 2; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.C = u.cout;
+            a.kd = sd; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.C = u.cout;
             a.parts = bn_bwd_b16_parts(lo.vox, u.cout); a.part = b.bnpart; a.coef = B.small; a.dx = dxr; a.dx_ldc = u.cout;
             RUN(launch_bn_bwd_b16_reduce(a, s));
             RUN(launch_bn_bwd_finalize(a.part, a.parts, u.cout, (float)(1.0 / (double)lo.vox), G(u.p_g), G(u.p_be), B.small, s));
@@ -343,27 +346,27 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
         if (u.is_up) {
             const int splits = upconv_b16_wgrad_splits(N, li.D, li.H, li.W);
             { ProfB pr(plan, s, k, 2);
-              RUN(launch_upconv_b16_wgrad(xin, xin_ldc, u.cin, dxr, u.cout, u.cout, b.slab, N, li.D, li.H, li.W, lo.D, lo.H, lo.W, 2, splits, s)); }
-            wred.push_back({b.slab, G(u.p_w), splits, 8, u.cin, u.cout, u.cin, u.cout});
+              RUN(launch_upconv_b16_wgrad(xin, xin_ldc, u.cin, dxr, u.cout, u.cout, b.slab, N, li.D, li.H, li.W, lo.D, lo.H, lo.W, sd, splits, s)); }
+            wred.push_back({b.slab, G(u.p_w), splits, sd * 4, u.cin, u.cout, u.cin, u.cout});
         } else if (u.cin < 8) {
-            const int splits = conv_small_b16_wgrad_splits(N, li.D, li.H, li.W);
-            { ProfB pr(plan, s, k, 2); RUN(launch_conv_small_b16_wgrad(xin, u.cin, dxr, u.cout, B.slab, N, li.D, li.H, li.W, u.cout, 0, s)); }
-            RUN(launch_wgrad_reduce(B.slab, G(u.p_w), splits, 27, u.cout, u.cin, u.cout, u.cin, s));
+            const int splits = conv_small_b16_wgrad_splits(N, li.D, li.H, li.W, pl);
+            { ProfB pr(plan, s, k, 2); RUN(launch_conv_small_b16_wgrad(xin, u.cin, dxr, u.cout, B.slab, N, li.D, li.H, li.W, u.cout, pl, s)); }
+            RUN(launch_wgrad_reduce(B.slab, G(u.p_w), splits, taps, u.cout, u.cin, u.cout, u.cin, s));
         } else {
             WgradB16Args a{};
             a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dxr; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = b.slab;
             a.x2 = xin2; a.x_split = xin2 ? u.cin / 2 : 0;
-            a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.planar = 0;
-            a.splits = wgrad_b16_splits(N, li.D, li.H, li.W, u.cin, u.cout, 0);
+            a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.planar = pl;
+            a.splits = wgrad_b16_splits(N, li.D, li.H, li.W, u.cin, u.cout, pl);
             { ProfB pr(plan, s, k, 2); RUN(launch_wgrad_b16(a, s)); }
-            wred.push_back({b.slab, G(u.p_w), a.splits, 27, u.cout, u.cin, u.cout, u.cin});
+            wred.push_back({b.slab, G(u.p_w), a.splits, taps, u.cout, u.cin, u.cout, u.cin});
         }
         // ---- data gradient -> g of the previous unit
         if (k == 0) break;
         if (u.is_up) {
             UpconvB16Args a{};
             a.x = B.g1[j + 1]; a.x_ldc = u.cin; a.Cin = u.cin; a.y = dxr; a.y_ldc = u.cout; a.Cout = u.cout; a.wt = b.wpk_d;
-            a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = 2;
+            a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = sd;
             { ProfB pr(plan, s, k, 1); RUN(launch_upconv_b16_dgrad(a, s)); }
             g = B.g1[j + 1]; g_ldc = u.cin;
         } else {
@@ -372,7 +375,7 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
             ConvB16Args a{};
             a.x = dxr; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = b.wpk_d; a.bias = nullptr; a.y = out; a.y_ldc = to_cat ? u.cin / 2 : u.cin;
             if (to_cat) { a.y2 = B.dcatB[j]; a.y_split = u.cin / 2; }
-            a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Cout = u.cin; a.planar = 0; a.partial = B.skws;
+            a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Cout = u.cin; a.planar = pl; a.partial = B.skws;
             { ProfB pr(plan, s, k, 1); RUN(launch_conv_b16(a, s)); }
             g = out; g_ldc = to_cat ? u.cin / 2 : u.cin;      // concat: the next unit (upconv) reads the first half
         }

@@ -280,7 +280,7 @@ int e3_swa_swap(void* stream, int n_tensors, void* const* params, void* const* s
  *   x: [N,in,D,H,W] bf16 NCDHW; params / grads: the SAME fp32 tables as e3_unet_forward / e3_unet_backward (conv weights are
  *   rounded to bf16 while they are packed); y / dy: fp32 NCDHW logits (values representable in bf16) and their gradient.
  *   dx must be NULL (no input gradient on this path).  e3_unet_bf16_supported(): 1 when the plan's configuration is covered
- *   (dim 3, no planar blocks, 'batch' norm with full_norm, ReLU, 'transpose', 'concat', 'same', in_channels < 8,
+ *   (any planar blocks incl. dim 2, 'batch' norm with full_norm, ReLU, 'transpose', 'concat', 'same', in_channels < 8,
  *   start_filts % 32 == 0, out_channels <= 8); other configurations compute in fp32 on up-cast copies.
  * ---------------------------------------------------------------------------------------------------------- */
 int e3_unet_bf16_supported(const e3_unet_plan* plan);

@@ -236,3 +236,47 @@ def test_unet_f16_against_reference_fixture():
     for k, v in m.state_dict().items():
         if 'running' in k:
             torch.testing.assert_close(v.float().cpu(), g['sd1_f16/' + k], rtol=4e-3, atol=4e-3 * float(g['sd1_f16/' + k].abs().max()), msg=lambda s: f'{k}: {s}')
+
+
+@pytest.mark.parametrize('lowp', [torch.float16, torch.bfloat16], ids=['f16', 'bf16'])
+@pytest.mark.parametrize('kw,shape', [(dict(n_blocks=3, planar_blocks=(0,)), (2, 1, 6, 24, 40)),
+                                      (dict(n_blocks=3, planar_blocks=(0, 1)), (1, 1, 5, 33, 47)),
+                                      (dict(n_blocks=4, planar_blocks=(0,)), (2, 1, 16, 64, 64)),        # the example script's network (train_unet_neurodata.py:96-106)
+                                      (dict(n_blocks=3, planar_blocks=(1,)), (1, 1, 8, 20, 28)),
+                                      (dict(n_blocks=3, dim=2), (2, 1, 44, 60))],
+                         ids=['planar0', 'planar01_odd', 'example_net', 'planar1', 'dim2'])
+def test_16bit_path_with_planar_blocks_tracks_the_fp32_path(lowp, kw, shape):
+    """Planar blocks (1x3x3 convs, (1,2,2) pooling and up-convolution, unet.py:114-128) and dim=2 on the native 16-bit path -- the reference's
+    example network has planar_blocks=(0,), so Trainer(mixed_precision=True) on it is this path.  Train step against the fp32 HIP path on the
+    same 16-bit-valued parameters and input, O(1) incoming gradient."""
+    from elektronn3_amd import _lib
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(17)
+    m32 = UNet(1, 2, start_filts=32, **kw)
+    with torch.no_grad():
+        for p in m32.parameters():
+            p.copy_(p.to(lowp).float())
+    m16 = UNet(1, 2, start_filts=32, **kw)
+    m16.load_state_dict(m32.state_dict())
+    m32, m16 = m32.to(DEV), m16.to(DEV).to(lowp)
+    lib = _lib.load()
+    assert (lib.e3_unet_f16_supported if lowp == torch.float16 else lib.e3_unet_bf16_supported)(m16._plan().handle) == 1
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(*shape, generator=g).to(lowp)
+    dl = torch.randn(shape[0], 2, *shape[2:], generator=g).to(lowp)
+    y32, g32 = _train_step(m32, x.float().to(DEV), dl.float().to(DEV))
+    y16, g16 = _train_step(m16, x.to(DEV), dl.to(DEV))
+    tol, gtol = (2e-2, 0.35) if lowp == torch.float16 else (1e-1, 0.7)
+    scale = float(y32.abs().max())
+    assert float((y16 - y32).abs().max()) < tol * scale, (float((y16 - y32).abs().max()), scale)
+    gscale = max(float(v.norm()) for v in g32.values())
+    for k, v in g32.items():
+        assert torch.isfinite(g16[k]).all(), k
+        if k.endswith('.bias') and 'norm' not in k and not k.startswith('conv_final'):
+            continue
+        rel = float((g16[k] - v).norm() / max(float(v.norm()), 1e-3 * gscale))
+        assert rel < gtol, f'gradient {k}: rel-L2 {rel}'
+    m32.eval(); m16.eval()
+    with torch.no_grad():
+        ye32, ye16 = m32(x.float().to(DEV)).cpu(), m16(x.to(DEV)).float().cpu()
+    assert float((ye16 - ye32).abs().max()) < tol * float(ye32.abs().max())
