@@ -58,7 +58,7 @@ __device__ unsigned long long* g_timing = nullptr;       // phase timestamps (to
 // register file: 64 accumulators + weight ring + fragments need > 128 registers) and a workgroup's staging meets two others' MFMA / store
 // phases (same bricks, same halo traffic, twice the barriers)
 template <int BD, int CO_T, int KD, int TW, int CH = 32>
-__global__ __launch_bounds__(256, (CH == 16 || BD == 2) ? 3 : 2) void conv_b16_kernel(const ConvB16Args a, int tilesD, int tilesH, int tilesW, int cgroups, int ksplit) {
+__global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_kernel(const ConvB16Args a, int tilesD, int tilesH, int tilesW, int cgroups, int ksplit) {
     using G = Geo<BD, KD, TW, CH>;
     constexpr int RB = G::RB, PPV = G::PPV, KS = G::KS;
     constexpr int HH = G::HH, HW = G::HW;
@@ -421,6 +421,7 @@ Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout) {
     const int bh = d.tw == 32 ? 4 : 8;
     const long b4 = (long)N * cdiv(D, 4) * cdiv(H, bh) * cdiv(W, d.tw);
     d.bd = (forced == 2 || forced == 4) ? forced : (b4 >= 512 ? 4 : 2);
+    if (D == 1) d.bd = 1;          // a depth-1 volume (dim = 2 networks): one-slice bricks, nothing of the tile is padding
     d.bricks = (long)N * cdiv(D, d.bd) * cdiv(H, bh) * cdiv(W, d.tw);
     // two output tiles per workgroup halve the staging per FLOP but cost a workgroup per CU (256 registers) and, on small grids, force a
     // split-K pass: measured on cfg 2, they pay at level 1 (512 bricks: 69 vs 71, 118 vs 120 us) but neither at level 2 (128 bricks: one tile
@@ -503,6 +504,11 @@ int launch_conv_b16(ConvB16Args a, hipStream_t s) {
     // 150 -> 133, 247 -> 227, 154 -> 138 us on the level-0 forward convs of cfg 2, 5.89 -> 5.76 ms per step (E3_B16_CH32=1 restores 32-channel images)
     static const bool ch16 = getenv("E3_B16_CH32") == nullptr;
     if (ch16 && d.bd == 4 && !a.planar && d.tw == 32 && d.ksplit == 1 && !two) rc = launch_t<4, 1, 3, 32, 16>(a, d.ksplit, s);
+    else if (d.bd == 1) {
+        E3_REQUIRE(a.planar, E3_ERR_INVALID, "bf16 conv: a depth-1 volume needs the planar (1x3x3) form");
+        rc = d.tw == 32 ? (two ? launch_t<1, 2, 1, 32>(a, d.ksplit, s) : launch_t<1, 1, 1, 32>(a, d.ksplit, s))
+                        : (two ? launch_t<1, 2, 1, 16>(a, d.ksplit, s) : launch_t<1, 1, 1, 16>(a, d.ksplit, s));
+    }
     else if (a.planar) rc = d.tw == 32 ? E3_B16_LAUNCH(1, 32) : E3_B16_LAUNCH(1, 16);
     else rc = d.tw == 32 ? E3_B16_LAUNCH(3, 32) : E3_B16_LAUNCH(3, 16);
 #undef E3_B16_LAUNCH

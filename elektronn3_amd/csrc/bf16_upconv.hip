@@ -225,10 +225,10 @@ __global__ __launch_bounds__(256) void upconv_b16_kernel(const UpconvB16Args a, 
 // low-resolution grid, each staged by LDS-DMA (whole 128-byte row segments, double-buffered: the next tile's loads are in flight
 // during the current tile's MFMAs and stores) and read back as conflict-free ds_read_b128 fragments (16-byte pieces of a row
 // XOR-swizzled by bits 1..3 of the row).  8 accumulator tiles per wave (one per tap); stores leave through the transposition tile.
-template <int CH>      // 64-channel chunks of K
+template <int CH, int SD>      // 64-channel chunks of K; depth stride (1: planar block / 2D network, taps (kh, kw) only)
 __global__ __launch_bounds__(256, 2) void upconv_fwd_b16_kernel(const UpconvB16Args a, size_t nvox, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int T = 8;
+    constexpr int T = 4 * SD;
     constexpr int WB = T * CH * 4 * 1024;                 // weights [tap][chunk][k-step][1 KB]
     constexpr int XB = CH * 128 * 128;                    // one X buffer [chunk][128 rows][128 B]
     unsigned char* xs = smem + WB;
@@ -278,11 +278,11 @@ __global__ __launch_bounds__(256, 2) void upconv_fwd_b16_kernel(const UpconvB16A
         const bool vin = v < nvox;
         size_t r = vin ? v : 0;
         const int w = r % a.W; r /= a.W; const int h = r % a.H; r /= a.H; const int d = r % a.D; const int n = (int)(r / a.D);
-        const unsigned obase = (unsigned)(((((size_t)n * a.Do + 2 * d) * a.Ho + 2 * h) * a.Wo + 2 * w) * a.y_ldc);
+        const unsigned obase = (unsigned)(((((size_t)n * a.Do + SD * d) * a.Ho + 2 * h) * a.Wo + 2 * w) * a.y_ldc);
         unsigned okm = 0;
 #pragma unroll
         for (int tap = 0; tap < T; ++tap)
-            if (vin && 2 * d + (tap >> 2) < a.Do && 2 * h + ((tap >> 1) & 1) < a.Ho && 2 * w + (tap & 1) < a.Wo) okm |= 1u << tap;
+            if (vin && SD * d + (tap >> 2) < a.Do && 2 * h + ((tap >> 1) & 1) < a.Ho && 2 * w + (tap & 1) < a.Wo) okm |= 1u << tap;
         f32x16 acc[T];
 #pragma unroll
         for (int tap = 0; tap < T; ++tap)
@@ -365,9 +365,10 @@ __global__ __launch_bounds__(256, 2) void upconv_fwd_b16_kernel(const UpconvB16A
 // persistent workgroups, the whole weight matrix (64 x 256 bf16 = 32 KB) in LDS, 64-voxel tiles of the LOW-resolution grid whose
 // 8 x 64 gathered dY rows (64 B each) are staged by LDS-DMA (a lane always fetches the same voxel, one tap per instruction),
 // double-buffered.  Wave (vt, rt) owns voxel tile vt and ci tile rt: 16 MFMAs per tile; 16-byte stores through the transposition tile.
+template <int SD>
 __global__ __launch_bounds__(256, 1) void upconv_dgrad_b16_kernel(const UpconvB16Args a, size_t nvox, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int T = 8, WB = 2 * 16 * 1024, YB = T * 64 * 64;        // weights [rt][ks][1 KB]; one dY buffer [tap][64 voxels][64 B]
+    constexpr int T = 4 * SD, WB = 2 * 2 * T * 1024, YB = T * 64 * 64;        // weights [rt][ks][1 KB]; one dY buffer [tap][64 voxels][64 B]
     unsigned char* ys = smem + WB;
     unsigned char* xp = smem + WB + 2 * YB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_b16_kernel(const UpconvB1
     const int vt = wave & 1, rt = wave >> 1;
     const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wt), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0x7fffffff, 0x00020000);
-    for (int p = wave; p < 32; p += 4) dma16(w_rs, (lds_ptr_t)(smem + p * 1024), 16, (unsigned)(p * 1024 + lane * 16), 0, 0, 0);
+    for (int p = wave; p < 4 * T; p += 4) dma16(w_rs, (lds_ptr_t)(smem + p * 1024), 16, (unsigned)(p * 1024 + lane * 16), 0, 0, 0);
     // staging: instruction k of a wave = tap k of the 16 voxels [16 wave, 16 wave + 16), lane = (voxel, 16-byte piece)
     const int sv = 16 * wave + (lane >> 2), sp = (lane & 3) ^ ((sv >> 2) & 3);
     auto stage = [&](int tile, int buf) {
@@ -384,17 +385,17 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_b16_kernel(const UpconvB1
         const bool vin = v < nvox;
         size_t r = vin ? v : 0;
         const int w = r % a.W; r /= a.W; const int h = r % a.H; r /= a.H; const int d = r % a.D; const int n = (int)(r / a.D);
-        const unsigned ob = (unsigned)((((((size_t)n * a.Do + 2 * d) * a.Ho + 2 * h) * a.Wo + 2 * w) * a.y_ldc) * 2 + sp * 16);
+        const unsigned ob = (unsigned)((((((size_t)n * a.Do + SD * d) * a.Ho + 2 * h) * a.Wo + 2 * w) * a.y_ldc) * 2 + sp * 16);
 #pragma unroll
         for (int tap = 0; tap < T; ++tap) {
-            const bool ok = vin && 2 * d + (tap >> 2) < a.Do && 2 * h + ((tap >> 1) & 1) < a.Ho && 2 * w + (tap & 1) < a.Wo;
+            const bool ok = vin && SD * d + (tap >> 2) < a.Do && 2 * h + ((tap >> 1) & 1) < a.Ho && 2 * w + (tap & 1) < a.Wo;
             const unsigned toff = (unsigned)(((((tap >> 2) * a.Ho + ((tap >> 1) & 1)) * a.Wo + (tap & 1)) * a.y_ldc) * 2);
             dma16(y_rs, (lds_ptr_t)(ys + buf * YB + (tap * 64 + 16 * wave) * 64), 16, ok ? ob + toff : OOB, 0, 0, 0);
         }
     };
     const int row = vt * 32 + j;
     const unsigned yrd = (unsigned)(row * 64), ysw = (unsigned)((row >> 2) & 3);
-    const unsigned wrd = (unsigned)(rt * 16 * 1024 + g * 512 + j * 16);
+    const unsigned wrd = (unsigned)(rt * 2 * T * 1024 + g * 512 + j * 16);
     int it = 0;
     if ((int)blockIdx.x < ntiles) stage(blockIdx.x, 0);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void upconv_dgrad_b16_kernel(const UpconvB1
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {           // k = (tap = ks / 2, 16 channels of dY)
+        for (int ks = 0; ks < 2 * T; ++ks) {        // k = (tap = ks / 2, 16 channels of dY)
             const bf16x8 b = *reinterpret_cast<const bf16x8*>(ys + buf * YB + (ks >> 1) * 4096 + yrd + (((2 * (ks & 1) + g) ^ ysw) << 4));
             const bf16x8 af = *reinterpret_cast<const bf16x8*>(smem + ks * 1024 + wrd);
             acc = E3_MFMA16(af, b, acc, 0, 0, 0);
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(256, 3) void upconv_wgrad_b16_kernel(const bf16_t* 
 constexpr int UP_NVT = 1;     // 32-voxel tiles per wave (generic kernel)
 static bool upconv_fwd_persistent(int Cin, int sd) {
     static const bool off = getenv("E3_B16_UP_GENERIC") != nullptr;      // A/B switch
-    return !off && sd == 2 && (Cin == 64 || Cin == 128);
+    return !off && (Cin == 64 || Cin == 128);
 }
 int upconv_b16_stats_parts(int N, int D, int H, int W, int sd, int Cin) {      // one record per workgroup
     const int tiles = (int)(((size_t)N * D * H * W + 128 * UP_NVT - 1) / (128 * UP_NVT));
@@ -558,17 +559,20 @@ int launch_upconv_b16_fwd(UpconvB16Args a, hipStream_t s) {
     if (upconv_fwd_persistent(a.Cin, a.sd)) {
         const int tiles = (int)((nvox + 127) / 128);
         const int gx = tiles < 512 ? tiles : 512;
-        const int CH = a.Cin / 64;
-        const int lds = 8 * CH * 4 * 1024 + 2 * CH * 16384 + 4 * 32 * 80 + 4 * 2 * 33 * 4;
-        if (CH == 1) {
-            static bool done = false;
-            if (!done) { (void)hipFuncSetAttribute((const void*)upconv_fwd_b16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
-            hipLaunchKernelGGL(upconv_fwd_b16_kernel<1>, dim3(gx, a.Cout / 32), dim3(256), lds, s, a, nvox, tiles);
-        } else {
-            static bool done = false;
-            if (!done) { (void)hipFuncSetAttribute((const void*)upconv_fwd_b16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
-            hipLaunchKernelGGL(upconv_fwd_b16_kernel<2>, dim3(gx, a.Cout / 32), dim3(256), lds, s, a, nvox, tiles);
+        const int CH = a.Cin / 64, T = 4 * a.sd;
+        const int lds = T * CH * 4 * 1024 + 2 * CH * 16384 + 4 * 32 * 80 + 4 * 2 * 33 * 4;
+        static bool done = false;
+        if (!done) {
+            const auto cap = hipFuncAttributeMaxDynamicSharedMemorySize;
+            (void)hipFuncSetAttribute((const void*)upconv_fwd_b16_kernel<1, 1>, cap, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)upconv_fwd_b16_kernel<1, 2>, cap, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)upconv_fwd_b16_kernel<2, 1>, cap, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)upconv_fwd_b16_kernel<2, 2>, cap, 160 * 1024);
+            done = true;
         }
+        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(gx, a.Cout / 32), dim3(256), lds, s, a, nvox, tiles); };
+        if (CH == 1) { if (a.sd == 2) go(upconv_fwd_b16_kernel<1, 2>); else go(upconv_fwd_b16_kernel<1, 1>); }
+        else         { if (a.sd == 2) go(upconv_fwd_b16_kernel<2, 2>); else go(upconv_fwd_b16_kernel<2, 1>); }
         E3_CHECK_HIP(hipGetLastError());
         return E3_OK;
     }
@@ -583,13 +587,19 @@ int launch_upconv_b16_dgrad(UpconvB16Args a, hipStream_t s) {
     const size_t nvox = (size_t)a.N * a.D * a.H * a.W;
     E3_REQUIRE((size_t)a.N * a.Do * a.Ho * a.Wo * a.y_ldc < (1ull << 32) && nvox * a.x_ldc < (1ull << 32), E3_ERR_UNSUPPORTED, "bf16 transposed conv: tensor too large for 32-bit element offsets");
     static const bool generic = getenv("E3_B16_UP_GENERIC") != nullptr;
-    if (!generic && a.sd == 2 && a.Cin == 64 && a.Cout == 32 && (size_t)a.N * a.Do * a.Ho * a.Wo * a.y_ldc < (1ull << 30)) {
+    if (!generic && a.Cin == 64 && a.Cout == 32 && (size_t)a.N * a.Do * a.Ho * a.Wo * a.y_ldc < (1ull << 30)) {
         const int tiles = (int)((nvox + 63) / 64);
         const int gx = tiles < 256 ? tiles : 256;
-        constexpr int lds = 2 * 16 * 1024 + 2 * 8 * 64 * 64 + 4 * 32 * 80;
+        const int T = 4 * a.sd;
+        const int lds = 4 * T * 1024 + 2 * T * 64 * 64 + 4 * 32 * 80;
         static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute((const void*)upconv_dgrad_b16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
-        hipLaunchKernelGGL(upconv_dgrad_b16_kernel, dim3(gx), dim3(256), lds, s, a, nvox, tiles);
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)upconv_dgrad_b16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)upconv_dgrad_b16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done = true;
+        }
+        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, s, a, nvox, tiles); };
+        if (a.sd == 2) go(upconv_dgrad_b16_kernel<2>); else go(upconv_dgrad_b16_kernel<1>);
         E3_CHECK_HIP(hipGetLastError());
         return E3_OK;
     }
