@@ -12,7 +12,7 @@ size_t e3_conv3d_workspace_bytes_bf16(int Cin, int Cout, int N, int D, int H, in
     const size_t pack = align_up(conv_b16_packed_elems(Cin, Cout, planar) * 2, 256);
     const size_t slab = Cin % 32 == 0 && Cout % 32 == 0 ? (size_t)wgrad_b16_splits(N, D, H, W, Cin, Cout, planar) * T * Cin * Cout * 4 : 0;
     // forward / dgrad: packed weights, then (low-resolution shapes) the split-K partial sums of either direction
-    const size_t pf = conv_b16_partial_floats(N, D, H, W, Cin, Cout), pd = conv_b16_partial_floats(N, D, H, W, Cout, Cin);
+    const size_t pf = conv_b16_partial_floats(N, D, H, W, Cin, Cout, planar), pd = conv_b16_partial_floats(N, D, H, W, Cout, Cin, planar);
     const size_t fwd = pack + align_up((pf > pd ? pf : pd) * 4, 256);
     return fwd > slab ? fwd : align_up(slab, 256);
 }

@@ -53,7 +53,7 @@ struct ConvB16Args {
     bf16_t* y2; int y_split;
 };
 int conv_b16_stats_parts(int N, int D, int H, int W, int Cin, int Cout, int planar);
-size_t conv_b16_partial_floats(int N, int D, int H, int W, int Cin, int Cout);
+size_t conv_b16_partial_floats(int N, int D, int H, int W, int Cin, int Cout, int planar);
 size_t conv_b16_packed_elems(int Cin, int Cout, int planar);
 // torch (Cout, Cin, T) fp32 weights -> packed bf16; dgrad = 1: the data-gradient form (taps flipped, roles of Cin / Cout swapped)
 int launch_pack_conv_b16(const float* w, bf16_t* out, int Cout, int Cin, int planar, int dgrad, hipStream_t s);

@@ -33,9 +33,14 @@ constexpr unsigned OOB = 0x80000000u;
 template <int BD, int KD, int TW, int CH = 32>
 struct Geo {
     static constexpr int RPT = 32 / TW;                   // h-rows per tile
-    static constexpr int BH = 4 * RPT, BW = TW;
+    // 3x3x3: a brick is BD slices x 4 row groups (wave = slice).  1x3x3 (planar block, dim = 2 network): the BD x 4 tiles all lie in ONE slice
+    // (wave = BD consecutive row groups) -- no depth halo to pay for, so the brick grows in h instead: 18 x 34 halo voxels for 16 x 32 outputs (1.2x)
+    // where BD slices of 6 x 34 cost 1.6x, and a depth-1 volume fills its tiles
+    static constexpr bool FLAT = KD == 1;
+    static constexpr int DZ = FLAT ? 1 : BD;              // brick depth
+    static constexpr int BH = 4 * RPT * (FLAT ? BD : 1), BW = TW;
     static constexpr int HH = BH + 2, HW = BW + 2;
-    static constexpr int HD = BD + (KD == 3 ? 2 : 0);
+    static constexpr int HD = FLAT ? 1 : BD + 2;
     static constexpr int HV = HD * HH * HW;              // halo voxels
     static constexpr int RB = CH * 2;                    // bytes of a voxel's row in the LDS image (CH channels per chunk: 32, or 16 = one k-step)
     static constexpr int PPV = RB / 16;                  // 16-byte pieces per voxel
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_k
     } else {
         tw = L % tilesW; L /= tilesW; th = L % tilesH; L /= tilesH; td = L % tilesD; n = L / tilesD;
     }
-    const int d0 = td * BD, h0 = th * G::BH, w0 = tw * G::BW;
+    const int d0 = td * G::DZ, h0 = th * G::BH, w0 = tw * G::BW;
     const int co0 = cg * 32 * CO_T;
     constexpr int PD = KD == 3 ? 1 : 0;
     const int nch = a.Cin / CH;
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_k
 
     // ---- lane read addresses (tap kd = kh = 0, tile 0 of the wave): 3 kw x 2 k-steps
     const int r = TW == 16 ? j >> 4 : 0, c = TW == 16 ? j & 15 : j;
-    const int T0 = wave * G::NV, dT0 = T0 >> 2, hp0 = T0 & 3;
+    const int T0 = wave * G::NV, dT0 = G::FLAT ? 0 : T0 >> 2, hp0 = G::FLAT ? T0 : T0 & 3;
     unsigned rd[3][KS];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_k
     // ---- statistics: S[wave][quantity][channel][33] floats in the (now free) image, column sums, (n, mean, M2) record per brick
     float* S = reinterpret_cast<float*>(smem);
     float* R = S + 4 * 2 * 32 * 33;                    // [2][4][32]
-    const int nd = a.D - d0 < BD ? a.D - d0 : BD, nh = a.H - h0 < G::BH ? a.H - h0 : G::BH, nw = a.W - w0 < G::BW ? a.W - w0 : G::BW;
+    const int nd = a.D - d0 < G::DZ ? a.D - d0 : G::DZ, nh = a.H - h0 < G::BH ? a.H - h0 : G::BH, nw = a.W - w0 < G::BW ? a.W - w0 : G::BW;
     const float cnt = (float)(nd * nh * nw);
 #pragma unroll
     for (int ct = 0; ct < CO_T; ++ct) {
@@ -396,7 +401,7 @@ __global__ void pack_multi_b16_kernel(const PackMultiArgs a) {
 template <int BD, int CO_T, int KD, int TW, int CH = 32>
 int launch_t(const ConvB16Args& a, int ksplit, hipStream_t s) {
     using G = Geo<BD, KD, TW, CH>;
-    const int tD = cdiv(a.D, BD), tH = cdiv(a.H, G::BH), tW = cdiv(a.W, G::BW);
+    const int tD = cdiv(a.D, G::DZ), tH = cdiv(a.H, G::BH), tW = cdiv(a.W, G::BW);
     const int cgroups = a.Cout / (32 * CO_T);
     const size_t grid = (size_t)a.N * tD * tH * tW * cgroups * ksplit;
     const int lds = G::IMG > 4 * 2 * 32 * 33 * 4 + 1024 ? G::IMG : 4 * 2 * 32 * 33 * 4 + 1024;
@@ -411,7 +416,7 @@ int launch_t(const ConvB16Args& a, int ksplit, hipStream_t s) {
 // instead of 2.8x -- where they still fill the chip), output-channel tiles per workgroup, and for the low-resolution levels (a few
 // dozen bricks for 256 CUs) a split of the input channels over several workgroups (fp32 partial sums, splitk_reduce_b16_kernel).
 struct Decomp { int bd, co_t, ksplit, tw; long bricks; };
-Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout) {
+Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout, int planar) {
     static const int forced = getenv("E3_B16_BD") ? atoi(getenv("E3_B16_BD")) : 0;
     static const bool no_split = getenv("E3_B16_NO_SPLITK") != nullptr;
     static const int forced_tw = getenv("E3_B16_TW") ? atoi(getenv("E3_B16_TW")) : 0;
@@ -419,10 +424,10 @@ Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout) {
     // 1 x 32-voxel tiles (conflict-free LDS reads) where the rows are long enough to fill them, 2 x 16 otherwise
     d.tw = (forced_tw == 16 || forced_tw == 32) ? forced_tw : (W % 32 == 0 || W >= 96 ? 32 : 16);
     const int bh = d.tw == 32 ? 4 : 8;
-    const long b4 = (long)N * cdiv(D, 4) * cdiv(H, bh) * cdiv(W, d.tw);
-    d.bd = (forced == 2 || forced == 4) ? forced : (b4 >= 512 ? 4 : 2);
-    if (D == 1) d.bd = 1;          // a depth-1 volume (dim = 2 networks): one-slice bricks, nothing of the tile is padding
-    d.bricks = (long)N * cdiv(D, d.bd) * cdiv(H, bh) * cdiv(W, d.tw);
+    // (planar: the brick is one slice deep and bd row groups high, Geo::FLAT)
+    auto bricks = [&](int bd) { return planar ? (long)N * D * cdiv(H, bh * bd) * cdiv(W, d.tw) : (long)N * cdiv(D, bd) * cdiv(H, bh) * cdiv(W, d.tw); };
+    d.bd = (forced == 2 || forced == 4) ? forced : (bricks(4) >= 512 ? 4 : 2);
+    d.bricks = bricks(d.bd);
     // two output tiles per workgroup halve the staging per FLOP but cost a workgroup per CU (256 registers) and, on small grids, force a
     // split-K pass: measured on cfg 2, they pay at level 1 (512 bricks: 69 vs 71, 118 vs 120 us) but neither at level 2 (128 bricks: one tile
     // fills the chip without split-K, 54 -> 39, 77 -> 67 us) nor at level 0 (4096 bricks: the three-workgroup 16-channel form wins, 264 -> 249 us)
@@ -448,13 +453,12 @@ extern "C" int e3_debug_conv_timing(void* buf) { return hipMemcpyToSymbol(HIP_SY
 #endif
 
 int conv_b16_stats_parts(int N, int D, int H, int W, int Cin, int Cout, int planar) {
-    (void)planar;
-    const Decomp d = conv_b16_decomp(N, D, H, W, Cin, Cout);
+    const Decomp d = conv_b16_decomp(N, D, H, W, Cin, Cout, planar);
     return d.ksplit > 1 ? reduce_blocks((size_t)N * D * H * W, Cout) : (int)d.bricks;
 }
 
-size_t conv_b16_partial_floats(int N, int D, int H, int W, int Cin, int Cout) {
-    const Decomp d = conv_b16_decomp(N, D, H, W, Cin, Cout);
+size_t conv_b16_partial_floats(int N, int D, int H, int W, int Cin, int Cout, int planar) {
+    const Decomp d = conv_b16_decomp(N, D, H, W, Cin, Cout, planar);
     return d.ksplit > 1 ? (size_t)d.ksplit * N * D * H * W * Cout : 0;
 }
 
@@ -493,7 +497,7 @@ int launch_conv_b16(ConvB16Args a, hipStream_t s) {
     E3_REQUIRE((!a.x2 || (a.x_split % 32 == 0 && a.x_split > 0 && a.x_split < a.Cin)) && (!a.y2 || (a.y_split % 32 == 0 && a.y_split > 0 && a.y_split < a.Cout)),
                E3_ERR_INVALID, "bf16 conv: a two-tensor operand splits at a multiple of 32 channels");
     E3_REQUIRE((size_t)a.D * a.H * a.W * a.x_ldc < (1ull << 30), E3_ERR_UNSUPPORTED, "bf16 conv: sample larger than 2 GB");
-    const Decomp d = conv_b16_decomp(a.N, a.D, a.H, a.W, a.Cin, a.Cout);
+    const Decomp d = conv_b16_decomp(a.N, a.D, a.H, a.W, a.Cin, a.Cout, a.planar);
     E3_REQUIRE(d.ksplit == 1 || a.partial, E3_ERR_INVALID, "bf16 conv: this shape needs the split-K scratch (conv_b16_partial_floats)");
     const bool two = d.co_t == 2;
     int rc;
@@ -503,12 +507,7 @@ int launch_conv_b16(ConvB16Args a, hipStream_t s) {
     // 16-channel LDS images, three workgroups per CU, where the shape allows (BD = 4, 3x3x3, 32-voxel rows, one 32-channel output tile, no split-K):
     // 150 -> 133, 247 -> 227, 154 -> 138 us on the level-0 forward convs of cfg 2, 5.89 -> 5.76 ms per step (E3_B16_CH32=1 restores 32-channel images)
     static const bool ch16 = getenv("E3_B16_CH32") == nullptr;
-    if (ch16 && d.bd == 4 && !a.planar && d.tw == 32 && d.ksplit == 1 && !two) rc = launch_t<4, 1, 3, 32, 16>(a, d.ksplit, s);
-    else if (d.bd == 1) {
-        E3_REQUIRE(a.planar, E3_ERR_INVALID, "bf16 conv: a depth-1 volume needs the planar (1x3x3) form");
-        rc = d.tw == 32 ? (two ? launch_t<1, 2, 1, 32>(a, d.ksplit, s) : launch_t<1, 1, 1, 32>(a, d.ksplit, s))
-                        : (two ? launch_t<1, 2, 1, 16>(a, d.ksplit, s) : launch_t<1, 1, 1, 16>(a, d.ksplit, s));
-    }
+    if (ch16 && d.bd == 4 && d.tw == 32 && d.ksplit == 1 && !two) rc = a.planar ? launch_t<4, 1, 1, 32, 16>(a, d.ksplit, s) : launch_t<4, 1, 3, 32, 16>(a, d.ksplit, s);
     else if (a.planar) rc = d.tw == 32 ? E3_B16_LAUNCH(1, 32) : E3_B16_LAUNCH(1, 16);
     else rc = d.tw == 32 ? E3_B16_LAUNCH(3, 32) : E3_B16_LAUNCH(3, 16);
 #undef E3_B16_LAUNCH

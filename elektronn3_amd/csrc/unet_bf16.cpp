@@ -88,8 +88,8 @@ void plan_b16(const e3_unet_plan* p, int N, int D, int H, int W, bool training, 
         } else {
             wmax = max(wmax, conv_b16_packed_elems(u.cin, u.cout, pl));
             statmax = max(statmax, (size_t)conv_b16_stats_parts(N, li.D, li.H, li.W, u.cin, u.cout, pl) * u.cout * 3);
-            skmax = max(skmax, conv_b16_partial_floats(N, li.D, li.H, li.W, u.cin, u.cout));
-            if (training) skmax = max(skmax, conv_b16_partial_floats(N, li.D, li.H, li.W, u.cout, u.cin));
+            skmax = max(skmax, conv_b16_partial_floats(N, li.D, li.H, li.W, u.cin, u.cout, pl));
+            if (training) skmax = max(skmax, conv_b16_partial_floats(N, li.D, li.H, li.W, u.cout, u.cin, pl));
             own = (size_t)wgrad_b16_splits(N, li.D, li.H, li.W, u.cin, u.cout, pl) * taps * u.cin * u.cout;
         }
         if (u.is_up || u.cin >= 8) {          // packed bf16 weights: forward form, data-gradient form (all packed by one launch per pass)
