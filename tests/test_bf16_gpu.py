@@ -54,17 +54,34 @@ CONV_CASES = [
 ]
 
 
+PLANAR_CONV_CASES = [
+    (1, 1, 8, 16, 32, 32),          # a depth-1 volume (dim = 2 networks)
+    (2, 3, 19, 37, 64, 32),         # ragged one-slice bricks, 2x16 tiles
+    (1, 1, 70, 100, 32, 64),        # 1x32 tiles, ragged rows and brick rows
+    (2, 16, 128, 64, 32, 32),       # >= 512 bricks of 16 x 32: the 4-row-group bricks in 16-channel LDS images
+    (1, 2, 13, 21, 128, 64),        # few bricks: split-K
+    (1, 1, 640, 96, 32, 32),        # 2D benchmark rows
+]
+
+
+@pytest.mark.parametrize('N,D,H,W,Cin,Cout', PLANAR_CONV_CASES)
+def test_conv3d_bf16_planar_forward_dgrad_wgrad_vs_fp64(N, D, H, W, Cin, Cout):
+    """1x3x3 convs (planar blocks, unet.py:114-128; dim = 2 networks): one-slice bricks (Geo::FLAT)."""
+    test_conv3d_bf16_forward_dgrad_wgrad_vs_fp64(N, D, H, W, Cin, Cout, planar=True)
+
+
 @pytest.mark.parametrize('N,D,H,W,Cin,Cout', CONV_CASES)
-def test_conv3d_bf16_forward_dgrad_wgrad_vs_fp64(N, D, H, W, Cin, Cout):
+def test_conv3d_bf16_forward_dgrad_wgrad_vs_fp64(N, D, H, W, Cin, Cout, planar=False):
     from elektronn3_amd import ops
     x = _bfvals(N, Cin, D, H, W, seed=1)
-    w = _bfvals(Cout, Cin, 3, 3, 3, seed=2, scale=0.05)
+    w = _bfvals(Cout, Cin, 1 if planar else 3, 3, 3, seed=2, scale=0.05)
+    pad = (0, 1, 1) if planar else 1
     b = torch.randn(Cout, generator=torch.Generator().manual_seed(3))
     dy = _bfvals(N, Cout, D, H, W, seed=4)
     xd, wd, dyd = x.to(DEV), w.to(DEV), dy.to(DEV)
     # forward with bias + statistics
-    y, stats = ops.conv3d_bf16(_ndhwc(xd), wd.float(), b.to(DEV), want_stats=True)
-    ref = torch.nn.functional.conv3d(x.double(), w.double(), b.double(), padding=1)
+    y, stats = ops.conv3d_bf16(_ndhwc(xd), wd.float(), b.to(DEV), planar=planar, want_stats=True)
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), b.double(), padding=pad)
     _close_bf16(_ncdhw(y), ref, 'conv forward')
     # statistics of the stored (rounded) values: merge the records like bn_finalize does
     st = stats.double().cpu()
@@ -77,17 +94,17 @@ def test_conv3d_bf16_forward_dgrad_wgrad_vs_fp64(N, D, H, W, Cin, Cout):
     # folded eval epilogue: relu(acc * scale + shift)
     sc = torch.rand(Cout, generator=torch.Generator().manual_seed(5)) + 0.5
     sh = torch.randn(Cout, generator=torch.Generator().manual_seed(6))
-    ye = ops.conv3d_bf16(_ndhwc(xd), wd.float(), None, epi=(sc.to(DEV), sh.to(DEV)))
-    acc = torch.nn.functional.conv3d(x.double(), w.double(), None, padding=1)
+    ye = ops.conv3d_bf16(_ndhwc(xd), wd.float(), None, planar=planar, epi=(sc.to(DEV), sh.to(DEV)))
+    acc = torch.nn.functional.conv3d(x.double(), w.double(), None, padding=pad)
     refe = torch.relu(acc * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1))
     _close_bf16(_ncdhw(ye), refe, 'conv eval epilogue', atol=2e-2 * 2.0 ** -8 * float(acc.abs().max()) + 1e-6)
     # data gradient
-    dx = ops.conv3d_dgrad_bf16(_ndhwc(dyd), wd.float())
-    refdx = torch.nn.grad.conv3d_input(x.shape, w.double(), dy.double(), padding=1)
+    dx = ops.conv3d_dgrad_bf16(_ndhwc(dyd), wd.float(), planar=planar)
+    refdx = torch.nn.grad.conv3d_input(x.shape, w.double(), dy.double(), padding=pad)
     _close_bf16(_ncdhw(dx), refdx, 'conv dgrad')
     # weight gradient (fp32 result)
-    dw = ops.conv3d_wgrad_bf16(_ndhwc(xd), _ndhwc(dyd))
-    refdw = torch.nn.grad.conv3d_weight(x.double(), w.shape, dy.double(), padding=1)
+    dw = ops.conv3d_wgrad_bf16(_ndhwc(xd), _ndhwc(dyd), planar=planar)
+    refdw = torch.nn.grad.conv3d_weight(x.double(), w.shape, dy.double(), padding=pad)
     rel = float((dw.double().cpu() - refdw).norm() / refdw.norm())
     assert rel < 2e-6, f'conv wgrad rel-L2 {rel}'
 

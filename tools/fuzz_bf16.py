@@ -26,13 +26,17 @@ for case in range(n_cases):
     nb = ri(2, 4); sf = 32 * ri(1, 2); inc = ri(1, 3); outc = ri(2, 4)
     mult = 2 ** (nb - 1)
     D = ri(1, 4) * mult + (ri(0, 3) if ri(0, 1) else 0); H = ri(1, 6) * mult + ri(0, 5); W = ri(1, 12) * mult + ri(0, 7); N = ri(1, 3)
+    dim = 2 if ri(0, 4) == 0 else 3
+    planar = () if dim == 2 or ri(0, 1) else tuple(i for i in range(nb) if ri(0, 1))      # (planar blocks: 1x3x3 convs, (1,2,2) pooling / up-convolution)
+    if dim == 2: H, W = H * ri(1, 6), W * ri(1, 3)
     torch.manual_seed(case)
-    m32 = UNet(inc, outc, n_blocks=nb, start_filts=sf).to(dev)
+    m32 = UNet(inc, outc, n_blocks=nb, start_filts=sf, planar_blocks=planar, dim=dim).to(dev)
     with torch.no_grad():
         for p in m32.parameters():
             p.copy_(bf(p).float())
     m16 = copy.deepcopy(m32).to(torch.bfloat16)
-    x = bf(torch.randn(N, inc, D, H, W, generator=g)); dl = bf(torch.randn(N, outc, D, H, W, generator=g) * 1e-3)
+    sp = (H, W) if dim == 2 else (D, H, W)
+    x = bf(torch.randn(N, inc, *sp, generator=g)); dl = bf(torch.randn(N, outc, *sp, generator=g) * 1e-3)
     res = {}
     for tag, m, xx, dd in (('f32', m32, x.float(), dl.float()), ('bf16', m16, x, dl)):
         m.train(); m.zero_grad(set_to_none=True)
@@ -57,7 +61,7 @@ for case in range(n_cases):
         if rel > worst: worst, wk = rel, k
     ok = p999 < 4e-2 * scale and float(err.max()) < 1e-1 * scale and worst < 0.9 and eerr < 1e-1 * escale and bool(torch.isfinite(y16).all())
     bad += not ok
-    print(f'{"ok " if ok else "BAD"} nb={nb} sf={sf} in={inc} out={outc} x=({N},{D},{H},{W}): logits p99.9 {p999 / scale:.2e} max {float(err.max()) / scale:.2e} of scale; '
+    print(f'{"ok " if ok else "BAD"} nb={nb} sf={sf} in={inc} out={outc} planar={planar} x={(N,) + sp}: logits p99.9 {p999 / scale:.2e} max {float(err.max()) / scale:.2e} of scale; '
           f'eval max {eerr / escale:.2e}; worst gradient {worst:.3f} ({wk})', flush=True)
 if dump:
     torch.save(saved, dump)
