@@ -75,7 +75,7 @@ size_t conv_packed_floats(ConvKind kind, int K, int ncols);
 int launch_pack_conv_auto(ConvKind kind, int dgrad, const float* w, float* out, int Cout, int Cin, int N, int D, int H, int W, int flags, hipStream_t s);
 // transposed conv (POINT + SCATTER_UP / GATHER_UP) as a plain LDS-tiled GEMM (upconv_gemm.hip); Cx = channels per voxel of x
 bool upconv_gemm_ok(int flags, int Cx, int Cout, int ncols);
-int upconv_stats_parts(int N, int D, int H, int W, int sd);
+int upconv_stats_parts(int N, int D, int H, int W, int sd, int Cx, int Cout);
 int launch_upconv_gemm(ConvArgs a, hipStream_t s);
 struct WgradArgs;
 bool upconv_wgrad_ok(int Cin, int Cout, int sd);                         // weight gradient of the transposed conv, all taps per workgroup

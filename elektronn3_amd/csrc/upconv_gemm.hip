@@ -13,6 +13,7 @@
 //   * epilogue: bias / folded eval-BN + ReLU, per-(brick, tap) Welford statistics for the train-mode BN that follows,
 //     rows transposed through a per-wave LDS tile so that every lane stores 16 B of whole 128-B voxel rows.
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -217,6 +218,158 @@ int launch_up(ConvArgs a, hipStream_t s) {
     return E3_OK;
 }
 
+
+// ---- forward, the full-resolution shape (Cin = 64: 67 MB in, 268 MB out at L1 -> L0 of a start_filts = 32 network; 140 us = 0.30 of the HBM
+// roof with the tiled kernel above, whose two-chunk K loop is all prologue and epilogue).  Persistent workgroups of EIGHT waves, one per CU: the
+// weights of a 32-channel output tile (T taps x 32 co x 64 ci = 64 KB) are staged into LDS ONCE, then the workgroup walks 128-voxel tiles of the
+// flattened low-resolution grid, each staged by LDS-DMA (256-byte rows, 16-byte pieces XOR-swizzled by row & 15 on the SOURCE side: conflict-free
+// ds_read_b128 fragments); waves 0..3 and 4..7 take half of the taps each for the same 4 x 32 voxels (two waves per SIMD cover each other's LDS and
+// store latencies); the next tile's DMA is issued after the MFMAs and lands during the epilogue, which is 2/3 of a tile's time.
+// Measured (up_convs.2.upconv of cfg 2): 143 -> 105 us.  Tried and dropped: four waves with all taps and a double-buffered X tile (156 us: one wave per
+// SIMD exposes every LDS / shuffle / store latency); the two halves one phase apart, MFMAs of one over the epilogue of the other (109 us: the
+// epilogue's fp32 VALU work waits for issue slots behind the other wave's MFMAs -- fp32 MFMA and VALU share the FMA lanes).
+// A = X (rows = voxels), B = W (columns = co): a lane holds one channel of 16 voxels, so the Welford statistics are per-lane sums (two-pass over
+// the 16 registers, merged across taps and tiles per lane) and the results leave through a per-wave transposition tile as whole 128-byte rows.
+typedef __attribute__((address_space(3))) void* lds_ptr_p;
+constexpr unsigned P_OOB = 0x80000000u;
+__device__ __forceinline__ void pdma16(__amdgpu_buffer_rsrc_t rs, lds_ptr_p dst, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, voff, 0, 0, 0);
+}
+
+template <int SD>
+__global__ __launch_bounds__(512, 1) void upconv_fwd_persist_kernel(const ConvArgs a, unsigned nvox, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pmem[];
+    constexpr int T = 4 * SD, TW = T / 2;          // taps; taps per wave (waves 0..3: the first half, 4..7: the second, of the same 4 x 32 voxels)
+    constexpr int WB = T * 32 * 256;               // weights: rows (tap, co) of 64 floats
+    constexpr int XB = 128 * 256;                  // the X tile: 128 voxels x 64 floats
+    constexpr int TP = 40;                         // transposition tile pitch in floats (the two lane halves hit disjoint banks)
+    unsigned char* xs = pmem + WB;
+    float* tiles = reinterpret_cast<float*>(pmem + WB + XB);           // [8 waves][32][TP]
+    float* S = tiles + 8 * 32 * TP;                                    // [8][32][3]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int vw = wave & 3, t0 = (wave >> 2) * TW;
+    const int j = lane & 31, g = lane >> 5;
+    const int cb = blockIdx.y * 32;
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wt), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
+    for (int i = wave; i < T * 8; i += 8) {        // one wave-instruction = 1 KB = 4 rows
+        const int R = i * 4 + (lane >> 4), slot = lane & 15;
+        const int tap = R >> 5, jj = R & 31;
+        pdma16(w_rs, (lds_ptr_p)(pmem + i * 1024), (unsigned)((((tap * a.Cout + cb + jj) * 64) + ((slot ^ (R & 15)) << 2)) * 4));
+    }
+    auto stage = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (i * 8 + wave) * 4 + (lane >> 4), slot = lane & 15;
+            const unsigned v = (unsigned)tile * 128u + row;
+            pdma16(x_rs, (lds_ptr_p)(xs + (i * 8 + wave) * 1024), v < nvox ? (v * (unsigned)a.x_ldc + ((slot ^ (row & 15)) << 2)) * 4u : P_OOB);
+        }
+    };
+    const int row = vw * 32 + j;
+    const unsigned xrd = (unsigned)(row * 256), wrd = (unsigned)(j * 256), sw = (unsigned)(j & 15);     // (row & 15 == j & 15)
+    const float bias = a.bias ? a.bias[cb + j] : 0.f;
+    const bool aff = a.epi_scale != nullptr;
+    const float es = aff ? a.epi_scale[cb + j] : 1.f, eh = aff ? a.epi_shift[cb + j] : 0.f;
+    float rc = 0.f, rm = 0.f, r2 = 0.f;            // running (count, mean, M2) of this lane's channel over its voxels and taps
+    float* tl = tiles + wave * 32 * TP;
+    const int c4 = 4 * (lane & 7);
+
+    if ((int)blockIdx.x < ntiles) stage(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x16 acc[TW];
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            const unsigned pc = ((2 * s4 + g) ^ sw) << 4;
+            const f32x4 av = *reinterpret_cast<const f32x4*>(xs + xrd + pc);
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(pmem + (t0 + t) * 8192 + wrd + pc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                        // every wave is done with the X tile:
+        if (tile + (int)gridDim.x < ntiles) stage(tile + gridDim.x);       // the next one is in flight during the epilogue
+        // this lane's own voxel (row j of the wave's 32): output base and per-tap validity (autocrop, unet.py:289-299)
+        const unsigned v = (unsigned)tile * 128u + row;
+        const bool vin = v < nvox;
+        unsigned r = vin ? v : 0u;
+        const int w = r % a.W; r /= a.W; const int h = r % a.H; r /= a.H; const int d = r % a.D; const int n = (int)(r / a.D);
+        const unsigned obase = (unsigned)(((((size_t)n * a.Do + SD * d) * a.Ho + 2 * h) * a.Wo + 2 * w) * a.y_ldc);
+        unsigned okm = 0;
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap)
+            if (vin && SD * d + (tap >> 2) < a.Do && 2 * h + ((tap >> 1) & 1) < a.Ho && 2 * w + (tap & 1) < a.Wo) okm |= 1u << tap;
+        const bool allok = __builtin_amdgcn_ballot_w64(okm == (1u << T) - 1u) == ~0ull;       // wave-uniform: the whole tile is stored
+        unsigned obp[4], omp[4];                   // rows this lane stores in the transposed pass: 8 p + (lane >> 3)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { obp[p] = (unsigned)__shfl((int)obase, 8 * p + (lane >> 3)); omp[p] = (unsigned)__shfl((int)okm, 8 * p + (lane >> 3)); }
+        auto epilogue = [&](auto all_ok) {
+            constexpr bool ALL = decltype(all_ok)::value;
+            unsigned okr[16];                      // validity of this lane's 16 voxels (rows (e & 3) + 8 (e >> 2) + 4 g): T bits each
+            if constexpr (!ALL) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) okr[e] = (unsigned)__shfl((int)okm, (e & 3) + 8 * (e >> 2) + 4 * g);
+            }
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                const int tap = t0 + t;
+                float cnt = ALL ? 16.f : 0.f, sum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float val = acc[t][e] + bias;
+                    if (aff) val = fmaxf(__builtin_fmaf(val, es, eh), 0.f);
+                    acc[t][e] = val;
+                    tl[((e & 3) + 8 * (e >> 2) + 4 * g) * TP + j] = val;
+                    if constexpr (ALL) sum += val;
+                    else { const bool ok = ((okr[e] >> tap) & 1u) != 0; cnt += ok ? 1.f : 0.f; sum += ok ? val : 0.f; }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const unsigned toff = (unsigned)((((tap >> 2) * a.Ho + ((tap >> 1) & 1)) * a.Wo + (tap & 1)) * a.y_ldc);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(tl + (8 * p + (lane >> 3)) * TP + c4);
+                    if (ALL || ((omp[p] >> tap) & 1u)) *reinterpret_cast<f32x4*>(a.y + obp[p] + toff + cb + c4) = o;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (a.stats) {
+                    const float mean = cnt > 0.f ? sum / cnt : 0.f;
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float dv = acc[t][e] - mean;
+                        if constexpr (ALL) m2 = __builtin_fmaf(dv, dv, m2);
+                        else m2 += ((okr[e] >> tap) & 1u) ? dv * dv : 0.f;
+                    }
+                    welford_merge(rc, rm, r2, cnt, mean, m2);
+                }
+            }
+        };
+        if (allok) epilogue(std::true_type{}); else epilogue(std::false_type{});
+    }
+    if (!a.stats) return;
+    {
+        const float c2 = __shfl_xor(rc, 32), m2_ = __shfl_xor(rm, 32), q2 = __shfl_xor(r2, 32);
+        welford_merge(rc, rm, r2, c2, m2_, q2);
+    }
+    if (g == 0) { float* sc = S + (wave * 32 + j) * 3; sc[0] = rc; sc[1] = rm; sc[2] = r2; }
+    __syncthreads();
+    if (tid < 32) {
+        float cnt = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) { const float* sc = S + (wv * 32 + tid) * 3; welford_merge(cnt, mean, m2, sc[0], sc[1], sc[2]); }
+        float* o = a.stats + ((size_t)blockIdx.x * a.Cout + cb + tid) * 3;
+        o[0] = cnt; o[1] = mean; o[2] = m2;
+    }
+}
+
 }  // namespace
 
 // Eligibility of the GEMM kernel for a POINT launch (everything else keeps the generic kernel): 32-channel granularity
@@ -229,12 +382,39 @@ bool upconv_gemm_ok(int flags, int Cx, int Cout, int ncols) {
     return true;
 }
 
-int upconv_stats_parts(int N, int D, int H, int W, int sd) { return N * D * cdiv(H, U_TH) * cdiv(W, 16) * sd * 4; }
+// the persistent forward above: Cin = 64, 32-channel output tiles, no prologue (E3_UPCONV_NO_PERSIST=1: A/B switch)
+bool upconv_fwd_persist_ok(int flags, int Cx, int Cout) {
+    static const bool enabled = getenv("E3_UPCONV_NO_PERSIST") == nullptr;
+    return enabled && (flags & CF_SCATTER_UP) && Cx == 64 && (Cout & 31) == 0;
+}
+static int persist_wgs(size_t nvox) { const size_t t = (nvox + 127) / 128; return (int)(t < 256 ? t : 256); }
+
+int upconv_stats_parts(int N, int D, int H, int W, int sd, int Cx, int Cout) {
+    if (upconv_fwd_persist_ok(CF_SCATTER_UP, Cx, Cout)) return persist_wgs((size_t)N * D * H * W);      // one record per workgroup
+    return N * D * cdiv(H, U_TH) * cdiv(W, 16) * sd * 4;
+}
 
 int launch_upconv_gemm(ConvArgs a, hipStream_t s) {
     E3_REQUIRE((a.x_ldc & 3) == 0 && (a.y_ldc & 3) == 0 && ((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.y & 15) == 0, E3_ERR_INVALID,
                "upconv views must be 16-byte aligned");
     const bool gather = (a.flags & CF_GATHER_UP) != 0;
+    const size_t nvox = (size_t)a.N * a.D * a.H * a.W;
+    if (!gather && !a.pro_scale && upconv_fwd_persist_ok(a.flags, a.Cin, a.Cout) && nvox * (size_t)a.x_ldc < (1ull << 29) &&
+        (size_t)a.N * a.Do * a.Ho * a.Wo * a.y_ldc < (1ull << 32)) {
+        const int tiles = (int)((nvox + 127) / 128), T = 4 * a.sd;
+        const int lds = T * 32 * 256 + 128 * 256 + 8 * 32 * 40 * 4 + 8 * 32 * 3 * 4;
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)upconv_fwd_persist_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)upconv_fwd_persist_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done = true;
+        }
+        const dim3 grid((unsigned)persist_wgs(nvox), (unsigned)(a.Cout / 32));
+        if (a.sd == 2) hipLaunchKernelGGL(upconv_fwd_persist_kernel<2>, grid, dim3(512), lds, s, a, (unsigned)nvox, tiles);
+        else hipLaunchKernelGGL(upconv_fwd_persist_kernel<1>, grid, dim3(512), lds, s, a, (unsigned)nvox, tiles);
+        E3_CHECK_HIP(hipGetLastError());
+        return E3_OK;
+    }
     const bool nt4 = (a.NPad % 128) == 0;
     if (gather) return nt4 ? launch_up<true, 4>(a, s) : launch_up<true, 2>(a, s);
     return nt4 ? launch_up<false, 4>(a, s) : launch_up<false, 2>(a, s);
