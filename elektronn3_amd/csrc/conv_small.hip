@@ -5,6 +5,7 @@
 #include "kernels.h"
 
 namespace {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------ first conv, forward
 // brick = 256 voxels (2x8x16, planar 1x16x16); thread = (channel quad q = tid%8, voxel group g = tid/8) and
@@ -12,7 +13,8 @@ namespace {
 // current input channel are held in registers.
 template <int KD, int TD, int TH>
 __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const ConvSmallArgs a, int tilesD, int tilesH, int tilesW) {
-    constexpr int TW = 16, PD = KD / 2, LD = TD + 2 * PD, LH = TH + 2, LW = TW + 2, NV = LD * LH * LW, T = KD * 9;
+    // (LW = 20: rows of 18 halo voxels padded to 80 bytes, so that a thread's run of 8 voxels + halo is three aligned ds_read_b128)
+    constexpr int TW = 16, PD = KD / 2, LD = TD + 2 * PD, LH = TH + 2, LW = TW + 4, NV = LD * LH * LW, T = KD * 9;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                       // [Cin][NV]
     float* ws = smem + ((a.Cin * NV + 3) & ~3);   // [Cin][T][32]  (current pass)
@@ -22,53 +24,82 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const ConvSmallArgs
     const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * TW;
     const int mtile = blockIdx.x;           // any bijection works for the stats records
 
-    for (int idx = tid; idx < a.Cin * NV; idx += 256) {
-        const int ci = idx / NV, v = idx % NV;
-        const int zw = v % LW, zh = (v / LW) % LH, zd = v / (LW * LH);
-        const int gd = d0 + zd - PD, gh = h0 + zh - 1, gw = w0 + zw - 1;
-        float val = 0.f;
-        if (gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
-            val = a.x[((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.Cin + ci];
-        xs[ci * NV + v] = val;
+    // (four loads in flight per thread, then the LDS writes: one exposed memory round trip per 1024 halo values instead of four)
+    for (int i0 = 0; i0 < a.Cin * NV; i0 += 1024) {
+        float val[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = i0 + u * 256 + tid;
+            const int ci = idx / NV, v = idx % NV;
+            const int zw = v % LW, zh = (v / LW) % LH, zd = v / (LW * LH);
+            const int gd = d0 + zd - PD, gh = h0 + zh - 1, gw = w0 + zw - 1;
+            val[u] = 0.f;
+            if (idx < a.Cin * NV && zw < TW + 2 && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
+                val[u] = a.x[((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.Cin + ci];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int idx = i0 + u * 256 + tid; if (idx < a.Cin * NV) xs[idx] = val[u]; }
     }
 
-    int vbase[8]; bool vok[8]; size_t voff[8];
+    // thread = channel quad q x a run of 8 consecutive voxels along w: run g = (row g >> 1 of the brick's TD x TH rows, half g & 1)
+    bool vok[8]; size_t voff[8];
+    const int rrow = g >> 1, ww0 = 8 * (g & 1), rhh = rrow % TH, rdd = rrow / TH;
+    const int rbase = (rdd * LH + rhh) * LW + ww0;             // halo voxel (kd = kh = kw = 0) of the run's first output: a multiple of 4 floats
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int v = g + 32 * i;
-        const int ww = v & 15, hh = (v >> 4) % TH, dd = (v >> 4) / TH;
-        vbase[i] = (dd * LH + hh) * LW + ww;
-        const int gd = d0 + dd, gh = h0 + hh, gw = w0 + ww;
+        const int gd = d0 + rdd, gh = h0 + rhh, gw = w0 + ww0 + i;
         vok[i] = gd < a.D && gh < a.H && gw < a.W;
         voff[i] = ((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.y_ldc;
     }
 
     for (int pass = 0; pass * 32 < a.Cout; ++pass) {
         __syncthreads();
-        for (int idx = tid; idx < a.Cin * T * 32; idx += 256) {
-            const int c = idx & 31, t = (idx >> 5) % T, ci = (idx >> 5) / T;
-            const int co = pass * 32 + c;
-            ws[idx] = co < a.Cout ? a.w[((size_t)co * a.Cin + ci) * T + t] : 0.f;
+        for (int i0 = 0; i0 < a.Cin * T * 32; i0 += 1024) {
+            float wv4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * 256 + tid;
+                const int c = idx & 31, t = (idx >> 5) % T, ci = (idx >> 5) / T;
+                const int co = pass * 32 + c;
+                wv4[u] = (idx < a.Cin * T * 32 && co < a.Cout) ? a.w[((size_t)co * a.Cin + ci) * T + t] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int idx = i0 + u * 256 + tid; if (idx < a.Cin * T * 32) ws[idx] = wv4[u]; }
         }
         __syncthreads();
-        f32x4 acc[8];
+        // the 8 x 4 accumulators as pairs: hipcc packs the <2 x float> fma into v_pk_fma_f32 (two FMAs per lane and issue slot: the scalar form of
+        // this loop was FMA-issue bound, 1.8 G v_fma_f32 at 4 cycles per wave); a (kd, kh) row of the run = 10 halo values = three ds_read_b128
+        // instead of 24 ds_read_b32
+        f32x2 alo[8], ahi[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 8; ++i) { alo[i] = f32x2{0.f, 0.f}; ahi[i] = f32x2{0.f, 0.f}; }
         for (int ci = 0; ci < a.Cin; ++ci) {
             f32x4 wr[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) wr[t] = *reinterpret_cast<const f32x4*>(ws + (ci * T + t) * 32 + 4 * q);
-            const float* xc = xs + ci * NV;
+            const float* xc = xs + ci * NV + rbase;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int r9 = 0; r9 < KD * 3; ++r9) {
+                const int kd = r9 / 3, kh = r9 % 3;
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xc + (kd * LH + kh) * LW), x1 = *reinterpret_cast<const f32x4*>(xc + (kd * LH + kh) * LW + 4),
+                            x2 = *reinterpret_cast<const f32x4*>(xc + (kd * LH + kh) * LW + 8);
+                const float xr[12] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x2[0], x2[1], x2[2], x2[3]};
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
-                    const float xv = xc[vbase[i] + (kd * LH + kh) * LW + kw];
+                for (int kw = 0; kw < 3; ++kw) {
+                    const f32x4 wv = wr[r9 * 3 + kw];
+                    const f32x2 wlo = {wv[0], wv[1]}, whi = {wv[2], wv[3]};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][e] = __builtin_fmaf(xv, wr[t][e], acc[i][e]);
+                    for (int i = 0; i < 8; ++i) {
+                        const f32x2 xv = {xr[i + kw], xr[i + kw]};
+                        alo[i] = __builtin_elementwise_fma(xv, wlo, alo[i]);
+                        ahi[i] = __builtin_elementwise_fma(xv, whi, ahi[i]);
+                    }
                 }
+            }
         }
+        f32x4 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = f32x4{alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]};
         const int co0 = pass * 32 + 4 * q;
         const bool cok = co0 < a.Cout;
         f32x4 bias = {0.f, 0.f, 0.f, 0.f}, es = {1.f, 1.f, 1.f, 1.f}, eh = bias;
@@ -91,24 +122,25 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const ConvSmallArgs
             }
         }
         if (a.stats) {
+            // two passes over the registers at WAVE level: (count, sum) of a channel over the 8 lanes x 8 voxels that hold it (lanes with equal q:
+            // lane bits 3,4,5), the wave's mean, then the squared deviations from it -- plain adds through the butterflies (Welford merges with their
+            // divisions at every level were as long as the convolution loop)
             f32x4 mean, m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int off = 8; off <= 32; off <<= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cnt[e] += __shfl_xor(cnt[e], off); sum[e] += __shfl_xor(sum[e], off); }
 #pragma unroll
             for (int e = 0; e < 4; ++e) mean[e] = cnt[e] > 0.f ? sum[e] / cnt[e] : 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 if (vok[i] && cok)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float d = acc[i][e] - mean[e]; m2[e] += d * d; }
-            // lanes with equal q (lane bits 3,4,5) hold the same channels
+                    for (int e = 0; e < 4; ++e) { const float d = acc[i][e] - mean[e]; m2[e] = __builtin_fmaf(d, d, m2[e]); }
 #pragma unroll
             for (int off = 8; off <= 32; off <<= 1)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float c1 = cnt[e], mn1 = mean[e], s1 = m2[e];
-                    const float c2 = __shfl_xor(c1, off), mn2 = __shfl_xor(mn1, off), s2 = __shfl_xor(s1, off);
-                    welford_merge(c1, mn1, s1, c2, mn2, s2);
-                    cnt[e] = c1; mean[e] = mn1; m2[e] = s1;
-                }
+                for (int e = 0; e < 4; ++e) m2[e] += __shfl_xor(m2[e], off);
             __syncthreads();   // ws is free now: reuse as scratch [wave][32][3]
             const int wave = tid >> 6, lane = tid & 63;
             if (lane < 8)
@@ -472,7 +504,7 @@ int launch_conv_small_fwd(ConvSmallArgs a, hipStream_t s) {
     int TD, TH; small_brick(a.planar, TD, TH);
     const int tD = cdiv(a.D, TD), tH = cdiv(a.H, TH), tW = cdiv(a.W, 16);
     const int KD = a.planar ? 1 : 3;
-    const int NV = (TD + (a.planar ? 0 : 2)) * (TH + 2) * 18;
+    const int NV = (TD + (a.planar ? 0 : 2)) * (TH + 2) * 20;
     // the weight slab is reused as the statistics scratch [4 waves][32][3]: planar convs with one input channel have only
     // 288 floats of weights (this under-allocation corrupted the BN statistics of a planar first conv with > 16 channels)
     const int wslab = a.Cin * KD * 9 * 32 > 4 * 32 * 3 ? a.Cin * KD * 9 * 32 : 4 * 32 * 3;
