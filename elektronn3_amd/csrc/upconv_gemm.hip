@@ -415,7 +415,10 @@ int launch_upconv_gemm(ConvArgs a, hipStream_t s) {
         E3_CHECK_HIP(hipGetLastError());
         return E3_OK;
     }
-    const bool nt4 = (a.NPad % 128) == 0;
+    // four column tiles per workgroup unless that leaves most of the chip idle (the data gradient of the lowest level: 32 bricks x 2 column groups)
+    const size_t mt = (size_t)a.N * a.D * cdiv(a.H, U_TH) * cdiv(a.W, 16);
+    const bool nt4 = (a.NPad % 128) == 0 && mt * (a.NPad / 128) >= 192;
+    if (gather && !nt4 && mt * (a.NPad / 64) < 192 && a.NPad % 32 == 0) return launch_up<true, 1>(a, s);
     if (gather) return nt4 ? launch_up<true, 4>(a, s) : launch_up<true, 2>(a, s);
     return nt4 ? launch_up<false, 4>(a, s) : launch_up<false, 2>(a, s);
 }
