@@ -603,7 +603,10 @@ int launch_upconv_b16_dgrad(UpconvB16Args a, hipStream_t s) {
         E3_CHECK_HIP(hipGetLastError());
         return E3_OK;
     }
-    hipLaunchKernelGGL((upconv_b16_kernel<true, 4, UP_NVT>), dim3((unsigned)((nvox + 128 * UP_NVT - 1) / (128 * UP_NVT)), cdiv(a.Cin / 32, 4)), dim3(256), 0, s, a, nvox);
+    const unsigned gx = (unsigned)((nvox + 128 * UP_NVT - 1) / (128 * UP_NVT));
+    // one ci tile per workgroup where four would leave most of the chip idle (lowest level of cfg 2: 32 voxel tiles x 2 -> x 8 workgroups)
+    if ((size_t)gx * cdiv(a.Cin / 32, 4) < 192) hipLaunchKernelGGL((upconv_b16_kernel<true, 1, UP_NVT>), dim3(gx, a.Cin / 32), dim3(256), 0, s, a, nvox);
+    else hipLaunchKernelGGL((upconv_b16_kernel<true, 4, UP_NVT>), dim3(gx, cdiv(a.Cin / 32, 4)), dim3(256), 0, s, a, nvox);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
