@@ -326,13 +326,13 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
     const size_t total = (size_t)N * S;
     const int sub = threadIdx.x % lpv;
     const size_t vpb = blockDim.x / lpv;
-    const size_t gstride = (size_t)gridDim.x * vpb;
-    const size_t vend = (total + vpb - 1) / vpb * vpb;
-    // U voxels per thread and iteration, their loads issued together (a single 16-byte load per lane and voxel leaves the memory system with
-    // too little in flight: 81 -> 5x us on the 268 MB head of cfg 2); `a` is streamed once: non-temporal.  Same summation order per voxel.
+    // U voxels per thread and iteration, their loads issued together; a workgroup's U x vpb voxels of an iteration are one contiguous run.
+    // `a` is streamed once: non-temporal.  Same summation order per voxel.
     constexpr int U = 4;
     const bool one = Q <= lpv;          // at most one channel quad per lane (the usual head: C = 32, eight lanes per voxel)
-    for (size_t v0 = blockIdx.x * vpb + threadIdx.x / lpv; v0 < vend; v0 += (one ? U : 1) * gstride) {
+    const size_t ustride = one ? vpb : 0, chunk = one ? vpb * U : vpb;
+    const size_t vend = (total + chunk - 1) / chunk * chunk;
+    for (size_t v0 = blockIdx.x * chunk + threadIdx.x / lpv; v0 < vend; v0 += gridDim.x * chunk) {
         float acc[U][COUT];
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -342,7 +342,7 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
             f32x4 av[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const size_t v = v0 + u * gstride;
+                const size_t v = v0 + u * ustride;
                 av[u] = (v < total && sub < Q) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * sub)) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (sub < Q) {
@@ -350,7 +350,7 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
                 if (pro_scale) { sc = *reinterpret_cast<const f32x4*>(pro_scale + 4 * sub); sh = *reinterpret_cast<const f32x4*>(pro_shift + 4 * sub); }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const size_t v = v0 + u * gstride;
+                    const size_t v = v0 + u * ustride;
                     if (v >= total) continue;
                     if (pro_scale) {
 #pragma unroll
@@ -383,7 +383,7 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (u > 0 && !one) break;
-            const size_t v = v0 + u * gstride;
+            const size_t v = v0 + u * ustride;
             for (int off = 1; off < lpv; off <<= 1)
 #pragma unroll
                 for (int co = 0; co < COUT; ++co) acc[u][co] += __shfl_xor(acc[u][co], off);
