@@ -214,7 +214,9 @@ def test_conv3_reads_and_writes_concat_views(ops, orc):
 CONVT_CASES = [(32, 16, (3, 5, 9), 2, 2, None), (64, 32, (2, 8, 17), 1, 1, None), (16, 8, (3, 4, 5), 2, 1, (5, 8, 9)),
                (128, 64, (4, 4, 4), 2, 1, None),
                # 32-channel granularity on both sides -> the LDS-tiled GEMM kernel (upconv_gemm.hip); odd extents, autocrop, NT=2/4
-               (64, 32, (3, 5, 6), 2, 2, (5, 10, 11)), (64, 64, (2, 9, 20), 2, 1, None), (96, 32, (1, 8, 16), 1, 1, None)]
+               (64, 32, (3, 5, 6), 2, 2, (5, 10, 11)), (64, 64, (2, 9, 20), 2, 1, None), (96, 32, (1, 8, 16), 1, 1, None),
+               # Cin = 64 forward = the persistent kernel: 289 tiles of 128 voxels for 256 workgroups (some walk two tiles, the last is ragged), autocrop
+               (64, 32, (9, 64, 64), 2, 1, (17, 128, 127)), (64, 32, (5, 70, 106), 1, 1, None)]
 
 
 @pytest.mark.parametrize('cin,cout,shape,sd,n,crop', CONVT_CASES)
