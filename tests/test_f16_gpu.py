@@ -40,18 +40,25 @@ def _close_f16(got, ref64, what, ulps=1.1, atol=1e-6):
     assert not bool(bad.any()), f'{what}: {int(bad.sum())} of {bad.numel()} beyond float16 rounding; worst {float((err / bound).max()):.2f}x the bound'
 
 
+@pytest.mark.parametrize('N,D,H,W,Cin,Cout', [(1, 1, 8, 16, 32, 32), (2, 3, 19, 37, 64, 32), (1, 1, 70, 100, 32, 64), (2, 16, 128, 64, 32, 32), (1, 2, 13, 21, 128, 64)])
+def test_conv3d_f16_planar_forward_dgrad_wgrad_vs_fp64(N, D, H, W, Cin, Cout):
+    """1x3x3 convs of planar blocks / dim = 2 networks in float16 (one-slice bricks, bf16_conv.hip Geo::FLAT)."""
+    test_conv3d_f16_forward_dgrad_wgrad_vs_fp64(N, D, H, W, Cin, Cout, planar=True)
+
+
 @pytest.mark.parametrize('N,D,H,W,Cin,Cout', [(1, 4, 8, 16, 32, 32), (2, 5, 11, 21, 64, 32), (1, 3, 9, 17, 128, 64), (2, 32, 64, 64, 32, 32),
                                             (1, 9, 13, 100, 64, 64)])
-def test_conv3d_f16_forward_dgrad_wgrad_vs_fp64(N, D, H, W, Cin, Cout):
+def test_conv3d_f16_forward_dgrad_wgrad_vs_fp64(N, D, H, W, Cin, Cout, planar=False):
     from elektronn3_amd import ops
+    pad = (0, 1, 1) if planar else 1
     x = _hvals(N, Cin, D, H, W, seed=1)
-    w = _hvals(Cout, Cin, 3, 3, 3, seed=2, scale=(27 * Cin) ** -0.5)
+    w = _hvals(Cout, Cin, 1 if planar else 3, 3, 3, seed=2, scale=((9 if planar else 27) * Cin) ** -0.5)
     b = torch.randn(Cout, generator=torch.Generator().manual_seed(3))
     dy = _hvals(N, Cout, D, H, W, seed=4)
     xd, wd, dyd = x.to(DEV), w.to(DEV), dy.to(DEV)
-    y, stats = ops.conv3d_bf16(_ndhwc(xd), wd.float(), b.to(DEV), want_stats=True)
+    y, stats = ops.conv3d_bf16(_ndhwc(xd), wd.float(), b.to(DEV), planar=planar, want_stats=True)
     assert y.dtype == HF
-    ref = F.conv3d(x.double(), w.double(), b.double(), padding=1)
+    ref = F.conv3d(x.double(), w.double(), b.double(), padding=pad)
     _close_f16(_ncdhw(y), ref, 'conv forward')
     # statistics records of the stored (rounded) values merge to the tensor's mean / variance
     yv = _ncdhw(y).double().cpu()
@@ -59,12 +66,12 @@ def test_conv3d_f16_forward_dgrad_wgrad_vs_fp64(N, D, H, W, Cin, Cout):
     tot = n.sum(0); gm = (n * mean).sum(0) / tot
     var = ((m2 + n * (mean - gm) ** 2).sum(0)) / tot
     assert torch.allclose(gm, yv.mean((0, 2, 3, 4)), atol=1e-4) and torch.allclose(var, yv.var((0, 2, 3, 4), unbiased=False), rtol=1e-3, atol=1e-4)
-    dx = ops.conv3d_dgrad_bf16(_ndhwc(dyd), wd.float())
-    refdx = F.conv_transpose3d(dy.double(), w.double(), padding=1)
+    dx = ops.conv3d_dgrad_bf16(_ndhwc(dyd), wd.float(), planar=planar)
+    refdx = F.conv_transpose3d(dy.double(), w.double(), padding=pad)
     _close_f16(_ncdhw(dx), refdx, 'conv dgrad')
-    dw = ops.conv3d_wgrad_bf16(_ndhwc(xd), _ndhwc(dyd))
+    dw = ops.conv3d_wgrad_bf16(_ndhwc(xd), _ndhwc(dyd), planar=planar)
     xr = x.double().requires_grad_(False); wr = w.double().requires_grad_(True)
-    F.conv3d(xr, wr, None, padding=1).backward(dy.double())
+    F.conv3d(xr, wr, None, padding=pad).backward(dy.double())
     assert float((dw.double().cpu() - wr.grad).norm() / wr.grad.norm()) < 1e-5        # fp32 accumulation, fp32 result
 
 
