@@ -13,7 +13,9 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, 
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, 'libe3unet.so')
+# E3_LIB_PATH: developer A/B switch -- load another BUILD of the same library (e.g. the previous round's, kept under tools/_bin/) to time
+# two versions of a kernel in one GPU session.  It must export the same ABI; it is never a fallback (a missing file raises like the default).
+_LIB_PATH = os.environ.get('E3_LIB_PATH') or os.path.join(_HERE, 'libe3unet.so')
 
 E3_FWD_TRAINING = 1
 E3_FWD_SOFTMAX = 2
@@ -140,7 +142,7 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    if build_if_missing:
+    if build_if_missing and not os.environ.get('E3_LIB_PATH'):
         try:
             from .build import build
             build()

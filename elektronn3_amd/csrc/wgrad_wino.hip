@@ -34,6 +34,13 @@ constexpr int G_EX = 4 * 9 * 4 * 64 * 4;                 // epilogue exchange: [
 constexpr int G_LDS_FLOATS = 2 * G_BUF > G_EX ? 2 * G_BUF : G_EX;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// The SelectionDAG linearisation lets pure VALU code drift across __builtin_amdgcn_sched_barrier (only side-effecting nodes are chained); a
+// volatile asm that "modifies" the values is chained with the barriers and pins producers before / consumers after it.  No instructions.
+__device__ __forceinline__ void pin8(float* v) {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+__device__ __forceinline__ void pin24(float* v) { pin8(v); pin8(v + 8); pin8(v + 16); }
+
 __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, int tilesD, int tilesH, int tilesW,
                                                             int tiles_per_split, int co_tiles, int ci_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -97,10 +104,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    // staging of one brick, split in 4 parts so that the DMA traffic of the NEXT brick can be issued in front of each of the
-    // 4 MFMA blocks of the current one (the texture-address path moves 64 B/clk: 72 KB per brick = 1.1k cycles that would
-    // otherwise sit between the barrier and the first transform)
-    unsigned xmask = 0, gmask = 0, xbase = 0, gbase = 0;
+    // ---- per-brick scalars of the DMA requests (set-up of brick b + 1 runs during the last MFMA block of brick b - 1 ... see below)
+    unsigned xmask = 0, gmask = 0;
     auto issue_setup = [&](int brick) {
         int Lt = brick < brick1 ? brick : brick1 - 1;     // (past the end the last brick harmlessly re-stages itself)
         const int tw_ = Lt % tilesW; Lt /= tilesW; const int th_ = Lt % tilesH; Lt /= tilesH; const int td_ = Lt % tilesD; const int nb = Lt / tilesD;
@@ -112,54 +117,76 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
         };
         xmask = range_mask(d0 - 1, 4, a.D) | (range_mask(h0 - 1, 6, a.H) << 4) | (range_mask(w0 - 1, 18, a.W) << 10);
         gmask = range_mask(d0, 2, a.D) | (range_mask(h0, 4, a.H) << 4) | (range_mask(w0, 16, a.W) << 10);
-        x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)nb * samp_x, 0, 0x7fffffff, 0x00020000);
-        g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy) + (size_t)nb * samp_g, 0, 0x7fffffff, 0x00020000);
-        xbase = (unsigned)(((((d0 - 1) * a.H + h0 - 1) * a.W + w0 - 1) * a.x_ldc) * 4);   // relative to the sample; wraps at the borders
-        gbase = (unsigned)((((d0 * a.H + h0) * a.W + w0) * a.dy_ldc) * 4);
+        // the descriptors start at the brick's halo origin (possibly in front of the tensor: only lanes whose voxel is inside the volume
+        // ever form an address from them), so a lane's offset is its constant position inside the halo -- no per-brick vector arithmetic
+        const long long xorg = (long long)nb * (long long)samp_x + ((((long long)(d0 - 1) * a.H + h0 - 1) * a.W + w0 - 1) * a.x_ldc);
+        const long long gorg = (long long)nb * (long long)samp_g + ((((long long)d0 * a.H + h0) * a.W + w0) * a.dy_ldc);
+        x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + xorg, 0, 0x7fffffff, 0x00020000);
+        g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy) + gorg, 0, 0x7fffffff, 0x00020000);
     };
-    auto issue_part = [&](int part, float* buf) {         // part 0..2: X pieces {0-5, 6-10, 11-13}, dY pieces {0-1, 2, 3}; part 3: nothing
-        // (the last MFMA block keeps the DMA queue draining: everything has landed when the brick's barrier is reached)
-        const int lo = part == 0 ? 0 : (part == 1 ? 6 : (part == 2 ? 11 : 14)), hi = part == 0 ? 6 : (part == 1 ? 11 : 14);
-        const int glo = part == 0 ? 0 : (part == 1 ? 2 : (part == 2 ? 3 : 4)), ghi = part == 0 ? 2 : (part == 1 ? 3 : 4);
+    // DMA requests of one brick in two parts (issued between the MFMAs of the first two blocks of the brick before): vector offset = the
+    // lane's constant offset inside the halo, or OOB for a voxel outside the volume / a channel beyond the tensor: 3 VALU per piece
+    // (and-compare-select), none for the address.
+    auto issue_part = [&](int part, float* buf) {         // part 0: X pieces 0-7, dY pieces 0-1; part 1: X pieces 8-13, dY pieces 2-3
+        const int lo = part == 0 ? 0 : 8, hi = part == 0 ? 8 : G_XI;
+        const int glo = part == 0 ? 0 : 2, ghi = part == 0 ? 2 : G_GI;
 #pragma unroll
         for (int it = 0; it < G_XI; ++it) {
             if (it < lo || it >= hi) continue;
             const int wp = it * 4 + wave < G_XW ? it * 4 + wave : G_XW - 1;
             const bool ok = (xmask & xpm[it]) == xpm[it];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(buf + wp * 256), 16, ok ? xrel[it] + xbase : OOB, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_ptr_t)(buf + wp * 256), 16, ok ? xrel[it] : OOB, 0, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < G_GI; ++it) {
             if (it < glo || it >= ghi) continue;
             const bool ok = (gmask & gpm[it]) == gpm[it];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rs, (lds_ptr_t)(buf + G_XS + (it * 4 + wave) * 256), 16, ok ? grel[it] + gbase : OOB, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rs, (lds_ptr_t)(buf + G_XS + (it * 4 + wave) * 256), 16, ok ? grel[it] : OOB, 0, 0, 0);
         }
     };
 
-    // one brick = 2 tile rows (chunks) x 2 halves of 2 k-steps each.  The LDS reads of half-chunk q+1 are issued before the
-    // MFMAs of half-chunk q (their latency hides under the matrix pipe), the transforms stay between the MFMA blocks.
-    auto compute = [&](const float* buf, float* nxt) {
-        float ra[4][6], rb[4][6], ry0[2][4], ry1[2][4];
-        auto read_raw = [&](int c, int hc) {
+    // One brick = 2 tile rows (chunks) x 2 halves of 2 k-steps each = 4 blocks of (transform, 32 MFMAs).  Only the transforms (fp32 VALU:
+    // they share the FMA lanes with the fp32 MFMA, nothing can hide them) stay between the MFMA blocks.  Everything else is issued IN
+    // BETWEEN the MFMAs (sched_group_barrier pipelines: an MFMA holds the matrix pipe for 64 cycles, a DS / VMEM / SALU instruction issued
+    // in its shadow is free; issued in front of the blocks, as in round 2, a brick's 140 LDS reads + 18 DMA requests + ~150 set-up scalars
+    // left the pipe idle for ~2-3k of its 12.7k cycles):
+    //   block 0, 1: the LDS-DMA requests of brick b + 1 (into the other stage) and the LDS reads of blocks 1, 2
+    //   block 2:    the LDS reads of block 3
+    //   block 3:    starts with the brick's barrier (DMA of b + 1 landed, every wave done reading stage b); its MFMAs cover the scalar
+    //               set-up of brick b + 2 and the LDS reads of block 0 of brick b + 1 -- no read is exposed after the barrier.
+    static_assert(G_NV * 128 < 65536 && 2 * G_MV * 128 < 65536, "LDS read offsets must fit the 16-bit immediate");
+    float ra[4][6], rb[4][6], ry0[2][4], ry1[2][4];
+    auto read_raw = [&](int oa, int ob, int oy, int c, int hc) {
+        // three lane bases per stage: every read is base + immediate (one base for the whole 70 KB stage overflowed the 16-bit offset
+        // field and cost 69 v_add_u32 per brick)
+        const float* pa = smem + oa;
+        const float* pb = smem + ob;
+        const float* py = smem + oy;
 #pragma unroll
-            for (int h = 0; h < 4; ++h)
+        for (int h = 0; h < 4; ++h)
 #pragma unroll
-                for (int w = 0; w < 6; ++w) {
-                    const int off = ((2 * c + h) * G_LW + 4 * hc + w) * 32;
-                    ra[h][w] = buf[xrd_a + off]; rb[h][w] = buf[xrd_b + off];
-                }
+            for (int w = 0; w < 6; ++w) {
+                const int off = ((2 * c + h) * G_LW + 4 * hc + w) * 32;
+                ra[h][w] = pa[off]; rb[h][w] = pb[off];
+            }
 #pragma unroll
-            for (int oh = 0; oh < 2; ++oh)
+        for (int oh = 0; oh < 2; ++oh)
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const int off = ((2 * c + oh) * 16 + 4 * hc + w) * 32;
-                    ry0[oh][w] = buf[yrd + off]; ry1[oh][w] = buf[yrd + off + 4 * 16 * 32];
-                }
-        };
-        read_raw(0, 0);
+            for (int w = 0; w < 4; ++w) {
+                const int off = ((2 * c + oh) * 16 + 4 * hc + w) * 32;
+                ry0[oh][w] = py[off]; ry1[oh][w] = py[off + 4 * 16 * 32];
+            }
+    };
+    auto compute = [&](int cur_off, int nxt_off, int setup_brick) {
+        int oa = cur_off + xrd_a, ob = cur_off + xrd_b, oy = cur_off + yrd;
+        asm volatile("" : "+v"(oa), "+v"(ob), "+v"(oy));
+        int na = nxt_off + xrd_a, nb_ = nxt_off + xrd_b, ny = nxt_off + yrd;
+        asm volatile("" : "+v"(na), "+v"(nb_), "+v"(ny));
+        float* const nxt = smem + nxt_off;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             // ---- X: rows h = 0..3 of the tile row, w window 8 hf + 4 hc + [0, 6) serves the lane's tiles 4 hf + 2 hc + {0, 1}
+            pin24(&ra[0][0]); pin24(&rb[0][0]); pin8(&ry0[0][0]); pin8(&ry1[0][0]);       // (consumers stay behind the previous block)
             float u[4][6];
 #pragma unroll
             for (int h = 0; h < 4; ++h)
@@ -198,32 +225,46 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
                     Y[tl][h][0] = hrow[h][0]; Y[tl][h][1] = hrow[h][0] + hrow[h][1]; Y[tl][h][2] = hrow[h][0] + m1 * hrow[h][1]; Y[tl][h][3] = hrow[h][1];
                 }
             }
+            pin8(&X[0][0][0]); pin24(&X[0][2][0]); pin8(&Y[0][0][0]); pin24(&Y[0][2][0]);   // (producers stay in front of the block)
             __builtin_amdgcn_sched_barrier(0);
-            issue_part(qd, nxt);                                     // next brick's DMA and this brick's next LDS reads:
-            if (qd < 3) read_raw((qd + 1) >> 1, (qd + 1) & 1);      // in flight during the 32 MFMAs below
-            __builtin_amdgcn_sched_barrier(0);
+            if (qd == 3) {
+                __syncthreads();             // (hipcc drains vmcnt in front of the barrier: the next brick's DMA has landed)
+                __builtin_amdgcn_sched_barrier(0);
+                issue_setup(setup_brick);
+                read_raw(na, nb_, ny, 0, 0);
+            } else {
+                read_raw(oa, ob, oy, (qd + 1) >> 1, (qd + 1) & 1);     // (reads first in program order: the scheduler keeps LDS reads and
+                if (qd < 2) issue_part(qd, nxt);                        // LDS-DMA writes, which it cannot tell apart, in that order)
+            }
             // ---- 16 positions x 2 k-steps (k-step s = 2 hc + tl: lane half hf supplies tile 4 hf + s)
 #pragma unroll
             for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
                 for (int p = 0; p < 16; ++p)
                     acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y[tl][p >> 2][p & 3], X[tl][p >> 2][p & 3], acc[p], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
+                if (qd == 3) __builtin_amdgcn_sched_group_barrier(0x004, 6, 0);      // set-up scalars
+                if (qd >= 2 || i < 20) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // two LDS reads (early: the next transform waits for them)
+                else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // one LDS-DMA request (late: it has two blocks to land)
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     if (brick0 < brick1) {
         issue_setup(brick0);
-#pragma unroll
-        for (int part = 0; part < 4; ++part) issue_part(part, smem);
+        issue_part(0, smem); issue_part(1, smem);
+        issue_setup(brick0 + 1);
         __syncthreads();                     // (hipcc drains vmcnt before the barrier: the DMA has landed)
+        read_raw(xrd_a, xrd_b, yrd, 0, 0);
         int par = 0;
         for (int b = brick0; b < brick1; ++b) {
-            issue_setup(b + 1);
-            compute(smem + par * G_BUF, smem + (par ^ 1) * G_BUF);
-            __syncthreads();
+            compute(par * G_BUF, (par ^ 1) * G_BUF, b + 2);
             par ^= 1;
         }
+        __syncthreads();                     // the last block's reads of the other stage (unused values) are done: the buffers are free
     }
 
     // ---- epilogue: A^T over (ph, pw) in registers.  acc[ph*4+pw][r]: row r -> co = (r&3) + 8 (r>>2) + 4 hf, column j = ci.
