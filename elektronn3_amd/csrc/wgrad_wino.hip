@@ -36,10 +36,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // The SelectionDAG linearisation lets pure VALU code drift across __builtin_amdgcn_sched_barrier (only side-effecting nodes are chained); a
 // volatile asm that "modifies" the values is chained with the barriers and pins producers before / consumers after it.  No instructions.
-__device__ __forceinline__ void pin8(float* v) {
-    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
-}
-__device__ __forceinline__ void pin24(float* v) { pin8(v); pin8(v + 8); pin8(v + 16); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pin4(f32x2* v) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])); }
 
 __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, int tilesD, int tilesH, int tilesW,
                                                             int tiles_per_split, int co_tiles, int ci_tiles) {
@@ -155,98 +153,113 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
     //   block 3:    starts with the brick's barrier (DMA of b + 1 landed, every wave done reading stage b); its MFMAs cover the scalar
     //               set-up of brick b + 2 and the LDS reads of block 0 of brick b + 1 -- no read is exposed after the barrier.
     static_assert(G_NV * 128 < 65536 && 2 * G_MV * 128 < 65536, "LDS read offsets must fit the 16-bit immediate");
-    float ra[4][6], rb[4][6], ry0[2][4], ry1[2][4];
-    auto read_raw = [&](int oa, int ob, int oy, int c, int hc) {
-        // three lane bases per stage: every read is base + immediate (one base for the whole 70 KB stage overflowed the 16-bit offset
-        // field and cost 69 v_add_u32 per brick)
-        const float* pa = smem + oa;
-        const float* pb = smem + ob;
-        const float* py = smem + oy;
+    // The transforms run PACKED (v_pk_add / v_pk_fma_f32: two lanes of work per VALU slot, ~7.9 vs 2 x 6.1 cycles).  The pairing that needs
+    // no register moves and no duplicate loads: a block handles the lane's tiles (hc = 0, tl) and (hc = 1, tl) of a tile row -- w windows
+    // 4 hc + 2 tl + [0, 4), disjoint -- as elements 0 / 1 of every pair; every pass is element-wise in the pair and the MFMA operands of
+    // k-step s = 2 hc + tl are the halves of the result pairs.
+    f32x2 ra[4][4], rb[4][4], ry0[2][2], ry1[2][2];      // [h][w], element hc: column 4 hc + 2 tl + w of the lane's 16-wide row
+    // LDS read addresses: one lane base PER WINDOW COLUMN w and array, every read = base + immediate.  (hipcc merges LDS reads that share
+    // a base register into ds_read2 forms in order of their offsets; with a base per column the two elements of a pair -- 4 voxels = 128
+    // dwords apart -- are offset-neighbours and land in one ds_read2st64_b32 that writes the pair directly.  With a shared base it pairs
+    // neighbouring columns instead and assembles the pairs with v_mov + s_waitcnt in the middle of the MFMAs.)
+    struct RdBase { int a[4], b[4], y[2]; };
+    auto make_bases = [&](int stage_off, RdBase& B) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            B.a[w] = stage_off + xrd_a + w * 32; B.b[w] = stage_off + xrd_b + w * 32;
+            asm volatile("" : "+v"(B.a[w]), "+v"(B.b[w]));
+        }
+#pragma unroll
+        for (int w = 0; w < 2; ++w) { B.y[w] = stage_off + yrd + w * 32; asm volatile("" : "+v"(B.y[w])); }
+    };
+    auto read_raw = [&](const RdBase& B, int c, int tl) {
 #pragma unroll
         for (int h = 0; h < 4; ++h)
 #pragma unroll
-            for (int w = 0; w < 6; ++w) {
-                const int off = ((2 * c + h) * G_LW + 4 * hc + w) * 32;
-                ra[h][w] = pa[off]; rb[h][w] = pb[off];
-            }
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int off = ((2 * c + h) * G_LW + 4 * e + 2 * tl) * 32;
+                    ra[h][w][e] = smem[B.a[w] + off]; rb[h][w][e] = smem[B.b[w] + off];
+                }
 #pragma unroll
         for (int oh = 0; oh < 2; ++oh)
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int off = ((2 * c + oh) * 16 + 4 * hc + w) * 32;
-                ry0[oh][w] = py[off]; ry1[oh][w] = py[off + 4 * 16 * 32];
-            }
+            for (int w = 0; w < 2; ++w)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int off = ((2 * c + oh) * 16 + 4 * e + 2 * tl) * 32;
+                    ry0[oh][w][e] = smem[B.y[w] + off]; ry1[oh][w][e] = smem[B.y[w] + off + 4 * 16 * 32];
+                }
     };
     auto compute = [&](int cur_off, int nxt_off, int setup_brick) {
-        int oa = cur_off + xrd_a, ob = cur_off + xrd_b, oy = cur_off + yrd;
-        asm volatile("" : "+v"(oa), "+v"(ob), "+v"(oy));
-        int na = nxt_off + xrd_a, nb_ = nxt_off + xrd_b, ny = nxt_off + yrd;
-        asm volatile("" : "+v"(na), "+v"(nb_), "+v"(ny));
+        RdBase Bc, Bn;
+        make_bases(cur_off, Bc); make_bases(nxt_off, Bn);
         float* const nxt = smem + nxt_off;
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            // ---- X: rows h = 0..3 of the tile row, w window 8 hf + 4 hc + [0, 6) serves the lane's tiles 4 hf + 2 hc + {0, 1}
-            pin24(&ra[0][0]); pin24(&rb[0][0]); pin8(&ry0[0][0]); pin8(&ry1[0][0]);       // (consumers stay behind the previous block)
-            float u[4][6];
+        for (int qd = 0; qd < 4; ++qd) {           // block qd = (tile row c = qd >> 1, tl = qd & 1)
+            // (consumers of the block's reads stay behind the previous block)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) { pin4(ra[h]); pin4(rb[h]); }
+            pin4(&ry0[0][0]); pin4(&ry1[0][0]);
+            // ---- X: rows h = 0..3 of the tile row, 4-wide w windows of the lane's tiles 4 hf + 2 hc + tl, hc = 0, 1
+            f32x2 u[4][4];
 #pragma unroll
             for (int h = 0; h < 4; ++h)
 #pragma unroll
-                for (int w = 0; w < 6; ++w) u[h][w] = ra[h][w] + sgn * rb[h][w];
+                for (int w = 0; w < 4; ++w) u[h][w] = ra[h][w] + sgn * rb[h][w];
 #pragma unroll
-            for (int w = 0; w < 6; ++w) {
-                const float v0 = u[0][w] + m1 * u[2][w], v1 = u[1][w] + u[2][w], v2 = u[2][w] + m1 * u[1][w], v3 = u[1][w] + m1 * u[3][w];
+            for (int w = 0; w < 4; ++w) {
+                const f32x2 v0 = u[0][w] + m1 * u[2][w], v1 = u[1][w] + u[2][w], v2 = u[2][w] + m1 * u[1][w], v3 = u[1][w] + m1 * u[3][w];
                 u[0][w] = v0; u[1][w] = v1; u[2][w] = v2; u[3][w] = v3;
             }
-            float X[2][4][4];                       // [tile][ph][pw]
+            f32x2 X[4][4];                          // [ph][pw], element hc
 #pragma unroll
-            for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const float* r = &u[h][2 * tl];
-                    X[tl][h][0] = r[0] + m1 * r[2]; X[tl][h][1] = r[1] + r[2]; X[tl][h][2] = r[2] + m1 * r[1]; X[tl][h][3] = r[1] + m1 * r[3];
-                }
-            // ---- Y: dY rows oh = 0, 1 of the tile row, both d planes, w window 8 hf + 4 hc + [0, 4)
-            float g[2][4];
+            for (int h = 0; h < 4; ++h) {
+                X[h][0] = u[h][0] + m1 * u[h][2]; X[h][1] = u[h][1] + u[h][2]; X[h][2] = u[h][2] + m1 * u[h][1]; X[h][3] = u[h][1] + m1 * u[h][3];
+            }
+            // ---- Y: dY rows oh = 0, 1 of the tile row, both d planes
+            f32x2 g[2][2];
 #pragma unroll
             for (int oh = 0; oh < 2; ++oh)
 #pragma unroll
-                for (int w = 0; w < 4; ++w) g[oh][w] = ya * ry0[oh][w] + yb * ry1[oh][w];
-            float Y[2][4][4];
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl) {
-                float hrow[4][2];
+                for (int w = 0; w < 2; ++w) g[oh][w] = ya * ry0[oh][w] + yb * ry1[oh][w];
+            f32x2 Y[4][4];
+            {
+                f32x2 hrow[4][2];
 #pragma unroll
                 for (int w = 0; w < 2; ++w) {
-                    const float g0 = g[0][2 * tl + w], g1 = g[1][2 * tl + w];
-                    hrow[0][w] = g0; hrow[1][w] = g0 + g1; hrow[2][w] = g0 + m1 * g1; hrow[3][w] = g1;
+                    hrow[0][w] = g[0][w]; hrow[1][w] = g[0][w] + g[1][w]; hrow[2][w] = g[0][w] + m1 * g[1][w]; hrow[3][w] = g[1][w];
                 }
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
-                    Y[tl][h][0] = hrow[h][0]; Y[tl][h][1] = hrow[h][0] + hrow[h][1]; Y[tl][h][2] = hrow[h][0] + m1 * hrow[h][1]; Y[tl][h][3] = hrow[h][1];
+                    Y[h][0] = hrow[h][0]; Y[h][1] = hrow[h][0] + hrow[h][1]; Y[h][2] = hrow[h][0] + m1 * hrow[h][1]; Y[h][3] = hrow[h][1];
                 }
             }
-            pin8(&X[0][0][0]); pin24(&X[0][2][0]); pin8(&Y[0][0][0]); pin24(&Y[0][2][0]);   // (producers stay in front of the block)
+            // (producers stay in front of the block)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) { pin4(X[h]); pin4(Y[h]); }
             __builtin_amdgcn_sched_barrier(0);
             if (qd == 3) {
                 __syncthreads();             // (hipcc drains vmcnt in front of the barrier: the next brick's DMA has landed)
                 __builtin_amdgcn_sched_barrier(0);
                 issue_setup(setup_brick);
-                read_raw(na, nb_, ny, 0, 0);
+                read_raw(Bn, 0, 0);
             } else {
-                read_raw(oa, ob, oy, (qd + 1) >> 1, (qd + 1) & 1);     // (reads first in program order: the scheduler keeps LDS reads and
+                read_raw(Bc, (qd + 1) >> 1, (qd + 1) & 1);     // (reads first in program order: the scheduler keeps LDS reads and
                 if (qd < 2) issue_part(qd, nxt);                        // LDS-DMA writes, which it cannot tell apart, in that order)
             }
             // ---- 16 positions x 2 k-steps (k-step s = 2 hc + tl: lane half hf supplies tile 4 hf + s)
 #pragma unroll
-            for (int tl = 0; tl < 2; ++tl)
+            for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int p = 0; p < 16; ++p)
-                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y[tl][p >> 2][p & 3], X[tl][p >> 2][p & 3], acc[p], 0, 0, 0);
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y[p >> 2][p & 3][e], X[p >> 2][p & 3][e], acc[p], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
                 if (qd == 3) __builtin_amdgcn_sched_group_barrier(0x004, 6, 0);      // set-up scalars
-                if (qd >= 2 || i < 20) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // two LDS reads (early: the next transform waits for them)
+                if (qd >= 2 || i < 20) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // two LDS reads (early: the next transform waits for them)
                 else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // one LDS-DMA request (late: it has two blocks to land)
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
         issue_part(0, smem); issue_part(1, smem);
         issue_setup(brick0 + 1);
         __syncthreads();                     // (hipcc drains vmcnt before the barrier: the DMA has landed)
-        read_raw(xrd_a, xrd_b, yrd, 0, 0);
+        { RdBase B0; make_bases(0, B0); read_raw(B0, 0, 0); }
         int par = 0;
         for (int b = brick0; b < brick1; ++b) {
             compute(par * G_BUF, (par ^ 1) * G_BUF, b + 2);
