@@ -46,6 +46,7 @@ __device__ __forceinline__ int plane_slot(int zh, int zw, int q) {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 template <bool PRO>
 __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
@@ -355,29 +356,48 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
     }
 }
 
-// ---- persistent variant: one workgroup per CU walks the bricks bid, bid + grid, ...; the input staging is software-pipelined ACROSS
-// bricks: the last chunk of a brick, whose "next chunk" slot is idle, fetches / D-transforms / stages the first chunk of the next
-// brick into the other LDS buffer, so a brick starts with its first chunk already in LDS (no exposed global-load latency, no
-// wasted re-staging).  Nothing but a few scalars lives across the epilogue, which has its own LDS region (130 KB in total).
+// ---- persistent variant: one workgroup per CU walks the bricks L0, L0 + step, ... (the XCD-aware order of the plain kernel: XCD x owns a
+// contiguous eighth of the brick range).  What differs from conv3_wino_kernel:
+//   * the staging is software-pipelined over the whole (brick, chunk) sequence, two units ahead: during the MFMAs of unit u the wave
+//     stores the D-transformed halo of unit u + 1 to LDS (raw data loaded during unit u - 1, transformed in the VALU phase of unit u)
+//     and requests the raw halo of unit u + 2 -- of the next brick when the current one is done, so a brick starts with its data in LDS;
+//   * fp32 VALU work shares the FMA lanes with the fp32 MFMA and is kept in one phase per unit (LDS reads, D transform of the staged
+//     halo, H / W passes); EVERYTHING else -- LDS stores, global loads, the scalar bookkeeping of the staging cursor (mixed-radix brick
+//     counters advanced without divisions or branches, descriptor and validity masks of the brick being staged) -- is issued between
+//     the MFMAs (sched_group_barrier pipeline), where an instruction that is not VALU costs nothing;
+//   * BatchNorm statistics: every lane keeps a running (count, mean, M2) of its channel over the workgroup's bricks (merged with
+//     v_rcp instead of a division) and the workgroup writes ONE record at the end (`wgstats`; 256 / ntiles records per layer instead of
+//     one per brick: no pre-merge launch, a tenth of the epilogue's statistic code per brick).  Where a workgroup's bricks do not all
+//     belong to one column tile (unusual grids) the records stay per brick.
 constexpr int W_PLDS_FLOATS = 2 * W_BUF + W_EX + 4 * 32 * 3;
 
-__global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, const unsigned nblk) {
+struct WinoPArgs { int s_nt, s_tw, s_th, s_td, s_nb; int wgstats; };   // digits of the logical step gridDim / 8 between a workgroup's bricks
+
+__global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, const unsigned nblk, const WinoPArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, hf = lane >> 5;
-    // The arguments are re-read from the kernarg segment (scalar loads) wherever a brick needs them instead of living in ~40 SGPRs
-    // across the whole persistent loop (which made hipcc spill 200+ scalars into vector lanes).
-    typedef const __attribute__((address_space(4))) ConvArgs* KArgs;
-    auto KA = []() -> KArgs { KArgs q = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(q)); return q; };
     const int NCH = a.Cin >> 3;
     constexpr unsigned OOB = 0x80000000u;
+    // arguments that only the epilogue needs are re-read from the kernarg segment there (scalar loads) instead of occupying ~25 SGPRs across
+    // the whole persistent loop (which made hipcc spill ~200 scalars into vector lanes, ~1k cycles of v_readlane / v_writelane per brick)
+    typedef const __attribute__((address_space(4))) ConvArgs* KArgs;
+    auto KA = []() -> KArgs { KArgs q = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(q)); return q; };
+    const int D = a.D, H = a.H, W = a.W, xl = a.x_ldc;
+    const int tilesD = a.tilesD, tilesH = a.tilesH, tilesW = a.tilesW, ntiles = a.ntiles;
+    const unsigned plane_xb = (unsigned)((size_t)H * W * xl * 4);
 
-    // ---- lane constants that do not depend on the brick
+    // ---- lane constants
     const bool col_on = tid < W_LH * W_LW * 2;
     const int cq = tid & 1, czw = (tid >> 1) % W_LW, czh = (tid >> 1) / W_LW;
-    const int a_dst = col_on ? plane_slot(czh, czw, cq) : 0;
+    // (the 40 threads without a column store zeros into the 5 unused slots of the 4 parity classes: no divergent branch around the stores)
+    const int a_dst = col_on ? plane_slot(czh, czw, cq) : (((tid - W_LH * W_LW * 2) / 10) * W_CLASS + 27 + ((tid - W_LH * W_LW * 2) % 10) / 2) * 8 + 4 * (tid & 1);
+    // staging: byte offset of the thread's halo column inside a d-plane relative to the brick's halo origin, and the two bits of the
+    // brick's validity mask (6 d bits | 6 h bits | 18 w bits) it needs (all-ones never matches: threads without a column load zeros)
+    const unsigned col_rel = (unsigned)(((czh * W + czw) * xl + 4 * cq) * 4);
+    const unsigned col_bits = col_on ? (1u << (6 + czh)) | (1u << (12 + czw)) : 0xffffffffu;
     float m1 = -1.f;
     asm volatile("" : "+s"(m1));
     const int ttd = j >> 4, tth = (j >> 3) & 1, ttw = j & 7;
@@ -387,85 +407,126 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
     for (int hh = 0; hh < 2; ++hh) rdA[hh] = lbase + 4 * (hf ^ ((tth + hh) & 1));
     const int b_voff = lane * 16;
 
-    // ---- per-brick state.  Out: where the brick's results go (scalars).  Stage: where the staging slot reads from -- the current
-    // brick, or already the NEXT one during a brick's last chunk: a descriptor, per-d-plane scalar offsets / validity flags and ONE
-    // vector register (byte offset of the thread's halo column inside a d-plane, OOB outside H x W).
-    struct Out { int d0, h0, w0, nb, n0, ntile, mtile; };
-    struct Stage { __amdgpu_buffer_rsrc_t x_rs; unsigned col_off; unsigned dflag[W_AI]; unsigned dsoff[W_AI]; };
-    auto divmod = [](unsigned& x, int d) {
-        int r;
-        if ((d & (d - 1)) == 0) { r = (int)(x & (unsigned)(d - 1)); x >>= __builtin_ctz((unsigned)d); }
-        else { r = (int)(x % (unsigned)d); x /= (unsigned)d; }
-        return r;
+    // ---- brick cursors: mixed-radix digits (column tile, tw, th, td, sample) of the logical brick index L
+    unsigned gdim = gridDim.x;
+    asm volatile("" : "+s"(gdim));          // (kept in a register: a conditional use of gridDim.x becomes a branch around its load)
+    struct Cur { int nt, tw, th, td, nb; unsigned bid; };      // bid: physical index blockIdx + k * gridDim (the brick exists while bid < nblk)
+    auto advance = [&](Cur& c, bool go) {        // c += step if go (no branch, no division)
+        int v = c.nt + (go ? pa.s_nt : 0); int cy = v >= ntiles ? 1 : 0; c.nt = v - (cy ? ntiles : 0);
+        v = c.tw + (go ? pa.s_tw : 0) + cy; cy = v >= tilesW ? 1 : 0; c.tw = v - (cy ? tilesW : 0);
+        v = c.th + (go ? pa.s_th : 0) + cy; cy = v >= tilesH ? 1 : 0; c.th = v - (cy ? tilesH : 0);
+        v = c.td + (go ? pa.s_td : 0) + cy; cy = v >= tilesD ? 1 : 0; c.td = v - (cy ? tilesD : 0);
+        c.nb += (go ? pa.s_nb : 0) + cy;
+        c.bid += go ? gdim : 0u;
     };
-    auto make_out = [&](unsigned bid, Out& o) {
-        const KArgs k = KA();
-        unsigned L = xcd_remap(bid, nblk);
-        o.ntile = divmod(L, k->ntiles);
-        // (a 4 x 4 x 2 block of bricks per XCD and pass instead of this w-h-d order was measured: 11 % fewer bytes fetched over the step's 15
-        // launches -- 4.90 -> 4.38 GB -- and 0.8 % MORE time, 13.13 -> 13.24 ms per step: the kernel is matrix/VALU-bound and the blocks
-        // start their waves on colder L2 lines.  Not kept.)
-        const int tw_ = divmod(L, k->tilesW);
-        const int th_ = divmod(L, k->tilesH);
-        const int td_ = divmod(L, k->tilesD);
-        o.nb = (int)L;
-        o.d0 = td_ * 4; o.h0 = th_ * 4; o.w0 = tw_ * 16; o.n0 = o.ntile * 32;
-        o.mtile = ((o.nb * k->tilesD + td_) * k->tilesH + th_) * k->tilesW + tw_;
+    auto range_mask = [](int lo, int n, int size) {      // bit z set: lo + z in [0, size), z in [0, n)
+        const int first = lo < 0 ? -lo : 0, last = size - lo < n ? size - lo : n;
+        return last > first ? ((1u << last) - 1u) & ~((1u << first) - 1u) : 0u;
     };
-    auto make_stage = [&](const Out& o, bool real, Stage& p) {
-        const KArgs k = KA();
-        const int D = k->D, H = k->H, W = k->W, xl = k->x_ldc;
-        const size_t plane_x = (size_t)H * W * xl;
-        const unsigned plane_xb = (unsigned)(plane_x * 4);
-        const int dlo = o.d0 > 0 ? o.d0 - 1 : 0;
-        const size_t xrem = (size_t)(D - dlo) * plane_x * 4;
-        p.x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(k->x) + ((size_t)o.nb * D + dlo) * plane_x, 0,
-                                                   (int)(xrem < 0x7fffffffu ? xrem : 0x7fffffffu), 0x00020000);
-        const int cgh = o.h0 + czh - 1, cgw = o.w0 + czw - 1;
-        const bool col_ok = real && col_on && cgh >= 0 && cgh < H && cgw >= 0 && cgw < W;
-        p.col_off = col_ok ? (unsigned)(((cgh * W + cgw) * xl + 4 * cq) * 4) : OOB;
-#pragma unroll
-        for (int zd = 0; zd < W_AI; ++zd) {
-            const int gd = o.d0 + zd - 1;
-            const bool ok = gd >= 0 && gd < D;
-            p.dflag[zd] = ok ? 0u : OOB;
-            p.dsoff[zd] = ok ? (unsigned)(gd - dlo) * plane_xb : 0u;
-        }
+    // descriptor of the halo of brick c (origin = voxel (d0 - 1, h0 - 1, w0 - 1), possibly in front of the tensor: only valid lanes
+    // form addresses from it) and its validity mask; a brick beyond the end of the range stages zeros
+    __amdgpu_buffer_rsrc_t s_rs;
+    unsigned s_mask_ = 0;
+    auto make_stage = [&](const Cur& c) {
+        const int d0 = c.td * 4, h0 = c.th * 4, w0 = c.tw * 16;
+        const long long org = ((long long)c.nb * D + (d0 - 1)) * ((long long)H * W * xl) + ((long long)(h0 - 1) * W + (w0 - 1)) * xl;
+        s_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + org, 0, 0x7fffffff, 0x00020000);
+        const unsigned m = range_mask(d0 - 1, 6, D) | (range_mask(h0 - 1, 6, H) << 6) | (range_mask(w0 - 1, 18, W) << 12);
+        s_mask_ = c.bid < nblk ? m : 0u;
     };
 
     f32x16 acc[16];
-    f32x4 xr[W_AI], Bv[16];
-    Stage S;
-    auto issue_raw = [&](int cb) {
+    f32x4 xr[W_AI], Bv[16], pD[8];
+    // raw halo column of the staging cursor's brick, channels [cb, cb + 8): 6 d-planes (plane offset in the scalar offset, which the
+    // range check ignores; an invalid plane or column is pushed out of range through the vector offset)
+    auto issue_raw = [&](int cb, bool off = false) {      // off: nothing is read (mask 0: every lane out of range), the registers get zeros
+        const unsigned s_mask = off ? 0u : s_mask_;
+        const bool ok = (s_mask & col_bits) == col_bits;
+        const unsigned voff = ok ? col_rel : OOB;
 #pragma unroll
-        for (int it = 0; it < W_AI; ++it)
-            xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(S.x_rs, S.col_off | S.dflag[it], (int)S.dsoff[it] + cb * 4, 0));
-    };
-    auto write_raw = [&](float* buf) {
-        if (col_on) {
-#pragma unroll
-            for (int td = 0; td < 2; ++td) {
-                const f32x4 x0 = xr[2 * td], x1 = xr[2 * td + 1], x2 = xr[2 * td + 2], x3 = xr[2 * td + 3];
-                *reinterpret_cast<f32x4*>(buf + (td * 4 + 0) * W_PLANE + a_dst) = x0 + m1 * x2;
-                *reinterpret_cast<f32x4*>(buf + (td * 4 + 1) * W_PLANE + a_dst) = x1 + x2;
-                *reinterpret_cast<f32x4*>(buf + (td * 4 + 2) * W_PLANE + a_dst) = x2 + m1 * x1;
-                *reinterpret_cast<f32x4*>(buf + (td * 4 + 3) * W_PLANE + a_dst) = x1 + m1 * x3;
-            }
+        for (int it = 0; it < W_AI; ++it) {
+            const unsigned dsel = ((s_mask >> it) & 1u) ? 0u : OOB;
+            xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s_rs, voff | dsel, (int)(it * plane_xb) + cb * 4, 0));
         }
     };
-    __amdgpu_buffer_rsrc_t b_rs;
-    auto load_B = [&](int c, int g) {
+    auto dtransform = [&]() {       // D pass of B^T for the two tile depths: rows x0 - x2, x1 + x2, x2 - x1, x1 - x3 of planes (0..3) and (2..5)
+#pragma unroll
+        for (int td = 0; td < 2; ++td) {
+            const f32x4 x0 = xr[2 * td], x1 = xr[2 * td + 1], x2 = xr[2 * td + 2], x3 = xr[2 * td + 3];
+            pD[td * 4 + 0] = x0 + m1 * x2; pD[td * 4 + 1] = x1 + x2; pD[td * 4 + 2] = x2 + m1 * x1; pD[td * 4 + 3] = x1 + m1 * x3;
+        }
+    };
+    auto write_staged = [&](float* buf) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4*>(buf + q * W_PLANE + a_dst) = pD[q];
+    };
+    const float* b_base = nullptr;
+    auto make_brs = [&](int ntile) { b_base = KA()->wt + ((size_t)ntile * NCH * 64 + wave * 16) * 256; };
+    auto load_B = [&](int c, int g, bool off = false) {   // off: a descriptor of size 0 -- nothing is read, the registers get zeros
+        const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b_base), 0, off ? 0 : NCH * 64 * 1024, 0x00020000);
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             Bv[g * 4 + p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_voff + p * 1024, (c * 64 + g * 4) * 1024, 0));
     };
 
-    // one 8-channel chunk of the current brick: transformed halo in `cur`; the chunk staged meanwhile into `nxt` is channel
-    // offset cb_next of stage S (the same brick, or the first chunk of the next brick when this is the brick's last chunk).
-    // `cB` = chunk whose weights are fetched for the next iteration.
-    auto chunk = [&](auto zero_tag, const float* cur, float* nxt, int cb_next, int cB) {
+    // ---- cursors: P = brick being computed, S = brick being staged (chunk sc of it is the next one to be requested)
+    Cur P;
+    {
+        unsigned L = xcd_remap(blockIdx.x, nblk);
+        P.bid = blockIdx.x;
+        P.nt = (int)(L % (unsigned)ntiles); L /= (unsigned)ntiles;
+        P.tw = (int)(L % (unsigned)tilesW); L /= (unsigned)tilesW;
+        P.th = (int)(L % (unsigned)tilesH); L /= (unsigned)tilesH;
+        P.td = (int)(L % (unsigned)tilesD); P.nb = (int)(L / (unsigned)tilesD);
+    }
+    Cur S = P;
+    int sc = 0;
+    auto stage_wrap = [&]() { sc = 0; advance(S, true); make_stage(S); };      // the cursor moves on to the workgroup's next brick
+    auto stage_step = [&]() {                   // request the raw halo of staging unit (S, sc) and move the cursor to the next unit
+        issue_raw(sc * 8);
+        if (sc + 1 == NCH) stage_wrap(); else ++sc;
+    };
+
+    float* cur = smem;
+    float* nxt = smem + W_BUF;
+    float* ex = smem + 2 * W_BUF;
+    float* scr = ex + W_EX;
+    // running statistics of this lane's channel over the workgroup's bricks
+    float rn = 0.f, rmean = 0.f, rm2 = 0.f;
+#ifndef E3_WINO_ABL
+#define E3_WINO_ABL 0       // developer builds: bit mask of pieces left out of the MFMA phase (timing experiments, wrong results)
+#endif
+#ifdef E3_WINO_TIMING      // developer build (tools/phase_timing_pwino.py): s_memtime stamps of the workgroup's second brick instead of statistics
+    long long* const tstamp = reinterpret_cast<long long*>(KA()->stats) + (size_t)blockIdx.x * 32;
+    int tbrick = 0;
+#define TSTAMP(i) do { if (tid == 0 && tbrick == 1) tstamp[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define TSTAMPC(i) do { if (tid == 0 && tbrick == 1 && tchunk == 1) tstamp[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    if (tid == 0) tstamp[14] = (long long)__builtin_amdgcn_s_memrealtime();
+#else
+#define TSTAMP(i)
+#define TSTAMPC(i)
+#endif
+
+    // ---- prologue: unit 0 staged, unit 1 requested, weights of chunk 0 requested
+    make_stage(S);
+    stage_step();
+    dtransform();
+    write_staged(cur);
+    stage_step();
+    make_brs(P.nt);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) load_B(0, g);
+    __syncthreads();
+
+    // One 8-channel chunk (unit u) of brick P: transformed halo in `cur`.  ZERO (compile time) = first chunk of a brick: the accumulators
+    // start from a literal zero.  `last` (run time, no branch) = last chunk of the brick: its requests read nothing (zero-sized descriptor
+    // / empty mask) and the staging cursor stays -- the raw halo of unit u + 2 and the first weights of the next brick are requested in the
+    // epilogue instead, after its register-hungry part (88 registers less to keep alive across the output transform).  `cB`: chunk whose
+    // weights are requested.
+    auto chunk = [&](auto zero_tag, bool last, int cB, int tchunk = 0) {
         constexpr bool ZERO = decltype(zero_tag)::value;
-        issue_raw(cb_next);
+        TSTAMPC(1);
+        // ---- VALU phase: H and W passes of B^T d B on this lane's tile of plane (td, pd), 4 channels at a time; D pass of the staged halo
         f32x4 t[4][4];
 #pragma unroll
         for (int h = 0; h < 4; ++h)
@@ -474,6 +535,8 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
                 const int imm = (((h & 1) * 2 + (w & 1)) * W_CLASS + (h >> 1) * 9 + (w >> 1)) * 8;
                 t[h][w] = *reinterpret_cast<const f32x4*>(cur + rdA[h >> 1] + imm);
             }
+        __builtin_amdgcn_sched_barrier(0);      // (the LDS reads are issued before anything waits for the staged raw halo)
+        dtransform();
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const f32x4 u0 = t[0][w] + m1 * t[2][w], u1 = t[1][w] + t[2][w], u2 = t[2][w] + m1 * t[1][w], u3 = t[1][w] + m1 * t[3][w];
@@ -484,101 +547,141 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
             const f32x4 u0 = t[h][0] + m1 * t[h][2], u1 = t[h][1] + t[h][2], u2 = t[h][2] + m1 * t[h][1], u3 = t[h][1] + m1 * t[h][3];
             t[h][0] = u0; t[h][1] = u1; t[h][2] = u2; t[h][3] = u3;
         }
+        // pin the packed results in front of the MFMA block (and keep hipcc from scalarising vector ops whose results are only used element-wise)
 #pragma unroll
         for (int h = 0; h < 4; ++h)
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 f32x2 lo = {t[h][w][0], t[h][w][1]}, hi = {t[h][w][2], t[h][w][3]};
-                asm("" : "+v"(lo)); asm("" : "+v"(hi));
+                asm volatile("" : "+v"(lo), "+v"(hi));
                 t[h][w][0] = lo[0]; t[h][w][1] = lo[1]; t[h][w][2] = hi[0]; t[h][w][3] = hi[1];
             }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    if (ZERO && s == 0) {
-                        f32x16 z;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                        acc[g * 4 + p] = __builtin_amdgcn_mfma_f32_32x32x2f32(t[g][p][s], Bv[g * 4 + p][s], z, 0, 0, 0);
-                    } else {
-                        acc[g * 4 + p] = __builtin_amdgcn_mfma_f32_32x32x2f32(t[g][p][s], Bv[g * 4 + p][s], acc[g * 4 + p], 0, 0, 0);
-                    }
-                }
-            load_B(cB, g);                            // (unconditional: a branch here makes hipcc drain every memory counter mid-MFMA)
+        for (int q = 0; q < 8; ++q) {
+            f32x2 lo = {pD[q][0], pD[q][1]}, hi = {pD[q][2], pD[q][3]};
+            asm volatile("" : "+v"(lo), "+v"(hi));
+            pD[q][0] = lo[0]; pD[q][1] = lo[1]; pD[q][2] = hi[0]; pD[q][3] = hi[1];
         }
         __builtin_amdgcn_sched_barrier(0);
-        write_raw(nxt);
-        __builtin_amdgcn_sched_barrier(0);
+        TSTAMPC(2);
+        // ---- MFMA phase: 16 quads of 4 MFMAs (4 positions of a row ph = g at one k-step: 4 independent accumulators in flight; a scheduling
+        // fence after each quad keeps that order -- left alone, the scheduler issues the 4 k-steps of one accumulator back to back).  Each
+        // quad carries its share of the rest: one LDS store of unit u + 1, one raw load of unit u + 2, one weight load of unit u + 1 (into a
+        // register whose MFMAs are done), a piece of the staging cursor's bookkeeping (no branches: advanced by 0 or 1 unit / brick).
+        asm volatile("" : "+s"(sc), "+s"(S.nt), "+s"(S.tw), "+s"(S.th), "+s"(S.td), "+s"(S.nb), "+s"(S.bid));    // (the scalar chain starts HERE, not in front of the VALU phase)
+        const unsigned rmask = last ? 0u : s_mask_;      // (last chunk: empty mask, nothing is read)
+        const bool rok = (rmask & col_bits) == col_bits;
+        const unsigned rvoff = rok ? col_rel : OOB;
+        const int rcb = sc * 8;
+        const bool wrap = !last && sc + 1 == NCH;
+        const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b_base), 0, last ? 0 : NCH * 64 * 1024, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rs = s_rs;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int g = q >> 2, ks = q & 3;
+            if (q < 8 && !(E3_WINO_ABL & 1)) *reinterpret_cast<f32x4*>(nxt + q * W_PLANE + a_dst) = pD[q];
+            if (q >= 1 && q < 7 && !(E3_WINO_ABL & 2)) {
+                const int it = q - 1;
+                const unsigned dsel = ((rmask >> it) & 1u) ? 0u : OOB;
+                xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, rvoff | dsel, (int)(it * plane_xb) + rcb * 4, 0));
+            }
+            if (q >= 4 && !(E3_WINO_ABL & 4)) {      // weights of group (q - 4) >> 2, whose 16 MFMAs are issued
+                const int gb = (q - 4) >> 2, pb = (q - 4) & 3;
+                Bv[gb * 4 + pb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_voff + pb * 1024, (cB * 64 + gb * 4) * 1024, 0));
+            }
+            if (q == 8 && !(E3_WINO_ABL & 8)) { sc = last ? sc : (wrap ? 0 : sc + 1); advance(S, wrap); }
+            if (q == 10 && !(E3_WINO_ABL & 8)) make_stage(S);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (ZERO && ks == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    acc[g * 4 + p] = __builtin_amdgcn_mfma_f32_32x32x2f32(t[g][p][ks], Bv[g * 4 + p][ks], z, 0, 0, 0);
+                } else {
+                    acc[g * 4 + p] = __builtin_amdgcn_mfma_f32_32x32x2f32(t[g][p][ks], Bv[g * 4 + p][ks], acc[g * 4 + p], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x004, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x004, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x004, 12, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x004, 12, 0);
+            if (!(E3_WINO_ABL & 16)) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+            if (!(E3_WINO_ABL & 4)) Bv[12 + pb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_voff + pb * 1024, (cB * 64 + 12) * 1024, 0));
+        TSTAMPC(3);
         __syncthreads();
+        TSTAMPC(4);
+        { float* tsw = cur; cur = nxt; nxt = tsw; }
     };
 
-    float* cur = smem;
-    float* nxt = smem + W_BUF;
-    float* ex = smem + 2 * W_BUF;
-    float* scr = ex + W_EX;
-    unsigned bid = blockIdx.x;
-    Out P;
-    make_out(bid, P);
-    make_stage(P, true, S);
-    issue_raw(0);
-    write_raw(cur);
-    __syncthreads();
     for (;;) {
-        const unsigned nbid = bid + gridDim.x;
-        const bool has_next = nbid < nblk;
-        b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(KA()->wt) + ((size_t)P.ntile * NCH * 64 + wave * 16) * 256, 0, NCH * 64 * 1024, 0x00020000);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) load_B(0, g);
-        auto advance_stage = [&]() {                      // from here on the staging slot works for the NEXT brick (zeros if none)
-            Out on;
-            make_out(has_next ? nbid : bid, on);
-            make_stage(on, has_next, S);
-        };
-        // chunk 0 starts the accumulators from a literal zero; the brick's last chunk stages the next brick's first chunk
-        if (NCH == 1) advance_stage();
-        chunk(std::true_type{}, cur, nxt, NCH == 1 ? 0 : 8, NCH == 1 ? 0 : 1);
-        { float* tsw = cur; cur = nxt; nxt = tsw; }
-        for (int c = 1; c < NCH; ++c) {
-            const bool last = c + 1 == NCH;
-            if (last) advance_stage();
-            chunk(std::false_type{}, cur, nxt, last ? 0 : (c + 1) * 8, last ? 0 : c + 1);   // (last: a harmless re-fetch of chunk 0's weights)
-            { float* tsw = cur; cur = nxt; nxt = tsw; }
-        }
+        // (the staging cursor's chunk index at chunk c is (c + 2) mod NCH: it wraps in chunk NCH - 3, or -- NCH <= 2 -- in the epilogue)
+        TSTAMP(0);
+        chunk(std::true_type{}, NCH == 1, NCH == 1 ? 0 : 1);
+        for (int c = 1; c < NCH; ++c) chunk(std::false_type{}, c + 1 == NCH, c + 1 == NCH ? 0 : c + 1, c);
+        TSTAMP(5);
 
-        // ---- epilogue (as in conv3_wino_kernel, with its own LDS region)
+        // ---- epilogue.  acc[ph*4+pw][r]: position (pd = wave, ph, pw), tile row r -> tile t = (r&3) + 8 (r>>2) + 4 hf, channel j.
+        const int d0 = P.td * 4, h0 = P.th * 4, w0 = P.tw * 16, n0 = P.nt * 32;
         const KArgs e = KA();
-        const int d0 = P.d0, h0 = P.h0, w0 = P.w0, n0 = P.n0;
-        const int eD = e->D, eH = e->H, eW = e->W, yl = e->y_ldc, eN = e->Ncols;
-        const size_t plane_y = (size_t)eH * eW * yl;
-        const size_t yrem = (size_t)(eD - d0) * plane_y * 4;
+        const int yl = e->y_ldc, eN = e->Ncols;
+        const size_t plane_y = (size_t)H * W * yl;
+        const size_t yrem = (size_t)(D - d0) * plane_y * 4;
         const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(
-            e->y + ((size_t)P.nb * eD + d0) * plane_y, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
-        f32x16 q[2][2];
+            e->y + ((size_t)P.nb * D + d0) * plane_y, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
+        // A^T m A over (ph, pw) in registers, in two halves of 8 accumulator rows (the next brick's weights and raw halo are live in
+        // registers across the epilogue: the full-width form needed 80 more than there are)
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            const f32x16 t0 = acc[ph * 4 + 0] + acc[ph * 4 + 1] + acc[ph * 4 + 2];
-            const f32x16 t1 = acc[ph * 4 + 1] + m1 * acc[ph * 4 + 2] + m1 * acc[ph * 4 + 3];
-            if (ph == 0) { q[0][0] = t0; q[0][1] = t1; }
-            else if (ph == 1) { q[0][0] += t0; q[0][1] += t1; q[1][0] = t0; q[1][1] = t1; }
-            else if (ph == 2) { q[0][0] += t0; q[0][1] += t1; q[1][0] += m1 * t0; q[1][1] += m1 * t1; }
-            else { q[1][0] += m1 * t0; q[1][1] += m1 * t1; }
+        for (int hv = 0; hv < 2; ++hv) {
+            f32x8 q[2][2];
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                f32x8 c[4];
+#pragma unroll
+                for (int pw = 0; pw < 4; ++pw)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) c[pw][r] = acc[ph * 4 + pw][hv * 8 + r];
+                const f32x8 t0 = c[0] + c[1] + c[2];
+                const f32x8 t1 = c[1] + m1 * c[2] + m1 * c[3];
+                if (ph == 0) { q[0][0] = t0; q[0][1] = t1; }
+                else if (ph == 1) { q[0][0] += t0; q[0][1] += t1; q[1][0] = t0; q[1][1] = t1; }
+                else if (ph == 2) { q[0][0] += t0; q[0][1] += t1; q[1][0] += m1 * t0; q[1][1] += m1 * t1; }
+                else { q[1][0] += m1 * t0; q[1][1] += m1 * t1; }
+            }
+#pragma unroll
+            for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                for (int ow = 0; ow < 2; ++ow)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = q[oh][ow][4 * k + e];
+                        *reinterpret_cast<f32x4*>(ex + ((wave * 16 + (oh * 2 + ow) * 4 + hv * 2 + k) * 64 + lane) * 4) = v;
+                    }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        TSTAMP(6);
+        // the accumulators are out of the way: request the raw halo of unit u + 2 and the first weights of the next brick
+        Cur Pn = P;
+        advance(Pn, true);
+        const bool has_next = Pn.bid < nblk;
+        if (!(E3_WINO_ABL & 32)) stage_step();
+        make_brs(Pn.nt);
 #pragma unroll
-        for (int oh = 0; oh < 2; ++oh)
-#pragma unroll
-            for (int ow = 0; ow < 2; ++ow)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = q[oh][ow][4 * k + e];
-                    *reinterpret_cast<f32x4*>(ex + ((wave * 16 + (oh * 2 + ow) * 4 + k) * 64 + lane) * 4) = v;
-                }
+        for (int g = 0; g < 4; ++g) if (!(E3_WINO_ABL & 128)) load_B(0, g);
         __syncthreads();
+        TSTAMP(7);
         const int oh = wave >> 1, ow = wave & 1;
         const int n = n0 + j;
         const bool nvalid = n < eN;
@@ -604,68 +707,106 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
                     for (int e = 0; e < 4; ++e) y[od][k][e] = fmaxf(__builtin_fmaf(y[od][k][e], es, eh), 0.f);
         }
         const int gw_l = w0 + 8 * hf + ow, gh_l = h0 + oh;
-        const unsigned y_voff = (unsigned)(((gh_l * eW + gw_l) * yl + n) * 4);
-        const bool full = d0 + 4 <= eD && h0 + 4 <= eH && w0 + 16 <= eW && n0 + 32 <= eN;
+        const unsigned y_voff = (unsigned)(((gh_l * W + gw_l) * yl + n) * 4);
+        const bool full = d0 + 4 <= D && h0 + 4 <= H && w0 + 16 <= W && n0 + 32 <= eN;
+#ifdef E3_WINO_TIMING
+        const bool do_stats = false;
+#else
         const bool do_stats = e->stats != nullptr;
-        float cnt = 0.f, sum = 0.f;
-        unsigned okmask = 0xffffffffu;
-        if (full) {
+#endif
+        float cnt, mean, m2;
+        if (full) {                 // (uniform) no masks: packed sums
 #pragma unroll
             for (int od = 0; od < 2; ++od)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int soff = ((((2 * (r >> 3) + od) * eH + 2 * ((r >> 2) & 1)) * eW + 2 * (r & 3)) * yl) * 4;
+                    const int soff = ((((2 * (r >> 3) + od) * H + 2 * ((r >> 2) & 1)) * W + 2 * (r & 3)) * yl) * 4;
                     const float v = y[od][r >> 2][r & 3];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, y_voff, soff, 0);
-                    sum += v;
+                    if (!(E3_WINO_ABL & 64)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, y_voff, soff, 0);
                 }
-            cnt = 32.f;
+            cnt = 32.f; mean = 0.f; m2 = 0.f;
+            if (do_stats) {
+                const f32x4 s4 = (y[0][0] + y[0][1]) + (y[0][2] + y[0][3]) + ((y[1][0] + y[1][1]) + (y[1][2] + y[1][3]));
+                mean = ((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.f / 32.f);
+                f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
+                const float nm = m1 * mean;
+#pragma unroll
+                for (int od = 0; od < 2; ++od)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const f32x4 dv = y[od][k] + nm; q4 += dv * dv; }
+                m2 = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+            }
         } else {
-            okmask = 0u;
+            unsigned okmask = 0u;
+            float sum = 0.f;
+            cnt = 0.f;
 #pragma unroll
             for (int od = 0; od < 2; ++od)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int gd = d0 + 2 * (r >> 3) + od, gh = gh_l + 2 * ((r >> 2) & 1), gw = gw_l + 2 * (r & 3);
-                    const bool ok = nvalid && gd < eD && gh < eH && gw < eW;
-                    const int soff = ((((2 * (r >> 3) + od) * eH + 2 * ((r >> 2) & 1)) * eW + 2 * (r & 3)) * yl) * 4;
+                    const bool ok = nvalid && gd < D && gh < H && gw < W;
+                    const int soff = ((((2 * (r >> 3) + od) * H + 2 * ((r >> 2) & 1)) * W + 2 * (r & 3)) * yl) * 4;
                     const float v = y[od][r >> 2][r & 3];
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, ok ? y_voff : OOB, soff, 0);
                     cnt += ok ? 1.f : 0.f;
                     sum += ok ? v : 0.f;
                     okmask |= (ok ? 1u : 0u) << (od * 16 + r);
                 }
+            mean = cnt > 0.f ? sum / cnt : 0.f;
+            m2 = 0.f;
+            if (do_stats) {
+#pragma unroll
+                for (int od = 0; od < 2; ++od)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float d = y[od][r >> 2][r & 3] - mean;
+                        m2 += ((okmask >> (od * 16 + r)) & 1u) ? d * d : 0.f;
+                    }
+            }
         }
-        if (do_stats) {
-            float mean = cnt > 0.f ? sum / cnt : 0.f, m2 = 0.f;
-#pragma unroll
-            for (int od = 0; od < 2; ++od)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float d = y[od][r >> 2][r & 3] - mean;
-                    m2 += ((okmask >> (od * 16 + r)) & 1u) ? d * d : 0.f;
-                }
-            const float cnt2 = __shfl_xor(cnt, 32), mean2 = __shfl_xor(mean, 32), m22 = __shfl_xor(m2, 32);
-            welford_merge(cnt, mean, m2, cnt2, mean2, m22);
+        TSTAMP(8);
+        // flush: merge the lane records of a channel (two lane halves, four waves) in a fixed order and write one record
+        auto flush = [&](float fc, float fm, float fs, size_t row) {
+            const float c2 = __shfl_xor(fc, 32), mm2 = __shfl_xor(fm, 32), s2 = __shfl_xor(fs, 32);
+            welford_merge(fc, fm, fs, c2, mm2, s2);
             if (hf == 0) {
-                float* sc = scr + (wave * 32 + j) * 3;
-                sc[0] = cnt; sc[1] = mean; sc[2] = m2;
+                float* sc_ = scr + (wave * 32 + j) * 3;
+                sc_[0] = fc; sc_[1] = fm; sc_[2] = fs;
             }
             __syncthreads();
-            if (tid < 32 && n < eN) {
+            if (tid < 32 && n0 + tid < eN) {
                 float c0 = 0.f, me = 0.f, mm = 0.f;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    const float* sc = scr + (w * 32 + tid) * 3;
-                    welford_merge(c0, me, mm, sc[0], sc[1], sc[2]);
+                    const float* sc_ = scr + (w * 32 + tid) * 3;
+                    welford_merge(c0, me, mm, sc_[0], sc_[1], sc_[2]);
                 }
-                float* o = e->stats + ((size_t)P.mtile * e->Cout + n) * 3;
+                float* o = KA()->stats + (row * KA()->Cout + n0 + tid) * 3;
                 o[0] = c0; o[1] = me; o[2] = mm;
             }
+        };
+        if (do_stats) {
+            if (pa.wgstats) {        // running record of this lane: Chan's merge with an approximate reciprocal (its error is far below the rounding of the sums)
+                const float nn = rn + cnt;
+                const float rf = cnt * __builtin_amdgcn_rcpf(fmaxf(nn, 1.f));
+                const float dl = mean - rmean;
+                rmean += dl * rf;
+                rm2 += m2 + dl * dl * rn * rf;
+                rn = nn;
+                if (!has_next) flush(rn, rmean, rm2, (size_t)((blockIdx.x & 7u) * (32u / (unsigned)ntiles) + (blockIdx.x >> 3) / (unsigned)ntiles));
+            } else {
+                const size_t mtile = (size_t)(((P.nb * tilesD + P.td) * tilesH + P.th) * tilesW + P.tw);
+                flush(cnt, mean, m2, mtile);
+            }
         }
+        TSTAMP(9);
+#ifdef E3_WINO_TIMING
+        if (tid == 0 && tbrick == 1) tstamp[15] = (long long)__builtin_amdgcn_s_memrealtime();
+        ++tbrick;
+#endif
         if (!has_next) break;
-        bid = nbid;
-        make_out(bid, P);
+        P = Pn;
     }
 }
 
@@ -827,6 +968,24 @@ int launch_pack_conv_auto(ConvKind kind, int dgrad, const float* w, float* out, 
     return launch_pack_weights(dgrad ? PACK_CONV_DGRAD : PACK_CONV_FWD, w, out, Cout, Cin, T, cdiv(ncols, ct) * ct, s);
 }
 
+// does a Winograd launch of `nblk` workgroup-bricks take the persistent kernel?  (splits == 1 and no BN prologue are the caller's business)
+static bool wino_persistent(size_t nblk, int flags) {
+    static const bool persist = getenv("E3_WINO_NO_PERSIST") == nullptr;
+    static const size_t pmin = getenv("E3_WINO_PERSIST_MIN") ? (size_t)atol(getenv("E3_WINO_PERSIST_MIN")) : 1024;   // (tests force 1: every shape)
+    return persist && nblk >= pmin && !(flags & (1024 | CF_NO_PERSIST));
+}
+// one statistics record per WORKGROUP (256 / ntiles rows of [Cout][3]) instead of one per brick: possible when every workgroup of the
+// 256-workgroup persistent grid stays inside one column tile and the workgroups of a row cover all column tiles -- XCD ranges that start
+// at multiples of ntiles (nblk / 8 a multiple of ntiles) and a step of 32 logical bricks that is one too
+static bool wino_wgstats(size_t nblk, int ntiles) {
+    return nblk >= 256 && nblk % 8 == 0 && (nblk / 8) % (size_t)ntiles == 0 && 32 % ntiles == 0;
+}
+int wino_stats_parts(int N, int D, int H, int W, int ncols, int flags) {
+    const int bricks = wino_bricks(N, D, H, W), ntiles = (ncols + 31) / 32;
+    const size_t nblk = (size_t)bricks * ntiles;
+    return (wino_persistent(nblk, flags) && wino_wgstats(nblk, ntiles)) ? 256 / ntiles : bricks;
+}
+
 int launch_conv3_wino(ConvArgs a, hipStream_t s) {
     a.tilesD = cdiv(a.D, 4); a.tilesH = cdiv(a.H, 4); a.tilesW = cdiv(a.W, 16);
     a.NPad = (a.Ncols + 31) / 32 * 32;
@@ -842,19 +1001,25 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
         E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
-    // persistent variant (staging pipelined across bricks) where a CU gets several bricks: it hides the first-chunk load latency of
-    // every brick but the first (-5..10 % on the 32-/64-channel layers at full resolution); with one or two bricks per CU the plain
-    // kernel is as fast or 1-3 % faster.  E3_WINO_NO_PERSIST=1: A/B switch.
-    static const bool persist = getenv("E3_WINO_NO_PERSIST") == nullptr;
-    static const size_t pmin = getenv("E3_WINO_PERSIST_MIN") ? (size_t)atol(getenv("E3_WINO_PERSIST_MIN")) : 1024;   // (tests force 1: every shape)
+    // persistent variant (staging pipelined across bricks) where a CU gets several bricks; with one or two bricks per CU the plain kernel is as
+    // fast.  E3_WINO_NO_PERSIST=1: A/B switch.
     const unsigned splits = a.splitk > 1 ? (unsigned)a.splitk : 1u;
     if (splits > 1) E3_REQUIRE(!a.bias && !a.stats && !a.epi_scale && !a.pro_scale && a.Cin == a.sk_x, E3_ERR_INVALID, "split-K conv: bias / statistics / fused prologue or epilogue are not available");
-    if (persist && splits == 1 && nblk >= pmin && !a.pro_scale && !(a.flags & (1024 | CF_NO_PERSIST))) {
+    if (splits == 1 && !a.pro_scale && wino_persistent(nblk, a.flags)) {
         constexpr int plds = W_PLDS_FLOATS * 4;
         static bool pattr = false;
         if (!pattr) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel), hipFuncAttributeMaxDynamicSharedMemorySize, plds)); pattr = true; }
         const unsigned pgrid = nblk >= 256 ? 256u : (unsigned)nblk;   // one workgroup per CU (256 is a multiple of the 8 XCDs; smaller grids run one brick each)
-        hipLaunchKernelGGL(conv3_wino_pkernel, dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk);
+        // a workgroup's bricks are L0, L0 + pgrid / 8, ... in the logical (XCD-blocked) order: digits of that step in the mixed radix
+        // (column tile, tw, th, td, sample) for the division-free brick counters
+        WinoPArgs pa{};
+        unsigned st = pgrid == 256u ? 32u : 0u;
+        pa.s_nt = (int)(st % (unsigned)a.ntiles); st /= (unsigned)a.ntiles;
+        pa.s_tw = (int)(st % (unsigned)a.tilesW); st /= (unsigned)a.tilesW;
+        pa.s_th = (int)(st % (unsigned)a.tilesH); st /= (unsigned)a.tilesH;
+        pa.s_td = (int)(st % (unsigned)a.tilesD); pa.s_nb = (int)(st / (unsigned)a.tilesD);
+        pa.wgstats = (a.stats && wino_wgstats(nblk, a.ntiles)) ? 1 : 0;
+        hipLaunchKernelGGL(conv3_wino_pkernel, dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
         E3_CHECK_HIP(hipGetLastError());
         return E3_OK;
     }

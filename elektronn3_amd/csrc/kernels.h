@@ -61,6 +61,7 @@ int launch_splitk_reduce(const float* src, int nsrc, size_t src_stride, const fl
                          float* stats, hipStream_t s);
 int launch_wino_pack_multi(const WinoPackJob* jobs, int njobs, hipStream_t s);   // the Winograd weight transforms of many layers in one launch
 int wino_bricks(int N, int D, int H, int W);
+int wino_stats_parts(int N, int D, int H, int W, int ncols, int flags);   // statistic records a Winograd launch writes (per brick, or per workgroup of the persistent kernel)
 int launch_conv3_wino(ConvArgs a, hipStream_t s);
 // planar 1x3x3: Winograd F(2x2,3x3) (conv_wino2d.hip), same contract
 bool conv_use_wino2d(ConvKind kind, int flags, int N, int D, int H, int W, int K, int ncols);

@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--what', default='fwd,dgrad,wgrad')
     ap.add_argument('--dtype', default='f32', choices=('f32', 'bf16'))
+    ap.add_argument('--no-stats', action='store_true', help='forward without the BatchNorm statistics epilogue')
     a = ap.parse_args()
     what = a.what.split(',')
     tot = {w: [0.0, 0.0] for w in what}
@@ -51,7 +52,7 @@ def main():
         line = f'{name:12s} {fl / 1e9:7.1f} GF '
         for wh in what:
             if wh == 'fwd':
-                ms = timeit(lambda: conv(x, w, b, want_stats=True), a.iters)
+                ms = timeit(lambda: conv(x, w, b, want_stats=not a.no_stats), a.iters)
             elif wh == 'dgrad':
                 ms = timeit(lambda: dgrad(dy, w), a.iters)
             else:
