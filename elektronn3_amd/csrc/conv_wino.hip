@@ -680,15 +680,16 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
         make_brs(Pn.nt);
 #pragma unroll
         for (int g = 0; g < 4; ++g) if (!(E3_WINO_ABL & 128)) load_B(0, g);
-        __syncthreads();
-        TSTAMP(7);
-        const int oh = wave >> 1, ow = wave & 1;
+        // (per-channel constants of the epilogue: requested in front of the barrier, their latency is covered by it)
         const int n = n0 + j;
         const bool nvalid = n < eN;
         const bool aff = e->epi_scale != nullptr;
         const float bias = (e->bias && nvalid) ? e->bias[n] : 0.f;
         float es = 1.f, eh = 0.f;
         if (aff && nvalid) { es = e->epi_scale[n]; eh = e->epi_shift[n]; }
+        __syncthreads();
+        TSTAMP(7);
+        const int oh = wave >> 1, ow = wave & 1;
         f32x4 y[2][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

@@ -17,6 +17,7 @@ Fixtures
     predictor.npz  Predictor.predict tiled + padded-shape case (inference.py:569-687)
     trainsteps.npz 3 AdamW steps: loss trajectory + final weights
     adamw.npz      torch.optim.AdamW alone: 5 steps on random tensors with a changing lr (parameters + both moments per step)
+    unet_nb2_sf32_wino_odd.npz  a train step at a size where the fp32 Winograd kernels (persistent and plain) run (`python make_golden.py wino`)
     unet_nb2_sf32_bf16.npz  the reference module cast to bf16 (BASELINE configs[2]): train step in bf16 and in fp32 on the same numbers
 """
 import importlib.util
@@ -436,6 +437,10 @@ if __name__ == '__main__':
         sys.exit(0)
     torch.set_num_threads(8)
     unet, inference, loss_mod = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'wino':      # a size at which the fp32 Winograd kernels run: start_filts=32, batch 2 of 31 x 61 x 67 -- 1280 bricks at level 0
+        # (the persistent kernel), 384 at level 1 (one brick per workgroup), all-odd extents (partial bricks and tiles in every dimension, autocrop)
+        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf32_wino_odd.npz', seed=32, n_blocks=2, start_filts=32, planar_blocks=(), shape=(31, 61, 67), batch=2)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'norms':     # only the normalization='none' / full_norm=False fixtures
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_nonorm.npz', seed=4, n_blocks=2, start_filts=8, planar_blocks=(), shape=(10, 13, 18), batch=2, normalization='none')
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_planar0_sparsenorm.npz', seed=5, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 18, 21), batch=2, full_norm=False)

@@ -29,7 +29,10 @@ CASES = ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb4_sf8_plana
          'unet_nb3_sf8_attention_odd.npz', 'unet2d_nb3_sf8_attention.npz', 'unet_nb3_sf8_attention_valid_planar0.npz',
          'unet_nb3_sf8_attention_add.npz',
          # elektronn3.models.resunet.UNet: plain ConvBlocks; residual ones (2 per encoder block + planar + odd; with attention, 'add', leaky; no norm)
-         'resunet_nb3_sf8_res00.npz', 'resunet_nb3_sf8_res21_odd.npz', 'resunet_nb3_sf8_res12_add_attention.npz', 'resunet_nb2_sf8_res11_nonorm.npz']
+         'resunet_nb3_sf8_res00.npz', 'resunet_nb3_sf8_res21_odd.npz', 'resunet_nb3_sf8_res12_add_attention.npz', 'resunet_nb2_sf8_res11_nonorm.npz',
+         # start_filts=32 at a size where the fp32 Winograd kernels run (persistent kernel at level 0, plain kernel at level 1, Winograd wgrad), all-odd extents:
+         # closes the chain reference -> fixture -> HIP path for the kernels that carry 85 % of the headline step
+         'unet_nb2_sf32_wino_odd.npz']
 
 
 def build(cfg, sd_np):
@@ -105,6 +108,32 @@ def test_train_step_matches_reference(case):
             assert eb <= 1e-2, (k, eb, er)
     assert any(all(eb <= max(3 * er, 1e-4) for eb, er in errs.values()) for errs in runs), \
         [max(errs.items(), key=lambda kv: kv[1][0]) for errs in runs]
+
+
+@pytest.mark.parametrize('case,key', [('unet_nb2_sf32_bf16.npz', 'bf16'), ('unet_nb2_sf32_f16.npz', 'f16')])
+def test_fp32_path_on_the_fp32_leg_of_the_16bit_fixtures(case, key):
+    """The 16-bit fixtures also hold the REFERENCE's fp32 run (logits_fp32, grad32/*) on the same 16-bit-valued weights and input,
+    start_filts=32: consumed here by the fp32 HIP path (logits 1e-4; gradients within SURVEY 8c's hard bound of 1e-2 rel-L2 per tensor --
+    the fixture has no fp64 twin to take the reference's own noise from)."""
+    import os
+    from helpers import load_bf16_fixture
+    from elektronn3_amd.unet import UNet
+    g = load_bf16_fixture(os.path.join(os.path.dirname(__file__), 'golden', case))
+    sd = {k[4:]: v.float() for k, v in g.items() if k.startswith('sd0/')}
+    m = UNet(1, 2, n_blocks=int(g['cfg.n_blocks']), start_filts=int(g['cfg.start_filts']))
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    x = g['x'].float().cuda()
+    y = m(x)
+    ref = g['logits_fp32']
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    y.backward(g['dlogits'].float().cuda())
+    for k, p in m.named_parameters():
+        if k.endswith('.bias') and 'norm' not in k and not k.startswith('conv_final'):
+            continue          # analytically zero (bias in front of a train-mode BatchNorm)
+        r = g['grad32/' + k].float()
+        e = float((p.grad.cpu() - r).norm() / r.norm())
+        assert e <= 1e-2, (k, e)
 
 
 def test_eval_forward_matches_reference():
