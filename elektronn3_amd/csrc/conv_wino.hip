@@ -523,19 +523,27 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
     // / empty mask) and the staging cursor stays -- the raw halo of unit u + 2 and the first weights of the next brick are requested in the
     // epilogue instead, after its register-hungry part (88 registers less to keep alive across the output transform).  `cB`: chunk whose
     // weights are requested.
+    f32x4 tn[4][4];            // the next chunk's tile, read from LDS while the current chunk's last MFMAs run
+    auto rd_imm = [](int h, int w) { return (((h & 1) * 2 + (w & 1)) * W_CLASS + (h >> 1) * 9 + (w >> 1)) * 8; };
     auto chunk = [&](auto zero_tag, bool last, int cB, int tchunk = 0) {
         constexpr bool ZERO = decltype(zero_tag)::value;
         TSTAMPC(1);
-        // ---- VALU phase: H and W passes of B^T d B on this lane's tile of plane (td, pd), 4 channels at a time; D pass of the staged halo
+        // ---- VALU phase: H and W passes of B^T d B on this lane's tile of plane (td, pd), 4 channels at a time; D pass of the staged halo.
+        // The tile's 16 LDS reads were issued during the last MFMAs of the previous chunk (`tn`, below); only a brick's first chunk reads here
+        // (its predecessor's reads would have to stay alive across the epilogue).
         f32x4 t[4][4];
+        if (ZERO) {
 #pragma unroll
-        for (int h = 0; h < 4; ++h)
+            for (int h = 0; h < 4; ++h)
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int imm = (((h & 1) * 2 + (w & 1)) * W_CLASS + (h >> 1) * 9 + (w >> 1)) * 8;
-                t[h][w] = *reinterpret_cast<const f32x4*>(cur + rdA[h >> 1] + imm);
-            }
-        __builtin_amdgcn_sched_barrier(0);      // (the LDS reads are issued before anything waits for the staged raw halo)
+                for (int w = 0; w < 4; ++w) t[h][w] = *reinterpret_cast<const f32x4*>(cur + rdA[h >> 1] + rd_imm(h, w));
+            __builtin_amdgcn_sched_barrier(0);      // (the LDS reads are issued before anything waits for the staged raw halo)
+        } else {
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) t[h][w] = tn[h][w];
+        }
         dtransform();
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -579,6 +587,18 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int g = q >> 2, ks = q & 3;
+            if (q == 12) {
+                // The chunk's barrier sits in front of the last 16 MFMAs: unit u + 1 is complete in `nxt` (its stores were issued with the
+                // first MFMAs) and every wave is done with `cur`.  The last quads then carry the next chunk's LDS reads -- rows 0..2 of the
+                // tile go into registers whose MFMAs are issued, row 3 follows the last quad -- so the next VALU phase starts with its operands.
+                __syncthreads();
+                TSTAMPC(4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (q >= 12 && q < 15) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) tn[q - 12][w] = *reinterpret_cast<const f32x4*>(nxt + rdA[(q - 12) >> 1] + rd_imm(q - 12, w));
+            }
             if (q < 8 && !(E3_WINO_ABL & 1)) *reinterpret_cast<f32x4*>(nxt + q * W_PLANE + a_dst) = pD[q];
             if (q >= 1 && q < 7 && !(E3_WINO_ABL & 2)) {
                 const int it = q - 1;
@@ -604,23 +624,27 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x004, 12, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x004, 12, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x004, 12, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x004, 12, 0);
             if (!(E3_WINO_ABL & 16)) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb)
             if (!(E3_WINO_ABL & 4)) Bv[12 + pb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_voff + pb * 1024, (cB * 64 + 12) * 1024, 0));
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tn[3][w] = *reinterpret_cast<const f32x4*>(nxt + rdA[1] + rd_imm(3, w));
         TSTAMPC(3);
-        __syncthreads();
-        TSTAMPC(4);
         { float* tsw = cur; cur = nxt; nxt = tsw; }
     };
 
