@@ -1,5 +1,6 @@
 // Internal plan structures shared by the fp32 executor (unet_plan.cpp) and the bf16 executor (unet_bf16.cpp).
 #pragma once
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,14 +54,21 @@ struct e3_unet_plan {
     std::vector<int> enc_last_unit;   // per level: index of the encoder block's last unit
     std::vector<int> up_unit;         // per level < n_blocks - 1: index of the decoder block's up-convolution unit
     int enc_convs = 2, dec_convs = 2; // plain conv units per encoder / decoder block (UNet: 2; ResUNet: 2 per ConvBlock)
-    // nn.RReLU in train mode: per-call seed (0 = off: fixed slope cfg.act_slope) and the slope interval (e3_unet_set_rrelu)
-    unsigned rrelu_seed = 0; float rrelu_lo = 0.125f, rrelu_hi = 1.f / 3.f;
+    // nn.RReLU in train mode: per-call seed (0 = off: fixed slope cfg.act_slope) and the slope interval.  e3_unet_set_rrelu stores them PER
+    // CALLING THREAD (keyed by the plan's uid): a plan is shared by every module with its configuration, and two threads driving two such
+    // modules -- one RReLU-train, one not; nn.DataParallel replicas -- must not see each other's seed between their set_rrelu and their call.
+    unsigned uid = 0;
+    struct RRelu { unsigned seed = 0; float lo = 0.125f, hi = 1.f / 3.f; };
+    RRelu& rrelu_state() const;                            // this thread's state for this plan (unet_plan.cpp)
     ActArg rrelu_of(ActArg a, int unit) const {           // unit's activation with its own stream of slopes
-        if (!rrelu_seed) return a;
-        const unsigned sd = (rrelu_seed * 0x9E3779B1u) ^ ((unsigned)(unit + 1) * 0x85EBCA77u);
-        return a.rrelu(sd | 1u, rrelu_lo, rrelu_hi);
+        const RRelu& r = rrelu_state();
+        if (!r.seed) return a;
+        const unsigned sd = (r.seed * 0x9E3779B1u) ^ ((unsigned)(unit + 1) * 0x85EBCA77u);
+        return a.rrelu(sd | 1u, r.lo, r.hi);
     }
-    // profiling
+    // profiling (e3_unet_profile_select / _read: a measurement aid of bench.py and tools/layer_table.py, plan-wide on purpose -- the backward of a
+    // step runs on autograd's worker thread -- and therefore the one piece of plan state that is NOT per thread; the event list is mutex-guarded)
+    std::mutex prof_mutex;
     int prof_layer = -1, prof_which = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;

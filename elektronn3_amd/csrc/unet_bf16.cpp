@@ -125,6 +125,7 @@ struct ProfB {      // same per-layer HIP-event profiling hook as the fp32 execu
     ProfB(e3_unet_plan* plan, hipStream_t st, int layer, int which) : p(plan), s(st) {
         on = plan->prof_layer >= 0 && plan->prof_layer == layer && plan->prof_which == which;
         if (on) {
+            std::lock_guard<std::mutex> lk(p->prof_mutex);
             if (p->prof_used == p->prof_events.size()) {
                 hipEvent_t a, b;
                 if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }

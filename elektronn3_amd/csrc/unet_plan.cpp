@@ -10,7 +10,9 @@
 //           into the first half (torch.cat, unet.py:398-399, never runs); pooled outputs; per-BN mean/invstd/
 //           scale/shift vectors.
 //   scratch packed weights, BN statistic records, gradient ping-pong buffers per level, split-K slabs.
+#include <atomic>
 #include <cstdlib>
+#include <unordered_map>
 #include <vector>
 
 #include "plan_internal.h"
@@ -48,6 +50,11 @@ void add_unit(e3_unet_plan* p, const std::string& conv, const std::string& bn, i
 LevelDims mkdims(int N, int D, int H, int W) { return {D, H, W, (size_t)N * (size_t)(D > 0 ? D : 0) * (size_t)(H > 0 ? H : 0) * (size_t)(W > 0 ? W : 0)}; }
 
 }  // namespace
+
+e3_unet_plan::RRelu& e3_unet_plan::rrelu_state() const {
+    static thread_local std::unordered_map<unsigned, RRelu> tls;      // (uid, not the address: a destroyed plan's address may be reused)
+    return tls[uid];
+}
 
 void net_dims(const e3_unet_plan* p, int N, int D, int H, int W, NetDims& nd) {
     const int nb = p->cfg.n_blocks;
@@ -344,6 +351,7 @@ struct Prof {
     Prof(e3_unet_plan* plan, hipStream_t st, int layer, int which) : p(plan), s(st) {
         on = plan->prof_layer >= 0 && plan->prof_layer == layer && plan->prof_which == which;
         if (on) {
+            std::lock_guard<std::mutex> lk(p->prof_mutex);
             if (p->prof_used == p->prof_events.size()) {
                 hipEvent_t a, b;
                 if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
@@ -382,6 +390,8 @@ int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
                "residual shortcuts need conv_mode='same' (a 'valid' conv2 is smaller than the block input it would be added to)");
     const bool last_norm = cfg->normalization != 0, all_norm = last_norm && cfg->full_norm != 0;
     e3_unet_plan* p = new e3_unet_plan();
+    static std::atomic<unsigned> next_uid{1};
+    p->uid = next_uid.fetch_add(1);
     p->cfg = *cfg;
     p->n_bn = 0;
     const int nb = cfg->n_blocks;
@@ -516,7 +526,8 @@ int e3_unet_conv_info(const e3_unet_plan* plan, int layer, char* name, int name_
 int e3_unet_set_rrelu(e3_unet_plan* plan, double lower, double upper, unsigned seed) {
     E3_REQUIRE(plan, E3_ERR_INVALID, "null plan");
     E3_REQUIRE(seed == 0 || (lower >= 0.0 && lower <= upper && upper <= 1.0), E3_ERR_INVALID, "RReLU needs 0 <= lower <= upper <= 1");
-    plan->rrelu_seed = seed; plan->rrelu_lo = (float)lower; plan->rrelu_hi = (float)upper;
+    e3_unet_plan::RRelu& r = plan->rrelu_state();       // per calling thread: the forward / backward call that follows on this thread reads it
+    r.seed = seed; r.lo = (float)lower; r.hi = (float)upper;
     return E3_OK;
 }
 

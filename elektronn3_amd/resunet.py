@@ -8,7 +8,9 @@ keys (``down_convs.i.convs.k.conv1.weight`` ..., ``up_convs.i.convs.k.proj.weigh
 whose native executor runs it: a residual unit's conv writes its accumulations next to the shortcut, and the BatchNorm statistics pass sums the
 two (csrc/unet_plan.cpp).  fp32 kernels; bf16 modules compute in fp32 on up-cast copies.
 """
-from typing import Sequence, Union
+from typing import List, Sequence, Union
+
+import torch
 
 from torch import nn
 
@@ -57,7 +59,7 @@ class DownBlock(nn.Module):
         for _ in range(res_blocks - 1):
             convs.append(ConvBlock(out_channels, out_channels, planar=planar, activation=activation, normalization=normalization,
                                    conv_mode=conv_mode, residual=on))
-        self.convs = nn.Sequential(*convs)
+        self.convs = nn.ModuleList(convs)      # (the reference holds them in a Sequential: same state_dict keys; a ModuleList keeps TorchScript from compiling a chained forward)
         self.pool = _LAYERS[dim][2](kernel_size=(1, 2, 2) if planar else 2, ceil_mode=True) if pooling else nn.Identity()
 
     def forward(self, x):
@@ -89,7 +91,7 @@ class UpBlock(nn.Module):
         for _ in range(res_blocks - 1):
             convs.append(ConvBlock(out_channels, out_channels, planar=planar, activation=activation, normalization=normalization,
                                    conv_mode=conv_mode, residual=on))
-        self.convs = nn.Sequential(*convs)
+        self.convs = nn.ModuleList(convs)      # (the reference holds them in a Sequential: same state_dict keys; a ModuleList keeps TorchScript from compiling a chained forward)
 
     def forward(self, enc, dec):
         raise RuntimeError('elektronn3_amd sub-modules only hold parameters; call UNet.forward')
@@ -140,3 +142,108 @@ class UNet(_unet.UNet):
 
     def _variant_key(self):
         return (1, int(self.enc_res_blocks), int(self.dec_res_blocks))
+
+    def _scripted_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """``forward`` as TorchScript sees it (the reference's resunet is scriptable and ``Trainer._save_model`` scripts the model when
+        ``save_jit='script'``, trainer.py:871-887): the tensors in the native parameter-table order -- per ConvBlock: conv1, norm1, [act1],
+        conv2, norm2, [act2], [proj]; per decoder block the up-convolution with norm0 / [act0] first -- and ONE call of e3unet::unet_fwd."""
+        if not self._script_ok:
+            raise RuntimeError('scripted elektronn3_amd.resunet.UNet: batch / group / no normalization, no attention, activations other than rrelu')
+        t: List[torch.Tensor] = []
+        bufs: List[torch.Tensor] = []
+        counters: List[torch.Tensor] = []
+        mom: List[float] = []
+        for blk in self.down_convs:
+            for cb in blk.convs:
+                t.append(cb.conv1.weight)
+                b1 = cb.conv1.bias
+                assert b1 is not None
+                t.append(b1)
+                if hasattr(cb.norm1, 'weight'):
+                    t.append(cb.norm1.weight); t.append(cb.norm1.bias)
+                    if hasattr(cb.norm1, 'running_mean'):
+                        rm, rv, nb, mo = cb.norm1.running_mean, cb.norm1.running_var, cb.norm1.num_batches_tracked, cb.norm1.momentum
+                        assert rm is not None and rv is not None and nb is not None and mo is not None
+                        t.append(rm); t.append(rv); bufs.append(rm); bufs.append(rv); counters.append(nb); mom.append(mo)
+                if hasattr(cb.act1, 'weight'):
+                    t.append(cb.act1.weight)
+                t.append(cb.conv2.weight)
+                b2 = cb.conv2.bias
+                assert b2 is not None
+                t.append(b2)
+                if hasattr(cb.norm2, 'weight'):
+                    t.append(cb.norm2.weight); t.append(cb.norm2.bias)
+                    if hasattr(cb.norm2, 'running_mean'):
+                        rm, rv, nb, mo = cb.norm2.running_mean, cb.norm2.running_var, cb.norm2.num_batches_tracked, cb.norm2.momentum
+                        assert rm is not None and rv is not None and nb is not None and mo is not None
+                        t.append(rm); t.append(rv); bufs.append(rm); bufs.append(rv); counters.append(nb); mom.append(mo)
+                if hasattr(cb.act2, 'weight'):
+                    t.append(cb.act2.weight)
+                if hasattr(cb.proj, 'weight'):
+                    t.append(cb.proj.weight)
+                    bp = cb.proj.bias
+                    assert bp is not None
+                    t.append(bp)
+        for ub in self.up_convs:
+            if hasattr(ub.upconv, 'conv'):
+                t.append(ub.upconv.conv.weight)
+                b0 = ub.upconv.conv.bias
+            else:
+                t.append(ub.upconv.weight)
+                b0 = ub.upconv.bias
+            assert b0 is not None
+            t.append(b0)
+            if hasattr(ub.norm0, 'weight'):
+                t.append(ub.norm0.weight); t.append(ub.norm0.bias)
+                if hasattr(ub.norm0, 'running_mean'):
+                    rm, rv, nb, mo = ub.norm0.running_mean, ub.norm0.running_var, ub.norm0.num_batches_tracked, ub.norm0.momentum
+                    assert rm is not None and rv is not None and nb is not None and mo is not None
+                    t.append(rm); t.append(rv); bufs.append(rm); bufs.append(rv); counters.append(nb); mom.append(mo)
+            if hasattr(ub.act0, 'weight'):
+                t.append(ub.act0.weight)
+            for cb in ub.convs:
+                t.append(cb.conv1.weight)
+                b1 = cb.conv1.bias
+                assert b1 is not None
+                t.append(b1)
+                if hasattr(cb.norm1, 'weight'):
+                    t.append(cb.norm1.weight); t.append(cb.norm1.bias)
+                    if hasattr(cb.norm1, 'running_mean'):
+                        rm, rv, nb, mo = cb.norm1.running_mean, cb.norm1.running_var, cb.norm1.num_batches_tracked, cb.norm1.momentum
+                        assert rm is not None and rv is not None and nb is not None and mo is not None
+                        t.append(rm); t.append(rv); bufs.append(rm); bufs.append(rv); counters.append(nb); mom.append(mo)
+                if hasattr(cb.act1, 'weight'):
+                    t.append(cb.act1.weight)
+                t.append(cb.conv2.weight)
+                b2 = cb.conv2.bias
+                assert b2 is not None
+                t.append(b2)
+                if hasattr(cb.norm2, 'weight'):
+                    t.append(cb.norm2.weight); t.append(cb.norm2.bias)
+                    if hasattr(cb.norm2, 'running_mean'):
+                        rm, rv, nb, mo = cb.norm2.running_mean, cb.norm2.running_var, cb.norm2.num_batches_tracked, cb.norm2.momentum
+                        assert rm is not None and rv is not None and nb is not None and mo is not None
+                        t.append(rm); t.append(rv); bufs.append(rm); bufs.append(rv); counters.append(nb); mom.append(mo)
+                if hasattr(cb.act2, 'weight'):
+                    t.append(cb.act2.weight)
+                if hasattr(cb.proj, 'weight'):
+                    t.append(cb.proj.weight)
+                    bp = cb.proj.bias
+                    assert bp is not None
+                    t.append(bp)
+        t.append(self.conv_final.weight)
+        bf = self.conv_final.bias
+        assert bf is not None
+        t.append(bf)
+        if self._script_key[5] == 2.0:       # nn.GroupNorm: statistics per sample in training and eval mode alike: one call per sample
+            ys: List[torch.Tensor] = []
+            for n in range(x.shape[0]):
+                ys.append(torch.ops.e3unet.unet_fwd(x[n:n + 1], t, self._script_key, mom, True, False)[0])
+            return torch.cat(ys, 0)
+        outs = torch.ops.e3unet.unet_fwd(x, t, self._script_key, mom, self.training, False)
+        if self.training:
+            for i in range(len(bufs)):
+                bufs[i].copy_(outs[2 + i])
+            for c in counters:
+                c.add_(1)
+        return outs[0]

@@ -96,6 +96,12 @@ def _get_scratch(device, nbytes):
     return buf
 
 
+def _alloc_saved(device, nbytes):
+    """The `saved` arena of one training forward (owned by its autograd node).  A function of its own so that tests can hand the library
+    canary-framed memory (tests/test_unet_gpu.py::test_arenas_are_not_overrun)."""
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
 def release_scratch():
     """Drop the cached scratch buffers (they are re-created on the next call)."""
     _scratch.clear()
@@ -129,7 +135,7 @@ def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, traini
     b16 = want16 if (want16 and not x_needs_grad and not frozen and plan.bf16_supported() and not _NO_BF16) else None
     xin = x.detach().to(b16 if b16 is not None else torch.float32).contiguous()
     saved_bytes, scratch_bytes = plan.sizes(N, D, H, W, training, bf16=b16)
-    saved = torch.empty(max(saved_bytes, 256), dtype=torch.uint8, device=dev) if training else None
+    saved = _alloc_saved(dev, max(saved_bytes, 256)) if training else None
     scratch = _get_scratch(dev, max(scratch_bytes, 256))
     Do, Ho, Wo = plan.out_dims(D, H, W)      # == (D, H, W) unless conv_mode='valid'
     y = torch.empty((N, plan.out_channels, Do, Ho, Wo), dtype=torch.float32, device=dev)
@@ -683,8 +689,7 @@ class UNet(nn.Module):
         self.conv_final = _LAYERS[dim][0](outs, out_channels, kernel_size=1)
         self.apply(self.weight_init)
         self._script_key = [float(v) for v in self._plan_key()]      # (read by the scripted forward)
-        self._script_ok = (normalization != 'instance' and dim == 3 and self._rrelu_interval() is None and not attention     # (train-mode RReLU needs a per-call seed)
-                           and res_blocks is None)
+        self._script_ok = (normalization != 'instance' and dim == 3 and self._rrelu_interval() is None and not attention)     # (train-mode RReLU needs a per-call seed)
 
     @staticmethod
     def weight_init(m):

@@ -40,10 +40,38 @@ def test_scripted_forward_gathers_the_parameter_table_in_order(kw, monkeypatch):
     torch.jit.script(m)                      # compiles (TorchScript resolves e3unet::unet_fwd from the operator registry)
 
 
+@pytest.mark.parametrize('kw', [dict(), dict(enc_res_blocks=1, dec_res_blocks=1), dict(enc_res_blocks=2, dec_res_blocks=1, normalization='none', activation='prelu', planar_blocks=(0,))])
+def test_resunet_scripts_and_gathers_its_parameter_table_in_order(kw, monkeypatch):
+    """elektronn3.models.resunet.UNet is scriptable and Trainer._save_model scripts it with save_jit='script' (trainer.py:871-887): the mirror
+    must compile too (the inherited forward walked blk.conv1 / norm0, which the ResUNet blocks do not have) and hand the operator
+    the plan's table (ConvBlocks: conv1, norm1, act1, conv2, norm2, act2, proj)."""
+    from elektronn3_amd.resunet import UNet
+    m = UNet(1, 2, n_blocks=3, start_filts=8, **kw)
+    plan = m._plan()
+    want = [m.get_parameter(n) if k == 0 else m.get_buffer(n) for n, k in zip(plan.names, plan.kinds)]
+    seen = {}
+
+    def fake_op(x, tensors, key, momenta, training, softmax):
+        seen.update(tensors=tensors, key=key, momenta=momenta)
+        bufs = [t.clone() for t, k in zip(tensors, plan.kinds) if k != 0]
+        return [x.new_zeros(1), x.new_zeros(0)] + (bufs if training else [])
+
+    monkeypatch.setattr(torch.ops.e3unet, 'unet_fwd', fake_op, raising=False)
+    m.train()
+    m._scripted_forward(torch.zeros(1, 1, 8, 8, 8))
+    assert len(seen['tensors']) == len(want) and all(a is b for a, b in zip(seen['tensors'], want))
+    assert tuple(seen['key']) == tuple(float(v) for v in m._plan_key())
+    monkeypatch.undo()
+    torch.jit.script(m)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize('kw', [dict(), dict(normalization='group', planar_blocks=(0,))])
+@pytest.mark.parametrize('kw', [dict(), dict(normalization='group', planar_blocks=(0,)), dict(resunet=True, enc_res_blocks=1, dec_res_blocks=1)])
 def test_script_save_load_gives_identical_results(kw):
     from elektronn3_amd.unet import UNet
+    kw = dict(kw)
+    if kw.pop('resunet', False):
+        from elektronn3_amd.resunet import UNet
     torch.manual_seed(0)
     m = UNet(1, 2, n_blocks=3, start_filts=8, **kw).cuda()
     x = torch.randn(2, 1, 12, 20, 24, device='cuda')

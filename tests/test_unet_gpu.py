@@ -1128,3 +1128,94 @@ def test_rrelu_train_mode_draws_slopes_and_backward_recomputes_them():
     with torch.no_grad():
         ye = m(x.detach())
     torch.testing.assert_close(ye[:, 0:1], -(((1.0 / 8 + 1.0 / 3) / 2) ** 2) * x.detach(), rtol=1e-5, atol=1e-7)
+
+
+def test_two_threads_share_one_plan_without_sharing_rrelu_state():
+    """Plans are cached per configuration and shared by every module (and thread) that has it; the RReLU seed of a call is per calling
+    thread (e3_unet_set_rrelu), so a train-mode RReLU module on one thread and an eval-mode module of the SAME configuration on another
+    give exactly the results of the serial runs (nn.DataParallel-style replicas, train_benchmark.py:109-110)."""
+    import threading
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(0)
+    kw = dict(n_blocks=2, start_filts=8, activation='rrelu')
+    ma, mb = UNet(1, 2, **kw).cuda(), UNet(1, 2, **kw).cuda()
+    mb.load_state_dict(ma.state_dict())
+    assert ma._plan() is mb._plan()
+    ma.train(); mb.eval()
+    x = torch.randn(2, 1, 12, 16, 20, device='cuda')
+    dy = torch.randn(2, 2, 12, 16, 20, device='cuda')
+    sd0 = {k: v.clone() for k, v in ma.state_dict().items()}
+
+    def train_steps(n):
+        ma.load_state_dict(sd0)
+        torch.manual_seed(7)
+        outs = []
+        for _ in range(n):
+            ma.zero_grad(set_to_none=True)
+            y = ma(x)
+            y.backward(dy)
+            outs.append((y.detach().clone(), ma.down_convs[0].conv1.weight.grad.clone()))
+        torch.cuda.synchronize()
+        return outs
+
+    def eval_steps(n, res):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(n):
+                res.append(mb(x).clone())
+        s.synchronize()
+
+    serial_train = train_steps(6)
+    serial_eval = []
+    eval_steps(3, serial_eval)
+    assert not torch.equal(serial_train[0][0], serial_eval[0])          # (train mode really draws slopes)
+    par_eval = []
+    th = threading.Thread(target=eval_steps, args=(40, par_eval))
+    th.start()
+    par_train = train_steps(6)
+    th.join()
+    for (ys, gs), (yp, gp) in zip(serial_train, par_train):
+        assert torch.equal(ys, yp) and torch.equal(gs, gp)
+    assert all(torch.equal(e, serial_eval[0]) for e in par_eval)
+
+
+@pytest.mark.parametrize('name,kw,shape,dtype', [
+    ('cfg2', dict(n_blocks=4, start_filts=32), (2, 1, 64, 128, 128), torch.float32),
+    ('cfg4', dict(n_blocks=4, start_filts=64, planar_blocks=(0, 1)), (1, 1, 32, 256, 256), torch.float32),
+    ('odd', dict(n_blocks=3, start_filts=16), (2, 1, 21, 45, 47), torch.float32),
+    ('odd_valid', dict(n_blocks=3, start_filts=8, conv_mode='valid', planar_blocks=(0,)), (1, 1, 21, 45, 47), torch.float32),
+    ('cfg3_bf16', dict(n_blocks=4, start_filts=32), (2, 1, 64, 128, 128), torch.bfloat16),
+])
+def test_arenas_are_not_overrun(name, kw, shape, dtype, monkeypatch):
+    """`saved` and `scratch` are sized by e3_unet_sizes and owned by the caller; a kernel that writes past its share of an arena would
+    corrupt a neighbour's memory unnoticed.  The library gets EXACTLY the requested bytes framed by 1 MiB of canaries on both sides
+    (forward + backward of cfg 2, cfg 4 at its own size, all-odd crops incl. conv_mode='valid', the native bf16 path); the canaries
+    must be intact afterwards and the arenas must have been written at all."""
+    from elektronn3_amd import unet as U
+    PAD = 1 << 20
+    frames = []
+
+    def framed(device, nbytes):
+        nbytes = int(nbytes)
+        big = torch.full((nbytes + 2 * PAD,), 0xA5, dtype=torch.uint8, device=device)
+        frames.append((big, nbytes))
+        return big[PAD:PAD + nbytes]
+
+    U.release_scratch()
+    monkeypatch.setattr(U, '_alloc_saved', framed)
+    monkeypatch.setattr(U, '_get_scratch', framed)
+    torch.manual_seed(0)
+    m = U.UNet(1, 2, **kw).cuda().train()
+    if dtype != torch.float32:
+        m = m.to(dtype)
+    x = torch.randn(*shape, device='cuda').to(dtype)
+    y = m(x)
+    y.float().square().mean().backward()
+    torch.cuda.synchronize()
+    assert len(frames) >= 3          # saved + scratch of the forward, scratch of the backward
+    for big, n in frames:
+        assert bool((big[:PAD] == 0xA5).all()) and bool((big[PAD + n:] == 0xA5).all()), (name, n)
+        assert not bool((big[PAD:PAD + n] == 0xA5).all())
+    assert all(torch.isfinite(p.grad.float()).all() for p in m.parameters())
+    monkeypatch.undo()
+    U.release_scratch()
