@@ -314,10 +314,19 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------ final 1x1x1 conv, forward (+ optional softmax)
-template <int COUT>
+// LOSS: the criterion of the training example (weighted CE + Dice, loss.hip) is evaluated on the logits while they are in registers --
+// the voxel's softmax, -log p[target], and the per-class Dice sums go into per-thread accumulators and leave as ONE partial row per
+// workgroup in the layout of ce_dice_fwd_kernel, so ce_dice_finalize_kernel / e3_ce_dice_bwd work unchanged ("loss on
+// device fused with conv_final": the logits are not re-read and the separate pass over logits + target disappears).
+struct HeadLossArgs { const long long* target; const float* w; float* partial; };
+template <int COUT, bool LOSS>
 __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, int C, const float* __restrict__ w,
                                       const float* __restrict__ bias, float* __restrict__ y, size_t S, int N, int lpv, int softmax,
-                                      const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, ActArg pro_act) {
+                                      const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, ActArg pro_act, HeadLossArgs la) {
+    constexpr int NV = 2 + 3 * COUT;
+    float lacc[LOSS ? NV : 1];
+#pragma unroll
+    for (int i = 0; i < (LOSS ? NV : 1); ++i) lacc[i] = 0.f;
     const float pro_slope = pro_act.get();
     // pro_scale/pro_shift: `a` is the RAW output of the last conv; its BatchNorm + ReLU, a := relu(a*scale + shift), is applied while
     // loading (same expression as bn_relu_apply_kernel) -- the last activation of the network is never written or re-read
@@ -391,6 +400,25 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
                 const size_t n = v / S, sp = v % S;
 #pragma unroll
                 for (int co = 0; co < COUT; ++co) acc[u][co] += bias ? bias[co] : 0.f;
+                if (LOSS) {          // same expressions as ce_dice_fwd_kernel (softmax_c) on the values that are stored below
+                    float m = acc[u][0];
+#pragma unroll
+                    for (int co = 1; co < COUT; ++co) m = fmaxf(m, acc[u][co]);
+                    float pr[COUT], sm = 0.f;
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) { pr[co] = __expf(acc[u][co] - m); sm += pr[co]; }
+                    const float inv = 1.f / sm, lse = m + __logf(sm);
+                    const int t = (int)la.target[v];
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) {
+                        const float pc = pr[co] * inv;
+                        const bool is = t == co;
+                        lacc[2 + co] += is ? pc : 0.f;
+                        lacc[2 + COUT + co] += pc;
+                        lacc[2 + 2 * COUT + co] += is ? 1.f : 0.f;
+                        if (is) { const float wc = la.w ? la.w[co] : 1.f; lacc[0] += wc * (lse - acc[u][co]); lacc[1] += wc; }
+                    }
+                }
                 if (softmax) {
                     float m = acc[u][0];
 #pragma unroll
@@ -406,6 +434,19 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
                 for (int co = 0; co < COUT; ++co) y[(n * COUT + co) * S + sp] = acc[u][co];
             }
         }
+    }
+    if (LOSS) {              // one partial row per workgroup, fixed order (wave butterflies, then the 4 waves in turn)
+        __shared__ float red[4][NV];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float sv = lacc[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
+            if (lane == 0) red[wave][i] = sv;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < NV) la.partial[(size_t)blockIdx.x * NV + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     }
 }
 
@@ -578,8 +619,24 @@ int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, cons
     const int lpv = final_lpv(C);
     const size_t vox = (size_t)N * S;
     size_t g = (vox * lpv + 255) / 256; if (g > 4096) g = 4096; if (g == 0) g = 1;
-    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_fwd_kernel<CO>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, S, N, lpv, softmax, pro_scale, pro_shift, pro_slope));
+    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_fwd_kernel<CO, false>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, S, N, lpv, softmax, pro_scale, pro_shift, pro_slope, HeadLossArgs{}));
     E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+// head + criterion partial sums; returns the number of partial rows (= workgroups) written to `partial` ([rows][2 + 3 Cout]) through *rows
+int launch_conv_final_fwd_loss(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y, int Cout, size_t S, int N, hipStream_t s,
+                               const float* pro_scale, const float* pro_shift, ActArg pro_slope, const long long* target, const float* class_w,
+                               float* partial, int max_rows, int* rows) {
+    E3_REQUIRE(C % 4 == 0 && a_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
+    E3_REQUIRE(Cout >= 2, E3_ERR_INVALID, "the criterion needs at least two classes");
+    const int lpv = final_lpv(C);
+    const size_t vox = (size_t)N * S;
+    size_t g = (vox * lpv + 255) / 256; if (g > (size_t)max_rows) g = (size_t)max_rows; if (g == 0) g = 1;
+    const HeadLossArgs la{target, class_w, partial};
+    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_fwd_kernel<CO, true>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, S, N, lpv, 0, pro_scale, pro_shift, pro_slope, la));
+    E3_CHECK_HIP(hipGetLastError());
+    *rows = (int)g;
     return E3_OK;
 }
 

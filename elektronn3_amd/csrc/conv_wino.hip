@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
     long long* const tstamp = reinterpret_cast<long long*>(KA()->stats) + (size_t)blockIdx.x * 32;
     int tbrick = 0;
 #define TSTAMP(i) do { if (tid == 0 && tbrick == 1) tstamp[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#define TSTAMPC(i) do { if (tid == 0 && tbrick == 1 && tchunk == 1) tstamp[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define TSTAMPC(i) do { if (tid == 0 && tbrick == 1) { const long long tm_ = (long long)__builtin_amdgcn_s_memtime(); if (tchunk == 1) tstamp[i] = tm_; if (tchunk == NCH - 1) tstamp[16 + i] = tm_; if (tchunk == NCH - 2) tstamp[24 + i] = tm_; } } while (0)
     if (tid == 0) tstamp[14] = (long long)__builtin_amdgcn_s_memrealtime();
 #else
 #define TSTAMP(i)
@@ -996,7 +996,7 @@ int launch_pack_conv_auto(ConvKind kind, int dgrad, const float* w, float* out, 
 // does a Winograd launch of `nblk` workgroup-bricks take the persistent kernel?  (splits == 1 and no BN prologue are the caller's business)
 static bool wino_persistent(size_t nblk, int flags) {
     static const bool persist = getenv("E3_WINO_NO_PERSIST") == nullptr;
-    static const size_t pmin = getenv("E3_WINO_PERSIST_MIN") ? (size_t)atol(getenv("E3_WINO_PERSIST_MIN")) : 1024;   // (tests force 1: every shape)
+    static const size_t pmin = getenv("E3_WINO_PERSIST_MIN") ? (size_t)atol(getenv("E3_WINO_PERSIST_MIN")) : 512;    // two bricks per workgroup are enough (measured: 512 = 1024 - 0.7 % of the step; tests force 1: every shape)
     return persist && nblk >= pmin && !(flags & (1024 | CF_NO_PERSIST));
 }
 // one statistics record per WORKGROUP (256 / ntiles rows of [Cout][3]) instead of one per brick: possible when every workgroup of the

@@ -118,6 +118,9 @@ int launch_conv_small_wgrad(const float* x, int Cin, const float* dy, int dy_ldc
 int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y_ncdhw,
                           int Cout, size_t voxels_per_sample, int N, int softmax, hipStream_t s,
                           const float* pro_scale = nullptr, const float* pro_shift = nullptr, ActArg pro_act = ActArg(0.f));   // a := act(a*scale + shift) while loading
+int launch_conv_final_fwd_loss(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y_ncdhw, int Cout, size_t voxels_per_sample, int N,
+                               hipStream_t s, const float* pro_scale, const float* pro_shift, ActArg pro_act, const long long* target, const float* class_w,
+                               float* partial /*[rows][2 + 3 Cout]*/, int max_rows, int* rows);     // head + partial sums of the CE + Dice criterion (loss.hip)
 int conv_final_bwd_parts(size_t total_voxels);
 int launch_conv_final_bwd(const float* a, int a_ldc, int C, const float* w, const float* dy_ncdhw, float* da, int da_ldc,
                           float* part /*[parts][Cout][C+1]*/, int Cout, size_t voxels_per_sample, int N, hipStream_t s,
@@ -125,6 +128,9 @@ int launch_conv_final_bwd(const float* a, int a_ldc, int C, const float* w, cons
 
 // ---------------------------------------------------------------- weighted CE + Dice criterion (loss.hip)
 size_t ce_dice_workspace_floats(int C);
+constexpr int CE_DICE_MAX_ROWS = 4096;      // partial rows the workspace holds (ce_dice_fwd_kernel writes 1024, the fused head up to 4096)
+// loss and backward coefficients from `rows` partial rows already in the workspace (the second half of launch_ce_dice_fwd)
+int launch_ce_dice_finalize(const float* w, int C, int rows, float a, float b, float eps, float smooth, float* workspace, float* loss_out, hipStream_t s);
 int launch_ce_dice_fwd(const float* logits, const long long* target, const float* w, int C, int N, size_t vps, float a, float b,
                        float eps, float smooth, float* workspace, float* loss_out, hipStream_t s);
 int launch_ce_dice_sums(const float* logits, const long long* target, const float* w, int C, int N, size_t vps, float* workspace,

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void ce_dice_bwd_kernel(const float* __restric
 
 }  // namespace
 
-size_t ce_dice_workspace_floats(int C) { return (size_t)LOSS_BLOCKS * (2 + 3 * C) + 1 + 2 * C; }
+static_assert(LOSS_BLOCKS <= CE_DICE_MAX_ROWS, "workspace rows");
+size_t ce_dice_workspace_floats(int C) { return (size_t)CE_DICE_MAX_ROWS * (2 + 3 * C) + 1 + 2 * C; }
 
 #define LOSS_DISPATCH(KERNEL, ...)                                                                                        \
     switch (C) {                                                                                                          \
@@ -182,9 +183,17 @@ size_t ce_dice_workspace_floats(int C) { return (size_t)LOSS_BLOCKS * (2 + 3 * C
 int launch_ce_dice_fwd(const float* logits, const long long* target, const float* w, int C, int N, size_t vps, float a, float b,
                        float eps, float smooth, float* workspace, float* loss_out, hipStream_t s) {
     float* partial = workspace;
-    float* coef = workspace + (size_t)LOSS_BLOCKS * (2 + 3 * C);
+    float* coef = workspace + (size_t)CE_DICE_MAX_ROWS * (2 + 3 * C);
     LOSS_DISPATCH(ce_dice_fwd_kernel, logits, target, w, N, vps, partial)
     hipLaunchKernelGGL(ce_dice_finalize_kernel, dim3(1), dim3(1024), 0, s, partial, LOSS_BLOCKS, C, w, a, b, eps, smooth, loss_out, coef);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+int launch_ce_dice_finalize(const float* w, int C, int rows, float a, float b, float eps, float smooth, float* workspace, float* loss_out, hipStream_t s) {
+    if (C < 2 || C > LOSS_MAXC || rows < 1 || rows > CE_DICE_MAX_ROWS) { e3_set_error("ce_dice_finalize: bad class / row count"); return E3_ERR_INVALID; }
+    float* coef = workspace + (size_t)CE_DICE_MAX_ROWS * (2 + 3 * C);
+    hipLaunchKernelGGL(ce_dice_finalize_kernel, dim3(1), dim3(1024), 0, s, workspace, rows, C, w, a, b, eps, smooth, loss_out, coef);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
@@ -201,7 +210,7 @@ int launch_ce_dice_sums(const float* logits, const long long* target, const floa
 int launch_ce_dice_from_sums(const double* sums, const float* w, int C, float a, float b, float eps, float smooth, float* workspace,
                              float* loss_out, hipStream_t s) {
     if (C < 2 || C > LOSS_MAXC) { e3_set_error("ce_dice: 2 <= C <= 16 classes supported"); return E3_ERR_UNSUPPORTED; }
-    float* coef = workspace + (size_t)LOSS_BLOCKS * (2 + 3 * C);
+    float* coef = workspace + (size_t)CE_DICE_MAX_ROWS * (2 + 3 * C);
     hipLaunchKernelGGL(ce_dice_from_sums_kernel, dim3(1), dim3(64), 0, s, sums, C, w, a, b, eps, smooth, loss_out, coef);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
@@ -209,7 +218,7 @@ int launch_ce_dice_from_sums(const double* sums, const float* w, int C, float a,
 
 int launch_ce_dice_bwd(const float* logits, const long long* target, const float* w, int C, int N, size_t vps,
                        const float* workspace, const float* gout, float* dlogits, hipStream_t s) {
-    const float* coef = workspace + (size_t)LOSS_BLOCKS * (2 + 3 * C);
+    const float* coef = workspace + (size_t)CE_DICE_MAX_ROWS * (2 + 3 * C);
     LOSS_DISPATCH(ce_dice_bwd_kernel, logits, target, w, coef, gout, N, vps, dlogits)
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;

@@ -591,9 +591,29 @@ int e3_unet_sizes(const e3_unet_plan* plan, int N, int D, int H, int W, int trai
     return E3_OK;
 }
 
+static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
+                             void* const* params, const float* momenta, float* y,
+                             void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const e3_ce_dice_args* la);
+
 int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
                     void* const* params, const float* momenta, float* y,
                     void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags) {
+    return unet_forward_impl(plan, stream, x, N, D, H, W, params, momenta, y, saved, saved_bytes, scratch, scratch_bytes, flags, nullptr);
+}
+
+int e3_unet_forward_loss(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
+                         void* const* params, const float* momenta, float* y,
+                         void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const e3_ce_dice_args* loss) {
+    E3_REQUIRE(plan && loss && loss->target && loss->workspace && loss->loss_out, E3_ERR_INVALID, "forward_loss: null criterion argument");
+    E3_REQUIRE(!(flags & E3_FWD_SOFTMAX), E3_ERR_INVALID, "forward_loss: the criterion takes logits (no E3_FWD_SOFTMAX)");
+    E3_REQUIRE(plan->cfg.out_channels >= 2, E3_ERR_INVALID, "forward_loss: the criterion needs at least two classes");
+    E3_REQUIRE(loss->workspace_bytes >= ce_dice_workspace_floats(plan->cfg.out_channels) * sizeof(float), E3_ERR_WORKSPACE, "ce_dice workspace too small");
+    return unet_forward_impl(plan, stream, x, N, D, H, W, params, momenta, y, saved, saved_bytes, scratch, scratch_bytes, flags, loss);
+}
+
+static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
+                             void* const* params, const float* momenta, float* y,
+                             void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const e3_ce_dice_args* la) {
     E3_REQUIRE(plan && x && y && params && scratch, E3_ERR_INVALID, "null argument");
     hipStream_t s = (hipStream_t)stream;
     const bool training = (flags & E3_FWD_TRAINING) != 0;
@@ -851,11 +871,20 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
         const UnitBufs& lb = B.ub.back();
         const bool fused = training && lu.has_norm();     // see above: head reads the raw conv output + (scale, shift)
         Prof pr(plan, s, (int)plan->units.size(), 0);
-        RUN(launch_conv_final_fwd(fused ? lb.raw : cur, fused ? lu.cout : cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y,
-                                  cfg.out_channels, ND.Y.vox / N, N, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s,
-                                  fused ? lb.scale : nullptr, fused ? lb.shift : nullptr,
-                                  (training && !frozen) ? plan->rrelu_of(lu.p_a >= 0 ? ActArg(0.f, P(lu.p_a)) : ActArg(cfg.act_slope), (int)plan->units.size() - 1)
-                                                        : (lu.p_a >= 0 ? ActArg(0.f, P(lu.p_a)) : ActArg(cfg.act_slope))));
+        const ActArg head_act = (training && !frozen) ? plan->rrelu_of(lu.p_a >= 0 ? ActArg(0.f, P(lu.p_a)) : ActArg(cfg.act_slope), (int)plan->units.size() - 1)
+                                                      : (lu.p_a >= 0 ? ActArg(0.f, P(lu.p_a)) : ActArg(cfg.act_slope));
+        if (la) {       // the criterion's sums are taken from the logits while the head has them in registers (e3_unet_forward_loss)
+            int rows = 0;
+            RUN(launch_conv_final_fwd_loss(fused ? lb.raw : cur, fused ? lu.cout : cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y,
+                                           cfg.out_channels, ND.Y.vox / N, N, s, fused ? lb.scale : nullptr, fused ? lb.shift : nullptr, head_act,
+                                           la->target, la->class_weight, (float*)la->workspace, CE_DICE_MAX_ROWS, &rows));
+            RUN(launch_ce_dice_finalize(la->class_weight, cfg.out_channels, rows, la->ce_weight, la->dice_weight, la->eps, la->smooth,
+                                        (float*)la->workspace, la->loss_out, s));
+        } else {
+            RUN(launch_conv_final_fwd(fused ? lb.raw : cur, fused ? lu.cout : cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y,
+                                      cfg.out_channels, ND.Y.vox / N, N, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s,
+                                      fused ? lb.scale : nullptr, fused ? lb.shift : nullptr, head_act));
+        }
     }
     return E3_OK;
 }

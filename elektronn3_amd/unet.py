@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import E3_BWD_FROZEN_BN, E3_FWD_FROZEN_BN, E3_FWD_SOFTMAX, E3_FWD_TRAINING, UNetCfg, c_size_t, c_void_p, check
+from ._lib import E3_BWD_FROZEN_BN, E3_FWD_FROZEN_BN, E3_FWD_SOFTMAX, E3_FWD_TRAINING, UNetCfg, c_size_t, c_void_p, check, ptr
 
 _plans = {}
 _plans_lock = threading.Lock()
@@ -125,7 +125,7 @@ def _fp32_table(module, tens):
     return cache[2]
 
 
-def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, training, momenta, frozen=False):
+def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, training, momenta, frozen=False, loss=None):
     """One call of e3_unet_forward / e3_unet_forward_bf16 / e3_unet_forward_f16.  `tens`: fp32 table tensors (contiguous); `want16`: None, or
     the 16-bit type to compute in (torch.bfloat16 / torch.float16).  Returns (y fp32, saved buffer or None, the input as handed to the
     library, the 16-bit type of the native path taken or None)."""
@@ -144,10 +144,20 @@ def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, traini
     flags = (E3_FWD_TRAINING if training else 0) | (E3_FWD_SOFTMAX if softmax else 0) | (E3_FWD_FROZEN_BN if frozen else 0)
     fwd = lib.e3_unet_forward_f16 if b16 is torch.float16 else (lib.e3_unet_forward_bf16 if b16 is not None else lib.e3_unet_forward)
     with torch.cuda.device(dev):
-        check(fwd(plan.handle, _lib.stream_ptr(dev), c_void_p(xin.data_ptr()), N, D, H, W, ptrs, cmom,
-                  c_void_p(y.data_ptr()), c_void_p(saved.data_ptr()) if saved is not None else None,
-                  c_size_t(saved.numel() if saved is not None else 0),
-                  c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), flags))
+        args = (plan.handle, _lib.stream_ptr(dev), c_void_p(xin.data_ptr()), N, D, H, W, ptrs, cmom,
+                c_void_p(y.data_ptr()), c_void_p(saved.data_ptr()) if saved is not None else None,
+                c_size_t(saved.numel() if saved is not None else 0),
+                c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), flags)
+        if loss is not None and b16 is None:      # criterion inside the head (fp32 path): loss = dict(target, weight, ce, dice, eps, smooth) -> + ws, out
+            nbytes = lib.e3_ce_dice_workspace_bytes(plan.out_channels)
+            loss['ws'] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            loss['out'] = torch.empty((), dtype=torch.float32, device=dev)
+            w = loss['weight']
+            la = _lib.CEDiceArgs(loss['target'].data_ptr(), w.data_ptr() if w is not None else None, loss['ce'], loss['dice'], loss['eps'], loss['smooth'],
+                                 loss['ws'].data_ptr(), nbytes, loss['out'].data_ptr())
+            check(lib.e3_unet_forward_loss(*args, ctypes.byref(la)))
+        else:
+            check(fwd(*args))
     return y, saved, xin, b16
 
 
@@ -178,6 +188,55 @@ def _native_backward(plan, dy, xin, tens, saved, b16, want_dx, sync=None, frozen
     if sync is not None:
         sync.after_backward(plan)
     return flat, views, dx
+
+
+class _UNetLossFunction(torch.autograd.Function):
+    """UNet.forward_with_loss: (logits, loss) = one native forward whose 1x1x1 head also evaluates the criterion (e3_unet_forward_loss);
+    the backward seeds e3_unet_backward with dLoss/dlogits from e3_ce_dice_bwd (+ an incoming logits gradient, if the logits are used too)."""
+
+    @staticmethod
+    def forward(ctx, module, crit, want16, x, target, *params):
+        ctx.set_materialize_grads(False)
+        req = dict(crit, target=target.contiguous())
+        module.__dict__['_loss_req'] = req
+        try:
+            y = _UNetFunction.forward(ctx, module, 2, want16, x, *params)
+        finally:
+            module.__dict__.pop('_loss_req', None)
+        lib = _lib.load()
+        N, C = y.shape[:2]
+        sp = [1] * (5 - y.dim()) + list(y.shape[2:])
+        ctx.ce_dims = (C, N, *sp)
+        if 'out' not in req:            # (the head did not take the criterion along -- a 16-bit native path: the separate pass over the logits)
+            nbytes = lib.e3_ce_dice_workspace_bytes(C)
+            req['ws'] = torch.empty(nbytes, dtype=torch.uint8, device=y.device)
+            req['out'] = torch.empty((), dtype=torch.float32, device=y.device)
+            y32 = y.float().contiguous()
+            w = req['weight']
+            check(lib.e3_ce_dice_fwd(_lib.stream_ptr(y.device), ptr(y32), ptr(req['target']), ptr(w) if w is not None else None, C, N, *sp,
+                                     req['ce'], req['dice'], req['eps'], req['smooth'], ptr(req['ws']), c_size_t(nbytes), ptr(req['out'])))
+        ctx.ce = (req['target'], req['weight'], req['ws'])
+        ctx.save_for_backward(y)
+        return y, req['out']
+
+    @staticmethod
+    def backward(ctx, dy, dloss):
+        y, = ctx.saved_tensors
+        target, w, ws = ctx.ce
+        C, N, D, H, W = ctx.ce_dims
+        dl = None
+        if dloss is not None:
+            y32 = y.float().contiguous()
+            dl = torch.empty_like(y32)
+            g = dloss.to(device=y.device, dtype=torch.float32).contiguous()
+            check(_lib.load().e3_ce_dice_bwd(_lib.stream_ptr(y.device), ptr(y32), ptr(target), ptr(w) if w is not None else None, C, N, D, H, W,
+                                             ptr(ws), c_size_t(ws.numel()), ptr(g), ptr(dl)))
+        if dy is not None:
+            dl = dy.float() if dl is None else dl + dy.float()
+        if dl is None:
+            dl = torch.zeros_like(y, dtype=torch.float32)
+        grads = _UNetFunction.backward(ctx, dl)
+        return grads[:4] + (None,) + grads[4:]
 
 
 def _store_attention_maps(module, plan, x, training, saved):
@@ -240,7 +299,8 @@ class _UNetFunction(torch.autograd.Function):
         check(_lib.load().e3_unet_set_rrelu(plan.handle, *(ctx.rrelu if ctx.rrelu is not None else (0.0, 0.0, 0))))
         y, saved, xin, b16 = _native_forward(module, plan, x, tens, softmax, want16 if want16 else (all16 if in_dtype == all16 else None),
                                              ctx.needs_input_grad[3], training or frozen,
-                                             module._momenta(plan) if (training or frozen) else None, frozen=frozen)
+                                             module._momenta(plan) if (training or frozen) else None, frozen=frozen,
+                                             loss=module.__dict__.get('_loss_req') if (training and not softmax) else None)
         if getattr(module, 'attention', False) and b16 is None:
             _store_attention_maps(module, plan, x, training or frozen, saved)
         ctx.frozen = frozen
@@ -922,6 +982,33 @@ class UNet(nn.Module):
         else:
             y = _UNetFunction.apply(self, mode, want16, x, *params)
         return y.squeeze(2) if self.dim == 2 else y
+
+    @torch.jit.unused
+    def forward_with_loss(self, x, target, criterion):
+        """``(out, loss)`` with ``out = self(x)`` and ``loss = criterion(out, target)`` -- the two lines of the reference's training step
+        (training/trainer.py:520-524) as ONE call, so that the criterion of the training example (``CombinedCEDiceLoss``, i.e.
+        ``CombinedLoss([CrossEntropyLoss(w), DiceLoss(apply_softmax=True, w)])``, modules/loss.py:19-49,158-234) is evaluated by the kernel of
+        the final 1x1x1 conv while it holds the logits in registers ("loss on device fused with conv_final").  Same values and
+        gradients as the two separate calls.  Any other criterion, module configuration or a data-parallel ``global_batch`` criterion (whose sums
+        travel between ranks first) takes exactly those two calls."""
+        from .loss import CombinedCEDiceLoss
+        fusable = (type(criterion) is CombinedCEDiceLoss and self.training and torch.is_grad_enabled() and self.dim == 3 and not self._per_sample_norm()
+                   and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 5 and target.dtype == torch.int64 and target.is_cuda
+                   and (not criterion.global_batch or criterion._world() == 1))
+        if not fusable:
+            out = self(x)
+            return out, criterion(out, target)
+        plan = self._plan()
+        params = [p for _, p in self._named_table_params(plan)]
+        want16 = None
+        if torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in (torch.bfloat16, torch.float16):
+            want16 = torch.get_autocast_dtype('cuda')
+        elif getattr(self, 'compute_dtype', None) in (torch.bfloat16, torch.float16):
+            want16 = self.compute_dtype
+        w = criterion.weight
+        crit = dict(weight=None if w is None else w.to(device=x.device, dtype=torch.float32).contiguous(), ce=criterion.ce_weight, dice=criterion.dice_weight,
+                    eps=criterion.eps, smooth=criterion.smooth)
+        return _UNetLossFunction.apply(self, crit, want16, x, target, *params)
 
     @torch.jit.unused
     def forward_softmax(self, x):

@@ -110,6 +110,21 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
                     void* const* params, const float* momenta, float* y,
                     void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags);
 
+/* e3_unet_forward with the training example's criterion evaluated INSIDE the 1x1x1 head (SURVEY.md 8f rank 1 "loss on device fused with
+ * conv_final"; replaces criterion(model(x), target) of training/trainer.py:520-524 with CombinedLoss([CrossEntropyLoss(w),
+ * DiceLoss(apply_softmax=True, w)], (ce_weight, dice_weight)), modules/loss.py:19-49,158-234): y = the logits as before; *loss_out
+ * (device scalar) = the loss of (y, target); `workspace` (e3_ce_dice_workspace_bytes(out_channels) bytes) receives the coefficients
+ * that e3_ce_dice_bwd(logits = y, target, workspace, gout) turns into dLoss/dy for e3_unet_backward.  target: [N, D', H', W'] int64
+ * class indices on the grid of y.  No E3_FWD_SOFTMAX. */
+typedef struct e3_ce_dice_args {
+    const long long* target; const float* class_weight /* [out_channels] or NULL */;
+    float ce_weight, dice_weight, eps, smooth;
+    void* workspace; size_t workspace_bytes; float* loss_out;
+} e3_ce_dice_args;
+int e3_unet_forward_loss(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
+                         void* const* params, const float* momenta, float* y,
+                         void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const e3_ce_dice_args* loss);
+
 /* Gradients of a scalar loss w.r.t. every trainable parameter (and optionally x), given dy = dLoss/dy.
  *   grads : table-ordered device pointers (entries of buffers are ignored, may be NULL); every trainable entry
  *           is OVERWRITTEN with the gradient (accumulation into .grad stays with autograd)

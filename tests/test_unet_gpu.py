@@ -1219,3 +1219,43 @@ def test_arenas_are_not_overrun(name, kw, shape, dtype, monkeypatch):
     assert all(torch.isfinite(p.grad.float()).all() for p in m.parameters())
     monkeypatch.undo()
     U.release_scratch()
+
+
+@pytest.mark.parametrize('case', ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb2_sf32_wino_odd.npz'])
+def test_forward_with_loss_matches_the_reference_step(case):
+    """UNet.forward_with_loss (the criterion evaluated inside the 1x1x1 head) against the reference's golden train step:
+    logits, loss value ('loss'), the seed d loss / d logits ('dlogits', through the parameter gradients) -- and bit-identical logits / equal
+    gradients to the two-call form criterion(model(x), target)."""
+    from elektronn3_amd.loss import CombinedCEDiceLoss
+    g = load_npz(case)
+    cfg = unet_cfg(g)
+    x = torch.from_numpy(g['x']).cuda()
+    t = torch.from_numpy(g['target']).cuda()
+    crit = CombinedCEDiceLoss(weight=torch.tensor([0.2653, 0.7347])).cuda()
+    ma = build(cfg, sub(g, 'sd0')).train()
+    out, loss = ma.forward_with_loss(x, t, crit)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g['logits'], rtol=1e-4, atol=1e-4)
+    assert abs(float(loss.detach()) - float(g['loss'])) < 2e-5
+    loss.backward()
+    mb = build(cfg, sub(g, 'sd0')).train()
+    out_b = mb(x)
+    loss_b = crit(out_b, t)
+    loss_b.backward()
+    assert torch.equal(out.detach(), out_b.detach())
+    assert abs(float(loss.detach()) - float(loss_b.detach())) <= 1e-6 * max(1.0, abs(float(loss_b.detach())))
+    ref64 = sub(g, 'grad64')
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        ga, gb = pa.grad.cpu().numpy(), pb.grad.cpu().numpy()
+        if is_prebn_bias(k, set(ref64), instance_norm_names(cfg)):
+            continue
+        assert rel_l2(ga, gb) <= 1e-5, (k, rel_l2(ga, gb))            # (different summation order of the criterion's partial sums only)
+        assert rel_l2(ga, ref64[k]) <= 1e-2, (k, rel_l2(ga, ref64[k]))
+    # the logits can be used next to the loss: their gradient adds to the criterion's
+    mc = build(cfg, sub(g, 'sd0')).train()
+    out_c, loss_c = mc.forward_with_loss(x, t, crit)
+    (loss_c + 1e-3 * out_c.square().mean()).backward()
+    md = build(cfg, sub(g, 'sd0')).train()
+    out_d = md(x)
+    (crit(out_d, t) + 1e-3 * out_d.square().mean()).backward()
+    k0 = 'down_convs.0.conv1.weight'
+    assert rel_l2(dict(mc.named_parameters())[k0].grad.cpu().numpy(), dict(md.named_parameters())[k0].grad.cpu().numpy()) <= 1e-5

@@ -18,3 +18,7 @@ for cin, cout, shp in ((32, 32, (2, 64, 128, 128)), (64, 32, (2, 64, 128, 128)),
     print(f'{cin}->{cout} {shp}: workgroups {len(t)}, brick total {np.median(t[:,9]-t[:,0]):.0f} ticks')
     for nme, v in zip(names, med):
         print(f'    {nme:44s} {v:8.0f}')
+    tt = raw[: 256 * 32].reshape(256, 32); tt = tt[(tt[:, 0] > 0) & (tt[:, 9] > tt[:, 0])]
+    for lab, o in (('second-to-last chunk', 24), ('last chunk', 16)):
+        # stamps 1 (start), 2 (after VALU phase), 4 (barrier in front of the last 16 MFMAs), 3 (end)
+        print(f'    {lab}: VALU phase {np.median(tt[:, o + 2] - tt[:, o + 1]):.0f}, to barrier {np.median(tt[:, o + 4] - tt[:, o + 2]):.0f}, barrier to end {np.median(tt[:, o + 3] - tt[:, o + 4]):.0f}, total {np.median(tt[:, o + 3] - tt[:, o + 1]):.0f}')
