@@ -118,7 +118,7 @@ struct BnBwdB16Args {
     bf16_t* dx; int dx_ldc;
     // the last unit: dA is recomputed from the head's (fp32, NCDHW) logits gradient and weights instead of being read
     const float* head_dy; const float* head_w; int head_cout; size_t head_S;
-    int pool_one_lane;                      // set by the launcher (E3_B16_POOL_ONE_LANE): one lane per pooling window instead of one per window column
+    int pool_one_lane;                      // set by the launcher: one lane per pooling window instead of one per window column
 };
 int bn_bwd_b16_parts(size_t voxels, int C);
 int launch_bn_bwd_b16_reduce(BnBwdB16Args a, hipStream_t s);

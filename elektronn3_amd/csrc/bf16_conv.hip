@@ -505,9 +505,8 @@ int launch_conv_b16(ConvB16Args a, hipStream_t s) {
     (d.bd == 4 ? (two ? launch_t<4, 2, KD_, TW_>(a, d.ksplit, s) : launch_t<4, 1, KD_, TW_>(a, d.ksplit, s))                 \
                : (two ? launch_t<2, 2, KD_, TW_>(a, d.ksplit, s) : launch_t<2, 1, KD_, TW_>(a, d.ksplit, s)))
     // 16-channel LDS images, three workgroups per CU, where the shape allows (BD = 4, 3x3x3, 32-voxel rows, one 32-channel output tile, no split-K):
-    // 150 -> 133, 247 -> 227, 154 -> 138 us on the level-0 forward convs of cfg 2, 5.89 -> 5.76 ms per step (E3_B16_CH32=1 restores 32-channel images)
-    static const bool ch16 = getenv("E3_B16_CH32") == nullptr;
-    if (ch16 && d.bd == 4 && d.tw == 32 && d.ksplit == 1 && !two) rc = a.planar ? launch_t<4, 1, 1, 32, 16>(a, d.ksplit, s) : launch_t<4, 1, 3, 32, 16>(a, d.ksplit, s);
+    // 150 -> 133, 247 -> 227, 154 -> 138 us on the level-0 forward convs of cfg 2, 5.89 -> 5.76 ms per step (the 32-channel-image form stays for the other decompositions)
+    if (d.bd == 4 && d.tw == 32 && d.ksplit == 1 && !two) rc = a.planar ? launch_t<4, 1, 1, 32, 16>(a, d.ksplit, s) : launch_t<4, 1, 3, 32, 16>(a, d.ksplit, s);
     else if (a.planar) rc = d.tw == 32 ? E3_B16_LAUNCH(1, 32) : E3_B16_LAUNCH(1, 16);
     else rc = d.tw == 32 ? E3_B16_LAUNCH(3, 32) : E3_B16_LAUNCH(3, 16);
 #undef E3_B16_LAUNCH

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool2_b16_kernel(const bf16_t* __
 // REDUCE: per-channel sum dz, sum dz*xhat.  APPLY: dx = bf16(gamma*invstd*(dz - c1 - xhat*c2)), sum dx (conv-bias gradient).
 template <bool POOL, bool APPLYPASS, bool HEAD>
 __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const BnBwdB16Args a) {
-    const bool g_pool_rows = a.pool_one_lane != 0;        // A/B switch (E3_B16_POOL_ONE_LANE): the one-lane-per-window form
+    const bool g_pool_rows = a.pool_one_lane != 0;        // the one-lane-per-window form (channel counts the lane-pair form does not cover)
     __shared__ float red[2][256][8];
     const int Q = a.C >> 3;
     const int kd = a.kd;
@@ -663,11 +663,10 @@ int final_lpv8(int C) {
     return l;
 }
 
-// a pooling window's two w-columns on two lanes: needs lane ^ Q inside the wave (E3_B16_POOL_ONE_LANE=1: the one-lane form, A/B switch)
+// a pooling window's two w-columns on two lanes: needs lane ^ Q inside the wave (other channel counts take the one-lane-per-window form)
 bool pool_pairs(int C) {
-    static const bool one_lane = getenv("E3_B16_POOL_ONE_LANE") != nullptr;
     const int Q = C / 8;
-    return !one_lane && (Q & (Q - 1)) == 0 && Q <= 32;
+    return (Q & (Q - 1)) == 0 && Q <= 32;
 }
 
 }  // namespace
@@ -706,8 +705,7 @@ int bn_bwd_b16_parts(size_t voxels, int C) {
 }
 
 static int bn_bwd_b16_launch(BnBwdB16Args a, bool apply, hipStream_t s) {
-    static const bool one_lane = getenv("E3_B16_POOL_ONE_LANE") != nullptr;
-    a.pool_one_lane = one_lane ? 1 : 0;
+    a.pool_one_lane = pool_pairs(a.C) ? 0 : 1;
     E3_REQUIRE(a.C % 8 == 0 && a.C <= 2048 && a.x_ldc % 8 == 0, E3_ERR_UNSUPPORTED, "bf16 passes need channel counts that are multiples of 8");
     const dim3 grid(a.parts), block(256);
     const bool pool = a.gpool != nullptr, head = a.g1 == nullptr && !pool;

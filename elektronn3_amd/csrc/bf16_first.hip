@@ -220,8 +220,7 @@ __global__ __launch_bounds__(256) void conv_first_b16_wgrad_kernel(const bf16_t*
 }  // namespace
 
 bool conv_first_b16_supported(int Cin, int Cout, int planar) {
-    static const bool off = getenv("E3_B16_FIRST_VALU") != nullptr;
-    return !off && Cin == 1 && Cout % 32 == 0 && !planar;
+    return Cin == 1 && Cout % 32 == 0 && !planar;
 }
 
 int launch_conv_first_b16_fwd(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int y_ldc, int N, int D, int H, int W, int Cout,

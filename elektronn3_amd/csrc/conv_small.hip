@@ -576,9 +576,8 @@ int launch_conv_small_wgrad(const float* x, int Cin, const float* dy, int dy_ldc
     const int splits = cdiv(ntiles, tps);
     const int NV = (TD + (planar ? 0 : 2)) * (TH + 2) * 18;
     const size_t lds = (size_t)(((NV + 3) & ~3) + 256 * 32) * 4;
-    static const bool no_mfma = getenv("E3_FIRST_WGRAD_VALU") != nullptr;
     if (planar) hipLaunchKernelGGL((conv_small_wgrad_kernel<1, 1, 16, false>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
-    else if (Cin == 1 && Cout % 32 == 0 && !no_mfma)
+    else if (Cin == 1 && Cout % 32 == 0)
         hipLaunchKernelGGL((conv_small_wgrad_kernel<3, 2, 8, true>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
     else hipLaunchKernelGGL((conv_small_wgrad_kernel<3, 2, 8, false>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
     E3_CHECK_HIP(hipGetLastError());

@@ -960,8 +960,8 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
     const float* g = B.g1[0]; int g_ldc = C0;
     bool event_done = bucket_event == nullptr;
     std::vector<WgradReduceJob> wred_jobs;   // slab reductions of the weight gradients (units with their own slab), several per launch
-    size_t wred_bytes = 0;                   // pending slab bytes (E3_REDUCE_BATCH_MB: flush earlier; measured 48/96/160 MB: no better than one launch)
-    static const size_t wred_limit = getenv("E3_REDUCE_BATCH_MB") ? (size_t)atol(getenv("E3_REDUCE_BATCH_MB")) << 20 : ~(size_t)0;
+    size_t wred_bytes = 0;                   // pending slab bytes (flushing every 48 / 96 / 160 MB was measured: no better than one launch)
+    const size_t wred_limit = ~(size_t)0;
     auto wred_push = [&](const WgradReduceJob& j) -> int {
         wred_jobs.push_back(j);
         wred_bytes += (size_t)j.splits * j.T * j.RPad * j.CPad * 4;

@@ -266,9 +266,6 @@ class _Tiling:
         self.tile_shape, self.overlap_shape, self.out_shape = as_array(tile_shape), as_array(overlap_shape), as_array(out_shape)
 
 
-_ZROW_ONLY = bool(int(__import__('os').environ.get('E3_PRED_ZROW_ONLY', '0')))     # A/B switch: the last z row of tiles goes back in one piece too
-
-
 class Predictor:
     """Tiled sliding-window inference with the reference's interface (inference.py:368-388)."""
 
@@ -526,7 +523,7 @@ class Predictor:
                 # one rank: whole z rows go back (contiguous in host memory) -- except the LAST z row, which goes back tile row by tile row:
                 # what is still to be downloaded when the last tile finishes is then one row (0.3 GB) instead of a z row (3.2 GB of the
                 # cfg-5 volume, ~0.25 s of exposed PCIe time)
-                per_row = world > 1 or (k == zrows[-1] and not _ZROW_ONLY)
+                per_row = world > 1 or k == zrows[-1]
                 if per_row or last_of_zrow:
                     ev = torch.cuda.Event(); ev.record(main)
                     downs.append(down_pool.submit(download, k, j if per_row else j_first, j + 1, ev))

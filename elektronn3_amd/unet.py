@@ -304,7 +304,9 @@ class _UNetFunction(torch.autograd.Function):
         if getattr(module, 'attention', False) and b16 is None:
             _store_attention_maps(module, plan, x, training or frozen, saved)
         ctx.frozen = frozen
-        out_dtype = want16 if (b16 is not None and want16) else in_dtype
+        # (autocast / compute_dtype: the result has that dtype whichever kernels computed it, as under torch.autocast with the reference --
+        # uncovered configurations, a requested input gradient or E3_NO_BF16 compute in fp32 and round once at the end)
+        out_dtype = want16 if want16 else in_dtype
         if training and not frozen and module.training:
             module._bump_num_batches_tracked(plan)
             if lowp is not None:         # running statistics were updated in the fp32 copies

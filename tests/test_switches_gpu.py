@@ -1,0 +1,34 @@
+"""Every kernel-selecting environment switch (README.md "Switches for A/B runs") under the parity tests: the switches are read once per
+process, so each group runs the per-op and whole-network tests in a child process with the group's environment.  (only the
+defaults ran in the driver's GPU tier; "suite green under every switch" was a builder claim.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+FP32_TESTS = ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', '-k',
+              'conv3 or convT or train_step_matches_reference or eval_forward or full_size_properties or forward_with_loss']
+B16_TESTS = ['tests/test_bf16_gpu.py', 'tests/test_f16_gpu.py', '-k', 'not full_size']
+GROUPS = {
+    'direct_kernels': (dict(E3_CONV_NO_WINO='1', E3_WGRAD_NO_WINO='1', E3_CONV_NO_WINO2D='1', E3_WGRAD_NO_WINO2D='1'), FP32_TESTS),
+    'unfused_unbatched': (dict(E3_WINO_NO_PERSIST='1', E3_NO_SPLITK='1', E3_NO_REDUCE_BATCH='1', E3_NO_FIRST_FUSE='1', E3_UPCONV_NO_GEMM='1'), FP32_TESTS),
+    'persistent_everywhere': (dict(E3_WINO_PERSIST_MIN='1', E3_UPCONV_NO_PERSIST='1', E3_CONV_NO_V3='1', E3_ATT_VALU='1'), FP32_TESTS),
+    'b16_alternatives': (dict(E3_B16_NO_SPLITK='1', E3_B16_UP_GENERIC='1', E3_B16_BD='2', E3_B16_TW='16', E3_B16_COT='1'), B16_TESTS),
+    'b16_on_fp32_kernels_plain_predictor': (dict(E3_NO_BF16='1', E3_PREDICTOR_NO_PIPELINE='1'),
+                                            ['tests/test_predictor.py', 'tests/test_bf16_gpu.py', '-k', 'predictor or fixture or autocast']),
+}
+
+
+@pytest.mark.parametrize('group', list(GROUPS))
+def test_parity_suite_under_switch_group(group):
+    env_extra, tests = GROUPS[group]
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', *tests], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout or '')[-3000:] + (r.stderr or '')[-1500:]
+    assert r.returncode == 0, f'{group} {env_extra}:\n{tail}'
+    assert ' passed' in r.stdout and 'no tests ran' not in r.stdout, tail

@@ -828,7 +828,7 @@ def test_state_dict_roundtrip_pickle_and_reference_keys(tmp_path):
 def test_trainer_protocol_autocast_gradscaler_dataparallel():
     """What Trainer._train_step wraps around the model (training/trainer.py:517-543): ``torch.autocast`` (fp16 by default),
     ``GradScaler.scale(loss).backward()`` + ``scaler.step(optimizer)``, and ``nn.DataParallel`` (benchmark/train_benchmark.py:109-110,
-    one visible GPU here).  The HIP path computes in fp32 whatever the autocast state: same logits/gradients as the plain call."""
+    one visible GPU here).  A configuration outside the native 16-bit path computes in fp32 under autocast: the plain call's logits rounded once."""
     from elektronn3_amd.loss import CombinedCEDiceLoss
     from elektronn3_amd.optim import AdamW
     from elektronn3_amd.unet import UNet
@@ -846,10 +846,15 @@ def test_trainer_protocol_autocast_gradscaler_dataparallel():
     with torch.autocast('cuda', dtype=torch.float16):
         out1 = dp(x)
         loss = crit(out1, t)
-    assert out1.dtype == torch.float32 and torch.equal(out1, out0)       # fp32 compute, bit-identical to the plain call
+    # start_filts=16 is not on the native 16-bit path: fp32 compute, ONE rounding to the autocast dtype at the end -- the output has the autocast
+    # dtype whichever kernels ran (as the reference's does), so its incoming gradient is a float16 tensor too
+    assert out1.dtype == torch.float16 and torch.equal(out1, out0.half())
     scaler.scale(loss).backward()
     for k, p in m.named_parameters():
-        torch.testing.assert_close(p.grad / 256.0, g0[k], rtol=1e-5, atol=1e-8, msg=k)   # scaled by a power of two: exact up to underflow
+        if is_prebn_bias(k, set(g0), set()):
+            continue
+        e = float((p.grad / 256.0 - g0[k]).norm() / g0[k].norm())
+        assert e < 3e-3, (k, e)          # the logits and their (scaled) gradient were rounded to float16 once each
     before = [p.detach().clone() for p in m.parameters()]
     scaler.step(opt); scaler.update()
     assert all(torch.isfinite(p).all() for p in m.parameters())
