@@ -22,6 +22,9 @@ import torch.distributed as dist
 
 class GradSync:
     def __init__(self, model, process_group=None, bucket_after_down_block=2, average=True):
+        if isinstance(model, torch.jit.ScriptModule):
+            # (the TorchScript operator's backward has no handle on this object: a scripted replica would silently skip the all-reduce)
+            raise TypeError('GradSync needs the eager elektronn3_amd.UNet: script the model for saving (Trainer save_jit), train the eager one')
         self.model = model
         self.group = process_group
         self.average = average

@@ -317,6 +317,15 @@ class _UNetFunction(torch.autograd.Function):
         ctx.softmax, ctx.eval_mode, ctx.in_dtype = softmax, not (training or frozen), in_dtype
         # (a low-precision module's fp32 table is a cache that the next forward refreshes with the same parameter values:
         # the backward only reads weights and affine parameters from it, never the running statistics)
+        if need_grad and lowp is not None:
+            # the fp32 table of a low-precision module is ONE persistent cache that the next forward overwrites in place: the backward of this
+            # forward gets its own copy (parameters changed in between -- an optimizer step between two pending graphs, an SWA swap -- would
+            # otherwise be read silently where torch raises a version error)
+            flat = torch.cat([t.reshape(-1) for t in tens])
+            own, off = [], 0
+            for t in tens:
+                own.append(flat[off:off + t.numel()].view(t.shape)); off += t.numel()
+            tens = own
         ctx.x32, ctx.saved_buf, ctx.tens = (xin, saved, tens) if need_grad else (None, None, None)
         return y if out_dtype == torch.float32 else y.to(out_dtype)
 
@@ -422,6 +431,9 @@ def _(dy, x, tensors, saved, key):
 
 def _unet_fwd_setup(ctx, inputs, output):
     x, tensors, key, momenta, training, softmax = inputs
+    if x.requires_grad:       # (silently returning no input gradient would be wrong; the eager module supports it)
+        raise NotImplementedError('scripted elektronn3_amd.UNet: a gradient w.r.t. the input is not available through the TorchScript operator '
+                                  '(use the eager module)')
     ctx.key, ctx.training, ctx.softmax, ctx.n_mom = key, training, softmax, len(momenta)
     # (the running statistics are overwritten right after the call and never read by the backward: placeholders keep the table's shape)
     kinds = _get_plan(_plan_key_from_floats(key)).kinds
