@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round profile on the GPU box: kernel statistics of the default bench command (fp32 and bf16) and the PMC passes behind
-# bench.py's roofline.traffic.  Usage (inside gpurun): bash tools/profile_round.sh r02
+# bench.py's roofline.traffic.  Usage (inside gpurun): bash tools/profile_round.sh r03
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -20,7 +20,7 @@ for dt in f32 bf16; do
   done
 done
 cd $R
-rm -f $O/r02_pmc_roofline.json
+rm -f $O/pmc_roofline.json
 python tools/pmc_roofline.py --dtype f32 --kernel conv3_wino_pkernel --fetch $O/pmc_f32_FETCH_SIZE --write $O/pmc_f32_WRITE_SIZE --busy $O/pmc_f32_SQ_VALU_MFMA_BUSY_CYCLES --steps 6 -o $O/pmc_roofline.json --command "$PB --dtype f32" > $O/pmc_roofline_f32.log 2>&1
 python tools/pmc_roofline.py --dtype bf16 --kernel "conv_b16_kernel<4, 1, 3, 32, 16>" --fetch $O/pmc_bf16_FETCH_SIZE --write $O/pmc_bf16_WRITE_SIZE --busy $O/pmc_bf16_SQ_VALU_MFMA_BUSY_CYCLES --steps 6 -o $O/pmc_roofline.json --command "$PB --dtype bf16" > $O/pmc_roofline_bf16.log 2>&1
 python tools/pmc_summary.py $O/pmc_bf16_FETCH_SIZE $O/pmc_bf16_WRITE_SIZE $O/pmc_bf16_SQ_VALU_MFMA_BUSY_CYCLES --filter "b16|bn_|wgrad_reduce" -o $O/pmc_bf16.md > /dev/null 2>&1
