@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
 //     v_rcp instead of a division) and the workgroup writes ONE record at the end (`wgstats`; 256 / ntiles records per layer instead of
 //     one per brick: no pre-merge launch, a tenth of the epilogue's statistic code per brick).  Where a workgroup's bricks do not all
 //     belong to one column tile (unusual grids) the records stay per brick.
-constexpr int W_PLDS_FLOATS = 2 * W_BUF + W_EX + 4 * 32 * 3;
+constexpr int W_PLDS_FLOATS = 2 * W_BUF + W_EX + 4 * 32 * 3 + 3 * 256;     // + the threads' running statistics
 
 struct WinoPArgs { int s_nt, s_tw, s_th, s_td, s_nb; int wgstats; };   // digits of the logical step gridDim / 8 between a workgroup's bricks
 
@@ -491,8 +491,9 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
     float* nxt = smem + W_BUF;
     float* ex = smem + 2 * W_BUF;
     float* scr = ex + W_EX;
-    // running statistics of this lane's channel over the workgroup's bricks
-    float rn = 0.f, rmean = 0.f, rm2 = 0.f;
+    // running statistics of this lane's channel over the workgroup's bricks: [3][256] floats in LDS, touched by their own thread only (in
+    // registers they were spilled around the main loop, and a scratch reload waits for every global load and store in flight)
+    { float* const run = scr + 4 * 32 * 3 + tid; run[0] = 0.f; run[256] = 0.f; run[512] = 0.f; }
 #ifndef E3_WINO_ABL
 #define E3_WINO_ABL 0       // developer builds: bit mask of pieces left out of the MFMA phase (timing experiments, wrong results)
 #endif
@@ -656,6 +657,11 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
         TSTAMP(5);
 
         // ---- epilogue.  acc[ph*4+pw][r]: position (pd = wave, ph, pw), tile row r -> tile t = (r&3) + 8 (r>>2) + 4 hf, channel j.
+        // (the lane index is taken afresh: lane constants of the epilogue kept across the main loop were spilled, and a scratch reload in here
+        // waits for every global request in flight -- the next brick's halo and weights, the output stores)
+        int elane;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
+        const int ej = elane & 31, ehf = elane >> 5;
         const int d0 = P.td * 4, h0 = P.th * 4, w0 = P.tw * 16, n0 = P.nt * 32;
         const KArgs e = KA();
         const int yl = e->y_ldc, eN = e->Ncols;
@@ -663,6 +669,20 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
         const size_t yrem = (size_t)(D - d0) * plane_y * 4;
         const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(
             e->y + ((size_t)P.nb * D + d0) * plane_y, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
+        // per-channel constants of the epilogue, requested first: they arrive during the output transform, and waiting for them does not wait
+        // for the requests of the next brick behind them (channels beyond Ncols: out of the descriptor's range, 0)
+        const int n = n0 + ej;
+        const bool nvalid = n < eN;
+        const bool aff = e->epi_scale != nullptr;
+        float bias, es, eh;
+        {
+            const __amdgpu_buffer_rsrc_t c_rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e->bias), 0, e->bias ? eN * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t c_rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e->epi_scale), 0, aff ? eN * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t c_rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e->epi_shift), 0, aff ? eN * 4 : 0, 0x00020000);
+            bias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rs0, n * 4, 0, 0));
+            es = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rs1, n * 4, 0, 0));
+            eh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rs2, n * 4, 0, 0));
+        }
         // A^T m A over (ph, pw) in registers, in two halves of 8 accumulator rows (the next brick's weights and raw halo are live in
         // registers across the epilogue: the full-width form needed 80 more than there are)
 #pragma unroll
@@ -691,7 +711,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
                         f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = q[oh][ow][4 * k + e];
-                        *reinterpret_cast<f32x4*>(ex + ((wave * 16 + (oh * 2 + ow) * 4 + hv * 2 + k) * 64 + lane) * 4) = v;
+                        *reinterpret_cast<f32x4*>(ex + ((wave * 16 + (oh * 2 + ow) * 4 + hv * 2 + k) * 64 + elane) * 4) = v;
                     }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -705,12 +725,6 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
 #pragma unroll
         for (int g = 0; g < 4; ++g) if (!(E3_WINO_ABL & 128)) load_B(0, g);
         // (per-channel constants of the epilogue: requested in front of the barrier, their latency is covered by it)
-        const int n = n0 + j;
-        const bool nvalid = n < eN;
-        const bool aff = e->epi_scale != nullptr;
-        const float bias = (e->bias && nvalid) ? e->bias[n] : 0.f;
-        float es = 1.f, eh = 0.f;
-        if (aff && nvalid) { es = e->epi_scale[n]; eh = e->epi_shift[n]; }
         __syncthreads();
         TSTAMP(7);
         const int oh = wave >> 1, ow = wave & 1;
@@ -719,7 +733,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
         for (int k = 0; k < 4; ++k) {
             f32x4 m[4];
 #pragma unroll
-            for (int pd = 0; pd < 4; ++pd) m[pd] = *reinterpret_cast<const f32x4*>(ex + ((pd * 16 + wave * 4 + k) * 64 + lane) * 4);
+            for (int pd = 0; pd < 4; ++pd) m[pd] = *reinterpret_cast<const f32x4*>(ex + ((pd * 16 + wave * 4 + k) * 64 + elane) * 4);
             y[0][k] = m[0] + m[1] + m[2] + bias;
             y[1][k] = m[1] + m1 * m[2] + m1 * m[3] + bias;
         }
@@ -731,7 +745,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
 #pragma unroll
                     for (int e = 0; e < 4; ++e) y[od][k][e] = fmaxf(__builtin_fmaf(y[od][k][e], es, eh), 0.f);
         }
-        const int gw_l = w0 + 8 * hf + ow, gh_l = h0 + oh;
+        const int gw_l = w0 + 8 * ehf + ow, gh_l = h0 + oh;
         const unsigned y_voff = (unsigned)(((gh_l * W + gw_l) * yl + n) * 4);
         const bool full = d0 + 4 <= D && h0 + 4 <= H && w0 + 16 <= W && n0 + 32 <= eN;
 #ifdef E3_WINO_TIMING
@@ -795,31 +809,32 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
         auto flush = [&](float fc, float fm, float fs, size_t row) {
             const float c2 = __shfl_xor(fc, 32), mm2 = __shfl_xor(fm, 32), s2 = __shfl_xor(fs, 32);
             welford_merge(fc, fm, fs, c2, mm2, s2);
-            if (hf == 0) {
-                float* sc_ = scr + (wave * 32 + j) * 3;
+            if (ehf == 0) {
+                float* sc_ = scr + (wave * 32 + ej) * 3;
                 sc_[0] = fc; sc_[1] = fm; sc_[2] = fs;
             }
             __syncthreads();
-            if (tid < 32 && n0 + tid < eN) {
+            if (wave == 0 && elane < 32 && n0 + elane < eN) {
                 float c0 = 0.f, me = 0.f, mm = 0.f;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    const float* sc_ = scr + (w * 32 + tid) * 3;
+                    const float* sc_ = scr + (w * 32 + elane) * 3;
                     welford_merge(c0, me, mm, sc_[0], sc_[1], sc_[2]);
                 }
-                float* o = KA()->stats + (row * KA()->Cout + n0 + tid) * 3;
+                float* o = KA()->stats + (row * KA()->Cout + n0 + elane) * 3;
                 o[0] = c0; o[1] = me; o[2] = mm;
             }
         };
         if (do_stats) {
             if (pa.wgstats) {        // running record of this lane: Chan's merge with an approximate reciprocal (its error is far below the rounding of the sums)
+                float* const run = scr + 4 * 32 * 3 + wave * 64 + elane;
+                const float rn = run[0], rmean = run[256], rm2 = run[512];
                 const float nn = rn + cnt;
                 const float rf = cnt * __builtin_amdgcn_rcpf(fmaxf(nn, 1.f));
                 const float dl = mean - rmean;
-                rmean += dl * rf;
-                rm2 += m2 + dl * dl * rn * rf;
-                rn = nn;
-                if (!has_next) flush(rn, rmean, rm2, (size_t)((blockIdx.x & 7u) * (32u / (unsigned)ntiles) + (blockIdx.x >> 3) / (unsigned)ntiles));
+                const float nmean = rmean + dl * rf, nm2 = rm2 + m2 + dl * dl * rn * rf;
+                run[0] = nn; run[256] = nmean; run[512] = nm2;
+                if (!has_next) flush(nn, nmean, nm2, (size_t)((blockIdx.x & 7u) * (32u / (unsigned)ntiles) + (blockIdx.x >> 3) / (unsigned)ntiles));
             } else {
                 const size_t mtile = (size_t)(((P.nb * tilesD + P.td) * tilesH + P.th) * tilesW + P.tw);
                 flush(cnt, mean, m2, mtile);
