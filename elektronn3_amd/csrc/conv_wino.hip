@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
 //     v_rcp instead of a division) and the workgroup writes ONE record at the end (`wgstats`; 256 / ntiles records per layer instead of
 //     one per brick: no pre-merge launch, a tenth of the epilogue's statistic code per brick).  Where a workgroup's bricks do not all
 //     belong to one column tile (unusual grids) the records stay per brick.
-constexpr int W_PLDS_FLOATS = 2 * W_BUF + W_EX + 4 * 32 * 3 + 3 * 256;     // + the threads' running statistics
+constexpr int W_PLDS_FLOATS = 2 * W_BUF + W_EX + 4 * 32 * 3 + 6 * 256;     // + the threads' running statistics and parked lane constants
 
 struct WinoPArgs { int s_nt, s_tw, s_th, s_td, s_nb; int wgstats; };   // digits of the logical step gridDim / 8 between a workgroup's bricks
 
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
     const bool col_on = tid < W_LH * W_LW * 2;
     const int cq = tid & 1, czw = (tid >> 1) % W_LW, czh = (tid >> 1) / W_LW;
     // (the 40 threads without a column store zeros into the 5 unused slots of the 4 parity classes: no divergent branch around the stores)
-    const int a_dst = col_on ? plane_slot(czh, czw, cq) : (((tid - W_LH * W_LW * 2) / 10) * W_CLASS + 27 + ((tid - W_LH * W_LW * 2) % 10) / 2) * 8 + 4 * (tid & 1);
+    int a_dst = col_on ? plane_slot(czh, czw, cq) : (((tid - W_LH * W_LW * 2) / 10) * W_CLASS + 27 + ((tid - W_LH * W_LW * 2) % 10) / 2) * 8 + 4 * (tid & 1);
     // staging: byte offset of the thread's halo column inside a d-plane relative to the brick's halo origin, and the two bits of the
     // brick's validity mask (6 d bits | 6 h bits | 18 w bits) it needs (all-ones never matches: threads without a column load zeros)
     const unsigned col_rel = (unsigned)(((czh * W + czw) * xl + 4 * cq) * 4);
@@ -494,6 +494,10 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
     // running statistics of this lane's channel over the workgroup's bricks: [3][256] floats in LDS, touched by their own thread only (in
     // registers they were spilled around the main loop, and a scratch reload waits for every global load and store in flight)
     { float* const run = scr + 4 * 32 * 3 + tid; run[0] = 0.f; run[256] = 0.f; run[512] = 0.f; }
+    // lane constants of the main loop that do not fit in registers across the output transform: parked in LDS and read back behind it (the
+    // register allocator's own choice -- scratch -- makes the main loop wait for the output stores in front of the reload)
+    int* const park = reinterpret_cast<int*>(scr + 4 * 32 * 3 + 3 * 256) + tid;
+    park[0] = a_dst; park[256] = rdA[0]; park[512] = rdA[1];
 #ifndef E3_WINO_ABL
 #define E3_WINO_ABL 0       // developer builds: bit mask of pieces left out of the MFMA phase (timing experiments, wrong results)
 #endif
@@ -683,6 +687,14 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
             es = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rs1, n * 4, 0, 0));
             eh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c_rs2, n * 4, 0, 0));
         }
+        // request the raw halo of unit u + 2 and the first weights of the next brick
+        Cur Pn = P;
+        advance(Pn, true);
+        const bool has_next = Pn.bid < nblk;
+        if (!(E3_WINO_ABL & 32)) stage_step();
+        make_brs(Pn.nt);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) if (!(E3_WINO_ABL & 128)) load_B(0, g);
         // A^T m A over (ph, pw) in registers, in two halves of 8 accumulator rows (the next brick's weights and raw halo are live in
         // registers across the epilogue: the full-width form needed 80 more than there are)
 #pragma unroll
@@ -716,14 +728,6 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
             __builtin_amdgcn_sched_barrier(0);
         }
         TSTAMP(6);
-        // the accumulators are out of the way: request the raw halo of unit u + 2 and the first weights of the next brick
-        Cur Pn = P;
-        advance(Pn, true);
-        const bool has_next = Pn.bid < nblk;
-        if (!(E3_WINO_ABL & 32)) stage_step();
-        make_brs(Pn.nt);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) if (!(E3_WINO_ABL & 128)) load_B(0, g);
         // (per-channel constants of the epilogue: requested in front of the barrier, their latency is covered by it)
         __syncthreads();
         TSTAMP(7);
@@ -846,6 +850,10 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
         ++tbrick;
 #endif
         if (!has_next) break;
+        {
+            const int* const pk = reinterpret_cast<const int*>(scr + 4 * 32 * 3 + 3 * 256) + wave * 64 + elane;
+            a_dst = pk[0]; rdA[0] = pk[256]; rdA[1] = pk[512];
+        }
         P = Pn;
     }
 }
