@@ -69,13 +69,39 @@ def cpu_baseline(iters=3):
             's_per_step': dt}
 
 
-def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_parallel=False, bf16=False):
+def needed_region_flops(tile_in, overlap, n_blocks=4, sf=32):
+    """(forward FLOP of one tile, FLOP the needed-region forward skips): the Predictor keeps the central crop of a tile, so the decoder's
+    3x3x3 convs only compute the Winograd bricks (4 x 4 x 16 voxels) that crop depends on -- the box grows by one voxel per conv and halves
+    per transposed conv on the way back through the decoder (elektronn3_amd/csrc/unet_plan.cpp, e3_unet_forward_roi)."""
+    vox = tile_in[0] * tile_in[1] * tile_in[2]
+    whole = 427.2e3 * vox                                                 # SURVEY 8d: forward FLOP per input voxel of UNet(n_blocks=4, sf=32)
+    lo = [o for o in overlap]; hi = [t - o for t, o in zip(tile_in, overlap)]
+    skipped = 0.0
+    for lvl in range(n_blocks - 1):
+        dims = [t >> lvl for t in tile_in]
+        c = sf << lvl
+        for cin in (c, 2 * c):                                            # conv2 (c -> c), then conv1 (concat 2c -> c), walking backwards
+            edge = (4, 4, 16)
+            blo = [l // e * e for l, e in zip(lo, edge)]
+            bhi = [min(-(-h // e) * e, d) for h, e, d in zip(hi, edge, dims)]
+            done = (bhi[0] - blo[0]) * (bhi[1] - blo[1]) * (bhi[2] - blo[2])
+            skipped += 2.0 * 27 * cin * c * (dims[0] * dims[1] * dims[2] - done)
+            lo = [max(0, l - 1) for l in lo]; hi = [min(d, h + 1) for h, d in zip(hi, dims)]
+        lo = [l // 2 for l in lo]; hi = [-(-h // 2) for h in hi]          # through the transposed conv
+    return whole, skipped
+
+
+def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_parallel=False, bf16=False, whole_tiles=False):
     """BASELINE.json's second metric ("Predictor MVox/s", configs[4]): tile 96x192x192, overlap 16, eval-mode UNet(n_blocks=4,
     start_filts=32), softmax output, fp32 volume in HOST memory, result back in host memory.  Input voxels / predict() wall time
     incl. H2D and D2H (benchmark/pred_benchmark.py:101).  bf16 (`--dtype bf16`): the module is cast with model.to(torch.bfloat16) after its
     running statistics are set -- the bf16 counterpart of pred_benchmark.py's float16 switch: bf16 tiles, native bf16 kernels, bf16 result volume."""
     from elektronn3_amd.inference import Predictor
     from elektronn3_amd.unet import UNet
+    from elektronn3_amd import inference as _inf
+    roi_default = _inf._ROI
+    if whole_tiles:
+        _inf._ROI = False
     torch.manual_seed(0)
     model = UNet(1, 2, n_blocks=4, start_filts=32).to(dev)
     model.train()
@@ -99,16 +125,22 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
     for n, t in zip(shape, tile):
         ntiles *= -(-n // t)
     tile_in = [t + 2 * o for t, o in zip(tile, overlap)]
-    tile_flop = 427.2e3 * tile_in[0] * tile_in[1] * tile_in[2]            # forward FLOP per tile incl. halo (2744 GFLOP)
+    tile_flop, skipped = needed_region_flops(tile_in, overlap)            # forward FLOP per tile incl. halo (2744 GFLOP)
+    roi_on = bool(_inf._ROI) and not bf16                                 # (fp32 path only: the bf16 kernels compute whole tiles)
+    done_flop = tile_flop - (skipped if roi_on else 0.0)
+    _inf._ROI = roi_default
     return {'metric': 'Predictor MVox/s', 'value': vol.numel() / dt / 1e6, 'unit': 'MVox/s (input voxels / predict() wall time incl. H2D + D2H)',
             'seconds': dt, 'volume': list(shape), 'tile': list(tile), 'overlap': list(overlap), 'tiles': ntiles, 'dtype': (bf16 if isinstance(bf16, str) else 'bf16') if bf16 else 'f32',
             'out_dtype': str(out.dtype).replace('torch.', ''),
             'timing': {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (getattr(pred, 'last_timing', None) or {}).items()},
             'finite': bool(torch.isfinite(out[..., ::32, ::32].float()).all()),
+            'needed_region': roi_on, 'flop_skipped_frac': (skipped / tile_flop) if roi_on else 0.0,
             'algorithmic_tflops': ntiles * tile_flop / dt / 1e12,
-            'mfma_executed_frac': ntiles * tile_flop * (1.0 if bf16 else 64.0 / 216.0) / dt / 1e12 / MFMA_PEAK_TFLOPS['bf16' if bf16 else 'f32'],
+            'mfma_executed_frac': ntiles * done_flop * (1.0 if bf16 else 64.0 / 216.0) / dt / 1e12 / MFMA_PEAK_TFLOPS['bf16' if bf16 else 'f32'],
             'note': ('executed fraction = matrix FLOP of the direct bf16 convs (= the algorithmic count) / wall time incl. PCIe / dense bf16 MFMA peak' if bf16 else
-                     'executed fraction = Winograd-executed matrix FLOP (64/216 of the algorithmic count) / wall time incl. PCIe / fp32 MFMA peak')}
+                     'needed_region: the decoder convs compute only the Winograd bricks that the kept central crop of a tile depends on (same predict() result; '
+                     'E3_PREDICTOR_NO_ROI=1 computes whole tiles); algorithmic_tflops counts whole tiles (what the reference computes), executed fraction = '
+                     'Winograd-executed matrix FLOP actually run (64/216 of the un-skipped algorithmic count) / wall time incl. PCIe / fp32 MFMA peak')}
 
 
 def respawn_under_launcher(args):
@@ -313,6 +345,12 @@ def main():
                 if world > 1:
                     p.update(n_gpus=world, parallelism=f'tile-parallel over {world} ranks, shared-memory output')
                 res['predictor'] = p
+            if world == 1 and p.get('needed_region'):      # the same Predictor on a 288x1152x1152 volume with whole tiles and with the needed region
+                sub = (288, 1152, 1152)
+                a = predictor_leg(dev, sub, whole_tiles=True)
+                b = p if tuple(shape) == sub else predictor_leg(dev, sub)
+                p['needed_region_ab'] = {'volume': list(sub), 'whole_tiles_mvox_s': a['value'], 'needed_region_mvox_s': b['value'],
+                                         'whole_tiles_compute_s': a['timing'].get('compute_stream_s'), 'needed_region_compute_s': b['timing'].get('compute_stream_s')}
         except Exception as e:  # noqa: BLE001
             if rank == 0:
                 res['predictor'] = {'metric': 'Predictor MVox/s', 'value': None, 'note': f'failed: {e}'}

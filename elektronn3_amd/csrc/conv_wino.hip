@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
     const int tw_ = divmod(L, a.tilesW);
     const int th_ = divmod(L, a.tilesH);
     const int td_ = divmod(L, a.tilesD); const int nb = (int)L;
-    const int d0 = td_ * 4, h0 = th_ * 4, w0 = tw_ * 16;
+    const int d0 = (td_ + a.o_td) * 4, h0 = (th_ + a.o_th) * 4, w0 = (tw_ + a.o_tw) * 16;      // (o_*: first brick of the needed region)
     const int n0 = ntile * 32;
     const int mtile = ((nb * a.tilesD + td_) * a.tilesH + th_) * a.tilesW + tw_;
     const int NCH = a.Cin >> 3;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
 //     belong to one column tile (unusual grids) the records stay per brick.
 constexpr int W_PLDS_FLOATS = 2 * W_BUF + W_EX + 4 * 32 * 3 + 6 * 256;     // + the threads' running statistics and parked lane constants
 
-struct WinoPArgs { int s_nt, s_tw, s_th, s_td, s_nb; int wgstats; };   // digits of the logical step gridDim / 8 between a workgroup's bricks
+struct WinoPArgs { int s_nt, s_tw, s_th, s_td, s_nb; int wgstats; int e_tw, e_th, e_td; };   // digits of the logical step gridDim / 8 between a workgroup's bricks; e_*: end (first brick + count) of the brick range per axis
 
 __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, const unsigned nblk, const WinoPArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -413,9 +413,10 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
     struct Cur { int nt, tw, th, td, nb; unsigned bid; };      // bid: physical index blockIdx + k * gridDim (the brick exists while bid < nblk)
     auto advance = [&](Cur& c, bool go) {        // c += step if go (no branch, no division)
         int v = c.nt + (go ? pa.s_nt : 0); int cy = v >= ntiles ? 1 : 0; c.nt = v - (cy ? ntiles : 0);
-        v = c.tw + (go ? pa.s_tw : 0) + cy; cy = v >= tilesW ? 1 : 0; c.tw = v - (cy ? tilesW : 0);
-        v = c.th + (go ? pa.s_th : 0) + cy; cy = v >= tilesH ? 1 : 0; c.th = v - (cy ? tilesH : 0);
-        v = c.td + (go ? pa.s_td : 0) + cy; cy = v >= tilesD ? 1 : 0; c.td = v - (cy ? tilesD : 0);
+        // (tw, th, td are absolute brick coordinates: they run over [e - tiles, e), the needed region's bricks -- e = tiles for a whole tensor)
+        v = c.tw + (go ? pa.s_tw : 0) + cy; cy = v >= pa.e_tw ? 1 : 0; c.tw = v - (cy ? tilesW : 0);
+        v = c.th + (go ? pa.s_th : 0) + cy; cy = v >= pa.e_th ? 1 : 0; c.th = v - (cy ? tilesH : 0);
+        v = c.td + (go ? pa.s_td : 0) + cy; cy = v >= pa.e_td ? 1 : 0; c.td = v - (cy ? tilesD : 0);
         c.nb += (go ? pa.s_nb : 0) + cy;
         c.bid += go ? gdim : 0u;
     };
@@ -478,6 +479,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
         P.tw = (int)(L % (unsigned)tilesW); L /= (unsigned)tilesW;
         P.th = (int)(L % (unsigned)tilesH); L /= (unsigned)tilesH;
         P.td = (int)(L % (unsigned)tilesD); P.nb = (int)(L / (unsigned)tilesD);
+        P.tw += pa.e_tw - tilesW; P.th += pa.e_th - tilesH; P.td += pa.e_td - tilesD;
     }
     Cur S = P;
     int sc = 0;
@@ -1036,6 +1038,19 @@ int wino_stats_parts(int N, int D, int H, int W, int ncols, int flags) {
 
 int launch_conv3_wino(ConvArgs a, hipStream_t s) {
     a.tilesD = cdiv(a.D, 4); a.tilesH = cdiv(a.H, 4); a.tilesW = cdiv(a.W, 16);
+    a.o_td = a.o_th = a.o_tw = 0;
+    if (a.box_hi[0] > 0) {      // needed region: the bricks that meet the box
+        E3_REQUIRE(!a.stats && a.splitk <= 1, E3_ERR_INVALID, "conv with a needed region: no statistics, no split-K");
+        const int dims[3] = {a.D, a.H, a.W}, edge[3] = {4, 4, 16};
+        int o[3], n[3];
+        for (int i = 0; i < 3; ++i) {
+            const int lo = a.box_lo[i] < 0 ? 0 : a.box_lo[i], hi = a.box_hi[i] > dims[i] ? dims[i] : a.box_hi[i];
+            E3_REQUIRE(hi > lo, E3_ERR_INVALID, "conv with a needed region: empty box");
+            o[i] = lo / edge[i]; n[i] = cdiv(hi, edge[i]) - o[i];
+        }
+        a.o_td = o[0]; a.o_th = o[1]; a.o_tw = o[2];
+        a.tilesD = n[0]; a.tilesH = n[1]; a.tilesW = n[2];
+    }
     a.NPad = (a.Ncols + 31) / 32 * 32;
     a.ntiles = a.NPad / 32;
     const size_t nblk = (size_t)a.N * a.tilesD * a.tilesH * a.tilesW * a.ntiles;
@@ -1067,6 +1082,7 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
         pa.s_th = (int)(st % (unsigned)a.tilesH); st /= (unsigned)a.tilesH;
         pa.s_td = (int)(st % (unsigned)a.tilesD); pa.s_nb = (int)(st / (unsigned)a.tilesD);
         pa.wgstats = (a.stats && wino_wgstats(nblk, a.ntiles)) ? 1 : 0;
+        pa.e_tw = a.o_tw + a.tilesW; pa.e_th = a.o_th + a.tilesH; pa.e_td = a.o_td + a.tilesD;
         hipLaunchKernelGGL(conv3_wino_pkernel, dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
         E3_CHECK_HIP(hipGetLastError());
         return E3_OK;

@@ -41,6 +41,10 @@ struct ConvArgs {
     // split-K (Winograd 3x3x3 only, conv_wino_splitk()): the grid is splitk x the bricks; split s reads the channels [s * sk_x, (s + 1) * sk_x)
     // (Cin = sk_x), its own packed weights (wt + s * sk_w) and writes its partial sums to y + s * sk_y.  bias / stats / epilogue must be off.
     int splitk; int sk_x; unsigned sk_w; size_t sk_y;
+    // needed region (Winograd 3x3x3 kernels only, inference): when box_hi[0] > 0 only the bricks that meet the voxel box [box_lo, box_hi)
+    // (d, h, w) are computed -- the rest of y is left untouched.  The other kernels ignore it and compute everything.  No statistics.
+    int box_lo[3], box_hi[3];
+    int o_td, o_th, o_tw;        // (set by the launcher: first brick of the box per axis)
 };
 
 // number of stats records (rows of [Cout][3]) the conv will write

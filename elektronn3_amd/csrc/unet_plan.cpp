@@ -593,7 +593,8 @@ int e3_unet_sizes(const e3_unet_plan* plan, int N, int D, int H, int W, int trai
 
 static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
                              void* const* params, const float* momenta, float* y,
-                             void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const e3_ce_dice_args* la);
+                             void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const e3_ce_dice_args* la,
+                             const int* roi = nullptr);
 
 int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
                     void* const* params, const float* momenta, float* y,
@@ -611,9 +612,18 @@ int e3_unet_forward_loss(e3_unet_plan* plan, void* stream, const float* x, int N
     return unet_forward_impl(plan, stream, x, N, D, H, W, params, momenta, y, saved, saved_bytes, scratch, scratch_bytes, flags, loss);
 }
 
+int e3_unet_forward_roi(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
+                        void* const* params, float* y, void* scratch, size_t scratch_bytes, uint32_t flags, const int roi[6]) {
+    E3_REQUIRE(roi, E3_ERR_INVALID, "forward_roi: null region");
+    E3_REQUIRE(!(flags & (E3_FWD_TRAINING | E3_FWD_FROZEN_BN)), E3_ERR_INVALID, "forward_roi: inference only");
+    for (int i = 0; i < 3; ++i) E3_REQUIRE(roi[i] >= 0 && roi[3 + i] > roi[i], E3_ERR_INVALID, "forward_roi: empty or negative region");
+    return unet_forward_impl(plan, stream, x, N, D, H, W, params, nullptr, y, nullptr, 0, scratch, scratch_bytes, flags, nullptr, roi);
+}
+
 static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
                              void* const* params, const float* momenta, float* y,
-                             void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const e3_ce_dice_args* la) {
+                             void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const e3_ce_dice_args* la,
+                             const int* roi) {
     E3_REQUIRE(plan && x && y && params && scratch, E3_ERR_INVALID, "null argument");
     hipStream_t s = (hipStream_t)stream;
     const bool training = (flags & E3_FWD_TRAINING) != 0;
@@ -634,6 +644,35 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
     E3_REQUIRE(ND.ok, E3_ERR_INVALID, "input too small for this network (conv_mode='valid' shrinks every conv by 2)");
     const bool valid = cfg.conv_valid != 0;
     auto P = [&](int i) { return (float*)params[i]; };
+
+    // needed regions (e3_unet_forward_roi): the caller keeps only the voxels [roi[0..2], roi[3..5]) of y (the Predictor's central crop of an
+    // overlapping tile, inference.py:496-525), so a decoder conv has to produce only what the layers behind it read for those voxels: the
+    // box grows by the 3x3x3 reach per conv and halves per transposed conv on the way back through the decoder, and stops mattering where
+    // it covers the tensor (the encoder is needed in full: the bottom level sees all of it).  The boxes are handed to the conv launchers;
+    // kernels without the facility compute the whole tensor.  Outside the boxes the buffers keep whatever they held.
+    struct NeedBox { int lo[3], hi[3]; bool on = false; };
+    std::vector<NeedBox> need(plan->units.size());
+    if (roi && !training && !valid && !cfg.attention) {
+        NeedBox b; b.on = true;
+        const int yd[3] = {ND.Y.D, ND.Y.H, ND.Y.W};
+        for (int i = 0; i < 3; ++i) { b.lo[i] = roi[i] < yd[i] ? roi[i] : yd[i] - 1; b.hi[i] = roi[3 + i] < yd[i] ? roi[3 + i] : yd[i]; }
+        for (size_t k = plan->units.size(); k-- > 0 && b.on;) {
+            const ConvUnit& u = plan->units[k];
+            if (u.is_down || u.res_in >= 0) break;
+            need[k] = b;
+            const int di[3] = {ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W};
+            if (u.is_up == 1) {            // transposed conv, kernel = stride: output voxel o reads input voxel o / stride
+                const int st[3] = {u.planar ? 1 : 2, 2, 2};
+                for (int i = 0; i < 3; ++i) { b.lo[i] = b.lo[i] / st[i]; b.hi[i] = (b.hi[i] + st[i] - 1) / st[i]; }
+            } else if (u.is_up) {
+                b.on = false;              // (ResizeConv: everything in front of it is computed in full)
+            } else {
+                const int r[3] = {u.planar ? 0 : 1, 1, 1};
+                for (int i = 0; i < 3; ++i) { b.lo[i] = b.lo[i] - r[i] < 0 ? 0 : b.lo[i] - r[i]; b.hi[i] = b.hi[i] + r[i] > di[i] ? di[i] : b.hi[i] + r[i]; }
+            }
+            for (int i = 0; i < 3; ++i) if (b.hi[i] > di[i]) b.hi[i] = di[i];
+        }
+    }
 
     // split-K of a bottom-level conv (conv_wino_splitk): training forward of units with batch statistics only (their raw output and its
     // statistics come from the reduction pass; the eval / no-norm paths keep the fused epilogues)
@@ -761,6 +800,8 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             if (residual) { a.y = B.res2; a.y_ldc = u.cout; a.bias = nullptr; a.stats = nullptr; }      // pure accumulations; bias + shortcut + statistics below
             parts = conv_stats_parts(kind, 0, N, ci.D, ci.H, ci.W, 2, u.cin, u.cout);
             const int S = (kind == CONV_K3) ? fwd_split(k) : 1;
+            if (need[k].on && kind == CONV_K3 && S == 1 && !a.stats)
+                for (int i = 0; i < 3; ++i) { a.box_lo[i] = need[k].lo[i]; a.box_hi[i] = need[k].hi[i]; }
             if (S > 1) {         // partial sums per share of the input channels, then sum + bias + statistics in one small pass
                 a.splitk = S; a.sk_x = u.cin / S; a.Cin = u.cin / S; a.sk_w = (unsigned)conv_packed_floats(CONV_K3, u.cin / S, u.cout);
                 a.sk_y = lo.vox * u.cout; a.y = B.skws; a.y_ldc = u.cout; a.bias = nullptr; a.stats = nullptr;

@@ -67,6 +67,9 @@ class _SharedHostTensor:
                 pass
 
 
+_ROI = os.environ.get('E3_PREDICTOR_NO_ROI') is None      # (A/B switch: whole tiles instead of the needed region)
+
+
 def _extend_nc(spatial_slice):
     return (slice(None), slice(None)) + tuple(spatial_slice)
 
@@ -349,9 +352,18 @@ class Predictor:
         self.offset, self.tile_shape, self.overlap_shape, self.out_shape = geo.offset, geo.tile_shape, geo.overlap_shape, geo.out_shape
 
     # ------------------------------------------------------------------ per-tile model call (inference.py:496-525)
-    def _call_model(self, dinp):
+    def _call_model(self, dinp, crop_slice=None):
+        """``crop_slice`` (the central crop that follows): the native UNet is told that only those voxels are wanted and skips what they
+        do not depend on (``UNet.forward_roi``; E3_PREDICTOR_NO_ROI=1: A/B switch, whole tiles)."""
         if self._native:
-            y = self.model.forward_softmax(dinp) if self._softmax else self.model(dinp)
+            roi = None
+            if crop_slice is not None and dinp.dim() == 5 and _ROI and hasattr(self.model, 'forward_roi'):
+                sp = tuple(dinp.shape[2:])
+                roi = tuple(sl.indices(n)[:2] for sl, n in zip(crop_slice[-3:], sp))
+            if roi is not None:
+                y = self.model.forward_roi(dinp, roi, softmax=self._softmax)
+            else:
+                y = self.model.forward_softmax(dinp) if self._softmax else self.model(dinp)
             return self._post(y) if self._post is not None else y
         return self.model(dinp)
 
@@ -360,7 +372,7 @@ class Predictor:
         """One tile: model call (+ test-time augmentation mean, + arg-max) and the central crop (inference.py:496-525)."""
         dinp = dinp.to(self.device, dtype=self.dtype)
         crop = (lambda t: t[crop_slice]) if crop_slice is not None else (lambda t: t)
-        dout = crop(self._call_model(dinp))
+        dout = crop(self._call_model(dinp, crop_slice))
         if self.augmentations is not None:       # mean over the identity and every flip (prediction of the flipped tile, flipped back)
             votes = [dout] + [crop(aug.backward(self._call_model(aug.forward(dinp)))) for aug in self.augmentations]
             dout = torch.stack(votes).mean(dim=0)

@@ -125,7 +125,7 @@ def _fp32_table(module, tens):
     return cache[2]
 
 
-def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, training, momenta, frozen=False, loss=None):
+def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, training, momenta, frozen=False, loss=None, roi=None):
     """One call of e3_unet_forward / e3_unet_forward_bf16 / e3_unet_forward_f16.  `tens`: fp32 table tensors (contiguous); `want16`: None, or
     the 16-bit type to compute in (torch.bfloat16 / torch.float16).  Returns (y fp32, saved buffer or None, the input as handed to the
     library, the 16-bit type of the native path taken or None)."""
@@ -156,6 +156,9 @@ def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, traini
             la = _lib.CEDiceArgs(loss['target'].data_ptr(), w.data_ptr() if w is not None else None, loss['ce'], loss['dice'], loss['eps'], loss['smooth'],
                                  loss['ws'].data_ptr(), nbytes, loss['out'].data_ptr())
             check(lib.e3_unet_forward_loss(*args, ctypes.byref(la)))
+        elif roi is not None and b16 is None and not training:      # only the voxels of `roi` are wanted (UNet.forward_roi)
+            check(lib.e3_unet_forward_roi(plan.handle, _lib.stream_ptr(dev), c_void_p(xin.data_ptr()), N, D, H, W, ptrs, c_void_p(y.data_ptr()),
+                                          c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), flags, (ctypes.c_int * 6)(*roi)))
         else:
             check(fwd(*args))
     return y, saved, xin, b16
@@ -300,7 +303,8 @@ class _UNetFunction(torch.autograd.Function):
         y, saved, xin, b16 = _native_forward(module, plan, x, tens, softmax, want16 if want16 else (all16 if in_dtype == all16 else None),
                                              ctx.needs_input_grad[3], training or frozen,
                                              module._momenta(plan) if (training or frozen) else None, frozen=frozen,
-                                             loss=module.__dict__.get('_loss_req') if (training and not softmax) else None)
+                                             loss=module.__dict__.get('_loss_req') if (training and not softmax) else None,
+                                             roi=module.__dict__.get('_roi_req') if not (training or frozen) else None)
         if getattr(module, 'attention', False) and b16 is None:
             _store_attention_maps(module, plan, x, training or frozen, saved)
         ctx.frozen = frozen
@@ -1028,6 +1032,21 @@ class UNet(nn.Module):
     def forward_softmax(self, x):
         """``softmax(forward(x), dim=1)`` with the softmax fused into the final 1x1x1 conv kernel (used by Predictor)."""
         return self._run(x, softmax=True)
+
+    @torch.jit.unused
+    def forward_roi(self, x, roi, softmax=False):
+        """Inference forward of which only the output voxels ``roi = ((d0, d1), (h0, h1), (w0, w1))`` will be used (the tile loop of
+        ``inference.Predictor`` keeps the central crop of every tile, inference.py:496-525): the result has the full shape and equals
+        ``self(x)`` (``forward_softmax(x)``) INSIDE the region; outside it the values are unspecified.  The decoder's 3x3x3 convs then skip
+        the bricks the region does not depend on (e3_unet_forward_roi).  Training mode, enabled grad or 2D modules: the plain forward."""
+        if self.training or torch.is_grad_enabled() or self.dim != 3 or self._per_sample_norm():
+            return self._run(x, softmax=softmax)
+        (d0, d1), (h0, h1), (w0, w1) = roi
+        self.__dict__['_roi_req'] = (int(d0), int(h0), int(w0), int(d1), int(h1), int(w1))
+        try:
+            return self._run(x, softmax=softmax)
+        finally:
+            del self.__dict__['_roi_req']
 
     @torch.jit.unused
     def forward_gradcp(self, x):

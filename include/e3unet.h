@@ -125,6 +125,15 @@ int e3_unet_forward_loss(e3_unet_plan* plan, void* stream, const float* x, int N
                          void* const* params, const float* momenta, float* y,
                          void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const e3_ce_dice_args* loss);
 
+/* Inference forward (no E3_FWD_TRAINING) of which the caller keeps only the output voxels [roi[0..2], roi[3..5]) (d, h, w on the grid of
+ * y) -- the tile loop of inference.Predictor, which crops the overlap off every tile's output (inference.py:496-525, tiled_apply :134-199):
+ * y holds the same values as after e3_unet_forward INSIDE that region and unspecified values outside it.  The decoder's 3x3x3 convs then
+ * compute only the bricks that the region needs (it grows by one voxel per conv and halves per transposed conv on the way back; the
+ * encoder is computed in full).  Configurations without the facility (valid convs, attention, ResizeConv, planar blocks, the bf16 path)
+ * simply compute everything. */
+int e3_unet_forward_roi(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
+                        void* const* params, float* y, void* scratch, size_t scratch_bytes, uint32_t flags, const int roi[6]);
+
 /* Gradients of a scalar loss w.r.t. every trainable parameter (and optionally x), given dy = dLoss/dy.
  *   grads : table-ordered device pointers (entries of buffers are ignored, may be NULL); every trainable entry
  *           is OVERWRITTEN with the gradient (accumulation into .grad stays with autograd)

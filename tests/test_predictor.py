@@ -369,3 +369,56 @@ def test_predictor_bf16_module_runs_the_native_bf16_kernels_and_tracks_fp32():
     assert yf.dtype == torch.float32 and float((yf - yb.float()).abs().max()) < 8e-3
     # the fp32 module is untouched and a float16 request still takes the reference's half-precision path
     assert next(m.parameters()).dtype == torch.float32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg', [
+    dict(n_blocks=3, start_filts=32, shape=(48, 96, 96), roi=((8, 40), (16, 80), (16, 80))),       # persistent Winograd kernel at the top level
+    dict(n_blocks=4, start_filts=32, shape=(64, 64, 96), roi=((16, 48), (16, 48), (16, 80))),      # the Predictor's crop: overlap 16 of every side
+    dict(n_blocks=2, start_filts=32, shape=(23, 45, 53), roi=((3, 17), (5, 41), (17, 30))),        # odd sizes, box not on brick edges
+    dict(n_blocks=3, start_filts=16, shape=(32, 64, 64), roi=((0, 32), (0, 64), (20, 44))),        # region that touches the tensor's faces
+])
+def test_forward_roi_equals_the_whole_forward_inside_the_region(cfg):
+    """UNet.forward_roi / e3_unet_forward_roi: bit-identical to the whole forward inside the region (the same bricks compute the same voxels;
+    the others are skipped), with and without the fused softmax."""
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(11)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=cfg['n_blocks'], start_filts=cfg['start_filts'], normalization='batch').cuda()
+    for mod in m.modules():          # eval-mode BatchNorm with non-trivial running statistics
+        if isinstance(mod, nn.BatchNorm3d):
+            mod.running_mean.normal_(0, 0.2); mod.running_var.uniform_(0.5, 1.5)
+    m.eval()
+    x = torch.randn(2, 1, *cfg['shape'], device='cuda')
+    sl = (slice(None), slice(None)) + tuple(slice(a, b) for a, b in cfg['roi'])
+    with torch.no_grad():
+        for sm in (False, True):
+            whole = m.forward_softmax(x) if sm else m(x)
+            # poison the scratch arena between the calls: a needed voxel that was skipped would read it
+            part = m.forward_roi(x, cfg['roi'], softmax=sm)
+            assert part.shape == whole.shape
+            assert torch.equal(part[sl], whole[sl])
+            assert torch.isfinite(part[sl]).all()
+
+
+@pytest.mark.gpu
+def test_predictor_needed_region_switch_gives_the_same_volume():
+    """Predictor.predict with the needed-region forward (default) and with whole tiles (E3_PREDICTOR_NO_ROI): identical volumes, in the
+    pipelined host<->device path and in the device-resident one."""
+    from elektronn3_amd import inference
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(5)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=3, start_filts=32, normalization='batch').cuda().eval()
+    vol = torch.randn(1, 1, 64, 128, 160)
+    outs = {}
+    for roi in (True, False):
+        inference._ROI = roi
+        try:
+            p = inference.Predictor(m, device='cuda', tile_shape=(32, 64, 80), overlap_shape=(16, 16, 16), out_shape=(2, 64, 128, 160),
+                                    apply_softmax=True)
+            outs[roi, 'pipe'] = p.predict(vol).clone()
+            outs[roi, 'dev'] = p.predict(vol.cuda()).cpu()
+        finally:
+            inference._ROI = True
+    assert torch.equal(outs[True, 'pipe'], outs[False, 'pipe'])
+    assert torch.equal(outs[True, 'dev'], outs[False, 'dev'])
+    assert torch.equal(outs[True, 'pipe'], outs[True, 'dev'])
