@@ -480,6 +480,24 @@ class Predictor:
                 uploaded[0] = b if uploaded[0] is None else max(uploaded[0], b)
                 up_events[k].record(up_stream)
 
+        # the FIRST z slab goes up in y pieces, one per row of tiles, so that the first row starts after 1 / nty of the slab has arrived (the
+        # cfg-5 volume: 0.24 GB instead of 2.1 GB of pageable host memory in front of the first tile); later slabs travel while tiles compute
+        k_first = zrows[0] if zrows else None
+        piece_events = [torch.cuda.Event() for _ in range(nty)]
+
+        def upload_piece(j):
+            a, b = need_lo[k_first], need_hi[k_first]
+            y0 = 0 if j == 0 else int(min(real[1], tile[1] * j + ov[1]))
+            y1 = int(real[1]) if j == nty - 1 else int(min(real[1], tile[1] * (j + 1) + ov[1]))
+            with torch.cuda.stream(up_stream):
+                if b > a and y1 > y0:
+                    dst = inp_padded[:, :, int(ov[0]) + a:int(ov[0]) + b, int(ov[1]) + y0:int(ov[1]) + y1, int(ov[2]):int(ov[2] + real[2])]
+                    dst.copy_(inp[:, :, a:b, y0:y1].to(self.dtype))
+                piece_events[j].record(up_stream)
+                if j == nty - 1:
+                    uploaded[0] = b
+                    up_events[k_first].record(up_stream)
+
         state = {'host_out': None, 'out_dev': None, 'shm': None}
         downs = []
 
@@ -514,13 +532,18 @@ class Predictor:
                     state['host_out'][:, :, z0:z1, y0:y1].copy_(state['out_dev'][:, :, z0:z1, y0:y1, :int(real[2])])
 
         with ThreadPoolExecutor(max_workers=1) as up_pool, ThreadPoolExecutor(max_workers=1) as down_pool:
-            ups = {k: up_pool.submit(upload, k) for k in zrows}
+            pieces = [up_pool.submit(upload_piece, j) for j in range(nty)] if zrows else []
+            ups = {k: up_pool.submit(upload, k) for k in zrows[1:]}
             if not mine:
                 make_outputs(None)
             for i, (k, j) in enumerate(mine):
+                if k == k_first:
+                    pieces[j].result()                # (the copy has been issued; the stream-side wait is the event)
+                    main.wait_event(piece_events[j])
                 if i == 0 or mine[i - 1][0] != k:
-                    ups[k].result()                   # (the copy has been issued; the stream-side wait is the event)
-                    main.wait_event(up_events[k])
+                    if k != k_first:
+                        ups[k].result()
+                        main.wait_event(up_events[k])
                     j_first = j
                     if i == 0:
                         ev_first.record(main)
