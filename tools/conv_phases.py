@@ -38,6 +38,13 @@ for mode in ('stats',):
     print(f'{cin}->{cout} {mode}: {int(used.sum())} workgroups; per brick (us): ' + ', '.join(f'{n} {d[:, i][used].mean():.2f}' for i, n in enumerate(names))
           + f'; total {(t[:, 7] - t[:, 0])[used].mean() * 10.0 / 1e3:.2f}; kernel span {(t[:, 7].max() - t[:, 0][used].min()) * 10.0 / 1e3:.1f} us')
 
+    if (t[:, 9] > 0).any():          # first chunk of a brick with several chunks: slots 9..13 = the same stamps
+        u0 = used & (t[:, 9] > 0)
+        c0 = np.diff(t[:, 9:14], axis=1) * 10.0 / 1e3
+        print(f'    prologue: start -> decoded {((t[:, 14] - t[:, 0])[u0]).mean() * 10.0 / 1e3:.2f}, -> staging plan {((t[:, 15] - t[:, 14])[u0]).mean() * 10.0 / 1e3:.2f}, -> first DMA issued {((t[:, 9] - t[:, 15])[u0]).mean() * 10.0 / 1e3:.2f}')
+        print(f'    first chunk: start -> DMA issued {((t[:, 9] - t[:, 0])[u0]).mean() * 10.0 / 1e3:.2f}, DMA wait {c0[:, 0][u0].mean():.2f}, barrier {c0[:, 1][u0].mean():.2f}, '
+              f'taps {c0[:, 2][u0].mean():.2f}, barrier {c0[:, 3][u0].mean():.2f}')
+
 # ---- weight gradient (same debug build): python tools/conv_phases.py 32 32  prints this after the forward's phases
 fnw = getattr(L, 'e3_debug_wgrad_timing', None)
 if fnw is not None:
