@@ -69,9 +69,9 @@ def cpu_baseline(iters=3):
             's_per_step': dt}
 
 
-def needed_region_flops(tile_in, overlap, n_blocks=4, sf=32):
+def needed_region_flops(tile_in, overlap, n_blocks=4, sf=32, bricks=((4, 4, 16),) * 3):
     """(forward FLOP of one tile, FLOP the needed-region forward skips): the Predictor keeps the central crop of a tile, so the decoder's
-    3x3x3 convs only compute the Winograd bricks (4 x 4 x 16 voxels) that crop depends on -- the box grows by one voxel per conv and halves
+    3x3x3 convs only compute the bricks (fp32 Winograd: 4 x 4 x 16 voxels; 16-bit kernels: 4 x 4 x 32 at level 0, 2 x 8 x 16 below) that crop depends on -- the box grows by one voxel per conv and halves
     per transposed conv on the way back through the decoder (elektronn3_amd/csrc/unet_plan.cpp, e3_unet_forward_roi)."""
     vox = tile_in[0] * tile_in[1] * tile_in[2]
     whole = 427.2e3 * vox                                                 # SURVEY 8d: forward FLOP per input voxel of UNet(n_blocks=4, sf=32)
@@ -81,7 +81,7 @@ def needed_region_flops(tile_in, overlap, n_blocks=4, sf=32):
         dims = [t >> lvl for t in tile_in]
         c = sf << lvl
         for cin in (c, 2 * c):                                            # conv2 (c -> c), then conv1 (concat 2c -> c), walking backwards
-            edge = (4, 4, 16)
+            edge = bricks[lvl]
             blo = [l // e * e for l, e in zip(lo, edge)]
             bhi = [min(-(-h // e) * e, d) for h, e, d in zip(hi, edge, dims)]
             done = (bhi[0] - blo[0]) * (bhi[1] - blo[1]) * (bhi[2] - blo[2])
@@ -125,8 +125,8 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
     for n, t in zip(shape, tile):
         ntiles *= -(-n // t)
     tile_in = [t + 2 * o for t, o in zip(tile, overlap)]
-    tile_flop, skipped = needed_region_flops(tile_in, overlap)            # forward FLOP per tile incl. halo (2744 GFLOP)
-    roi_on = bool(_inf._ROI) and not bf16                                 # (fp32 path only: the bf16 kernels compute whole tiles)
+    tile_flop, skipped = needed_region_flops(tile_in, overlap, bricks=((4, 4, 32), (2, 8, 16), (2, 8, 16)) if bf16 else ((4, 4, 16),) * 3)   # forward FLOP per tile incl. halo (2744 GFLOP)
+    roi_on = bool(_inf._ROI)
     done_flop = tile_flop - (skipped if roi_on else 0.0)
     _inf._ROI = roi_default
     return {'metric': 'Predictor MVox/s', 'value': vol.numel() / dt / 1e6, 'unit': 'MVox/s (input voxels / predict() wall time incl. H2D + D2H)',
@@ -137,7 +137,7 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
             'needed_region': roi_on, 'flop_skipped_frac': (skipped / tile_flop) if roi_on else 0.0,
             'algorithmic_tflops': ntiles * tile_flop / dt / 1e12,
             'mfma_executed_frac': ntiles * done_flop * (1.0 if bf16 else 64.0 / 216.0) / dt / 1e12 / MFMA_PEAK_TFLOPS['bf16' if bf16 else 'f32'],
-            'note': ('executed fraction = matrix FLOP of the direct bf16 convs (= the algorithmic count) / wall time incl. PCIe / dense bf16 MFMA peak' if bf16 else
+            'note': ('needed_region: as in the fp32 leg; executed fraction = matrix FLOP of the direct 16-bit convs actually run / wall time incl. PCIe / dense bf16 MFMA peak' if bf16 else
                      'needed_region: the decoder convs compute only the Winograd bricks that the kept central crop of a tile depends on (same predict() result; '
                      'E3_PREDICTOR_NO_ROI=1 computes whole tiles); algorithmic_tflops counts whole tiles (what the reference computes), executed fraction = '
                      'Winograd-executed matrix FLOP actually run (64/216 of the un-skipped algorithmic count) / wall time incl. PCIe / fp32 MFMA peak')}
@@ -347,8 +347,9 @@ def main():
                 res['predictor'] = p
             if world == 1 and p.get('needed_region'):      # the same Predictor on a 288x1152x1152 volume with whole tiles and with the needed region
                 sub = (288, 1152, 1152)
-                a = predictor_leg(dev, sub, whole_tiles=True)
-                b = p if tuple(shape) == sub else predictor_leg(dev, sub)
+                b16 = args.dtype if args.dtype in ('bf16', 'f16') else False
+                a = predictor_leg(dev, sub, whole_tiles=True, bf16=b16)
+                b = p if tuple(shape) == sub else predictor_leg(dev, sub, bf16=b16)
                 p['needed_region_ab'] = {'volume': list(sub), 'whole_tiles_mvox_s': a['value'], 'needed_region_mvox_s': b['value'],
                                          'whole_tiles_compute_s': a['timing'].get('compute_stream_s'), 'needed_region_compute_s': b['timing'].get('compute_stream_s')}
         except Exception as e:  # noqa: BLE001

@@ -56,6 +56,8 @@ _SIG = {
     'e3_unet_forward_loss': (_I, [c_void_p, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), POINTER(c_float), _P,
                                   _P, c_size_t, _P, c_size_t, c_uint32, POINTER(CEDiceArgs)]),
     'e3_unet_forward_roi': (_I, [c_void_p, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), _P, _P, c_size_t, c_uint32, POINTER(c_int)]),
+    'e3_unet_forward_roi_bf16': (_I, [c_void_p, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), _P, _P, c_size_t, c_uint32, POINTER(c_int)]),
+    'e3_unet_forward_roi_f16': (_I, [c_void_p, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), _P, _P, c_size_t, c_uint32, POINTER(c_int)]),
     'e3_unet_backward': (_I, [c_void_p, _P, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), POINTER(c_void_p), _P,
                               _P, c_size_t, _P, c_size_t, _P, _I]),
     'e3_unet_bf16_supported': (_I, [c_void_p]),

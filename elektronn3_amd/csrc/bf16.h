@@ -51,6 +51,9 @@ struct ConvB16Args {
     // to y2 (same y_ldc).  x_split / y_split are multiples of 32; 0 = single tensor.
     const bf16_t* x2; int x_split;
     bf16_t* y2; int y_split;
+    // needed region (inference, 3x3x3 only): when box_hi[0] > 0 only the bricks that meet the voxel box [box_lo, box_hi) are computed, the rest of y
+    // is left untouched.  No statistics.
+    int box_lo[3], box_hi[3];
 };
 int conv_b16_stats_parts(int N, int D, int H, int W, int Cin, int Cout, int planar);
 size_t conv_b16_partial_floats(int N, int D, int H, int W, int Cin, int Cout, int planar);

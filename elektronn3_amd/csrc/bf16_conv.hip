@@ -63,7 +63,7 @@ __device__ unsigned long long* g_timing = nullptr;       // phase timestamps (to
 // register file: 64 accumulators + weight ring + fragments need > 128 registers) and a workgroup's staging meets two others' MFMA / store
 // phases (same bricks, same halo traffic, twice the barriers)
 template <int BD, int CO_T, int KD, int TW, int CH = 32>
-__global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_kernel(const ConvB16Args a, int tilesD, int tilesH, int tilesW, int cgroups, int ksplit) {
+__global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_kernel(const ConvB16Args a, int tilesD, int tilesH, int tilesW, int cgroups, int ksplit, int o_td, int o_th, int o_tw) {
     using G = Geo<BD, KD, TW, CH>;
     constexpr int RB = G::RB, PPV = G::PPV, KS = G::KS;
     constexpr int HH = G::HH, HW = G::HW;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_k
     } else {
         tw = L % tilesW; L /= tilesW; th = L % tilesH; L /= tilesH; td = L % tilesD; n = L / tilesD;
     }
-    const int d0 = td * G::DZ, h0 = th * G::BH, w0 = tw * G::BW;
+    const int d0 = (td + o_td) * G::DZ, h0 = (th + o_th) * G::BH, w0 = (tw + o_tw) * G::BW;      // (o_*: first brick of the needed region)
     const int co0 = cg * 32 * CO_T;
     constexpr int PD = KD == 3 ? 1 : 0;
     const int nch = a.Cin / CH;
@@ -401,13 +401,25 @@ __global__ void pack_multi_b16_kernel(const PackMultiArgs a) {
 template <int BD, int CO_T, int KD, int TW, int CH = 32>
 int launch_t(const ConvB16Args& a, int ksplit, hipStream_t s) {
     using G = Geo<BD, KD, TW, CH>;
-    const int tD = cdiv(a.D, G::DZ), tH = cdiv(a.H, G::BH), tW = cdiv(a.W, G::BW);
+    int tD = cdiv(a.D, G::DZ), tH = cdiv(a.H, G::BH), tW = cdiv(a.W, G::BW);
+    int o[3] = {0, 0, 0};
+    if (a.box_hi[0] > 0 && !G::FLAT) {      // needed region: the bricks that meet the box
+        E3_REQUIRE(!a.stats, E3_ERR_INVALID, "bf16 conv with a needed region: no statistics");
+        const int dims[3] = {a.D, a.H, a.W}, edge[3] = {G::DZ, G::BH, G::BW};
+        int n[3];
+        for (int i = 0; i < 3; ++i) {
+            const int lo = a.box_lo[i] < 0 ? 0 : a.box_lo[i], hi = a.box_hi[i] > dims[i] ? dims[i] : a.box_hi[i];
+            E3_REQUIRE(hi > lo, E3_ERR_INVALID, "bf16 conv with a needed region: empty box");
+            o[i] = lo / edge[i]; n[i] = cdiv(hi, edge[i]) - o[i];
+        }
+        tD = n[0]; tH = n[1]; tW = n[2];
+    }
     const int cgroups = a.Cout / (32 * CO_T);
     const size_t grid = (size_t)a.N * tD * tH * tW * cgroups * ksplit;
     const int lds = G::IMG > 4 * 2 * 32 * 33 * 4 + 1024 ? G::IMG : 4 * 2 * 32 * 33 * 4 + 1024;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)conv_b16_kernel<BD, CO_T, KD, TW, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
-    hipLaunchKernelGGL((conv_b16_kernel<BD, CO_T, KD, TW, CH>), dim3((unsigned)grid), dim3(256), lds, s, a, tD, tH, tW, cgroups, ksplit);
+    hipLaunchKernelGGL((conv_b16_kernel<BD, CO_T, KD, TW, CH>), dim3((unsigned)grid), dim3(256), lds, s, a, tD, tH, tW, cgroups, ksplit, o[0], o[1], o[2]);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

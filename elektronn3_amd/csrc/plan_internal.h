@@ -94,3 +94,9 @@ struct NetDims {
 };
 
 void net_dims(const e3_unet_plan* p, int N, int D, int H, int W, NetDims& nd);
+
+// Needed regions of an inference forward whose caller keeps only the output voxels [roi[0..2], roi[3..5]) (e3_unet_forward_roi*): per unit the
+// box of ITS output that the layers behind it read for those voxels (on = false: the whole tensor).  The box grows by the 3x3x3 reach per
+// conv and halves per transposed conv on the way back through the decoder; the encoder is needed in full (the bottom level sees all of it).
+struct NeedBox { int lo[3], hi[3]; bool on = false; };
+std::vector<NeedBox> need_boxes(const e3_unet_plan* plan, const NetDims& ND, const int* roi);

@@ -160,9 +160,27 @@ int e3_unet_sizes_bf16(const e3_unet_plan* plan, int N, int D, int H, int W, int
     return E3_OK;
 }
 
+static int forward_b16_impl(e3_unet_plan* plan, void* stream, const void* x, int N, int D, int H, int W,
+                            void* const* params, const float* momenta, float* y,
+                            void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const int* roi);
+
 int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N, int D, int H, int W,
                          void* const* params, const float* momenta, float* y,
                          void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags) {
+    return forward_b16_impl(plan, stream, x, N, D, H, W, params, momenta, y, saved, saved_bytes, scratch, scratch_bytes, flags, nullptr);
+}
+
+int e3_unet_forward_roi_bf16(e3_unet_plan* plan, void* stream, const void* x, int N, int D, int H, int W,
+                             void* const* params, float* y, void* scratch, size_t scratch_bytes, uint32_t flags, const int roi[6]) {
+    E3_REQUIRE(roi, E3_ERR_INVALID, "forward_roi: null region");
+    E3_REQUIRE(!(flags & (E3_FWD_TRAINING | E3_FWD_FROZEN_BN)), E3_ERR_INVALID, "forward_roi: inference only");
+    for (int i = 0; i < 3; ++i) E3_REQUIRE(roi[i] >= 0 && roi[3 + i] > roi[i], E3_ERR_INVALID, "forward_roi: empty or negative region");
+    return forward_b16_impl(plan, stream, x, N, D, H, W, params, nullptr, y, nullptr, 0, scratch, scratch_bytes, flags, roi);
+}
+
+static int forward_b16_impl(e3_unet_plan* plan, void* stream, const void* x, int N, int D, int H, int W,
+                            void* const* params, const float* momenta, float* y,
+                            void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const int* roi) {
     E3_REQUIRE(plan && x && y && params && scratch, E3_ERR_INVALID, "null argument");
     E3_REQUIRE(supported(plan->cfg), E3_ERR_UNSUPPORTED, "configuration not on the native bf16 path");
     hipStream_t s = (hipStream_t)stream;
@@ -178,6 +196,7 @@ int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N,
     NetDims ND; net_dims(plan, N, D, H, W, ND);
     auto P = [&](int i) { return (float*)params[i]; };
     const size_t nu = plan->units.size();
+    const std::vector<NeedBox> need = need_boxes(plan, ND, training ? nullptr : roi);      // (e3_unet_forward_roi_bf16; plan_internal.h)
 
     if (!training) {     // eval mode: BN folded into every conv epilogue (running statistics), all folds in one launch
         std::vector<FoldJob> jobs;
@@ -230,6 +249,8 @@ int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N,
             a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Cout = u.cout; a.planar = pl;
             a.epi_scale = es; a.epi_shift = eh; a.stats = training ? B.stats : nullptr; a.partial = B.skws;
             parts = conv_b16_stats_parts(N, li.D, li.H, li.W, u.cin, u.cout, pl);
+            if (need[k].on && !pl && !a.stats)
+                for (int i = 0; i < 3; ++i) { a.box_lo[i] = need[k].lo[i]; a.box_hi[i] = need[k].hi[i]; }
             { ProfB pr(plan, s, (int)k, 0); RUN(launch_conv_b16(a, s)); }
         }
         if (training) {

@@ -367,6 +367,31 @@ struct Prof {
 
 }  // namespace
 
+std::vector<NeedBox> need_boxes(const e3_unet_plan* plan, const NetDims& ND, const int* roi) {
+    std::vector<NeedBox> need(plan->units.size());
+    if (!roi) return need;
+    NeedBox b; b.on = true;
+    const int yd[3] = {ND.Y.D, ND.Y.H, ND.Y.W};
+    for (int i = 0; i < 3; ++i) { b.lo[i] = roi[i] < yd[i] ? roi[i] : yd[i] - 1; b.hi[i] = roi[3 + i] < yd[i] ? roi[3 + i] : yd[i]; }
+    for (size_t k = plan->units.size(); k-- > 0 && b.on;) {
+        const ConvUnit& u = plan->units[k];
+        if (u.is_down || u.res_in >= 0) break;
+        need[k] = b;
+        const int di[3] = {ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W};
+        if (u.is_up == 1) {            // transposed conv, kernel = stride: output voxel o reads input voxel o / stride
+            const int st[3] = {u.planar ? 1 : 2, 2, 2};
+            for (int i = 0; i < 3; ++i) { b.lo[i] = b.lo[i] / st[i]; b.hi[i] = (b.hi[i] + st[i] - 1) / st[i]; }
+        } else if (u.is_up) {
+            b.on = false;              // (ResizeConv: everything in front of it is computed in full)
+        } else {
+            const int r[3] = {u.planar ? 0 : 1, 1, 1};
+            for (int i = 0; i < 3; ++i) { b.lo[i] = b.lo[i] - r[i] < 0 ? 0 : b.lo[i] - r[i]; b.hi[i] = b.hi[i] + r[i] > di[i] ? di[i] : b.hi[i] + r[i]; }
+        }
+        for (int i = 0; i < 3; ++i) if (b.hi[i] > di[i]) b.hi[i] = di[i];
+    }
+    return need;
+}
+
 extern "C" {
 
 int e3_unet_plan_create(const e3_unet_cfg* cfg, e3_unet_plan** out) {
@@ -650,29 +675,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
     // box grows by the 3x3x3 reach per conv and halves per transposed conv on the way back through the decoder, and stops mattering where
     // it covers the tensor (the encoder is needed in full: the bottom level sees all of it).  The boxes are handed to the conv launchers;
     // kernels without the facility compute the whole tensor.  Outside the boxes the buffers keep whatever they held.
-    struct NeedBox { int lo[3], hi[3]; bool on = false; };
-    std::vector<NeedBox> need(plan->units.size());
-    if (roi && !training && !valid && !cfg.attention) {
-        NeedBox b; b.on = true;
-        const int yd[3] = {ND.Y.D, ND.Y.H, ND.Y.W};
-        for (int i = 0; i < 3; ++i) { b.lo[i] = roi[i] < yd[i] ? roi[i] : yd[i] - 1; b.hi[i] = roi[3 + i] < yd[i] ? roi[3 + i] : yd[i]; }
-        for (size_t k = plan->units.size(); k-- > 0 && b.on;) {
-            const ConvUnit& u = plan->units[k];
-            if (u.is_down || u.res_in >= 0) break;
-            need[k] = b;
-            const int di[3] = {ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W};
-            if (u.is_up == 1) {            // transposed conv, kernel = stride: output voxel o reads input voxel o / stride
-                const int st[3] = {u.planar ? 1 : 2, 2, 2};
-                for (int i = 0; i < 3; ++i) { b.lo[i] = b.lo[i] / st[i]; b.hi[i] = (b.hi[i] + st[i] - 1) / st[i]; }
-            } else if (u.is_up) {
-                b.on = false;              // (ResizeConv: everything in front of it is computed in full)
-            } else {
-                const int r[3] = {u.planar ? 0 : 1, 1, 1};
-                for (int i = 0; i < 3; ++i) { b.lo[i] = b.lo[i] - r[i] < 0 ? 0 : b.lo[i] - r[i]; b.hi[i] = b.hi[i] + r[i] > di[i] ? di[i] : b.hi[i] + r[i]; }
-            }
-            for (int i = 0; i < 3; ++i) if (b.hi[i] > di[i]) b.hi[i] = di[i];
-        }
-    }
+    const std::vector<NeedBox> need = need_boxes(plan, ND, (roi && !training && !valid && !cfg.attention) ? roi : nullptr);
 
     // split-K of a bottom-level conv (conv_wino_splitk): training forward of units with batch statistics only (their raw output and its
     // statistics come from the reduction pass; the eval / no-norm paths keep the fused epilogues)

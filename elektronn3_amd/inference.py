@@ -34,6 +34,107 @@ logger = logging.getLogger('elektronn3log')
 Transform = Callable[[np.ndarray, Optional[np.ndarray]], Tuple[np.ndarray, Optional[np.ndarray]]]
 
 
+_COPY_POOL = None
+
+
+def _host_copy(dst, src):
+    """dst.copy_(src) for two host tensors (N, C, z, ...), large ones split along z over a few threads: a single memcpy stream (~5 GB/s with the
+    page faults of a fresh output buffer) is less than the 16-bit Predictor moves per second."""
+    global _COPY_POOL
+    nz = src.shape[2] if src.dim() >= 3 else 1
+    if src.numel() * src.element_size() < (64 << 20) or nz < 4:
+        dst.copy_(src)
+        return
+    if _COPY_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _COPY_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix='e3copy')
+    step = -(-nz // 4)
+    futs = [_COPY_POOL.submit(lambda a=a: dst[:, :, a:a + step].copy_(src[:, :, a:a + step])) for a in range(0, nz, step)]
+    for f in futs:
+        f.result()
+
+
+class _PinnedRing:
+    """Two page-locked staging buffers per direction for the Predictor's host <-> device pipeline: a slab of a pageable host tensor is copied
+    into a pinned slot by the CPU and from there to the device by the copy engines (and the other way round), so the transfers are asynchronous
+    DMA instead of the runtime's pageable path (which stages through its own bounce buffer and moves the data with copy KERNELS on the compute
+    units, beside the model's kernels).  One ring per Predictor and direction; used by one thread at a time."""
+
+    def __init__(self, slot_bytes=256 << 20):
+        self.slots = [torch.empty(slot_bytes, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        self.events = [None, None]
+        self.pending = [None, None]          # d2h: (host view, slot view) still to be copied out
+        self.i = 0
+
+    def _slot(self, shape, dtype):
+        k = self.i
+        self.i ^= 1
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+            self.events[k] = None
+        if self.pending[k] is not None:
+            host, view = self.pending[k]
+            _host_copy(host, view)
+            self.pending[k] = None
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        return k, self.slots[k][:n].view(dtype).view(*shape)
+
+    def _planes(self, t):
+        per_plane = max(1, t[:, :, :1].numel() * t.element_size())
+        return max(1, self.slots[0].numel() // per_plane)
+
+    def h2d(self, dst, src, stream, convert_on_device):
+        """pageable host view src (N, C, z, y, x) -> device view dst, slabs of z planes through the pinned slots"""
+        step = self._planes(src)
+        for z in range(0, src.shape[2], step):
+            part = src[:, :, z:z + step]
+            k, view = self._slot(part.shape, part.dtype)
+            _host_copy(view, part)
+            d = dst[:, :, z:z + step]
+            if part.dtype == d.dtype or not convert_on_device:
+                d.copy_(view, non_blocking=True)
+            else:                                 # (another dtype than the model's: converted on the device, not by the host thread)
+                stage = torch.empty(part.shape, dtype=part.dtype, device=d.device)
+                stage.copy_(view, non_blocking=True)
+                d.copy_(stage)
+            self.events[k] = torch.cuda.Event()
+            self.events[k].record(stream)
+
+    def d2h(self, dst, src, stream):
+        """device view src -> pageable host view dst"""
+        step = self._planes(src)
+        for z in range(0, src.shape[2], step):
+            part = src[:, :, z:z + step]
+            k, view = self._slot(part.shape, part.dtype)
+            view.copy_(part, non_blocking=True)
+            self.events[k] = torch.cuda.Event()
+            self.events[k].record(stream)
+            self.pending[k] = (dst[:, :, z:z + step], view)
+
+    def flush(self):
+        for k in (self.i, self.i ^ 1):
+            if self.events[k] is not None:
+                self.events[k].synchronize()
+                self.events[k] = None
+            if self.pending[k] is not None:
+                host, view = self.pending[k]
+                _host_copy(host, view)
+                self.pending[k] = None
+
+
+_RINGS = {}
+
+
+def _rings_for(device):
+    """(upload ring, download ring) of a device, allocated once per process (1 GB of page-locked memory); None with E3_PREDICTOR_NO_PINNED=1."""
+    if os.environ.get('E3_PREDICTOR_NO_PINNED') is not None:
+        return None
+    key = torch.device(device).index or 0
+    if key not in _RINGS:
+        _RINGS[key] = (_PinnedRing(), _PinnedRing())
+    return _RINGS[key]
+
+
 class _SharedHostTensor:
     """A host tensor backed by a file in /dev/shm that the ranks of one node map together (np.memmap): the tile-parallel
     Predictor's output buffer.  The creator unlinks the name once every rank has finished writing; the mappings stay valid
@@ -349,6 +450,8 @@ class Predictor:
 
         geo = _Tiling(tile_shape, overlap_shape, offset, out_shape, estimate_offset)
         self.enable_tiling = geo.enabled
+        if self.enable_tiling and self.device.type == 'cuda' and geo.out_shape is not None:
+            _rings_for(self.device)           # (page-locked staging of the host <-> device pipeline: allocated here, once per process, not inside predict())
         self.offset, self.tile_shape, self.overlap_shape, self.out_shape = geo.offset, geo.tile_shape, geo.overlap_shape, geo.out_shape
 
     # ------------------------------------------------------------------ per-tile model call (inference.py:496-525)
@@ -469,6 +572,20 @@ class Predictor:
         need_hi = {k: int(min(real[0], tile[0] * (k + 1) + ov[0])) for k in zrows}
         up_events = {k: torch.cuda.Event() for k in zrows}
         uploaded = [None]                                                 # z plane up to which the input is on the device
+        # pinned staging rings (one per direction, kept by the Predictor): E3_PREDICTOR_NO_PINNED=1 = the runtime's pageable copies
+        rings = _rings_for(dev)
+
+        def put(dst, src):
+            """host slab -> device view.  A volume in another dtype than the model's (fp32 volume, bf16 / float16 model) travels as it is and is
+            converted on the device: converting 2 G voxels on the host first made the upload thread the bottleneck of the 16-bit Predictor."""
+            if rings is not None:
+                rings[0].h2d(dst, src, up_stream, True)
+            elif src.dtype == dst.dtype:
+                dst.copy_(src)
+            else:
+                stage = torch.empty(src.shape, dtype=src.dtype, device=dev)
+                stage.copy_(src)
+                dst.copy_(stage)
 
         def upload(k):
             a = need_lo[k] if uploaded[0] is None else max(uploaded[0], need_lo[k])
@@ -476,7 +593,7 @@ class Predictor:
             with torch.cuda.stream(up_stream):
                 if b > a:
                     dst = inp_padded[:, :, int(ov[0]) + a:int(ov[0]) + b, int(ov[1]):int(ov[1] + real[1]), int(ov[2]):int(ov[2] + real[2])]
-                    dst.copy_(inp[:, :, a:b].to(self.dtype))
+                    put(dst, inp[:, :, a:b])
                 uploaded[0] = b if uploaded[0] is None else max(uploaded[0], b)
                 up_events[k].record(up_stream)
 
@@ -492,7 +609,7 @@ class Predictor:
             with torch.cuda.stream(up_stream):
                 if b > a and y1 > y0:
                     dst = inp_padded[:, :, int(ov[0]) + a:int(ov[0]) + b, int(ov[1]) + y0:int(ov[1]) + y1, int(ov[2]):int(ov[2] + real[2])]
-                    dst.copy_(inp[:, :, a:b, y0:y1].to(self.dtype))
+                    put(dst, inp[:, :, a:b, y0:y1])
                 piece_events[j].record(up_stream)
                 if j == nty - 1:
                     uploaded[0] = b
@@ -529,7 +646,10 @@ class Predictor:
                 z0, z1 = int(tile[0] * k), int(min(tile[0] * (k + 1), real[0]))
                 y0, y1 = int(tile[1] * j0), int(min(tile[1] * j1, real[1]))
                 if z1 > z0 and y1 > y0:
-                    state['host_out'][:, :, z0:z1, y0:y1].copy_(state['out_dev'][:, :, z0:z1, y0:y1, :int(real[2])])
+                    if rings is not None:
+                        rings[1].d2h(state['host_out'][:, :, z0:z1, y0:y1], state['out_dev'][:, :, z0:z1, y0:y1, :int(real[2])], down_stream)
+                    else:
+                        state['host_out'][:, :, z0:z1, y0:y1].copy_(state['out_dev'][:, :, z0:z1, y0:y1, :int(real[2])])
 
         with ThreadPoolExecutor(max_workers=1) as up_pool, ThreadPoolExecutor(max_workers=1) as down_pool:
             pieces = [up_pool.submit(upload_piece, j) for j in range(nty)] if zrows else []
@@ -566,6 +686,8 @@ class Predictor:
             t_issued = time.perf_counter()
             for d in downs:
                 d.result()
+            if rings is not None:
+                down_pool.submit(rings[1].flush).result()
         torch.cuda.synchronize(dev)
         # where the wall time went (bench.py reports it): the compute stream's span from the first tile to the last one (it includes waits for
         # uploads), the host time to issue the tile loop, and the wall time around both

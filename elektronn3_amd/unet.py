@@ -156,8 +156,9 @@ def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, traini
             la = _lib.CEDiceArgs(loss['target'].data_ptr(), w.data_ptr() if w is not None else None, loss['ce'], loss['dice'], loss['eps'], loss['smooth'],
                                  loss['ws'].data_ptr(), nbytes, loss['out'].data_ptr())
             check(lib.e3_unet_forward_loss(*args, ctypes.byref(la)))
-        elif roi is not None and b16 is None and not training:      # only the voxels of `roi` are wanted (UNet.forward_roi)
-            check(lib.e3_unet_forward_roi(plan.handle, _lib.stream_ptr(dev), c_void_p(xin.data_ptr()), N, D, H, W, ptrs, c_void_p(y.data_ptr()),
+        elif roi is not None and not training:      # only the voxels of `roi` are wanted (UNet.forward_roi)
+            fwd_roi = lib.e3_unet_forward_roi_f16 if b16 is torch.float16 else (lib.e3_unet_forward_roi_bf16 if b16 is not None else lib.e3_unet_forward_roi)
+            check(fwd_roi(plan.handle, _lib.stream_ptr(dev), c_void_p(xin.data_ptr()), N, D, H, W, ptrs, c_void_p(y.data_ptr()),
                                           c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), flags, (ctypes.c_int * 6)(*roi)))
         else:
             check(fwd(*args))

@@ -312,6 +312,9 @@ int e3_unet_sizes_bf16(const e3_unet_plan* plan, int N, int D, int H, int W, int
 int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N, int D, int H, int W,
                          void* const* params, const float* momenta, float* y,
                          void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags);
+/* e3_unet_forward_roi on this path (inference; the needed region of the Predictor's central crop, see e3_unet_forward_roi) */
+int e3_unet_forward_roi_bf16(e3_unet_plan* plan, void* stream, const void* x, int N, int D, int H, int W,
+                             void* const* params, float* y, void* scratch, size_t scratch_bytes, uint32_t flags, const int roi[6]);
 int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, const void* x, int N, int D, int H, int W,
                           void* const* params, void* const* grads, void* dx,
                           void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
@@ -348,6 +351,8 @@ int e3_unet_sizes_f16(const e3_unet_plan* plan, int N, int D, int H, int W, int 
 int e3_unet_forward_f16(e3_unet_plan* plan, void* stream, const void* x, int N, int D, int H, int W,
                          void* const* params, const float* momenta, float* y,
                          void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags);
+int e3_unet_forward_roi_f16(e3_unet_plan* plan, void* stream, const void* x, int N, int D, int H, int W,
+                            void* const* params, float* y, void* scratch, size_t scratch_bytes, uint32_t flags, const int roi[6]);
 int e3_unet_backward_f16(e3_unet_plan* plan, void* stream, const float* dy, const void* x, int N, int D, int H, int W,
                           void* const* params, void* const* grads, void* dx,
                           void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,

@@ -378,17 +378,21 @@ def test_predictor_bf16_module_runs_the_native_bf16_kernels_and_tracks_fp32():
     dict(n_blocks=2, start_filts=32, shape=(23, 45, 53), roi=((3, 17), (5, 41), (17, 30))),        # odd sizes, box not on brick edges
     dict(n_blocks=3, start_filts=16, shape=(32, 64, 64), roi=((0, 32), (0, 64), (20, 44))),        # region that touches the tensor's faces
 ])
-def test_forward_roi_equals_the_whole_forward_inside_the_region(cfg):
-    """UNet.forward_roi / e3_unet_forward_roi: bit-identical to the whole forward inside the region (the same bricks compute the same voxels;
-    the others are skipped), with and without the fused softmax."""
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_forward_roi_equals_the_whole_forward_inside_the_region(cfg, dtype):
+    """UNet.forward_roi / e3_unet_forward_roi (fp32), _roi_bf16, _roi_f16: bit-identical to the whole forward inside the region (the same
+    bricks compute the same voxels; the others are skipped), with and without the fused softmax."""
     from elektronn3_amd.unet import UNet
+    if dtype != torch.float32 and cfg['start_filts'] % 32:
+        pytest.skip('the native 16-bit path needs start_filts % 32 == 0')
     torch.manual_seed(11)
     m = UNet(in_channels=1, out_channels=2, n_blocks=cfg['n_blocks'], start_filts=cfg['start_filts'], normalization='batch').cuda()
     for mod in m.modules():          # eval-mode BatchNorm with non-trivial running statistics
         if isinstance(mod, nn.BatchNorm3d):
             mod.running_mean.normal_(0, 0.2); mod.running_var.uniform_(0.5, 1.5)
     m.eval()
-    x = torch.randn(2, 1, *cfg['shape'], device='cuda')
+    m = m.to(dtype)
+    x = torch.randn(2, 1, *cfg['shape'], device='cuda').to(dtype)
     sl = (slice(None), slice(None)) + tuple(slice(a, b) for a, b in cfg['roi'])
     with torch.no_grad():
         for sm in (False, True):
@@ -397,7 +401,7 @@ def test_forward_roi_equals_the_whole_forward_inside_the_region(cfg):
             part = m.forward_roi(x, cfg['roi'], softmax=sm)
             assert part.shape == whole.shape
             assert torch.equal(part[sl], whole[sl])
-            assert torch.isfinite(part[sl]).all()
+            assert torch.isfinite(part[sl].float()).all()
 
 
 @pytest.mark.gpu
@@ -422,3 +426,26 @@ def test_predictor_needed_region_switch_gives_the_same_volume():
     assert torch.equal(outs[True, 'pipe'], outs[False, 'pipe'])
     assert torch.equal(outs[True, 'dev'], outs[False, 'dev'])
     assert torch.equal(outs[True, 'pipe'], outs[True, 'dev'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_predictor_pinned_staging_switch_gives_the_same_volume(monkeypatch, dtype):
+    """The host <-> device pipeline through the page-locked staging rings (default; slabs larger than a 256 MB slot are split, a fp32 volume for
+    a 16-bit model is converted on the device) and through the runtime's pageable copies (E3_PREDICTOR_NO_PINNED=1): identical volumes."""
+    from elektronn3_amd import inference
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(6)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=2, start_filts=32, normalization='batch').cuda().eval().to(dtype)
+    vol = torch.randn(1, 1, 40, 96, 130)                      # fp32 host volume, odd width (cropped rows on the way back)
+    outs = []
+    for pinned in (True, False):
+        if pinned:
+            monkeypatch.delenv('E3_PREDICTOR_NO_PINNED', raising=False)
+            monkeypatch.setattr(inference, '_RINGS', {0: (inference._PinnedRing(3 << 20), inference._PinnedRing(1 << 20))})   # small slots: several slabs per row
+        else:
+            monkeypatch.setenv('E3_PREDICTOR_NO_PINNED', '1')
+        p = inference.Predictor(m, device='cuda', tile_shape=(20, 48, 65), overlap_shape=(8, 8, 8), out_shape=(2, 40, 96, 130), apply_softmax=True)
+        assert p.dtype == dtype
+        outs.append(p.predict(vol).clone())
+    assert outs[0].dtype == outs[1].dtype and torch.equal(outs[0], outs[1])
