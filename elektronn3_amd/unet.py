@@ -286,6 +286,9 @@ class _UNetFunction(torch.autograd.Function):
         # (grad mode is off inside Function.forward; needs_input_grad tells whether a backward can follow)
         # (needs_input_grad mirrors requires_grad of the inputs whatever the grad mode: `mode` carries torch.is_grad_enabled() of the caller,
         # so that validation under torch.no_grad() takes the inference path instead of saving activations nobody will use)
+        roi = None
+        if isinstance(mode, tuple):          # (mode bits, needed region): UNet.forward_roi
+            mode, roi = mode
         softmax, grad_on = bool(mode & 1), bool(mode & 2)
         need_grad = grad_on and any(ctx.needs_input_grad) and not softmax
         # a module in eval mode that a backward will follow (frozen-BatchNorm fine-tuning, training/recalibration.py:53-73 style uses):
@@ -305,7 +308,7 @@ class _UNetFunction(torch.autograd.Function):
                                              ctx.needs_input_grad[3], training or frozen,
                                              module._momenta(plan) if (training or frozen) else None, frozen=frozen,
                                              loss=module.__dict__.get('_loss_req') if (training and not softmax) else None,
-                                             roi=module.__dict__.get('_roi_req') if not (training or frozen) else None)
+                                             roi=roi if not (training or frozen) else None)
         if getattr(module, 'attention', False) and b16 is None:
             _store_attention_maps(module, plan, x, training or frozen, saved)
         ctx.frozen = frozen
@@ -970,7 +973,7 @@ class UNet(nn.Module):
             return (float(a.lower), float(a.upper))
         return None
 
-    def _run(self, x, softmax=False):
+    def _run(self, x, softmax=False, roi=None):
         if self.dim == 2:
             if not isinstance(x, torch.Tensor) or x.dim() != 4:
                 raise ValueError('expected a 4D (N, C, H, W) tensor')
@@ -994,6 +997,8 @@ class UNet(nn.Module):
         if any(p.device != x.device for p in params):
             raise RuntimeError('input and parameters are on different devices')
         mode = (1 if softmax else 0) | (2 if torch.is_grad_enabled() else 0)
+        if roi is not None:
+            mode = (mode, roi)
         if self._per_sample_norm():
             # per-sample statistics in training AND eval mode (nn.InstanceNorm3d defaults, nn.GroupNorm): one native call per sample;
             # autograd sums the parameter gradients of the calls
@@ -1043,11 +1048,7 @@ class UNet(nn.Module):
         if self.training or torch.is_grad_enabled() or self.dim != 3 or self._per_sample_norm():
             return self._run(x, softmax=softmax)
         (d0, d1), (h0, h1), (w0, w1) = roi
-        self.__dict__['_roi_req'] = (int(d0), int(h0), int(w0), int(d1), int(h1), int(w1))
-        try:
-            return self._run(x, softmax=softmax)
-        finally:
-            del self.__dict__['_roi_req']
+        return self._run(x, softmax=softmax, roi=(int(d0), int(h0), int(w0), int(d1), int(h1), int(w1)))
 
     @torch.jit.unused
     def forward_gradcp(self, x):
