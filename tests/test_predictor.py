@@ -449,3 +449,27 @@ def test_predictor_pinned_staging_switch_gives_the_same_volume(monkeypatch, dtyp
         assert p.dtype == dtype
         outs.append(p.predict(vol).clone())
     assert outs[0].dtype == outs[1].dtype and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw', [
+    dict(planar_blocks=(0,)),                       # planar level 0: the box propagates through 1x3x3 convs / (1,2,2) transposed convs, the planar kernels ignore it
+    dict(attention=True),                           # no needed region with attention gates
+    dict(conv_mode='valid'),                        # ... nor with valid convs
+    dict(up_mode='resizeconv_nearest'),             # ResizeConv: everything in front of it in full
+    dict(activation='leaky'),                       # two-pass units (conv, then the apply pass over the whole tensor)
+    dict(merge_mode='add'),
+])
+def test_forward_roi_on_configurations_without_the_facility(kw):
+    """Configurations whose kernels do not take a needed region compute (at least) what the region needs: same values inside it."""
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(3)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=3, start_filts=16, normalization='batch', **kw).cuda().eval()
+    x = torch.randn(1, 1, 44, 60, 76, device='cuda')
+    with torch.no_grad():
+        whole = m(x)
+        D, H, W = whole.shape[2:]
+        roi = ((1, D - 1), (2, H - 1), (3, W - 2))
+        part = m.forward_roi(x, roi)
+    sl = (slice(None), slice(None)) + tuple(slice(a, b) for a, b in roi)
+    assert part.shape == whole.shape and torch.equal(part[sl], whole[sl])
