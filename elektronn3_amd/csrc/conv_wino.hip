@@ -373,6 +373,9 @@ constexpr int W_PLDS_FLOATS = 2 * W_BUF + W_EX + 4 * 32 * 3 + 6 * 256;     // + 
 
 struct WinoPArgs { int s_nt, s_tw, s_th, s_td, s_nb; int wgstats; int e_tw, e_th, e_td; };   // digits of the logical step gridDim / 8 between a workgroup's bricks; e_*: end (first brick + count) of the brick range per axis
 
+// AFF: the folded scale / shift + ReLU epilogue (inference; no statistics) -- a compile-time split: as a run-time branch its merge cost ~50 register
+// moves per brick in both forms
+template <bool AFF>
 __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, const unsigned nblk, const WinoPArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
         // for the requests of the next brick behind them (channels beyond Ncols: out of the descriptor's range, 0)
         const int n = n0 + ej;
         const bool nvalid = n < eN;
-        const bool aff = e->epi_scale != nullptr;
+        constexpr bool aff = AFF;
         float bias, es, eh;
         {
             const __amdgpu_buffer_rsrc_t c_rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e->bias), 0, e->bias ? eN * 4 : 0, 0x00020000);
@@ -757,7 +760,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
 #ifdef E3_WINO_TIMING
         const bool do_stats = false;
 #else
-        const bool do_stats = e->stats != nullptr;
+        const bool do_stats = !AFF && e->stats != nullptr;
 #endif
         float cnt, mean, m2;
         if (full) {                 // (uniform) no masks: packed sums
@@ -1071,7 +1074,12 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
     if (splits == 1 && !a.pro_scale && wino_persistent(nblk, a.flags)) {
         constexpr int plds = W_PLDS_FLOATS * 4;
         static bool pattr = false;
-        if (!pattr) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel), hipFuncAttributeMaxDynamicSharedMemorySize, plds)); pattr = true; }
+        if (!pattr) {
+            E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, plds));
+            E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, plds));
+            pattr = true;
+        }
+        E3_REQUIRE(!(a.epi_scale && a.stats), E3_ERR_INVALID, "Winograd conv: statistics and the folded epilogue exclude each other");
         const unsigned pgrid = nblk >= 256 ? 256u : (unsigned)nblk;   // one workgroup per CU (256 is a multiple of the 8 XCDs; smaller grids run one brick each)
         // a workgroup's bricks are L0, L0 + pgrid / 8, ... in the logical (XCD-blocked) order: digits of that step in the mixed radix
         // (column tile, tw, th, td, sample) for the division-free brick counters
@@ -1083,7 +1091,8 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
         pa.s_td = (int)(st % (unsigned)a.tilesD); pa.s_nb = (int)(st / (unsigned)a.tilesD);
         pa.wgstats = (a.stats && wino_wgstats(nblk, a.ntiles)) ? 1 : 0;
         pa.e_tw = a.o_tw + a.tilesW; pa.e_th = a.o_th + a.tilesH; pa.e_td = a.o_td + a.tilesD;
-        hipLaunchKernelGGL(conv3_wino_pkernel, dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
+        if (a.epi_scale) hipLaunchKernelGGL(conv3_wino_pkernel<true>, dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
+        else hipLaunchKernelGGL(conv3_wino_pkernel<false>, dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
         E3_CHECK_HIP(hipGetLastError());
         return E3_OK;
     }
