@@ -32,6 +32,9 @@ class GradSync:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # world == 1 normally short-circuits; `force` keeps the whole event/side-stream/all-reduce path alive (tests)
         self.force = bool(int(__import__('os').environ.get('E3_FORCE_GRADSYNC', '0')))
+        # E3_DP_NO_OVERLAP=1: both buckets are reduced AFTER the backward (A/B switch for multi-GPU boxes: a collective's kernel that is resident
+        # beside the persistent conv kernels makes them take a second round of workgroups)
+        self.no_overlap = __import__('os').environ.get('E3_DP_NO_OVERLAP') is not None
         self._flat = None
         self._views = None
         self._split = 0
@@ -83,7 +86,10 @@ class GradSync:
         cur = torch.cuda.current_stream(flat.device)
         works = []
         with torch.cuda.stream(self._comm_stream):
-            self._comm_stream.wait_event(self._event)      # bucket A's gradients are final
+            if self.no_overlap:
+                self._comm_stream.wait_stream(cur)
+            else:
+                self._comm_stream.wait_event(self._event)  # bucket A's gradients are final
             works.append(self._allreduce(a, async_op=True))
             self._comm_stream.wait_stream(cur)             # the whole backward has been enqueued on `cur`
             if b.numel():
