@@ -209,46 +209,57 @@ __global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_k
         E3_TICK(6);
         return;
     }
+    // Everything outside the MFMA phase costs a wave ~13-24 cycles per vector instruction while the CU's other workgroups run their MFMAs
+    // (profiles/r03_bf16_conv_experiments.md), so the epilogue is written for few instructions: the two run-time choices -- folded scale / shift
+    // + ReLU or bias, interior brick or a brick that sticks out of the volume -- select one of four straight-line bodies (no per-element
+    // branches or selects), four channels at a time as vectors (packed fp32 ops, packed conversions).
     float ssum[CO_T][16], ssq[CO_T][16];
     const bool want_stats = a.stats != nullptr;
+    const bool interior = d0 + G::DZ <= a.D && h0 + G::BH <= a.H && w0 + G::BW <= a.W;
+    auto body = [&](auto aff_tag, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool AFF = decltype(aff_tag)::value, FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int ct = 0; ct < CO_T; ++ct)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { ssum[ct][e] = 0.f; ssq[ct][e] = 0.f; }
-#pragma unroll
-    for (int ct = 0; ct < CO_T; ++ct) {
-        f32x4 bq[4], sq[4], hq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cb = co0 + ct * 32 + 8 * q + 4 * g;
-            bq[q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (a.epi_scale) { sq[q] = *reinterpret_cast<const f32x4*>(a.epi_scale + cb); hq[q] = *reinterpret_cast<const f32x4*>(a.epi_shift + cb); }
-        }
-#pragma unroll
-        for (int t = 0; t < G::NV; ++t) {
-            const int d = d0 + dT0, h = h0 + G::RPT * (hp0 + t) + r, w = w0 + c;
-            const bool valid = d < a.D && h < a.H && w < a.W;
-            const int cot = co0 + ct * 32;
-            bf16_t* yrow = (a.y2 && cot >= a.y_split ? a.y2 + (cot - a.y_split) : a.y + cot) + ((((size_t)n * a.D + d) * a.H + h) * a.W + w) * a.y_ldc + 4 * g;
+        for (int ct = 0; ct < CO_T; ++ct) {
+            f32x4 bq[4], sq[4], hq[4], s1[4], s2[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                u16x4 o;
+                const int cb = co0 + ct * 32 + 8 * q + 4 * g;
+                bq[q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (AFF) { sq[q] = *reinterpret_cast<const f32x4*>(a.epi_scale + cb); hq[q] = *reinterpret_cast<const f32x4*>(a.epi_shift + cb); }
+                s1[q] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float val = acc[ct][t][4 * q + e];
-                    if (a.epi_scale) val = fmaxf(__builtin_fmaf(val, sq[q][e], hq[q][e]), 0.f);
-                    else val += bq[q][e];
-                    const bf16_t rb = f2bf(val);
-                    o[e] = rb;
-                    if (want_stats) {
-                        const float dv = valid ? bf2f(rb) - bq[q][e] : 0.f;
-                        ssum[ct][4 * q + e] += dv; ssq[ct][4 * q + e] = __builtin_fmaf(dv, dv, ssq[ct][4 * q + e]);
+            for (int t = 0; t < G::NV; ++t) {
+                const int d = d0 + dT0, h = h0 + G::RPT * (hp0 + t) + r, w = w0 + c;
+                const bool valid = FULL || (d < a.D && h < a.H && w < a.W);
+                const int cot = co0 + ct * 32;
+                bf16_t* yrow = (a.y2 && cot >= a.y_split ? a.y2 + (cot - a.y_split) : a.y + cot) + ((((size_t)n * a.D + d) * a.H + h) * a.W + w) * a.y_ldc + 4 * g;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[ct][t][4 * q], acc[ct][t][4 * q + 1], acc[ct][t][4 * q + 2], acc[ct][t][4 * q + 3]};
+                    if (AFF) {
+                        v = v * sq[q] + hq[q];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    } else v = v + bq[q];
+                    const bf16x4 rb = __builtin_convertvector(v, bf16x4);            // round to nearest even
+                    if (valid) *reinterpret_cast<bf16x4*>(yrow + 8 * q) = rb;
+                    if (!AFF) {               // (statistics only exist without the folded epilogue)
+                        f32x4 dv = __builtin_convertvector(rb, f32x4) - bq[q];
+                        if (!FULL) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) dv[e] = valid ? dv[e] : 0.f;
+                        }
+                        s1[q] += dv; s2[q] += dv * dv;
                     }
                 }
-                if (valid) *reinterpret_cast<u16x4*>(yrow + 8 * q) = o;
             }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { ssum[ct][e] = s1[e >> 2][e & 3]; ssq[ct][e] = s2[e >> 2][e & 3]; }
         }
-    }
+    };
+    if (a.epi_scale) { if (interior) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+    else { if (interior) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
     E3_TICK(6);
     if (!want_stats) { E3_TICK(7); return; }
     // ---- statistics: S[wave][quantity][channel][33] floats in the (now free) image, column sums, (n, mean, M2) record per brick
