@@ -83,6 +83,10 @@ class _PinnedRing:
         per_plane = max(1, t[:, :, :1].numel() * t.element_size())
         return max(1, self.slots[0].numel() // per_plane)
 
+    def fits(self, t):
+        """a z plane of t fits into a slot (otherwise the caller takes the runtime's pageable copy)"""
+        return t[:, :, :1].numel() * t.element_size() <= self.slots[0].numel()
+
     def h2d(self, dst, src, stream, convert_on_device):
         """pageable host view src (N, C, z, y, x) -> device view dst, slabs of z planes through the pinned slots"""
         step = self._planes(src)
@@ -123,6 +127,7 @@ class _PinnedRing:
 
 
 _RINGS = {}
+_RING_LOCKS = {}
 
 
 def _rings_for(device):
@@ -133,6 +138,12 @@ def _rings_for(device):
     if key not in _RINGS:
         _RINGS[key] = (_PinnedRing(), _PinnedRing())
     return _RINGS[key]
+
+
+def _ring_lock(device):
+    """The staging rings of a device serve one pipelined predict() at a time (Predictors on several threads take turns)."""
+    import threading
+    return _RING_LOCKS.setdefault(torch.device(device).index or 0, threading.Lock())
 
 
 class _SharedHostTensor:
@@ -578,7 +589,7 @@ class Predictor:
         def put(dst, src):
             """host slab -> device view.  A volume in another dtype than the model's (fp32 volume, bf16 / float16 model) travels as it is and is
             converted on the device: converting 2 G voxels on the host first made the upload thread the bottleneck of the 16-bit Predictor."""
-            if rings is not None:
+            if rings is not None and rings[0].fits(src):
                 rings[0].h2d(dst, src, up_stream, True)
             elif src.dtype == dst.dtype:
                 dst.copy_(src)
@@ -646,7 +657,7 @@ class Predictor:
                 z0, z1 = int(tile[0] * k), int(min(tile[0] * (k + 1), real[0]))
                 y0, y1 = int(tile[1] * j0), int(min(tile[1] * j1, real[1]))
                 if z1 > z0 and y1 > y0:
-                    if rings is not None:
+                    if rings is not None and rings[1].fits(state['out_dev'][:, :, z0:z1, y0:y1, :int(real[2])]):
                         rings[1].d2h(state['host_out'][:, :, z0:z1, y0:y1], state['out_dev'][:, :, z0:z1, y0:y1, :int(real[2])], down_stream)
                     else:
                         state['host_out'][:, :, z0:z1, y0:y1].copy_(state['out_dev'][:, :, z0:z1, y0:y1, :int(real[2])])
@@ -704,7 +715,8 @@ class Predictor:
         t_start = time.time()
         inp = torch.as_tensor(self._transformed(inp))
         if self._pipeline_applicable(inp):                       # host volume streamed through the GPU in rows of tiles
-            out = self._pipelined_predict(inp)
+            with _ring_lock(self.device):
+                out = self._pipelined_predict(inp)
             self._report(t_start, out.numel())
             return out
         # device-resident path: (padded) input and output live in HBM, one upload and one download
