@@ -452,6 +452,23 @@ def test_predictor_pinned_staging_switch_gives_the_same_volume(monkeypatch, dtyp
 
 
 @pytest.mark.gpu
+def test_forward_roi_resunet_and_wider_channel_counts():
+    """ResUNet (residual units stop the region's way back through the decoder) and a model with several input / output channels."""
+    from elektronn3_amd.unet import UNet
+    from elektronn3_amd import resunet
+    torch.manual_seed(4)
+    for m, cin in ((resunet.UNet(in_channels=1, out_channels=2, n_blocks=3, start_filts=16, enc_res_blocks=1, dec_res_blocks=1), 1),
+                   (UNet(in_channels=2, out_channels=5, n_blocks=3, start_filts=32), 2)):
+        m = m.cuda().eval()
+        x = torch.randn(1, cin, 40, 64, 96, device='cuda')
+        roi = ((8, 32), (16, 48), (16, 80))
+        with torch.no_grad():
+            whole, part = m(x), m.forward_roi(x, roi)
+        sl = (slice(None), slice(None)) + tuple(slice(a, b) for a, b in roi)
+        assert torch.equal(part[sl], whole[sl])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('kw', [
     dict(planar_blocks=(0,)),                       # planar level 0: the box propagates through 1x3x3 convs / (1,2,2) transposed convs, the planar kernels ignore it
     dict(attention=True),                           # no needed region with attention gates
