@@ -490,3 +490,18 @@ def test_forward_roi_on_configurations_without_the_facility(kw):
         part = m.forward_roi(x, roi)
     sl = (slice(None), slice(None)) + tuple(slice(a, b) for a, b in roi)
     assert part.shape == whole.shape and torch.equal(part[sl], whole[sl])
+
+
+def test_threaded_host_copy_is_a_copy():
+    """inference._host_copy (slabs above 64 MB are split along z over four threads) against Tensor.copy_, contiguous and strided views."""
+    from elektronn3_amd import inference
+    src = torch.arange(1 * 2 * 20 * 512 * 1024, dtype=torch.float32).view(1, 2, 20, 512, 1024)          # 80 MB
+    dst = torch.empty_like(src)
+    inference._host_copy(dst, src)
+    assert torch.equal(dst, src)
+    big = torch.zeros(1, 2, 24, 600, 1100)
+    inference._host_copy(big[:, :, 2:22, 40:552, 30:1054], src)                                          # strided destination
+    assert torch.equal(big[:, :, 2:22, 40:552, 30:1054], src) and float(big.sum()) == float(src.sum())
+    small = torch.randn(1, 1, 3, 8, 8); out = torch.empty_like(small)
+    inference._host_copy(out, small)
+    assert torch.equal(out, small)
