@@ -501,7 +501,9 @@ def test_threaded_host_copy_is_a_copy():
     assert torch.equal(dst, src)
     big = torch.zeros(1, 2, 24, 600, 1100)
     inference._host_copy(big[:, :, 2:22, 40:552, 30:1054], src)                                          # strided destination
-    assert torch.equal(big[:, :, 2:22, 40:552, 30:1054], src) and float(big.sum()) == float(src.sum())
+    assert torch.equal(big[:, :, 2:22, 40:552, 30:1054], src)
+    big[:, :, 2:22, 40:552, 30:1054] = 0
+    assert not big.any()                    # nothing outside the view was touched
     small = torch.randn(1, 1, 3, 8, 8); out = torch.empty_like(small)
     inference._host_copy(out, small)
     assert torch.equal(out, small)
