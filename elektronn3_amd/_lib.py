@@ -32,6 +32,11 @@ class UNetCfg(ctypes.Structure):
                 ('planar_mask', c_uint32), ('normalization', c_int32), ('bn_eps', c_float), ('full_norm', c_int32), ('merge_add', c_int32), ('num_groups', c_int32), ('up_resize', c_int32), ('conv_valid', c_int32), ('act_slope', c_float), ('attention', c_int32), ('resunet', c_int32), ('enc_res_blocks', c_int32), ('dec_res_blocks', c_int32)]
 
 
+class TileView(ctypes.Structure):
+    """e3_tile_view of include/e3unet.h (a tile read in place from the padded volume, its kept region written in place: e3_unet_forward_tile)."""
+    _fields_ = [('x', c_void_p), ('x_stride', ctypes.c_longlong * 3), ('y', c_void_p), ('y_stride', ctypes.c_longlong * 4)]
+
+
 class CEDiceArgs(ctypes.Structure):
     """e3_ce_dice_args of include/e3unet.h (criterion evaluated inside the head, e3_unet_forward_loss)."""
     _fields_ = [('target', c_void_p), ('class_weight', c_void_p), ('ce_weight', c_float), ('dice_weight', c_float), ('eps', c_float), ('smooth', c_float),
@@ -56,6 +61,7 @@ _SIG = {
     'e3_unet_forward_loss': (_I, [c_void_p, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), POINTER(c_float), _P,
                                   _P, c_size_t, _P, c_size_t, c_uint32, POINTER(CEDiceArgs)]),
     'e3_unet_forward_roi': (_I, [c_void_p, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), _P, _P, c_size_t, c_uint32, POINTER(c_int)]),
+    'e3_unet_forward_tile': (_I, [c_void_p, _P, POINTER(TileView), _I, _I, _I, _I, POINTER(c_void_p), _P, c_size_t, c_uint32, POINTER(c_int)]),
     'e3_unet_forward_roi_bf16': (_I, [c_void_p, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), _P, _P, c_size_t, c_uint32, POINTER(c_int)]),
     'e3_unet_forward_roi_f16': (_I, [c_void_p, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), _P, _P, c_size_t, c_uint32, POINTER(c_int)]),
     'e3_unet_backward': (_I, [c_void_p, _P, _P, _P, _I, _I, _I, _I, POINTER(c_void_p), POINTER(c_void_p), _P,

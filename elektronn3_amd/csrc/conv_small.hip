@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const ConvSmallArgs
             const int gd = d0 + zd - PD, gh = h0 + zh - 1, gw = w0 + zw - 1;
             val[u] = 0.f;
             if (idx < a.Cin * NV && zw < TW + 2 && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
-                val[u] = a.x[((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.Cin + ci];
+                val[u] = a.xs_d ? a.x[(size_t)nb * a.xs_n + (size_t)gd * a.xs_d + (size_t)gh * a.xs_h + (size_t)gw * a.Cin + ci]      // a view inside a larger volume (e3_unet_forward_tile)
+                                : a.x[((((size_t)nb * a.D + gd) * a.H + gh) * a.W + gw) * a.Cin + ci];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const int idx = i0 + u * 256 + tid; if (idx < a.Cin * NV) xs[idx] = val[u]; }
@@ -319,10 +320,13 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
 // workgroup in the layout of ce_dice_fwd_kernel, so ce_dice_finalize_kernel / e3_ce_dice_bwd work unchanged ("loss on
 // device fused with conv_final": the logits are not re-read and the separate pass over logits + target disappears).
 struct HeadLossArgs { const long long* target; const float* w; float* partial; };
+// Box form (e3_unet_forward_tile): only the voxels [d0, d0 + bd) x [h0, h0 + bh) x [w0, w0 + bw) of the (D, H, W) grid are read and their
+// results go to a view of a larger NCDHW volume: voxel (bz, by, bx) of the box, channel co, sample n -> y + n ys_n + co ys_c + bz ys_d + by ys_h + bx
+struct HeadBox { int on, bd, bh, bw, d0, h0, w0, D, H, W; long long ys_n, ys_c, ys_d, ys_h; };
 template <int COUT, bool LOSS>
 __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, int C, const float* __restrict__ w,
                                       const float* __restrict__ bias, float* __restrict__ y, size_t S, int N, int lpv, int softmax,
-                                      const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, ActArg pro_act, HeadLossArgs la) {
+                                      const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, ActArg pro_act, HeadLossArgs la, HeadBox box) {
     constexpr int NV = 2 + 3 * COUT;
     float lacc[LOSS ? NV : 1];
 #pragma unroll
@@ -332,7 +336,16 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
     // loading (same expression as bn_relu_apply_kernel) -- the last activation of the network is never written or re-read
     // lpv (1,2,4,8) consecutive lanes share one voxel; each walks every lpv-th channel quad
     const int Q = C >> 2;
-    const size_t total = (size_t)N * S;
+    const size_t total = box.on ? (size_t)N * box.bd * box.bh * box.bw : (size_t)N * S;
+    // loop index -> voxel of the input grid (the identity without a box)
+    auto src_voxel = [&](size_t i) -> size_t {
+        if (!box.on) return i;
+        unsigned r = (unsigned)i;
+        const unsigned bx = r % (unsigned)box.bw; r /= (unsigned)box.bw;
+        const unsigned by = r % (unsigned)box.bh; r /= (unsigned)box.bh;
+        const unsigned bz = r % (unsigned)box.bd; const unsigned n = r / (unsigned)box.bd;
+        return (((size_t)n * box.D + box.d0 + bz) * box.H + box.h0 + by) * box.W + box.w0 + bx;
+    };
     const int sub = threadIdx.x % lpv;
     const size_t vpb = blockDim.x / lpv;
     // U voxels per thread and iteration, their loads issued together; a workgroup's U x vpb voxels of an iteration are one contiguous run.
@@ -352,7 +365,7 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const size_t v = v0 + u * ustride;
-                av[u] = (v < total && sub < Q) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a + v * a_ldc + 4 * sub)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                av[u] = (v < total && sub < Q) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a + src_voxel(v) * a_ldc + 4 * sub)) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (sub < Q) {
                 f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -362,8 +375,9 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
                     const size_t v = v0 + u * ustride;
                     if (v >= total) continue;
                     if (pro_scale) {
+                        const size_t vs = src_voxel(v);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) av[u][e] = act_fwd(__builtin_fmaf(av[u][e], sc[e], sh[e]), act_slope_at(pro_act, pro_slope, (unsigned)(v * C + 4 * sub + e)));
+                        for (int e = 0; e < 4; ++e) av[u][e] = act_fwd(__builtin_fmaf(av[u][e], sc[e], sh[e]), act_slope_at(pro_act, pro_slope, (unsigned)(vs * C + 4 * sub + e)));
                     }
 #pragma unroll
                     for (int co = 0; co < COUT; ++co) {
@@ -374,12 +388,13 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
                 }
             }
         } else if (v0 < total) {
+            const size_t vs0 = src_voxel(v0);
             for (int q = sub; q < Q; q += lpv) {
-                f32x4 xv = *reinterpret_cast<const f32x4*>(a + v0 * a_ldc + 4 * q);
+                f32x4 xv = *reinterpret_cast<const f32x4*>(a + vs0 * a_ldc + 4 * q);
                 if (pro_scale) {
                     const f32x4 sc = *reinterpret_cast<const f32x4*>(pro_scale + 4 * q), sh = *reinterpret_cast<const f32x4*>(pro_shift + 4 * q);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) xv[e] = act_fwd(__builtin_fmaf(xv[e], sc[e], sh[e]), act_slope_at(pro_act, pro_slope, (unsigned)(v0 * C + 4 * q + e)));
+                    for (int e = 0; e < 4; ++e) xv[e] = act_fwd(__builtin_fmaf(xv[e], sc[e], sh[e]), act_slope_at(pro_act, pro_slope, (unsigned)(vs0 * C + 4 * q + e)));
                 }
 #pragma unroll
                 for (int co = 0; co < COUT; ++co) {
@@ -423,6 +438,16 @@ __global__ void conv_final_fwd_kernel(const float* __restrict__ a, int a_ldc, in
                 const float inv = 1.f / sm;
 #pragma unroll
                 for (int co = 0; co < COUT; ++co) lg[co] *= inv;
+            }
+            if (box.on) {
+                unsigned r = (unsigned)v;
+                const unsigned bx = r % (unsigned)box.bw; r /= (unsigned)box.bw;
+                const unsigned by = r % (unsigned)box.bh; r /= (unsigned)box.bh;
+                const unsigned bz = r % (unsigned)box.bd; const unsigned nn = r / (unsigned)box.bd;
+                float* const yo = y + (long long)nn * box.ys_n + (long long)bz * box.ys_d + (long long)by * box.ys_h + bx;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) yo[(long long)co * box.ys_c] = lg[co];
+                return;
             }
 #pragma unroll
             for (int co = 0; co < COUT; ++co) y[(n * COUT + co) * S + sp] = lg[co];
@@ -639,7 +664,24 @@ int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, cons
     const int lpv = final_lpv(C);
     const size_t vox = (size_t)N * S;
     size_t g = (vox * lpv + 255) / 256; if (g > 4096) g = 4096; if (g == 0) g = 1;
-    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_fwd_kernel<CO, false>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, S, N, lpv, softmax, pro_scale, pro_shift, pro_slope, HeadLossArgs{}));
+    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_fwd_kernel<CO, false>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, S, N, lpv, softmax, pro_scale, pro_shift, pro_slope, HeadLossArgs{}, HeadBox{}));
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
+// box form: the voxels of `box` (lo, size; on the (D, H, W) grid of `a`) only, written into a view of a larger NCDHW volume (strides in elements)
+int launch_conv_final_fwd_box(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y, int Cout, int N, int D, int H, int W,
+                              const int lo[3], const int size[3], const long long ystride[4], int softmax, hipStream_t s,
+                              const float* pro_scale, const float* pro_shift, ActArg pro_slope) {
+    E3_REQUIRE(C % 4 == 0 && a_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 4");
+    const size_t vox = (size_t)N * size[0] * size[1] * size[2];
+    E3_REQUIRE(vox > 0 && vox < 0xffffffffull, E3_ERR_INVALID, "head box: empty or too large");
+    for (int i = 0; i < 3; ++i) E3_REQUIRE(lo[i] >= 0 && size[i] > 0, E3_ERR_INVALID, "head box: bad extent");
+    E3_REQUIRE(lo[0] + size[0] <= D && lo[1] + size[1] <= H && lo[2] + size[2] <= W, E3_ERR_INVALID, "head box: outside the grid");
+    const int lpv = final_lpv(C);
+    size_t g = (vox * lpv + 255) / 256; if (g > 4096) g = 4096; if (g == 0) g = 1;
+    const HeadBox box{1, size[0], size[1], size[2], lo[0], lo[1], lo[2], D, H, W, ystride[0], ystride[1], ystride[2], ystride[3]};
+    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_fwd_kernel<CO, false>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, (size_t)D * H * W, N, lpv, softmax, pro_scale, pro_shift, pro_slope, HeadLossArgs{}, box));
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
@@ -655,7 +697,7 @@ int launch_conv_final_fwd_loss(const float* a, int a_ldc, int C, const float* w,
     // (1024 workgroups: the grid-stride loop does not care, and the criterion's finaliser walks the rows with one wave per value)
     size_t g = (vox * lpv + 255) / 256; if (g > 1024) g = 1024; if (g > (size_t)max_rows) g = (size_t)max_rows; if (g == 0) g = 1;
     const HeadLossArgs la{target, class_w, partial};
-    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_fwd_kernel<CO, true>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, S, N, lpv, 0, pro_scale, pro_shift, pro_slope, la));
+    E3_COUT_SWITCH(Cout, hipLaunchKernelGGL((conv_final_fwd_kernel<CO, true>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, S, N, lpv, 0, pro_scale, pro_shift, pro_slope, la, HeadBox{}));
     E3_CHECK_HIP(hipGetLastError());
     *rows = (int)g;
     return E3_OK;

@@ -108,6 +108,7 @@ struct ConvSmallArgs {
     int planar;
     const float* epi_scale; const float* epi_shift;
     float* stats;
+    long long xs_n, xs_d, xs_h;  // xs_d != 0: x is a view inside a larger volume (element strides of sample, d-plane, h-row; w stride = Cin)
 };
 int conv_small_stats_parts(int N, int D, int H, int W, int planar);
 int launch_conv_small_fwd(ConvSmallArgs a, hipStream_t s);
@@ -122,6 +123,10 @@ int launch_conv_small_wgrad(const float* x, int Cin, const float* dy, int dy_ldc
 int launch_conv_final_fwd(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y_ncdhw,
                           int Cout, size_t voxels_per_sample, int N, int softmax, hipStream_t s,
                           const float* pro_scale = nullptr, const float* pro_shift = nullptr, ActArg pro_act = ActArg(0.f));   // a := act(a*scale + shift) while loading
+// box form (e3_unet_forward_tile): only the voxels [lo, lo + size) of the (D, H, W) grid, written to a view of a larger NCDHW volume (element strides n, c, d, h)
+int launch_conv_final_fwd_box(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y, int Cout, int N, int D, int H, int W,
+                              const int lo[3], const int size[3], const long long ystride[4], int softmax, hipStream_t s,
+                              const float* pro_scale = nullptr, const float* pro_shift = nullptr, ActArg pro_act = ActArg(0.f));
 int launch_conv_final_fwd_loss(const float* a, int a_ldc, int C, const float* w, const float* bias, float* y_ncdhw, int Cout, size_t voxels_per_sample, int N,
                                hipStream_t s, const float* pro_scale, const float* pro_shift, ActArg pro_act, const long long* target, const float* class_w,
                                float* partial /*[rows][2 + 3 Cout]*/, int max_rows, int* rows);     // head + partial sums of the CE + Dice criterion (loss.hip)

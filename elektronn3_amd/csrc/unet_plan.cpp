@@ -619,7 +619,7 @@ int e3_unet_sizes(const e3_unet_plan* plan, int N, int D, int H, int W, int trai
 static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
                              void* const* params, const float* momenta, float* y,
                              void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const e3_ce_dice_args* la,
-                             const int* roi = nullptr);
+                             const int* roi = nullptr, const e3_tile_view* view = nullptr);
 
 int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
                     void* const* params, const float* momenta, float* y,
@@ -645,10 +645,22 @@ int e3_unet_forward_roi(e3_unet_plan* plan, void* stream, const float* x, int N,
     return unet_forward_impl(plan, stream, x, N, D, H, W, params, nullptr, y, nullptr, 0, scratch, scratch_bytes, flags, nullptr, roi);
 }
 
+int e3_unet_forward_tile(e3_unet_plan* plan, void* stream, const e3_tile_view* view, int N, int D, int H, int W,
+                         void* const* params, void* scratch, size_t scratch_bytes, uint32_t flags, const int roi[6]) {
+    E3_REQUIRE(plan && view && view->x && view->y && roi, E3_ERR_INVALID, "forward_tile: null argument");
+    E3_REQUIRE(!(flags & (E3_FWD_TRAINING | E3_FWD_FROZEN_BN)), E3_ERR_INVALID, "forward_tile: inference only");
+    E3_REQUIRE(plan->cfg.in_channels == 1 && !plan->cfg.conv_valid && plan->units.front().cin < 8, E3_ERR_UNSUPPORTED,
+               "forward_tile: one input channel and 'same' convolutions (copy the tile and take e3_unet_forward_roi)");
+    for (int i = 0; i < 3; ++i) E3_REQUIRE(roi[i] >= 0 && roi[3 + i] > roi[i], E3_ERR_INVALID, "forward_tile: empty or negative region");
+    E3_REQUIRE(roi[3] <= D && roi[4] <= H && roi[5] <= W, E3_ERR_INVALID, "forward_tile: region outside the tile");
+    E3_REQUIRE(view->x_stride[1] > 0 && view->x_stride[2] > 0, E3_ERR_INVALID, "forward_tile: bad input strides");
+    return unet_forward_impl(plan, stream, view->x, N, D, H, W, params, nullptr, view->y, nullptr, 0, scratch, scratch_bytes, flags, nullptr, roi, view);
+}
+
 static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
                              void* const* params, const float* momenta, float* y,
                              void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const e3_ce_dice_args* la,
-                             const int* roi) {
+                             const int* roi, const e3_tile_view* view) {
     E3_REQUIRE(plan && x && y && params && scratch, E3_ERR_INVALID, "null argument");
     hipStream_t s = (hipStream_t)stream;
     const bool training = (flags & E3_FWD_TRAINING) != 0;
@@ -788,6 +800,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             a.x = cur; a.Cin = u.cin; a.w = P(u.p_w); a.bias = bn_train ? P(u.p_b) : nullptr; a.y = vcrop ? B.rtmp : dst; a.y_ldc = dst_ldc;
             a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.Cout = u.cout; a.planar = u.planar;
             a.epi_scale = es; a.epi_shift = eh; a.stats = (bn_train && !vcrop) ? stat_buf : nullptr;
+            if (view && k == 0) { a.xs_n = view->x_stride[0]; a.xs_d = view->x_stride[1]; a.xs_h = view->x_stride[2]; }      // (the tile is read in place)
             parts = conv_small_stats_parts(N, ci.D, ci.H, ci.W, u.planar);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_small_fwd(a, s)); }
         } else {
@@ -924,6 +937,10 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
                                            la->target, la->class_weight, (float*)la->workspace, CE_DICE_MAX_ROWS, &rows));
             RUN(launch_ce_dice_finalize(la->class_weight, cfg.out_channels, rows, la->ce_weight, la->dice_weight, la->eps, la->smooth,
                                         (float*)la->workspace, la->loss_out, s));
+        } else if (view) {      // only the kept region, straight into its place in the output volume
+            const int lo[3] = {roi[0], roi[1], roi[2]}, size[3] = {roi[3] - roi[0], roi[4] - roi[1], roi[5] - roi[2]};
+            RUN(launch_conv_final_fwd_box(cur, cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y, cfg.out_channels, N, ND.Y.D, ND.Y.H, ND.Y.W,
+                                          lo, size, view->y_stride, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s, nullptr, nullptr, head_act));
         } else {
             RUN(launch_conv_final_fwd(fused ? lb.raw : cur, fused ? lu.cout : cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y,
                                       cfg.out_channels, ND.Y.vox / N, N, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s,

@@ -628,11 +628,14 @@ class Predictor:
 
         state = {'host_out': None, 'out_dev': None, 'shm': None}
         downs = []
+        # no tile copy / crop copy around the native fp32 model (E3_PREDICTOR_NO_INPLACE=1: A/B switch)
+        in_place = (self._native and _ROI and self._post is None and self.augmentations is None and not self.apply_argmax_after_tta
+                    and self.dtype == torch.float32 and self.out_dtype == torch.float32 and hasattr(self.model, 'forward_tile')
+                    and os.environ.get('E3_PREDICTOR_NO_INPLACE') is None)
 
-        def make_outputs(out_tile):
+        def make_outputs(out_tile, meta=None):
             """Output buffers, once the first tile tells channel layout and dtype (world > 1: every rank calls this exactly once,
             whether it has tiles or not -- the shared-memory name travels in one broadcast_object_list)."""
-            meta = None
             if out_tile is not None:
                 meta = (tuple(int(v) for v in out_tile.shape[1:-3]), out_tile.dtype)
             if world > 1:
@@ -680,6 +683,15 @@ class Predictor:
                         ev_first.record(main)
                 for ti in range((k * nty + j) * ntx, (k * nty + j + 1) * ntx):
                     ilo, ihi, olo, ohi = plan[ti]
+                    if in_place:          # the tile is read where it lies and its kept region written where it belongs (UNet.forward_tile)
+                        try:
+                            if state['out_dev'] is None:
+                                make_outputs(None, ((int(self.model.out_channels),), torch.float32))
+                            self.model.forward_tile(inp_padded, ilo, [h - l for l, h in zip(ilo, ihi)], state['out_dev'], olo,
+                                                    [(int(o), int(o + t)) for o, t in zip(ov, tile)], softmax=self._softmax)
+                            continue
+                        except NotImplementedError:
+                            in_place = False
                     inp_tile = inp_padded[_extend_nc([slice(l, h) for l, h in zip(ilo, ihi)])].contiguous()
                     out_tile = self._predict(inp_tile, crop)
                     if state['out_dev'] is None:

@@ -1051,6 +1051,42 @@ class UNet(nn.Module):
         return self._run(x, softmax=softmax, roi=(int(d0), int(h0), int(w0), int(d1), int(h1), int(w1)))
 
     @torch.jit.unused
+    def forward_tile(self, vol, in_lo, tile_shape, out, out_lo, roi, softmax=False):
+        """One tile of a tiled inference run WITHOUT the tile copy in front of the model and the crop copy behind it (the tile loop of
+        ``inference.tiled_apply``, inference.py:153-199): the tile ``vol[:, :, in_lo : in_lo + tile_shape]`` of the padded device volume is read in
+        place (zero padding at the tile's faces, exactly like a contiguous copy of it), and the output voxels ``roi = ((d0, d1), (h0, h1), (w0, w1))``
+        of the tile go to ``out[:, :, out_lo : out_lo + (d1 - d0, ...)]`` (e3_unet_forward_tile).  fp32 module / tensors, one input channel,
+        'same' convolutions, eval mode; anything else raises NotImplementedError (callers copy the tile and use forward_roi)."""
+        if (self.training or torch.is_grad_enabled() or self.dim != 3 or self._per_sample_norm() or self.in_channels != 1 or self.conv_mode != 'same'
+                or getattr(self, 'attention', False) or vol.dtype != torch.float32 or out.dtype != torch.float32 or not vol.is_cuda
+                or vol.stride(-1) != 1 or out.stride(-1) != 1 or vol.dim() != 5 or out.dim() != 5):
+            raise NotImplementedError('forward_tile: configuration outside the in-place tile path')
+        plan = self._plan()
+        params = [p for _, p in self._named_table_params(plan)]
+        tens = self._table(plan, params)
+        if any(t.dtype != torch.float32 for t in tens):
+            raise NotImplementedError('forward_tile: fp32 modules only')
+        tens = [t if t.is_contiguous() else t.contiguous() for t in tens]
+        lib = _lib.load()
+        dev = vol.device
+        N = int(vol.shape[0])
+        D, H, W = (int(v) for v in tile_shape)
+        _, scratch_bytes = plan.sizes(N, D, H, W, False, bf16=None)
+        scratch = _get_scratch(dev, max(scratch_bytes, 256))
+        (d0, d1), (h0, h1), (w0, w1) = roi
+        view = _lib.TileView()
+        view.x = vol.data_ptr() + 4 * (int(in_lo[0]) * vol.stride(2) + int(in_lo[1]) * vol.stride(3) + int(in_lo[2]))
+        view.x_stride[:] = [vol.stride(0), vol.stride(2), vol.stride(3)]
+        view.y = out.data_ptr() + 4 * (int(out_lo[0]) * out.stride(2) + int(out_lo[1]) * out.stride(3) + int(out_lo[2]))
+        view.y_stride[:] = [out.stride(0), out.stride(1), out.stride(2), out.stride(3)]
+        ptrs = (c_void_p * len(tens))(*[t.data_ptr() for t in tens])
+        with torch.cuda.device(dev):
+            check(lib.e3_unet_set_rrelu(plan.handle, 0.0, 0.0, 0))
+            check(lib.e3_unet_forward_tile(plan.handle, _lib.stream_ptr(dev), ctypes.byref(view), N, D, H, W, ptrs, c_void_p(scratch.data_ptr()),
+                                           c_size_t(scratch.numel()), E3_FWD_SOFTMAX if softmax else 0,
+                                           (ctypes.c_int * 6)(int(d0), int(h0), int(w0), int(d1), int(h1), int(w1))))
+
+    @torch.jit.unused
     def forward_gradcp(self, x):
         """Same as :meth:`forward` (unet.py:918-935 trades recompute for memory; with 288 GB of HBM nothing needs to be
         recomputed, so checkpointing is a no-op here)."""

@@ -312,6 +312,19 @@ int e3_unet_sizes_bf16(const e3_unet_plan* plan, int N, int D, int H, int W, int
 int e3_unet_forward_bf16(e3_unet_plan* plan, void* stream, const void* x, int N, int D, int H, int W,
                          void* const* params, const float* momenta, float* y,
                          void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags);
+/* e3_unet_forward_roi for ONE TILE OF A LARGER VOLUME, without the tile copy in front of the model and the crop copy behind it (the tile loop of
+ * tiled_apply, inference.py:153-199: `inp_tile = inp_padded[tile].contiguous(); out[out_slice] = model(inp_tile)[crop]`): x is read through
+ * strides as a (N, in, D, H, W) view of the padded volume (the tile's borders are zero-padded like a contiguous tile's), and the voxels of `roi`
+ * go straight to their place in the output volume: output voxel (d, h, w) of the region, channel c, sample n is written to
+ * y + n*y_stride[0] + c*y_stride[1] + (d - roi[0])*y_stride[2] + (h - roi[1])*y_stride[3] + (w - roi[2]).  Strides in elements, w stride 1.
+ * fp32 path, in_channels == 1, 'same' convolutions (anything else: E3_ERR_UNSUPPORTED, callers take e3_unet_forward_roi on a copied tile). */
+typedef struct e3_tile_view {
+    const float* x; long long x_stride[3];      /* sample, d-plane, h-row */
+    float* y; long long y_stride[4];            /* sample, channel, d-plane, h-row */
+} e3_tile_view;
+int e3_unet_forward_tile(e3_unet_plan* plan, void* stream, const e3_tile_view* view, int N, int D, int H, int W,
+                         void* const* params, void* scratch, size_t scratch_bytes, uint32_t flags, const int roi[6]);
+
 /* e3_unet_forward_roi on this path (inference; the needed region of the Predictor's central crop, see e3_unet_forward_roi) */
 int e3_unet_forward_roi_bf16(e3_unet_plan* plan, void* stream, const void* x, int N, int D, int H, int W,
                              void* const* params, float* y, void* scratch, size_t scratch_bytes, uint32_t flags, const int roi[6]);

@@ -507,3 +507,30 @@ def test_threaded_host_copy_is_a_copy():
     small = torch.randn(1, 1, 3, 8, 8); out = torch.empty_like(small)
     inference._host_copy(out, small)
     assert torch.equal(out, small)
+
+
+@pytest.mark.gpu
+def test_predictor_in_place_tiles_switch_gives_the_same_volume(monkeypatch):
+    """Tiles read in place from the padded volume and written in place into the output volume (UNet.forward_tile / e3_unet_forward_tile, the default
+    for the native fp32 model) against the copied-tile path (E3_PREDICTOR_NO_INPLACE=1): identical volumes, also with a ragged last tile."""
+    from elektronn3_amd import inference
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(8)
+    m = UNet(in_channels=1, out_channels=3, n_blocks=3, start_filts=32, normalization='batch').cuda().eval()
+    vol = torch.randn(2, 1, 50, 100, 150)                     # not a multiple of the tile shape: padded, cropped on the way back
+    outs = []
+    calls = []
+    real = UNet.forward_tile
+    monkeypatch.setattr(UNet, 'forward_tile', lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1])
+    for in_place in (True, False):
+        if in_place:
+            monkeypatch.delenv('E3_PREDICTOR_NO_INPLACE', raising=False)
+        else:
+            monkeypatch.setenv('E3_PREDICTOR_NO_INPLACE', '1')
+        p = inference.Predictor(m, device='cuda', tile_shape=(32, 64, 80), overlap_shape=(8, 16, 16), out_shape=(3, 50, 100, 150), apply_softmax=True,
+                                strict_shapes=False)
+        n0 = len(calls)
+        outs.append(p.predict(vol).clone())
+        assert (len(calls) > n0) == in_place
+    assert torch.equal(outs[0], outs[1])
+    assert torch.allclose(outs[0].sum(1), torch.ones_like(outs[0][:, 0]), atol=1e-5)
