@@ -793,6 +793,16 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = sd;   // autocrop of the up-convolved tensor (unet.py:289-299)
             a.Cout = u.cout; a.Ncols = taps * u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
             a.stats = bn_train ? stat_buf : nullptr; a.G = 1; a.flags = CF_SCATTER_UP;
+            if (need[k].on && N == 1 && !bn_train && !two_pass) {
+                // needed region along D only (a transposed conv with kernel = stride has no halo, so a range of input planes is simply a smaller
+                // tensor: pointers and depths move, the kernels do not change); one sample, because the sample stride is implied by the dims
+                const int p0 = need[k].lo[0] / sd, p1 = (need[k].hi[0] + sd - 1) / sd < li.D ? (need[k].hi[0] + sd - 1) / sd : li.D;
+                if (p1 > p0 && (p0 > 0 || p1 < li.D)) {
+                    const int o0 = p0 * sd, o1 = p1 * sd < lo.D ? p1 * sd : lo.D;
+                    a.x = cur + (size_t)p0 * li.H * li.W * cur_ldc; a.D = p1 - p0;
+                    a.y = dst + (size_t)o0 * lo.H * lo.W * dst_ldc; a.Do = o1 - o0;
+                }
+            }
             parts = conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, li.D, li.H, li.W, sd, u.cin, taps * u.cout);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(CONV_POINT, a, s)); }
         } else if (u.cin < 8) {
