@@ -235,6 +235,14 @@ static int forward_b16_impl(e3_unet_plan* plan, void* stream, const void* x, int
             a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.y = dst; a.y_ldc = dst_ldc; a.Cout = u.cout; a.wt = b.wpk_f;
             a.bias = training ? P(u.p_b) : nullptr; a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = sd;
             a.epi_scale = es; a.epi_shift = eh; a.stats = training ? B.stats : nullptr;
+            if (need[k].on && N == 1 && !training) {      // needed region along D (no halo: a range of input planes is a smaller tensor), as in the fp32 executor
+                const int p0 = need[k].lo[0] / sd, p1 = (need[k].hi[0] + sd - 1) / sd < li.D ? (need[k].hi[0] + sd - 1) / sd : li.D;
+                if (p1 > p0 && (p0 > 0 || p1 < li.D)) {
+                    const int o0 = p0 * sd, o1 = p1 * sd < lo.D ? p1 * sd : lo.D;
+                    a.x = cur + (size_t)p0 * li.H * li.W * cur_ldc; a.D = p1 - p0;
+                    a.y = dst + (size_t)o0 * lo.H * lo.W * dst_ldc; a.Do = o1 - o0;
+                }
+            }
             parts = upconv_b16_stats_parts(N, li.D, li.H, li.W, sd, u.cin);
             { ProfB pr(plan, s, (int)k, 0); RUN(launch_upconv_b16_fwd(a, s)); }
         } else if (u.cin < 8) {
