@@ -142,7 +142,7 @@ int launch_conv_small_b16_wgrad(const bf16_t* x, int Cin, const bf16_t* dy, int 
                                 int N, int D, int H, int W, int Cout, int planar, hipStream_t s);
 // 1x1x1 head: a (bf16, optionally BN+ReLU applied while loading) -> fp32 NCDHW logits (+ softmax); backward: dW/db partials (+ da)
 int launch_conv_final_b16_fwd(const bf16_t* a, int a_ldc, int C, const float* w, const float* bias, float* y_ncdhw, int Cout,
-                              size_t voxels_per_sample, int N, int softmax, const float* pro_scale, const float* pro_shift, hipStream_t s);
+                              size_t voxels_per_sample, int N, int softmax, const float* pro_scale, const float* pro_shift, hipStream_t s, size_t ychan = 0)   /* ychan: voxels between the channel planes of y (0 = S; larger when y is a range of d-planes of a bigger tensor) */;
 int conv_final_b16_bwd_parts(size_t total_voxels);
 int launch_conv_final_b16_bwd(const bf16_t* a, int a_ldc, int C, const float* w, const float* dy_ncdhw, bf16_t* da, int da_ldc,
                               float* part /*[parts][Cout][C+1]*/, int Cout, size_t voxels_per_sample, int N,

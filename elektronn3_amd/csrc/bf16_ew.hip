@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void conv_small_b16_wgrad_kernel(const bf16_t*
 template <int COUT>
 __global__ void conv_final_b16_fwd_kernel(const bf16_t* __restrict__ a, int a_ldc, int C, const float* __restrict__ w, const float* __restrict__ bias,
                                           float* __restrict__ y, size_t S, int N, int lpv, int softmax,
-                                          const float* __restrict__ pro_scale, const float* __restrict__ pro_shift) {
+                                          const float* __restrict__ pro_scale, const float* __restrict__ pro_shift, size_t ychan) {
     const int Q = C >> 3;
     const size_t total = (size_t)N * S;
     const int sub = threadIdx.x % lpv;
@@ -566,7 +566,7 @@ __global__ void conv_final_b16_fwd_kernel(const bf16_t* __restrict__ a, int a_ld
                 for (int co = 0; co < COUT; ++co) acc[co] *= inv;
             }
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) y[(n * COUT + co) * S + sp] = acc[co];
+            for (int co = 0; co < COUT; ++co) y[(n * COUT + co) * ychan + sp] = acc[co];      // (ychan: voxels between the channel planes of y; = S unless y is a range of d-planes)
         }
     }
 }
@@ -782,12 +782,13 @@ int launch_conv_small_b16_wgrad(const bf16_t* x, int Cin, const bf16_t* dy, int 
     }
 
 int launch_conv_final_b16_fwd(const bf16_t* a, int a_ldc, int C, const float* w, const float* bias, float* y, int Cout,
-                              size_t S, int N, int softmax, const float* pro_scale, const float* pro_shift, hipStream_t s) {
+                              size_t S, int N, int softmax, const float* pro_scale, const float* pro_shift, hipStream_t s, size_t ychan) {
     E3_REQUIRE(C % 8 == 0 && a_ldc % 8 == 0, E3_ERR_UNSUPPORTED, "channels must be a multiple of 8");
+    if (ychan == 0) ychan = S;
     const int lpv = final_lpv8(C);
     const size_t vox = (size_t)N * S;
     size_t g = (vox * lpv + 255) / 256; if (g > 4096) g = 4096; if (g == 0) g = 1;
-    E3_COUT_SWITCH_B16(Cout, hipLaunchKernelGGL((conv_final_b16_fwd_kernel<CO>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, S, N, lpv, softmax, pro_scale, pro_shift));
+    E3_COUT_SWITCH_B16(Cout, hipLaunchKernelGGL((conv_final_b16_fwd_kernel<CO>), dim3((unsigned)g), dim3(256), 0, s, a, a_ldc, C, w, bias, y, S, N, lpv, softmax, pro_scale, pro_shift, ychan));
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

@@ -282,6 +282,13 @@ static int forward_b16_impl(e3_unet_plan* plan, void* stream, const void* x, int
         const ConvUnit& lu = plan->units.back();
         const UnitB& lb = B.ub.back();
         ProfB pr(plan, s, (int)nu, 0);
+        if (roi && !training && N == 1 && (roi[0] > 0 || roi[3] < ND.Y.D)) {
+            // needed region along D: the head reads and writes the d-planes [roi[0], roi[3]) only (a contiguous range of voxels of one sample)
+            const int p0 = roi[0], p1 = roi[3] < ND.Y.D ? roi[3] : ND.Y.D;
+            const size_t hw = (size_t)ND.Y.H * ND.Y.W;
+            RUN(launch_conv_final_b16_fwd(cur + (size_t)p0 * hw * cur_ldc, cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y + (size_t)p0 * hw,
+                                          cfg.out_channels, (size_t)(p1 - p0) * hw, 1, (flags & E3_FWD_SOFTMAX) ? 1 : 0, nullptr, nullptr, s, ND.Y.vox));
+        } else
         RUN(launch_conv_final_b16_fwd(training ? lb.raw : cur, training ? lu.cout : cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y,
                                       cfg.out_channels, ND.Y.vox / N, N, (flags & E3_FWD_SOFTMAX) ? 1 : 0, training ? lb.scale : nullptr,
                                       training ? lb.shift : nullptr, s));
