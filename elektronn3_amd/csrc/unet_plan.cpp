@@ -951,6 +951,13 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             const int lo[3] = {roi[0], roi[1], roi[2]}, size[3] = {roi[3] - roi[0], roi[4] - roi[1], roi[5] - roi[2]};
             RUN(launch_conv_final_fwd_box(cur, cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y, cfg.out_channels, N, ND.Y.D, ND.Y.H, ND.Y.W,
                                           lo, size, view->y_stride, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s, nullptr, nullptr, head_act));
+        } else if (roi && !training && !fused && roi[3] <= ND.Y.D && roi[4] <= ND.Y.H && roi[5] <= ND.Y.W) {
+            // e3_unet_forward_roi: the head reads and writes the kept region only (y keeps the tile's own layout)
+            const int lo[3] = {roi[0], roi[1], roi[2]}, size[3] = {roi[3] - roi[0], roi[4] - roi[1], roi[5] - roi[2]};
+            const long long S1 = (long long)(ND.Y.vox / N), ys[4] = {(long long)cfg.out_channels * S1, S1, (long long)ND.Y.H * ND.Y.W, (long long)ND.Y.W};
+            RUN(launch_conv_final_fwd_box(cur, cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b),
+                                          y + (long long)lo[0] * ys[2] + (long long)lo[1] * ys[3] + lo[2], cfg.out_channels, N, ND.Y.D, ND.Y.H, ND.Y.W,
+                                          lo, size, ys, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s, nullptr, nullptr, head_act));
         } else {
             RUN(launch_conv_final_fwd(fused ? lb.raw : cur, fused ? lu.cout : cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y,
                                       cfg.out_channels, ND.Y.vox / N, N, (flags & E3_FWD_SOFTMAX) ? 1 : 0, s,
