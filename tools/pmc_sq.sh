@@ -1,5 +1,7 @@
 #!/bin/bash
 # SQ-level counters of the bf16 step's kernels (one pass, 8 SQ slots): where do the waves spend their cycles
+# (lds_active / lds_conflict = LDS-array cycles per CU cycle: a ds_read_b128 wave-instruction is 4 of them, MI355X_MICROARCH.md "LDS";
+#  until round 3 the two columns carried a spurious factor 4)
 R=$PWD; O=$R/gpurun_out/sq_$1; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $O/pmc -o run --output-format csv -- python $R/bench.py --no-cpu-baseline --no-predictor --steps 1 --warmup 1 --dtype ${2:-bf16} > $O/pmc.log 2>&1
 cd $R
@@ -26,5 +28,5 @@ for (name, grid), L in sorted(per.items(), key=lambda kv: -sum(d for d, _ in kv[
     us = med(lambda d, c: d / 1e3)
     g = lambda n: med(lambda d, c: c.get(n, 0))
     wc = g('SQ_WAVE_CYCLES')
-    print(f"| {name} | {grid} | {len(L)} | {us:.1f} | {cyc / (us * 1e3):.2f} | {g('SQ_VALU_MFMA_BUSY_CYCLES') / (cyc * 1024):.3f} | {4 * wc / (cyc * 1024):.2f} | {g('SQ_WAIT_ANY') / wc:.2f} | {g('SQ_WAIT_INST_ANY') / wc:.2f} | {g('SQ_WAIT_INST_LDS') / wc:.2f} | {4 * g('SQ_LDS_IDX_ACTIVE') / (cyc * 256):.2f} | {4 * g('SQ_LDS_BANK_CONFLICT') / (cyc * 256):.2f} |")
+    print(f"| {name} | {grid} | {len(L)} | {us:.1f} | {cyc / (us * 1e3):.2f} | {g('SQ_VALU_MFMA_BUSY_CYCLES') / (cyc * 1024):.3f} | {4 * wc / (cyc * 1024):.2f} | {g('SQ_WAIT_ANY') / wc:.2f} | {g('SQ_WAIT_INST_ANY') / wc:.2f} | {g('SQ_WAIT_INST_LDS') / wc:.2f} | {g('SQ_LDS_IDX_ACTIVE') / (cyc * 256):.2f} | {g('SQ_LDS_BANK_CONFLICT') / (cyc * 256):.2f} |")
 PY
