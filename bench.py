@@ -117,6 +117,7 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
     Predictor(model, device=dev, apply_softmax=True).predict(torch.randn(1, 1, *[t + 2 * o for t, o in zip(tile, overlap)]))   # warm-up tile
     pred = Predictor(model, device=dev, tile_shape=tile, overlap_shape=overlap, offset=None, out_shape=(2, *shape), apply_softmax=True,
                      strict_shapes=False, tile_parallel=tile_parallel)
+    pred.prepare(vol)            # (the page-locked staging slots of the host <-> device pipeline: once per process, not part of a predict() call)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = pred.predict(vol)
@@ -143,6 +144,80 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
                      'Winograd-executed matrix FLOP actually run (64/216 of the un-skipped algorithmic count) / wall time incl. PCIe / fp32 MFMA peak')}
 
 
+def train_leg(dev, kind, steps=10, warmup=3):
+    """Secondary training legs of the DEFAULT run (N = 1), so that the driver records BASELINE's other training configurations too:
+      'bf16'  configs[2]'s per-GPU workload: the cfg-2 module cast with model.to(torch.bfloat16), bf16 crops, native bf16 kernels;
+      'cfg4'  configs[3]'s per-GPU workload: anisotropic UNet (planar_blocks=(0,1), start_filts=64), fp32, batch 2 of 32x256x256;
+      'two_call'  cfg 2 in fp32 through the reference's two calls (out = model(inp); loss = criterion(out, target), trainer.py:520-524) instead
+                  of UNet.forward_with_loss (the boundary the headline uses).
+    Same step as the headline: forward + CE/Dice loss + backward, optimizer excluded, inputs resident, `warmup` untimed + `steps` timed steps."""
+    from elektronn3_amd.unet import UNet
+    from elektronn3_amd.loss import CombinedCEDiceLoss
+    torch.manual_seed(0)
+    if kind == 'cfg4':
+        model = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=64, planar_blocks=(0, 1), normalization='batch').to(dev).train()
+        crop, prof_layer = (32, 256, 256), None
+    else:
+        model = UNet(in_channels=1, out_channels=2, n_blocks=4, start_filts=32, normalization='batch').to(dev).train()
+        crop, prof_layer = CROP, 'up_convs.2.conv1'
+    x = torch.randn(BATCH_PER_GPU, 1, *crop, device=dev)
+    tgt = torch.randint(0, 2, (BATCH_PER_GPU, *crop), device=dev)
+    if kind == 'bf16':
+        model = model.to(torch.bfloat16)
+        x = x.to(torch.bfloat16)
+        if not model._plan().bf16_supported():
+            return {'value': None, 'note': 'configuration not on the native bf16 path'}
+    criterion = CombinedCEDiceLoss(weight=[0.2653, 0.7347]).to(dev)
+
+    def step():
+        if kind == 'two_call':
+            loss = criterion(model(x), tgt)
+        else:
+            _, loss = model.forward_with_loss(x, tgt, criterion)
+        for p in model.parameters():
+            p.grad = None
+        loss.backward()
+
+    li = None
+    if prof_layer is not None:
+        layers = model.conv_layers()
+        li = [l[0] for l in layers].index(prof_layer)
+        model.profile_select(li, 0)
+    for _ in range(warmup):
+        step()
+    if li is not None:
+        model.profile_select(li, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    vox = BATCH_PER_GPU * crop[0] * crop[1] * crop[2]
+    res = {'ms_per_step': dt * 1e3, 'value': vox / dt, 'unit': 'voxels/s', 'steps': steps, 'warmup': warmup, 'batch': BATCH_PER_GPU, 'crop': list(crop),
+           'dtype': 'bf16' if kind == 'bf16' else 'f32', 'max_memory_gib': torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+    if li is not None:
+        k_ms, k_n = model.profile_read()
+        model.profile_select(-1, 0)
+        _, lcin, lcout, ltaps, llevel = layers[li]
+        lvox = vox // (8 ** llevel)
+        lflops = 2.0 * lcin * lcout * ltaps * lvox
+        if kind == 'bf16' and k_ms > 0:
+            ach = lflops / (k_ms * 1e-3) / 1e12
+            res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s', 'frac': ach / MFMA_PEAK_TFLOPS['bf16'],
+                               'kernel': f'conv_b16_kernel fwd of {prof_layer} ({lcin}->{lcout}, {ltaps} taps, {lvox} voxels)', 'ms_per_launch': k_ms, 'launches_timed': k_n,
+                               'hbm_frac': (lvox * (lcin + lcout) + lcin * lcout * ltaps) * 2 / (k_ms * 1e-3) / HBM_PEAK}
+    if kind == 'cfg4':
+        res['workload'] = 'BASELINE.json configs[3] per-GPU workload: UNet(n_blocks=4, start_filts=64, planar_blocks=(0,1)) fp32 train fwd+bwd, batch 2 of 1x32x256x256'
+    elif kind == 'bf16':
+        res['workload'] = 'BASELINE.json configs[2] per-GPU workload: the cfg-2 module cast with model.to(torch.bfloat16), bf16 crops, native bf16 kernels'
+    else:
+        res['workload'] = 'cfg 2 (the headline) through the two separate calls out = model(x); loss = criterion(out, target) instead of UNet.forward_with_loss'
+    del model, x, tgt
+    torch.cuda.empty_cache()
+    return res
+
+
 def respawn_under_launcher(args):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: run the same command one process per GPU."""
     import socket
@@ -165,6 +240,9 @@ def main():
     ap.add_argument('--no-predictor', action='store_true', help='skip the Predictor MVox/s leg')
     ap.add_argument('--predictor-volume', choices=('full', 'sub'), default=None, help='full = 512x2048x2048 (default for N = 1), sub = 288x1152x1152')
     ap.add_argument('--profile-layer', default='up_convs.2.conv1')
+    ap.add_argument('--no-extra-legs', action='store_true', help='skip the cfg-3 (bf16) / cfg-4 / two-call training legs of the default f32 run')
+    ap.add_argument('--dp-overlap', action='store_true', help='N > 1: all-reduce bucket A at the bucket event, overlapped with the rest of the backward '
+                    '(GradSync(overlap=True): 16 CUs reserved after the event); default: one all-reduce behind the backward')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -183,6 +261,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if args.dp_overlap or os.environ.get('E3_DP_OVERLAP') is not None:
+            os.environ.setdefault('NCCL_MAX_NCHANNELS', os.environ.get('E3_DP_CU_RESERVE', '16'))     # RCCL's kernel: at most as many workgroups as CUs are reserved
         # RCCL's kernels must get compute units while the (512-register, one-workgroup-per-CU) conv kernels of the backward own the
         # chip: run the collectives on a high-priority stream so that they are dispatched first whenever a CU frees up
         pg_opts = None
@@ -209,7 +289,7 @@ def main():
     sync = None
     if world > 1 or (dist is not None):
         from elektronn3_amd.dataparallel import GradSync
-        sync = GradSync(model)
+        sync = GradSync(model, overlap=True if args.dp_overlap else None)
     torch.manual_seed(1000 + rank)                         # different synthetic crops per rank
     x = torch.randn(BATCH_PER_GPU, 1, *CROP, device=dev)
     if bf16:
@@ -286,7 +366,8 @@ def main():
             'metric': 'voxels/sec (train fwd+bwd) 3D UNet 64x128x128',
             'value': vox_per_step / (ms_per_step * 1e-3),
             'unit': 'voxels/s',
-            'n_gpus': world, 'rccl_ranks': (dist.get_world_size() if dist is not None else 0), 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': world, 'rccl_ranks': (dist.get_world_size() if dist is not None else 0),
+            'dp_mode': (sync.mode if sync is not None else None), 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
@@ -314,6 +395,17 @@ def main():
                 res['cpu_baseline'] = {'value': None, 'unit': 'voxels/s', 'cores': torch.get_num_threads(), 'kind': 'port',
                                        'sample': f'failed: {e}'}
 
+    # ---- BASELINE's other training configurations and the two-call boundary (N = 1, default dtype only; ~0.5 s of GPU time)
+    if world == 1 and dist is None and args.dtype == 'f32' and not args.no_extra_legs and os.environ.get('E3_BENCH_NO_EXTRA') is None:
+        del model, x, tgt
+        x = tgt = None
+        torch.cuda.empty_cache()
+        for key, kind in (('two_call', 'two_call'), ('cfg3_bf16', 'bf16'), ('cfg4', 'cfg4')):
+            try:
+                res[key] = train_leg(dev, kind)
+            except Exception as e:  # noqa: BLE001
+                res[key] = {'value': None, 'note': f'failed: {e}'}
+
     # ---- Predictor leg (all ranks take part when N > 1)
     done = threading.Event()
 
@@ -323,7 +415,7 @@ def main():
             print(json.dumps(res), flush=True)
 
     if not args.no_predictor and os.environ.get('E3_BENCH_NO_PREDICTOR') is None:
-        del x, tgt
+        x = tgt = None
         torch.cuda.empty_cache()
         vol_kind = args.predictor_volume or ('full' if world == 1 else 'sub')
         shape = (512, 2048, 2048) if vol_kind == 'full' else (288, 1152, 1152)

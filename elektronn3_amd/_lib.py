@@ -23,6 +23,12 @@ E3_FWD_FROZEN_BN = 4
 E3_BWD_FROZEN_BN = 1
 
 
+def E3_BWD_CU_RESERVE(n):
+    """flag bits of e3_unet_backward2: CUs (multiple of 8, <= 128) left to a collective after the bucket event (include/e3unet.h)"""
+    return ((int(n) >> 3) & 0x1f) << 8
+
+
+
 class E3Error(RuntimeError):
     pass
 
@@ -196,4 +202,4 @@ def ptr(t):
 
 
 __all__ = ['load', 'check', 'ptr', 'stream_ptr', 'UNetCfg', 'E3Error', 'EXPORTED_SYMBOLS', 'E3_FWD_TRAINING',
-           'E3_FWD_SOFTMAX', 'E3_FWD_FROZEN_BN', 'E3_BWD_FROZEN_BN', 'byref', 'c_size_t', 'c_void_p', 'c_float', 'c_int', 'c_int64', 'c_double', 'POINTER']
+           'E3_FWD_SOFTMAX', 'E3_FWD_FROZEN_BN', 'E3_BWD_FROZEN_BN', 'E3_BWD_CU_RESERVE', 'byref', 'c_size_t', 'c_void_p', 'c_float', 'c_int', 'c_int64', 'c_double', 'POINTER']

@@ -1030,8 +1030,8 @@ static bool wino_persistent(size_t nblk, int flags) {
 // one statistics record per WORKGROUP (256 / ntiles rows of [Cout][3]) instead of one per brick: possible when every workgroup of the
 // 256-workgroup persistent grid stays inside one column tile and the workgroups of a row cover all column tiles -- XCD ranges that start
 // at multiples of ntiles (nblk / 8 a multiple of ntiles) and a step of 32 logical bricks that is one too
-static bool wino_wgstats(size_t nblk, int ntiles) {
-    return nblk >= 256 && nblk % 8 == 0 && (nblk / 8) % (size_t)ntiles == 0 && 32 % ntiles == 0;
+static bool wino_wgstats(size_t nblk, int ntiles, unsigned pgrid = 256u) {
+    return pgrid == 256u && nblk >= 256 && nblk % 8 == 0 && (nblk / 8) % (size_t)ntiles == 0 && 32 % ntiles == 0;
 }
 int wino_stats_parts(int N, int D, int H, int W, int ncols, int flags) {
     const int bricks = wino_bricks(N, D, H, W), ntiles = (ncols + 31) / 32;
@@ -1056,6 +1056,7 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
     }
     a.NPad = (a.Ncols + 31) / 32 * 32;
     a.ntiles = a.NPad / 32;
+    if (a.stats) a.cu_reserve = 0;      // (the statistic records are sized for the full grid; only data gradients run beside a collective)
     const size_t nblk = (size_t)a.N * a.tilesD * a.tilesH * a.tilesW * a.ntiles;
     E3_REQUIRE(nblk > 0 && nblk < (1u << 31), E3_ERR_INVALID, "conv grid out of range");
     E3_REQUIRE((size_t)6 * a.H * a.W * (size_t)(a.x_ldc > a.y_ldc ? a.x_ldc : a.y_ldc) * 4 < 0x7fffffffu, E3_ERR_UNSUPPORTED,
@@ -1080,16 +1081,20 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
             pattr = true;
         }
         E3_REQUIRE(!(a.epi_scale && a.stats), E3_ERR_INVALID, "Winograd conv: statistics and the folded epilogue exclude each other");
-        const unsigned pgrid = nblk >= 256 ? 256u : (unsigned)nblk;   // one workgroup per CU (256 is a multiple of the 8 XCDs; smaller grids run one brick each)
+        // one workgroup per CU (256 is a multiple of the 8 XCDs; smaller grids run one brick each).  cu_reserve > 0 (a multiple of 8): that many
+        // CUs are left to the resident workgroups of a collective on a side stream -- a persistent workgroup that finds no free CU would
+        // only start when another one has finished ALL its bricks, i.e. the launch would take twice as long
+        const unsigned pfull = 256u - (unsigned)((a.cu_reserve < 0 ? 0 : (a.cu_reserve > 128 ? 128 : a.cu_reserve)) & ~7);
+        const unsigned pgrid = nblk >= pfull ? pfull : (unsigned)nblk;
         // a workgroup's bricks are L0, L0 + pgrid / 8, ... in the logical (XCD-blocked) order: digits of that step in the mixed radix
         // (column tile, tw, th, td, sample) for the division-free brick counters
         WinoPArgs pa{};
-        unsigned st = pgrid == 256u ? 32u : 0u;
+        unsigned st = pgrid == pfull ? pfull / 8u : 0u;
         pa.s_nt = (int)(st % (unsigned)a.ntiles); st /= (unsigned)a.ntiles;
         pa.s_tw = (int)(st % (unsigned)a.tilesW); st /= (unsigned)a.tilesW;
         pa.s_th = (int)(st % (unsigned)a.tilesH); st /= (unsigned)a.tilesH;
         pa.s_td = (int)(st % (unsigned)a.tilesD); pa.s_nb = (int)(st / (unsigned)a.tilesD);
-        pa.wgstats = (a.stats && wino_wgstats(nblk, a.ntiles)) ? 1 : 0;
+        pa.wgstats = (a.stats && wino_wgstats(nblk, a.ntiles, pgrid)) ? 1 : 0;
         pa.e_tw = a.o_tw + a.tilesW; pa.e_th = a.o_th + a.tilesH; pa.e_td = a.o_td + a.tilesD;
         if (a.epi_scale) hipLaunchKernelGGL(conv3_wino_pkernel<true>, dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
         else hipLaunchKernelGGL(conv3_wino_pkernel<false>, dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);

@@ -45,6 +45,10 @@ struct ConvArgs {
     // (d, h, w) are computed -- the rest of y is left untouched.  The other kernels ignore it and compute everything.  No statistics.
     int box_lo[3], box_hi[3];
     int o_td, o_th, o_tw;        // (set by the launcher: first brick of the box per axis)
+    // compute units to leave alone (0 = use the whole chip; a multiple of 8 = one share per XCD): kernels that size their grid for ONE
+    // residency round of one workgroup per CU (the persistent Winograd kernel) launch 256 - cu_reserve workgroups, so that they all fit
+    // beside the resident workgroups of a collective running on a side stream (data-parallel backward)
+    int cu_reserve;
 };
 
 // number of stats records (rows of [Cout][3]) the conv will write
@@ -192,8 +196,9 @@ struct WgradArgs {
     int CoPad, CiPad, splits;
     // POINT (transposed conv): x has dims (N,D,H,W); dy has dims (N,Do,Ho,Wo), row p pairs with dy voxel 2p+tap
     int Do, Ho, Wo, sd;
+    int cu_reserve;                         // as ConvArgs::cu_reserve: the one-round kernels split the voxels over 256 - cu_reserve workgroups (3x3x3 Winograd kernel only)
 };
-int wgrad_splits(ConvKind kind, int N, int D, int H, int W, int Cin, int Cout);
+int wgrad_splits(ConvKind kind, int N, int D, int H, int W, int Cin, int Cout, int cu_reserve = 0);
 int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s);
 // Winograd F(3x3x3, 2x2x2) variant for CONV_K3 (wgrad_wino.hip): same bricks, splits and partial-slab layout
 bool wgrad_use_wino(ConvKind kind);

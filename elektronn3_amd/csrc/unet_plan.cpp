@@ -1037,6 +1037,9 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
     // ---- walk the units backwards.  `g` = gradient w.r.t. the current unit's activation.
     const float* g = B.g1[0]; int g_ldc = C0;
     bool event_done = bucket_event == nullptr;
+    // after the bucket event a collective may be resident on some CUs: the one-round kernels leave `reserve` CUs alone (E3_BWD_CU_RESERVE)
+    const int reserve_req = bucket_event ? (int)((flags >> 8) & 0x1fu) * 8 : 0;
+    auto reserve = [&]() { return event_done ? reserve_req : 0; };
     std::vector<WgradReduceJob> wred_jobs;   // slab reductions of the weight gradients (units with their own slab), several per launch
     size_t wred_bytes = 0;                   // pending slab bytes (flushing every 48 / 96 / 160 MB was measured: no better than one launch)
     const size_t wred_limit = ~(size_t)0;
@@ -1235,7 +1238,8 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
             WgradArgs a{};
             a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dyu; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = B.slab_u[k] ? B.slab_u[k] : B.slab;
             a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
-            a.splits = wgrad_splits(kind, N, ci.D, ci.H, ci.W, u.cin, u.cout);
+            a.cu_reserve = reserve();      // (fewer, longer splits: the slab sized for the full chip is large enough)
+            a.splits = wgrad_splits(kind, N, ci.D, ci.H, ci.W, u.cin, u.cout, a.cu_reserve);
             { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(kind, a, s)); }
             if (B.slab_u[k]) RUN(wred_push({a.part, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin}));
             else RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
@@ -1291,7 +1295,10 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
             a.x = dyu; a.x_ldc = u.cout; a.Cin = u.cout; a.wt = B.wpk_d[k] ? B.wpk_d[k] : B.wpack; a.y = out; a.y_ldc = out_ldc;
             a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.sd = 2;
             a.Cout = u.cin; a.Ncols = u.cin; a.NPad = NPad; a.G = 1;
-            a.flags = (bucket_event != nullptr && event_done) ? CF_NO_PERSIST : 0;   // the gradient all-reduce may be running on some CUs
+            // the gradient all-reduce may be running on some CUs: with a reserve the persistent kernel leaves them alone, without one the
+            // one-brick-per-workgroup kernel degrades by the fraction of CUs taken instead of needing a second round
+            a.cu_reserve = reserve();
+            a.flags = (bucket_event != nullptr && event_done && a.cu_reserve == 0) ? CF_NO_PERSIST : 0;
             const int S = (kind == CONV_K3) ? bwd_split(k) : 1;
             const size_t gvox = (size_t)N * ci.D * ci.H * ci.W;
             if (S > 1) {

@@ -310,16 +310,19 @@ int tiles_per_split(int ntiles, int other, int resident = 512) {
     return cdiv(ntiles, want);
 }
 
+// compute units a one-round weight-gradient launch leaves to a collective's resident workgroups (clamped: at least half the chip works)
+int wgrad_reserve(int cu_reserve) { return cu_reserve < 0 ? 0 : (cu_reserve > 128 ? 128 : cu_reserve); }
+
 }  // namespace
 
-int wgrad_splits(ConvKind kind, int N, int D, int H, int W, int Cin, int Cout) {
+int wgrad_splits(ConvKind kind, int N, int D, int H, int W, int Cin, int Cout, int cu_reserve) {
     // (POINT: D, H, W are the INPUT dims of the transposed conv; sd is not known here, the GEMM kernel serves sd = 1 and 2 alike)
     if (kind == CONV_POINT && upconv_wgrad_ok(Cin, Cout, 2)) return upconv_wgrad_splits(N, D, H, W, Cin, Cout);
     if (wgrad_use_wino2d(kind, Cin, Cout)) return wgrad_wino2d_splits(N, D, H, W, Cin, Cout);
     int TD, TH; wgeo(kind, TD, TH);
     const int ntiles = N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, 16);
     const int other = cdiv(Cout, 32) * cdiv(Cin, 32) * (kind == CONV_POINT ? 8 : 1);   // POINT: one workgroup per tap too
-    return cdiv(ntiles, tiles_per_split(ntiles, other, wgrad_use_wino(kind) ? 256 : 512));
+    return cdiv(ntiles, tiles_per_split(ntiles, other, wgrad_use_wino(kind) ? 256 - wgrad_reserve(cu_reserve) : 512));
 }
 
 int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s) {
@@ -330,7 +333,7 @@ int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s) {
     const int tD = cdiv(a.D, TD), tH = cdiv(a.H, TH), tW = cdiv(a.W, 16);
     const int ntiles = a.N * tD * tH * tW;
     const int co_tiles = cdiv(a.Cout, 32), ci_tiles = cdiv(a.Cin, 32);
-    const int tps = tiles_per_split(ntiles, co_tiles * ci_tiles * (kind == CONV_POINT ? 8 : 1), wgrad_use_wino(kind) ? 256 : 512);
+    const int tps = tiles_per_split(ntiles, co_tiles * ci_tiles * (kind == CONV_POINT ? 8 : 1), wgrad_use_wino(kind) ? 256 - wgrad_reserve(a.cu_reserve) : 512);
     const int splits = cdiv(ntiles, tps);
     E3_REQUIRE(splits == a.splits, E3_ERR_INVALID, "wgrad: splits mismatch");
     if (kind == CONV_POINT) {

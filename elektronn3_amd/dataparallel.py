@@ -4,7 +4,8 @@ Replaces ``torch.nn.DataParallel`` as the reference uses it (benchmark/train_ben
 elektronn3/models/base.py:48-49): instead of one process that re-broadcasts all parameters, scatters the batch and
 reduces gradients onto GPU 0 every iteration, every rank owns a replica and a minibatch shard (samples are the
 independent units) and the only exchange is ONE sum of the flat fp32 gradient buffer
-(5.6 M floats = 22.4 MB for cfg 2), issued on a side HIP stream in two buckets:
+(5.6 M floats = 22.4 MB for cfg 2), issued on a side HIP stream -- by default as one collective behind the backward
+(``overlap=False``), with ``overlap=True`` in two buckets:
 
   bucket A  every layer except the first ``bucket_after_down_block`` encoder blocks.  Its gradients are complete
             while the backward is still working through the full-resolution encoder blocks (which hold only ~3 %
@@ -21,7 +22,16 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model, process_group=None, bucket_after_down_block=2, average=True):
+    """``overlap``: False (default) = both buckets are reduced when the backward has finished -- the all-reduce of 22 MB costs ~3-4 % of a
+    cfg-2 step on xGMI and nothing else is touched.  True (or ``E3_DP_OVERLAP=1``) = bucket A is reduced on the side stream WHILE the backward
+    works through the first encoder blocks; the kernels launched after the bucket's event then leave ``cu_reserve`` compute units (a multiple of
+    8, default 16 = two per XCD; ``E3_DP_CU_RESERVE``) to the collective's resident workgroups: the persistent conv kernels occupy every CU they
+    get with one 512-register workgroup, and one that found its CU taken would wait a whole round (measured: +55 % on the step with ONE foreign
+    wave, tools/probe_foreign_waves.py).  ``NCCL_MAX_NCHANNELS`` is set to ``cu_reserve`` (unless the caller set it) so that RCCL's kernel has at
+    most that many workgroups."""
+
+    def __init__(self, model, process_group=None, bucket_after_down_block=2, average=True, overlap=None, cu_reserve=None):
+        import os
         if isinstance(model, torch.jit.ScriptModule):
             # (the TorchScript operator's backward has no handle on this object: a scripted replica would silently skip the all-reduce)
             raise TypeError('GradSync needs the eager elektronn3_amd.UNet: script the model for saving (Trainer save_jit), train the eager one')
@@ -31,10 +41,16 @@ class GradSync:
         self.bucket_after_down_block = int(min(bucket_after_down_block, model.n_blocks))
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # world == 1 normally short-circuits; `force` keeps the whole event/side-stream/all-reduce path alive (tests)
-        self.force = bool(int(__import__('os').environ.get('E3_FORCE_GRADSYNC', '0')))
-        # E3_DP_NO_OVERLAP=1: both buckets are reduced AFTER the backward (A/B switch for multi-GPU boxes: a collective's kernel that is resident
-        # beside the persistent conv kernels makes them take a second round of workgroups)
-        self.no_overlap = __import__('os').environ.get('E3_DP_NO_OVERLAP') is not None
+        self.force = bool(int(os.environ.get('E3_FORCE_GRADSYNC', '0')))
+        if overlap is None:
+            overlap = os.environ.get('E3_DP_OVERLAP') is not None and os.environ.get('E3_DP_NO_OVERLAP') is None
+        self.overlap = bool(overlap)
+        if cu_reserve is None:
+            cu_reserve = int(os.environ.get('E3_DP_CU_RESERVE', '16'))
+        self.cu_reserve = max(0, min(128, int(cu_reserve))) // 8 * 8 if self.overlap else 0
+        if self.overlap and self.cu_reserve:
+            os.environ.setdefault('NCCL_MAX_NCHANNELS', str(self.cu_reserve))      # (read when the communicator is created: the first collective)
+        self.collective = None        # tests / probes: callable(tensor) run on the side stream in place of the all-reduce
         self._flat = None
         self._views = None
         self._split = 0
@@ -43,6 +59,11 @@ class GradSync:
         self._works = []
         # plain attribute, not a sub-module/parameter: keeps state_dict and pickling of the model unchanged
         object.__setattr__(model, '_grad_sync', self)
+
+    @property
+    def mode(self):
+        return (f'overlap (bucket event after down block {self.bucket_after_down_block}, {self.cu_reserve} CUs reserved)' if self.overlap
+                else 'serial (all-reduce after the backward)')
 
     # -- called from _UNetFunction.backward ------------------------------------------------------------------
     def flat_views(self, plan, tens):
@@ -63,15 +84,20 @@ class GradSync:
         self._split = split
         return self._flat, self._views
 
+    def _side_stream(self):
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self._flat.device, priority=-1)   # collectives ahead of queued compute
+        return self._comm_stream
+
     def bucket_event(self):
-        """Raw hipEvent_t (as c_void_p) that libe3unet records when bucket A is complete; None on CPU."""
-        if self._flat is None or not self._flat.is_cuda or (self.world == 1 and not self.force):
+        """Raw hipEvent_t (as c_void_p) that libe3unet records when bucket A is complete; None on CPU and in serial mode (the library then
+        launches everything for the whole chip)."""
+        if self._flat is None or not self._flat.is_cuda or (self.world == 1 and not self.force) or not self.overlap:
             return None
         import ctypes
         if self._event is None:
             self._event = torch.cuda.Event()
             self._event.record()          # forces creation of the underlying hipEvent_t
-            self._comm_stream = torch.cuda.Stream(device=self._flat.device, priority=-1)   # collectives ahead of queued compute
         return ctypes.c_void_p(self._event.cuda_event)
 
     def after_backward(self, plan):
@@ -84,16 +110,18 @@ class GradSync:
             self._allreduce(b)
             return
         cur = torch.cuda.current_stream(flat.device)
+        side = self._side_stream()
         works = []
-        with torch.cuda.stream(self._comm_stream):
-            if self.no_overlap:
-                self._comm_stream.wait_stream(cur)
-            else:
-                self._comm_stream.wait_event(self._event)  # bucket A's gradients are final
-            works.append(self._allreduce(a, async_op=True))
-            self._comm_stream.wait_stream(cur)             # the whole backward has been enqueued on `cur`
-            if b.numel():
-                works.append(self._allreduce(b, async_op=True))
+        with torch.cuda.stream(side):
+            if self.overlap:
+                side.wait_event(self._event)               # bucket A's gradients are final
+                works.append(self._allreduce(a, async_op=True))
+                side.wait_stream(cur)                      # the whole backward has been enqueued on `cur`
+                if b.numel():
+                    works.append(self._allreduce(b, async_op=True))
+            else:                                          # one collective over the whole buffer, behind the backward
+                side.wait_stream(cur)
+                works.append(self._allreduce(flat, async_op=True))
         for w in works:                                    # stream-level wait: `cur` resumes after the collectives
             if w is not None:
                 w.wait()
@@ -104,6 +132,9 @@ class GradSync:
     # -- helpers -----------------------------------------------------------------------------------------------
     def _allreduce(self, t, async_op=False):
         if t.numel() == 0:
+            return None
+        if self.collective is not None:
+            self.collective(t)
             return None
         backend = dist.get_backend(self.group)
         if self.average and backend == 'nccl':

@@ -115,6 +115,12 @@ class _PinnedRing:
             self.events[k].record(stream)
             self.pending[k] = (dst[:, :, z:z + step], view)
 
+    def reset(self):
+        """Forget events and pending copies (a predict() that raised midway must not leave them to the next one)."""
+        self.events = [None, None]
+        self.pending = [None, None]
+        self.i = 0
+
     def flush(self):
         for k in (self.i, self.i ^ 1):
             if self.events[k] is not None:
@@ -128,22 +134,38 @@ class _PinnedRing:
 
 _RINGS = {}
 _RING_LOCKS = {}
+_RINGS_GUARD = __import__('threading').Lock()
+_RING_SLOT_BYTES = 256 << 20
 
 
-def _rings_for(device):
-    """(upload ring, download ring) of a device, allocated once per process (1 GB of page-locked memory); None with E3_PREDICTOR_NO_PINNED=1."""
+def _rings_for(device, slot_bytes=_RING_SLOT_BYTES):
+    """(upload ring, download ring) of a device: allocated on the FIRST pipelined predict() of the process (not when a Predictor is constructed:
+    device-resident or small inputs never take the pipelined path), slots sized for the slabs that path moves (capped at 256 MB each, 1 GB
+    of page-locked memory at most).  None with E3_PREDICTOR_NO_PINNED=1, or when the page-locked allocation fails (memlock limit of a
+    container, small host): the caller then takes the runtime's pageable copies."""
     if os.environ.get('E3_PREDICTOR_NO_PINNED') is not None:
         return None
     key = torch.device(device).index or 0
-    if key not in _RINGS:
-        _RINGS[key] = (_PinnedRing(), _PinnedRing())
-    return _RINGS[key]
+    slot_bytes = int(max(1 << 20, min(_RING_SLOT_BYTES, slot_bytes)))
+    with _RINGS_GUARD:
+        have = _RINGS.get(key)
+        if have is False:                       # an earlier allocation failed: do not retry per call
+            return None
+        if have is not None and have[0].slots[0].numel() >= slot_bytes:
+            return have
+        try:
+            _RINGS[key] = (_PinnedRing(slot_bytes), _PinnedRing(slot_bytes))
+        except RuntimeError as e:               # hipHostMalloc failed
+            logger.warning(f'Predictor: no page-locked staging buffers ({e}); using pageable host copies')
+            _RINGS[key] = False
+            return None
+        return _RINGS[key]
 
 
 def _ring_lock(device):
     """The staging rings of a device serve one pipelined predict() at a time (Predictors on several threads take turns)."""
-    import threading
-    return _RING_LOCKS.setdefault(torch.device(device).index or 0, threading.Lock())
+    with _RINGS_GUARD:
+        return _RING_LOCKS.setdefault(torch.device(device).index or 0, __import__('threading').Lock())
 
 
 class _SharedHostTensor:
@@ -461,8 +483,6 @@ class Predictor:
 
         geo = _Tiling(tile_shape, overlap_shape, offset, out_shape, estimate_offset)
         self.enable_tiling = geo.enabled
-        if self.enable_tiling and self.device.type == 'cuda' and geo.out_shape is not None:
-            _rings_for(self.device)           # (page-locked staging of the host <-> device pipeline: allocated here, once per process, not inside predict())
         self.offset, self.tile_shape, self.overlap_shape, self.out_shape = geo.offset, geo.tile_shape, geo.overlap_shape, geo.out_shape
 
     # ------------------------------------------------------------------ per-tile model call (inference.py:496-525)
@@ -539,6 +559,30 @@ class Predictor:
             return torch.distributed.get_world_size(), torch.distributed.get_rank()
         return 1, 0
 
+    def _ring_bytes(self, inp):
+        """Bytes of the largest slab the pipelined path moves in one piece for this input (a z row of tiles incl. its halo going up; a z row of
+        output going down, at most 4 bytes x 16 channels per voxel) -- the page-locked slots need not be larger (cap: 256 MB)."""
+        N, Cin = int(inp.shape[0]), int(inp.shape[1])
+        z = int(self.tile_shape[0] + 2 * self.overlap_shape[0])
+        plane = int(np.prod(self.out_shape[2:]))
+        up = N * Cin * z * plane * inp.element_size()
+        down = N * 16 * int(self.tile_shape[0]) * plane * 4
+        return min(_RING_SLOT_BYTES, max(up, down))
+
+    def prepare(self, inp_like=None):
+        """Optional: allocate what the host <-> device pipeline of predict() needs once per process (the page-locked staging slots, up to 1 GB)
+        before the first call instead of inside it.  `inp_like`: a tensor / array of the shape and dtype predict() will get (default: the
+        largest slots)."""
+        if self.enable_tiling and self.device.type == 'cuda' and self.out_shape is not None:
+            nbytes = _RING_SLOT_BYTES
+            if inp_like is not None:
+                t = torch.as_tensor(inp_like)
+                if t.dim() == 5:
+                    nbytes = self._ring_bytes(t)
+            with _ring_lock(self.device):
+                _rings_for(self.device, nbytes)
+        return self
+
     @torch.no_grad()
     def _pipelined_predict(self, inp):
         """Same result as the plain path (pad to a multiple of the tile shape, zero halo, tiles in the reference's C order,
@@ -583,8 +627,9 @@ class Predictor:
         need_hi = {k: int(min(real[0], tile[0] * (k + 1) + ov[0])) for k in zrows}
         up_events = {k: torch.cuda.Event() for k in zrows}
         uploaded = [None]                                                 # z plane up to which the input is on the device
-        # pinned staging rings (one per direction, kept by the Predictor): E3_PREDICTOR_NO_PINNED=1 = the runtime's pageable copies
-        rings = _rings_for(dev)
+        # pinned staging rings (one per direction and device, allocated on first use -- or ahead of time by prepare()): E3_PREDICTOR_NO_PINNED=1
+        # = the runtime's pageable copies
+        rings = _rings_for(dev, self._ring_bytes(inp))
 
         def put(dst, src):
             """host slab -> device view.  A volume in another dtype than the model's (fp32 volume, bf16 / float16 model) travels as it is and is
@@ -728,7 +773,13 @@ class Predictor:
         inp = torch.as_tensor(self._transformed(inp))
         if self._pipeline_applicable(inp):                       # host volume streamed through the GPU in rows of tiles
             with _ring_lock(self.device):
-                out = self._pipelined_predict(inp)
+                try:
+                    out = self._pipelined_predict(inp)
+                finally:                                     # (a call that raised midway must not leave its events / pending copies to the next one)
+                    have = _RINGS.get(self.device.index or 0)
+                    if have:
+                        for r in have:
+                            r.reset()
             self._report(t_start, out.numel())
             return out
         # device-resident path: (padded) input and output live in HBM, one upload and one download

@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import E3_BWD_FROZEN_BN, E3_FWD_FROZEN_BN, E3_FWD_SOFTMAX, E3_FWD_TRAINING, UNetCfg, c_size_t, c_void_p, check, ptr
+from ._lib import E3_BWD_CU_RESERVE, E3_BWD_FROZEN_BN, E3_FWD_FROZEN_BN, E3_FWD_SOFTMAX, E3_FWD_TRAINING, UNetCfg, c_size_t, c_void_p, check, ptr
 
 _plans = {}
 _plans_lock = threading.Lock()
@@ -188,7 +188,8 @@ def _native_backward(plan, dy, xin, tens, saved, b16, want_dx, sync=None, frozen
         elif b16:
             check(lib.e3_unet_backward_bf16(*args))
         else:
-            check(lib.e3_unet_backward2(*args, E3_BWD_FROZEN_BN if frozen else 0))
+            reserve = getattr(sync, 'cu_reserve', 0) if (sync is not None and ev is not None) else 0
+            check(lib.e3_unet_backward2(*args, (E3_BWD_FROZEN_BN if frozen else 0) | E3_BWD_CU_RESERVE(reserve)))
     if sync is not None:
         sync.after_backward(plan)
     return flat, views, dx
@@ -202,11 +203,9 @@ class _UNetLossFunction(torch.autograd.Function):
     def forward(ctx, module, crit, want16, x, target, *params):
         ctx.set_materialize_grads(False)
         req = dict(crit, target=target.contiguous())
-        module.__dict__['_loss_req'] = req
-        try:
-            y = _UNetFunction.forward(ctx, module, 2, want16, x, *params)
-        finally:
-            module.__dict__.pop('_loss_req', None)
+        # (the request travels in `mode` like the needed region does: nothing is parked on the module, so a concurrent or re-entrant plain
+        # forward of the same module cannot pick it up)
+        y = _UNetFunction.forward(ctx, module, (2, None, req), want16, x, *params)
         lib = _lib.load()
         N, C = y.shape[:2]
         sp = [1] * (5 - y.dim()) + list(y.shape[2:])
@@ -286,9 +285,9 @@ class _UNetFunction(torch.autograd.Function):
         # (grad mode is off inside Function.forward; needs_input_grad tells whether a backward can follow)
         # (needs_input_grad mirrors requires_grad of the inputs whatever the grad mode: `mode` carries torch.is_grad_enabled() of the caller,
         # so that validation under torch.no_grad() takes the inference path instead of saving activations nobody will use)
-        roi = None
-        if isinstance(mode, tuple):          # (mode bits, needed region): UNet.forward_roi
-            mode, roi = mode
+        roi, loss_req = None, None
+        if isinstance(mode, tuple):          # (mode bits, needed region[, criterion request]): UNet.forward_roi / forward_with_loss
+            mode, roi, loss_req = (tuple(mode) + (None,))[:3]
         softmax, grad_on = bool(mode & 1), bool(mode & 2)
         need_grad = grad_on and any(ctx.needs_input_grad) and not softmax
         # a module in eval mode that a backward will follow (frozen-BatchNorm fine-tuning, training/recalibration.py:53-73 style uses):
@@ -307,7 +306,7 @@ class _UNetFunction(torch.autograd.Function):
         y, saved, xin, b16 = _native_forward(module, plan, x, tens, softmax, want16 if want16 else (all16 if in_dtype == all16 else None),
                                              ctx.needs_input_grad[3], training or frozen,
                                              module._momenta(plan) if (training or frozen) else None, frozen=frozen,
-                                             loss=module.__dict__.get('_loss_req') if (training and not softmax) else None,
+                                             loss=loss_req if (training and not softmax) else None,
                                              roi=roi if not (training or frozen) else None)
         if getattr(module, 'attention', False) and b16 is None:
             _store_attention_maps(module, plan, x, training or frozen, saved)
@@ -1019,6 +1018,13 @@ class UNet(nn.Module):
         fusable = (type(criterion) is CombinedCEDiceLoss and self.training and torch.is_grad_enabled() and self.dim == 3 and not self._per_sample_norm()
                    and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 5 and target.dtype == torch.int64 and target.is_cuda
                    and (not criterion.global_batch or criterion._world() == 1))
+        if fusable:
+            # the head kernel reads target[v] for every output voxel: the target must be exactly the logits' grid on the input's device (a target
+            # on another grid -- the input size with conv_mode='valid', an (N, 1, D, H, W) tensor -- takes the separate calls, which raise
+            # like the reference's CrossEntropyLoss does)
+            out_sp = self._plan().out_dims(*(int(v) for v in x.shape[2:]))
+            fusable = (x.shape[1] == self.in_channels and target.device == x.device
+                       and tuple(target.shape) == (int(x.shape[0]), *out_sp))
         if not fusable:
             out = self(x)
             return out, criterion(out, target)
@@ -1071,9 +1077,22 @@ class UNet(nn.Module):
         dev = vol.device
         N = int(vol.shape[0])
         D, H, W = (int(v) for v in tile_shape)
+        (d0, d1), (h0, h1), (w0, w1) = roi
+        # the library sees raw pointers and strides: everything it will touch is checked here
+        if out.device != dev or any(t.device != dev for t in tens):
+            raise ValueError('forward_tile: volume, output and parameters must be on one device')
+        if int(vol.shape[1]) != 1 or int(out.shape[0]) != N or int(out.shape[1]) != self.out_channels:
+            raise ValueError('forward_tile: vol must be (N, 1, ...), out (N, out_channels, ...)')
+        for ax, (lo, n, size) in enumerate(zip(in_lo, (D, H, W), vol.shape[2:])):
+            if n <= 0 or int(lo) < 0 or int(lo) + n > int(size):
+                raise ValueError(f'forward_tile: tile [{int(lo)}, {int(lo) + n}) exceeds the volume (axis {ax}, size {int(size)})')
+        for ax, ((r0, r1), n, lo, size) in enumerate(zip(roi, (D, H, W), out_lo, out.shape[2:])):
+            if not (0 <= int(r0) < int(r1) <= n):
+                raise ValueError(f'forward_tile: region [{int(r0)}, {int(r1)}) is not inside the tile (axis {ax}, size {n})')
+            if int(lo) < 0 or int(lo) + int(r1) - int(r0) > int(size):
+                raise ValueError(f'forward_tile: region written at {int(lo)} exceeds the output (axis {ax}, size {int(size)})')
         _, scratch_bytes = plan.sizes(N, D, H, W, False, bf16=None)
         scratch = _get_scratch(dev, max(scratch_bytes, 256))
-        (d0, d1), (h0, h1), (w0, w1) = roi
         view = _lib.TileView()
         view.x = vol.data_ptr() + 4 * (int(in_lo[0]) * vol.stride(2) + int(in_lo[1]) * vol.stride(3) + int(in_lo[2]))
         view.x_stride[:] = [vol.stride(0), vol.stride(2), vol.stride(3)]

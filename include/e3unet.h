@@ -100,6 +100,12 @@ int e3_unet_sizes(const e3_unet_plan* plan, int N, int D, int H, int W, int trai
 #define E3_FWD_FROZEN_BN 4u /* with E3_FWD_TRAINING: save activations for a backward, but normalise with the RUNNING statistics and leave them
                              * untouched -- autograd through a module in eval mode (frozen-BN fine-tuning, training/recalibration.py:53-73) */
 #define E3_BWD_FROZEN_BN 1u /* e3_unet_backward2: the matching backward (BatchNorm statistics are constants) */
+/* e3_unet_backward2, with a bucket_event: compute units (a multiple of 8, at most 128: one share per XCD) that the kernels launched AFTER the
+ * event leave alone -- the kernels that fill the chip with exactly one workgroup per CU (persistent Winograd data gradients, Winograd weight
+ * gradients) launch 256 - n workgroups, so that all of them are resident beside the workgroups of the collective the caller starts on a
+ * side stream at the event (one that found no free CU would wait for a whole round: measured +55 % on the step with ONE foreign wave).
+ * Results do not depend on it bit for bit only for the data gradients; the weight-gradient partial sums are split differently. */
+#define E3_BWD_CU_RESERVE(n) ((((uint32_t)(n) >> 3) & 0x1fu) << 8)
 
 /* y[N,out,D,H,W] = UNet(x[N,in,D,H,W]).
  *   params : e3_unet_param_count() device pointers in table order
@@ -129,8 +135,8 @@ int e3_unet_forward_loss(e3_unet_plan* plan, void* stream, const float* x, int N
  * y) -- the tile loop of inference.Predictor, which crops the overlap off every tile's output (inference.py:496-525, tiled_apply :134-199):
  * y holds the same values as after e3_unet_forward INSIDE that region and unspecified values outside it.  The decoder's 3x3x3 convs then
  * compute only the bricks that the region needs (it grows by one voxel per conv and halves per transposed conv on the way back; the
- * encoder is computed in full).  Configurations without the facility (valid convs, attention, ResizeConv, planar blocks, the bf16 path)
- * simply compute everything. */
+ * encoder is computed in full).  Configurations without the facility (valid convs, attention, ResizeConv, ResUNet, planar blocks) simply
+ * compute everything.  The 16-bit executors have the same entry point (e3_unet_forward_roi_bf16 / _f16 below). */
 int e3_unet_forward_roi(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
                         void* const* params, float* y, void* scratch, size_t scratch_bytes, uint32_t flags, const int roi[6]);
 

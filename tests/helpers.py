@@ -135,3 +135,41 @@ def load_bf16_fixture(path):
         else:
             out[k] = torch.from_numpy(a) if a.ndim else torch.tensor(a.item())
     return out
+
+
+# ---------------------------------------------------------------------------------------------- resident "foreign" kernel (test infrastructure)
+_SPIN = None
+
+
+def spin_lib():
+    """ctypes handle of tests/native/spin_kernel.hip, built in-tree with hipcc on first use (None when hipcc is missing)."""
+    global _SPIN
+    if _SPIN is None:
+        import ctypes
+        import shutil
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        src, out = os.path.join(here, 'native', 'spin_kernel.hip'), os.path.join(here, 'native', 'libspin.so')
+        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+            hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+            if not os.path.exists(hipcc):
+                return None
+            tmp = out + f'.tmp{os.getpid()}'
+            subprocess.run([hipcc, '--offload-arch=gfx950', '-O2', '-shared', '-fPIC', '-o', tmp, src], check=True, capture_output=True)
+            os.replace(tmp, out)
+        _SPIN = ctypes.CDLL(out)
+        _SPIN.spin_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
+        _SPIN.spin_launch.restype = ctypes.c_int
+    return _SPIN
+
+
+def spin(stream, blocks, microseconds, lds_bytes=16384, sink=None):
+    """`blocks` workgroups of 256 threads resident on `stream` (a torch.cuda.Stream) for `microseconds`."""
+    import torch
+    lib = spin_lib()
+    assert lib is not None, 'hipcc not available: cannot build the spin kernel'
+    if sink is None:
+        sink = torch.zeros(4, dtype=torch.int32, device='cuda')
+    rc = lib.spin_launch(stream.cuda_stream, int(blocks), int(lds_bytes), int(microseconds * 100), sink.data_ptr())
+    assert rc == 0, rc
+    return sink

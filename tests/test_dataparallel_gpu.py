@@ -37,14 +37,19 @@ def _make(seed=0, bf16=False):
     return m.to(torch.bfloat16) if bf16 else m
 
 
-def _batch():
+def _batch(big=False):
+    """big: 2 x 32 x 64 x 64 per rank = 1024 Winograd bricks at level 0 -- the persistent conv kernel and the one-round weight-gradient
+    kernel run (the small case takes the one-brick-per-workgroup kernels)."""
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(4, 1, 16, 32, 32, generator=g)
-    t = (torch.rand(4, 16, 32, 32, generator=g) < torch.tensor([0.1, 0.3, 0.6, 0.9]).view(4, 1, 1, 1)).long()     # unbalanced shards
+    sp = (32, 64, 64) if big else (16, 32, 32)
+    x = torch.randn(4, 1, *sp, generator=g)
+    t = (torch.rand(4, *sp, generator=g) < torch.tensor([0.1, 0.3, 0.6, 0.9]).view(4, 1, 1, 1)).long()     # unbalanced shards
     return x, t
 
 
-def _worker(rank, world, port, backend, tmp, bf16=False):
+def _worker(rank, world, port, backend, tmp, bf16=False, mode='overlap', big=False):
+    """mode: 'serial' (GradSync's default: one all-reduce behind the backward), 'overlap' (bucket A reduced at the bucket event, 16 CUs
+    reserved), 'overlap+spin' (as 'overlap', and a stand-in for RCCL's kernel -- 8 resident workgroups -- in front of the all-reduce)."""
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -56,9 +61,18 @@ def _worker(rank, world, port, backend, tmp, bf16=False):
         from elektronn3_amd.dataparallel import GradSync, shard_batch
         from elektronn3_amd.loss import CombinedCEDiceLoss
         model = _make(bf16=bf16).to(dev).train()
-        sync = GradSync(model, bucket_after_down_block=2)
+        sync = GradSync(model, bucket_after_down_block=2, overlap=mode != 'serial', cu_reserve=16)
+        assert sync.overlap == (mode != 'serial') and sync.cu_reserve == (16 if sync.overlap else 0) and mode.split('+')[0] in sync.mode
+        if mode == 'overlap+spin':
+            from helpers import spin
+            real = sync._allreduce
+
+            def with_foreign_kernel(tns, async_op=False):
+                spin(torch.cuda.current_stream(), 8, 300.0)          # resident on the side stream while the backward's tail runs
+                return real(tns, async_op=async_op)
+            sync._allreduce = with_foreign_kernel
         crit = CombinedCEDiceLoss(weight=CW, global_batch=True).to(dev)
-        x, t = _batch()
+        x, t = _batch(big)
         xr, tr = shard_batch(x, rank, world).to(dev), shard_batch(t, rank, world).to(dev)
         if bf16:
             xr = xr.to(torch.bfloat16)
@@ -68,19 +82,20 @@ def _worker(rank, world, port, backend, tmp, bf16=False):
             loss.backward()
             sync.wait()
         torch.cuda.synchronize()
-        torch.save({'loss': float(loss), 'grads': {k: p.grad.float().cpu() for k, p in model.named_parameters()}}, os.path.join(tmp, f'dp{rank}.pt'))
+        torch.save({'loss': float(loss), 'grads': {k: p.grad.float().cpu() for k, p in model.named_parameters()},
+                    'buffers': {k: b.float().cpu() for k, b in model.named_buffers()}}, os.path.join(tmp, f'dp{rank}.pt'))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def _reference(bf16=False):
+def _reference(bf16=False, big=False):
     """One process, both shards through the same replica (per-shard BatchNorm statistics), ONE loss over the gathered logits."""
     from elektronn3_amd.loss import CombinedCEDiceLoss
     dev = torch.device('cuda', 0)
     model = _make(bf16=bf16).to(dev).train()
     crit = CombinedCEDiceLoss(weight=CW).to(dev)
-    x, t = _batch()
+    x, t = _batch(big)
     for step in range(2):
         model.zero_grad(set_to_none=True)
         outs = [model(x[r * 2:(r + 1) * 2].to(dev).to(torch.bfloat16 if bf16 else torch.float32)) for r in range(2)]
@@ -127,3 +142,38 @@ def test_two_rank_train_step_bf16_module(tmp_path):
             assert err < 2e-2, (r, k, err)
     for k in g_ref:
         assert torch.equal(res[0]['grads'][k], res[1]['grads'][k]), k        # identical replicas after the all-reduce
+
+
+@pytest.mark.parametrize('mode', ['serial', 'overlap+spin'])
+def test_two_rank_step_beside_a_resident_foreign_kernel(mode, tmp_path):
+    """The data-parallel step at a size where the persistent Winograd kernels run, (a) with GradSync's default (serial) mode and (b) with the
+    overlapped bucket, 16 compute units reserved after the bucket event (E3_BWD_CU_RESERVE) and a stand-in for RCCL's kernel -- 8 workgroups
+    resident on the side stream for 300 us -- in front of the real (gloo) all-reduce: same gradients as the gathered batch, identical
+    replicas, and BatchNorm statistics that are bit-identical to the serial run's (the reserve only touches kernels after the event:
+    data and weight gradients of the first encoder blocks)."""
+    from helpers import spin_lib
+    if mode != 'serial' and spin_lib() is None:
+        pytest.skip('hipcc is not available: the resident stand-in kernel cannot be built')
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), 'gloo', str(tmp_path), False, mode, True), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f'dp{r}.pt') for r in range(world)]
+    loss_ref, g_ref = _reference(big=True)
+    gscale = max(float(g.norm()) for g in g_ref.values())
+    for r in range(world):
+        assert abs(res[r]['loss'] - loss_ref) < 1e-5 * max(1.0, abs(loss_ref)), (r, res[r]['loss'], loss_ref)
+        for k, g in g_ref.items():
+            err = float((res[r]['grads'][k] - g).norm()) / max(float(g.norm()), 1e-4 * gscale)
+            assert err < 2e-3, (mode, r, k, err)
+    for k in g_ref:
+        assert torch.allclose(res[0]['grads'][k], res[1]['grads'][k], rtol=0, atol=1e-6 * gscale), k
+    if mode != 'serial':       # against the serial run of the same ranks: statistics bit for bit, gradients to rounding (other split of the weight-gradient sums)
+        sub = tmp_path / 'serial'
+        sub.mkdir()
+        mp.spawn(_worker, args=(world, _free_port(), 'gloo', str(sub), False, 'serial', True), nprocs=world, join=True)
+        for r in range(world):
+            ser = torch.load(sub / f'dp{r}.pt')
+            for k, b in ser['buffers'].items():
+                assert torch.equal(b, res[r]['buffers'][k]), (r, k)
+            for k, g in ser['grads'].items():
+                err = float((res[r]['grads'][k] - g).norm()) / max(float(g.norm()), 1e-4 * gscale)
+                assert err < 1e-5, (r, k, err)
