@@ -86,7 +86,8 @@ class GradSync:
 
     def _side_stream(self):
         if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=self._flat.device, priority=-1)   # collectives ahead of queued compute
+            import os
+            self._comm_stream = quiet_side_stream(self._flat.device, priority=int(os.environ.get('E3_DP_SIDE_PRIORITY', '-1')))   # collectives ahead of queued compute
         return self._comm_stream
 
     def bucket_event(self):
@@ -110,18 +111,22 @@ class GradSync:
             self._allreduce(b)
             return
         cur = torch.cuda.current_stream(flat.device)
+        if not self.overlap:
+            # serial: ONE collective over the whole buffer on the compute stream itself, behind the backward -- no stream of ours is involved
+            # (a wait parked on another hardware queue while the backward's ~100 small kernels run can cost ~50 us per kernel when the two
+            # queues share a command-processor pipe, see quiet_side_stream)
+            w = self._allreduce(flat, async_op=True)
+            if w is not None:
+                w.wait()
+            return
         side = self._side_stream()
         works = []
         with torch.cuda.stream(side):
-            if self.overlap:
-                side.wait_event(self._event)               # bucket A's gradients are final
-                works.append(self._allreduce(a, async_op=True))
-                side.wait_stream(cur)                      # the whole backward has been enqueued on `cur`
-                if b.numel():
-                    works.append(self._allreduce(b, async_op=True))
-            else:                                          # one collective over the whole buffer, behind the backward
-                side.wait_stream(cur)
-                works.append(self._allreduce(flat, async_op=True))
+            side.wait_event(self._event)                   # bucket A's gradients are final
+            works.append(self._allreduce(a, async_op=True))
+            side.wait_stream(cur)                          # the whole backward has been enqueued on `cur`
+            if b.numel():
+                works.append(self._allreduce(b, async_op=True))
         for w in works:                                    # stream-level wait: `cur` resumes after the collectives
             if w is not None:
                 w.wait()
@@ -156,6 +161,51 @@ class GradSync:
             return
         for t in list(self.model.parameters()) + list(self.model.buffers()):
             dist.broadcast(t.data, src=src, group=self.group)
+
+
+_REJECTED_STREAMS = []      # kept alive: a candidate that was found noisy keeps its hardware queue, so the next candidate gets another one
+
+
+def quiet_side_stream(device, priority=-1, tries=8, verbose=False):
+    """A side stream whose HARDWARE queue does not disturb the compute stream.
+
+    Measured on MI355X (tools/probe_foreign_waves.py, profiles/r04_dp_probe.md): HIP maps streams onto a few hardware queues in order of first
+    use; while a cross-stream wait (hipStreamWaitEvent) is parked on some of them, EVERY kernel of the compute stream takes ~50 us longer
+    (the cfg-2 backward: 12 -> 18 ms) -- which ones depends on how many streams the process used before (every fourth or so).  So the
+    candidate is tested the way GradSync uses it: a wait parked on it while a burst of tiny kernels runs on the current stream, timed against
+    the same burst alone; a noisy candidate is set aside (kept alive) and the next stream is tried."""
+    cur = torch.cuda.current_stream(device)
+    x = torch.zeros(256, device=device)
+    K = 48
+
+    def burst(side):
+        e0, e1, gate = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
+        torch.cuda._sleep(2_000_000)                 # ~1 ms on the compute stream: the host gets ahead, so the wait below is parked while the burst runs
+        e0.record(cur)
+        for _ in range(K):
+            x.add_(1.0)
+        e1.record(cur)
+        gate.record(cur)
+        if side is not None:
+            side.wait_event(gate)
+            with torch.cuda.stream(side):
+                x.mul_(1.0)
+        torch.cuda.synchronize(device)
+        return e0.elapsed_time(e1)
+
+    with torch.cuda.device(device):
+        burst(None)
+        base = min(burst(None) for _ in range(3))
+        cand = None
+        for _ in range(tries):
+            cand = torch.cuda.Stream(device=device, priority=priority)
+            t = min(burst(cand) for _ in range(2))
+            if verbose:
+                print(f'quiet_side_stream: candidate {cand.cuda_stream:#x}: burst {t:.3f} ms (alone {base:.3f} ms)')
+            if t < 2.0 * base + 0.05:
+                return cand
+            _REJECTED_STREAMS.append(cand)
+    return cand       # (none was quiet: the last one)
 
 
 def shard_batch(batch, rank, world):

@@ -889,13 +889,15 @@ m = UNet(1, 2, n_blocks=3, start_filts=8).cuda().train()
 x = torch.randn(2, 1, 16, 32, 32, device='cuda')
 out = m(x); out.backward(torch.ones_like(out) * 1e-3)
 ref = [p.grad.clone() for p in m.parameters()]
-sync = GradSync(m, bucket_after_down_block=2)
-for p in m.parameters(): p.grad = None
-m.load_state_dict(m.state_dict())
-out = m(x); out.backward(torch.ones_like(out) * 1e-3)
-torch.cuda.synchronize()
-assert sync._event is not None and sync._split > 0
-bad = [n for (n, p), r in zip(m.named_parameters(), ref) if not torch.equal(p.grad, r)]
+bad = []
+for overlap in (False, True):          # GradSync's default (one all-reduce behind the backward) and the overlapped bucket (no CU reserve: bit-identical weight gradients)
+    sync = GradSync(m, bucket_after_down_block=2, overlap=overlap, cu_reserve=0)
+    for p in m.parameters(): p.grad = None
+    m.load_state_dict(m.state_dict())
+    out = m(x); out.backward(torch.ones_like(out) * 1e-3)
+    torch.cuda.synchronize()
+    assert sync._split > 0 and (sync._event is not None) == overlap, (overlap, sync._event)
+    bad += [(overlap, n) for (n, p), r in zip(m.named_parameters(), ref) if not torch.equal(p.grad, r)]
 print('BAD', bad)
 dist.destroy_process_group()
 ''' % root)
@@ -911,6 +913,7 @@ dist.destroy_process_group()
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     res = json.loads(line)
     assert res['n_gpus'] == 1 and res['value'] > 1e6 and res['roofline']['achieved'] > 10
+    assert res['dp_mode'].startswith('serial'), res['dp_mode']         # bench.py says which data-parallel mode ran
 
 
 # ------------------------------------------------------------------------------------------------ device criterion

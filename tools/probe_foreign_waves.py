@@ -33,6 +33,8 @@ def run(label, overlap=None, reserve=0, blocks=0, iters=8):
     model = UNet(1, 2, n_blocks=4, start_filts=32).to(dev).train()
     if overlap is not None:
         sync = GradSync(model, overlap=overlap, cu_reserve=reserve)
+        if os.environ.get('PROBE_NO_CALIBRATION') is not None and overlap:       # A/B: the first stream, whatever queue it lands on
+            sync._comm_stream = torch.cuda.Stream(device=dev, priority=-1)
         calls = [0]
 
         def fake(tensor):       # runs on GradSync's side stream in place of dist.all_reduce
@@ -49,20 +51,39 @@ def run(label, overlap=None, reserve=0, blocks=0, iters=8):
     for _ in range(3):
         step()
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
-    for _ in range(iters):
+    evs[0].record()
+    for i in range(iters):
         step()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
-    print(f'{label:72s} {ms:7.2f} ms per step', flush=True)
+    per = [evs[i].elapsed_time(evs[i + 1]) for i in range(iters)]
+    ms1 = torch.cuda.memory_stats()
+    dm = {k: ms1.get(k, 0) - ms0.get(k, 0) for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries', 'num_sync_all_streams')}
+    print(f'{label:72s} {ms:7.2f} ms per step   (per step: {" ".join(f"{v:.1f}" for v in per)})  hipMalloc {dm["num_device_alloc"]} hipFree {dm["num_device_free"]} '
+          f'retries {dm["num_alloc_retries"]} reserved {ms1.get("reserved_bytes.all.current", 0) / 2**30:.1f} GiB', flush=True)
     return ms
 
 
+_keep = [torch.cuda.Stream(priority=-1) for _ in range(int(os.environ.get('PROBE_SKIP_STREAMS', '0')))]     # (which HARDWARE queue a side stream lands on depends on how many streams were USED before it)
+for _s in _keep:
+    with torch.cuda.stream(_s):
+        torch.zeros(16, device=dev)
+torch.cuda.synchronize()
+if len(sys.argv) > 3 and sys.argv[2] == 'serial':
+    run(f'serial, {int(sys.argv[3])} wg', overlap=False, blocks=int(sys.argv[3]), iters=3)
+    sys.exit(0)
+if len(sys.argv) > 3:        # one configuration (for a rocprofv3 --kernel-trace run): us reserve blocks
+    run(f'overlap, reserve {int(sys.argv[2])} CUs, {int(sys.argv[3])} wg', overlap=True, reserve=int(sys.argv[2]), blocks=int(sys.argv[3]), iters=3)
+    sys.exit(0)
 base = run('no GradSync')
 run('no GradSync (again)')
 for blocks in (1, 8, 16, 32):
     print(f'--- stand-in collective: {blocks} resident workgroup(s) for {US:.0f} us')
     run(f'serial, {blocks} wg', overlap=False, blocks=blocks)
-    for r in (0, 8, 16, 32):
+    for r in (0, 8, 16, 32) if os.environ.get('PROBE_REVERSE') is None else (32, 16, 8, 0):
         run(f'overlap, reserve {r:2d} CUs, {blocks} wg', overlap=True, reserve=r, blocks=blocks)
 print(f'(serial costs the collective\'s {US:.0f} us on top of {base:.2f} ms; overlap hides it if the kernels after the event keep their speed)')
