@@ -175,12 +175,12 @@ def quiet_side_stream(device, priority=-1, tries=8, verbose=False):
     candidate is tested the way GradSync uses it: a wait parked on it while a burst of tiny kernels runs on the current stream, timed against
     the same burst alone; a noisy candidate is set aside (kept alive) and the next stream is tried."""
     cur = torch.cuda.current_stream(device)
-    x = torch.zeros(256, device=device)
-    K = 48
+    x = torch.zeros(1 << 20, device=device)      # (kernels of ~1000 workgroups, ~5 us each, like the backward's elementwise passes)
+    K = 64
 
     def burst(side):
         e0, e1, gate = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
-        torch.cuda._sleep(2_000_000)                 # ~1 ms on the compute stream: the host gets ahead, so the wait below is parked while the burst runs
+        torch.cuda._sleep(6_000_000)                 # ~3 ms on the compute stream: the host gets ahead, so the wait below is parked while the burst runs
         e0.record(cur)
         for _ in range(K):
             x.add_(1.0)

@@ -61,8 +61,12 @@ def _worker(rank, world, port, backend, tmp, bf16=False, mode='overlap', big=Fal
         from elektronn3_amd.dataparallel import GradSync, shard_batch
         from elektronn3_amd.loss import CombinedCEDiceLoss
         model = _make(bf16=bf16).to(dev).train()
-        sync = GradSync(model, bucket_after_down_block=2, overlap=mode != 'serial', cu_reserve=16)
-        assert sync.overlap == (mode != 'serial') and sync.cu_reserve == (16 if sync.overlap else 0) and mode.split('+')[0] in sync.mode
+        if mode == 'env':          # GradSync's own defaults: serial, unless the environment says otherwise (E3_DP_OVERLAP / E3_DP_CU_RESERVE: tests/test_switches_gpu.py)
+            sync = GradSync(model, bucket_after_down_block=2)
+            assert sync.overlap == (os.environ.get('E3_DP_OVERLAP') is not None), sync.mode
+        else:
+            sync = GradSync(model, bucket_after_down_block=2, overlap=mode != 'serial', cu_reserve=16)
+            assert sync.overlap == (mode != 'serial') and sync.cu_reserve == (16 if sync.overlap else 0) and mode.split('+')[0] in sync.mode
         if mode == 'overlap+spin':
             from helpers import spin
             real = sync._allreduce
@@ -105,12 +109,12 @@ def _reference(bf16=False, big=False):
     return float(loss), {k: p.grad.float().cpu() for k, p in model.named_parameters()}
 
 
-@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
-def test_two_rank_train_step_equals_gathered_batch(backend, tmp_path):
+@pytest.mark.parametrize('backend,mode', [('gloo', 'overlap'), ('gloo', 'env'), ('nccl', 'overlap'), ('nccl', 'env')])
+def test_two_rank_train_step_equals_gathered_batch(backend, mode, tmp_path):
     if backend == 'nccl' and torch.cuda.device_count() < 2:
         pytest.skip('RCCL needs one GPU per rank; this box has one')
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), backend, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), backend, str(tmp_path), False, mode), nprocs=world, join=True)
     loss_ref, g_ref = _reference()
     res = [torch.load(tmp_path / f'dp{r}.pt') for r in range(world)]
     gscale = max(float(g.norm()) for g in g_ref.values())

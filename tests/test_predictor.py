@@ -397,7 +397,13 @@ def test_forward_roi_equals_the_whole_forward_inside_the_region(cfg, dtype):
     with torch.no_grad():
         for sm in (False, True):
             whole = m.forward_softmax(x) if sm else m(x)
-            # poison the scratch arena between the calls: a needed voxel that was skipped would read it
+            # poison the scratch arena between the calls (every byte 0xFF = NaN in fp32, bf16 and float16): a needed voxel whose producer
+            # was skipped would otherwise read the whole forward's stale-but-correct value of the same buffer and pass
+            from elektronn3_amd import unet as unet_mod
+            torch.cuda.synchronize()
+            assert unet_mod._scratch, 'the forward keeps its scratch arena cached per (device, stream)'
+            for buf in unet_mod._scratch.values():
+                buf.fill_(0xFF)
             part = m.forward_roi(x, cfg['roi'], softmax=sm)
             assert part.shape == whole.shape
             assert torch.equal(part[sl], whole[sl])

@@ -20,6 +20,11 @@ GROUPS = {
     'b16_alternatives': (dict(E3_B16_NO_SPLITK='1', E3_B16_UP_GENERIC='1', E3_B16_BD='2', E3_B16_TW='16', E3_B16_COT='1'), B16_TESTS),
     'b16_on_fp32_kernels_plain_predictor': (dict(E3_NO_BF16='1', E3_PREDICTOR_NO_PIPELINE='1'),
                                             ['tests/test_predictor.py', 'tests/test_bf16_gpu.py', '-k', 'predictor or fixture or autocast']),
+    # data-parallel: overlapped bucket with a CU reserve as GradSync's default; Predictor: the runtime's pageable copies; elementwise passes: non-temporal
+    # loads from 1 MB on  (E3_STAGE_BATCH is a compile-time constant of conv_mfma.hip, not an environment switch)
+    'dp_overlap_pageable_copies': (dict(E3_DP_OVERLAP='1', E3_DP_CU_RESERVE='8', E3_PREDICTOR_NO_PINNED='1', E3_EW_NT_MB='1'),
+                                   ['tests/test_dataparallel_gpu.py', 'tests/test_predictor.py', 'tests/test_unet_gpu.py', '-k',
+                                    'two_rank or pipelined or needed_region or in_place or train_step_matches_reference']),
 }
 
 

@@ -94,7 +94,17 @@ def test_train_step_matches_reference(case):
     # fixture).  So: every run must meet SURVEY 8c's bound (rel-L2 <= 1e-2 per tensor), and the implementation must be
     # exact up to such decisions: at least one of a few runs with inputs dithered far below fp32 resolution of the
     # problem (3e-7 relative) must meet the tight bound max(3 x reference fp32-vs-fp64 error, 1e-4) on every tensor.
+    # WHICH fixtures contain such a decision is known: tests/golden/tie_counts.json (make_golden.py ties) counts, in the reference's own fp64
+    # run of every fixture, the pre-activations within 2e-6 of zero and the pooling windows whose two largest inputs are closer than that.
+    # Where there is none (12 of the 26 fixtures) the tight bound must hold on the FIRST run, no dither, no retry.
+    import json
+    import os
+    ties = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'tie_counts.json')))['cases'][case]
     runs = [grad_errors(m)]
+    if ties['act_ties'] == 0 and ties['pool_ties'] == 0:
+        bad = {k: v for k, v in runs[0].items() if v[0] > max(3 * v[1], 1e-4)}
+        assert not bad, ('no near-tie decision in this fixture: the tight bound holds without retries', bad)
+        return
     torch.manual_seed(123)
     for _ in range(5):
         if all(eb <= max(3 * er, 1e-4) for eb, er in runs[-1].values()):

@@ -33,6 +33,9 @@ def run(label, overlap=None, reserve=0, blocks=0, iters=8):
     model = UNet(1, 2, n_blocks=4, start_filts=32).to(dev).train()
     if overlap is not None:
         sync = GradSync(model, overlap=overlap, cu_reserve=reserve)
+        if overlap and os.environ.get("PROBE_VERBOSE"):
+            from elektronn3_amd.dataparallel import quiet_side_stream
+            sync._flat = x; sync._comm_stream = quiet_side_stream(dev, verbose=True)
         if os.environ.get('PROBE_NO_CALIBRATION') is not None and overlap:       # A/B: the first stream, whatever queue it lands on
             sync._comm_stream = torch.cuda.Stream(device=dev, priority=-1)
         calls = [0]
