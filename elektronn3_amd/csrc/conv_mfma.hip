@@ -433,7 +433,7 @@ void conv_decomposition(ConvKind kind, int flags, int N, int D, int H, int W, in
 int conv_col_tile(int ncols) { return ncols >= 64 ? 64 : 32; }
 
 int conv_stats_parts(ConvKind kind, int flags, int N, int D, int H, int W, int sd, int Cin, int ncols) {
-    if (conv_use_wino(kind, flags, N, D, H, W, Cin, ncols)) return wino_stats_parts(N, D, H, W, ncols, flags);
+    if (conv_use_wino(kind, flags, N, D, H, W, Cin, ncols)) return wino_stats_parts(N, D, H, W, Cin, ncols, flags);
     if (conv_use_wino2d(kind, flags, N, D, H, W, Cin, ncols)) return wino2d_bricks(N, D, H, W);
     if (kind == CONV_POINT && (flags & CF_SCATTER_UP) && upconv_gemm_ok(flags, Cin, ncols / (sd * 4), ncols)) return upconv_stats_parts(N, D, H, W, sd, Cin, ncols / (sd * 4));
     int ks, nt; conv_decomposition(kind, flags, N, D, H, W, Cin, ncols, &ks, &nt);

@@ -867,13 +867,20 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
 //   dgrad == 0:  g[tap][n = co][k = ci] = w[co][ci][tap]           (w is (Cout, Cin, 27))
 //   dgrad == 1:  g[tap][n = ci][k = co] = w[co][ci][26 - tap]      (rows/cols swapped, taps flipped)
 // K = number of GEMM-K channels (multiple of 8), Ncols = real columns, NPad = padded to 32.
-__device__ __forceinline__ void wino_pack_item(const float* __restrict__ w, float* __restrict__ out, int Cin, int dgrad, int K, int Ncols, size_t i) {
+// layout 1 (conv_wino16.hip): the 256 floats of a (column tile, chunk, position) are [lane 64][ks 2][half 2] of v_mfma_f32_16x16x4_f32's A operand:
+//   lane = kk * 16 + m  ->  k = chunk * 8 + 2 kk + ks,  n = ntile * 32 + 8 (m >> 2) + 4 half + (m & 3)
+__device__ __forceinline__ void wino_pack_item(const float* __restrict__ w, float* __restrict__ out, int Cin, int dgrad, int K, int Ncols, size_t i, int layout = 0) {
     const int NCH = K >> 3;
     {
         const int e = i & 3, co = (i >> 2) & 31, hf = (i >> 7) & 1;
         const size_t r = i >> 8;
         const int ch = r % NCH, nt = r / NCH;
-        const int n = nt * 32 + co, k = ch * 8 + hf * 4 + e;
+        int n = nt * 32 + co, k = ch * 8 + hf * 4 + e;
+        if (layout == 1) {
+            const int ln = (int)((i >> 2) & 63), m = ln & 15, kq = ln >> 4, ks = e >> 1, half = e & 1;
+            n = nt * 32 + 8 * (m >> 2) + 4 * half + (m & 3);
+            k = ch * 8 + 2 * kq + ks;
+        }
         double g[27];
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
@@ -912,17 +919,17 @@ __device__ __forceinline__ void wino_pack_item(const float* __restrict__ w, floa
     }
 }
 
-__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int dgrad, int K, int Ncols, int NPad) {
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int dgrad, int K, int Ncols, int NPad, int layout) {
     const size_t total = (size_t)(NPad >> 5) * (K >> 3) * 256;     // one thread per (ntile, chunk, hf, co, e): all 64 positions
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-        wino_pack_item(w, out, Cin, dgrad, K, Ncols, i);
+        wino_pack_item(w, out, Cin, dgrad, K, Ncols, i, layout);
 }
 
 // all layers of a network in ONE launch (each layer alone is a 4..256-workgroup, latency-bound kernel: 25 of them cost
 // 0.19 ms per training step); workgroup -> job by binary search over the block prefix
 struct WinoPackMultiArgs {
     const float* w[WINO_PACK_MAX_JOBS]; float* out[WINO_PACK_MAX_JOBS];
-    int Cin[WINO_PACK_MAX_JOBS], K[WINO_PACK_MAX_JOBS], Ncols[WINO_PACK_MAX_JOBS], dgrad[WINO_PACK_MAX_JOBS];
+    int Cin[WINO_PACK_MAX_JOBS], K[WINO_PACK_MAX_JOBS], Ncols[WINO_PACK_MAX_JOBS], dgrad[WINO_PACK_MAX_JOBS], layout[WINO_PACK_MAX_JOBS];
     int bstart[WINO_PACK_MAX_JOBS + 1];
     int n;
 };
@@ -934,7 +941,7 @@ __global__ __launch_bounds__(256) void wino_pack_multi_kernel(const WinoPackMult
     const int K = a.K[j], Ncols = a.Ncols[j], NPad = (Ncols + 31) / 32 * 32;
     const size_t total = (size_t)(NPad >> 5) * (K >> 3) * 256;
     const size_t i = (size_t)(b - a.bstart[j]) * 256 + threadIdx.x;
-    if (i < total) wino_pack_item(a.w[j], a.out[j], a.Cin[j], a.dgrad[j], K, Ncols, i);
+    if (i < total) wino_pack_item(a.w[j], a.out[j], a.Cin[j], a.dgrad[j], K, Ncols, i, a.layout[j]);
 }
 
 }  // namespace
@@ -984,7 +991,7 @@ int launch_wino_pack_multi(const WinoPackJob* jobs, int njobs, hipStream_t s) {
                 w += (size_t)q.k0 * 27 * (q.dgrad ? q.Cin : 1);
                 K = q.kn;
             }
-            a.w[j] = w; a.out[j] = q.out; a.Cin[j] = q.Cin; a.K[j] = K; a.Ncols[j] = ncols; a.dgrad[j] = q.dgrad;
+            a.w[j] = w; a.out[j] = q.out; a.Cin[j] = q.Cin; a.K[j] = K; a.Ncols[j] = ncols; a.dgrad[j] = q.dgrad; a.layout[j] = q.layout;
             a.bstart[j] = b;
             b += (int)(((size_t)(NPad >> 5) * (K >> 3) * 256 + 255) / 256);
         }
@@ -995,12 +1002,12 @@ int launch_wino_pack_multi(const WinoPackJob* jobs, int njobs, hipStream_t s) {
     return E3_OK;
 }
 
-int launch_wino_pack(const float* w, float* out, int Cout, int Cin, int dgrad, hipStream_t s) {
+int launch_wino_pack(const float* w, float* out, int Cout, int Cin, int dgrad, hipStream_t s, int layout = 0) {
     const int K = dgrad ? Cout : Cin, ncols = dgrad ? Cin : Cout;
     const int NPad = (ncols + 31) / 32 * 32;
     const size_t total = (size_t)(NPad >> 5) * (K >> 3) * 256;
     const int grid = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(wino_pack_kernel, dim3(grid), dim3(256), 0, s, w, out, Cout, Cin, dgrad, K, ncols, NPad);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3(grid), dim3(256), 0, s, w, out, Cout, Cin, dgrad, K, ncols, NPad, layout);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
@@ -1015,7 +1022,7 @@ size_t conv_packed_floats(ConvKind kind, int K, int ncols) {
 
 int launch_pack_conv_auto(ConvKind kind, int dgrad, const float* w, float* out, int Cout, int Cin, int N, int D, int H, int W, int flags, hipStream_t s) {
     const int K = dgrad ? Cout : Cin, ncols = dgrad ? Cin : Cout;
-    if (conv_use_wino(kind, flags, N, D, H, W, K, ncols)) return launch_wino_pack(w, out, Cout, Cin, dgrad, s);
+    if (conv_use_wino(kind, flags, N, D, H, W, K, ncols)) return launch_wino_pack(w, out, Cout, Cin, dgrad, s, conv_wino_layout(flags, D, H, W, K, ncols, 1));
     if (conv_use_wino2d(kind, flags, N, D, H, W, K, ncols)) return launch_wino2d_pack(w, out, Cout, Cin, dgrad, s);
     const int T = kind == CONV_K3 ? 27 : 9, ct = conv_col_tile(ncols);
     return launch_pack_weights(dgrad ? PACK_CONV_DGRAD : PACK_CONV_FWD, w, out, Cout, Cin, T, cdiv(ncols, ct) * ct, s);
@@ -1033,13 +1040,15 @@ static bool wino_persistent(size_t nblk, int flags) {
 static bool wino_wgstats(size_t nblk, int ntiles, unsigned pgrid = 256u) {
     return pgrid == 256u && nblk >= 256 && nblk % 8 == 0 && (nblk / 8) % (size_t)ntiles == 0 && 32 % ntiles == 0;
 }
-int wino_stats_parts(int N, int D, int H, int W, int ncols, int flags) {
+int wino_stats_parts(int N, int D, int H, int W, int Cin, int ncols, int flags) {
+    if (conv_wino_layout(flags, D, H, W, Cin, ncols, 1) == 1) return wino16_stats_parts(N, D, H, W, ncols);
     const int bricks = wino_bricks(N, D, H, W), ntiles = (ncols + 31) / 32;
     const size_t nblk = (size_t)bricks * ntiles;
     return (wino_persistent(nblk, flags) && wino_wgstats(nblk, ntiles)) ? 256 / ntiles : bricks;
 }
 
 int launch_conv3_wino(ConvArgs a, hipStream_t s) {
+    if (conv_wino_layout(a.flags, a.D, a.H, a.W, a.Cin, a.Ncols, a.splitk) == 1) return launch_conv3_wino16(a, s);
     a.tilesD = cdiv(a.D, 4); a.tilesH = cdiv(a.H, 4); a.tilesW = cdiv(a.W, 16);
     a.o_td = a.o_th = a.o_tw = 0;
     if (a.box_hi[0] > 0) {      // needed region: the bricks that meet the box

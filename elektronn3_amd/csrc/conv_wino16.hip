@@ -1,0 +1,435 @@
+// 3x3x3 stride-1 convolution as Winograd F(2x2x2, 3x3x3) on the fp32 matrix cores, second decomposition: 16-tile bricks,
+// TWO workgroups per CU (forward and dgrad of torch.nn.Conv3d(k=3, padding=1) in elektronn3's conv3 blocks, unet.py:131-149).
+//
+// conv_wino.hip's kernels keep the 64 positions x (32 tiles x 32 channels) of a brick in 4 waves x 256 accumulator registers: one
+// wave per SIMD, every stall of that wave (LDS store issue, scattered halo loads, barriers, the whole epilogue) is idle matrix-pipe
+// time (measured: 0.58 of the fp32 MFMA peak, 6.0 k cycles per 4.1 k-cycle chunk, 5.4 k-cycle epilogue).  Here a brick is half as
+// large -- 2x2x4 tiles = 4x4x8 output voxels, 6x6x10 halo -- so a wave's 16 positions need 128 registers and a lane needs < 256:
+// two independent workgroups share a CU, and whatever one of them waits for, the other one's MFMAs fill (the planar kernels of
+// conv_wino2d.hip run that way).  What changes with the brick:
+//   * v_mfma_f32_16x16x4_f32 with the WEIGHTS as the A operand: D[co][tile], lane l holds tile l & 15 and the four consecutive
+//     channels 4 (l >> 4) .. + 3 of a 16-channel half -> the output leaves as 16-byte stores (channel order inside a 32-channel tile is
+//     permuted by the packer so that a lane's two halves are 8 consecutive channels, 4 lanes = one 128-byte voxel row);
+//   * the B operand is the transformed input: lane (tile, kk = l >> 4) feeds channels 2 kk, 2 kk + 1 of the 8-channel chunk (two
+//     k-steps), so the H / W passes of B^T d B run on float2 = one packed op each, and the lane that computes a value feeds it;
+//   * BatchNorm statistics: a lane owns 8 channels of one tile; it keeps a running (n, mean[8], M2[8]) over the workgroup's bricks in
+//     LDS (Chan merge of the brick's two values per channel) and the workgroup writes ONE record at the end (512 / ntiles per layer).
+// Same arithmetic as conv_wino.hip (same transform matrices, fp32 fmaf chains on the matrix cores) with a different summation order
+// over the input channels of a chunk; which convs take this kernel is decided by conv_wino_layout() per SAMPLE grid, so results do
+// not depend on the batch size.
+#include <type_traits>
+#include "kernels.h"
+
+#ifndef E3_W16_ABL
+#define E3_W16_ABL 0       // developer builds: bit mask of pieces left out (timing experiments, wrong results)
+#endif
+
+namespace {
+
+constexpr int Q_LW = 10;                          // (h, w) extent of the halo of a 4x4x8 brick (6 d-planes)
+constexpr int Q_CLASS = 16;                                 // slots per (zh, zw) parity class of a plane (3 x 5 = 15 used)
+constexpr int Q_PLANE = 4 * Q_CLASS * 8 + 8;                // floats of one D-transformed plane + 32 B skew: planes (td = 0 / 1, pd) sit 128 B mod 256 B apart
+constexpr int Q_BUF = 8 * Q_PLANE;                          // 8 planes (td, pd): 16.6 KB
+constexpr int Q_EX = 4 * 8 * 64 * 4;                        // epilogue exchange [pd][(oh, ow, half)][lane][4] floats (32 KB), aliases the staging buffers
+constexpr int Q_STAGE = 2 * Q_BUF > Q_EX ? 2 * Q_BUF : Q_EX;
+constexpr int Q_SCR = 4 * 32 * 3;                           // cross-wave merge of the statistics
+constexpr int Q_RUN = 17 * 256;                             // running statistics of every thread: n, mean[8], M2[8]
+constexpr int Q_LDS_FLOATS = Q_STAGE + Q_SCR + Q_RUN;       // 52 KB: two (three) workgroups per CU
+
+typedef float f32x2q __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4q;
+
+// float offset of halo voxel (zh, zw), 16-B half q inside a plane: parity classes keep the stride-2 tile origins contiguous; the
+// half is XOR-ed with bit 0 of zh/2 so that the 32 lanes of a ds_read_b64 group (16 tiles x 2 channel pairs) cover all 64 banks
+__device__ __forceinline__ int slot16(int zh, int zw, int q) {
+    const int slot = ((zh & 1) * 2 + (zw & 1)) * Q_CLASS + (zh >> 1) * 5 + (zw >> 1);
+    return slot * 8 + 4 * (q ^ ((zh >> 1) & 1));
+}
+
+template <bool AFF>
+__global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, const unsigned nblk, const int wgstats) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tl = lane & 15, kk = lane >> 4;
+    const int ttd = tl >> 3, tth = (tl >> 2) & 1, ttw = tl & 3;
+    const int NCH = a.Cin >> 3;
+    constexpr unsigned OOB = 0x80000000u;       // buffer offset beyond every descriptor below: loads return 0, stores are dropped
+    const int D = a.D, H = a.H, W = a.W, xl = a.x_ldc, yl = a.y_ldc;
+    const unsigned plane_xb = (unsigned)((size_t)H * W * xl * 4);
+
+    // ---- staging plan: thread -> (tile depth sd, halo column (zh, zw), 16-B half q): loads the 4 d-planes of that tile depth, stores
+    // the 4 D-transformed planes (threads 240..255 idle)
+    const bool col_on = tid < 240;
+    const int sd = tid >= 120 ? 1 : 0;
+    const int col = tid - 120 * sd;
+    const int cq = col & 1, czw = (col >> 1) % Q_LW, czh = (col >> 1) / Q_LW;
+    const int a_dst = col_on ? sd * 4 * Q_PLANE + slot16(czh, czw, cq) : 0;
+    const unsigned col_rel = (unsigned)(((czh * W + czw) * xl + 4 * cq) * 4) + (unsigned)sd * 2u * plane_xb;
+    const unsigned col_bits = col_on ? (1u << (6 + czh)) | (1u << (12 + czw)) : 0xffffffffu;     // (all-ones never matches: idle threads read nothing)
+    float m1 = -1.f;
+    asm volatile("" : "+s"(m1));     // opaque -1: a + m1*b becomes v_pk_fma_f32 (hipcc only packs fadd/ffma, never fsub)
+
+    // ---- read plan of lane (tile tl, channel pair kk): plane (ttd, pd = wave); window rows h = 0,1 have zh/2 = tth, rows 2,3 tth + 1
+    int rd[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) rd[hh] = (ttd * 4 + wave) * Q_PLANE + ((tth + hh) * 5 + ttw) * 8 + 2 * (kk ^ (2 * ((tth + hh) & 1)));
+    auto rd_imm = [](int h, int w) { return (((h & 1) * 2 + (w & 1)) * Q_CLASS + (w >> 1)) * 8; };
+
+    float* const buf0 = smem;
+    float* const buf1 = smem + Q_BUF;
+    float* const ex = smem;
+    float* const scr = smem + Q_STAGE;
+    float* const run = scr + Q_SCR + tid;
+    const bool do_stats = !AFF && a.stats != nullptr;
+    if (do_stats) {
+#pragma unroll
+        for (int k = 0; k < 17; ++k) run[k * 256] = 0.f;
+    }
+
+    // ---- the workgroup's bricks: XCD x owns a contiguous eighth of the logical (XCD-blocked) brick range, its workgroups walk it with
+    // stride gridDim / 8; a grid of nblk workgroups does one brick each
+    unsigned L, Lend, Lstep;
+    if (gridDim.x == nblk) { L = xcd_remap(blockIdx.x, nblk); Lend = L + 1; Lstep = 1; }
+    else {
+        const unsigned xcd = blockIdx.x & 7u, q = nblk >> 3, r = nblk & 7u;
+        const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        L = base + (blockIdx.x >> 3); Lend = base + q + (xcd < r ? 1u : 0u); Lstep = gridDim.x >> 3;
+    }
+    auto divmod = [](unsigned& x, int d) {
+        int r;
+        if ((d & (d - 1)) == 0) { r = (int)(x & (unsigned)(d - 1)); x >>= __builtin_ctz((unsigned)d); }
+        else { r = (int)(x % (unsigned)d); x /= (unsigned)d; }
+        return r;
+    };
+    auto range_mask = [](int lo, int n, int size) {      // bit z set: lo + z in [0, size), z in [0, n)
+        const int first = lo < 0 ? -lo : 0, last = size - lo < n ? size - lo : n;
+        return last > first ? ((1u << last) - 1u) & ~((1u << first) - 1u) : 0u;
+    };
+
+    for (; L < Lend; L += Lstep) {
+        unsigned Lq = L;
+        const int ntile = divmod(Lq, a.ntiles);
+        const int tw_ = divmod(Lq, a.tilesW);
+        const int th_ = divmod(Lq, a.tilesH);
+        const int td_ = divmod(Lq, a.tilesD); const int nb = (int)Lq;
+        const int d0 = (td_ + a.o_td) * 4, h0 = (th_ + a.o_th) * 4, w0 = (tw_ + a.o_tw) * 8;      // (o_*: first brick of the needed region)
+        const int n0 = ntile * 32;
+
+        // halo descriptor at voxel (d0 - 1, h0 - 1, w0 - 1) (possibly in front of the tensor: only valid lanes form addresses from it)
+        // and the brick's validity mask (6 d bits | 6 h bits | 10 w bits)
+        const long long org = ((long long)nb * D + (d0 - 1)) * ((long long)H * W * xl) + ((long long)(h0 - 1) * W + (w0 - 1)) * xl;
+        const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + org, 0, 0x7fffffff, 0x00020000);
+        const unsigned bmask = range_mask(d0 - 1, 6, D) | (range_mask(h0 - 1, 6, H) << 6) | (range_mask(w0 - 1, 10, W) << 12);
+        const bool col_ok = (bmask & col_bits) == col_bits;
+        const unsigned dm = (bmask >> (2 * sd)) & 15u;       // validity of the thread's 4 d-planes
+        // transformed weights: U[ntile][chunk][pos 64][lane 64][ks 2][half 2]; wave = pd owns positions 16 pd .. 16 pd + 15
+        const float* const b_base = a.wt + ((size_t)ntile * NCH * 64 + wave * 16) * 256;
+        const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b_base), 0, NCH * 64 * 1024, 0x00020000);
+        const __amdgpu_buffer_rsrc_t b_rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b_base), 0, 0, 0x00020000);     // size 0: reads nothing, returns zeros
+        const int b_voff = lane * 16;
+
+        f32x4 acc[16][2];
+        f32x4 xr[4], Bv[8];
+        auto issue_raw = [&](int cb) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                if (E3_W16_ABL & 1) continue;
+                unsigned voff = (col_ok && ((dm >> it) & 1u)) ? col_rel : OOB;
+                if (E3_W16_ABL & 64) {      // (an 8 KB window at the start of the tensor: L1 hits)
+                    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x10000, 0x00020000);
+                    xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, col_rel & 0x1ff0u, it * 16, 0)); continue;
+                }
+                xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, voff, (int)(it * plane_xb) + cb * 4, 0));
+            }
+        };
+        auto write_staged = [&](float* buf) {       // D pass of B^T: rows x0 - x2, x1 + x2, x2 - x1, x1 - x3 of the thread's 4 d-planes
+            if (col_on && !(E3_W16_ABL & 8)) {
+                *reinterpret_cast<f32x4*>(buf + 0 * Q_PLANE + a_dst) = xr[0] + m1 * xr[2];
+                *reinterpret_cast<f32x4*>(buf + 1 * Q_PLANE + a_dst) = xr[1] + xr[2];
+                *reinterpret_cast<f32x4*>(buf + 2 * Q_PLANE + a_dst) = xr[2] + m1 * xr[1];
+                *reinterpret_cast<f32x4*>(buf + 3 * Q_PLANE + a_dst) = xr[1] + m1 * xr[3];
+            }
+        };
+
+        // One 8-channel chunk: D-transformed halo in `cur`, the next chunk's goes to `nxt`.  Weights: a ring of 8 positions, position
+        // p + 8 (of the next chunk when it wraps) is requested as soon as the MFMAs of position p are issued.
+        auto chunk = [&](auto zero_tag, int c, const float* cur, float* nxt) {
+            constexpr bool ZERO = decltype(zero_tag)::value;
+            const bool lastc = c + 1 == NCH;
+            const int cn = lastc ? c : c + 1;
+            issue_raw(cn * 8);      // (the last chunk harmlessly re-reads itself: no branch in the loop body)
+            f32x2q t[4][4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) t[h][w] = *reinterpret_cast<const f32x2q*>(cur + rd[h >> 1] + rd_imm(h, w));
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const f32x2q u0 = t[0][w] + m1 * t[2][w], u1 = t[1][w] + t[2][w], u2 = t[2][w] + m1 * t[1][w], u3 = t[1][w] + m1 * t[3][w];
+                t[0][w] = u0; t[1][w] = u1; t[2][w] = u2; t[3][w] = u3;
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const f32x2q u0 = t[h][0] + m1 * t[h][2], u1 = t[h][1] + t[h][2], u2 = t[h][2] + m1 * t[h][1], u3 = t[h][1] + m1 * t[h][3];
+                t[h][0] = u0; t[h][1] = u1; t[h][2] = u2; t[h][3] = u3;
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) asm volatile("" : "+v"(t[h][w]));     // keep the transform packed and in front of the MFMA block
+            __builtin_amdgcn_sched_barrier(0);
+            const __amdgpu_buffer_rsrc_t b_nx = lastc ? b_rs0 : b_rs;
+#pragma unroll
+            for (int pp = 0; pp < 16; pp += 2) {        // two positions at a time: 4 independent accumulators in flight, then their ring slots are refilled
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int p = pp; p < pp + 2; ++p)
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {
+                            if (E3_W16_ABL & 32) continue;
+                            const float wv = Bv[p & 7][ks * 2 + hf], tv = t[p >> 2][p & 3][ks];
+                            if (ZERO && ks == 0) {
+                                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                                acc[p][hf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, tv, z, 0, 0, 0);
+                            } else
+                                acc[p][hf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, tv, acc[p][hf], 0, 0, 0);
+                        }
+#pragma unroll
+                for (int p = pp; p < pp + 2; ++p) {
+                    if (E3_W16_ABL & 2) continue;
+                    if (p < 8) Bv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_voff, (c * 64 + p + 8) * 1024, 0));
+                    else Bv[p - 8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_nx, b_voff, (cn * 64 + p - 8) * 1024, 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            write_staged(nxt);
+            __syncthreads();
+        };
+
+        issue_raw(0);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) Bv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_voff, p * 1024, 0));
+        write_staged(buf0);
+        __syncthreads();
+        chunk(std::true_type{}, 0, buf0, buf1);
+        for (int c = 1; c < NCH; c += 2) {
+            chunk(std::false_type{}, c, buf1, buf0);
+            if (c + 1 < NCH) chunk(std::false_type{}, c + 1, buf0, buf1);
+        }
+
+        // ---- epilogue.  acc[ph*4+pw][half][i]: position (pd = wave, ph, pw), tile tl, channel n0 + 8 kk + 4 half + i.
+        // per-channel constants first: they arrive during the output transform
+        const int nq = n0 + 8 * kk;
+        f32x4 bias[2], es[2], eh[2];
+        {
+            const int eN = a.Ncols;
+            const __amdgpu_buffer_rsrc_t c_rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? eN * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t c_rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.epi_scale), 0, AFF ? eN * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t c_rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.epi_shift), 0, AFF ? eN * 4 : 0, 0x00020000);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                bias[hf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c_rs0, (nq + 4 * hf) * 4, 0, 0));
+                if (AFF) {
+                    es[hf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c_rs1, (nq + 4 * hf) * 4, 0, 0));
+                    eh[hf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c_rs2, (nq + 4 * hf) * 4, 0, 0));
+                }
+            }
+        }
+        // A^T m A over (ph, pw) in registers (the barrier that ended the last chunk separates the staging buffers from their reuse as `ex`)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            f32x4 q[2][2];
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const f32x4 t0 = acc[ph * 4 + 0][hf] + acc[ph * 4 + 1][hf] + acc[ph * 4 + 2][hf];
+                const f32x4 t1 = acc[ph * 4 + 1][hf] + m1 * acc[ph * 4 + 2][hf] + m1 * acc[ph * 4 + 3][hf];
+                if (ph == 0) { q[0][0] = t0; q[0][1] = t1; }
+                else if (ph == 1) { q[0][0] += t0; q[0][1] += t1; q[1][0] = t0; q[1][1] = t1; }
+                else if (ph == 2) { q[0][0] += t0; q[0][1] += t1; q[1][0] += m1 * t0; q[1][1] += m1 * t1; }
+                else { q[1][0] += m1 * t0; q[1][1] += m1 * t1; }
+            }
+#pragma unroll
+            for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                for (int ow = 0; ow < 2; ++ow)
+                    *reinterpret_cast<f32x4*>(ex + ((wave * 8 + (oh * 2 + ow) * 2 + hf) * 64 + lane) * 4) = q[oh][ow];
+        }
+        __syncthreads();
+        // wave w now owns output offset (oh, ow) = (w >> 1, w & 1) of every tile and sums the pd axis: od = 0, 1
+        const int oh = wave >> 1, ow = wave & 1;
+        f32x4 y[2][2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            f32x4 m[4];
+#pragma unroll
+            for (int pd = 0; pd < 4; ++pd) m[pd] = *reinterpret_cast<const f32x4*>(ex + ((pd * 8 + wave * 2 + hf) * 64 + lane) * 4);
+            y[0][hf] = m[0] + m[1] + m[2] + bias[hf];
+            y[1][hf] = m[1] + m1 * m[2] + m1 * m[3] + bias[hf];
+            if (AFF) {
+#pragma unroll
+                for (int od = 0; od < 2; ++od)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[od][hf][e] = fmaxf(__builtin_fmaf(y[od][hf][e], es[hf][e], eh[hf][e]), 0.f);
+            }
+        }
+        // voxel (d0 + 2 ttd + od, h0 + 2 tth + oh, w0 + 2 ttw + ow), channels nq + 4 half .. + 3: 16-byte stores
+        const size_t plane_y = (size_t)H * W * yl;
+        const size_t yrem = (size_t)(D - d0) * plane_y * 4;
+        const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(
+            a.y + ((size_t)nb * D + d0) * plane_y, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
+        const int gh = h0 + 2 * tth + oh, gw = w0 + 2 * ttw + ow, gd = d0 + 2 * ttd;
+        const unsigned y_voff = (unsigned)((((2 * ttd * H + gh) * W + gw) * yl + nq) * 4);
+        const bool vox_ok = gh < H && gw < W;
+        const bool ok0 = vox_ok && gd < D, ok1 = vox_ok && gd + 1 < D;
+        const int od_off = (int)(plane_y * 4);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const bool cok = nq + 4 * hf < a.Ncols;
+            if (E3_W16_ABL & 4) continue;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4q, y[0][hf]), y_rs, (ok0 && cok) ? y_voff + 16 * hf : OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4q, y[1][hf]), y_rs, (ok1 && cok) ? y_voff + 16 * hf : OOB, od_off, 0);
+        }
+        if (do_stats) {
+            // running record of this lane's 8 channels: Chan merge of the brick's (up to) two values per channel, approximate reciprocal
+            // (its error is far below the rounding of the sums)
+            const float rn = run[0];
+            const float cb = (ok0 ? 1.f : 0.f) + (ok1 ? 1.f : 0.f);
+            const float nn = rn + cb;
+            const float rf = cb * __builtin_amdgcn_rcpf(fmaxf(nn, 1.f));
+            const float rc = cb == 2.f ? 0.5f : 1.f;
+            const float rnf = rn * rf;
+            const bool both = ok0 && ok1;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ch = hf * 4 + e;
+                    const float v0 = ok0 ? y[0][hf][e] : 0.f, v1 = ok1 ? y[1][hf][e] : 0.f;
+                    const float bm = (v0 + v1) * rc;
+                    const float dd = both ? v0 - v1 : 0.f;
+                    const float rmean = run[(1 + ch) * 256], rm2 = run[(9 + ch) * 256];
+                    const float dl = bm - rmean;
+                    run[(1 + ch) * 256] = rmean + dl * rf;
+                    run[(9 + ch) * 256] = rm2 + 0.5f * dd * dd + dl * dl * rnf;
+                }
+            run[0] = nn;
+            const bool flush_now = !wgstats || L + Lstep >= Lend;
+            if (flush_now) {       // (uniform) merge the lanes of a channel (16 tiles, then the 4 waves) in a fixed order, one record
+                float fn = run[0], fm[8], fs[8];
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) { fm[ch] = run[(1 + ch) * 256]; fs[ch] = run[(9 + ch) * 256]; }
+#pragma unroll
+                for (int sft = 1; sft < 16; sft <<= 1) {
+                    const float n2 = __shfl_xor(fn, sft);
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) {
+                        float na = fn;
+                        welford_merge(na, fm[ch], fs[ch], n2, __shfl_xor(fm[ch], sft), __shfl_xor(fs[ch], sft));
+                    }
+                    fn += n2;
+                }
+                if (tl == 0) {
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) {
+                        float* sc_ = scr + (wave * 32 + 8 * kk + ch) * 3;
+                        sc_[0] = fn; sc_[1] = fm[ch]; sc_[2] = fs[ch];
+                    }
+                }
+                __syncthreads();
+                if (tid < 32 && n0 + tid < a.Ncols) {
+                    float c0 = 0.f, me = 0.f, mm = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float* sc_ = scr + (w * 32 + tid) * 3;
+                        welford_merge(c0, me, mm, sc_[0], sc_[1], sc_[2]);
+                    }
+                    const size_t row = wgstats ? (size_t)((blockIdx.x & 7u) * ((gridDim.x >> 3) / (unsigned)a.ntiles) + (blockIdx.x >> 3) / (unsigned)a.ntiles)
+                                               : (size_t)(((nb * a.tilesD + td_) * a.tilesH + th_) * a.tilesW + tw_);
+                    float* o = a.stats + (row * a.Cout + n0 + tid) * 3;
+                    o[0] = c0; o[1] = me; o[2] = mm;
+                }
+                if (!wgstats) {
+#pragma unroll
+                    for (int k = 0; k < 17; ++k) run[k * 256] = 0.f;
+                }
+            }
+        }
+        __syncthreads();        // `ex` (and the merge scratch) are the next brick's staging buffers
+    }
+}
+
+}  // namespace
+
+// ---- host side
+int wino16_bricks(int N, int D, int H, int W) { return N * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 8); }
+
+static bool wino16_wgstats(size_t nblk, int ntiles, unsigned grid) {
+    return grid == 512u && nblk > 512 && nblk % 8 == 0 && (nblk / 8) % (size_t)ntiles == 0 && 64 % ntiles == 0;
+}
+
+// Which decomposition a Winograd 3x3x3 launch takes: 0 = 32-tile bricks (conv_wino.hip), 1 = 16-tile bricks, two workgroups per CU
+// (this file).  THE predicate: the weight packers (the two kernels want different layouts), the statistics sizing and the launcher all ask
+// it.  Decided on the grid of ONE sample (like conv_use_wino) so that the arithmetic does not depend on the batch size; a split-K launch,
+// the timing flag and column counts that rule out 16-byte stores keep the first kernels.
+int conv_wino_layout(int flags, int D, int H, int W, int K, int ncols, int splitk) {
+    static const bool enabled = getenv("E3_NO_WINO16") == nullptr;
+    static const size_t minblk = getenv("E3_WINO16_MIN") ? (size_t)atol(getenv("E3_WINO16_MIN")) : 512;
+    if (!enabled || splitk > 1 || (flags & 1024) || (ncols & 3) || (K & 7)) return 0;
+    const size_t nblk1 = (size_t)wino16_bricks(1, D, H, W) * ((ncols + 31) / 32);
+    return nblk1 >= minblk ? 1 : 0;
+}
+
+int wino16_stats_parts(int N, int D, int H, int W, int ncols) {
+    const int bricks = wino16_bricks(N, D, H, W), ntiles = (ncols + 31) / 32;
+    const size_t nblk = (size_t)bricks * ntiles;
+    return wino16_wgstats(nblk, ntiles, nblk >= 512 ? 512u : (unsigned)nblk) ? 512 / ntiles : bricks;
+}
+
+int launch_conv3_wino16(ConvArgs a, hipStream_t s) {
+    a.tilesD = cdiv(a.D, 4); a.tilesH = cdiv(a.H, 4); a.tilesW = cdiv(a.W, 8);
+    a.o_td = a.o_th = a.o_tw = 0;
+    if (a.box_hi[0] > 0) {      // needed region: the bricks that meet the box
+        E3_REQUIRE(!a.stats, E3_ERR_INVALID, "conv with a needed region: no statistics");
+        const int dims[3] = {a.D, a.H, a.W}, edge[3] = {4, 4, 8};
+        int o[3], n[3];
+        for (int i = 0; i < 3; ++i) {
+            const int lo = a.box_lo[i] < 0 ? 0 : a.box_lo[i], hi = a.box_hi[i] > dims[i] ? dims[i] : a.box_hi[i];
+            E3_REQUIRE(hi > lo, E3_ERR_INVALID, "conv with a needed region: empty box");
+            o[i] = lo / edge[i]; n[i] = cdiv(hi, edge[i]) - o[i];
+        }
+        a.o_td = o[0]; a.o_th = o[1]; a.o_tw = o[2];
+        a.tilesD = n[0]; a.tilesH = n[1]; a.tilesW = n[2];
+    }
+    a.NPad = (a.Ncols + 31) / 32 * 32;
+    a.ntiles = a.NPad / 32;
+    if (a.stats) a.cu_reserve = 0;      // (the statistic records are sized for the full grid; only data gradients run beside a collective)
+    const size_t nblk = (size_t)a.N * a.tilesD * a.tilesH * a.tilesW * a.ntiles;
+    E3_REQUIRE(nblk > 0 && nblk < (1u << 31), E3_ERR_INVALID, "conv grid out of range");
+    E3_REQUIRE((size_t)6 * a.H * a.W * (size_t)(a.x_ldc > a.y_ldc ? a.x_ldc : a.y_ldc) * 4 < 0x7fffffffu, E3_ERR_UNSUPPORTED,
+               "six d-planes of the conv input/output view exceed 2^31 bytes (32-bit buffer offsets)");
+    E3_REQUIRE((a.y_ldc & 3) == 0 && (a.x_ldc & 3) == 0 && ((uintptr_t)a.y & 15) == 0 && ((uintptr_t)a.x & 15) == 0 && (a.Ncols & 3) == 0, E3_ERR_INVALID,
+               "Winograd conv (16-tile bricks): views must be 16-byte aligned with channel counts that are multiples of 4");
+    E3_REQUIRE(!(a.epi_scale && a.stats), E3_ERR_INVALID, "Winograd conv: statistics and the folded epilogue exclude each other");
+    E3_REQUIRE(a.splitk <= 1 && !a.pro_scale, E3_ERR_INVALID, "Winograd conv (16-tile bricks): no split-K, no fused prologue");
+    constexpr int lds = Q_LDS_FLOATS * 4;
+    static bool attr = false;
+    if (!attr) {
+        E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    // two workgroups per CU (cu_reserve > 0, a multiple of 8: that many CUs are left to the resident workgroups of a collective on a side stream)
+    const unsigned full = 2u * (256u - (unsigned)((a.cu_reserve < 0 ? 0 : (a.cu_reserve > 128 ? 128 : a.cu_reserve)) & ~7));
+    static const unsigned gover = getenv("E3_W16_GRID") ? (unsigned)atoi(getenv("E3_W16_GRID")) : 0u;      // (timing experiments)
+    const unsigned gcap = (gover && !a.stats) ? gover : full;
+    const unsigned grid = nblk >= gcap ? gcap : (unsigned)nblk;
+    const int wgstats = (a.stats && wino16_wgstats(nblk, a.ntiles, grid)) ? 1 : 0;
+    if (a.epi_scale) hipLaunchKernelGGL(conv3_wino16_kernel<true>, dim3(grid), dim3(256), lds, s, a, (unsigned)nblk, wgstats);
+    else hipLaunchKernelGGL(conv3_wino16_kernel<false>, dim3(grid), dim3(256), lds, s, a, (unsigned)nblk, wgstats);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}

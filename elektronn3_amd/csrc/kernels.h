@@ -61,7 +61,12 @@ int launch_conv3_v3(ConvKind kind, ConvArgs a, int nt, hipStream_t s);   // conv
 // statistics sizing and launch_conv_mfma() all ask it, with K = GEMM-K channels and ncols = GEMM columns.
 bool conv_use_wino(ConvKind kind, int flags, int N, int D, int H, int W, int K, int ncols);
 constexpr int WINO_PACK_MAX_JOBS = 40;
-struct WinoPackJob { const float* w; float* out; int Cout, Cin, dgrad; int k0 = 0, kn = 0; };   // kn > 0: only the GEMM-K channels [k0, k0 + kn)
+struct WinoPackJob { const float* w; float* out; int Cout, Cin, dgrad; int k0 = 0, kn = 0; int layout = 0; };   // kn > 0: only the GEMM-K channels [k0, k0 + kn); layout: conv_wino_layout() of the launch that will read them
+// Winograd decomposition of a 3x3x3 launch (conv_wino16.hip): 0 = 32-tile bricks (conv_wino.hip), 1 = 16-tile bricks with two workgroups per CU.
+// THE predicate for the packed-weight layout, the statistics sizing and the launcher (K = GEMM-K channels, ncols = GEMM columns; per-sample grid).
+int conv_wino_layout(int flags, int D, int H, int W, int K, int ncols, int splitk);
+int wino16_stats_parts(int N, int D, int H, int W, int ncols);
+int launch_conv3_wino16(ConvArgs a, hipStream_t s);
 // split-K factor (1, 2 or 4) of a Winograd 3x3x3 conv whose bricks cannot fill the chip (decided per sample, like conv_use_wino)
 int conv_wino_splitk(int D, int H, int W, int K, int ncols);   // (0 if the conv does not use the Winograd kernel even with the splits)
 // dst[u][c] (ldc) = sum_s src[s * src_stride + u * C + c] (+ bias[c]); stats (optional): crop_stats_parts(units, C) records per channel
@@ -69,7 +74,7 @@ int launch_splitk_reduce(const float* src, int nsrc, size_t src_stride, const fl
                          float* stats, hipStream_t s);
 int launch_wino_pack_multi(const WinoPackJob* jobs, int njobs, hipStream_t s);   // the Winograd weight transforms of many layers in one launch
 int wino_bricks(int N, int D, int H, int W);
-int wino_stats_parts(int N, int D, int H, int W, int ncols, int flags);   // statistic records a Winograd launch writes (per brick, or per workgroup of the persistent kernel)
+int wino_stats_parts(int N, int D, int H, int W, int Cin, int ncols, int flags);   // statistic records a Winograd launch writes (per brick, or per workgroup of the persistent kernel)
 int launch_conv3_wino(ConvArgs a, hipStream_t s);
 // planar 1x3x3: Winograd F(2x2,3x3) (conv_wino2d.hip), same contract
 bool conv_use_wino2d(ConvKind kind, int flags, int N, int D, int H, int W, int K, int ncols);

@@ -703,7 +703,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             if (!B.wpk_f[k]) continue;
             const ConvUnit& u = plan->units[k];
             const int S = fwd_split(k);
-            if (S == 1) { jobs.push_back({P(u.p_w), B.wpk_f[k], u.cout, u.cin, 0}); continue; }
+            if (S == 1) { jobs.push_back({P(u.p_w), B.wpk_f[k], u.cout, u.cin, 0, 0, 0, conv_wino_layout(0, ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cin, u.cout, 1)}); continue; }
             for (int sp = 0; sp < S; ++sp)     // one packed weight set per share of the input channels
                 jobs.push_back({P(u.p_w), B.wpk_f[k] + sp * conv_packed_floats(CONV_K3, u.cin / S, u.cout), u.cout, u.cin, 0, sp * (u.cin / S), u.cin / S});
         }
@@ -1026,7 +1026,7 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
             if (!(B.wpk_d[k] && (k > 0 || dx))) continue;
             const ConvUnit& u = plan->units[k];
             const int S = bwd_split(k);
-            if (S == 1) { jobs.push_back({P(u.p_w), B.wpk_d[k], u.cout, u.cin, 1}); continue; }
+            if (S == 1) { jobs.push_back({P(u.p_w), B.wpk_d[k], u.cout, u.cin, 1, 0, 0, conv_wino_layout(0, ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cout, u.cin, 1)}); continue; }
             for (int sp = 0; sp < S; ++sp)     // dgrad: the GEMM-K channels are the conv's OUTPUT channels
                 jobs.push_back({P(u.p_w), B.wpk_d[k] + sp * conv_packed_floats(CONV_K3, u.cout / S, u.cin), u.cout, u.cin, 1, sp * (u.cout / S), u.cout / S});
         }
