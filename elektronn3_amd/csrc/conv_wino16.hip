@@ -20,31 +20,33 @@
 #include <type_traits>
 #include "kernels.h"
 
+#ifndef E3_W16_PRIO
+#define E3_W16_PRIO 3       // s_setprio of the VALU phases (transform, epilogue) over the other workgroup's MFMA phase
+#endif
+#ifndef E3_W16_ROWS
+#define E3_W16_ROWS 2       // window rows read from LDS per round (1: 16, 2: 32 registers of raw values in flight)
+#endif
 #ifndef E3_W16_ABL
 #define E3_W16_ABL 0       // developer builds: bit mask of pieces left out (timing experiments, wrong results)
 #endif
 
 namespace {
 
-constexpr int Q_LW = 10;                          // (h, w) extent of the halo of a 4x4x8 brick (6 d-planes)
 constexpr int Q_CLASS = 16;                                 // slots per (zh, zw) parity class of a plane (3 x 5 = 15 used)
-constexpr int Q_PLANE = 4 * Q_CLASS * 8 + 8;                // floats of one D-transformed plane + 32 B skew: planes (td = 0 / 1, pd) sit 128 B mod 256 B apart
-constexpr int Q_BUF = 8 * Q_PLANE;                          // 8 planes (td, pd): 16.6 KB
-constexpr int Q_EX = 4 * 8 * 64 * 4;                        // epilogue exchange [pd][(oh, ow, half)][lane][4] floats (32 KB), aliases the staging buffers
-constexpr int Q_STAGE = 2 * Q_BUF > Q_EX ? 2 * Q_BUF : Q_EX;
+constexpr int Q_RPLANE = 4 * Q_CLASS * 8 + 16;              // floats of one raw d-plane of the halo + 64 B skew: the planes of tile depth 0 / 1 (two planes apart) sit 128 B mod 256 B apart
+constexpr int Q_RBUF = 6 * Q_RPLANE;                        // 6 raw planes: 12.4 KB per stage buffer
+constexpr int Q_EX = 4 * 8 * 64 * 4;                        // epilogue exchange [pd][(oh, ow, half)][lane][4] floats (32 KB)
 constexpr int Q_SCR = 4 * 32 * 3;                           // cross-wave merge of the statistics
 constexpr int Q_RUN = 17 * 256;                             // running statistics of every thread: n, mean[8], M2[8]
-constexpr int Q_LDS_FLOATS = Q_STAGE + Q_SCR + Q_RUN;       // 52 KB: two (three) workgroups per CU
+constexpr int Q_LDS_FLOATS = 2 * Q_RBUF + Q_EX + Q_SCR + Q_RUN;   // 75 KB: two workgroups per CU
 
 typedef float f32x2q __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4q;
+typedef __attribute__((address_space(3))) void* lds_ptr_q;
 
-// float offset of halo voxel (zh, zw), 16-B half q inside a plane: parity classes keep the stride-2 tile origins contiguous; the
-// half is XOR-ed with bit 0 of zh/2 so that the 32 lanes of a ds_read_b64 group (16 tiles x 2 channel pairs) cover all 64 banks
-__device__ __forceinline__ int slot16(int zh, int zw, int q) {
-    const int slot = ((zh & 1) * 2 + (zw & 1)) * Q_CLASS + (zh >> 1) * 5 + (zw >> 1);
-    return slot * 8 + 4 * (q ^ ((zh >> 1) & 1));
-}
+// Layout of a raw plane: halo voxel (zh, zw) -> slot ((zh & 1) * 2 + (zw & 1)) * Q_CLASS + (zh >> 1) * 5 + (zw >> 1) of 32 bytes (parity classes keep
+// the stride-2 tile origins contiguous); its 16-byte half q sits at q ^ ((zh >> 1) & 1), so that the 32 lanes of a ds_read_b64 group (16 tiles x 2
+// channel pairs) cover all 64 banks.
 
 template <bool AFF>
 __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, const unsigned nblk, const int wgstats) {
@@ -56,33 +58,54 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
     const int ttd = tl >> 3, tth = (tl >> 2) & 1, ttw = tl & 3;
     const int NCH = a.Cin >> 3;
     constexpr unsigned OOB = 0x80000000u;       // buffer offset beyond every descriptor below: loads return 0, stores are dropped
-    const int D = a.D, H = a.H, W = a.W, xl = a.x_ldc, yl = a.y_ldc;
+    // arguments that only the per-brick set-up and the epilogue need are re-read from the kernarg segment there (scalar loads) instead of
+    // occupying SGPRs across the chunk loop (hipcc spilled ~70 scalars into vector lanes)
+    typedef const __attribute__((address_space(4))) ConvArgs* KArgs;
+    auto KA = []() -> KArgs { KArgs q = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(q)); return q; };
+    const int D = a.D, H = a.H, W = a.W, xl = a.x_ldc;
     const unsigned plane_xb = (unsigned)((size_t)H * W * xl * 4);
 
-    // ---- staging plan: thread -> (tile depth sd, halo column (zh, zw), 16-B half q): loads the 4 d-planes of that tile depth, stores
-    // the 4 D-transformed planes (threads 240..255 idle)
-    const bool col_on = tid < 240;
-    const int sd = tid >= 120 ? 1 : 0;
-    const int col = tid - 120 * sd;
-    const int cq = col & 1, czw = (col >> 1) % Q_LW, czh = (col >> 1) / Q_LW;
-    const int a_dst = col_on ? sd * 4 * Q_PLANE + slot16(czh, czw, cq) : 0;
-    const unsigned col_rel = (unsigned)(((czh * W + czw) * xl + 4 * cq) * 4) + (unsigned)sd * 2u * plane_xb;
-    const unsigned col_bits = col_on ? (1u << (6 + czh)) | (1u << (12 + czw)) : 0xffffffffu;     // (all-ones never matches: idle threads read nothing)
+    // ---- staging by LDS-DMA (buffer_load_dwordx4 ... lds: 1 KB per wave-instruction, lane i lands at base + 16 i): a raw d-plane of the
+    // halo is two such pieces, a chunk is 12; wave w issues pieces w, w + 4, w + 8 = half hp = w & 1 of the planes w >> 1, 2 + (w >> 1),
+    // 4 + (w >> 1).  The layout of a plane (parity classes, XOR-ed halves) is produced on the SOURCE side: lane i of half hp asks for the
+    // 16 bytes that belong at piece g = 64 hp + i.
+    const int hp = wave & 1;
+    unsigned col_rel, col_bits;
+    {
+        const int g = hp * 64 + lane, slot = g >> 1, qd = g & 1;
+        const int cls = slot >> 4, sic = slot & 15;
+        const int zhh = sic / 5, zwh = sic % 5;
+        const int zh = 2 * zhh + (cls >> 1), zw = 2 * zwh + (cls & 1), q = qd ^ (zhh & 1);
+        const bool used = sic < 15;
+        col_rel = (unsigned)(((zh * W + zw) * xl + 4 * q) * 4);
+        col_bits = used ? (1u << (6 + zh)) | (1u << (12 + zw)) : 0xffffffffu;     // (all-ones never matches: the unused slots get zeros)
+    }
     float m1 = -1.f;
     asm volatile("" : "+s"(m1));     // opaque -1: a + m1*b becomes v_pk_fma_f32 (hipcc only packs fadd/ffma, never fsub)
 
-    // ---- read plan of lane (tile tl, channel pair kk): plane (ttd, pd = wave); window rows h = 0,1 have zh/2 = tth, rows 2,3 tth + 1
-    int rd[2];
+    // ---- read plan of lane (tile tl, channel pair kk).  The D pass of B^T is done while reading: row pd = wave of the tile depth's 4
+    // raw planes is  x[A] + sgn x[B]  with (A, B, sgn) = (0, 2, -), (1, 2, +), (2, 1, -), (1, 3, -).  Window rows h = 0, 1 have zh/2 = tth,
+    // rows 2, 3 have tth + 1 (the XOR of the 16-byte half follows).
+    const int pA = wave == 0 ? 0 : (wave == 2 ? 2 : 1), pB = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float dsg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(wave == 1 ? 0x3f800000 : (int)0xbf800000));
+    int rdA[2], rdB[2];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) rd[hh] = (ttd * 4 + wave) * Q_PLANE + ((tth + hh) * 5 + ttw) * 8 + 2 * (kk ^ (2 * ((tth + hh) & 1)));
+    for (int hh = 0; hh < 2; ++hh) {
+        const int r = ((tth + hh) * 5 + ttw) * 8 + 2 * (kk ^ (2 * ((tth + hh) & 1)));
+        rdA[hh] = (2 * ttd + pA) * Q_RPLANE + r; rdB[hh] = (2 * ttd + pB) * Q_RPLANE + r;
+    }
     auto rd_imm = [](int h, int w) { return (((h & 1) * 2 + (w & 1)) * Q_CLASS + (w >> 1)) * 8; };
 
-    float* const buf0 = smem;
-    float* const buf1 = smem + Q_BUF;
-    float* const ex = smem;
-    float* const scr = smem + Q_STAGE;
+    float* cur = smem;
+    float* nxt = smem + Q_RBUF;
+    float* const ex = smem + 2 * Q_RBUF;
+    float* const scr = ex + Q_EX;
     float* const run = scr + Q_SCR + tid;
+#ifdef E3_W16_TIMING
+    const bool do_stats = false;
+#else
     const bool do_stats = !AFF && a.stats != nullptr;
+#endif
     if (do_stats) {
 #pragma unroll
         for (int k = 0; k < 17; ++k) run[k * 256] = 0.f;
@@ -107,64 +130,87 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
         const int first = lo < 0 ? -lo : 0, last = size - lo < n ? size - lo : n;
         return last > first ? ((1u << last) - 1u) & ~((1u << first) - 1u) : 0u;
     };
-
-    for (; L < Lend; L += Lstep) {
-        unsigned Lq = L;
-        const int ntile = divmod(Lq, a.ntiles);
-        const int tw_ = divmod(Lq, a.tilesW);
-        const int th_ = divmod(Lq, a.tilesH);
-        const int td_ = divmod(Lq, a.tilesD); const int nb = (int)Lq;
-        const int d0 = (td_ + a.o_td) * 4, h0 = (th_ + a.o_th) * 4, w0 = (tw_ + a.o_tw) * 8;      // (o_*: first brick of the needed region)
-        const int n0 = ntile * 32;
-
-        // halo descriptor at voxel (d0 - 1, h0 - 1, w0 - 1) (possibly in front of the tensor: only valid lanes form addresses from it)
-        // and the brick's validity mask (6 d bits | 6 h bits | 10 w bits)
-        const long long org = ((long long)nb * D + (d0 - 1)) * ((long long)H * W * xl) + ((long long)(h0 - 1) * W + (w0 - 1)) * xl;
-        const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + org, 0, 0x7fffffff, 0x00020000);
-        const unsigned bmask = range_mask(d0 - 1, 6, D) | (range_mask(h0 - 1, 6, H) << 6) | (range_mask(w0 - 1, 10, W) << 12);
-        const bool col_ok = (bmask & col_bits) == col_bits;
-        const unsigned dm = (bmask >> (2 * sd)) & 15u;       // validity of the thread's 4 d-planes
-        // transformed weights: U[ntile][chunk][pos 64][lane 64][ks 2][half 2]; wave = pd owns positions 16 pd .. 16 pd + 15
-        const float* const b_base = a.wt + ((size_t)ntile * NCH * 64 + wave * 16) * 256;
-        const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b_base), 0, NCH * 64 * 1024, 0x00020000);
-        const __amdgpu_buffer_rsrc_t b_rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b_base), 0, 0, 0x00020000);     // size 0: reads nothing, returns zeros
-        const int b_voff = lane * 16;
-
-        f32x4 acc[16][2];
-        f32x4 xr[4], Bv[8];
-        auto issue_raw = [&](int cb) {
+    // a brick: coordinates, halo descriptor at voxel (d0 - 1, h0 - 1, w0 - 1) (possibly in front of the tensor: only valid lanes form
+    // addresses from it), validity mask (6 d bits | 6 h bits | 10 w bits), the wave's transformed weights
+    //   U[ntile][chunk][pos 64][lane 64][ks 2][half 2]; wave = pd owns positions 16 pd .. 16 pd + 15
+    // (plain scalars, no struct: selecting between two structs' fields made hipcc keep them in scratch memory)
+#define E3_BRICK_VARS(X) int X##d0, X##h0, X##w0, X##nb, X##n0, X##row; unsigned X##mask; const float* X##xorg; const float* X##wbase
+#define E3_DECODE(X, Lval, on) do {                                                                                                   \
+        unsigned Lq_ = (Lval);                                                                                                         \
+        const KArgs k_ = KA();                                                                                                         \
+        const int ntile_ = divmod(Lq_, k_->ntiles);                                                                                      \
+        const int tw_ = divmod(Lq_, k_->tilesW);                                                                                         \
+        const int th_ = divmod(Lq_, k_->tilesH);                                                                                         \
+        const int td_ = divmod(Lq_, k_->tilesD);                                                                                         \
+        X##nb = (int)Lq_;                                                                                                              \
+        X##d0 = (td_ + k_->o_td) * 4; X##h0 = (th_ + k_->o_th) * 4; X##w0 = (tw_ + k_->o_tw) * 8;   /* (o_*: first brick of the needed region) */ \
+        X##n0 = ntile_ * 32;                                                                                                           \
+        X##row = ((X##nb * k_->tilesD + td_) * k_->tilesH + th_) * k_->tilesW + tw_;                                                         \
+        X##xorg = k_->x + (((long long)X##nb * D + (X##d0 - 1)) * ((long long)H * W * xl) + ((long long)(X##h0 - 1) * W + (X##w0 - 1)) * xl); \
+        const unsigned m_ = range_mask(X##d0 - 1, 6, D) | (range_mask(X##h0 - 1, 6, H) << 6) | (range_mask(X##w0 - 1, 10, W) << 12);    \
+        X##mask = (on) ? m_ : 0u;       /* (a brick beyond the end of the range stages zeros) */                                        \
+        X##wbase = k_->wt + ((size_t)ntile_ * NCH * 64 + wave * 16) * 256;                                                               \
+    } while (0)
+    // the 3 DMA pieces of this wave for chunk cb of a brick (halo origin xorg, validity mask), into stage buffer `buf`
+    auto issue_dma = [&](const float* xorg, unsigned mask, int cb, float* buf) {
+        if (E3_W16_ABL & 1) return;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xorg), 0, 0x7fffffff, 0x00020000);
+        const bool ok = (mask & col_bits) == col_bits;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                if (E3_W16_ABL & 1) continue;
-                unsigned voff = (col_ok && ((dm >> it) & 1u)) ? col_rel : OOB;
-                if (E3_W16_ABL & 64) {      // (an 8 KB window at the start of the tensor: L1 hits)
-                    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x10000, 0x00020000);
-                    xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, col_rel & 0x1ff0u, it * 16, 0)); continue;
-                }
-                xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, voff, (int)(it * plane_xb) + cb * 4, 0));
-            }
-        };
-        auto write_staged = [&](float* buf) {       // D pass of B^T: rows x0 - x2, x1 + x2, x2 - x1, x1 - x3 of the thread's 4 d-planes
-            if (col_on && !(E3_W16_ABL & 8)) {
-                *reinterpret_cast<f32x4*>(buf + 0 * Q_PLANE + a_dst) = xr[0] + m1 * xr[2];
-                *reinterpret_cast<f32x4*>(buf + 1 * Q_PLANE + a_dst) = xr[1] + xr[2];
-                *reinterpret_cast<f32x4*>(buf + 2 * Q_PLANE + a_dst) = xr[2] + m1 * xr[1];
-                *reinterpret_cast<f32x4*>(buf + 3 * Q_PLANE + a_dst) = xr[1] + m1 * xr[3];
-            }
-        };
+        for (int k = 0; k < 3; ++k) {
+            const int plane = 2 * k + (wave >> 1);
+            const unsigned dsel = ((mask >> plane) & 1u) ? 0u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_q)(buf + plane * Q_RPLANE + hp * 256), 16, (ok ? col_rel : OOB) | dsel,
+                                                     (int)(plane * plane_xb) + cb * 32, 0, 0);
+        }
+    };
+    const int b_voff = lane * 16;
+    f32x4 acc[16][2];
+    f32x4 Bv[16];
 
-        // One 8-channel chunk: D-transformed halo in `cur`, the next chunk's goes to `nxt`.  Weights: a ring of 8 positions, position
-        // p + 8 (of the next chunk when it wraps) is requested as soon as the MFMAs of position p are issued.
-        auto chunk = [&](auto zero_tag, int c, const float* cur, float* nxt) {
+#ifdef E3_W16_TIMING      // developer build (tools/phase_timing_w16.py): s_memtime stamps of the workgroup's third brick instead of statistics
+    long long* const tstamp = reinterpret_cast<long long*>(KA()->stats) + (size_t)blockIdx.x * 40;
+    int tbrick = 0;
+#define TSTAMP(i) do { if (tid == 0 && tbrick == 2) tstamp[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(i)
+#endif
+    E3_BRICK_VARS(P_); E3_BRICK_VARS(N_);
+    E3_DECODE(P_, L, true);
+    {   // prologue: unit 0 staged, its weights requested
+        issue_dma(P_xorg, P_mask, 0, cur);
+        const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P_wbase), 0, NCH * 64 * 1024, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) Bv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_voff, p * 1024, 0));
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    for (;;) {
+        const bool has_next = L + Lstep < Lend;
+        E3_DECODE(N_, has_next ? L + Lstep : L, has_next);
+
+        // One 8-channel chunk c of brick P (raw halo in `cur`).  Program order: LDS reads + transform; the DMA requests of the NEXT unit
+        // (chunk c + 1, or chunk 0 of brick N) into `nxt`; 16 positions x 4 MFMAs, each position pair followed by the weight requests of
+        // the same positions of the next unit (a ring of 16: one full chunk of look-ahead).  The memory counter retires in order, so the
+        // order of the requests is what hides their latency: DMA (long, HBM) before the 16 weight loads (short, L2) of the same chunk, both
+        // needed only after this chunk's MFMAs; stores of an epilogue are younger than everything the next chunk waits for.
+        auto chunk = [&](auto zero_tag, int c) {
             constexpr bool ZERO = decltype(zero_tag)::value;
             const bool lastc = c + 1 == NCH;
-            const int cn = lastc ? c : c + 1;
-            issue_raw(cn * 8);      // (the last chunk harmlessly re-reads itself: no branch in the loop body)
+            if (E3_W16_PRIO) __builtin_amdgcn_s_setprio(E3_W16_PRIO);      // the VALU phase goes in front of the other workgroup's MFMAs
             f32x2q t[4][4];
 #pragma unroll
-            for (int h = 0; h < 4; ++h)
+            for (int h = 0; h < 4; ++h) {        // (row by row: at most 16 registers of raw values in flight)
 #pragma unroll
-                for (int w = 0; w < 4; ++w) t[h][w] = *reinterpret_cast<const f32x2q*>(cur + rd[h >> 1] + rd_imm(h, w));
+                for (int w = 0; w < 4; ++w) {
+                    const f32x2q xa = *reinterpret_cast<const f32x2q*>(cur + rdA[h >> 1] + rd_imm(h, w));
+                    const f32x2q xb = *reinterpret_cast<const f32x2q*>(cur + rdB[h >> 1] + rd_imm(h, w));
+                    t[h][w] = xa + dsg * xb;
+                }
+                if (E3_W16_ROWS == 1 || (h & 1)) __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const f32x2q u0 = t[0][w] + m1 * t[2][w], u1 = t[1][w] + t[2][w], u2 = t[2][w] + m1 * t[1][w], u3 = t[1][w] + m1 * t[3][w];
@@ -180,7 +226,13 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
 #pragma unroll
                 for (int w = 0; w < 4; ++w) asm volatile("" : "+v"(t[h][w]));     // keep the transform packed and in front of the MFMA block
             __builtin_amdgcn_sched_barrier(0);
-            const __amdgpu_buffer_rsrc_t b_nx = lastc ? b_rs0 : b_rs;
+            if (E3_W16_PRIO) __builtin_amdgcn_s_setprio(0);
+            if (c < 8) TSTAMP(1 + 4 * c);
+            issue_dma(lastc ? N_xorg : P_xorg, lastc ? N_mask : P_mask, lastc ? 0 : c + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            const float* const wb = lastc ? N_wbase : P_wbase;
+            const __amdgpu_buffer_rsrc_t b_nx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wb), 0, (lastc && !has_next) ? 0 : NCH * 64 * 1024, 0x00020000);
+            const int cB = lastc ? 0 : c + 1;
 #pragma unroll
             for (int pp = 0; pp < 16; pp += 2) {        // two positions at a time: 4 independent accumulators in flight, then their ring slots are refilled
 #pragma unroll
@@ -190,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
 #pragma unroll
                         for (int hf = 0; hf < 2; ++hf) {
                             if (E3_W16_ABL & 32) continue;
-                            const float wv = Bv[p & 7][ks * 2 + hf], tv = t[p >> 2][p & 3][ks];
+                            const float wv = Bv[p][ks * 2 + hf], tv = t[p >> 2][p & 3][ks];
                             if (ZERO && ks == 0) {
                                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                                 acc[p][hf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, tv, z, 0, 0, 0);
@@ -200,36 +252,37 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
 #pragma unroll
                 for (int p = pp; p < pp + 2; ++p) {
                     if (E3_W16_ABL & 2) continue;
-                    if (p < 8) Bv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_voff, (c * 64 + p + 8) * 1024, 0));
-                    else Bv[p - 8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_nx, b_voff, (cn * 64 + p - 8) * 1024, 0));
+                    Bv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_nx, b_voff, (cB * 64 + p) * 1024, 0));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // this wave's DMA pieces have landed once at most the 16 weight requests behind them are outstanding; the barrier then
+            // publishes every wave's pieces and retires `cur`
+            if (c < 8) TSTAMP(2 + 4 * c);
+            if (E3_W16_ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (c < 8) TSTAMP(3 + 4 * c);
+            __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            write_staged(nxt);
-            __syncthreads();
+            if (c < 8) TSTAMP(4 + 4 * c);
+            { float* tsw = cur; cur = nxt; nxt = tsw; }
         };
 
-        issue_raw(0);
-#pragma unroll
-        for (int p = 0; p < 8; ++p) Bv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_voff, p * 1024, 0));
-        write_staged(buf0);
-        __syncthreads();
-        chunk(std::true_type{}, 0, buf0, buf1);
-        for (int c = 1; c < NCH; c += 2) {
-            chunk(std::false_type{}, c, buf1, buf0);
-            if (c + 1 < NCH) chunk(std::false_type{}, c + 1, buf0, buf1);
-        }
+        TSTAMP(0);
+        chunk(std::true_type{}, 0);
+        for (int c = 1; c < NCH; ++c) chunk(std::false_type{}, c);
 
         // ---- epilogue.  acc[ph*4+pw][half][i]: position (pd = wave, ph, pw), tile tl, channel n0 + 8 kk + 4 half + i.
         // per-channel constants first: they arrive during the output transform
+        if (E3_W16_PRIO) __builtin_amdgcn_s_setprio(E3_W16_PRIO);
+        const int n0 = P_n0, d0 = P_d0, h0 = P_h0, w0 = P_w0;
         const int nq = n0 + 8 * kk;
         f32x4 bias[2], es[2], eh[2];
         {
-            const int eN = a.Ncols;
-            const __amdgpu_buffer_rsrc_t c_rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias ? eN * 4 : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t c_rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.epi_scale), 0, AFF ? eN * 4 : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t c_rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.epi_shift), 0, AFF ? eN * 4 : 0, 0x00020000);
+            const KArgs e = KA();
+            const int eN = e->Ncols;
+            const __amdgpu_buffer_rsrc_t c_rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e->bias), 0, e->bias ? eN * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t c_rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e->epi_scale), 0, AFF ? eN * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t c_rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e->epi_shift), 0, AFF ? eN * 4 : 0, 0x00020000);
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 bias[hf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c_rs0, (nq + 4 * hf) * 4, 0, 0));
@@ -239,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
                 }
             }
         }
-        // A^T m A over (ph, pw) in registers (the barrier that ended the last chunk separates the staging buffers from their reuse as `ex`)
+        // A^T m A over (ph, pw) in registers (`ex` is its own LDS region: the next brick's first chunk is already in the stage buffers)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             f32x4 q[2][2];
@@ -258,7 +311,11 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
                 for (int ow = 0; ow < 2; ++ow)
                     *reinterpret_cast<f32x4*>(ex + ((wave * 8 + (oh * 2 + ow) * 2 + hf) * 64 + lane) * 4) = q[oh][ow];
         }
-        __syncthreads();
+        TSTAMP(33);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        TSTAMP(34);
         // wave w now owns output offset (oh, ow) = (w >> 1, w & 1) of every tile and sums the pd axis: od = 0, 1
         const int oh = wave >> 1, ow = wave & 1;
         f32x4 y[2][2];
@@ -277,10 +334,11 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
             }
         }
         // voxel (d0 + 2 ttd + od, h0 + 2 tth + oh, w0 + 2 ttw + ow), channels nq + 4 half .. + 3: 16-byte stores
+        const int yl = KA()->y_ldc;
         const size_t plane_y = (size_t)H * W * yl;
         const size_t yrem = (size_t)(D - d0) * plane_y * 4;
         const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(
-            a.y + ((size_t)nb * D + d0) * plane_y, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
+            KA()->y + ((size_t)P_nb * D + d0) * plane_y, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
         const int gh = h0 + 2 * tth + oh, gw = w0 + 2 * ttw + ow, gd = d0 + 2 * ttd;
         const unsigned y_voff = (unsigned)((((2 * ttd * H + gh) * W + gw) * yl + nq) * 4);
         const bool vox_ok = gh < H && gw < W;
@@ -288,11 +346,12 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
         const int od_off = (int)(plane_y * 4);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            const bool cok = nq + 4 * hf < a.Ncols;
+            const bool cok = nq + 4 * hf < KA()->Ncols;
             if (E3_W16_ABL & 4) continue;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4q, y[0][hf]), y_rs, (ok0 && cok) ? y_voff + 16 * hf : OOB, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4q, y[1][hf]), y_rs, (ok1 && cok) ? y_voff + 16 * hf : OOB, od_off, 0);
         }
+        TSTAMP(35);
         if (do_stats) {
             // running record of this lane's 8 channels: Chan merge of the brick's (up to) two values per channel, approximate reciprocal
             // (its error is far below the rounding of the sums)
@@ -317,8 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
                     run[(9 + ch) * 256] = rm2 + 0.5f * dd * dd + dl * dl * rnf;
                 }
             run[0] = nn;
-            const bool flush_now = !wgstats || L + Lstep >= Lend;
-            if (flush_now) {       // (uniform) merge the lanes of a channel (16 tiles, then the 4 waves) in a fixed order, one record
+            if (!wgstats || !has_next) {       // (uniform) merge the lanes of a channel (16 tiles, then the 4 waves) in a fixed order, one record
                 float fn = run[0], fm[8], fs[8];
 #pragma unroll
                 for (int ch = 0; ch < 8; ++ch) { fm[ch] = run[(1 + ch) * 256]; fs[ch] = run[(9 + ch) * 256]; }
@@ -339,17 +397,19 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
                         sc_[0] = fn; sc_[1] = fm[ch]; sc_[2] = fs[ch];
                     }
                 }
-                __syncthreads();
-                if (tid < 32 && n0 + tid < a.Ncols) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (tid < 32 && n0 + tid < KA()->Ncols) {
                     float c0 = 0.f, me = 0.f, mm = 0.f;
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
                         const float* sc_ = scr + (w * 32 + tid) * 3;
                         welford_merge(c0, me, mm, sc_[0], sc_[1], sc_[2]);
                     }
-                    const size_t row = wgstats ? (size_t)((blockIdx.x & 7u) * ((gridDim.x >> 3) / (unsigned)a.ntiles) + (blockIdx.x >> 3) / (unsigned)a.ntiles)
-                                               : (size_t)(((nb * a.tilesD + td_) * a.tilesH + th_) * a.tilesW + tw_);
-                    float* o = a.stats + (row * a.Cout + n0 + tid) * 3;
+                    const size_t row = wgstats ? (size_t)((blockIdx.x & 7u) * ((gridDim.x >> 3) / (unsigned)KA()->ntiles) + (blockIdx.x >> 3) / (unsigned)KA()->ntiles)
+                                               : (size_t)P_row;
+                    float* o = KA()->stats + (row * KA()->Cout + n0 + tid) * 3;
                     o[0] = c0; o[1] = me; o[2] = mm;
                 }
                 if (!wgstats) {
@@ -358,7 +418,14 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
                 }
             }
         }
-        __syncthreads();        // `ex` (and the merge scratch) are the next brick's staging buffers
+        if (E3_W16_PRIO) __builtin_amdgcn_s_setprio(0);
+        TSTAMP(36);
+#ifdef E3_W16_TIMING
+        ++tbrick;
+#endif
+        if (!has_next) break;
+        P_d0 = N_d0; P_h0 = N_h0; P_w0 = N_w0; P_nb = N_nb; P_n0 = N_n0; P_row = N_row; P_mask = N_mask; P_xorg = N_xorg; P_wbase = N_wbase;
+        L += Lstep;
     }
 }
 
@@ -376,7 +443,9 @@ static bool wino16_wgstats(size_t nblk, int ntiles, unsigned grid) {
 // it.  Decided on the grid of ONE sample (like conv_use_wino) so that the arithmetic does not depend on the batch size; a split-K launch,
 // the timing flag and column counts that rule out 16-byte stores keep the first kernels.
 int conv_wino_layout(int flags, int D, int H, int W, int K, int ncols, int splitk) {
-    static const bool enabled = getenv("E3_NO_WINO16") == nullptr;
+    // OFF by default: measured at parity with conv_wino.hip's persistent kernel on the cfg-2 layers (profiles/r04_wino16_experiment.md), not
+    // ahead of it -- E3_WINO16=1 selects it (A/B switch; tests/test_switches_gpu.py runs the parity suites with it)
+    static const bool enabled = getenv("E3_WINO16") != nullptr && getenv("E3_NO_WINO16") == nullptr;
     static const size_t minblk = getenv("E3_WINO16_MIN") ? (size_t)atol(getenv("E3_WINO16_MIN")) : 512;
     if (!enabled || splitk > 1 || (flags & 1024) || (ncols & 3) || (K & 7)) return 0;
     const size_t nblk1 = (size_t)wino16_bricks(1, D, H, W) * ((ncols + 31) / 32);

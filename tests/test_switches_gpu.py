@@ -25,6 +25,11 @@ GROUPS = {
     'dp_overlap_pageable_copies': (dict(E3_DP_OVERLAP='1', E3_DP_CU_RESERVE='8', E3_PREDICTOR_NO_PINNED='1', E3_EW_NT_MB='1'),
                                    ['tests/test_dataparallel_gpu.py', 'tests/test_predictor.py', 'tests/test_unet_gpu.py', '-k',
                                     'two_rank or pipelined or needed_region or in_place or train_step_matches_reference']),
+    # second Winograd decomposition (conv_wino16.hip: 16-tile bricks, two workgroups per CU) for every grid that has a brick: forward with
+    # statistics, data gradients, the folded eval epilogue, the needed-region forward
+    'wino16_bricks': (dict(E3_WINO16='1', E3_WINO16_MIN='1'),
+                      ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', 'tests/test_predictor.py', '-k',
+                       'conv3 or train_step_matches_reference or eval_forward or full_size_properties or forward_with_loss or forward_roi or needed_region or full_size_cfg2']),
 }
 
 
