@@ -248,7 +248,14 @@ __global__ void bn_relu_pool_kernel(const float* __restrict__ x, int x_ldc, cons
 // dA(v) = g1(v) + [v is the first arg-max of its pooling window] * gpool(window)
 // dz = dA * (z > 0),  z = x*scale + shift ;  xhat = (x - mean) * invstd
 // pass 1 (REDUCE): per-channel sum dz, sum dz*xhat.   pass 2 (APPLY): dx = gamma*invstd*(dz - c1 - xhat*c2), sum dx.
-template <bool POOL, bool APPLYPASS, bool HEAD = false>
+// HL > 0 (head form only): the head gradient comes from the criterion (hl_* fields) for HL classes, and the REDUCE pass also takes the head's own
+// weight / bias gradient sums -- a separate instantiation so that the plain forms keep their register count (64: eight waves per SIMD)
+// items in flight per thread in the criterion form of the head's REDUCE pass: 2 (106 registers, four workgroups per CU = the 1024-workgroup grid in one
+// residency round: 103 us at cfg 2); 4 needs 162 registers -- three per CU, 174 us (138 us on a 768-workgroup grid)
+#ifndef E3_HEADRED_NU
+#define E3_HEADRED_NU 2
+#endif
+template <bool POOL, bool APPLYPASS, bool HEAD = false, int HL = 0>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
     __shared__ float red[3][256][4];
     const int Q = a.C >> 2;
@@ -285,17 +292,32 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
             for (int e = 0; e < 4; ++e) gi[e] = gm[e] * is[e];
         }
         const size_t vstride = stride / Q;                  // voxels between consecutive items of this thread
-        constexpr int NU = 4;                               // items in flight per thread (8 for the HEAD form: 96 -> 168 us, measured)
+        constexpr int NU = (HEAD && HL > 0 && !APPLYPASS) ? E3_HEADRED_NU : 4;     // items in flight per thread (8 for the HEAD form: 96 -> 168 us, measured)
         const bool big = units * (size_t)a.C * 4 > a.nt_bytes;
         // HEAD: the head's weights of this thread's channel quad stay in registers (the first four outputs: every usual head), and the sample
         // index of a voxel is carried along instead of divided out per item (the division cost more than the rest of the item)
-        f32x4 hw[4];
+        f32x4 hw[HL > 0 ? HL : 4];
         size_t hn = 0, hbase = 0;
+        // criterion form of the head gradient: per-thread copies of the class constants (<= 4 classes)
+        constexpr bool hloss = HEAD && HL > 0;
+        constexpr int HC = HL > 0 ? HL : 1;
+        float lw[HC], lgn[HC], lgd[HC], law = 0.f, lg = 1.f;
+        // head gradients (REDUCE pass): dW of this thread's channel quad, db
+        constexpr bool hgrad = HEAD && HL > 0 && !APPLYPASS;
+        f32x4 dwacc[HC]; float dbacc[HC];
+#pragma unroll
+        for (int co = 0; co < HC; ++co) { dwacc[co] = f32x4{0.f, 0.f, 0.f, 0.f}; dbacc[co] = 0.f; lw[co] = 1.f; lgn[co] = 0.f; lgd[co] = 0.f; }
         if (HEAD) {
 #pragma unroll
-            for (int co = 0; co < 4; ++co) hw[co] = co < a.head_cout ? *reinterpret_cast<const f32x4*>(a.head_w + co * a.C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int co = 0; co < (HL > 0 ? HL : 4); ++co) hw[co] = co < a.head_cout ? *reinterpret_cast<const f32x4*>(a.head_w + co * a.C + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
             hn = (i00 / Q) / a.head_S; hbase = hn * a.head_S;
+            if (hloss) {
+#pragma unroll
+                for (int co = 0; co < HC; ++co) { lw[co] = a.hl_cw ? a.hl_cw[co] : 1.f; lgn[co] = a.hl_coef[1 + co]; lgd[co] = a.hl_coef[1 + HC + co]; }
+                law = a.hl_coef[0]; lg = a.hl_gout ? a.hl_gout[0] : 1.f;
+            }
         }
+        float gys[hloss ? NU : 1][HC];         // the head's logits gradient of the items in flight (kept for dW / db)
         for (size_t v0 = i00 / Q; threadIdx.x < BT && v0 < units; v0 += NU * vstride) {
             f32x4 xv[NU], g[NU]; bool ok[NU];
 #pragma unroll
@@ -307,21 +329,52 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                 if (HEAD) {
                     xv[u] = ok[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + v * a.x_ldc + 4 * q)) : f32x4{0.f, 0.f, 0.f, 0.f};
                     g[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (hloss) {
+#pragma unroll
+                        for (int co = 0; co < HC; ++co) gys[u][co] = 0.f;
+                    }
                     if (ok[u]) {
                         while (v >= hbase + a.head_S) { hbase += a.head_S; ++hn; }       // (v only grows along a thread's items)
                         const size_t n = hn, sp = v - hbase;
+                        if (hloss) {
+                            // dL/dlogits of this voxel: the expressions of ce_dice_bwd_kernel (loss.hip) on the logits the forward wrote
+                            float z[HC], pr[HC], m = -3.4e38f;
 #pragma unroll
-                        for (int co = 0; co < 4; ++co)                    // same fma order over co as conv_final_bwd_kernel
-                            if (co < a.head_cout) {
-                                const float gy = a.head_dy[(n * a.head_cout + co) * a.head_S + sp];
+                            for (int co = 0; co < HC; ++co) { z[co] = a.hl_logits[(n * HC + co) * a.head_S + sp]; m = fmaxf(m, z[co]); }
+                            float sum = 0.f;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) g[u][e] = __builtin_fmaf(gy, hw[co][e], g[u][e]);
+                            for (int co = 0; co < HC; ++co) { pr[co] = __expf(z[co] - m); sum += pr[co]; }
+                            const float inv = 1.f / sum;
+                            const int t = (int)a.hl_target[n * a.head_S + sp];
+                            float G[HC], dot = 0.f, wt = 0.f;
+#pragma unroll
+                            for (int co = 0; co < HC; ++co) {
+                                pr[co] *= inv;
+                                const bool is = t == co;
+                                G[co] = lgn[co] - (is ? lgd[co] : 0.f);
+                                dot += pr[co] * G[co];
+                                wt += is ? lw[co] : 0.f;
                             }
-                        for (int co = 4; co < a.head_cout; ++co) {
-                            const float gy = a.head_dy[(n * a.head_cout + co) * a.head_S + sp];
-                            const f32x4 wv = *reinterpret_cast<const f32x4*>(a.head_w + co * a.C + 4 * q);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) g[u][e] = __builtin_fmaf(gy, wv[e], g[u][e]);
+                            for (int co = 0; co < HC; ++co) {
+                                gys[u][co] = lg * (law * wt * (pr[co] - (t == co ? 1.f : 0.f)) + pr[co] * (G[co] - dot));
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) g[u][e] = __builtin_fmaf(gys[u][co], hw[co][e], g[u][e]);      // same fma order over co as conv_final_bwd_kernel
+                            }
+                        } else {
+#pragma unroll
+                            for (int co = 0; co < 4; ++co)                    // same fma order over co as conv_final_bwd_kernel
+                                if (co < a.head_cout) {
+                                    const float gy = a.head_dy[(n * a.head_cout + co) * a.head_S + sp];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) g[u][e] = __builtin_fmaf(gy, hw[co][e], g[u][e]);
+                                }
+                            for (int co = 4; co < a.head_cout; ++co) {
+                                const float gy = a.head_dy[(n * a.head_cout + co) * a.head_S + sp];
+                                const f32x4 wv = *reinterpret_cast<const f32x4*>(a.head_w + co * a.C + 4 * q);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) g[u][e] = __builtin_fmaf(gy, wv[e], g[u][e]);
+                            }
                         }
                     }
                 } else if (big) {
@@ -338,14 +391,48 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float z = __builtin_fmaf(xv[u][e], sc[e], sh[e]);   // same expression as the forward apply
-                    const float dz = act_bwd(z, g[u][e], act_slope_at(a.act, slope, (unsigned)((v0 + u * vstride) * a.C + 4 * q + e)));
+                    const float sl_e = act_slope_at(a.act, slope, (unsigned)((v0 + u * vstride) * a.C + 4 * q + e));
+                    const float dz = act_bwd(z, g[u][e], sl_e);
+                    if (hgrad && ok[u]) {       // head weight gradient: the activation the head saw (same expression as its prologue)
+                        const float av = act_fwd(z, sl_e);
+#pragma unroll
+                        for (int co = 0; co < HC; ++co) dwacc[co][e] = __builtin_fmaf(gys[u][co], av, dwacc[co][e]);
+                    }
                     if (!APPLYPASS && prelu) s3[e] += g[u][e] * fminf(z, 0.f);
                     const float xh = (xv[u][e] - mu[e]) * is[e];
                     if (APPLYPASS) { o[e] = ok[u] ? gi[e] * (dz - c1[e] - xh * c2[e]) - (k1[e] + xh * k2[e]) : 0.f; s3[e] += o[e]; }
                     else { s1[e] += dz; s2[e] += dz * xh; }
                 }
                 if (APPLYPASS && ok[u]) *reinterpret_cast<f32x4*>(a.dx + (v0 + u * vstride) * a.dx_ldc + 4 * q) = o;
+                if (hgrad && ok[u] && q == 0) {
+#pragma unroll
+                    for (int co = 0; co < HC; ++co) dbacc[co] += gys[u][co];
+                }
             }
+        }
+        if (hgrad) {        // (uniform) block partials of the head's gradients, one output row at a time: the layout / order of conv_final_bwd_kernel
+            const int pstride = HC * a.C + HC;
+            const int tid = threadIdx.x;
+#pragma unroll
+            for (int co = 0; co < HC; ++co) {
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[0][tid][e] = tid < BT ? dwacc[co][e] : 0.f;
+                red[1][tid][0] = (tid < BT && q == 0) ? dbacc[co] : 0.f;
+                __syncthreads();
+                for (int t = tid; t < Q * 4; t += 256) {
+                    const int e = t & 3, qq = t >> 2;
+                    float acc = 0.f;
+                    for (int k = qq; k < BT; k += Q) acc += red[0][k][e];
+                    a.head_part[(size_t)blockIdx.x * pstride + co * a.C + 4 * qq + e] = acc;
+                }
+                if (tid == 0) {
+                    float acc = 0.f;
+                    for (int k = 0; k < BT; k += Q) acc += red[1][k][0];
+                    a.head_part[(size_t)blockIdx.x * pstride + HC * a.C + co] = acc;
+                }
+            }
+            __syncthreads();
         }
     }
     for (size_t i = (size_t)blockIdx.x * BT + threadIdx.x; POOL && threadIdx.x < BT && i < total; i += stride) {
@@ -870,8 +957,21 @@ static int bn_bwd_launch(BnBwdArgs a, bool apply, hipStream_t s) {
         if (apply) hipLaunchKernelGGL((bn_bwd_kernel<true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((bn_bwd_kernel<true, false>), grid, block, 0, s, a);
     } else if (a.g1 == nullptr) {
-        E3_REQUIRE(a.head_dy && a.head_w && a.head_cout > 0 && a.head_S > 0, E3_ERR_INVALID, "BN backward without an incoming gradient");
-        if (apply) hipLaunchKernelGGL((bn_bwd_kernel<false, true, true>), grid, block, 0, s, a);
+        E3_REQUIRE((a.head_dy || a.hl_logits) && a.head_w && a.head_cout > 0 && a.head_S > 0, E3_ERR_INVALID, "BN backward without an incoming gradient");
+        E3_REQUIRE(!a.hl_logits || (a.head_cout >= 2 && a.head_cout <= 4 && a.hl_target && a.hl_coef), E3_ERR_UNSUPPORTED,
+                   "BN backward, head form with the criterion: 2..4 classes");
+        E3_REQUIRE(!a.head_part || a.hl_logits, E3_ERR_INVALID, "BN backward: the head's gradients come with the criterion form only");
+        if (a.hl_logits) {      // criterion form (+ the head's own gradients in the REDUCE pass)
+            E3_REQUIRE(apply || a.head_part, E3_ERR_INVALID, "BN backward, criterion form: the reduce pass takes the head's gradients");
+            switch (a.head_cout * 2 + (apply ? 1 : 0)) {
+                case 4: hipLaunchKernelGGL((bn_bwd_kernel<false, false, true, 2>), grid, block, 0, s, a); break;
+                case 5: hipLaunchKernelGGL((bn_bwd_kernel<false, true, true, 2>), grid, block, 0, s, a); break;
+                case 6: hipLaunchKernelGGL((bn_bwd_kernel<false, false, true, 3>), grid, block, 0, s, a); break;
+                case 7: hipLaunchKernelGGL((bn_bwd_kernel<false, true, true, 3>), grid, block, 0, s, a); break;
+                case 8: hipLaunchKernelGGL((bn_bwd_kernel<false, false, true, 4>), grid, block, 0, s, a); break;
+                default: hipLaunchKernelGGL((bn_bwd_kernel<false, true, true, 4>), grid, block, 0, s, a); break;
+            }
+        } else if (apply) hipLaunchKernelGGL((bn_bwd_kernel<false, true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((bn_bwd_kernel<false, false, true>), grid, block, 0, s, a);
     } else {
         if (apply) hipLaunchKernelGGL((bn_bwd_kernel<false, true>), grid, block, 0, s, a);

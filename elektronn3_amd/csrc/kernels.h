@@ -259,6 +259,13 @@ struct BnBwdArgs {
     // non-pool path, g1 == nullptr: the incoming gradient is that of the 1x1x1 head, g[v][c] = sum_co head_dy[n][co][sp] * head_w[co][c],
     // recomputed from the (tiny) NCDHW logits gradient instead of being written by conv_final_bwd and re-read twice
     const float* head_dy; const float* head_w; int head_cout; size_t head_S;
+    // ... or (head_dy == nullptr, hl_logits set; head_cout <= 4) formed from the criterion e3_unet_forward_loss evaluated in the head: the logits it
+    // wrote, the target and the finalised coefficients (loss.hip: coef[0] = a / Ws, [1 + k], [1 + C + k]) -- no dlogits tensor exists.
+    // hl_gout: device scalar d(final)/d(loss) or null (= 1).
+    const float* hl_logits; const long long* hl_target; const float* hl_cw; const float* hl_coef; const float* hl_gout;
+    // REDUCE pass of the head form, head_part != nullptr: also the head's own gradients (what conv_final_bwd_kernel computes from a second
+    // pass over x): partial sums [parts][head_cout * C + head_cout] of dW[co][c] = sum g[co] * act(z)[c] and db[co] = sum g[co]
+    float* head_part;
     ActArg act;                           // activation: slope 0 = ReLU, > 0 = LeakyReLU(slope), 1 = identity, ACT_SILU; or a PReLU pointer
     // PReLU: the REDUCE pass also writes sum dA*min(z,0) per channel into row 2 of `part` (the APPLY pass overwrites it later)
 };

@@ -975,11 +975,41 @@ int e3_unet_backward(e3_unet_plan* plan, void* stream, const float* dy, const fl
                              bucket_after_down_block, 0);
 }
 
+// the criterion's request of e3_unet_backward_loss: dLoss/dlogits is formed inside the head's backward kernels
+struct HeadLossReq { const float* logits; const long long* target; const float* cw; const float* coef; const float* gout; };
+static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, const HeadLossReq* hl, const float* x, int N, int D, int H, int W,
+                         void* const* params, void* const* grads, float* dx,
+                         void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                         void* bucket_event, int bucket_after_down_block, uint32_t flags);
+
 int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const float* x, int N, int D, int H, int W,
                       void* const* params, void* const* grads, float* dx,
                       void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
                       void* bucket_event, int bucket_after_down_block, uint32_t flags) {
-    E3_REQUIRE(plan && dy && x && params && grads && saved && scratch, E3_ERR_INVALID, "null argument");
+    E3_REQUIRE(dy, E3_ERR_INVALID, "null argument");
+    return backward_impl(plan, stream, dy, nullptr, x, N, D, H, W, params, grads, dx, saved, saved_bytes, scratch, scratch_bytes, bucket_event,
+                         bucket_after_down_block, flags);
+}
+
+int e3_unet_backward_loss(e3_unet_plan* plan, void* stream, const float* y, const e3_ce_dice_args* loss, const float* gout, const float* x,
+                          int N, int D, int H, int W, void* const* params, void* const* grads, float* dx,
+                          void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                          void* bucket_event, int bucket_after_down_block, uint32_t flags) {
+    E3_REQUIRE(plan && y && loss && loss->target && loss->workspace, E3_ERR_INVALID, "null argument");
+    const int C = plan->cfg.out_channels;
+    E3_REQUIRE(loss->workspace_bytes >= e3_ce_dice_workspace_bytes(C), E3_ERR_WORKSPACE, "ce_dice workspace too small");
+    // the fused form lives in the BatchNorm backward of the network's last unit (head form: at most 4 classes in registers)
+    if (!(C >= 2 && C <= 4 && plan->units.back().has_norm())) { e3_set_error("e3_unet_backward_loss: needs 2..4 classes and a norm in front of the head"); return E3_ERR_UNSUPPORTED; }
+    const HeadLossReq hl{y, loss->target, loss->class_weight, (const float*)loss->workspace + (size_t)CE_DICE_MAX_ROWS * (2 + 3 * C), gout};
+    return backward_impl(plan, stream, nullptr, &hl, x, N, D, H, W, params, grads, dx, saved, saved_bytes, scratch, scratch_bytes, bucket_event,
+                         bucket_after_down_block, flags);
+}
+
+static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, const HeadLossReq* hl, const float* x, int N, int D, int H, int W,
+                         void* const* params, void* const* grads, float* dx,
+                         void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                         void* bucket_event, int bucket_after_down_block, uint32_t flags) {
+    E3_REQUIRE(plan && (dy || hl) && x && params && grads && saved && scratch, E3_ERR_INVALID, "null argument");
     // the forward ran with E3_FWD_FROZEN_BN: the statistics are constants, so dx = gamma * invstd * dz (no mean / variance terms)
     const bool frozen = (flags & E3_BWD_FROZEN_BN) != 0 && (plan->cfg.normalization == 1 || plan->cfg.attention);
     hipStream_t s = (hipStream_t)stream;
@@ -1000,7 +1030,9 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
 
     // ---- conv_final (unet.py:912): da, dW, db
     const UnitBufs& last = B.ub[nunits - 1 - 0];   // last unit of the forward feeds conv_final
-    {
+    // (e3_unet_backward_loss: no pass of its own -- the REDUCE pass of the last unit's BatchNorm backward, which reads the same tensor, also
+    // takes the head's weight / bias gradient sums; see below)
+    if (!hl) {
         const int parts = conv_final_bwd_parts(ND.Y.vox);
         const int ps = cfg.out_channels * C0 + cfg.out_channels;
         { Prof pr(plan, s, nunits, 1);
@@ -1115,6 +1147,7 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
             }
             if (k == nunits - 1) {      // incoming gradient = that of the 1x1x1 head, recomputed on the fly
                 a.g1 = nullptr; a.head_dy = dy; a.head_w = P(plan->p_final_w); a.head_cout = cfg.out_channels; a.head_S = ND.Y.vox / N;
+                if (hl) { a.hl_logits = hl->logits; a.hl_target = hl->target; a.hl_cw = hl->cw; a.hl_coef = hl->coef; a.hl_gout = hl->gout; a.head_part = B.slab; }
             }
             else if (pooled_unit && cfg.attention && !valid) {   // the GridAttention's backward wrote the skip's gradient
                 a.g1 = B.gskip[j]; a.g1_ldc = u.cout; a.gpool = g; a.a = b.act; a.a_ldc = b.act_ldc; a.pooled = B.pooled[j];
@@ -1136,7 +1169,13 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
                 RUN(launch_prelu_dslope(a.part, a.parts, u.cout, B.small + 4 * u.cout, G(u.p_a), s));
             }
             if (u.has_norm()) {
-                RUN(launch_bn_bwd_reduce(a, s));
+                { Prof pr(plan, s, nunits, hl && k == nunits - 1 ? 1 : -1); RUN(launch_bn_bwd_reduce(a, s)); }
+                if (a.head_part) {      // the head's gradients from the partial sums of that pass
+                    const int ps = cfg.out_channels * C0 + cfg.out_channels;
+                    RUN(launch_colsum_finalize(B.slab, a.parts, ps, 0, cfg.out_channels * C0, G(plan->p_final_w), s));
+                    RUN(launch_colsum_finalize(B.slab, a.parts, ps, cfg.out_channels * C0, cfg.out_channels, G(plan->p_final_b), s));
+                    a.head_part = nullptr;
+                }
                 if (u.p_a >= 0) RUN(launch_prelu_dslope(a.part, a.parts, u.cout, B.small + 4 * u.cout, G(u.p_a), s));
                 RUN(launch_bn_bwd_finalize(a.part, a.parts, u.cout, (float)(1.0 / (double)lo.vox), G(u.p_g), G(u.p_be), B.small, s));
                 if (frozen) a.coef = B.zeros;      // (dgamma = sum dz*xhat and dbeta = sum dz stand; the correction terms vanish)

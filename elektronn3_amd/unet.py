@@ -24,6 +24,7 @@ from ._lib import E3_BWD_CU_RESERVE, E3_BWD_FROZEN_BN, E3_FWD_FROZEN_BN, E3_FWD_
 _plans = {}
 _plans_lock = threading.Lock()
 _scratch = {}
+_NO_LOSS_BWD = bool(int(__import__('os').environ.get('E3_NO_LOSS_BWD', '0')))   # A/B switch: forward_with_loss' backward through e3_ce_dice_bwd + e3_unet_backward2
 _NO_BF16 = bool(int(__import__('os').environ.get('E3_NO_BF16', '0')))      # A/B switch: low-precision modules on the fp32 kernels
 
 
@@ -156,6 +157,7 @@ def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, traini
             la = _lib.CEDiceArgs(loss['target'].data_ptr(), w.data_ptr() if w is not None else None, loss['ce'], loss['dice'], loss['eps'], loss['smooth'],
                                  loss['ws'].data_ptr(), nbytes, loss['out'].data_ptr())
             check(lib.e3_unet_forward_loss(*args, ctypes.byref(la)))
+            loss['in_head'] = True
         elif roi is not None and not training:      # only the voxels of `roi` are wanted (UNet.forward_roi)
             fwd_roi = lib.e3_unet_forward_roi_f16 if b16 is torch.float16 else (lib.e3_unet_forward_roi_bf16 if b16 is not None else lib.e3_unet_forward_roi)
             check(fwd_roi(plan.handle, _lib.stream_ptr(dev), c_void_p(xin.data_ptr()), N, D, H, W, ptrs, c_void_p(y.data_ptr()),
@@ -165,12 +167,13 @@ def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, traini
     return y, saved, xin, b16
 
 
-def _native_backward(plan, dy, xin, tens, saved, b16, want_dx, sync=None, frozen=False):
-    """One call of e3_unet_backward / _bf16: (flat fp32 gradient buffer, its per-table-entry views, dx or None)."""
+def _native_backward(plan, dy, xin, tens, saved, b16, want_dx, sync=None, frozen=False, loss=None):
+    """One call of e3_unet_backward / _bf16: (flat fp32 gradient buffer, its per-table-entry views, dx or None).
+    loss = (logits, CEDiceArgs, gout or None): e3_unet_backward_loss -- `dy` is then ignored (the head's kernels form dLoss/dlogits)."""
     lib = _lib.load()
     N, _, D, H, W = xin.shape
-    dev = dy.device
-    dy32 = dy.detach().to(torch.float32).contiguous()
+    dev = xin.device
+    dy32 = dy.detach().to(torch.float32).contiguous() if loss is None else None
     # one flat gradient buffer; every trainable tensor gets a view (table order)
     flat, views = (sync.flat_views(plan, tens) if sync is not None else _flat_views(plan, tens, dev))
     gptrs = (c_void_p * len(tens))(*[(v.data_ptr() if v is not None else None) for v in views])
@@ -179,11 +182,17 @@ def _native_backward(plan, dy, xin, tens, saved, b16, want_dx, sync=None, frozen
     _, scratch_bytes = plan.sizes(N, D, H, W, True, bf16=b16)
     scratch = _get_scratch(dev, max(scratch_bytes, 256))
     ev, ev_blk = (sync.bucket_event(), sync.bucket_after_down_block) if sync is not None else (None, 0)
-    args = (plan.handle, _lib.stream_ptr(dev), c_void_p(dy32.data_ptr()), c_void_p(xin.data_ptr()),
-            N, D, H, W, ptrs, gptrs, c_void_p(dx.data_ptr()) if dx is not None else None,
+    tail = (c_void_p(xin.data_ptr()), N, D, H, W, ptrs, gptrs, c_void_p(dx.data_ptr()) if dx is not None else None,
             c_void_p(saved.data_ptr()), c_size_t(saved.numel()), c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), ev, ev_blk)
+    args = (plan.handle, _lib.stream_ptr(dev), c_void_p(dy32.data_ptr()) if dy32 is not None else None) + tail
     with torch.cuda.device(dev):
-        if b16 is torch.float16:
+        if loss is not None:
+            y, la, gout = loss
+            reserve = getattr(sync, 'cu_reserve', 0) if (sync is not None and ev is not None) else 0
+            check(lib.e3_unet_backward_loss(plan.handle, _lib.stream_ptr(dev), c_void_p(y.data_ptr()), ctypes.byref(la),
+                                            c_void_p(gout.data_ptr()) if gout is not None else None, *tail,
+                                            (E3_BWD_FROZEN_BN if frozen else 0) | E3_BWD_CU_RESERVE(reserve)))
+        elif b16 is torch.float16:
             check(lib.e3_unet_backward_f16(*args))
         elif b16:
             check(lib.e3_unet_backward_bf16(*args))
@@ -219,6 +228,9 @@ class _UNetLossFunction(torch.autograd.Function):
             check(lib.e3_ce_dice_fwd(_lib.stream_ptr(y.device), ptr(y32), ptr(req['target']), ptr(w) if w is not None else None, C, N, *sp,
                                      req['ce'], req['dice'], req['eps'], req['smooth'], ptr(req['ws']), c_size_t(nbytes), ptr(req['out'])))
         ctx.ce = (req['target'], req['weight'], req['ws'])
+        # the criterion went through the head (fp32 path, 2..4 classes, a norm in front of the head): its backward can stay there too
+        ctx.ce_in_head = bool(req.get('in_head')) and 2 <= C <= 4 and module.normalization == 'batch' and not _NO_LOSS_BWD
+        ctx.ce_w = (req['ce'], req['dice'], req['eps'], req['smooth'])
         ctx.save_for_backward(y)
         return y, req['out']
 
@@ -228,6 +240,13 @@ class _UNetLossFunction(torch.autograd.Function):
         target, w, ws = ctx.ce
         C, N, D, H, W = ctx.ce_dims
         dl = None
+        if dloss is not None and dy is None and ctx.ce_in_head and ctx.b16 is None and y.dtype == torch.float32:
+            # e3_unet_backward_loss: dLoss/dlogits is formed inside the head's backward kernels (no dlogits tensor, no e3_ce_dice_bwd pass)
+            g = dloss.to(device=y.device, dtype=torch.float32).contiguous()
+            la = _lib.CEDiceArgs(target.data_ptr(), w.data_ptr() if w is not None else None, *ctx.ce_w, ws.data_ptr(), ws.numel(), None)
+            ctx.loss_bwd = (y, la, g)
+            grads = _UNetFunction.backward(ctx, None)
+            return grads[:4] + (None,) + grads[4:]
         if dloss is not None:
             y32 = y.float().contiguous()
             dl = torch.empty_like(y32)
@@ -347,7 +366,8 @@ class _UNetFunction(torch.autograd.Function):
         module, plan = ctx.module, ctx.plan
         check(_lib.load().e3_unet_set_rrelu(plan.handle, *(ctx.rrelu if ctx.rrelu is not None else (0.0, 0.0, 0))))
         flat, views, dx = _native_backward(plan, dy, ctx.x32, ctx.tens, ctx.saved_buf, ctx.b16, ctx.needs_input_grad[3],
-                                           getattr(module, '_grad_sync', None), frozen=ctx.frozen)
+                                           getattr(module, '_grad_sync', None), frozen=ctx.frozen, loss=getattr(ctx, 'loss_bwd', None))
+        ctx.loss_bwd = None
         ctx.saved_buf = ctx.x32 = ctx.tens = None   # free the activations now
         named = list(module._named_table_params(plan))
         lowp_dtype = next((p.dtype for _, p in named if p.dtype != torch.float32), None)

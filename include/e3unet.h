@@ -160,6 +160,17 @@ int e3_unet_backward2(e3_unet_plan* plan, void* stream, const float* dy, const f
                       void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
                       void* bucket_event, int bucket_after_down_block, uint32_t flags);
 
+/* e3_unet_backward2 behind e3_unet_forward_loss: the loss IS the criterion of that forward, so dLoss/dlogits never becomes a tensor -- the
+ * backward kernels of the head form it in registers from y (the logits that forward wrote), loss->target, loss->class_weight and the
+ * coefficients in loss->workspace, and the head's own weight / bias gradients come out of the pass over the network's last raw tensor that
+ * the BatchNorm backward makes anyway (no e3_ce_dice_bwd pass, no separate head-backward pass; criterion(out, target).backward() of
+ * training/trainer.py:520-524,539).  gout: device scalar d(final)/d(loss), or NULL = 1 (a GradScaler's scale).  2..4 classes and a
+ * normalisation in front of the head; anything else returns E3_ERR_UNSUPPORTED and the caller takes e3_ce_dice_bwd + e3_unet_backward2. */
+int e3_unet_backward_loss(e3_unet_plan* plan, void* stream, const float* y, const e3_ce_dice_args* loss, const float* gout, const float* x,
+                          int N, int D, int H, int W, void* const* params, void* const* grads, float* dx,
+                          void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                          void* bucket_event, int bucket_after_down_block, uint32_t flags);
+
 /* Per-layer profiling hook used by bench.py for the roofline line: when `layer` >= 0, hipEvents are recorded
  * around that layer's dominant kernel in every subsequent forward (which=0), dgrad (1) or wgrad (2); read the
  * mean duration of all recorded launches (and reset) with e3_unet_profile_read.  `layer` indexes the conv list
