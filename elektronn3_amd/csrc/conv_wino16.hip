@@ -37,8 +37,9 @@ constexpr int Q_RPLANE = 4 * Q_CLASS * 8 + 16;              // floats of one raw
 constexpr int Q_RBUF = 6 * Q_RPLANE;                        // 6 raw planes: 12.4 KB per stage buffer
 constexpr int Q_EX = 4 * 8 * 64 * 4;                        // epilogue exchange [pd][(oh, ow, half)][lane][4] floats (32 KB)
 constexpr int Q_SCR = 4 * 32 * 3;                           // cross-wave merge of the statistics
-constexpr int Q_RUN = 17 * 256;                             // running statistics of every thread: n, mean[8], M2[8]
-constexpr int Q_LDS_FLOATS = 2 * Q_RBUF + Q_EX + Q_SCR + Q_RUN;   // 75 KB: two workgroups per CU
+constexpr int Q_RUN = 20 * 256;                             // running statistics of every thread: n, mean[8], M2[8] ([k][thread]; BNRED: [thread][20], 16 sums)
+constexpr int Q_KST = 4 * 32;                               // BNRED: scale / shift / mean / invstd of the workgroup's 32 channels
+constexpr int Q_LDS_FLOATS = 2 * Q_RBUF + Q_EX + Q_SCR + Q_RUN + Q_KST;   // 76 KB: two workgroups per CU
 
 typedef float f32x2q __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4q;
@@ -48,7 +49,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_q;
 // the stride-2 tile origins contiguous); its 16-byte half q sits at q ^ ((zh >> 1) & 1), so that the 32 lanes of a ds_read_b64 group (16 tiles x 2
 // channel pairs) cover all 64 banks.
 
-template <bool AFF>
+// BNRED (data gradients): the epilogue also takes the REDUCE sums of the BatchNorm backward of the unit in front (ConvArgs::br_*)
+template <bool AFF, bool BNRED = false>
 __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, const unsigned nblk, const int wgstats) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -104,11 +106,11 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
 #ifdef E3_W16_TIMING
     const bool do_stats = false;
 #else
-    const bool do_stats = !AFF && a.stats != nullptr;
+    const bool do_stats = !AFF && !BNRED && a.stats != nullptr;
 #endif
-    if (do_stats) {
+    if (do_stats || BNRED) {
 #pragma unroll
-        for (int k = 0; k < 17; ++k) run[k * 256] = 0.f;
+        for (int k = 0; k < 20; ++k) run[k * 256] = 0.f;
     }
 
     // ---- the workgroup's bricks: XCD x owns a contiguous eighth of the logical (XCD-blocked) brick range, its workgroups walk it with
@@ -177,6 +179,12 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
 #endif
     E3_BRICK_VARS(P_); E3_BRICK_VARS(N_);
     E3_DECODE(P_, L, true);
+    if (BNRED && tid < 128) {      // (one column tile per workgroup in this mode: the constants of its 32 channels, once)
+        const KArgs e = KA();
+        const float* const src = (tid >> 5) == 0 ? e->br_scale : ((tid >> 5) == 1 ? e->br_shift : ((tid >> 5) == 2 ? e->br_mean : e->br_invstd));
+        const int ch = P_n0 + (tid & 31);
+        (scr + Q_SCR + Q_RUN)[tid] = ch < e->Ncols ? src[ch] : 0.f;
+    }
     {   // prologue: unit 0 staged, its weights requested
         issue_dma(P_xorg, P_mask, 0, cur);
         const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P_wbase), 0, NCH * 64 * 1024, 0x00020000);
@@ -292,6 +300,26 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
                 }
             }
         }
+        // BNRED: the raw tensor of the unit in front at this lane's two voxels (requested once the accumulators are dead, used behind the stores)
+        f32x4 bx[2][2];
+        const int gh = h0 + 2 * tth + (wave >> 1), gw = w0 + 2 * ttw + (wave & 1), gd = d0 + 2 * ttd;
+        const bool vox_ok = gh < H && gw < W;
+        const bool ok0 = vox_ok && gd < D, ok1 = vox_ok && gd + 1 < D;
+        if (BNRED) {
+            const KArgs e = KA();
+            const int bl = e->br_ldc;
+            const size_t plane_b = (size_t)H * W * bl;
+            const size_t brem = (size_t)(D - d0) * plane_b * 4;
+            const __amdgpu_buffer_rsrc_t x2_rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(e->br_x) + ((size_t)P_nb * D + d0) * plane_b, 0, (int)(brem < 0x7fffffffu ? brem : 0x7fffffffu), 0x00020000);
+            const unsigned b_off = (unsigned)((((2 * ttd * H + gh) * W + gw) * bl + nq) * 4);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const bool cok = nq + 4 * hf < e->Ncols;
+                bx[0][hf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x2_rs, (ok0 && cok) ? b_off + 16 * hf : OOB, 0, 0));
+                bx[1][hf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x2_rs, (ok1 && cok) ? b_off + 16 * hf : OOB, (int)(plane_b * 4), 0));
+            }
+        }
         // A^T m A over (ph, pw) in registers (`ex` is its own LDS region: the next brick's first chunk is already in the stage buffers)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -339,10 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
         const size_t yrem = (size_t)(D - d0) * plane_y * 4;
         const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(
             KA()->y + ((size_t)P_nb * D + d0) * plane_y, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
-        const int gh = h0 + 2 * tth + oh, gw = w0 + 2 * ttw + ow, gd = d0 + 2 * ttd;
         const unsigned y_voff = (unsigned)((((2 * ttd * H + gh) * W + gw) * yl + nq) * 4);
-        const bool vox_ok = gh < H && gw < W;
-        const bool ok0 = vox_ok && gd < D, ok1 = vox_ok && gd + 1 < D;
         const int od_off = (int)(plane_y * 4);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -352,6 +377,65 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4q, y[1][hf]), y_rs, (ok1 && cok) ? y_voff + 16 * hf : OOB, od_off, 0);
         }
         TSTAMP(35);
+        if (BNRED) {
+            // dz = dA * act'(z), z = x * scale + shift;  xhat = (x - mean) * invstd  (the expressions of bn_bwd_kernel); running sums of this
+            // lane's 8 channels in LDS, one partial row per workgroup at the end
+            const KArgs e = KA();
+            const int eN = e->Ncols;
+            const float slope = e->br_slope;
+            const float* const kst = scr + Q_SCR + Q_RUN;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(kst + 0 * 32 + 8 * kk + 4 * hf);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(kst + 1 * 32 + 8 * kk + 4 * hf);
+                const f32x4 mu = *reinterpret_cast<const f32x4*>(kst + 2 * 32 + 8 * kk + 4 * hf);
+                const f32x4 is = *reinterpret_cast<const f32x4*>(kst + 3 * 32 + 8 * kk + 4 * hf);
+                f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+#pragma unroll
+                for (int od = 0; od < 2; ++od) {
+                    const bool okd = od ? ok1 : ok0;
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const float xv = bx[od][hf][e4];
+                        const float z = __builtin_fmaf(xv, sc[e4], sh[e4]);
+                        const float dz = okd ? act_bwd(z, y[od][hf][e4], slope) : 0.f;
+                        const float xh = (xv - mu[e4]) * is[e4];
+                        s1[e4] += dz; s2[e4] = __builtin_fmaf(dz, xh, s2[e4]);
+                    }
+                }
+                float* const r2 = scr + Q_SCR + tid * 20 + 4 * hf;
+                *reinterpret_cast<f32x4*>(r2) += s1;
+                *reinterpret_cast<f32x4*>(r2 + 8) += s2;
+            }
+            if (!has_next) {       // (uniform) sums over the 16 tiles of a lane group, then the 4 waves, fixed order; row = the workgroup
+                float f1[8], f2[8];
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) { f1[ch] = (scr + Q_SCR + tid * 20)[ch]; f2[ch] = (scr + Q_SCR + tid * 20)[8 + ch]; }
+#pragma unroll
+                for (int sft = 1; sft < 16; sft <<= 1)
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) { f1[ch] += __shfl_xor(f1[ch], sft); f2[ch] += __shfl_xor(f2[ch], sft); }
+                if (tl == 0) {
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) {
+                        float* sc_ = scr + (wave * 32 + 8 * kk + ch) * 3;
+                        sc_[0] = f1[ch]; sc_[1] = f2[ch];
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (tid < 32 && n0 + tid < eN) {
+                    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { t1 += scr[(w * 32 + tid) * 3]; t2 += scr[(w * 32 + tid) * 3 + 1]; }
+                    const unsigned nt_ = (unsigned)e->ntiles;
+                    const size_t row = (size_t)((blockIdx.x & 7u) * ((gridDim.x >> 3) / nt_) + (blockIdx.x >> 3) / nt_);
+                    float* o = e->br_part + row * 3 * (size_t)eN + n0 + tid;
+                    o[0] = t1; o[eN] = t2;
+                }
+            }
+        }
         if (do_stats) {
             // running record of this lane's 8 channels: Chan merge of the brick's (up to) two values per channel, approximate reciprocal
             // (its error is far below the rounding of the sums)
@@ -434,6 +518,8 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
 // ---- host side
 int wino16_bricks(int N, int D, int H, int W) { return N * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 8); }
 
+// one column tile per workgroup and every column tile covered by the workgroups of a row: XCD ranges that start at multiples of ntiles and a
+// stride of 64 logical bricks that is one too
 static bool wino16_wgstats(size_t nblk, int ntiles, unsigned grid) {
     return grid == 512u && nblk > 512 && nblk % 8 == 0 && (nblk / 8) % (size_t)ntiles == 0 && 64 % ntiles == 0;
 }
@@ -447,9 +533,18 @@ int conv_wino_layout(int flags, int D, int H, int W, int K, int ncols, int split
     // ahead of it -- E3_WINO16=1 selects it (A/B switch; tests/test_switches_gpu.py runs the parity suites with it)
     static const bool enabled = getenv("E3_WINO16") != nullptr && getenv("E3_NO_WINO16") == nullptr;
     static const size_t minblk = getenv("E3_WINO16_MIN") ? (size_t)atol(getenv("E3_WINO16_MIN")) : 512;
-    if (!enabled || splitk > 1 || (flags & 1024) || (ncols & 3) || (K & 7)) return 0;
+    if (splitk > 1 || (flags & 1024) || (ncols & 3) || (K & 7)) return 0;
+    if (flags & CF_BNRED) return 1;       // (the caller checked conv_wino16_bnred_parts(): only this kernel has the fused reduction)
+    if (!enabled) return 0;
     const size_t nblk1 = (size_t)wino16_bricks(1, D, H, W) * ((ncols + 31) / 32);
     return nblk1 >= minblk ? 1 : 0;
+}
+
+int conv_wino16_bnred_parts(int N, int D, int H, int W, int K, int ncols) {
+    if ((ncols & 3) || (K & 7)) return 0;
+    const int ntiles = (ncols + 31) / 32;
+    const size_t nblk = (size_t)wino16_bricks(N, D, H, W) * ntiles;
+    return wino16_wgstats(nblk, ntiles, nblk > 512 ? 512u : (unsigned)nblk) ? 512 / ntiles : 0;
 }
 
 int wino16_stats_parts(int N, int D, int H, int W, int ncols) {
@@ -497,7 +592,14 @@ int launch_conv3_wino16(ConvArgs a, hipStream_t s) {
     const unsigned gcap = (gover && !a.stats) ? gover : full;
     const unsigned grid = nblk >= gcap ? gcap : (unsigned)nblk;
     const int wgstats = (a.stats && wino16_wgstats(nblk, a.ntiles, grid)) ? 1 : 0;
-    if (a.epi_scale) hipLaunchKernelGGL(conv3_wino16_kernel<true>, dim3(grid), dim3(256), lds, s, a, (unsigned)nblk, wgstats);
+    if (a.flags & CF_BNRED) {
+        E3_REQUIRE(a.br_x && a.br_scale && a.br_shift && a.br_mean && a.br_invstd && a.br_part && !a.stats && !a.epi_scale && !a.bias && a.box_hi[0] <= 0 &&
+                   (a.br_ldc & 3) == 0 && ((uintptr_t)a.br_x & 15) == 0 && a.cu_reserve == 0, E3_ERR_INVALID, "conv with the fused BatchNorm-backward reduction: bad arguments");
+        E3_REQUIRE(wino16_wgstats(nblk, a.ntiles, grid), E3_ERR_INVALID, "conv with the fused BatchNorm-backward reduction: the grid does not tile (conv_wino16_bnred_parts)");
+        static bool attr2 = false;
+        if (!attr2) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino16_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr2 = true; }
+        hipLaunchKernelGGL((conv3_wino16_kernel<false, true>), dim3(grid), dim3(256), lds, s, a, (unsigned)nblk, 0);
+    } else if (a.epi_scale) hipLaunchKernelGGL(conv3_wino16_kernel<true>, dim3(grid), dim3(256), lds, s, a, (unsigned)nblk, wgstats);
     else hipLaunchKernelGGL(conv3_wino16_kernel<false>, dim3(grid), dim3(256), lds, s, a, (unsigned)nblk, wgstats);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;

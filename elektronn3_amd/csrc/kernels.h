@@ -16,6 +16,7 @@ enum ConvFlags {
     CF_NO_WINO = 8,     // direct kernels only (set by callers that pass a BN+ReLU prologue)
     CF_NO_PERSIST = 16, // one brick per workgroup even on large grids: a collective may hold CUs while this kernel runs, and a static
                         // 256-workgroup kernel that does not get all 256 CUs at once needs a full second round
+    CF_BNRED = 64,      // data-gradient launch that carries the REDUCE pass of the BatchNorm backward in front (ConvArgs::br_*): takes conv3_wino16_kernel
     CF_SPLITK_OK = 32,  // the caller can run the conv split over its input channels (conv_wino_splitk): count the splits when deciding
                         // whether the Winograd grid is large enough
 };
@@ -49,7 +50,16 @@ struct ConvArgs {
     // residency round of one workgroup per CU (the persistent Winograd kernel) launch 256 - cu_reserve workgroups, so that they all fit
     // beside the resident workgroups of a collective running on a side stream (data-parallel backward)
     int cu_reserve;
+    // REDUCE pass of a BatchNorm backward fused into the epilogue of a DATA-GRADIENT launch (conv3_wino16_kernel only, flag CF_BNRED): the
+    // conv's output y IS dA, the gradient w.r.t. the activation of the unit in front; with that unit's raw tensor br_x and its constants the
+    // epilogue also takes sum dz and sum dz * xhat per channel (dz = dA * act'(x*scale + shift), xhat = (x - mean) * invstd) -- one record per
+    // workgroup, br_part[row][3][Ncols] rows 0 and 1 like bn_bwd_kernel's, conv_wino16_bnred_parts() rows -- so the separate pass over
+    // (dA, x) disappears.  Constant slope activations only.
+    const float* br_x; int br_ldc; const float *br_scale, *br_shift, *br_mean, *br_invstd; float br_slope; float* br_part;
 };
+// CF_BNRED launches: 0 when the launch cannot carry the reduction (grid does not tile into one column tile per workgroup), else the number of
+// partial rows it writes
+int conv_wino16_bnred_parts(int N, int D, int H, int W, int K, int ncols);
 
 // number of stats records (rows of [Cout][3]) the conv will write
 int conv_stats_parts(ConvKind kind, int flags, int N, int D, int H, int W, int sd, int Cin, int ncols);
