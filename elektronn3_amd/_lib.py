@@ -46,7 +46,7 @@ class TileView(ctypes.Structure):
 class CEDiceArgs(ctypes.Structure):
     """e3_ce_dice_args of include/e3unet.h (criterion evaluated inside the head, e3_unet_forward_loss)."""
     _fields_ = [('target', c_void_p), ('class_weight', c_void_p), ('ce_weight', c_float), ('dice_weight', c_float), ('eps', c_float), ('smooth', c_float),
-                ('workspace', c_void_p), ('workspace_bytes', c_size_t), ('loss_out', c_void_p)]
+                ('workspace', c_void_p), ('workspace_bytes', c_size_t), ('loss_out', c_void_p), ('sums_out', c_void_p)]
 
 
 _P = c_void_p  # device pointer

@@ -159,6 +159,7 @@ size_t ce_dice_workspace_floats(int C);
 constexpr int CE_DICE_MAX_ROWS = 4096;      // partial rows the workspace holds (ce_dice_fwd_kernel writes 1024, the fused head up to 4096)
 // loss and backward coefficients from `rows` partial rows already in the workspace (the second half of launch_ce_dice_fwd)
 int launch_ce_dice_finalize(const float* w, int C, int rows, float a, float b, float eps, float smooth, float* workspace, float* loss_out, hipStream_t s);
+int launch_ce_dice_sums_rows(int C, int rows, const float* workspace, double* sums, hipStream_t s);
 int launch_ce_dice_fwd(const float* logits, const long long* target, const float* w, int C, int N, size_t vps, float a, float b,
                        float eps, float smooth, float* workspace, float* loss_out, hipStream_t s);
 int launch_ce_dice_sums(const float* logits, const long long* target, const float* w, int C, int N, size_t vps, float* workspace,

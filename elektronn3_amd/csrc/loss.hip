@@ -198,6 +198,14 @@ int launch_ce_dice_finalize(const float* w, int C, int rows, float a, float b, f
     return E3_OK;
 }
 
+// the 2 + 3C sums of `rows` partial rows already in the workspace (a fused head wrote them): the first half of a sharded criterion
+int launch_ce_dice_sums_rows(int C, int rows, const float* workspace, double* sums, hipStream_t s) {
+    if (C < 2 || C > LOSS_MAXC || rows < 1 || rows > CE_DICE_MAX_ROWS) { e3_set_error("ce_dice_sums: bad class / row count"); return E3_ERR_INVALID; }
+    hipLaunchKernelGGL(ce_dice_sums_kernel, dim3(1), dim3(1024), 0, s, workspace, rows, C, sums);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
+
 int launch_ce_dice_sums(const float* logits, const long long* target, const float* w, int C, int N, size_t vps, float* workspace,
                         double* sums, hipStream_t s) {
     float* partial = workspace;

@@ -630,7 +630,7 @@ int e3_unet_forward(e3_unet_plan* plan, void* stream, const float* x, int N, int
 int e3_unet_forward_loss(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
                          void* const* params, const float* momenta, float* y,
                          void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const e3_ce_dice_args* loss) {
-    E3_REQUIRE(plan && loss && loss->target && loss->workspace && loss->loss_out, E3_ERR_INVALID, "forward_loss: null criterion argument");
+    E3_REQUIRE(plan && loss && loss->target && loss->workspace && (loss->loss_out || loss->sums_out), E3_ERR_INVALID, "forward_loss: null criterion argument");
     E3_REQUIRE(!(flags & E3_FWD_SOFTMAX), E3_ERR_INVALID, "forward_loss: the criterion takes logits (no E3_FWD_SOFTMAX)");
     E3_REQUIRE(plan->cfg.out_channels >= 2, E3_ERR_INVALID, "forward_loss: the criterion needs at least two classes");
     E3_REQUIRE(loss->workspace_bytes >= ce_dice_workspace_floats(plan->cfg.out_channels) * sizeof(float), E3_ERR_WORKSPACE, "ce_dice workspace too small");
@@ -945,8 +945,11 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             RUN(launch_conv_final_fwd_loss(fused ? lb.raw : cur, fused ? lu.cout : cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y,
                                            cfg.out_channels, ND.Y.vox / N, N, s, fused ? lb.scale : nullptr, fused ? lb.shift : nullptr, head_act,
                                            la->target, la->class_weight, (float*)la->workspace, CE_DICE_MAX_ROWS, &rows));
-            RUN(launch_ce_dice_finalize(la->class_weight, cfg.out_channels, rows, la->ce_weight, la->dice_weight, la->eps, la->smooth,
-                                        (float*)la->workspace, la->loss_out, s));
+            if (la->sums_out)       // sharded minibatch: the caller sums these over the ranks and finishes with e3_ce_dice_from_sums
+                RUN(launch_ce_dice_sums_rows(cfg.out_channels, rows, (const float*)la->workspace, la->sums_out, s));
+            else
+                RUN(launch_ce_dice_finalize(la->class_weight, cfg.out_channels, rows, la->ce_weight, la->dice_weight, la->eps, la->smooth,
+                                            (float*)la->workspace, la->loss_out, s));
         } else if (view) {      // only the kept region, straight into its place in the output volume
             const int lo[3] = {roi[0], roi[1], roi[2]}, size[3] = {roi[3] - roi[0], roi[4] - roi[1], roi[5] - roi[2]};
             RUN(launch_conv_final_fwd_box(cur, cur_ldc, plan->chan(0), P(plan->p_final_w), P(plan->p_final_b), y, cfg.out_channels, N, ND.Y.D, ND.Y.H, ND.Y.W,

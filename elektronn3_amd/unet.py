@@ -154,9 +154,15 @@ def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, traini
             loss['ws'] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             loss['out'] = torch.empty((), dtype=torch.float32, device=dev)
             w = loss['weight']
+            reduce_sums = loss.get('reduce_sums')      # sharded minibatch (CombinedCEDiceLoss(global_batch=True)): the sums travel between the ranks first
+            sums = torch.empty(2 + 3 * plan.out_channels, dtype=torch.float64, device=dev) if reduce_sums is not None else None
             la = _lib.CEDiceArgs(loss['target'].data_ptr(), w.data_ptr() if w is not None else None, loss['ce'], loss['dice'], loss['eps'], loss['smooth'],
-                                 loss['ws'].data_ptr(), nbytes, loss['out'].data_ptr())
+                                 loss['ws'].data_ptr(), nbytes, loss['out'].data_ptr(), sums.data_ptr() if sums is not None else None)
             check(lib.e3_unet_forward_loss(*args, ctypes.byref(la)))
+            if sums is not None:
+                sums = reduce_sums(sums)
+                check(lib.e3_ce_dice_from_sums(_lib.stream_ptr(dev), ptr(sums), w.data_ptr() if w is not None else None, plan.out_channels,
+                                               loss['ce'], loss['dice'], loss['eps'], loss['smooth'], ptr(loss['ws']), c_size_t(nbytes), ptr(loss['out'])))
             loss['in_head'] = True
         elif roi is not None and not training:      # only the voxels of `roi` are wanted (UNet.forward_roi)
             fwd_roi = lib.e3_unet_forward_roi_f16 if b16 is torch.float16 else (lib.e3_unet_forward_roi_bf16 if b16 is not None else lib.e3_unet_forward_roi)
@@ -225,12 +231,21 @@ class _UNetLossFunction(torch.autograd.Function):
             req['out'] = torch.empty((), dtype=torch.float32, device=y.device)
             y32 = y.float().contiguous()
             w = req['weight']
-            check(lib.e3_ce_dice_fwd(_lib.stream_ptr(y.device), ptr(y32), ptr(req['target']), ptr(w) if w is not None else None, C, N, *sp,
-                                     req['ce'], req['dice'], req['eps'], req['smooth'], ptr(req['ws']), c_size_t(nbytes), ptr(req['out'])))
+            if req.get('reduce_sums') is not None:      # sharded minibatch: local sums -> sum over ranks -> loss and coefficients from the totals
+                sums = torch.empty(2 + 3 * C, dtype=torch.float64, device=y.device)
+                check(lib.e3_ce_dice_sums(_lib.stream_ptr(y.device), ptr(y32), ptr(req['target']), ptr(w) if w is not None else None, C, N, *sp,
+                                          ptr(req['ws']), c_size_t(nbytes), ptr(sums)))
+                sums = req['reduce_sums'](sums)
+                check(lib.e3_ce_dice_from_sums(_lib.stream_ptr(y.device), ptr(sums), ptr(w) if w is not None else None, C,
+                                               req['ce'], req['dice'], req['eps'], req['smooth'], ptr(req['ws']), c_size_t(nbytes), ptr(req['out'])))
+            else:
+                check(lib.e3_ce_dice_fwd(_lib.stream_ptr(y.device), ptr(y32), ptr(req['target']), ptr(w) if w is not None else None, C, N, *sp,
+                                         req['ce'], req['dice'], req['eps'], req['smooth'], ptr(req['ws']), c_size_t(nbytes), ptr(req['out'])))
         ctx.ce = (req['target'], req['weight'], req['ws'])
         # the criterion went through the head (fp32 path, 2..4 classes, a norm in front of the head): its backward can stay there too
         ctx.ce_in_head = bool(req.get('in_head')) and 2 <= C <= 4 and module.normalization == 'batch' and not _NO_LOSS_BWD
         ctx.ce_w = (req['ce'], req['dice'], req['eps'], req['smooth'])
+        ctx.ce_scale = float(req.get('grad_scale', 1.0))      # (sharded minibatch with averaged gradients: x world size)
         ctx.save_for_backward(y)
         return y, req['out']
 
@@ -243,14 +258,16 @@ class _UNetLossFunction(torch.autograd.Function):
         if dloss is not None and dy is None and ctx.ce_in_head and ctx.b16 is None and y.dtype == torch.float32:
             # e3_unet_backward_loss: dLoss/dlogits is formed inside the head's backward kernels (no dlogits tensor, no e3_ce_dice_bwd pass)
             g = dloss.to(device=y.device, dtype=torch.float32).contiguous()
-            la = _lib.CEDiceArgs(target.data_ptr(), w.data_ptr() if w is not None else None, *ctx.ce_w, ws.data_ptr(), ws.numel(), None)
+            if ctx.ce_scale != 1.0:
+                g = g * ctx.ce_scale
+            la = _lib.CEDiceArgs(target.data_ptr(), w.data_ptr() if w is not None else None, *ctx.ce_w, ws.data_ptr(), ws.numel(), None, None)
             ctx.loss_bwd = (y, la, g)
             grads = _UNetFunction.backward(ctx, None)
             return grads[:4] + (None,) + grads[4:]
         if dloss is not None:
             y32 = y.float().contiguous()
             dl = torch.empty_like(y32)
-            g = dloss.to(device=y.device, dtype=torch.float32).contiguous()
+            g = dloss.to(device=y.device, dtype=torch.float32).contiguous() * ctx.ce_scale
             check(_lib.load().e3_ce_dice_bwd(_lib.stream_ptr(y.device), ptr(y32), ptr(target), ptr(w) if w is not None else None, C, N, D, H, W,
                                              ptr(ws), c_size_t(ws.numel()), ptr(g), ptr(dl)))
         if dy is not None:
@@ -1037,7 +1054,7 @@ class UNet(nn.Module):
         from .loss import CombinedCEDiceLoss
         fusable = (type(criterion) is CombinedCEDiceLoss and self.training and torch.is_grad_enabled() and self.dim == 3 and not self._per_sample_norm()
                    and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 5 and target.dtype == torch.int64 and target.is_cuda
-                   and (not criterion.global_batch or criterion._world() == 1))
+                   )
         if fusable:
             # the head kernel reads target[v] for every output voxel: the target must be exactly the logits' grid on the input's device (a target
             # on another grid -- the input size with conv_mode='valid', an (N, 1, D, H, W) tensor -- takes the separate calls, which raise
@@ -1058,6 +1075,11 @@ class UNet(nn.Module):
         w = criterion.weight
         crit = dict(weight=None if w is None else w.to(device=x.device, dtype=torch.float32).contiguous(), ce=criterion.ce_weight, dice=criterion.dice_weight,
                     eps=criterion.eps, smooth=criterion.smooth)
+        if criterion.global_batch:       # a minibatch sharded over ranks: the criterion's 2 + 3C sums are exchanged between head and finaliser
+            world = criterion._world()
+            if world != 1:
+                crit['reduce_sums'] = criterion._reduce_sums
+                crit['grad_scale'] = float(abs(world)) if criterion.grads_averaged else 1.0
         return _UNetLossFunction.apply(self, crit, want16, x, target, *params)
 
     @torch.jit.unused

@@ -126,6 +126,11 @@ typedef struct e3_ce_dice_args {
     const long long* target; const float* class_weight /* [out_channels] or NULL */;
     float ce_weight, dice_weight, eps, smooth;
     void* workspace; size_t workspace_bytes; float* loss_out;
+    /* a minibatch sharded over ranks (one process per GPU; the reference's loss is ONE loss over the gathered batch, trainer.py:520-524):
+     * non-NULL -> e3_unet_forward_loss stops at the criterion's 2 + 3 out_channels sums of THIS shard (device doubles, the layout of
+     * e3_ce_dice_sums); the caller adds them over the ranks (one all-reduce) and e3_ce_dice_from_sums(sums, ..., workspace, loss_out) writes
+     * the batch-wide loss and the coefficients e3_unet_backward_loss reads.  loss_out is not touched by the forward then. */
+    double* sums_out;
 } e3_ce_dice_args;
 int e3_unet_forward_loss(e3_unet_plan* plan, void* stream, const float* x, int N, int D, int H, int W,
                          void* const* params, const float* momenta, float* y,

@@ -178,6 +178,9 @@ def test_two_rank_step_beside_a_resident_foreign_kernel(mode, tmp_path):
             ser = torch.load(sub / f'dp{r}.pt')
             for k, b in ser['buffers'].items():
                 assert torch.equal(b, res[r]['buffers'][k]), (r, k)
+            from helpers import is_prebn_bias
             for k, g in ser['grads'].items():
+                if is_prebn_bias(k):       # analytically zero (bias in front of a train-mode BatchNorm): the value IS the rounding of the BatchNorm backward's
+                    continue               # sums, whose order differs (with a CU reserve the reduce pass is its own kernel, without it part of the data gradient)
                 err = float((res[r]['grads'][k] - g).norm()) / max(float(g.norm()), 1e-4 * gscale)
                 assert err < 1e-5, (r, k, err)

@@ -1023,6 +1023,54 @@ def test_ce_dice_loss_over_sharded_minibatch_equals_gathered_batch():
     assert abs(sum(per) / world - float(ld)) > 1e-4
 
 
+def test_forward_with_loss_on_a_sharded_minibatch_equals_the_two_calls():
+    """UNet.forward_with_loss with CombinedCEDiceLoss(global_batch=True) (what bench.py --gpus N runs per rank): the head emits the criterion's
+    2 + 3C sums of the shard, they are summed over the 'ranks' (emulated in-process), the finaliser writes the batch-wide loss and the
+    coefficients, and e3_unet_backward_loss seeds the backward from them.  Loss and parameter gradients must equal the two separate calls
+    out = model(x); loss = criterion(out, target) on the same shard with the same exchanged sums, and a scaled loss must scale the gradients."""
+    from elektronn3_amd.loss import CombinedCEDiceLoss
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(3)
+    world = 2
+    xs = [torch.randn(1, 1, 12, 20, 24, device='cuda') for _ in range(world)]
+    ts = [torch.randint(0, 2, (1, 12, 20, 24), device='cuda') for _ in range(world)]
+    ref = UNet(1, 2, n_blocks=2, start_filts=8).cuda().train()
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    # the 'all-reduce': shard sums of the unfused criterion on the logits of every shard
+    from elektronn3_amd import _lib
+    from elektronn3_amd._lib import c_size_t, check, ptr, stream_ptr
+    L = _lib.load()
+    nbytes = L.e3_ce_dice_workspace_bytes(2)
+    wt = torch.tensor([0.2653, 0.7347], device='cuda')
+    total = torch.zeros(8, dtype=torch.float64, device='cuda')
+    for xr, tr in zip(xs, ts):
+        m = UNet(1, 2, n_blocks=2, start_filts=8).cuda().train(); m.load_state_dict(sd)
+        z = m(xr).detach().contiguous()
+        ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda'); sm = torch.empty(8, dtype=torch.float64, device='cuda')
+        check(L.e3_ce_dice_sums(stream_ptr(z.device), ptr(z), ptr(tr), ptr(wt), 2, 1, 12, 20, 24, ptr(ws), c_size_t(nbytes), ptr(sm)))
+        total += sm
+
+    class Sharded(CombinedCEDiceLoss):
+        def _world(self): return world
+        def _reduce_sums(self, sums): return total.clone()
+
+    crit = Sharded(weight=[0.2653, 0.7347], global_batch=True).cuda()
+    for xr, tr in zip(xs, ts):
+        ma = UNet(1, 2, n_blocks=2, start_filts=8).cuda().train(); ma.load_state_dict(sd)
+        mb = UNet(1, 2, n_blocks=2, start_filts=8).cuda().train(); mb.load_state_dict(sd)
+        out_a, loss_a = ma.forward_with_loss(xr, tr, crit)
+        (loss_a * 1.7).backward()
+        out_b = mb(xr); loss_b = crit(out_b, tr)
+        (loss_b * 1.7).backward()
+        assert torch.equal(out_a.detach(), out_b.detach())
+        assert abs(float(loss_a.detach()) - float(loss_b.detach())) <= 2e-6 * max(1.0, abs(float(loss_b.detach())))
+        for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            ga, gb = pa.grad.cpu().numpy(), pb.grad.cpu().numpy()
+            if k.endswith('.bias') and not k.startswith('conv_final') and 'norm' not in k:
+                continue       # analytically-zero gradients (bias feeding a train-mode BN)
+            assert rel_l2(ga, gb) <= 2e-5, (k, rel_l2(ga, gb))
+
+
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
 def test_low_precision_module_trains_with_fp32_compute(dt):
     """model.bfloat16() / model.half() (BASELINE configs[2] stores the model in bf16; Predictor(float16=True)): parameters, input and
