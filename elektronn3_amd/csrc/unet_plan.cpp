@@ -1072,6 +1072,10 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
             const LevelDims& c1 = ND.u[k1].in;
             const LevelDims& o0 = ND.u[k1 - 1].out;
             if (c1.D != o0.D || c1.H != o0.H || c1.W != o0.W) continue;
+            // (measured at cfg 2: the launch costs +17..23 % with the reduction on board, the pass it replaces ~10 us at level 2, 30 at level 1, 105 at
+            // level 0 -- below 32 MB the separate pass is cheaper)
+            static const size_t min_mb = getenv("E3_BNRED_MIN_MB") ? (size_t)atol(getenv("E3_BNRED_MIN_MB")) : 32;      // (tests: 0 = wherever the grid allows)
+            if (o0.vox * (size_t)u0.cout * 4 < (min_mb << 20)) continue;
             const int parts = conv_wino16_bnred_parts(N, c1.D, c1.H, c1.W, u1.cout, u1.cin);
             if (parts > 0 && parts <= bn_bwd_parts(o0.vox, u0.cout)) bnred_parts[(size_t)k1] = parts;
         }

@@ -2,18 +2,18 @@
 # Round profile on the GPU box: kernel statistics of the default bench command (fp32 and bf16) and the PMC passes behind
 # bench.py's roofline.traffic.  Usage (inside gpurun): bash tools/profile_round.sh r03
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$PWD
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --no-cpu-baseline --no-predictor --steps 5 --warmup 2"
+BENCH="python $R/bench.py --no-cpu-baseline --no-predictor --no-extra-legs --steps 5 --warmup 2"
 for dt in f32 bf16; do
   rocprofv3 --kernel-trace --stats -d $O/stats_$dt -o run -- $BENCH --dtype $dt > $O/stats_$dt.log 2>&1
   python $R/tools/prof_summary.py $O/stats_$dt -o $O/kernel_stats_$dt.md --title "rocprofv3 --kernel-trace --stats of: bench.py --dtype $dt --steps 5 --warmup 2 (+ 2 x 2 per-layer timing steps)" > /dev/null
 done
-PB="python $R/bench.py --no-cpu-baseline --no-predictor --steps 1 --warmup 1"
+PB="python $R/bench.py --no-cpu-baseline --no-predictor --no-extra-legs --steps 1 --warmup 1"
 for dt in f32 bf16; do
   for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
     rocprofv3 --kernel-trace --pmc $c -d $O/pmc_${dt}_$c -o run --output-format csv -- $PB --dtype $dt > $O/pmc_${dt}_$c.log 2>&1
