@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
         const int gh = h0 + 2 * tth + (wave >> 1), gw = w0 + 2 * ttw + (wave & 1), gd = d0 + 2 * ttd;
         const bool vox_ok = gh < H && gw < W;
         const bool ok0 = vox_ok && gd < D, ok1 = vox_ok && gd + 1 < D;
+        auto issue_bx = [&]() {
         if (BNRED) {
             const KArgs e = KA();
             const int bl = e->br_ldc;
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
                 bx[1][hf] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x2_rs, (ok1 && cok) ? b_off + 16 * hf : OOB, (int)(plane_b * 4), 0));
             }
         }
+        };
         // A^T m A over (ph, pw) in registers (`ex` is its own LDS region: the next brick's first chunk is already in the stage buffers)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -338,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wino16_kernel(const ConvArgs a, 
 #pragma unroll
                 for (int ow = 0; ow < 2; ++ow)
                     *reinterpret_cast<f32x4*>(ex + ((wave * 8 + (oh * 2 + ow) * 2 + hf) * 64 + lane) * 4) = q[oh][ow];
+            if (hf == 0) { __builtin_amdgcn_sched_barrier(0); issue_bx(); __builtin_amdgcn_sched_barrier(0); }      // (half of the accumulators are dead: 64 registers free)
         }
         TSTAMP(33);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
