@@ -108,6 +108,10 @@ _SIG = {
                                _P, c_size_t, _P, c_size_t, _P, _I, c_uint32]),
     'e3_unet_backward_loss': (_I, [c_void_p, _P, _P, POINTER(CEDiceArgs), _P, _P, _I, _I, _I, _I, POINTER(c_void_p), POINTER(c_void_p), _P,
                                    _P, c_size_t, _P, c_size_t, _P, _I, c_uint32]),
+    'e3_unet_backward_loss_bf16': (_I, [c_void_p, _P, _P, POINTER(CEDiceArgs), _P, _P, _I, _I, _I, _I, POINTER(c_void_p), POINTER(c_void_p), _P,
+                                        _P, c_size_t, _P, c_size_t, _P, _I]),
+    'e3_unet_backward_loss_f16': (_I, [c_void_p, _P, _P, POINTER(CEDiceArgs), _P, _P, _I, _I, _I, _I, POINTER(c_void_p), POINTER(c_void_p), _P,
+                                       _P, c_size_t, _P, c_size_t, _P, _I]),
     'e3_unet_conv_count': (_I, [c_void_p]),
     'e3_unet_conv_info': (_I, [c_void_p, _I, c_char_p, _I, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     'e3_unet_profile_select': (_I, [c_void_p, _I, _I]),

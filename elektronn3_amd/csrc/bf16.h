@@ -122,6 +122,10 @@ struct BnBwdB16Args {
     // the last unit: dA is recomputed from the head's (fp32, NCDHW) logits gradient and weights instead of being read
     const float* head_dy; const float* head_w; int head_cout; size_t head_S;
     int pool_one_lane;                      // set by the launcher: one lane per pooling window instead of one per window column
+    // head form, criterion variant (head_dy == nullptr, hl_logits set; 2..4 classes): the logits gradient is formed per voxel from the logits the
+    // forward wrote, the target and the criterion's finalised coefficients (loss.hip) -- no dlogits tensor; the REDUCE pass then also takes the
+    // head's own gradient sums head_part[parts][cout * C + cout] (what conv_final_b16_bwd_kernel computes from a second pass over x)
+    const float* hl_logits; const long long* hl_target; const float* hl_cw; const float* hl_coef; const float* hl_gout; float* head_part;
 };
 int bn_bwd_b16_parts(size_t voxels, int C);
 int launch_bn_bwd_b16_reduce(BnBwdB16Args a, hipStream_t s);

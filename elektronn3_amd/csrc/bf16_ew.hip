@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool2_b16_kernel(const bf16_t* __
 // ------------------------------------------------------------------ BN + ReLU (+ pool, + skip) backward
 // dA(v) = g1(v) + [v is the first arg-max of its window] * gpool(window);  dz = dA * (z > 0), z = x*scale + shift
 // REDUCE: per-channel sum dz, sum dz*xhat.  APPLY: dx = bf16(gamma*invstd*(dz - c1 - xhat*c2)), sum dx (conv-bias gradient).
-template <bool POOL, bool APPLYPASS, bool HEAD>
+// HL > 0 (head form): criterion variant for HL classes (BnBwdB16Args::hl_*), see elementwise.hip's bn_bwd_kernel
+template <bool POOL, bool APPLYPASS, bool HEAD, int HL = 0>
 __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const BnBwdB16Args a) {
     const bool g_pool_rows = a.pool_one_lane != 0;        // the one-lane-per-window form (channel counts the lane-pair form does not cover)
     __shared__ float red[2][256][8];
@@ -180,6 +181,22 @@ __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const BnBwdB16Args a) {
     const size_t vstride = stride / Q;
     if (!POOL) {
         constexpr int U = HEAD ? 2 : 4;          // independent (x, g) pairs in flight per lane
+        constexpr bool hloss = HEAD && HL > 0, hgrad = hloss && !APPLYPASS;
+        constexpr int HC = HL > 0 ? HL : 1;
+        float lw[HC], lgn[HC], lgd[HC], law = 0.f, lg = 1.f, dbacc[HC];
+        f8 dwacc[HC], hw[HC];
+#pragma unroll
+        for (int co = 0; co < HC; ++co) {
+            lw[co] = 1.f; lgn[co] = 0.f; lgd[co] = 0.f; dbacc[co] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dwacc[co].v[e] = 0.f; hw[co].v[e] = 0.f; }
+        }
+        if (hloss) {
+#pragma unroll
+            for (int co = 0; co < HC; ++co) { lw[co] = a.hl_cw ? a.hl_cw[co] : 1.f; lgn[co] = a.hl_coef[1 + co]; lgd[co] = a.hl_coef[1 + HC + co]; hw[co] = ldf8(a.head_w + co * a.C + 8 * q); }
+            law = a.hl_coef[0]; lg = a.hl_gout ? a.hl_gout[0] : 1.f;
+        }
+        float gys[hloss ? U : 1][HC];
         for (size_t v0 = i00 / Q; active && v0 < units; v0 += U * vstride) {
             f8 xv[U], g[U]; bool ok[U];
 #pragma unroll
@@ -192,6 +209,32 @@ __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const BnBwdB16Args a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) g[u].v[e] = 0.f;
                     const size_t n = vs / a.head_S, sp = vs - n * a.head_S;
+                    if (hloss) {
+                        // dL/dlogits of this voxel: the expressions of ce_dice_bwd_kernel (loss.hip) on the logits the forward wrote
+                        float z[HC], pr[HC], m = -3.4e38f;
+#pragma unroll
+                        for (int co = 0; co < HC; ++co) { z[co] = a.hl_logits[(n * HC + co) * a.head_S + sp]; m = fmaxf(m, z[co]); }
+                        float sum = 0.f;
+#pragma unroll
+                        for (int co = 0; co < HC; ++co) { pr[co] = __expf(z[co] - m); sum += pr[co]; }
+                        const float inv = 1.f / sum;
+                        const int t = (int)a.hl_target[n * a.head_S + sp];
+                        float Gc[HC], dot = 0.f, wt = 0.f;
+#pragma unroll
+                        for (int co = 0; co < HC; ++co) {
+                            pr[co] *= inv;
+                            const bool is = t == co;
+                            Gc[co] = lgn[co] - (is ? lgd[co] : 0.f);
+                            dot += pr[co] * Gc[co];
+                            wt += is ? lw[co] : 0.f;
+                        }
+#pragma unroll
+                        for (int co = 0; co < HC; ++co) {
+                            gys[u][co] = ok[u] ? lg * (law * wt * (pr[co] - (t == co ? 1.f : 0.f)) + pr[co] * (Gc[co] - dot)) : 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) g[u].v[e] = __builtin_fmaf(gys[u][co], hw[co].v[e], g[u].v[e]);
+                        }
+                    } else
                     for (int co = 0; co < a.head_cout; ++co) {
                         const float gy = a.head_dy[(n * a.head_cout + co) * a.head_S + sp];
                         const f8 wv = ldf8(a.head_w + co * a.C + 8 * q);
@@ -214,9 +257,42 @@ __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const BnBwdB16Args a) {
                     const float xh = (xv[u].v[e] - mu.v[e]) * is.v[e];
                     if (APPLYPASS) { o.v[e] = ok[u] ? round_bf(gi.v[e] * (dz - c1.v[e] - xh * c2.v[e])) : 0.f; s1.v[e] += o.v[e]; }
                     else { s1.v[e] += dz; s2.v[e] = __builtin_fmaf(dz, xh, s2.v[e]); }
+                    if (hgrad) {       // head weight gradient: the activation the head saw (the expression of conv_final_b16_bwd_kernel's prologue)
+                        const float av = round_bf(fmaxf(z, 0.f));
+#pragma unroll
+                        for (int co = 0; co < HC; ++co) dwacc[co].v[e] = __builtin_fmaf(gys[u][co], av, dwacc[co].v[e]);
+                    }
                 }
                 if (APPLYPASS && ok[u]) st8(a.dx + (v0 + u * vstride) * a.dx_ldc + 8 * q, o);
+                if (hgrad && q == 0) {
+#pragma unroll
+                    for (int co = 0; co < HC; ++co) dbacc[co] += gys[u][co];
+                }
             }
+        }
+        if (hgrad) {        // (uniform) block partials of the head's gradients, one output row at a time: the layout of conv_final_b16_bwd_kernel
+            const int pstride = HC * a.C + HC;
+            const int tid = threadIdx.x;
+#pragma unroll
+            for (int co = 0; co < HC; ++co) {
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[0][tid][e] = active ? dwacc[co].v[e] : 0.f;
+                red[1][tid][0] = (active && q == 0) ? dbacc[co] : 0.f;
+                __syncthreads();
+                for (int t = tid; t < Q * 8; t += 256) {
+                    const int e = t & 7, qq = t >> 3;
+                    float acc = 0.f;
+                    for (int k = qq; k < BT; k += Q) acc += red[0][k][e];
+                    a.head_part[(size_t)blockIdx.x * pstride + co * a.C + 8 * qq + e] = acc;
+                }
+                if (tid == 0) {
+                    float acc = 0.f;
+                    for (int k = 0; k < BT; k += Q) acc += red[1][k][0];
+                    a.head_part[(size_t)blockIdx.x * pstride + HC * a.C + co] = acc;
+                }
+            }
+            __syncthreads();
         }
     } else if ((Q & (Q - 1)) == 0 && Q <= 32 && !g_pool_rows) {
         // A window's two w-columns go to two lanes (lane ^ Q): 2Q consecutive lanes then read 2 voxels x C channels = ONE contiguous run
@@ -709,7 +785,20 @@ static int bn_bwd_b16_launch(BnBwdB16Args a, bool apply, hipStream_t s) {
     E3_REQUIRE(a.C % 8 == 0 && a.C <= 2048 && a.x_ldc % 8 == 0, E3_ERR_UNSUPPORTED, "bf16 passes need channel counts that are multiples of 8");
     const dim3 grid(a.parts), block(256);
     const bool pool = a.gpool != nullptr, head = a.g1 == nullptr && !pool;
-    if (head) E3_REQUIRE(a.head_dy && a.head_w, E3_ERR_INVALID, "bn backward: no incoming gradient");
+    if (head) E3_REQUIRE((a.head_dy || a.hl_logits) && a.head_w, E3_ERR_INVALID, "bn backward: no incoming gradient");
+    if (head && a.hl_logits) {      // criterion variant (+ the head's own gradients in the REDUCE pass)
+        E3_REQUIRE(a.head_cout >= 2 && a.head_cout <= 4 && a.hl_target && a.hl_coef && (apply || a.head_part), E3_ERR_UNSUPPORTED, "bn backward, criterion form: 2..4 classes");
+        switch (a.head_cout * 2 + (apply ? 1 : 0)) {
+            case 4: hipLaunchKernelGGL((bn_bwd_b16_kernel<false, false, true, 2>), grid, block, 0, s, a); break;
+            case 5: hipLaunchKernelGGL((bn_bwd_b16_kernel<false, true, true, 2>), grid, block, 0, s, a); break;
+            case 6: hipLaunchKernelGGL((bn_bwd_b16_kernel<false, false, true, 3>), grid, block, 0, s, a); break;
+            case 7: hipLaunchKernelGGL((bn_bwd_b16_kernel<false, true, true, 3>), grid, block, 0, s, a); break;
+            case 8: hipLaunchKernelGGL((bn_bwd_b16_kernel<false, false, true, 4>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((bn_bwd_b16_kernel<false, true, true, 4>), grid, block, 0, s, a); break;
+        }
+        E3_CHECK_HIP(hipGetLastError());
+        return E3_OK;
+    }
     if (pool) {
         if (apply) hipLaunchKernelGGL((bn_bwd_b16_kernel<true, true, false>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((bn_bwd_b16_kernel<true, false, false>), grid, block, 0, s, a);

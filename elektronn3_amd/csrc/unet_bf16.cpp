@@ -296,11 +296,38 @@ static int forward_b16_impl(e3_unet_plan* plan, void* stream, const void* x, int
     return E3_OK;
 }
 
+// the criterion's request of e3_unet_backward_loss_bf16: dLoss/dlogits is formed inside the head's backward kernels
+struct HeadLossReqB { const float* logits; const long long* target; const float* cw; const float* coef; const float* gout; };
+static int backward_b16_impl(e3_unet_plan* plan, void* stream, const float* dy, const HeadLossReqB* hl, const void* x, int N, int D, int H, int W,
+                             void* const* params, void* const* grads, void* dx,
+                             void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                             void* bucket_event, int bucket_after_down_block);
+
 int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, const void* x, int N, int D, int H, int W,
                           void* const* params, void* const* grads, void* dx,
                           void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
                           void* bucket_event, int bucket_after_down_block) {
-    E3_REQUIRE(plan && dy && x && params && grads && saved && scratch, E3_ERR_INVALID, "null argument");
+    E3_REQUIRE(dy, E3_ERR_INVALID, "null argument");
+    return backward_b16_impl(plan, stream, dy, nullptr, x, N, D, H, W, params, grads, dx, saved, saved_bytes, scratch, scratch_bytes, bucket_event, bucket_after_down_block);
+}
+
+int e3_unet_backward_loss_bf16(e3_unet_plan* plan, void* stream, const float* y, const e3_ce_dice_args* loss, const float* gout, const void* x,
+                               int N, int D, int H, int W, void* const* params, void* const* grads, void* dx,
+                               void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                               void* bucket_event, int bucket_after_down_block) {
+    E3_REQUIRE(plan && y && loss && loss->target && loss->workspace, E3_ERR_INVALID, "null argument");
+    const int C = plan->cfg.out_channels;
+    E3_REQUIRE(loss->workspace_bytes >= e3_ce_dice_workspace_bytes(C), E3_ERR_WORKSPACE, "ce_dice workspace too small");
+    if (!(C >= 2 && C <= 4)) { e3_set_error("e3_unet_backward_loss: needs 2..4 classes"); return E3_ERR_UNSUPPORTED; }
+    const HeadLossReqB hl{y, loss->target, loss->class_weight, (const float*)loss->workspace + (size_t)CE_DICE_MAX_ROWS * (2 + 3 * C), gout};
+    return backward_b16_impl(plan, stream, nullptr, &hl, x, N, D, H, W, params, grads, dx, saved, saved_bytes, scratch, scratch_bytes, bucket_event, bucket_after_down_block);
+}
+
+static int backward_b16_impl(e3_unet_plan* plan, void* stream, const float* dy, const HeadLossReqB* hl, const void* x, int N, int D, int H, int W,
+                             void* const* params, void* const* grads, void* dx,
+                             void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                             void* bucket_event, int bucket_after_down_block) {
+    E3_REQUIRE(plan && (dy || hl) && x && params && grads && saved && scratch, E3_ERR_INVALID, "null argument");
     E3_REQUIRE(supported(plan->cfg), E3_ERR_UNSUPPORTED, "configuration not on the native bf16 path");
     E3_REQUIRE(dx == nullptr, E3_ERR_UNSUPPORTED, "the native bf16 path does not compute the gradient of the network input");
     hipStream_t s = (hipStream_t)stream;
@@ -316,7 +343,7 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
     const int C0 = plan->chan(0);
     const int nunits = (int)plan->units.size();
 
-    {   // 1x1x1 head: dW, db (its data gradient is recomputed by the last unit's BN backward)
+    if (!hl) {   // 1x1x1 head: dW, db (its data gradient is recomputed by the last unit's BN backward); e3_unet_backward_loss: that pass takes them along
         const UnitB& last = B.ub[nunits - 1];
         const int parts = conv_final_b16_bwd_parts(ND.Y.vox);
         const int ps = cfg.out_channels * C0 + cfg.out_channels;
@@ -358,12 +385,21 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
         {
             BnBwdB16Args a{};
             a.x = b.raw; a.x_ldc = u.cout; a.mean = b.mean; a.invstd = b.invstd; a.gamma = P(u.p_g); a.scale = b.scale; a.shift = b.shift;
-            if (k == nunits - 1) { a.g1 = nullptr; a.head_dy = dy; a.head_w = P(plan->p_final_w); a.head_cout = cfg.out_channels; a.head_S = ND.Y.vox / N; }
+            if (k == nunits - 1) {
+                a.g1 = nullptr; a.head_dy = dy; a.head_w = P(plan->p_final_w); a.head_cout = cfg.out_channels; a.head_S = ND.Y.vox / N;
+                if (hl) { a.hl_logits = hl->logits; a.hl_target = hl->target; a.hl_cw = hl->cw; a.hl_coef = hl->coef; a.hl_gout = hl->gout; a.head_part = B.slab; }
+            }
             else if (pooled_unit) { a.g1 = B.dcatB[j]; a.g1_ldc = u.cout; a.gpool = g; a.pooled = B.pooled[j]; }
             else { a.g1 = g; a.g1_ldc = g_ldc; }
             a.kd = sd; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.C = u.cout;
             a.parts = bn_bwd_b16_parts(lo.vox, u.cout); a.part = b.bnpart; a.coef = B.small; a.dx = dxr; a.dx_ldc = u.cout;
             RUN(launch_bn_bwd_b16_reduce(a, s));
+            if (a.head_part) {      // the head's gradients from the partial sums of that pass
+                const int ps = cfg.out_channels * C0 + cfg.out_channels;
+                RUN(launch_colsum_finalize(B.slab, a.parts, ps, 0, cfg.out_channels * C0, G(plan->p_final_w), s));
+                RUN(launch_colsum_finalize(B.slab, a.parts, ps, cfg.out_channels * C0, cfg.out_channels, G(plan->p_final_b), s));
+                a.head_part = nullptr;
+            }
             RUN(launch_bn_bwd_finalize(a.part, a.parts, u.cout, (float)(1.0 / (double)lo.vox), G(u.p_g), G(u.p_be), B.small, s));
             RUN(launch_bn_bwd_b16_apply(a, s));
             bias_jobs.push_back({a.part, a.parts, 3 * u.cout, 2 * u.cout, u.cout, G(u.p_b)});

@@ -194,6 +194,12 @@ def _native_backward(plan, dy, xin, tens, saved, b16, want_dx, sync=None, frozen
     with torch.cuda.device(dev):
         if loss is not None:
             y, la, gout = loss
+            if b16 is not None:
+                fn = lib.e3_unet_backward_loss_f16 if b16 is torch.float16 else lib.e3_unet_backward_loss_bf16
+                check(fn(plan.handle, _lib.stream_ptr(dev), c_void_p(y.data_ptr()), ctypes.byref(la), c_void_p(gout.data_ptr()) if gout is not None else None, *tail))
+                if sync is not None:
+                    sync.after_backward(plan)
+                return flat, views, dx
             reserve = getattr(sync, 'cu_reserve', 0) if (sync is not None and ev is not None) else 0
             check(lib.e3_unet_backward_loss(plan.handle, _lib.stream_ptr(dev), c_void_p(y.data_ptr()), ctypes.byref(la),
                                             c_void_p(gout.data_ptr()) if gout is not None else None, *tail,
@@ -244,6 +250,7 @@ class _UNetLossFunction(torch.autograd.Function):
         ctx.ce = (req['target'], req['weight'], req['ws'])
         # the criterion went through the head (fp32 path, 2..4 classes, a norm in front of the head): its backward can stay there too
         ctx.ce_in_head = bool(req.get('in_head')) and 2 <= C <= 4 and module.normalization == 'batch' and not _NO_LOSS_BWD
+        ctx.ce_b16_ok = 2 <= C <= 4 and not _NO_LOSS_BWD       # (native 16-bit paths: the criterion ran as its own pass over the fp32 logits; its backward still lives in the head's kernels)
         ctx.ce_w = (req['ce'], req['dice'], req['eps'], req['smooth'])
         ctx.ce_scale = float(req.get('grad_scale', 1.0))      # (sharded minibatch with averaged gradients: x world size)
         ctx.save_for_backward(y)
@@ -255,13 +262,13 @@ class _UNetLossFunction(torch.autograd.Function):
         target, w, ws = ctx.ce
         C, N, D, H, W = ctx.ce_dims
         dl = None
-        if dloss is not None and dy is None and ctx.ce_in_head and ctx.b16 is None and y.dtype == torch.float32:
+        if dloss is not None and dy is None and (ctx.ce_in_head or (ctx.b16 is not None and ctx.ce_b16_ok)):
             # e3_unet_backward_loss: dLoss/dlogits is formed inside the head's backward kernels (no dlogits tensor, no e3_ce_dice_bwd pass)
             g = dloss.to(device=y.device, dtype=torch.float32).contiguous()
             if ctx.ce_scale != 1.0:
                 g = g * ctx.ce_scale
             la = _lib.CEDiceArgs(target.data_ptr(), w.data_ptr() if w is not None else None, *ctx.ce_w, ws.data_ptr(), ws.numel(), None, None)
-            ctx.loss_bwd = (y, la, g)
+            ctx.loss_bwd = (y if y.dtype == torch.float32 else y.float().contiguous(), la, g)
             grads = _UNetFunction.backward(ctx, None)
             return grads[:4] + (None,) + grads[4:]
         if dloss is not None:

@@ -354,6 +354,12 @@ int e3_unet_backward_bf16(e3_unet_plan* plan, void* stream, const float* dy, con
                           void* const* params, void* const* grads, void* dx,
                           void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
                           void* bucket_event, int bucket_after_down_block);
+/* e3_unet_backward_loss on the native 16-bit paths (the criterion itself is evaluated on the fp32 logits y by e3_ce_dice_fwd / e3_ce_dice_sums + e3_ce_dice_from_sums,
+ * whose workspace this call reads): no dlogits tensor, no e3_ce_dice_bwd / head-backward pass.  2..4 classes. */
+int e3_unet_backward_loss_bf16(e3_unet_plan* plan, void* stream, const float* y, const e3_ce_dice_args* loss, const float* gout, const void* x,
+                               int N, int D, int H, int W, void* const* params, void* const* grads, void* dx,
+                               void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                               void* bucket_event, int bucket_after_down_block);
 /* Per-op entry points of the bf16 path (unit parity tests): bf16 NDHWC views, fp32 torch-layout weights / weight gradients.
  *   e3_conv3d_*_bf16    nn.Conv3d k=3 (planar: (1,3,3)), stride 1, padding 1            [unet.py:131-149]; Cin, Cout multiples of 32, or -- the
  *                       network's first conv, fwd / wgrad only -- Cin < 8 with a dense [voxel][Cin] input (x_ldc = Cin), 3x3x3, Cout % 4 == 0
@@ -392,6 +398,10 @@ int e3_unet_backward_f16(e3_unet_plan* plan, void* stream, const float* dy, cons
                           void* const* params, void* const* grads, void* dx,
                           void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
                           void* bucket_event, int bucket_after_down_block);
+int e3_unet_backward_loss_f16(e3_unet_plan* plan, void* stream, const float* y, const e3_ce_dice_args* loss, const float* gout, const void* x,
+                              int N, int D, int H, int W, void* const* params, void* const* grads, void* dx,
+                              void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                              void* bucket_event, int bucket_after_down_block);
 size_t e3_conv3d_workspace_bytes_f16(int Cin, int Cout, int N, int D, int H, int W, int planar);
 int e3_conv3d_stats_parts_f16(int Cin, int Cout, int N, int D, int H, int W, int planar);
 int e3_conv3d_fwd_f16(void* stream, const void* x, int x_ldc, int Cin, const float* w, const float* bias, void* y, int y_ldc, int Cout,

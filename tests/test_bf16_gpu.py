@@ -360,3 +360,32 @@ def test_unet_bf16_full_size_cfg3_shard_against_fp64_and_torch_bf16():
         if e1 > worst[0]:
             worst = (e1, e2, k)
     print(f'cfg 3 shard: logits p99.9 err {p_ours:.3e} (torch bf16 {p_ref:.3e}, scale {scale:.2f}); worst gradient rel-L2 {worst[0]:.3e} (torch bf16 {worst[1]:.3e}) at {worst[2]}')
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_forward_with_loss_on_the_native_16bit_path_equals_the_two_calls(dt):
+    """UNet.forward_with_loss on a 16-bit module: the criterion is its own pass over the fp32 logits, its BACKWARD lives in the head's kernels
+    (e3_unet_backward_loss_bf16 / _f16: no dlogits tensor, the head's weight / bias gradients from the last BatchNorm backward's reduce pass).
+    Loss and parameter gradients must equal the two separate calls (16-bit rounding of the per-parameter results only)."""
+    from elektronn3_amd.loss import CombinedCEDiceLoss
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(5)
+    x = torch.randn(2, 1, 16, 32, 32, device='cuda').to(dt)
+    t = torch.randint(0, 2, (2, 16, 32, 32), device='cuda')
+    crit = CombinedCEDiceLoss(weight=[0.2653, 0.7347]).cuda()
+    ref = UNet(1, 2, n_blocks=2, start_filts=32).cuda().train().to(dt)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    ma = UNet(1, 2, n_blocks=2, start_filts=32).cuda().train().to(dt); ma.load_state_dict(sd)
+    mb = UNet(1, 2, n_blocks=2, start_filts=32).cuda().train().to(dt); mb.load_state_dict(sd)
+    out_a, loss_a = ma.forward_with_loss(x, t, crit)
+    (loss_a * 64.0).backward()
+    out_b = mb(x); loss_b = crit(out_b, t)
+    (loss_b * 64.0).backward()
+    assert torch.equal(out_a.detach(), out_b.detach())
+    assert abs(float(loss_a.detach()) - float(loss_b.detach())) <= 1e-6 * max(1.0, abs(float(loss_b.detach())))
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        if k.endswith('.bias') and not k.startswith('conv_final') and 'norm' not in k:
+            continue       # analytically-zero gradients (bias feeding a train-mode BN)
+        ga, gb = pa.grad.float(), pb.grad.float()
+        err = float((ga - gb).norm()) / max(float(gb.norm()), 1e-12)
+        assert err <= 2e-2, (k, err)          # (both are rounded to 16 bits once; the sums behind them differ in order only)
