@@ -375,7 +375,10 @@ struct WinoPArgs { int s_nt, s_tw, s_th, s_td, s_nb; int wgstats; int e_tw, e_th
 
 // AFF: the folded scale / shift + ReLU epilogue (inference; no statistics) -- a compile-time split: as a run-time branch its merge cost ~50 register
 // moves per brick in both forms
-template <bool AFF>
+// TR (launches without statistics: data gradients, the folded-epilogue inference form): TRANSPOSED accumulators -- the weights are the A operand, so a lane
+// holds one tile (column) and, per register quad, 4 consecutive output channels (rows (r & 3) + 8 (r >> 2) + 4 hf): the brick leaves as 8 16-byte stores
+// per lane instead of 32 dword stores.  Same operands, same arithmetic, same exchange; only the result orientation differs.
+template <bool AFF, bool TR = false>
 __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, const unsigned nblk, const WinoPArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -627,9 +630,11 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
                     f32x16 z;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                    acc[g * 4 + p] = __builtin_amdgcn_mfma_f32_32x32x2f32(t[g][p][ks], Bv[g * 4 + p][ks], z, 0, 0, 0);
+                    acc[g * 4 + p] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(Bv[g * 4 + p][ks], t[g][p][ks], z, 0, 0, 0)
+                                        : __builtin_amdgcn_mfma_f32_32x32x2f32(t[g][p][ks], Bv[g * 4 + p][ks], z, 0, 0, 0);
                 } else {
-                    acc[g * 4 + p] = __builtin_amdgcn_mfma_f32_32x32x2f32(t[g][p][ks], Bv[g * 4 + p][ks], acc[g * 4 + p], 0, 0, 0);
+                    acc[g * 4 + p] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(Bv[g * 4 + p][ks], t[g][p][ks], acc[g * 4 + p], 0, 0, 0)
+                                        : __builtin_amdgcn_mfma_f32_32x32x2f32(t[g][p][ks], Bv[g * 4 + p][ks], acc[g * 4 + p], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -684,6 +689,22 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
         const bool nvalid = n < eN;
         constexpr bool aff = AFF;
         float bias, es, eh;
+        f32x4 tbias[4], tes[4], teh[4];      // TR: the lane's 16 channels n0 + 8 k + 4 hf .. + 3
+        if (TR) {
+            const __amdgpu_buffer_rsrc_t c_rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e->bias), 0, e->bias ? eN * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t c_rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e->epi_scale), 0, aff ? eN * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t c_rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e->epi_shift), 0, aff ? eN * 4 : 0, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int co = (n0 + 8 * k + 4 * ehf) * 4;
+                tbias[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c_rs0, co, 0, 0));
+                if (aff) {
+                    tes[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c_rs1, co, 0, 0));
+                    teh[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c_rs2, co, 0, 0));
+                }
+            }
+            bias = es = eh = 0.f;
+        } else
         {
             const __amdgpu_buffer_rsrc_t c_rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e->bias), 0, e->bias ? eN * 4 : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t c_rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e->epi_scale), 0, aff ? eN * 4 : 0, 0x00020000);
@@ -743,8 +764,13 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
             f32x4 m[4];
 #pragma unroll
             for (int pd = 0; pd < 4; ++pd) m[pd] = *reinterpret_cast<const f32x4*>(ex + ((pd * 16 + wave * 4 + k) * 64 + elane) * 4);
-            y[0][k] = m[0] + m[1] + m[2] + bias;
-            y[1][k] = m[1] + m1 * m[2] + m1 * m[3] + bias;
+            if (TR) {
+                y[0][k] = m[0] + m[1] + m[2] + tbias[k];
+                y[1][k] = m[1] + m1 * m[2] + m1 * m[3] + tbias[k];
+            } else {
+                y[0][k] = m[0] + m[1] + m[2] + bias;
+                y[1][k] = m[1] + m1 * m[2] + m1 * m[3] + bias;
+            }
         }
         if (aff) {
 #pragma unroll
@@ -752,7 +778,38 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y[od][k][e] = fmaxf(__builtin_fmaf(y[od][k][e], es, eh), 0.f);
+                    for (int e = 0; e < 4; ++e) y[od][k][e] = TR ? fmaxf(__builtin_fmaf(y[od][k][e], tes[k][e], teh[k][e]), 0.f) : fmaxf(__builtin_fmaf(y[od][k][e], es, eh), 0.f);
+        }
+        if (TR) {
+            // value (od, k, e): tile = lane column ej -> (td, th, tw) = (ej >> 4, (ej >> 3) & 1, ej & 7), channel n0 + 8 k + 4 hf + e:
+            // voxel (d0 + 2 td + od, h0 + 2 th + oh, w0 + 2 tw + ow), 16 bytes per (od, k)
+            const int ttd_ = ej >> 4, tth_ = (ej >> 3) & 1, ttw_ = ej & 7;
+            const int gd = d0 + 2 * ttd_, gh = h0 + 2 * tth_ + oh, gw = w0 + 2 * ttw_ + ow;
+            const unsigned t_voff = (unsigned)((((2 * ttd_ * H + gh) * W + gw) * yl + n0 + 4 * ehf) * 4);
+            const bool vok = gh < H && gw < W;
+            const bool ok0 = vok && gd < D, ok1 = vok && gd + 1 < D;
+            const int od_off = (int)(plane_y * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool cok = n0 + 8 * k + 4 * ehf < eN;
+                if (!(E3_WINO_ABL & 64)) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[0][k]), y_rs, (ok0 && cok) ? t_voff + 32 * k : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[1][k]), y_rs, (ok1 && cok) ? t_voff + 32 * k : OOB, od_off, 0);
+                }
+            }
+            TSTAMP(8);
+            TSTAMP(9);
+#ifdef E3_WINO_TIMING
+            if (tid == 0 && tbrick == 1) tstamp[15] = (long long)__builtin_amdgcn_s_memrealtime();
+            ++tbrick;
+#endif
+            if (!has_next) break;
+            {
+                const int* const pk = reinterpret_cast<const int*>(scr + 4 * 32 * 3 + 3 * 256) + wave * 64 + elane;
+                a_dst = pk[0]; rdA[0] = pk[256]; rdA[1] = pk[512];
+            }
+            P = Pn;
+            continue;
         }
         const int gw_l = w0 + 8 * ehf + ow, gh_l = h0 + oh;
         const unsigned y_voff = (unsigned)(((gh_l * W + gw_l) * yl + n) * 4);
@@ -1105,7 +1162,19 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
         pa.s_td = (int)(st % (unsigned)a.tilesD); pa.s_nb = (int)(st / (unsigned)a.tilesD);
         pa.wgstats = (a.stats && wino_wgstats(nblk, a.ntiles, pgrid)) ? 1 : 0;
         pa.e_tw = a.o_tw + a.tilesW; pa.e_th = a.o_th + a.tilesH; pa.e_td = a.o_td + a.tilesD;
-        if (a.epi_scale) hipLaunchKernelGGL(conv3_wino_pkernel<true>, dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
+        // launches without statistics whose output view allows 16-byte stores: transposed accumulators (E3_WINO_NO_TR=1: A/B switch)
+        static const bool no_tr = getenv("E3_WINO_NO_TR") != nullptr;
+        const bool tr = !no_tr && !a.stats && (a.Ncols & 3) == 0 && (a.y_ldc & 3) == 0 && ((uintptr_t)a.y & 15) == 0;
+        if (tr) {
+            static bool tattr = false;
+            if (!tattr) {
+                E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, plds));
+                E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, plds));
+                tattr = true;
+            }
+            if (a.epi_scale) hipLaunchKernelGGL((conv3_wino_pkernel<true, true>), dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
+            else hipLaunchKernelGGL((conv3_wino_pkernel<false, true>), dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
+        } else if (a.epi_scale) hipLaunchKernelGGL(conv3_wino_pkernel<true>, dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
         else hipLaunchKernelGGL(conv3_wino_pkernel<false>, dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
         E3_CHECK_HIP(hipGetLastError());
         return E3_OK;

@@ -1060,7 +1060,10 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
     // bnred_parts[k1] > 0: that launch writes the partial rows of unit k1 - 1, whose own reduce pass (a read of dA and x) is skipped.
     std::vector<int> bnred_parts((size_t)nunits, 0);
     {
-        static const bool off = getenv("E3_NO_BNRED_FUSE") != nullptr;      // A/B switch
+        // OFF by default: with the transposed-accumulator form of the persistent kernel (16-byte stores) a plain data gradient plus the separate reduce
+        // pass is 0.06 ms per step FASTER at cfg 2 than the 16-tile kernel with the reduction on board (11.70 vs 11.76 ms, same box); E3_BNRED_FUSE=1
+        // turns the fusion on (it removes 1.2 GB of HBM reads per step; tests/test_switches_gpu.py runs the parity suites with it)
+        static const bool off = getenv("E3_BNRED_FUSE") == nullptr || getenv("E3_NO_BNRED_FUSE") != nullptr;
         const int reserve_req0 = bucket_event ? (int)((flags >> 8) & 0x1fu) * 8 : 0;
         for (int k1 = 1; k1 < nunits && !off && !valid && !cfg.attention && !cfg.resunet && cfg.normalization == 1 && reserve_req0 == 0; ++k1) {
             const ConvUnit& u1 = plan->units[k1];

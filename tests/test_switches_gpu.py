@@ -15,7 +15,7 @@ FP32_TESTS = ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', '-k',
 B16_TESTS = ['tests/test_bf16_gpu.py', 'tests/test_f16_gpu.py', '-k', 'not full_size']
 GROUPS = {
     'direct_kernels': (dict(E3_CONV_NO_WINO='1', E3_WGRAD_NO_WINO='1', E3_CONV_NO_WINO2D='1', E3_WGRAD_NO_WINO2D='1'), FP32_TESTS),
-    'unfused_unbatched': (dict(E3_WINO_NO_PERSIST='1', E3_NO_SPLITK='1', E3_NO_REDUCE_BATCH='1', E3_NO_FIRST_FUSE='1', E3_UPCONV_NO_GEMM='1', E3_NO_BNRED_FUSE='1',
+    'unfused_unbatched': (dict(E3_WINO_NO_PERSIST='1', E3_NO_SPLITK='1', E3_NO_REDUCE_BATCH='1', E3_NO_FIRST_FUSE='1', E3_UPCONV_NO_GEMM='1', E3_WINO_NO_TR='1',
                                E3_NO_LOSS_BWD='1'), FP32_TESTS),
     'persistent_everywhere': (dict(E3_WINO_PERSIST_MIN='1', E3_UPCONV_NO_PERSIST='1', E3_CONV_NO_V3='1', E3_ATT_VALU='1'), FP32_TESTS),
     'b16_alternatives': (dict(E3_B16_NO_SPLITK='1', E3_B16_UP_GENERIC='1', E3_B16_BD='2', E3_B16_TW='16', E3_B16_COT='1'), B16_TESTS),
@@ -29,7 +29,8 @@ GROUPS = {
     # second Winograd decomposition (conv_wino16.hip: 16-tile bricks, two workgroups per CU) for every grid that has a brick: forward with
     # statistics, data gradients, the folded eval epilogue, the needed-region forward
     # (+ the BatchNorm-backward reduction inside the data gradients at every size whose grid tiles)
-    'wino16_bricks': (dict(E3_WINO16='1', E3_WINO16_MIN='1', E3_BNRED_MIN_MB='0'),
+    'bnred_in_the_data_gradient': (dict(E3_BNRED_FUSE='1'), ['tests/test_unet_gpu.py', '-k', 'train_step_matches_reference or full_size_cfg2 or full_size_properties or forward_with_loss']),
+    'wino16_bricks': (dict(E3_WINO16='1', E3_WINO16_MIN='1', E3_BNRED_FUSE='1', E3_BNRED_MIN_MB='0'),
                       ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', 'tests/test_predictor.py', '-k',
                        'conv3 or train_step_matches_reference or eval_forward or full_size_properties or forward_with_loss or forward_roi or needed_region or full_size_cfg2']),
 }
