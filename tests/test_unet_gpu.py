@@ -1287,6 +1287,60 @@ def test_arenas_are_not_overrun(name, kw, shape, dtype, monkeypatch):
     U.release_scratch()
 
 
+@pytest.mark.parametrize('name,kw,shape,dtype', [
+    ('cfg2', dict(n_blocks=4, start_filts=32), (2, 1, 64, 128, 128), torch.float32),
+    ('odd', dict(n_blocks=3, start_filts=16), (2, 1, 21, 45, 47), torch.float32),
+    ('odd_valid_planar', dict(n_blocks=3, start_filts=8, conv_mode='valid', planar_blocks=(0,)), (1, 1, 21, 45, 47), torch.float32),
+    ('cfg3_bf16', dict(n_blocks=4, start_filts=32), (2, 1, 64, 128, 128), torch.bfloat16),
+])
+def test_results_do_not_depend_on_what_the_arenas_and_their_surroundings_held(name, kw, shape, dtype, monkeypatch):
+    """READ-side counterpart of test_arenas_are_not_overrun (a mis-sized buffer descriptor would pass every write canary).  The
+    same training step runs twice: once with `saved`, `scratch` and 1 MiB on both sides of them -- and of the input tensor -- filled with zero
+    bytes, once with 0xFF bytes (NaN in fp32, bf16 and fp16).  A kernel that reads anything it (or an earlier kernel of the call) did not
+    write -- stale scratch, a halo read that leaves its view inside an arena, a read past the input -- would turn results into NaN or make the
+    two runs differ; logits, loss gradients and the updated running statistics must be finite and bit-identical.  (Reads that leave a buffer
+    descriptor's range return 0 by hardware: that IS the zero padding of the convolutions.)"""
+    from elektronn3_amd import unet as U
+    PAD = 1 << 20
+    fill = [0]
+
+    def framed(device, nbytes):
+        nbytes = int(nbytes)
+        big = torch.full((nbytes + 2 * PAD,), fill[0], dtype=torch.uint8, device=device)
+        return big[PAD:PAD + nbytes]
+
+    def run(byte):
+        fill[0] = byte
+        U.release_scratch()
+        torch.manual_seed(0)
+        m = U.UNet(1, 2, **kw).cuda().train()
+        if dtype != torch.float32:
+            m = m.to(dtype)
+        torch.manual_seed(1)
+        x0 = torch.randn(*shape, device='cuda').to(dtype)
+        esz = x0.element_size()
+        xb = torch.full((x0.numel() * esz + 2 * PAD,), byte, dtype=torch.uint8, device='cuda')
+        x = xb[PAD:PAD + x0.numel() * esz].view(dtype).view(shape)
+        x.copy_(x0)
+        y = m(x)
+        y.float().square().mean().backward()
+        torch.cuda.synchronize()
+        return y.detach().clone(), [p.grad.detach().clone() for p in m.parameters()], [b.detach().clone() for b in m.buffers()]
+
+    monkeypatch.setattr(U, '_alloc_saved', framed)
+    monkeypatch.setattr(U, '_get_scratch', framed)
+    ya, ga, ba = run(0x00)
+    yb, gb, bb = run(0xFF)
+    monkeypatch.undo()
+    U.release_scratch()
+    assert bool(torch.isfinite(ya.float()).all()) and bool(torch.isfinite(yb.float()).all()), name
+    assert torch.equal(ya, yb), name
+    for a, b in zip(ga, gb):
+        assert bool(torch.isfinite(b.float()).all()) and torch.equal(a, b), name
+    for a, b in zip(ba, bb):
+        assert torch.equal(a, b), name
+
+
 @pytest.mark.parametrize('case', ['unet_nb2_sf8.npz', 'unet_nb3_sf8_planar0_odd.npz', 'unet_nb2_sf32_wino_odd.npz'])
 def test_forward_with_loss_matches_the_reference_step(case):
     """UNet.forward_with_loss (the criterion evaluated inside the 1x1x1 head) against the reference's golden train step:
