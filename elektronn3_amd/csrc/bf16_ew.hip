@@ -603,46 +603,68 @@ __global__ void conv_final_b16_fwd_kernel(const bf16_t* __restrict__ a, int a_ld
     const size_t total = (size_t)N * S;
     const int sub = threadIdx.x % lpv;
     const size_t vpb = blockDim.x / lpv;
-    for (size_t v = blockIdx.x * vpb + threadIdx.x / lpv; v < (total + vpb - 1) / vpb * vpb; v += (size_t)gridDim.x * vpb) {
-        float acc[COUT];
+    // U voxels per lane group and iteration, their loads issued together (one load in flight per lane left the kernel latency-bound: 58 us for
+    // 151 MB); a workgroup's U x vpb voxels of an iteration are one contiguous run.  Same summation order per voxel.
+    constexpr int U = 4;
+    const size_t chunk = vpb * U;
+    for (size_t v0 = blockIdx.x * chunk + threadIdx.x / lpv; v0 < (total + chunk - 1) / chunk * chunk; v0 += (size_t)gridDim.x * chunk) {
+        float acc[U][COUT];
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-        const bool ok = v < total;
-        if (ok)
-            for (int q = sub; q < Q; q += lpv) {
-                f8 av = ld8(a + v * a_ldc + 8 * q);
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[u][co] = 0.f;
+        for (int q = sub; q < Q; q += lpv) {
+            f8 av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t v = v0 + u * vpb;
+                av[u] = ld8(a + (v < total ? v : 0) * a_ldc + 8 * q);
+            }
+            f8 sc, sh;
+            if (pro_scale) { sc = ldf8(pro_scale + 8 * q); sh = ldf8(pro_shift + 8 * q); }
+            f8 wv[COUT];
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                wv[co] = ldf8(w + co * C + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) wv[co].v[e] = round_bf(wv[co].v[e]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
                 if (pro_scale) {
-                    const f8 sc = ldf8(pro_scale + 8 * q), sh = ldf8(pro_shift + 8 * q);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) av.v[e] = round_bf(fmaxf(__builtin_fmaf(av.v[e], sc.v[e], sh.v[e]), 0.f));
+                    for (int e = 0; e < 8; ++e) av[u].v[e] = round_bf(fmaxf(__builtin_fmaf(av[u].v[e], sc.v[e], sh.v[e]), 0.f));
                 }
 #pragma unroll
-                for (int co = 0; co < COUT; ++co) {
-                    const f8 wv = ldf8(w + co * C + 8 * q);
+                for (int co = 0; co < COUT; ++co)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[co] = __builtin_fmaf(av.v[e], round_bf(wv.v[e]), acc[co]);
+                    for (int e = 0; e < 8; ++e) acc[u][co] = __builtin_fmaf(av[u].v[e], wv[co].v[e], acc[u][co]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            for (int off = 1; off < lpv; off <<= 1)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[u][co] += __shfl_xor(acc[u][co], off);
+            const size_t v = v0 + u * vpb;
+            if (v < total && sub == 0) {
+                const size_t n = v / S, sp = v % S;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[u][co] = round_bf(acc[u][co] + (bias ? bias[co] : 0.f));     // the module returns bf16 logits
+                if (softmax) {
+                    float m = acc[u][0];
+#pragma unroll
+                    for (int co = 1; co < COUT; ++co) m = fmaxf(m, acc[u][co]);
+                    float s = 0.f;
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) { acc[u][co] = __expf(acc[u][co] - m); s += acc[u][co]; }
+                    const float inv = 1.f / s;
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[u][co] *= inv;
                 }
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) y[(n * COUT + co) * ychan + sp] = acc[u][co];      // (ychan: voxels between the channel planes of y; = S unless y is a range of d-planes)
             }
-        for (int off = 1; off < lpv; off <<= 1)
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) acc[co] += __shfl_xor(acc[co], off);
-        if (ok && sub == 0) {
-            const size_t n = v / S, sp = v % S;
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) acc[co] = round_bf(acc[co] + (bias ? bias[co] : 0.f));     // the module returns bf16 logits
-            if (softmax) {
-                float m = acc[0];
-#pragma unroll
-                for (int co = 1; co < COUT; ++co) m = fmaxf(m, acc[co]);
-                float s = 0.f;
-#pragma unroll
-                for (int co = 0; co < COUT; ++co) { acc[co] = __expf(acc[co] - m); s += acc[co]; }
-                const float inv = 1.f / s;
-#pragma unroll
-                for (int co = 0; co < COUT; ++co) acc[co] *= inv;
-            }
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) y[(n * COUT + co) * ychan + sp] = acc[co];      // (ychan: voxels between the channel planes of y; = S unless y is a range of d-planes)
         }
     }
 }
