@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
 //     one per brick: no pre-merge launch, a tenth of the epilogue's statistic code per brick).  Where a workgroup's bricks do not all
 //     belong to one column tile (unusual grids) the records stay per brick.
 constexpr int W_PLDS_FLOATS = 2 * W_BUF + W_EX + 4 * 32 * 3 + 6 * 256;     // + the threads' running statistics and parked lane constants
+constexpr int W_POOLX = 4 * 64 * 16;                                         // fused max-pool: [wave (oh, ow)][lane][16 channels] (16 KB)
 
 struct WinoPArgs { int s_nt, s_tw, s_th, s_td, s_nb; int wgstats; int e_tw, e_th, e_td; };   // digits of the logical step gridDim / 8 between a workgroup's bricks; e_*: end (first brick + count) of the brick range per axis
 
@@ -378,7 +379,8 @@ struct WinoPArgs { int s_nt, s_tw, s_th, s_td, s_nb; int wgstats; int e_tw, e_th
 // TR (launches without statistics: data gradients, the folded-epilogue inference form): TRANSPOSED accumulators -- the weights are the A operand, so a lane
 // holds one tile (column) and, per register quad, 4 consecutive output channels (rows (r & 3) + 8 (r >> 2) + 4 hf): the brick leaves as 8 16-byte stores
 // per lane instead of 32 dword stores.  Same operands, same arithmetic, same exchange; only the result orientation differs.
-template <bool AFF, bool TR = false>
+// POOL (AFF && TR, inference): the 2x2x2 ceil-mode max-pool of the output in the epilogue (ConvArgs::pool_out)
+template <bool AFF, bool TR = false, bool POOL = false>
 __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, const unsigned nblk, const WinoPArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -797,6 +799,32 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[1][k]), y_rs, (ok1 && cok) ? t_voff + 32 * k : OOB, od_off, 0);
                 }
             }
+            if (POOL) {
+                // a Winograd tile = one pooling window: max over od in the lane, over (oh, ow) = the four waves through LDS (voxels outside the tensor
+                // do not take part: ceil_mode; NaN propagates as in nn.MaxPool3d); wave w then stores channel quad k = w of every window
+                float* const px = scr + 4 * 32 * 3 + 6 * 256;
+                auto nmax = [](float a_, float b_) { return (b_ > a_ || b_ != b_) ? b_ : a_; };
+                constexpr float NEG = -3.4028235e38f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f32x4 pm;
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) pm[e4] = nmax(ok0 ? y[0][k][e4] : NEG, ok1 ? y[1][k][e4] : NEG);
+                    *reinterpret_cast<f32x4*>(px + ((wave * 64 + elane) * 16) + 4 * k) = pm;
+                }
+                __syncthreads();
+                f32x4 best = *reinterpret_cast<const f32x4*>(px + ((0 * 64 + elane) * 16) + 4 * wave);
+#pragma unroll
+                for (int w2 = 1; w2 < 4; ++w2) {
+                    const f32x4 o2 = *reinterpret_cast<const f32x4*>(px + ((w2 * 64 + elane) * 16) + 4 * wave);
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) best[e4] = nmax(best[e4], o2[e4]);
+                }
+                const int Dp = (D + 1) >> 1, Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+                const int pd_ = (d0 >> 1) + ttd_, ph_ = (h0 >> 1) + tth_, pw_ = (w0 >> 1) + ttw_;
+                const bool pok = pd_ < Dp && ph_ < Hp && pw_ < Wp && n0 + 8 * wave + 4 * ehf < eN;
+                if (pok) *reinterpret_cast<f32x4*>(e->pool_out + ((((size_t)P.nb * Dp + pd_) * Hp + ph_) * Wp + pw_) * eN + n0 + 8 * wave + 4 * ehf) = best;
+            }
             TSTAMP(8);
             TSTAMP(9);
 #ifdef E3_WINO_TIMING
@@ -1172,7 +1200,14 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
                 E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, plds));
                 tattr = true;
             }
-            if (a.epi_scale) hipLaunchKernelGGL((conv3_wino_pkernel<true, true>), dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
+            static const bool no_pool = getenv("E3_WINO_NO_POOL") != nullptr;      // A/B switch
+            if (a.epi_scale && a.pool_out && a.pool_done && !no_pool && a.box_hi[0] <= 0 && (a.Ncols & 31) == 0) {      // + the max-pool behind it
+                constexpr int plds_pool = (W_PLDS_FLOATS + W_POOLX) * 4;
+                static bool pattr2 = false;
+                if (!pattr2) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, plds_pool)); pattr2 = true; }
+                hipLaunchKernelGGL((conv3_wino_pkernel<true, true, true>), dim3(pgrid), dim3(256), plds_pool, s, a, (unsigned)nblk, pa);
+                *a.pool_done = 1;
+            } else if (a.epi_scale) hipLaunchKernelGGL((conv3_wino_pkernel<true, true>), dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
             else hipLaunchKernelGGL((conv3_wino_pkernel<false, true>), dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
         } else if (a.epi_scale) hipLaunchKernelGGL(conv3_wino_pkernel<true>, dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);
         else hipLaunchKernelGGL(conv3_wino_pkernel<false>, dim3(pgrid), dim3(256), plds, s, a, (unsigned)nblk, pa);

@@ -56,6 +56,10 @@ struct ConvArgs {
     // workgroup, br_part[row][3][Ncols] rows 0 and 1 like bn_bwd_kernel's, conv_wino16_bnred_parts() rows -- so the separate pass over
     // (dA, x) disappears.  Constant slope activations only.
     const float* br_x; int br_ldc; const float *br_scale, *br_shift, *br_mean, *br_invstd; float br_slope; float* br_part;
+    // inference: nn.MaxPool3d(2, ceil_mode=True) of the (folded-epilogue) output taken in the conv's epilogue -- a Winograd output tile IS a pooling
+    // window -- into pool_out [N][ceil(D/2)][ceil(H/2)][ceil(W/2)][Ncols] (packed).  Honoured by the persistent Winograd kernel's transposed form only;
+    // the launcher sets *pool_done = 1 when it took the pooling along (the caller runs the pooling pass otherwise).
+    float* pool_out; int* pool_done;
 };
 // CF_BNRED launches: 0 when the launch cannot carry the reduction (grid does not tile into one column tile per workgroup), else the number of
 // partial rows it writes

@@ -732,6 +732,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
         unit_ins[k] = {cur, cur_ldc};
         const bool is_enc_conv2 = u.enc_last;
         const bool pool_after = is_enc_conv2 && u.level < nb - 1;
+        int pool_fused = 0;          // the conv's epilogue took the max-pool along (ConvArgs::pool_out)
         const int kd = u.planar ? 1 : 2;
         const float slope = cfg.act_slope;
         ActArg act = u.p_a >= 0 ? ActArg(0.f, P(u.p_a)) : ActArg(slope);
@@ -826,6 +827,8 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             if (residual) { a.y = B.res2; a.y_ldc = u.cout; a.bias = nullptr; a.stats = nullptr; }      // pure accumulations; bias + shortcut + statistics below
             parts = conv_stats_parts(kind, 0, N, ci.D, ci.H, ci.W, 2, u.cin, u.cout);
             const int S = (kind == CONV_K3) ? fwd_split(k) : 1;
+            // inference: the ceil-mode max-pool behind an encoder block rides in the conv's epilogue where the kernel can take it (a Winograd tile is a window)
+            if (pool_after && !training && !two_pass && kd == 2 && kind == CONV_K3 && es && !vcrop && !residual) { a.pool_out = B.pooled[u.level]; a.pool_done = &pool_fused; }
             if (need[k].on && kind == CONV_K3 && S == 1 && !a.stats)
                 for (int i = 0; i < 3; ++i) { a.box_lo[i] = need[k].lo[i]; a.box_hi[i] = need[k].hi[i]; }
             if (S > 1) {         // partial sums per share of the input channels, then sum + bias + statistics in one small pass
@@ -879,7 +882,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
         } else if (two_pass) {      // raw = pure accumulations; (scale, shift) = folded eval-mode BN, or (1, conv bias) without a norm
             RUN(launch_bn_relu_apply(b.raw, u.cout, b.scale, b.shift, b.act, b.act_ldc, pool_after ? B.pooled[u.level] : nullptr, kd,
                                      N, lo.D, lo.H, lo.W, u.cout, s, act));
-        } else if (pool_after) {
+        } else if (pool_after && !pool_fused) {
             RUN(launch_maxpool(b.act, b.act_ldc, B.pooled[u.level], kd, N, lo.D, lo.H, lo.W, u.cout, s));
         }
         if (u.is_up && cfg.attention) {

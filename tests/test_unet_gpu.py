@@ -482,6 +482,28 @@ def test_cfg5_tile_eval_softmax_against_fp64():
     assert float((y.sum(1) - 1).abs().max()) < 1e-5
 
 
+def test_eval_forward_with_the_pool_in_the_conv_epilogue_at_odd_sizes_against_fp64():
+    """Eval mode at start_filts=32: the ceil-mode max-pool behind an encoder block is taken in the epilogue of the persistent Winograd kernel
+    (conv3_wino_pkernel<true, true, true>, ConvArgs::pool_out; models/unet.py:244-253 pooling = MaxPool3d(2, ceil_mode=True)).  Odd extents on
+    every axis and at every level: windows that hang over the tensor's edge take part with the voxels inside only."""
+    from elektronn3_amd.unet import UNet
+    from oracle.torch_ref import unet_forward
+    torch.manual_seed(3)
+    m = UNet(1, 2, n_blocks=3, start_filts=32).cuda().train()
+    with torch.no_grad():
+        for _ in range(3):
+            m(torch.randn(2, 1, 16, 32, 32, device='cuda'))
+    m.eval()
+    for shape in [(2, 1, 37, 75, 85), (1, 1, 64, 96, 130)]:
+        x = torch.randn(*shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(11))
+        with torch.no_grad():
+            y = m(x)
+            sd = {k: v.double() if v.is_floating_point() else v for k, v in m.state_dict().items()}
+            ref = unet_forward(sd, x.double(), 3, (), training=False)
+        err = float((y.double() - ref).abs().max())
+        assert err < 1e-4, (shape, err)
+
+
 @pytest.mark.parametrize('kw', [dict(normalization='none'), dict(normalization='batch', full_norm=False, planar_blocks=(0,)),
                                 dict(merge_mode='add'), dict(merge_mode='add', normalization='none', planar_blocks=(0,)),
                                 dict(normalization='instance', planar_blocks=(0,)), dict(normalization='group', planar_blocks=(0,)),
