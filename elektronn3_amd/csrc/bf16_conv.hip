@@ -19,6 +19,9 @@
 
 namespace {
 
+// GEMM row r of a 32-row tile holds output channel swap23(r) (bits 2 and 3 exchanged): the accumulator layout of v_mfma_f32_32x32x16 then gives
+// lane (voxel, g) the channels 16 k + 8 g + 0..7 in registers 8 k .. 8 k + 7 -- 16-byte stores, two lanes = 32 contiguous bytes of a voxel's row
+__host__ __device__ __forceinline__ int swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // (a plain function: called straight from a kernel TEMPLATE, hipcc's host pass drops the kernel's stub)
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, lds_ptr_t dst, int, unsigned voff, int, int, int) {
@@ -200,10 +203,10 @@ __global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_k
             for (int t = 0; t < G::NV; ++t) {
                 const int d = d0 + dT0, h = h0 + G::RPT * (hp0 + t) + r, w = w0 + c;
                 if (d < a.D && h < a.H && w < a.W) {
-                    float* prow = a.partial + ((size_t)ksp * vox + (((size_t)n * a.D + d) * a.H + h) * a.W + w) * a.Cout + co0 + ct * 32 + 4 * g;
+                    float* prow = a.partial + ((size_t)ksp * vox + (((size_t)n * a.D + d) * a.H + h) * a.W + w) * a.Cout + co0 + ct * 32 + 8 * g;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<f32x4*>(prow + 8 * q) = f32x4{acc[ct][t][4 * q], acc[ct][t][4 * q + 1], acc[ct][t][4 * q + 2], acc[ct][t][4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(prow + 16 * (q >> 1) + 4 * (q & 1)) = f32x4{acc[ct][t][4 * q], acc[ct][t][4 * q + 1], acc[ct][t][4 * q + 2], acc[ct][t][4 * q + 3]};
                 }
             }
         E3_TICK(6);
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_k
             f32x4 bq[4], sq[4], hq[4], s1[4], s2[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int cb = co0 + ct * 32 + 8 * q + 4 * g;
+                const int cb = co0 + ct * 32 + 16 * (q >> 1) + 8 * g + 4 * (q & 1);
                 bq[q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
                 if (AFF) { sq[q] = *reinterpret_cast<const f32x4*>(a.epi_scale + cb); hq[q] = *reinterpret_cast<const f32x4*>(a.epi_shift + cb); }
                 s1[q] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -233,7 +236,8 @@ __global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_k
                 const int d = d0 + dT0, h = h0 + G::RPT * (hp0 + t) + r, w = w0 + c;
                 const bool valid = FULL || (d < a.D && h < a.H && w < a.W);
                 const int cot = co0 + ct * 32;
-                bf16_t* yrow = (a.y2 && cot >= a.y_split ? a.y2 + (cot - a.y_split) : a.y + cot) + ((((size_t)n * a.D + d) * a.H + h) * a.W + w) * a.y_ldc + 4 * g;
+                bf16_t* yrow = (a.y2 && cot >= a.y_split ? a.y2 + (cot - a.y_split) : a.y + cot) + ((((size_t)n * a.D + d) * a.H + h) * a.W + w) * a.y_ldc + 8 * g;
+                bf16x4 rprev;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f32x4 v = {acc[ct][t][4 * q], acc[ct][t][4 * q + 1], acc[ct][t][4 * q + 2], acc[ct][t][4 * q + 3]};
@@ -243,7 +247,8 @@ __global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_k
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     } else v = v + bq[q];
                     const bf16x4 rb = __builtin_convertvector(v, bf16x4);            // round to nearest even
-                    if (valid) *reinterpret_cast<bf16x4*>(yrow + 8 * q) = rb;
+                    if (q & 1) { if (valid) *reinterpret_cast<bf16x8*>(yrow + 16 * (q >> 1)) = __builtin_shufflevector(rprev, rb, 0, 1, 2, 3, 4, 5, 6, 7); }
+                    else rprev = rb;
                     if (!AFF) {               // (statistics only exist without the folded epilogue)
                         f32x4 dv = __builtin_convertvector(rb, f32x4) - bq[q];
                         if (!FULL) {
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_k
         if (ct) __syncthreads();
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int col = (e & 3) + 8 * (e >> 2) + 4 * g;
+            const int col = 16 * (e >> 3) + 8 * g + (e & 7);
             S[((wave * 2 + 0) * 32 + col) * 33 + j] = ssum[ct][e];
             S[((wave * 2 + 1) * 32 + col) * 33 + j] = ssq[ct][e];
         }
@@ -300,6 +305,264 @@ __global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_k
 }
 #undef E3_TICK
 
+// ---------------------------------------------------------------- persistent form of the 3x3x3 kernel (level-0 shapes: thousands of bricks)
+// Same arithmetic, same operands, same LDS image as conv_b16_kernel<4, 1, 3, 32, 16> (bricks of 4 x 4 x 32 voxels x 32 output channels, 16-channel
+// images), but 512 workgroups (two per CU) WALK the work items and the latency chain of a brick -- kernel arguments, index decode, staging plan, first
+// weights, halo DMA, barrier, taps, bias loads, stores, statistics, workgroup turnaround: 28 us per brick of which 3 us are matrix instructions
+// (profiles/r03_bf16_conv_experiments.md) -- is taken apart:
+//   * the image is DOUBLE-BUFFERED: the halo DMA of unit u + 1 (unit = 16-channel chunk of an item; the next item's first chunk after an item's last)
+//     is issued right after the barrier that opens unit u, one barrier per unit;
+//   * the weight ring (9 taps; 27 = 3 x 9, so slots are static) runs across units: the first taps of unit u + 1 are requested during the last taps of u;
+//   * per-lane staging constants (offset relative to the brick origin, halo coordinates) are computed once per workgroup; per item the validity of a
+//     piece is three unsigned compares, the brick coordinates come from multiply-high divisions of wave-uniform values;
+//   * BatchNorm statistics are running per-lane sums over the workgroup's items (the workgroup's output-channel group is fixed: the per-XCD item
+//     ranges and the stride are multiples of the group count), reduced through LDS ONCE: one (n, mean, M2) record per workgroup.
+// XCD x owns a contiguous range of items (neighbouring bricks share halo planes in that XCD's L2), its 64 workgroups stride through it.
+#ifndef E3_PABL
+#define E3_PABL 0      // developer builds (tools/build_b16p_variants.sh), timing only, wrong results: 1 one LDS fragment per step, 2 no weight loads in the loop, 4 no DMA, 8 no MFMAs, 16 no stores
+#endif
+struct ConvB16PArgs {
+    unsigned items, per_xcd;
+    unsigned cgroups, m_cg, per, m_per, ncol, m_ncol, tw2, m_tw2;      // divisors and their multiply-high constants (0: divisor 1)
+};
+__device__ __forceinline__ unsigned fdiv(unsigned x, unsigned m) { return m ? __umulhi(x, m) : x; }
+
+template <int CO_T>
+__global__ __launch_bounds__(256, 2) void conv_b16_pkernel(const ConvB16Args a, const ConvB16PArgs p) {
+    using G = Geo<4, 3, 32, 16>;
+    constexpr int RB = G::RB, HH = G::HH, HW = G::HW, NIW = G::NIW, NI = G::NI, IMG = G::IMG, NV = G::NV;
+    constexpr int RING = 9, TAPS = 27;
+    static_assert(G::PPV == 2 && G::KS == 1 && TAPS % RING == 0, "geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, g = lane >> 5;
+    const unsigned xcd = blockIdx.x & 7u, wi = blockIdx.x >> 3, wstride = gridDim.x >> 3;
+    const unsigned L_hi = (xcd + 1) * p.per_xcd, L_end = L_hi < p.items ? L_hi : p.items;
+    unsigned L = xcd * p.per_xcd + wi;
+    const int cg = (int)(wi - fdiv(wi, p.m_cg) * p.cgroups);            // the same for every item of this workgroup
+    const int co0 = cg * 32 * CO_T;
+    const int nch = a.Cin / 16;
+    const int xsplit_ch = a.x2 ? a.x_split / 16 : nch;
+    const size_t samp = (size_t)a.D * a.H * a.W * a.x_ldc;
+
+    // ---- lane constants of the staging plan: wave-piece wi = it * 4 + wave, lane -> (halo voxel, LDS piece); source piece = LDS piece ^ swizzle
+    unsigned relc[NIW], pz[NIW];
+#pragma unroll
+    for (int it = 0; it < NIW; ++it) {
+        const int idx = (it * 4 + wave) * 64 + lane;
+        const int v = idx >> 1, qp = idx & 1;
+        const int zw = v % HW, zh = (v / HW) % HH, zd = v / (HW * HH);
+        const int q = qp ^ ((zw >> 3) & 1);
+        relc[it] = (unsigned)((((zd * a.H + zh) * a.W + zw) * a.x_ldc) * 2 + q * 16);
+        pz[it] = v < G::HV ? (unsigned)(zd | (zh << 8) | (zw << 16)) : 0x00ffffffu;       // (a piece behind the halo: never valid)
+    }
+    // ---- lane read addresses (tap kd = kh = 0, tile 0 of the wave): 3 kw
+    unsigned rd[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int hw = j + kw, sw = (hw >> 3) & 1;
+        rd[kw] = (unsigned)(((wave * HH) * HW + hw) * RB + ((g ^ sw) << 4));
+    }
+    const size_t wstep = (size_t)a.Cout * 16;                          // elements per (tap, 16-channel chunk)
+    const bf16_t* wlane = a.wt + (size_t)(co0 + j) * 16 + g * 8;
+
+    struct Item { int d0, h0, w0, n; };
+    auto decode = [&](unsigned Li) {
+        unsigned r0 = fdiv(Li, p.m_cg);                                  // brick index (output-channel group innermost)
+        const unsigned col = fdiv(r0, p.m_per), r = r0 - col * p.per;
+        const unsigned n = fdiv(col, p.m_ncol), c2 = col - n * p.ncol;
+        const unsigned c2h = fdiv(c2, p.m_tw2), c2w = c2 - c2h * p.tw2;
+        Item it;
+        it.n = (int)n; it.d0 = (int)(r >> 2) * 4; it.h0 = (int)(2 * c2h + ((r >> 1) & 1)) * 4; it.w0 = (int)(2 * c2w + (r & 1)) * 32;
+        return it;
+    };
+    unsigned voff[NIW];
+    auto plan = [&](const Item& it) {
+        const unsigned base = (unsigned)((((it.d0 - 1) * a.H + (it.h0 - 1)) * a.W + (it.w0 - 1)) * a.x_ldc * 2);
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) {
+            const unsigned gd = (unsigned)(it.d0 - 1) + (pz[i] & 0xffu), gh = (unsigned)(it.h0 - 1) + ((pz[i] >> 8) & 0xffu), gw = (unsigned)(it.w0 - 1) + (pz[i] >> 16);
+            const bool ok = gd < (unsigned)a.D && gh < (unsigned)a.H && gw < (unsigned)a.W;
+            voff[i] = ok ? relc[i] + base : OOB;
+        }
+    };
+    auto issue = [&](const Item& it, int ch, int buf) {
+        const bool first = ch < xsplit_ch;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(first ? a.x : a.x2) + (size_t)it.n * samp, 0, 0x7fffffff, 0x00020000);
+        const unsigned coff = (unsigned)(first ? ch : ch - xsplit_ch) * (unsigned)RB;
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) {
+            const int w_i = i * 4 + wave;
+            if (w_i < NI) dma16(rs, (lds_ptr_t)(smem + buf * IMG + w_i * 1024), 16, voff[i] == OOB ? OOB : voff[i] + coff, 0, 0, 0);
+        }
+    };
+
+    float* const S = reinterpret_cast<float*>(smem);                   // statistics scratch (after the last unit): [wave][2][32][33] + [2][4][32]
+    const bool want_stats = a.stats != nullptr;
+    f32x4 s1[CO_T][4], s2[CO_T][4];
+#pragma unroll
+    for (int ct = 0; ct < CO_T; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s1[ct][q] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[ct][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float cnt = 0.f;
+
+    if (L < L_end) {
+        Item cur = decode(L), dm = cur;
+        unsigned Ldm = L; int chdm = 0, ch = 0, buf = 0;
+        plan(dm);
+        issue(dm, 0, 0);
+        bf16x8 wf[RING][CO_T];
+#define E3_LOAD_WP(TAP, CHK, SLOT)                                                                                                  \
+    _Pragma("unroll") for (int ct_ = 0; ct_ < CO_T; ++ct_)                                                                          \
+        wf[SLOT][ct_] = *reinterpret_cast<const bf16x8*>(wlane + (size_t)((TAP) * nch + (CHK)) * wstep + ct_ * 512)
+#pragma unroll
+        for (int t0 = 0; t0 < RING - 1; ++t0) { E3_LOAD_WP(t0, 0, t0); }
+        f32x16 acc[CO_T][NV];
+#pragma unroll
+        for (int ct = 0; ct < CO_T; ++ct)
+#pragma unroll
+            for (int t = 0; t < NV; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[ct][t][e] = 0.f;
+
+        bool ring_ahead = true;            // the ring already holds requests of this unit's first taps (issued behind this unit's DMA)
+        while (true) {
+            // this unit's DMA is older than the RING - 1 weight requests of its first taps: loads return in order, so "at most RING - 1 outstanding"
+            // means the image has landed whatever the (unordered) stores of an epilogue in between are doing
+            if (ring_ahead) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RING - 1) * CO_T) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();               // unit u's image has landed (every wave waited for its own pieces); everybody is done reading the other buffer
+            // the staging pointer runs one unit ahead
+            if (++chdm == nch) { chdm = 0; Ldm += wstride; if (Ldm < L_end) { dm = decode(Ldm); plan(dm); } }
+            const bool more = Ldm < L_end;
+            if (more && !(E3_PABL & 4)) issue(dm, chdm, buf ^ 1);
+            const int chn = ch + 1 == nch ? 0 : ch + 1;        // chunk of the next unit (its first weights enter the ring during this unit's last taps)
+            {
+                const unsigned char* img = smem + buf * IMG;
+                bf16x8 b[2][NV];
+#pragma unroll
+                for (int t = 0; t < NV; ++t) b[0][t] = *reinterpret_cast<const bf16x8*>(img + rd[0] + (t * HW) * RB);
+#pragma unroll
+                for (int st = 0; st < TAPS; ++st) {
+                    if (!(E3_PABL & 2)) {
+                    if (st + RING - 1 < TAPS) { E3_LOAD_WP(st + RING - 1, ch, (st + RING - 1) % RING); }
+                    else if (more) { E3_LOAD_WP(st + RING - 1 - TAPS, chn, (st + RING - 1) % RING); }
+                    }
+                    if (st + 1 < TAPS) {
+                        const int tn = st + 1;
+                        const int kd = tn / 9, kh = (tn / 3) % 3, kw = tn % 3;
+#pragma unroll
+                        for (int t = 0; t < ((E3_PABL & 1) ? 1 : NV); ++t)
+                            b[(st + 1) & 1][t] = *reinterpret_cast<const bf16x8*>(img + rd[kw] + ((kd * HH + t + kh) * HW) * RB);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ct = 0; ct < CO_T; ++ct)
+#pragma unroll
+                        for (int t = 0; t < NV; ++t) {
+                            if (E3_PABL & 8) { if (t == 0) asm volatile("" :: "v"(b[st & 1][0]), "v"(b[st & 1][(E3_PABL & 1) ? 0 : 1]), "v"(b[st & 1][(E3_PABL & 1) ? 0 : 2]), "v"(b[st & 1][(E3_PABL & 1) ? 0 : 3]), "v"(wf[st % RING][ct])); }
+                            else acc[ct][t] = E3_MFMA16(wf[st % RING][ct], b[st & 1][(E3_PABL & 1) ? 0 : t], acc[ct][t], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            buf ^= 1;
+            ring_ahead = more;
+            if (++ch < nch) continue;
+            // ---- the item is complete: lane (j, g) holds, for tile t and register e, the output of voxel j and channel (e&3) + 8*(e>>2) + 4*g
+            {
+                const int d0 = cur.d0, h0 = cur.h0, w0 = cur.w0, n = cur.n;
+                const bool interior = d0 + 4 <= a.D && h0 + 4 <= a.H && w0 + 32 <= a.W;
+                auto body = [&](auto aff_tag, auto full_tag) __attribute__((always_inline)) {
+                    constexpr bool AFF = decltype(aff_tag)::value, FULL = decltype(full_tag)::value;
+#pragma unroll
+                    for (int ct = 0; ct < CO_T; ++ct) {
+                        f32x4 bq[4], sq[4], hq[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int cb = co0 + ct * 32 + 16 * (q >> 1) + 8 * g + 4 * (q & 1);
+                            bq[q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cb) : f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (AFF) { sq[q] = *reinterpret_cast<const f32x4*>(a.epi_scale + cb); hq[q] = *reinterpret_cast<const f32x4*>(a.epi_shift + cb); }
+                        }
+#pragma unroll
+                        for (int t = 0; t < NV; ++t) {
+                            const int d = d0 + wave, h = h0 + t, w = w0 + j;
+                            const bool valid = FULL || (d < a.D && h < a.H && w < a.W);
+                            const int cot = co0 + ct * 32;
+                            bf16_t* yrow = (a.y2 && cot >= a.y_split ? a.y2 + (cot - a.y_split) : a.y + cot) + ((((size_t)n * a.D + d) * a.H + h) * a.W + w) * a.y_ldc + 8 * g;
+                            bf16x4 rprev;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                f32x4 v = {acc[ct][t][4 * q], acc[ct][t][4 * q + 1], acc[ct][t][4 * q + 2], acc[ct][t][4 * q + 3]};
+                                if (AFF) {
+                                    v = v * sq[q] + hq[q];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                                } else v = v + bq[q];
+                                const bf16x4 rb = __builtin_convertvector(v, bf16x4);            // round to nearest even
+                                if (q & 1) { if (valid && !((E3_PABL & 16) && a.D > 0)) *reinterpret_cast<bf16x8*>(yrow + 16 * (q >> 1)) = __builtin_shufflevector(rprev, rb, 0, 1, 2, 3, 4, 5, 6, 7); }
+                                else rprev = rb;
+                                if (!AFF) {               // (statistics only exist without the folded epilogue)
+                                    f32x4 dv = __builtin_convertvector(rb, f32x4) - bq[q];
+                                    if (!FULL) {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) dv[e] = valid ? dv[e] : 0.f;
+                                    }
+                                    s1[ct][q] += dv; s2[ct][q] += dv * dv;
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[ct][t][e] = 0.f;
+                        }
+                    }
+                };
+                if (a.epi_scale) { if (interior) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+                else { if (interior) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
+                const int nd = a.D - d0 < 4 ? a.D - d0 : 4, nh = a.H - h0 < 4 ? a.H - h0 : 4, nw = a.W - w0 < 32 ? a.W - w0 : 32;
+                cnt += (float)(nd * nh * nw);
+            }
+            ch = 0; L += wstride;
+            if (L >= L_end) break;
+            cur = dm;
+        }
+#undef E3_LOAD_WP
+    }
+    if (!want_stats) return;
+    // ---- statistics of the workgroup's items: S[wave][quantity][channel][33] floats, column sums, ONE (n, mean, M2) record
+    float* R = S + 4 * 2 * 32 * 33;                    // [2][4][32]
+    const int part = (int)(xcd * (wstride / p.cgroups) + fdiv(wi, p.m_cg));
+#pragma unroll
+    for (int ct = 0; ct < CO_T; ++ct) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int col = 16 * (e >> 3) + 8 * g + (e & 7);
+            S[((wave * 2 + 0) * 32 + col) * 33 + j] = s1[ct][e >> 2][e & 3];
+            S[((wave * 2 + 1) * 32 + col) * 33 + j] = s2[ct][e >> 2][e & 3];
+        }
+        __syncthreads();
+        {
+            const int col = tid & 31, qn = (tid >> 5) & 1, wv = tid >> 6;
+            const float* row = S + ((wv * 2 + qn) * 32 + col) * 33;
+            float sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) sm += row[k];
+            R[(qn * 4 + wv) * 32 + col] = sm;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const float sm = (R[0 * 32 + tid] + R[1 * 32 + tid]) + (R[2 * 32 + tid] + R[3 * 32 + tid]);
+            const float q2 = (R[4 * 32 + tid] + R[5 * 32 + tid]) + (R[6 * 32 + tid] + R[7 * 32 + tid]);
+            const int co = co0 + ct * 32 + tid;
+            const float b = a.bias ? a.bias[co] : 0.f;
+            const float m = cnt > 0.f ? sm / cnt : 0.f;
+            float* rec = a.stats + ((size_t)part * a.Cout + co) * 3;
+            rec[0] = cnt; rec[1] = b + m; rec[2] = fmaxf(q2 - sm * m, 0.f);
+        }
+    }
+}
+
 // torch (Cout, Cin, T) fp32 -> packed bf16 [tap][chunk][k-step][Cg][2][8], Cg = GEMM rows (output channels of THIS launch)
 __global__ void pack_conv_b16_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int T, int dgrad) {
     const int Kg = dgrad ? Cout : Cin, Cg = dgrad ? Cin : Cout;       // GEMM-K channels, GEMM rows
@@ -309,7 +572,8 @@ __global__ void pack_conv_b16_kernel(const float* __restrict__ w, bf16_t* __rest
         const int e = r & 7; r >>= 3; const int g = r & 1; r >>= 1; const int row = r % Cg; r /= Cg;
         const int ks = r & 1; r >>= 1; const int ch = r % (Kg >> 5); const int tap = (int)(r / (Kg >> 5));
         const int k = ch * 32 + ks * 16 + g * 8 + e;
-        const float v = dgrad ? w[((size_t)k * Cin + row) * T + (T - 1 - tap)] : w[((size_t)row * Cin + k) * T + tap];
+        const int rc = swap23(row);
+        const float v = dgrad ? w[((size_t)k * Cin + rc) * T + (T - 1 - tap)] : w[((size_t)rc * Cin + k) * T + tap];
         out[i] = f2bf(v);
     }
 }
@@ -392,7 +656,8 @@ __global__ void pack_multi_b16_kernel(const PackMultiArgs a) {
             const int row = r % Cg; r /= Cg;
             const int ks = r & 1; r >>= 1; const int ch = r % (Kg >> 5); const int tap = (int)(r / (Kg >> 5));
             const int k = ch * 32 + ks * 16 + g * 8 + e;
-            v = dgrad ? J.w[((size_t)k * J.Cin + row) * J.T + (J.T - 1 - tap)] : J.w[((size_t)row * J.Cin + k) * J.T + tap];
+            const int rc = swap23(row);
+            v = dgrad ? J.w[((size_t)k * J.Cin + rc) * J.T + (J.T - 1 - tap)] : J.w[((size_t)rc * J.Cin + k) * J.T + tap];
         } else {                    // transposed conv: [row tile][k-step][32][2][8]; torch (Cin, Cout, T)
             const int dgrad = J.mode - 2;
             const int K = dgrad ? J.T * J.Cout : J.Cin;
@@ -438,7 +703,8 @@ int launch_t(const ConvB16Args& a, int ksplit, hipStream_t s) {
 // Work decomposition of one launch: brick depth (4x8x16 bricks -- each weight fragment feeds 4 tiles per wave, halo overhead 2.1x
 // instead of 2.8x -- where they still fill the chip), output-channel tiles per workgroup, and for the low-resolution levels (a few
 // dozen bricks for 256 CUs) a split of the input channels over several workgroups (fp32 partial sums, splitk_reduce_b16_kernel).
-struct Decomp { int bd, co_t, ksplit, tw; long bricks; };
+struct Decomp { int bd, co_t, ksplit, tw; long bricks; bool persist; };
+constexpr int PGRID = 512;      // workgroups of the persistent form (two per CU)
 Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout, int planar) {
     static const int forced = getenv("E3_B16_BD") ? atoi(getenv("E3_B16_BD")) : 0;
     static const bool no_split = getenv("E3_B16_NO_SPLITK") != nullptr;
@@ -460,6 +726,11 @@ Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout, int planar
     const int nch = Cin / 32;
     d.ksplit = 1;
     while (!no_split && wgs * d.ksplit < 512 && nch % (2 * d.ksplit) == 0 && d.ksplit < 8) d.ksplit *= 2;
+    // persistent form (conv_b16_pkernel): 3x3x3, 4 x 4 x 32 bricks in the column order, one output tile per workgroup, several items per workgroup
+    static const bool no_persist = getenv("E3_B16_NO_PERSIST") != nullptr;      // A/B switch
+    const int cgroups = Cout / 32;
+    d.persist = !no_persist && !planar && d.bd == 4 && d.tw == 32 && d.co_t == 1 && d.ksplit == 1 && wgs >= 4 * PGRID && 64 % cgroups == 0 &&
+                (cdiv(H, 4) & 1) == 0 && (cdiv(W, 32) & 1) == 0 && wgs * 256 < (1l << 32);
     return d;
 }
 int reduce_blocks(size_t vox, int C) {
@@ -477,7 +748,7 @@ extern "C" int e3_debug_conv_timing(void* buf) { return hipMemcpyToSymbol(HIP_SY
 
 int conv_b16_stats_parts(int N, int D, int H, int W, int Cin, int Cout, int planar) {
     const Decomp d = conv_b16_decomp(N, D, H, W, Cin, Cout, planar);
-    return d.ksplit > 1 ? reduce_blocks((size_t)N * D * H * W, Cout) : (int)d.bricks;
+    return d.ksplit > 1 ? reduce_blocks((size_t)N * D * H * W, Cout) : (d.persist ? PGRID / (Cout / 32) : (int)d.bricks);
 }
 
 size_t conv_b16_partial_floats(int N, int D, int H, int W, int Cin, int Cout, int planar) {
@@ -516,7 +787,7 @@ int launch_pack_multi_b16(const PackB16Job* jobs, int njobs, hipStream_t s) {
 
 int launch_conv_b16(ConvB16Args a, hipStream_t s) {
     E3_REQUIRE(a.Cin % 32 == 0 && a.Cout % 32 == 0, E3_ERR_UNSUPPORTED, "bf16 conv: channel counts must be multiples of 32");
-    E3_REQUIRE(a.x_ldc % 8 == 0 && a.y_ldc % 4 == 0, E3_ERR_INVALID, "bf16 conv: misaligned view");
+    E3_REQUIRE(a.x_ldc % 8 == 0 && a.y_ldc % 8 == 0 && ((uintptr_t)a.y & 15) == 0 && (!a.y2 || ((uintptr_t)a.y2 & 15) == 0), E3_ERR_INVALID, "bf16 conv: misaligned view");
     E3_REQUIRE((!a.x2 || (a.x_split % 32 == 0 && a.x_split > 0 && a.x_split < a.Cin)) && (!a.y2 || (a.y_split % 32 == 0 && a.y_split > 0 && a.y_split < a.Cout)),
                E3_ERR_INVALID, "bf16 conv: a two-tensor operand splits at a multiple of 32 channels");
     E3_REQUIRE((size_t)a.D * a.H * a.W * a.x_ldc < (1ull << 30), E3_ERR_UNSUPPORTED, "bf16 conv: sample larger than 2 GB");
@@ -527,6 +798,25 @@ int launch_conv_b16(ConvB16Args a, hipStream_t s) {
 #define E3_B16_LAUNCH(KD_, TW_)                                                                                              \
     (d.bd == 4 ? (two ? launch_t<4, 2, KD_, TW_>(a, d.ksplit, s) : launch_t<4, 1, KD_, TW_>(a, d.ksplit, s))                 \
                : (two ? launch_t<2, 2, KD_, TW_>(a, d.ksplit, s) : launch_t<2, 1, KD_, TW_>(a, d.ksplit, s)))
+    if (d.persist && !(a.box_hi[0] > 0)) {
+        const int tD = cdiv(a.D, 4), tH = cdiv(a.H, 4), tW = cdiv(a.W, 32);
+        ConvB16PArgs pa{};
+        auto magic = [](unsigned dv) { return dv == 1 ? 0u : (unsigned)(((1ull << 32) + dv - 1) / dv); };
+        pa.cgroups = (unsigned)(a.Cout / 32); pa.m_cg = magic(pa.cgroups);
+        pa.per = (unsigned)tD * 4; pa.m_per = magic(pa.per);
+        pa.ncol = (unsigned)(tH >> 1) * (unsigned)(tW >> 1); pa.m_ncol = magic(pa.ncol);
+        pa.tw2 = (unsigned)(tW >> 1); pa.m_tw2 = magic(pa.tw2);
+        pa.items = (unsigned)((size_t)a.N * tD * tH * tW * pa.cgroups);
+        pa.per_xcd = (pa.items + 7) / 8; pa.per_xcd = (pa.per_xcd + pa.cgroups - 1) / pa.cgroups * pa.cgroups;
+        using GP = Geo<4, 3, 32, 16>;
+        constexpr int lds = 2 * GP::IMG;
+        static_assert(GP::IMG >= 4 * 2 * 32 * 33 * 4 + 1024, "statistics scratch fits one image");
+        static bool pattr = false;
+        if (!pattr) { E3_CHECK_HIP(hipFuncSetAttribute((const void*)conv_b16_pkernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); pattr = true; }
+        hipLaunchKernelGGL((conv_b16_pkernel<1>), dim3(PGRID), dim3(256), lds, s, a, pa);
+        E3_CHECK_HIP(hipGetLastError());
+        return E3_OK;
+    }
     // 16-channel LDS images, three workgroups per CU, where the shape allows (BD = 4, 3x3x3, 32-voxel rows, one 32-channel output tile, no split-K):
     // 150 -> 133, 247 -> 227, 154 -> 138 us on the level-0 forward convs of cfg 2, 5.89 -> 5.76 ms per step (the 32-channel-image form stays for the other decompositions)
     if (d.bd == 4 && d.tw == 32 && d.ksplit == 1 && !two) rc = a.planar ? launch_t<4, 1, 1, 32, 16>(a, d.ksplit, s) : launch_t<4, 1, 3, 32, 16>(a, d.ksplit, s);
