@@ -703,7 +703,7 @@ int launch_t(const ConvB16Args& a, int ksplit, hipStream_t s) {
 // Work decomposition of one launch: brick depth (4x8x16 bricks -- each weight fragment feeds 4 tiles per wave, halo overhead 2.1x
 // instead of 2.8x -- where they still fill the chip), output-channel tiles per workgroup, and for the low-resolution levels (a few
 // dozen bricks for 256 CUs) a split of the input channels over several workgroups (fp32 partial sums, splitk_reduce_b16_kernel).
-struct Decomp { int bd, co_t, ksplit, tw; long bricks; bool persist; };
+struct Decomp { int bd, co_t, ksplit, tw; long bricks; int persist; };      // persist: 1 = conv_b16_pkernel
 constexpr int PGRID = 512;      // workgroups of the persistent form (two per CU)
 Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout, int planar) {
     static const int forced = getenv("E3_B16_BD") ? atoi(getenv("E3_B16_BD")) : 0;
@@ -729,8 +729,8 @@ Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout, int planar
     // persistent form (conv_b16_pkernel): 3x3x3, 4 x 4 x 32 bricks in the column order, one output tile per workgroup, several items per workgroup
     static const bool no_persist = getenv("E3_B16_NO_PERSIST") != nullptr;      // A/B switch
     const int cgroups = Cout / 32;
-    d.persist = !no_persist && !planar && d.bd == 4 && d.tw == 32 && d.co_t == 1 && d.ksplit == 1 && wgs >= 4 * PGRID && 64 % cgroups == 0 &&
-                (cdiv(H, 4) & 1) == 0 && (cdiv(W, 32) & 1) == 0 && wgs * 256 < (1l << 32);
+    d.persist = (!no_persist && !planar && d.bd == 4 && d.tw == 32 && d.co_t == 1 && d.ksplit == 1 && wgs >= 4 * PGRID && 64 % cgroups == 0 &&
+                 (cdiv(H, 4) & 1) == 0 && (cdiv(W, 32) & 1) == 0 && wgs * 256 < (1l << 32)) ? 1 : 0;
     return d;
 }
 int reduce_blocks(size_t vox, int C) {

@@ -51,6 +51,8 @@ CONV_CASES = [
     (1, 3, 9, 17, 128, 64),         # few bricks: the input channels are split over workgroups (fp32 partial sums + reduce pass)
     (2, 32, 64, 64, 32, 32),        # enough bricks for the 4-deep bricks; W % 32 == 0: 1x32-voxel tiles
     (1, 9, 13, 100, 64, 64),        # 1x32 tiles with ragged rows (W = 100), two column tiles, odd D / H
+    (2, 30, 125, 100, 32, 64),      # >= 2048 items in the column order: the persistent kernel (conv_b16_pkernel), ragged in D / H / W, two output-channel groups (forward), two chunks (dgrad)
+    (1, 64, 64, 128, 64, 32),       # the persistent kernel, four chunks, interior bricks only
 ]
 
 
