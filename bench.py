@@ -432,7 +432,8 @@ def main():
             watchdog.daemon = True
             watchdog.start()
         try:
-            p = predictor_leg(dev, shape, tile_parallel=world > 1, bf16=(args.dtype if args.dtype in ('bf16', 'f16') else False))
+            b16_leg = args.dtype if args.dtype in ('bf16', 'f16') else False
+            p = predictor_leg(dev, shape, tile_parallel=world > 1, bf16=b16_leg)
             if rank == 0:
                 if world > 1:
                     p.update(n_gpus=world, parallelism=f'tile-parallel over {world} ranks, shared-memory output')
@@ -444,6 +445,16 @@ def main():
                 b = p if tuple(shape) == sub else predictor_leg(dev, sub, bf16=b16)
                 p['needed_region_ab'] = {'volume': list(sub), 'whole_tiles_mvox_s': a['value'], 'needed_region_mvox_s': b['value'],
                                          'whole_tiles_compute_s': a['timing'].get('compute_stream_s'), 'needed_region_compute_s': b['timing'].get('compute_stream_s')}
+            if world == 1 and not b16_leg and not args.no_extra_legs:
+                # the reference's own reduced-precision inference switch: Predictor(float16=True) = model.half() + float16 tiles (inference.py:445-446,
+                # benchmark/pred_benchmark.py:55,71), on the native float16 kernels; same tiling on the 288x1152x1152 sub-volume
+                try:
+                    h = predictor_leg(dev, (288, 1152, 1152), bf16='f16')
+                    res['predictor_f16'] = {k: h[k] for k in ('metric', 'value', 'unit', 'seconds', 'volume', 'tile', 'overlap', 'tiles', 'dtype', 'out_dtype', 'timing', 'finite',
+                                                              'needed_region', 'mfma_executed_frac')}
+                    res['predictor_f16']['workload'] = 'configs[4] tiling on a 288x1152x1152 volume with Predictor(float16=True) semantics: model.half(), float16 tiles, native float16 kernels'
+                except Exception as e:  # noqa: BLE001
+                    res['predictor_f16'] = {'value': None, 'note': f'failed: {e}'}
         except Exception as e:  # noqa: BLE001
             if rank == 0:
                 res['predictor'] = {'metric': 'Predictor MVox/s', 'value': None, 'note': f'failed: {e}'}

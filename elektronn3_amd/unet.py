@@ -12,6 +12,7 @@ at call time (nothing is cached across calls except scratch memory).
 There is no CPU path: a CPU input raises ``RuntimeError``.
 """
 import ctypes
+import weakref
 import threading
 from typing import List, Sequence, Union
 
@@ -108,6 +109,14 @@ def release_scratch():
     _scratch.clear()
 
 
+class _TableRef:
+    """The parameter table a pending backward will read: `shared` while it is the module's fp32 cache itself (see _fp32_table)."""
+    __slots__ = ('tens', 'shared', '__weakref__')
+
+    def __init__(self, tens, shared):
+        self.tens, self.shared = tens, shared
+
+
 def _fp32_table(module, tens):
     """fp32 copies of a low-precision module's table tensors in ONE persistent flat buffer, refreshed with a single multi-tensor copy
     (121 separate `.float()` launches would cost more than the forward's convolutions)."""
@@ -120,8 +129,20 @@ def _fp32_table(module, tens):
         for t, n in zip(tens, sizes):
             views.append(flat[off:off + t.numel()].view(t.shape))
             off += n
-        cache = (key, flat, views)
+        cache = (key, flat, views, [])
         module.__dict__['_fp32_cache'] = cache
+    # copy on write: a forward whose backward is still pending reads this cache in its backward -- it gets its own copy of the values BEFORE they are
+    # overwritten (an optimizer step or an SWA swap between two pending graphs would otherwise be read silently where torch raises a version error);
+    # the usual step (forward, backward, forward, ...) never pays for the copy
+    pending = cache[3]
+    while pending:
+        holder = pending.pop()()
+        if holder is not None and holder.shared:
+            own_flat = cache[1].clone()
+            off, own = 0, []
+            for t in cache[2]:
+                own.append(own_flat[off:off + t.numel()].view(t.shape)); off += (t.numel() + 63) // 64 * 64
+            holder.tens, holder.shared = own, False
     torch._foreach_copy_(cache[2], list(tens))
     return cache[2]
 
@@ -367,16 +388,14 @@ class _UNetFunction(torch.autograd.Function):
         ctx.softmax, ctx.eval_mode, ctx.in_dtype = softmax, not (training or frozen), in_dtype
         # (a low-precision module's fp32 table is a cache that the next forward refreshes with the same parameter values:
         # the backward only reads weights and affine parameters from it, never the running statistics)
+        ctx.x32, ctx.saved_buf, ctx.tens = (xin, saved, _TableRef(tens, False)) if need_grad else (None, None, None)
         if need_grad and lowp is not None:
-            # the fp32 table of a low-precision module is ONE persistent cache that the next forward overwrites in place: the backward of this
-            # forward gets its own copy (parameters changed in between -- an optimizer step between two pending graphs, an SWA swap -- would
-            # otherwise be read silently where torch raises a version error)
-            flat = torch.cat([t.reshape(-1) for t in tens])
-            own, off = [], 0
-            for t in tens:
-                own.append(flat[off:off + t.numel()].view(t.shape)); off += t.numel()
-            tens = own
-        ctx.x32, ctx.saved_buf, ctx.tens = (xin, saved, tens) if need_grad else (None, None, None)
+            # the fp32 table of a low-precision module is ONE persistent cache that the next forward overwrites in place: this forward registers its
+            # table reference, and _fp32_table hands it a private copy if the cache is refreshed while the backward is still pending (copy on write)
+            cache = module.__dict__.get('_fp32_cache')
+            if cache is not None and len(tens) == len(cache[2]) and all(a is b for a, b in zip(tens, cache[2])):
+                ctx.tens.shared = True
+                cache[3].append(weakref.ref(ctx.tens))
         return y if out_dtype == torch.float32 else y.to(out_dtype)
 
     @staticmethod
@@ -389,7 +408,7 @@ class _UNetFunction(torch.autograd.Function):
             raise NotImplementedError('backward through the fused softmax head is not implemented')
         module, plan = ctx.module, ctx.plan
         check(_lib.load().e3_unet_set_rrelu(plan.handle, *(ctx.rrelu if ctx.rrelu is not None else (0.0, 0.0, 0))))
-        flat, views, dx = _native_backward(plan, dy, ctx.x32, ctx.tens, ctx.saved_buf, ctx.b16, ctx.needs_input_grad[3],
+        flat, views, dx = _native_backward(plan, dy, ctx.x32, ctx.tens.tens, ctx.saved_buf, ctx.b16, ctx.needs_input_grad[3],
                                            getattr(module, '_grad_sync', None), frozen=ctx.frozen, loss=getattr(ctx, 'loss_bwd', None))
         ctx.loss_bwd = None
         ctx.saved_buf = ctx.x32 = ctx.tens = None   # free the activations now

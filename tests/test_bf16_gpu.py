@@ -271,6 +271,31 @@ def test_unet_bf16_eval_and_determinism():
         assert torch.equal(ga[k], gb[k]), k
 
 
+def test_unet_bf16_backward_reads_the_parameters_of_its_own_forward():
+    """A bf16 module computes from ONE persistent fp32 copy of its parameters that every forward refreshes in place.  A backward that is still pending
+    when the next forward (after an optimizer step / SWA swap) refreshes that copy must read the values of ITS forward: the pending graph gets a private
+    copy at that moment (copy on write, unet._fp32_table) -- the usual forward / backward / forward order never pays for one."""
+    _, m16 = _models(2, 32, seed=9)
+    m16.train()
+    x1, x2 = _bfvals(1, 1, 8, 16, 16, seed=41).to(DEV), _bfvals(1, 1, 8, 16, 16, seed=42).to(DEV)
+    dl = _bfvals(1, 2, 8, 16, 16, seed=43, scale=1e-3).to(DEV)
+    sd = {k: v.clone() for k, v in m16.state_dict().items()}
+    # reference: backward right behind its forward
+    _, g_ref = _train_step(m16, x1, dl)
+    m16.load_state_dict(sd)
+    for p in m16.parameters():
+        p.grad = None
+    y1 = m16(x1)                                    # graph 1 pending
+    with torch.no_grad():
+        for p in m16.parameters():
+            p.mul_(1.5)                             # "optimizer step"
+    y2 = m16(x2)                                    # refreshes the fp32 copy while graph 1 is pending
+    y1.backward(dl.to(y1.dtype))
+    for k, p in m16.named_parameters():
+        assert torch.equal(p.grad.float().cpu(), g_ref[k]), k
+    del y2
+
+
 def test_unet_bf16_autocast_keeps_fp32_master_weights():
     """torch.autocast('cuda', dtype=torch.bfloat16) around a fp32 module (the bf16 counterpart of Trainer(mixed_precision=True),
     trainer.py:519): bf16 compute, bf16 logits, fp32 parameters and fp32 gradients."""
