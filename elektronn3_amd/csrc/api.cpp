@@ -24,7 +24,7 @@ size_t e3_conv3d_workspace_bytes(int Cin, int Cout, int planar) {
 }
 
 int e3_conv3d_stats_parts(int Cin, int Cout, int N, int D, int H, int W, int planar) {
-    if (Cin < 8) return conv_small_stats_parts(N, D, H, W, planar);
+    if (Cin < 8) return conv_small_stats_parts2(N, D, H, W, planar, Cin, Cout);
     // (a call with a BN prologue uses the direct kernel: report the larger of the two record counts, empty records are neutral)
     const int p0 = conv_stats_parts(kind_of(planar), 0, N, D, H, W, 2, Cin, Cout), p1 = conv_stats_parts(kind_of(planar), CF_NO_WINO | CF_NO_KSPLIT, N, D, H, W, 2, Cin, Cout);
     return p0 > p1 ? p0 : p1;

@@ -6,6 +6,7 @@
 
 namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ first conv, forward
 // brick = 256 voxels (2x8x16, planar 1x16x16); thread = (channel quad q = tid%8, voxel group g = tid/8) and
@@ -159,6 +160,195 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const ConvSmallArgs
                 o[0] = c; o[1] = mn; o[2] = s;
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------ first conv (ONE input channel, 3x3x3), forward on the fp32 matrix cores
+// The 27 taps (padded to 28) are the K of 14 v_mfma_f32_32x32x2_f32 per 32 voxels x 32 output channels:  Y^T[co][v] = sum_tap W[co][tap] * X[v + tap].
+//   A operand = the weights, 14 registers per lane, loaded ONCE per workgroup (row r of the tile holds channel swap23(r): a lane then owns the channels
+//               16 k + 8 hf + 0..7 in registers 8 k .. 8 k + 7 -- 16-byte stores, two lanes = 64 contiguous bytes of a voxel's row)
+//   B operand = patches: lane (voxel n of a 32-voxel row, k-half kk) reads x[v + tap(2 s + kk)] from the LDS image of the brick's halo (one ds_read_b32 with
+//               an immediate row offset per MFMA; 8 KB per brick)
+// PERSISTENT: 1024 workgroups walk the bricks (4 x 8 x 32 voxels, wave = d-slice, 8 rows of 32 voxels); the halo of the next brick is requested before
+// the current brick's MFMAs and written to the other LDS buffer behind them (nothing a wave waits for inside a brick comes through the vector L1 -- its
+// returns are in order, csrc/bf16_conv.hip); lane constants and weights are computed / loaded once.  As a VALU kernel with one workgroup per 256 voxels the
+// layer ran at a third of the FMA peak (448 us per Predictor tile whose 822 MB of output need 150 us): per-brick weight fetch, index arithmetic per halo
+// element, three barriers; an MFMA form with the same one-brick workgroups was slower still (round-4 notes in DESIGN.md).
+// Statistics (training): per-lane running sums of (y - bias) and its square over the lane's voxels, Chan merges across lanes and waves at the end: ONE
+// (n, mean, M2) record per workgroup (conv_small_stats_parts2).
+constexpr int FB_D = 4, FB_H = 8, FB_W = 32, FH_H = FB_H + 2, FH_W = FB_W + 2, FNV = (FB_D + 2) * FH_H * FH_W, FGRID = 1024;
+__host__ __device__ __forceinline__ int swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+template <bool AFF, bool STATS>
+__global__ __launch_bounds__(256, 2) void conv_first_mfma_kernel(const ConvSmallArgs a, int tilesD, int tilesH, int tilesW, int npass, unsigned nitems) {
+    __shared__ __attribute__((aligned(16))) float xs[2][2048];
+    __shared__ float red[4][32][3];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, kk = lane >> 5;
+    const unsigned G = gridDim.x;
+    const int pass = (int)(blockIdx.x % (unsigned)npass);      // (G is a multiple of npass: every item of this workgroup has this pass)
+    const int cbase = pass * 32;
+    // ---- weights (A operand) and the lane's patch addresses (B operand), one per k-step
+    float aw[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int tap = 2 * s + kk;
+        aw[s] = tap < 27 ? a.w[(size_t)(cbase + swap23(n)) * 27 + tap] : 0.f;
+    }
+    const unsigned ab0 = (unsigned)(((wave * FH_H) * FH_W + n) * 4);
+    // byte offset of tap 2 s + kk inside the image (tap 27 is the zero-weight pad: any address) -- a select between two immediates, not 14 registers
+    auto ab = [&](int s) {
+        const int t0 = 2 * s, t1 = 2 * s + 1 < 27 ? 2 * s + 1 : 26;
+        const unsigned o0 = (unsigned)((((t0 / 9) * FH_H + (t0 / 3) % 3) * FH_W + t0 % 3) * 4), o1 = (unsigned)((((t1 / 9) * FH_H + (t1 / 3) % 3) * FH_W + t1 % 3) * 4);
+        return ab0 + (kk ? o1 : o0);
+    };
+    // ---- epilogue constants: registers 8 k + 4 m + e of a tile = channel cbase + 16 k + 8 kk + 4 m + e
+    f32x4 bq[4], sq[4], hq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = cbase + 16 * (q >> 1) + 8 * kk + 4 * (q & 1);
+        bq[q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (AFF) { sq[q] = *reinterpret_cast<const f32x4*>(a.epi_scale + c); hq[q] = *reinterpret_cast<const f32x4*>(a.epi_shift + c); }
+    }
+    // ---- staging plan: thread -> 8 halo elements idx = tid + 256 k (consecutive threads = consecutive w: coalesced rows)
+    const long long sd = a.xs_d ? a.xs_d : (long long)a.H * a.W, sh = a.xs_d ? a.xs_h : (long long)a.W, sn = a.xs_d ? a.xs_n : (long long)a.D * a.H * a.W;
+    constexpr unsigned OOB = 0x80000000u;
+    struct Item { int d0, h0, w0, nb; };
+    auto decode = [&](unsigned item) {
+        unsigned L = item / (unsigned)npass;
+        Item it;
+        it.w0 = (int)(L % (unsigned)tilesW) * FB_W; L /= (unsigned)tilesW;
+        it.h0 = (int)(L % (unsigned)tilesH) * FB_H; L /= (unsigned)tilesH;
+        it.d0 = (int)(L % (unsigned)tilesD) * FB_D; it.nb = (int)(L / (unsigned)tilesD);
+        return it;
+    };
+    float hv[8];
+    auto load_halo = [&](const Item& it) {
+        // descriptor at the brick's halo origin (possibly in front of the tensor: only valid lanes form addresses from it); zero padding = range check
+        const float* base = a.x + (long long)it.nb * sn + (long long)(it.d0 - 1) * sd + (long long)(it.h0 - 1) * sh + (it.w0 - 1);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+        int tv = tid;
+        asm volatile("" : "+v"(tv));        // (keeps the compiler from hoisting the 8 x 3 coordinates out of the brick loop: a few dozen VALU operations per brick against 24 registers)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = tv + 256 * k;
+            const int zw = idx % FH_W, zh = (idx / FH_W) % FH_H, zd = idx / (FH_W * FH_H);
+            const unsigned gd = (unsigned)(it.d0 - 1 + zd), gh = (unsigned)(it.h0 - 1 + zh), gw = (unsigned)(it.w0 - 1 + zw);
+            const bool ok = idx < FNV && gd < (unsigned)a.D && gh < (unsigned)a.H && gw < (unsigned)a.W;
+            hv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (unsigned)((zd * sd + zh * sh + zw) * 4) : OOB, 0, 0));
+        }
+    };
+    auto store_halo = [&](float* dst) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[tid + 256 * k] = hv[k];
+    };
+    // running statistics of this lane's 16 channels: sums of (y - bias) and its square over the lane's valid voxels
+    f32x4 s1[4], s2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s1[q] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[q] = s1[q]; }
+    float cnt = 0.f;
+
+    unsigned item = blockIdx.x;
+    int cur = 0;
+    if (item < nitems) {
+        Item it = decode(item);
+        load_halo(it);
+        store_halo(xs[0]);
+        __syncthreads();
+        while (true) {
+            const unsigned nxt = item + G;
+            const bool more = nxt < nitems;
+            Item itn = it;
+            if (more) { itn = decode(nxt); load_halo(itn); }       // in flight during this brick's MFMAs
+            const char* img = reinterpret_cast<const char*>(xs[cur]);
+            const int d = it.d0 + wave;
+            // output descriptor at the brick's first voxel (launcher: four d-planes of the output view < 2^31 bytes); voxels outside the tensor: out-of-range offset
+            const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(a.y + ((((size_t)it.nb * a.D + it.d0) * a.H + it.h0) * a.W + it.w0) * a.y_ldc + cbase, 0, 0x7fffffff, 0x00020000);
+            // patches of a row: 14 LDS reads, requested one row ahead of the 14 MFMAs that consume them (one accumulator chain: a dependent
+            // v_mfma_f32_32x32x2_f32 issues right behind its predecessor's 16 passes)
+            float bb[2][14];
+#pragma unroll
+            for (int s = 0; s < 14; ++s) bb[0][s] = *reinterpret_cast<const float*>(img + ab(s));
+#pragma unroll
+            for (int r = 0; r < FB_H; ++r) {
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                if (r + 1 < FB_H) {
+#pragma unroll
+                    for (int s = 0; s < 14; ++s) bb[(r + 1) & 1][s] = *reinterpret_cast<const float*>(img + ab(s) + (r + 1) * FH_W * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 14; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[s], bb[r & 1][s], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const int h = it.h0 + r, w = it.w0 + n;
+                    const bool valid = d < a.D && h < a.H && w < a.W;
+                    const unsigned yoff = valid ? (unsigned)(((((wave * a.H) + r) * a.W + n) * a.y_ldc + 8 * kk) * 4) : OOB;       // relative to the brick's first voxel
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                        v = v + bq[q];
+                        if (AFF) {
+                            v = v * sq[q] + hq[q];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rs, yoff, (16 * (q >> 1) + 4 * (q & 1)) * 4, 0);
+                        if (STATS) {
+                            f32x4 dv = v - bq[q];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) dv[e] = valid ? dv[e] : 0.f;
+                            s1[q] += dv; s2[q] += dv * dv;
+                        }
+                    }
+                    if (STATS) cnt += valid ? 1.f : 0.f;
+                }
+            }
+            if (!more) break;
+            store_halo(xs[cur ^ 1]);
+            __syncthreads();
+            cur ^= 1; item = nxt; it = itn;
+        }
+    }
+    if (!STATS) return;
+    // ---- statistics: plain sums over the 32 lanes that hold the same channels give the wave's count and mean; every lane then takes its own sum of
+    // squares about THAT mean (its sums cover a few dozen voxels: no cancellation to speak of), summed over the lanes; Chan merges over the 4 waves
+    float cn = cnt, mn[16], m2[16];
+#pragma unroll
+    for (int off = 1; off <= 16; off <<= 1) {
+        cn += __shfl_xor(cn, off);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mn[e] = (off == 1 ? s1[e >> 2][e & 3] : mn[e]) + __shfl_xor(off == 1 ? s1[e >> 2][e & 3] : mn[e], off);
+    }
+    const float rcn = cn > 0.f ? 1.f / cn : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        mn[e] *= rcn;
+        const float sl = s1[e >> 2][e & 3], ql = s2[e >> 2][e & 3];
+        m2[e] = __builtin_fmaf(mn[e], __builtin_fmaf(mn[e], cnt, -2.f * sl), ql);        // sum (dv - mean)^2 over the lane's voxels
+    }
+#pragma unroll
+    for (int off = 1; off <= 16; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m2[e] += __shfl_xor(m2[e], off);
+    if (n == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = 16 * (e >> 3) + 8 * kk + (e & 7);
+            red[wave][c][0] = cn; red[wave][c][1] = mn[e]; red[wave][c][2] = fmaxf(m2[e], 0.f);
+        }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float c = 0.f, m = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) welford_merge(c, m, q, red[w][tid][0], red[w][tid][1], red[w][tid][2]);
+        const float b = a.bias ? a.bias[cbase + tid] : 0.f;
+        float* o = a.stats + ((size_t)(blockIdx.x / (unsigned)npass) * a.Cout + cbase + tid) * 3;
+        o[0] = c; o[1] = b + m; o[2] = q;
     }
 }
 
@@ -584,10 +774,32 @@ int conv_small_stats_parts(int N, int D, int H, int W, int planar) {
     int TD, TH; small_brick(planar, TD, TH);
     return N * cdiv(D, TD) * cdiv(H, TH) * cdiv(W, 16);
 }
+// one input channel, 3x3x3, 32-channel output tiles, enough bricks of 4 x 8 x 32 voxels: the persistent matrix-core kernel (E3_FIRST_NO_MFMA=1: A/B switch)
+static bool first_mfma(int N, int D, int H, int W, int planar, int Cin, int Cout) {
+    static const bool off = getenv("E3_FIRST_NO_MFMA") != nullptr;
+    if (off || planar || Cin != 1 || Cout % 32 != 0 || FGRID % (Cout / 32) != 0) return false;
+    const long long items = (long long)N * cdiv(D, FB_D) * cdiv(H, FB_H) * cdiv(W, FB_W) * (Cout / 32);
+    return items >= FGRID && items < (1ll << 31);
+}
+int conv_small_stats_parts2(int N, int D, int H, int W, int planar, int Cin, int Cout) {
+    return first_mfma(N, D, H, W, planar, Cin, Cout) ? FGRID / (Cout / 32) : conv_small_stats_parts(N, D, H, W, planar);
+}
 
 int launch_conv_small_fwd(ConvSmallArgs a, hipStream_t s) {
     E3_REQUIRE(a.Cin >= 1 && a.Cin < 8, E3_ERR_UNSUPPORTED, "direct conv handles 1..7 input channels");
     E3_REQUIRE(a.Cout % 4 == 0 && a.y_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "output channels must be a multiple of 4");
+    if (first_mfma(a.N, a.D, a.H, a.W, a.planar, a.Cin, a.Cout)) {
+        E3_REQUIRE(((uintptr_t)a.y & 15) == 0, E3_ERR_INVALID, "first conv: misaligned output");
+        E3_REQUIRE((long long)a.H * a.W * a.y_ldc * 4 * 4 < 0x7fffffffll, E3_ERR_UNSUPPORTED, "first conv: four d-planes of the output view exceed 2^31 bytes (32-bit buffer offsets)");
+        E3_REQUIRE((a.xs_d ? a.xs_d : (long long)a.H * a.W) * 6 * 4 < 0x7fffffffll, E3_ERR_UNSUPPORTED, "first conv: six d-planes of the input view exceed 2^31 bytes (32-bit buffer offsets)");
+        const int tD = cdiv(a.D, FB_D), tH = cdiv(a.H, FB_H), tW = cdiv(a.W, FB_W), npass = a.Cout / 32;
+        const unsigned nitems = (unsigned)((size_t)a.N * tD * tH * tW * npass);
+        if (a.epi_scale) hipLaunchKernelGGL((conv_first_mfma_kernel<true, false>), dim3(FGRID), dim3(256), 0, s, a, tD, tH, tW, npass, nitems);
+        else if (a.stats) hipLaunchKernelGGL((conv_first_mfma_kernel<false, true>), dim3(FGRID), dim3(256), 0, s, a, tD, tH, tW, npass, nitems);
+        else hipLaunchKernelGGL((conv_first_mfma_kernel<false, false>), dim3(FGRID), dim3(256), 0, s, a, tD, tH, tW, npass, nitems);
+        E3_CHECK_HIP(hipGetLastError());
+        return E3_OK;
+    }
     int TD, TH; small_brick(a.planar, TD, TH);
     const int tD = cdiv(a.D, TD), tH = cdiv(a.H, TH), tW = cdiv(a.W, 16);
     const int KD = a.planar ? 1 : 3;

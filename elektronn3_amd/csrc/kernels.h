@@ -134,6 +134,7 @@ struct ConvSmallArgs {
     long long xs_n, xs_d, xs_h;  // xs_d != 0: x is a view inside a larger volume (element strides of sample, d-plane, h-row; w stride = Cin)
 };
 int conv_small_stats_parts(int N, int D, int H, int W, int planar);
+int conv_small_stats_parts2(int N, int D, int H, int W, int planar, int Cin, int Cout);      // record count of launch_conv_small_fwd for this shape
 int launch_conv_small_fwd(ConvSmallArgs a, hipStream_t s);
 // dW partials for the first layer: part[split][T][CoPad=Cout][CiPad=Cin] ; returns number of splits used
 int conv_small_wgrad_splits(int N, int D, int H, int W, int planar);

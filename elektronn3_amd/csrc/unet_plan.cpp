@@ -244,7 +244,7 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
                 if (training) { slab_own[k] = (size_t)wgrad_splits(kind, N, ci.D, ci.H, ci.W, u.cin, u.cout) * taps * (cdiv(u.cout, 32) * 32) * (cdiv(u.cin, 32) * 32); slabmax = max_sz(slabmax, slab_own[k]); }
             } else {
                 wmax = max_sz(wmax, conv_packed_floats(kind, u.cout, u.cin));   // only its dgrad (dx requested) packs weights
-                statmax = max_sz(statmax, (size_t)conv_small_stats_parts(N, ci.D, ci.H, ci.W, u.planar) * u.cout * 3);
+                statmax = max_sz(statmax, (size_t)conv_small_stats_parts2(N, ci.D, ci.H, ci.W, u.planar, u.cin, u.cout) * u.cout * 3);
                 if (training) slabmax = max_sz(slabmax, (size_t)conv_small_wgrad_splits(N, ci.D, ci.H, ci.W, u.planar) * taps * u.cout * u.cin);
             }
         }
@@ -812,7 +812,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.Cout = u.cout; a.planar = u.planar;
             a.epi_scale = es; a.epi_shift = eh; a.stats = (bn_train && !vcrop) ? stat_buf : nullptr;
             if (view && k == 0) { a.xs_n = view->x_stride[0]; a.xs_d = view->x_stride[1]; a.xs_h = view->x_stride[2]; }      // (the tile is read in place)
-            parts = conv_small_stats_parts(N, ci.D, ci.H, ci.W, u.planar);
+            parts = conv_small_stats_parts2(N, ci.D, ci.H, ci.W, u.planar, u.cin, u.cout);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_small_fwd(a, s)); }
         } else {
             const int taps = u.planar ? 9 : 27, NPad = pad_cols(u.cout);

@@ -141,6 +141,8 @@ CONV_CASES = [
     (24, 8, (5, 5, 5), False, 1),        # CK=8 with 3 chunks, tiny Cout
     (64, 32, (2, 20, 33), True, 2),      # planar 1x3x3
     (1, 32, (5, 9, 19), False, 2),       # first layer (direct kernel)
+    (1, 32, (30, 125, 130), False, 2),   # first layer, >= 1024 bricks of 4x8x32: the persistent matrix-core kernel (conv_first_mfma_kernel), ragged in every dim
+    (1, 64, (20, 70, 100), False, 3),    # the same with two 32-channel passes
     (2, 16, (4, 6, 7), True, 1),         # direct kernel, 2 input channels, planar
     (1, 64, (3, 20, 33), True, 2),       # direct kernel, planar, 2 passes of 32 channels (statistics scratch > weight slab)
     (128, 64, (4, 8, 16), False, 1),     # small grid -> intra-workgroup split-K (KS=4), NT=1
@@ -192,6 +194,17 @@ def test_conv3_fused_prologue_epilogue(ops, orc):
     xin = np.maximum(x * ps[None, :, None, None, None] + ph[None, :, None, None, None], 0)
     ref = np.maximum(orc.conv3d_fwd(xin, w, None, (1, 1, 1)) * es[None, :, None, None, None] + eh[None, :, None, None, None], 0)
     y = ops.conv3d(dev(x), cu(w), None, pro=(cu(ps), cu(ph)), epi=(cu(es), cu(eh)))
+    np.testing.assert_allclose(host(y), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_first_conv_matrix_core_kernel_eval_epilogue(ops, orc):
+    """Folded eval-mode BN + ReLU on store in the persistent first-conv kernel (one input channel, >= 1024 bricks)."""
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((1, 1, 33, 130, 131), dtype=np.float32)
+    w = rng.standard_normal((32, 1, 3, 3, 3), dtype=np.float32) * 0.2
+    es, eh = rng.standard_normal(32, dtype=np.float32), rng.standard_normal(32, dtype=np.float32)
+    ref = np.maximum(orc.conv3d_fwd(x, w, None, (1, 1, 1)) * es[None, :, None, None, None] + eh[None, :, None, None, None], 0)
+    y = ops.conv3d(dev(x), cu(w), None, epi=(cu(es), cu(eh)))
     np.testing.assert_allclose(host(y), ref, rtol=1e-4, atol=1e-4)
 
 
