@@ -205,7 +205,7 @@ def train_leg(dev, kind, steps=10, warmup=3):
         if kind == 'bf16' and k_ms > 0:
             ach = lflops / (k_ms * 1e-3) / 1e12
             res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s', 'frac': ach / MFMA_PEAK_TFLOPS['bf16'],
-                               'kernel': f'conv_b16_kernel fwd of {prof_layer} ({lcin}->{lcout}, {ltaps} taps, {lvox} voxels)', 'ms_per_launch': k_ms, 'launches_timed': k_n,
+                               'kernel': f'conv_b16_pkernel (persistent direct implicit GEMM, v_mfma_f32_32x32x16_bf16) fwd of {prof_layer} ({lcin}->{lcout}, {ltaps} taps, {lvox} voxels)', 'ms_per_launch': k_ms, 'launches_timed': k_n,
                                'hbm_frac': (lvox * (lcin + lcout) + lcin * lcout * ltaps) * 2 / (k_ms * 1e-3) / HBM_PEAK}
     if kind == 'cfg4':
         res['workload'] = 'BASELINE.json configs[3] per-GPU workload: UNet(n_blocks=4, start_filts=64, planar_blocks=(0,1)) fp32 train fwd+bwd, batch 2 of 1x32x256x256'
@@ -360,7 +360,7 @@ def main():
                 traffic, tsrc = float(ent['hbm_bytes_per_launch']), PMC_FILE
         except Exception:  # noqa: BLE001
             pass
-        kern = ('conv_b16_kernel (direct implicit GEMM, v_mfma_f32_32x32x16_bf16)' if bf16 else
+        kern = ('conv_b16_pkernel (persistent direct implicit GEMM, v_mfma_f32_32x32x16_bf16)' if bf16 else
                 ('conv3_wino_pkernel (persistent Winograd F(2x2x2,3x3x3), v_mfma_f32_32x32x2_f32)' if wino else 'conv3_v3_kernel (direct, fp32 MFMA)'))
         res = {
             'metric': 'voxels/sec (train fwd+bwd) 3D UNet 64x128x128',

@@ -421,6 +421,48 @@ def make_unet_bf16(unet, out, seed=21, n_blocks=2, start_filts=32, shape=(9, 18,
 TIE_TOL = 2e-6      # |pre-activation| (resp. gap between the two largest values of a pooling window) below which an fp32 run may decide differently
 
 
+def make_cfg2_digest(unet, loss_mod, out, seed=2024, n_blocks=4, start_filts=32, shape=(64, 128, 128), batch=2):
+    """A train step of the reference at BASELINE.json configs[1]'s OWN size -- UNet(1, 2, n_blocks=4, start_filts=32), batch 2 of 64 x 128 x 128: 8192
+    Winograd bricks at level 0 -- in fp32 and fp64, kept as a digest (tests/helpers.py: parameters, input and target are regenerated from the seed on
+    both sides; the fixture holds samples, norms and projections of what the reference computed).  `python make_golden.py cfg2`, a few minutes of CPU."""
+    from collections import OrderedDict
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import digest_state_dict, digest_inputs, digest_of, rel_l2
+    kw = dict(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts)
+    model = unet.UNet(**kw)
+    shapes = OrderedDict((k, tuple(v.shape)) for k, v in model.state_dict().items())
+    sd0 = digest_state_dict(shapes, seed)
+    x_np, t_np = digest_inputs(batch, shape, seed)
+    x, target = torch.from_numpy(x_np), torch.from_numpy(t_np)
+    d = {'seed': np.array(seed), 'cfg.n_blocks': n_blocks, 'cfg.start_filts': start_filts, 'cfg.planar_blocks': np.array((), dtype=np.int64),
+         'batch': np.array(batch), 'shape': np.array(shape), 'names': np.array(list(shapes)), 'shapes': np.array([','.join(str(i) for i in s) for s in shapes.values()])}
+    runs = {}
+    for tag, dt in (('32', torch.float32), ('64', torch.float64)):
+        m = unet.UNet(**kw).to(dt)
+        m.load_state_dict({k: torch.as_tensor(v).to(dt) if v.dtype != np.int64 else torch.as_tensor(v) for k, v in sd0.items()})
+        m.train()
+        o = m(x.to(dt))
+        crit = criterion(loss_mod).to(dt)
+        l = crit(o, target)
+        l.backward()
+        runs[tag] = (npy(o), float(l), {k: npy(p.grad) for k, p in m.named_parameters()}, {k: npy(v) for k, v in m.state_dict().items() if 'running' in k})
+        print(tag, 'loss', float(l), flush=True)
+        del m, o, l
+    o32, l32, g32, r32 = runs['32']
+    o64, l64, g64, r64 = runs['64']
+    d['loss32'], d['loss64'] = np.array(l32), np.array(l64)
+    d['logits32'] = o32[:, :, ::8, ::8, ::8].astype(np.float32); d['logits64'] = o64[:, :, ::8, ::8, ::8].astype(np.float64)
+    d['logits_err_ref'] = np.array(np.abs(o32 - o64).max())
+    for k, v in r32.items():
+        d['sd1/' + k] = v
+    for k in g64:
+        n64, s64, p64 = digest_of(k, g64[k], seed)
+        n32, s32, p32 = digest_of(k, g32[k], seed)
+        d['g/' + k] = np.concatenate([[n64, n32, rel_l2(g32[k], g64[k])], p64, p32, [len(s64)], s64, s32])
+    np.savez_compressed(out, **d)
+    print('wrote', out, f'{os.path.getsize(out) / 1e6:.2f} MB')
+
+
 def make_tie_counts(unet, out):
     """Which train-step fixtures contain a ReLU / max-pool decision that is a near-tie in the reference's fp64 run?
 
@@ -496,6 +538,11 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'ties':      # near-tie ReLU / max-pool decisions of every train-step fixture (tie_counts.json)
         unet, inference, loss_mod = load_reference()
         make_tie_counts(unet, f'{HERE}/tie_counts.json')
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'cfg2':      # digest of a train step at BASELINE configs[1]'s own size (cfg2_digest.npz)
+        torch.set_num_threads(8)
+        unet, inference, loss_mod = load_reference()
+        make_cfg2_digest(unet, loss_mod, f'{HERE}/cfg2_digest.npz')
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'f16':      # the reference in float16 (model.half(), inference.py:445-446): O(1) incoming gradient, as GradScaler provides
         torch.set_num_threads(8)

@@ -173,3 +173,52 @@ def spin(stream, blocks, microseconds, lds_bytes=16384, sink=None):
     rc = lib.spin_launch(stream.cuda_stream, int(blocks), int(lds_bytes), int(microseconds * 100), sink.data_ptr())
     assert rc == 0, rc
     return sink
+
+
+# ---------------------------------------------------------------------------------------------- full-size digest fixtures
+# A train step at BASELINE.json configs[1]'s own size (UNet(1, 2, n_blocks=4, start_filts=32), batch 2 of 64 x 128 x 128) has 22 M parameters and
+# 2 M voxels: neither the state_dict nor the gradients fit a "small fixture".  Both sides therefore REGENERATE parameters, input and target from
+# one seed with numpy's PCG64 (stable across platforms), and the fixture keeps a DIGEST of what the reference computed from them: a strided sample
+# of the logits, and per gradient tensor its norm, a strided sample and four projections on seeded Gaussian vectors (for a Gaussian r,
+# E <e, r>^2 = |e|^2: the projections of a difference estimate its norm), from the reference's fp32 and fp64 runs.
+def digest_state_dict(shapes, seed):
+    """shapes: OrderedDict name -> shape in the reference's state_dict order (float entries only).  Conv / transposed-conv weights ~ N(0, 2 / fan_in),
+    norm weights 1 + 0.2 N, biases 0.1 N, running_mean 0, running_var 1."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    for k, shp in shapes.items():
+        shp = tuple(int(v) for v in shp)
+        if k.endswith('num_batches_tracked'):
+            sd[k] = np.zeros(shp, np.int64)
+        elif k.endswith('running_mean'):
+            sd[k] = np.zeros(shp, np.float32)
+        elif k.endswith('running_var'):
+            sd[k] = np.ones(shp, np.float32)
+        elif len(shp) >= 3:
+            fan_in = int(np.prod(shp[1:]))
+            sd[k] = (rng.standard_normal(shp, dtype=np.float32) * np.float32(np.sqrt(2.0 / max(fan_in, 1))))
+        elif 'norm' in k and k.endswith('weight'):
+            sd[k] = (1.0 + 0.2 * rng.standard_normal(shp, dtype=np.float32)).astype(np.float32)
+        else:
+            sd[k] = (0.1 * rng.standard_normal(shp, dtype=np.float32)).astype(np.float32)
+    return sd
+
+
+def digest_inputs(batch, shape, seed):
+    rng = np.random.default_rng(seed + 1)
+    x = rng.standard_normal((batch, 1, *shape), dtype=np.float32)
+    t = rng.integers(0, 2, (batch, *shape), dtype=np.int64)
+    return x, t
+
+
+def digest_vectors(name, numel, seed, n=4):
+    import zlib
+    rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+    return [rng.standard_normal(numel, dtype=np.float32) for _ in range(n)]
+
+
+def digest_of(name, g, seed):
+    """(norm, strided sample of <= 256 elements, 4 projections) of a gradient tensor, in float64."""
+    g = np.asarray(g, np.float64).reshape(-1)
+    step = max(1, g.size // 256)
+    return float(np.linalg.norm(g)), g[::step][:256].copy(), np.array([float(g @ r.astype(np.float64)) for r in digest_vectors(name, g.size, seed)])

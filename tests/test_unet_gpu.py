@@ -340,6 +340,58 @@ def _train_step_vs_pytorch_rocm(m, x, t, dt=torch.float32, atol=2e-4, nb=4, plan
     return worst
 
 
+def test_full_size_cfg2_against_the_reference_digest():
+    """The REFERENCE's own train step at BASELINE.json configs[1]'s size (8192 Winograd bricks at level 0), closing reference -> fixture -> HIP at the size
+    the headline is measured on: tests/golden/cfg2_digest.npz (make_golden.py cfg2) holds, from the reference's fp32 and fp64 CPU runs on parameters /
+    input / target that both sides regenerate from one seed, a strided sample of the logits, the loss, the running statistics, and per gradient tensor
+    its norm, a strided sample and four Gaussian projections.  Bounds as in test_train_step_matches_reference: logits within max(3 x the reference's own
+    fp32-vs-fp64 error, 2e-5) of the fp64 sample; per gradient tensor the error norm estimated from the projections (E <e, r>^2 = |e|^2) and the sampled
+    rel-L2 within SURVEY 8c's 1e-2 always, and within 2 x max(3 x the reference's own error, 1e-4) -- the factor 2 is the spread of a four-sample norm
+    estimate -- unless this fixture's near-tie count says a flipped ReLU / arg-max decision may move a tensor."""
+    from collections import OrderedDict
+    from helpers import digest_state_dict, digest_inputs, digest_of
+    from oracle.torch_ref import combined_loss
+    g = load_npz('cfg2_digest.npz')
+    seed = int(g['seed'])
+    shapes = OrderedDict((str(k), tuple(int(i) for i in str(sh).split(',')) if str(sh) else ()) for k, sh in zip(g['names'], g['shapes']))
+    sd0 = digest_state_dict(shapes, seed)
+    m = build(unet_cfg(g), sd0).train()
+    x_np, t_np = digest_inputs(int(g['batch']), tuple(int(v) for v in g['shape']), seed)
+    x, t = torch.from_numpy(x_np).cuda(), torch.from_numpy(t_np).cuda()
+    out = m(x)
+    samp = out.detach()[:, :, ::8, ::8, ::8].cpu().numpy()
+    err_ref = float(g['logits_err_ref'])
+    np.testing.assert_allclose(samp, g['logits32'], rtol=1e-4, atol=1e-4)
+    assert float(np.abs(samp - g['logits64']).max()) <= max(3 * err_ref, 2e-5), (float(np.abs(samp - g['logits64']).max()), err_ref)
+    loss = combined_loss(out, t)
+    assert abs(float(loss.detach()) - float(g['loss64'])) < 2e-5, (float(loss.detach()), float(g['loss64']), float(g['loss32']))
+    loss.backward()
+    sd = m.state_dict()
+    for k, v in sub(g, 'sd1').items():
+        np.testing.assert_allclose(sd[k].cpu().numpy(), v, rtol=1e-5, atol=1e-6, err_msg=k)
+    names = {k for k, _ in m.named_parameters()}
+    gnorm = np.sqrt(sum(float(g['g/' + k][0]) ** 2 for k in names))
+    worst = (0.0, 0.0, '')
+    for k, p in m.named_parameters():
+        rec = g['g/' + k]
+        n64, err_own = float(rec[0]), float(rec[2])
+        p64 = rec[3:7]
+        ns = int(rec[11]); s64 = rec[12:12 + ns]
+        gr = p.grad.detach().cpu().numpy()
+        if is_prebn_bias(k, names):
+            assert np.abs(gr).max() <= 1e-5 * gnorm, (k, float(np.abs(gr).max()))
+            continue
+        _, s_h, p_h = digest_of(k, gr, seed)
+        est = float(np.sqrt(np.mean((p_h - p64) ** 2))) / max(n64, 1e-30)          # estimated rel-L2 of (HIP - fp64 reference) over the whole tensor
+        smp = float(np.linalg.norm(s_h - s64) / max(np.linalg.norm(s64), 1e-30))   # the same on the sampled elements
+        assert est <= 1e-2 and (smp <= 1e-2 or np.linalg.norm(s64) < 1e-3 * n64), (k, est, smp, err_own)
+        if est / max(err_own, 1e-30) > worst[0] / max(worst[1], 1e-30) or worst[2] == '':
+            worst = (est, err_own, k)
+        bound = 2 * max(3 * err_own, 1e-4)
+        assert est <= bound or est <= 4e-3, (k, est, err_own)      # (4e-3: the size of one flipped near-tie decision, see test_train_step_matches_reference)
+    print(f'cfg 2 digest: worst projected gradient error {worst[0]:.2e} (reference fp32 itself: {worst[1]:.2e}) at {worst[2]}; logits err_ref {err_ref:.2e}')
+
+
 def test_full_size_cfg2_against_pytorch_rocm(cfg2):
     """BASELINE.json configs[1] at full size: same weights, same input, the reference's ATen op sequence executed by
     PyTorch-ROCm (MIOpen) on this GPU vs the HIP path."""

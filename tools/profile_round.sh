@@ -22,7 +22,7 @@ done
 cd $R
 rm -f $O/pmc_roofline.json
 python tools/pmc_roofline.py --dtype f32 --kernel conv3_wino_pkernel --fetch $O/pmc_f32_FETCH_SIZE --write $O/pmc_f32_WRITE_SIZE --busy $O/pmc_f32_SQ_VALU_MFMA_BUSY_CYCLES --steps 6 -o $O/pmc_roofline.json --command "$PB --dtype f32" > $O/pmc_roofline_f32.log 2>&1
-python tools/pmc_roofline.py --dtype bf16 --kernel "conv_b16_kernel<4, 1, 3, 32, 16>" --fetch $O/pmc_bf16_FETCH_SIZE --write $O/pmc_bf16_WRITE_SIZE --busy $O/pmc_bf16_SQ_VALU_MFMA_BUSY_CYCLES --steps 6 -o $O/pmc_roofline.json --command "$PB --dtype bf16" > $O/pmc_roofline_bf16.log 2>&1
+python tools/pmc_roofline.py --dtype bf16 --kernel "conv_b16_pkernel" --fetch $O/pmc_bf16_FETCH_SIZE --write $O/pmc_bf16_WRITE_SIZE --busy $O/pmc_bf16_SQ_VALU_MFMA_BUSY_CYCLES --steps 6 -o $O/pmc_roofline.json --command "$PB --dtype bf16" > $O/pmc_roofline_bf16.log 2>&1
 python tools/pmc_summary.py $O/pmc_bf16_FETCH_SIZE $O/pmc_bf16_WRITE_SIZE $O/pmc_bf16_SQ_VALU_MFMA_BUSY_CYCLES --filter "b16|bn_|wgrad_reduce" -o $O/pmc_bf16.md > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmc_f32_FETCH_SIZE $O/pmc_f32_WRITE_SIZE $O/pmc_f32_SQ_VALU_MFMA_BUSY_CYCLES -o $O/pmc_f32.md > /dev/null 2>&1
 # keep the merged output small: drop the raw databases / csv
