@@ -264,3 +264,27 @@ def test_swa_running_average():
     for i in range(n):      # swap_swa_sgd
         np.testing.assert_array_equal(g[f'p_swapped/{i}'], bufs[i])
         np.testing.assert_array_equal(g[f'b_swapped/{i}'], g[f'p{steps}/{i}'])
+
+
+def test_torch_restatement_at_the_headline_size_against_the_reference_digest():
+    """oracle/torch_ref.py (the checker of every full-size GPU parity test and bench.py's cpu_baseline) against the REFERENCE's own forward at
+    BASELINE.json configs[1]'s size: tests/golden/cfg2_digest.npz holds a strided sample of the reference's train-mode logits and its loss for
+    parameters / input / target that are regenerated here from the digest's seed (helpers.digest_*).  Forward + criterion only (the backward at this
+    size is covered on the GPU side by test_full_size_cfg2_against_the_reference_digest); ~10 s of CPU."""
+    from collections import OrderedDict
+    import torch
+    from helpers import digest_inputs, digest_state_dict
+    from oracle.torch_ref import combined_loss, unet_forward
+    g = load_npz('cfg2_digest.npz')
+    seed = int(g['seed'])
+    shapes = OrderedDict((str(k), tuple(int(i) for i in str(sh).split(',')) if str(sh) else ()) for k, sh in zip(g['names'], g['shapes']))
+    sd = {k: torch.from_numpy(v) for k, v in digest_state_dict(shapes, seed).items()}
+    x_np, t_np = digest_inputs(int(g['batch']), tuple(int(v) for v in g['shape']), seed)
+    with torch.no_grad():
+        out = unet_forward(sd, torch.from_numpy(x_np), int(g['cfg.n_blocks']), (), training=True)
+        loss = float(combined_loss(out, torch.from_numpy(t_np)))
+    samp = out[:, :, ::8, ::8, ::8].numpy()
+    err_ref = float(g['logits_err_ref'])
+    assert float(np.abs(samp - g['logits64']).max()) <= max(3 * err_ref, 2e-5)
+    np.testing.assert_allclose(samp, g['logits32'], rtol=1e-4, atol=1e-4)
+    assert abs(loss - float(g['loss64'])) < 2e-5
