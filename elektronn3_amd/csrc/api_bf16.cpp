@@ -18,7 +18,7 @@ size_t e3_conv3d_workspace_bytes_bf16(int Cin, int Cout, int N, int D, int H, in
 }
 
 int e3_conv3d_stats_parts_bf16(int Cin, int Cout, int N, int D, int H, int W, int planar) {
-    return Cin < 8 ? conv_small_b16_stats_parts(N, D, H, W, planar) : conv_b16_stats_parts(N, D, H, W, Cin, Cout, planar);
+    return Cin < 8 ? conv_small_b16_stats_parts2(N, D, H, W, planar, Cin, Cout) : conv_b16_stats_parts(N, D, H, W, Cin, Cout, planar);
 }
 
 int e3_conv3d_fwd_bf16(void* stream, const void* x, int x_ldc, int Cin, const float* w, const float* bias, void* y, int y_ldc, int Cout,

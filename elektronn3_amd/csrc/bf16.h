@@ -139,6 +139,8 @@ int launch_conv_first_b16_fwd(const bf16_t* x, const float* w, const float* bias
 int launch_conv_first_b16_wgrad(const bf16_t* x, const bf16_t* dy, int dy_ldc, float* part, int N, int D, int H, int W, int Cout, int tiles_per_split, int splits,
                                 hipStream_t s);
 int conv_small_b16_stats_parts(int N, int D, int H, int W, int planar = 0);
+int conv_first_b16_stats_parts(int N, int D, int H, int W, int Cout);      // > 0: launch_conv_first_b16_fwd writes that many records (persistent kernel)
+int conv_small_b16_stats_parts2(int N, int D, int H, int W, int planar, int Cin, int Cout);      // record count of launch_conv_small_b16_fwd for this shape
 int launch_conv_small_b16_fwd(const bf16_t* x, int Cin, const float* w /*torch (Cout,Cin,T) fp32*/, const float* bias, bf16_t* y, int y_ldc,
                               int N, int D, int H, int W, int Cout, int planar, const float* epi_scale, const float* epi_shift, float* stats, hipStream_t s);
 int conv_small_b16_wgrad_splits(int N, int D, int H, int W, int planar = 0);

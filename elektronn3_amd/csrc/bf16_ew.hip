@@ -839,6 +839,10 @@ int launch_bn_bwd_b16_apply(BnBwdB16Args a, hipStream_t s) { return bn_bwd_b16_l
 
 // brick of the first conv: 2 x 8 x 16 voxels, planar (1x3x3 taps, unet.py:114-128) 1 x 16 x 16
 int conv_small_b16_stats_parts(int N, int D, int H, int W, int planar) { return planar ? N * D * cdiv(H, 16) * cdiv(W, 16) : N * cdiv(D, 2) * cdiv(H, 8) * cdiv(W, 16); }
+int conv_small_b16_stats_parts2(int N, int D, int H, int W, int planar, int Cin, int Cout) {
+    const int p = conv_first_b16_supported(Cin, Cout, planar) ? conv_first_b16_stats_parts(N, D, H, W, Cout) : 0;
+    return p > 0 ? p : conv_small_b16_stats_parts(N, D, H, W, planar);
+}
 
 int launch_conv_small_b16_fwd(const bf16_t* x, int Cin, const float* w, const float* bias, bf16_t* y, int y_ldc,
                               int N, int D, int H, int W, int Cout, int planar, const float* epi_scale, const float* epi_shift, float* stats, hipStream_t s) {

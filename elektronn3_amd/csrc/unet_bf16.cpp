@@ -246,7 +246,7 @@ static int forward_b16_impl(e3_unet_plan* plan, void* stream, const void* x, int
             parts = upconv_b16_stats_parts(N, li.D, li.H, li.W, sd, u.cin);
             { ProfB pr(plan, s, (int)k, 0); RUN(launch_upconv_b16_fwd(a, s)); }
         } else if (u.cin < 8) {
-            parts = conv_small_b16_stats_parts(N, li.D, li.H, li.W, pl);
+            parts = conv_small_b16_stats_parts2(N, li.D, li.H, li.W, pl, u.cin, u.cout);
             ProfB pr(plan, s, (int)k, 0);
             RUN(launch_conv_small_b16_fwd(cur, u.cin, P(u.p_w), training ? P(u.p_b) : nullptr, dst, dst_ldc, N, li.D, li.H, li.W, u.cout, pl, es, eh,
                                           training ? B.stats : nullptr, s));

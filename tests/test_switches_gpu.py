@@ -19,7 +19,7 @@ GROUPS = {
                                E3_NO_LOSS_BWD='1'), FP32_TESTS),
     'persistent_everywhere': (dict(E3_WINO_PERSIST_MIN='1', E3_UPCONV_NO_PERSIST='1', E3_CONV_NO_V3='1', E3_ATT_VALU='1'), FP32_TESTS),
     'b16_alternatives': (dict(E3_B16_NO_SPLITK='1', E3_B16_UP_GENERIC='1', E3_B16_BD='2', E3_B16_TW='16', E3_B16_COT='1'), B16_TESTS),
-    'b16_no_persistent_conv': (dict(E3_B16_NO_PERSIST='1'), ['tests/test_bf16_gpu.py', '-k', 'full_size or fixture']),
+    'b16_no_persistent_conv': (dict(E3_B16_NO_PERSIST='1', E3_B16_FIRST_NO_PERSIST='1'), ['tests/test_bf16_gpu.py', '-k', 'full_size or fixture']),
     'b16_on_fp32_kernels_plain_predictor': (dict(E3_NO_BF16='1', E3_PREDICTOR_NO_PIPELINE='1'),
                                             ['tests/test_predictor.py', 'tests/test_bf16_gpu.py', '-k', 'predictor or fixture or autocast']),
     # data-parallel: overlapped bucket with a CU reserve as GradSync's default; Predictor: the runtime's pageable copies; elementwise passes: non-temporal
