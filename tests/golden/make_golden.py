@@ -421,20 +421,20 @@ def make_unet_bf16(unet, out, seed=21, n_blocks=2, start_filts=32, shape=(9, 18,
 TIE_TOL = 2e-6      # |pre-activation| (resp. gap between the two largest values of a pooling window) below which an fp32 run may decide differently
 
 
-def make_cfg2_digest(unet, loss_mod, out, seed=2024, n_blocks=4, start_filts=32, shape=(64, 128, 128), batch=2):
+def make_cfg2_digest(unet, loss_mod, out, seed=2024, n_blocks=4, start_filts=32, shape=(64, 128, 128), batch=2, planar_blocks=()):
     """A train step of the reference at BASELINE.json configs[1]'s OWN size -- UNet(1, 2, n_blocks=4, start_filts=32), batch 2 of 64 x 128 x 128: 8192
     Winograd bricks at level 0 -- in fp32 and fp64, kept as a digest (tests/helpers.py: parameters, input and target are regenerated from the seed on
     both sides; the fixture holds samples, norms and projections of what the reference computed).  `python make_golden.py cfg2`, a few minutes of CPU."""
     from collections import OrderedDict
     sys.path.insert(0, os.path.dirname(HERE))
     from helpers import digest_state_dict, digest_inputs, digest_of, rel_l2
-    kw = dict(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts)
+    kw = dict(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts, planar_blocks=planar_blocks)
     model = unet.UNet(**kw)
     shapes = OrderedDict((k, tuple(v.shape)) for k, v in model.state_dict().items())
     sd0 = digest_state_dict(shapes, seed)
     x_np, t_np = digest_inputs(batch, shape, seed)
     x, target = torch.from_numpy(x_np), torch.from_numpy(t_np)
-    d = {'seed': np.array(seed), 'cfg.n_blocks': n_blocks, 'cfg.start_filts': start_filts, 'cfg.planar_blocks': np.array((), dtype=np.int64),
+    d = {'seed': np.array(seed), 'cfg.n_blocks': n_blocks, 'cfg.start_filts': start_filts, 'cfg.planar_blocks': np.array(planar_blocks, dtype=np.int64),
          'batch': np.array(batch), 'shape': np.array(shape), 'names': np.array(list(shapes)), 'shapes': np.array([','.join(str(i) for i in s) for s in shapes.values()])}
     runs = {}
     for tag, dt in (('32', torch.float32), ('64', torch.float64)):
@@ -543,6 +543,11 @@ if __name__ == '__main__':
         torch.set_num_threads(8)
         unet, inference, loss_mod = load_reference()
         make_cfg2_digest(unet, loss_mod, f'{HERE}/cfg2_digest.npz')
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'cfg4':      # the same for BASELINE configs[3]: anisotropic UNet(planar_blocks=(0, 1), start_filts=64), batch 2 of 32 x 256 x 256 (cfg4_digest.npz; ~20 GB, tens of minutes)
+        torch.set_num_threads(8)
+        unet, inference, loss_mod = load_reference()
+        make_cfg2_digest(unet, loss_mod, f'{HERE}/cfg4_digest.npz', seed=2025, n_blocks=4, start_filts=64, shape=(32, 256, 256), batch=2, planar_blocks=(0, 1))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'f16':      # the reference in float16 (model.half(), inference.py:445-446): O(1) incoming gradient, as GradScaler provides
         torch.set_num_threads(8)

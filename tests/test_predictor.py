@@ -516,14 +516,16 @@ def test_threaded_host_copy_is_a_copy():
 
 
 @pytest.mark.gpu
-def test_predictor_in_place_tiles_switch_gives_the_same_volume(monkeypatch):
+@pytest.mark.parametrize('vshape,tile', [((2, 1, 50, 100, 150), (32, 64, 80)), ((1, 1, 44, 150, 170), (40, 128, 128))],
+                         ids=['small_tiles', 'tiles_of_1400_first_conv_bricks'])       # (the second case reaches conv_first_mfma_kernel through the strides of the padded volume)
+def test_predictor_in_place_tiles_switch_gives_the_same_volume(monkeypatch, vshape, tile):
     """Tiles read in place from the padded volume and written in place into the output volume (UNet.forward_tile / e3_unet_forward_tile, the default
     for the native fp32 model) against the copied-tile path (E3_PREDICTOR_NO_INPLACE=1): identical volumes, also with a ragged last tile."""
     from elektronn3_amd import inference
     from elektronn3_amd.unet import UNet
     torch.manual_seed(8)
     m = UNet(in_channels=1, out_channels=3, n_blocks=3, start_filts=32, normalization='batch').cuda().eval()
-    vol = torch.randn(2, 1, 50, 100, 150)                     # not a multiple of the tile shape: padded, cropped on the way back
+    vol = torch.randn(*vshape)                                # not a multiple of the tile shape: padded, cropped on the way back
     outs = []
     calls = []
     real = UNet.forward_tile
@@ -533,7 +535,7 @@ def test_predictor_in_place_tiles_switch_gives_the_same_volume(monkeypatch):
             monkeypatch.delenv('E3_PREDICTOR_NO_INPLACE', raising=False)
         else:
             monkeypatch.setenv('E3_PREDICTOR_NO_INPLACE', '1')
-        p = inference.Predictor(m, device='cuda', tile_shape=(32, 64, 80), overlap_shape=(8, 16, 16), out_shape=(3, 50, 100, 150), apply_softmax=True,
+        p = inference.Predictor(m, device='cuda', tile_shape=tile, overlap_shape=(8, 16, 16), out_shape=(3, *vshape[2:]), apply_softmax=True,
                                 strict_shapes=False)
         n0 = len(calls)
         outs.append(p.predict(vol).clone())

@@ -340,7 +340,8 @@ def _train_step_vs_pytorch_rocm(m, x, t, dt=torch.float32, atol=2e-4, nb=4, plan
     return worst
 
 
-def test_full_size_cfg2_against_the_reference_digest():
+@pytest.mark.parametrize('case', ['cfg2_digest.npz', 'cfg4_digest.npz'])
+def test_full_size_cfg2_against_the_reference_digest(case):
     """The REFERENCE's own train step at BASELINE.json configs[1]'s size (8192 Winograd bricks at level 0), closing reference -> fixture -> HIP at the size
     the headline is measured on: tests/golden/cfg2_digest.npz (make_golden.py cfg2) holds, from the reference's fp32 and fp64 CPU runs on parameters /
     input / target that both sides regenerate from one seed, a strided sample of the logits, the loss, the running statistics, and per gradient tensor
@@ -351,7 +352,7 @@ def test_full_size_cfg2_against_the_reference_digest():
     from collections import OrderedDict
     from helpers import digest_state_dict, digest_inputs, digest_of
     from oracle.torch_ref import combined_loss
-    g = load_npz('cfg2_digest.npz')
+    g = load_npz(case)      # (cfg4_digest.npz: the same for BASELINE configs[3], UNet(planar_blocks=(0, 1), start_filts=64) on 2 x 32x256x256 -- the planar Winograd kernels at their own size)
     seed = int(g['seed'])
     shapes = OrderedDict((str(k), tuple(int(i) for i in str(sh).split(',')) if str(sh) else ()) for k, sh in zip(g['names'], g['shapes']))
     sd0 = digest_state_dict(shapes, seed)
@@ -389,7 +390,7 @@ def test_full_size_cfg2_against_the_reference_digest():
             worst = (est, err_own, k)
         bound = 2 * max(3 * err_own, 1e-4)
         assert est <= bound or est <= 4e-3, (k, est, err_own)      # (4e-3: the size of one flipped near-tie decision, see test_train_step_matches_reference)
-    print(f'cfg 2 digest: worst projected gradient error {worst[0]:.2e} (reference fp32 itself: {worst[1]:.2e}) at {worst[2]}; logits err_ref {err_ref:.2e}')
+    print(f'{case}: worst projected gradient error {worst[0]:.2e} (reference fp32 itself: {worst[1]:.2e}) at {worst[2]}; logits err_ref {err_ref:.2e}')
 
 
 def test_full_size_cfg2_against_pytorch_rocm(cfg2):
