@@ -728,8 +728,9 @@ Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout, int planar
     while (!no_split && wgs * d.ksplit < 512 && nch % (2 * d.ksplit) == 0 && d.ksplit < 8) d.ksplit *= 2;
     // persistent form (conv_b16_pkernel): 3x3x3, 4 x 4 x 32 bricks in the column order, one output tile per workgroup, several items per workgroup
     static const bool no_persist = getenv("E3_B16_NO_PERSIST") != nullptr;      // A/B switch
+    static const long persist_min = getenv("E3_B16_PERSIST_MIN") ? atol(getenv("E3_B16_PERSIST_MIN")) : 4 * PGRID;      // (tests: 1 = every shape the kernel can take)
     const int cgroups = Cout / 32;
-    d.persist = (!no_persist && !planar && d.bd == 4 && d.tw == 32 && d.co_t == 1 && d.ksplit == 1 && wgs >= 4 * PGRID && 64 % cgroups == 0 &&
+    d.persist = (!no_persist && !planar && d.bd == 4 && d.tw == 32 && d.co_t == 1 && d.ksplit == 1 && wgs >= persist_min && 64 % cgroups == 0 &&
                  (cdiv(H, 4) & 1) == 0 && (cdiv(W, 32) & 1) == 0 && wgs * 256 < (1l << 32)) ? 1 : 0;
     return d;
 }

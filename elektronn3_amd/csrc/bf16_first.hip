@@ -420,7 +420,8 @@ static bool first_b16_persist(int N, int D, int H, int W, int Cout) {
     static const bool off = getenv("E3_B16_FIRST_NO_PERSIST") != nullptr;
     if (off || PGRID1 % (Cout / 32) != 0) return false;
     const long long items = (long long)N * cdiv(D, PB_D) * cdiv(H, PB_H) * cdiv(W, PB_W) * (Cout / 32);
-    return items >= PGRID1 && items < (1ll << 31) && (long long)H * W * 6 * 2 < 0x7fffffffll;
+    static const long long min_items = getenv("E3_B16_FIRST_PERSIST_MIN") ? atoll(getenv("E3_B16_FIRST_PERSIST_MIN")) : PGRID1;      // (tests: 1 = every shape the kernel can take)
+    return items >= min_items && items < (1ll << 31) && (long long)H * W * 6 * 2 < 0x7fffffffll;
 }
 int conv_first_b16_stats_parts(int N, int D, int H, int W, int Cout) {      // 0: the brick records of the conv_small_* kernels
     return first_b16_persist(N, D, H, W, Cout) ? PGRID1 / (Cout / 32) : 0;

@@ -779,7 +779,8 @@ static bool first_mfma(int N, int D, int H, int W, int planar, int Cin, int Cout
     static const bool off = getenv("E3_FIRST_NO_MFMA") != nullptr;
     if (off || planar || Cin != 1 || Cout % 32 != 0 || FGRID % (Cout / 32) != 0) return false;
     const long long items = (long long)N * cdiv(D, FB_D) * cdiv(H, FB_H) * cdiv(W, FB_W) * (Cout / 32);
-    return items >= FGRID && items < (1ll << 31);
+    static const long long min_items = getenv("E3_FIRST_MFMA_MIN") ? atoll(getenv("E3_FIRST_MFMA_MIN")) : FGRID;      // (tests: 1 = every shape the kernel can take)
+    return items >= min_items && items < (1ll << 31);
 }
 int conv_small_stats_parts2(int N, int D, int H, int W, int planar, int Cin, int Cout) {
     return first_mfma(N, D, H, W, planar, Cin, Cout) ? FGRID / (Cout / 32) : conv_small_stats_parts(N, D, H, W, planar);

@@ -19,6 +19,12 @@ GROUPS = {
                                E3_NO_LOSS_BWD='1'), FP32_TESTS),
     'persistent_everywhere': (dict(E3_WINO_PERSIST_MIN='1', E3_UPCONV_NO_PERSIST='1', E3_CONV_NO_V3='1', E3_ATT_VALU='1'), FP32_TESTS),
     'b16_alternatives': (dict(E3_B16_NO_SPLITK='1', E3_B16_UP_GENERIC='1', E3_B16_BD='2', E3_B16_TW='16', E3_B16_COT='1'), B16_TESTS),
+    # the round-4 persistent kernels (conv_first_mfma_kernel, conv_first_b16_pkernel, conv_b16_pkernel) at EVERY size they can take: small and ragged grids,
+    # workgroups without a single item, statistics records of empty workgroups
+    'persistent_kernels_on_small_grids': (dict(E3_FIRST_MFMA_MIN='1', E3_B16_FIRST_PERSIST_MIN='1', E3_B16_PERSIST_MIN='1', E3_B16_BD='4', E3_B16_TW='32', E3_B16_COT='1',
+                                               E3_B16_NO_SPLITK='1'),
+                                          ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', 'tests/test_bf16_gpu.py', 'tests/test_f16_gpu.py', 'tests/test_predictor.py', '-k',
+                                           'conv3 or first_conv or train_step_matches_reference or eval_forward or forward_with_loss or bf16 or f16 or fixture or predictor']),
     'b16_no_persistent_conv': (dict(E3_B16_NO_PERSIST='1', E3_B16_FIRST_NO_PERSIST='1'), ['tests/test_bf16_gpu.py', '-k', 'full_size or fixture']),
     'b16_on_fp32_kernels_plain_predictor': (dict(E3_NO_BF16='1', E3_PREDICTOR_NO_PIPELINE='1'),
                                             ['tests/test_predictor.py', 'tests/test_bf16_gpu.py', '-k', 'predictor or fixture or autocast']),
