@@ -547,7 +547,7 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'cfg4':      # the same for BASELINE configs[3]: anisotropic UNet(planar_blocks=(0, 1), start_filts=64), batch 2 of 32 x 256 x 256 (cfg4_digest.npz; ~20 GB, tens of minutes)
         torch.set_num_threads(8)
         unet, inference, loss_mod = load_reference()
-        make_cfg2_digest(unet, loss_mod, f'{HERE}/cfg4_digest.npz', seed=2025, n_blocks=4, start_filts=64, shape=(32, 256, 256), batch=2, planar_blocks=(0, 1))
+        make_cfg2_digest(unet, loss_mod, f'{HERE}/cfg4_digest.npz', seed=2025, n_blocks=4, start_filts=64, shape=(32, 256, 256), batch=1, planar_blocks=(0, 1))      # (batch 1: the fp64 run of batch 2 does not fit this container's 62 GB)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'f16':      # the reference in float16 (model.half(), inference.py:445-446): O(1) incoming gradient, as GradScaler provides
         torch.set_num_threads(8)

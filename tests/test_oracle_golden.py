@@ -270,7 +270,7 @@ def test_torch_restatement_at_the_headline_size_against_the_reference_digest():
     """oracle/torch_ref.py (the checker of every full-size GPU parity test and bench.py's cpu_baseline) against the REFERENCE's own forward at
     BASELINE.json configs[1]'s size: tests/golden/cfg2_digest.npz holds a strided sample of the reference's train-mode logits and its loss for
     parameters / input / target that are regenerated here from the digest's seed (helpers.digest_*).  Forward + criterion only (the backward at this
-    size is covered on the GPU side by test_full_size_cfg2_against_the_reference_digest); ~10 s of CPU."""
+    size is covered on the GPU side by test_full_size_against_the_reference_digest); ~10 s of CPU."""
     from collections import OrderedDict
     import torch
     from helpers import digest_inputs, digest_state_dict

@@ -341,7 +341,7 @@ def _train_step_vs_pytorch_rocm(m, x, t, dt=torch.float32, atol=2e-4, nb=4, plan
 
 
 @pytest.mark.parametrize('case', ['cfg2_digest.npz', 'cfg4_digest.npz'])
-def test_full_size_cfg2_against_the_reference_digest(case):
+def test_full_size_against_the_reference_digest(case):
     """The REFERENCE's own train step at BASELINE.json configs[1]'s size (8192 Winograd bricks at level 0), closing reference -> fixture -> HIP at the size
     the headline is measured on: tests/golden/cfg2_digest.npz (make_golden.py cfg2) holds, from the reference's fp32 and fp64 CPU runs on parameters /
     input / target that both sides regenerate from one seed, a strided sample of the logits, the loss, the running statistics, and per gradient tensor
