@@ -397,36 +397,46 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
 #pragma unroll
                 for (int e = 0; e < 16; ++e) macc[e] = 0.f;
             }
-            for (int tile = tile0; tile < tile0 + tiles_per_split && tile < ntiles; ++tile) {
+            // The brick's operands travel global -> registers -> LDS; the loads of brick b + 1 are issued BEHIND the barrier that publishes brick b's LDS image
+            // and fly during its MFMAs (as one load / wait / compute chain per brick the kernel moved 3.6 GB/s per workgroup: 146 us for 545 MB).
+            constexpr int XI = (NV + 255) / 256;
+            float xh[XI];
+            f32x4 xv[8], gv[8]; bool ok[8]; unsigned eidx[8];
+            auto issue = [&](int tile) {
                 int L = tile;
                 const int tw_ = L % tilesW; L /= tilesW; const int th_ = L % tilesH; L /= tilesH; const int td_ = L % tilesD; const int nb = L / tilesD;
                 const int d0 = td_ * TD, h0 = th_ * TH, w0 = tw_ * TW;
-                __syncthreads();
-                for (int v = tid; v < NV; v += 256) {
+#pragma unroll
+                for (int i = 0; i < XI; ++i) {
+                    const int v = tid + 256 * i;
                     const int zw = v % LW, zh = (v / LW) % LH, zd = v / (LW * LH);
                     const int gd = d0 + zd - PD, gh = h0 + zh - 1, gw = w0 + zw - 1;
-                    float val = 0.f;
-                    if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
-                        val = x[((((size_t)nb * D + gd) * H + gh) * W + gw) * Cin + ci];
-                    xs[v] = val;
+                    xh[i] = 0.f;
+                    if (v < NV && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                        xh[i] = x[((((size_t)nb * D + gd) * H + gh) * W + gw) * Cin + ci];
                 }
-                // the brick of dY (or of the tensors it is computed from): all 8 (16) loads of a thread in flight before the first use
-                // (rolled, every pass of this loop waited a memory round trip: 180 -> 128 us with the MFMAs alone, -> ? with this)
-                {
-                    f32x4 xv[8], gv[8]; bool ok[8]; unsigned eidx[8];
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int idx = tid + 256 * it;
-                        const int v = idx >> 3, qq = idx & 7;
-                        const int ww = v & 15, hh = (v >> 4) % TH, dd = (v >> 4) / TH;
-                        const int gd = d0 + dd, gh = h0 + hh, gw = w0 + ww;
-                        ok[it] = gd < D && gh < H && gw < W && pass * 32 + 4 * qq < Cout;
-                        const size_t vox = ok[it] ? (((size_t)nb * D + gd) * H + gh) * W + gw : 0;
-                        const int c0 = ok[it] ? pass * 32 + 4 * qq : 0;
-                        eidx[it] = (unsigned)(vox * Cout + c0);
-                        if (f.x1) { xv[it] = *reinterpret_cast<const f32x4*>(f.x1 + vox * f.x1_ldc + c0); gv[it] = *reinterpret_cast<const f32x4*>(f.g + vox * f.g_ldc + c0); }
-                        else gv[it] = *reinterpret_cast<const f32x4*>(dy + vox * dy_ldc + c0);
-                    }
+                for (int it = 0; it < 8; ++it) {
+                    const int idx = tid + 256 * it;
+                    const int v = idx >> 3, qq = idx & 7;
+                    const int ww = v & 15, hh = (v >> 4) % TH, dd = (v >> 4) / TH;
+                    const int gd = d0 + dd, gh = h0 + hh, gw = w0 + ww;
+                    ok[it] = gd < D && gh < H && gw < W && pass * 32 + 4 * qq < Cout;
+                    const size_t vox = ok[it] ? (((size_t)nb * D + gd) * H + gh) * W + gw : 0;
+                    const int c0 = ok[it] ? pass * 32 + 4 * qq : 0;
+                    eidx[it] = (unsigned)(vox * Cout + c0);
+                    if (f.x1) { xv[it] = *reinterpret_cast<const f32x4*>(f.x1 + vox * f.x1_ldc + c0); gv[it] = *reinterpret_cast<const f32x4*>(f.g + vox * f.g_ldc + c0); }
+                    else gv[it] = *reinterpret_cast<const f32x4*>(dy + vox * dy_ldc + c0);
+                }
+            };
+            const int tile_end = tile0 + tiles_per_split < ntiles ? tile0 + tiles_per_split : ntiles;
+            if (tile0 < tile_end) issue(tile0);
+            for (int tile = tile0; tile < tile_end; ++tile) {
+                __syncthreads();                      // the previous brick's MFMAs are done with the LDS images
+#pragma unroll
+                for (int i = 0; i < XI; ++i)
+                    if (tid + 256 * i < NV) xs[tid + 256 * i] = xh[i];
+                {
 #pragma unroll
                     for (int it = 0; it < 8; ++it) {
                         const int idx = tid + 256 * it;
@@ -438,8 +448,8 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
                                 for (int e = 0; e < 4; ++e) {
                                     const float z = __builtin_fmaf(xv[it][e], fsc[e], fsh[e]);
                                     const float dz = act_bwd(z, gv[it][e], act_slope_at(f.act, fslope, eidx[it] + e));
-                                    const float xh = (xv[it][e] - fmu[e]) * fis[e];
-                                    val[e] = fgi[e] * (dz - fc1[e] - xh * fc2[e]);
+                                    const float xh2 = (xv[it][e] - fmu[e]) * fis[e];
+                                    val[e] = fgi[e] * (dz - fc1[e] - xh2 * fc2[e]);
                                     if (ci == 0) bsum[e] += val[e];
                                 }
                             } else val = gv[it];
@@ -448,6 +458,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float* __re
                     }
                 }
                 __syncthreads();
+                if (tile + 1 < tile_end) issue(tile + 1);      // in flight during this brick's MFMAs
                 if constexpr (MFMA) {
                     const int lane = tid & 63, wave = tid >> 6, jj = lane & 31, kk = lane >> 5;
                     const int tj = jj < T ? jj : T - 1;                                  // (columns 27..31 of the tap tile are never stored)
