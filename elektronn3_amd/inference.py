@@ -202,6 +202,7 @@ class _SharedHostTensor:
 
 
 _ROI = os.environ.get('E3_PREDICTOR_NO_ROI') is None      # (A/B switch: whole tiles instead of the needed region)
+_NO_CLIP = os.environ.get('E3_PREDICTOR_NO_CLIP') is not None      # (A/B switch: edge tiles compute their whole kept crop, also the part beyond the volume's end)
 
 
 def _extend_nc(spatial_slice):
@@ -486,7 +487,7 @@ class Predictor:
         self.offset, self.tile_shape, self.overlap_shape, self.out_shape = geo.offset, geo.tile_shape, geo.overlap_shape, geo.out_shape
 
     # ------------------------------------------------------------------ per-tile model call (inference.py:496-525)
-    def _call_model(self, dinp, crop_slice=None):
+    def _call_model(self, dinp, crop_slice=None, keep=None):
         """``crop_slice`` (the central crop that follows): the native UNet is told that only those voxels are wanted and skips what they
         do not depend on (``UNet.forward_roi``; E3_PREDICTOR_NO_ROI=1: A/B switch, whole tiles)."""
         if self._native:
@@ -494,6 +495,8 @@ class Predictor:
             if crop_slice is not None and dinp.dim() == 5 and _ROI and hasattr(self.model, 'forward_roi'):
                 sp = tuple(dinp.shape[2:])
                 roi = tuple(sl.indices(n)[:2] for sl, n in zip(crop_slice[-3:], sp))
+                if keep is not None:      # an edge tile of the pipelined run: only the first `keep` voxels of the crop lie inside the volume
+                    roi = tuple((lo, min(hi, lo + int(kp))) for (lo, hi), kp in zip(roi, keep))
             if roi is not None:
                 y = self.model.forward_roi(dinp, roi, softmax=self._softmax)
             else:
@@ -502,11 +505,11 @@ class Predictor:
         return self.model(dinp)
 
     @torch.no_grad()
-    def _predict(self, dinp, crop_slice=None):
+    def _predict(self, dinp, crop_slice=None, keep=None):
         """One tile: model call (+ test-time augmentation mean, + arg-max) and the central crop (inference.py:496-525)."""
         dinp = dinp.to(self.device, dtype=self.dtype)
         crop = (lambda t: t[crop_slice]) if crop_slice is not None else (lambda t: t)
-        dout = crop(self._call_model(dinp, crop_slice))
+        dout = crop(self._call_model(dinp, crop_slice, keep))
         if self.augmentations is not None:       # mean over the identity and every flip (prediction of the flipped tile, flipped back)
             votes = [dout] + [crop(aug.backward(self._call_model(aug.forward(dinp)))) for aug in self.augmentations]
             dout = torch.stack(votes).mean(dim=0)
@@ -732,13 +735,17 @@ class Predictor:
                         try:
                             if state['out_dev'] is None:
                                 make_outputs(None, ((int(self.model.out_channels),), torch.float32))
+                            # kept region of the tile, clipped to the REAL volume: the last tile of an axis hangs over the volume's end (the padded volume is a
+                            # multiple of the tile shape), what it would write there is never downloaded -- the needed-region forward does not compute it
+                            # (the cfg-5 volume: 512 = 5.33 x 96, 2048 = 10.67 x 192: 16 % of the kept voxels of all tiles lie outside; E3_PREDICTOR_NO_CLIP=1: A/B)
+                            keep = [int(t) if _NO_CLIP else max(1, min(int(t), int(r) - int(lo_))) for t, r, lo_ in zip(tile, real, olo)]
                             self.model.forward_tile(inp_padded, ilo, [h - l for l, h in zip(ilo, ihi)], state['out_dev'], olo,
-                                                    [(int(o), int(o + t)) for o, t in zip(ov, tile)], softmax=self._softmax)
+                                                    [(int(o), int(o) + kp) for o, kp in zip(ov, keep)], softmax=self._softmax)
                             continue
                         except NotImplementedError:
                             in_place = False
                     inp_tile = inp_padded[_extend_nc([slice(l, h) for l, h in zip(ilo, ihi)])].contiguous()
-                    out_tile = self._predict(inp_tile, crop)
+                    out_tile = self._predict(inp_tile, crop, None if _NO_CLIP else [max(1, min(int(t), int(r) - int(lo_))) for t, r, lo_ in zip(tile, real, olo)])
                     if state['out_dev'] is None:
                         make_outputs(out_tile)
                     state['out_dev'][_extend_nc([slice(l, h) for l, h in zip(olo, ohi)])] = out_tile

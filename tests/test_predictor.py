@@ -542,3 +542,26 @@ def test_predictor_in_place_tiles_switch_gives_the_same_volume(monkeypatch, vsha
         assert (len(calls) > n0) == in_place
     assert torch.equal(outs[0], outs[1])
     assert torch.allclose(outs[0].sum(1), torch.ones_like(outs[0][:, 0]), atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16], ids=['fp32_in_place', 'bf16_copied_tiles'])
+def test_predictor_edge_tiles_compute_only_what_lies_inside_the_volume(monkeypatch, dt):
+    """The last tile of an axis hangs over the end of the volume (the padded volume is a multiple of the tile shape, inference.py:153-199); its kept crop is
+    clipped to the real volume before it becomes the needed region (E3_PREDICTOR_NO_CLIP=1 / inference._NO_CLIP: the whole crop).  What predict() returns is
+    the real volume only: both forms must give the identical tensor."""
+    from elektronn3_amd import inference
+    from elektronn3_amd.unet import UNet
+    torch.manual_seed(9)
+    m = UNet(in_channels=1, out_channels=2, n_blocks=3, start_filts=32, normalization='batch').cuda().eval()
+    if dt != torch.float32:
+        m = m.to(dt)
+    vol = torch.randn(1, 1, 41, 150, 171)                       # 41 = 1.3 x 32, 150 = 2.3 x 64, 171 = 2.1 x 80: every axis ends inside a tile
+    outs = []
+    for no_clip in (False, True):
+        monkeypatch.setattr(inference, '_NO_CLIP', no_clip)
+        p = inference.Predictor(m, device='cuda', tile_shape=(32, 64, 80), overlap_shape=(8, 16, 16), out_shape=(2, 41, 150, 171), apply_softmax=True,
+                                strict_shapes=False, float16=False)
+        outs.append(p.predict(vol.to(dt) if dt != torch.float32 else vol).clone())
+    assert outs[0].shape[-3:] == (41, 150, 171)
+    assert torch.equal(outs[0], outs[1])
