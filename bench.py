@@ -237,6 +237,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--dtype', choices=('f32', 'bf16', 'f16'), default='f32', help='f32 = BASELINE configs[1] (the metric\'s config); bf16 = configs[2] per-GPU workload; f16 = the same with model.half() (the reference\'s own mixed-precision type)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true', help='(internal) time the CPU baseline, print its JSON object, exit')
     ap.add_argument('--no-predictor', action='store_true', help='skip the Predictor MVox/s leg')
     ap.add_argument('--predictor-volume', choices=('full', 'sub'), default=None, help='full = 512x2048x2048 (default for N = 1), sub = 288x1152x1152')
     ap.add_argument('--profile-layer', default='up_convs.2.conv1')
@@ -245,6 +246,9 @@ def main():
                     '(GradSync(overlap=True): 16 CUs reserved after the event); default: one all-reduce behind the backward')
     args = ap.parse_args()
 
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()), flush=True)
+        return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         respawn_under_launcher(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -390,7 +394,15 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res['cpu_baseline'] = cpu_baseline()
+                # in a CHILD process: the 128-thread CPU run leaves thread pools and allocator state behind that slow the host side of the Predictor leg
+                # further down (measured: 398 -> 365 MVox/s on the 512x2048x2048 volume when it ran in this process)
+                import subprocess
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only'], capture_output=True, text=True, timeout=900,
+                                   env={**os.environ, 'HIP_VISIBLE_DEVICES': '', 'CUDA_VISIBLE_DEVICES': ''})
+                line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+                if r.returncode != 0 or not line:
+                    raise RuntimeError((r.stderr or r.stdout)[-300:])
+                res['cpu_baseline'] = json.loads(line[-1])
             except Exception as e:  # noqa: BLE001
                 res['cpu_baseline'] = {'value': None, 'unit': 'voxels/s', 'cores': torch.get_num_threads(), 'kind': 'port',
                                        'sample': f'failed: {e}'}
