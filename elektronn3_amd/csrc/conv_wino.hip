@@ -380,7 +380,8 @@ struct WinoPArgs { int s_nt, s_tw, s_th, s_td, s_nb; int wgstats; int e_tw, e_th
 // holds one tile (column) and, per register quad, 4 consecutive output channels (rows (r & 3) + 8 (r >> 2) + 4 hf): the brick leaves as 8 16-byte stores
 // per lane instead of 32 dword stores.  Same operands, same arithmetic, same exchange; only the result orientation differs.
 // POOL (AFF && TR, inference): the 2x2x2 ceil-mode max-pool of the output in the epilogue (ConvArgs::pool_out)
-template <bool AFF, bool TR = false, bool POOL = false>
+// HEAD (AFF && TR, inference, 32 output channels): the 1x1x1 head (+ softmax) on the activations in registers instead of storing them (ConvArgs::head_*)
+template <bool AFF, bool TR = false, bool POOL = false, bool HEAD = false>
 __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, const unsigned nblk, const WinoPArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -508,6 +509,12 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
     // register allocator's own choice -- scratch -- makes the main loop wait for the output stores in front of the reload)
     int* const park = reinterpret_cast<int*>(scr + 4 * 32 * 3 + 3 * 256) + tid;
     park[0] = a_dst; park[256] = rdA[0]; park[512] = rdA[1];
+    if (HEAD) {          // the head's weights [class][32] and biases [4] behind the parked constants (published by the prologue's barrier)
+        float* const hw = scr + 4 * 32 * 3 + 6 * 256;
+        const KArgs hk = KA();
+        if (tid < 128) hw[tid] = tid < hk->head_cout * 32 ? hk->head_w[tid] : 0.f;
+        else if (tid < 132) hw[tid] = (hk->head_b && tid - 128 < hk->head_cout) ? hk->head_b[tid - 128] : 0.f;
+    }
 #ifndef E3_WINO_ABL
 #define E3_WINO_ABL 0       // developer builds: bit mask of pieces left out of the MFMA phase (timing experiments, wrong results)
 #endif
@@ -791,12 +798,61 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
             const bool vok = gh < H && gw < W;
             const bool ok0 = vok && gd < D, ok1 = vok && gd + 1 < D;
             const int od_off = (int)(plane_y * 4);
+            if (!HEAD) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const bool cok = n0 + 8 * k + 4 * ehf < eN;
                 if (!(E3_WINO_ABL & 64)) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[0][k]), y_rs, (ok0 && cok) ? t_voff + 32 * k : OOB, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[1][k]), y_rs, (ok1 && cok) ? t_voff + 32 * k : OOB, od_off, 0);
+                }
+            }
+            }
+            if (HEAD) {
+                // conv_final_fwd_kernel's arithmetic on the registers: channel quad q = 2 k + hf of the voxel is summed as an fmaf chain from 0, the eight
+                // quad sums meet as ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7)) -- this lane holds the quads of its half, the partner lane (^ 32) the others
+                const float* const hw = scr + 4 * 32 * 3 + 6 * 256;
+                const int hc = e->head_cout;
+                float lg[2][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float p[2][4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(hw + c * 32 + 8 * k + 4 * ehf);
+#pragma unroll
+                        for (int od = 0; od < 2; ++od) {
+                            float sacc = 0.f;
+#pragma unroll
+                            for (int e4 = 0; e4 < 4; ++e4) sacc = __builtin_fmaf(y[od][k][e4], wv[e4], sacc);
+                            p[od][k] = sacc + __shfl_xor(sacc, 32);
+                        }
+                    }
+#pragma unroll
+                    for (int od = 0; od < 2; ++od) lg[od][c] = ((p[od][0] + p[od][1]) + (p[od][2] + p[od][3])) + hw[128 + c];
+                }
+                // this lane finishes the voxel od = hf
+                float l4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) l4[c] = ehf ? lg[1][c] : lg[0][c];
+                if (e->head_softmax) {
+                    float m = l4[0];
+#pragma unroll
+                    for (int c = 1; c < 4; ++c) m = c < hc ? fmaxf(m, l4[c]) : m;
+                    float sm = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { l4[c] = c < hc ? __expf(l4[c] - m) : 0.f; sm += l4[c]; }
+                    const float inv = 1.f / sm;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) l4[c] *= inv;
+                }
+                const int vd = gd + ehf;
+                const bool inb = vok && vd < D && vd >= e->head_lo[0] && vd < e->head_hi[0] && gh >= e->head_lo[1] && gh < e->head_hi[1] && gw >= e->head_lo[2] && gw < e->head_hi[2];
+                if (inb) {
+                    float* const yo = e->head_y + (long long)P.nb * e->head_ys[0] + (long long)(vd - e->head_lo[0]) * e->head_ys[2] + (long long)(gh - e->head_lo[1]) * e->head_ys[3] + (gw - e->head_lo[2]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < hc) yo[(long long)c * e->head_ys[1]] = l4[c];
                 }
             }
             if (POOL) {
@@ -1199,6 +1255,16 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
                 E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, plds));
                 E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, plds));
                 tattr = true;
+            }
+            static const bool no_head = getenv("E3_WINO_NO_HEAD") != nullptr;      // A/B switch
+            if (a.epi_scale && a.head_w && a.head_done && !no_head && a.Ncols == 32 && a.head_cout >= 1 && a.head_cout <= 4 && !a.pool_out) {      // + the 1x1x1 head behind it
+                constexpr int plds_head = (W_PLDS_FLOATS + W_POOLX) * 4;
+                static bool hattr = false;
+                if (!hattr) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino_pkernel<true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, plds_head)); hattr = true; }
+                hipLaunchKernelGGL((conv3_wino_pkernel<true, true, false, true>), dim3(pgrid), dim3(256), plds_head, s, a, (unsigned)nblk, pa);
+                *a.head_done = 1;
+                E3_CHECK_HIP(hipGetLastError());
+                return E3_OK;
             }
             static const bool no_pool = getenv("E3_WINO_NO_POOL") != nullptr;      // A/B switch
             if (a.epi_scale && a.pool_out && a.pool_done && !no_pool && a.box_hi[0] <= 0 && (a.Ncols & 31) == 0) {      // + the max-pool behind it

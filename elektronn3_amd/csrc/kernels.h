@@ -60,6 +60,12 @@ struct ConvArgs {
     // window -- into pool_out [N][ceil(D/2)][ceil(H/2)][ceil(W/2)][Ncols] (packed).  Honoured by the persistent Winograd kernel's transposed form only;
     // the launcher sets *pool_done = 1 when it took the pooling along (the caller runs the pooling pass otherwise).
     float* pool_out; int* pool_done;
+    // inference: the network's 1x1x1 head (conv_final, unet.py:881,912; + Softmax(1) of the Predictor) taken in the epilogue of the LAST 3x3x3 conv -- in
+    // the transposed-accumulator form a voxel's 32 activations sit in two lanes -- so the last activation tensor is neither written nor re-read.
+    // head_w [head_cout][32], head_b [head_cout] (or null); voxel (d, h, w) inside [head_lo, head_hi) of sample n, class c goes to
+    // head_y + n ys[0] + c ys[1] + (d - lo[0]) ys[2] + (h - lo[1]) ys[3] + (w - lo[2]).  Same arithmetic and summation order as conv_final_fwd_kernel
+    // (bit-identical results).  Honoured by the persistent kernel's folded-epilogue transposed form at Ncols == 32; the launcher sets *head_done = 1.
+    const float* head_w; const float* head_b; int head_cout, head_softmax; float* head_y; long long head_ys[4]; int head_lo[3], head_hi[3]; int* head_done;
 };
 // CF_BNRED launches: 0 when the launch cannot carry the reduction (grid does not tile into one column tile per workgroup), else the number of
 // partial rows it writes

@@ -722,6 +722,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
     if (cfg.in_channels > 1) { RUN(launch_ncdhw_to_ndhwc(x, B.xin, N, cfg.in_channels, ND.X[0].vox / N, s)); cur = B.xin; }
 
     std::vector<std::pair<const float*, int>> unit_ins(plan->units.size());      // input view of every unit (shortcut source of the ResUNet's ConvBlocks)
+    int head_fused = 0;          // the last conv's epilogue took the 1x1x1 head along (ConvArgs::head_*)
     for (size_t k = 0; k < plan->units.size(); ++k) {
         const ConvUnit& u = plan->units[k];
         UnitBufs& b = B.ub[k];
@@ -829,6 +830,26 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             const int S = (kind == CONV_K3) ? fwd_split(k) : 1;
             // inference: the ceil-mode max-pool behind an encoder block rides in the conv's epilogue where the kernel can take it (a Winograd tile is a window)
             if (pool_after && !training && !two_pass && kd == 2 && kind == CONV_K3 && es && !vcrop && !residual) { a.pool_out = B.pooled[u.level]; a.pool_done = &pool_fused; }
+            // inference: the 1x1x1 head (+ softmax) rides in the epilogue of the network's LAST conv where the kernel can take it (ConvArgs::head_*): the
+            // last activation tensor is neither written nor read
+            if (k + 1 == plan->units.size() && !training && !la && !two_pass && kind == CONV_K3 && es && !vcrop && !residual && S == 1 && u.cout == 32 &&
+                plan->chan(0) == 32 && cfg.out_channels <= 4 && (!roi || view || (roi[3] <= ND.Y.D && roi[4] <= ND.Y.H && roi[5] <= ND.Y.W))) {
+                a.head_w = P(plan->p_final_w); a.head_b = P(plan->p_final_b); a.head_cout = cfg.out_channels; a.head_softmax = (flags & E3_FWD_SOFTMAX) ? 1 : 0;
+                a.head_done = &head_fused;
+                const long long S1 = (long long)(ND.Y.vox / N);
+                if (view) {           // the kept region, straight into its place in the output volume
+                    a.head_y = y; for (int i = 0; i < 4; ++i) a.head_ys[i] = view->y_stride[i];
+                    for (int i = 0; i < 3; ++i) { a.head_lo[i] = roi[i]; a.head_hi[i] = roi[3 + i]; }
+                } else {
+                    a.head_ys[0] = (long long)cfg.out_channels * S1; a.head_ys[1] = S1; a.head_ys[2] = (long long)ND.Y.H * ND.Y.W; a.head_ys[3] = ND.Y.W;
+                    if (roi) {        // e3_unet_forward_roi: the kept region only, in the tile's own layout
+                        for (int i = 0; i < 3; ++i) { a.head_lo[i] = roi[i]; a.head_hi[i] = roi[3 + i]; }
+                        a.head_y = y + (long long)roi[0] * a.head_ys[2] + (long long)roi[1] * a.head_ys[3] + roi[2];
+                    } else {
+                        a.head_y = y; a.head_lo[0] = a.head_lo[1] = a.head_lo[2] = 0; a.head_hi[0] = ND.Y.D; a.head_hi[1] = ND.Y.H; a.head_hi[2] = ND.Y.W;
+                    }
+                }
+            }
             if (need[k].on && kind == CONV_K3 && S == 1 && !a.stats)
                 for (int i = 0; i < 3; ++i) { a.box_lo[i] = need[k].lo[i]; a.box_hi[i] = need[k].hi[i]; }
             if (S > 1) {         // partial sums per share of the input channels, then sum + bias + statistics in one small pass
@@ -936,7 +957,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
         else if (u.is_up) { cur = B.cat[u.level]; cur_ldc = 2 * u.cout; }   // conv1 of the UpConv reads the whole concat buffer
         else { cur = b.act; cur_ldc = b.act_ldc; }
     }
-    {
+    if (!head_fused) {
         const ConvUnit& lu = plan->units.back();
         const UnitBufs& lb = B.ub.back();
         const bool fused = training && lu.has_norm();     // see above: head reads the raw conv output + (scale, shift)

@@ -1454,3 +1454,33 @@ def test_forward_with_loss_matches_the_reference_step(case):
     (crit(out_d, t) + 1e-3 * out_d.square().mean()).backward()
     k0 = 'down_convs.0.conv1.weight'
     assert rel_l2(dict(mc.named_parameters())[k0].grad.cpu().numpy(), dict(md.named_parameters())[k0].grad.cpu().numpy()) <= 1e-5
+
+
+def test_head_in_the_last_conv_epilogue_is_bit_identical_to_the_separate_head(tmp_path):
+    """Inference at start_filts=32: the 1x1x1 head (+ softmax) is evaluated in the epilogue of the last 3x3x3 conv (conv3_wino_pkernel<true, true, false, true>,
+    ConvArgs::head_*; unet.py:881,912) with conv_final_fwd_kernel's arithmetic and summation order.  A child process with E3_WINO_NO_HEAD=1 (the switch is read
+    once per process) computes the same forwards through the separate head kernel: logits, softmax output and a needed-region forward must agree bit for bit."""
+    import subprocess, sys, os
+    script = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from elektronn3_amd.unet import UNet
+torch.manual_seed(4)
+m = UNet(1, 3, n_blocks=2, start_filts=32).cuda().train()
+with torch.no_grad():
+    for _ in range(2):
+        m(torch.randn(2, 1, 16, 32, 32, device='cuda'))
+m.eval()
+x = torch.randn(2, 1, 37, 70, 83, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5))
+with torch.no_grad():
+    out = {'logits': m(x).cpu(), 'softmax': m.forward_softmax(x).cpu(), 'roi': m.forward_roi(x[:1], ((4, 30), (8, 61), (16, 70)), softmax=True)[:, :, 4:30, 8:61, 16:70].cpu()}
+torch.save(out, sys.argv[1])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, extra in (('fused', {}), ('separate', {'E3_WINO_NO_HEAD': '1'})):
+        f = str(tmp_path / f'{tag}.pt')
+        r = subprocess.run([sys.executable, '-c', script, f], env={**os.environ, **extra}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+    for k in outs[0]:
+        assert torch.isfinite(outs[0][k]).all() and torch.equal(outs[0][k], outs[1][k]), k
