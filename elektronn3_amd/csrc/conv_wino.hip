@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
     const int tw_ = divmod(L, a.tilesW);
     const int th_ = divmod(L, a.tilesH);
     const int td_ = divmod(L, a.tilesD); const int nb = (int)L;
-    const int d0 = (td_ + a.o_td) * 4, h0 = (th_ + a.o_th) * 4, w0 = (tw_ + a.o_tw) * 16;      // (o_*: first brick of the needed region)
+    const int d0 = (td_ + a.o_td) * 4 + a.org_d, h0 = (th_ + a.o_th) * 4 + a.org_h, w0 = (tw_ + a.o_tw) * 16 + a.org_w;      // (o_*, org_*: first brick / voxel origin of the needed region)
     const int n0 = ntile * 32;
     const int mtile = ((nb * a.tilesD + td_) * a.tilesH + th_) * a.tilesW + tw_;
     const int NCH = a.Cin >> 3;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
 constexpr int W_PLDS_FLOATS = 2 * W_BUF + W_EX + 4 * 32 * 3 + 6 * 256;     // + the threads' running statistics and parked lane constants
 constexpr int W_POOLX = 4 * 64 * 16;                                         // fused max-pool: [wave (oh, ow)][lane][16 channels] (16 KB)
 
-struct WinoPArgs { int s_nt, s_tw, s_th, s_td, s_nb; int wgstats; int e_tw, e_th, e_td; };   // digits of the logical step gridDim / 8 between a workgroup's bricks; e_*: end (first brick + count) of the brick range per axis
+struct WinoPArgs { int s_nt, s_tw, s_th, s_td, s_nb; int wgstats; int e_tw, e_th, e_td; int org_d, org_h, org_w; };   // digits of the logical step gridDim / 8 between a workgroup's bricks; e_*: end (first brick + count) of the brick range per axis
 
 // AFF: the folded scale / shift + ReLU epilogue (inference; no statistics) -- a compile-time split: as a run-time branch its merge cost ~50 register
 // moves per brick in both forms
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
     __amdgpu_buffer_rsrc_t s_rs;
     unsigned s_mask_ = 0;
     auto make_stage = [&](const Cur& c) {
-        const int d0 = c.td * 4, h0 = c.th * 4, w0 = c.tw * 16;
+        const int d0 = c.td * 4 + pa.org_d, h0 = c.th * 4 + pa.org_h, w0 = c.tw * 16 + pa.org_w;
         const long long org = ((long long)c.nb * D + (d0 - 1)) * ((long long)H * W * xl) + ((long long)(h0 - 1) * W + (w0 - 1)) * xl;
         s_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + org, 0, 0x7fffffff, 0x00020000);
         const unsigned m = range_mask(d0 - 1, 6, D) | (range_mask(h0 - 1, 6, H) << 6) | (range_mask(w0 - 1, 18, W) << 12);
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
         int elane;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
         const int ej = elane & 31, ehf = elane >> 5;
-        const int d0 = P.td * 4, h0 = P.th * 4, w0 = P.tw * 16, n0 = P.nt * 32;
+        const int d0 = P.td * 4 + pa.org_d, h0 = P.th * 4 + pa.org_h, w0 = P.tw * 16 + pa.org_w, n0 = P.nt * 32;
         const KArgs e = KA();
         const int yl = e->y_ldc, eN = e->Ncols;
         const size_t plane_y = (size_t)H * W * yl;
@@ -1199,9 +1199,14 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
         for (int i = 0; i < 3; ++i) {
             const int lo = a.box_lo[i] < 0 ? 0 : a.box_lo[i], hi = a.box_hi[i] > dims[i] ? dims[i] : a.box_hi[i];
             E3_REQUIRE(hi > lo, E3_ERR_INVALID, "conv with a needed region: empty box");
-            o[i] = lo / edge[i]; n[i] = cdiv(hi, edge[i]) - o[i];
+            // bricks start at the box's (even) low corner, not at a multiple of the brick edge: the 1-voxel margins that the box of a conv in front of
+            // another conv carries would otherwise cost a whole extra brick per axis (cfg 5's level-0 concat conv: 26 x 50 x 14 -> 25 x 49 x 13 bricks).
+            // EVEN origins keep every voxel in the 2x2x2 Winograd tile it has in the whole-tensor launch: same arithmetic, bit-identical values.
+            static const bool brick_aligned = getenv("E3_WINO_BOX_ALIGNED") != nullptr;      // A/B switch: origins at multiples of the brick edge
+            o[i] = brick_aligned ? lo / edge[i] * edge[i] : (lo & ~1);
+            n[i] = cdiv(hi - o[i], edge[i]);
         }
-        a.o_td = o[0]; a.o_th = o[1]; a.o_tw = o[2];
+        a.org_d = o[0]; a.org_h = o[1]; a.org_w = o[2];
         a.tilesD = n[0]; a.tilesH = n[1]; a.tilesW = n[2];
     }
     a.NPad = (a.Ncols + 31) / 32 * 32;
@@ -1246,6 +1251,7 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
         pa.s_td = (int)(st % (unsigned)a.tilesD); pa.s_nb = (int)(st / (unsigned)a.tilesD);
         pa.wgstats = (a.stats && wino_wgstats(nblk, a.ntiles, pgrid)) ? 1 : 0;
         pa.e_tw = a.o_tw + a.tilesW; pa.e_th = a.o_th + a.tilesH; pa.e_td = a.o_td + a.tilesD;
+        pa.org_d = a.org_d; pa.org_h = a.org_h; pa.org_w = a.org_w;
         // launches without statistics whose output view allows 16-byte stores: transposed accumulators (E3_WINO_NO_TR=1: A/B switch)
         static const bool no_tr = getenv("E3_WINO_NO_TR") != nullptr;
         const bool tr = !no_tr && !a.stats && (a.Ncols & 3) == 0 && (a.y_ldc & 3) == 0 && ((uintptr_t)a.y & 15) == 0;

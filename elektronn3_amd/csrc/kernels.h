@@ -46,6 +46,7 @@ struct ConvArgs {
     // (d, h, w) are computed -- the rest of y is left untouched.  The other kernels ignore it and compute everything.  No statistics.
     int box_lo[3], box_hi[3];
     int o_td, o_th, o_tw;        // (set by the launcher: first brick of the box per axis)
+    int org_d, org_h, org_w;     // (set by the launcher: voxel origin of brick (0, 0, 0) -- EVEN, so that a needed region keeps the Winograd tile alignment of the whole tensor)
     // compute units to leave alone (0 = use the whole chip; a multiple of 8 = one share per XCD): kernels that size their grid for ONE
     // residency round of one workgroup per CU (the persistent Winograd kernel) launch 256 - cu_reserve workgroups, so that they all fit
     // beside the resident workgroups of a collective running on a side stream (data-parallel backward)
