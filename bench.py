@@ -82,8 +82,8 @@ def needed_region_flops(tile_in, overlap, n_blocks=4, sf=32, bricks=((4, 4, 16),
         c = sf << lvl
         for cin in (c, 2 * c):                                            # conv2 (c -> c), then conv1 (concat 2c -> c), walking backwards
             edge = bricks[lvl]
-            blo = [l // e * e for l, e in zip(lo, edge)]
-            bhi = [min(-(-h // e) * e, d) for h, e, d in zip(hi, edge, dims)]
+            blo = [l & ~1 for l in lo] if len(set(bricks)) == 1 else list(lo)      # bricks start at the box's low corner (fp32 Winograd: rounded down to an even voxel)
+            bhi = [min(b + -(-(h - b) // e) * e, d) for b, h, e, d in zip(blo, hi, edge, dims)]
             done = (bhi[0] - blo[0]) * (bhi[1] - blo[1]) * (bhi[2] - blo[2])
             skipped += 2.0 * 27 * cin * c * (dims[0] * dims[1] * dims[2] - done)
             lo = [max(0, l - 1) for l in lo]; hi = [min(d, h + 1) for h, d in zip(hi, dims)]

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_k
     } else {
         tw = L % tilesW; L /= tilesW; th = L % tilesH; L /= tilesH; td = L % tilesD; n = L / tilesD;
     }
-    const int d0 = (td + o_td) * G::DZ, h0 = (th + o_th) * G::BH, w0 = (tw + o_tw) * G::BW;      // (o_*: first brick of the needed region)
+    const int d0 = td * G::DZ + o_td, h0 = th * G::BH + o_th, w0 = tw * G::BW + o_tw;      // (o_*: voxel origin of the needed region's first brick)
     const int co0 = cg * 32 * CO_T;
     constexpr int PD = KD == 3 ? 1 : 0;
     const int nch = a.Cin / CH;
@@ -686,7 +686,9 @@ int launch_t(const ConvB16Args& a, int ksplit, hipStream_t s) {
         for (int i = 0; i < 3; ++i) {
             const int lo = a.box_lo[i] < 0 ? 0 : a.box_lo[i], hi = a.box_hi[i] > dims[i] ? dims[i] : a.box_hi[i];
             E3_REQUIRE(hi > lo, E3_ERR_INVALID, "bf16 conv with a needed region: empty box");
-            o[i] = lo / edge[i]; n[i] = cdiv(hi, edge[i]) - o[i];
+            // bricks start at the box's low corner (a direct conv has no tile alignment to keep: any origin gives the same values): the 1-voxel margins of
+            // a box in front of another conv do not cost an extra brick per axis
+            o[i] = lo; n[i] = cdiv(hi - lo, edge[i]);
         }
         tD = n[0]; tH = n[1]; tW = n[2];
     }
