@@ -44,3 +44,23 @@ if os.environ.get('E3_TILE_WITH_COPIES'):
         torch.cuda.current_stream().synchronize(); dt2 = (time.perf_counter() - t0) / n
     stop[0] = True; th.join()
     print(f'tile forward beside continuous H2D + D2H copies: {dt2 * 1e3:.3f} ms per tile')
+# several tiles of a row as ONE call: a "batch" whose sample stride is the tile step along w (overlapping views of the same padded volume)
+if os.environ.get('E3_TILE_BATCH'):
+    nb = int(os.environ['E3_TILE_BATCH'])
+    volb = torch.randn(1, 1, 128, 224, 32 + 192 * nb, device='cuda')
+    outb = torch.zeros(1, 2, 96, 192, 192 * nb, device='cuda')
+    vb = torch.as_strided(volb, (nb, 1, 128, 224, 224), (192, volb.stride(1), volb.stride(2), volb.stride(3), 1))
+    ob = torch.as_strided(outb, (nb, 2, 96, 192, 192), (192, outb.stride(1), outb.stride(2), outb.stride(3), 1))
+    with torch.no_grad():
+        for _ in range(2):
+            m.forward_tile(vb, (0, 0, 0), (128, 224, 224), ob, (0, 0, 0), roi, softmax=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(max(1, n // nb)):
+            m.forward_tile(vb, (0, 0, 0), (128, 224, 224), ob, (0, 0, 0), roi, softmax=True)
+        torch.cuda.synchronize(); dtb = (time.perf_counter() - t0) / max(1, n // nb) / nb
+        # the same tiles one by one
+        ref = torch.zeros_like(outb)
+        for i in range(nb):
+            m.forward_tile(volb, (0, 0, 192 * i), (128, 224, 224), ref, (0, 0, 192 * i), roi, softmax=True)
+        torch.cuda.synchronize()
+    print(f'{nb} tiles of a row per call: {dtb * 1e3:.3f} ms per tile; identical to one-by-one: {bool(torch.equal(ref, outb))}, max diff {float((ref - outb).abs().max()):.2e}')
