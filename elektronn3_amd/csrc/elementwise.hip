@@ -845,7 +845,9 @@ int launch_pack_weights(PackMode mode, const float* w, float* out, int Cout, int
 }
 
 int launch_bn_finalize(BnFinalizeArgs a, hipStream_t s) {
-    if (a.scratch && a.parts > 4 * BN_PRERED && a.C <= 1024) {
+    // (up to 1024 records -- the persistent kernels' one-per-workgroup records, the 512-brick levels -- the finaliser's 1024 threads take one record each:
+    // the pre-merge launch would cost more than it saves; thousands of per-brick records are merged to BN_PRERED coalesced partials first)
+    if (a.scratch && a.parts > 1024 && a.C <= 1024) {
         hipLaunchKernelGGL(bn_premerge_kernel, dim3(BN_PRERED), dim3(1024), 0, s, a.stats, a.parts, a.C, a.scratch);
         a.stats = a.scratch; a.parts = BN_PRERED;
     }
