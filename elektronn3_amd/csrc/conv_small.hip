@@ -846,7 +846,10 @@ int launch_conv_small_wgrad(const float* x, int Cin, const float* dy, int dy_ldc
     const int splits = cdiv(ntiles, tps);
     const int NV = (TD + (planar ? 0 : 2)) * (TH + 2) * 18;
     const size_t lds = (size_t)(((NV + 3) & ~3) + 256 * 32) * 4;
-    if (planar) hipLaunchKernelGGL((conv_small_wgrad_kernel<1, 1, 16, false>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
+    static const bool planar_valu = getenv("E3_FIRST_WGRAD_PLANAR_VALU") != nullptr;      // A/B switch
+    if (planar && Cin == 1 && Cout % 32 == 0 && !planar_valu)       // (the 9 taps are the MFMA tile's columns, as the 27 of the 3x3x3 form)
+        hipLaunchKernelGGL((conv_small_wgrad_kernel<1, 1, 16, true>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
+    else if (planar) hipLaunchKernelGGL((conv_small_wgrad_kernel<1, 1, 16, false>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
     else if (Cin == 1 && Cout % 32 == 0)
         hipLaunchKernelGGL((conv_small_wgrad_kernel<3, 2, 8, true>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
     else hipLaunchKernelGGL((conv_small_wgrad_kernel<3, 2, 8, false>), dim3(splits), dim3(256), lds, s, x, Cin, dy, dy_ldc, part, N, D, H, W, Cout, tD, tH, tW, tps, f);
