@@ -515,6 +515,9 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
         if (tid < 128) hw[tid] = tid < hk->head_cout * 32 ? hk->head_w[tid] : 0.f;
         else if (tid < 132) hw[tid] = (hk->head_b && tid - 128 < hk->head_cout) ? hk->head_b[tid - 128] : 0.f;
     }
+#ifndef E3_WINO_ST_AUX
+#define E3_WINO_ST_AUX 0      // cache-policy bits of the output stores (developer builds: 2 = non-temporal)
+#endif
 #ifndef E3_WINO_ABL
 #define E3_WINO_ABL 0       // developer builds: bit mask of pieces left out of the MFMA phase (timing experiments, wrong results)
 #endif
@@ -803,8 +806,8 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
             for (int k = 0; k < 4; ++k) {
                 const bool cok = n0 + 8 * k + 4 * ehf < eN;
                 if (!(E3_WINO_ABL & 64)) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[0][k]), y_rs, (ok0 && cok) ? t_voff + 32 * k : OOB, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[1][k]), y_rs, (ok1 && cok) ? t_voff + 32 * k : OOB, od_off, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[0][k]), y_rs, (ok0 && cok) ? t_voff + 32 * k : OOB, 0, E3_WINO_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y[1][k]), y_rs, (ok1 && cok) ? t_voff + 32 * k : OOB, od_off, E3_WINO_ST_AUX);
                 }
             }
             }
@@ -911,7 +914,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
                 for (int r = 0; r < 16; ++r) {
                     const int soff = ((((2 * (r >> 3) + od) * H + 2 * ((r >> 2) & 1)) * W + 2 * (r & 3)) * yl) * 4;
                     const float v = y[od][r >> 2][r & 3];
-                    if (!(E3_WINO_ABL & 64)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, y_voff, soff, 0);
+                    if (!(E3_WINO_ABL & 64)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, y_voff, soff, E3_WINO_ST_AUX);
                 }
             cnt = 32.f; mean = 0.f; m2 = 0.f;
             if (do_stats) {
@@ -937,7 +940,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
                     const bool ok = nvalid && gd < D && gh < H && gw < W;
                     const int soff = ((((2 * (r >> 3) + od) * H + 2 * ((r >> 2) & 1)) * W + 2 * (r & 3)) * yl) * 4;
                     const float v = y[od][r >> 2][r & 3];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, ok ? y_voff : OOB, soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, ok ? y_voff : OOB, soff, E3_WINO_ST_AUX);
                     cnt += ok ? 1.f : 0.f;
                     sum += ok ? v : 0.f;
                     okmask |= (ok ? 1u : 0u) << (od * 16 + r);
