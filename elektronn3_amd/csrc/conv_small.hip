@@ -800,10 +800,11 @@ int conv_small_stats_parts2(int N, int D, int H, int W, int planar, int Cin, int
 int launch_conv_small_fwd(ConvSmallArgs a, hipStream_t s) {
     E3_REQUIRE(a.Cin >= 1 && a.Cin < 8, E3_ERR_UNSUPPORTED, "direct conv handles 1..7 input channels");
     E3_REQUIRE(a.Cout % 4 == 0 && a.y_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "output channels must be a multiple of 4");
-    if (first_mfma(a.N, a.D, a.H, a.W, a.planar, a.Cin, a.Cout)) {
-        E3_REQUIRE(((uintptr_t)a.y & 15) == 0, E3_ERR_INVALID, "first conv: misaligned output");
-        E3_REQUIRE((long long)a.H * a.W * a.y_ldc * 4 * 4 < 0x7fffffffll, E3_ERR_UNSUPPORTED, "first conv: four d-planes of the output view exceed 2^31 bytes (32-bit buffer offsets)");
-        E3_REQUIRE((a.xs_d ? a.xs_d : (long long)a.H * a.W) * 6 * 4 < 0x7fffffffll, E3_ERR_UNSUPPORTED, "first conv: six d-planes of the input view exceed 2^31 bytes (32-bit buffer offsets)");
+    // (32-bit buffer offsets: four d-planes of the output view and six of the input view must stay below 2^31 bytes; larger views -- and misaligned outputs --
+    // take the one-brick kernel below, except with statistics, whose record count the caller has already sized for this kernel)
+    const bool fits = ((uintptr_t)a.y & 15) == 0 && (long long)a.H * a.W * a.y_ldc * 4 * 4 < 0x7fffffffll && (a.xs_d ? a.xs_d : (long long)a.H * a.W) * 6 * 4 < 0x7fffffffll;
+    if (first_mfma(a.N, a.D, a.H, a.W, a.planar, a.Cin, a.Cout) && (fits || a.stats)) {
+        E3_REQUIRE(fits, E3_ERR_UNSUPPORTED, "first conv with statistics: view too large or misaligned for the persistent kernel (32-bit buffer offsets)");
         const int tD = cdiv(a.D, FB_D), tH = cdiv(a.H, FB_H), tW = cdiv(a.W, FB_W), npass = a.Cout / 32;
         const unsigned nitems = (unsigned)((size_t)a.N * tD * tH * tW * npass);
         if (a.epi_scale) hipLaunchKernelGGL((conv_first_mfma_kernel<true, false>), dim3(FGRID), dim3(256), 0, s, a, tD, tH, tW, npass, nitems);
