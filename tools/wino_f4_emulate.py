@@ -10,6 +10,7 @@ tests/test_unet_gpu.py::test_full_size_against_the_reference_digest against test
 
     python tools/wino_f4_emulate.py direct f222 f224 f224:0,1,-1,1/2,-2 [--levels 0,1] [--out profiles/r05_f224_emulation.md]
 
+`f224-dgrad` = forward on today's F(2x2x2) tiles, only the data gradient on F(2x2x4) (ReLU / arg-max decisions are taken in the forward pass).
 `direct` = ATen's conv everywhere (calibration: the reference's fp32 run itself), `f222` = the tiles conv3_wino_pkernel computes today, `f224[:points]` =
 F(4,3) along W with the given interpolation points (default 0,1,-1,2,-2; infinity is always the last point).
 """
@@ -151,10 +152,10 @@ def wino_conv3(x, w, ms, mat, chunk=8):
 class WinoConv(torch.autograd.Function):
     """conv3d(x, w, b, padding=1): forward and data gradient on emulated Winograd tiles, weight gradient by ATen (the weight-gradient kernel does not change)."""
     @staticmethod
-    def forward(ctx, x, w, b, ms, mat):
+    def forward(ctx, x, w, b, ms, mat, ms_fwd=None):
         ctx.save_for_backward(x, w)
         ctx.ms, ctx.mat = ms, mat
-        return wino_conv3(x, w, ms, mat) + b.view(1, -1, 1, 1, 1)
+        return wino_conv3(x, w, ms_fwd or ms, mat) + b.view(1, -1, 1, 1, 1)
 
     @staticmethod
     def backward(ctx, dy):
@@ -162,7 +163,7 @@ class WinoConv(torch.autograd.Function):
         wt = w.flip(2, 3, 4).transpose(0, 1).contiguous()
         dx = wino_conv3(dy.contiguous(), wt, ctx.ms, ctx.mat)
         dw = torch.nn.grad.conv3d_weight(x, w.shape, dy, padding=1)
-        return dx, dw, dy.sum((0, 2, 3, 4)), None, None
+        return dx, dw, dy.sum((0, 2, 3, 4)), None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ the digest's assertions
@@ -237,6 +238,8 @@ def parse_mode(spec):
     if spec == 'direct':
         return None, 'direct (ATen fp32 everywhere)'
     name, _, pts = spec.partition(':')
+    dgrad_only = name.endswith('-dgrad')       # forward on the F(2x2x2) tiles of today's kernel, only the DATA GRADIENT on the larger tiles
+    name = name[:-6] if dgrad_only else name
     ms = {'f222': (2, 2, 2), 'f224': (2, 2, 4), 'f244': (2, 4, 4), 'f444': (4, 4, 4)}[name]
     mat = {2: mats(2)}
     if 4 in ms:
@@ -245,7 +248,7 @@ def parse_mode(spec):
             pts, _, sc = pts.partition('@')
             scales = [Fraction(s) for s in sc.split(',')]
         mat[4] = mats(4, [Fraction(p) for p in pts.split(',')] if pts else None, scales)
-    return (lambda x, w, b: WinoConv.apply(x, w, b, ms, mat)), f'{name} tiles' + (f', F(4,3) points {pts or "0,1,-1,2,-2"}' if 4 in ms else '')
+    return (lambda x, w, b: WinoConv.apply(x, w, b, ms, mat, (2, 2, 2) if dgrad_only else None)), f'{name} tiles' + (' for the data gradient only (forward: F(2x2x2))' if dgrad_only else '') + (f', F(4,3) points {pts or "0,1,-1,2,-2"}' if 4 in ms else '')
 
 
 def main():
