@@ -47,7 +47,8 @@ int e3_conv3d_fwd(void* stream, const float* x, int x_ldc, int Cin, const float*
     E3_REQUIRE(workspace_bytes >= e3_conv3d_workspace_bytes(Cin, Cout, planar), E3_ERR_WORKSPACE, "conv3d workspace too small");
     const int T = planar ? 9 : 27, NPad = pad_cols(Cout);
     (void)T;
-    const int flags0 = pro_scale ? (CF_NO_WINO | CF_NO_KSPLIT) : 0;    // the Winograd kernels have no BN prologue
+    // (the Winograd kernels have no BN prologue; the folded epilogue is the eval-mode forward, which may take the F(2x2x4) tiles of conv_wino4.hip)
+    const int flags0 = pro_scale ? (CF_NO_WINO | CF_NO_KSPLIT) : ((epi_scale && !stats) ? CF_WINO4 : 0);
     int rc = launch_pack_conv_auto(kind_of(planar), 0, w, (float*)workspace, Cout, Cin, N, D, H, W, flags0, s);
     if (rc) return rc;
     ConvArgs a{};
@@ -66,12 +67,12 @@ int e3_conv3d_dgrad(void* stream, const float* dy, int dy_ldc, int Cout, const f
     E3_REQUIRE(workspace_bytes >= e3_conv3d_workspace_bytes(Cin, Cout, planar), E3_ERR_WORKSPACE, "conv3d workspace too small");
     const int T = planar ? 9 : 27, NPad = pad_cols(Cin);
     (void)T;
-    int rc = launch_pack_conv_auto(kind_of(planar), 1, w, (float*)workspace, Cout, Cin, N, D, H, W, 0, s);
+    int rc = launch_pack_conv_auto(kind_of(planar), 1, w, (float*)workspace, Cout, Cin, N, D, H, W, CF_WINO4, s);
     if (rc) return rc;
     ConvArgs a{};
     a.x = dy; a.x_ldc = dy_ldc; a.Cin = Cout; a.wt = (const float*)workspace; a.bias = nullptr;
     a.y = dx; a.y_ldc = dx_ldc; a.N = N; a.D = D; a.H = H; a.W = W; a.sd = 2;
-    a.Cout = Cin; a.Ncols = Cin; a.NPad = NPad; a.G = 1; a.flags = 0;
+    a.Cout = Cin; a.Ncols = Cin; a.NPad = NPad; a.G = 1; a.flags = CF_WINO4;
     return launch_conv_mfma(kind_of(planar), a, s);
 }
 

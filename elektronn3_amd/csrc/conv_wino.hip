@@ -1020,7 +1020,7 @@ __device__ __forceinline__ void wino_pack_item(const float* __restrict__ w, floa
         const size_t r = i >> 8;
         const int ch = r % NCH, nt = r / NCH;
         int n = nt * 32 + co, k = ch * 8 + hf * 4 + e;
-        if (layout == 1) {
+        if (layout >= 1) {
             const int ln = (int)((i >> 2) & 63), m = ln & 15, kq = ln >> 4, ks = e >> 1, half = e & 1;
             n = nt * 32 + 8 * (m >> 2) + 4 * half + (m & 3);
             k = ch * 8 + 2 * kq + ks;
@@ -1048,6 +1048,23 @@ __device__ __forceinline__ void wino_pack_item(const float* __restrict__ w, floa
                 const double g0 = u1[pd][0][c], g1 = u1[pd][1][c], g2 = u1[pd][2][c];
                 u2[pd][0][c] = g0; u2[pd][1][c] = 0.5 * (g0 + g1 + g2); u2[pd][2][c] = 0.5 * (g0 - g1 + g2); u2[pd][3][c] = g2;
             }
+        if (layout == 2) {      // F(2x2x4) tiles (conv_wino4.hip): 96 positions (pd, ph, pw 6), G of F(4,3) along the w taps; lane layout as layout 1
+            float* o4 = out + ((size_t)(nt * NCH + ch) * 96) * 256 + (i & 255);
+#pragma unroll
+            for (int pd = 0; pd < 4; ++pd)
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) {
+                    const double g0 = u2[pd][ph][0], g1 = u2[pd][ph][1], g2 = u2[pd][ph][2];
+                    const int pos = (pd * 4 + ph) * 6;
+                    o4[(size_t)(pos + 0) * 256] = (float)(0.25 * g0);
+                    o4[(size_t)(pos + 1) * 256] = (float)(-(g0 + g1 + g2) / 6.0);
+                    o4[(size_t)(pos + 2) * 256] = (float)(-(g0 - g1 + g2) / 6.0);
+                    o4[(size_t)(pos + 3) * 256] = (float)(g0 / 24.0 + g1 / 12.0 + g2 / 6.0);
+                    o4[(size_t)(pos + 4) * 256] = (float)(g0 / 24.0 - g1 / 12.0 + g2 / 6.0);
+                    o4[(size_t)(pos + 5) * 256] = (float)g2;
+                }
+            return;
+        }
         float* o = out + ((size_t)(nt * NCH + ch) * 64) * 256 + (hf * 32 + co) * 4 + e;
 #pragma unroll
         for (int pd = 0; pd < 4; ++pd)
@@ -1091,7 +1108,7 @@ __global__ __launch_bounds__(256) void wino_pack_multi_kernel(const WinoPackMult
 }  // namespace
 
 // ---- host side
-size_t wino_packed_floats(int K, int ncols) { return (size_t)64 * K * (size_t)((ncols + 31) / 32 * 32); }
+size_t wino_packed_floats(int K, int ncols) { return (size_t)96 * K * (size_t)((ncols + 31) / 32 * 32); }      // (96 positions: the F(2x2x4) layout; F(2x2x2) needs 64)
 
 int wino_bricks(int N, int D, int H, int W) { return N * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16); }
 
@@ -1185,14 +1202,18 @@ static bool wino_wgstats(size_t nblk, int ntiles, unsigned pgrid = 256u) {
     return pgrid == 256u && nblk >= 256 && nblk % 8 == 0 && (nblk / 8) % (size_t)ntiles == 0 && 32 % ntiles == 0;
 }
 int wino_stats_parts(int N, int D, int H, int W, int Cin, int ncols, int flags) {
-    if (conv_wino_layout(flags, D, H, W, Cin, ncols, 1) == 1) return wino16_stats_parts(N, D, H, W, ncols);
+    const int lay = conv_wino_layout(flags, D, H, W, Cin, ncols, 1);
+    if (lay == 1) return wino16_stats_parts(N, D, H, W, ncols);
+    if (lay == 2) return wino4_stats_parts(N, D, H, W, ncols);
     const int bricks = wino_bricks(N, D, H, W), ntiles = (ncols + 31) / 32;
     const size_t nblk = (size_t)bricks * ntiles;
     return (wino_persistent(nblk, flags) && wino_wgstats(nblk, ntiles)) ? 256 / ntiles : bricks;
 }
 
 int launch_conv3_wino(ConvArgs a, hipStream_t s) {
-    if (conv_wino_layout(a.flags, a.D, a.H, a.W, a.Cin, a.Ncols, a.splitk) == 1) return launch_conv3_wino16(a, s);
+    const int lay = conv_wino_layout(a.flags, a.D, a.H, a.W, a.Cin, a.Ncols, a.splitk);
+    if (lay == 1) return launch_conv3_wino16(a, s);
+    if (lay == 2) return launch_conv3_wino4(a, s);
     a.tilesD = cdiv(a.D, 4); a.tilesH = cdiv(a.H, 4); a.tilesW = cdiv(a.W, 16);
     a.o_td = a.o_th = a.o_tw = 0;
     if (a.box_hi[0] > 0) {      // needed region: the bricks that meet the box

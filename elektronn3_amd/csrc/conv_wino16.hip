@@ -527,22 +527,6 @@ static bool wino16_wgstats(size_t nblk, int ntiles, unsigned grid) {
     return grid == 512u && nblk > 512 && nblk % 8 == 0 && (nblk / 8) % (size_t)ntiles == 0 && 64 % ntiles == 0;
 }
 
-// Which decomposition a Winograd 3x3x3 launch takes: 0 = 32-tile bricks (conv_wino.hip), 1 = 16-tile bricks, two workgroups per CU
-// (this file).  THE predicate: the weight packers (the two kernels want different layouts), the statistics sizing and the launcher all ask
-// it.  Decided on the grid of ONE sample (like conv_use_wino) so that the arithmetic does not depend on the batch size; a split-K launch,
-// the timing flag and column counts that rule out 16-byte stores keep the first kernels.
-int conv_wino_layout(int flags, int D, int H, int W, int K, int ncols, int splitk) {
-    // OFF by default: measured at parity with conv_wino.hip's persistent kernel on the cfg-2 layers (profiles/r04_wino16_experiment.md), not
-    // ahead of it -- E3_WINO16=1 selects it (A/B switch; tests/test_switches_gpu.py runs the parity suites with it)
-    static const bool enabled = getenv("E3_WINO16") != nullptr && getenv("E3_NO_WINO16") == nullptr;
-    static const size_t minblk = getenv("E3_WINO16_MIN") ? (size_t)atol(getenv("E3_WINO16_MIN")) : 512;
-    if (splitk > 1 || (flags & 1024) || (ncols & 3) || (K & 7)) return 0;
-    if (flags & CF_BNRED) return 1;       // (the caller checked conv_wino16_bnred_parts(): only this kernel has the fused reduction)
-    if (!enabled) return 0;
-    const size_t nblk1 = (size_t)wino16_bricks(1, D, H, W) * ((ncols + 31) / 32);
-    return nblk1 >= minblk ? 1 : 0;
-}
-
 int conv_wino16_bnred_parts(int N, int D, int H, int W, int K, int ncols) {
     if ((ncols & 3) || (K & 7)) return 0;
     const int ntiles = (ncols + 31) / 32;

@@ -1,0 +1,736 @@
+// 3x3x3 stride-1 convolution as Winograd F(2x2x4, 3x3x3) on the fp32 matrix cores: F(2,3) along D and H, F(4,3) along W -- 96 multiplies per
+// 2x2x4 output tile and (ci, co) pair = 6 per output voxel, where conv_wino.hip's F(2x2x2) tiles spend 8 and the direct kernels 27.
+// (torch.nn.Conv3d(k=3, padding=1) in elektronn3's conv3 blocks, unet.py:131-149.)
+//
+// Who takes it (conv_wino_layout() == 2, flag CF_WINO4 set by the caller): the eval-mode forward with the folded BatchNorm epilogue (Predictor)
+// and every DATA GRADIENT.  The F(4,3) transforms carry the constants 4, 5, 8 and cost 2.5x the conv error of F(2,3) (4.5e-7 instead of 1.8e-7
+// rel-L2 at 64 channels): far inside the forward tolerance, and invisible in a data gradient -- but a train-mode FORWARD on these tiles flips
+// enough ReLU / arg-max decisions to push encoder weight gradients over the 1e-2 bound of the full-size digest test
+// (profiles/r05_f224_emulation.md), so the training forward stays on F(2x2x2).
+//
+// Work decomposition (one workgroup = 4 waves, ONE wave per SIMD):
+//   * brick = 2x2x4 tiles = 4x4x16 output voxels (6x6x18 halo, the brick of conv_wino.hip) x 32 output channels;
+//   * the 96 Winograd positions (pd 4, ph 4, pw 6) are 96 GEMMs  M = 32 channels, N = 16 tiles, K = Cin  on v_mfma_f32_16x16x4_f32 with the
+//     WEIGHTS as the A operand: D[co][tile], lane l holds tile l & 15 and the channels 4 (l >> 4) .. + 3 of a 16-channel half, the packer permutes the
+//     channels of a 32-channel tile so that a lane's two halves are 8 consecutive channels -> the brick leaves as 16-byte stores.  Wave w owns the 24
+//     positions with pd = w: 24 x 2 accumulator quads = 192 registers;
+//   * K is walked in chunks of 8 channels.  The raw halo is staged by LDS-DMA (buffer_load_dwordx4 ... lds, 6 x 1 KB per wave and chunk, the bank
+//     layout is produced on the source side, zero padding = range check), double buffered across chunks AND bricks; lane (tile, kk) reads its 4 x 6
+//     window of channels 2 kk, 2 kk + 1 from the two d-planes its pd needs (D pass of B^T while reading), does the H (F(2,3)) and W (F(4,3)) passes
+//     on float2 and feeds the result straight to the MFMAs: the transformed tile never touches LDS.  The reads of chunk c + 1 are issued under the
+//     last MFMAs of chunk c, the weights (24 x 16 bytes per lane and chunk, from L2) one chunk ahead into the registers whose MFMAs are issued;
+//   * epilogue: A^T over (pw: 6 -> 4, ph: 4 -> 2) in registers, over pd through LDS (wave w then owns oh = w >> 1 and the two ow = 2 (w & 1), + 1 of
+//     every tile), bias / folded BN + ReLU / running Welford statistics per lane (8 channels of one tile, one record per workgroup) / 16-byte stores.
+#include <type_traits>
+#include "kernels.h"
+
+#ifndef E3_W4_ABL
+#define E3_W4_ABL 0       // developer builds (-DE3_TIMING): bit mask of pieces left out (timing experiments, wrong results)
+#endif
+
+namespace {
+
+constexpr int V_ROW = 20;                                   // slots per halo row: zw -> (zw & 3) * 5 + (zw >> 2)  (18 of 20 used)
+constexpr int V_RPLANE = 128 * 8 + 16;                      // floats of one raw d-plane: 6 rows x 20 slots of 32 bytes, padded to 4 DMA pieces of 1 KB, + 64 B skew
+constexpr int V_RBUF = 6 * V_RPLANE;                        // 6 raw planes: 24.4 KB per stage buffer
+constexpr int V_EX = 4 * 16 * 64 * 4;                       // epilogue exchange [pd][(oh, ow, half)][lane][4] floats (64 KB)
+constexpr int V_SCR = 4 * 32 * 3;                           // cross-wave merge of the statistics
+constexpr int V_RUN = 17 * 256;                             // running statistics of every thread: n, mean[8], M2[8]  ([k][thread])
+constexpr int V_POOLX = 4 * 64 * 8;                         // fused max-pool: [wave][lane][8 channels] (8 KB)
+constexpr int V_HEADW = 160;                                // fused head: weights [4][32] + biases [4] (padded)
+constexpr int V_KST = 2 * 96;                                // bias / folded scale / folded shift of the workgroup's 32 channels, two slots
+constexpr int V_LDS_FLOATS = 3 * V_RBUF + V_EX + V_SCR + V_RUN + V_KST;   // 160.1 KB of the CU's 160 KiB (163 840 B): one workgroup per CU (the fused pool / head scratch lives in the statistics' region)
+static_assert(V_POOLX + V_HEADW <= V_RUN && V_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
+typedef __attribute__((address_space(3))) void* lds_ptr_v;
+
+// Layout of a raw plane: halo voxel (zh, zw) -> slot ((zh & 1) * 3 + (zh >> 1)) * 20 + (zw & 3) * 5 + (zw >> 2) of 32 bytes (8 channels): the stride-2
+// tile origins along h and the stride-4 origins along w are consecutive slots; the 16-byte half q of a voxel sits at q ^ ((zh >> 1) & 1), and planes
+// are 64 B mod 256 B apart -- so the 32 lanes of a ds_read_b64 group (2 x 2 x 4 tiles x 2 channel pairs) cover all 64 banks.
+
+// POOL (AFF, inference): the 2x2x2 ceil-mode max-pool of the output in the epilogue (ConvArgs::pool_out)
+// HEAD (AFF, inference, 32 output channels): the 1x1x1 head (+ softmax) on the activations in registers instead of storing them (ConvArgs::head_*)
+template <bool AFF, bool POOL = false, bool HEAD = false>
+__global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, const unsigned nblk, const int wgstats) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tl = lane & 15, kk = lane >> 4;
+    const int ttd = tl >> 3, tth = (tl >> 2) & 1, ttw = tl & 3;
+    const int NCH = a.Cin >> 3;
+    constexpr unsigned OOB = 0x80000000u;       // buffer offset beyond every descriptor below: loads return 0, stores are dropped
+    // arguments that only the per-brick set-up and the epilogue need are re-read from the kernarg segment there (scalar loads) instead of
+    // occupying SGPRs across the chunk loop
+    typedef const __attribute__((address_space(4))) ConvArgs* KArgs;
+    auto KA = []() -> KArgs { KArgs q = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(q)); return q; };
+    const int D = a.D, H = a.H, W = a.W, xl = a.x_ldc;
+    const unsigned plane_xb = (unsigned)((size_t)H * W * xl * 4);
+
+    // ---- staging by LDS-DMA (1 KB per wave-instruction, lane i lands at base + 16 i): a raw d-plane of the halo is four such pieces; wave w
+    // issues quarter w of each of the six planes.  The layout of a plane is produced on the SOURCE side: lane i of quarter w asks for the 16
+    // bytes that belong at piece g = 64 w + i.
+    unsigned col_rel, col_bits;
+    {
+        const int g = wave * 64 + lane, slot = g >> 1, qd = g & 1;
+        const int rs = slot / V_ROW, sw = slot % V_ROW;
+        const int cls = sw / 5, idx = sw % 5;
+        const int zh = 2 * (rs % 3) + rs / 3, zw = 4 * idx + cls;
+        const bool used = rs < 6 && zw < 18;
+        const int q = qd ^ ((rs % 3) & 1);
+        col_rel = (unsigned)(((zh * W + zw) * xl + 4 * q) * 4);
+        col_bits = used ? (1u << (6 + zh)) | (1u << (12 + zw)) : 0xffffffffu;     // (all-ones never matches: the unused slots get zeros)
+    }
+    float m1 = -1.f, c2 = 2.f, c4 = 4.f, c8 = 8.f, cm4 = -4.f, cm5 = -5.f, cm2 = -2.f;
+    asm volatile("" : "+s"(m1), "+s"(c2), "+s"(c4), "+s"(c8), "+s"(cm4), "+s"(cm5), "+s"(cm2));     // opaque constants: a + c*b becomes v_pk_fma_f32
+
+    // ---- read plan of lane (tile tl, channel pair kk).  The D pass of B^T is done while reading: row pd = wave of the tile depth's 4
+    // raw planes is  x[A] + sgn x[B]  with (A, B, sgn) = (0, 2, -), (1, 2, +), (2, 1, -), (1, 3, -).  Window rows h = 0, 1 have zh/2 = tth,
+    // rows 2, 3 have tth + 1 (the XOR of the 16-byte half follows).
+    const int pA = wave == 0 ? 0 : (wave == 2 ? 2 : 1), pB = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float dsg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(wave == 1 ? 0x3f800000 : (int)0xbf800000));
+    int rdA[2], rdB[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int r = ((tth + hh) * V_ROW + ttw) * 8 + 2 * (kk ^ (2 * ((tth + hh) & 1)));
+        rdA[hh] = (2 * ttd + pA) * V_RPLANE + r; rdB[hh] = (2 * ttd + pB) * V_RPLANE + r;
+    }
+    auto rd_imm = [](int h, int w) { return (((h & 1) * 3) * V_ROW + (w & 3) * 5 + (w >> 2)) * 8; };
+
+    // three stage buffers: `cur` = the unit being computed, `nx1` = the next unit (landed: its window is read under this unit's MFMAs), `nx2` = the
+    // unit after that (its DMA is issued under this unit's MFMAs and has a whole unit to land)
+    float* cur = smem;
+    float* nx1 = smem + V_RBUF;
+    float* nx2 = smem + 2 * V_RBUF;
+    float* const ex = smem + 3 * V_RBUF;
+    float* const scr = ex + V_EX;
+    float* const run = scr + V_SCR + tid;
+#ifdef E3_W4_TIMING
+    const bool do_stats = false;
+#else
+    const bool do_stats = !AFF && a.stats != nullptr;
+#endif
+    if (do_stats) {
+#pragma unroll
+        for (int k = 0; k < 17; ++k) run[k * 256] = 0.f;
+    }
+    // per-channel constants of the epilogue (bias, folded scale / shift) of the brick's 32 channels live in LDS: as buffer loads in the epilogue they
+    // waited -- the memory counter retires in order -- for every request of the next units in front of them.  Reloaded only when a workgroup's
+    // column tile changes (never when the grid tiles); two slots, because a wave may still be in the previous brick's epilogue.
+    float* const kst = scr + V_SCR + V_RUN;
+    int kslot = 0, k_n0 = -1;
+    auto load_consts = [&](int n0) {
+        if (n0 == k_n0) return;
+        k_n0 = n0; kslot ^= 1;
+        if (tid < 96) {
+            const KArgs e = KA();
+            const int which = tid >> 5, ch = n0 + (tid & 31);
+            const float* const src = which == 0 ? e->bias : (which == 1 ? e->epi_scale : e->epi_shift);
+            kst[kslot * 96 + tid] = (src != nullptr && ch < e->Ncols) ? src[ch] : (which == 1 ? 1.f : 0.f);
+        }
+    };
+    if (HEAD) {          // the head's weights [class][32] and biases [4] in the running statistics' region (no statistics in this form; published by the prologue's barrier)
+        float* const hw = scr + V_SCR + V_POOLX;
+        const KArgs hk = KA();
+        if (tid < 128) hw[tid] = tid < hk->head_cout * 32 ? hk->head_w[tid] : 0.f;
+        else if (tid < 132) hw[tid] = (hk->head_b && tid - 128 < hk->head_cout) ? hk->head_b[tid - 128] : 0.f;
+    }
+
+    // ---- the workgroup's bricks: XCD x owns a contiguous eighth of the logical (XCD-blocked) brick range, its workgroups walk it with
+    // stride gridDim / 8; a grid of nblk workgroups does one brick each
+    unsigned L, Lend, Lstep;
+    if (gridDim.x == nblk) { L = xcd_remap(blockIdx.x, nblk); Lend = L + 1; Lstep = 1; }
+    else {
+        const unsigned xcd = blockIdx.x & 7u, q = nblk >> 3, r = nblk & 7u;
+        const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        L = base + (blockIdx.x >> 3); Lend = base + q + (xcd < r ? 1u : 0u); Lstep = gridDim.x >> 3;
+    }
+    auto divmod = [](unsigned& x, int d) {
+        int r;
+        if ((d & (d - 1)) == 0) { r = (int)(x & (unsigned)(d - 1)); x >>= __builtin_ctz((unsigned)d); }
+        else { r = (int)(x % (unsigned)d); x /= (unsigned)d; }
+        return r;
+    };
+    auto range_mask = [](int lo, int n, int size) {      // bit z set: lo + z in [0, size), z in [0, n)
+        const int first = lo < 0 ? -lo : 0, last = size - lo < n ? size - lo : n;
+        return last > first ? ((1u << last) - 1u) & ~((1u << first) - 1u) : 0u;
+    };
+    // a brick: coordinates, halo origin at voxel (d0 - 1, h0 - 1, w0 - 1) (possibly in front of the tensor: only valid lanes form
+    // addresses from it), validity mask (6 d bits | 6 h bits | 18 w bits), the wave's transformed weights
+    //   U[ntile][chunk][pos 96][lane 64][ks 2][half 2]; wave = pd owns positions 24 pd .. 24 pd + 23
+    // (plain scalars, no struct: selecting between two structs' fields made hipcc keep them in scratch memory)
+#define E3_BRICK_VARS(X) int X##d0, X##h0, X##w0, X##nb, X##n0, X##row; const float* X##wbase
+#define E3_DECODE(X, Lval) do {                                                                                                        \
+        unsigned Lq_ = (Lval);                                                                                                         \
+        const KArgs k_ = KA();                                                                                                         \
+        const int ntile_ = divmod(Lq_, k_->ntiles);                                                                                      \
+        const int tw_ = divmod(Lq_, k_->tilesW);                                                                                         \
+        const int th_ = divmod(Lq_, k_->tilesH);                                                                                         \
+        const int td_ = divmod(Lq_, k_->tilesD);                                                                                         \
+        X##nb = (int)Lq_;                                                                                                              \
+        X##d0 = td_ * 4 + k_->org_d; X##h0 = th_ * 4 + k_->org_h; X##w0 = tw_ * 16 + k_->org_w;   /* (org_*: voxel origin of the needed region's first brick) */ \
+        X##n0 = ntile_ * 32;                                                                                                           \
+        X##row = ((X##nb * k_->tilesD + td_) * k_->tilesH + th_) * k_->tilesW + tw_;                                                         \
+        X##wbase = k_->wt + ((size_t)ntile_ * NCH * 96 + wave * 24) * 256;                                                               \
+    } while (0)
+    // the STAGING cursor runs two units (8-channel chunks) ahead of the computation, across bricks: S_L = its brick, S_c = its chunk,
+    // S_xorg / S_mask = halo origin and validity mask of that brick (a brick beyond the end of the workgroup's range stages zeros)
+    unsigned S_L = L, S_mask; int S_c = 0; const float* S_xorg;
+#define E3_DECODE_STAGE() do {                                                                                                         \
+        unsigned Lq_ = S_L;                                                                                                            \
+        const KArgs k_ = KA();                                                                                                         \
+        (void)divmod(Lq_, k_->ntiles);                                                                                                   \
+        const int tw_ = divmod(Lq_, k_->tilesW);                                                                                         \
+        const int th_ = divmod(Lq_, k_->tilesH);                                                                                         \
+        const int td_ = divmod(Lq_, k_->tilesD);                                                                                         \
+        const int sd0_ = td_ * 4 + k_->org_d, sh0_ = th_ * 4 + k_->org_h, sw0_ = tw_ * 16 + k_->org_w;                                  \
+        S_xorg = k_->x + (((long long)(int)Lq_ * D + (sd0_ - 1)) * ((long long)H * W * xl) + ((long long)(sh0_ - 1) * W + (sw0_ - 1)) * xl); \
+        const unsigned m_ = range_mask(sd0_ - 1, 6, D) | (range_mask(sh0_ - 1, 6, H) << 6) | (range_mask(sw0_ - 1, 18, W) << 12);         \
+        S_mask = S_L < Lend ? m_ : 0u;                                                                                                 \
+    } while (0)
+    auto stage_advance = [&]() { if (++S_c == NCH) { S_c = 0; S_L += Lstep; E3_DECODE_STAGE(); } };
+    // DMA piece `plane` (of this wave's quarter) of the staging cursor's unit into stage buffer `buf`: the plane's validity is the size of its
+    // descriptor (scalar work only), the lane's validity the out-of-range offset
+    auto issue_dma = [&](unsigned voff, float* buf, int plane) {
+        if (E3_W4_ABL & 1) return;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S_xorg), 0, ((S_mask >> plane) & 1u) ? 0x7fffffff : 0, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_v)(buf + plane * V_RPLANE + wave * 256), 16, voff, (int)(plane * plane_xb) + S_c * 32, 0, 0);
+    };
+    auto stage_voff = [&]() { return ((S_mask & col_bits) == col_bits) ? col_rel : OOB; };
+    const int b_voff = lane * 16;
+    f32x4 acc[24][2];
+    f32x4 Bv[24];
+    f32x2v ra[4][6], rb[4][6];          // raw window of the NEXT unit (planes A and B), read under the MFMAs of the current one
+    auto read_window = [&](const float* buf, int h, int w) {
+        ra[h][w] = *reinterpret_cast<const f32x2v*>(buf + rdA[h >> 1] + rd_imm(h, w));
+        rb[h][w] = *reinterpret_cast<const f32x2v*>(buf + rdB[h >> 1] + rd_imm(h, w));
+    };
+
+#ifdef E3_W4_TIMING      // developer build (tools/phase_timing_w4.py): s_memtime stamps of the workgroup's third brick instead of statistics
+    long long* const tstamp = reinterpret_cast<long long*>(KA()->stats) + (size_t)blockIdx.x * 48;
+    int tbrick = 0;
+#define TSTAMP(i) do { if (tid == 0 && tbrick == 2) tstamp[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(i)
+#endif
+    E3_BRICK_VARS(P_); E3_BRICK_VARS(N_);
+    E3_DECODE(P_, L);
+    load_consts(P_n0);
+    {   // prologue: units 0 and 1 staged, the weights of unit 0 requested, the window of unit 0 read
+        E3_DECODE_STAGE();
+        {
+            const unsigned voff = stage_voff();
+#pragma unroll
+            for (int p = 0; p < 6; ++p) issue_dma(voff, cur, p);
+        }
+        stage_advance();
+        {
+            const unsigned voff = stage_voff();
+#pragma unroll
+            for (int p = 0; p < 6; ++p) issue_dma(voff, nx1, p);
+        }
+        stage_advance();
+        const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P_wbase), 0, NCH * 96 * 1024, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < 24; ++p) Bv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_voff + (p & 3) * 1024, (p & ~3) * 1024, 0));
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(30)" ::: "memory");       // (unit 0 has landed: its 6 pieces are the oldest requests)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int w = 0; w < 6; ++w) read_window(cur, h, w);
+    }
+
+    for (;;) {
+        const bool has_next = L + Lstep < Lend;
+        E3_DECODE(N_, has_next ? L + Lstep : L);
+
+        // One 8-channel chunk c (unit u) of brick P.  Its raw window is in the registers ra / rb (read under the MFMAs of the previous unit, or
+        // in the previous brick's epilogue).  Program order: D, H, W passes (VALU phase: fp32 VALU and fp32 MFMA share the FMA lanes, so
+        // nothing else is put here); wait for this wave's DMA pieces of unit u + 1 (issued during unit u - 1: the 14 weight requests behind
+        // the last piece may still be outstanding), barrier (publishes every wave's pieces of unit u + 1 and retires the buffer of unit u - 1);
+        // then 12 position pairs of 8 MFMAs, each carrying two window reads (ds_read2_b64) of unit u + 1 and the weight requests of the same
+        // positions of unit u + 1 (a ring of 24: one full unit of look-ahead); the first six pairs also carry one DMA piece of unit u + 2.
+        auto chunk = [&](auto zero_tag, int c) {
+            constexpr bool ZERO = decltype(zero_tag)::value;
+            const bool lastc = c + 1 == NCH;
+            f32x2v t[4][6];
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+#pragma unroll
+                for (int w = 0; w < 6; ++w) t[h][w] = ra[h][w] + dsg * rb[h][w];
+            // H pass: F(2,3) rows  t0 - t2,  t1 + t2,  t2 - t1,  t1 - t3
+#pragma unroll
+            for (int w = 0; w < 6 && !(E3_W4_ABL & 8); ++w) {
+                const f32x2v u0 = t[0][w] + m1 * t[2][w], u1 = t[1][w] + t[2][w], u2 = t[2][w] + m1 * t[1][w], u3 = t[1][w] + m1 * t[3][w];
+                t[0][w] = u0; t[1][w] = u1; t[2][w] = u2; t[3][w] = u3;
+            }
+            // W pass: F(4,3) rows  4 d0 - 5 d2 + d4,  -4 d1 - 4 d2 + d3 + d4,  4 d1 - 4 d2 - d3 + d4,  -2 d1 - d2 + 2 d3 + d4,  2 d1 - d2 - 2 d3 + d4,  4 d1 - 5 d3 + d5
+#pragma unroll
+            for (int h = 0; h < 4 && !(E3_W4_ABL & 8); ++h) {
+                const f32x2v d0 = t[h][0], d1 = t[h][1], d2 = t[h][2], d3 = t[h][3], d4 = t[h][4], d5 = t[h][5];
+                const f32x2v e0 = d4 + cm4 * d2, e1 = d3 + cm4 * d1, f0 = d4 + m1 * d2, f1 = d3 + m1 * d1;
+                t[h][0] = (d4 + cm5 * d2) + c4 * d0;
+                t[h][1] = e0 + e1;
+                t[h][2] = e0 + m1 * e1;
+                t[h][3] = f0 + c2 * f1;
+                t[h][4] = f0 + cm2 * f1;
+                t[h][5] = (d5 + cm5 * d3) + c4 * d1;
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+#pragma unroll
+                for (int w = 0; w < 6; ++w) asm volatile("" : "+v"(t[h][w]));     // keep the transform packed and in front of the MFMA block
+            __builtin_amdgcn_sched_barrier(0);
+            if (c < 8) TSTAMP(1 + 5 * c);
+            if (E3_W4_ABL & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            if (c < 8) TSTAMP(2 + 5 * c);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (c < 8) TSTAMP(3 + 5 * c);
+            const unsigned d_voff = stage_voff();
+            const float* const wb = lastc ? N_wbase : P_wbase;
+            const int cB = lastc ? 0 : c + 1;
+            // (the chunk's share of the weights starts at the descriptor's base: the scalar offsets below are compile-time constants)
+            const __amdgpu_buffer_rsrc_t b_nx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wb) + (size_t)cB * 96 * 256, 0, (lastc && !has_next) ? 0 : 96 * 1024, 0x00020000);
+#pragma unroll
+            for (int pp = 0; pp < 24; pp += 2) {        // two positions at a time: 4 independent accumulators in flight, then their ring slots are refilled
+                if (pp < 12) issue_dma(d_voff, nx2, pp >> 1);
+                if (!(E3_W4_ABL & 64)) {                // window elements (h, w) and (h, w') of unit u + 1: w' = w + 4 (w = 0, 1) resp. 3 (w = 2) -- 32 / 160 bytes apart: one ds_read2_b64 per plane
+                    const int k = pp >> 1, h = k / 3, wa = k % 3, wb2 = wa == 2 ? 3 : wa + 4;
+                    read_window(nx1, h, wa); read_window(nx1, h, wb2);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int p = pp; p < pp + 2; ++p)
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {
+                            if (E3_W4_ABL & 32) continue;
+                            const float wv = Bv[p][ks * 2 + hf], tv = t[p / 6][p % 6][ks];
+                            if (ZERO && ks == 0) {
+                                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                                acc[p][hf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, tv, z, 0, 0, 0);
+                            } else
+                                acc[p][hf] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, tv, acc[p][hf], 0, 0, 0);
+                        }
+#pragma unroll
+                for (int p = pp; p < pp + 2; ++p) {
+                    if (E3_W4_ABL & 2) continue;
+                    Bv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_nx, b_voff + (p & 3) * 1024, (p & ~3) * 1024, 0));
+                }
+                // issue order inside the pair: MFMA, window read, MFMA, DMA piece, MFMA, window read, MFMAs, weight requests
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (pp < 12) { __builtin_amdgcn_sched_group_barrier(0x004, 8, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pp == 10 && c < 8) TSTAMP(4 + 5 * c);
+            }
+            stage_advance();
+            if (c < 8) TSTAMP(5 + 5 * c);
+            { float* tsw = cur; cur = nx1; nx1 = nx2; nx2 = tsw; }
+        };
+
+        TSTAMP(0);
+        chunk(std::true_type{}, 0);
+        for (int c = 1; c < NCH; ++c) chunk(std::false_type{}, c);
+
+        // ---- epilogue.  acc[ph*6+pw][half][i]: position (pd = wave, ph, pw), tile tl, channel n0 + 8 kk + 4 half + i.
+        // per-channel constants first: they arrive during the output transform
+        // (the lane index is taken afresh: lane constants of the epilogue kept across the main loop were spilled, and a scratch reload in here waits -- the
+        // memory counter retires in order -- for every request of the next units in flight)
+        int elane;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(elane));
+        const int etl = elane & 15, ekk = elane >> 4;
+        const int ettd = etl >> 3, etth = (etl >> 2) & 1, ettw = etl & 3;
+        const int etid = wave * 64 + elane;
+        float* const erun = scr + V_SCR + etid;
+        const int n0 = P_n0, d0 = P_d0, h0 = P_h0, w0 = P_w0;
+        const int nq = n0 + 8 * ekk;
+        // A^T m A over (pw, ph) in registers, one channel half at a time, one ph row at a time (`ex` is its own LDS region: the next brick's first
+        // chunk is already in the stage buffers).  W: F(4,3) rows  m0+m1+m2+m3+m4,  m1-m2+2m3-2m4,  m1+m2+4m3+4m4,  m1-m2+8m3-8m4+m5
+#pragma unroll
+        for (int hf = 0; hf < 2 && !(E3_W4_ABL & 128); ++hf) {
+            f32x4 q[2][4];
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const f32x4 a0 = acc[ph * 6 + 0][hf], a1 = acc[ph * 6 + 1][hf], a2 = acc[ph * 6 + 2][hf], a3 = acc[ph * 6 + 3][hf], a4 = acc[ph * 6 + 4][hf], a5 = acc[ph * 6 + 5][hf];
+                const f32x4 s12 = a1 + a2, d12 = a1 + m1 * a2, s34 = a3 + a4, d34 = a3 + m1 * a4;
+                f32x4 o[4];
+                o[0] = (a0 + s12) + s34;
+                o[1] = d12 + c2 * d34;
+                o[2] = s12 + c4 * s34;
+                o[3] = (d12 + c8 * d34) + a5;
+#pragma unroll
+                for (int ow = 0; ow < 4; ++ow) {
+                    if (ph == 0) q[0][ow] = o[ow];
+                    else if (ph == 1) { q[0][ow] += o[ow]; q[1][ow] = o[ow]; }
+                    else if (ph == 2) { q[0][ow] += o[ow]; q[1][ow] += m1 * o[ow]; }
+                    else q[1][ow] += m1 * o[ow];
+                }
+            }
+#pragma unroll
+            for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+                for (int ow = 0; ow < 4; ++ow)
+                    *reinterpret_cast<f32x4*>(ex + ((wave * 16 + (oh * 4 + ow) * 2 + hf) * 64 + elane) * 4) = q[oh][ow];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        TSTAMP(41);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        TSTAMP(42);
+        // wave w now owns output offsets oh = w >> 1, ow = 2 (w & 1) + {0, 1} of every tile and sums the pd axis: od = 0, 1
+        const int oh = wave >> 1, owb = 2 * (wave & 1);
+        f32x4 y[2][2][2];       // [od][owi][half]
+        {
+            f32x4 m[2][2][4], bias[2], es[2], eh[2];
+#pragma unroll
+            for (int owi = 0; owi < 2; ++owi)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int pd = 0; pd < 4; ++pd) m[owi][hf][pd] = *reinterpret_cast<const f32x4*>(ex + ((pd * 16 + (oh * 4 + owb + owi) * 2 + hf) * 64 + elane) * 4);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                bias[hf] = *reinterpret_cast<const f32x4*>(kst + kslot * 96 + 8 * ekk + 4 * hf);
+                if (AFF) {
+                    es[hf] = *reinterpret_cast<const f32x4*>(kst + kslot * 96 + 32 + 8 * ekk + 4 * hf);
+                    eh[hf] = *reinterpret_cast<const f32x4*>(kst + kslot * 96 + 64 + 8 * ekk + 4 * hf);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int owi = 0; owi < 2; ++owi)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    y[0][owi][hf] = m[owi][hf][0] + m[owi][hf][1] + m[owi][hf][2] + bias[hf];
+                    y[1][owi][hf] = m[owi][hf][1] + m1 * m[owi][hf][2] + m1 * m[owi][hf][3] + bias[hf];
+                    if (AFF) {
+#pragma unroll
+                        for (int od = 0; od < 2; ++od)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[od][owi][hf][e] = fmaxf(__builtin_fmaf(y[od][owi][hf][e], es[hf][e], eh[hf][e]), 0.f);
+                    }
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the accumulators and the exchanged sums are dead: the window of the next brick's first unit (in `cur` after the rotation; landed and published by
+        // the last chunk's barrier) is read under the stores and the statistics
+        if (!(E3_W4_ABL & 64)) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+#pragma unroll
+                for (int w = 0; w < 6; ++w) read_window(cur, h, w);
+        }
+        // voxel (d0 + 2 ettd + od, h0 + 2 etth + oh, w0 + 4 ettw + owb + owi), channels nq + 4 half .. + 3: 16-byte stores
+        const int gh = h0 + 2 * etth + oh, gw = w0 + 4 * ettw + owb, gd = d0 + 2 * ettd;
+        const bool okw[2] = {gh < H && gw < W, gh < H && gw + 1 < W};
+        const bool okd[2] = {gd < D, gd + 1 < D};
+        const int yl = KA()->y_ldc;
+        const size_t plane_y = (size_t)H * W * yl;
+        if (!HEAD) {
+            // The accumulator layout gives a elane 16 bytes of a voxel and puts the four lanes of a voxel 16 lanes apart: stored directly, every instruction is 64
+            // scattered 16-byte fragments (measured: the 8 stores of a brick took ~4 k cycles of issue).  The wave's 64 voxels x 32 channels are transposed
+            // through LDS instead -- in the 8 KB of the exchange buffer that only THIS wave has just read (its (oh, ow) entries of pd = 0 and 1; LDS executes
+            // a wave's accesses in order, no barrier) -- so that 8 consecutive lanes store one whole 128-byte voxel row.  Row v = (od * 2 + owi) * 16 + tile,
+            // 16-byte piece 2 ekk + half at position piece ^ (tile & 7) (conflict-free writes).
+            float* const tA = ex + (((oh * 4 + owb) * 2) * 64) * 4;
+#pragma unroll
+            for (int od = 0; od < 2; ++od)
+#pragma unroll
+                for (int owi = 0; owi < 2; ++owi)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+                        *reinterpret_cast<f32x4*>(tA + od * (16 * 64 * 4) + (owi * 16 + etl) * 32 + (((2 * ekk + hf) ^ (etl & 7)) * 4)) = y[od][owi][hf];
+            const size_t yrem = (size_t)(D - d0) * plane_y * 4;
+            const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(
+                KA()->y + ((size_t)P_nb * D + d0) * plane_y, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
+            // elane (r = elane >> 3, position elane & 7) stores piece (elane & 7) ^ r of the rows v = 8 j + r: tile 8 (j & 1) + r = (td j & 1, th r >> 2, tw r & 3),
+            // od = j >> 2, owi = (j >> 1) & 1
+            const int r = elane >> 3, pc = (elane & 7) ^ r;
+            const int sgh = h0 + 2 * (r >> 2) + oh, sgw = w0 + 4 * (r & 3) + owb;
+            const bool cok = n0 + 4 * pc < KA()->Ncols && sgh < H;
+            const unsigned s_voff = (unsigned)(((sgh * W + sgw) * yl + n0 + 4 * pc) * 4);
+            const unsigned sv[2] = {(cok && sgw < W) ? s_voff : OOB, (cok && sgw + 1 < W) ? s_voff : OOB};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (E3_W4_ABL & 4) continue;
+                const int od = j >> 2, owi = (j >> 1) & 1, std_ = 2 * (j & 1) + od;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tA + od * (16 * 64 * 4) + (owi * 16 + 8 * (j & 1) + r) * 32 + (elane & 7) * 4);
+                const bool dok = d0 + std_ < D;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), y_rs, dok ? sv[owi] : OOB, (int)((std_ * plane_y + owi * yl) * 4), 0);
+            }
+        }
+        TSTAMP(43);
+        if (HEAD) {
+            // conv_final_fwd_kernel's arithmetic on the registers: channel quad q of the voxel is summed as an fmaf chain from 0, the eight quad sums meet as
+            // ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7)) -- this elane holds quads 2 ekk (half 0) and 2 ekk + 1 (half 1), the lanes ^ 16, ^ 32 the others
+            const float* const hw = scr + V_SCR + V_POOLX;
+            const KArgs e = KA();
+            const int hc = e->head_cout;
+            float lg[2][2][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 wv0 = *reinterpret_cast<const f32x4*>(hw + c * 32 + 8 * ekk), wv1 = *reinterpret_cast<const f32x4*>(hw + c * 32 + 8 * ekk + 4);
+                const float hb = hw[128 + c];
+#pragma unroll
+                for (int od = 0; od < 2; ++od)
+#pragma unroll
+                    for (int owi = 0; owi < 2; ++owi) {
+                        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) { s0 = __builtin_fmaf(y[od][owi][0][e4], wv0[e4], s0); s1 = __builtin_fmaf(y[od][owi][1][e4], wv1[e4], s1); }
+                        float p = s0 + s1;                  // q(2 ekk) + q(2 ekk + 1)
+                        p = p + __shfl_xor(p, 16);          // (q0 + q1) + (q2 + q3)   resp.   (q4 + q5) + (q6 + q7)
+                        p = p + __shfl_xor(p, 32);
+                        lg[od][owi][c] = p + hb;
+                    }
+            }
+            // elane ekk finishes voxel (od, owi) = (ekk >> 1, ekk & 1)
+            float l4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) l4[c] = ekk == 0 ? lg[0][0][c] : (ekk == 1 ? lg[0][1][c] : (ekk == 2 ? lg[1][0][c] : lg[1][1][c]));
+            if (e->head_softmax) {
+                float m = l4[0];
+#pragma unroll
+                for (int c = 1; c < 4; ++c) m = c < hc ? fmaxf(m, l4[c]) : m;
+                float sm = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { l4[c] = c < hc ? __expf(l4[c] - m) : 0.f; sm += l4[c]; }
+                const float inv = 1.f / sm;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) l4[c] *= inv;
+            }
+            const int vd = gd + (ekk >> 1), vw = gw + (ekk & 1);
+            const bool inb = gh < H && vw < W && vd < D && vd >= e->head_lo[0] && vd < e->head_hi[0] && gh >= e->head_lo[1] && gh < e->head_hi[1] && vw >= e->head_lo[2] && vw < e->head_hi[2];
+            if (inb) {
+                float* const yo = e->head_y + (long long)P_nb * e->head_ys[0] + (long long)(vd - e->head_lo[0]) * e->head_ys[2] + (long long)(gh - e->head_lo[1]) * e->head_ys[3] + (vw - e->head_lo[2]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < hc) yo[(long long)c * e->head_ys[1]] = l4[c];
+            }
+        }
+        if (POOL) {
+            // a 2x2x4 tile = two pooling windows (ow 0, 1 | ow 2, 3): max over od and the elane's two ow in registers, over oh = the wave pairs (w, w ^ 2) through
+            // LDS (voxels outside the tensor do not take part: ceil_mode; NaN propagates as in nn.MaxPool3d); wave w then stores channel half oh of window w & 1
+            float* const px = scr + V_SCR;
+            auto nmax = [](float a_, float b_) { return (b_ > a_ || b_ != b_) ? b_ : a_; };
+            constexpr float NEG = -3.4028235e38f;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x4 pm;
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    float v = NEG;
+#pragma unroll
+                    for (int od = 0; od < 2; ++od)
+#pragma unroll
+                        for (int owi = 0; owi < 2; ++owi) v = nmax(v, (okd[od] && okw[owi]) ? y[od][owi][hf][e4] : NEG);
+                    pm[e4] = v;
+                }
+                *reinterpret_cast<f32x4*>(px + ((wave * 64 + elane) * 8) + 4 * hf) = pm;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // wave w: window (w & 1), channel half (w >> 1): max of the partials of waves (w & 1) and (w & 1) + 2
+            const int win = wave & 1, ch = wave >> 1;
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(px + ((win * 64 + elane) * 8) + 4 * ch);
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(px + (((win + 2) * 64 + elane) * 8) + 4 * ch);
+            f32x4 best;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) best[e4] = nmax(p0[e4], p1[e4]);
+            const KArgs e = KA();
+            const int eN = e->Ncols;
+            const int Dp = (D + 1) >> 1, Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+            const int pd_ = (d0 >> 1) + ettd, ph_ = (h0 >> 1) + etth, pw_ = (w0 >> 1) + 2 * ettw + win;
+            const bool pok = pd_ < Dp && ph_ < Hp && pw_ < Wp && nq + 4 * ch < eN;
+            if (pok) *reinterpret_cast<f32x4*>(e->pool_out + ((((size_t)P_nb * Dp + pd_) * Hp + ph_) * Wp + pw_) * eN + nq + 4 * ch) = best;
+        }
+        if (do_stats) {
+            // running record of this elane's 8 channels: Chan merge of the brick's (up to) four values per channel, approximate reciprocal
+            // (its error is far below the rounding of the sums)
+            const float rn = erun[0];
+            float cb = 0.f;
+#pragma unroll
+            for (int od = 0; od < 2; ++od)
+#pragma unroll
+                for (int owi = 0; owi < 2; ++owi) cb += (okd[od] && okw[owi]) ? 1.f : 0.f;
+            const float nn = rn + cb;
+            const float rf = cb * __builtin_amdgcn_rcpf(fmaxf(nn, 1.f));
+            const float rc = cb == 4.f ? 0.25f : (cb == 2.f ? 0.5f : (cb == 1.f ? 1.f : (cb == 3.f ? (1.f / 3.f) : 0.f)));
+            const float rnf = rn * rf;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ch = hf * 4 + e;
+                    float v[4];
+#pragma unroll
+                    for (int od = 0; od < 2; ++od)
+#pragma unroll
+                        for (int owi = 0; owi < 2; ++owi) v[od * 2 + owi] = y[od][owi][hf][e];
+                    float s = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s += (okd[i >> 1] && okw[i & 1]) ? v[i] : 0.f;
+                    const float bm = s * rc;
+                    float b2 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float dv = v[i] - bm; b2 += (okd[i >> 1] && okw[i & 1]) ? dv * dv : 0.f; }
+                    const float rmean = erun[(1 + ch) * 256], rm2 = erun[(9 + ch) * 256];
+                    const float dl = bm - rmean;
+                    erun[(1 + ch) * 256] = rmean + dl * rf;
+                    erun[(9 + ch) * 256] = rm2 + b2 + dl * dl * rnf;
+                }
+            erun[0] = nn;
+            if (!wgstats || !has_next) {       // (uniform) merge the lanes of a channel (16 tiles, then the 4 waves) in a fixed order, one record
+                float fn = erun[0], fm[8], fs[8];
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) { fm[ch] = erun[(1 + ch) * 256]; fs[ch] = erun[(9 + ch) * 256]; }
+#pragma unroll
+                for (int sft = 1; sft < 16; sft <<= 1) {
+                    const float n2 = __shfl_xor(fn, sft);
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) {
+                        float na = fn;
+                        welford_merge(na, fm[ch], fs[ch], n2, __shfl_xor(fm[ch], sft), __shfl_xor(fs[ch], sft));
+                    }
+                    fn += n2;
+                }
+                if (etl == 0) {
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) {
+                        float* sc_ = scr + (wave * 32 + 8 * ekk + ch) * 3;
+                        sc_[0] = fn; sc_[1] = fm[ch]; sc_[2] = fs[ch];
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (etid < 32 && n0 + etid < KA()->Ncols) {
+                    float c0 = 0.f, me = 0.f, mm = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float* sc_ = scr + (w * 32 + etid) * 3;
+                        welford_merge(c0, me, mm, sc_[0], sc_[1], sc_[2]);
+                    }
+                    const size_t row = wgstats ? (size_t)((blockIdx.x & 7u) * ((gridDim.x >> 3) / (unsigned)KA()->ntiles) + (blockIdx.x >> 3) / (unsigned)KA()->ntiles)
+                                               : (size_t)P_row;
+                    float* o = KA()->stats + (row * KA()->Cout + n0 + etid) * 3;
+                    o[0] = c0; o[1] = me; o[2] = mm;
+                }
+                if (!wgstats) {
+#pragma unroll
+                    for (int k = 0; k < 17; ++k) erun[k * 256] = 0.f;
+                }
+            }
+        }
+        TSTAMP(44);
+#ifdef E3_W4_TIMING
+        ++tbrick;
+#endif
+        if (!has_next) break;
+        P_d0 = N_d0; P_h0 = N_h0; P_w0 = N_w0; P_nb = N_nb; P_n0 = N_n0; P_row = N_row; P_wbase = N_wbase;
+        load_consts(P_n0);
+        L += Lstep;
+    }
+}
+
+}  // namespace
+
+// ---- host side
+int wino4_bricks(int N, int D, int H, int W) { return N * cdiv(D, 4) * cdiv(H, 4) * cdiv(W, 16); }
+
+// one column tile per workgroup and every column tile covered by the workgroups of a row: XCD ranges that start at multiples of ntiles and a
+// stride of 32 logical bricks that is one too
+static bool wino4_wgstats(size_t nblk, int ntiles, unsigned grid) {
+    return grid == 256u && nblk > 256 && nblk % 8 == 0 && (nblk / 8) % (size_t)ntiles == 0 && 32 % ntiles == 0;
+}
+
+int wino4_stats_parts(int N, int D, int H, int W, int ncols) {
+    const int bricks = wino4_bricks(N, D, H, W), ntiles = (ncols + 31) / 32;
+    const size_t nblk = (size_t)bricks * ntiles;
+    return wino4_wgstats(nblk, ntiles, nblk >= 256 ? 256u : (unsigned)nblk) ? 256 / ntiles : bricks;
+}
+
+// Which decomposition a Winograd 3x3x3 launch takes: 0 = F(2x2x2) tiles (conv_wino.hip), 1 = F(2x2x2) in 16-tile bricks (conv_wino16.hip, CF_BNRED launches only), 2 = F(2x2x4) tiles (this file).  THE predicate: the weight
+// packers (different layouts), the statistics sizing and the launcher all ask it.  Decided on the grid of ONE sample (like conv_use_wino) so that the
+// arithmetic does not depend on the batch size.  The caller allows the larger tiles per launch with CF_WINO4 (eval-mode forwards, data gradients: see the
+// head of this file); a split-K launch, the timing flag and views that rule out 16-byte accesses keep F(2x2x2).
+int conv_wino_layout(int flags, int D, int H, int W, int K, int ncols, int splitk) {
+    static const int mode = getenv("E3_WINO4") ? atoi(getenv("E3_WINO4")) : 1;      // 0: never (A/B switch), 1: where the caller allows it, 2: every eligible launch (tests)
+    static const size_t minblk = getenv("E3_WINO4_MIN") ? (size_t)atol(getenv("E3_WINO4_MIN")) : 512;
+    if (splitk > 1 || (flags & 1024) || (ncols & 3) || (K & 7)) return 0;
+    if (flags & CF_BNRED) return 1;       // (the caller checked conv_wino16_bnred_parts(): only conv3_wino16_kernel has the fused reduction)
+    if (mode <= 0 || (mode == 1 && !(flags & CF_WINO4))) return 0;
+    const size_t nblk1 = (size_t)wino4_bricks(1, D, H, W) * ((ncols + 31) / 32);
+    return nblk1 >= minblk ? 2 : 0;
+}
+
+int launch_conv3_wino4(ConvArgs a, hipStream_t s) {
+    a.tilesD = cdiv(a.D, 4); a.tilesH = cdiv(a.H, 4); a.tilesW = cdiv(a.W, 16);
+    a.o_td = a.o_th = a.o_tw = 0;
+    a.org_d = a.org_h = a.org_w = 0;
+    if (a.box_hi[0] > 0) {      // needed region: the bricks that meet the box
+        E3_REQUIRE(!a.stats, E3_ERR_INVALID, "conv with a needed region: no statistics");
+        const int dims[3] = {a.D, a.H, a.W}, edge[3] = {4, 4, 16}, tile[3] = {2, 2, 4};
+        int o[3], n[3];
+        for (int i = 0; i < 3; ++i) {
+            const int lo = a.box_lo[i] < 0 ? 0 : a.box_lo[i], hi = a.box_hi[i] > dims[i] ? dims[i] : a.box_hi[i];
+            E3_REQUIRE(hi > lo, E3_ERR_INVALID, "conv with a needed region: empty box");
+            // bricks start at the box's low corner rounded down to a TILE origin (2, 2, 4): every voxel keeps the Winograd tile it has in the
+            // whole-tensor launch -- same arithmetic, bit-identical values
+            o[i] = lo / tile[i] * tile[i];
+            n[i] = cdiv(hi - o[i], edge[i]);
+        }
+        a.org_d = o[0]; a.org_h = o[1]; a.org_w = o[2];
+        a.tilesD = n[0]; a.tilesH = n[1]; a.tilesW = n[2];
+    }
+    a.NPad = (a.Ncols + 31) / 32 * 32;
+    a.ntiles = a.NPad / 32;
+    if (a.stats) a.cu_reserve = 0;      // (the statistic records are sized for the full grid; only data gradients run beside a collective)
+    const size_t nblk = (size_t)a.N * a.tilesD * a.tilesH * a.tilesW * a.ntiles;
+    E3_REQUIRE(nblk > 0 && nblk < (1u << 31), E3_ERR_INVALID, "conv grid out of range");
+    E3_REQUIRE((size_t)6 * a.H * a.W * (size_t)(a.x_ldc > a.y_ldc ? a.x_ldc : a.y_ldc) * 4 < 0x7fffffffu, E3_ERR_UNSUPPORTED,
+               "six d-planes of the conv input/output view exceed 2^31 bytes (32-bit buffer offsets)");
+    E3_REQUIRE((a.y_ldc & 3) == 0 && (a.x_ldc & 3) == 0 && ((uintptr_t)a.y & 15) == 0 && ((uintptr_t)a.x & 15) == 0 && (a.Ncols & 3) == 0, E3_ERR_INVALID,
+               "Winograd conv (F(2x2x4) tiles): views must be 16-byte aligned with channel counts that are multiples of 4");
+    E3_REQUIRE(!(a.epi_scale && a.stats), E3_ERR_INVALID, "Winograd conv: statistics and the folded epilogue exclude each other");
+    E3_REQUIRE(a.splitk <= 1 && !a.pro_scale, E3_ERR_INVALID, "Winograd conv (F(2x2x4) tiles): no split-K, no fused prologue");
+    constexpr int lds = V_LDS_FLOATS * 4;
+    constexpr int lds_x = lds;
+    static bool attr = false;
+    if (!attr) {
+        E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino4_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_x));
+        E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino4_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_x));
+        attr = true;
+    }
+    // one workgroup per CU (cu_reserve > 0, a multiple of 8: that many CUs are left to the resident workgroups of a collective on a side stream)
+    const unsigned full = 256u - (unsigned)((a.cu_reserve < 0 ? 0 : (a.cu_reserve > 128 ? 128 : a.cu_reserve)) & ~7);
+    const unsigned grid = nblk >= full ? full : (unsigned)nblk;
+    const int wgstats = (a.stats && wino4_wgstats(nblk, a.ntiles, grid)) ? 1 : 0;
+    static const bool no_head = getenv("E3_WINO_NO_HEAD") != nullptr, no_pool = getenv("E3_WINO_NO_POOL") != nullptr;      // A/B switches (shared with conv_wino.hip)
+    if (a.epi_scale && a.head_w && a.head_done && !no_head && a.Ncols == 32 && a.head_cout >= 1 && a.head_cout <= 4 && !a.pool_out) {      // + the 1x1x1 head behind it
+        hipLaunchKernelGGL((conv3_wino4_kernel<true, false, true>), dim3(grid), dim3(256), lds_x, s, a, (unsigned)nblk, 0);
+        *a.head_done = 1;
+    } else if (a.epi_scale && a.pool_out && a.pool_done && !no_pool && a.box_hi[0] <= 0 && (a.Ncols & 31) == 0) {      // + the max-pool behind it
+        hipLaunchKernelGGL((conv3_wino4_kernel<true, true>), dim3(grid), dim3(256), lds_x, s, a, (unsigned)nblk, 0);
+        *a.pool_done = 1;
+    } else if (a.epi_scale) hipLaunchKernelGGL(conv3_wino4_kernel<true>, dim3(grid), dim3(256), lds, s, a, (unsigned)nblk, wgstats);
+    else hipLaunchKernelGGL(conv3_wino4_kernel<false>, dim3(grid), dim3(256), lds, s, a, (unsigned)nblk, wgstats);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}

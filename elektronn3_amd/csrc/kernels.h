@@ -17,6 +17,8 @@ enum ConvFlags {
     CF_NO_PERSIST = 16, // one brick per workgroup even on large grids: a collective may hold CUs while this kernel runs, and a static
                         // 256-workgroup kernel that does not get all 256 CUs at once needs a full second round
     CF_BNRED = 64,      // data-gradient launch that carries the REDUCE pass of the BatchNorm backward in front (ConvArgs::br_*): takes conv3_wino16_kernel
+    CF_WINO4 = 128,     // the launch may take the F(2x2x4) Winograd tiles of conv_wino4.hip (eval-mode forwards with the folded epilogue, data gradients:
+                        // the caller's statement that no ReLU / arg-max decision of a training step hangs on this launch's rounding)
     CF_SPLITK_OK = 32,  // the caller can run the conv split over its input channels (conv_wino_splitk): count the splits when deciding
                         // whether the Winograd grid is large enough
 };
@@ -83,11 +85,13 @@ int launch_conv3_v3(ConvKind kind, ConvArgs a, int nt, hipStream_t s);   // conv
 bool conv_use_wino(ConvKind kind, int flags, int N, int D, int H, int W, int K, int ncols);
 constexpr int WINO_PACK_MAX_JOBS = 40;
 struct WinoPackJob { const float* w; float* out; int Cout, Cin, dgrad; int k0 = 0, kn = 0; int layout = 0; };   // kn > 0: only the GEMM-K channels [k0, k0 + kn); layout: conv_wino_layout() of the launch that will read them
-// Winograd decomposition of a 3x3x3 launch (conv_wino16.hip): 0 = 32-tile bricks (conv_wino.hip), 1 = 16-tile bricks with two workgroups per CU.
+// Winograd decomposition of a 3x3x3 launch: 0 = F(2x2x2) tiles in 32-tile bricks (conv_wino.hip), 1 = F(2x2x2) in 16-tile bricks (conv_wino16.hip), 2 = F(2x2x4) tiles (conv_wino4.hip).
 // THE predicate for the packed-weight layout, the statistics sizing and the launcher (K = GEMM-K channels, ncols = GEMM columns; per-sample grid).
 int conv_wino_layout(int flags, int D, int H, int W, int K, int ncols, int splitk);
 int wino16_stats_parts(int N, int D, int H, int W, int ncols);
 int launch_conv3_wino16(ConvArgs a, hipStream_t s);
+int wino4_stats_parts(int N, int D, int H, int W, int ncols);
+int launch_conv3_wino4(ConvArgs a, hipStream_t s);
 // split-K factor (1, 2 or 4) of a Winograd 3x3x3 conv whose bricks cannot fill the chip (decided per sample, like conv_use_wino)
 int conv_wino_splitk(int D, int H, int W, int K, int ncols);   // (0 if the conv does not use the Winograd kernel even with the splits)
 // dst[u][c] (ldc) = sum_s src[s * src_stride + u * C + c] (+ bias[c]); stats (optional): crop_stats_parts(units, C) records per channel

@@ -697,13 +697,16 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
         const int S = conv_wino_splitk(ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cin, u.cout);
         return S > 1 ? S : 1;
     };
+    // eval-mode forwards may take the F(2x2x4) Winograd tiles (conv_wino4.hip); a training forward -- whose ReLU / arg-max decisions the gradients
+    // hang on -- keeps F(2x2x2) (profiles/r05_f224_emulation.md)
+    const int w4f = training ? 0 : CF_WINO4;
     {   // Winograd weight transforms of every layer that uses them, in one launch
         std::vector<WinoPackJob> jobs;
         for (size_t k = 0; k < plan->units.size(); ++k) {
             if (!B.wpk_f[k]) continue;
             const ConvUnit& u = plan->units[k];
             const int S = fwd_split(k);
-            if (S == 1) { jobs.push_back({P(u.p_w), B.wpk_f[k], u.cout, u.cin, 0, 0, 0, conv_wino_layout(0, ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cin, u.cout, 1)}); continue; }
+            if (S == 1) { jobs.push_back({P(u.p_w), B.wpk_f[k], u.cout, u.cin, 0, 0, 0, conv_wino_layout(w4f, ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cin, u.cout, 1)}); continue; }
             for (int sp = 0; sp < S; ++sp)     // one packed weight set per share of the input channels
                 jobs.push_back({P(u.p_w), B.wpk_f[k] + sp * conv_packed_floats(CONV_K3, u.cin / S, u.cout), u.cout, u.cin, 0, sp * (u.cin / S), u.cin / S});
         }
@@ -819,14 +822,14 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             const int taps = u.planar ? 9 : 27, NPad = pad_cols(u.cout);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             (void)taps;
-            if (!B.wpk_f[k]) RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, ci.D, ci.H, ci.W, 0, s));
+            if (!B.wpk_f[k]) RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, ci.D, ci.H, ci.W, w4f, s));
             ConvArgs a{};
             a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpk_f[k] ? B.wpk_f[k] : B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
             a.y = vcrop ? B.rtmp : dst; a.y_ldc = dst_ldc; a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.sd = 2;
             a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
-            a.stats = (bn_train && !vcrop) ? stat_buf : nullptr; a.G = 1; a.flags = 0;
+            a.stats = (bn_train && !vcrop) ? stat_buf : nullptr; a.G = 1; a.flags = w4f;
             if (residual) { a.y = B.res2; a.y_ldc = u.cout; a.bias = nullptr; a.stats = nullptr; }      // pure accumulations; bias + shortcut + statistics below
-            parts = conv_stats_parts(kind, 0, N, ci.D, ci.H, ci.W, 2, u.cin, u.cout);
+            parts = conv_stats_parts(kind, w4f, N, ci.D, ci.H, ci.W, 2, u.cin, u.cout);
             const int S = (kind == CONV_K3) ? fwd_split(k) : 1;
             // inference: the ceil-mode max-pool behind an encoder block rides in the conv's epilogue where the kernel can take it (a Winograd tile is a window)
             if (pool_after && !training && !two_pass && kd == 2 && kind == CONV_K3 && es && !vcrop && !residual) { a.pool_out = B.pooled[u.level]; a.pool_done = &pool_fused; }
@@ -1107,13 +1110,16 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
             if (parts > 0 && parts <= bn_bwd_parts(o0.vox, u0.cout)) bnred_parts[(size_t)k1] = parts;
         }
     }
+    // a data gradient takes no ReLU / arg-max decision: F(2x2x4) Winograd tiles (conv_wino4.hip) -- except in the overlapped data-parallel mode without a CU
+    // reserve, whose launches behind the bucket event must be one-brick kernels (CF_NO_PERSIST)
+    const int w4d = (bucket_event != nullptr && ((flags >> 8) & 0x1fu) == 0) ? 0 : CF_WINO4;
     {   // dgrad form of the Winograd weights of every layer, in one launch
         std::vector<WinoPackJob> jobs;
         for (int k = 0; k < nunits; ++k) {
             if (!(B.wpk_d[k] && (k > 0 || dx))) continue;
             const ConvUnit& u = plan->units[k];
             const int S = bwd_split(k);
-            if (S == 1) { jobs.push_back({P(u.p_w), B.wpk_d[k], u.cout, u.cin, 1, 0, 0, conv_wino_layout(bnred_parts[(size_t)k] ? CF_BNRED : 0, ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cout, u.cin, 1)}); continue; }
+            if (S == 1) { jobs.push_back({P(u.p_w), B.wpk_d[k], u.cout, u.cin, 1, 0, 0, conv_wino_layout(bnred_parts[(size_t)k] ? CF_BNRED : w4d, ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cout, u.cin, 1)}); continue; }
             for (int sp = 0; sp < S; ++sp)     // dgrad: the GEMM-K channels are the conv's OUTPUT channels
                 jobs.push_back({P(u.p_w), B.wpk_d[k] + sp * conv_packed_floats(CONV_K3, u.cout / S, u.cin), u.cout, u.cin, 1, sp * (u.cout / S), u.cout / S});
         }
@@ -1383,7 +1389,7 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
             const int taps = u.planar ? 9 : 27, NPad = pad_cols(u.cin);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             (void)taps;
-            if (!B.wpk_d[k]) RUN(launch_pack_conv_auto(kind, 1, P(u.p_w), B.wpack, u.cout, u.cin, N, ci.D, ci.H, ci.W, 0, s));
+            if (!B.wpk_d[k]) RUN(launch_pack_conv_auto(kind, 1, P(u.p_w), B.wpack, u.cout, u.cin, N, ci.D, ci.H, ci.W, w4d, s));
             const bool to_cat = u.to_cat;   // UpConv.conv1: gradient of the concat buffer
             float* out; int out_ldc = u.cin;
             if (k == 0) out = (cfg.in_channels > 1) ? B.g1[0] : dx;   // g1[0] is free by now (C0 >= in_channels)
@@ -1396,7 +1402,7 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
             // the gradient all-reduce may be running on some CUs: with a reserve the persistent kernel leaves them alone, without one the
             // one-brick-per-workgroup kernel degrades by the fraction of CUs taken instead of needing a second round
             a.cu_reserve = reserve();
-            a.flags = (bucket_event != nullptr && event_done && a.cu_reserve == 0) ? CF_NO_PERSIST : 0;
+            a.flags = ((bucket_event != nullptr && event_done && a.cu_reserve == 0) ? CF_NO_PERSIST : 0) | w4d;
             if (bnred_parts[(size_t)k]) {      // this launch also takes the REDUCE sums of unit k - 1's BatchNorm backward
                 const UnitBufs& b0 = B.ub[k - 1];
                 a.flags |= CF_BNRED;
