@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libe3unet.so')
 OBJDIR = os.path.join(HERE, 'build')
-SOURCES = ['conv_mfma.hip', 'conv_v3.hip', 'conv_wino.hip', 'conv_wino16.hip', 'conv_wino4.hip', 'conv_wino2d.hip', 'upconv_gemm.hip', 'wgrad_mfma.hip', 'wgrad_wino.hip', 'wgrad_wino2d.hip', 'conv_small.hip', 'elementwise.hip', 'loss.hip', 'optim.hip', 'api.cpp', 'unet_plan.cpp',
+SOURCES = ['conv_mfma.hip', 'conv_v3.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_wino2d.hip', 'upconv_gemm.hip', 'wgrad_mfma.hip', 'wgrad_wino.hip', 'wgrad_wino2d.hip', 'conv_small.hip', 'elementwise.hip', 'loss.hip', 'optim.hip', 'api.cpp', 'unet_plan.cpp',
            'attention.hip', 'bf16_conv.hip', 'bf16_wgrad.hip', 'bf16_upconv.hip', 'bf16_ew.hip', 'bf16_first.hip', 'api_bf16.cpp', 'unet_bf16.cpp']
 # the 16-bit path is compiled a second time for IEEE half (-DE3_F16, external symbols renamed by f16_names.h; see csrc/bf16.h)
 F16_SOURCES = ['bf16_conv.hip', 'bf16_wgrad.hip', 'bf16_upconv.hip', 'bf16_ew.hip', 'bf16_first.hip', 'api_bf16.cpp', 'unet_bf16.cpp']

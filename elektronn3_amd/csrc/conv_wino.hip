@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
 //   dgrad == 0:  g[tap][n = co][k = ci] = w[co][ci][tap]           (w is (Cout, Cin, 27))
 //   dgrad == 1:  g[tap][n = ci][k = co] = w[co][ci][26 - tap]      (rows/cols swapped, taps flipped)
 // K = number of GEMM-K channels (multiple of 8), Ncols = real columns, NPad = padded to 32.
-// layout 1 (conv_wino16.hip): the 256 floats of a (column tile, chunk, position) are [lane 64][ks 2][half 2] of v_mfma_f32_16x16x4_f32's A operand:
+// layout 2 (conv_wino4.hip; 96 positions per chunk): the 256 floats of a (column tile, chunk, position) are [lane 64][ks 2][half 2] of v_mfma_f32_16x16x4_f32's A operand:
 //   lane = kk * 16 + m  ->  k = chunk * 8 + 2 kk + ks,  n = ntile * 32 + 8 (m >> 2) + 4 half + (m & 3)
 __device__ __forceinline__ void wino_pack_item(const float* __restrict__ w, float* __restrict__ out, int Cin, int dgrad, int K, int Ncols, size_t i, int layout = 0) {
     const int NCH = K >> 3;
@@ -1203,7 +1203,6 @@ static bool wino_wgstats(size_t nblk, int ntiles, unsigned pgrid = 256u) {
 }
 int wino_stats_parts(int N, int D, int H, int W, int Cin, int ncols, int flags) {
     const int lay = conv_wino_layout(flags, D, H, W, Cin, ncols, 1);
-    if (lay == 1) return wino16_stats_parts(N, D, H, W, ncols);
     if (lay == 2) return wino4_stats_parts(N, D, H, W, ncols);
     const int bricks = wino_bricks(N, D, H, W), ntiles = (ncols + 31) / 32;
     const size_t nblk = (size_t)bricks * ntiles;
@@ -1212,7 +1211,6 @@ int wino_stats_parts(int N, int D, int H, int W, int Cin, int ncols, int flags) 
 
 int launch_conv3_wino(ConvArgs a, hipStream_t s) {
     const int lay = conv_wino_layout(a.flags, a.D, a.H, a.W, a.Cin, a.Ncols, a.splitk);
-    if (lay == 1) return launch_conv3_wino16(a, s);
     if (lay == 2) return launch_conv3_wino4(a, s);
     a.tilesD = cdiv(a.D, 4); a.tilesH = cdiv(a.H, 4); a.tilesW = cdiv(a.W, 16);
     a.o_td = a.o_th = a.o_tw = 0;

@@ -52,8 +52,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_v;
 
 // POOL (AFF, inference): the 2x2x2 ceil-mode max-pool of the output in the epilogue (ConvArgs::pool_out)
 // HEAD (AFF, inference, 32 output channels): the 1x1x1 head (+ softmax) on the activations in registers instead of storing them (ConvArgs::head_*)
+struct W4PArgs { int s_nt, s_tw, s_th, s_td, s_nb; };      // digits of the step between a workgroup's bricks (gridDim / 8 logical bricks) in the mixed radix (column tile, tw, th, td, sample)
+
 template <bool AFF, bool POOL = false, bool HEAD = false>
-__global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, const unsigned nblk, const int wgstats) {
+__global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, const unsigned nblk, const int wgstats, const W4PArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -147,50 +149,46 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
         L = base + (blockIdx.x >> 3); Lend = base + q + (xcd < r ? 1u : 0u); Lstep = gridDim.x >> 3;
     }
-    auto divmod = [](unsigned& x, int d) {
-        int r;
-        if ((d & (d - 1)) == 0) { r = (int)(x & (unsigned)(d - 1)); x >>= __builtin_ctz((unsigned)d); }
-        else { r = (int)(x % (unsigned)d); x /= (unsigned)d; }
-        return r;
-    };
     auto range_mask = [](int lo, int n, int size) {      // bit z set: lo + z in [0, size), z in [0, n)
         const int first = lo < 0 ? -lo : 0, last = size - lo < n ? size - lo : n;
         return last > first ? ((1u << last) - 1u) & ~((1u << first) - 1u) : 0u;
     };
-    // a brick: coordinates, halo origin at voxel (d0 - 1, h0 - 1, w0 - 1) (possibly in front of the tensor: only valid lanes form
-    // addresses from it), validity mask (6 d bits | 6 h bits | 18 w bits), the wave's transformed weights
-    //   U[ntile][chunk][pos 96][lane 64][ks 2][half 2]; wave = pd owns positions 24 pd .. 24 pd + 23
-    // (plain scalars, no struct: selecting between two structs' fields made hipcc keep them in scratch memory)
-#define E3_BRICK_VARS(X) int X##d0, X##h0, X##w0, X##nb, X##n0, X##row; const float* X##wbase
-#define E3_DECODE(X, Lval) do {                                                                                                        \
-        unsigned Lq_ = (Lval);                                                                                                         \
-        const KArgs k_ = KA();                                                                                                         \
-        const int ntile_ = divmod(Lq_, k_->ntiles);                                                                                      \
-        const int tw_ = divmod(Lq_, k_->tilesW);                                                                                         \
-        const int th_ = divmod(Lq_, k_->tilesH);                                                                                         \
-        const int td_ = divmod(Lq_, k_->tilesD);                                                                                         \
-        X##nb = (int)Lq_;                                                                                                              \
-        X##d0 = td_ * 4 + k_->org_d; X##h0 = th_ * 4 + k_->org_h; X##w0 = tw_ * 16 + k_->org_w;   /* (org_*: voxel origin of the needed region's first brick) */ \
-        X##n0 = ntile_ * 32;                                                                                                           \
-        X##row = ((X##nb * k_->tilesD + td_) * k_->tilesH + th_) * k_->tilesW + tw_;                                                         \
-        X##wbase = k_->wt + ((size_t)ntile_ * NCH * 96 + wave * 24) * 256;                                                               \
-    } while (0)
-    // the STAGING cursor runs two units (8-channel chunks) ahead of the computation, across bricks: S_L = its brick, S_c = its chunk,
-    // S_xorg / S_mask = halo origin and validity mask of that brick (a brick beyond the end of the workgroup's range stages zeros)
-    unsigned S_L = L, S_mask; int S_c = 0; const float* S_xorg;
-#define E3_DECODE_STAGE() do {                                                                                                         \
-        unsigned Lq_ = S_L;                                                                                                            \
-        const KArgs k_ = KA();                                                                                                         \
-        (void)divmod(Lq_, k_->ntiles);                                                                                                   \
-        const int tw_ = divmod(Lq_, k_->tilesW);                                                                                         \
-        const int th_ = divmod(Lq_, k_->tilesH);                                                                                         \
-        const int td_ = divmod(Lq_, k_->tilesD);                                                                                         \
-        const int sd0_ = td_ * 4 + k_->org_d, sh0_ = th_ * 4 + k_->org_h, sw0_ = tw_ * 16 + k_->org_w;                                  \
-        S_xorg = k_->x + (((long long)(int)Lq_ * D + (sd0_ - 1)) * ((long long)H * W * xl) + ((long long)(sh0_ - 1) * W + (sw0_ - 1)) * xl); \
-        const unsigned m_ = range_mask(sd0_ - 1, 6, D) | (range_mask(sh0_ - 1, 6, H) << 6) | (range_mask(sw0_ - 1, 18, W) << 12);         \
-        S_mask = S_L < Lend ? m_ : 0u;                                                                                                 \
-    } while (0)
-    auto stage_advance = [&]() { if (++S_c == NCH) { S_c = 0; S_L += Lstep; E3_DECODE_STAGE(); } };
+    // ---- brick cursors: mixed-radix digits (column tile, tw, th, td, sample) of a logical brick index, advanced by the workgroup's step with carries --
+    // no division and no kernel-argument reload between bricks (the divisions of a per-brick decode cost ~1 k cycles outside the MFMA shadow).
+    // P = the brick being computed, S = the brick of the staging cursor, which runs two units (8-channel chunks) ahead: S_c = its chunk.
+    struct Cur { int nt, tw, th, td, nb; unsigned L; };
+    const int tilesD = a.tilesD, tilesH = a.tilesH, tilesW = a.tilesW, ntiles = a.ntiles;
+    auto advance = [&](Cur& c) {
+        int v = c.nt + pa.s_nt; int cy = v >= ntiles ? 1 : 0; c.nt = v - (cy ? ntiles : 0);
+        v = c.tw + pa.s_tw + cy; cy = v >= tilesW ? 1 : 0; c.tw = v - (cy ? tilesW : 0);
+        v = c.th + pa.s_th + cy; cy = v >= tilesH ? 1 : 0; c.th = v - (cy ? tilesH : 0);
+        v = c.td + pa.s_td + cy; cy = v >= tilesD ? 1 : 0; c.td = v - (cy ? tilesD : 0);
+        c.nb += pa.s_nb + cy;
+        c.L += Lstep;
+    };
+    Cur P;
+    {
+        unsigned Lq = L;
+        P.L = L;
+        P.nt = (int)(Lq % (unsigned)ntiles); Lq /= (unsigned)ntiles;
+        P.tw = (int)(Lq % (unsigned)tilesW); Lq /= (unsigned)tilesW;
+        P.th = (int)(Lq % (unsigned)tilesH); Lq /= (unsigned)tilesH;
+        P.td = (int)(Lq % (unsigned)tilesD); P.nb = (int)(Lq / (unsigned)tilesD);
+    }
+    Cur S = P;
+    int S_c = 0;
+    // halo origin (voxel (d0 - 1, h0 - 1, w0 - 1) of the brick, possibly in front of the tensor: only valid lanes form addresses from it) and validity
+    // mask (6 d bits | 6 h bits | 18 w bits) of the staging cursor's brick; a brick beyond the end of the workgroup's range stages zeros
+    const float* S_xorg; unsigned S_mask;
+    auto stage_brick = [&]() {
+        const int sd0 = S.td * 4 + a.org_d, sh0 = S.th * 4 + a.org_h, sw0 = S.tw * 16 + a.org_w;      // (org_*: voxel origin of the needed region's first brick)
+        S_xorg = a.x + (((long long)S.nb * D + (sd0 - 1)) * ((long long)H * W * xl) + ((long long)(sh0 - 1) * W + (sw0 - 1)) * xl);
+        const unsigned m_ = range_mask(sd0 - 1, 6, D) | (range_mask(sh0 - 1, 6, H) << 6) | (range_mask(sw0 - 1, 18, W) << 12);
+        S_mask = S.L < Lend ? m_ : 0u;
+    };
+    auto stage_advance = [&]() { const bool wrap = S_c + 1 == NCH; S_c = wrap ? 0 : S_c + 1; if (wrap) { advance(S); stage_brick(); } };
+    // the wave's transformed weights  U[ntile][chunk][pos 96][lane 64][ks 2][half 2]: wave = pd owns positions 24 pd .. 24 pd + 23
+    auto wbase_of = [&](int nt) { return a.wt + ((size_t)nt * NCH * 96 + wave * 24) * 256; };
     // DMA piece `plane` (of this wave's quarter) of the staging cursor's unit into stage buffer `buf`: the plane's validity is the size of its
     // descriptor (scalar work only), the lane's validity the out-of-range offset
     auto issue_dma = [&](unsigned voff, float* buf, int plane) {
@@ -215,11 +213,9 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
 #else
 #define TSTAMP(i)
 #endif
-    E3_BRICK_VARS(P_); E3_BRICK_VARS(N_);
-    E3_DECODE(P_, L);
-    load_consts(P_n0);
+    load_consts(P.nt * 32);
     {   // prologue: units 0 and 1 staged, the weights of unit 0 requested, the window of unit 0 read
-        E3_DECODE_STAGE();
+        stage_brick();
         {
             const unsigned voff = stage_voff();
 #pragma unroll
@@ -232,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
             for (int p = 0; p < 6; ++p) issue_dma(voff, nx1, p);
         }
         stage_advance();
-        const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P_wbase), 0, NCH * 96 * 1024, 0x00020000);
+        const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbase_of(P.nt)), 0, NCH * 96 * 1024, 0x00020000);
 #pragma unroll
         for (int p = 0; p < 24; ++p) Bv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_voff + (p & 3) * 1024, (p & ~3) * 1024, 0));
         __builtin_amdgcn_sched_barrier(0);
@@ -246,8 +242,11 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
     }
 
     for (;;) {
-        const bool has_next = L + Lstep < Lend;
-        E3_DECODE(N_, has_next ? L + Lstep : L);
+        const bool has_next = P.L + Lstep < Lend;
+        Cur N = P;
+        advance(N);
+        const float* const P_wbase = wbase_of(P.nt);
+        const float* const N_wbase = wbase_of(N.nt);
 
         // One 8-channel chunk c (unit u) of brick P.  Its raw window is in the registers ra / rb (read under the MFMAs of the previous unit, or
         // in the previous brick's epilogue).  Program order: D, H, W passes (VALU phase: fp32 VALU and fp32 MFMA share the FMA lanes, so
@@ -333,9 +332,9 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
                 __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (pp == 12) stage_advance();      // (the cursor's scalar arithmetic rides in the matrix shadow; the last piece of this unit went out in pair 5)
                 if (pp == 10 && c < 8) TSTAMP(4 + 5 * c);
             }
-            stage_advance();
             if (c < 8) TSTAMP(5 + 5 * c);
             { float* tsw = cur; cur = nx1; nx1 = nx2; nx2 = tsw; }
         };
@@ -354,7 +353,8 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         const int ettd = etl >> 3, etth = (etl >> 2) & 1, ettw = etl & 3;
         const int etid = wave * 64 + elane;
         float* const erun = scr + V_SCR + etid;
-        const int n0 = P_n0, d0 = P_d0, h0 = P_h0, w0 = P_w0;
+        const int n0 = P.nt * 32, d0 = P.td * 4 + KA()->org_d, h0 = P.th * 4 + KA()->org_h, w0 = P.tw * 16 + KA()->org_w;
+        const int P_nb = P.nb;
         const int nq = n0 + 8 * ekk;
         // A^T m A over (pw, ph) in registers, one channel half at a time, one ph row at a time (`ex` is its own LDS region: the next brick's first
         // chunk is already in the stage buffers).  W: F(4,3) rows  m0+m1+m2+m3+m4,  m1-m2+2m3-2m4,  m1+m2+4m3+4m4,  m1-m2+8m3-8m4+m5
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
                         welford_merge(c0, me, mm, sc_[0], sc_[1], sc_[2]);
                     }
                     const size_t row = wgstats ? (size_t)((blockIdx.x & 7u) * ((gridDim.x >> 3) / (unsigned)KA()->ntiles) + (blockIdx.x >> 3) / (unsigned)KA()->ntiles)
-                                               : (size_t)P_row;
+                                               : (size_t)(((P.nb * tilesD + P.td) * tilesH + P.th) * tilesW + P.tw);
                     float* o = KA()->stats + (row * KA()->Cout + n0 + etid) * 3;
                     o[0] = c0; o[1] = me; o[2] = mm;
                 }
@@ -641,9 +641,8 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         ++tbrick;
 #endif
         if (!has_next) break;
-        P_d0 = N_d0; P_h0 = N_h0; P_w0 = N_w0; P_nb = N_nb; P_n0 = N_n0; P_row = N_row; P_wbase = N_wbase;
-        load_consts(P_n0);
-        L += Lstep;
+        P = N;
+        load_consts(P.nt * 32);
     }
 }
 
@@ -664,7 +663,7 @@ int wino4_stats_parts(int N, int D, int H, int W, int ncols) {
     return wino4_wgstats(nblk, ntiles, nblk >= 256 ? 256u : (unsigned)nblk) ? 256 / ntiles : bricks;
 }
 
-// Which decomposition a Winograd 3x3x3 launch takes: 0 = F(2x2x2) tiles (conv_wino.hip), 1 = F(2x2x2) in 16-tile bricks (conv_wino16.hip, CF_BNRED launches only), 2 = F(2x2x4) tiles (this file).  THE predicate: the weight
+// Which decomposition a Winograd 3x3x3 launch takes: 0 = F(2x2x2) tiles (conv_wino.hip), 2 = F(2x2x4) tiles (this file).  THE predicate: the weight
 // packers (different layouts), the statistics sizing and the launcher all ask it.  Decided on the grid of ONE sample (like conv_use_wino) so that the
 // arithmetic does not depend on the batch size.  The caller allows the larger tiles per launch with CF_WINO4 (eval-mode forwards, data gradients: see the
 // head of this file); a split-K launch, the timing flag and views that rule out 16-byte accesses keep F(2x2x2).
@@ -672,7 +671,6 @@ int conv_wino_layout(int flags, int D, int H, int W, int K, int ncols, int split
     static const int mode = getenv("E3_WINO4") ? atoi(getenv("E3_WINO4")) : 1;      // 0: never (A/B switch), 1: where the caller allows it, 2: every eligible launch (tests)
     static const size_t minblk = getenv("E3_WINO4_MIN") ? (size_t)atol(getenv("E3_WINO4_MIN")) : 512;
     if (splitk > 1 || (flags & 1024) || (ncols & 3) || (K & 7)) return 0;
-    if (flags & CF_BNRED) return 1;       // (the caller checked conv_wino16_bnred_parts(): only conv3_wino16_kernel has the fused reduction)
     if (mode <= 0 || (mode == 1 && !(flags & CF_WINO4))) return 0;
     const size_t nblk1 = (size_t)wino4_bricks(1, D, H, W) * ((ncols + 31) / 32);
     return nblk1 >= minblk ? 2 : 0;
@@ -722,15 +720,24 @@ int launch_conv3_wino4(ConvArgs a, hipStream_t s) {
     const unsigned full = 256u - (unsigned)((a.cu_reserve < 0 ? 0 : (a.cu_reserve > 128 ? 128 : a.cu_reserve)) & ~7);
     const unsigned grid = nblk >= full ? full : (unsigned)nblk;
     const int wgstats = (a.stats && wino4_wgstats(nblk, a.ntiles, grid)) ? 1 : 0;
+    // a workgroup's bricks are L0, L0 + grid / 8, ... in the logical (XCD-blocked) order: digits of that step for the division-free brick cursors
+    W4PArgs pa{};
+    {
+        unsigned st = grid == nblk ? 1u : grid / 8u;
+        pa.s_nt = (int)(st % (unsigned)a.ntiles); st /= (unsigned)a.ntiles;
+        pa.s_tw = (int)(st % (unsigned)a.tilesW); st /= (unsigned)a.tilesW;
+        pa.s_th = (int)(st % (unsigned)a.tilesH); st /= (unsigned)a.tilesH;
+        pa.s_td = (int)(st % (unsigned)a.tilesD); pa.s_nb = (int)(st / (unsigned)a.tilesD);
+    }
     static const bool no_head = getenv("E3_WINO_NO_HEAD") != nullptr, no_pool = getenv("E3_WINO_NO_POOL") != nullptr;      // A/B switches (shared with conv_wino.hip)
     if (a.epi_scale && a.head_w && a.head_done && !no_head && a.Ncols == 32 && a.head_cout >= 1 && a.head_cout <= 4 && !a.pool_out) {      // + the 1x1x1 head behind it
-        hipLaunchKernelGGL((conv3_wino4_kernel<true, false, true>), dim3(grid), dim3(256), lds_x, s, a, (unsigned)nblk, 0);
+        hipLaunchKernelGGL((conv3_wino4_kernel<true, false, true>), dim3(grid), dim3(256), lds_x, s, a, (unsigned)nblk, 0, pa);
         *a.head_done = 1;
     } else if (a.epi_scale && a.pool_out && a.pool_done && !no_pool && a.box_hi[0] <= 0 && (a.Ncols & 31) == 0) {      // + the max-pool behind it
-        hipLaunchKernelGGL((conv3_wino4_kernel<true, true>), dim3(grid), dim3(256), lds_x, s, a, (unsigned)nblk, 0);
+        hipLaunchKernelGGL((conv3_wino4_kernel<true, true>), dim3(grid), dim3(256), lds_x, s, a, (unsigned)nblk, 0, pa);
         *a.pool_done = 1;
-    } else if (a.epi_scale) hipLaunchKernelGGL(conv3_wino4_kernel<true>, dim3(grid), dim3(256), lds, s, a, (unsigned)nblk, wgstats);
-    else hipLaunchKernelGGL(conv3_wino4_kernel<false>, dim3(grid), dim3(256), lds, s, a, (unsigned)nblk, wgstats);
+    } else if (a.epi_scale) hipLaunchKernelGGL(conv3_wino4_kernel<true>, dim3(grid), dim3(256), lds, s, a, (unsigned)nblk, wgstats, pa);
+    else hipLaunchKernelGGL(conv3_wino4_kernel<false>, dim3(grid), dim3(256), lds, s, a, (unsigned)nblk, wgstats, pa);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }

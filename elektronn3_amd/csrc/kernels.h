@@ -16,7 +16,6 @@ enum ConvFlags {
     CF_NO_WINO = 8,     // direct kernels only (set by callers that pass a BN+ReLU prologue)
     CF_NO_PERSIST = 16, // one brick per workgroup even on large grids: a collective may hold CUs while this kernel runs, and a static
                         // 256-workgroup kernel that does not get all 256 CUs at once needs a full second round
-    CF_BNRED = 64,      // data-gradient launch that carries the REDUCE pass of the BatchNorm backward in front (ConvArgs::br_*): takes conv3_wino16_kernel
     CF_WINO4 = 128,     // the launch may take the F(2x2x4) Winograd tiles of conv_wino4.hip (eval-mode forwards with the folded epilogue, data gradients:
                         // the caller's statement that no ReLU / arg-max decision of a training step hangs on this launch's rounding)
     CF_SPLITK_OK = 32,  // the caller can run the conv split over its input channels (conv_wino_splitk): count the splits when deciding
@@ -53,27 +52,17 @@ struct ConvArgs {
     // residency round of one workgroup per CU (the persistent Winograd kernel) launch 256 - cu_reserve workgroups, so that they all fit
     // beside the resident workgroups of a collective running on a side stream (data-parallel backward)
     int cu_reserve;
-    // REDUCE pass of a BatchNorm backward fused into the epilogue of a DATA-GRADIENT launch (conv3_wino16_kernel only, flag CF_BNRED): the
-    // conv's output y IS dA, the gradient w.r.t. the activation of the unit in front; with that unit's raw tensor br_x and its constants the
-    // epilogue also takes sum dz and sum dz * xhat per channel (dz = dA * act'(x*scale + shift), xhat = (x - mean) * invstd) -- one record per
-    // workgroup, br_part[row][3][Ncols] rows 0 and 1 like bn_bwd_kernel's, conv_wino16_bnred_parts() rows -- so the separate pass over
-    // (dA, x) disappears.  Constant slope activations only.
-    const float* br_x; int br_ldc; const float *br_scale, *br_shift, *br_mean, *br_invstd; float br_slope; float* br_part;
     // inference: nn.MaxPool3d(2, ceil_mode=True) of the (folded-epilogue) output taken in the conv's epilogue -- a Winograd output tile IS a pooling
-    // window -- into pool_out [N][ceil(D/2)][ceil(H/2)][ceil(W/2)][Ncols] (packed).  Honoured by the persistent Winograd kernel's transposed form only;
+    // window -- into pool_out [N][ceil(D/2)][ceil(H/2)][ceil(W/2)][Ncols] (packed).  Honoured by the persistent Winograd kernel's transposed form and by conv_wino4.hip;
     // the launcher sets *pool_done = 1 when it took the pooling along (the caller runs the pooling pass otherwise).
     float* pool_out; int* pool_done;
     // inference: the network's 1x1x1 head (conv_final, unet.py:881,912; + Softmax(1) of the Predictor) taken in the epilogue of the LAST 3x3x3 conv -- in
     // the transposed-accumulator form a voxel's 32 activations sit in two lanes -- so the last activation tensor is neither written nor re-read.
     // head_w [head_cout][32], head_b [head_cout] (or null); voxel (d, h, w) inside [head_lo, head_hi) of sample n, class c goes to
     // head_y + n ys[0] + c ys[1] + (d - lo[0]) ys[2] + (h - lo[1]) ys[3] + (w - lo[2]).  Same arithmetic and summation order as conv_final_fwd_kernel
-    // (bit-identical results).  Honoured by the persistent kernel's folded-epilogue transposed form at Ncols == 32; the launcher sets *head_done = 1.
+    // (bit-identical results).  Honoured by the persistent kernel's folded-epilogue transposed form and by conv_wino4.hip at Ncols == 32; the launcher sets *head_done = 1.
     const float* head_w; const float* head_b; int head_cout, head_softmax; float* head_y; long long head_ys[4]; int head_lo[3], head_hi[3]; int* head_done;
 };
-// CF_BNRED launches: 0 when the launch cannot carry the reduction (grid does not tile into one column tile per workgroup), else the number of
-// partial rows it writes
-int conv_wino16_bnred_parts(int N, int D, int H, int W, int K, int ncols);
-
 // number of stats records (rows of [Cout][3]) the conv will write
 int conv_stats_parts(ConvKind kind, int flags, int N, int D, int H, int W, int sd, int Cin, int ncols);
 // chosen work decomposition: ks = 1 (256-voxel bricks) or 4 (64-voxel bricks, waves split K); nt = 32-column tiles per workgroup
@@ -85,11 +74,9 @@ int launch_conv3_v3(ConvKind kind, ConvArgs a, int nt, hipStream_t s);   // conv
 bool conv_use_wino(ConvKind kind, int flags, int N, int D, int H, int W, int K, int ncols);
 constexpr int WINO_PACK_MAX_JOBS = 40;
 struct WinoPackJob { const float* w; float* out; int Cout, Cin, dgrad; int k0 = 0, kn = 0; int layout = 0; };   // kn > 0: only the GEMM-K channels [k0, k0 + kn); layout: conv_wino_layout() of the launch that will read them
-// Winograd decomposition of a 3x3x3 launch: 0 = F(2x2x2) tiles in 32-tile bricks (conv_wino.hip), 1 = F(2x2x2) in 16-tile bricks (conv_wino16.hip), 2 = F(2x2x4) tiles (conv_wino4.hip).
+// Winograd decomposition of a 3x3x3 launch: 0 = F(2x2x2) tiles in 32-tile bricks (conv_wino.hip), 2 = F(2x2x4) tiles in 16-tile bricks (conv_wino4.hip).
 // THE predicate for the packed-weight layout, the statistics sizing and the launcher (K = GEMM-K channels, ncols = GEMM columns; per-sample grid).
 int conv_wino_layout(int flags, int D, int H, int W, int K, int ncols, int splitk);
-int wino16_stats_parts(int N, int D, int H, int W, int ncols);
-int launch_conv3_wino16(ConvArgs a, hipStream_t s);
 int wino4_stats_parts(int N, int D, int H, int W, int ncols);
 int launch_conv3_wino4(ConvArgs a, hipStream_t s);
 // split-K factor (1, 2 or 4) of a Winograd 3x3x3 conv whose bricks cannot fill the chip (decided per sample, like conv_use_wino)

@@ -385,6 +385,11 @@ std::vector<NeedBox> need_boxes(const e3_unet_plan* plan, const NetDims& ND, con
             b.on = false;              // (ResizeConv: everything in front of it is computed in full)
         } else {
             const int r[3] = {u.planar ? 0 : 1, 1, 1};
+            // F(2x2x4) Winograd tiles (conv_wino4.hip): an F(2,3) output never touches the tile's far input -- structural zeros of the transforms -- but
+            // the four outputs of an F(4,3) tile meet all six of its inputs and are independent of the far ones only up to rounding: every input of
+            // every W tile that holds a needed output must be a computed value, so the box grows to the tile grid along W first
+            if (!u.planar && u.cin >= 8 && conv_use_wino(CONV_K3, 0, 1, di[0], di[1], di[2], u.cin, u.cout) &&
+                conv_wino_layout(CF_WINO4, di[0], di[1], di[2], u.cin, u.cout, 1) == 2) { b.lo[2] = b.lo[2] / 4 * 4; b.hi[2] = (b.hi[2] + 3) / 4 * 4; }
             for (int i = 0; i < 3; ++i) { b.lo[i] = b.lo[i] - r[i] < 0 ? 0 : b.lo[i] - r[i]; b.hi[i] = b.hi[i] + r[i] > di[i] ? di[i] : b.hi[i] + r[i]; }
         }
         for (int i = 0; i < 3; ++i) if (b.hi[i] > di[i]) b.hi[i] = di[i];
@@ -1082,34 +1087,6 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
         const int S = conv_wino_splitk(ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cout, u.cin);
         return S > 1 ? S : 1;
     };
-    // REDUCE pass of a BatchNorm backward inside the data-gradient launch that produces its dA (ConvArgs::br_*, conv_wino16.hip): unit k1 is a plain
-    // 3x3x3 conv whose input is the activation of the plain BatchNorm unit k1 - 1 -- the second conv of every encoder / decoder block.
-    // bnred_parts[k1] > 0: that launch writes the partial rows of unit k1 - 1, whose own reduce pass (a read of dA and x) is skipped.
-    std::vector<int> bnred_parts((size_t)nunits, 0);
-    {
-        // OFF by default: with the transposed-accumulator form of the persistent kernel (16-byte stores) a plain data gradient plus the separate reduce
-        // pass is 0.06 ms per step FASTER at cfg 2 than the 16-tile kernel with the reduction on board (11.70 vs 11.76 ms, same box); E3_BNRED_FUSE=1
-        // turns the fusion on (it removes 1.2 GB of HBM reads per step; tests/test_switches_gpu.py runs the parity suites with it)
-        static const bool off = getenv("E3_BNRED_FUSE") == nullptr || getenv("E3_NO_BNRED_FUSE") != nullptr;
-        const int reserve_req0 = bucket_event ? (int)((flags >> 8) & 0x1fu) * 8 : 0;
-        for (int k1 = 1; k1 < nunits && !off && !valid && !cfg.attention && !cfg.resunet && cfg.normalization == 1 && reserve_req0 == 0; ++k1) {
-            const ConvUnit& u1 = plan->units[k1];
-            const ConvUnit& u0 = plan->units[k1 - 1];
-            if (u1.is_up || u1.planar || u1.cin < 8 || u1.to_cat || u1.res_in >= 0 || !B.wpk_d[k1] || bwd_split(k1) != 1) continue;
-            if (u0.is_up || u0.level != u1.level || !u0.has_norm() || u0.p_a >= 0 || u0.res_in >= 0 || u0.cout != u1.cin) continue;
-            if (u0.enc_last && u0.level < nb - 1) continue;      // (pooled unit: its dA is pool gradient + skip gradient)
-            if (plan->rrelu_of(ActArg(cfg.act_slope), k1 - 1).seed != 0u) continue;
-            const LevelDims& c1 = ND.u[k1].in;
-            const LevelDims& o0 = ND.u[k1 - 1].out;
-            if (c1.D != o0.D || c1.H != o0.H || c1.W != o0.W) continue;
-            // (measured at cfg 2: the launch costs +17..23 % with the reduction on board, the pass it replaces ~10 us at level 2, 30 at level 1, 105 at
-            // level 0 -- below 32 MB the separate pass is cheaper)
-            static const size_t min_mb = getenv("E3_BNRED_MIN_MB") ? (size_t)atol(getenv("E3_BNRED_MIN_MB")) : 32;      // (tests: 0 = wherever the grid allows)
-            if (o0.vox * (size_t)u0.cout * 4 < (min_mb << 20)) continue;
-            const int parts = conv_wino16_bnred_parts(N, c1.D, c1.H, c1.W, u1.cout, u1.cin);
-            if (parts > 0 && parts <= bn_bwd_parts(o0.vox, u0.cout)) bnred_parts[(size_t)k1] = parts;
-        }
-    }
     // a data gradient takes no ReLU / arg-max decision: F(2x2x4) Winograd tiles (conv_wino4.hip) -- except in the overlapped data-parallel mode without a CU
     // reserve, whose launches behind the bucket event must be one-brick kernels (CF_NO_PERSIST)
     const int w4d = (bucket_event != nullptr && ((flags >> 8) & 0x1fu) == 0) ? 0 : CF_WINO4;
@@ -1119,7 +1096,7 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
             if (!(B.wpk_d[k] && (k > 0 || dx))) continue;
             const ConvUnit& u = plan->units[k];
             const int S = bwd_split(k);
-            if (S == 1) { jobs.push_back({P(u.p_w), B.wpk_d[k], u.cout, u.cin, 1, 0, 0, conv_wino_layout(bnred_parts[(size_t)k] ? CF_BNRED : w4d, ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cout, u.cin, 1)}); continue; }
+            if (S == 1) { jobs.push_back({P(u.p_w), B.wpk_d[k], u.cout, u.cin, 1, 0, 0, conv_wino_layout(w4d, ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cout, u.cin, 1)}); continue; }
             for (int sp = 0; sp < S; ++sp)     // dgrad: the GEMM-K channels are the conv's OUTPUT channels
                 jobs.push_back({P(u.p_w), B.wpk_d[k] + sp * conv_packed_floats(CONV_K3, u.cout / S, u.cin), u.cout, u.cin, 1, sp * (u.cout / S), u.cout / S});
         }
@@ -1229,11 +1206,7 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
                 RUN(launch_bn_bwd_reduce(a, s));
                 RUN(launch_prelu_dslope(a.part, a.parts, u.cout, B.small + 4 * u.cout, G(u.p_a), s));
             }
-            const int fused_red = (k + 1 < nunits) ? bnred_parts[(size_t)k + 1] : 0;      // the data gradient of unit k + 1 took the sums along
-            if (u.has_norm() && fused_red) {
-                RUN(launch_bn_bwd_finalize(a.part, fused_red, u.cout, (float)(1.0 / (double)lo.vox), G(u.p_g), G(u.p_be), B.small, s));
-                if (frozen) a.coef = B.zeros;
-            } else if (u.has_norm()) {
+            if (u.has_norm()) {
                 { Prof pr(plan, s, nunits, hl && k == nunits - 1 ? 1 : -1); RUN(launch_bn_bwd_reduce(a, s)); }
                 if (a.head_part) {      // the head's gradients from the partial sums of that pass
                     const int ps = cfg.out_channels * C0 + cfg.out_channels;
@@ -1403,12 +1376,6 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
             // one-brick-per-workgroup kernel degrades by the fraction of CUs taken instead of needing a second round
             a.cu_reserve = reserve();
             a.flags = ((bucket_event != nullptr && event_done && a.cu_reserve == 0) ? CF_NO_PERSIST : 0) | w4d;
-            if (bnred_parts[(size_t)k]) {      // this launch also takes the REDUCE sums of unit k - 1's BatchNorm backward
-                const UnitBufs& b0 = B.ub[k - 1];
-                a.flags |= CF_BNRED;
-                a.br_x = b0.raw; a.br_ldc = plan->units[k - 1].cout; a.br_scale = b0.scale; a.br_shift = b0.shift; a.br_mean = b0.mean; a.br_invstd = b0.invstd;
-                a.br_slope = cfg.act_slope; a.br_part = B.bnpart_u[k - 1];
-            }
             const int S = (kind == CONV_K3) ? bwd_split(k) : 1;
             const size_t gvox = (size_t)N * ci.D * ci.H * ci.W;
             if (S > 1) {
