@@ -69,26 +69,49 @@ def cpu_baseline(iters=3):
             's_per_step': dt}
 
 
-def needed_region_flops(tile_in, overlap, n_blocks=4, sf=32, bricks=((4, 4, 16),) * 3):
-    """(forward FLOP of one tile, FLOP the needed-region forward skips): the Predictor keeps the central crop of a tile, so the decoder's
-    3x3x3 convs only compute the bricks (fp32 Winograd: 4 x 4 x 16 voxels; 16-bit kernels: 4 x 4 x 32 at level 0, 2 x 8 x 16 below) that crop depends on -- the box grows by one voxel per conv and halves
-    per transposed conv on the way back through the decoder (elektronn3_amd/csrc/unet_plan.cpp, e3_unet_forward_roi)."""
+def needed_region_flops(tile_in, overlap, n_blocks=4, sf=32, bricks=((4, 4, 16),) * 3, fp32=True):
+    """(forward FLOP of one tile, FLOP the needed-region forward skips, matrix FLOP the fp32 kernels EXECUTE for what is not skipped): the Predictor keeps
+    the central crop of a tile, so the decoder's 3x3x3 convs only compute the bricks (fp32 Winograd: 4 x 4 x 16 voxels; 16-bit kernels: 4 x 4 x 32 at level
+    0, 2 x 8 x 16 below) that crop depends on -- the box grows by one voxel per conv and halves per transposed conv on the way back through the decoder
+    (elektronn3_amd/csrc/unet_plan.cpp, e3_unet_forward_roi).  fp32: levels whose per-sample grid has >= 512 workgroup-bricks run the eval-mode forward on
+    F(2x2x4) Winograd tiles (csrc/conv_wino4.hip: 96 multiplies per 16 outputs = 96/432 of the direct count; bricks start at multiples of 4 along W and the
+    box of a layer in FRONT of such a conv grows to the W tile grid), the others on F(2x2x2) (64/216)."""
     vox = tile_in[0] * tile_in[1] * tile_in[2]
     whole = 427.2e3 * vox                                                 # SURVEY 8d: forward FLOP per input voxel of UNet(n_blocks=4, sf=32)
     lo = [o for o in overlap]; hi = [t - o for t, o in zip(tile_in, overlap)]
     skipped = 0.0
+    F222, F224 = 64.0 / 216.0, 96.0 / 432.0
+
+    def factor(lvl):
+        d = [t >> lvl for t in tile_in]
+        nblk1 = -(-d[0] // 4) * -(-d[1] // 4) * -(-d[2] // 16) * ((sf << lvl) // 32)
+        return F224 if (fp32 and nblk1 >= 512) else F222
+    conv_flop = {}                                                        # level -> 3x3x3 conv FLOP of the whole tile (encoder + decoder)
+    for lvl in range(n_blocks):
+        d = [t >> lvl for t in tile_in]
+        c = sf << lvl
+        pairs = [(c // 2 if lvl else 0, c), (c, c)] + ([(2 * c, c), (c, c)] if lvl < n_blocks - 1 else [])      # (the 1 -> 32 first conv is not a Winograd layer)
+        conv_flop[lvl] = sum(2.0 * 27 * ci * co for ci, co in pairs) * d[0] * d[1] * d[2]
+    skipped_lvl = {lvl: 0.0 for lvl in range(n_blocks)}
     for lvl in range(n_blocks - 1):
         dims = [t >> lvl for t in tile_in]
         c = sf << lvl
+        w4 = factor(lvl) == F224
         for cin in (c, 2 * c):                                            # conv2 (c -> c), then conv1 (concat 2c -> c), walking backwards
             edge = bricks[lvl]
             blo = [l & ~1 for l in lo] if len(set(bricks)) == 1 else list(lo)      # bricks start at the box's low corner (fp32 Winograd: rounded down to an even voxel)
+            if w4:
+                blo[2] = lo[2] // 4 * 4
             bhi = [min(b + -(-(h - b) // e) * e, d) for b, h, e, d in zip(blo, hi, edge, dims)]
             done = (bhi[0] - blo[0]) * (bhi[1] - blo[1]) * (bhi[2] - blo[2])
-            skipped += 2.0 * 27 * cin * c * (dims[0] * dims[1] * dims[2] - done)
+            sk = 2.0 * 27 * cin * c * (dims[0] * dims[1] * dims[2] - done)
+            skipped += sk; skipped_lvl[lvl] += sk
+            if w4:
+                lo[2] = lo[2] // 4 * 4; hi[2] = -(-hi[2] // 4) * 4
             lo = [max(0, l - 1) for l in lo]; hi = [min(d, h + 1) for h, d in zip(hi, dims)]
         lo = [l // 2 for l in lo]; hi = [-(-h // 2) for h in hi]          # through the transposed conv
-    return whole, skipped
+    executed = sum((conv_flop[lvl] - skipped_lvl[lvl]) * factor(lvl) for lvl in range(n_blocks)) + (whole - sum(conv_flop.values())) * 1.0
+    return whole, skipped, executed
 
 
 def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_parallel=False, bf16=False, whole_tiles=False):
@@ -126,9 +149,11 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
     for n, t in zip(shape, tile):
         ntiles *= -(-n // t)
     tile_in = [t + 2 * o for t, o in zip(tile, overlap)]
-    tile_flop, skipped = needed_region_flops(tile_in, overlap, bricks=((4, 4, 32), (2, 8, 16), (2, 8, 16)) if bf16 else ((4, 4, 16),) * 3)   # forward FLOP per tile incl. halo (2744 GFLOP)
+    tile_flop, skipped, executed = needed_region_flops(tile_in, overlap, bricks=((4, 4, 32), (2, 8, 16), (2, 8, 16)) if bf16 else ((4, 4, 16),) * 3, fp32=not bf16)   # forward FLOP per tile incl. halo (2744 GFLOP)
     roi_on = bool(_inf._ROI)
     done_flop = tile_flop - (skipped if roi_on else 0.0)
+    if not roi_on:
+        executed = needed_region_flops(tile_in, [0, 0, 0], bricks=((4, 4, 16),) * 3, fp32=not bf16)[2]
     _inf._ROI = roi_default
     return {'metric': 'Predictor MVox/s', 'value': vol.numel() / dt / 1e6, 'unit': 'MVox/s (input voxels / predict() wall time incl. H2D + D2H)',
             'seconds': dt, 'volume': list(shape), 'tile': list(tile), 'overlap': list(overlap), 'tiles': ntiles, 'dtype': (bf16 if isinstance(bf16, str) else 'bf16') if bf16 else 'f32',
@@ -137,11 +162,11 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
             'finite': bool(torch.isfinite(out[..., ::32, ::32].float()).all()),
             'needed_region': roi_on, 'flop_skipped_frac': (skipped / tile_flop) if roi_on else 0.0,
             'algorithmic_tflops': ntiles * tile_flop / dt / 1e12,
-            'mfma_executed_frac': ntiles * done_flop * (1.0 if bf16 else 64.0 / 216.0) / dt / 1e12 / MFMA_PEAK_TFLOPS['bf16' if bf16 else 'f32'],
+            'mfma_executed_frac': ntiles * (done_flop if bf16 else executed) / dt / 1e12 / MFMA_PEAK_TFLOPS['bf16' if bf16 else 'f32'],
             'note': ('needed_region: as in the fp32 leg; executed fraction = matrix FLOP of the direct 16-bit convs actually run / wall time incl. PCIe / dense bf16 MFMA peak' if bf16 else
                      'needed_region: the decoder convs compute only the Winograd bricks that the kept central crop of a tile depends on (same predict() result; '
                      'E3_PREDICTOR_NO_ROI=1 computes whole tiles); algorithmic_tflops counts whole tiles (what the reference computes), executed fraction = '
-                     'Winograd-executed matrix FLOP actually run (64/216 of the un-skipped algorithmic count) / wall time incl. PCIe / fp32 MFMA peak')}
+                     'matrix FLOP actually executed (un-skipped 3x3x3 conv FLOP x 96/432 on the levels that run F(2x2x4) Winograd tiles, x 64/216 on the F(2x2x2) levels, other layers as they are) / wall time incl. PCIe / fp32 MFMA peak')}
 
 
 def train_leg(dev, kind, steps=10, warmup=3):

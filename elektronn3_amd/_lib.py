@@ -20,6 +20,7 @@ _LIB_PATH = os.environ.get('E3_LIB_PATH') or os.path.join(_HERE, 'libe3unet.so')
 E3_FWD_TRAINING = 1
 E3_FWD_SOFTMAX = 2
 E3_FWD_FROZEN_BN = 4
+E3_FWD_REUSE_PACKED = 8
 E3_BWD_FROZEN_BN = 1
 
 
@@ -208,4 +209,4 @@ def ptr(t):
 
 
 __all__ = ['load', 'check', 'ptr', 'stream_ptr', 'UNetCfg', 'E3Error', 'EXPORTED_SYMBOLS', 'E3_FWD_TRAINING',
-           'E3_FWD_SOFTMAX', 'E3_FWD_FROZEN_BN', 'E3_BWD_FROZEN_BN', 'E3_BWD_CU_RESERVE', 'byref', 'c_size_t', 'c_void_p', 'c_float', 'c_int', 'c_int64', 'c_double', 'POINTER']
+           'E3_FWD_SOFTMAX', 'E3_FWD_FROZEN_BN', 'E3_FWD_REUSE_PACKED', 'E3_BWD_FROZEN_BN', 'E3_BWD_CU_RESERVE', 'byref', 'c_size_t', 'c_void_p', 'c_float', 'c_int', 'c_int64', 'c_double', 'POINTER']

@@ -119,6 +119,7 @@ struct Buffers {
     float* rtmp; float* rpad; float* rdu; // ResizeConv scratch: conv output / padded gradient at the up-sampled size, gradient of the up-sampled input
     float* biaspart0;                    // [splits][Cout] conv-bias gradient partials of the first conv when its BN backward is fused into its wgrad
     std::vector<float*> bnpart_u;        // per unit: block partials of the BN backward [parts][3][C]; row 2 (sum dx = conv-bias gradient) is summed for all units at once
+    std::vector<float*> wpk_u;           // inference: per unit, its OWN buffer for what is otherwise packed on the spot into the shared `wpack` -- packed weights then survive the call (E3_FWD_REUSE_PACKED)
     std::vector<float*> wpk_f, wpk_d;    // per unit: Winograd-transformed weights (forward / dgrad form), all packed by ONE launch; nullptr = packed on the spot into wpack
     std::vector<float*> g1, g2, dcat;    // gradient buffers per level
     std::vector<float*> gskip;           // conv_mode='valid' / attention: gradient of the (un-cropped) skip activation per level
@@ -284,6 +285,18 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         }
     }
     if (skmax) B.skws = T.take(skmax);
+    B.wpk_u.assign(p->units.size(), nullptr);
+    if (!training) {
+        for (size_t k = 0; k < p->units.size(); ++k) {
+            const ConvUnit& u = p->units[k];
+            const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
+            size_t n = 0;
+            if (u.is_up == 2) n = max_sz(conv_packed_floats(kind, u.cin, u.cout), p->cfg.up_resize >= 3 ? conv_packed_floats(CONV_K3_PLANAR, u.cin, u.cout) : 0);
+            else if (u.is_up) n = (size_t)pad_cols((u.planar ? 4 : 8) * u.cout) * u.cin;
+            else if (u.cin >= 8 && !B.wpk_f[k]) n = conv_packed_floats(kind, u.cin, u.cout);
+            if (n) B.wpk_u[k] = T.take(n);
+        }
+    }
     for (int j = 0; att_on && j + 1 < nb; ++j) {
         const LevelDims& lo = ND.u[up_unit(j)].out;
         statmax = max_sz(statmax, (size_t)crop_stats_parts(lo.vox, p->chan(j)) * p->chan(j) * 3);
@@ -705,6 +718,11 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
     // eval-mode forwards may take the F(2x2x4) Winograd tiles (conv_wino4.hip); a training forward -- whose ReLU / arg-max decisions the gradients
     // hang on -- keeps F(2x2x2) (profiles/r05_f224_emulation.md)
     const int w4f = training ? 0 : CF_WINO4;
+    // inference: the caller states that the packed / folded weights of the previous call (same plan, same scratch, same N, D, H, W, same parameter values) are
+    // still in place -- the tile loop of a Predictor re-packed 22 MB of weights 726 times.  (Not with the shared `wemb` of the 1x1x1 ResizeConv variants.)
+    const bool reuse = !training && (flags & E3_FWD_REUSE_PACKED) != 0 && cfg.up_resize < 3;
+    auto wp_of = [&](size_t k) { return (!training && B.wpk_u[k]) ? B.wpk_u[k] : B.wpack; };
+    if (!reuse)
     {   // Winograd weight transforms of every layer that uses them, in one launch
         std::vector<WinoPackJob> jobs;
         for (size_t k = 0; k < plan->units.size(); ++k) {
@@ -717,6 +735,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
         }
         if (!jobs.empty()) RUN(launch_wino_pack_multi(jobs.data(), (int)jobs.size(), s));
     }
+    if (!reuse)
     {   // epilogue constants of every unit that has them (eval-mode BN fold; bias fold of units without a norm), in one launch
         std::vector<FoldJob> jobs;
         for (size_t k = 0; k < plan->units.size(); ++k) {
@@ -766,9 +785,9 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             const int sd = u.planar ? 1 : 2, Ud = li.D * sd, Uh = li.H * 2, Uw = li.W * 2, NPad = pad_cols(u.cout);
             const bool lin = cfg.up_resize == 4;
             RUN(launch_embed_center_tap(P(u.p_w), B.wemb, (size_t)u.cout * u.cin, 9, s));
-            RUN(launch_pack_conv_auto(CONV_K3_PLANAR, 0, B.wemb, B.wpack, u.cout, u.cin, N, li.D, li.H, li.W, 0, s));
+            RUN(launch_pack_conv_auto(CONV_K3_PLANAR, 0, B.wemb, wp_of(k), u.cout, u.cin, N, li.D, li.H, li.W, 0, s));
             ConvArgs a{};
-            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
+            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = wp_of(k); a.bias = bn_train ? P(u.p_b) : nullptr;
             a.y = B.rdu; a.y_ldc = u.cout; a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.sd = 2;
             a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.G = 1; a.flags = 0; a.stats = nullptr;
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(CONV_K3_PLANAR, a, s)); }
@@ -781,9 +800,9 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             const bool same = Ud == lo.D && Uh == lo.H && Uw == lo.W;
             RUN(launch_upsample_nearest(cur, cur_ldc, B.ups[k], u.cin, N, li.D, li.H, li.W, sd, s, cfg.up_resize == 2));
-            RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, Ud, Uh, Uw, 0, s));
+            if (!reuse) RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), wp_of(k), u.cout, u.cin, N, Ud, Uh, Uw, 0, s));
             ConvArgs a{};
-            a.x = B.ups[k]; a.x_ldc = u.cin; a.Cin = u.cin; a.wt = B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
+            a.x = B.ups[k]; a.x_ldc = u.cin; a.Cin = u.cin; a.wt = wp_of(k); a.bias = bn_train ? P(u.p_b) : nullptr;
             a.y = same ? b.raw : B.rtmp; a.y_ldc = u.cout; a.N = N; a.D = Ud; a.H = Uh; a.W = Uw; a.sd = 2;
             a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.G = 1; a.flags = 0;
             a.stats = (bn_train && same) ? stat_buf : nullptr;
@@ -796,9 +815,9 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
         } else if (u.is_up) {
             const LevelDims& li = ND.u[k].in;
             const int sd = u.planar ? 1 : 2, taps = sd * 4, NPad = pad_cols(taps * u.cout);
-            RUN(launch_pack_weights(PACK_UP_FWD, P(u.p_w), B.wpack, u.cout, u.cin, taps, NPad, s));
+            if (!reuse) RUN(launch_pack_weights(PACK_UP_FWD, P(u.p_w), wp_of(k), u.cout, u.cin, taps, NPad, s));
             ConvArgs a{};
-            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
+            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = wp_of(k); a.bias = bn_train ? P(u.p_b) : nullptr;
             a.y = dst; a.y_ldc = dst_ldc; a.N = N; a.D = li.D; a.H = li.H; a.W = li.W;
             a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = sd;   // autocrop of the up-convolved tensor (unet.py:289-299)
             a.Cout = u.cout; a.Ncols = taps * u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
@@ -827,9 +846,9 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             const int taps = u.planar ? 9 : 27, NPad = pad_cols(u.cout);
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             (void)taps;
-            if (!B.wpk_f[k]) RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), B.wpack, u.cout, u.cin, N, ci.D, ci.H, ci.W, w4f, s));
+            if (!B.wpk_f[k] && !reuse) RUN(launch_pack_conv_auto(kind, 0, P(u.p_w), wp_of(k), u.cout, u.cin, N, ci.D, ci.H, ci.W, w4f, s));
             ConvArgs a{};
-            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpk_f[k] ? B.wpk_f[k] : B.wpack; a.bias = bn_train ? P(u.p_b) : nullptr;
+            a.x = cur; a.x_ldc = cur_ldc; a.Cin = u.cin; a.wt = B.wpk_f[k] ? B.wpk_f[k] : wp_of(k); a.bias = bn_train ? P(u.p_b) : nullptr;
             a.y = vcrop ? B.rtmp : dst; a.y_ldc = dst_ldc; a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.sd = 2;
             a.Cout = u.cout; a.Ncols = u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
             a.stats = (bn_train && !vcrop) ? stat_buf : nullptr; a.G = 1; a.flags = w4f;

@@ -519,6 +519,11 @@ class Predictor:
             dout = dout.argmax(dim=1)
         return dout.to(self.out_dtype)
 
+    def _frozen(self):
+        """Nobody changes the weights during a predict() call: the native model packs them for the first tile only (UNet.frozen_weights)."""
+        import contextlib
+        return self.model.frozen_weights() if (self._native and hasattr(self.model, 'frozen_weights')) else contextlib.nullcontext()
+
     def _tiled_predict(self, inp, out_shape=None):
         if not self.enable_tiling:
             return self._predict(inp)
@@ -776,6 +781,10 @@ class Predictor:
     # ------------------------------------------------------------------ public API (inference.py:569-642)
     def predict(self, inp):
         """``inp``: ndarray or tensor (N, C, *spatial) -> CPU tensor (inference.py:569-642)."""
+        with self._frozen():
+            return self._predict_volume(inp)
+
+    def _predict_volume(self, inp):
         t_start = time.time()
         inp = torch.as_tensor(self._transformed(inp))
         if self._pipeline_applicable(inp):                       # host volume streamed through the GPU in rows of tiles

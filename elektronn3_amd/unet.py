@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import E3_BWD_CU_RESERVE, E3_BWD_FROZEN_BN, E3_FWD_FROZEN_BN, E3_FWD_SOFTMAX, E3_FWD_TRAINING, UNetCfg, c_size_t, c_void_p, check, ptr
+from ._lib import E3_BWD_CU_RESERVE, E3_BWD_FROZEN_BN, E3_FWD_FROZEN_BN, E3_FWD_REUSE_PACKED, E3_FWD_SOFTMAX, E3_FWD_TRAINING, UNetCfg, c_size_t, c_void_p, check, ptr
 
 _plans = {}
 _plans_lock = threading.Lock()
@@ -85,17 +85,39 @@ def _get_plan(key):
         return p
 
 
-def _get_scratch(device, nbytes):
+import itertools as _itertools
+_scope_ids = _itertools.count(1)
+_packed = {}        # scratch key -> token of the inference forward whose packed weights lie in that buffer (frozen_weights scopes)
+_NO_PACK_REUSE = __import__('os').environ.get('E3_NO_PACK_REUSE') is not None      # A/B switch: every inference forward packs its weights again
+
+
+def _get_scratch(device, nbytes, token=None):
     """Per-(device, stream) scratch buffer, grown on demand.  Safe to share between consecutive calls on one stream
-    (everything is stream-ordered)."""
+    (everything is stream-ordered).  ``token`` (inference forwards inside a ``UNet.frozen_weights()`` scope): returns ``(buffer, reuse)`` --
+    ``reuse`` says that the previous call on this buffer carried the same token, i.e. its packed weights are still in place
+    (E3_FWD_REUSE_PACKED); every other call clears the buffer's token."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = None
         _scratch.pop(key, None)
+        _packed.pop(key, None)
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _scratch[key] = buf
-    return buf
+    if token is None:
+        _packed.pop(key, None)
+        return buf
+    reuse = _packed.get(key) == token and not _NO_PACK_REUSE
+    _packed[key] = token
+    return buf, reuse
+
+
+def _frozen_token(module, plan, dims, tens):
+    """Token of an inference forward inside ``module.frozen_weights()`` (None outside a scope): scope, plan, shape and the parameter table's addresses."""
+    scope = module.__dict__.get('_frozen_scope')
+    if scope is None:
+        return None
+    return (scope, plan.handle.value if hasattr(plan.handle, 'value') else int(plan.handle), tuple(dims), tuple(t.data_ptr() for t in tens))
 
 
 def _alloc_saved(device, nbytes):
@@ -107,6 +129,7 @@ def _alloc_saved(device, nbytes):
 def release_scratch():
     """Drop the cached scratch buffers (they are re-created on the next call)."""
     _scratch.clear()
+    _packed.clear()
 
 
 class _TableRef:
@@ -158,12 +181,16 @@ def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, traini
     xin = x.detach().to(b16 if b16 is not None else torch.float32).contiguous()
     saved_bytes, scratch_bytes = plan.sizes(N, D, H, W, training, bf16=b16)
     saved = _alloc_saved(dev, max(saved_bytes, 256)) if training else None
-    scratch = _get_scratch(dev, max(scratch_bytes, 256))
+    token = _frozen_token(module, plan, (N, D, H, W), tens) if (not training and b16 is None and loss is None) else None
+    if token is not None:
+        scratch, reuse = _get_scratch(dev, max(scratch_bytes, 256), token)
+    else:
+        scratch, reuse = _get_scratch(dev, max(scratch_bytes, 256)), False
     Do, Ho, Wo = plan.out_dims(D, H, W)      # == (D, H, W) unless conv_mode='valid'
     y = torch.empty((N, plan.out_channels, Do, Ho, Wo), dtype=torch.float32, device=dev)
     ptrs = (c_void_p * len(tens))(*[t.data_ptr() for t in tens])
     cmom = (ctypes.c_float * len(momenta))(*momenta) if training else None
-    flags = (E3_FWD_TRAINING if training else 0) | (E3_FWD_SOFTMAX if softmax else 0) | (E3_FWD_FROZEN_BN if frozen else 0)
+    flags = (E3_FWD_TRAINING if training else 0) | (E3_FWD_SOFTMAX if softmax else 0) | (E3_FWD_FROZEN_BN if frozen else 0) | (E3_FWD_REUSE_PACKED if reuse else 0)
     fwd = lib.e3_unet_forward_f16 if b16 is torch.float16 else (lib.e3_unet_forward_bf16 if b16 is not None else lib.e3_unet_forward)
     with torch.cuda.device(dev):
         args = (plan.handle, _lib.stream_ptr(dev), c_void_p(xin.data_ptr()), N, D, H, W, ptrs, cmom,
@@ -1114,6 +1141,25 @@ class UNet(nn.Module):
         return self._run(x, softmax=True)
 
     @torch.jit.unused
+    @torch.jit.unused
+    def frozen_weights(self):
+        """Context manager: the caller promises not to change parameters or running statistics inside the ``with`` block.  Inference forwards of one
+        shape (``self(x)``, ``forward_roi``, ``forward_tile``) then pack / Winograd-transform / fold the weights ONCE and later calls take them as
+        they lie in the scratch buffer (E3_FWD_REUSE_PACKED) -- the tile loop of ``inference.Predictor`` packed 22 MB of weights 726 times.  A call of
+        another shape, of another module on the same stream, or any training call simply packs again; nesting is allowed."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            outer = self.__dict__.get('_frozen_scope')
+            self.__dict__['_frozen_scope'] = outer if outer is not None else next(_scope_ids)
+            try:
+                yield self
+            finally:
+                if outer is None:
+                    self.__dict__.pop('_frozen_scope', None)
+        return scope()
+
     def forward_roi(self, x, roi, softmax=False):
         """Inference forward of which only the output voxels ``roi = ((d0, d1), (h0, h1), (w0, w1))`` will be used (the tile loop of
         ``inference.Predictor`` keeps the central crop of every tile, inference.py:496-525): the result has the full shape and equals
@@ -1160,7 +1206,11 @@ class UNet(nn.Module):
             if int(lo) < 0 or int(lo) + int(r1) - int(r0) > int(size):
                 raise ValueError(f'forward_tile: region written at {int(lo)} exceeds the output (axis {ax}, size {int(size)})')
         _, scratch_bytes = plan.sizes(N, D, H, W, False, bf16=None)
-        scratch = _get_scratch(dev, max(scratch_bytes, 256))
+        token = _frozen_token(self, plan, (N, D, H, W), tens)
+        if token is not None:
+            scratch, reuse = _get_scratch(dev, max(scratch_bytes, 256), token)
+        else:
+            scratch, reuse = _get_scratch(dev, max(scratch_bytes, 256)), False
         view = _lib.TileView()
         view.x = vol.data_ptr() + 4 * (int(in_lo[0]) * vol.stride(2) + int(in_lo[1]) * vol.stride(3) + int(in_lo[2]))
         view.x_stride[:] = [vol.stride(0), vol.stride(2), vol.stride(3)]
@@ -1170,7 +1220,7 @@ class UNet(nn.Module):
         with torch.cuda.device(dev):
             check(lib.e3_unet_set_rrelu(plan.handle, 0.0, 0.0, 0))
             check(lib.e3_unet_forward_tile(plan.handle, _lib.stream_ptr(dev), ctypes.byref(view), N, D, H, W, ptrs, c_void_p(scratch.data_ptr()),
-                                           c_size_t(scratch.numel()), E3_FWD_SOFTMAX if softmax else 0,
+                                           c_size_t(scratch.numel()), (E3_FWD_SOFTMAX if softmax else 0) | (E3_FWD_REUSE_PACKED if reuse else 0),
                                            (ctypes.c_int * 6)(int(d0), int(h0), int(w0), int(d1), int(h1), int(w1))))
 
     @torch.jit.unused

@@ -99,6 +99,10 @@ int e3_unet_sizes(const e3_unet_plan* plan, int N, int D, int H, int W, int trai
 #define E3_FWD_SOFTMAX 2u   /* y = softmax over channels (Predictor's nn.Sequential(model, nn.Softmax(1)), inference.py:443-444) */
 #define E3_FWD_FROZEN_BN 4u /* with E3_FWD_TRAINING: save activations for a backward, but normalise with the RUNNING statistics and leave them
                              * untouched -- autograd through a module in eval mode (frozen-BN fine-tuning, training/recalibration.py:53-73) */
+#define E3_FWD_REUSE_PACKED 8u /* inference only (ignored with E3_FWD_TRAINING): the caller states that the PREVIOUS call on this plan was an inference
+                                * forward with the same scratch buffer, N, D, H, W and parameter VALUES, and that nothing has written the scratch since: the
+                                * packed / Winograd-transformed weights and the folded BatchNorm constants are used as they lie (no packing launches).  The
+                                * tile loop of inference.Predictor (inference.py:153-199) sets it from its second tile on. */
 #define E3_BWD_FROZEN_BN 1u /* e3_unet_backward2: the matching backward (BatchNorm statistics are constants) */
 /* e3_unet_backward2, with a bucket_event: compute units (a multiple of 8, at most 128: one share per XCD) that the kernels launched AFTER the
  * event leave alone -- the kernels that fill the chip with exactly one workgroup per CU (persistent Winograd data gradients, Winograd weight

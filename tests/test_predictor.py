@@ -565,3 +565,39 @@ def test_predictor_edge_tiles_compute_only_what_lies_inside_the_volume(monkeypat
         outs.append(p.predict(vol.to(dt) if dt != torch.float32 else vol).clone())
     assert outs[0].shape[-3:] == (41, 150, 171)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_frozen_weights_scope_packs_once_and_never_serves_stale_weights():
+    """UNet.frozen_weights() (the Predictor's tile loop runs inside it): inference forwards of one shape reuse the packed weights of the first one
+    (E3_FWD_REUSE_PACKED) -- bit-identical outputs --, and every way out of the promise packs again: another shape, a training call in between, leaving the
+    scope, a parameter changed OUTSIDE a scope (also through ``.data``, which bumps no version counter: training/swa.py:182-202 swaps weights that way)."""
+    from elektronn3_amd.unet import UNet
+    from elektronn3_amd import unet as unet_mod
+    torch.manual_seed(3)
+    m = UNet(1, 2, n_blocks=2, start_filts=32).cuda()
+    with torch.no_grad():
+        m.train(); m(torch.randn(2, 1, 8, 16, 32, device='cuda')); m.eval()
+        x = torch.randn(1, 1, 16, 32, 48, device='cuda'); x2 = torch.randn(1, 1, 8, 16, 32, device='cuda')
+        ref, ref2 = m(x).clone(), m(x2).clone()
+        key = next(iter(unet_mod._scratch))
+        with m.frozen_weights():
+            a = m(x).clone()
+            assert unet_mod._packed.get(key) is not None
+            b = m(x).clone()                 # reuses
+            c = m(x2).clone()                # another shape: packs again
+            d = m(x).clone()                 # ... and again
+            r = m.forward_roi(x, ((2, 14), (4, 28), (8, 40))).clone()
+        for t_ in (a, b, d):
+            assert torch.equal(t_, ref)
+        assert torch.equal(c, ref2)
+        assert torch.equal(r[:, :, 2:14, 4:28, 8:40], ref[:, :, 2:14, 4:28, 8:40])
+        assert m.__dict__.get('_frozen_scope') is None
+        m.down_convs[0].conv2.weight.data.mul_(1.5)          # outside a scope: the next forward must see it
+        changed = m(x)
+        assert not torch.equal(changed, ref)
+        with m.frozen_weights():
+            e = m(x).clone()
+            m.train(); m(x2); m.eval()       # a training call clears the buffer's token (and moves the running statistics)
+            f = m(x).clone()
+        assert torch.equal(e, changed) and not torch.equal(f, e)

@@ -15,7 +15,7 @@ m.eval()
 vol = torch.randn(1, 1, 128, 224, 224 * 3, device='cuda')
 out = torch.zeros(1, 2, 96, 192, 192 * 3, device='cuda')
 roi = [(16, 112), (16, 208), (16, 208)]
-with torch.no_grad():
+with torch.no_grad(), m.frozen_weights():      # (as in Predictor.predict: the weights are packed for the first tile only)
     for i in range(3):
         m.forward_tile(vol, (0, 0, 224 * (i % 3)), (128, 224, 224), out, (0, 0, 192 * (i % 3)), roi, softmax=True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
