@@ -57,7 +57,9 @@ int e3_conv3d_fwd(void* stream, const float* x, int x_ldc, int Cin, const float*
     a.Cout = Cout; a.Ncols = Cout; a.NPad = NPad;
     a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.epi_scale = epi_scale; a.epi_shift = epi_shift;
     a.stats = stats; a.G = 1; a.flags = flags0;
-    if (const char* dbg = getenv("E3_CONV_ABLATE")) a.flags |= atoi(dbg) & (256 | 512 | 1024);   // timing experiments only
+#ifdef E3_TIMING
+    if (const char* dbg = getenv("E3_CONV_ABLATE")) a.flags |= atoi(dbg) & (256 | 512 | 1024);   // timing experiments (developer builds only)
+#endif
     return launch_conv_mfma(kind_of(planar), a, s);
 }
 

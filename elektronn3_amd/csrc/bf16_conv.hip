@@ -811,14 +811,24 @@ int launch_conv_b16(ConvB16Args a, hipStream_t s) {
         pa.tw2 = (unsigned)(tW >> 1); pa.m_tw2 = magic(pa.tw2);
         pa.items = (unsigned)((size_t)a.N * tD * tH * tW * pa.cgroups);
         pa.per_xcd = (pa.items + 7) / 8; pa.per_xcd = (pa.per_xcd + pa.cgroups - 1) / pa.cgroups * pa.cgroups;
+        // multiply-high division x / d = umulhi(x, ceil(2^32 / d)) is exact only while x * (m d - 2^32) < 2^32: every dividend of the kernel is below the item
+        // count (+ one XCD share for the padded ranges); a shape beyond that bound takes the one-brick kernels below
+        bool exact = true;
+        for (unsigned dv : {pa.cgroups, pa.per, pa.ncol, pa.tw2}) {
+            if (dv <= 1) continue;
+            const unsigned long long m = ((1ull << 32) + dv - 1) / dv, e = m * dv - (1ull << 32), xmax = (unsigned long long)pa.items + pa.per_xcd + 256;
+            if (e * xmax >= (1ull << 32)) exact = false;
+        }
         using GP = Geo<4, 3, 32, 16>;
         constexpr int lds = 2 * GP::IMG;
         static_assert(GP::IMG >= 4 * 2 * 32 * 33 * 4 + 1024, "statistics scratch fits one image");
         static bool pattr = false;
         if (!pattr) { E3_CHECK_HIP(hipFuncSetAttribute((const void*)conv_b16_pkernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); pattr = true; }
-        hipLaunchKernelGGL((conv_b16_pkernel<1>), dim3(PGRID), dim3(256), lds, s, a, pa);
-        E3_CHECK_HIP(hipGetLastError());
-        return E3_OK;
+        if (exact) {
+            hipLaunchKernelGGL((conv_b16_pkernel<1>), dim3(PGRID), dim3(256), lds, s, a, pa);
+            E3_CHECK_HIP(hipGetLastError());
+            return E3_OK;
+        }
     }
     // 16-channel LDS images, three workgroups per CU, where the shape allows (BD = 4, 3x3x3, 32-voxel rows, one 32-channel output tile, no split-K):
     // 150 -> 133, 247 -> 227, 154 -> 138 us on the level-0 forward convs of cfg 2, 5.89 -> 5.76 ms per step (the 32-channel-image form stays for the other decompositions)

@@ -104,3 +104,12 @@ __device__ __forceinline__ void welford_merge(float& na, float& ma, float& sa, f
         na = n;
     }
 }
+
+// Timing experiments (flag bits 256: skip the staging, 512: skip the stores, 1024: s_memtime stamps instead of statistics; wrong results) exist in developer
+// builds only (-DE3_TIMING, e.g. E3_HIPCC_EXTRA=-DE3_TIMING python -m elektronn3_amd.build --force into a copy of the tree): in the library that ships the
+// bits read as zero and the code behind them is compiled out.
+#ifdef E3_TIMING
+#define E3_DBG_FLAGS(f) (f)
+#else
+#define E3_DBG_FLAGS(f) 0
+#endif

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         }
         for (int cb0 = 0; cb0 < a.Cin; cb0 += CK * KS) {
             __syncthreads();
-            if (!(a.flags & 256)) {   // flag 256: timing ablation (skip staging)
+            if (!(E3_DBG_FLAGS(a.flags) & 256)) {   // flag 256: timing ablation (skip staging)
                 // every item of a thread is the same channel quad (256 % Q == 0): one scale/shift pair per chunk
                 f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
                 if (pro) {
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                 float v = acc[s][ns][r] + bias;
                 if (aff) v = fmaxf(__builtin_fmaf(v, es, eh), 0.f);
                 acc[s][ns][r] = v;
-                if (ok && (a.flags & 512)) ok = (v == 12345.678f);   // flag 512: timing ablation (skip the stores)
+                if (ok && (E3_DBG_FLAGS(a.flags) & 512)) ok = (v == 12345.678f);   // flag 512: timing ablation (skip the stores)
                 if (wide) tile[(s * 32 + row) * 32 + j] = v;
                 if (ok) {
                     if (!wide) a.y[off] = v;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                 const int trow = 8 * p + (lane >> 3);
                 const int m = rowbase + trow;
                 const int gw = w0 + (m & 15), gh = h0 + (m >> 4) % TH, gd = d0 + (m >> 4) / TH;
-                bool ok = nt0 + c4 < a.Ncols && gd < a.D && gh < a.H && gw < a.W && !(a.flags & 512);
+                bool ok = nt0 + c4 < a.Ncols && gd < a.D && gh < a.H && gw < a.W && !(E3_DBG_FLAGS(a.flags) & 512);
                 size_t off;
                 if (scatter) {
                     const int od = a.sd * gd + wtd, oh = 2 * gh + wth, ow = 2 * gw + wtw;

@@ -791,7 +791,10 @@ static bool first_mfma(int N, int D, int H, int W, int planar, int Cin, int Cout
     if (off || planar || Cin != 1 || Cout % 32 != 0 || FGRID % (Cout / 32) != 0) return false;
     const long long items = (long long)N * cdiv(D, FB_D) * cdiv(H, FB_H) * cdiv(W, FB_W) * (Cout / 32);
     static const long long min_items = getenv("E3_FIRST_MFMA_MIN") ? atoll(getenv("E3_FIRST_MFMA_MIN")) : FGRID;      // (tests: 1 = every shape the kernel can take)
-    return items >= min_items && items < (1ll << 31);
+    // (32-bit buffer offsets: four d-planes of a packed output and six of the input must stay below 2^31 bytes -- decided HERE, from the shape alone, so that
+    // the statistics sizing and the launcher agree; what is left to the launcher are properties of a caller's VIEW: alignment, a larger channel stride)
+    const bool planes_fit = (long long)H * W * Cout * 4 * 4 < 0x7fffffffll && (long long)H * W * 6 * 4 < 0x7fffffffll;
+    return items >= min_items && items < (1ll << 31) && planes_fit;
 }
 int conv_small_stats_parts2(int N, int D, int H, int W, int planar, int Cin, int Cout) {
     return first_mfma(N, D, H, W, planar, Cin, Cout) ? FGRID / (Cout / 32) : conv_small_stats_parts(N, D, H, W, planar);

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3_v3_kernel(const Co
             for (int r = 0; r < 16; ++r) acc[s][ns][r] = 0.f;
 
     const bool pro = a.pro_scale != nullptr;
-    const bool dbg = (a.flags & 1024) != 0;
+    const bool dbg = (E3_DBG_FLAGS(a.flags) & 1024) != 0;
     long long* dbgp = reinterpret_cast<long long*>(a.stats) + (size_t)blockIdx.x * 16;
     int dbgi = 0;
     auto stamp = [&]() { if (dbg && tid == 0 && dbgi < 12) dbgp[dbgi++] = (long long)__builtin_amdgcn_s_memtime(); };
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3_v3_kernel(const Co
                 const int line = wave * 4 + (p >> 1);
                 const int gd = d0 + line / TH, gh = h0 + line % TH, gw = w0 + (row & 15);
                 const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * 32 + 4 * (lane & 7));
-                if (c4 < a.Ncols && gd < a.D && gh < a.H && gw < a.W && !(a.flags & 512))
+                if (c4 < a.Ncols && gd < a.D && gh < a.H && gw < a.W && !(E3_DBG_FLAGS(a.flags) & 512))
                     *reinterpret_cast<f32x4*>(a.y + (size_t)(((nb * a.D + gd) * a.H + gh) * a.W + gw) * a.y_ldc + c4) = v;
             }
         } else {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3_v3_kernel(const Co
                 const int row = 2 * rr + hf;
                 const int line = wave * 4 + (row >> 4);
                 const int gd = d0 + line / TH, gh = h0 + line % TH, gw = w0 + (row & 15);
-                if (nvalid && gd < a.D && gh < a.H && gw < a.W && !(a.flags & 512))
+                if (nvalid && gd < a.D && gh < a.H && gw < a.W && !(E3_DBG_FLAGS(a.flags) & 512))
                     a.y[(size_t)(((nb * a.D + gd) * a.H + gh) * a.W + gw) * a.y_ldc + co] = tile[row * 32 + j];
             }
         }

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    const bool dbg = (a.flags & 1024) != 0;     // timing experiments: s_memtime stamps into the statistics buffer
+    const bool dbg = (E3_DBG_FLAGS(a.flags) & 1024) != 0;     // timing experiments: s_memtime stamps into the statistics buffer
     long long* dbgp = reinterpret_cast<long long*>(a.stats) + (size_t)blockIdx.x * 16;
     int dbgi = 0;
     auto stamp = [&]() { if (dbg && tid == 0 && dbgi < 14) dbgp[dbgi++] = (long long)__builtin_amdgcn_s_memtime(); };

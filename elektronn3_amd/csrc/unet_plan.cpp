@@ -258,6 +258,8 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
     if (training) {
         const int C0 = p->chan(0);
         slabmax = max_sz(slabmax, (size_t)conv_final_bwd_parts(ND.Y.vox) * (p->cfg.out_channels * C0 + p->cfg.out_channels));
+        // (e3_unet_backward_loss: the head's partial rows ride in the last unit's BatchNorm-backward reduce pass, one row per workgroup of THAT pass)
+        slabmax = max_sz(slabmax, (size_t)bn_bwd_parts(ND.Y.vox, C0) * (p->cfg.out_channels * C0 + p->cfg.out_channels));
     }
     B.wpack = T.take(wmax);
     B.wemb = B.gemb = nullptr;
@@ -1053,7 +1055,8 @@ int e3_unet_backward_loss(e3_unet_plan* plan, void* stream, const float* y, cons
     const int C = plan->cfg.out_channels;
     E3_REQUIRE(loss->workspace_bytes >= e3_ce_dice_workspace_bytes(C), E3_ERR_WORKSPACE, "ce_dice workspace too small");
     // the fused form lives in the BatchNorm backward of the network's last unit (head form: at most 4 classes in registers)
-    if (!(C >= 2 && C <= 4 && plan->units.back().has_norm())) { e3_set_error("e3_unet_backward_loss: needs 2..4 classes and a norm in front of the head"); return E3_ERR_UNSUPPORTED; }
+    // (BatchNorm only -- what the Python caller takes this entry point for and what the tests cover: the per-sample norms run one call per sample)
+    if (!(C >= 2 && C <= 4 && plan->units.back().has_norm() && plan->cfg.normalization == 1)) { e3_set_error("e3_unet_backward_loss: needs 2..4 classes and a BatchNorm in front of the head"); return E3_ERR_UNSUPPORTED; }
     const HeadLossReq hl{y, loss->target, loss->class_weight, (const float*)loss->workspace + (size_t)CE_DICE_MAX_ROWS * (2 + 3 * C), gout};
     return backward_impl(plan, stream, nullptr, &hl, x, N, D, H, W, params, grads, dx, saved, saved_bytes, scratch, scratch_bytes, bucket_event,
                          bucket_after_down_block, flags);

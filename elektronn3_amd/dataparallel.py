@@ -27,8 +27,8 @@ class GradSync:
     works through the first encoder blocks; the kernels launched after the bucket's event then leave ``cu_reserve`` compute units (a multiple of
     8, default 16 = two per XCD; ``E3_DP_CU_RESERVE``) to the collective's resident workgroups: the persistent conv kernels occupy every CU they
     get with one 512-register workgroup, and one that found its CU taken would wait a whole round (measured: +55 % on the step with ONE foreign
-    wave, tools/probe_foreign_waves.py).  ``NCCL_MAX_NCHANNELS`` is set to ``cu_reserve`` (unless the caller set it) so that RCCL's kernel has at
-    most that many workgroups."""
+    wave, tools/probe_foreign_waves.py).  ``NCCL_MAX_NCHANNELS`` must be ``<= cu_reserve`` in the environment before the process group's first collective, so that RCCL's
+    kernel has at most that many workgroups (the constructor warns otherwise; it does not change the environment)."""
 
     def __init__(self, model, process_group=None, bucket_after_down_block=2, average=True, overlap=None, cu_reserve=None):
         import os
@@ -43,13 +43,21 @@ class GradSync:
         # world == 1 normally short-circuits; `force` keeps the whole event/side-stream/all-reduce path alive (tests)
         self.force = bool(int(os.environ.get('E3_FORCE_GRADSYNC', '0')))
         if overlap is None:
-            overlap = os.environ.get('E3_DP_OVERLAP') is not None and os.environ.get('E3_DP_NO_OVERLAP') is None
+            overlap = os.environ.get('E3_DP_OVERLAP') is not None
         self.overlap = bool(overlap)
         if cu_reserve is None:
             cu_reserve = int(os.environ.get('E3_DP_CU_RESERVE', '16'))
         self.cu_reserve = max(0, min(128, int(cu_reserve))) // 8 * 8 if self.overlap else 0
         if self.overlap and self.cu_reserve:
-            os.environ.setdefault('NCCL_MAX_NCHANNELS', str(self.cu_reserve))      # (read when the communicator is created: the first collective)
+            # RCCL's kernel must fit the reserve: NCCL_MAX_NCHANNELS (read when a communicator is created, i.e. it must be in the environment BEFORE
+            # torch.distributed's first collective -- the launcher's business, bench.py --dp-overlap sets it before init_process_group) bounds its
+            # workgroups.  The constructor does not touch the environment (it would throttle every communicator created afterwards and would come too late
+            # for the one that matters); it only says so when the bound is missing or larger than the reserve.
+            import warnings
+            ch = os.environ.get('NCCL_MAX_NCHANNELS')
+            if ch is None or not ch.isdigit() or int(ch) > self.cu_reserve:
+                warnings.warn(f'GradSync(overlap=True, cu_reserve={self.cu_reserve}): NCCL_MAX_NCHANNELS={ch!r} does not bound the collective to the reserved '
+                              f'compute units; export NCCL_MAX_NCHANNELS={self.cu_reserve} before the process group is created', RuntimeWarning, stacklevel=2)
         self.collective = None        # tests / probes: callable(tensor) run on the side stream in place of the all-reduce
         self._flat = None
         self._views = None
@@ -86,8 +94,7 @@ class GradSync:
 
     def _side_stream(self):
         if self._comm_stream is None:
-            import os
-            self._comm_stream = quiet_side_stream(self._flat.device, priority=int(os.environ.get('E3_DP_SIDE_PRIORITY', '-1')))   # collectives ahead of queued compute
+            self._comm_stream = quiet_side_stream(self._flat.device)   # (high priority: collectives ahead of queued compute)
         return self._comm_stream
 
     def bucket_event(self):
@@ -166,6 +173,9 @@ class GradSync:
 _REJECTED_STREAMS = []      # kept alive: a candidate that was found noisy keeps its hardware queue, so the next candidate gets another one
 
 
+_QUIET_STREAMS = {}         # device index -> the side stream found for it (one probe per device and process, not per GradSync)
+
+
 def quiet_side_stream(device, priority=-1, tries=8, verbose=False):
     """A side stream whose HARDWARE queue does not disturb the compute stream.
 
@@ -174,6 +184,9 @@ def quiet_side_stream(device, priority=-1, tries=8, verbose=False):
     (the cfg-2 backward: 12 -> 18 ms) -- which ones depends on how many streams the process used before (every fourth or so).  So the
     candidate is tested the way GradSync uses it: a wait parked on it while a burst of tiny kernels runs on the current stream, timed against
     the same burst alone; a noisy candidate is set aside (kept alive) and the next stream is tried."""
+    dkey = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), priority)
+    if dkey in _QUIET_STREAMS and not verbose:
+        return _QUIET_STREAMS[dkey]
     cur = torch.cuda.current_stream(device)
     x = torch.zeros(1 << 20, device=device)      # (kernels of ~1000 workgroups, ~5 us each, like the backward's elementwise passes)
     K = 64
@@ -203,9 +216,10 @@ def quiet_side_stream(device, priority=-1, tries=8, verbose=False):
             if verbose:
                 print(f'quiet_side_stream: candidate {cand.cuda_stream:#x}: burst {t:.3f} ms (alone {base:.3f} ms)')
             if t < 2.0 * base + 0.05:
-                return cand
+                break
             _REJECTED_STREAMS.append(cand)
-    return cand       # (none was quiet: the last one)
+    _QUIET_STREAMS[dkey] = cand       # (none was quiet: the last one)
+    return cand
 
 
 def shard_batch(batch, rank, world):

@@ -116,7 +116,11 @@ class _PinnedRing:
             self.pending[k] = (dst[:, :, z:z + step], view)
 
     def reset(self):
-        """Forget events and pending copies (a predict() that raised midway must not leave them to the next one)."""
+        """Forget events and pending copies (a predict() that raised midway must not leave them to the next one) -- after the copy engines are done with the
+        page-locked slots: a DMA still in flight would otherwise race the next call's staging of the same slot."""
+        for ev in self.events:
+            if ev is not None:
+                ev.synchronize()
         self.events = [None, None]
         self.pending = [None, None]
         self.i = 0
@@ -607,6 +611,7 @@ class Predictor:
         import time
         dev = self.device
         t_start = time.perf_counter()
+        cpu_start = time.thread_time()
         ev_first, ev_last = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         world, rank = self._dist()
         N, Cin = int(inp.shape[0]), int(inp.shape[1])
@@ -764,6 +769,7 @@ class Predictor:
                     downs.append(down_pool.submit(download, k, j if per_row else j_first, j + 1, ev))
             ev_last.record(main)
             t_issued = time.perf_counter()
+            cpu_issued = time.thread_time()
             for d in downs:
                 d.result()
             if rings is not None:
@@ -771,7 +777,9 @@ class Predictor:
         torch.cuda.synchronize(dev)
         # where the wall time went (bench.py reports it): the compute stream's span from the first tile to the last one (it includes waits for
         # uploads), the host time to issue the tile loop, and the wall time around both
-        self.last_timing = {'wall_s': time.perf_counter() - t_start, 'issue_s': t_issued - t_start,
+        # (issue_s is wall time of the issuing thread INCLUDING the time it is blocked -- on the bounded launch queue of a busy GPU, on the upload workers;
+        # issue_cpu_s is the CPU time that thread actually spent: what the host side of the tile loop costs)
+        self.last_timing = {'wall_s': time.perf_counter() - t_start, 'issue_s': t_issued - t_start, 'issue_cpu_s': cpu_issued - cpu_start,
                             'compute_stream_s': (ev_first.elapsed_time(ev_last) / 1e3) if mine else 0.0, 'tiles': len(mine) * ntx}
         if world > 1:
             torch.distributed.barrier()               # every rank's rows are in the shared buffer

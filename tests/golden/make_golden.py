@@ -184,7 +184,7 @@ def make_rrelu_eval(unet, out, seed=17):
     np.savez_compressed(out, **d)
 
 
-def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu', up_mode='transpose', conv_mode='same', attention=False, res_blocks=None):
+def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_blocks, shape, batch, dim=3, normalization='batch', full_norm=True, merge_mode='concat', activation='relu', up_mode='transpose', conv_mode='same', attention=False, res_blocks=None, tie_free=False):
     # res_blocks = (enc_res_blocks, dec_res_blocks): `unet` is then the reference's models/resunet.py module
     extra = {} if res_blocks is None else dict(enc_res_blocks=res_blocks[0], dec_res_blocks=res_blocks[1])
     torch.manual_seed(seed)
@@ -201,6 +201,20 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
                 p.copy_(0.25 + 0.3 * torch.randn_like(p))
     sd0 = {k: npy(v).copy() for k, v in model.state_dict().items()}
     x = torch.randn(batch, 1, *shape)
+    if tie_free:
+        # the fixture must not contain a ReLU / arg-max decision within TIE_TOL of a tie in the reference's fp64 run (a flipped decision moves whole gradient
+        # tensors by ~4e-3: no implementation can be held to a tight bound on such a fixture).  A seed that has one is replaced by seed + 1000 (recursively);
+        # the seed that generated the file is stored in it.
+        rng_state = torch.get_rng_state()       # (building the checker consumes random numbers: the fixture itself is generated as without the check)
+        m64t = unet.UNet(in_channels=1, out_channels=2, n_blocks=n_blocks, start_filts=start_filts,
+                         planar_blocks=planar_blocks, activation=activation, normalization=normalization, dim=dim, full_norm=full_norm, merge_mode=merge_mode, up_mode=up_mode, conv_mode=conv_mode, attention=attention, **extra).double()
+        m64t.load_state_dict({k: torch.as_tensor(v).double() if v.dtype != np.int64 else torch.as_tensor(v) for k, v in sd0.items()})
+        stat, _ = count_ties(m64t, x.double())
+        torch.set_rng_state(rng_state)
+        if stat['act_ties'] or stat['pool_ties']:
+            print(f'{os.path.basename(out)}: seed {seed} has {stat["act_ties"]} + {stat["pool_ties"]} near-ties, trying {seed + 1000}')
+            return make_unet_case(unet, loss_mod, out, seed + 1000, n_blocks, start_filts, planar_blocks, shape, batch, dim=dim, normalization=normalization, full_norm=full_norm,
+                                  merge_mode=merge_mode, activation=activation, up_mode=up_mode, conv_mode=conv_mode, attention=attention, res_blocks=res_blocks, tie_free=True)
     model.train()
     crit = criterion(loss_mod)
     out_t = model(x)
@@ -208,7 +222,7 @@ def make_unet_case(unet, loss_mod, out, seed, n_blocks, start_filts, planar_bloc
     loss = crit(out_t, target)
     dout, = torch.autograd.grad(loss, out_t, retain_graph=True)
     loss.backward()
-    d = {'cfg.n_blocks': n_blocks, 'cfg.start_filts': start_filts, 'cfg.planar_blocks': np.array(planar_blocks, dtype=np.int64),
+    d = {'cfg.n_blocks': n_blocks, 'cfg.start_filts': start_filts, 'cfg.planar_blocks': np.array(planar_blocks, dtype=np.int64), 'seed': np.array(seed),
          'x': npy(x), 'target': npy(target), 'logits': npy(out_t), 'loss': npy(loss), 'dlogits': npy(dout)}
     if dim != 3:
         d['cfg.dim'] = dim
@@ -441,7 +455,13 @@ def make_cfg2_digest(unet, loss_mod, out, seed=2024, n_blocks=4, start_filts=32,
         m = unet.UNet(**kw).to(dt)
         m.load_state_dict({k: torch.as_tensor(v).to(dt) if v.dtype != np.int64 else torch.as_tensor(v) for k, v in sd0.items()})
         m.train()
+        stat, handles = tie_hooks(m) if tag == '64' else (None, [])      # near-tie ReLU / arg-max decisions of the fp64 run (stored: the test's allowance for a flipped decision hangs on it)
         o = m(x.to(dt))
+        for h in handles:
+            h.remove()
+        if stat is not None:
+            d['act_ties'], d['pool_ties'], d['tie_tol'] = np.array(stat['act_ties']), np.array(stat['pool_ties']), np.array(TIE_TOL)
+            print('near-ties of the fp64 run:', stat['act_ties'], '+', stat['pool_ties'], 'of', stat['act_elements'], '+', stat['pool_windows'], flush=True)
         crit = criterion(loss_mod).to(dt)
         l = crit(o, target)
         l.backward()
@@ -463,18 +483,73 @@ def make_cfg2_digest(unet, loss_mod, out, seed=2024, n_blocks=4, start_filts=32,
     print('wrote', out, f'{os.path.getsize(out) / 1e6:.2f} MB')
 
 
+def tie_hooks(m):
+    """Forward hooks on every piecewise-linear activation (count |input| < TIE_TOL) and every max-pool (count windows whose two largest inputs are closer
+    than TIE_TOL) of the reference model `m`: returns (statistics dict, filled by the next forwards; hook handles)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    stat = {'act_ties': 0, 'pool_ties': 0, 'min_abs_preact': float('inf'), 'min_pool_gap': float('inf'), 'act_elements': 0, 'pool_windows': 0}
+
+    def act_hook(_m, inp, _out):
+        z = inp[0].detach().abs()
+        stat['act_ties'] += int((z < TIE_TOL).sum())
+        stat['min_abs_preact'] = min(stat['min_abs_preact'], float(z.min()))
+        stat['act_elements'] += z.numel()
+
+    def pool_hook(pm, inp, _out):
+        x = inp[0].detach()
+        nd = x.dim() - 2
+        ks = pm.kernel_size if isinstance(pm.kernel_size, (tuple, list)) else (pm.kernel_size,) * nd
+        pad = []
+        for n, k in zip(reversed(x.shape[2:]), reversed(ks)):       # ceil_mode=True: windows may overhang; pad with -inf
+            pad += [0, (-n) % k]
+        xp = F.pad(x, pad, value=float('-inf'))
+        v = xp
+        for ax, k in enumerate(ks):                                 # -> (..., n_ax / k, k) per axis, window elements gathered last
+            v = v.unflatten(2 + 2 * ax, (xp.shape[2 + ax] // k, k))
+        perm = list(range(2)) + [2 + 2 * a for a in range(nd)] + [3 + 2 * a for a in range(nd)]
+        w = v.permute(perm).flatten(2 + nd)
+        top = w.topk(2, dim=-1).values
+        gap = top[..., 0] - top[..., 1]
+        # (two exact zeros -- ReLU outputs -- are an exact tie in every implementation: the first one wins, and its gradient dies in the ReLU)
+        live = torch.isfinite(gap) & ~((top[..., 0] == 0) & (top[..., 1] == 0))
+        gap = gap[live]
+        stat['pool_ties'] += int((gap < TIE_TOL).sum())
+        stat['min_pool_gap'] = min(stat['min_pool_gap'], float(gap.min())) if gap.numel() else stat['min_pool_gap']
+        stat['pool_windows'] += gap.numel()
+
+    handles = []
+    for sub_m in m.modules():
+        if isinstance(sub_m, (nn.ReLU, nn.LeakyReLU, nn.PReLU, nn.RReLU)):
+            handles.append(sub_m.register_forward_hook(act_hook))
+        elif isinstance(sub_m, (nn.MaxPool3d, nn.MaxPool2d)):
+            handles.append(sub_m.register_forward_hook(pool_hook))
+    return stat, handles
+
+
+def count_ties(m, x64):
+    """Near-tie decisions of one fp64 train-mode forward of the reference model `m` on `x64`.  Returns (statistics, output)."""
+    stat, handles = tie_hooks(m)
+    was_training = m.training
+    m.train()
+    with torch.no_grad():
+        o = m(x64)
+    for h in handles:
+        h.remove()
+    m.train(was_training)
+    return {k: (v if np.isfinite(v) else None) for k, v in stat.items()}, o
+
+
 def make_tie_counts(unet, out):
     """Which train-step fixtures contain a ReLU / max-pool decision that is a near-tie in the reference's fp64 run?
 
     The gradients of such a fixture are not a smooth function of fp32-level perturbations (a flipped decision moves whole gradient tensors
     by ~4e-3 rel-L2), so tests/test_unet_gpu.py::test_train_step_matches_reference may only demand its tight bound unconditionally where there
-    is none.  Per fixture: the reference model is rebuilt in fp64 from the fixture's own cfg / sd0 / x and run in train mode with forward
-    hooks on every piecewise-linear activation (count |input| < TIE_TOL) and every max-pool (count windows whose two largest inputs are
-    closer than TIE_TOL).  Written to tie_counts.json."""
+    is none.  Per fixture: the reference model is rebuilt in fp64 from the fixture's own cfg / sd0 / x and run in train mode with count_ties().
+    The small fixtures are GENERATED tie-free (make_unet_case(tie_free=True) moves the seed until the count is zero); only the Winograd-size
+    fixture -- 60 M activations: ~70 within TIE_TOL of zero whatever the seed -- keeps ties.  Written to tie_counts.json."""
     import glob
     import json
-    import torch.nn as nn
-    import torch.nn.functional as F
     sys.path.insert(0, os.path.dirname(HERE))
     from helpers import unet_cfg
     res = {}
@@ -489,47 +564,10 @@ def make_tie_counts(unet, out):
         m = mod.UNet(in_channels=1, out_channels=2, **cfg).double()
         sd0 = {k[4:]: g[k] for k in g.files if k.startswith('sd0/')}
         m.load_state_dict({k: torch.as_tensor(v).double() if v.dtype != np.int64 else torch.as_tensor(v) for k, v in sd0.items()})
-        m.train()
-        stat = {'act_ties': 0, 'pool_ties': 0, 'min_abs_preact': float('inf'), 'min_pool_gap': float('inf'), 'act_elements': 0, 'pool_windows': 0}
-
-        def act_hook(_m, inp, _out):
-            z = inp[0].detach().abs()
-            stat['act_ties'] += int((z < TIE_TOL).sum())
-            stat['min_abs_preact'] = min(stat['min_abs_preact'], float(z.min()))
-            stat['act_elements'] += z.numel()
-
-        def pool_hook(pm, inp, _out):
-            x = inp[0].detach()
-            nd = x.dim() - 2
-            ks = pm.kernel_size if isinstance(pm.kernel_size, (tuple, list)) else (pm.kernel_size,) * nd
-            pad = []
-            for n, k in zip(reversed(x.shape[2:]), reversed(ks)):       # ceil_mode=True: windows may overhang; pad with -inf
-                pad += [0, (-n) % k]
-            xp = F.pad(x, pad, value=float('-inf'))
-            v = xp
-            for ax, k in enumerate(ks):                                 # -> (..., n_ax / k, k) per axis, window elements gathered last
-                v = v.unflatten(2 + 2 * ax, (xp.shape[2 + ax] // k, k))
-            perm = list(range(2)) + [2 + 2 * a for a in range(nd)] + [3 + 2 * a for a in range(nd)]
-            w = v.permute(perm).flatten(2 + nd)
-            top = w.topk(2, dim=-1).values
-            gap = top[..., 0] - top[..., 1]
-            # (two exact zeros -- ReLU outputs -- are an exact tie in every implementation: the first one wins, and its gradient dies in the ReLU)
-            live = torch.isfinite(gap) & ~((top[..., 0] == 0) & (top[..., 1] == 0))
-            gap = gap[live]
-            stat['pool_ties'] += int((gap < TIE_TOL).sum())
-            stat['min_pool_gap'] = min(stat['min_pool_gap'], float(gap.min())) if gap.numel() else stat['min_pool_gap']
-            stat['pool_windows'] += gap.numel()
-
-        for sub_m in m.modules():
-            if isinstance(sub_m, (nn.ReLU, nn.LeakyReLU, nn.PReLU, nn.RReLU)):
-                sub_m.register_forward_hook(act_hook)
-            elif isinstance(sub_m, (nn.MaxPool3d, nn.MaxPool2d)):
-                sub_m.register_forward_hook(pool_hook)
-        with torch.no_grad():
-            o = m(torch.as_tensor(g['x']).double())
+        stat, o = count_ties(m, torch.as_tensor(g['x']).double())
         assert np.abs(npy(o).astype(np.float32) - g['logits64']).max() < 1e-6, path      # the rebuilt fp64 run IS the fixture's
-        res[os.path.basename(path)] = {k: (v if np.isfinite(v) else None) for k, v in stat.items()}
-        print(os.path.basename(path), res[os.path.basename(path)])
+        res[os.path.basename(path)] = stat
+        print(os.path.basename(path), stat)
     json.dump({'tol': TIE_TOL, 'cases': res}, open(out, 'w'), indent=1, sort_keys=True)
     print('wrote', out)
 
@@ -567,96 +605,84 @@ if __name__ == '__main__':
         sys.exit(0)
     torch.set_num_threads(8)
     unet, inference, loss_mod = load_reference()
+    # ---- the train-step fixtures: (file, command-line group, reference module, arguments).  `python make_golden.py <group>` writes one group, no argument all
+    # of them + the other fixtures.  All but the Winograd-size one are generated tie-free (make_unet_case: the seed moves by 1000 until the fp64 run has no
+    # ReLU / arg-max decision within TIE_TOL of a tie; the seed used is stored in the file).
+    U, R = 'unet', 'resunet'
+    UNET_CASES = [
+        # cfg 1 of BASELINE.json at a reduced crop: UNet(1,2,n_blocks=2,start_filts=8)
+        ('unet_nb2_sf8', 'base', U, dict(seed=0, n_blocks=2, start_filts=8, planar_blocks=(), shape=(16, 24, 24), batch=1)),
+        # odd sizes (ceil-mode pooling + autocrop of the up-convolved tensor), batch 2, planar first block
+        ('unet_nb3_sf8_planar0_odd', 'base', U, dict(seed=1, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 17, 21), batch=2)),
+        # the headline depth (n_blocks=4) at start_filts=8, cfg-4 style mixed 3D/2D (planar_blocks=(0,1))
+        ('unet_nb4_sf8_planar01', 'base', U, dict(seed=2, n_blocks=4, start_filts=8, planar_blocks=(0, 1), shape=(8, 32, 32), batch=2)),
+        # dim=2 (Conv2d/BatchNorm2d/MaxPool2d/ConvTranspose2d), odd sizes
+        ('unet2d_nb3_sf8_odd', 'unet2d', U, dict(seed=3, n_blocks=3, start_filts=8, planar_blocks=(), shape=(37, 46), batch=2, dim=2)),
+        # nn.Identity norms: normalization='none'; full_norm=False ("sparse" normalization scheme of the examples' comments)
+        ('unet_nb2_sf8_nonorm', 'norms', U, dict(seed=4, n_blocks=2, start_filts=8, planar_blocks=(), shape=(10, 13, 18), batch=2, normalization='none')),
+        ('unet_nb3_sf8_planar0_sparsenorm', 'norms', U, dict(seed=5, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 18, 21), batch=2, full_norm=False)),
+        # merge_mode='add' (skip connection summed instead of concatenated), odd sizes, planar middle block
+        ('unet_nb3_sf8_add_odd', 'add', U, dict(seed=6, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 14, 19), batch=2, merge_mode='add')),
+        # nn.InstanceNorm3d norms (no parameters, per-sample statistics in training and eval mode)
+        ('unet_nb3_sf8_instance', 'instance', U, dict(seed=7, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 17, 20), batch=2, normalization='instance')),
+        # nn.GroupNorm(4, C) norms (affine, per-sample group statistics, no running stats), odd sizes
+        ('unet_nb3_sf8_group4_odd', 'group', U, dict(seed=8, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 21), batch=2, normalization='group4')),
+        # other activations: LeakyReLU(0.1) with BatchNorm, identity ('lin') without a norm, SiLU
+        ('unet_nb3_sf8_leaky_odd', 'act', U, dict(seed=9, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(10, 13, 19), batch=2, activation='leaky')),
+        ('unet_nb2_sf8_lin_nonorm', 'act', U, dict(seed=10, n_blocks=2, start_filts=8, planar_blocks=(), shape=(6, 10, 12), batch=2, activation='lin', normalization='none')),
+        ('unet_nb3_sf8_silu_odd', 'silu', U, dict(seed=11, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 15, 18), batch=2, activation='silu')),
+        # up_mode='resizeconv_*' (up-sampling + conv instead of the transposed conv), odd sizes, planar blocks
+        ('unet_nb3_sf8_resizeconv_odd', 'resize', U, dict(seed=12, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 19), batch=2, up_mode='resizeconv_nearest')),
+        ('unet_nb3_sf8_resizelinear_odd', 'resizelin', U, dict(seed=13, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(7, 15, 18), batch=2, up_mode='resizeconv_linear')),
+        ('unet_nb3_sf8_resizenearest1_odd', 'resize1', U, dict(seed=14, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 13, 18), batch=2, up_mode='resizeconv_nearest1')),
+        # nn.PReLU(1) activations (learnable slopes) with the sparse norm scheme: slopes behind a norm and behind nn.Identity
+        ('unet_nb3_sf8_prelu_odd', 'prelu', U, dict(seed=15, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 15, 19), batch=2, activation='prelu', full_norm=False)),
+        # conv_mode='valid' (padding 0: shrinking grids, centre-cropped skips), planar first block, odd sizes
+        ('unet_nb3_sf8_valid', 'valid', U, dict(seed=16, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(21, 45, 47), batch=2, conv_mode='valid')),
+        # attention=True (GridAttention, unet.py:452-541): odd sizes (phi(g) and the gate are resized), dim=2, conv_mode='valid' + a planar block (theta halves
+        # the depth the pooling kept), merge_mode='add'
+        ('unet_nb3_sf8_attention_odd', 'attention', U, dict(seed=17, n_blocks=3, start_filts=8, planar_blocks=(), shape=(9, 14, 19), batch=2, attention=True)),
+        ('unet2d_nb3_sf8_attention', 'attention', U, dict(seed=18, n_blocks=3, start_filts=8, planar_blocks=(), shape=(37, 46), batch=2, dim=2, attention=True)),
+        ('unet_nb3_sf8_attention_valid_planar0', 'attention', U, dict(seed=19, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(22, 45, 47), batch=2, conv_mode='valid', attention=True)),
+        ('unet_nb3_sf8_attention_add', 'attention', U, dict(seed=20, n_blocks=3, start_filts=8, planar_blocks=(), shape=(8, 12, 16), batch=2, merge_mode='add', activation='leaky', attention=True)),
+        # elektronn3.models.resunet.UNet (resunet.py:598-934): plain ConvBlocks, residual ones (identity and projected shortcuts, several per block), with planar
+        # blocks / attention / merge 'add' / no norm
+        ('resunet_nb3_sf8_res00', 'resunet', R, dict(seed=21, n_blocks=3, start_filts=8, planar_blocks=(), shape=(8, 12, 16), batch=2, res_blocks=(0, 0))),
+        ('resunet_nb3_sf8_res21_odd', 'resunet', R, dict(seed=22, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 19), batch=2, res_blocks=(2, 1))),
+        ('resunet_nb3_sf8_res12_add_attention', 'resunet', R, dict(seed=23, n_blocks=3, start_filts=8, planar_blocks=(), shape=(9, 13, 18), batch=2, merge_mode='add', activation='leaky', attention=True, res_blocks=(1, 2))),
+        ('resunet_nb2_sf8_res11_nonorm', 'resunet', R, dict(seed=24, n_blocks=2, start_filts=8, planar_blocks=(), shape=(10, 12, 14), batch=2, normalization='none', res_blocks=(1, 1))),
+    ]
+    resunet = None
+
+    def run_cases(group):
+        global_resunet = None
+        for name, grp, which, kw in UNET_CASES:
+            if group is not None and grp != group:
+                continue
+            mod = unet
+            if which == R:
+                if global_resunet is None:
+                    global_resunet = _load('elektronn3.models.resunet', f'{REF}/models/resunet.py')
+                mod = global_resunet
+            make_unet_case(mod, loss_mod, f'{HERE}/{name}.npz', tie_free=True, **kw)
+
     if len(sys.argv) > 1 and sys.argv[1] == 'wino':      # a size at which the fp32 Winograd kernels run: start_filts=32, batch 2 of 31 x 61 x 67 -- 1280 bricks at level 0
-        # (the persistent kernel), 384 at level 1 (one brick per workgroup), all-odd extents (partial bricks and tiles in every dimension, autocrop)
+        # (the persistent kernel), 384 at level 1 (one brick per workgroup), all-odd extents (partial bricks and tiles in every dimension, autocrop).  NOT tie-free:
+        # 60 M activations have ~70 pre-activations within TIE_TOL of zero whatever the seed (tie_counts.json)
         make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf32_wino_odd.npz', seed=32, n_blocks=2, start_filts=32, planar_blocks=(), shape=(31, 61, 67), batch=2)
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'norms':     # only the normalization='none' / full_norm=False fixtures
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_nonorm.npz', seed=4, n_blocks=2, start_filts=8, planar_blocks=(), shape=(10, 13, 18), batch=2, normalization='none')
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_planar0_sparsenorm.npz', seed=5, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 18, 21), batch=2, full_norm=False)
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'act':
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_leaky_odd.npz', seed=9, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(10, 13, 19), batch=2, activation='leaky')
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_lin_nonorm.npz', seed=10, n_blocks=2, start_filts=8, planar_blocks=(), shape=(6, 10, 12), batch=2, activation='lin', normalization='none')
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'rrelu':
         make_rrelu_eval(unet, f'{HERE}/unet_nb3_sf8_rrelu_eval.npz')
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'resize':
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizeconv_odd.npz', seed=12, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 19), batch=2, up_mode='resizeconv_nearest')
+    if len(sys.argv) > 1 and sys.argv[1] == 'steps':     # every train-step fixture of the table
+        run_cases(None)
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'resize1':
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizenearest1_odd.npz', seed=14, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 13, 18), batch=2, up_mode='resizeconv_nearest1')
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'resizelin':
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizelinear_odd.npz', seed=13, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(7, 15, 18), batch=2, up_mode='resizeconv_linear')
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'valid':
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_valid.npz', seed=16, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(21, 45, 47), batch=2, conv_mode='valid')
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'prelu':
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_prelu_odd.npz', seed=15, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 15, 19), batch=2, activation='prelu', full_norm=False)
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'silu':
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_silu_odd.npz', seed=11, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 15, 18), batch=2, activation='silu')
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'group':
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_group4_odd.npz', seed=8, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 21), batch=2, normalization='group4')
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'instance':
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_instance.npz', seed=7, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 17, 20), batch=2, normalization='instance')
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'add':
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_add_odd.npz', seed=6, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 14, 19), batch=2, merge_mode='add')
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'resunet':     # elektronn3.models.resunet.UNet (resunet.py:598-934): plain ConvBlocks, residual ones
-        # (identity and projected shortcuts, several per block), with planar blocks / attention / merge 'add' / no norm
-        resunet = _load('elektronn3.models.resunet', f'{REF}/models/resunet.py')
-        make_unet_case(resunet, loss_mod, f'{HERE}/resunet_nb3_sf8_res00.npz', seed=21, n_blocks=3, start_filts=8, planar_blocks=(), shape=(8, 12, 16), batch=2, res_blocks=(0, 0))
-        make_unet_case(resunet, loss_mod, f'{HERE}/resunet_nb3_sf8_res21_odd.npz', seed=22, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 19), batch=2, res_blocks=(2, 1))
-        make_unet_case(resunet, loss_mod, f'{HERE}/resunet_nb3_sf8_res12_add_attention.npz', seed=23, n_blocks=3, start_filts=8, planar_blocks=(), shape=(9, 13, 18), batch=2, merge_mode='add', activation='leaky', attention=True, res_blocks=(1, 2))
-        make_unet_case(resunet, loss_mod, f'{HERE}/resunet_nb2_sf8_res11_nonorm.npz', seed=24, n_blocks=2, start_filts=8, planar_blocks=(), shape=(10, 12, 14), batch=2, normalization='none', res_blocks=(1, 1))
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'attention':     # attention=True (GridAttention, unet.py:452-541): odd sizes (phi(g) and the gate are resized),
-        # dim=2, conv_mode='valid' + a planar block (theta halves the depth the pooling kept), merge_mode='add'
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_attention_odd.npz', seed=17, n_blocks=3, start_filts=8, planar_blocks=(), shape=(9, 14, 19), batch=2, attention=True)
-        make_unet_case(unet, loss_mod, f'{HERE}/unet2d_nb3_sf8_attention.npz', seed=18, n_blocks=3, start_filts=8, planar_blocks=(), shape=(37, 46), batch=2, dim=2, attention=True)
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_attention_valid_planar0.npz', seed=19, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(22, 45, 47), batch=2, conv_mode='valid', attention=True)
-        make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_attention_add.npz', seed=20, n_blocks=3, start_filts=8, planar_blocks=(), shape=(8, 12, 16), batch=2, merge_mode='add', activation='leaky', attention=True)
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'unet2d':    # only the dim=2 fixture
-        make_unet_case(unet, loss_mod, f'{HERE}/unet2d_nb3_sf8_odd.npz', seed=3, n_blocks=3, start_filts=8, planar_blocks=(), shape=(37, 46), batch=2, dim=2)
+    if len(sys.argv) > 1:
+        assert sys.argv[1] in {g for _, g, _, _ in UNET_CASES}, f'unknown fixture group {sys.argv[1]}'
+        run_cases(sys.argv[1])
         sys.exit(0)
     make_ops(unet, f'{HERE}/ops.npz')
-    # cfg 1 of BASELINE.json at a reduced crop: UNet(1,2,n_blocks=2,start_filts=8)
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8.npz', seed=0, n_blocks=2, start_filts=8, planar_blocks=(), shape=(16, 24, 24), batch=1)
-    # odd sizes (ceil-mode pooling + autocrop of the up-convolved tensor), batch 2, planar first block
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_planar0_odd.npz', seed=1, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 17, 21), batch=2)
-    # the headline depth (n_blocks=4) at start_filts=8, cfg-4 style mixed 3D/2D (planar_blocks=(0,1))
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb4_sf8_planar01.npz', seed=2, n_blocks=4, start_filts=8, planar_blocks=(0, 1), shape=(8, 32, 32), batch=2)
-    # dim=2 (Conv2d/BatchNorm2d/MaxPool2d/ConvTranspose2d), odd sizes
-    make_unet_case(unet, loss_mod, f'{HERE}/unet2d_nb3_sf8_odd.npz', seed=3, n_blocks=3, start_filts=8, planar_blocks=(), shape=(37, 46), batch=2, dim=2)
-    # nn.Identity norms: normalization='none'; full_norm=False ("sparse" normalization scheme of the examples' comments)
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_nonorm.npz', seed=4, n_blocks=2, start_filts=8, planar_blocks=(), shape=(10, 13, 18), batch=2, normalization='none')
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_planar0_sparsenorm.npz', seed=5, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 18, 21), batch=2, full_norm=False)
-    # merge_mode='add' (skip connection summed instead of concatenated), odd sizes, planar middle block
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_add_odd.npz', seed=6, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 14, 19), batch=2, merge_mode='add')
-    # nn.InstanceNorm3d norms (no parameters, per-sample statistics in training and eval mode)
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_instance.npz', seed=7, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 17, 20), batch=2, normalization='instance')
-    # nn.GroupNorm(4, C) norms (affine, per-sample group statistics, no running stats), odd sizes
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_group4_odd.npz', seed=8, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 21), batch=2, normalization='group4')
-    # other activations: LeakyReLU(0.1) with BatchNorm, identity ('lin') without a norm
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_leaky_odd.npz', seed=9, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(10, 13, 19), batch=2, activation='leaky')
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb2_sf8_lin_nonorm.npz', seed=10, n_blocks=2, start_filts=8, planar_blocks=(), shape=(6, 10, 12), batch=2, activation='lin', normalization='none')
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_silu_odd.npz', seed=11, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 15, 18), batch=2, activation='silu')
-    # up_mode='resizeconv_nearest' (nearest up-sampling + conv3 instead of the transposed conv), odd sizes, planar first block
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizeconv_odd.npz', seed=12, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(9, 14, 19), batch=2, up_mode='resizeconv_nearest')
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizelinear_odd.npz', seed=13, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(7, 15, 18), batch=2, up_mode='resizeconv_linear')
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_resizenearest1_odd.npz', seed=14, n_blocks=3, start_filts=8, planar_blocks=(1,), shape=(9, 13, 18), batch=2, up_mode='resizeconv_nearest1')
-    # nn.PReLU(1) activations (learnable slopes) with the sparse norm scheme: slopes behind a norm and behind nn.Identity
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_prelu_odd.npz', seed=15, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(8, 15, 19), batch=2, activation='prelu', full_norm=False)
-    # conv_mode='valid' (padding 0: shrinking grids, centre-cropped skips), planar first block, odd sizes
-    make_unet_case(unet, loss_mod, f'{HERE}/unet_nb3_sf8_valid.npz', seed=16, n_blocks=3, start_filts=8, planar_blocks=(0,), shape=(21, 45, 47), batch=2, conv_mode='valid')
+    run_cases(None)
     make_rrelu_eval(unet, f'{HERE}/unet_nb3_sf8_rrelu_eval.npz')
     make_predictor(unet, inference, f'{HERE}/predictor.npz')
     make_adamw(f'{HERE}/adamw.npz')

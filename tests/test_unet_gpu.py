@@ -88,18 +88,18 @@ def test_train_step_matches_reference(case):
             errs[k] = (rel_l2(gr[k], ref64[k]), rel_l2(ref32[k], ref64[k]))
         return errs
 
-    # Gradients are piecewise smooth in the activations: one ReLU / arg-max decision on an element whose
-    # pre-activation is ~1e-7 flips under ANY fp32-level perturbation (a 1e-7 relative input dither moves the OLD
-    # kernels, and would move the reference, between two gradient states that differ by ~4e-3 rel-L2 in this very
-    # fixture).  So: every run must meet SURVEY 8c's bound (rel-L2 <= 1e-2 per tensor), and the implementation must be
-    # exact up to such decisions: at least one of a few runs with inputs dithered far below fp32 resolution of the
-    # problem (3e-7 relative) must meet the tight bound max(3 x reference fp32-vs-fp64 error, 1e-4) on every tensor.
-    # WHICH fixtures contain such a decision is known: tests/golden/tie_counts.json (make_golden.py ties) counts, in the reference's own fp64
-    # run of every fixture, the pre-activations within 2e-6 of zero and the pooling windows whose two largest inputs are closer than that.
-    # Where there is none (12 of the 26 fixtures) the tight bound must hold on the FIRST run, no dither, no retry.
+    # Gradients are piecewise smooth in the activations: one ReLU / arg-max decision on an element whose pre-activation is ~1e-7 flips under ANY fp32-level
+    # perturbation, and a flipped decision moves whole gradient tensors by ~4e-3 rel-L2.  The fixtures are therefore GENERATED tie-free (make_golden.py moves a
+    # fixture's seed until the reference's own fp64 run has no pre-activation within 2e-6 of zero and no pooling window whose two largest inputs are closer than
+    # that; tests/golden/tie_counts.json records the census): on them the tight bound max(3 x the reference's fp32-vs-fp64 error, 1e-4) must hold on the
+    # FIRST run, no dither, no retry.  The one exception is the Winograd-size fixture -- 60 M activations have ~70 pre-activations inside that band whatever
+    # the seed -- where SURVEY 8c's bound (rel-L2 <= 1e-2 per tensor) must hold on every run and the tight bound on at least one of a few runs with inputs
+    # dithered far below fp32 resolution of the problem (3e-7 relative).
     import json
     import os
-    ties = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'tie_counts.json')))['cases'][case]
+    census = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'tie_counts.json')))['cases']
+    assert {k for k, v in census.items() if v['act_ties'] or v['pool_ties']} <= {'unet_nb2_sf32_wino_odd.npz'}, 'a small fixture was generated with a near-tie decision'
+    ties = census[case]
     runs = [grad_errors(m)]
     if ties['act_ties'] == 0 and ties['pool_ties'] == 0:
         bad = {k: v for k, v in runs[0].items() if v[0] > max(3 * v[1], 1e-4)}
@@ -348,7 +348,9 @@ def test_full_size_against_the_reference_digest(case):
     its norm, a strided sample and four Gaussian projections.  Bounds as in test_train_step_matches_reference: logits within max(3 x the reference's own
     fp32-vs-fp64 error, 2e-5) of the fp64 sample; per gradient tensor the error norm estimated from the projections (E <e, r>^2 = |e|^2) and the sampled
     rel-L2 within SURVEY 8c's 1e-2 always, and within 2 x max(3 x the reference's own error, 1e-4) -- the factor 2 is the spread of a four-sample norm
-    estimate -- unless this fixture's near-tie count says a flipped ReLU / arg-max decision may move a tensor."""
+    estimate -- unless this fixture's near-tie count (act_ties + pool_ties of the reference's fp64 run, stored in the
+    digest) says a flipped ReLU / arg-max decision may move a tensor.  cfg4_digest.npz is batch 1 (the fp64 reference run of batch 2 does not fit the authoring
+    container)."""
     from collections import OrderedDict
     from helpers import digest_state_dict, digest_inputs, digest_of
     from oracle.torch_ref import combined_loss
@@ -362,6 +364,7 @@ def test_full_size_against_the_reference_digest(case):
     out = m(x)
     samp = out.detach()[:, :, ::8, ::8, ::8].cpu().numpy()
     err_ref = float(g['logits_err_ref'])
+    near_ties = int(g['act_ties']) + int(g['pool_ties'])
     np.testing.assert_allclose(samp, g['logits32'], rtol=1e-4, atol=1e-4)
     assert float(np.abs(samp - g['logits64']).max()) <= max(3 * err_ref, 2e-5), (float(np.abs(samp - g['logits64']).max()), err_ref)
     loss = combined_loss(out, t)
@@ -389,7 +392,9 @@ def test_full_size_against_the_reference_digest(case):
         if est / max(err_own, 1e-30) > worst[0] / max(worst[1], 1e-30) or worst[2] == '':
             worst = (est, err_own, k)
         bound = 2 * max(3 * err_own, 1e-4)
-        assert est <= bound or est <= 4e-3, (k, est, err_own)      # (4e-3: the size of one flipped near-tie decision, see test_train_step_matches_reference)
+        # (4e-3: the size of one flipped near-tie decision, see test_train_step_matches_reference -- allowed only where the fixture's own census of the
+        # reference's fp64 run says there ARE decisions within 2e-6 of a tie; at these sizes there are hundreds)
+        assert est <= bound or (near_ties > 0 and est <= 4e-3), (k, est, err_own, near_ties)
     print(f'{case}: worst projected gradient error {worst[0]:.2e} (reference fp32 itself: {worst[1]:.2e}) at {worst[2]}; logits err_ref {err_ref:.2e}')
 
 
