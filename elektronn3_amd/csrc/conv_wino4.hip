@@ -38,7 +38,7 @@ constexpr int V_SCR = 4 * 32 * 3;                           // cross-wave merge 
 constexpr int V_RUN = 17 * 256;                             // running statistics of every thread: n, mean[8], M2[8]  ([k][thread])
 constexpr int V_POOLX = 4 * 64 * 8;                         // fused max-pool: [wave][lane][8 channels] (8 KB)
 constexpr int V_HEADW = 160;                                // fused head: weights [4][32] + biases [4] (padded)
-constexpr int V_KST = 2 * 96;                                // bias / folded scale / folded shift of the workgroup's 32 channels, two slots
+constexpr int V_KST = 2 * 96 + 128;                          // bias / folded scale / folded shift of the workgroup's 32 channels, two slots; BNRED: scale / shift / mean / invstd of the unit in front
 constexpr int V_LDS_FLOATS = 3 * V_RBUF + V_EX + V_SCR + V_RUN + V_KST;   // 160.1 KB of the CU's 160 KiB (163 840 B): one workgroup per CU (the fused pool / head scratch lives in the statistics' region)
 static_assert(V_POOLX + V_HEADW <= V_RUN && V_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
@@ -54,14 +54,13 @@ typedef __attribute__((address_space(3))) void* lds_ptr_v;
 // HEAD (AFF, inference, 32 output channels): the 1x1x1 head (+ softmax) on the activations in registers instead of storing them (ConvArgs::head_*)
 struct W4PArgs { int s_nt, s_tw, s_th, s_td, s_nb; };      // digits of the step between a workgroup's bricks (gridDim / 8 logical bricks) in the mixed radix (column tile, tw, th, td, sample)
 
-template <bool AFF, bool POOL = false, bool HEAD = false>
+// BNRED (data gradients): the store phase also takes the REDUCE sums of the BatchNorm backward of the unit in front (ConvArgs::br_*)
+template <bool AFF, bool POOL = false, bool HEAD = false, bool BNRED = false>
 __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, const unsigned nblk, const int wgstats, const W4PArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tl = lane & 15, kk = lane >> 4;
-    const int ttd = tl >> 3, tth = (tl >> 2) & 1, ttw = tl & 3;
     const int NCH = a.Cin >> 3;
     constexpr unsigned OOB = 0x80000000u;       // buffer offset beyond every descriptor below: loads return 0, stores are dropped
     // arguments that only the per-brick set-up and the epilogue need are re-read from the kernarg segment there (scalar loads) instead of
@@ -74,9 +73,16 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
     // ---- staging by LDS-DMA (1 KB per wave-instruction, lane i lands at base + 16 i): a raw d-plane of the halo is four such pieces; wave w
     // issues quarter w of each of the six planes.  The layout of a plane is produced on the SOURCE side: lane i of quarter w asks for the 16
     // bytes that belong at piece g = 64 w + i.
+    // (the lane constants of the chunk loop -- DMA source offset and validity bits, the four window-read addresses, the weight offset -- are taken afresh
+    // from the lane index at the top of every brick: kept across the epilogue they were spilled, and a scratch reload in there waits -- the memory counter
+    // retires in order -- for every request in flight)
     unsigned col_rel, col_bits;
-    {
-        const int g = wave * 64 + lane, slot = g >> 1, qd = g & 1;
+    int rdA[2], rdB[2], b_voff;
+    const int pA = wave == 0 ? 0 : (wave == 2 ? 2 : 1), pB = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    auto lane_consts = [&]() {
+        int fl;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(fl));
+        const int g = wave * 64 + fl, slot = g >> 1, qd = g & 1;
         const int rs = slot / V_ROW, sw = slot % V_ROW;
         const int cls = sw / 5, idx = sw % 5;
         const int zh = 2 * (rs % 3) + rs / 3, zw = 4 * idx + cls;
@@ -84,21 +90,23 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         const int q = qd ^ ((rs % 3) & 1);
         col_rel = (unsigned)(((zh * W + zw) * xl + 4 * q) * 4);
         col_bits = used ? (1u << (6 + zh)) | (1u << (12 + zw)) : 0xffffffffu;     // (all-ones never matches: the unused slots get zeros)
-    }
+        // read plan of lane (tile tl, channel pair kk): window rows h = 0, 1 have zh/2 = tth, rows 2, 3 have tth + 1 (the XOR of the 16-byte half follows)
+        const int ftl = fl & 15, fkk = fl >> 4, fttd = ftl >> 3, ftth = (ftl >> 2) & 1, fttw = ftl & 3;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int r = ((ftth + hh) * V_ROW + fttw) * 8 + 2 * (fkk ^ (2 * ((ftth + hh) & 1)));
+            rdA[hh] = (2 * fttd + pA) * V_RPLANE + r; rdB[hh] = (2 * fttd + pB) * V_RPLANE + r;
+        }
+        b_voff = fl * 16;
+    };
+    lane_consts();
     float m1 = -1.f, c2 = 2.f, c4 = 4.f, c8 = 8.f, cm4 = -4.f, cm5 = -5.f, cm2 = -2.f;
     asm volatile("" : "+s"(m1), "+s"(c2), "+s"(c4), "+s"(c8), "+s"(cm4), "+s"(cm5), "+s"(cm2));     // opaque constants: a + c*b becomes v_pk_fma_f32
 
     // ---- read plan of lane (tile tl, channel pair kk).  The D pass of B^T is done while reading: row pd = wave of the tile depth's 4
     // raw planes is  x[A] + sgn x[B]  with (A, B, sgn) = (0, 2, -), (1, 2, +), (2, 1, -), (1, 3, -).  Window rows h = 0, 1 have zh/2 = tth,
     // rows 2, 3 have tth + 1 (the XOR of the 16-byte half follows).
-    const int pA = wave == 0 ? 0 : (wave == 2 ? 2 : 1), pB = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float dsg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(wave == 1 ? 0x3f800000 : (int)0xbf800000));
-    int rdA[2], rdB[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-        const int r = ((tth + hh) * V_ROW + ttw) * 8 + 2 * (kk ^ (2 * ((tth + hh) & 1)));
-        rdA[hh] = (2 * ttd + pA) * V_RPLANE + r; rdB[hh] = (2 * ttd + pB) * V_RPLANE + r;
-    }
     auto rd_imm = [](int h, int w) { return (((h & 1) * 3) * V_ROW + (w & 3) * 5 + (w >> 2)) * 8; };
 
     // three stage buffers: `cur` = the unit being computed, `nx1` = the next unit (landed: its window is read under this unit's MFMAs), `nx2` = the
@@ -112,9 +120,9 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
 #ifdef E3_W4_TIMING
     const bool do_stats = false;
 #else
-    const bool do_stats = !AFF && a.stats != nullptr;
+    const bool do_stats = !AFF && !BNRED && a.stats != nullptr;
 #endif
-    if (do_stats) {
+    if (do_stats || BNRED) {
 #pragma unroll
         for (int k = 0; k < 17; ++k) run[k * 256] = 0.f;
     }
@@ -197,7 +205,6 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_v)(buf + plane * V_RPLANE + wave * 256), 16, voff, (int)(plane * plane_xb) + S_c * 32, 0, 0);
     };
     auto stage_voff = [&]() { return ((S_mask & col_bits) == col_bits) ? col_rel : OOB; };
-    const int b_voff = lane * 16;
     f32x4 acc[24][2];
     f32x4 Bv[24];
     f32x2v ra[4][6], rb[4][6];          // raw window of the NEXT unit (planes A and B), read under the MFMAs of the current one
@@ -214,6 +221,12 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
 #define TSTAMP(i)
 #endif
     load_consts(P.nt * 32);
+    if (BNRED && tid < 128) {      // (one column tile per workgroup in this mode: the constants of its 32 channels, once; published by the prologue's barrier)
+        const KArgs e = KA();
+        const float* const src = (tid >> 5) == 0 ? e->br_scale : ((tid >> 5) == 1 ? e->br_shift : ((tid >> 5) == 2 ? e->br_mean : e->br_invstd));
+        const int ch = P.nt * 32 + (tid & 31);
+        (kst + 2 * 96)[tid] = ch < e->Ncols ? src[ch] : 0.f;
+    }
     {   // prologue: units 0 and 1 staged, the weights of unit 0 requested, the window of unit 0 read
         stage_brick();
         {
@@ -356,6 +369,29 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         const int n0 = P.nt * 32, d0 = P.td * 4 + KA()->org_d, h0 = P.th * 4 + KA()->org_h, w0 = P.tw * 16 + KA()->org_w;
         const int P_nb = P.nb;
         const int nq = n0 + 8 * ekk;
+        // BNRED: the raw tensor of the unit in front at the eight voxel rows this lane will STORE (rows v = 8 j + r of the transposed tile, piece (lane & 7) ^ r;
+        // same voxels as the output, its own channel stride) is requested here, in front of the output transform: the rows come from HBM, and requested next to
+        // the stores they cost a memory round trip per brick (+18 % on the launch)
+        f32x4 bx[8];
+        if (BNRED) {
+            const KArgs e = KA();
+            const int bl = e->br_ldc;
+            const int oh_ = wave >> 1, owb_ = 2 * (wave & 1);
+            const int r_ = elane >> 3, pc_ = (elane & 7) ^ r_;
+            const int sgh_ = h0 + 2 * (r_ >> 2) + oh_, sgw_ = w0 + 4 * (r_ & 3) + owb_;
+            const size_t plane_b = (size_t)H * W * bl;
+            const size_t brem = (size_t)(D - d0) * plane_b * 4;
+            const __amdgpu_buffer_rsrc_t x2_rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(e->br_x) + ((size_t)P_nb * D + d0) * plane_b, 0, (int)(brem < 0x7fffffffu ? brem : 0x7fffffffu), 0x00020000);
+            const bool cok_ = n0 + 4 * pc_ < e->Ncols && sgh_ < H;
+            const unsigned b_off = (unsigned)(((sgh_ * W + sgw_) * bl + n0 + 4 * pc_) * 4);
+            const unsigned bv[2] = {(cok_ && sgw_ < W) ? b_off : OOB, (cok_ && sgw_ + 1 < W) ? b_off : OOB};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int od = j >> 2, owi = (j >> 1) & 1, std_ = 2 * (j & 1) + od;
+                bx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x2_rs, (d0 + std_ < D) ? bv[owi] : OOB, (int)((std_ * plane_b + owi * bl) * 4), 0));
+            }
+        }
         // A^T m A over (pw, ph) in registers, one channel half at a time, one ph row at a time (`ex` is its own LDS region: the next brick's first
         // chunk is already in the stage buffers).  W: F(4,3) rows  m0+m1+m2+m3+m4,  m1-m2+2m3-2m4,  m1+m2+4m3+4m4,  m1-m2+8m3-8m4+m5
 #pragma unroll
@@ -427,7 +463,8 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         __builtin_amdgcn_sched_barrier(0);
         // the accumulators and the exchanged sums are dead: the window of the next brick's first unit (in `cur` after the rotation; landed and published by
         // the last chunk's barrier) is read under the stores and the statistics
-        if (!(E3_W4_ABL & 64)) {
+        // (BNRED: behind the reduction instead -- its raw rows and sums need the registers)
+        if (!(E3_W4_ABL & 64) && !BNRED) {
 #pragma unroll
             for (int h = 0; h < 4; ++h)
 #pragma unroll
@@ -463,6 +500,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
             const bool cok = n0 + 4 * pc < KA()->Ncols && sgh < H;
             const unsigned s_voff = (unsigned)(((sgh * W + sgw) * yl + n0 + 4 * pc) * 4);
             const unsigned sv[2] = {(cok && sgw < W) ? s_voff : OOB, (cok && sgw + 1 < W) ? s_voff : OOB};
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (E3_W4_ABL & 4) continue;
@@ -470,7 +508,59 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
                 const f32x4 v = *reinterpret_cast<const f32x4*>(tA + od * (16 * 64 * 4) + (owi * 16 + 8 * (j & 1) + r) * 32 + (elane & 7) * 4);
                 const bool dok = d0 + std_ < D;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), y_rs, dok ? sv[owi] : OOB, (int)((std_ * plane_y + owi * yl) * 4), 0);
+                if (BNRED) {
+                    // dz = dA * act'(z), z = x * scale + shift;  xhat = (x - mean) * invstd  (the expressions of bn_bwd_kernel)
+                    const float* const kb = kst + 2 * 96 + 4 * pc;
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(kb), sh = *reinterpret_cast<const f32x4*>(kb + 32);
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(kb + 64), is = *reinterpret_cast<const f32x4*>(kb + 96);
+                    const bool vok = dok && sv[owi] != OOB;
+                    const float slope = KA()->br_slope;
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const float xv = bx[j][e4];
+                        const float z = __builtin_fmaf(xv, sc[e4], sh[e4]);
+                        const float gv = vok ? v[e4] : 0.f, gs = slope * gv + 0.f;
+                        const float dz = z > 0.f ? gv : gs;      // (act_bwd of a constant-slope activation: the caller's condition; no branch)
+                        const float xh = (xv - mu[e4]) * is[e4];
+                        s1[e4] += dz; s2[e4] = __builtin_fmaf(dz, xh, s2[e4]);
+                    }
+                }
             }
+            if (BNRED) {
+                // running sums of this lane's 4 channels in LDS (no registers across the chunk loop); one partial row per workgroup at the end
+                f32x4 r1, r2;
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) { r1[e4] = erun[e4 * 256] + s1[e4]; r2[e4] = erun[(4 + e4) * 256] + s2[e4]; }
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) { erun[e4 * 256] = r1[e4]; erun[(4 + e4) * 256] = r2[e4]; }
+                if (!has_next) {       // (uniform) channel c = 4 pc + e: its 8 lanes per wave are l = 8 r' + (pc ^ r'), the 4 waves in order: fixed summation order
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    const KArgs e = KA();
+                    const int eN = e->Ncols;
+                    if (etid < 32 && n0 + etid < eN) {
+                        const int cpc = etid >> 2, ce = etid & 3;
+                        float t1 = 0.f, t2 = 0.f;
+                        for (int w = 0; w < 4; ++w)
+                            for (int rr = 0; rr < 8; ++rr) {
+                                const float* const src = scr + V_SCR + w * 64 + 8 * rr + (cpc ^ rr);
+                                t1 += src[ce * 256]; t2 += src[(4 + ce) * 256];
+                            }
+                        const unsigned nt_ = (unsigned)e->ntiles;
+                        const size_t row = (size_t)((blockIdx.x & 7u) * ((gridDim.x >> 3) / nt_) + (blockIdx.x >> 3) / nt_);
+                        float* o = e->br_part + row * 3 * (size_t)eN + n0 + etid;
+                        o[0] = t1; o[eN] = t2;
+                    }
+                }
+            }
+        }
+        if (!(E3_W4_ABL & 64) && BNRED) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+#pragma unroll
+                for (int w = 0; w < 6; ++w) read_window(cur, h, w);
         }
         TSTAMP(43);
         if (HEAD) {
@@ -643,6 +733,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         if (!has_next) break;
         P = N;
         load_consts(P.nt * 32);
+        lane_consts();
     }
 }
 
@@ -655,6 +746,13 @@ int wino4_bricks(int N, int D, int H, int W) { return N * cdiv(D, 4) * cdiv(H, 4
 // stride of 32 logical bricks that is one too
 static bool wino4_wgstats(size_t nblk, int ntiles, unsigned grid) {
     return grid == 256u && nblk > 256 && nblk % 8 == 0 && (nblk / 8) % (size_t)ntiles == 0 && 32 % ntiles == 0;
+}
+
+int conv_wino4_bnred_parts(int N, int D, int H, int W, int K, int ncols) {
+    if ((ncols & 3) || (K & 7)) return 0;
+    const int ntiles = (ncols + 31) / 32;
+    const size_t nblk = (size_t)wino4_bricks(N, D, H, W) * ntiles;
+    return wino4_wgstats(nblk, ntiles, nblk >= 256 ? 256u : (unsigned)nblk) ? 256 / ntiles : 0;
 }
 
 int wino4_stats_parts(int N, int D, int H, int W, int ncols) {
@@ -730,6 +828,16 @@ int launch_conv3_wino4(ConvArgs a, hipStream_t s) {
         pa.s_td = (int)(st % (unsigned)a.tilesD); pa.s_nb = (int)(st / (unsigned)a.tilesD);
     }
     static const bool no_head = getenv("E3_WINO_NO_HEAD") != nullptr, no_pool = getenv("E3_WINO_NO_POOL") != nullptr;      // A/B switches (shared with conv_wino.hip)
+    if (a.flags & CF_BNRED) {
+        E3_REQUIRE(a.br_x && a.br_scale && a.br_shift && a.br_mean && a.br_invstd && a.br_part && !a.stats && !a.epi_scale && !a.bias && a.box_hi[0] <= 0 &&
+                   (a.br_ldc & 3) == 0 && ((uintptr_t)a.br_x & 15) == 0 && a.cu_reserve == 0, E3_ERR_INVALID, "conv with the fused BatchNorm-backward reduction: bad arguments");
+        E3_REQUIRE(wino4_wgstats(nblk, a.ntiles, grid), E3_ERR_INVALID, "conv with the fused BatchNorm-backward reduction: the grid does not tile (conv_wino4_bnred_parts)");
+        static bool attr2 = false;
+        if (!attr2) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino4_kernel<false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr2 = true; }
+        hipLaunchKernelGGL((conv3_wino4_kernel<false, false, false, true>), dim3(grid), dim3(256), lds, s, a, (unsigned)nblk, 0, pa);
+        E3_CHECK_HIP(hipGetLastError());
+        return E3_OK;
+    }
     if (a.epi_scale && a.head_w && a.head_done && !no_head && a.Ncols == 32 && a.head_cout >= 1 && a.head_cout <= 4 && !a.pool_out) {      // + the 1x1x1 head behind it
         hipLaunchKernelGGL((conv3_wino4_kernel<true, false, true>), dim3(grid), dim3(256), lds_x, s, a, (unsigned)nblk, 0, pa);
         *a.head_done = 1;

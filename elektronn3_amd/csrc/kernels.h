@@ -16,6 +16,7 @@ enum ConvFlags {
     CF_NO_WINO = 8,     // direct kernels only (set by callers that pass a BN+ReLU prologue)
     CF_NO_PERSIST = 16, // one brick per workgroup even on large grids: a collective may hold CUs while this kernel runs, and a static
                         // 256-workgroup kernel that does not get all 256 CUs at once needs a full second round
+    CF_BNRED = 64,      // data-gradient launch that carries the REDUCE pass of the BatchNorm backward in front (ConvArgs::br_*): takes conv3_wino4_kernel
     CF_WINO4 = 128,     // the launch may take the F(2x2x4) Winograd tiles of conv_wino4.hip (eval-mode forwards with the folded epilogue, data gradients:
                         // the caller's statement that no ReLU / arg-max decision of a training step hangs on this launch's rounding)
     CF_SPLITK_OK = 32,  // the caller can run the conv split over its input channels (conv_wino_splitk): count the splits when deciding
@@ -52,6 +53,12 @@ struct ConvArgs {
     // residency round of one workgroup per CU (the persistent Winograd kernel) launch 256 - cu_reserve workgroups, so that they all fit
     // beside the resident workgroups of a collective running on a side stream (data-parallel backward)
     int cu_reserve;
+    // REDUCE pass of a BatchNorm backward fused into the epilogue of a DATA-GRADIENT launch (conv_wino4.hip only, flag CF_BNRED): the conv's output y IS dA,
+    // the gradient w.r.t. the activation of the unit in front; with that unit's raw tensor br_x and its constants the store phase -- which holds dA as
+    // whole voxel rows -- also takes sum dz and sum dz * xhat per channel (dz = dA * act'(x*scale + shift), xhat = (x - mean) * invstd): one record per
+    // workgroup, br_part[row][3][Ncols] rows 0 and 1 like bn_bwd_kernel's, conv_wino4_bnred_parts() rows -- so the separate pass over (dA, x)
+    // disappears.  Constant slope activations only.
+    const float* br_x; int br_ldc; const float *br_scale, *br_shift, *br_mean, *br_invstd; float br_slope; float* br_part;
     // inference: nn.MaxPool3d(2, ceil_mode=True) of the (folded-epilogue) output taken in the conv's epilogue -- a Winograd output tile IS a pooling
     // window -- into pool_out [N][ceil(D/2)][ceil(H/2)][ceil(W/2)][Ncols] (packed).  Honoured by the persistent Winograd kernel's transposed form and by conv_wino4.hip;
     // the launcher sets *pool_done = 1 when it took the pooling along (the caller runs the pooling pass otherwise).
@@ -78,6 +85,8 @@ struct WinoPackJob { const float* w; float* out; int Cout, Cin, dgrad; int k0 = 
 // THE predicate for the packed-weight layout, the statistics sizing and the launcher (K = GEMM-K channels, ncols = GEMM columns; per-sample grid).
 int conv_wino_layout(int flags, int D, int H, int W, int K, int ncols, int splitk);
 int wino4_stats_parts(int N, int D, int H, int W, int ncols);
+// CF_BNRED launches: 0 when the launch cannot carry the reduction (grid does not tile into one column tile per workgroup), else the number of partial rows it writes
+int conv_wino4_bnred_parts(int N, int D, int H, int W, int K, int ncols);
 int launch_conv3_wino4(ConvArgs a, hipStream_t s);
 // split-K factor (1, 2 or 4) of a Winograd 3x3x3 conv whose bricks cannot fill the chip (decided per sample, like conv_use_wino)
 int conv_wino_splitk(int D, int H, int W, int K, int ncols);   // (0 if the conv does not use the Winograd kernel even with the splits)

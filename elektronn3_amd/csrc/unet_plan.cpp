@@ -1109,6 +1109,34 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
         const int S = conv_wino_splitk(ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cout, u.cin);
         return S > 1 ? S : 1;
     };
+    const bool w4d_ok = !(bucket_event != nullptr && ((flags >> 8) & 0x1fu) == 0);
+    // REDUCE pass of a BatchNorm backward inside the data-gradient launch that produces its dA (ConvArgs::br_*, conv_wino4.hip): unit k1 is a plain
+    // 3x3x3 conv whose input is the activation of the plain BatchNorm unit k1 - 1 -- the second conv of every encoder / decoder block.
+    // bnred_parts[k1] > 0: that launch writes the partial rows of unit k1 - 1, whose own reduce pass (a read of dA and x) is skipped.
+    std::vector<int> bnred_parts((size_t)nunits, 0);
+    {
+        // ON where the data gradient runs on the F(2x2x4) kernel of conv_wino4.hip, whose store phase holds dA as whole voxel rows (E3_NO_BNRED_FUSE=1: A/B
+        // switch; round 4 had the fusion in a 16-tile F(2x2x2) kernel that was slower than the persistent kernel by more than the pass it saved)
+        static const bool off = getenv("E3_NO_BNRED_FUSE") != nullptr;
+        const int reserve_req0 = bucket_event ? (int)((flags >> 8) & 0x1fu) * 8 : 0;
+        for (int k1 = 1; k1 < nunits && !off && !valid && !cfg.attention && !cfg.resunet && cfg.normalization == 1 && reserve_req0 == 0; ++k1) {
+            const ConvUnit& u1 = plan->units[k1];
+            const ConvUnit& u0 = plan->units[k1 - 1];
+            if (u1.is_up || u1.planar || u1.cin < 8 || u1.to_cat || u1.res_in >= 0 || !B.wpk_d[k1] || bwd_split(k1) != 1) continue;
+            if (u0.is_up || u0.level != u1.level || !u0.has_norm() || u0.p_a >= 0 || u0.res_in >= 0 || u0.cout != u1.cin) continue;
+            if (u0.enc_last && u0.level < nb - 1) continue;      // (pooled unit: its dA is pool gradient + skip gradient)
+            if (plan->rrelu_of(ActArg(cfg.act_slope), k1 - 1).seed != 0u || !(cfg.act_slope >= 0.f && cfg.act_slope <= 1.f)) continue;      // (constant-slope activations: ReLU, LeakyReLU, identity)
+            const LevelDims& c1 = ND.u[k1].in;
+            const LevelDims& o0 = ND.u[k1 - 1].out;
+            if (c1.D != o0.D || c1.H != o0.H || c1.W != o0.W) continue;
+            // (measured at cfg 2: the launch costs +17..23 % with the reduction on board, the pass it replaces ~10 us at level 2, 30 at level 1, 105 at
+            // level 0 -- below 32 MB the separate pass is cheaper)
+            static const size_t min_mb = getenv("E3_BNRED_MIN_MB") ? (size_t)atol(getenv("E3_BNRED_MIN_MB")) : 32;      // (tests: 0 = wherever the grid allows)
+            if (o0.vox * (size_t)u0.cout * 4 < (min_mb << 20)) continue;
+            const int parts = ((w4d_ok && conv_wino_layout(CF_WINO4, c1.D, c1.H, c1.W, u1.cout, u1.cin, 1) == 2) ? conv_wino4_bnred_parts(N, c1.D, c1.H, c1.W, u1.cout, u1.cin) : 0);
+            if (parts > 0 && parts <= bn_bwd_parts(o0.vox, u0.cout)) bnred_parts[(size_t)k1] = parts;
+        }
+    }
     // a data gradient takes no ReLU / arg-max decision: F(2x2x4) Winograd tiles (conv_wino4.hip) -- except in the overlapped data-parallel mode without a CU
     // reserve, whose launches behind the bucket event must be one-brick kernels (CF_NO_PERSIST)
     const int w4d = (bucket_event != nullptr && ((flags >> 8) & 0x1fu) == 0) ? 0 : CF_WINO4;
@@ -1118,7 +1146,7 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
             if (!(B.wpk_d[k] && (k > 0 || dx))) continue;
             const ConvUnit& u = plan->units[k];
             const int S = bwd_split(k);
-            if (S == 1) { jobs.push_back({P(u.p_w), B.wpk_d[k], u.cout, u.cin, 1, 0, 0, conv_wino_layout(w4d, ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cout, u.cin, 1)}); continue; }
+            if (S == 1) { jobs.push_back({P(u.p_w), B.wpk_d[k], u.cout, u.cin, 1, 0, 0, conv_wino_layout(bnred_parts[(size_t)k] ? (CF_BNRED | CF_WINO4) : w4d, ND.u[k].in.D, ND.u[k].in.H, ND.u[k].in.W, u.cout, u.cin, 1)}); continue; }
             for (int sp = 0; sp < S; ++sp)     // dgrad: the GEMM-K channels are the conv's OUTPUT channels
                 jobs.push_back({P(u.p_w), B.wpk_d[k] + sp * conv_packed_floats(CONV_K3, u.cout / S, u.cin), u.cout, u.cin, 1, sp * (u.cout / S), u.cout / S});
         }
@@ -1228,7 +1256,11 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
                 RUN(launch_bn_bwd_reduce(a, s));
                 RUN(launch_prelu_dslope(a.part, a.parts, u.cout, B.small + 4 * u.cout, G(u.p_a), s));
             }
-            if (u.has_norm()) {
+            const int fused_red = (k + 1 < nunits) ? bnred_parts[(size_t)k + 1] : 0;      // the data gradient of unit k + 1 took the sums along
+            if (u.has_norm() && fused_red) {
+                RUN(launch_bn_bwd_finalize(a.part, fused_red, u.cout, (float)(1.0 / (double)lo.vox), G(u.p_g), G(u.p_be), B.small, s));
+                if (frozen) a.coef = B.zeros;
+            } else if (u.has_norm()) {
                 { Prof pr(plan, s, nunits, hl && k == nunits - 1 ? 1 : -1); RUN(launch_bn_bwd_reduce(a, s)); }
                 if (a.head_part) {      // the head's gradients from the partial sums of that pass
                     const int ps = cfg.out_channels * C0 + cfg.out_channels;
@@ -1398,6 +1430,12 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
             // one-brick-per-workgroup kernel degrades by the fraction of CUs taken instead of needing a second round
             a.cu_reserve = reserve();
             a.flags = ((bucket_event != nullptr && event_done && a.cu_reserve == 0) ? CF_NO_PERSIST : 0) | w4d;
+            if (bnred_parts[(size_t)k]) {      // this launch also takes the REDUCE sums of unit k - 1's BatchNorm backward
+                const UnitBufs& b0 = B.ub[k - 1];
+                a.flags |= CF_BNRED | CF_WINO4;
+                a.br_x = b0.raw; a.br_ldc = plan->units[k - 1].cout; a.br_scale = b0.scale; a.br_shift = b0.shift; a.br_mean = b0.mean; a.br_invstd = b0.invstd;
+                a.br_slope = cfg.act_slope; a.br_part = B.bnpart_u[k - 1];
+            }
             const int S = (kind == CONV_K3) ? bwd_split(k) : 1;
             const size_t gvox = (size_t)N * ci.D * ci.H * ci.W;
             if (S > 1) {

@@ -34,13 +34,16 @@ GROUPS = {
                                    ['tests/test_dataparallel_gpu.py', 'tests/test_predictor.py', 'tests/test_unet_gpu.py', '-k',
                                     'two_rank or pipelined or needed_region or in_place or train_step_matches_reference']),
     # F(2x2x4) Winograd tiles (conv_wino4.hip; by default the eval-mode forward and the data gradients of grids with >= 512 bricks): OFF everywhere ...
-    'wino4_off': (dict(E3_WINO4='0'), ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', 'tests/test_predictor.py', '-k',
+    'wino4_off': (dict(E3_WINO4='0', E3_NO_BNRED_FUSE='1'), ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', 'tests/test_predictor.py', '-k',
                                        'conv3 or train_step_matches_reference or eval_forward or full_size_properties or forward_with_loss or forward_roi or needed_region or full_size_cfg2 or predictor']),
     # ... and on every grid that has a brick (ragged grids, workgroups without a brick, one brick per workgroup): data gradients, the folded eval epilogue
     # with the fused pool / head, the needed-region forward, the in-place tiles
     'wino4_on_every_grid': (dict(E3_WINO4_MIN='1'),
                             ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', 'tests/test_predictor.py', '-k',
                              'conv3 or train_step_matches_reference or eval_forward or full_size_properties or forward_with_loss or forward_roi or needed_region or head_in_the_last or pool_in_the_conv or predictor']),
+    # the REDUCE pass of the BatchNorm backward inside the F(2x2x4) data gradients (default from 32 MB tensors on) wherever a grid tiles, small ones included
+    'bnred_in_the_data_gradient': (dict(E3_WINO4_MIN='1', E3_BNRED_MIN_MB='0'),
+                                   ['tests/test_unet_gpu.py', '-k', 'train_step_matches_reference or full_size_cfg2 or full_size_properties or forward_with_loss or digest']),
     # ... and for the TRAINING forward with its statistics as well (E3_WINO4=2; not a default: DESIGN.md section 3e) -- per-op parity and the property tests
     'wino4_training_forward': (dict(E3_WINO4='2', E3_WINO4_MIN='1'), ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', '-k', 'conv3 or full_size_properties or forward_with_loss or eval_forward']),
 }
