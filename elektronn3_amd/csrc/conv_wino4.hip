@@ -59,7 +59,6 @@ template <bool AFF, bool POOL = false, bool HEAD = false, bool BNRED = false>
 __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, const unsigned nblk, const int wgstats, const W4PArgs pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NCH = a.Cin >> 3;
     constexpr unsigned OOB = 0x80000000u;       // buffer offset beyond every descriptor below: loads return 0, stores are dropped

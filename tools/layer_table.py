@@ -4,7 +4,7 @@ Every conv / transposed conv / head of UNet(1,2,n_blocks=4,start_filts=32) is ti
 events around its dominant kernel (e3_unet_profile_select/read), forward, dgrad and wgrad separately.  Algorithmic work
 per launch follows SURVEY.md section 8(d): FLOPs = 2*Cin*Cout*taps per output voxel (transposed conv: per input voxel),
 bytes = x + y + w (fwd), dy + w + dx (dgrad), x + dy + dw (wgrad), fp32.
-Fractions: HBM = bytes / t / 8 TB/s, fp32 = FLOPs / t / 157.3 TFLOP/s (Winograd layers can exceed 1: they execute 64/216 resp.
+Fractions: HBM = bytes / t / 8 TB/s, fp32 = FLOPs / t / 157.3 TFLOP/s (Winograd layers can exceed 1: the F(2x2x2) kernels execute 64/216, the F(2x2x4) data gradients of levels 0 and 1 96/432, the planar ones
 16/36 of the algorithmic multiplies).
 Usage: python tools/layer_table.py [steps] > profiles/rNN_per_layer.md"""
 import os, sys, torch
