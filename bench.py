@@ -40,7 +40,7 @@ BATCH_PER_GPU = 2
 MFMA_PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0, 'f16': 2500.0}   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16, dense
 HBM_PEAK = 8.0e12                                    # B/s (spec)
 FWDBWD_FLOP_PER_VOXEL = 1279.9e3                     # SURVEY.md 8d (cfg 2 network)
-PMC_FILE = os.path.join('profiles', 'r04_pmc_roofline.json')
+PMC_FILE = os.path.join('profiles', 'r05_pmc_roofline.json')
 
 
 def cpu_baseline(iters=3):

@@ -1,5 +1,6 @@
 """Sustained shader clock inside the conv kernels: s_memtime (shader clock) over s_memrealtime (100 MHz) per workgroup.
-Needs the debug stamps of conv_v3.hip (E3_CONV_ABLATE=1024).  Usage: python tools/clock_probe.py"""
+Needs the debug stamps of conv_v3.hip: a developer build of the library (E3_HIPCC_EXTRA=-DE3_TIMING python -m elektronn3_amd.build --force;
+the release library compiles the stamps and the E3_CONV_ABLATE switch out) with E3_CONV_ABLATE=1024.  Usage: python tools/clock_probe.py"""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('E3_CONV_ABLATE', '1024')

@@ -1,3 +1,5 @@
+"""Phase timing of the direct conv kernel (conv_v3.hip).  Needs a developer build of the library: E3_HIPCC_EXTRA=-DE3_TIMING python -m elektronn3_amd.build --force
+(the release library compiles the stamps and the E3_CONV_ABLATE switch out)."""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('E3_CONV_ABLATE', '1024')

@@ -2,7 +2,7 @@
 # Round profile on the GPU box: kernel statistics of the default bench command (fp32 and bf16) and the PMC passes behind
 # bench.py's roofline.traffic.  Usage (inside gpurun): bash tools/profile_round.sh r03
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$PWD
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
