@@ -158,7 +158,7 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
     return {'metric': 'Predictor MVox/s', 'value': vol.numel() / dt / 1e6, 'unit': 'MVox/s (input voxels / predict() wall time incl. H2D + D2H)',
             'seconds': dt, 'volume': list(shape), 'tile': list(tile), 'overlap': list(overlap), 'tiles': ntiles, 'dtype': (bf16 if isinstance(bf16, str) else 'bf16') if bf16 else 'f32',
             'out_dtype': str(out.dtype).replace('torch.', ''),
-            'timing': {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (getattr(pred, 'last_timing', None) or {}).items()},
+            'timing': {k: (round(v, 6 if k.startswith('tile_call') else 4) if isinstance(v, float) else v) for k, v in (getattr(pred, 'last_timing', None) or {}).items()},
             'finite': bool(torch.isfinite(out[..., ::32, ::32].float()).all()),
             'needed_region': roi_on, 'flop_skipped_frac': (skipped / tile_flop) if roi_on else 0.0,
             'algorithmic_tflops': ntiles * tile_flop / dt / 1e12,

@@ -686,6 +686,7 @@ class Predictor:
 
         state = {'host_out': None, 'out_dev': None, 'shm': None}
         downs = []
+        call_s = []                                                       # wall time of every in-place tile call on the issuing thread
         # no tile copy / crop copy around the native fp32 model (E3_PREDICTOR_NO_INPLACE=1: A/B switch)
         in_place = (self._native and _ROI and self._post is None and self.augmentations is None and not self.apply_argmax_after_tta
                     and self.dtype == torch.float32 and self.out_dtype == torch.float32 and hasattr(self.model, 'forward_tile')
@@ -749,8 +750,10 @@ class Predictor:
                             # multiple of the tile shape), what it would write there is never downloaded -- the needed-region forward does not compute it
                             # (the cfg-5 volume: 512 = 5.33 x 96, 2048 = 10.67 x 192: 16 % of the kept voxels of all tiles lie outside; E3_PREDICTOR_NO_CLIP=1: A/B)
                             keep = [int(t) if _NO_CLIP else max(1, min(int(t), int(r) - int(lo_))) for t, r, lo_ in zip(tile, real, olo)]
+                            t_call = time.perf_counter()
                             self.model.forward_tile(inp_padded, ilo, [h - l for l, h in zip(ilo, ihi)], state['out_dev'], olo,
                                                     [(int(o), int(o) + kp) for o, kp in zip(ov, keep)], softmax=self._softmax)
+                            call_s.append(time.perf_counter() - t_call)
                             continue
                         except NotImplementedError:
                             in_place = False
@@ -778,9 +781,13 @@ class Predictor:
         # where the wall time went (bench.py reports it): the compute stream's span from the first tile to the last one (it includes waits for
         # uploads), the host time to issue the tile loop, and the wall time around both
         # (issue_s is wall time of the issuing thread INCLUDING the time it is blocked -- on the bounded launch queue of a busy GPU, on the upload workers;
-        # issue_cpu_s is the CPU time that thread actually spent: what the host side of the tile loop costs)
+        # issue_cpu_s is that thread's CPU time, which still contains the runtime's spinning on a full queue; tile_call_s is what ONE tile costs the host when
+        # nothing blocks it: the lower quartile of the tile calls' wall times -- the first dozens of tiles are issued into an empty queue)
         self.last_timing = {'wall_s': time.perf_counter() - t_start, 'issue_s': t_issued - t_start, 'issue_cpu_s': cpu_issued - cpu_start,
                             'compute_stream_s': (ev_first.elapsed_time(ev_last) / 1e3) if mine else 0.0, 'tiles': len(mine) * ntx}
+        if call_s:
+            srt = sorted(call_s)
+            self.last_timing.update(tile_call_s=srt[len(srt) // 4], tile_call_min_s=srt[0], tile_call_median_s=srt[len(srt) // 2])
         if world > 1:
             torch.distributed.barrier()               # every rank's rows are in the shared buffer
             state['shm'].unlink_if_owner()            # the mapping stays valid; the name disappears

@@ -29,8 +29,8 @@ GROUPS = {
     'b16_on_fp32_kernels_plain_predictor': (dict(E3_NO_BF16='1', E3_PREDICTOR_NO_PIPELINE='1'),
                                             ['tests/test_predictor.py', 'tests/test_bf16_gpu.py', '-k', 'predictor or fixture or autocast']),
     # data-parallel: overlapped bucket with a CU reserve as GradSync's default; Predictor: the runtime's pageable copies; elementwise passes: non-temporal
-    # loads from 1 MB on  (E3_STAGE_BATCH is a compile-time constant of conv_mfma.hip, not an environment switch)
-    'dp_overlap_pageable_copies': (dict(E3_DP_OVERLAP='1', E3_DP_CU_RESERVE='8', E3_PREDICTOR_NO_PINNED='1', E3_EW_NT_MB='1'),
+    # loads from 1 MB on; weights packed again for every tile  (E3_STAGE_BATCH is a compile-time constant of conv_mfma.hip, not an environment switch)
+    'dp_overlap_pageable_copies': (dict(E3_DP_OVERLAP='1', E3_DP_CU_RESERVE='8', E3_PREDICTOR_NO_PINNED='1', E3_EW_NT_MB='1', E3_NO_PACK_REUSE='1'),
                                    ['tests/test_dataparallel_gpu.py', 'tests/test_predictor.py', 'tests/test_unet_gpu.py', '-k',
                                     'two_rank or pipelined or needed_region or in_place or train_step_matches_reference']),
     # F(2x2x4) Winograd tiles (conv_wino4.hip; by default the eval-mode forward and the data gradients of grids with >= 512 bricks): OFF everywhere ...
