@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         const bool used = rs < 6 && zw < 18;
         const int q = qd ^ ((rs % 3) & 1);
         col_rel = (unsigned)(((zh * W + zw) * xl + 4 * q) * 4);
+        if (E3_W4_ABL & 1024) col_rel = (unsigned)(((zh * W + 1) * xl + zw * 8 + 4 * q) * 4);      // (timing only: a quarter's 16-byte pieces as contiguous runs of the h row)
         col_bits = used ? (1u << (6 + zh)) | (1u << (12 + zw)) : 0xffffffffu;     // (all-ones never matches: the unused slots get zeros)
         // read plan of lane (tile tl, channel pair kk): window rows h = 0, 1 have zh/2 = tth, rows 2, 3 have tth + 1 (the XOR of the 16-byte half follows)
         const int ftl = fl & 15, fkk = fl >> 4, fttd = ftl >> 3, ftth = (ftl >> 2) & 1, fttw = ftl & 3;
@@ -199,8 +200,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
     // DMA piece `plane` (of this wave's quarter) of the staging cursor's unit into stage buffer `buf`: the plane's validity is the size of its
     // descriptor (scalar work only), the lane's validity the out-of-range offset
     auto issue_dma = [&](unsigned voff, float* buf, int plane) {
-        if (E3_W4_ABL & 1) return;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S_xorg), 0, ((S_mask >> plane) & 1u) ? 0x7fffffff : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S_xorg), 0, (((S_mask >> plane) & 1u) && !(E3_W4_ABL & 1)) ? 0x7fffffff : 0, 0x00020000);      // (ablation 1: every request out of range -- issued, answered with zeros, no traffic)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_v)(buf + plane * V_RPLANE + wave * 256), 16, voff, (int)(plane * plane_xb) + S_c * 32, 0, 0);
     };
     auto stage_voff = [&]() { return ((S_mask & col_bits) == col_bits) ? col_rel : OOB; };
