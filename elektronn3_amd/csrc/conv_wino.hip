@@ -405,7 +405,11 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
     int a_dst = col_on ? plane_slot(czh, czw, cq) : (((tid - W_LH * W_LW * 2) / 10) * W_CLASS + 27 + ((tid - W_LH * W_LW * 2) % 10) / 2) * 8 + 4 * (tid & 1);
     // staging: byte offset of the thread's halo column inside a d-plane relative to the brick's halo origin, and the two bits of the
     // brick's validity mask (6 d bits | 6 h bits | 18 w bits) it needs (all-ones never matches: threads without a column load zeros)
+#ifdef E3_WINO_ABL_CONTIG      // developer builds, timing only (wrong data): a halo row's 32-byte pieces as one contiguous run (what channel-chunked planes would give)
+    const unsigned col_rel = (unsigned)(((czh * W + 1) * xl + czw * 8 + 4 * cq) * 4);
+#else
     const unsigned col_rel = (unsigned)(((czh * W + czw) * xl + 4 * cq) * 4);
+#endif
     const unsigned col_bits = col_on ? (1u << (6 + czh)) | (1u << (12 + czw)) : 0xffffffffu;
     float m1 = -1.f;
     asm volatile("" : "+s"(m1));
@@ -1212,6 +1216,7 @@ int wino_stats_parts(int N, int D, int H, int W, int Cin, int ncols, int flags) 
 int launch_conv3_wino(ConvArgs a, hipStream_t s) {
     const int lay = conv_wino_layout(a.flags, a.D, a.H, a.W, a.Cin, a.Ncols, a.splitk);
     if (lay == 2) return launch_conv3_wino4(a, s);
+    E3_REQUIRE(!a.x_chunk, E3_ERR_UNSUPPORTED, "channel-chunked input: F(2x2x4) Winograd kernel only");
     a.tilesD = cdiv(a.D, 4); a.tilesH = cdiv(a.H, 4); a.tilesW = cdiv(a.W, 16);
     a.o_td = a.o_th = a.o_tw = 0;
     if (a.box_hi[0] > 0) {      // needed region: the bricks that meet the box

@@ -66,8 +66,10 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
     // occupying SGPRs across the chunk loop
     typedef const __attribute__((address_space(4))) ConvArgs* KArgs;
     auto KA = []() -> KArgs { KArgs q = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(q)); return q; };
-    const int D = a.D, H = a.H, W = a.W, xl = a.x_ldc;
+    // channel-chunked input (ConvArgs::x_chunk): a voxel's row is the 8 channels of ONE chunk (xl = 8) and the chunks are x_chunk floats apart
+    const int D = a.D, H = a.H, W = a.W, xl = a.x_chunk ? 8 : a.x_ldc;
     const unsigned plane_xb = (unsigned)((size_t)H * W * xl * 4);
+    const int chunk_xb = a.x_chunk ? (int)(a.x_chunk * 4) : 32;
 
     // ---- staging by LDS-DMA (1 KB per wave-instruction, lane i lands at base + 16 i): a raw d-plane of the halo is four such pieces; wave w
     // issues quarter w of each of the six planes.  The layout of a plane is produced on the SOURCE side: lane i of quarter w asks for the 16
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
     // descriptor (scalar work only), the lane's validity the out-of-range offset
     auto issue_dma = [&](unsigned voff, float* buf, int plane) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S_xorg), 0, (((S_mask >> plane) & 1u) && !(E3_W4_ABL & 1)) ? 0x7fffffff : 0, 0x00020000);      // (ablation 1: every request out of range -- issued, answered with zeros, no traffic)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_v)(buf + plane * V_RPLANE + wave * 256), 16, voff, (int)(plane * plane_xb) + S_c * 32, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_v)(buf + plane * V_RPLANE + wave * 256), 16, voff, (int)(plane * plane_xb) + S_c * chunk_xb, 0, 0);
     };
     auto stage_voff = [&]() { return ((S_mask & col_bits) == col_bits) ? col_rel : OOB; };
     f32x4 acc[24][2];
@@ -803,6 +805,8 @@ int launch_conv3_wino4(ConvArgs a, hipStream_t s) {
                "Winograd conv (F(2x2x4) tiles): views must be 16-byte aligned with channel counts that are multiples of 4");
     E3_REQUIRE(!(a.epi_scale && a.stats), E3_ERR_INVALID, "Winograd conv: statistics and the folded epilogue exclude each other");
     E3_REQUIRE(a.splitk <= 1 && !a.pro_scale, E3_ERR_INVALID, "Winograd conv (F(2x2x4) tiles): no split-K, no fused prologue");
+    E3_REQUIRE(!a.x_chunk || (a.x_chunk == (size_t)a.N * a.D * a.H * a.W * 8 && chunked_layout_ok((size_t)a.N * a.D * a.H * a.W, a.Cin)), E3_ERR_INVALID,
+               "Winograd conv (F(2x2x4) tiles): bad channel-chunked input");
     constexpr int lds = V_LDS_FLOATS * 4;
     constexpr int lds_x = lds;
     static bool attr = false;

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                     if (APPLYPASS) { o[e] = ok[u] ? gi[e] * (dz - c1[e] - xh * c2[e]) - (k1[e] + xh * k2[e]) : 0.f; s3[e] += o[e]; }
                     else { s1[e] += dz; s2[e] += dz * xh; }
                 }
-                if (APPLYPASS && ok[u]) *reinterpret_cast<f32x4*>(a.dx + (v0 + u * vstride) * a.dx_ldc + 4 * q) = o;
+                if (APPLYPASS && ok[u]) *reinterpret_cast<f32x4*>(a.dx_chunk ? a.dx + (size_t)(q >> 1) * a.dx_chunk + (v0 + u * vstride) * 8 + 4 * (q & 1) : a.dx + (v0 + u * vstride) * a.dx_ldc + 4 * q) = o;
                 if (hgrad && ok[u] && q == 0) {
 #pragma unroll
                     for (int co = 0; co < HC; ++co) dbacc[co] += gys[u][co];
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdArgs a) {
                             if (APPLYPASS) { o[e] = gi[e] * (dz - c1[e] - xh * c2[e]) - (k1[e] + xh * k2[e]); s3[e] += o[e]; }
                             else { s1[e] += dz; s2[e] += dz * xh; }
                         }
-                        if (APPLYPASS) *reinterpret_cast<f32x4*>(a.dx + v * a.dx_ldc + 4 * q) = o;
+                        if (APPLYPASS) *reinterpret_cast<f32x4*>(a.dx_chunk ? a.dx + (size_t)(q >> 1) * a.dx_chunk + v * 8 + 4 * (q & 1) : a.dx + v * a.dx_ldc + 4 * q) = o;
                     }
                 }
             }

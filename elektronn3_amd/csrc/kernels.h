@@ -44,6 +44,10 @@ struct ConvArgs {
     // split-K (Winograd 3x3x3 only, conv_wino_splitk()): the grid is splitk x the bricks; split s reads the channels [s * sk_x, (s + 1) * sk_x)
     // (Cin = sk_x), its own packed weights (wt + s * sk_w) and writes its partial sums to y + s * sk_y.  bias / stats / epilogue must be off.
     int splitk; int sk_x; unsigned sk_w; size_t sk_y;
+    // channel-chunked input (conv_wino4.hip only; 0 = the usual [voxel][x_ldc] rows): x is laid out [Cin / 8][N][D][H][W][8], x_chunk = floats between two
+    // chunk planes (= N D H W 8).  A halo row of one 8-channel chunk is then ONE contiguous run instead of 32 bytes out of every voxel's row (the staging's
+    // line efficiency, profiles/r05_w4_phases.md section 5).  Written by the APPLY pass of the BatchNorm backward (BnBwdArgs::dx_chunk).
+    size_t x_chunk;
     // needed region (Winograd 3x3x3 kernels only, inference): when box_hi[0] > 0 only the bricks that meet the voxel box [box_lo, box_hi)
     // (d, h, w) are computed -- the rest of y is left untouched.  The other kernels ignore it and compute everything.  No statistics.
     int box_lo[3], box_hi[3];
@@ -219,6 +223,7 @@ int launch_adamw(int n_tensors, void* const* params, void* const* grads, const l
 struct WgradArgs {
     const float* x; int x_ldc; int Cin;     // conv input activation view
     const float* dy; int dy_ldc; int Cout;  // gradient w.r.t. conv output
+    size_t dy_chunk;                        // != 0 (wgrad_wino.hip only): dy is channel-chunked, [Cout / 8][N][D][H][W][8], dy_chunk = N D H W 8 (ConvArgs::x_chunk)
     float* part;                            // [splits][T][CoPad][CiPad]
     int N, D, H, W;
     int CoPad, CiPad, splits;
@@ -226,6 +231,9 @@ struct WgradArgs {
     int Do, Ho, Wo, sd;
     int cu_reserve;                         // as ConvArgs::cu_reserve: the one-round kernels split the voxels over 256 - cu_reserve workgroups (3x3x3 Winograd kernel only)
 };
+// channel-chunked tensors ([C / 8][N][D][H][W][8]: ConvArgs::x_chunk, WgradArgs::dy_chunk, BnBwdArgs::dx_chunk): the chunk planes are addressed through
+// 32-bit buffer offsets, so the whole tensor has to stay below 2 GiB
+inline bool chunked_layout_ok(size_t vox, int C) { return C % 8 == 0 && vox * (size_t)C * 4 < 0x7fffffffu; }
 int wgrad_splits(ConvKind kind, int N, int D, int H, int W, int Cin, int Cout, int cu_reserve = 0);
 int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s);
 // Winograd F(3x3x3, 2x2x2) variant for CONV_K3 (wgrad_wino.hip): same bricks, splits and partial-slab layout
@@ -278,6 +286,7 @@ struct BnBwdArgs {
     int parts;
     const float* coef;                    // apply pass: [4][C] = (c1 = sum dz / n, c2 = sum dz*xhat / n, k1, k2): dx = g*istd*(dz - c1 - xh*c2) - (k1 + xh*k2)
     float* dx; int dx_ldc;                // apply pass output
+    size_t dx_chunk;                      // != 0: the apply pass writes dx channel-chunked, [C / 8][N][D][H][W][8] (dx_chunk = N D H W 8), for consumers that stage 8-channel chunks
     size_t nt_bytes;                      // set by the launcher: tensors above this size are read with non-temporal loads
     // non-pool path, g1 == nullptr: the incoming gradient is that of the 1x1x1 head, g[v][c] = sum_co head_dy[n][co][sp] * head_w[co][c],
     // recomputed from the (tiny) NCDHW logits gradient instead of being written by conv_final_bwd and re-read twice

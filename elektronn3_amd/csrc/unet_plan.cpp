@@ -1221,6 +1221,14 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
         // -- BN + ReLU (+ pool, + skip) backward -> dxr = gradient w.r.t. the raw conv output
         // (residual unit: the raw tensor is conv2(..) + shortcut; its gradient also feeds the shortcut and must outlive the ConvBlock's first conv)
         float* dxr = u.res_in >= 0 ? B.gres[j] : B.g2[j];
+        // Channel-chunked dxr ([Cout / 8][voxel][8]) where BOTH its consumers stage 8-channel chunks of it -- the F(2x2x4) data gradient and the Winograd
+        // weight gradient: a halo row of a chunk is then one contiguous run instead of 32 bytes out of every voxel's row (measured on the staging of
+        // conv3_wino4_kernel: profiles/r05_w4_phases.md section 5).  The APPLY pass below writes it that way at no cost.  E3_NO_CHUNKED=1: A/B switch.
+        static const bool no_chunked = getenv("E3_NO_CHUNKED") != nullptr;
+        const int dgrad_flags = ((bucket_event != nullptr && event_done && reserve() == 0) ? CF_NO_PERSIST : 0) | w4d | (bnred_parts[(size_t)k] ? (CF_BNRED | CF_WINO4) : 0);
+        const bool dz_chunked = !no_chunked && !u.is_up && !u.planar && u.cin >= 8 && u.res_in < 0 && !vcrop && (k > 0 || dx) && B.wpk_d[k] && bwd_split(k) == 1 &&
+                                wgrad_use_wino(CONV_K3) && chunked_layout_ok(lo.vox, u.cout) && conv_wino_layout(dgrad_flags, ci.D, ci.H, ci.W, u.cout, u.cin, 1) == 2;
+        const size_t dz_chunk = dz_chunked ? lo.vox * 8 : 0;
         bool fuse_first = false; SmallWgradFuse first_fuse{};
         {
             BnBwdArgs a{};
@@ -1251,7 +1259,7 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
             else if (pooled_unit) { a.g1 = cfg.merge_add ? B.dcat[j] : B.dcat[j] + u.cout; a.g1_ldc = cfg.merge_add ? u.cout : 2 * u.cout; a.gpool = g; a.a = b.act; a.a_ldc = b.act_ldc; a.pooled = B.pooled[j]; }
             else { a.g1 = g; a.g1_ldc = g_ldc; }
             a.kd = kd; a.N = N; a.D = lo.D; a.H = lo.H; a.W = lo.W; a.C = u.cout;
-            a.parts = bn_bwd_parts(lo.vox, u.cout); a.part = B.bnpart_u[k]; a.coef = B.small; a.dx = dxr; a.dx_ldc = u.cout;
+            a.parts = bn_bwd_parts(lo.vox, u.cout); a.part = B.bnpart_u[k]; a.coef = B.small; a.dx = dxr; a.dx_ldc = u.cout; a.dx_chunk = dz_chunk;
             if (!u.has_norm() && u.p_a >= 0) {   // no norm, but the PReLU slope gradient needs the REDUCE pass (its row 2)
                 RUN(launch_bn_bwd_reduce(a, s));
                 RUN(launch_prelu_dslope(a.part, a.parts, u.cout, B.small + 4 * u.cout, G(u.p_a), s));
@@ -1367,7 +1375,7 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
             const int taps = u.planar ? 9 : 27;
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
             WgradArgs a{};
-            a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dyu; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = B.slab_u[k] ? B.slab_u[k] : B.slab;
+            a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dyu; a.dy_ldc = u.cout; a.dy_chunk = dz_chunk; a.Cout = u.cout; a.part = B.slab_u[k] ? B.slab_u[k] : B.slab;
             a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
             a.cu_reserve = reserve();      // (fewer, longer splits: the slab sized for the full chip is large enough)
             a.splits = wgrad_splits(kind, N, ci.D, ci.H, ci.W, u.cin, u.cout, a.cu_reserve);
@@ -1430,6 +1438,7 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
             // one-brick-per-workgroup kernel degrades by the fraction of CUs taken instead of needing a second round
             a.cu_reserve = reserve();
             a.flags = ((bucket_event != nullptr && event_done && a.cu_reserve == 0) ? CF_NO_PERSIST : 0) | w4d;
+            a.x_chunk = dz_chunk;
             if (bnred_parts[(size_t)k]) {      // this launch also takes the REDUCE sums of unit k - 1's BatchNorm backward
                 const UnitBufs& b0 = B.ub[k - 1];
                 a.flags |= CF_BNRED | CF_WINO4;

@@ -327,6 +327,7 @@ int wgrad_splits(ConvKind kind, int N, int D, int H, int W, int Cin, int Cout, i
 
 int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s) {
     E3_REQUIRE(a.Cin % 4 == 0 && a.Cout % 4 == 0 && a.x_ldc % 4 == 0 && a.dy_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "wgrad needs channel counts that are multiples of 4");
+    E3_REQUIRE(!a.dy_chunk || (kind == CONV_K3 && wgrad_use_wino(kind)), E3_ERR_UNSUPPORTED, "channel-chunked dy: Winograd 3x3x3 weight gradient only");
     if (kind == CONV_POINT && upconv_wgrad_ok(a.Cin, a.Cout, a.sd)) return launch_upconv_wgrad(a, s);   // upconv_gemm.hip
     if (wgrad_use_wino2d(kind, a.Cin, a.Cout)) return launch_wgrad_wino2d(a, s);                        // wgrad_wino2d.hip
     int TD, TH; wgeo(kind, TD, TH);

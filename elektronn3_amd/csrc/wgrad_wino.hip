@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
     // one descriptor per sample (rebuilt per brick, scalar work): offsets stay below 2^31 for any batch size
     __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
     __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, 0x7fffffff, 0x00020000);
-    const size_t samp_x = (size_t)a.D * a.H * a.W * a.x_ldc, samp_g = (size_t)a.D * a.H * a.W * a.dy_ldc;
+    const int gl = a.dy_chunk ? 8 : a.dy_ldc;
+    const size_t samp_x = (size_t)a.D * a.H * a.W * a.x_ldc, samp_g = (size_t)a.D * a.H * a.W * gl;
     // lane constants: wave-piece (it*4 + wave), lane -> piece idx -> (voxel, 4-channel group).  Validity of a halo voxel is
     // separable, so a brick only needs one 28-bit scalar mask (4 d bits | 6 h bits | 18 w bits) and each piece the
     // constant pattern of its three bits: 4 VALU per piece and brick, no branches.
@@ -82,7 +83,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
         const int ww = v & 15, hh = (v >> 4) & 3, dd = v >> 6;
         const bool cok = co0 + 4 * q < a.Cout;
         gpm[it] = cok ? (1u << dd) | (1u << (4 + hh)) | (1u << (10 + ww)) : 0xffffffffu;
-        grel[it] = (unsigned)((((dd * a.H + hh) * a.W + ww) * a.dy_ldc + co0 + 4 * q) * 4);
+        // (channel-chunked dy, WgradArgs::dy_chunk: the piece's 4 channels are half of an 8-channel chunk plane's voxel row)
+        grel[it] = a.dy_chunk ? (unsigned)(((size_t)((co0 + 4 * q) >> 3) * a.dy_chunk + (size_t)(((dd * a.H + hh) * a.W + ww) * 8 + 4 * (q & 1))) * 4)
+                              : (unsigned)((((dd * a.H + hh) * a.W + ww) * a.dy_ldc + co0 + 4 * q) * 4);
     }
 
     // ---- read plan.  D pass of Winograd row pd = wave: X: 0: x0 - x2, 1: x1 + x2, 2: x2 - x1, 3: x1 - x3;  Y: y0, y0+y1, y0-y1, y1
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
         // the descriptors start at the brick's halo origin (possibly in front of the tensor: only lanes whose voxel is inside the volume
         // ever form an address from them), so a lane's offset is its constant position inside the halo -- no per-brick vector arithmetic
         const long long xorg = (long long)nb * (long long)samp_x + ((((long long)(d0 - 1) * a.H + h0 - 1) * a.W + w0 - 1) * a.x_ldc);
-        const long long gorg = (long long)nb * (long long)samp_g + ((((long long)d0 * a.H + h0) * a.W + w0) * a.dy_ldc);
+        const long long gorg = (long long)nb * (long long)samp_g + ((((long long)d0 * a.H + h0) * a.W + w0) * gl);
         x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + xorg, 0, 0x7fffffff, 0x00020000);
         g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy) + gorg, 0, 0x7fffffff, 0x00020000);
     };
@@ -346,6 +349,8 @@ bool wgrad_use_wino(ConvKind kind) {
 int launch_wgrad_wino(WgradArgs a, int tD, int tH, int tW, int tps, int co_tiles, int ci_tiles, int splits, hipStream_t s) {
     E3_REQUIRE((size_t)a.D * a.H * a.W * (size_t)(a.x_ldc > a.dy_ldc ? a.x_ldc : a.dy_ldc) * 4 < 0x7fffffffu, E3_ERR_UNSUPPORTED,
                "Winograd wgrad: one sample beyond 2 GiB (32-bit buffer offsets); set E3_WGRAD_NO_WINO=1");
+    E3_REQUIRE(!a.dy_chunk || (a.dy_chunk == (size_t)a.N * a.D * a.H * a.W * 8 && chunked_layout_ok((size_t)a.N * a.D * a.H * a.W, a.Cout)), E3_ERR_INVALID,
+               "Winograd wgrad: bad channel-chunked dy");
     constexpr int lds_bytes = G_LDS_FLOATS * 4;
     static bool set = false;
     if (!set) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); set = true; }

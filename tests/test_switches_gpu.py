@@ -44,6 +44,10 @@ GROUPS = {
     # the REDUCE pass of the BatchNorm backward inside the F(2x2x4) data gradients (default from 32 MB tensors on) wherever a grid tiles, small ones included
     'bnred_in_the_data_gradient': (dict(E3_WINO4_MIN='1', E3_BNRED_MIN_MB='0'),
                                    ['tests/test_unet_gpu.py', '-k', 'train_step_matches_reference or full_size_cfg2 or full_size_properties or forward_with_loss or digest']),
+    # ... with the data gradients' input in plain [voxel][C] rows instead of channel-chunked planes (E3_NO_CHUNKED=1; the chunked form is the default wherever the
+    # F(2x2x4) data gradient and the Winograd weight gradient both read the tensor, so the two groups above run it on every grid)
+    'wino4_plain_rows': (dict(E3_WINO4_MIN='1', E3_BNRED_MIN_MB='0', E3_NO_CHUNKED='1'),
+                         ['tests/test_unet_gpu.py', '-k', 'train_step_matches_reference or full_size_cfg2 or full_size_properties or forward_with_loss or digest']),
     # ... and for the TRAINING forward with its statistics as well (E3_WINO4=2; not a default: DESIGN.md section 3a) -- per-op parity and the property tests
     'wino4_training_forward': (dict(E3_WINO4='2', E3_WINO4_MIN='1'), ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', '-k', 'conv3 or full_size_properties or forward_with_loss or eval_forward']),
 }
