@@ -114,7 +114,7 @@ def _get_scratch(device, nbytes, token=None):
 
 def _frozen_token(module, plan, dims, tens):
     """Token of an inference forward inside ``module.frozen_weights()`` (None outside a scope): scope, plan, shape and the parameter table's addresses."""
-    scope = module.__dict__.get('_frozen_scope')
+    scope = module.__dict__.get('_frozen_scope') if module is not None else None      # (the registered operator of the scripted module has no module at hand)
     if scope is None:
         return None
     return (scope, plan.handle.value if hasattr(plan.handle, 'value') else int(plan.handle), tuple(dims), tuple(t.data_ptr() for t in tens))
