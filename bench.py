@@ -73,7 +73,7 @@ def needed_region_flops(tile_in, overlap, n_blocks=4, sf=32, bricks=((4, 4, 16),
     """(forward FLOP of one tile, FLOP the needed-region forward skips, matrix FLOP the fp32 kernels EXECUTE for what is not skipped): the Predictor keeps
     the central crop of a tile, so the decoder's 3x3x3 convs only compute the bricks (fp32 Winograd: 4 x 4 x 16 voxels; 16-bit kernels: 4 x 4 x 32 at level
     0, 2 x 8 x 16 below) that crop depends on -- the box grows by one voxel per conv and halves per transposed conv on the way back through the decoder
-    (elektronn3_amd/csrc/unet_plan.cpp, e3_unet_forward_roi).  fp32: levels whose per-sample grid has >= 512 workgroup-bricks run the eval-mode forward on
+    (elektronn3_amd/csrc/unet_plan.cpp, e3_unet_forward_roi).  fp32: levels whose per-sample grid has >= 256 workgroup-bricks run the eval-mode forward on
     F(2x2x4) Winograd tiles (csrc/conv_wino4.hip: 96 multiplies per 16 outputs = 96/432 of the direct count; bricks start at multiples of 4 along W and the
     box of a layer in FRONT of such a conv grows to the W tile grid), the others on F(2x2x2) (64/216)."""
     vox = tile_in[0] * tile_in[1] * tile_in[2]
@@ -85,7 +85,7 @@ def needed_region_flops(tile_in, overlap, n_blocks=4, sf=32, bricks=((4, 4, 16),
     def factor(lvl):
         d = [t >> lvl for t in tile_in]
         nblk1 = -(-d[0] // 4) * -(-d[1] // 4) * -(-d[2] // 16) * ((sf << lvl) // 32)
-        return F224 if (fp32 and nblk1 >= 512) else F222
+        return F224 if (fp32 and nblk1 >= 256) else F222
     conv_flop = {}                                                        # level -> 3x3x3 conv FLOP of the whole tile (encoder + decoder)
     for lvl in range(n_blocks):
         d = [t >> lvl for t in tile_in]

@@ -768,7 +768,7 @@ int wino4_stats_parts(int N, int D, int H, int W, int ncols) {
 // head of this file); a split-K launch, the timing flag and views that rule out 16-byte accesses keep F(2x2x2).
 int conv_wino_layout(int flags, int D, int H, int W, int K, int ncols, int splitk) {
     static const int mode = getenv("E3_WINO4") ? atoi(getenv("E3_WINO4")) : 1;      // 0: never (A/B switch), 1: where the caller allows it, 2: every eligible launch (tests)
-    static const size_t minblk = getenv("E3_WINO4_MIN") ? (size_t)atol(getenv("E3_WINO4_MIN")) : 512;
+    static const size_t minblk = getenv("E3_WINO4_MIN") ? (size_t)atol(getenv("E3_WINO4_MIN")) : 256;      // (measured 512 / 256 / 128: 11.23 / 11.21 / 11.21 ms per step, Predictor tile 7.03 / 6.98 / 6.98 ms)
     if (splitk > 1 || (flags & 1024) || (ncols & 3) || (K & 7)) return 0;
     if (mode <= 0 || (mode == 1 && !(flags & CF_WINO4))) return 0;
     const size_t nblk1 = (size_t)wino4_bricks(1, D, H, W) * ((ncols + 31) / 32);

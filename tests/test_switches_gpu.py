@@ -33,7 +33,7 @@ GROUPS = {
     'dp_overlap_pageable_copies': (dict(E3_DP_OVERLAP='1', E3_DP_CU_RESERVE='8', E3_PREDICTOR_NO_PINNED='1', E3_EW_NT_MB='1', E3_NO_PACK_REUSE='1'),
                                    ['tests/test_dataparallel_gpu.py', 'tests/test_predictor.py', 'tests/test_unet_gpu.py', '-k',
                                     'two_rank or pipelined or needed_region or in_place or train_step_matches_reference']),
-    # F(2x2x4) Winograd tiles (conv_wino4.hip; by default the eval-mode forward and the data gradients of grids with >= 512 bricks): OFF everywhere ...
+    # F(2x2x4) Winograd tiles (conv_wino4.hip; by default the eval-mode forward and the data gradients of grids with >= 256 bricks): OFF everywhere ...
     'wino4_off': (dict(E3_WINO4='0', E3_NO_BNRED_FUSE='1'), ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', 'tests/test_predictor.py', '-k',
                                        'conv3 or train_step_matches_reference or eval_forward or full_size_properties or forward_with_loss or forward_roi or needed_region or full_size_cfg2 or predictor']),
     # ... and on every grid that has a brick (ragged grids, workgroups without a brick, one brick per workgroup): data gradients, the folded eval epilogue
