@@ -299,35 +299,51 @@ __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const BnBwdB16Args a) {
         // (128 bytes at C = 32) per (dz, dy), where the one-lane-per-window form asks for half cache lines at a 128-byte stride -- the
         // fp32 kernel, whose voxels are whole lines, runs the same loop at 5 TB/s, this one ran at 1.7-2.2.  "First arg-max wins" across
         // the pair: each lane finds its first match (dz, dy), the pair compares 2 * k + dx through one shuffle.
+        // Software-pipelined: the ten 16-byte loads of the lane's NEXT window are in flight -- kept as raw bf16 registers, 40 instead of 80 -- while the current
+        // one is computed.  (The kernel holds 220 registers = two waves per SIMD; without the look-ahead each wave alternated between a load phase and ~1100
+        // VALU instructions with nothing in flight: 2.9 TB/s, VALU 11 % busy, SQ_WAIT_ANY 0.6 -- tools/pmc_valu.sh.  With the look-ahead: APPLY 139 -> 123 us,
+        // REDUCE 125 -> 104 us on the level-0 tensor; forcing three waves per SIMD instead spills 46 registers and is slower.)
         const int dxl = (int)((i00 / Q) & 1);
-        for (size_t u0 = i00 / (2 * Q); u0 < (units + vstride / 2 - 1) / (vstride / 2) * (vstride / 2); u0 += vstride / 2) {     // (all lanes of a pair iterate together)
-            const bool uok = active && u0 < units;
-            size_t r = uok ? u0 : 0;
-            const int pw = r % Wp; r /= Wp; const int ph = r % Hp; r /= Hp; const int pd = r % Dp; const int n = r / Dp;
-            const size_t pidx = ((((size_t)n * Dp + pd) * Hp + ph) * Wp + pw) * a.C + 8 * q;
-            const int w = pw * 2 + dxl;
-            f8 gp, pm, xv[4], g[4]; bool ok[4];
-            gp = ld8(a.gpool + pidx); pm = ld8(a.pooled + pidx);
+        const size_t step = vstride / 2;
+        const size_t uend = (units + step - 1) / step * step;      // (all lanes of a pair iterate together)
+        struct Win { int pw, ph, pd, n; bool uok; };
+        struct Raw { u16x8 x[4], g[4], gp, pm; };
+        auto decode = [&](size_t u0) {
+            Win w; w.uok = active && u0 < units;
+            size_t r = w.uok ? u0 : 0;
+            w.pw = (int)(r % Wp); r /= Wp; w.ph = (int)(r % Hp); r /= Hp; w.pd = (int)(r % Dp); w.n = (int)(r / Dp);
+            return w;
+        };
+        auto okk = [&](const Win& w, int k) { return w.uok && (k >> 1) < kd && w.pd * kd + (k >> 1) < a.D && w.ph * 2 + (k & 1) < a.H && w.pw * 2 + dxl < a.W; };
+        auto vox = [&](const Win& w, int k) { return (((size_t)w.n * a.D + (w.pd * kd + (k >> 1))) * a.H + (w.ph * 2 + (k & 1))) * a.W + (w.pw * 2 + dxl); };
+        auto load = [&](const Win& w, Raw& R) {
+            const size_t pidx = ((((size_t)w.n * Dp + w.pd) * Hp + w.ph) * Wp + w.pw) * a.C + 8 * q;
+            R.gp = *reinterpret_cast<const u16x8*>(a.gpool + pidx); R.pm = *reinterpret_cast<const u16x8*>(a.pooled + pidx);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int d = pd * kd + (k >> 1), h = ph * 2 + (k & 1);
-                ok[k] = uok && (k >> 1) < kd && d < a.D && h < a.H && w < a.W;
-                const size_t v = ok[k] ? (((size_t)n * a.D + d) * a.H + h) * a.W + w : 0;
-                xv[k] = ld8(a.x + v * a.x_ldc + 8 * q);
-                if (a.g1) g[k] = ld8(a.g1 + v * a.g1_ldc + 8 * q);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) g[k].v[e] = 0.f;
-                }
+                const size_t v = okk(w, k) ? vox(w, k) : 0;
+                R.x[k] = *reinterpret_cast<const u16x8*>(a.x + v * a.x_ldc + 8 * q);
+                if (a.g1) R.g[k] = *reinterpret_cast<const u16x8*>(a.g1 + v * a.g1_ldc + 8 * q);
+                else R.g[k] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
+        };
+        Win wc = decode(i00 / (2 * Q));
+        Raw Rc; load(wc, Rc);
+        for (size_t u0 = i00 / (2 * Q); u0 < uend; u0 += step) {
+            Win wn = wc; Raw Rn = Rc;
+            if (u0 + step < uend) { wn = decode(u0 + step); load(wn, Rn); }
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ok[k] = okk(wc, k);
             unsigned code = 0;                       // per channel: 2 * (first matching k) + dx, 15 = no match in this column
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 unsigned c = 15u;
+                const float pme = bf2f(Rc.pm[e]);
 #pragma unroll
                 for (int k = 3; k >= 0; --k) {
-                    const float av = round_bf(fmaxf(__builtin_fmaf(xv[k].v[e], sc.v[e], sh.v[e]), 0.f));
-                    if (ok[k] && av == pm.v[e]) c = (unsigned)(2 * k + dxl);
+                    const float av = round_bf(fmaxf(__builtin_fmaf(bf2f(Rc.x[k][e]), sc.v[e], sh.v[e]), 0.f));
+                    if (ok[k] && av == pme) c = (unsigned)(2 * k + dxl);
                 }
                 code |= c << (4 * e);
             }
@@ -335,22 +351,23 @@ __global__ __launch_bounds__(256) void bn_bwd_b16_kernel(const BnBwdB16Args a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (!ok[k]) continue;
-                const int d = pd * kd + (k >> 1), h = ph * 2 + (k & 1);
-                const size_t v = (((size_t)n * a.D + d) * a.H + h) * a.W + w;
+                const size_t v = vox(wc, k);
                 f8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float z = __builtin_fmaf(xv[k].v[e], sc.v[e], sh.v[e]);
+                    const float xe = bf2f(Rc.x[k][e]);
+                    const float z = __builtin_fmaf(xe, sc.v[e], sh.v[e]);
                     const unsigned mine = (code >> (4 * e)) & 15u, theirs = (other >> (4 * e)) & 15u;
-                    float dA = g[k].v[e];
-                    if (mine == (unsigned)(2 * k + dxl) && mine < theirs) dA += gp.v[e];     // first arg-max of the window wins (ATen)
+                    float dA = bf2f(Rc.g[k][e]);
+                    if (mine == (unsigned)(2 * k + dxl) && mine < theirs) dA += bf2f(Rc.gp[e]);     // first arg-max of the window wins (ATen)
                     const float dz = z > 0.f ? dA : 0.f;
-                    const float xh = (xv[k].v[e] - mu.v[e]) * is.v[e];
+                    const float xh = (xe - mu.v[e]) * is.v[e];
                     if (APPLYPASS) { o.v[e] = round_bf(gi.v[e] * (dz - c1.v[e] - xh * c2.v[e])); s1.v[e] += o.v[e]; }
                     else { s1.v[e] += dz; s2.v[e] = __builtin_fmaf(dz, xh, s2.v[e]); }
                 }
                 if (APPLYPASS) st8(a.dx + v * a.dx_ldc + 8 * q, o);
             }
+            wc = wn; Rc = Rn;
         }
     } else {
         for (size_t u0 = i00 / Q; active && u0 < units; u0 += vstride) {
