@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         const KArgs e = KA();
         const float* const src = (tid >> 5) == 0 ? e->br_scale : ((tid >> 5) == 1 ? e->br_shift : ((tid >> 5) == 2 ? e->br_mean : e->br_invstd));
         const int ch = P.nt * 32 + (tid & 31);
-        (kst + 2 * 96)[tid] = ch < e->Ncols ? src[ch] : 0.f;
+        (kst + 2 * 96)[tid] = ch < (e->br_cols ? e->br_cols : e->Ncols) ? src[ch] : 0.f;      // (br_cols: the unit in front owns only the first channels of y -- a concat gradient)
     }
     {   // prologue: units 0 and 1 staged, the weights of unit 0 requested, the window of unit 0 read
         stage_brick();
@@ -374,6 +374,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         // same voxels as the output, its own channel stride) is requested here, in front of the output transform: the rows come from HBM, and requested next to
         // the stores they cost a memory round trip per brick (+18 % on the launch)
         f32x4 bx[8];
+        // (a concat gradient, br_cols < Ncols: the workgroups of the other column tiles ask for nothing -- every lane out of range -- and their sums are never written)
         if (BNRED) {
             const KArgs e = KA();
             const int bl = e->br_ldc;
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
             const size_t brem = (size_t)(D - d0) * plane_b * 4;
             const __amdgpu_buffer_rsrc_t x2_rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(e->br_x) + ((size_t)P_nb * D + d0) * plane_b, 0, (int)(brem < 0x7fffffffu ? brem : 0x7fffffffu), 0x00020000);
-            const bool cok_ = n0 + 4 * pc_ < e->Ncols && sgh_ < H;
+            const bool cok_ = n0 + 4 * pc_ < (e->br_cols ? e->br_cols : e->Ncols) && sgh_ < H;
             const unsigned b_off = (unsigned)(((sgh_ * W + sgw_) * bl + n0 + 4 * pc_) * 4);
             const unsigned bv[2] = {(cok_ && sgw_ < W) ? b_off : OOB, (cok_ && sgw_ + 1 < W) ? b_off : OOB};
 #pragma unroll
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     const KArgs e = KA();
-                    const int eN = e->Ncols;
+                    const int eN = e->br_cols ? e->br_cols : e->Ncols;
                     if (etid < 32 && n0 + etid < eN) {
                         const int cpc = etid >> 2, ce = etid & 3;
                         float t1 = 0.f, t2 = 0.f;
@@ -833,7 +834,8 @@ int launch_conv3_wino4(ConvArgs a, hipStream_t s) {
     static const bool no_head = getenv("E3_WINO_NO_HEAD") != nullptr, no_pool = getenv("E3_WINO_NO_POOL") != nullptr;      // A/B switches (shared with conv_wino.hip)
     if (a.flags & CF_BNRED) {
         E3_REQUIRE(a.br_x && a.br_scale && a.br_shift && a.br_mean && a.br_invstd && a.br_part && !a.stats && !a.epi_scale && !a.bias && a.box_hi[0] <= 0 &&
-                   (a.br_ldc & 3) == 0 && ((uintptr_t)a.br_x & 15) == 0 && a.cu_reserve == 0, E3_ERR_INVALID, "conv with the fused BatchNorm-backward reduction: bad arguments");
+                   (a.br_ldc & 3) == 0 && ((uintptr_t)a.br_x & 15) == 0 && a.cu_reserve == 0 && a.br_cols >= 0 && a.br_cols <= a.Ncols && (a.br_cols & 31) == 0, E3_ERR_INVALID,
+                   "conv with the fused BatchNorm-backward reduction: bad arguments");
         E3_REQUIRE(wino4_wgstats(nblk, a.ntiles, grid), E3_ERR_INVALID, "conv with the fused BatchNorm-backward reduction: the grid does not tile (conv_wino4_bnred_parts)");
         static bool attr2 = false;
         if (!attr2) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wino4_kernel<false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr2 = true; }

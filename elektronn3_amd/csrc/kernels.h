@@ -63,6 +63,9 @@ struct ConvArgs {
     // workgroup, br_part[row][3][Ncols] rows 0 and 1 like bn_bwd_kernel's, conv_wino4_bnred_parts() rows -- so the separate pass over (dA, x)
     // disappears.  Constant slope activations only.
     const float* br_x; int br_ldc; const float *br_scale, *br_shift, *br_mean, *br_invstd; float br_slope; float* br_part;
+    // br_cols != 0 (a multiple of 32): y holds dA of the unit in front only in its first br_cols channels (the data gradient of a decoder block's first conv writes
+    // the gradient of the whole concat buffer; the up-convolution's BatchNorm owns the first half); br_part rows are then [3][br_cols]
+    int br_cols;
     // inference: nn.MaxPool3d(2, ceil_mode=True) of the (folded-epilogue) output taken in the conv's epilogue -- a Winograd output tile IS a pooling
     // window -- into pool_out [N][ceil(D/2)][ceil(H/2)][ceil(W/2)][Ncols] (packed).  Honoured by the persistent Winograd kernel's transposed form and by conv_wino4.hip;
     // the launcher sets *pool_done = 1 when it took the pooling along (the caller runs the pooling pass otherwise).

@@ -1122,8 +1122,11 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
         for (int k1 = 1; k1 < nunits && !off && !valid && !cfg.attention && !cfg.resunet && cfg.normalization == 1 && reserve_req0 == 0; ++k1) {
             const ConvUnit& u1 = plan->units[k1];
             const ConvUnit& u0 = plan->units[k1 - 1];
-            if (u1.is_up || u1.planar || u1.cin < 8 || u1.to_cat || u1.res_in >= 0 || !B.wpk_d[k1] || bwd_split(k1) != 1) continue;
-            if (u0.is_up || u0.level != u1.level || !u0.has_norm() || u0.p_a >= 0 || u0.res_in >= 0 || u0.cout != u1.cin) continue;
+            // ... or the FIRST conv of a decoder block behind the transposed conv's BatchNorm: its data gradient is that of the whole concat buffer, whose first
+            // half is dA of that unit (ConvArgs::br_cols; the second half belongs to the encoder's pooled unit, whose dA also takes the pool's gradient)
+            const bool cat_pair = u1.to_cat && u0.is_up == 1 && !cfg.merge_add && 2 * u0.cout == u1.cin && u0.cout % 32 == 0;
+            if (u1.is_up || u1.planar || u1.cin < 8 || (u1.to_cat && !cat_pair) || u1.res_in >= 0 || !B.wpk_d[k1] || bwd_split(k1) != 1) continue;
+            if ((u0.is_up && !cat_pair) || u0.level != u1.level || !u0.has_norm() || u0.p_a >= 0 || u0.res_in >= 0 || (!cat_pair && u0.cout != u1.cin)) continue;
             if (u0.enc_last && u0.level < nb - 1) continue;      // (pooled unit: its dA is pool gradient + skip gradient)
             if (plan->rrelu_of(ActArg(cfg.act_slope), k1 - 1).seed != 0u || !(cfg.act_slope >= 0.f && cfg.act_slope <= 1.f)) continue;      // (constant-slope activations: ReLU, LeakyReLU, identity)
             const LevelDims& c1 = ND.u[k1].in;
@@ -1443,7 +1446,7 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
                 const UnitBufs& b0 = B.ub[k - 1];
                 a.flags |= CF_BNRED | CF_WINO4;
                 a.br_x = b0.raw; a.br_ldc = plan->units[k - 1].cout; a.br_scale = b0.scale; a.br_shift = b0.shift; a.br_mean = b0.mean; a.br_invstd = b0.invstd;
-                a.br_slope = cfg.act_slope; a.br_part = B.bnpart_u[k - 1];
+                a.br_slope = cfg.act_slope; a.br_part = B.bnpart_u[k - 1]; a.br_cols = u.to_cat ? plan->units[k - 1].cout : 0;
             }
             const int S = (kind == CONV_K3) ? bwd_split(k) : 1;
             const size_t gvox = (size_t)N * ci.D * ci.H * ci.W;
