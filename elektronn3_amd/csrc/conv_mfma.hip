@@ -452,6 +452,9 @@ int launch_conv_mfma(ConvKind kind, ConvArgs a, hipStream_t s) {
         E3_REQUIRE(vin * (size_t)a.x_ldc < ((size_t)1 << 31), E3_ERR_UNSUPPORTED, "conv input view exceeds 2^31 elements (32-bit offsets)");
     }
     if (a.G <= 0) a.G = 1;
+    E3_REQUIRE(!a.y_chunk || (kind == CONV_K3 && a.splitk <= 1 && conv_use_wino(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols)) ||
+                   (kind == CONV_POINT && (a.flags & CF_SCATTER_UP) && upconv_gemm_ok(a.flags, a.Cin, a.Cout, a.Ncols)), E3_ERR_UNSUPPORTED,
+               "channel-chunked output: F(2x2x4) Winograd kernel and the transposed-conv GEMM kernels only");
     E3_REQUIRE(!a.x_chunk || (kind == CONV_K3 && a.splitk <= 1 && conv_use_wino(kind, a.flags, a.N, a.D, a.H, a.W, a.Cin, a.Ncols)), E3_ERR_UNSUPPORTED,
                "channel-chunked input: F(2x2x4) Winograd kernel only");
     if (kind == CONV_POINT && upconv_gemm_ok(a.flags, a.Cin, a.Cout, a.Ncols)) return launch_upconv_gemm(a, s);   // upconv_gemm.hip

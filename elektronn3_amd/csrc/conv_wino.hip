@@ -1216,7 +1216,7 @@ int wino_stats_parts(int N, int D, int H, int W, int Cin, int ncols, int flags) 
 int launch_conv3_wino(ConvArgs a, hipStream_t s) {
     const int lay = conv_wino_layout(a.flags, a.D, a.H, a.W, a.Cin, a.Ncols, a.splitk);
     if (lay == 2) return launch_conv3_wino4(a, s);
-    E3_REQUIRE(!a.x_chunk, E3_ERR_UNSUPPORTED, "channel-chunked input: F(2x2x4) Winograd kernel only");
+    E3_REQUIRE(!a.x_chunk && !a.y_chunk, E3_ERR_UNSUPPORTED, "channel-chunked input / output: F(2x2x4) Winograd kernel only");
     a.tilesD = cdiv(a.D, 4); a.tilesH = cdiv(a.H, 4); a.tilesW = cdiv(a.W, 16);
     a.o_td = a.o_th = a.o_tw = 0;
     if (a.box_hi[0] > 0) {      // needed region: the bricks that meet the box

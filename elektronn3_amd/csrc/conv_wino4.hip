@@ -492,15 +492,21 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf)
                         *reinterpret_cast<f32x4*>(tA + od * (16 * 64 * 4) + (owi * 16 + etl) * 32 + (((2 * ekk + hf) ^ (etl & 7)) * 4)) = y[od][owi][hf];
-            const size_t yrem = (size_t)(D - d0) * plane_y * 4;
+            // channel-chunked output (ConvArgs::y_chunk, plain stores only): a voxel's row is the 8 channels of ONE chunk plane (ys = 8), the chunk planes
+            // are y_chunk floats apart -- the lane's two-piece half of a chunk goes to plane (n0 + 4 pc) / 8.  (The launcher bounds the whole tensor by 2^31 bytes.)
+            const size_t ychk = BNRED ? (size_t)0 : KA()->y_chunk;
+            const int ys = ychk ? 8 : yl;
+            const size_t plane_s = ychk ? (size_t)H * W * 8 : plane_y;
+            const size_t yrem = ychk ? (size_t)0x7fffffffu : (size_t)(D - d0) * plane_y * 4;
             const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(
-                KA()->y + ((size_t)P_nb * D + d0) * plane_y, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
+                KA()->y + ((size_t)P_nb * D + d0) * plane_s, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
             // elane (r = elane >> 3, position elane & 7) stores piece (elane & 7) ^ r of the rows v = 8 j + r: tile 8 (j & 1) + r = (td j & 1, th r >> 2, tw r & 3),
             // od = j >> 2, owi = (j >> 1) & 1
             const int r = elane >> 3, pc = (elane & 7) ^ r;
             const int sgh = h0 + 2 * (r >> 2) + oh, sgw = w0 + 4 * (r & 3) + owb;
             const bool cok = n0 + 4 * pc < KA()->Ncols && sgh < H;
-            const unsigned s_voff = (unsigned)(((sgh * W + sgw) * yl + n0 + 4 * pc) * 4);
+            const unsigned s_voff = ychk ? (unsigned)(((size_t)((n0 + 4 * pc) >> 3) * ychk + (size_t)((sgh * W + sgw) * 8 + 4 * (pc & 1))) * 4)
+                                         : (unsigned)(((sgh * W + sgw) * yl + n0 + 4 * pc) * 4);
             const unsigned sv[2] = {(cok && sgw < W) ? s_voff : OOB, (cok && sgw + 1 < W) ? s_voff : OOB};
             f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
 #pragma unroll
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
                 const int od = j >> 2, owi = (j >> 1) & 1, std_ = 2 * (j & 1) + od;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(tA + od * (16 * 64 * 4) + (owi * 16 + 8 * (j & 1) + r) * 32 + (elane & 7) * 4);
                 const bool dok = d0 + std_ < D;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), y_rs, dok ? sv[owi] : OOB, (int)((std_ * plane_y + owi * yl) * 4), 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), y_rs, dok ? sv[owi] : OOB, (int)((std_ * plane_s + owi * ys) * 4), 0);
                 if (BNRED) {
                     // dz = dA * act'(z), z = x * scale + shift;  xhat = (x - mean) * invstd  (the expressions of bn_bwd_kernel)
                     const float* const kb = kst + 2 * 96 + 4 * pc;
@@ -808,6 +814,9 @@ int launch_conv3_wino4(ConvArgs a, hipStream_t s) {
     E3_REQUIRE(a.splitk <= 1 && !a.pro_scale, E3_ERR_INVALID, "Winograd conv (F(2x2x4) tiles): no split-K, no fused prologue");
     E3_REQUIRE(!a.x_chunk || (a.x_chunk == (size_t)a.N * a.D * a.H * a.W * 8 && chunked_layout_ok((size_t)a.N * a.D * a.H * a.W, a.Cin)), E3_ERR_INVALID,
                "Winograd conv (F(2x2x4) tiles): bad channel-chunked input");
+    E3_REQUIRE(!a.y_chunk || (a.y_chunk == (size_t)a.N * a.D * a.H * a.W * 8 && chunked_layout_ok((size_t)a.N * a.D * a.H * a.W, a.Ncols) && !a.stats &&
+                              !(a.flags & CF_BNRED) && !(a.head_w && a.head_done)), E3_ERR_INVALID,
+               "Winograd conv (F(2x2x4) tiles): bad channel-chunked output (no statistics, no fused head; a fused pool's output stays in rows)");
     constexpr int lds = V_LDS_FLOATS * 4;
     constexpr int lds_x = lds;
     static bool attr = false;

@@ -48,6 +48,10 @@ struct ConvArgs {
     // chunk planes (= N D H W 8).  A halo row of one 8-channel chunk is then ONE contiguous run instead of 32 bytes out of every voxel's row (the staging's
     // line efficiency, profiles/r05_w4_phases.md section 5).  Written by the APPLY pass of the BatchNorm backward (BnBwdArgs::dx_chunk).
     size_t x_chunk;
+    // channel-chunked OUTPUT (conv_wino4.hip only, plain store epilogue -- no fused pool / head / statistics): y is written [Ncols / 8][N][D][H][W][8],
+    // y_chunk = floats between two chunk planes (= N D H W 8); y_ldc is ignored.  For a tensor whose only consumer stages 8-channel chunks
+    // (the conv1 -> conv2 chains of an inference forward).
+    size_t y_chunk;
     // needed region (Winograd 3x3x3 kernels only, inference): when box_hi[0] > 0 only the bricks that meet the voxel box [box_lo, box_hi)
     // (d, h, w) are computed -- the rest of y is left untouched.  The other kernels ignore it and compute everything.  No statistics.
     int box_lo[3], box_hi[3];

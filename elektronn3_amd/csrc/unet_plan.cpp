@@ -752,6 +752,44 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
 
     std::vector<std::pair<const float*, int>> unit_ins(plan->units.size());      // input view of every unit (shortcut source of the ResUNet's ConvBlocks)
     int head_fused = 0;          // the last conv's epilogue took the 1x1x1 head along (ConvArgs::head_*)
+    // inference: a conv1 -> conv2 chain whose two launches take the F(2x2x4) kernel hands its tensor over channel-chunked ([C / 8][voxel][8], ConvArgs::y_chunk ->
+    // x_chunk): conv2 stages 8-channel chunks, and a halo row of a chunk plane is one contiguous run instead of 32 bytes out of every voxel's row
+    // (profiles/r05_w4_phases.md section 5: the staging's line efficiency).  Only where conv2 is the tensor's ONLY reader.  E3_NO_CHUNKED_FWD=1: A/B switch.
+    static const bool no_chunked_fwd = getenv("E3_NO_CHUNKED_FWD") != nullptr;
+    size_t cur_chunk = 0;        // != 0: `cur` is channel-chunked with this many floats between chunk planes
+    // ... and the concat buffer of a decoder level (B.cat[j]: the transposed conv's output | the encoder's skip activation, read by the level's first conv
+    // alone) likewise: the two halves are the plane groups [0, C / 8) and [C / 8, 2 C / 8) of ONE chunked tensor of 2 C channels.  Its writers are the
+    // transposed-conv GEMM kernels and the encoder conv's F(2x2x4) epilogue (plain or with the fused pool, whose pooled output stays in rows).
+    static const bool no_pool_fuse = getenv("E3_WINO_NO_POOL") != nullptr;      // (the separate pool pass reads rows)
+    auto cat_chunked = [&](int j) -> size_t {
+        if (no_chunked_fwd || no_pool_fuse || training || valid || cfg.attention || cfg.merge_add || cfg.up_resize || cfg.act_slope != 0.f || j >= nb - 1 || !B.cat[j]) return 0;
+        const size_t ke = (size_t)plan->enc_last_unit[j];
+        size_t ku = 0;
+        for (; ku < plan->units.size(); ++ku) if (plan->units[ku].is_up && plan->units[ku].level == j) break;
+        if (ku + 1 >= plan->units.size()) return 0;
+        const ConvUnit& e = plan->units[ke]; const ConvUnit& up = plan->units[ku]; const ConvUnit& c1 = plan->units[ku + 1];
+        const int C = up.cout;
+        if (up.is_up != 1 || up.planar || e.planar || c1.planar || e.cout != C || c1.cin != 2 * C || (C & 31) || e.cin < 8 || e.res_in >= 0 || c1.res_in >= 0 || c1.is_up) return 0;
+        if (!B.wpk_f[ke] || !B.wpk_f[ku + 1] || B.ub[ke].act != B.cat[j] + C || B.ub[ku].act != B.cat[j] || need[ke].on) return 0;
+        for (size_t q = 0; q < plan->units.size(); ++q)
+            if (plan->units[q].res_in == (int)ku + 1 || plan->units[q].res_in == (int)ke + 1) return 0;           // (a ResUNet shortcut reads a half as well)
+        const LevelDims& ei = ND.u[ke].in; const LevelDims& eo = ND.u[ke].out; const LevelDims& ci1 = ND.u[ku + 1].in; const LevelDims& uo = ND.u[ku].out;
+        if (eo.D != uo.D || eo.H != uo.H || eo.W != uo.W || ci1.D != uo.D || ci1.H != uo.H || ci1.W != uo.W || eo.vox != uo.vox) return 0;
+        if (!chunked_layout_ok(uo.vox, 2 * C) || !upconv_gemm_ok(CF_SCATTER_UP, up.cin, C, 4 * (up.planar ? 1 : 2) * C)) return 0;
+        if (conv_wino_layout(w4f, ei.D, ei.H, ei.W, e.cin, e.cout, 1) != 2 || conv_wino_layout(w4f, ci1.D, ci1.H, ci1.W, c1.cin, c1.cout, 1) != 2) return 0;
+        return uo.vox * 8;
+    };
+    auto chain_chunked = [&](size_t k, bool plain_epilogue) -> bool {
+        if (no_chunked_fwd || training || !plain_epilogue || k + 1 >= plan->units.size()) return false;
+        const ConvUnit& u = plan->units[k]; const ConvUnit& v = plan->units[k + 1];
+        if (u.is_up || u.planar || u.cin < 8 || u.enc_last || u.res_in >= 0 || !B.wpk_f[k]) return false;
+        if (v.is_up || v.planar || v.cin != u.cout || v.res_in >= 0 || !B.wpk_f[k + 1] || B.ub[k].act_ldc != u.cout) return false;
+        for (size_t j = 0; j < plan->units.size(); ++j)
+            if (plan->units[j].res_in == (int)k + 1) return false;           // (a ResUNet shortcut reads the tensor as well)
+        const LevelDims& a0 = ND.u[k].in; const LevelDims& a1 = ND.u[k + 1].in;
+        return chunked_layout_ok(ND.u[k].out.vox, u.cout) && conv_wino_layout(w4f, a0.D, a0.H, a0.W, u.cin, u.cout, 1) == 2 &&
+               conv_wino_layout(w4f, a1.D, a1.H, a1.W, v.cin, v.cout, 1) == 2 && a1.D == ND.u[k].out.D && a1.H == ND.u[k].out.H && a1.W == ND.u[k].out.W;
+    };
     for (size_t k = 0; k < plan->units.size(); ++k) {
         const ConvUnit& u = plan->units[k];
         UnitBufs& b = B.ub[k];
@@ -759,6 +797,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
         const LevelDims& ci = ND.u[k].in;          // plain convs: the grid the conv kernel runs on (== lo unless conv_mode='valid')
         const bool vcrop = valid && !u.is_up;      // 'valid' conv = the 'same' conv on the input grid, cropped by the padding
         const float* const unit_in = cur; const int unit_in_ldc = cur_ldc;      // (the gating signal of the block's GridAttention)
+        E3_REQUIRE(!cur_chunk || (!u.is_up && u.cin >= 8 && !u.planar && B.wpk_f[k]), E3_ERR_INVALID, "channel-chunked tensor handed to a unit that reads rows");
         unit_ins[k] = {cur, cur_ldc};
         const bool is_enc_conv2 = u.enc_last;
         const bool pool_after = is_enc_conv2 && u.level < nb - 1;
@@ -824,6 +863,9 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             a.Do = lo.D; a.Ho = lo.H; a.Wo = lo.W; a.sd = sd;   // autocrop of the up-convolved tensor (unet.py:289-299)
             a.Cout = u.cout; a.Ncols = taps * u.cout; a.NPad = NPad; a.epi_scale = es; a.epi_shift = eh;
             a.stats = bn_train ? stat_buf : nullptr; a.G = 1; a.flags = CF_SCATTER_UP;
+            const size_t upck = cat_chunked(u.level);
+            E3_REQUIRE(!upck || (!two_pass && es && !bn_train), E3_ERR_INVALID, "channel-chunked concat buffer: the transposed conv cannot write its half");
+            if (upck) { a.y_chunk = upck; a.y_ldc = 8; }
             if (need[k].on && N == 1 && !bn_train && !two_pass) {
                 // needed region along D only (a transposed conv with kernel = stride has no halo, so a range of input planes is simply a smaller
                 // tensor: pointers and depths move, the kernels do not change); one sample, because the sample stride is implied by the dims
@@ -831,7 +873,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
                 if (p1 > p0 && (p0 > 0 || p1 < li.D)) {
                     const int o0 = p0 * sd, o1 = p1 * sd < lo.D ? p1 * sd : lo.D;
                     a.x = cur + (size_t)p0 * li.H * li.W * cur_ldc; a.D = p1 - p0;
-                    a.y = dst + (size_t)o0 * lo.H * lo.W * dst_ldc; a.Do = o1 - o0;
+                    a.y = dst + (size_t)o0 * lo.H * lo.W * (upck ? 8 : dst_ldc); a.Do = o1 - o0;
                 }
             }
             parts = conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, li.D, li.H, li.W, sd, u.cin, taps * u.cout);
@@ -857,6 +899,8 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             if (residual) { a.y = B.res2; a.y_ldc = u.cout; a.bias = nullptr; a.stats = nullptr; }      // pure accumulations; bias + shortcut + statistics below
             parts = conv_stats_parts(kind, w4f, N, ci.D, ci.H, ci.W, 2, u.cin, u.cout);
             const int S = (kind == CONV_K3) ? fwd_split(k) : 1;
+            a.x_chunk = cur_chunk; cur_chunk = 0;
+            if (kind == CONV_K3 && S == 1 && es && !two_pass && !vcrop && !residual && !pool_after && chain_chunked(k, true)) { a.y_chunk = lo.vox * 8; cur_chunk = a.y_chunk; }
             // inference: the ceil-mode max-pool behind an encoder block rides in the conv's epilogue where the kernel can take it (a Winograd tile is a window)
             if (pool_after && !training && !two_pass && kd == 2 && kind == CONV_K3 && es && !vcrop && !residual) { a.pool_out = B.pooled[u.level]; a.pool_done = &pool_fused; }
             // inference: the 1x1x1 head (+ softmax) rides in the epilogue of the network's LAST conv where the kernel can take it (ConvArgs::head_*): the
@@ -885,7 +929,14 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
                 a.splitk = S; a.sk_x = u.cin / S; a.Cin = u.cin / S; a.sk_w = (unsigned)conv_packed_floats(CONV_K3, u.cin / S, u.cout);
                 a.sk_y = lo.vox * u.cout; a.y = B.skws; a.y_ldc = u.cout; a.bias = nullptr; a.stats = nullptr;
             }
+            // the encoder's skip activation: second half of the level's concat buffer = its plane groups [C / 8, 2 C / 8).  (Only with the pool in
+            // the epilogue: the separate pool pass reads rows.)
+            const size_t skck = (is_enc_conv2 && pool_after) ? cat_chunked(u.level) : 0;
+            E3_REQUIRE(!skck || (kind == CONV_K3 && S == 1 && es && !two_pass && !vcrop && !residual && dst == B.cat[u.level] + u.cout && a.box_hi[0] <= 0 && a.pool_out),
+                       E3_ERR_INVALID, "channel-chunked concat buffer: the encoder conv cannot write its half");
+            if (skck) { a.y = B.cat[u.level] + (size_t)u.cout * lo.vox; a.y_chunk = skck; }
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(kind, a, s)); }
+            E3_REQUIRE(!skck || !pool_after || pool_fused, E3_ERR_INVALID, "channel-chunked skip tensor without the pool in the conv's epilogue");
             if (S > 1) {
                 RUN(launch_splitk_reduce(B.skws, S, lo.vox * u.cout, P(u.p_b), dst, dst_ldc, u.cout, lo.vox, stat_buf, s));
                 parts = crop_stats_parts(lo.vox, u.cout);
@@ -983,7 +1034,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             RUN(launch_add_views(B.cat[u.level], 2 * u.cout, B.cat[u.level] + u.cout, 2 * u.cout, B.sum[u.level], u.cout, lo.vox, u.cout, s));
             cur = B.sum[u.level]; cur_ldc = u.cout;
         }
-        else if (u.is_up) { cur = B.cat[u.level]; cur_ldc = 2 * u.cout; }   // conv1 of the UpConv reads the whole concat buffer
+        else if (u.is_up) { cur = B.cat[u.level]; cur_ldc = 2 * u.cout; cur_chunk = cat_chunked(u.level); }   // conv1 of the UpConv reads the whole concat buffer
         else { cur = b.act; cur_ldc = b.act_ldc; }
     }
     if (!head_fused) {

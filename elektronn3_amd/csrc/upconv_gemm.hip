@@ -168,7 +168,9 @@ __global__ __launch_bounds__(256, 2) void upconv_gemm_kernel(const ConvArgs a) {
             else {
                 const int od = a.sd * d0 + utd, oh = 2 * gh + uth, ow = 2 * gw + utw;
                 ok = ok && od < a.Do && oh < a.Ho && ow < a.Wo;
-                off = (size_t)(((nb * a.Do + od) * a.Ho + oh) * a.Wo + ow) * a.y_ldc + c0 + c4;
+                const size_t ov = (size_t)(((nb * a.Do + od) * a.Ho + oh) * a.Wo + ow);
+                // (channel-chunked output, ConvArgs::y_chunk: [Cout / 8][voxel][8])
+                off = a.y_chunk ? (size_t)((c0 + c4) >> 3) * a.y_chunk + ov * 8 + (c4 & 4) : ov * a.y_ldc + c0 + c4;
             }
             const f32x4 v = *reinterpret_cast<const f32x4*>(tile + trow * 32 + c4);
             if (ok) *reinterpret_cast<f32x4*>(a.y + off) = v;
@@ -274,6 +276,7 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_persist_kernel(const ConvAr
     float rc = 0.f, rm = 0.f, r2 = 0.f;            // running (count, mean, M2) of this lane's channel over its voxels and taps
     float* tl = tiles + wave * 32 * TP;
     const int c4 = 4 * (lane & 7);
+    const size_t ych = a.y_chunk ? (size_t)((cb + c4) >> 3) * a.y_chunk + (c4 & 4) : (size_t)(cb + c4);      // the lane's channel offset inside a voxel row / its chunk plane
 
     if ((int)blockIdx.x < ntiles) stage(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -302,7 +305,9 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_persist_kernel(const ConvAr
         const bool vin = v < nvox;
         unsigned r = vin ? v : 0u;
         const int w = r % a.W; r /= a.W; const int h = r % a.H; r /= a.H; const int d = r % a.D; const int n = (int)(r / a.D);
-        const unsigned obase = (unsigned)(((((size_t)n * a.Do + SD * d) * a.Ho + 2 * h) * a.Wo + 2 * w) * a.y_ldc);
+        // (channel-chunked output, ConvArgs::y_chunk: [Cout / 8][voxel][8] -- a voxel's row is 8 floats, this lane's 16 bytes go to plane (cb + c4) / 8)
+        const int ys = a.y_chunk ? 8 : a.y_ldc;
+        const unsigned obase = (unsigned)(((((size_t)n * a.Do + SD * d) * a.Ho + 2 * h) * a.Wo + 2 * w) * ys);
         unsigned okm = 0;
 #pragma unroll
         for (int tap = 0; tap < T; ++tap)
@@ -332,11 +337,11 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_persist_kernel(const ConvAr
                     else { const bool ok = ((okr[e] >> tap) & 1u) != 0; cnt += ok ? 1.f : 0.f; sum += ok ? val : 0.f; }
                 }
                 __builtin_amdgcn_wave_barrier();
-                const unsigned toff = (unsigned)((((tap >> 2) * a.Ho + ((tap >> 1) & 1)) * a.Wo + (tap & 1)) * a.y_ldc);
+                const unsigned toff = (unsigned)((((tap >> 2) * a.Ho + ((tap >> 1) & 1)) * a.Wo + (tap & 1)) * ys);
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const f32x4 o = *reinterpret_cast<const f32x4*>(tl + (8 * p + (lane >> 3)) * TP + c4);
-                    if (ALL || ((omp[p] >> tap) & 1u)) *reinterpret_cast<f32x4*>(a.y + obp[p] + toff + cb + c4) = o;
+                    if (ALL || ((omp[p] >> tap) & 1u)) *reinterpret_cast<f32x4*>(a.y + obp[p] + toff + ych) = o;
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (a.stats) {
@@ -399,8 +404,10 @@ int launch_upconv_gemm(ConvArgs a, hipStream_t s) {
                "upconv views must be 16-byte aligned");
     const bool gather = (a.flags & CF_GATHER_UP) != 0;
     const size_t nvox = (size_t)a.N * a.D * a.H * a.W;
+    E3_REQUIRE(!a.y_chunk || (!gather && !a.stats && (a.Cout & 31) == 0 && a.y_chunk * (size_t)(a.Cout / 8) * 4 < 0x7fffffffu), E3_ERR_INVALID,
+               "upconv: bad channel-chunked output (forward without statistics, 32-channel tiles)");
     if (!gather && !a.pro_scale && upconv_fwd_persist_ok(a.flags, a.Cin, a.Cout) && nvox * (size_t)a.x_ldc < (1ull << 29) &&
-        (size_t)a.N * a.Do * a.Ho * a.Wo * a.y_ldc < (1ull << 32)) {
+        (size_t)a.N * a.Do * a.Ho * a.Wo * (a.y_chunk ? 8 : a.y_ldc) < (1ull << 32)) {
         const int tiles = (int)((nvox + 127) / 128), T = 4 * a.sd;
         const int lds = T * 32 * 256 + 128 * 256 + 8 * 32 * 40 * 4 + 8 * 32 * 3 * 4;
         static bool done = false;

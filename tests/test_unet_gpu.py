@@ -1489,3 +1489,37 @@ torch.save(out, sys.argv[1])
         outs.append(torch.load(f))
     for k in outs[0]:
         assert torch.isfinite(outs[0][k]).all() and torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_channel_chunked_conv1_to_conv2_chain_is_bit_identical_to_rows(tmp_path):
+    """Inference: where conv1 and conv2 of a block both run on the F(2x2x4) Winograd kernel and conv2 is the tensor's only reader, conv1 writes its activation
+    channel-chunked ([C / 8][voxel][8], ConvArgs::y_chunk) and conv2 stages it that way (x_chunk) -- a change of layout only (unet.py:131-149, 244-253: the same
+    conv / BatchNorm / ReLU sequence).  A child process with E3_NO_CHUNKED_FWD=1 (read once per process) computes the same forwards through [voxel][C] rows:
+    logits, softmax output and a needed-region forward must agree bit for bit, on ragged grids and with the kernel forced onto every grid (E3_WINO4_MIN=1)."""
+    import subprocess, sys, os
+    script = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from elektronn3_amd.unet import UNet
+out = {}
+for nb, sf, shape in ((3, 16, (1, 1, 37, 70, 83)), (2, 32, (2, 1, 24, 40, 48))):
+    torch.manual_seed(4 + nb)
+    m = UNet(1, 3, n_blocks=nb, start_filts=sf).cuda().train()
+    with torch.no_grad():
+        for _ in range(2):
+            m(torch.randn(2, 1, 16, 32, 32, device='cuda'))
+    m.eval()
+    x = torch.randn(*shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5))
+    with torch.no_grad():
+        out[f'logits{nb}'] = m(x).cpu(); out[f'softmax{nb}'] = m.forward_softmax(x).cpu()
+        out[f'roi{nb}'] = m.forward_roi(x[:1], ((4, 20), (8, 33), (16, 40)), softmax=True)[:, :, 4:20, 8:33, 16:40].cpu()
+torch.save(out, sys.argv[1])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, extra in (('chunked', {'E3_WINO4_MIN': '1'}), ('rows', {'E3_WINO4_MIN': '1', 'E3_NO_CHUNKED_FWD': '1'})):
+        f = str(tmp_path / f'{tag}.pt')
+        r = subprocess.run([sys.executable, '-c', script, f], env={**os.environ, **extra}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+    for k in outs[0]:
+        assert torch.isfinite(outs[0][k]).all() and torch.equal(outs[0][k], outs[1][k]), k
