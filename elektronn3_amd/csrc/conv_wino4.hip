@@ -654,7 +654,9 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
             const int Dp = (D + 1) >> 1, Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
             const int pd_ = (d0 >> 1) + ettd, ph_ = (h0 >> 1) + etth, pw_ = (w0 >> 1) + 2 * ettw + win;
             const bool pok = pd_ < Dp && ph_ < Hp && pw_ < Wp && nq + 4 * ch < eN;
-            if (pok) *reinterpret_cast<f32x4*>(e->pool_out + ((((size_t)P_nb * Dp + pd_) * Hp + ph_) * Wp + pw_) * eN + nq + 4 * ch) = best;
+            const size_t pv = (((size_t)P_nb * Dp + pd_) * Hp + ph_) * Wp + pw_;
+            const size_t pck = e->pool_chunk;      // (channel-chunked pooled tensor: plane (nq + 4 ch) / 8, ConvArgs::pool_chunk)
+            if (pok) *reinterpret_cast<f32x4*>(e->pool_out + (pck ? (size_t)((nq + 4 * ch) >> 3) * pck + pv * 8 + ((nq + 4 * ch) & 4) : pv * eN + nq + 4 * ch)) = best;
         }
         if (do_stats) {
             // running record of this elane's 8 channels: Chan merge of the brick's (up to) four values per channel, approximate reciprocal

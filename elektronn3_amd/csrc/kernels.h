@@ -52,6 +52,7 @@ struct ConvArgs {
     // y_chunk = floats between two chunk planes (= N D H W 8); y_ldc is ignored.  For a tensor whose only consumer stages 8-channel chunks
     // (the conv1 -> conv2 chains of an inference forward).
     size_t y_chunk;
+    size_t pool_chunk;           // != 0: the fused pool's output (pool_out) is channel-chunked as well, pool_chunk = N Dp Hp Wp 8
     // needed region (Winograd 3x3x3 kernels only, inference): when box_hi[0] > 0 only the bricks that meet the voxel box [box_lo, box_hi)
     // (d, h, w) are computed -- the rest of y is left untouched.  The other kernels ignore it and compute everything.  No statistics.
     int box_lo[3], box_hi[3];

@@ -779,16 +779,22 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
         if (conv_wino_layout(w4f, ei.D, ei.H, ei.W, e.cin, e.cout, 1) != 2 || conv_wino_layout(w4f, ci1.D, ci1.H, ci1.W, c1.cin, c1.cout, 1) != 2) return 0;
         return uo.vox * 8;
     };
-    auto chain_chunked = [&](size_t k, bool plain_epilogue) -> bool {
-        if (no_chunked_fwd || training || !plain_epilogue || k + 1 >= plan->units.size()) return false;
-        const ConvUnit& u = plan->units[k]; const ConvUnit& v = plan->units[k + 1];
-        if (u.is_up || u.planar || u.cin < 8 || u.enc_last || u.res_in >= 0 || !B.wpk_f[k]) return false;
-        if (v.is_up || v.planar || v.cin != u.cout || v.res_in >= 0 || !B.wpk_f[k + 1] || B.ub[k].act_ldc != u.cout) return false;
+    // unit k + 1 is a plain 3x3x3 conv on the F(2x2x4) kernel that reads a packed C-channel tensor on the grid `g` -- and nobody else reads that tensor
+    auto next_reads_chunks = [&](size_t k, int C, const LevelDims& g) -> bool {
+        if (no_chunked_fwd || training || valid || k + 1 >= plan->units.size()) return false;
+        const ConvUnit& v = plan->units[k + 1];
+        if (v.is_up || v.planar || v.cin != C || v.res_in >= 0 || !B.wpk_f[k + 1]) return false;
         for (size_t j = 0; j < plan->units.size(); ++j)
             if (plan->units[j].res_in == (int)k + 1) return false;           // (a ResUNet shortcut reads the tensor as well)
-        const LevelDims& a0 = ND.u[k].in; const LevelDims& a1 = ND.u[k + 1].in;
-        return chunked_layout_ok(ND.u[k].out.vox, u.cout) && conv_wino_layout(w4f, a0.D, a0.H, a0.W, u.cin, u.cout, 1) == 2 &&
-               conv_wino_layout(w4f, a1.D, a1.H, a1.W, v.cin, v.cout, 1) == 2 && a1.D == ND.u[k].out.D && a1.H == ND.u[k].out.H && a1.W == ND.u[k].out.W;
+        const LevelDims& a1 = ND.u[k + 1].in;
+        return chunked_layout_ok(g.vox, C) && conv_wino_layout(w4f, a1.D, a1.H, a1.W, v.cin, v.cout, 1) == 2 && a1.D == g.D && a1.H == g.H && a1.W == g.W && a1.vox == g.vox;
+    };
+    auto chain_chunked = [&](size_t k, bool plain_epilogue) -> bool {
+        if (!plain_epilogue) return false;
+        const ConvUnit& u = plan->units[k];
+        if (u.is_up || u.planar || u.cin < 8 || u.enc_last || u.res_in >= 0 || !B.wpk_f[k] || B.ub[k].act_ldc != u.cout) return false;
+        const LevelDims& a0 = ND.u[k].in;
+        return conv_wino_layout(w4f, a0.D, a0.H, a0.W, u.cin, u.cout, 1) == 2 && next_reads_chunks(k, u.cout, ND.u[k].out);
     };
     for (size_t k = 0; k < plan->units.size(); ++k) {
         const ConvUnit& u = plan->units[k];
@@ -802,6 +808,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
         const bool is_enc_conv2 = u.enc_last;
         const bool pool_after = is_enc_conv2 && u.level < nb - 1;
         int pool_fused = 0;          // the conv's epilogue took the max-pool along (ConvArgs::pool_out)
+        size_t pool_chunk_out = 0;   // ... and wrote the pooled tensor channel-chunked
         const int kd = u.planar ? 1 : 2;
         const float slope = cfg.act_slope;
         ActArg act = u.p_a >= 0 ? ActArg(0.f, P(u.p_a)) : ActArg(slope);
@@ -935,8 +942,15 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             E3_REQUIRE(!skck || (kind == CONV_K3 && S == 1 && es && !two_pass && !vcrop && !residual && dst == B.cat[u.level] + u.cout && a.box_hi[0] <= 0 && a.pool_out),
                        E3_ERR_INVALID, "channel-chunked concat buffer: the encoder conv cannot write its half");
             if (skck) { a.y = B.cat[u.level] + (size_t)u.cout * lo.vox; a.y_chunk = skck; }
+            // ... and the pooled tensor goes to the next level's first conv chunked as well (only out of the conv epilogue: the separate pool pass writes rows)
+            size_t plck = 0;
+            if (a.pool_out && !no_pool_fuse && a.box_hi[0] <= 0 && (u.cout & 31) == 0 && conv_wino_layout(w4f, ci.D, ci.H, ci.W, u.cin, u.cout, 1) == 2 && es) {
+                LevelDims pg = lo; pg.D = (lo.D + 1) / 2; pg.H = (lo.H + 1) / 2; pg.W = (lo.W + 1) / 2; pg.vox = (size_t)N * pg.D * pg.H * pg.W;
+                if (next_reads_chunks(k, u.cout, pg)) { plck = pg.vox * 8; a.pool_chunk = plck; }
+            }
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(kind, a, s)); }
-            E3_REQUIRE(!skck || !pool_after || pool_fused, E3_ERR_INVALID, "channel-chunked skip tensor without the pool in the conv's epilogue");
+            E3_REQUIRE((!skck && !plck) || !pool_after || pool_fused, E3_ERR_INVALID, "channel-chunked skip / pooled tensor without the pool in the conv's epilogue");
+            pool_chunk_out = plck;
             if (S > 1) {
                 RUN(launch_splitk_reduce(B.skws, S, lo.vox * u.cout, P(u.p_b), dst, dst_ldc, u.cout, lo.vox, stat_buf, s));
                 parts = crop_stats_parts(lo.vox, u.cout);
@@ -1029,7 +1043,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             RUN(launch_crop_copy(eb.act, B.cat[j] + u.cout, 2 * u.cout, u.cout, N, e.D, e.H, e.W, lo.D, lo.H, lo.W, ND.sd_[j], ND.sh_[j], ND.sw_[j], s));
         }
         // input of the next unit
-        if (pool_after) { cur = B.pooled[u.level]; cur_ldc = u.cout; }
+        if (pool_after) { cur = B.pooled[u.level]; cur_ldc = u.cout; cur_chunk = pool_chunk_out; }
         else if (u.is_up && cfg.merge_add) {   // mrg = updec + genc (unet.py:400-401): the two halves of the buffer summed
             RUN(launch_add_views(B.cat[u.level], 2 * u.cout, B.cat[u.level] + u.cout, 2 * u.cout, B.sum[u.level], u.cout, lo.vox, u.cout, s));
             cur = B.sum[u.level]; cur_ldc = u.cout;
