@@ -504,17 +504,19 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
             // od = j >> 2, owi = (j >> 1) & 1
             const int r = elane >> 3, pc = (elane & 7) ^ r;
             const int sgh = h0 + 2 * (r >> 2) + oh, sgw = w0 + 4 * (r & 3) + owb;
-            const bool cok = n0 + 4 * pc < KA()->Ncols && sgh < H;
+            // (store box, ConvArgs::sbox_*: the launcher sets [0, dims) when it is off)
+            const int sb_d0 = KA()->sbox_lo[0], sb_d1 = KA()->sbox_hi[0], sb_h0 = KA()->sbox_lo[1], sb_h1 = KA()->sbox_hi[1], sb_w0 = KA()->sbox_lo[2], sb_w1 = KA()->sbox_hi[2];
+            const bool cok = n0 + 4 * pc < KA()->Ncols && sgh < sb_h1 && sgh >= sb_h0;
             const unsigned s_voff = ychk ? (unsigned)(((size_t)((n0 + 4 * pc) >> 3) * ychk + (size_t)((sgh * W + sgw) * 8 + 4 * (pc & 1))) * 4)
                                          : (unsigned)(((sgh * W + sgw) * yl + n0 + 4 * pc) * 4);
-            const unsigned sv[2] = {(cok && sgw < W) ? s_voff : OOB, (cok && sgw + 1 < W) ? s_voff : OOB};
+            const unsigned sv[2] = {(cok && sgw < sb_w1 && sgw >= sb_w0) ? s_voff : OOB, (cok && sgw + 1 < sb_w1 && sgw + 1 >= sb_w0) ? s_voff : OOB};
             f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (E3_W4_ABL & 4) continue;
                 const int od = j >> 2, owi = (j >> 1) & 1, std_ = 2 * (j & 1) + od;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(tA + od * (16 * 64 * 4) + (owi * 16 + 8 * (j & 1) + r) * 32 + (elane & 7) * 4);
-                const bool dok = d0 + std_ < D;
+                const bool dok = d0 + std_ < sb_d1 && d0 + std_ >= sb_d0;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), y_rs, dok ? sv[owi] : OOB, (int)((std_ * plane_s + owi * ys) * 4), 0);
                 if (BNRED) {
                     // dz = dA * act'(z), z = x * scale + shift;  xhat = (x - mean) * invstd  (the expressions of bn_bwd_kernel)
@@ -802,6 +804,15 @@ int launch_conv3_wino4(ConvArgs a, hipStream_t s) {
         }
         a.org_d = o[0]; a.org_h = o[1]; a.org_w = o[2];
         a.tilesD = n[0]; a.tilesH = n[1]; a.tilesW = n[2];
+    }
+    {   // store box: clipped to the tensor; off = the whole tensor
+        const int dims[3] = {a.D, a.H, a.W};
+        const bool on = a.sbox_hi[0] > 0;
+        E3_REQUIRE(!on || (!a.stats && !(a.flags & CF_BNRED)), E3_ERR_INVALID, "conv with a store box: no statistics");
+        for (int i = 0; i < 3; ++i) {
+            a.sbox_lo[i] = on ? (a.sbox_lo[i] < 0 ? 0 : a.sbox_lo[i]) : 0;
+            a.sbox_hi[i] = on ? (a.sbox_hi[i] > dims[i] ? dims[i] : a.sbox_hi[i]) : dims[i];
+        }
     }
     a.NPad = (a.Ncols + 31) / 32 * 32;
     a.ntiles = a.NPad / 32;

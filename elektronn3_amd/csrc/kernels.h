@@ -53,6 +53,10 @@ struct ConvArgs {
     // (the conv1 -> conv2 chains of an inference forward).
     size_t y_chunk;
     size_t pool_chunk;           // != 0: the fused pool's output (pool_out) is channel-chunked as well, pool_chunk = N Dp Hp Wp 8
+    // store box (conv_wino4.hip only, inference): when sbox_hi[0] > 0 only the voxels [sbox_lo, sbox_hi) (d, h, w) of y are WRITTEN -- everything is still computed
+    // (a fused pool sees all of it).  The skip activation of an encoder block when the decoder conv that reads it has a needed region (ConvArgs::box_*): the rest of
+    // the tensor is never read.  The other kernels ignore it and store everything.
+    int sbox_lo[3], sbox_hi[3];
     // needed region (Winograd 3x3x3 kernels only, inference): when box_hi[0] > 0 only the bricks that meet the voxel box [box_lo, box_hi)
     // (d, h, w) are computed -- the rest of y is left untouched.  The other kernels ignore it and compute everything.  No statistics.
     int box_lo[3], box_hi[3];

@@ -942,6 +942,16 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             E3_REQUIRE(!skck || (kind == CONV_K3 && S == 1 && es && !two_pass && !vcrop && !residual && dst == B.cat[u.level] + u.cout && a.box_hi[0] <= 0 && a.pool_out),
                        E3_ERR_INVALID, "channel-chunked concat buffer: the encoder conv cannot write its half");
             if (skck) { a.y = B.cat[u.level] + (size_t)u.cout * lo.vox; a.y_chunk = skck; }
+            // needed region: of the skip activation the decoder reads only what the level's transposed conv has to produce (need[] of the up unit = the box of the concat
+            // buffer's voxels that the block's first conv reads) -- the rest is computed for the pool but not stored (E3_NO_STORE_BOX=1: A/B switch)
+            static const bool no_store_box = getenv("E3_NO_STORE_BOX") != nullptr;
+            if (!no_store_box && is_enc_conv2 && pool_after && a.pool_out && !no_pool_fuse && a.box_hi[0] <= 0 && (u.cout & 31) == 0 && es && S == 1 &&
+                conv_wino_layout(w4f, ci.D, ci.H, ci.W, u.cin, u.cout, 1) == 2 && !training && !vcrop && !residual && !cfg.attention && !cfg.merge_add && dst == B.cat[u.level] + u.cout) {
+                size_t ku = 0;
+                for (; ku < plan->units.size(); ++ku) if (plan->units[ku].is_up && plan->units[ku].level == u.level) break;
+                if (ku < plan->units.size() && need[ku].on && ND.u[ku].out.D == lo.D && ND.u[ku].out.H == lo.H && ND.u[ku].out.W == lo.W)
+                    for (int i = 0; i < 3; ++i) { a.sbox_lo[i] = need[ku].lo[i]; a.sbox_hi[i] = need[ku].hi[i]; }
+            }
             // ... and the pooled tensor goes to the next level's first conv chunked as well (only out of the conv epilogue: the separate pool pass writes rows)
             size_t plck = 0;
             if (a.pool_out && !no_pool_fuse && a.box_hi[0] <= 0 && (u.cout & 31) == 0 && conv_wino_layout(w4f, ci.D, ci.H, ci.W, u.cin, u.cout, 1) == 2 && es) {
@@ -949,7 +959,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
                 if (next_reads_chunks(k, u.cout, pg)) { plck = pg.vox * 8; a.pool_chunk = plck; }
             }
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(kind, a, s)); }
-            E3_REQUIRE((!skck && !plck) || !pool_after || pool_fused, E3_ERR_INVALID, "channel-chunked skip / pooled tensor without the pool in the conv's epilogue");
+            E3_REQUIRE((!skck && !plck && a.sbox_hi[0] <= 0) || !pool_after || pool_fused, E3_ERR_INVALID, "channel-chunked / partly stored skip tensor without the pool in the conv's epilogue");
             pool_chunk_out = plck;
             if (S > 1) {
                 RUN(launch_splitk_reduce(B.skws, S, lo.vox * u.cout, P(u.p_b), dst, dst_ldc, u.cout, lo.vox, stat_buf, s));

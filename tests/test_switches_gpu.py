@@ -50,8 +50,8 @@ GROUPS = {
                          ['tests/test_unet_gpu.py', '-k', 'train_step_matches_reference or full_size_cfg2 or full_size_properties or forward_with_loss or digest']),
     # inference forwards with every tensor in plain [voxel][C] rows (E3_NO_CHUNKED_FWD=1; by default the conv1 -> conv2 chains and the decoder's concat buffers
     # are channel-chunked wherever their writers and their reader take the kernels that can: the groups 'wino4_on_every_grid' / 'persistent_kernels_on_small_grids'
-    # and the defaults run the chunked form)
-    'forward_plain_rows': (dict(E3_WINO4_MIN='1', E3_NO_CHUNKED_FWD='1'),
+    # and the defaults run the chunked form); E3_NO_STORE_BOX=1: the encoder's skip activations stored in full although the decoder has a needed region)
+    'forward_plain_rows': (dict(E3_WINO4_MIN='1', E3_NO_CHUNKED_FWD='1', E3_NO_STORE_BOX='1'),
                            ['tests/test_unet_gpu.py', 'tests/test_predictor.py', '-k', 'eval_forward or forward_roi or needed_region or head_in_the_last or pool_in_the_conv or predictor or cfg5']),
     # ... and for the TRAINING forward with its statistics as well (E3_WINO4=2; not a default: DESIGN.md section 3a) -- per-op parity and the property tests
     'wino4_training_forward': (dict(E3_WINO4='2', E3_WINO4_MIN='1'), ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', '-k', 'conv3 or full_size_properties or forward_with_loss or eval_forward']),
