@@ -882,6 +882,13 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
                     a.x = cur + (size_t)p0 * li.H * li.W * cur_ldc; a.D = p1 - p0;
                     a.y = dst + (size_t)o0 * lo.H * lo.W * (upck ? 8 : dst_ldc); a.Do = o1 - o0;
                 }
+                // ... and a box of input rows / columns for the kernels that can walk one (ConvArgs::box_* in INPUT voxels; E3_NO_STORE_BOX=1: whole planes)
+                static const bool no_up_box = getenv("E3_NO_STORE_BOX") != nullptr;
+                if (!no_up_box) {
+                    a.box_lo[0] = 0; a.box_hi[0] = a.D;
+                    a.box_lo[1] = need[k].lo[1] / 2; a.box_hi[1] = (need[k].hi[1] + 1) / 2 < li.H ? (need[k].hi[1] + 1) / 2 : li.H;
+                    a.box_lo[2] = need[k].lo[2] / 2; a.box_hi[2] = (need[k].hi[2] + 1) / 2 < li.W ? (need[k].hi[2] + 1) / 2 : li.W;
+                }
             }
             parts = conv_stats_parts(CONV_POINT, CF_SCATTER_UP, N, li.D, li.H, li.W, sd, u.cin, taps * u.cout);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_mfma(CONV_POINT, a, s)); }

@@ -35,7 +35,10 @@ __global__ __launch_bounds__(256, 2) void upconv_gemm_kernel(const ConvArgs a) {
     const int tw_ = L % a.tilesW; L /= a.tilesW;
     const int th_ = L % a.tilesH; L /= a.tilesH;
     const int d0 = L % a.D; const int nb = L / a.D;
-    const int h0 = th_ * U_TH, w0 = tw_ * 16;
+    // (needed region of a forward launch, ConvArgs::box_* in INPUT voxels of h and w: the bricks start at the box's low corner and stop at its high one;
+    // the launcher sets [0, H) x [0, W) when it is off, so the statistics records keep their order)
+    const int bh1 = GATHER ? a.H : a.box_hi[1], bw1 = GATHER ? a.W : a.box_hi[2];
+    const int h0 = (GATHER ? 0 : a.box_lo[1]) + th_ * U_TH, w0 = (GATHER ? 0 : a.box_lo[2]) + tw_ * 16;
     const int n0 = ntile * 32 * NT;
     const int mtile = ((nb * a.D + d0) * a.tilesH + th_) * a.tilesW + tw_;
     const int Cx = a.Cin;                                  // channels per voxel of x
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void upconv_gemm_kernel(const ConvArgs a) {
         const int idx = tid + it * 256;
         const int m = idx >> 3, q = idx & 7;
         const int gh = h0 + (m >> 4), gw = w0 + (m & 15);
-        const bool ok = gh < a.H && gw < a.W;
+        const bool ok = gh < bh1 && gw < bw1;
         if (GATHER) a_vox[it] = ok ? (gh << 16) | gw : -1;
         else a_vox[it] = ok ? (((nb * a.D + d0) * a.H + gh) * a.W + gw) * a.x_ldc + 4 * q : -1;
         a_dst[it] = swz(m, q);
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void upconv_gemm_kernel(const ConvArgs a) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
             const int m = wave * 32 + row;
             const int gh = h0 + (m >> 4), gw = w0 + (m & 15);
-            bool ok = nvalid && gh < a.H && gw < a.W;
+            bool ok = nvalid && gh < bh1 && gw < bw1;
             if (!GATHER) ok = ok && a.sd * d0 + utd < a.Do && 2 * gh + uth < a.Ho && 2 * gw + utw < a.Wo;
             float v = acc[ns][r] + bias;
             if (aff) v = fmaxf(__builtin_fmaf(v, es, eh), 0.f);
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void upconv_gemm_kernel(const ConvArgs a) {
             const int trow = 8 * p + (lane >> 3);
             const int m = wave * 32 + trow;
             const int gh = h0 + (m >> 4), gw = w0 + (m & 15);
-            bool ok = nt0 + c4 < a.Ncols && gh < a.H && gw < a.W;
+            bool ok = nt0 + c4 < a.Ncols && gh < bh1 && gw < bw1;
             size_t off;
             if (GATHER) off = (size_t)(((nb * a.D + d0) * a.H + gh) * a.W + gw) * a.y_ldc + nt0 + c4;
             else {
@@ -209,7 +212,13 @@ __global__ __launch_bounds__(256, 2) void upconv_gemm_kernel(const ConvArgs a) {
 
 template <bool GATHER, int NT>
 int launch_up(ConvArgs a, hipStream_t s) {
-    a.tilesD = a.D; a.tilesH = cdiv(a.H, U_TH); a.tilesW = cdiv(a.W, 16);
+    if (GATHER || a.box_hi[0] <= 0 || a.stats) { a.box_lo[1] = a.box_lo[2] = 0; a.box_hi[1] = a.H; a.box_hi[2] = a.W; }
+    else for (int i = 1; i < 3; ++i) {
+        const int dim = i == 1 ? a.H : a.W;
+        a.box_lo[i] = a.box_lo[i] < 0 ? 0 : a.box_lo[i]; a.box_hi[i] = a.box_hi[i] > dim ? dim : a.box_hi[i];
+        E3_REQUIRE(a.box_hi[i] > a.box_lo[i], E3_ERR_INVALID, "upconv with a needed region: empty box");
+    }
+    a.tilesD = a.D; a.tilesH = cdiv(a.box_hi[1] - a.box_lo[1], U_TH); a.tilesW = cdiv(a.box_hi[2] - a.box_lo[2], 16);
     a.ntiles = a.NPad / (32 * NT);
     const size_t nblk = (size_t)a.N * a.D * a.tilesH * a.tilesW * a.ntiles;
     E3_REQUIRE(nblk > 0 && nblk < (1u << 31), E3_ERR_INVALID, "upconv grid out of range");
@@ -260,12 +269,21 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_persist_kernel(const ConvAr
         const int tap = R >> 5, jj = R & 31;
         pdma16(w_rs, (lds_ptr_p)(pmem + i * 1024), (unsigned)((((tap * a.Cout + cb + jj) * 64) + ((slot ^ (R & 15)) << 2)) * 4));
     }
+    // needed region (ConvArgs::box_* in INPUT voxels of h and w; the launcher sets [0, H) x [0, W) when it is off): the flattened index runs over the box,
+    // voxel v of it is (n d, h, w) = (v / (bH bW), box_lo[1] + (v / bW) % bH, box_lo[2] + v % bW) of the tensor
+    const unsigned bW = (unsigned)(a.box_hi[2] - a.box_lo[2]), bH = (unsigned)(a.box_hi[1] - a.box_lo[1]);
+    const bool boxed = bW != (unsigned)a.W || bH != (unsigned)a.H;
+    auto box_voxel = [&](unsigned v) -> unsigned {          // index of box voxel v in the tensor
+        if (!boxed) return v;
+        const unsigned t = v / bW, w = v - t * bW, nd = t / bH, h = t - nd * bH;
+        return (nd * (unsigned)a.H + h + (unsigned)a.box_lo[1]) * (unsigned)a.W + w + (unsigned)a.box_lo[2];
+    };
     auto stage = [&](int tile) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (i * 8 + wave) * 4 + (lane >> 4), slot = lane & 15;
             const unsigned v = (unsigned)tile * 128u + row;
-            pdma16(x_rs, (lds_ptr_p)(xs + (i * 8 + wave) * 1024), v < nvox ? (v * (unsigned)a.x_ldc + ((slot ^ (row & 15)) << 2)) * 4u : P_OOB);
+            pdma16(x_rs, (lds_ptr_p)(xs + (i * 8 + wave) * 1024), v < nvox ? (box_voxel(v) * (unsigned)a.x_ldc + ((slot ^ (row & 15)) << 2)) * 4u : P_OOB);
         }
     };
     const int row = vw * 32 + j;
@@ -304,7 +322,7 @@ __global__ __launch_bounds__(512, 1) void upconv_fwd_persist_kernel(const ConvAr
         const unsigned v = (unsigned)tile * 128u + row;
         const bool vin = v < nvox;
         unsigned r = vin ? v : 0u;
-        const int w = r % a.W; r /= a.W; const int h = r % a.H; r /= a.H; const int d = r % a.D; const int n = (int)(r / a.D);
+        const int w = a.box_lo[2] + (int)(r % bW); r /= bW; const int h = a.box_lo[1] + (int)(r % bH); r /= bH; const int d = r % a.D; const int n = (int)(r / a.D);
         // (channel-chunked output, ConvArgs::y_chunk: [Cout / 8][voxel][8] -- a voxel's row is 8 floats, this lane's 16 bytes go to plane (cb + c4) / 8)
         const int ys = a.y_chunk ? 8 : a.y_ldc;
         const unsigned obase = (unsigned)(((((size_t)n * a.Do + SD * d) * a.Ho + 2 * h) * a.Wo + 2 * w) * ys);
@@ -406,9 +424,16 @@ int launch_upconv_gemm(ConvArgs a, hipStream_t s) {
     const size_t nvox = (size_t)a.N * a.D * a.H * a.W;
     E3_REQUIRE(!a.y_chunk || (!gather && !a.stats && (a.Cout & 31) == 0 && a.y_chunk * (size_t)(a.Cout / 8) * 4 < 0x7fffffffu), E3_ERR_INVALID,
                "upconv: bad channel-chunked output (forward without statistics, 32-channel tiles)");
+    if (gather || a.box_hi[0] <= 0 || a.stats) { a.box_lo[1] = a.box_lo[2] = 0; a.box_hi[1] = a.H; a.box_hi[2] = a.W; a.box_hi[0] = 0; }
     if (!gather && !a.pro_scale && upconv_fwd_persist_ok(a.flags, a.Cin, a.Cout) && nvox * (size_t)a.x_ldc < (1ull << 29) &&
         (size_t)a.N * a.Do * a.Ho * a.Wo * (a.y_chunk ? 8 : a.y_ldc) < (1ull << 32)) {
-        const int tiles = (int)((nvox + 127) / 128), T = 4 * a.sd;
+        if (a.box_hi[0] > 0) for (int i = 1; i < 3; ++i) {
+            const int dim = i == 1 ? a.H : a.W;
+            a.box_lo[i] = a.box_lo[i] < 0 ? 0 : a.box_lo[i]; a.box_hi[i] = a.box_hi[i] > dim ? dim : a.box_hi[i];
+            E3_REQUIRE(a.box_hi[i] > a.box_lo[i], E3_ERR_INVALID, "upconv with a needed region: empty box");
+        }
+        const size_t bvox = (size_t)a.N * a.D * (a.box_hi[1] - a.box_lo[1]) * (a.box_hi[2] - a.box_lo[2]);      // voxels the workgroups walk (the box; == nvox without one)
+        const int tiles = (int)((bvox + 127) / 128), T = 4 * a.sd;
         const int lds = T * 32 * 256 + 128 * 256 + 8 * 32 * 40 * 4 + 8 * 32 * 3 * 4;
         static bool done = false;
         if (!done) {
@@ -416,9 +441,9 @@ int launch_upconv_gemm(ConvArgs a, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)upconv_fwd_persist_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             done = true;
         }
-        const dim3 grid((unsigned)persist_wgs(nvox), (unsigned)(a.Cout / 32));
-        if (a.sd == 2) hipLaunchKernelGGL(upconv_fwd_persist_kernel<2>, grid, dim3(512), lds, s, a, (unsigned)nvox, tiles);
-        else hipLaunchKernelGGL(upconv_fwd_persist_kernel<1>, grid, dim3(512), lds, s, a, (unsigned)nvox, tiles);
+        const dim3 grid((unsigned)persist_wgs(a.stats ? nvox : bvox), (unsigned)(a.Cout / 32));
+        if (a.sd == 2) hipLaunchKernelGGL(upconv_fwd_persist_kernel<2>, grid, dim3(512), lds, s, a, (unsigned)bvox, tiles);
+        else hipLaunchKernelGGL(upconv_fwd_persist_kernel<1>, grid, dim3(512), lds, s, a, (unsigned)bvox, tiles);
         E3_CHECK_HIP(hipGetLastError());
         return E3_OK;
     }
