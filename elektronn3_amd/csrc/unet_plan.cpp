@@ -952,7 +952,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             // needed region: of the skip activation the decoder reads only what the level's transposed conv has to produce (need[] of the up unit = the box of the concat
             // buffer's voxels that the block's first conv reads) -- the rest is computed for the pool but not stored (E3_NO_STORE_BOX=1: A/B switch)
             static const bool no_store_box = getenv("E3_NO_STORE_BOX") != nullptr;
-            if (!no_store_box && is_enc_conv2 && pool_after && a.pool_out && !no_pool_fuse && a.box_hi[0] <= 0 && (u.cout & 31) == 0 && es && S == 1 &&
+            if (!no_store_box && is_enc_conv2 && pool_after && a.pool_out && !no_pool_fuse && a.box_hi[0] <= 0 && (u.cout & 31) == 0 && es && S == 1 && B.wpk_f[k] &&
                 conv_wino_layout(w4f, ci.D, ci.H, ci.W, u.cin, u.cout, 1) == 2 && !training && !vcrop && !residual && !cfg.attention && !cfg.merge_add && dst == B.cat[u.level] + u.cout) {
                 size_t ku = 0;
                 for (; ku < plan->units.size(); ++ku) if (plan->units[ku].is_up && plan->units[ku].level == u.level) break;
@@ -961,7 +961,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             }
             // ... and the pooled tensor goes to the next level's first conv chunked as well (only out of the conv epilogue: the separate pool pass writes rows)
             size_t plck = 0;
-            if (a.pool_out && !no_pool_fuse && a.box_hi[0] <= 0 && (u.cout & 31) == 0 && conv_wino_layout(w4f, ci.D, ci.H, ci.W, u.cin, u.cout, 1) == 2 && es) {
+            if (a.pool_out && !no_pool_fuse && a.box_hi[0] <= 0 && (u.cout & 31) == 0 && B.wpk_f[k] && S == 1 && conv_wino_layout(w4f, ci.D, ci.H, ci.W, u.cin, u.cout, 1) == 2 && es) {
                 LevelDims pg = lo; pg.D = (lo.D + 1) / 2; pg.H = (lo.H + 1) / 2; pg.W = (lo.W + 1) / 2; pg.vox = (size_t)N * pg.D * pg.H * pg.W;
                 if (next_reads_chunks(k, u.cout, pg)) { plck = pg.vox * 8; a.pool_chunk = plck; }
             }
