@@ -1523,3 +1523,12 @@ torch.save(out, sys.argv[1])
         outs.append(torch.load(f))
     for k in outs[0]:
         assert torch.isfinite(outs[0][k]).all() and torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_inference_tensor_layouts_fuzz():
+    """tools/fuzz_eval_layouts.py on a handful of random configurations (options, ResUNet blocks, ragged grids, needed regions): the default inference layouts
+    (channel-chunked tensors, store boxes, transposed-conv boxes) against plain rows / whole tensors in two child processes, bit for bit."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_eval_layouts.py'), '14', '3'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and ' 0 mismatches' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

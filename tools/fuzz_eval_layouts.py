@@ -17,7 +17,8 @@ def child(n_cases, seed, path):
     for case in range(n_cases):
         nb = ri(2, 4); sf = (16, 32, 32, 64)[ri(0, 3)]; inc = ri(1, 2); outc = ri(2, 4)
         mult = 2 ** (nb - 1)
-        D = ri(1, 4) * mult + (ri(0, 3) if ri(0, 1) else 0); H = ri(2, 6) * mult + ri(0, 5); W = ri(2, 8) * mult + ri(0, 5)
+        big = 3 if os.environ.get('FUZZ_BIG') else 1        # (FUZZ_BIG=1: grids on which the kernels are the default choice, not forced)
+        D = ri(1, 4) * big * mult + (ri(0, 3) if ri(0, 1) else 0); H = ri(2, 6) * big * mult + ri(0, 5); W = ri(2, 8) * big * mult + ri(0, 5)
         N = ri(1, 2)
         kw = {}
         v = ri(0, 9)
