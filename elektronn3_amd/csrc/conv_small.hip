@@ -264,7 +264,13 @@ __global__ __launch_bounds__(256, 2) void conv_first_mfma_kernel(const ConvSmall
             const char* img = reinterpret_cast<const char*>(xs[cur]);
             const int d = it.d0 + wave;
             // output descriptor at the brick's first voxel (launcher: four d-planes of the output view < 2^31 bytes); voxels outside the tensor: out-of-range offset
-            const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(a.y + ((((size_t)it.nb * a.D + it.d0) * a.H + it.h0) * a.W + it.w0) * a.y_ldc + cbase, 0, 0x7fffffff, 0x00020000);
+            // (channel-chunked output, ConvSmallArgs::y_chunk: a voxel's row is the 8 channels of one chunk plane; channel cbase + 16 (q >> 1) + 8 kk + 4 (q & 1)
+            // lives in plane cbase / 8 + 2 (q >> 1) + kk at float 4 (q & 1): the plane offsets are part of the LANE offsets)
+            const size_t ychk = a.y_chunk;
+            const int ys = ychk ? 8 : a.y_ldc;
+            const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(a.y + ((((size_t)it.nb * a.D + it.d0) * a.H + it.h0) * a.W + it.w0) * ys +
+                                                                                  (ychk ? (size_t)(cbase >> 3) * ychk : (size_t)cbase), 0, 0x7fffffff, 0x00020000);
+            const unsigned qstep = ychk ? (unsigned)(2 * ychk * 4) : 64u, kstep = ychk ? (unsigned)(ychk * 4) : 32u;      // bytes between q >> 1 = 0, 1 / between kk = 0, 1
             // patches of a row: 14 LDS reads, requested one row ahead of the 14 MFMAs that consume them (one accumulator chain: a dependent
             // v_mfma_f32_32x32x2_f32 issues right behind its predecessor's 16 passes)
             float bb[2][14];
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_mfma_kernel(const ConvSmall
                 {
                     const int h = it.h0 + r, w = it.w0 + n;
                     const bool valid = d < a.D && h < a.H && w < a.W;
-                    const unsigned yoff = valid ? (unsigned)(((((wave * a.H) + r) * a.W + n) * a.y_ldc + 8 * kk) * 4) : OOB;       // relative to the brick's first voxel
+                    const unsigned yoff = valid ? (unsigned)((((wave * a.H) + r) * a.W + n) * ys * 4) + (unsigned)kk * kstep : OOB;       // relative to the brick's first voxel
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_mfma_kernel(const ConvSmall
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                         }
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rs, yoff, (16 * (q >> 1) + 4 * (q & 1)) * 4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rs, valid ? yoff + (unsigned)(q >> 1) * qstep : OOB, (4 * (q & 1)) * 4, 0);
                         if (STATS) {
                             f32x4 dv = v - bq[q];
 #pragma unroll
@@ -796,6 +802,9 @@ static bool first_mfma(int N, int D, int H, int W, int planar, int Cin, int Cout
     const bool planes_fit = (long long)H * W * Cout * 4 * 4 < 0x7fffffffll && (long long)H * W * 6 * 4 < 0x7fffffffll;
     return items >= min_items && items < (1ll << 31) && planes_fit;
 }
+bool conv_first_chunk_ok(int N, int D, int H, int W, int planar, int Cin, int Cout) {
+    return first_mfma(N, D, H, W, planar, Cin, Cout) && chunked_layout_ok((size_t)N * D * H * W, Cout);
+}
 int conv_small_stats_parts2(int N, int D, int H, int W, int planar, int Cin, int Cout) {
     return first_mfma(N, D, H, W, planar, Cin, Cout) ? FGRID / (Cout / 32) : conv_small_stats_parts(N, D, H, W, planar);
 }
@@ -806,6 +815,8 @@ int launch_conv_small_fwd(ConvSmallArgs a, hipStream_t s) {
     // (32-bit buffer offsets: four d-planes of the output view and six of the input view must stay below 2^31 bytes; larger views -- and misaligned outputs --
     // take the one-brick kernel below, except with statistics, whose record count the caller has already sized for this kernel)
     const bool fits = ((uintptr_t)a.y & 15) == 0 && (long long)a.H * a.W * a.y_ldc * 4 * 4 < 0x7fffffffll && (a.xs_d ? a.xs_d : (long long)a.H * a.W) * 6 * 4 < 0x7fffffffll;
+    E3_REQUIRE(!a.y_chunk || (fits && !a.stats && a.y_chunk == (size_t)a.N * a.D * a.H * a.W * 8 && conv_first_chunk_ok(a.N, a.D, a.H, a.W, a.planar, a.Cin, a.Cout)), E3_ERR_INVALID,
+               "first conv: bad channel-chunked output (persistent matrix-core kernel without statistics only)");
     if (first_mfma(a.N, a.D, a.H, a.W, a.planar, a.Cin, a.Cout) && (fits || a.stats)) {
         E3_REQUIRE(fits, E3_ERR_UNSUPPORTED, "first conv with statistics: view too large or misaligned for the persistent kernel (32-bit buffer offsets)");
         const int tD = cdiv(a.D, FB_D), tH = cdiv(a.H, FB_H), tW = cdiv(a.W, FB_W), npass = a.Cout / 32;

@@ -155,7 +155,9 @@ struct ConvSmallArgs {
     const float* epi_scale; const float* epi_shift;
     float* stats;
     long long xs_n, xs_d, xs_h;  // xs_d != 0: x is a view inside a larger volume (element strides of sample, d-plane, h-row; w stride = Cin)
+    size_t y_chunk;              // != 0 (persistent matrix-core kernel only, conv_first_chunk_ok()): y is written channel-chunked, [Cout / 8][N][D][H][W][8] (ConvArgs::y_chunk)
 };
+bool conv_first_chunk_ok(int N, int D, int H, int W, int planar, int Cin, int Cout);      // the first conv of this shape can write a channel-chunked output
 int conv_small_stats_parts(int N, int D, int H, int W, int planar);
 int conv_small_stats_parts2(int N, int D, int H, int W, int planar, int Cin, int Cout);      // record count of launch_conv_small_fwd for this shape
 int launch_conv_small_fwd(ConvSmallArgs a, hipStream_t s);

@@ -898,6 +898,8 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
             a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.Cout = u.cout; a.planar = u.planar;
             a.epi_scale = es; a.epi_shift = eh; a.stats = (bn_train && !vcrop) ? stat_buf : nullptr;
             if (view && k == 0) { a.xs_n = view->x_stride[0]; a.xs_d = view->x_stride[1]; a.xs_h = view->x_stride[2]; }      // (the tile is read in place)
+            if (es && !two_pass && !vcrop && !u.enc_last && dst_ldc == u.cout && conv_first_chunk_ok(N, ci.D, ci.H, ci.W, u.planar, u.cin, u.cout) &&
+                next_reads_chunks(k, u.cout, lo)) { a.y_chunk = lo.vox * 8; cur_chunk = a.y_chunk; }
             parts = conv_small_stats_parts2(N, ci.D, ci.H, ci.W, u.planar, u.cin, u.cout);
             { Prof pr(plan, s, (int)k, 0); RUN(launch_conv_small_fwd(a, s)); }
         } else {
