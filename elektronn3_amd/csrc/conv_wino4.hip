@@ -45,6 +45,7 @@ static_assert(V_POOLX + V_HEADW <= V_RUN && V_LDS_FLOATS * 4 <= 160 * 1024, "LDS
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
 typedef __attribute__((address_space(3))) void* lds_ptr_v;
+typedef const volatile __attribute__((address_space(3))) f32x2v* lds_cv2;      // (volatile: see read_window)
 
 // Layout of a raw plane: halo voxel (zh, zw) -> slot ((zh & 1) * 3 + (zh >> 1)) * 20 + (zw & 3) * 5 + (zw >> 2) of 32 bytes (8 channels): the stride-2
 // tile origins along h and the stride-4 origins along w are consecutive slots; the 16-byte half q of a voxel sits at q ^ ((zh >> 1) & 1), and planes
@@ -209,9 +210,12 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
     f32x4 acc[24][2];
     f32x4 Bv[24];
     f32x2v ra[4][6], rb[4][6];          // raw window of the NEXT unit (planes A and B), read under the MFMAs of the current one
+    // (volatile LDS accesses: the compiler pairs plain 8-byte reads of one base into ds_read2_b64, which the LDS serves in 16-lane groups on 32 banks --
+    // 8 LDS cycles per wave-instruction, and the two depth tiles of a group then meet on the same bank: 16 -- where two ds_read_b64 (32-lane groups on
+    // 64 banks: the layout above is conflict-free for them) take 2 + 2.  SQ_LDS_BANK_CONFLICT 0.13 of the kernel's cycles before, profiles/r05_sq_counters.md.)
     auto read_window = [&](const float* buf, int h, int w) {
-        ra[h][w] = *reinterpret_cast<const f32x2v*>(buf + rdA[h >> 1] + rd_imm(h, w));
-        rb[h][w] = *reinterpret_cast<const f32x2v*>(buf + rdB[h >> 1] + rd_imm(h, w));
+        ra[h][w] = *(lds_cv2)(buf + rdA[h >> 1] + rd_imm(h, w));
+        rb[h][w] = *(lds_cv2)(buf + rdB[h >> 1] + rd_imm(h, w));
     };
 
 #ifdef E3_W4_TIMING      // developer build (tools/phase_timing_w4.py): s_memtime stamps of the workgroup's third brick instead of statistics
@@ -338,11 +342,11 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
                 }
                 // issue order inside the pair: MFMA, window read, MFMA, DMA piece, MFMA, window read, MFMAs, weight requests
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (pp < 12) { __builtin_amdgcn_sched_group_barrier(0x004, 8, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
                 __builtin_amdgcn_sched_barrier(0);
