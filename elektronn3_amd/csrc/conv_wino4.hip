@@ -341,11 +341,11 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
                     Bv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_nx, b_voff + (p & 3) * 1024, (p & ~3) * 1024, 0));
                 }
                 // issue order inside the pair: MFMA, window read, MFMA, DMA piece, MFMA, window read, MFMAs, weight requests
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                // (the window reads are volatile and stay behind the DMA piece in front of them)
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (pp < 12) { __builtin_amdgcn_sched_group_barrier(0x004, 8, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
