@@ -340,15 +340,20 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
                     if (E3_W4_ABL & 2) continue;
                     Bv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_nx, b_voff + (p & 3) * 1024, (p & ~3) * 1024, 0));
                 }
-                // issue order inside the pair: MFMA, window read, MFMA, DMA piece, MFMA, window read, MFMAs, weight requests
                 // (the window reads are volatile and stay behind the DMA piece in front of them)
+// issue order inside the pair: MFMA, [DMA piece], two window reads, 2 MFMAs, two window reads, 3 MFMAs, weight request, 2 MFMAs, weight request
+                // (a position's weights are free after its last MFMA: the sixth resp. eighth of the pair).  Measured alternatives, same box, cfg-5 tile: the four
+                // reads together 6.69 ms, both weight requests at the end 6.60, this order 6.58, one read per MFMA 6.63, DMA piece late 6.64, position-major
+                // MFMAs with the first request after four 6.65 (profiles/r05_w4_phases.md section 9)
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (pp < 12) { __builtin_amdgcn_sched_group_barrier(0x004, 8, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (pp == 12) stage_advance();      // (the cursor's scalar arithmetic rides in the matrix shadow; the last piece of this unit went out in pair 5)
                 if (pp == 10 && c < 8) TSTAMP(4 + 5 * c);
