@@ -24,6 +24,9 @@
 #include <type_traits>
 #include "kernels.h"
 
+#ifndef E3_W4_NT_MIN_MB
+#define E3_W4_NT_MIN_MB 128   // non-temporal output stores of the training forms (rows) from this tensor size on (same-box A/B: 0 and 128 alike, step 11.205 -> 11.105 ms)
+#endif
 #ifndef E3_W4_ABL
 #define E3_W4_ABL 0       // developer builds (-DE3_TIMING): bit mask of pieces left out (timing experiments, wrong results)
 #endif
@@ -505,6 +508,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
             // are y_chunk floats apart -- the lane's two-piece half of a chunk goes to plane (n0 + 4 pc) / 8.  (The launcher bounds the whole tensor by 2^31 bytes.)
             const size_t ychk = BNRED ? (size_t)0 : KA()->y_chunk;
             const int ys = ychk ? 8 : yl;
+            const bool nt_out = !AFF && !ychk && (size_t)KA()->N * D * H * W * KA()->Ncols * 4 > (size_t)E3_W4_NT_MIN_MB * 1048576;
             const size_t plane_s = ychk ? (size_t)H * W * 8 : plane_y;
             const size_t yrem = ychk ? (size_t)0x7fffffffu : (size_t)(D - d0) * plane_y * 4;
             const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -526,7 +530,10 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
                 const int od = j >> 2, owi = (j >> 1) & 1, std_ = 2 * (j & 1) + od;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(tA + od * (16 * 64 * 4) + (owi * 16 + 8 * (j & 1) + r) * 32 + (elane & 7) * 4);
                 const bool dok = d0 + std_ < sb_d1 && d0 + std_ >= sb_d0;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), y_rs, dok ? sv[owi] : OOB, (int)((std_ * plane_s + owi * ys) * 4), 0);
+                // (training forms, rows: the gradient / raw tensor of a large grid is streamed out past the caches -- non-temporal, aux = 2 -- so that the halo lines and the
+                // weights the neighbouring bricks re-read stay resident: step -0.08 ms; the 32-byte fragments of the channel-chunked inference tensors must NOT go that way: tile +6.6 %)
+                if (nt_out) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), y_rs, dok ? sv[owi] : OOB, (int)((std_ * plane_s + owi * ys) * 4), 2);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), y_rs, dok ? sv[owi] : OOB, (int)((std_ * plane_s + owi * ys) * 4), 0);
                 if (BNRED) {
                     // dz = dA * act'(z), z = x * scale + shift;  xhat = (x - mean) * invstd  (the expressions of bn_bwd_kernel)
                     const float* const kb = kst + 2 * 96 + 4 * pc;
