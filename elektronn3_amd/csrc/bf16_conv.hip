@@ -501,15 +501,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16_pkernel(const ConvB16Args a, 
                                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                                 } else v = v + bq[q];
                                 const bf16x4 rb = __builtin_convertvector(v, bf16x4);            // round to nearest even
-#ifdef E3_B16_NT_MIN_MB
-                                if (q & 1) { if (valid && !((E3_PABL & 16) && a.D > 0)) {
-                                    const bf16x8 o8 = __builtin_shufflevector(rprev, rb, 0, 1, 2, 3, 4, 5, 6, 7);
-                                    if (!AFF && (size_t)a.N * a.D * a.H * a.W * a.Cout * 2 > (size_t)E3_B16_NT_MIN_MB * 1048576) __builtin_nontemporal_store(o8, reinterpret_cast<bf16x8*>(yrow + 16 * (q >> 1)));
-                                    else *reinterpret_cast<bf16x8*>(yrow + 16 * (q >> 1)) = o8;
-                                } }
-#else
                                 if (q & 1) { if (valid && !((E3_PABL & 16) && a.D > 0)) *reinterpret_cast<bf16x8*>(yrow + 16 * (q >> 1)) = __builtin_shufflevector(rprev, rb, 0, 1, 2, 3, 4, 5, 6, 7); }
-#endif
                                 else rprev = rb;
                                 if (!AFF) {               // (statistics only exist without the folded epilogue)
                                     f32x4 dv = __builtin_convertvector(rb, f32x4) - bq[q];
