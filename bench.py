@@ -273,7 +273,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='(internal) time the CPU baseline, print its JSON object, exit')
     ap.add_argument('--no-predictor', action='store_true', help='skip the Predictor MVox/s leg')
-    ap.add_argument('--predictor-volume', choices=('full', 'sub'), default=None, help='full = 512x2048x2048 (default for N = 1), sub = 288x1152x1152')
+    ap.add_argument('--predictor-volume', choices=('full', 'sub', 'tiny'), default=None, help='full = 512x2048x2048 (default for N = 1), sub = 288x1152x1152, tiny = 96x384x384 (dry runs)')
+    ap.add_argument('--backend', choices=('nccl', 'gloo'), default='nccl', help='process-group backend for N > 1.  nccl = RCCL (the measured configuration).  gloo is TEST-ONLY: it lets the whole '
+                    'N > 1 branch (launcher respawn, barriers, MAX-reduced time, global-batch criterion, GradSync, tile-parallel Predictor leg, rank-0 JSON) run where RCCL cannot, '
+                    'e.g. with --share-device on a one-GPU box; the line is then marked "test_only"')
+    ap.add_argument('--share-device', action='store_true', help='TEST-ONLY: every rank uses cuda:0 (dry run of the N > 1 branch on a one-GPU box; implies nothing about scaling)')
     ap.add_argument('--profile-layer', default='up_convs.2.conv1')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the cfg-3 (bf16) / cfg-4 / two-call training legs of the default f32 run')
     ap.add_argument('--dp-overlap', action='store_true', help='N > 1: all-reduce bucket A at the bucket event, overlapped with the rest of the backward '
@@ -292,8 +296,11 @@ def main():
         raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); pass the same N to both')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU (the HIP path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    if args.share_device and args.backend == 'nccl' and world > 1:
+        raise SystemExit('bench.py: --share-device needs --backend gloo (RCCL wants one GPU per rank)')
+    dev_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     dist = None
     if world > 1 or 'RANK' in os.environ:   # launched by torch.distributed.run (also with a single rank)
         import torch.distributed as dist
@@ -308,7 +315,10 @@ def main():
             pg_opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
         except Exception:  # noqa: BLE001
             pg_opts = None
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev, **({'pg_options': pg_opts} if pg_opts is not None else {}))
+        if args.backend == 'gloo':
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev, **({'pg_options': pg_opts} if pg_opts is not None else {}))
 
     from elektronn3_amd.unet import UNet
     from elektronn3_amd.loss import CombinedCEDiceLoss   # the example's criterion (0.5 CE + 0.5 Dice, class weights) on device
@@ -404,7 +414,10 @@ def main():
             'metric': 'voxels/sec (train fwd+bwd) 3D UNet 64x128x128',
             'value': vox_per_step / (ms_per_step * 1e-3),
             'unit': 'voxels/s',
-            'n_gpus': world, 'rccl_ranks': (dist.get_world_size() if dist is not None else 0),
+            'n_gpus': world, 'rccl_ranks': (dist.get_world_size() if (dist is not None and args.backend == 'nccl') else 0),
+            'backend': (args.backend if dist is not None else None),
+            **({'test_only': f'dry run of the N > 1 branch: backend {args.backend}, ' + ('all ranks on cuda:0' if args.share_device else 'one GPU per rank') + ' -- not a measurement',
+                'dist_ranks': dist.get_world_size()} if (dist is not None and (args.backend != 'nccl' or args.share_device)) else {}),
             'dp_mode': (sync.mode if sync is not None else None), 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -464,7 +477,7 @@ def main():
         x = tgt = None
         torch.cuda.empty_cache()
         vol_kind = args.predictor_volume or ('full' if world == 1 else 'sub')
-        shape = (512, 2048, 2048) if vol_kind == 'full' else (288, 1152, 1152)
+        shape = {'full': (512, 2048, 2048), 'sub': (288, 1152, 1152), 'tiny': (96, 384, 384)}[vol_kind]
         # the tile-parallel leg has a control-plane exchange (shared-memory name, closing barrier): a rank that dies in it must not
         # take the training line down with it -- after 300 s rank 0 prints what it has and every rank leaves
         watchdog = None

@@ -734,6 +734,19 @@ Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout, int planar
     const int cgroups = Cout / 32;
     d.persist = (!no_persist && !planar && d.bd == 4 && d.tw == 32 && d.co_t == 1 && d.ksplit == 1 && wgs >= persist_min && 64 % cgroups == 0 &&
                  (cdiv(H, 4) & 1) == 0 && (cdiv(W, 32) & 1) == 0 && wgs * 256 < (1l << 32)) ? 1 : 0;
+    if (d.persist) {
+        // multiply-high division x / d = umulhi(x, ceil(2^32 / d)) is exact only while x * (m d - 2^32) < 2^32: every dividend of the kernel is below the item
+        // count (+ one XCD share for the padded ranges); a shape beyond that bound takes the one-brick kernels -- decided HERE, so that the statistics sizing
+        // (conv_b16_stats_parts) and the launcher ask one predicate
+        const unsigned tD = (unsigned)cdiv(D, 4), tH = (unsigned)cdiv(H, 4), tW = (unsigned)cdiv(W, 32);
+        const unsigned long long items = (unsigned long long)N * tD * tH * tW * cgroups;
+        unsigned long long per_xcd = (items + 7) / 8; per_xcd = (per_xcd + cgroups - 1) / cgroups * cgroups;
+        for (unsigned dv : {(unsigned)cgroups, tD * 4, (tH >> 1) * (tW >> 1), tW >> 1}) {
+            if (dv <= 1) continue;
+            const unsigned long long m = ((1ull << 32) + dv - 1) / dv, e = m * dv - (1ull << 32), xmax = items + per_xcd + 256;
+            if (e * xmax >= (1ull << 32)) d.persist = 0;
+        }
+    }
     return d;
 }
 int reduce_blocks(size_t vox, int C) {
@@ -811,24 +824,14 @@ int launch_conv_b16(ConvB16Args a, hipStream_t s) {
         pa.tw2 = (unsigned)(tW >> 1); pa.m_tw2 = magic(pa.tw2);
         pa.items = (unsigned)((size_t)a.N * tD * tH * tW * pa.cgroups);
         pa.per_xcd = (pa.items + 7) / 8; pa.per_xcd = (pa.per_xcd + pa.cgroups - 1) / pa.cgroups * pa.cgroups;
-        // multiply-high division x / d = umulhi(x, ceil(2^32 / d)) is exact only while x * (m d - 2^32) < 2^32: every dividend of the kernel is below the item
-        // count (+ one XCD share for the padded ranges); a shape beyond that bound takes the one-brick kernels below
-        bool exact = true;
-        for (unsigned dv : {pa.cgroups, pa.per, pa.ncol, pa.tw2}) {
-            if (dv <= 1) continue;
-            const unsigned long long m = ((1ull << 32) + dv - 1) / dv, e = m * dv - (1ull << 32), xmax = (unsigned long long)pa.items + pa.per_xcd + 256;
-            if (e * xmax >= (1ull << 32)) exact = false;
-        }
         using GP = Geo<4, 3, 32, 16>;
         constexpr int lds = 2 * GP::IMG;
         static_assert(GP::IMG >= 4 * 2 * 32 * 33 * 4 + 1024, "statistics scratch fits one image");
         static bool pattr = false;
         if (!pattr) { E3_CHECK_HIP(hipFuncSetAttribute((const void*)conv_b16_pkernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); pattr = true; }
-        if (exact) {
-            hipLaunchKernelGGL((conv_b16_pkernel<1>), dim3(PGRID), dim3(256), lds, s, a, pa);
-            E3_CHECK_HIP(hipGetLastError());
-            return E3_OK;
-        }
+        hipLaunchKernelGGL((conv_b16_pkernel<1>), dim3(PGRID), dim3(256), lds, s, a, pa);      // (conv_b16_decomp has checked that the magic divisions are exact)
+        E3_CHECK_HIP(hipGetLastError());
+        return E3_OK;
     }
     // 16-channel LDS images, three workgroups per CU, where the shape allows (BD = 4, 3x3x3, 32-voxel rows, one 32-channel output tile, no split-K):
     // 150 -> 133, 247 -> 227, 154 -> 138 us on the level-0 forward convs of cfg 2, 5.89 -> 5.76 ms per step (the 32-channel-image form stays for the other decompositions)

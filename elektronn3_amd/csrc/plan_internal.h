@@ -100,3 +100,11 @@ void net_dims(const e3_unet_plan* p, int N, int D, int H, int W, NetDims& nd);
 // conv and halves per transposed conv on the way back through the decoder; the encoder is needed in full (the bottom level sees all of it).
 struct NeedBox { int lo[3], hi[3]; bool on = false; };
 std::vector<NeedBox> need_boxes(const e3_unet_plan* plan, const NetDims& ND, const int* roi);
+
+// What the packed / folded weights lying in a scratch buffer belong to (E3_FWD_REUSE_PACKED is honoured only when the caller's claim can be checked):
+// recorded by a successful fp32 inference forward, forgotten by every other call that is handed the same scratch pointer (unet_plan.cpp).
+struct PackedSig {
+    const void* plan = nullptr; int N = 0, D = 0, H = 0, W = 0; uint64_t params = 0; uint32_t mode = 0;
+    bool operator==(const PackedSig& o) const { return plan == o.plan && N == o.N && D == o.D && H == o.H && W == o.W && params == o.params && mode == o.mode; }
+};
+void packed_sig_forget(const void* scratch);

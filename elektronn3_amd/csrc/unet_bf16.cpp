@@ -182,6 +182,7 @@ static int forward_b16_impl(e3_unet_plan* plan, void* stream, const void* x, int
                             void* const* params, const float* momenta, float* y,
                             void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, uint32_t flags, const int* roi) {
     E3_REQUIRE(plan && x && y && params && scratch, E3_ERR_INVALID, "null argument");
+    packed_sig_forget(scratch);
     E3_REQUIRE(supported(plan->cfg), E3_ERR_UNSUPPORTED, "configuration not on the native bf16 path");
     hipStream_t s = (hipStream_t)stream;
     const bool training = (flags & E3_FWD_TRAINING) != 0;
@@ -328,6 +329,7 @@ static int backward_b16_impl(e3_unet_plan* plan, void* stream, const float* dy, 
                              void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
                              void* bucket_event, int bucket_after_down_block) {
     E3_REQUIRE(plan && (dy || hl) && x && params && grads && saved && scratch, E3_ERR_INVALID, "null argument");
+    packed_sig_forget(scratch);
     E3_REQUIRE(supported(plan->cfg), E3_ERR_UNSUPPORTED, "configuration not on the native bf16 path");
     E3_REQUIRE(dx == nullptr, E3_ERR_UNSUPPORTED, "the native bf16 path does not compute the gradient of the network input");
     hipStream_t s = (hipStream_t)stream;

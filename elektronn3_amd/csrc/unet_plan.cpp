@@ -12,6 +12,7 @@
 //   scratch packed weights, BN statistic records, gradient ping-pong buffers per level, split-K slabs.
 #include <atomic>
 #include <cstdlib>
+#include <map>
 #include <unordered_map>
 #include <vector>
 
@@ -382,6 +383,20 @@ struct Prof {
 
 }  // namespace
 
+// scratch pointer -> what its packed weights belong to (plan_internal.h: PackedSig)
+static std::mutex g_sig_mutex;
+static std::map<const void*, PackedSig> g_sigs;
+void packed_sig_forget(const void* scratch) { std::lock_guard<std::mutex> g(g_sig_mutex); g_sigs.erase(scratch); }
+// true when the record of `scratch` equals `sig`; the record is removed either way (the caller puts it back when its call has succeeded)
+static bool packed_sig_take(const void* scratch, const PackedSig& sig) {
+    std::lock_guard<std::mutex> g(g_sig_mutex);
+    auto it = g_sigs.find(scratch);
+    const bool same = it != g_sigs.end() && it->second == sig;
+    if (it != g_sigs.end()) g_sigs.erase(it);
+    return same;
+}
+static void packed_sig_record(const void* scratch, const PackedSig& sig) { std::lock_guard<std::mutex> g(g_sig_mutex); g_sigs[scratch] = sig; }
+
 std::vector<NeedBox> need_boxes(const e3_unet_plan* plan, const NetDims& ND, const int* roi) {
     std::vector<NeedBox> need(plan->units.size());
     if (!roi) return need;
@@ -722,7 +737,14 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
     const int w4f = training ? 0 : CF_WINO4;
     // inference: the caller states that the packed / folded weights of the previous call (same plan, same scratch, same N, D, H, W, same parameter values) are
     // still in place -- the tile loop of a Predictor re-packed 22 MB of weights 726 times.  (Not with the shared `wemb` of the 1x1x1 ResizeConv variants.)
-    const bool reuse = !training && (flags & E3_FWD_REUSE_PACKED) != 0 && cfg.up_resize < 3;
+    // The claim is checked against what the last successful inference forward on this scratch buffer recorded (plan, shape, the parameter table's addresses,
+    // roi / tile form): a caller that sets the flag wrongly gets a fresh pack, not stale weights.  Every call forgets the record first, so a call that fails
+    // half-way leaves none behind.
+    PackedSig sig; sig.plan = plan; sig.N = N; sig.D = D; sig.H = H; sig.W = W; sig.mode = (roi ? 1u : 0u) | (view ? 2u : 0u);
+    sig.params = 1469598103934665603ull;
+    for (size_t i = 0; i < plan->params.size(); ++i) sig.params = (sig.params ^ (uint64_t)(uintptr_t)params[i]) * 1099511628211ull;
+    const bool sig_match = packed_sig_take(scratch, sig);
+    const bool reuse = !training && (flags & E3_FWD_REUSE_PACKED) != 0 && cfg.up_resize < 3 && sig_match;
     auto wp_of = [&](size_t k) { return (!training && B.wpk_u[k]) ? B.wpk_u[k] : B.wpack; };
     if (!reuse)
     {   // Winograd weight transforms of every layer that uses them, in one launch
@@ -1104,6 +1126,7 @@ static int unet_forward_impl(e3_unet_plan* plan, void* stream, const float* x, i
                                       fused ? lb.scale : nullptr, fused ? lb.shift : nullptr, head_act));
         }
     }
+    if (!training && cfg.up_resize < 3) packed_sig_record(scratch, sig);
     return E3_OK;
 }
 
@@ -1151,6 +1174,7 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
                          void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
                          void* bucket_event, int bucket_after_down_block, uint32_t flags) {
     E3_REQUIRE(plan && (dy || hl) && x && params && grads && saved && scratch, E3_ERR_INVALID, "null argument");
+    packed_sig_forget(scratch);
     // the forward ran with E3_FWD_FROZEN_BN: the statistics are constants, so dx = gamma * invstd * dz (no mean / variance terms)
     const bool frozen = (flags & E3_BWD_FROZEN_BN) != 0 && (plan->cfg.normalization == 1 || plan->cfg.attention);
     hipStream_t s = (hipStream_t)stream;

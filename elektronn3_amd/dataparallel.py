@@ -28,7 +28,9 @@ class GradSync:
     8, default 16 = two per XCD; ``E3_DP_CU_RESERVE``) to the collective's resident workgroups: the persistent conv kernels occupy every CU they
     get with one 512-register workgroup, and one that found its CU taken would wait a whole round (measured: +55 % on the step with ONE foreign
     wave, tools/probe_foreign_waves.py).  ``NCCL_MAX_NCHANNELS`` must be ``<= cu_reserve`` in the environment before the process group's first collective, so that RCCL's
-    kernel has at most that many workgroups (the constructor warns otherwise; it does not change the environment)."""
+    kernel has at most that many workgroups.  The constructor does not change the environment; it configures itself from it (see the comment in ``__init__``):
+    ``overlap=None`` overlaps iff that bound (or ``E3_DP_OVERLAP``) is exported, an overlap request that RCCL's channel count does not fit runs serial with a warning,
+    and so does a device on which no quiet side stream is found.  ``GradSync.mode`` reports the choice and its reason (``bench.py`` prints it as ``dp_mode``)."""
 
     def __init__(self, model, process_group=None, bucket_after_down_block=2, average=True, overlap=None, cu_reserve=None):
         import os
@@ -42,22 +44,35 @@ class GradSync:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # world == 1 normally short-circuits; `force` keeps the whole event/side-stream/all-reduce path alive (tests)
         self.force = bool(int(os.environ.get('E3_FORCE_GRADSYNC', '0')))
-        if overlap is None:
-            overlap = os.environ.get('E3_DP_OVERLAP') is not None
-        self.overlap = bool(overlap)
+        # Mode: overlap needs RCCL's kernel bounded to the reserved compute units, and that bound (NCCL_MAX_NCHANNELS) is read when
+        # the communicator is created -- the launcher's business, before torch.distributed's first collective (bench.py --dp-overlap exports it in front
+        # of init_process_group).  The constructor never touches the environment; it CONFIGURES ITSELF from it:
+        #   overlap=None   overlap iff E3_DP_OVERLAP is set or NCCL_MAX_NCHANNELS <= the reserve is already exported; serial otherwise
+        #   overlap=True   overlap -- but with an RCCL process group whose channel bound is missing or larger than the reserve: serial + a RuntimeWarning
+        #                  (an unbounded collective beside one-512-register-workgroup-per-CU kernels is the slowest form measured, never a safe default)
+        #   overlap=False  serial
+        # Backends without a device kernel of their own (gloo; the tests' `collective` stand-in) need no bound.  `mode` says what was chosen and why.
         if cu_reserve is None:
             cu_reserve = int(os.environ.get('E3_DP_CU_RESERVE', '16'))
-        self.cu_reserve = max(0, min(128, int(cu_reserve))) // 8 * 8 if self.overlap else 0
-        if self.overlap and self.cu_reserve:
-            # RCCL's kernel must fit the reserve: NCCL_MAX_NCHANNELS (read when a communicator is created, i.e. it must be in the environment BEFORE
-            # torch.distributed's first collective -- the launcher's business, bench.py --dp-overlap sets it before init_process_group) bounds its
-            # workgroups.  The constructor does not touch the environment (it would throttle every communicator created afterwards and would come too late
-            # for the one that matters); it only says so when the bound is missing or larger than the reserve.
+        reserve = max(0, min(128, int(cu_reserve))) // 8 * 8
+        ch = os.environ.get('NCCL_MAX_NCHANNELS')
+        bounded = ch is not None and ch.isdigit() and 0 < int(ch) <= reserve
+        try:
+            rccl = dist.is_initialized() and dist.get_backend(process_group) == 'nccl'
+        except Exception:      # (no default group yet)
+            rccl = False
+        requested = (os.environ.get('E3_DP_OVERLAP') is not None or bounded) if overlap is None else bool(overlap)
+        self.why = 'requested' if requested else 'default'
+        if requested and rccl and reserve and not bounded:
             import warnings
-            ch = os.environ.get('NCCL_MAX_NCHANNELS')
-            if ch is None or not ch.isdigit() or int(ch) > self.cu_reserve:
-                warnings.warn(f'GradSync(overlap=True, cu_reserve={self.cu_reserve}): NCCL_MAX_NCHANNELS={ch!r} does not bound the collective to the reserved '
-                              f'compute units; export NCCL_MAX_NCHANNELS={self.cu_reserve} before the process group is created', RuntimeWarning, stacklevel=2)
+            warnings.warn(f'GradSync: overlap requested with cu_reserve={reserve}, but NCCL_MAX_NCHANNELS={ch!r} does not bound RCCL\'s kernel to the reserved '
+                          f'compute units (export NCCL_MAX_NCHANNELS={reserve} before the process group is created): running SERIAL', RuntimeWarning, stacklevel=2)
+            requested = False
+            self.why = f'overlap refused: NCCL_MAX_NCHANNELS={ch!r} > reserve {reserve}'
+        elif requested and overlap is None and bounded:
+            self.why = f'NCCL_MAX_NCHANNELS={ch} <= reserve {reserve}'
+        self.overlap = requested
+        self.cu_reserve = reserve if self.overlap else 0
         self.collective = None        # tests / probes: callable(tensor) run on the side stream in place of the all-reduce
         self._flat = None
         self._views = None
@@ -70,8 +85,8 @@ class GradSync:
 
     @property
     def mode(self):
-        return (f'overlap (bucket event after down block {self.bucket_after_down_block}, {self.cu_reserve} CUs reserved)' if self.overlap
-                else 'serial (all-reduce after the backward)')
+        return (f'overlap (bucket event after down block {self.bucket_after_down_block}, {self.cu_reserve} CUs reserved; {self.why})' if self.overlap
+                else f'serial (all-reduce after the backward; {self.why})')
 
     # -- called from _UNetFunction.backward ------------------------------------------------------------------
     def flat_views(self, plan, tens):
@@ -93,14 +108,22 @@ class GradSync:
         return self._flat, self._views
 
     def _side_stream(self):
-        if self._comm_stream is None:
+        """The quiet side stream of this device (probed once per device and process), or None -- overlap is then switched off for good:
+        a side stream whose hardware queue slows every kernel of the compute stream costs more than the hidden collective is worth."""
+        if self._comm_stream is None and self.overlap:
             self._comm_stream = quiet_side_stream(self._flat.device)   # (high priority: collectives ahead of queued compute)
+            if self._comm_stream is None:
+                import warnings
+                warnings.warn('GradSync: no quiet side stream on this device (every candidate queue disturbs the compute stream): running SERIAL', RuntimeWarning)
+                self.overlap, self.cu_reserve, self.why = False, 0, 'overlap refused: no quiet side stream'
         return self._comm_stream
 
     def bucket_event(self):
         """Raw hipEvent_t (as c_void_p) that libe3unet records when bucket A is complete; None on CPU and in serial mode (the library then
         launches everything for the whole chip)."""
         if self._flat is None or not self._flat.is_cuda or (self.world == 1 and not self.force) or not self.overlap:
+            return None
+        if self._side_stream() is None:      # (decided HERE, in front of the backward's launches: without the event the library launches for the whole chip)
             return None
         import ctypes
         if self._event is None:
@@ -173,6 +196,7 @@ class GradSync:
 _REJECTED_STREAMS = []      # kept alive: a candidate that was found noisy keeps its hardware queue, so the next candidate gets another one
 
 
+_QUIET_FACTOR = 2.0         # a candidate passes when the burst beside its parked wait takes < 2 x the burst alone (a noisy queue: 4-5 x; tests lower it to force a refusal)
 _QUIET_STREAMS = {}         # device index -> the side stream found for it (one probe per device and process, not per GradSync)
 
 
@@ -183,7 +207,8 @@ def quiet_side_stream(device, priority=-1, tries=8, verbose=False):
     use; while a cross-stream wait (hipStreamWaitEvent) is parked on some of them, EVERY kernel of the compute stream takes ~50 us longer
     (the cfg-2 backward: 12 -> 18 ms) -- which ones depends on how many streams the process used before (every fourth or so).  So the
     candidate is tested the way GradSync uses it: a wait parked on it while a burst of tiny kernels runs on the current stream, timed against
-    the same burst alone; a noisy candidate is set aside (kept alive) and the next stream is tried."""
+    the same burst alone; a noisy candidate is set aside (kept alive) and the next stream is tried.  The verdict is cached per (device, priority):
+    one probe per process.  None when no candidate passes (the caller stays serial)."""
     dkey = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), priority)
     if dkey in _QUIET_STREAMS and not verbose:
         return _QUIET_STREAMS[dkey]
@@ -209,17 +234,18 @@ def quiet_side_stream(device, priority=-1, tries=8, verbose=False):
     with torch.cuda.device(device):
         burst(None)
         base = min(burst(None) for _ in range(3))
-        cand = None
+        found = None
         for _ in range(tries):
             cand = torch.cuda.Stream(device=device, priority=priority)
             t = min(burst(cand) for _ in range(2))
             if verbose:
                 print(f'quiet_side_stream: candidate {cand.cuda_stream:#x}: burst {t:.3f} ms (alone {base:.3f} ms)')
-            if t < 2.0 * base + 0.05:
+            if t < _QUIET_FACTOR * base + 0.05:
+                found = cand
                 break
             _REJECTED_STREAMS.append(cand)
-    _QUIET_STREAMS[dkey] = cand       # (none was quiet: the last one)
-    return cand
+    _QUIET_STREAMS[dkey] = found      # (None: no candidate was quiet)
+    return found
 
 
 def shard_batch(batch, rank, world):

@@ -93,9 +93,11 @@ _NO_PACK_REUSE = __import__('os').environ.get('E3_NO_PACK_REUSE') is not None   
 
 def _get_scratch(device, nbytes, token=None):
     """Per-(device, stream) scratch buffer, grown on demand.  Safe to share between consecutive calls on one stream
-    (everything is stream-ordered).  ``token`` (inference forwards inside a ``UNet.frozen_weights()`` scope): returns ``(buffer, reuse)`` --
-    ``reuse`` says that the previous call on this buffer carried the same token, i.e. its packed weights are still in place
-    (E3_FWD_REUSE_PACKED); every other call clears the buffer's token."""
+    (everything is stream-ordered).  ``token`` (inference forwards inside a ``UNet.frozen_weights()`` scope): returns ``(buffer, reuse, key)`` --
+    ``reuse`` says that the previous SUCCESSFUL call on this buffer carried the same token, i.e. its packed weights are still in place
+    (E3_FWD_REUSE_PACKED).  The buffer's token is cleared here in every case; the caller records it with ``_packed_ok(key, token)`` once its
+    native call has returned without an error (a call that raises half-way -- out of memory for the output, a refused argument -- must not
+    leave a promise behind that the next call of the same shape would trust)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
@@ -107,9 +109,14 @@ def _get_scratch(device, nbytes, token=None):
     if token is None:
         _packed.pop(key, None)
         return buf
-    reuse = _packed.get(key) == token and not _NO_PACK_REUSE
-    _packed[key] = token
-    return buf, reuse
+    reuse = _packed.pop(key, None) == token and not _NO_PACK_REUSE
+    return buf, reuse, key
+
+
+def _packed_ok(key, token):
+    """The native inference forward that packed (or reused) the weights in scratch buffer `key` has succeeded."""
+    if key in _scratch:
+        _packed[key] = token
 
 
 def _frozen_token(module, plan, dims, tens):
@@ -183,9 +190,9 @@ def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, traini
     saved = _alloc_saved(dev, max(saved_bytes, 256)) if training else None
     token = _frozen_token(module, plan, (N, D, H, W), tens) if (not training and b16 is None and loss is None) else None
     if token is not None:
-        scratch, reuse = _get_scratch(dev, max(scratch_bytes, 256), token)
+        scratch, reuse, pkey = _get_scratch(dev, max(scratch_bytes, 256), token)
     else:
-        scratch, reuse = _get_scratch(dev, max(scratch_bytes, 256)), False
+        scratch, reuse, pkey = _get_scratch(dev, max(scratch_bytes, 256)), False, None
     Do, Ho, Wo = plan.out_dims(D, H, W)      # == (D, H, W) unless conv_mode='valid'
     y = torch.empty((N, plan.out_channels, Do, Ho, Wo), dtype=torch.float32, device=dev)
     ptrs = (c_void_p * len(tens))(*[t.data_ptr() for t in tens])
@@ -218,6 +225,8 @@ def _native_forward(module, plan, x, tens, softmax, want16, x_needs_grad, traini
                                           c_void_p(scratch.data_ptr()), c_size_t(scratch.numel()), flags, (ctypes.c_int * 6)(*roi)))
         else:
             check(fwd(*args))
+    if pkey is not None:
+        _packed_ok(pkey, token)
     return y, saved, xin, b16
 
 
@@ -1141,7 +1150,6 @@ class UNet(nn.Module):
         return self._run(x, softmax=True)
 
     @torch.jit.unused
-    @torch.jit.unused
     def frozen_weights(self):
         """Context manager: the caller promises not to change parameters or running statistics inside the ``with`` block.  Inference forwards of one
         shape (``self(x)``, ``forward_roi``, ``forward_tile``) then pack / Winograd-transform / fold the weights ONCE and later calls take them as
@@ -1160,6 +1168,7 @@ class UNet(nn.Module):
                     self.__dict__.pop('_frozen_scope', None)
         return scope()
 
+    @torch.jit.unused
     def forward_roi(self, x, roi, softmax=False):
         """Inference forward of which only the output voxels ``roi = ((d0, d1), (h0, h1), (w0, w1))`` will be used (the tile loop of
         ``inference.Predictor`` keeps the central crop of every tile, inference.py:496-525): the result has the full shape and equals
@@ -1208,9 +1217,9 @@ class UNet(nn.Module):
         _, scratch_bytes = plan.sizes(N, D, H, W, False, bf16=None)
         token = _frozen_token(self, plan, (N, D, H, W), tens)
         if token is not None:
-            scratch, reuse = _get_scratch(dev, max(scratch_bytes, 256), token)
+            scratch, reuse, pkey = _get_scratch(dev, max(scratch_bytes, 256), token)
         else:
-            scratch, reuse = _get_scratch(dev, max(scratch_bytes, 256)), False
+            scratch, reuse, pkey = _get_scratch(dev, max(scratch_bytes, 256)), False, None
         view = _lib.TileView()
         view.x = vol.data_ptr() + 4 * (int(in_lo[0]) * vol.stride(2) + int(in_lo[1]) * vol.stride(3) + int(in_lo[2]))
         view.x_stride[:] = [vol.stride(0), vol.stride(2), vol.stride(3)]
@@ -1222,6 +1231,8 @@ class UNet(nn.Module):
             check(lib.e3_unet_forward_tile(plan.handle, _lib.stream_ptr(dev), ctypes.byref(view), N, D, H, W, ptrs, c_void_p(scratch.data_ptr()),
                                            c_size_t(scratch.numel()), (E3_FWD_SOFTMAX if softmax else 0) | (E3_FWD_REUSE_PACKED if reuse else 0),
                                            (ctypes.c_int * 6)(int(d0), int(h0), int(w0), int(d1), int(h1), int(w1))))
+        if pkey is not None:
+            _packed_ok(pkey, token)
 
     @torch.jit.unused
     def forward_gradcp(self, x):

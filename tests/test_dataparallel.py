@@ -110,3 +110,46 @@ def test_gradsync_and_tile_parallel_gloo_world2(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f'ok{r}').exists() for r in range(world))
+
+
+def test_gradsync_configures_its_mode_from_the_environment(monkeypatch):
+    """overlap only when RCCL's channel bound fits the CU reserve (the launcher exported NCCL_MAX_NCHANNELS before the process
+    group was created); an overlap request without it runs serial and says so; backends without a device kernel need no bound."""
+    import warnings
+    from elektronn3_amd import dataparallel as dp
+    from elektronn3_amd.unet import UNet
+    model = UNet(1, 2, n_blocks=2, start_filts=8)
+    for k in ('E3_DP_OVERLAP', 'NCCL_MAX_NCHANNELS', 'E3_DP_CU_RESERVE'):
+        monkeypatch.delenv(k, raising=False)
+    s = dp.GradSync(model)
+    assert not s.overlap and s.cu_reserve == 0 and s.mode.startswith('serial') and 'default' in s.mode
+    # the bound is in the environment: overlap configures itself
+    monkeypatch.setenv('NCCL_MAX_NCHANNELS', '16')
+    s = dp.GradSync(model)
+    assert s.overlap and s.cu_reserve == 16 and 'NCCL_MAX_NCHANNELS=16' in s.mode
+    monkeypatch.setenv('NCCL_MAX_NCHANNELS', '32')         # larger than the default reserve: not a bound
+    assert not dp.GradSync(model).overlap
+    assert dp.GradSync(model, cu_reserve=32).overlap
+    assert not dp.GradSync(model, overlap=False, cu_reserve=32).overlap
+    # an RCCL group (faked: no GPU here) without the bound: an explicit request is refused, loudly
+    monkeypatch.delenv('NCCL_MAX_NCHANNELS')
+    monkeypatch.setattr(dp.dist, 'is_initialized', lambda: True)
+    monkeypatch.setattr(dp.dist, 'get_backend', lambda group=None: 'nccl')
+    monkeypatch.setattr(dp.dist, 'get_world_size', lambda group=None: 2)
+    with pytest.warns(RuntimeWarning, match='running SERIAL'):
+        s = dp.GradSync(model, overlap=True)
+    assert not s.overlap and s.cu_reserve == 0 and 'refused' in s.mode
+    monkeypatch.setenv('E3_DP_OVERLAP', '1')
+    with pytest.warns(RuntimeWarning, match='NCCL_MAX_NCHANNELS'):
+        assert not dp.GradSync(model).overlap
+    monkeypatch.setenv('NCCL_MAX_NCHANNELS', '8')
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        s = dp.GradSync(model, overlap=True)
+    assert s.overlap and s.cu_reserve == 16 and 'requested' in s.mode
+    # gloo: no device kernel of its own, no bound needed
+    monkeypatch.delenv('NCCL_MAX_NCHANNELS')
+    monkeypatch.setattr(dp.dist, 'get_backend', lambda group=None: 'gloo')
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        assert dp.GradSync(model, overlap=True).overlap

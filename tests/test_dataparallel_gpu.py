@@ -56,6 +56,8 @@ def _worker(rank, world, port, backend, tmp, bf16=False, mode='overlap', big=Fal
     dev = torch.device('cuda', rank if backend == 'nccl' else 0)
     torch.cuda.set_device(dev)
     kw = {'device_id': dev} if backend == 'nccl' else {}
+    if backend == 'nccl' and mode.startswith('overlap'):
+        os.environ['NCCL_MAX_NCHANNELS'] = '16'      # the launcher's part of the contract: RCCL's kernel fits the CU reserve (GradSync refuses to overlap otherwise)
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     try:
         from elektronn3_amd.dataparallel import GradSync, shard_batch
@@ -184,3 +186,28 @@ def test_two_rank_step_beside_a_resident_foreign_kernel(mode, tmp_path):
                     continue               # sums, whose order differs (with a CU reserve the reduce pass is its own kernel, without it part of the data gradient)
                 err = float((res[r]['grads'][k] - g).norm()) / max(float(g.norm()), 1e-4 * gscale)
                 assert err < 1e-5, (r, k, err)
+
+
+def test_bench_n_gt_1_branch_dry_run_on_one_gpu():
+    """`python bench.py --gpus 2` end to end -- launcher respawn (torch.distributed.run), process group, barriers, the
+    MAX-reduced timed region, the global-batch criterion, GradSync, the tile-parallel Predictor leg and rank 0's ONE JSON line -- with the
+    test-only `--backend gloo --share-device` (both ranks on cuda:0), so that bench.py's N > 1 branch has run before it meets an 8-GPU node."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'E3_DP_OVERLAP', 'NCCL_MAX_NCHANNELS')}
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--backend', 'gloo', '--share-device',
+           '--predictor-volume', 'tiny']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['dist_ranks'] == 2 and res['backend'] == 'gloo' and res['rccl_ranks'] == 0 and 'test_only' in res
+    assert res['steps'] == 2 and res['warmup'] == 1 and res['scaling'] == 'weak' and res['config']['global_batch'] == 4 and res['config']['parallelism'] == 'dp2'
+    assert res['dp_mode'].startswith('serial') and res['ms_per_step'] > 0 and res['value'] > 0
+    assert abs(res['value'] - 4 * 64 * 128 * 128 / (res['ms_per_step'] * 1e-3)) < 1e-6 * res['value']
+    assert res['roofline']['launches_timed'] == 2 and 0 < res['roofline']['frac'] < 1       # one launch of the profiled layer per timed step
+    assert 'cpu_baseline' not in res                       # rank 0 at N = 1 only
+    p = res['predictor']
+    assert p['value'] and p['n_gpus'] == 2 and p['tiles'] == 4 and p['finite'] and 'tile-parallel over 2 ranks' in p['parallelism']
