@@ -302,7 +302,14 @@ __global__ __launch_bounds__(256, 2) void conv_first_mfma_kernel(const ConvSmall
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                         }
+#if !defined(E3_FIRST_SOFFSET)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rs, valid ? yoff + (unsigned)(q >> 1) * qstep : OOB, (4 * (q & 1)) * 4, 0);
+#elif E3_FIRST_SOFFSET == 1      // developer builds (tools/repro_first_soffset.sh): the wave-uniform part (q >> 1) * qstep in the SCALAR offset operand
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rs, valid ? yoff : OOB, (unsigned)(q >> 1) * qstep + (4 * (q & 1)) * 4, 0);
+#else                            // ... and the lane-dependent plane offset kk * kstep as well (round 5's dropped form: the compiler wraps the store in a waterfall loop)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rs, valid ? yoff - (unsigned)kk * kstep : OOB,
+                                                               (unsigned)kk * kstep + (unsigned)(q >> 1) * qstep + (4 * (q & 1)) * 4, 0);
+#endif
                         if (STATS) {
                             f32x4 dv = v - bq[q];
 #pragma unroll

@@ -601,3 +601,58 @@ def test_frozen_weights_scope_packs_once_and_never_serves_stale_weights():
             m.train(); m(x2); m.eval()       # a training call clears the buffer's token (and moves the running statistics)
             f = m(x).clone()
         assert torch.equal(e, changed) and not torch.equal(f, e)
+
+
+@pytest.mark.gpu
+def test_bench_volume_tiles_against_fp64():
+    """BASELINE.json configs[4] at ITS size: bench.py's Predictor leg -- the full 512x2048x2048 synthetic volume, tile 96x192x192, overlap 16, 726 tiles
+    through the pipelined native path -- and then four of its tiles against the fp64 op sequence + softmax on the same (zero-padded) input tiles:
+    the near corner, the far corner (ragged along every axis: the volume is not a multiple of the tile), a face tile and an interior tile
+    (the full-size run was only checked for finiteness).  Tolerance 1e-4 on probabilities (fp32 against fp64)."""
+    import bench
+    from elektronn3_amd.inference import Predictor
+    from elektronn3_amd.unet import UNet
+    from oracle.torch_ref import unet_forward
+    try:
+        import psutil
+        if psutil.virtual_memory().available < 40 * 2 ** 30:
+            pytest.skip('needs ~30 GB of host memory for the volume and its two-class result')
+    except ImportError:
+        pass
+    shape, tile, ov = (512, 2048, 2048), (96, 192, 192), (16, 16, 16)
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    model = UNet(1, 2, n_blocks=4, start_filts=32).to(dev).train()
+    with torch.no_grad():
+        for _ in range(10):
+            model(torch.randn(2, 1, 32, 64, 64, device=dev))
+    model.eval()
+    vol = torch.empty(1, 1, *shape)
+    gen = torch.Generator().manual_seed(0)
+    for z in range(0, shape[0], 32):
+        vol[0, 0, z:z + 32].normal_(generator=gen)
+    pred = Predictor(model, device=dev, tile_shape=tile, overlap_shape=ov, offset=None, out_shape=(2, *shape), apply_softmax=True, strict_shapes=False)
+    out = pred.predict(vol)
+    assert tuple(out.shape) == (1, 2, *shape)
+    ntile = [-(-n // t) for n, t in zip(shape, tile)]
+    assert ntile == [6, 11, 11]
+    sd = {k: v.double() if v.is_floating_point() else v for k, v in model.state_dict().items()}
+    worst = 0.0
+    for idx in [(0, 0, 0), (5, 10, 10), (0, 5, 5), (2, 5, 5)]:
+        lo = [i * t - o for i, t, o in zip(idx, tile, ov)]                    # input tile in volume coordinates (may hang over every face)
+        tin = torch.zeros(1, 1, *[t + 2 * o for t, o in zip(tile, ov)])
+        src = [slice(max(l, 0), min(l + t + 2 * o, n)) for l, t, o, n in zip(lo, tile, ov, shape)]
+        dst = [slice(s.start - l, s.stop - l) for s, l in zip(src, lo)]
+        tin[(0, 0, *dst)] = vol[(0, 0, *src)]
+        with torch.no_grad():
+            ref = torch.softmax(unet_forward(sd, tin.to(dev).double(), 4, (), training=False), 1)[:, :, ov[0]:ov[0] + tile[0], ov[1]:ov[1] + tile[1], ov[2]:ov[2] + tile[2]].cpu()
+        olo = [i * t for i, t in zip(idx, tile)]
+        ohi = [min(l + t, n) for l, t, n in zip(olo, tile, shape)]
+        got = out[:, :, olo[0]:ohi[0], olo[1]:ohi[1], olo[2]:ohi[2]].double()
+        want = ref[:, :, :ohi[0] - olo[0], :ohi[1] - olo[1], :ohi[2] - olo[2]]
+        err = float((got - want).abs().max())
+        worst = max(worst, err)
+        assert err < 1e-4, (idx, err)
+        del ref, tin
+    print(f'bench volume, 4 of 726 tiles against fp64: worst |p - p64| = {worst:.2e}')
+    assert bench.CROP == (64, 128, 128)

@@ -36,23 +36,20 @@ GROUPS = {
     # F(2x2x4) Winograd tiles (conv_wino4.hip; by default the eval-mode forward and the data gradients of grids with >= 256 bricks): OFF everywhere ...
     'wino4_off': (dict(E3_WINO4='0', E3_NO_BNRED_FUSE='1'), ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', 'tests/test_predictor.py', '-k',
                                        'conv3 or train_step_matches_reference or eval_forward or full_size_properties or forward_with_loss or forward_roi or needed_region or full_size_cfg2 or predictor']),
-    # ... and on every grid that has a brick (ragged grids, workgroups without a brick, one brick per workgroup): data gradients, the folded eval epilogue
-    # with the fused pool / head, the needed-region forward, the in-place tiles
-    'wino4_on_every_grid': (dict(E3_WINO4_MIN='1'),
+    # ... and on every grid that has a brick (ragged grids, workgroups without a brick, one brick per workgroup): data gradients -- with the REDUCE pass of the
+    # BatchNorm backward inside them wherever a grid tiles (E3_BNRED_MIN_MB=0; default: from 32 MB tensors on, the separate pass runs in the default suite and in
+    # 'wino4_off') --, the folded eval epilogue with the fused pool / head, the needed-region forward, the in-place tiles.  (Round 6: this group took over
+    # 'bnred_in_the_data_gradient', which differed from it in that one flag.)
+    'wino4_on_every_grid': (dict(E3_WINO4_MIN='1', E3_BNRED_MIN_MB='0'),
                             ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', 'tests/test_predictor.py', '-k',
-                             'conv3 or train_step_matches_reference or eval_forward or full_size_properties or forward_with_loss or forward_roi or needed_region or head_in_the_last or pool_in_the_conv or predictor']),
-    # the REDUCE pass of the BatchNorm backward inside the F(2x2x4) data gradients (default from 32 MB tensors on) wherever a grid tiles, small ones included
-    'bnred_in_the_data_gradient': (dict(E3_WINO4_MIN='1', E3_BNRED_MIN_MB='0'),
-                                   ['tests/test_unet_gpu.py', '-k', 'train_step_matches_reference or full_size_cfg2 or full_size_properties or forward_with_loss or digest']),
-    # ... with the data gradients' input in plain [voxel][C] rows instead of channel-chunked planes (E3_NO_CHUNKED=1; the chunked form is the default wherever the
-    # F(2x2x4) data gradient and the Winograd weight gradient both read the tensor, so the two groups above run it on every grid)
-    'wino4_plain_rows': (dict(E3_WINO4_MIN='1', E3_BNRED_MIN_MB='0', E3_NO_CHUNKED='1'),
-                         ['tests/test_unet_gpu.py', '-k', 'train_step_matches_reference or full_size_cfg2 or full_size_properties or forward_with_loss or digest']),
-    # inference forwards with every tensor in plain [voxel][C] rows (E3_NO_CHUNKED_FWD=1; by default the conv1 -> conv2 chains and the decoder's concat buffers
-    # are channel-chunked wherever their writers and their reader take the kernels that can: the groups 'wino4_on_every_grid' / 'persistent_kernels_on_small_grids'
-    # and the defaults run the chunked form); E3_NO_STORE_BOX=1: the encoder's skip activations stored in full although the decoder has a needed region)
-    'forward_plain_rows': (dict(E3_WINO4_MIN='1', E3_NO_CHUNKED_FWD='1', E3_NO_STORE_BOX='1'),
-                           ['tests/test_unet_gpu.py', 'tests/test_predictor.py', '-k', 'eval_forward or forward_roi or needed_region or head_in_the_last or pool_in_the_conv or predictor or cfg5']),
+                             'conv3 or train_step_matches_reference or eval_forward or full_size_properties or forward_with_loss or forward_roi or needed_region or head_in_the_last or pool_in_the_conv or predictor or full_size_cfg2 or digest']),
+    # ... with every tensor in plain [voxel][C] rows: the data gradients' input (E3_NO_CHUNKED=1; the chunked form is the default wherever the F(2x2x4) data gradient
+    # and the Winograd weight gradient both read the tensor), the inference forwards' conv1 -> conv2 tensors and concat buffers (E3_NO_CHUNKED_FWD=1), and the
+    # encoder's skip activations stored in full although the decoder has a needed region (E3_NO_STORE_BOX=1).  The groups above and the defaults run the chunked
+    # forms.  (Round 6: 'wino4_plain_rows' + 'forward_plain_rows' in one child process -- the two sets of flags touch disjoint launches.)
+    'plain_rows': (dict(E3_WINO4_MIN='1', E3_BNRED_MIN_MB='0', E3_NO_CHUNKED='1', E3_NO_CHUNKED_FWD='1', E3_NO_STORE_BOX='1'),
+                   ['tests/test_unet_gpu.py', 'tests/test_predictor.py', '-k',
+                    'train_step_matches_reference or full_size_cfg2 or full_size_properties or forward_with_loss or digest or eval_forward or forward_roi or needed_region or head_in_the_last or pool_in_the_conv or predictor or cfg5']),
     # ... and for the TRAINING forward with its statistics as well (E3_WINO4=2; not a default: DESIGN.md section 3a) -- per-op parity and the property tests
     'wino4_training_forward': (dict(E3_WINO4='2', E3_WINO4_MIN='1'), ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', '-k', 'conv3 or full_size_properties or forward_with_loss or eval_forward']),
 }
@@ -62,6 +59,7 @@ GROUPS = {
 def test_parity_suite_under_switch_group(group):
     env_extra, tests = GROUPS[group]
     env = dict(os.environ, **env_extra)
+    env['E3_MARGINS_DIR'] = os.path.join(ROOT, 'gpurun_out', 'switch_groups', group)      # (the default run's parity-margin tables are not overwritten by a variant's)
     r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', *tests], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=1500)
     tail = (r.stdout or '')[-3000:] + (r.stderr or '')[-1500:]
