@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         const int ch = P.nt * 32 + (tid & 31);
         (kst + 2 * 96)[tid] = ch < (e->br_cols ? e->br_cols : e->Ncols) ? src[ch] : 0.f;      // (br_cols: the unit in front owns only the first channels of y -- a concat gradient)
     }
-    {   // prologue: units 0 and 1 staged, the weights of unit 0 requested, the window of unit 0 read
+    {   // prologue: units 0, 1 and 2 staged, the weights of unit 0 requested, the window of unit 0 read
         stage_brick();
         {
             const unsigned voff = stage_voff();
@@ -249,11 +249,17 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
             for (int p = 0; p < 6; ++p) issue_dma(voff, nx1, p);
         }
         stage_advance();
+        {
+            const unsigned voff = stage_voff();
+#pragma unroll
+            for (int p = 0; p < 6; ++p) issue_dma(voff, nx2, p);
+        }
+        stage_advance();
         const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbase_of(P.nt)), 0, NCH * 96 * 1024, 0x00020000);
 #pragma unroll
         for (int p = 0; p < 24; ++p) Bv[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_voff + (p & 3) * 1024, (p & ~3) * 1024, 0));
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(30)" ::: "memory");       // (unit 0 has landed: its 6 pieces are the oldest requests)
+        asm volatile("s_waitcnt vmcnt(36)" ::: "memory");       // (unit 0 has landed: its 6 pieces are the oldest requests)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -275,8 +281,11 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         // the last piece may still be outstanding), barrier (publishes every wave's pieces of unit u + 1 and retires the buffer of unit u - 1);
         // then 12 position pairs of 8 MFMAs, each carrying two window reads (ds_read2_b64) of unit u + 1 and the weight requests of the same
         // positions of unit u + 1 (a ring of 24: one full unit of look-ahead); the first six pairs also carry one DMA piece of unit u + 2.
-        auto chunk = [&](auto zero_tag, int c) {
+        // LAST (a brick's last chunk when it has more than one): unit u + 1 is the next brick's first unit, whose window the epilogue reads again
+        // anyway (the registers do not survive the output transform) -- the 48 ds_read_b64 under this chunk's MFMAs are left out
+        auto chunk = [&](auto zero_tag, auto last_tag, int c) {
             constexpr bool ZERO = decltype(zero_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value;
             const bool lastc = c + 1 == NCH;
             f32x2v t[4][6];
 #pragma unroll
@@ -307,7 +316,10 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
                 for (int w = 0; w < 6; ++w) asm volatile("" : "+v"(t[h][w]));     // keep the transform packed and in front of the MFMA block
             __builtin_amdgcn_sched_barrier(0);
             if (c < 8) TSTAMP(1 + 5 * c);
-            if (E3_W4_ABL & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            // (unit u + 1's pieces went out in pairs 6 - 11 of unit u - 2; behind the last of them: that pair's 2 weight requests, then unit u - 1's 24 + 6 -- or,
+            // after the prologue, unit 2's 6 pieces + 24 weight requests: 30 covers both.  In the steady state the wait never stalls: weight requests younger than
+            // the pieces were consumed a unit ago, and the memory counter retires in order.)
+            if (E3_W4_ABL & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
             if (c < 8) TSTAMP(2 + 5 * c);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -319,8 +331,8 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
             const __amdgpu_buffer_rsrc_t b_nx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wb) + (size_t)cB * 96 * 256, 0, (lastc && !has_next) ? 0 : 96 * 1024, 0x00020000);
 #pragma unroll
             for (int pp = 0; pp < 24; pp += 2) {        // two positions at a time: 4 independent accumulators in flight, then their ring slots are refilled
-                if (pp < 12) issue_dma(d_voff, nx2, pp >> 1);
-                if (!(E3_W4_ABL & 64)) {                // window elements (h, w) and (h, w') of unit u + 1: w' = w + 4 (w = 0, 1) resp. 3 (w = 2) -- 32 / 160 bytes apart: one ds_read2_b64 per plane
+                if (pp >= 12) issue_dma(d_voff, cur, (pp - 12) >> 1);      // unit u + 3 into the buffer of unit u (its window went to registers a unit ago)
+                if (!(E3_W4_ABL & 64) && !LAST) {       // window elements (h, w) and (h, w') of unit u + 1: w' = w + 4 (w = 0, 1) resp. 3 (w = 2) -- 32 / 160 bytes apart: one ds_read2_b64 per plane
                     const int k = pp >> 1, h = k / 3, wa = k % 3, wb2 = wa == 2 ? 3 : wa + 4;
                     read_window(nx1, h, wa); read_window(nx1, h, wb2);
                 }
@@ -349,16 +361,16 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
                 // reads together 6.69 ms, both weight requests at the end 6.60, this order 6.58, one read per MFMA 6.63, DMA piece late 6.64, position-major
                 // MFMAs with the first request after four 6.65 (profiles/r05_w4_phases.md section 9)
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (pp < 12) { __builtin_amdgcn_sched_group_barrier(0x004, 8, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                if (pp >= 12) { __builtin_amdgcn_sched_group_barrier(0x004, 8, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+                if (!LAST) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                if (!LAST) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (pp == 12) stage_advance();      // (the cursor's scalar arithmetic rides in the matrix shadow; the last piece of this unit went out in pair 5)
+                if (pp == 22) stage_advance();      // (the cursor's scalar arithmetic rides in the matrix shadow; the last piece of this unit has just gone out)
                 if (pp == 10 && c < 8) TSTAMP(4 + 5 * c);
             }
             if (c < 8) TSTAMP(5 + 5 * c);
@@ -366,8 +378,9 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         };
 
         TSTAMP(0);
-        chunk(std::true_type{}, 0);
-        for (int c = 1; c < NCH; ++c) chunk(std::false_type{}, c);
+        chunk(std::true_type{}, std::false_type{}, 0);      // (a one-chunk brick, Cin = 8, takes this form too: its reads are merely redundant)
+        for (int c = 1; c + 1 < NCH; ++c) chunk(std::false_type{}, std::false_type{}, c);
+        if (NCH > 1) chunk(std::false_type{}, std::true_type{}, NCH - 1);
 
         // ---- epilogue.  acc[ph*6+pw][half][i]: position (pd = wave, ph, pw), tile tl, channel n0 + 8 kk + 4 half + i.
         // per-channel constants first: they arrive during the output transform

@@ -124,6 +124,41 @@ def inspect(so_path=None):
     return out
 
 
+def wide_store_hazards(so_path=None, window=3):
+    """[(kernel, store, overwriting instruction)]: buffer_store_dwordx3/x4 (or format_xyz/xyzw) with an SGPR soffset whose data registers a VALU
+    instruction writes within the next `window` instructions.  LLVM's hazard recognizer inserts the store-data wait state only when the soffset is NOT
+    a register (the gfx9 guides' exemption); gfx950 shows the hazard for SGPR offsets as well (tools/repro_soffset.hip)."""
+    so_path = so_path or os.path.join(ROOT, 'elektronn3_amd', 'libe3unet.so')
+    found = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for i, img in enumerate(code_objects(so_path)):
+            p = os.path.join(tmp, f'co{i}.elf')
+            open(p, 'wb').write(img)
+            txt = subprocess.run([_tool('llvm-objdump'), '-d', '--mcpu=gfx950', p], capture_output=True, text=True, check=True).stdout.splitlines()
+            name = None
+            for n, line in enumerate(txt):
+                m = re.match(r'^[0-9a-f]+ <(.+)>:$', line)
+                if m:
+                    name = m.group(1)
+                    continue
+                m = re.match(r'\s+(buffer_store_(?:dwordx[34]|format_xyzw?))\s+v\[(\d+):(\d+)\], \S+ s\[\d+:\d+\], (s\d+|m0|vcc_lo|vcc_hi)\b', line)
+                if not m:
+                    continue
+                lo, hi = int(m.group(2)), int(m.group(3))
+                for nxt in txt[n + 1:n + 1 + window]:
+                    ins = re.sub(r'\s*//.*', '', nxt).strip()
+                    if re.match(r'(s_cbranch|s_branch|s_endpgm|s_barrier)', ins):
+                        break
+                    w = re.match(r'(v_(?!cmp|cmpx|readfirstlane|readlane|accvgpr_write|mfma)\S+)\s+v\[?(\d+)(?::(\d+))?\]?', ins)
+                    if w:
+                        a = int(w.group(2))
+                        b = int(w.group(3) or a)
+                        if not (b < lo or a > hi):
+                            found.append((name, re.sub(r'\s*//.*', '', line).strip(), ins))
+                            break
+    return found
+
+
 def mfma_ops(hist):
     return {op: n for op, n in hist.items() if op.startswith('v_mfma') or op.startswith('v_smfma')}
 
