@@ -281,11 +281,10 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         // the last piece may still be outstanding), barrier (publishes every wave's pieces of unit u + 1 and retires the buffer of unit u - 1);
         // then 12 position pairs of 8 MFMAs, each carrying two window reads (ds_read2_b64) of unit u + 1 and the weight requests of the same
         // positions of unit u + 1 (a ring of 24: one full unit of look-ahead); the first six pairs also carry one DMA piece of unit u + 2.
-        // LAST (a brick's last chunk when it has more than one): unit u + 1 is the next brick's first unit, whose window the epilogue reads again
-        // anyway (the registers do not survive the output transform) -- the 48 ds_read_b64 under this chunk's MFMAs are left out
-        auto chunk = [&](auto zero_tag, auto last_tag, int c) {
+        // (Measured and dropped, round 6: a third form of the chunk for a brick's LAST chunk without its window reads -- unit u + 1 is then the next brick's
+        // first unit, whose window the epilogue reads again anyway: bit-identical, step and cfg-5 tile +-0 on the same box, 6 KB more code.)
+        auto chunk = [&](auto zero_tag, int c) {
             constexpr bool ZERO = decltype(zero_tag)::value;
-            constexpr bool LAST = decltype(last_tag)::value;
             const bool lastc = c + 1 == NCH;
             f32x2v t[4][6];
 #pragma unroll
@@ -332,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
 #pragma unroll
             for (int pp = 0; pp < 24; pp += 2) {        // two positions at a time: 4 independent accumulators in flight, then their ring slots are refilled
                 if (pp >= 12) issue_dma(d_voff, cur, (pp - 12) >> 1);      // unit u + 3 into the buffer of unit u (its window went to registers a unit ago)
-                if (!(E3_W4_ABL & 64) && !LAST) {       // window elements (h, w) and (h, w') of unit u + 1: w' = w + 4 (w = 0, 1) resp. 3 (w = 2) -- 32 / 160 bytes apart: one ds_read2_b64 per plane
+                if (!(E3_W4_ABL & 64)) {                // window elements (h, w) and (h, w') of unit u + 1: w' = w + 4 (w = 0, 1) resp. 3 (w = 2) -- 32 / 160 bytes apart: one ds_read2_b64 per plane
                     const int k = pp >> 1, h = k / 3, wa = k % 3, wb2 = wa == 2 ? 3 : wa + 4;
                     read_window(nx1, h, wa); read_window(nx1, h, wb2);
                 }
@@ -362,9 +361,9 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
                 // MFMAs with the first request after four 6.65 (profiles/r05_w4_phases.md section 9)
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (pp >= 12) { __builtin_amdgcn_sched_group_barrier(0x004, 8, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-                if (!LAST) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                if (!LAST) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -378,9 +377,8 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         };
 
         TSTAMP(0);
-        chunk(std::true_type{}, std::false_type{}, 0);      // (a one-chunk brick, Cin = 8, takes this form too: its reads are merely redundant)
-        for (int c = 1; c + 1 < NCH; ++c) chunk(std::false_type{}, std::false_type{}, c);
-        if (NCH > 1) chunk(std::false_type{}, std::true_type{}, NCH - 1);
+        chunk(std::true_type{}, 0);
+        for (int c = 1; c < NCH; ++c) chunk(std::false_type{}, c);
 
         // ---- epilogue.  acc[ph*6+pw][half][i]: position (pd = wave, ph, pw), tile tl, channel n0 + 8 kk + 4 half + i.
         // per-channel constants first: they arrive during the output transform

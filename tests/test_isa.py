@@ -44,9 +44,9 @@ def test_wino4_window_reads_stay_unpaired(kernels):
     for k in _family(kernels, 'conv3_wino4_kernel'):
         h = k['hist']
         assert h.get('ds_read2_b64', 0) == 0 and h.get('ds_read2st64_b64', 0) == 0, (k['name'], 'hipcc paired the window reads again')
-        assert h.get('ds_read_b64', 0) == 192, (k['name'], h.get('ds_read_b64'))      # prologue, first + middle chunk forms, epilogue: 4 x 48 (the last chunk form reads nothing)
-        assert h.get('v_mfma_f32_16x16x4_f32', 0) == 3 * 96, (k['name'], h.get('v_mfma_f32_16x16x4_f32'))      # three chunk forms: first, middle, last
-        assert h.get('buffer_load_dwordx4 lds', 0) == 36, (k['name'], 'the halo planes are staged with LDS-DMA: 3 x 6 pieces in the prologue, 6 per chunk form')
+        assert h.get('ds_read_b64', 0) == 192, (k['name'], h.get('ds_read_b64'))      # prologue, two chunk forms, epilogue: 4 x 48
+        assert h.get('v_mfma_f32_16x16x4_f32', 0) == 2 * 96, (k['name'], h.get('v_mfma_f32_16x16x4_f32'))      # two chunk forms: a brick's first chunk (zero accumulators) and the others
+        assert h.get('buffer_load_dwordx4 lds', 0) == 30, (k['name'], 'the halo planes are staged with LDS-DMA: 3 x 6 pieces in the prologue, 6 per chunk form')
 
 
 # family -> the one MFMA opcode it is built on (exact fp32: v_mfma_f32_32x32x2_f32 / 16x16x4_f32; the 16-bit path: 32x32x16, compiled for bf16 and f16)
