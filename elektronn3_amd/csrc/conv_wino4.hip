@@ -38,7 +38,7 @@ constexpr int V_RPLANE = 128 * 8 + 16;                      // floats of one raw
 constexpr int V_RBUF = 6 * V_RPLANE;                        // 6 raw planes: 24.4 KB per stage buffer
 constexpr int V_EX = 4 * 16 * 64 * 4;                       // epilogue exchange [pd][(oh, ow, half)][lane][4] floats (64 KB)
 constexpr int V_SCR = 4 * 32 * 3;                           // cross-wave merge of the statistics
-constexpr int V_RUN = 17 * 256;                             // running statistics of every thread: n, mean[8], M2[8]  ([k][thread])
+constexpr int V_RUN = 9 * 256;                              // running statistics of every thread: n, mean[4], M2[4]  ([k][thread]; BNRED: 4 + 4 sums)
 constexpr int V_POOLX = 4 * 64 * 8;                         // fused max-pool: [wave][lane][8 channels] (8 KB)
 constexpr int V_HEADW = 160;                                // fused head: weights [4][32] + biases [4] (padded)
 constexpr int V_KST = 2 * 96 + 128;                          // bias / folded scale / folded shift of the workgroup's 32 channels, two slots; BNRED: scale / shift / mean / invstd of the unit in front
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
 #endif
     if (do_stats || BNRED) {
 #pragma unroll
-        for (int k = 0; k < 17; ++k) run[k * 256] = 0.f;
+        for (int k = 0; k < 9; ++k) run[k * 256] = 0.f;
     }
     // per-channel constants of the epilogue (bias, folded scale / shift) of the brick's 32 channels live in LDS: as buffer loads in the epilogue they
     // waited -- the memory counter retires in order -- for every request of the next units in front of them.  Reloaded only when a workgroup's
@@ -392,8 +392,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         float* const erun = scr + V_SCR + etid;
         const int n0 = P.nt * 32, d0 = P.td * 4 + KA()->org_d, h0 = P.th * 4 + KA()->org_h, w0 = P.tw * 16 + KA()->org_w;
         const int P_nb = P.nb;
-        const int nq = n0 + 8 * ekk;
-        // BNRED: the raw tensor of the unit in front at the eight voxel rows this lane will STORE (rows v = 8 j + r of the transposed tile, piece (lane & 7) ^ r;
+        // BNRED: the raw tensor of the unit in front at the eight voxel rows this lane will STORE (rows v = 8 j + r, piece (lane & 7) ^ r;
         // same voxels as the output, its own channel stride) is requested here, in front of the output transform: the rows come from HBM, and requested next to
         // the stores they cost a memory round trip per brick (+18 % on the launch)
         f32x4 bx[8];
@@ -402,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
             const KArgs e = KA();
             const int bl = e->br_ldc;
             const int oh_ = wave >> 1, owb_ = 2 * (wave & 1);
-            const int r_ = elane >> 3, pc_ = (elane & 7) ^ r_;
+            const int r_ = elane >> 3, pc_ = (elane & 7) ^ r_;      // (the lane's rows and piece of the store phase below)
             const int sgh_ = h0 + 2 * (r_ >> 2) + oh_, sgw_ = w0 + 4 * (r_ & 3) + owb_;
             const size_t plane_b = (size_t)H * W * bl;
             const size_t brem = (size_t)(D - d0) * plane_b * 4;
@@ -443,7 +442,10 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
             for (int oh = 0; oh < 2; ++oh)
 #pragma unroll
                 for (int ow = 0; ow < 4; ++ow)
-                    *reinterpret_cast<f32x4*>(ex + ((wave * 16 + (oh * 4 + ow) * 2 + hf) * 64 + elane) * 4) = q[oh][ow];
+                {
+                    if constexpr (HEAD) *reinterpret_cast<f32x4*>(ex + ((wave * 16 + (oh * 4 + ow) * 2 + hf) * 64 + elane) * 4) = q[oh][ow];
+                    else *reinterpret_cast<f32x4*>(ex + (((wave * 8 + oh * 4 + ow) * 16 + etl) * 8 + ((2 * ekk + hf) ^ (etl & 7))) * 4) = q[oh][ow];
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
         TSTAMP(41);
@@ -453,70 +455,161 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         TSTAMP(42);
         // wave w now owns output offsets oh = w >> 1, ow = 2 (w & 1) + {0, 1} of every tile and sums the pd axis: od = 0, 1
         const int oh = wave >> 1, owb = 2 * (wave & 1);
-        f32x4 y[2][2][2];       // [od][owi][half]
-        {
-            f32x4 m[2][2][4], bias[2], es[2], eh[2];
-#pragma unroll
-            for (int owi = 0; owi < 2; ++owi)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                    for (int pd = 0; pd < 4; ++pd) m[owi][hf][pd] = *reinterpret_cast<const f32x4*>(ex + ((pd * 16 + (oh * 4 + owb + owi) * 2 + hf) * 64 + elane) * 4);
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                bias[hf] = *reinterpret_cast<const f32x4*>(kst + kslot * 96 + 8 * ekk + 4 * hf);
-                if (AFF) {
-                    es[hf] = *reinterpret_cast<const f32x4*>(kst + kslot * 96 + 32 + 8 * ekk + 4 * hf);
-                    eh[hf] = *reinterpret_cast<const f32x4*>(kst + kslot * 96 + 64 + 8 * ekk + 4 * hf);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int owi = 0; owi < 2; ++owi)
-#pragma unroll
+        if constexpr (HEAD) {
+            // (the fused head works on the accumulator layout -- lane = (tile, channel octet) -- and stores no rows: the exchange keeps the lane-major layout)
+            f32x4 y[2][2][2];       // [od][owi][half]
+            {
+                f32x4 m[2][2][4], bias[2], es[2], eh[2];
+    #pragma unroll
+                for (int owi = 0; owi < 2; ++owi)
+    #pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+    #pragma unroll
+                        for (int pd = 0; pd < 4; ++pd) m[owi][hf][pd] = *reinterpret_cast<const f32x4*>(ex + ((pd * 16 + (oh * 4 + owb + owi) * 2 + hf) * 64 + elane) * 4);
+    #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    y[0][owi][hf] = m[owi][hf][0] + m[owi][hf][1] + m[owi][hf][2] + bias[hf];
-                    y[1][owi][hf] = m[owi][hf][1] + m1 * m[owi][hf][2] + m1 * m[owi][hf][3] + bias[hf];
+                    bias[hf] = *reinterpret_cast<const f32x4*>(kst + kslot * 96 + 8 * ekk + 4 * hf);
                     if (AFF) {
-#pragma unroll
-                        for (int od = 0; od < 2; ++od)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) y[od][owi][hf][e] = fmaxf(__builtin_fmaf(y[od][owi][hf][e], es[hf][e], eh[hf][e]), 0.f);
+                        es[hf] = *reinterpret_cast<const f32x4*>(kst + kslot * 96 + 32 + 8 * ekk + 4 * hf);
+                        eh[hf] = *reinterpret_cast<const f32x4*>(kst + kslot * 96 + 64 + 8 * ekk + 4 * hf);
                     }
                 }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // the accumulators and the exchanged sums are dead: the window of the next brick's first unit (in `cur` after the rotation; landed and published by
-        // the last chunk's barrier) is read under the stores and the statistics
-        // (BNRED: behind the reduction instead -- its raw rows and sums need the registers)
-        if (!(E3_W4_ABL & 64) && !BNRED) {
-#pragma unroll
-            for (int h = 0; h < 4; ++h)
-#pragma unroll
-                for (int w = 0; w < 6; ++w) read_window(cur, h, w);
-        }
-        // voxel (d0 + 2 ettd + od, h0 + 2 etth + oh, w0 + 4 ettw + owb + owi), channels nq + 4 half .. + 3: 16-byte stores
-        const int gh = h0 + 2 * etth + oh, gw = w0 + 4 * ettw + owb, gd = d0 + 2 * ettd;
-        const bool okw[2] = {gh < H && gw < W, gh < H && gw + 1 < W};
-        const bool okd[2] = {gd < D, gd + 1 < D};
-        const int yl = KA()->y_ldc;
-        const size_t plane_y = (size_t)H * W * yl;
-        if (!HEAD) {
-            // The accumulator layout gives a elane 16 bytes of a voxel and puts the four lanes of a voxel 16 lanes apart: stored directly, every instruction is 64
-            // scattered 16-byte fragments (measured: the 8 stores of a brick took ~4 k cycles of issue).  The wave's 64 voxels x 32 channels are transposed
-            // through LDS instead -- in the 8 KB of the exchange buffer that only THIS wave has just read (its (oh, ow) entries of pd = 0 and 1; LDS executes
-            // a wave's accesses in order, no barrier) -- so that 8 consecutive lanes store one whole 128-byte voxel row.  Row v = (od * 2 + owi) * 16 + tile,
-            // 16-byte piece 2 ekk + half at position piece ^ (tile & 7) (conflict-free writes).
-            float* const tA = ex + (((oh * 4 + owb) * 2) * 64) * 4;
-#pragma unroll
-            for (int od = 0; od < 2; ++od)
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int owi = 0; owi < 2; ++owi)
+    #pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        y[0][owi][hf] = m[owi][hf][0] + m[owi][hf][1] + m[owi][hf][2] + bias[hf];
+                        y[1][owi][hf] = m[owi][hf][1] + m1 * m[owi][hf][2] + m1 * m[owi][hf][3] + bias[hf];
+                        if (AFF) {
+    #pragma unroll
+                            for (int od = 0; od < 2; ++od)
+    #pragma unroll
+                                for (int e = 0; e < 4; ++e) y[od][owi][hf][e] = fmaxf(__builtin_fmaf(y[od][owi][hf][e], es[hf][e], eh[hf][e]), 0.f);
+                        }
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the accumulators and the exchanged sums are dead: the window of the next brick's first unit (in `cur` after the rotation; landed and published by
+            // the last chunk's barrier) is read under the stores and the statistics
+            // (BNRED: behind the reduction instead -- its raw rows and sums need the registers)
+            // (the lane constants of the chunk loop are taken afresh right HERE, in front of their first use: the window addresses that survived the output transform
+            // were spilled in the BNRED form, and their scratch reload waited -- the memory counter retires in order -- for the staging requests of two units)
+            if (!BNRED) lane_consts();
+            if (!(E3_W4_ABL & 64) && !BNRED) {
+    #pragma unroll
+                for (int h = 0; h < 4; ++h)
+    #pragma unroll
+                    for (int w = 0; w < 6; ++w) read_window(cur, h, w);
+            }
+            // voxel (d0 + 2 ettd + od, h0 + 2 etth + oh, w0 + 4 ettw + owb + owi), channels nq + 4 half .. + 3: 16-byte stores
+            const int gh = h0 + 2 * etth + oh, gw = w0 + 4 * ettw + owb, gd = d0 + 2 * ettd;
+
+            if (HEAD) {
+                // conv_final_fwd_kernel's arithmetic on the registers: channel quad q of the voxel is summed as an fmaf chain from 0, the eight quad sums meet as
+                // ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7)) -- this elane holds quads 2 ekk (half 0) and 2 ekk + 1 (half 1), the lanes ^ 16, ^ 32 the others
+                const float* const hw = scr + V_SCR + V_POOLX;
+                const KArgs e = KA();
+                const int hc = e->head_cout;
+                float lg[2][2][4];
+    #pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 wv0 = *reinterpret_cast<const f32x4*>(hw + c * 32 + 8 * ekk), wv1 = *reinterpret_cast<const f32x4*>(hw + c * 32 + 8 * ekk + 4);
+                    const float hb = hw[128 + c];
+    #pragma unroll
+                    for (int od = 0; od < 2; ++od)
+    #pragma unroll
+                        for (int owi = 0; owi < 2; ++owi) {
+                            float s0 = 0.f, s1 = 0.f;
+    #pragma unroll
+                            for (int e4 = 0; e4 < 4; ++e4) { s0 = __builtin_fmaf(y[od][owi][0][e4], wv0[e4], s0); s1 = __builtin_fmaf(y[od][owi][1][e4], wv1[e4], s1); }
+                            float p = s0 + s1;                  // q(2 ekk) + q(2 ekk + 1)
+                            p = p + __shfl_xor(p, 16);          // (q0 + q1) + (q2 + q3)   resp.   (q4 + q5) + (q6 + q7)
+                            p = p + __shfl_xor(p, 32);
+                            lg[od][owi][c] = p + hb;
+                        }
+                }
+                // elane ekk finishes voxel (od, owi) = (ekk >> 1, ekk & 1)
+                float l4[4];
+    #pragma unroll
+                for (int c = 0; c < 4; ++c) l4[c] = ekk == 0 ? lg[0][0][c] : (ekk == 1 ? lg[0][1][c] : (ekk == 2 ? lg[1][0][c] : lg[1][1][c]));
+                if (e->head_softmax) {
+                    float m = l4[0];
+    #pragma unroll
+                    for (int c = 1; c < 4; ++c) m = c < hc ? fmaxf(m, l4[c]) : m;
+                    float sm = 0.f;
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c) { l4[c] = c < hc ? __expf(l4[c] - m) : 0.f; sm += l4[c]; }
+                    const float inv = 1.f / sm;
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c) l4[c] *= inv;
+                }
+                const int vd = gd + (ekk >> 1), vw = gw + (ekk & 1);
+                const bool inb = gh < H && vw < W && vd < D && vd >= e->head_lo[0] && vd < e->head_hi[0] && gh >= e->head_lo[1] && gh < e->head_hi[1] && vw >= e->head_lo[2] && vw < e->head_hi[2];
+                if (inb) {
+                    float* const yo = e->head_y + (long long)P_nb * e->head_ys[0] + (long long)(vd - e->head_lo[0]) * e->head_ys[2] + (long long)(gh - e->head_lo[1]) * e->head_ys[3] + (vw - e->head_lo[2]);
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < hc) yo[(long long)c * e->head_ys[1]] = l4[c];
+                }
+            }
+        } else {
+            // Round 6: the exchange is written tile-major ([pd][(oh, ow)][tile][8 pieces of 4 channels], piece 2 kk + half at slot piece ^ (tile & 7):
+            // conflict-free writes: a ds_write_b128 is served in groups of 8 consecutive lanes = 8 tiles on 32 banks), so the lane that sums the pd axis can pick the pieces in STORE order: lane (r = lane >> 3, pos = lane & 7) takes the
+            // piece pc = pos ^ r of the tiles 8 th + r, th = 0, 1 (the slot is pos; 8 consecutive lanes read one tile's 128 contiguous bytes, the 16-lane
+            // groups of a ds_read_b128 cover all 64 banks) and holds, summed, the rows  j = 4 od + 2 owi + th  of 8 lanes x 16 bytes = one whole 128-byte voxel row per 8 lanes -- what round 5
+            // obtained with a second pass through LDS (8 ds_write_b128 + 8 ds_read_b128 per lane and brick: 64 KB of the epilogue's ~290 KB of LDS
+            // traffic, and one more dependent LDS round trip).  Same sums in the same order: bit-identical results.
+            const int r = elane >> 3, pos = elane & 7, pc = pos ^ r;
+            f32x4 yv[8];
+            {
+                f32x4 m[2][2][4], bias, es, eh;
 #pragma unroll
                 for (int owi = 0; owi < 2; ++owi)
 #pragma unroll
-                    for (int hf = 0; hf < 2; ++hf)
-                        *reinterpret_cast<f32x4*>(tA + od * (16 * 64 * 4) + (owi * 16 + etl) * 32 + (((2 * ekk + hf) ^ (etl & 7)) * 4)) = y[od][owi][hf];
+                    for (int th = 0; th < 2; ++th)
+#pragma unroll
+                        for (int pd = 0; pd < 4; ++pd)
+                            m[owi][th][pd] = *reinterpret_cast<const f32x4*>(ex + (((pd * 8 + oh * 4 + owb + owi) * 16 + 8 * th + r) * 8 + pos) * 4);
+                bias = *reinterpret_cast<const f32x4*>(kst + kslot * 96 + 4 * pc);
+                if (AFF) {
+                    es = *reinterpret_cast<const f32x4*>(kst + kslot * 96 + 32 + 4 * pc);
+                    eh = *reinterpret_cast<const f32x4*>(kst + kslot * 96 + 64 + 4 * pc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int owi = 0; owi < 2; ++owi)
+#pragma unroll
+                    for (int th = 0; th < 2; ++th) {
+                        yv[owi * 2 + th] = m[owi][th][0] + m[owi][th][1] + m[owi][th][2] + bias;
+                        yv[4 + owi * 2 + th] = m[owi][th][1] + m1 * m[owi][th][2] + m1 * m[owi][th][3] + bias;
+                        if (AFF) {
+#pragma unroll
+                            for (int od = 0; od < 2; ++od)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) yv[od * 4 + owi * 2 + th][e] = fmaxf(__builtin_fmaf(yv[od * 4 + owi * 2 + th][e], es[e], eh[e]), 0.f);
+                        }
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the accumulators and the exchanged sums are dead: the window of the next brick's first unit (in `cur` after the rotation; landed and published by
+            // the last chunk's barrier) is read under the stores and the statistics (BNRED: behind the reduction instead -- its raw rows and sums need the registers).
+            // The lane constants of the chunk loop are taken afresh right HERE, in front of their first use: the window addresses that survived the output
+            // transform were spilled in the BNRED form, and their scratch reload waited -- the memory counter retires in order -- for the staging requests in flight.
+            if (!BNRED) lane_consts();
+            if (!(E3_W4_ABL & 64) && !BNRED) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h)
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) read_window(cur, h, w);
+            }
+            // lane (r, pos) stores piece pc of the rows v = 8 j + r: tile 8 (j & 1) + r = (td j & 1, th r >> 2, tw r & 3), od = j >> 2, owi = (j >> 1) & 1:
+            // voxel (d0 + 2 (j & 1) + od, h0 + 2 (r >> 2) + oh, w0 + 4 (r & 3) + owb + owi), channels n0 + 4 pc .. + 3
+            const int sgh = h0 + 2 * (r >> 2) + oh, sgw = w0 + 4 * (r & 3) + owb;
+            const int yl = KA()->y_ldc;
+            const size_t plane_y = (size_t)H * W * yl;
             // channel-chunked output (ConvArgs::y_chunk, plain stores only): a voxel's row is the 8 channels of ONE chunk plane (ys = 8), the chunk planes
-            // are y_chunk floats apart -- the lane's two-piece half of a chunk goes to plane (n0 + 4 pc) / 8.  (The launcher bounds the whole tensor by 2^31 bytes.)
+            // are y_chunk floats apart -- the lane's piece goes to plane (n0 + 4 pc) / 8.  (The launcher bounds the whole tensor by 2^31 bytes.)
             const size_t ychk = BNRED ? (size_t)0 : KA()->y_chunk;
             const int ys = ychk ? 8 : yl;
             const bool nt_out = !AFF && !ychk && (size_t)KA()->N * D * H * W * KA()->Ncols * 4 > (size_t)E3_W4_NT_MIN_MB * 1048576;
@@ -524,10 +617,6 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
             const size_t yrem = ychk ? (size_t)0x7fffffffu : (size_t)(D - d0) * plane_y * 4;
             const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(
                 KA()->y + ((size_t)P_nb * D + d0) * plane_s, 0, (int)(yrem < 0x7fffffffu ? yrem : 0x7fffffffu), 0x00020000);
-            // elane (r = elane >> 3, position elane & 7) stores piece (elane & 7) ^ r of the rows v = 8 j + r: tile 8 (j & 1) + r = (td j & 1, th r >> 2, tw r & 3),
-            // od = j >> 2, owi = (j >> 1) & 1
-            const int r = elane >> 3, pc = (elane & 7) ^ r;
-            const int sgh = h0 + 2 * (r >> 2) + oh, sgw = w0 + 4 * (r & 3) + owb;
             // (store box, ConvArgs::sbox_*: the launcher sets [0, dims) when it is off)
             const int sb_d0 = KA()->sbox_lo[0], sb_d1 = KA()->sbox_hi[0], sb_h0 = KA()->sbox_lo[1], sb_h1 = KA()->sbox_hi[1], sb_w0 = KA()->sbox_lo[2], sb_w1 = KA()->sbox_hi[2];
             const bool cok = n0 + 4 * pc < KA()->Ncols && sgh < sb_h1 && sgh >= sb_h0;
@@ -539,7 +628,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
             for (int j = 0; j < 8; ++j) {
                 if (E3_W4_ABL & 4) continue;
                 const int od = j >> 2, owi = (j >> 1) & 1, std_ = 2 * (j & 1) + od;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(tA + od * (16 * 64 * 4) + (owi * 16 + 8 * (j & 1) + r) * 32 + (elane & 7) * 4);
+                const f32x4 v = yv[j];
                 const bool dok = d0 + std_ < sb_d1 && d0 + std_ >= sb_d0;
                 // (training forms, rows: the gradient / raw tensor of a large grid is streamed out past the caches -- non-temporal, aux = 2 -- so that the halo lines and the
                 // weights the neighbouring bricks re-read stay resident: step -0.08 ms; the 32-byte fragments of the channel-chunked inference tensors must NOT go that way: tile +6.6 %)
@@ -590,178 +679,110 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
                         o[0] = t1; o[eN] = t2;
                     }
                 }
-            }
-        }
-        if (!(E3_W4_ABL & 64) && BNRED) {
-            __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
+                lane_consts();
+                if (!(E3_W4_ABL & 64)) {
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int h = 0; h < 4; ++h)
+                    for (int h = 0; h < 4; ++h)
 #pragma unroll
-                for (int w = 0; w < 6; ++w) read_window(cur, h, w);
-        }
-        TSTAMP(43);
-        if (HEAD) {
-            // conv_final_fwd_kernel's arithmetic on the registers: channel quad q of the voxel is summed as an fmaf chain from 0, the eight quad sums meet as
-            // ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7)) -- this elane holds quads 2 ekk (half 0) and 2 ekk + 1 (half 1), the lanes ^ 16, ^ 32 the others
-            const float* const hw = scr + V_SCR + V_POOLX;
-            const KArgs e = KA();
-            const int hc = e->head_cout;
-            float lg[2][2][4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 wv0 = *reinterpret_cast<const f32x4*>(hw + c * 32 + 8 * ekk), wv1 = *reinterpret_cast<const f32x4*>(hw + c * 32 + 8 * ekk + 4);
-                const float hb = hw[128 + c];
-#pragma unroll
-                for (int od = 0; od < 2; ++od)
-#pragma unroll
-                    for (int owi = 0; owi < 2; ++owi) {
-                        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                        for (int e4 = 0; e4 < 4; ++e4) { s0 = __builtin_fmaf(y[od][owi][0][e4], wv0[e4], s0); s1 = __builtin_fmaf(y[od][owi][1][e4], wv1[e4], s1); }
-                        float p = s0 + s1;                  // q(2 ekk) + q(2 ekk + 1)
-                        p = p + __shfl_xor(p, 16);          // (q0 + q1) + (q2 + q3)   resp.   (q4 + q5) + (q6 + q7)
-                        p = p + __shfl_xor(p, 32);
-                        lg[od][owi][c] = p + hb;
-                    }
-            }
-            // elane ekk finishes voxel (od, owi) = (ekk >> 1, ekk & 1)
-            float l4[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) l4[c] = ekk == 0 ? lg[0][0][c] : (ekk == 1 ? lg[0][1][c] : (ekk == 2 ? lg[1][0][c] : lg[1][1][c]));
-            if (e->head_softmax) {
-                float m = l4[0];
-#pragma unroll
-                for (int c = 1; c < 4; ++c) m = c < hc ? fmaxf(m, l4[c]) : m;
-                float sm = 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { l4[c] = c < hc ? __expf(l4[c] - m) : 0.f; sm += l4[c]; }
-                const float inv = 1.f / sm;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) l4[c] *= inv;
-            }
-            const int vd = gd + (ekk >> 1), vw = gw + (ekk & 1);
-            const bool inb = gh < H && vw < W && vd < D && vd >= e->head_lo[0] && vd < e->head_hi[0] && gh >= e->head_lo[1] && gh < e->head_hi[1] && vw >= e->head_lo[2] && vw < e->head_hi[2];
-            if (inb) {
-                float* const yo = e->head_y + (long long)P_nb * e->head_ys[0] + (long long)(vd - e->head_lo[0]) * e->head_ys[2] + (long long)(gh - e->head_lo[1]) * e->head_ys[3] + (vw - e->head_lo[2]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (c < hc) yo[(long long)c * e->head_ys[1]] = l4[c];
-            }
-        }
-        if (POOL) {
-            // a 2x2x4 tile = two pooling windows (ow 0, 1 | ow 2, 3): max over od and the elane's two ow in registers, over oh = the wave pairs (w, w ^ 2) through
-            // LDS (voxels outside the tensor do not take part: ceil_mode; NaN propagates as in nn.MaxPool3d); wave w then stores channel half oh of window w & 1
-            float* const px = scr + V_SCR;
-            auto nmax = [](float a_, float b_) { return (b_ > a_ || b_ != b_) ? b_ : a_; };
-            constexpr float NEG = -3.4028235e38f;
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                f32x4 pm;
-#pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) {
-                    float v = NEG;
-#pragma unroll
-                    for (int od = 0; od < 2; ++od)
-#pragma unroll
-                        for (int owi = 0; owi < 2; ++owi) v = nmax(v, (okd[od] && okw[owi]) ? y[od][owi][hf][e4] : NEG);
-                    pm[e4] = v;
+                        for (int w = 0; w < 6; ++w) read_window(cur, h, w);
                 }
-                *reinterpret_cast<f32x4*>(px + ((wave * 64 + elane) * 8) + 4 * hf) = pm;
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // wave w: window (w & 1), channel half (w >> 1): max of the partials of waves (w & 1) and (w & 1) + 2
-            const int win = wave & 1, ch = wave >> 1;
-            const f32x4 p0 = *reinterpret_cast<const f32x4*>(px + ((win * 64 + elane) * 8) + 4 * ch);
-            const f32x4 p1 = *reinterpret_cast<const f32x4*>(px + (((win + 2) * 64 + elane) * 8) + 4 * ch);
-            f32x4 best;
+            TSTAMP(43);
+            // validity of the lane's eight rows (POOL, statistics)
+            const bool okh = sgh < H;
+            const bool okw[2] = {okh && sgw < W, okh && sgw + 1 < W};
+            if (POOL) {
+                // a 2x2x4 tile = two pooling windows (ow 0, 1 | ow 2, 3): max over od and the lane's two ow in registers (per tile th, the lane's 4 channels), over
+                // oh = the wave pairs (w, w ^ 2) through LDS (voxels outside the tensor do not take part: ceil_mode; NaN propagates as in nn.MaxPool3d); wave w
+                // then stores the tiles th = w >> 1 of window w & 1
+                float* const px = scr + V_SCR;
+                auto nmax = [](float a_, float b_) { return (b_ > a_ || b_ != b_) ? b_ : a_; };
+                constexpr float NEG = -3.4028235e38f;
 #pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) best[e4] = nmax(p0[e4], p1[e4]);
-            const KArgs e = KA();
-            const int eN = e->Ncols;
-            const int Dp = (D + 1) >> 1, Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
-            const int pd_ = (d0 >> 1) + ettd, ph_ = (h0 >> 1) + etth, pw_ = (w0 >> 1) + 2 * ettw + win;
-            const bool pok = pd_ < Dp && ph_ < Hp && pw_ < Wp && nq + 4 * ch < eN;
-            const size_t pv = (((size_t)P_nb * Dp + pd_) * Hp + ph_) * Wp + pw_;
-            const size_t pck = e->pool_chunk;      // (channel-chunked pooled tensor: plane (nq + 4 ch) / 8, ConvArgs::pool_chunk)
-            if (pok) *reinterpret_cast<f32x4*>(e->pool_out + (pck ? (size_t)((nq + 4 * ch) >> 3) * pck + pv * 8 + ((nq + 4 * ch) & 4) : pv * eN + nq + 4 * ch)) = best;
-        }
-        if (do_stats) {
-            // running record of this elane's 8 channels: Chan merge of the brick's (up to) four values per channel, approximate reciprocal
-            // (its error is far below the rounding of the sums)
-            const float rn = erun[0];
-            float cb = 0.f;
+                for (int th = 0; th < 2; ++th) {
+                    f32x4 pm;
 #pragma unroll
-            for (int od = 0; od < 2; ++od)
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        float v = NEG;
 #pragma unroll
-                for (int owi = 0; owi < 2; ++owi) cb += (okd[od] && okw[owi]) ? 1.f : 0.f;
-            const float nn = rn + cb;
-            const float rf = cb * __builtin_amdgcn_rcpf(fmaxf(nn, 1.f));
-            const float rc = cb == 4.f ? 0.25f : (cb == 2.f ? 0.5f : (cb == 1.f ? 1.f : (cb == 3.f ? (1.f / 3.f) : 0.f)));
-            const float rnf = rn * rf;
+                        for (int od = 0; od < 2; ++od)
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ch = hf * 4 + e;
-                    float v[4];
-#pragma unroll
-                    for (int od = 0; od < 2; ++od)
-#pragma unroll
-                        for (int owi = 0; owi < 2; ++owi) v[od * 2 + owi] = y[od][owi][hf][e];
-                    float s = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) s += (okd[i >> 1] && okw[i & 1]) ? v[i] : 0.f;
-                    const float bm = s * rc;
-                    float b2 = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { const float dv = v[i] - bm; b2 += (okd[i >> 1] && okw[i & 1]) ? dv * dv : 0.f; }
-                    const float rmean = erun[(1 + ch) * 256], rm2 = erun[(9 + ch) * 256];
-                    const float dl = bm - rmean;
-                    erun[(1 + ch) * 256] = rmean + dl * rf;
-                    erun[(9 + ch) * 256] = rm2 + b2 + dl * dl * rnf;
-                }
-            erun[0] = nn;
-            if (!wgstats || !has_next) {       // (uniform) merge the lanes of a channel (16 tiles, then the 4 waves) in a fixed order, one record
-                float fn = erun[0], fm[8], fs[8];
-#pragma unroll
-                for (int ch = 0; ch < 8; ++ch) { fm[ch] = erun[(1 + ch) * 256]; fs[ch] = erun[(9 + ch) * 256]; }
-#pragma unroll
-                for (int sft = 1; sft < 16; sft <<= 1) {
-                    const float n2 = __shfl_xor(fn, sft);
-#pragma unroll
-                    for (int ch = 0; ch < 8; ++ch) {
-                        float na = fn;
-                        welford_merge(na, fm[ch], fs[ch], n2, __shfl_xor(fm[ch], sft), __shfl_xor(fs[ch], sft));
+                            for (int owi = 0; owi < 2; ++owi) v = nmax(v, (d0 + 2 * th + od < D && okw[owi]) ? yv[od * 4 + owi * 2 + th][e4] : NEG);
+                        pm[e4] = v;
                     }
-                    fn += n2;
-                }
-                if (etl == 0) {
-#pragma unroll
-                    for (int ch = 0; ch < 8; ++ch) {
-                        float* sc_ = scr + (wave * 32 + 8 * ekk + ch) * 3;
-                        sc_[0] = fn; sc_[1] = fm[ch]; sc_[2] = fs[ch];
-                    }
+                    *reinterpret_cast<f32x4*>(px + ((wave * 64 + elane) * 8) + 4 * th) = pm;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                if (etid < 32 && n0 + etid < KA()->Ncols) {
-                    float c0 = 0.f, me = 0.f, mm = 0.f;
+                // wave w: window (w & 1), tiles th = (w >> 1): max of the partials of waves (w & 1) and (w & 1) + 2
+                const int win = wave & 1, tsel = wave >> 1;
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(px + ((win * 64 + elane) * 8) + 4 * tsel);
+                const f32x4 p1 = *reinterpret_cast<const f32x4*>(px + (((win + 2) * 64 + elane) * 8) + 4 * tsel);
+                f32x4 best;
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const float* sc_ = scr + (w * 32 + etid) * 3;
-                        welford_merge(c0, me, mm, sc_[0], sc_[1], sc_[2]);
-                    }
-                    const size_t row = wgstats ? (size_t)((blockIdx.x & 7u) * ((gridDim.x >> 3) / (unsigned)KA()->ntiles) + (blockIdx.x >> 3) / (unsigned)KA()->ntiles)
-                                               : (size_t)(((P.nb * tilesD + P.td) * tilesH + P.th) * tilesW + P.tw);
-                    float* o = KA()->stats + (row * KA()->Cout + n0 + etid) * 3;
-                    o[0] = c0; o[1] = me; o[2] = mm;
+                for (int e4 = 0; e4 < 4; ++e4) best[e4] = nmax(p0[e4], p1[e4]);
+                const KArgs e = KA();
+                const int eN = e->Ncols;
+                const int Dp = (D + 1) >> 1, Hp = (H + 1) >> 1, Wp = (W + 1) >> 1;
+                const int pd_ = (d0 >> 1) + tsel, ph_ = (h0 >> 1) + (r >> 2), pw_ = (w0 >> 1) + 2 * (r & 3) + win;
+                const int pch = n0 + 4 * pc;
+                const bool pok = pd_ < Dp && ph_ < Hp && pw_ < Wp && pch < eN;
+                const size_t pv = (((size_t)P_nb * Dp + pd_) * Hp + ph_) * Wp + pw_;
+                const size_t pck = e->pool_chunk;      // (channel-chunked pooled tensor: plane pch / 8, ConvArgs::pool_chunk)
+                if (pok) *reinterpret_cast<f32x4*>(e->pool_out + (pck ? (size_t)(pch >> 3) * pck + pv * 8 + (pch & 4) : pv * eN + pch)) = best;
+            }
+            if (do_stats) {
+                // running record (count, mean[4], M2[4]) of this lane's 4 channels: Chan merge of the brick's (up to) eight values per channel
+                bool ok[8];
+                float cb = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { ok[j] = d0 + 2 * (j & 1) + (j >> 2) < D && okw[(j >> 1) & 1]; cb += ok[j] ? 1.f : 0.f; }
+                const float rn = erun[0];
+                const float nn = rn + cb;
+                const float rf = cb * __builtin_amdgcn_rcpf(fmaxf(nn, 1.f));      // (approximate reciprocal: its error is far below the rounding of the sums)
+                const float rc = cb > 0.f ? 1.f / cb : 0.f;
+                const float rnf = rn * rf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s += ok[j] ? yv[j][e] : 0.f;
+                    const float bm = s * rc;
+                    float b2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float dv = yv[j][e] - bm; b2 += ok[j] ? dv * dv : 0.f; }
+                    const float rmean = erun[(1 + e) * 256], rm2 = erun[(5 + e) * 256];
+                    const float dl = bm - rmean;
+                    erun[(1 + e) * 256] = rmean + dl * rf;
+                    erun[(5 + e) * 256] = rm2 + b2 + dl * dl * rnf;
                 }
-                if (!wgstats) {
+                erun[0] = nn;
+                if (!wgstats || !has_next) {       // (uniform) one record per channel: its 8 lanes per wave are l = 8 r' + (pc ^ r'), the 4 waves in order
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (etid < 32 && n0 + etid < KA()->Ncols) {
+                        const int cpc = etid >> 2, ce = etid & 3;
+                        float c0 = 0.f, me = 0.f, mm = 0.f;
+                        for (int w = 0; w < 4; ++w)
+                            for (int rr = 0; rr < 8; ++rr) {
+                                const float* const src = scr + V_SCR + w * 64 + 8 * rr + (cpc ^ rr);
+                                welford_merge(c0, me, mm, src[0], src[(1 + ce) * 256], src[(5 + ce) * 256]);
+                            }
+                        const size_t row = wgstats ? (size_t)((blockIdx.x & 7u) * ((gridDim.x >> 3) / (unsigned)KA()->ntiles) + (blockIdx.x >> 3) / (unsigned)KA()->ntiles)
+                                                   : (size_t)(((P.nb * tilesD + P.td) * tilesH + P.th) * tilesW + P.tw);
+                        float* o = KA()->stats + (row * KA()->Cout + n0 + etid) * 3;
+                        o[0] = c0; o[1] = me; o[2] = mm;
+                    }
+                    if (!wgstats) {      // one record per brick: the lanes start afresh -- behind the merge that read their records
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int k = 0; k < 17; ++k) erun[k * 256] = 0.f;
+                        for (int k = 0; k < 9; ++k) erun[k * 256] = 0.f;
+                    }
                 }
             }
         }
@@ -772,7 +793,6 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         if (!has_next) break;
         P = N;
         load_consts(P.nt * 32);
-        lane_consts();
     }
 }
 

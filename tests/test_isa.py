@@ -80,7 +80,7 @@ SPILL_FENCE = {
     ('conv3_wino4_kernel', 'ILb1ELb0ELb0ELb0EE'): 0,      # eval forward
     ('conv3_wino4_kernel', 'ILb1ELb1ELb0ELb0EE'): 0,      # eval forward + pool
     ('conv3_wino4_kernel', 'ILb1ELb0ELb1ELb0EE'): 0,      # eval forward + head
-    ('conv3_wino4_kernel', 'ILb0ELb0ELb0ELb1EE'): 7,      # data gradient + BatchNorm reduce
+    ('conv3_wino4_kernel', 'ILb0ELb0ELb0ELb1EE'): 5,      # data gradient + BatchNorm reduce
     ('conv3_wino_pkernel', None): 3,
     ('wgrad_wino_kernel', None): 19,
 }
