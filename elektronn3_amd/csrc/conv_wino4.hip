@@ -42,7 +42,8 @@ constexpr int V_RUN = 9 * 256;                              // running statistic
 constexpr int V_POOLX = 4 * 64 * 8;                         // fused max-pool: [wave][lane][8 channels] (8 KB)
 constexpr int V_HEADW = 160;                                // fused head: weights [4][32] + biases [4] (padded)
 constexpr int V_KST = 2 * 96 + 128;                          // bias / folded scale / folded shift of the workgroup's 32 channels, two slots; BNRED: scale / shift / mean / invstd of the unit in front
-constexpr int V_LDS_FLOATS = 3 * V_RBUF + V_EX + V_SCR + V_RUN + V_KST;   // 160.1 KB of the CU's 160 KiB (163 840 B): one workgroup per CU (the fused pool / head scratch lives in the statistics' region)
+constexpr int V_LC = 8 * 256;                                // the chunk loop's lane constants, parked: [thread][8]
+constexpr int V_LDS_FLOATS = 3 * V_RBUF + V_EX + V_SCR + V_RUN + V_KST + V_LC;   // 158.0 KB of the CU's 160 KiB (163 840 B): one workgroup per CU (the fused pool / head scratch lives in the statistics' region)
 static_assert(V_POOLX + V_HEADW <= V_RUN && V_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
 typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
     unsigned col_rel, col_bits;
     int rdA[2], rdB[2], b_voff;
     const int pA = wave == 0 ? 0 : (wave == 2 ? 2 : 1), pB = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
-    auto lane_consts = [&]() {
+    // (round 6: computed ONCE and parked in LDS -- two ds_read_b128 per brick instead of ~60 VALU instructions with three constant divisions in the epilogue)
+    auto lane_consts_compute = [&]() {
         int fl;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(fl));
         const int g = wave * 64 + fl, slot = g >> 1, qd = g & 1;
@@ -105,7 +107,21 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         }
         b_voff = fl * 16;
     };
-    lane_consts();
+    typedef int i32x4v __attribute__((ext_vector_type(4)));
+    lane_consts_compute();
+    {
+        i32x4v* const lc = reinterpret_cast<i32x4v*>(smem + 3 * V_RBUF + V_EX + V_SCR + V_RUN + V_KST) + 2 * tid;
+        lc[0] = i32x4v{(int)col_rel, (int)col_bits, rdA[0], rdA[1]};
+        lc[1] = i32x4v{rdB[0], rdB[1], b_voff, 0};
+    }
+    auto lane_consts = [&]() {      // (the lane's own slots, written by itself: LDS serves a wave's accesses in order)
+        int fl;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(fl));
+        const volatile i32x4v* const lc = reinterpret_cast<const volatile i32x4v*>(smem + 3 * V_RBUF + V_EX + V_SCR + V_RUN + V_KST) + 2 * (wave * 64 + fl);
+        const i32x4v a0 = lc[0], a1 = lc[1];
+        col_rel = (unsigned)a0[0]; col_bits = (unsigned)a0[1]; rdA[0] = a0[2]; rdA[1] = a0[3];
+        rdB[0] = a1[0]; rdB[1] = a1[1]; b_voff = a1[2];
+    };
     float m1 = -1.f, c2 = 2.f, c4 = 4.f, c8 = 8.f, cm4 = -4.f, cm5 = -5.f, cm2 = -2.f;
     asm volatile("" : "+s"(m1), "+s"(c2), "+s"(c4), "+s"(c8), "+s"(cm4), "+s"(cm5), "+s"(cm2));     // opaque constants: a + c*b becomes v_pk_fma_f32
 
@@ -418,6 +434,8 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         }
         // A^T m A over (pw, ph) in registers, one channel half at a time, one ph row at a time (`ex` is its own LDS region: the next brick's first
         // chunk is already in the stage buffers).  W: F(4,3) rows  m0+m1+m2+m3+m4,  m1-m2+2m3-2m4,  m1+m2+4m3+4m4,  m1-m2+8m3-8m4+m5
+        // (Measured and dropped, round 6: the H pass first -- 44 instead of 56 vector ops per channel half, 48 packed instructions fewer per brick -- changes the
+        // rounding and moves nothing: cfg-5 tile 6.326 -> 6.317 ms, step 10.952 -> 10.979 ms on one box.)
 #pragma unroll
         for (int hf = 0; hf < 2 && !(E3_W4_ABL & 128); ++hf) {
             f32x4 q[2][4];
