@@ -253,6 +253,10 @@ int launch_wgrad_mfma(ConvKind kind, WgradArgs a, hipStream_t s);
 // Winograd F(3x3x3, 2x2x2) variant for CONV_K3 (wgrad_wino.hip): same bricks, splits and partial-slab layout
 bool wgrad_use_wino(ConvKind kind);
 int launch_wgrad_wino(WgradArgs a, int tD, int tH, int tW, int tps, int co_tiles, int ci_tiles, int splits, hipStream_t s);
+// ... and the weight gradients of MANY layers in one stream-K launch (wgrad_wino.hip, round 6): dw = torch layout (Cout, Cin, 27), written directly
+struct WgradSkLayer { const float* x; int x_ldc; int Cin; const float* dy; int dy_ldc; int Cout; size_t dy_chunk; int N, D, H, W; float* dw; };
+size_t wgrad_wino_sk_slab_floats(int tile_pairs);      // tile_pairs = sum over the layers of ceil(Cout / 32) * ceil(Cin / 32)
+int launch_wgrad_wino_sk(const WgradSkLayer* layers, int n, float* slab, size_t slab_floats, hipStream_t s);
 // planar: Winograd F(3x3, 2x2) (wgrad_wino2d.hip); 64-channel granularity on the co side, 32 on the ci side
 bool wgrad_use_wino2d(ConvKind kind, int Cin, int Cout);
 int wgrad_wino2d_splits(int N, int D, int H, int W, int Cin, int Cout);

@@ -116,6 +116,10 @@ struct Buffers {
     std::vector<float*> ups;             // ResizeConv units: the up-sampled input [N, sd*D', 2H', 2W', Cin] (kept for the weight gradient)
     float* wemb; float* gemb;            // ResizeConv(kernel_size=1): weights / weight gradient embedded as the centre tap of a 27-tap kernel
     std::vector<float*> slab_u;          // per unit: own wgrad slab where the slab reduction is deferred to ONE launch (nullptr: B.slab, reduced on the spot)
+    // Round 6: the Winograd weight gradients of all plain 3x3x3 convs run as ONE stream-K launch at the end of the backward (launch_wgrad_wino_sk): such a unit keeps
+    // the gradient of its raw output in a buffer of its own until then, and the launch has one pool of tile slabs (E3_WGRAD_NO_DEFER=1: one launch per layer)
+    std::vector<float*> dz_u;
+    float* wsk_slab = nullptr; size_t wsk_floats = 0;
     float* skws = nullptr;               // split-K partial sums of the bottom-level convs (training only)
     float* rtmp; float* rpad; float* rdu; // ResizeConv scratch: conv output / padded gradient at the up-sampled size, gradient of the up-sampled input
     float* biaspart0;                    // [splits][Cout] conv-bias gradient partials of the first conv when its BN backward is fused into its wgrad
@@ -345,8 +349,26 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
         B.slab = T.take(slabmax);
         static const bool batch_reduce = getenv("E3_NO_REDUCE_BATCH") == nullptr;
         B.slab_u.assign(p->units.size(), nullptr);
+        B.dz_u.assign(p->units.size(), nullptr);
+        static const bool no_defer = getenv("E3_WGRAD_NO_DEFER") != nullptr;      // A/B switch
+        int sk_tile_pairs = 0;
+        for (size_t k = 0; !no_defer && k < p->units.size(); ++k) {
+            const ConvUnit& u = p->units[k];
+            if (valid || u.is_up || u.planar || u.cin < 8 || u.res_in >= 0 || !wgrad_use_wino(CONV_K3)) continue;
+            bool feeds_res = false;      // (a ConvBlock's first conv: its data gradient takes the shortcut's along -- left on the per-layer path)
+            for (size_t q = 0; q < p->units.size(); ++q) feeds_res = feeds_res || p->units[q].res_in == (int)k;
+            if (feeds_res) continue;
+            // Not the level-0 layers: their dZ (268 MB at cfg 2) is read by the weight gradient right behind the pass that wrote it -- partly out of the memory-side
+            // cache --, deferred it comes from HBM with the staging stalls that brings.  Same box, cfg-2 step: one launch per layer 10.975 ms, layers up to 20 MB
+            // deferred 10.934, up to 80 MB (levels 1 - 3) 10.930, ALL layers 11.128 (profiles/r06_wgrad_streamk.md).  E3_WGRAD_DEFER_MAX_MB moves the limit.
+            static const double defer_max_mb = getenv("E3_WGRAD_DEFER_MAX_MB") ? atof(getenv("E3_WGRAD_DEFER_MAX_MB")) : 80.0;
+            if ((double)ND.u[k].out.vox * u.cout * 4.0 > defer_max_mb * 1048576.0) continue;
+            B.dz_u[k] = T.take(ND.u[k].out.vox * u.cout);
+            sk_tile_pairs += cdiv(u.cout, 32) * cdiv(u.cin, 32);
+        }
+        if (sk_tile_pairs) { B.wsk_floats = wgrad_wino_sk_slab_floats(sk_tile_pairs); B.wsk_slab = T.take(B.wsk_floats); }
         for (size_t k = 0; batch_reduce && k < p->units.size(); ++k)
-            if (slab_own[k]) B.slab_u[k] = T.take(slab_own[k]);
+            if (slab_own[k] && !B.dz_u[k]) B.slab_u[k] = T.take(slab_own[k]);
         for (int j = 0; j < nb; ++j) {
             const size_t n = ND.X[j].vox * p->chan(j);        // the level's input grid is its largest
             B.g1[j] = T.take(n); B.g2[j] = T.take(n);
@@ -1271,6 +1293,10 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
     // after the bucket event a collective may be resident on some CUs: the one-round kernels leave `reserve` CUs alone (E3_BWD_CU_RESERVE)
     const int reserve_req = bucket_event ? (int)((flags >> 8) & 0x1fu) * 8 : 0;
     auto reserve = [&]() { return event_done ? reserve_req : 0; };
+    // Winograd weight gradients deferred to ONE stream-K launch behind the loop (Buffers::dz_u) -- unless the caller wants gradients of a bucket early (the
+    // overlapped all-reduce) or the per-layer profile of a weight gradient is being taken
+    const bool defer_wgrad = bucket_event == nullptr && !(plan->prof_layer >= 0 && plan->prof_which == 2);
+    std::vector<WgradSkLayer> wsk_layers;
     std::vector<WgradReduceJob> wred_jobs;   // slab reductions of the weight gradients (units with their own slab), several per launch
     size_t wred_bytes = 0;                   // pending slab bytes (flushing every 48 / 96 / 160 MB was measured: no better than one launch)
     const size_t wred_limit = ~(size_t)0;
@@ -1331,7 +1357,7 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
         }
         // -- BN + ReLU (+ pool, + skip) backward -> dxr = gradient w.r.t. the raw conv output
         // (residual unit: the raw tensor is conv2(..) + shortcut; its gradient also feeds the shortcut and must outlive the ConvBlock's first conv)
-        float* dxr = u.res_in >= 0 ? B.gres[j] : B.g2[j];
+        float* dxr = u.res_in >= 0 ? B.gres[j] : ((defer_wgrad && B.dz_u[k]) ? B.dz_u[k] : B.g2[j]);
         // Channel-chunked dxr ([Cout / 8][voxel][8]) where BOTH its consumers stage 8-channel chunks of it -- the F(2x2x4) data gradient and the Winograd
         // weight gradient: a halo row of a chunk is then one contiguous run instead of 32 bytes out of every voxel's row (measured on the staging of
         // conv3_wino4_kernel: profiles/r05_w4_phases.md section 5).  The APPLY pass below writes it that way at no cost.  E3_NO_CHUNKED=1: A/B switch.
@@ -1485,6 +1511,9 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
         } else {
             const int taps = u.planar ? 9 : 27;
             const ConvKind kind = u.planar ? CONV_K3_PLANAR : CONV_K3;
+            if (defer_wgrad && B.dz_u[k] && kind == CONV_K3) {      // one stream-K launch for all of them behind the loop
+                wsk_layers.push_back(WgradSkLayer{xin, xin_ldc, u.cin, dyu, u.cout, u.cout, dz_chunk, N, ci.D, ci.H, ci.W, G(u.p_w)});
+            } else {
             WgradArgs a{};
             a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dyu; a.dy_ldc = u.cout; a.dy_chunk = dz_chunk; a.Cout = u.cout; a.part = B.slab_u[k] ? B.slab_u[k] : B.slab;
             a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
@@ -1493,6 +1522,7 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
             { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(kind, a, s)); }
             if (B.slab_u[k]) RUN(wred_push({a.part, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin}));
             else RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
+            }
         }
         // -- data gradient -> g for the previous unit
         if (k == 0 && !dx) break;
@@ -1578,6 +1608,7 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
             RUN(launch_att_bwd_gate_input(att_d, att_resized(att_d) ? B.att_dphi : B.att_df, att_p, B.g1[j + 1], u.cin, s));
     }
     if (!bias_jobs.empty()) RUN(launch_colsum_multi(bias_jobs.data(), (int)bias_jobs.size(), s));
+    if (!wsk_layers.empty()) RUN(launch_wgrad_wino_sk(wsk_layers.data(), (int)wsk_layers.size(), B.wsk_slab, B.wsk_floats, s));
     if (!wred_jobs.empty()) RUN(launch_wgrad_reduce_multi(wred_jobs.data(), (int)wred_jobs.size(), s));
     if (!event_done) E3_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_event, s));
     return E3_OK;

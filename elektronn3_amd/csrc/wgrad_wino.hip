@@ -39,19 +39,23 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void pin4(f32x2* v) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])); }
 
-__global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, int tilesD, int tilesH, int tilesW,
-                                                            int tiles_per_split, int co_tiles, int ci_tiles) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// One unit of work: the (32 co x 32 ci) tile (co0, ci0) of one layer over the bricks [brick0, brick1).  The one-layer kernel runs ONE segment per
+// workgroup (its split), the cross-layer stream-K kernel (round 6) a short list of them.  The partial result goes to
+// out[tap * tap_stride + row * row_stride + column]  (the layer's slab [split][tap][CoPad][CiPad], resp. a private [27][32][32] tile slab).
+struct WSeg {
+    const float* x; const float* dy; size_t dy_chunk;
+    int x_ldc, dy_ldc, Cin, Cout, N, D, H, W, tilesD, tilesH, tilesW;
+    int ci0, co0, brick0, brick1;
+    float* out; int tap_stride, row_stride;
+};
+
+__device__ __forceinline__ void wgrad_wino_segment(const WSeg& a, float* const smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, hf = lane >> 5;
-    unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-    const int ci_t = L % ci_tiles; L /= ci_tiles;
-    const int co_t = L % co_tiles; const int split = L / co_tiles;
-    const int ci0 = ci_t * 32, co0 = co_t * 32;
-    const int nbricks = a.N * tilesD * tilesH * tilesW;
-    const int brick0 = split * tiles_per_split;
-    const int brick1 = brick0 + tiles_per_split < nbricks ? brick0 + tiles_per_split : nbricks;
+    const int tilesD = a.tilesD, tilesH = a.tilesH, tilesW = a.tilesW;
+    const int ci0 = a.ci0, co0 = a.co0;
+    const int brick0 = a.brick0, brick1 = a.brick1;
     constexpr unsigned OOB = 0x80000000u;       // buffer offset beyond the descriptors: the DMA writes zeros
 
     // ---- staging by LDS-DMA (buffer_load_dwordx4 ... lds): a wave-instruction moves 64 x 16 B = 8 voxels x 32 channels
@@ -332,10 +336,100 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * k4 + e;
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
-                    a.part[(((size_t)split * 27 + tap) * a.CoPad + co0 + row) * a.CiPad + ci0 + j] = w3[kd][e];
+                    a.out[(size_t)tap * a.tap_stride + row * a.row_stride + j] = w3[kd][e];
                 }
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, int tilesD, int tilesH, int tilesW,
+                                                            int tiles_per_split, int co_tiles, int ci_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int ci_t = L % ci_tiles; L /= ci_tiles;
+    const int co_t = L % co_tiles; const int split = L / co_tiles;
+    const int nbricks = a.N * tilesD * tilesH * tilesW;
+    WSeg g;
+    g.x = a.x; g.dy = a.dy; g.dy_chunk = a.dy_chunk; g.x_ldc = a.x_ldc; g.dy_ldc = a.dy_ldc; g.Cin = a.Cin; g.Cout = a.Cout;
+    g.N = a.N; g.D = a.D; g.H = a.H; g.W = a.W; g.tilesD = tilesD; g.tilesH = tilesH; g.tilesW = tilesW;
+    g.ci0 = ci_t * 32; g.co0 = co_t * 32;
+    g.brick0 = split * tiles_per_split;
+    g.brick1 = g.brick0 + tiles_per_split < nbricks ? g.brick0 + tiles_per_split : nbricks;
+    g.out = a.part + ((size_t)split * 27 * a.CoPad + g.co0) * a.CiPad + g.ci0; g.tap_stride = a.CoPad * a.CiPad; g.row_stride = a.CiPad;
+    wgrad_wino_segment(g, smem);
+}
+
+// ---------------------------------------------------------------- cross-layer stream-K launch (round 6)
+// The Winograd weight gradients of ALL layers of a backward pass in ONE launch: the (layer, tile pair, brick) units of work of the layers form one
+// list in which a layer's tile pairs follow each other and a tile pair's bricks are consecutive; workgroup i (logical, XCD-blocked index) takes
+// the units [start(i), start(i + 1)) of an equal partition and walks the segments -- maximal runs inside one tile pair -- its range cuts out.  A segment's
+// partial tile goes to the private slab  i + t  (t = the tile pair's index over all layers: both indices grow along the list, so the slabs of a
+// tile pair are consecutive and no two segments share one); wgrad_sk_reduce_kernel adds a tile pair's slabs in that order.  Fixed partition, fixed
+// order: run-to-run identical.  Against one launch per layer (each cut into 256 splits to fill the chip: 28 MB of slabs per layer, 368 MB per cfg-2
+// step written and read back) this writes at most 256 + (number of tile pairs) tile slabs -- 49 MB for cfg 2 --, and the bottom levels, whose few
+// bricks per workgroup could not amortise a launch's prologue and epilogue, ride along.
+constexpr int WSK_MAX_LAYERS = 16;
+struct WSkLayer {
+    const float* x; const float* dy; unsigned long long dy_chunk; float* dw;
+    int x_ldc, dy_ldc, Cin, Cout, N, D, H, W, tilesD, tilesH, tilesW, ci_tiles, nbricks;
+    unsigned g0, t0;         // first unit of work / first tile pair of the layer
+};
+struct WSkArgs { WSkLayer L[WSK_MAX_LAYERS]; int n; unsigned total, q, r, ntp; float* slab; };
+constexpr int WSK_TILE = 27 * 32 * 32;
+__device__ __forceinline__ unsigned wsk_start(const WSkArgs& a, unsigned i) { return i * a.q + (i < a.r ? i : a.r); }
+__device__ __forceinline__ unsigned wsk_owner(const WSkArgs& a, unsigned g) {      // the workgroup whose range holds unit g
+    const unsigned cut = a.r * (a.q + 1);
+    return g < cut ? g / (a.q + 1) : a.r + (g - cut) / a.q;
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_wino_sk_kernel(const WSkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    unsigned g = wsk_start(a, wg);
+    const unsigned gend = wsk_start(a, wg + 1);
+    int l = 0;
+    while (g < gend) {
+        while (l + 1 < a.n && a.L[l + 1].g0 <= g) ++l;
+        const WSkLayer& Ly = a.L[l];
+        const unsigned rel = g - Ly.g0, tp = rel / (unsigned)Ly.nbricks, b0 = rel - tp * (unsigned)Ly.nbricks;
+        const unsigned left = (unsigned)Ly.nbricks - b0, want = gend - g, nb = want < left ? want : left;
+        WSeg s;
+        s.x = Ly.x; s.dy = Ly.dy; s.dy_chunk = (size_t)Ly.dy_chunk; s.x_ldc = Ly.x_ldc; s.dy_ldc = Ly.dy_ldc; s.Cin = Ly.Cin; s.Cout = Ly.Cout;
+        s.N = Ly.N; s.D = Ly.D; s.H = Ly.H; s.W = Ly.W; s.tilesD = Ly.tilesD; s.tilesH = Ly.tilesH; s.tilesW = Ly.tilesW;
+        s.ci0 = (int)(tp % (unsigned)Ly.ci_tiles) * 32; s.co0 = (int)(tp / (unsigned)Ly.ci_tiles) * 32;
+        s.brick0 = (int)b0; s.brick1 = (int)(b0 + nb);
+        s.out = a.slab + (size_t)(wg + Ly.t0 + tp) * WSK_TILE; s.tap_stride = 1024; s.row_stride = 32;
+        wgrad_wino_segment(s, smem);
+        __syncthreads();              // the segment's exchange buffer overlays the stage buffers of the next one
+        g += nb;
+    }
+}
+
+// dW (torch layout (Cout, Cin, 27)) of every layer from the tile slabs: one thread per (tile pair, tap, row, 4 columns), the slabs of the tile pair's
+// workgroups in ascending order, fp64 accumulation like wgrad_reduce_kernel
+__global__ __launch_bounds__(256) void wgrad_sk_reduce_kernel(const WSkArgs a) {
+    const unsigned t = blockIdx.x / 27u, tap = blockIdx.x % 27u;       // 27 blocks of 256 threads = 32 rows x 8 column quads per tile pair
+    int l = 0;
+    while (l + 1 < a.n && a.L[l + 1].t0 <= t) ++l;
+    const WSkLayer& Ly = a.L[l];
+    const unsigned tp = t - Ly.t0;
+    const int ci0 = (int)(tp % (unsigned)Ly.ci_tiles) * 32, co0 = (int)(tp / (unsigned)Ly.ci_tiles) * 32;
+    const unsigned g0 = Ly.g0 + tp * (unsigned)Ly.nbricks, g1 = g0 + (unsigned)Ly.nbricks;
+    const unsigned w0 = wsk_owner(a, g0), w1 = wsk_owner(a, g1 - 1);
+    const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    const float* p = a.slab + (size_t)(w0 + t) * WSK_TILE + (size_t)tap * 1024 + row * 32 + c4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (unsigned w = w0; w <= w1; ++w, p += WSK_TILE) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += (double)v[e];
+    }
+    const int co = co0 + row;
+    if (co < Ly.Cout) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (ci0 + c4 + e < Ly.Cin) Ly.dw[((size_t)co * Ly.Cin + ci0 + c4 + e) * 27 + tap] = (float)acc[e];
     }
 }
 
@@ -344,6 +438,43 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
 bool wgrad_use_wino(ConvKind kind) {
     static const bool enabled = getenv("E3_WGRAD_NO_WINO") == nullptr;
     return enabled && kind == CONV_K3;
+}
+
+size_t wgrad_wino_sk_slab_floats(int tile_pairs) { return (size_t)(256 + tile_pairs) * WSK_TILE; }
+
+int launch_wgrad_wino_sk(const WgradSkLayer* layers, int n, float* slab, size_t slab_floats, hipStream_t s) {
+    constexpr int lds_bytes = G_LDS_FLOATS * 4;
+    static bool set = false;
+    if (!set) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_wino_sk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); set = true; }
+    for (int l0 = 0; l0 < n; l0 += WSK_MAX_LAYERS) {      // (more layers than the argument block holds: several launches, each its own partition of the same slab)
+        WSkArgs a{};
+        a.n = n - l0 < WSK_MAX_LAYERS ? n - l0 : WSK_MAX_LAYERS;
+        unsigned g = 0, t = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const WgradSkLayer& q = layers[l0 + i];
+            E3_REQUIRE(q.Cin % 4 == 0 && q.Cout % 4 == 0 && q.x_ldc % 4 == 0 && q.dy_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "wgrad needs channel counts that are multiples of 4");
+            E3_REQUIRE((size_t)q.D * q.H * q.W * (size_t)(q.x_ldc > q.dy_ldc ? q.x_ldc : q.dy_ldc) * 4 < 0x7fffffffu, E3_ERR_UNSUPPORTED,
+                       "Winograd wgrad: one sample beyond 2 GiB (32-bit buffer offsets); set E3_WGRAD_NO_WINO=1");
+            E3_REQUIRE(!q.dy_chunk || (q.dy_chunk == (size_t)q.N * q.D * q.H * q.W * 8 && chunked_layout_ok((size_t)q.N * q.D * q.H * q.W, q.Cout)), E3_ERR_INVALID,
+                       "Winograd wgrad: bad channel-chunked dy");
+            WSkLayer& L = a.L[i];
+            L.x = q.x; L.dy = q.dy; L.dy_chunk = q.dy_chunk; L.dw = q.dw; L.x_ldc = q.x_ldc; L.dy_ldc = q.dy_ldc; L.Cin = q.Cin; L.Cout = q.Cout;
+            L.N = q.N; L.D = q.D; L.H = q.H; L.W = q.W; L.tilesD = cdiv(q.D, 2); L.tilesH = cdiv(q.H, 4); L.tilesW = cdiv(q.W, 16);
+            L.ci_tiles = cdiv(q.Cin, 32);
+            L.nbricks = q.N * L.tilesD * L.tilesH * L.tilesW;
+            const unsigned tps = (unsigned)(cdiv(q.Cout, 32) * L.ci_tiles);
+            E3_REQUIRE(L.nbricks > 0 && (size_t)g + (size_t)tps * L.nbricks < (1u << 31), E3_ERR_INVALID, "wgrad (stream-K): work list out of range");
+            L.g0 = g; L.t0 = t;
+            g += tps * (unsigned)L.nbricks; t += tps;
+        }
+        a.total = g; a.ntp = t; a.q = g / 256u; a.r = g % 256u; a.slab = slab;
+        E3_REQUIRE(slab_floats >= wgrad_wino_sk_slab_floats((int)t), E3_ERR_WORKSPACE, "wgrad (stream-K): slab too small");
+        hipLaunchKernelGGL(wgrad_wino_sk_kernel, dim3(256), dim3(256), lds_bytes, s, a);
+        E3_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(wgrad_sk_reduce_kernel, dim3(t * 27u), dim3(256), 0, s, a);
+        E3_CHECK_HIP(hipGetLastError());
+    }
+    return E3_OK;
 }
 
 int launch_wgrad_wino(WgradArgs a, int tD, int tH, int tW, int tps, int co_tiles, int ci_tiles, int splits, hipStream_t s) {

@@ -16,8 +16,9 @@ B16_TESTS = ['tests/test_bf16_gpu.py', 'tests/test_f16_gpu.py', '-k', 'not full_
 GROUPS = {
     'direct_kernels': (dict(E3_CONV_NO_WINO='1', E3_WGRAD_NO_WINO='1', E3_CONV_NO_WINO2D='1', E3_WGRAD_NO_WINO2D='1'), FP32_TESTS),
     'unfused_unbatched': (dict(E3_WINO_NO_PERSIST='1', E3_NO_SPLITK='1', E3_NO_REDUCE_BATCH='1', E3_NO_FIRST_FUSE='1', E3_UPCONV_NO_GEMM='1', E3_WINO_NO_TR='1', E3_WINO_NO_POOL='1', E3_WINO_NO_HEAD='1', E3_WINO_BOX_ALIGNED='1', E3_FIRST_WGRAD_PLANAR_VALU='1', E3_FIRST_NO_MFMA='1',
-                               E3_NO_LOSS_BWD='1'), FP32_TESTS),
-    'persistent_everywhere': (dict(E3_WINO_PERSIST_MIN='1', E3_UPCONV_NO_PERSIST='1', E3_CONV_NO_V3='1', E3_ATT_VALU='1'), FP32_TESTS),
+                               E3_NO_LOSS_BWD='1', E3_WGRAD_NO_DEFER='1'), FP32_TESTS),
+    # (E3_WGRAD_DEFER_MAX_MB: EVERY Winograd weight gradient in the one stream-K launch at the end of the backward, not only the layers up to 80 MB)
+    'persistent_everywhere': (dict(E3_WINO_PERSIST_MIN='1', E3_UPCONV_NO_PERSIST='1', E3_CONV_NO_V3='1', E3_ATT_VALU='1', E3_WGRAD_DEFER_MAX_MB='100000'), FP32_TESTS),
     'b16_alternatives': (dict(E3_B16_NO_SPLITK='1', E3_B16_UP_GENERIC='1', E3_B16_BD='2', E3_B16_TW='16', E3_B16_COT='1'), B16_TESTS),
     # the round-4 persistent kernels (conv_first_mfma_kernel, conv_first_b16_pkernel, conv_b16_pkernel) at EVERY size they can take: small and ragged grids,
     # workgroups without a single item, statistics records of empty workgroups
