@@ -80,6 +80,10 @@ struct WgradB16Args {
 };
 int wgrad_b16_splits(int N, int D, int H, int W, int Cin, int Cout, int planar);
 int launch_wgrad_b16(WgradB16Args a, hipStream_t s);
+// ... and the 3x3x3 weight gradients of many layers in one stream-K launch (bf16_wgrad.hip; scheme: kernels.h WSkPart): dw = fp32 torch layout (Cout, Cin, 27)
+struct WgradSkB16Layer { const bf16_t* x; const bf16_t* x2; int x_split; int x_ldc; int Cin; const bf16_t* dy; int dy_ldc; int Cout; int N, D, H, W; float* dw; };
+size_t wgrad_b16_sk_slab_floats(int tile_pairs);
+int launch_wgrad_b16_sk(const WgradSkB16Layer* layers, int n, float* slab, size_t slab_floats, hipStream_t s);
 
 // ---------------------------------------------------------------- transposed conv k = s = (sd, 2, 2) (bf16_upconv.hip)
 // forward: y[(sd d + kd, 2h + kh, 2w + kw)][co] = bf16(bias[co] + sum_ci x[(d,h,w)][ci] * w[ci][co][tap]) for output voxels inside

@@ -14,6 +14,7 @@
 // w-row; the dY fragment of a k-step is shared by the wave's taps.  Result: fp32 partial slabs part[split][tap][co][ci] in the
 // layout of the fp32 path, finished by wgrad_reduce_kernel.
 #include "bf16.h"
+#include "kernels.h"      // (WSkPart: the stream-K partition shared with the fp32 path)
 
 namespace {
 
@@ -47,28 +48,31 @@ __device__ unsigned long long* g_wtiming = nullptr;      // phase timestamps (to
 #define E3_WTICK(k)
 #endif
 
+// One unit of work: the (32 co x 32 ci) tile (co0, ci0) of one layer over the bricks [brick0, brick1); the partial result goes to
+// out[tap * tap_stride + row * row_stride + column].  The one-layer kernel runs one segment per workgroup, the cross-layer stream-K kernel (round 6) a list.
+struct WSegB {
+    const bf16_t* x; const bf16_t* x2; const bf16_t* dy;
+    int x_split, x_ldc, dy_ldc, N, D, H, W, tilesD, tilesH, tilesW;
+    int ci0, co0, brick0, brick1;
+    float* out; int tap_stride, row_stride;
+};
+
 template <int KD>
-__global__ __launch_bounds__(256, 2) void wgrad_b16_kernel(const WgradB16Args a, int tilesD, int tilesH, int tilesW, int bricks_per_split,
-                                                           int co_tiles, int ci_tiles) {
+__device__ __forceinline__ void wgrad_b16_segment(const WSegB& a, unsigned char* const smem) {
     constexpr int HD = 2 + (KD == 3 ? 2 : 0), PD = KD == 3 ? 1 : 0;
     constexpr int HV = HD * HH * HW;
     constexpr int XP = (HV * 4 + 63) / 64;        // 1 KB pieces of the X image (45 / 23)
     constexpr int XI = (XP + 3) / 4;
     constexpr int XIMG = XP * 1024;
     constexpr int TAPS = KD * 9, TPW = (TAPS + 3) / 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned L = xcd_remap(blockIdx.x, gridDim.x);
-    const int ci_t = L % ci_tiles; L /= ci_tiles;
-    const int co_t = L % co_tiles; const int split = L / co_tiles;
-    const int ci0 = ci_t * 32, co0 = co_t * 32;
+    const int tilesD = a.tilesD, tilesH = a.tilesH, tilesW = a.tilesW;
+    const int ci0 = a.ci0, co0 = a.co0;
     const bool second = a.x2 && ci0 >= a.x_split;                       // this tile's input channels live in the second tensor
     const bf16_t* xsrc = second ? a.x2 : a.x;
     const int cisrc = second ? ci0 - a.x_split : ci0;
-    const int nbricks = a.N * tilesD * tilesH * tilesW;
-    const int brick0 = split * bricks_per_split;
-    const int brick1 = brick0 + bricks_per_split < nbricks ? brick0 + bricks_per_split : nbricks;
+    const int brick0 = a.brick0, brick1 = a.brick1;
 
     // ---- staging plan.  Validity of a halo voxel is separable: one scalar mask per brick (4 d | 10 h | 18 w bits), one constant
     // 3-bit pattern per lane and piece
@@ -160,15 +164,62 @@ __global__ __launch_bounds__(256, 2) void wgrad_b16_kernel(const WgradB16Args a,
         E3_WTICK(3);
         __syncthreads();
     }
-    // ---- slab: part[split][tap][CoPad][CiPad]; lane holds column ci = lane & 31, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
-    const int CoPad = co_tiles * 32, CiPad = ci_tiles * 32;
+    // ---- partial tile: lane holds column ci = lane & 31, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int tap = wave * TPW + i;
         if (tap >= TAPS) continue;
-        float* dst = a.part + (((size_t)split * TAPS + tap) * CoPad + co0) * CiPad + ci0 + (lane & 31);
+        float* dst = a.out + (size_t)tap * a.tap_stride + (lane & 31);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dst[(size_t)((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * CiPad] = acc[i][e];
+        for (int e = 0; e < 16; ++e) dst[(size_t)((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * a.row_stride] = acc[i][e];
+    }
+}
+
+template <int KD>
+__global__ __launch_bounds__(256, 2) void wgrad_b16_kernel(const WgradB16Args a, int tilesD, int tilesH, int tilesW, int bricks_per_split,
+                                                           int co_tiles, int ci_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TAPS = KD * 9;
+    unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+    const int ci_t = L % ci_tiles; L /= ci_tiles;
+    const int co_t = L % co_tiles; const int split = L / co_tiles;
+    const int nbricks = a.N * tilesD * tilesH * tilesW;
+    const int CoPad = co_tiles * 32, CiPad = ci_tiles * 32;
+    WSegB g;
+    g.x = a.x; g.x2 = a.x2; g.dy = a.dy; g.x_split = a.x_split; g.x_ldc = a.x_ldc; g.dy_ldc = a.dy_ldc;
+    g.N = a.N; g.D = a.D; g.H = a.H; g.W = a.W; g.tilesD = tilesD; g.tilesH = tilesH; g.tilesW = tilesW;
+    g.ci0 = ci_t * 32; g.co0 = co_t * 32;
+    g.brick0 = split * bricks_per_split;
+    g.brick1 = g.brick0 + bricks_per_split < nbricks ? g.brick0 + bricks_per_split : nbricks;
+    g.out = a.part + ((size_t)split * TAPS * CoPad + g.co0) * CiPad + g.ci0; g.tap_stride = CoPad * CiPad; g.row_stride = CiPad;
+    wgrad_b16_segment<KD>(g, smem);
+}
+
+// ---- cross-layer stream-K launch (round 6; the fp32 twin and the scheme: wgrad_wino.hip / kernels.h WSkPart): the 3x3x3 weight gradients of many layers in ONE
+// launch of 512 workgroups (two per CU), a private [27][32][32] fp32 tile slab per (workgroup, tile pair) segment, reduced by launch_wgrad_sk_reduce
+struct WSkLayerB { const bf16_t* x; const bf16_t* x2; const bf16_t* dy; int x_split, x_ldc, dy_ldc, N, D, H, W, tilesD, tilesH, tilesW; };
+struct WSkArgsB { WSkPart p; WSkLayerB L[WSK_MAX_LAYERS]; };
+
+__global__ __launch_bounds__(256, 2) void wgrad_b16_sk_kernel(const WSkArgsB a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    unsigned g = wg * a.p.q + (wg < a.p.r ? wg : a.p.r);
+    const unsigned gend = (wg + 1) * a.p.q + (wg + 1 < a.p.r ? wg + 1 : a.p.r);
+    int l = 0;
+    while (g < gend) {
+        while (l + 1 < a.p.n && a.p.L[l + 1].g0 <= g) ++l;
+        const WSkPartLayer& Lp = a.p.L[l];
+        const WSkLayerB& Ly = a.L[l];
+        const unsigned rel = g - Lp.g0, tp = rel / (unsigned)Lp.nbricks, b0 = rel - tp * (unsigned)Lp.nbricks;
+        const unsigned left = (unsigned)Lp.nbricks - b0, want = gend - g, nb = want < left ? want : left;
+        WSegB s;
+        s.x = Ly.x; s.x2 = Ly.x2; s.dy = Ly.dy; s.x_split = Ly.x_split; s.x_ldc = Ly.x_ldc; s.dy_ldc = Ly.dy_ldc;
+        s.N = Ly.N; s.D = Ly.D; s.H = Ly.H; s.W = Ly.W; s.tilesD = Ly.tilesD; s.tilesH = Ly.tilesH; s.tilesW = Ly.tilesW;
+        s.ci0 = (int)(tp % (unsigned)Lp.ci_tiles) * 32; s.co0 = (int)(tp / (unsigned)Lp.ci_tiles) * 32;
+        s.brick0 = (int)b0; s.brick1 = (int)(b0 + nb);
+        s.out = a.p.slab + (size_t)(wg + Lp.t0 + tp) * (27 * 1024); s.tap_stride = 1024; s.row_stride = 32;
+        wgrad_b16_segment<3>(s, smem);      // (its brick loop ends with a barrier: the stage is free for the next segment)
+        g += nb;
     }
 }
 
@@ -187,6 +238,33 @@ int wgrad_b16_splits(int N, int D, int H, int W, int Cin, int Cout, int planar) 
     if (splits < 1) splits = 1;
     const int per = cdiv(nbricks, splits);
     return cdiv(nbricks, per);                 // no empty split
+}
+
+size_t wgrad_b16_sk_slab_floats(int tile_pairs) { return wgrad_sk_slab_floats(tile_pairs, 512); }
+
+int launch_wgrad_b16_sk(const WgradSkB16Layer* layers, int n, float* slab, size_t slab_floats, hipStream_t s) {
+    constexpr int lds = ((4 * HH * HW * 4 + 63) / 64) * 1024 + 16384;
+    for (int l0 = 0; l0 < n; l0 += WSK_MAX_LAYERS) {
+        WSkArgsB a{};
+        const int m = n - l0 < WSK_MAX_LAYERS ? n - l0 : WSK_MAX_LAYERS;
+        int Cin[WSK_MAX_LAYERS], Cout[WSK_MAX_LAYERS], nbr[WSK_MAX_LAYERS]; float* dw[WSK_MAX_LAYERS];
+        for (int i = 0; i < m; ++i) {
+            const WgradSkB16Layer& q = layers[l0 + i];
+            E3_REQUIRE(q.Cin % 32 == 0 && q.Cout % 32 == 0, E3_ERR_UNSUPPORTED, "bf16 wgrad: channel counts must be multiples of 32");
+            E3_REQUIRE(q.x_ldc % 8 == 0 && q.dy_ldc % 8 == 0, E3_ERR_INVALID, "bf16 wgrad: misaligned view");
+            WSkLayerB& L = a.L[i];
+            L.x = q.x; L.x2 = q.x2; L.dy = q.dy; L.x_split = q.x_split; L.x_ldc = q.x_ldc; L.dy_ldc = q.dy_ldc;
+            L.N = q.N; L.D = q.D; L.H = q.H; L.W = q.W; L.tilesD = cdiv(q.D, 2); L.tilesH = cdiv(q.H, 8); L.tilesW = cdiv(q.W, 16);
+            Cin[i] = q.Cin; Cout[i] = q.Cout; nbr[i] = q.N * L.tilesD * L.tilesH * L.tilesW; dw[i] = q.dw;
+        }
+        const int rc = wgrad_sk_partition(a.p, m, Cin, Cout, nbr, dw, 512, slab, slab_floats);
+        if (rc) return rc;
+        hipLaunchKernelGGL(wgrad_b16_sk_kernel, dim3(512), dim3(256), lds, s, a);
+        E3_CHECK_HIP(hipGetLastError());
+        const int rr = launch_wgrad_sk_reduce(a.p, s);
+        if (rr) return rr;
+    }
+    return E3_OK;
 }
 
 int launch_wgrad_b16(WgradB16Args a, hipStream_t s) {

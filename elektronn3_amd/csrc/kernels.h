@@ -256,6 +256,14 @@ int launch_wgrad_wino(WgradArgs a, int tD, int tH, int tW, int tps, int co_tiles
 // ... and the weight gradients of MANY layers in one stream-K launch (wgrad_wino.hip, round 6): dw = torch layout (Cout, Cin, 27), written directly
 struct WgradSkLayer { const float* x; int x_ldc; int Cin; const float* dy; int dy_ldc; int Cout; size_t dy_chunk; int N, D, H, W; float* dw; };
 size_t wgrad_wino_sk_slab_floats(int tile_pairs);      // tile_pairs = sum over the layers of ceil(Cout / 32) * ceil(Cin / 32)
+// the partition of such a launch (shared by the fp32 and the 16-bit kernels and their common reduction): unit g of layer i = brick (g - g0) % nbricks of tile pair
+// (g - g0) / nbricks; workgroup w of nwg owns the units [w q + min(w, r), ...); the partial tile of (workgroup w, tile pair t) is slab w + t
+constexpr int WSK_MAX_LAYERS = 16;
+struct WSkPartLayer { float* dw; int Cin, Cout, ci_tiles, nbricks; unsigned g0, t0; };
+struct WSkPart { WSkPartLayer L[WSK_MAX_LAYERS]; int n; unsigned total, q, r, ntp, nwg; float* slab; };
+size_t wgrad_sk_slab_floats(int tile_pairs, int workgroups);
+int wgrad_sk_partition(WSkPart& p, int n, const int* Cin, const int* Cout, const int* nbricks, float* const* dw, int workgroups, float* slab, size_t slab_floats);
+int launch_wgrad_sk_reduce(const WSkPart& p, hipStream_t s);
 int launch_wgrad_wino_sk(const WgradSkLayer* layers, int n, float* slab, size_t slab_floats, hipStream_t s);
 // planar: Winograd F(3x3, 2x2) (wgrad_wino2d.hip); 64-channel granularity on the co side, 32 on the ci side
 bool wgrad_use_wino2d(ConvKind kind, int Cin, int Cout);

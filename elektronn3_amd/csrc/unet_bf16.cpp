@@ -37,6 +37,8 @@ struct BufB {
     std::vector<bf16_t*> catA, catB, pooled, g1, g2, dcatA, dcatB;     // concat halves as separate tensors: A = transposed-conv output, B = encoder skip
     bf16_t* xin; bf16_t* wpack; bf16_t* evalA;
     float *stats, *small, *slab, *bnred, *skws;
+    // round 6: 3x3x3 weight gradients deferred to ONE stream-K launch at the end of the backward (launch_wgrad_b16_sk): the unit's dZ in a buffer of its own
+    std::vector<bf16_t*> dz_u; float* wsk_slab = nullptr; size_t wsk_floats = 0;
     size_t saved_bytes, scratch_bytes;
 };
 
@@ -71,6 +73,8 @@ void plan_b16(const e3_unet_plan* p, int N, int D, int H, int W, bool training, 
     }
     B.saved_bytes = S.off;
     size_t wmax = 0, statmax = 0, slabmax = 0, skmax = 0;
+    B.dz_u.assign(nu, nullptr); B.wsk_slab = nullptr; B.wsk_floats = 0;
+    int sk_tile_pairs = 0;
     const int Cmax = p->chan(nb - 1);
     for (size_t k = 0; k < nu; ++k) {
         const ConvUnit& u = p->units[k];
@@ -99,9 +103,15 @@ void plan_b16(const e3_unet_plan* p, int N, int D, int H, int W, bool training, 
         }
         if (training) {
             b.bnpart = T.take_f((size_t)bn_bwd_b16_parts(ND.u[k].out.vox, u.cout) * 3 * u.cout);
+            // (which layers: as in the fp32 executor, unet_plan.cpp -- the large layers' dZ is read by the per-layer launch right behind the pass that wrote it)
+            static const bool no_defer = getenv("E3_WGRAD_NO_DEFER") != nullptr;
+            static const double defer_max_mb = getenv("E3_WGRAD_DEFER_MAX_MB") ? atof(getenv("E3_WGRAD_DEFER_MAX_MB")) : 80.0;
+            const bool defer = !no_defer && !u.is_up && u.cin >= 8 && !pl && (double)ND.u[k].out.vox * u.cout * 2.0 <= defer_max_mb * 1048576.0;
+            if (defer) { B.dz_u[k] = T.take_h(ND.u[k].out.vox * u.cout); sk_tile_pairs += (u.cin / 32) * (u.cout / 32); slabmax = max(slabmax, own); own = 0; }      // (the per-layer fallback of such a unit takes the shared slab)
             b.slab = own ? T.take_f(own) : nullptr;
         }
     }
+    if (sk_tile_pairs) { B.wsk_floats = wgrad_b16_sk_slab_floats(sk_tile_pairs); B.wsk_slab = T.take_f(B.wsk_floats); }
     if (training) slabmax = max(slabmax, (size_t)conv_final_b16_bwd_parts(ND.Y.vox) * (p->cfg.out_channels * p->chan(0) + p->cfg.out_channels));
     (void)wmax; B.wpack = nullptr;
     B.stats = T.take_f(statmax);
@@ -367,6 +377,9 @@ static int backward_b16_impl(e3_unet_plan* plan, void* stream, const float* dy, 
     bool event_done = bucket_event == nullptr;
     std::vector<WgradReduceJob> wred;
     std::vector<ColsumJob> bias_jobs;
+    // (not with the overlapped all-reduce -- its early bucket wants final gradients -- and not while a per-layer weight-gradient profile is taken)
+    const bool defer_wgrad = bucket_event == nullptr && !(plan->prof_layer >= 0 && plan->prof_which == 2);
+    std::vector<WgradSkB16Layer> wsk_layers;
     for (int k = nunits - 1; k >= 0; --k) {
         const ConvUnit& u = plan->units[k];
         const UnitB& b = B.ub[k];
@@ -383,7 +396,7 @@ static int backward_b16_impl(e3_unet_plan* plan, void* stream, const float* dy, 
             E3_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_event, s)); event_done = true;
         }
         // ---- BN + ReLU (+ pool, + skip) backward -> dxr
-        bf16_t* dxr = B.g2[j];
+        bf16_t* dxr = (defer_wgrad && B.dz_u[k]) ? B.dz_u[k] : B.g2[j];
         {
             BnBwdB16Args a{};
             a.x = b.raw; a.x_ldc = u.cout; a.mean = b.mean; a.invstd = b.invstd; a.gamma = P(u.p_g); a.scale = b.scale; a.shift = b.shift;
@@ -427,14 +440,17 @@ static int backward_b16_impl(e3_unet_plan* plan, void* stream, const float* dy, 
             const int splits = conv_small_b16_wgrad_splits(N, li.D, li.H, li.W, pl);
             { ProfB pr(plan, s, k, 2); RUN(launch_conv_small_b16_wgrad(xin, u.cin, dxr, u.cout, B.slab, N, li.D, li.H, li.W, u.cout, pl, s)); }
             RUN(launch_wgrad_reduce(B.slab, G(u.p_w), splits, taps, u.cout, u.cin, u.cout, u.cin, s));
+        } else if (defer_wgrad && B.dz_u[k]) {      // one stream-K launch for all of them behind the loop
+            wsk_layers.push_back(WgradSkB16Layer{xin, xin2, xin2 ? u.cin / 2 : 0, xin_ldc, u.cin, dxr, u.cout, u.cout, N, li.D, li.H, li.W, G(u.p_w)});
         } else {
             WgradB16Args a{};
-            a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dxr; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = b.slab;
+            a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dxr; a.dy_ldc = u.cout; a.Cout = u.cout; a.part = b.slab ? b.slab : B.slab;
             a.x2 = xin2; a.x_split = xin2 ? u.cin / 2 : 0;
             a.N = N; a.D = li.D; a.H = li.H; a.W = li.W; a.planar = pl;
             a.splits = wgrad_b16_splits(N, li.D, li.H, li.W, u.cin, u.cout, pl);
             { ProfB pr(plan, s, k, 2); RUN(launch_wgrad_b16(a, s)); }
-            wred.push_back({b.slab, G(u.p_w), a.splits, taps, u.cout, u.cin, u.cout, u.cin});
+            if (b.slab) wred.push_back({b.slab, G(u.p_w), a.splits, taps, u.cout, u.cin, u.cout, u.cin});
+            else RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, u.cout, u.cin, u.cout, u.cin, s));      // (a deferrable unit on the per-layer path: the shared slab, reduced on the spot)
         }
         // ---- data gradient -> g of the previous unit
         if (k == 0) break;
@@ -456,6 +472,7 @@ static int backward_b16_impl(e3_unet_plan* plan, void* stream, const float* dy, 
         }
     }
     if (!bias_jobs.empty()) RUN(launch_colsum_multi(bias_jobs.data(), (int)bias_jobs.size(), s));
+    if (!wsk_layers.empty()) RUN(launch_wgrad_b16_sk(wsk_layers.data(), (int)wsk_layers.size(), B.wsk_slab, B.wsk_floats, s));
     if (!wred.empty()) RUN(launch_wgrad_reduce_multi(wred.data(), (int)wred.size(), s));
     if (!event_done) E3_CHECK_HIP(hipEventRecord((hipEvent_t)bucket_event, s));
     return E3_OK;

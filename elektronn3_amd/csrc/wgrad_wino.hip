@@ -369,16 +369,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
 // order: run-to-run identical.  Against one launch per layer (each cut into 256 splits to fill the chip: 28 MB of slabs per layer, 368 MB per cfg-2
 // step written and read back) this writes at most 256 + (number of tile pairs) tile slabs -- 49 MB for cfg 2 --, and the bottom levels, whose few
 // bricks per workgroup could not amortise a launch's prologue and epilogue, ride along.
-constexpr int WSK_MAX_LAYERS = 16;
-struct WSkLayer {
-    const float* x; const float* dy; unsigned long long dy_chunk; float* dw;
-    int x_ldc, dy_ldc, Cin, Cout, N, D, H, W, tilesD, tilesH, tilesW, ci_tiles, nbricks;
-    unsigned g0, t0;         // first unit of work / first tile pair of the layer
+struct WSkLayer {      // what the kernel needs of a layer beside the partition (kernels.h: WSkPart)
+    const float* x; const float* dy; unsigned long long dy_chunk;
+    int x_ldc, dy_ldc, N, D, H, W, tilesD, tilesH, tilesW;
 };
-struct WSkArgs { WSkLayer L[WSK_MAX_LAYERS]; int n; unsigned total, q, r, ntp; float* slab; };
+struct WSkArgs { WSkPart p; WSkLayer L[WSK_MAX_LAYERS]; };
 constexpr int WSK_TILE = 27 * 32 * 32;
-__device__ __forceinline__ unsigned wsk_start(const WSkArgs& a, unsigned i) { return i * a.q + (i < a.r ? i : a.r); }
-__device__ __forceinline__ unsigned wsk_owner(const WSkArgs& a, unsigned g) {      // the workgroup whose range holds unit g
+__device__ __forceinline__ unsigned wsk_start(const WSkPart& a, unsigned i) { return i * a.q + (i < a.r ? i : a.r); }
+__device__ __forceinline__ unsigned wsk_owner(const WSkPart& a, unsigned g) {      // the workgroup whose range holds unit g
     const unsigned cut = a.r * (a.q + 1);
     return g < cut ? g / (a.q + 1) : a.r + (g - cut) / a.q;
 }
@@ -386,20 +384,21 @@ __device__ __forceinline__ unsigned wsk_owner(const WSkArgs& a, unsigned g) {   
 __global__ __launch_bounds__(256, 1) void wgrad_wino_sk_kernel(const WSkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
-    unsigned g = wsk_start(a, wg);
-    const unsigned gend = wsk_start(a, wg + 1);
+    unsigned g = wsk_start(a.p, wg);
+    const unsigned gend = wsk_start(a.p, wg + 1);
     int l = 0;
     while (g < gend) {
-        while (l + 1 < a.n && a.L[l + 1].g0 <= g) ++l;
+        while (l + 1 < a.p.n && a.p.L[l + 1].g0 <= g) ++l;
+        const WSkPartLayer& Lp = a.p.L[l];
         const WSkLayer& Ly = a.L[l];
-        const unsigned rel = g - Ly.g0, tp = rel / (unsigned)Ly.nbricks, b0 = rel - tp * (unsigned)Ly.nbricks;
-        const unsigned left = (unsigned)Ly.nbricks - b0, want = gend - g, nb = want < left ? want : left;
+        const unsigned rel = g - Lp.g0, tp = rel / (unsigned)Lp.nbricks, b0 = rel - tp * (unsigned)Lp.nbricks;
+        const unsigned left = (unsigned)Lp.nbricks - b0, want = gend - g, nb = want < left ? want : left;
         WSeg s;
-        s.x = Ly.x; s.dy = Ly.dy; s.dy_chunk = (size_t)Ly.dy_chunk; s.x_ldc = Ly.x_ldc; s.dy_ldc = Ly.dy_ldc; s.Cin = Ly.Cin; s.Cout = Ly.Cout;
+        s.x = Ly.x; s.dy = Ly.dy; s.dy_chunk = (size_t)Ly.dy_chunk; s.x_ldc = Ly.x_ldc; s.dy_ldc = Ly.dy_ldc; s.Cin = Lp.Cin; s.Cout = Lp.Cout;
         s.N = Ly.N; s.D = Ly.D; s.H = Ly.H; s.W = Ly.W; s.tilesD = Ly.tilesD; s.tilesH = Ly.tilesH; s.tilesW = Ly.tilesW;
-        s.ci0 = (int)(tp % (unsigned)Ly.ci_tiles) * 32; s.co0 = (int)(tp / (unsigned)Ly.ci_tiles) * 32;
+        s.ci0 = (int)(tp % (unsigned)Lp.ci_tiles) * 32; s.co0 = (int)(tp / (unsigned)Lp.ci_tiles) * 32;
         s.brick0 = (int)b0; s.brick1 = (int)(b0 + nb);
-        s.out = a.slab + (size_t)(wg + Ly.t0 + tp) * WSK_TILE; s.tap_stride = 1024; s.row_stride = 32;
+        s.out = a.p.slab + (size_t)(wg + Lp.t0 + tp) * WSK_TILE; s.tap_stride = 1024; s.row_stride = 32;
         wgrad_wino_segment(s, smem);
         __syncthreads();              // the segment's exchange buffer overlays the stage buffers of the next one
         g += nb;
@@ -407,12 +406,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_sk_kernel(const WSkArgs a) 
 }
 
 // dW (torch layout (Cout, Cin, 27)) of every layer from the tile slabs: one thread per (tile pair, tap, row, 4 columns), the slabs of the tile pair's
-// workgroups in ascending order, fp64 accumulation like wgrad_reduce_kernel
-__global__ __launch_bounds__(256) void wgrad_sk_reduce_kernel(const WSkArgs a) {
+// workgroups in ascending order, fp64 accumulation like wgrad_reduce_kernel.  (Shared with the 16-bit path: launch_wgrad_sk_reduce.)
+__global__ __launch_bounds__(256) void wgrad_sk_reduce_kernel(const WSkPart a) {
     const unsigned t = blockIdx.x / 27u, tap = blockIdx.x % 27u;       // 27 blocks of 256 threads = 32 rows x 8 column quads per tile pair
     int l = 0;
     while (l + 1 < a.n && a.L[l + 1].t0 <= t) ++l;
-    const WSkLayer& Ly = a.L[l];
+    const WSkPartLayer& Ly = a.L[l];
     const unsigned tp = t - Ly.t0;
     const int ci0 = (int)(tp % (unsigned)Ly.ci_tiles) * 32, co0 = (int)(tp / (unsigned)Ly.ci_tiles) * 32;
     const unsigned g0 = Ly.g0 + tp * (unsigned)Ly.nbricks, g1 = g0 + (unsigned)Ly.nbricks;
@@ -440,7 +439,33 @@ bool wgrad_use_wino(ConvKind kind) {
     return enabled && kind == CONV_K3;
 }
 
-size_t wgrad_wino_sk_slab_floats(int tile_pairs) { return (size_t)(256 + tile_pairs) * WSK_TILE; }
+size_t wgrad_sk_slab_floats(int tile_pairs, int workgroups) { return (size_t)(workgroups + tile_pairs) * WSK_TILE; }
+size_t wgrad_wino_sk_slab_floats(int tile_pairs) { return wgrad_sk_slab_floats(tile_pairs, 256); }
+
+// the partition of a stream-K launch: layer i has nbricks[i] bricks per tile pair
+int wgrad_sk_partition(WSkPart& p, int n, const int* Cin, const int* Cout, const int* nbricks, float* const* dw, int workgroups, float* slab, size_t slab_floats) {
+    E3_REQUIRE(n >= 1 && n <= WSK_MAX_LAYERS, E3_ERR_INVALID, "wgrad (stream-K): 1..16 layers per launch");
+    p = WSkPart{};
+    p.n = n; p.nwg = (unsigned)workgroups; p.slab = slab;
+    unsigned g = 0, t = 0;
+    for (int i = 0; i < n; ++i) {
+        WSkPartLayer& L = p.L[i];
+        L.dw = dw[i]; L.Cin = Cin[i]; L.Cout = Cout[i]; L.ci_tiles = cdiv(Cin[i], 32); L.nbricks = nbricks[i];
+        const unsigned tps = (unsigned)(cdiv(Cout[i], 32) * L.ci_tiles);
+        E3_REQUIRE(L.nbricks > 0 && (size_t)g + (size_t)tps * L.nbricks < (1u << 31), E3_ERR_INVALID, "wgrad (stream-K): work list out of range");
+        L.g0 = g; L.t0 = t;
+        g += tps * (unsigned)L.nbricks; t += tps;
+    }
+    p.total = g; p.ntp = t; p.q = g / p.nwg; p.r = g % p.nwg;
+    E3_REQUIRE(slab_floats >= wgrad_sk_slab_floats((int)t, workgroups), E3_ERR_WORKSPACE, "wgrad (stream-K): slab too small");
+    return E3_OK;
+}
+
+int launch_wgrad_sk_reduce(const WSkPart& p, hipStream_t s) {
+    hipLaunchKernelGGL(wgrad_sk_reduce_kernel, dim3(p.ntp * 27u), dim3(256), 0, s, p);
+    E3_CHECK_HIP(hipGetLastError());
+    return E3_OK;
+}
 
 int launch_wgrad_wino_sk(const WgradSkLayer* layers, int n, float* slab, size_t slab_floats, hipStream_t s) {
     constexpr int lds_bytes = G_LDS_FLOATS * 4;
@@ -448,9 +473,9 @@ int launch_wgrad_wino_sk(const WgradSkLayer* layers, int n, float* slab, size_t 
     if (!set) { E3_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_wino_sk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); set = true; }
     for (int l0 = 0; l0 < n; l0 += WSK_MAX_LAYERS) {      // (more layers than the argument block holds: several launches, each its own partition of the same slab)
         WSkArgs a{};
-        a.n = n - l0 < WSK_MAX_LAYERS ? n - l0 : WSK_MAX_LAYERS;
-        unsigned g = 0, t = 0;
-        for (int i = 0; i < a.n; ++i) {
+        const int m = n - l0 < WSK_MAX_LAYERS ? n - l0 : WSK_MAX_LAYERS;
+        int Cin[WSK_MAX_LAYERS], Cout[WSK_MAX_LAYERS], nbr[WSK_MAX_LAYERS]; float* dw[WSK_MAX_LAYERS];
+        for (int i = 0; i < m; ++i) {
             const WgradSkLayer& q = layers[l0 + i];
             E3_REQUIRE(q.Cin % 4 == 0 && q.Cout % 4 == 0 && q.x_ldc % 4 == 0 && q.dy_ldc % 4 == 0, E3_ERR_UNSUPPORTED, "wgrad needs channel counts that are multiples of 4");
             E3_REQUIRE((size_t)q.D * q.H * q.W * (size_t)(q.x_ldc > q.dy_ldc ? q.x_ldc : q.dy_ldc) * 4 < 0x7fffffffu, E3_ERR_UNSUPPORTED,
@@ -458,21 +483,16 @@ int launch_wgrad_wino_sk(const WgradSkLayer* layers, int n, float* slab, size_t 
             E3_REQUIRE(!q.dy_chunk || (q.dy_chunk == (size_t)q.N * q.D * q.H * q.W * 8 && chunked_layout_ok((size_t)q.N * q.D * q.H * q.W, q.Cout)), E3_ERR_INVALID,
                        "Winograd wgrad: bad channel-chunked dy");
             WSkLayer& L = a.L[i];
-            L.x = q.x; L.dy = q.dy; L.dy_chunk = q.dy_chunk; L.dw = q.dw; L.x_ldc = q.x_ldc; L.dy_ldc = q.dy_ldc; L.Cin = q.Cin; L.Cout = q.Cout;
+            L.x = q.x; L.dy = q.dy; L.dy_chunk = q.dy_chunk; L.x_ldc = q.x_ldc; L.dy_ldc = q.dy_ldc;
             L.N = q.N; L.D = q.D; L.H = q.H; L.W = q.W; L.tilesD = cdiv(q.D, 2); L.tilesH = cdiv(q.H, 4); L.tilesW = cdiv(q.W, 16);
-            L.ci_tiles = cdiv(q.Cin, 32);
-            L.nbricks = q.N * L.tilesD * L.tilesH * L.tilesW;
-            const unsigned tps = (unsigned)(cdiv(q.Cout, 32) * L.ci_tiles);
-            E3_REQUIRE(L.nbricks > 0 && (size_t)g + (size_t)tps * L.nbricks < (1u << 31), E3_ERR_INVALID, "wgrad (stream-K): work list out of range");
-            L.g0 = g; L.t0 = t;
-            g += tps * (unsigned)L.nbricks; t += tps;
+            Cin[i] = q.Cin; Cout[i] = q.Cout; nbr[i] = q.N * L.tilesD * L.tilesH * L.tilesW; dw[i] = q.dw;
         }
-        a.total = g; a.ntp = t; a.q = g / 256u; a.r = g % 256u; a.slab = slab;
-        E3_REQUIRE(slab_floats >= wgrad_wino_sk_slab_floats((int)t), E3_ERR_WORKSPACE, "wgrad (stream-K): slab too small");
+        const int rc = wgrad_sk_partition(a.p, m, Cin, Cout, nbr, dw, 256, slab, slab_floats);
+        if (rc) return rc;
         hipLaunchKernelGGL(wgrad_wino_sk_kernel, dim3(256), dim3(256), lds_bytes, s, a);
         E3_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(wgrad_sk_reduce_kernel, dim3(t * 27u), dim3(256), 0, s, a);
-        E3_CHECK_HIP(hipGetLastError());
+        const int rr = launch_wgrad_sk_reduce(a.p, s);
+        if (rr) return rr;
     }
     return E3_OK;
 }
