@@ -40,7 +40,42 @@ BATCH_PER_GPU = 2
 MFMA_PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0, 'f16': 2500.0}   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16, dense
 HBM_PEAK = 8.0e12                                    # B/s (spec)
 FWDBWD_FLOP_PER_VOXEL = 1279.9e3                     # SURVEY.md 8d (cfg 2 network)
-PMC_FILE = os.path.join('profiles', 'r05_pmc_roofline.json')
+PMC_FILE = os.path.join('profiles', 'r06_pmc_roofline.json')      # fallback of roofline.traffic when the live PMC passes cannot run
+
+
+def live_traffic(dtype, kernel_substr, timeout=240):
+    """roofline.traffic measured IN this run (it used to be replayed from a committed file): two child runs of this script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `... WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes; 1 warm-up + 1 timed + 2 x 2 per-layer
+    timing steps each), the dispatches of the roofline kernel grouped by their position in a step, FETCH_SIZE doubled (gfx950 wide-read correction).
+    Returns (hbm bytes per launch of the roofline layer, description) or (None, reason)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        from pmc_roofline import per_position
+    except Exception as e:  # noqa: BLE001
+        return None, f'tools/pmc_roofline.py: {e}'
+    vals = {}
+    with tempfile.TemporaryDirectory(dir='/tmp') as tmp:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, '--kernel-trace', '--pmc', counter, '-d', out, '-o', 'run', '--output-format', 'csv', '--', sys.executable, os.path.abspath(__file__),
+                   '--no-cpu-baseline', '--no-predictor', '--no-extra-legs', '--no-live-traffic', '--steps', '1', '--warmup', '1', '--dtype', dtype]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=tmp, env={**os.environ, 'TMPDIR': '/tmp'})
+                if r.returncode != 0:
+                    return None, f'rocprofv3 --pmc {counter} failed: {(r.stderr or r.stdout)[-200:]}'
+                vals[counter] = per_position(out, kernel_substr, counter, 6)
+            except Exception as e:  # noqa: BLE001
+                return None, f'rocprofv3 --pmc {counter}: {e}'
+    rd, wr = vals['FETCH_SIZE'], vals['WRITE_SIZE']
+    pos = max(range(len(rd)), key=lambda i: rd[i])      # the roofline layer (64 -> 32 at full resolution) has the largest read volume
+    return rd[pos] * 1024 * 2 + wr[pos] * 1024, (f'live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child passes of this run); launch {pos} of {len(rd)} '
+                                               f'of {kernel_substr} per step: fetch {rd[pos] * 2048 / 1e6:.1f} MB (FETCH_SIZE x 2), write {wr[pos] * 1024 / 1e6:.1f} MB')
 
 
 def cpu_baseline(iters=3):
@@ -273,6 +308,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='(internal) time the CPU baseline, print its JSON object, exit')
     ap.add_argument('--no-predictor', action='store_true', help='skip the Predictor MVox/s leg')
+    ap.add_argument('--no-live-traffic', action='store_true', help='roofline.traffic from the committed PMC file instead of two rocprofv3 --pmc child passes (N = 1 only)')
     ap.add_argument('--predictor-volume', choices=('full', 'sub', 'tiny'), default=None, help='full = 512x2048x2048 (default for N = 1), sub = 288x1152x1152, tiny = 96x384x384 (dry runs)')
     ap.add_argument('--backend', choices=('nccl', 'gloo'), default='nccl', help='process-group backend for N > 1.  nccl = RCCL (the measured configuration).  gloo is TEST-ONLY: it lets the whole '
                     'N > 1 branch (launcher respawn, barriers, MAX-reduced time, global-batch criterion, GradSync, tile-parallel Predictor leg, rank-0 JSON) run where RCCL cannot, '
@@ -408,6 +444,14 @@ def main():
                 traffic, tsrc = float(ent['hbm_bytes_per_launch']), PMC_FILE
         except Exception:  # noqa: BLE001
             pass
+        # (the plain default run only: the developer flags of the A/B and profiling scripts -- which may themselves run under rocprofv3 -- keep the committed file)
+        if (world == 1 and dist is None and not args.no_live_traffic and not args.no_cpu_baseline and not args.no_extra_legs and args.profile_layer == 'up_convs.2.conv1'
+                and os.environ.get('E3_BENCH_NO_LIVE_TRAFFIC') is None):
+            lt, why = live_traffic(args.dtype, 'conv_b16_pkernel' if bf16 else 'conv3_wino_pkernel')
+            if lt is not None:
+                traffic, tsrc = float(lt), why
+            else:
+                tsrc = f'{tsrc} (live PMC passes unavailable: {why})'
         kern = ('conv_b16_pkernel (persistent direct implicit GEMM, v_mfma_f32_32x32x16_bf16)' if bf16 else
                 ('conv3_wino_pkernel (persistent Winograd F(2x2x2,3x3x3), v_mfma_f32_32x32x2_f32)' if wino else 'conv3_v3_kernel (direct, fp32 MFMA)'))
         res = {
