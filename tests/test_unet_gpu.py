@@ -978,7 +978,9 @@ def test_gradsync_rccl_single_rank_path(tmp_path):
     must equal the plain single-GPU gradients bit for bit and bench.py must print its JSON line."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, E3_FORCE_GRADSYNC='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    # (E3_WGRAD_NO_DEFER: with a bucket event the executor keeps one weight-gradient launch per layer -- the early bucket wants final gradients --, without it the
+    # small layers take the cross-layer stream-K launch, whose sums have another order: bit-identity between the modes is a statement about ONE of the two forms)
+    env = dict(os.environ, E3_FORCE_GRADSYNC='1', HSA_ENABLE_IPC_MODE_LEGACY='0', E3_WGRAD_NO_DEFER='1')
     script = tmp_path / 'dp_check.py'
     script.write_text('''
 import os, sys, torch, torch.distributed as dist

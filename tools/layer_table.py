@@ -54,7 +54,7 @@ for li, (name, cin, cout, taps, level) in enumerate(model.conv_layers()):
     rows.append((name, cin, cout, taps, vout, flops, byts, ms))
 model.profile_select(-1, 0)
 
-print(f'# Round 3: per-conv-layer roofline, cfg 2 (UNet n_blocks=4 start_filts=32, batch 2 of 64x128x128, {"bf16 (native path)" if BF16 else "fp32"}), one MI355X')
+print(f'# Per-conv-layer roofline (tools/layer_table.py), cfg 2 (UNet n_blocks=4 start_filts=32, batch 2 of 64x128x128, {"bf16 (native path)" if BF16 else "fp32"}), one MI355X')
 print()
 print(f'HIP events around each layer\'s dominant kernel inside full training steps (`tools/layer_table.py`, mean of {steps} steps per cell). '
       f'HBM = algorithmic bytes / t / 8 TB/s; {PEAKNAME} = algorithmic FLOPs / t / {PEAK} TFLOP/s' + ('' if BF16 else ' (Winograd kernels execute 64/216 of the '

@@ -63,6 +63,10 @@ def main():
         rd = med('FETCH_SIZE') * 1024 * 2 / 1e6 if med('FETCH_SIZE') is not None else None
         wr = med('WRITE_SIZE') * 1024 / 1e6 if med('WRITE_SIZE') is not None else None
         lines.append(f'| `{name}` | {grid} | {len(c["dur_us"])} | {f(dur, 1)} | {f(clock)} | {f(util, 3)} | {f(wps)} | {f(wa)} | {f(wi)} | {f(rd, 1)} | {f(wr, 1)} |')
+    # columns without a single value (their counters were not in any of the passes) are dropped instead of printed empty
+    rows = [[c.strip() for c in l.strip('|').split('|')] for l in lines]
+    keep = [j for j in range(len(rows[0])) if j < 4 or any(r[j] for r in rows[2:])]
+    lines = ['| ' + ' | '.join(r[j] for j in keep) + ' |' for r in rows]
     text = '\n'.join(lines) + '\n'
     if a.out:
         hdr = ('# PMC counters (rocprofv3 --pmc, separate passes for SQ / FETCH_SIZE / WRITE_SIZE)\n\n'
