@@ -346,14 +346,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_b16_sk_kernel(const WSkArgsB a) 
         while (l + 1 < a.p.n && a.p.L[l + 1].g0 <= g) ++l;
         const WSkPartLayer& Lp = a.p.L[l];
         const WSkLayerB& Ly = a.L[l];
-        const unsigned rel = g - Lp.g0, tp = rel / (unsigned)Lp.nbricks, b0 = rel - tp * (unsigned)Lp.nbricks;
-        const unsigned left = (unsigned)Lp.nbricks - b0, want = gend - g, nb = want < left ? want : left;
+        const WSkUnit u = wsk_unit(Lp, g - Lp.g0);
+        const unsigned tp = u.tp, b0 = u.brick, want = gend - g, nb = want < u.left ? want : u.left;
         WSegB s;
         s.x = Ly.x; s.x2 = Ly.x2; s.dy = Ly.dy; s.x_split = Ly.x_split; s.x_ldc = Ly.x_ldc; s.dy_ldc = Ly.dy_ldc;
         s.N = Ly.N; s.D = Ly.D; s.H = Ly.H; s.W = Ly.W; s.tilesD = Ly.tilesD; s.tilesH = Ly.tilesH; s.tilesW = Ly.tilesW;
         s.ci0 = (int)(tp % (unsigned)Lp.ci_tiles) * 32; s.co0 = (int)(tp / (unsigned)Lp.ci_tiles) * 32;
         s.brick0 = (int)b0; s.brick1 = (int)(b0 + nb);
-        s.out = a.p.slab + (size_t)(wg + Lp.t0 + tp) * (27 * 1024); s.tap_stride = 1024; s.row_stride = 32;
+        s.out = a.p.slab + (size_t)(wg + Lp.c0 + u.block * (unsigned)Lp.tps + tp) * (27 * 1024); s.tap_stride = 1024; s.row_stride = 32;
         if constexpr (SLIDE) wgrad_b16_segment_sw(s, smem); else wgrad_b16_segment<3>(s, smem);      // (the brick loop ends with a barrier: the stage is free for the next segment)
         g += nb;
     }

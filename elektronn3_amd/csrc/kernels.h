@@ -256,12 +256,26 @@ int launch_wgrad_wino(WgradArgs a, int tD, int tH, int tW, int tps, int co_tiles
 // ... and the weight gradients of MANY layers in one stream-K launch (wgrad_wino.hip, round 6): dw = torch layout (Cout, Cin, 27), written directly
 struct WgradSkLayer { const float* x; int x_ldc; int Cin; const float* dy; int dy_ldc; int Cout; size_t dy_chunk; int N, D, H, W; float* dw; };
 size_t wgrad_wino_sk_slab_floats(int tile_pairs);      // tile_pairs = sum over the layers of ceil(Cout / 32) * ceil(Cin / 32)
-// the partition of such a launch (shared by the fp32 and the 16-bit kernels and their common reduction): unit g of layer i = brick (g - g0) % nbricks of tile pair
-// (g - g0) / nbricks; workgroup w of nwg owns the units [w q + min(w, r), ...); the partial tile of (workgroup w, tile pair t) is slab w + t
+// the partition of such a launch (shared by the fp32 and the 16-bit kernels and their common reduction).  A layer's bricks are cut into `nblocks` blocks of B bricks
+// (about one workgroup's share); its units of work are ordered (block, tile pair, brick of the block): the workgroups that run side by side work on the SAME bricks for
+// different tile pairs, so the X / dY lines a brick needs are fetched from HBM once and shared through the XCD's L2 (with the order (tile pair, brick) every tile pair
+// re-read its operands from HBM long after the others: 3.3 GB of reads for 0.8 GB of tensors, profiles/r06_pmc_f32.md of the first version).  A (block, tile pair)
+// cell has the global index c = c0 + block * tps + tile pair; workgroup w of nwg owns the units [w q + min(w, r), ...); the partial tile of (workgroup w, cell c) is
+// slab w + c -- both grow along the list, so no two segments share a slab.
 constexpr int WSK_MAX_LAYERS = 16;
-struct WSkPartLayer { float* dw; int Cin, Cout, ci_tiles, nbricks; unsigned g0, t0; };
-struct WSkPart { WSkPartLayer L[WSK_MAX_LAYERS]; int n; unsigned total, q, r, ntp, nwg; float* slab; };
-size_t wgrad_sk_slab_floats(int tile_pairs, int workgroups);
+struct WSkPartLayer { float* dw; int Cin, Cout, ci_tiles, tps, nbricks, B, nblocks; unsigned g0, t0, c0; };
+struct WSkPart { WSkPartLayer L[WSK_MAX_LAYERS]; int n; unsigned total, q, r, ntp, ncells, nwg; float* slab; };
+// unit `rel` (relative to the layer's g0) -> block, tile pair, first brick, bricks left in the cell
+struct WSkUnit { unsigned block, tp, brick, left; };
+__host__ __device__ inline WSkUnit wsk_unit(const WSkPartLayer& L, unsigned rel) {
+    const unsigned per = (unsigned)L.B * (unsigned)L.tps;
+    unsigned b = rel / per;
+    if (b >= (unsigned)L.nblocks) b = (unsigned)L.nblocks - 1;           // (the last block may be the short one: its cells are smaller)
+    const unsigned bsz = b + 1 == (unsigned)L.nblocks ? (unsigned)L.nbricks - b * (unsigned)L.B : (unsigned)L.B;
+    const unsigned r2 = rel - b * per, tp = r2 / bsz, off = r2 - tp * bsz;
+    return WSkUnit{b, tp, b * (unsigned)L.B + off, bsz - off};
+}
+size_t wgrad_sk_slab_floats(int tile_pairs, int workgroups);      // slabs of ANY partition: ids w + c < 3 workgroups + tile pairs (cells < total / q + tile pairs < 2 workgroups + tile pairs)
 int wgrad_sk_partition(WSkPart& p, int n, const int* Cin, const int* Cout, const int* nbricks, float* const* dw, int workgroups, float* slab, size_t slab_floats);
 int launch_wgrad_sk_reduce(const WSkPart& p, hipStream_t s);
 int launch_wgrad_wino_sk(const WgradSkLayer* layers, int n, float* slab, size_t slab_floats, hipStream_t s);

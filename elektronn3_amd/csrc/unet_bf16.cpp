@@ -103,9 +103,10 @@ void plan_b16(const e3_unet_plan* p, int N, int D, int H, int W, bool training, 
         }
         if (training) {
             b.bnpart = T.take_f((size_t)bn_bwd_b16_parts(ND.u[k].out.vox, u.cout) * 3 * u.cout);
-            // (which layers: as in the fp32 executor, unet_plan.cpp -- the large layers' dZ is read by the per-layer launch right behind the pass that wrote it)
+            // (which layers: ALL of them on this path -- the 16-bit level-0 dZ is 134 MB and the per-layer launches' 512 slabs per layer cost more than its trip to HBM:
+            // same box, cfg-3 step: per layer 5.273 ms, layers up to 80 MB 5.118, all 5.091; the fp32 executor stops at 80 MB, unet_plan.cpp)
             static const bool no_defer = getenv("E3_WGRAD_NO_DEFER") != nullptr;
-            static const double defer_max_mb = getenv("E3_WGRAD_DEFER_MAX_MB") ? atof(getenv("E3_WGRAD_DEFER_MAX_MB")) : 80.0;
+            static const double defer_max_mb = getenv("E3_WGRAD_DEFER_MAX_MB") ? atof(getenv("E3_WGRAD_DEFER_MAX_MB")) : 1e9;
             const bool defer = !no_defer && !u.is_up && u.cin >= 8 && !pl && (double)ND.u[k].out.vox * u.cout * 2.0 <= defer_max_mb * 1048576.0;
             if (defer) { B.dz_u[k] = T.take_h(ND.u[k].out.vox * u.cout); sk_tile_pairs += (u.cin / 32) * (u.cout / 32); slabmax = max(slabmax, own); own = 0; }      // (the per-layer fallback of such a unit takes the shared slab)
             b.slab = own ? T.take_f(own) : nullptr;

@@ -363,9 +363,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_kernel(const WgradArgs a, i
 // ---------------------------------------------------------------- cross-layer stream-K launch (round 6)
 // The Winograd weight gradients of ALL layers of a backward pass in ONE launch: the (layer, tile pair, brick) units of work of the layers form one
 // list in which a layer's tile pairs follow each other and a tile pair's bricks are consecutive; workgroup i (logical, XCD-blocked index) takes
-// the units [start(i), start(i + 1)) of an equal partition and walks the segments -- maximal runs inside one tile pair -- its range cuts out.  A segment's
-// partial tile goes to the private slab  i + t  (t = the tile pair's index over all layers: both indices grow along the list, so the slabs of a
-// tile pair are consecutive and no two segments share one); wgrad_sk_reduce_kernel adds a tile pair's slabs in that order.  Fixed partition, fixed
+// the units [start(i), start(i + 1)) of an equal partition and walks the segments -- maximal runs inside one (block, tile pair) cell, kernels.h WSkPart -- its
+// range cuts out.  A segment's partial tile goes to the private slab  i + c  (c = the cell's index over all layers: both indices grow along the list, so no two
+// segments share a slab); wgrad_sk_reduce_kernel adds a tile pair's slabs block by block, workgroups ascending.  Fixed partition, fixed
 // order: run-to-run identical.  Against one launch per layer (each cut into 256 splits to fill the chip: 28 MB of slabs per layer, 368 MB per cfg-2
 // step written and read back) this writes at most 256 + (number of tile pairs) tile slabs -- 49 MB for cfg 2 --, and the bottom levels, whose few
 // bricks per workgroup could not amortise a launch's prologue and epilogue, ride along.
@@ -391,14 +391,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_sk_kernel(const WSkArgs a) 
         while (l + 1 < a.p.n && a.p.L[l + 1].g0 <= g) ++l;
         const WSkPartLayer& Lp = a.p.L[l];
         const WSkLayer& Ly = a.L[l];
-        const unsigned rel = g - Lp.g0, tp = rel / (unsigned)Lp.nbricks, b0 = rel - tp * (unsigned)Lp.nbricks;
-        const unsigned left = (unsigned)Lp.nbricks - b0, want = gend - g, nb = want < left ? want : left;
+        const WSkUnit u = wsk_unit(Lp, g - Lp.g0);
+        const unsigned tp = u.tp, b0 = u.brick, want = gend - g, nb = want < u.left ? want : u.left;
         WSeg s;
         s.x = Ly.x; s.dy = Ly.dy; s.dy_chunk = (size_t)Ly.dy_chunk; s.x_ldc = Ly.x_ldc; s.dy_ldc = Ly.dy_ldc; s.Cin = Lp.Cin; s.Cout = Lp.Cout;
         s.N = Ly.N; s.D = Ly.D; s.H = Ly.H; s.W = Ly.W; s.tilesD = Ly.tilesD; s.tilesH = Ly.tilesH; s.tilesW = Ly.tilesW;
         s.ci0 = (int)(tp % (unsigned)Lp.ci_tiles) * 32; s.co0 = (int)(tp / (unsigned)Lp.ci_tiles) * 32;
         s.brick0 = (int)b0; s.brick1 = (int)(b0 + nb);
-        s.out = a.p.slab + (size_t)(wg + Lp.t0 + tp) * WSK_TILE; s.tap_stride = 1024; s.row_stride = 32;
+        s.out = a.p.slab + (size_t)(wg + Lp.c0 + u.block * (unsigned)Lp.tps + tp) * WSK_TILE; s.tap_stride = 1024; s.row_stride = 32;
         wgrad_wino_segment(s, smem);
         __syncthreads();              // the segment's exchange buffer overlays the stage buffers of the next one
         g += nb;
@@ -414,15 +414,18 @@ __global__ __launch_bounds__(256) void wgrad_sk_reduce_kernel(const WSkPart a) {
     const WSkPartLayer& Ly = a.L[l];
     const unsigned tp = t - Ly.t0;
     const int ci0 = (int)(tp % (unsigned)Ly.ci_tiles) * 32, co0 = (int)(tp / (unsigned)Ly.ci_tiles) * 32;
-    const unsigned g0 = Ly.g0 + tp * (unsigned)Ly.nbricks, g1 = g0 + (unsigned)Ly.nbricks;
-    const unsigned w0 = wsk_owner(a, g0), w1 = wsk_owner(a, g1 - 1);
     const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
-    const float* p = a.slab + (size_t)(w0 + t) * WSK_TILE + (size_t)tap * 1024 + row * 32 + c4;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (unsigned w = w0; w <= w1; ++w, p += WSK_TILE) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    for (unsigned b = 0; b < (unsigned)Ly.nblocks; ++b) {          // the tile pair's cells, block by block; a cell's workgroups in ascending order
+        const unsigned bsz = b + 1 == (unsigned)Ly.nblocks ? (unsigned)Ly.nbricks - b * (unsigned)Ly.B : (unsigned)Ly.B;
+        const unsigned g0 = Ly.g0 + b * (unsigned)Ly.B * (unsigned)Ly.tps + tp * bsz, g1 = g0 + bsz;
+        const unsigned w0 = wsk_owner(a, g0), w1 = wsk_owner(a, g1 - 1);
+        const float* p = a.slab + (size_t)(w0 + Ly.c0 + b * (unsigned)Ly.tps + tp) * WSK_TILE + (size_t)tap * 1024 + row * 32 + c4;
+        for (unsigned w = w0; w <= w1; ++w, p += WSK_TILE) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += (double)v[e];
+            for (int e = 0; e < 4; ++e) acc[e] += (double)v[e];
+        }
     }
     const int co = co0 + row;
     if (co < Ly.Cout) {
@@ -439,7 +442,7 @@ bool wgrad_use_wino(ConvKind kind) {
     return enabled && kind == CONV_K3;
 }
 
-size_t wgrad_sk_slab_floats(int tile_pairs, int workgroups) { return (size_t)(workgroups + tile_pairs) * WSK_TILE; }
+size_t wgrad_sk_slab_floats(int tile_pairs, int workgroups) { return (size_t)(3 * workgroups + tile_pairs) * WSK_TILE; }
 size_t wgrad_wino_sk_slab_floats(int tile_pairs) { return wgrad_sk_slab_floats(tile_pairs, 256); }
 
 // the partition of a stream-K launch: layer i has nbricks[i] bricks per tile pair
@@ -451,13 +454,23 @@ int wgrad_sk_partition(WSkPart& p, int n, const int* Cin, const int* Cout, const
     for (int i = 0; i < n; ++i) {
         WSkPartLayer& L = p.L[i];
         L.dw = dw[i]; L.Cin = Cin[i]; L.Cout = Cout[i]; L.ci_tiles = cdiv(Cin[i], 32); L.nbricks = nbricks[i];
-        const unsigned tps = (unsigned)(cdiv(Cout[i], 32) * L.ci_tiles);
-        E3_REQUIRE(L.nbricks > 0 && (size_t)g + (size_t)tps * L.nbricks < (1u << 31), E3_ERR_INVALID, "wgrad (stream-K): work list out of range");
+        L.tps = cdiv(Cout[i], 32) * L.ci_tiles;
+        E3_REQUIRE(L.nbricks > 0 && (size_t)g + (size_t)L.tps * L.nbricks < (1u << 31), E3_ERR_INVALID, "wgrad (stream-K): work list out of range");
         L.g0 = g; L.t0 = t;
-        g += tps * (unsigned)L.nbricks; t += tps;
+        g += (unsigned)L.tps * (unsigned)L.nbricks; t += (unsigned)L.tps;
     }
     p.total = g; p.ntp = t; p.q = g / p.nwg; p.r = g % p.nwg;
-    E3_REQUIRE(slab_floats >= wgrad_sk_slab_floats((int)t, workgroups), E3_ERR_WORKSPACE, "wgrad (stream-K): slab too small");
+    unsigned c = 0;
+    for (int i = 0; i < n; ++i) {      // blocks of about one workgroup's share
+        WSkPartLayer& L = p.L[i];
+        const int want = p.q > 0 ? (int)p.q : 1;
+        L.B = L.nbricks < want ? L.nbricks : want;
+        L.nblocks = cdiv(L.nbricks, L.B);
+        L.c0 = c;
+        c += (unsigned)L.nblocks * (unsigned)L.tps;
+    }
+    p.ncells = c;
+    E3_REQUIRE((size_t)(p.nwg + c) * WSK_TILE <= slab_floats, E3_ERR_WORKSPACE, "wgrad (stream-K): slab too small");
     return E3_OK;
 }
 
