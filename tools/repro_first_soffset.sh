@@ -10,7 +10,7 @@ if [ "${1:-build}" = build ]; then
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/_bin/repro_soffset tools/repro_soffset.hip 2>/dev/null
   objs=$(ls elektronn3_amd/build/*.o | grep -v "conv_small.hip.o")
   for v in 1 2; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -DE3_FIRST_SOFFSET=$v -save-temps=obj -c elektronn3_amd/csrc/conv_small.hip -o tools/_bin/conv_small_soff$v.o 2>/dev/null
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -DE3_FIRST_SOFFSET=$v -c elektronn3_amd/csrc/conv_small.hip -o tools/_bin/conv_small_soff$v.o 2>/dev/null
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/_bin/libe3unet_soff$v.so $objs tools/_bin/conv_small_soff$v.o
   done
   ls -la tools/_bin/repro_soffset tools/_bin/libe3unet_soff*.so
