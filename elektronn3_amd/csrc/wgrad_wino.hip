@@ -416,16 +416,30 @@ __global__ __launch_bounds__(256) void wgrad_sk_reduce_kernel(const WSkPart a) {
     const int ci0 = (int)(tp % (unsigned)Ly.ci_tiles) * 32, co0 = (int)(tp / (unsigned)Ly.ci_tiles) * 32;
     const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (unsigned b = 0; b < (unsigned)Ly.nblocks; ++b) {          // the tile pair's cells, block by block; a cell's workgroups in ascending order
-        const unsigned bsz = b + 1 == (unsigned)Ly.nblocks ? (unsigned)Ly.nbricks - b * (unsigned)Ly.B : (unsigned)Ly.B;
-        const unsigned g0 = Ly.g0 + b * (unsigned)Ly.B * (unsigned)Ly.tps + tp * bsz, g1 = g0 + bsz;
-        const unsigned w0 = wsk_owner(a, g0), w1 = wsk_owner(a, g1 - 1);
-        const float* p = a.slab + (size_t)(w0 + Ly.c0 + b * (unsigned)Ly.tps + tp) * WSK_TILE + (size_t)tap * 1024 + row * 32 + c4;
-        for (unsigned w = w0; w <= w1; ++w, p += WSK_TILE) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    // the tile pair's cells, block by block; a cell (at most one workgroup's share of units) was cut by at most ONE workgroup boundary: slabs w0 and, where the
+    // cell straddles it, w0 + 1.  Four blocks' loads are in flight together (the loop was a chain of ~140 dependent 16-byte loads for a level-0 tile pair:
+    // 132 us for 132 MB); absent slabs contribute an exact + 0.0, the order of the additions is the old one.
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (unsigned b = 0; b < (unsigned)Ly.nblocks; b += 4) {
+        f32x4 v[4][2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += (double)v[e];
+        for (int u = 0; u < 4; ++u) {
+            const unsigned bb = b + u;
+            const bool on = bb < (unsigned)Ly.nblocks;
+            const unsigned bc = on ? bb : 0u;
+            const unsigned bsz = bc + 1 == (unsigned)Ly.nblocks ? (unsigned)Ly.nbricks - bc * (unsigned)Ly.B : (unsigned)Ly.B;
+            const unsigned g0 = Ly.g0 + bc * (unsigned)Ly.B * (unsigned)Ly.tps + tp * bsz, g1 = g0 + bsz;
+            const unsigned w0 = wsk_owner(a, g0), w1 = wsk_owner(a, g1 - 1);
+            const float* p = a.slab + (size_t)(w0 + Ly.c0 + bc * (unsigned)Ly.tps + tp) * WSK_TILE + (size_t)tap * 1024 + row * 32 + c4;
+            v[u][0] = on ? *reinterpret_cast<const f32x4*>(p) : zero4;
+            v[u][1] = (on && w1 > w0) ? *reinterpret_cast<const f32x4*>(p + WSK_TILE) : zero4;
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += (double)v[u][h][e];
     }
     const int co = co0 + row;
     if (co < Ly.Cout) {
@@ -469,7 +483,7 @@ int wgrad_sk_partition(WSkPart& p, int n, const int* Cin, const int* Cout, const
         L.c0 = c;
         c += (unsigned)L.nblocks * (unsigned)L.tps;
     }
-    p.ncells = c;
+    p.ncells = c;      // (a cell holds at most max(q, 1) units <= a workgroup's share: it meets at most two workgroups -- what wgrad_sk_reduce_kernel relies on)
     E3_REQUIRE((size_t)(p.nwg + c) * WSK_TILE <= slab_floats, E3_ERR_WORKSPACE, "wgrad (stream-K): slab too small");
     return E3_OK;
 }
