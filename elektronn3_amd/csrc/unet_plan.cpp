@@ -359,8 +359,8 @@ void plan_buffers(const e3_unet_plan* p, int N, int D, int H, int W, bool traini
             for (size_t q = 0; q < p->units.size(); ++q) feeds_res = feeds_res || p->units[q].res_in == (int)k;
             if (feeds_res) continue;
             // Not the level-0 layers: their dZ (268 MB at cfg 2) is read by the weight gradient right behind the pass that wrote it -- partly out of the memory-side
-            // cache --, deferred it comes from HBM with the staging stalls that brings.  Same box, cfg-2 step: one launch per layer 10.975 ms, layers up to 20 MB
-            // deferred 10.934, up to 80 MB (levels 1 - 3) 10.930, ALL layers 11.128 (profiles/r06_wgrad_streamk.md).  E3_WGRAD_DEFER_MAX_MB moves the limit.
+            // cache --, deferred it comes from HBM with the staging stalls that brings.  Same box, cfg-2 step: one launch per layer 11.054 ms, layers up to 80 MB
+            // (levels 1 - 3) deferred 11.006, ALL layers 11.140 (profiles/r06_wgrad_streamk.md, second table).  E3_WGRAD_DEFER_MAX_MB moves the limit.
             static const double defer_max_mb = getenv("E3_WGRAD_DEFER_MAX_MB") ? atof(getenv("E3_WGRAD_DEFER_MAX_MB")) : 80.0;
             if ((double)ND.u[k].out.vox * u.cout * 4.0 > defer_max_mb * 1048576.0) continue;
             B.dz_u[k] = T.take(ND.u[k].out.vox * u.cout);
@@ -1514,14 +1514,14 @@ static int backward_impl(e3_unet_plan* plan, void* stream, const float* dy, cons
             if (defer_wgrad && B.dz_u[k] && kind == CONV_K3) {      // one stream-K launch for all of them behind the loop
                 wsk_layers.push_back(WgradSkLayer{xin, xin_ldc, u.cin, dyu, u.cout, u.cout, dz_chunk, N, ci.D, ci.H, ci.W, G(u.p_w)});
             } else {
-            WgradArgs a{};
-            a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dyu; a.dy_ldc = u.cout; a.dy_chunk = dz_chunk; a.Cout = u.cout; a.part = B.slab_u[k] ? B.slab_u[k] : B.slab;
-            a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
-            a.cu_reserve = reserve();      // (fewer, longer splits: the slab sized for the full chip is large enough)
-            a.splits = wgrad_splits(kind, N, ci.D, ci.H, ci.W, u.cin, u.cout, a.cu_reserve);
-            { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(kind, a, s)); }
-            if (B.slab_u[k]) RUN(wred_push({a.part, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin}));
-            else RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
+                WgradArgs a{};
+                a.x = xin; a.x_ldc = xin_ldc; a.Cin = u.cin; a.dy = dyu; a.dy_ldc = u.cout; a.dy_chunk = dz_chunk; a.Cout = u.cout; a.part = B.slab_u[k] ? B.slab_u[k] : B.slab;
+                a.N = N; a.D = ci.D; a.H = ci.H; a.W = ci.W; a.CoPad = cdiv(u.cout, 32) * 32; a.CiPad = cdiv(u.cin, 32) * 32;
+                a.cu_reserve = reserve();      // (fewer, longer splits: the slab sized for the full chip is large enough)
+                a.splits = wgrad_splits(kind, N, ci.D, ci.H, ci.W, u.cin, u.cout, a.cu_reserve);
+                { Prof pr(plan, s, k, 2); RUN(launch_wgrad_mfma(kind, a, s)); }
+                if (B.slab_u[k]) RUN(wred_push({a.part, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin}));
+                else RUN(launch_wgrad_reduce(B.slab, G(u.p_w), a.splits, taps, a.CoPad, a.CiPad, u.cout, u.cin, s));
             }
         }
         // -- data gradient -> g for the previous unit

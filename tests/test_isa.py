@@ -52,11 +52,12 @@ def test_wino4_window_reads_stay_unpaired(kernels):
 # family -> the one MFMA opcode it is built on (exact fp32: v_mfma_f32_32x32x2_f32 / 16x16x4_f32; the 16-bit path: 32x32x16, compiled for bf16 and f16)
 MFMA_OF = {
     'conv3_wino_pkernel': {'v_mfma_f32_32x32x2_f32'}, 'conv3_wino_kernel': {'v_mfma_f32_32x32x2_f32'}, 'conv3_wino4_kernel': {'v_mfma_f32_16x16x4_f32'},
-    'wgrad_wino_kernel': {'v_mfma_f32_32x32x2_f32'}, 'conv2_wino_kernel': {'v_mfma_f32_32x32x2_f32'}, 'wgrad_wino2d_kernel': {'v_mfma_f32_32x32x2_f32'},
+    'wgrad_wino_kernel': {'v_mfma_f32_32x32x2_f32'}, 'wgrad_wino_sk_kernel': {'v_mfma_f32_32x32x2_f32'}, 'conv2_wino_kernel': {'v_mfma_f32_32x32x2_f32'}, 'wgrad_wino2d_kernel': {'v_mfma_f32_32x32x2_f32'},
     'conv_first_mfma_kernel': {'v_mfma_f32_32x32x2_f32'}, 'upconv_gemm_kernel': {'v_mfma_f32_32x32x2_f32'}, 'upconv_fwd_persist_kernel': {'v_mfma_f32_32x32x2_f32'},
     'upconv_wgrad_kernel': {'v_mfma_f32_32x32x2_f32'},
     'conv_b16_pkernel': {'v_mfma_f32_32x32x16_bf16', 'v_mfma_f32_32x32x16_f16'}, 'conv_b16_kernel': {'v_mfma_f32_32x32x16_bf16', 'v_mfma_f32_32x32x16_f16'},
-    'wgrad_b16_kernel': {'v_mfma_f32_32x32x16_bf16', 'v_mfma_f32_32x32x16_f16'}, 'upconv_fwd_b16_kernel': {'v_mfma_f32_32x32x16_bf16', 'v_mfma_f32_32x32x16_f16'},
+    'wgrad_b16_kernel': {'v_mfma_f32_32x32x16_bf16', 'v_mfma_f32_32x32x16_f16'}, 'wgrad_b16_sk_kernel': {'v_mfma_f32_32x32x16_bf16', 'v_mfma_f32_32x32x16_f16'},
+    'upconv_fwd_b16_kernel': {'v_mfma_f32_32x32x16_bf16', 'v_mfma_f32_32x32x16_f16'},
 }
 
 
@@ -82,7 +83,8 @@ SPILL_FENCE = {
     ('conv3_wino4_kernel', 'ILb1ELb0ELb1ELb0EE'): 0,      # eval forward + head
     ('conv3_wino4_kernel', 'ILb0ELb0ELb0ELb1EE'): 5,      # data gradient + BatchNorm reduce
     ('conv3_wino_pkernel', None): 3,
-    ('wgrad_wino_kernel', None): 19,
+    ('wgrad_wino_kernel', None): 11,
+    ('wgrad_wino_sk_kernel', None): 18,      # (the segment loop's state; the brick loop itself is the one-layer kernel's)
 }
 
 
@@ -102,9 +104,15 @@ def test_spill_fence_of_the_512_register_kernels(kernels):
 
 
 def test_the_16bit_conv_kernels_fit_two_waves_per_simd(kernels):
-    """conv_b16_pkernel runs two 256-thread workgroups per CU: more than 256 registers would halve its occupancy."""
+    """conv_b16_pkernel and the 16-bit weight-gradient kernels run two 256-thread workgroups per CU: more than 256 registers would halve their occupancy, and the
+    sliding-window weight gradient must not spill (a first form with two copies of the k-step loop spilled 160+ VGPRs)."""
     for k in _family(kernels, 'conv_b16_pkernel'):
         assert k['meta']['vgpr_count'] <= 256 and k['meta'].get('vgpr_spill_count', 0) == 0, (k['name'], k['meta'])
+    for fam in ('wgrad_b16_kernel', 'wgrad_b16_sk_kernel'):
+        for k in _family(kernels, fam):
+            assert k['meta']['vgpr_count'] <= 256, (k['name'], k['meta'])
+            if 'Lb1E' in k['mangled']:      # the sliding-window forms
+                assert k['meta'].get('vgpr_spill_count', 0) == 0, (k['name'], k['meta'])
 
 
 def test_no_wide_store_with_scalar_offset_is_followed_by_a_write_of_its_data():
