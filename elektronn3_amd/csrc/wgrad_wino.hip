@@ -375,6 +375,7 @@ struct WSkLayer {      // what the kernel needs of a layer beside the partition 
 };
 struct WSkArgs { WSkPart p; WSkLayer L[WSK_MAX_LAYERS]; };
 constexpr int WSK_TILE = 27 * 32 * 32;
+constexpr int WSK_CELLS_MAX = 2048;            // blocks of one layer (wgrad_sk_partition checks; a block is about one workgroup's share, so ~ workgroups / tile pairs)
 __device__ __forceinline__ unsigned wsk_start(const WSkPart& a, unsigned i) { return i * a.q + (i < a.r ? i : a.r); }
 __device__ __forceinline__ unsigned wsk_owner(const WSkPart& a, unsigned g) {      // the workgroup whose range holds unit g
     const unsigned cut = a.r * (a.q + 1);
@@ -407,40 +408,59 @@ __global__ __launch_bounds__(256, 1) void wgrad_wino_sk_kernel(const WSkArgs a) 
 
 // dW (torch layout (Cout, Cin, 27)) of every layer from the tile slabs: one thread per (tile pair, tap, row, 4 columns), the slabs of the tile pair's
 // workgroups in ascending order, fp64 accumulation like wgrad_reduce_kernel.  (Shared with the 16-bit path: launch_wgrad_sk_reduce.)
-__global__ __launch_bounds__(256) void wgrad_sk_reduce_kernel(const WSkPart a) {
-    const unsigned t = blockIdx.x / 27u, tap = blockIdx.x % 27u;       // 27 blocks of 256 threads = 32 rows x 8 column quads per tile pair
+__global__ __launch_bounds__(1024) void wgrad_sk_reduce_kernel(const WSkPart a) {
+    const unsigned t = blockIdx.x / 27u, tap = blockIdx.x % 27u;       // one workgroup per (tile pair, tap): 4 groups of 256 threads = 32 rows x 8 column quads each
     int l = 0;
     while (l + 1 < a.n && a.L[l + 1].t0 <= t) ++l;
     const WSkPartLayer& Ly = a.L[l];
     const unsigned tp = t - Ly.t0;
     const int ci0 = (int)(tp % (unsigned)Ly.ci_tiles) * 32, co0 = (int)(tp / (unsigned)Ly.ci_tiles) * 32;
-    const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8;
+    const int row = tid >> 3, c4 = (tid & 7) * 4;
     // the tile pair's cells, block by block; a cell (at most one workgroup's share of units) was cut by at most ONE workgroup boundary: slabs w0 and, where the
-    // cell straddles it, w0 + 1.  Four blocks' loads are in flight together (the loop was a chain of ~140 dependent 16-byte loads for a level-0 tile pair:
-    // 132 us for 132 MB); absent slabs contribute an exact + 0.0, the order of the additions is the old one.
+    // cell straddles it, w0 + 1.  The cells' first slab and straddle flag are worked out once per workgroup and read from LDS.  Group g adds the blocks
+    // g, g + 4, g + 8, ... (two blocks' loads in flight: a level-0 tile pair of the 16-bit path has 68 blocks -- one thread walking them all was a chain of ~140
+    // dependent loads, 130 us for 130 MB), then the four partial sums meet in the order g = 0..3: fixed partition, fixed order.  Absent slabs contribute + 0.0.
+    __shared__ unsigned cell[WSK_CELLS_MAX];       // (first slab index << 1) | straddles
+    __shared__ double part[3][256][4];
+    for (unsigned b = threadIdx.x; b < (unsigned)Ly.nblocks; b += blockDim.x) {
+        const unsigned bsz = b + 1 == (unsigned)Ly.nblocks ? (unsigned)Ly.nbricks - b * (unsigned)Ly.B : (unsigned)Ly.B;
+        const unsigned g0 = Ly.g0 + b * (unsigned)Ly.B * (unsigned)Ly.tps + tp * bsz, g1 = g0 + bsz;
+        const unsigned w0 = wsk_owner(a, g0), w1 = wsk_owner(a, g1 - 1);
+        cell[b] = ((w0 + Ly.c0 + b * (unsigned)Ly.tps + tp) << 1) | (w1 > w0 ? 1u : 0u);
+    }
+    __syncthreads();
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (unsigned b = 0; b < (unsigned)Ly.nblocks; b += 4) {
-        f32x4 v[4][2];
+    const float* const base = a.slab + (size_t)tap * 1024 + row * 32 + c4;
+    for (unsigned b = (unsigned)grp; b < (unsigned)Ly.nblocks; b += 8) {
+        f32x4 v[2][2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned bb = b + u;
+        for (int u = 0; u < 2; ++u) {
+            const unsigned bb = b + 4 * u;
             const bool on = bb < (unsigned)Ly.nblocks;
-            const unsigned bc = on ? bb : 0u;
-            const unsigned bsz = bc + 1 == (unsigned)Ly.nblocks ? (unsigned)Ly.nbricks - bc * (unsigned)Ly.B : (unsigned)Ly.B;
-            const unsigned g0 = Ly.g0 + bc * (unsigned)Ly.B * (unsigned)Ly.tps + tp * bsz, g1 = g0 + bsz;
-            const unsigned w0 = wsk_owner(a, g0), w1 = wsk_owner(a, g1 - 1);
-            const float* p = a.slab + (size_t)(w0 + Ly.c0 + bc * (unsigned)Ly.tps + tp) * WSK_TILE + (size_t)tap * 1024 + row * 32 + c4;
+            const unsigned cw = cell[on ? bb : 0u];
+            const float* p = base + (size_t)(cw >> 1) * WSK_TILE;
             v[u][0] = on ? *reinterpret_cast<const f32x4*>(p) : zero4;
-            v[u][1] = (on && w1 > w0) ? *reinterpret_cast<const f32x4*>(p + WSK_TILE) : zero4;
+            v[u][1] = (on && (cw & 1u)) ? *reinterpret_cast<const f32x4*>(p + WSK_TILE) : zero4;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] += (double)v[u][h][e];
     }
+    if (grp > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[grp - 1][tid][e] = acc[e];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += part[g][tid][e];
     const int co = co0 + row;
     if (co < Ly.Cout) {
 #pragma unroll
@@ -480,6 +500,7 @@ int wgrad_sk_partition(WSkPart& p, int n, const int* Cin, const int* Cout, const
         const int want = p.q > 0 ? (int)p.q : 1;
         L.B = L.nbricks < want ? L.nbricks : want;
         L.nblocks = cdiv(L.nbricks, L.B);
+        E3_REQUIRE(L.nblocks <= WSK_CELLS_MAX, E3_ERR_UNSUPPORTED, "wgrad (stream-K): too many blocks in one layer");
         L.c0 = c;
         c += (unsigned)L.nblocks * (unsigned)L.tps;
     }
@@ -489,7 +510,7 @@ int wgrad_sk_partition(WSkPart& p, int n, const int* Cin, const int* Cout, const
 }
 
 int launch_wgrad_sk_reduce(const WSkPart& p, hipStream_t s) {
-    hipLaunchKernelGGL(wgrad_sk_reduce_kernel, dim3(p.ntp * 27u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(wgrad_sk_reduce_kernel, dim3(p.ntp * 27u), dim3(1024), 0, s, p);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
