@@ -18,7 +18,7 @@ SOURCES = ['conv_mfma.hip', 'conv_v3.hip', 'conv_wino.hip', 'conv_wino4.hip', 'c
            'attention.hip', 'bf16_conv.hip', 'bf16_wgrad.hip', 'bf16_upconv.hip', 'bf16_ew.hip', 'bf16_first.hip', 'api_bf16.cpp', 'unet_bf16.cpp']
 # the 16-bit path is compiled a second time for IEEE half (-DE3_F16, external symbols renamed by f16_names.h; see csrc/bf16.h)
 F16_SOURCES = ['bf16_conv.hip', 'bf16_wgrad.hip', 'bf16_upconv.hip', 'bf16_ew.hip', 'bf16_first.hip', 'api_bf16.cpp', 'unet_bf16.cpp']
-HEADERS = ['common.h', 'kernels.h', 'bf16.h', 'f16_names.h', 'plan_internal.h', os.path.join('..', '..', 'include', 'e3unet.h')]
+HEADERS = ['common.h', 'kernels.h', 'brick_order.h', 'bf16.h', 'f16_names.h', 'plan_internal.h', os.path.join('..', '..', 'include', 'e3unet.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-x', 'hip'] + os.environ.get('E3_HIPCC_EXTRA', '').split()
 # per-file extras.  wgrad_wino: the SLP vectoriser turns its scalar transforms into v_pk_* ops plus ~200 v_mov per brick
 # to pair the operands up; packed fp32 is not faster than two scalar ops on gfx950 (7 vs 2 x 4.5 cycles), the moves are pure loss.

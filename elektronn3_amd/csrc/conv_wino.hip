@@ -22,6 +22,7 @@
 //     tile), then bias / folded eval-BN + ReLU / per-brick Welford statistics / store as in the direct kernels.
 #include <type_traits>
 #include "kernels.h"
+#include "brick_order.h"
 
 namespace {
 
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_kernel(const ConvArgs a) {
 constexpr int W_PLDS_FLOATS = 2 * W_BUF + W_EX + 4 * 32 * 3 + 6 * 256;     // + the threads' running statistics and parked lane constants
 constexpr int W_POOLX = 4 * 64 * 16;                                         // fused max-pool: [wave (oh, ow)][lane][16 channels] (16 KB)
 
-struct WinoPArgs { int s_nt, s_tw, s_th, s_td, s_nb; int wgstats; int e_tw, e_th, e_td; int org_d, org_h, org_w; };   // digits of the logical step gridDim / 8 between a workgroup's bricks; e_*: end (first brick + count) of the brick range per axis
+struct WinoPArgs { BrickStep b; int wgstats; int org_d, org_h, org_w; };   // b: the logical brick order and the digits of the step gridDim / 8 between a workgroup's bricks (brick_order.h); org_*: voxel origin of the brick range's first brick
 
 // AFF: the folded scale / shift + ReLU epilogue (inference; no statistics) -- a compile-time split: as a run-time branch its merge cost ~50 register
 // moves per brick in both forms
@@ -420,17 +421,12 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
     for (int hh = 0; hh < 2; ++hh) rdA[hh] = lbase + 4 * (hf ^ ((tth + hh) & 1));
     const int b_voff = lane * 16;
 
-    // ---- brick cursors: mixed-radix digits (column tile, tw, th, td, sample) of the logical brick index L
+    // ---- brick cursors: mixed-radix digits (column tile, block-local w / h / d, block w / h / d, sample: brick_order.h) of the logical brick index L
     unsigned gdim = gridDim.x;
     asm volatile("" : "+s"(gdim));          // (kept in a register: a conditional use of gridDim.x becomes a branch around its load)
     struct Cur { int nt, tw, th, td, nb; unsigned bid; };      // bid: physical index blockIdx + k * gridDim (the brick exists while bid < nblk)
-    auto advance = [&](Cur& c, bool go) {        // c += step if go (no branch, no division)
-        int v = c.nt + (go ? pa.s_nt : 0); int cy = v >= ntiles ? 1 : 0; c.nt = v - (cy ? ntiles : 0);
-        // (tw, th, td are absolute brick coordinates: they run over [e - tiles, e), the needed region's bricks -- e = tiles for a whole tensor)
-        v = c.tw + (go ? pa.s_tw : 0) + cy; cy = v >= pa.e_tw ? 1 : 0; c.tw = v - (cy ? tilesW : 0);
-        v = c.th + (go ? pa.s_th : 0) + cy; cy = v >= pa.e_th ? 1 : 0; c.th = v - (cy ? tilesH : 0);
-        v = c.td + (go ? pa.s_td : 0) + cy; cy = v >= pa.e_td ? 1 : 0; c.td = v - (cy ? tilesD : 0);
-        c.nb += (go ? pa.s_nb : 0) + cy;
+    auto advance = [&](Cur& c, bool go) {        // c += step if go (no branch, no division; tw, th, td count from the brick range's first brick)
+        brick_advance(pa.b, go, ntiles, tilesW, tilesH, tilesD, c.nt, c.tw, c.th, c.td, c.nb);
         c.bid += go ? gdim : 0u;
     };
     auto range_mask = [](int lo, int n, int size) {      // bit z set: lo + z in [0, size), z in [0, n)
@@ -486,13 +482,8 @@ __global__ __launch_bounds__(256, 1) void conv3_wino_pkernel(const ConvArgs a, c
     // ---- cursors: P = brick being computed, S = brick being staged (chunk sc of it is the next one to be requested)
     Cur P;
     {
-        unsigned L = xcd_remap(blockIdx.x, nblk);
         P.bid = blockIdx.x;
-        P.nt = (int)(L % (unsigned)ntiles); L /= (unsigned)ntiles;
-        P.tw = (int)(L % (unsigned)tilesW); L /= (unsigned)tilesW;
-        P.th = (int)(L % (unsigned)tilesH); L /= (unsigned)tilesH;
-        P.td = (int)(L % (unsigned)tilesD); P.nb = (int)(L / (unsigned)tilesD);
-        P.tw += pa.e_tw - tilesW; P.th += pa.e_th - tilesH; P.td += pa.e_td - tilesD;
+        brick_decode(xcd_remap(blockIdx.x, nblk), pa.b, ntiles, tilesW, tilesH, tilesD, P.nt, P.tw, P.th, P.td, P.nb);
     }
     Cur S = P;
     int sc = 0;
@@ -1269,16 +1260,11 @@ int launch_conv3_wino(ConvArgs a, hipStream_t s) {
         const unsigned pfull = 256u - (unsigned)((a.cu_reserve < 0 ? 0 : (a.cu_reserve > 128 ? 128 : a.cu_reserve)) & ~7);
         const unsigned pgrid = nblk >= pfull ? pfull : (unsigned)nblk;
         // a workgroup's bricks are L0, L0 + pgrid / 8, ... in the logical (XCD-blocked) order: digits of that step in the mixed radix
-        // (column tile, tw, th, td, sample) for the division-free brick counters
+        // of brick_order.h for the division-free brick counters
         WinoPArgs pa{};
-        unsigned st = pgrid == pfull ? pfull / 8u : 0u;
-        pa.s_nt = (int)(st % (unsigned)a.ntiles); st /= (unsigned)a.ntiles;
-        pa.s_tw = (int)(st % (unsigned)a.tilesW); st /= (unsigned)a.tilesW;
-        pa.s_th = (int)(st % (unsigned)a.tilesH); st /= (unsigned)a.tilesH;
-        pa.s_td = (int)(st % (unsigned)a.tilesD); pa.s_nb = (int)(st / (unsigned)a.tilesD);
+        pa.b = brick_step_make(pgrid == pfull ? pfull / 8u : 0u, pgrid / 8u, a.ntiles, a.tilesW, a.tilesH, a.tilesD, 64);
         pa.wgstats = (a.stats && wino_wgstats(nblk, a.ntiles, pgrid)) ? 1 : 0;
-        pa.e_tw = a.o_tw + a.tilesW; pa.e_th = a.o_th + a.tilesH; pa.e_td = a.o_td + a.tilesD;
-        pa.org_d = a.org_d; pa.org_h = a.org_h; pa.org_w = a.org_w;
+        pa.org_d = a.org_d + 4 * a.o_td; pa.org_h = a.org_h + 4 * a.o_th; pa.org_w = a.org_w + 16 * a.o_tw;      // (o_t*: first brick of a needed region)
         // launches without statistics whose output view allows 16-byte stores: transposed accumulators (E3_WINO_NO_TR=1: A/B switch)
         static const bool no_tr = getenv("E3_WINO_NO_TR") != nullptr;
         const bool tr = !no_tr && !a.stats && (a.Ncols & 3) == 0 && (a.y_ldc & 3) == 0 && ((uintptr_t)a.y & 15) == 0;

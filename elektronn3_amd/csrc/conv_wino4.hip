@@ -23,6 +23,7 @@
 //     every tile), bias / folded BN + ReLU / running Welford statistics per lane (8 channels of one tile, one record per workgroup) / 16-byte stores.
 #include <type_traits>
 #include "kernels.h"
+#include "brick_order.h"
 
 #ifndef E3_W4_NT_MIN_MB
 #define E3_W4_NT_MIN_MB 128   // non-temporal output stores of the training forms (rows) from this tensor size on (same-box A/B: 0 and 128 alike, step 11.205 -> 11.105 ms)
@@ -57,7 +58,7 @@ typedef const volatile __attribute__((address_space(3))) f32x2v* lds_cv2;      /
 
 // POOL (AFF, inference): the 2x2x2 ceil-mode max-pool of the output in the epilogue (ConvArgs::pool_out)
 // HEAD (AFF, inference, 32 output channels): the 1x1x1 head (+ softmax) on the activations in registers instead of storing them (ConvArgs::head_*)
-struct W4PArgs { int s_nt, s_tw, s_th, s_td, s_nb; };      // digits of the step between a workgroup's bricks (gridDim / 8 logical bricks) in the mixed radix (column tile, tw, th, td, sample)
+typedef BrickStep W4PArgs;      // the logical brick order and the digits of the step between a workgroup's bricks (gridDim / 8 logical bricks): brick_order.h
 
 // BNRED (data gradients): the store phase also takes the REDUCE sums of the BatchNorm backward of the unit in front (ConvArgs::br_*)
 template <bool AFF, bool POOL = false, bool HEAD = false, bool BNRED = false>
@@ -183,27 +184,19 @@ __global__ __launch_bounds__(256, 1) void conv3_wino4_kernel(const ConvArgs a, c
         const int first = lo < 0 ? -lo : 0, last = size - lo < n ? size - lo : n;
         return last > first ? ((1u << last) - 1u) & ~((1u << first) - 1u) : 0u;
     };
-    // ---- brick cursors: mixed-radix digits (column tile, tw, th, td, sample) of a logical brick index, advanced by the workgroup's step with carries --
+    // ---- brick cursors: mixed-radix digits (column tile, block-local w / h / d, block w / h / d, sample: brick_order.h) of a logical brick index, advanced by the workgroup's step with carries --
     // no division and no kernel-argument reload between bricks (the divisions of a per-brick decode cost ~1 k cycles outside the MFMA shadow).
     // P = the brick being computed, S = the brick of the staging cursor, which runs two units (8-channel chunks) ahead: S_c = its chunk.
     struct Cur { int nt, tw, th, td, nb; unsigned L; };
     const int tilesD = a.tilesD, tilesH = a.tilesH, tilesW = a.tilesW, ntiles = a.ntiles;
     auto advance = [&](Cur& c) {
-        int v = c.nt + pa.s_nt; int cy = v >= ntiles ? 1 : 0; c.nt = v - (cy ? ntiles : 0);
-        v = c.tw + pa.s_tw + cy; cy = v >= tilesW ? 1 : 0; c.tw = v - (cy ? tilesW : 0);
-        v = c.th + pa.s_th + cy; cy = v >= tilesH ? 1 : 0; c.th = v - (cy ? tilesH : 0);
-        v = c.td + pa.s_td + cy; cy = v >= tilesD ? 1 : 0; c.td = v - (cy ? tilesD : 0);
-        c.nb += pa.s_nb + cy;
+        brick_advance(pa, true, ntiles, tilesW, tilesH, tilesD, c.nt, c.tw, c.th, c.td, c.nb);
         c.L += Lstep;
     };
     Cur P;
     {
-        unsigned Lq = L;
         P.L = L;
-        P.nt = (int)(Lq % (unsigned)ntiles); Lq /= (unsigned)ntiles;
-        P.tw = (int)(Lq % (unsigned)tilesW); Lq /= (unsigned)tilesW;
-        P.th = (int)(Lq % (unsigned)tilesH); Lq /= (unsigned)tilesH;
-        P.td = (int)(Lq % (unsigned)tilesD); P.nb = (int)(Lq / (unsigned)tilesD);
+        brick_decode(L, pa, ntiles, tilesW, tilesH, tilesD, P.nt, P.tw, P.th, P.td, P.nb);
     }
     Cur S = P;
     int S_c = 0;
@@ -910,14 +903,7 @@ int launch_conv3_wino4(ConvArgs a, hipStream_t s) {
     const unsigned grid = nblk >= full ? full : (unsigned)nblk;
     const int wgstats = (a.stats && wino4_wgstats(nblk, a.ntiles, grid)) ? 1 : 0;
     // a workgroup's bricks are L0, L0 + grid / 8, ... in the logical (XCD-blocked) order: digits of that step for the division-free brick cursors
-    W4PArgs pa{};
-    {
-        unsigned st = grid == nblk ? 1u : grid / 8u;
-        pa.s_nt = (int)(st % (unsigned)a.ntiles); st /= (unsigned)a.ntiles;
-        pa.s_tw = (int)(st % (unsigned)a.tilesW); st /= (unsigned)a.tilesW;
-        pa.s_th = (int)(st % (unsigned)a.tilesH); st /= (unsigned)a.tilesH;
-        pa.s_td = (int)(st % (unsigned)a.tilesD); pa.s_nb = (int)(st / (unsigned)a.tilesD);
-    }
+    const W4PArgs pa = brick_step_make(grid == nblk ? 1u : grid / 8u, grid / 8u, a.ntiles, a.tilesW, a.tilesH, a.tilesD, 64);
     static const bool no_head = getenv("E3_WINO_NO_HEAD") != nullptr, no_pool = getenv("E3_WINO_NO_POOL") != nullptr;      // A/B switches (shared with conv_wino.hip)
     if (a.flags & CF_BNRED) {
         E3_REQUIRE(a.br_x && a.br_scale && a.br_shift && a.br_mean && a.br_invstd && a.br_part && !a.stats && !a.epi_scale && !a.bias && a.box_hi[0] <= 0 &&
