@@ -12,20 +12,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 FP32_TESTS = ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', '-k',
               'conv3 or convT or train_step_matches_reference or eval_forward or full_size_properties or forward_with_loss']
-B16_TESTS = ['tests/test_bf16_gpu.py', 'tests/test_f16_gpu.py', '-k', 'not full_size']
+# (the two largest per-op cases -- 9 s each, most of it the fp64 reference -- run under the default switches only: no switch below selects by size above them)
+B16_TESTS = ['tests/test_bf16_gpu.py', 'tests/test_f16_gpu.py', '-k', 'not full_size and not 64-64-128-64-32 and not 30-125-100-32-64']
 GROUPS = {
     'direct_kernels': (dict(E3_CONV_NO_WINO='1', E3_WGRAD_NO_WINO='1', E3_CONV_NO_WINO2D='1', E3_WGRAD_NO_WINO2D='1'), FP32_TESTS),
     'unfused_unbatched': (dict(E3_WINO_NO_PERSIST='1', E3_NO_SPLITK='1', E3_NO_REDUCE_BATCH='1', E3_NO_FIRST_FUSE='1', E3_UPCONV_NO_GEMM='1', E3_WINO_NO_TR='1', E3_WINO_NO_POOL='1', E3_WINO_NO_HEAD='1', E3_WINO_BOX_ALIGNED='1', E3_FIRST_WGRAD_PLANAR_VALU='1', E3_FIRST_NO_MFMA='1',
                                E3_NO_LOSS_BWD='1', E3_WGRAD_NO_DEFER='1'), FP32_TESTS),
     # (E3_WGRAD_DEFER_MAX_MB: EVERY Winograd weight gradient in the one stream-K launch at the end of the backward, not only the layers up to 80 MB)
-    'persistent_everywhere': (dict(E3_WINO_PERSIST_MIN='1', E3_UPCONV_NO_PERSIST='1', E3_CONV_NO_V3='1', E3_ATT_VALU='1', E3_WGRAD_DEFER_MAX_MB='100000'), FP32_TESTS),
+    # (E3_WINO_BLOCK=kw,kh,kd: a forced block shape of the persistent kernels' logical brick order, here 2 x 8 x 1 bricks wherever the counts divide; the default
+    # rule runs in the other groups, the plain order in 'plain_rows')
+    'persistent_everywhere': (dict(E3_WINO_PERSIST_MIN='1', E3_UPCONV_NO_PERSIST='1', E3_CONV_NO_V3='1', E3_ATT_VALU='1', E3_WGRAD_DEFER_MAX_MB='100000', E3_WINO_BLOCK='1,3,0'), FP32_TESTS),
     'b16_alternatives': (dict(E3_B16_NO_SPLITK='1', E3_B16_UP_GENERIC='1', E3_B16_BD='2', E3_B16_TW='16', E3_B16_COT='1'), B16_TESTS),
     # the round-4 persistent kernels (conv_first_mfma_kernel, conv_first_b16_pkernel, conv_b16_pkernel) at EVERY size they can take: small and ragged grids,
     # workgroups without a single item, statistics records of empty workgroups
     'persistent_kernels_on_small_grids': (dict(E3_FIRST_MFMA_MIN='1', E3_B16_FIRST_PERSIST_MIN='1', E3_B16_PERSIST_MIN='1', E3_B16_BD='4', E3_B16_TW='32', E3_B16_COT='1',
                                                E3_B16_NO_SPLITK='1'),
                                           ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', 'tests/test_bf16_gpu.py', 'tests/test_f16_gpu.py', 'tests/test_predictor.py', '-k',
-                                           'conv3 or first_conv or train_step_matches_reference or eval_forward or forward_with_loss or bf16 or f16 or fixture or predictor']),
+                                           '(conv3 or first_conv or train_step_matches_reference or eval_forward or forward_with_loss or bf16 or f16 or fixture or pipelined) '
+                                           'and not 64-64-128-64-32 and not 30-125-100-32-64']),
     'b16_no_persistent_conv': (dict(E3_B16_NO_PERSIST='1', E3_B16_FIRST_NO_PERSIST='1'), ['tests/test_bf16_gpu.py', '-k', 'full_size or fixture']),
     'b16_on_fp32_kernels_plain_predictor': (dict(E3_NO_BF16='1', E3_PREDICTOR_NO_PIPELINE='1'),
                                             ['tests/test_predictor.py', 'tests/test_bf16_gpu.py', '-k', 'predictor or fixture or autocast']),
@@ -48,7 +52,7 @@ GROUPS = {
     # and the Winograd weight gradient both read the tensor), the inference forwards' conv1 -> conv2 tensors and concat buffers (E3_NO_CHUNKED_FWD=1), and the
     # encoder's skip activations stored in full although the decoder has a needed region (E3_NO_STORE_BOX=1).  The groups above and the defaults run the chunked
     # forms.  (Round 6: 'wino4_plain_rows' + 'forward_plain_rows' in one child process -- the two sets of flags touch disjoint launches.)
-    'plain_rows': (dict(E3_WINO4_MIN='1', E3_BNRED_MIN_MB='0', E3_NO_CHUNKED='1', E3_NO_CHUNKED_FWD='1', E3_NO_STORE_BOX='1'),
+    'plain_rows': (dict(E3_WINO4_MIN='1', E3_BNRED_MIN_MB='0', E3_NO_CHUNKED='1', E3_NO_CHUNKED_FWD='1', E3_NO_STORE_BOX='1', E3_WINO_BLOCK='0'),
                    ['tests/test_unet_gpu.py', 'tests/test_predictor.py', '-k',
                     'train_step_matches_reference or full_size_cfg2 or full_size_properties or forward_with_loss or digest or eval_forward or forward_roi or needed_region or head_in_the_last or pool_in_the_conv or predictor or cfg5']),
     # ... and for the TRAINING forward with its statistics as well (E3_WINO4=2; not a default: DESIGN.md section 3a) -- per-op parity and the property tests
