@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256, (CH == 16 || BD <= 2) ? 3 : 2) void conv_b16_k
 struct ConvB16PArgs {
     unsigned items, per_xcd;
     unsigned cgroups, m_cg, per, m_per, ncol, m_ncol, tw2, m_tw2;      // divisors and their multiply-high constants (0: divisor 1)
+    unsigned ca, cb;                                                   // log2 of a column's cross-section in bricks (H, W)
 };
 __device__ __forceinline__ unsigned fdiv(unsigned x, unsigned m) { return m ? __umulhi(x, m) : x; }
 
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16_pkernel(const ConvB16Args a, 
         const unsigned n = fdiv(col, p.m_ncol), c2 = col - n * p.ncol;
         const unsigned c2h = fdiv(c2, p.m_tw2), c2w = c2 - c2h * p.tw2;
         Item it;
-        it.n = (int)n; it.d0 = (int)(r >> 2) * 4; it.h0 = (int)(2 * c2h + ((r >> 1) & 1)) * 4; it.w0 = (int)(2 * c2w + (r & 1)) * 32;
+        it.n = (int)n; it.d0 = (int)(r >> (p.ca + p.cb)) * 4; it.h0 = (int)((c2h << p.ca) + ((r >> p.cb) & ((1u << p.ca) - 1u))) * 4; it.w0 = (int)((c2w << p.cb) + (r & ((1u << p.cb) - 1u))) * 32;
         return it;
     };
     unsigned voff[NIW];
@@ -705,13 +706,26 @@ int launch_t(const ConvB16Args& a, int ksplit, hipStream_t s) {
 // Work decomposition of one launch: brick depth (4x8x16 bricks -- each weight fragment feeds 4 tiles per wave, halo overhead 2.1x
 // instead of 2.8x -- where they still fill the chip), output-channel tiles per workgroup, and for the low-resolution levels (a few
 // dozen bricks for 256 CUs) a split of the input channels over several workgroups (fp32 partial sums, splitk_reduce_b16_kernel).
-struct Decomp { int bd, co_t, ksplit, tw; long bricks; int persist; };      // persist: 1 = conv_b16_pkernel
+struct Decomp { int bd, co_t, ksplit, tw; long bricks; int persist; int ca, cb; };      // persist: 1 = conv_b16_pkernel (ca, cb: log2 of its columns' cross-section in bricks)
+// cross-section of the persistent kernel's brick columns (bricks of 4 rows x 32 voxels; a column runs through D; an XCD's 64 workgroups work on 64 consecutive
+// bricks of a column): 8 x 2 bricks = 32 rows x 64 voxels, clamped to what divides the brick counts.  Measured on cfg 3's shard (tools/b16_col_sweep.sh,
+// profiles/r06_brick_order.md): against round 5's 2 x 2 columns the six launches of a step read 1 389 instead of 1 550 MB, the step is 0.3 - 0.5 % shorter;
+// columns 4 bricks wide (128 voxels) read 13 % MORE.  E3_B16_COL=a,b (log2, H and W): A/B switch, 1,1 = round 5's columns.
+static void conv_b16_column(unsigned tH, unsigned tW, int& ca, int& cb) {
+    static const char* const env = getenv("E3_B16_COL");
+    int wa = 3, wb = 1;
+    if (env) sscanf(env, "%d,%d", &wa, &wb);
+    ca = cb = 0;
+    while (ca < wa && ca < 4 && tH % (2u << ca) == 0) ++ca;
+    while (cb < wb && cb < 4 && tW % (2u << cb) == 0) ++cb;
+}
 constexpr int PGRID = 512;      // workgroups of the persistent form (two per CU)
 Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout, int planar) {
     static const int forced = getenv("E3_B16_BD") ? atoi(getenv("E3_B16_BD")) : 0;
     static const bool no_split = getenv("E3_B16_NO_SPLITK") != nullptr;
     static const int forced_tw = getenv("E3_B16_TW") ? atoi(getenv("E3_B16_TW")) : 0;
     Decomp d;
+    d.ca = d.cb = 1;
     // 1 x 32-voxel tiles (conflict-free LDS reads) where the rows are long enough to fill them, 2 x 16 otherwise
     d.tw = (forced_tw == 16 || forced_tw == 32) ? forced_tw : (W % 32 == 0 || W >= 96 ? 32 : 16);
     const int bh = d.tw == 32 ? 4 : 8;
@@ -739,9 +753,10 @@ Decomp conv_b16_decomp(int N, int D, int H, int W, int Cin, int Cout, int planar
         // count (+ one XCD share for the padded ranges); a shape beyond that bound takes the one-brick kernels -- decided HERE, so that the statistics sizing
         // (conv_b16_stats_parts) and the launcher ask one predicate
         const unsigned tD = (unsigned)cdiv(D, 4), tH = (unsigned)cdiv(H, 4), tW = (unsigned)cdiv(W, 32);
+        conv_b16_column(tH, tW, d.ca, d.cb);
         const unsigned long long items = (unsigned long long)N * tD * tH * tW * cgroups;
         unsigned long long per_xcd = (items + 7) / 8; per_xcd = (per_xcd + cgroups - 1) / cgroups * cgroups;
-        for (unsigned dv : {(unsigned)cgroups, tD * 4, (tH >> 1) * (tW >> 1), tW >> 1}) {
+        for (unsigned dv : {(unsigned)cgroups, tD << (d.ca + d.cb), (tH >> d.ca) * (tW >> d.cb), tW >> d.cb}) {
             if (dv <= 1) continue;
             const unsigned long long m = ((1ull << 32) + dv - 1) / dv, e = m * dv - (1ull << 32), xmax = items + per_xcd + 256;
             if (e * xmax >= (1ull << 32)) d.persist = 0;
@@ -819,9 +834,10 @@ int launch_conv_b16(ConvB16Args a, hipStream_t s) {
         ConvB16PArgs pa{};
         auto magic = [](unsigned dv) { return dv == 1 ? 0u : (unsigned)(((1ull << 32) + dv - 1) / dv); };
         pa.cgroups = (unsigned)(a.Cout / 32); pa.m_cg = magic(pa.cgroups);
-        pa.per = (unsigned)tD * 4; pa.m_per = magic(pa.per);
-        pa.ncol = (unsigned)(tH >> 1) * (unsigned)(tW >> 1); pa.m_ncol = magic(pa.ncol);
-        pa.tw2 = (unsigned)(tW >> 1); pa.m_tw2 = magic(pa.tw2);
+        pa.ca = (unsigned)d.ca; pa.cb = (unsigned)d.cb;
+        pa.per = (unsigned)tD << (d.ca + d.cb); pa.m_per = magic(pa.per);
+        pa.ncol = (unsigned)(tH >> d.ca) * (unsigned)(tW >> d.cb); pa.m_ncol = magic(pa.ncol);
+        pa.tw2 = (unsigned)(tW >> d.cb); pa.m_tw2 = magic(pa.tw2);
         pa.items = (unsigned)((size_t)a.N * tD * tH * tW * pa.cgroups);
         pa.per_xcd = (pa.items + 7) / 8; pa.per_xcd = (pa.per_xcd + pa.cgroups - 1) / pa.cgroups * pa.cgroups;
         using GP = Geo<4, 3, 32, 16>;

@@ -24,8 +24,8 @@ GROUPS = {
     'persistent_everywhere': (dict(E3_WINO_PERSIST_MIN='1', E3_UPCONV_NO_PERSIST='1', E3_CONV_NO_V3='1', E3_ATT_VALU='1', E3_WGRAD_DEFER_MAX_MB='100000', E3_WINO_BLOCK='1,3,0'), FP32_TESTS),
     'b16_alternatives': (dict(E3_B16_NO_SPLITK='1', E3_B16_UP_GENERIC='1', E3_B16_BD='2', E3_B16_TW='16', E3_B16_COT='1'), B16_TESTS),
     # the round-4 persistent kernels (conv_first_mfma_kernel, conv_first_b16_pkernel, conv_b16_pkernel) at EVERY size they can take: small and ragged grids,
-    # workgroups without a single item, statistics records of empty workgroups
-    'persistent_kernels_on_small_grids': (dict(E3_FIRST_MFMA_MIN='1', E3_B16_FIRST_PERSIST_MIN='1', E3_B16_PERSIST_MIN='1', E3_B16_BD='4', E3_B16_TW='32', E3_B16_COT='1',
+    # workgroups without a single item, statistics records of empty workgroups (E3_B16_COL: brick columns of 2 x 4 bricks instead of the default 8 x 2)
+    'persistent_kernels_on_small_grids': (dict(E3_FIRST_MFMA_MIN='1', E3_B16_FIRST_PERSIST_MIN='1', E3_B16_PERSIST_MIN='1', E3_B16_BD='4', E3_B16_TW='32', E3_B16_COT='1', E3_B16_COL='1,2',
                                                E3_B16_NO_SPLITK='1'),
                                           ['tests/test_ops_gpu.py', 'tests/test_unet_gpu.py', 'tests/test_bf16_gpu.py', 'tests/test_f16_gpu.py', 'tests/test_predictor.py', '-k',
                                            '(conv3 or first_conv or train_step_matches_reference or eval_forward or forward_with_loss or bf16 or f16 or fixture or pipelined) '
