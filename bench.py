@@ -149,6 +149,71 @@ def needed_region_flops(tile_in, overlap, n_blocks=4, sf=32, bricks=((4, 4, 16),
     return whole, skipped, executed
 
 
+class GpuSensors:
+    """Shader clock, socket power and temperature of THIS process' GPU, and how many of the node's other GPUs are busy, sampled from sysfs (amdgpu hwmon)
+    every 50 ms on a thread while a leg runs.  Reporting only: the boxes of the pool are shared nodes, and single runs of the same build differ by a few
+    percent (the Predictor leg by up to 11 %) with what the neighbours do -- the line says under which conditions its numbers were taken."""
+
+    def __init__(self, dev):
+        self.me, self.others = None, []
+        try:
+            bus = torch.cuda.get_device_properties(dev).pci_bus_id
+            want = f'{int(bus):02x}:' if isinstance(bus, int) else None
+            import glob
+            for d in sorted(glob.glob('/sys/class/drm/card*/device')):
+                hw = glob.glob(os.path.join(d, 'hwmon', 'hwmon*'))
+                if not hw or not os.path.exists(os.path.join(hw[0], 'freq1_input')):
+                    continue
+                addr = os.path.basename(os.path.realpath(d))              # 0000:bb:dd.f
+                if want is not None and addr.split(':', 1)[1].startswith(want) and self.me is None:
+                    self.me = hw[0]
+                else:
+                    self.others.append(hw[0])
+        except Exception:  # noqa: BLE001
+            self.me = None
+        self.rows, self._stop, self._thr = [], None, None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except Exception:  # noqa: BLE001
+            return None
+
+    def _loop(self):
+        while not self._stop.is_set():
+            busy = sum(1 for o in self.others if (self._read(os.path.join(o, 'freq1_input')) or 0) > 1.0e9)
+            self.rows.append((self._read(os.path.join(self.me, 'freq1_input')), self._read(os.path.join(self.me, 'power1_input')),
+                              self._read(os.path.join(self.me, 'temp2_input')), busy))
+            self._stop.wait(0.05)
+
+    def __enter__(self):
+        if self.me is not None:
+            self.rows, self._stop = [], threading.Event()
+            self._thr = threading.Thread(target=self._loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thr is not None:
+            self._stop.set()
+            self._thr.join()
+            self._thr = None
+        return False
+
+    def summary(self):
+        if not self.rows:
+            return None
+        def col(i, scale):
+            v = [r[i] * scale for r in self.rows if r[i] is not None]
+            return [round(min(v), 1), round(sum(v) / len(v), 1), round(max(v), 1)] if v else None
+        return {'samples': len(self.rows), 'sclk_mhz_min_mean_max': col(0, 1e-6), 'socket_power_w_min_mean_max': col(1, 1e-6), 'temp_c_min_mean_max': col(2, 1e-3),
+                'power_cap_w': (lambda v: round(v * 1e-6, 1) if v else None)(self._read(os.path.join(self.me, 'power1_cap'))),
+                'other_gpus_of_the_node_busy_mean': round(sum(r[3] for r in self.rows) / len(self.rows), 2), 'other_gpus_seen': len(self.others),
+                'source': 'amdgpu hwmon in sysfs, 50 ms samples'}
+
+
 def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_parallel=False, bf16=False, whole_tiles=False):
     """BASELINE.json's second metric ("Predictor MVox/s", configs[4]): tile 96x192x192, overlap 16, eval-mode UNet(n_blocks=4,
     start_filts=32), softmax output, fp32 volume in HOST memory, result back in host memory.  Input voxels / predict() wall time
@@ -177,9 +242,10 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
                      strict_shapes=False, tile_parallel=tile_parallel)
     pred.prepare(vol)            # (the page-locked staging slots of the host <-> device pipeline: once per process, not part of a predict() call)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = pred.predict(vol)
-    dt = time.perf_counter() - t0
+    with GpuSensors(dev) as sensors:
+        t0 = time.perf_counter()
+        out = pred.predict(vol)
+        dt = time.perf_counter() - t0
     ntiles = 1
     for n, t in zip(shape, tile):
         ntiles *= -(-n // t)
@@ -194,6 +260,7 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
             'seconds': dt, 'volume': list(shape), 'tile': list(tile), 'overlap': list(overlap), 'tiles': ntiles, 'dtype': (bf16 if isinstance(bf16, str) else 'bf16') if bf16 else 'f32',
             'out_dtype': str(out.dtype).replace('torch.', ''),
             'timing': {k: (round(v, 6 if k.startswith('tile_call') else 4) if isinstance(v, float) else v) for k, v in (getattr(pred, 'last_timing', None) or {}).items()},
+            'sensors': sensors.summary(),
             'finite': bool(torch.isfinite(out[..., ::32, ::32].float()).all()),
             'needed_region': roi_on, 'flop_skipped_frac': (skipped / tile_flop) if roi_on else 0.0,
             'algorithmic_tflops': ntiles * tile_flop / dt / 1e12,
@@ -412,7 +479,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    dt, k_ms, k_n = timed(args.steps, 0)
+    with GpuSensors(dev) as step_sensors:
+        dt, k_ms, k_n = timed(args.steps, 0)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -465,7 +533,7 @@ def main():
             'dp_mode': (sync.mode if sync is not None else None), 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.dtype, 'data': 'synthetic',
+            'dtype': args.dtype, 'data': 'synthetic', 'sensors': step_sensors.summary(),
             'config': {'workload': (f'BASELINE.json configs[{2 if bf16 else 1}]: UNet(in=1,out=2,n_blocks=4,start_filts=32,bn) '
                                     f'{("float16 (model.half(), float16 crops, native f16 kernels)" if args.dtype == "f16" else "bf16 (model.to(bfloat16), bf16 crops, native bf16 kernels)") if bf16 else "fp32"} train fwd+bwd, '
                                     f'batch {BATCH_PER_GPU}/GPU of 1x64x128x128 random crops, CE+Dice loss, optimizer excluded'),

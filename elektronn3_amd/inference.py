@@ -656,7 +656,10 @@ class Predictor:
                 stage.copy_(src)
                 dst.copy_(stage)
 
+        busy = {'up': 0.0, 'down': 0.0}                                   # wall time the two copy workers spent in their jobs (last_timing)
+
         def upload(k):
+            t_job = time.perf_counter()
             a = need_lo[k] if uploaded[0] is None else max(uploaded[0], need_lo[k])
             b = need_hi[k]
             with torch.cuda.stream(up_stream):
@@ -665,6 +668,7 @@ class Predictor:
                     put(dst, inp[:, :, a:b])
                 uploaded[0] = b if uploaded[0] is None else max(uploaded[0], b)
                 up_events[k].record(up_stream)
+            busy['up'] += time.perf_counter() - t_job
 
         # the FIRST z slab goes up in y pieces, one per row of tiles, so that the first row starts after 1 / nty of the slab has arrived (the
         # cfg-5 volume: 0.24 GB instead of 2.1 GB of pageable host memory in front of the first tile); later slabs travel while tiles compute
@@ -672,6 +676,7 @@ class Predictor:
         piece_events = [torch.cuda.Event() for _ in range(nty)]
 
         def upload_piece(j):
+            t_job = time.perf_counter()
             a, b = need_lo[k_first], need_hi[k_first]
             y0 = 0 if j == 0 else int(min(real[1], tile[1] * j + ov[1]))
             y1 = int(real[1]) if j == nty - 1 else int(min(real[1], tile[1] * (j + 1) + ov[1]))
@@ -683,6 +688,7 @@ class Predictor:
                 if j == nty - 1:
                     uploaded[0] = b
                     up_events[k_first].record(up_stream)
+            busy['up'] += time.perf_counter() - t_job
 
         state = {'host_out': None, 'out_dev': None, 'shm': None}
         downs = []
@@ -714,6 +720,7 @@ class Predictor:
             state['out_dev'] = torch.zeros((N, *meta[0], *(int(v) for v in padded)), dtype=meta[1], device=dev)
 
         def download(k, j0, j1, ev):
+            t_job = time.perf_counter()
             with torch.cuda.stream(down_stream):
                 down_stream.wait_event(ev)
                 z0, z1 = int(tile[0] * k), int(min(tile[0] * (k + 1), real[0]))
@@ -723,7 +730,9 @@ class Predictor:
                         rings[1].d2h(state['host_out'][:, :, z0:z1, y0:y1], state['out_dev'][:, :, z0:z1, y0:y1, :int(real[2])], down_stream)
                     else:
                         state['host_out'][:, :, z0:z1, y0:y1].copy_(state['out_dev'][:, :, z0:z1, y0:y1, :int(real[2])])
+            busy['down'] += time.perf_counter() - t_job
 
+        row_events = []                                                   # (first, last) event of every row of tiles on the compute stream, behind its waits
         with ThreadPoolExecutor(max_workers=1) as up_pool, ThreadPoolExecutor(max_workers=1) as down_pool:
             pieces = [up_pool.submit(upload_piece, j) for j in range(nty)] if zrows else []
             ups = {k: up_pool.submit(upload, k) for k in zrows[1:]}
@@ -740,6 +749,8 @@ class Predictor:
                     j_first = j
                     if i == 0:
                         ev_first.record(main)
+                row_events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                row_events[-1][0].record(main)
                 for ti in range((k * nty + j) * ntx, (k * nty + j + 1) * ntx):
                     ilo, ihi, olo, ohi = plan[ti]
                     if in_place:          # the tile is read where it lies and its kept region written where it belongs (UNet.forward_tile)
@@ -762,6 +773,7 @@ class Predictor:
                     if state['out_dev'] is None:
                         make_outputs(out_tile)
                     state['out_dev'][_extend_nc([slice(l, h) for l, h in zip(olo, ohi)])] = out_tile
+                row_events[-1][1].record(main)
                 last_of_zrow = i + 1 == len(mine) or mine[i + 1][0] != k
                 # one rank: whole z rows go back (contiguous in host memory) -- except the LAST z row, which goes back tile row by tile row:
                 # what is still to be downloaded when the last tile finishes is then one row (0.3 GB) instead of a z row (3.2 GB of the
@@ -784,7 +796,10 @@ class Predictor:
         # issue_cpu_s is that thread's CPU time, which still contains the runtime's spinning on a full queue; tile_call_s is what ONE tile costs the host when
         # nothing blocks it: the lower quartile of the tile calls' wall times -- the first dozens of tiles are issued into an empty queue)
         self.last_timing = {'wall_s': time.perf_counter() - t_start, 'issue_s': t_issued - t_start, 'issue_cpu_s': cpu_issued - cpu_start,
-                            'compute_stream_s': (ev_first.elapsed_time(ev_last) / 1e3) if mine else 0.0, 'tiles': len(mine) * ntx}
+                            'compute_stream_s': (ev_first.elapsed_time(ev_last) / 1e3) if mine else 0.0, 'tiles': len(mine) * ntx,
+                            # rows_s: the compute stream's time inside the rows of tiles, i.e. compute_stream_s without its waits for uploads;
+                            # upload_worker_s / download_worker_s: wall time the two copy workers spent in their jobs (host copies + issuing the DMA)
+                            'rows_s': sum(a.elapsed_time(b) for a, b in row_events) / 1e3, 'upload_worker_s': busy['up'], 'download_worker_s': busy['down']}
         if call_s:
             srt = sorted(call_s)
             self.last_timing.update(tile_call_s=srt[len(srt) // 4], tile_call_min_s=srt[0], tile_call_median_s=srt[len(srt) // 2])
