@@ -35,6 +35,27 @@ Transform = Callable[[np.ndarray, Optional[np.ndarray]], Tuple[np.ndarray, Optio
 
 
 _COPY_POOL = None
+_LIBC = None
+
+
+def _advise_hugepages(t):
+    """madvise(MADV_HUGEPAGE) on a freshly allocated (not yet touched) host tensor: the result volume of the pipelined predict() is faulted in by the download worker
+    while it copies (17 GB of the cfg-5 result = 4 M page faults of 4 KB); with transparent huge pages in `madvise` mode (the usual default) this makes them 2 MB
+    faults.  Best effort: no effect where the kernel does not offer it.  E3_PREDICTOR_NO_HUGEPAGES=1: A/B switch."""
+    global _LIBC
+    if os.environ.get('E3_PREDICTOR_NO_HUGEPAGES') is not None or t.numel() * t.element_size() < (64 << 20):
+        return
+    try:
+        import ctypes
+        if _LIBC is None:
+            _LIBC = ctypes.CDLL(None, use_errno=True)
+            _LIBC.madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        lo = (t.data_ptr() + (2 << 20) - 1) & ~((2 << 20) - 1)
+        hi = (t.data_ptr() + t.numel() * t.element_size()) & ~((2 << 20) - 1)
+        if hi > lo:
+            _LIBC.madvise(lo, hi - lo, 14)          # MADV_HUGEPAGE
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def _host_copy(dst, src):
@@ -624,7 +645,9 @@ class Predictor:
         ntz, nty, ntx = (int(v) for v in padded // tile)
         if self.out_dtype is None:
             self.out_dtype = torch.uint8 if self.argmax_with_threshold is not None else self.dtype      # (inp is cast to the compute dtype first, inference.py:606-614)
+        t_alloc = time.perf_counter()
         inp_padded = torch.zeros((N, Cin, *(int(v) for v in padded + 2 * ov)), dtype=self.dtype, device=dev)
+        alloc_s = {'input': time.perf_counter() - t_alloc, 'output': 0.0}       # host time of the two big device allocations (last_timing)
         crop = _extend_nc([slice(int(l), int(h)) for l, h in zip(ov, tile + ov)])
         plan = tile_plan(padded, tile, ov)
         main = torch.cuda.current_stream(dev)
@@ -691,6 +714,7 @@ class Predictor:
             busy['up'] += time.perf_counter() - t_job
 
         state = {'host_out': None, 'out_dev': None, 'shm': None}
+        fill_events = []                                                  # around the zero fill of the output buffer on the compute stream (last_timing)
         downs = []
         call_s = []                                                       # wall time of every in-place tile call on the issuing thread
         # no tile copy / crop copy around the native fp32 model (E3_PREDICTOR_NO_INPLACE=1: A/B switch)
@@ -717,7 +741,13 @@ class Predictor:
                 state['host_out'] = state['shm'].tensor
             else:
                 state['host_out'] = torch.empty((N, *meta[0], *(int(v) for v in real)), dtype=meta[1])
+                _advise_hugepages(state['host_out'])
+            t_out = time.perf_counter()
+            fill_events.extend([torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)])
+            fill_events[0].record(main)
             state['out_dev'] = torch.zeros((N, *meta[0], *(int(v) for v in padded)), dtype=meta[1], device=dev)
+            fill_events[1].record(main)
+            alloc_s['output'] = time.perf_counter() - t_out
 
         def download(k, j0, j1, ev):
             t_job = time.perf_counter()
@@ -736,7 +766,11 @@ class Predictor:
         with ThreadPoolExecutor(max_workers=1) as up_pool, ThreadPoolExecutor(max_workers=1) as down_pool:
             pieces = [up_pool.submit(upload_piece, j) for j in range(nty)] if zrows else []
             ups = {k: up_pool.submit(upload, k) for k in zrows[1:]}
-            if not mine:
+            if in_place:
+                # the output buffers NOW, while the first piece of the input travels: a cold hipMalloc of the cfg-5 result (21 GB) takes up to 0.5 s on the
+                # calling thread (profiles/r06_predictor_modes.md); layout and dtype of the in-place path's result are known without a first tile
+                make_outputs(None, ((int(self.model.out_channels),), torch.float32))
+            elif not mine:
                 make_outputs(None)
             for i, (k, j) in enumerate(mine):
                 if k == k_first:
@@ -799,7 +833,12 @@ class Predictor:
                             'compute_stream_s': (ev_first.elapsed_time(ev_last) / 1e3) if mine else 0.0, 'tiles': len(mine) * ntx,
                             # rows_s: the compute stream's time inside the rows of tiles, i.e. compute_stream_s without its waits for uploads;
                             # upload_worker_s / download_worker_s: wall time the two copy workers spent in their jobs (host copies + issuing the DMA)
-                            'rows_s': sum(a.elapsed_time(b) for a, b in row_events) / 1e3, 'upload_worker_s': busy['up'], 'download_worker_s': busy['down']}
+                            'rows_s': sum(a.elapsed_time(b) for a, b in row_events) / 1e3, 'upload_worker_s': busy['up'], 'download_worker_s': busy['down'],
+                            'alloc_input_s': alloc_s['input'], 'alloc_output_s': alloc_s['output'],
+                            'fill_output_s': (fill_events[0].elapsed_time(fill_events[1]) / 1e3) if fill_events else 0.0}
+        if row_events:      # (per row of tiles, in ms: a uniformly slower GPU shifts all three, interference shows in the maximum only)
+            per_row = sorted(a.elapsed_time(b) for a, b in row_events)
+            self.last_timing['row_ms_min_median_max'] = [round(per_row[0], 2), round(per_row[len(per_row) // 2], 2), round(per_row[-1], 2)]
         if call_s:
             srt = sorted(call_s)
             self.last_timing.update(tile_call_s=srt[len(srt) // 4], tile_call_min_s=srt[0], tile_call_median_s=srt[len(srt) // 2])
