@@ -766,10 +766,13 @@ class Predictor:
         with ThreadPoolExecutor(max_workers=1) as up_pool, ThreadPoolExecutor(max_workers=1) as down_pool:
             pieces = [up_pool.submit(upload_piece, j) for j in range(nty)] if zrows else []
             ups = {k: up_pool.submit(upload, k) for k in zrows[1:]}
-            if in_place:
-                # the output buffers NOW, while the first piece of the input travels: a cold hipMalloc of the cfg-5 result (21 GB) takes up to 0.5 s on the
-                # calling thread (profiles/r06_predictor_modes.md); layout and dtype of the in-place path's result are known without a first tile
-                make_outputs(None, ((int(self.model.out_channels),), torch.float32))
+            # the output buffers NOW, while the first piece of the input travels -- allocated inside the first row of tiles (behind the stream's wait for the upload,
+            # beside the upload worker's copies) they stalled the compute stream by 0.49 s in every third process (profiles/r06_predictor_modes.md).  Layout and
+            # dtype of a native module's result are known without a first tile: (out_channels,) and out_dtype, unless an argmax / threshold stage follows
+            early_meta = None
+            if self._native and self._post is None and not self.apply_argmax_after_tta and hasattr(self.model, 'out_channels') and (in_place or world == 1):
+                early_meta = ((int(self.model.out_channels),), torch.float32 if in_place else self.out_dtype)
+                make_outputs(None, early_meta)
             elif not mine:
                 make_outputs(None)
             for i, (k, j) in enumerate(mine):
@@ -804,8 +807,9 @@ class Predictor:
                             in_place = False
                     inp_tile = inp_padded[_extend_nc([slice(l, h) for l, h in zip(ilo, ihi)])].contiguous()
                     out_tile = self._predict(inp_tile, crop, None if _NO_CLIP else [max(1, min(int(t), int(r) - int(lo_))) for t, r, lo_ in zip(tile, real, olo)])
-                    if state['out_dev'] is None:
-                        make_outputs(out_tile)
+                    if state['out_dev'] is None or (early_meta is not None and (tuple(int(v) for v in out_tile.shape[1:-3]), out_tile.dtype) != early_meta):
+                        early_meta = None
+                        make_outputs(out_tile)                            # (the first tile tells; an early guess that did not hold is replaced)
                     state['out_dev'][_extend_nc([slice(l, h) for l, h in zip(olo, ohi)])] = out_tile
                 row_events[-1][1].record(main)
                 last_of_zrow = i + 1 == len(mine) or mine[i + 1][0] != k
