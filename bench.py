@@ -242,10 +242,14 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
                      strict_shapes=False, tile_parallel=tile_parallel)
     pred.prepare(vol)            # (the page-locked staging slots of the host <-> device pipeline: once per process, not part of a predict() call)
     torch.cuda.synchronize()
+    ms0 = torch.cuda.memory_stats(dev)
     with GpuSensors(dev) as sensors:
         t0 = time.perf_counter()
         out = pred.predict(vol)
         dt = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats(dev)
+    # device allocations / frees of torch's caching allocator inside predict() (a hipFree synchronises the device: a retry after a failed allocation would show as a stalled row)
+    alloc_delta = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries', 'num_ooms')}
     ntiles = 1
     for n, t in zip(shape, tile):
         ntiles *= -(-n // t)
@@ -260,7 +264,7 @@ def predictor_leg(dev, shape, tile=(96, 192, 192), overlap=(16, 16, 16), tile_pa
             'seconds': dt, 'volume': list(shape), 'tile': list(tile), 'overlap': list(overlap), 'tiles': ntiles, 'dtype': (bf16 if isinstance(bf16, str) else 'bf16') if bf16 else 'f32',
             'out_dtype': str(out.dtype).replace('torch.', ''),
             'timing': {k: (round(v, 6 if k.startswith('tile_call') else 4) if isinstance(v, float) else v) for k, v in (getattr(pred, 'last_timing', None) or {}).items()},
-            'sensors': sensors.summary(),
+            'sensors': sensors.summary(), 'allocator': alloc_delta,
             'finite': bool(torch.isfinite(out[..., ::32, ::32].float()).all()),
             'needed_region': roi_on, 'flop_skipped_frac': (skipped / tile_flop) if roi_on else 0.0,
             'algorithmic_tflops': ntiles * tile_flop / dt / 1e12,

@@ -81,8 +81,12 @@ class _PinnedRing:
     DMA instead of the runtime's pageable path (which stages through its own bounce buffer and moves the data with copy KERNELS on the compute
     units, beside the model's kernels).  One ring per Predictor and direction; used by one thread at a time."""
 
-    def __init__(self, slot_bytes=256 << 20):
+    def __init__(self, slot_bytes=256 << 20, device=None):
         self.slots = [torch.empty(slot_bytes, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        # device-side twins of the slots: the gather / scatter between a strided view of the volume and a contiguous slab goes through THESE instead of
+        # the temporaries torch.Tensor.copy_ allocates for a non-contiguous side -- a first-time device allocation in the middle of predict() stalls the
+        # running rows of tiles by 50 - 150 ms (profiles/r06_predictor_modes.md), these are allocated with the ring
+        self.dev_slots = [torch.empty(slot_bytes, dtype=torch.uint8, device=device) for _ in range(2)] if device is not None else None
         self.events = [None, None]
         self.pending = [None, None]          # d2h: (host view, slot view) still to be copied out
         self.i = 0
@@ -98,7 +102,8 @@ class _PinnedRing:
             _host_copy(host, view)
             self.pending[k] = None
         n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
-        return k, self.slots[k][:n].view(dtype).view(*shape)
+        dev_view = self.dev_slots[k][:n].view(dtype).view(*shape) if self.dev_slots is not None else None
+        return k, self.slots[k][:n].view(dtype).view(*shape), dev_view
 
     def _planes(self, t):
         per_plane = max(1, t[:, :, :1].numel() * t.element_size())
@@ -113,10 +118,13 @@ class _PinnedRing:
         step = self._planes(src)
         for z in range(0, src.shape[2], step):
             part = src[:, :, z:z + step]
-            k, view = self._slot(part.shape, part.dtype)
+            k, view, dev_view = self._slot(part.shape, part.dtype)
             _host_copy(view, part)
             d = dst[:, :, z:z + step]
-            if part.dtype == d.dtype or not convert_on_device:
+            if dev_view is not None:              # contiguous DMA into the slot's device twin, then the scatter (and a dtype conversion) as one device copy
+                dev_view.copy_(view, non_blocking=True)
+                d.copy_(dev_view)
+            elif part.dtype == d.dtype or not convert_on_device:
                 d.copy_(view, non_blocking=True)
             else:                                 # (another dtype than the model's: converted on the device, not by the host thread)
                 stage = torch.empty(part.shape, dtype=part.dtype, device=d.device)
@@ -130,8 +138,12 @@ class _PinnedRing:
         step = self._planes(src)
         for z in range(0, src.shape[2], step):
             part = src[:, :, z:z + step]
-            k, view = self._slot(part.shape, part.dtype)
-            view.copy_(part, non_blocking=True)
+            k, view, dev_view = self._slot(part.shape, part.dtype)
+            if dev_view is not None:              # gather into the slot's device twin, contiguous DMA from there
+                dev_view.copy_(part)
+                view.copy_(dev_view, non_blocking=True)
+            else:
+                view.copy_(part, non_blocking=True)
             self.events[k] = torch.cuda.Event()
             self.events[k].record(stream)
             self.pending[k] = (dst[:, :, z:z + step], view)
@@ -179,7 +191,7 @@ def _rings_for(device, slot_bytes=_RING_SLOT_BYTES):
         if have is not None and have[0].slots[0].numel() >= slot_bytes:
             return have
         try:
-            _RINGS[key] = (_PinnedRing(slot_bytes), _PinnedRing(slot_bytes))
+            _RINGS[key] = (_PinnedRing(slot_bytes, torch.device(device)), _PinnedRing(slot_bytes, torch.device(device)))
         except RuntimeError as e:               # hipHostMalloc failed
             logger.warning(f'Predictor: no page-locked staging buffers ({e}); using pageable host copies')
             _RINGS[key] = False
@@ -763,12 +775,15 @@ class Predictor:
             busy['down'] += time.perf_counter() - t_job
 
         row_events = []                                                   # (first, last) event of every row of tiles on the compute stream, behind its waits
+        lead = {}                                                         # host time in front of the first tile (last_timing)
+        t_pool = time.perf_counter()
         with ThreadPoolExecutor(max_workers=1) as up_pool, ThreadPoolExecutor(max_workers=1) as down_pool:
             pieces = [up_pool.submit(upload_piece, j) for j in range(nty)] if zrows else []
             ups = {k: up_pool.submit(upload, k) for k in zrows[1:]}
             # the output buffers NOW, while the first piece of the input travels -- allocated inside the first row of tiles (behind the stream's wait for the upload,
             # beside the upload worker's copies) they stalled the compute stream by 0.49 s in every third process (profiles/r06_predictor_modes.md).  Layout and
             # dtype of a native module's result are known without a first tile: (out_channels,) and out_dtype, unless an argmax / threshold stage follows
+            lead['to_uploads_submitted_s'] = time.perf_counter() - t_start
             early_meta = None
             if self._native and self._post is None and not self.apply_argmax_after_tta and hasattr(self.model, 'out_channels') and (in_place or world == 1):
                 early_meta = ((int(self.model.out_channels),), torch.float32 if in_place else self.out_dtype)
@@ -777,8 +792,12 @@ class Predictor:
                 make_outputs(None)
             for i, (k, j) in enumerate(mine):
                 if k == k_first:
+                    t_wait = time.perf_counter()
                     pieces[j].result()                # (the copy has been issued; the stream-side wait is the event)
                     main.wait_event(piece_events[j])
+                    if i == 0:
+                        lead['first_piece_wait_s'] = time.perf_counter() - t_wait
+                        lead['to_first_tile_s'] = time.perf_counter() - t_start
                 if i == 0 or mine[i - 1][0] != k:
                     if k != k_first:
                         ups[k].result()
@@ -839,10 +858,12 @@ class Predictor:
                             # upload_worker_s / download_worker_s: wall time the two copy workers spent in their jobs (host copies + issuing the DMA)
                             'rows_s': sum(a.elapsed_time(b) for a, b in row_events) / 1e3, 'upload_worker_s': busy['up'], 'download_worker_s': busy['down'],
                             'alloc_input_s': alloc_s['input'], 'alloc_output_s': alloc_s['output'],
-                            'fill_output_s': (fill_events[0].elapsed_time(fill_events[1]) / 1e3) if fill_events else 0.0}
+                            'fill_output_s': (fill_events[0].elapsed_time(fill_events[1]) / 1e3) if fill_events else 0.0, **lead}
         if row_events:      # (per row of tiles, in ms: a uniformly slower GPU shifts all three, interference shows in the maximum only)
-            per_row = sorted(a.elapsed_time(b) for a, b in row_events)
+            rows_ms = [a.elapsed_time(b) for a, b in row_events]
+            per_row = sorted(rows_ms)
             self.last_timing['row_ms_min_median_max'] = [round(per_row[0], 2), round(per_row[len(per_row) // 2], 2), round(per_row[-1], 2)]
+            self.last_timing['slowest_rows'] = [[i, round(rows_ms[i], 2)] for i in sorted(range(len(rows_ms)), key=lambda i: -rows_ms[i])[:3]]      # (row index in issue order, ms)
         if call_s:
             srt = sorted(call_s)
             self.last_timing.update(tile_call_s=srt[len(srt) // 4], tile_call_min_s=srt[0], tile_call_median_s=srt[len(srt) // 2])

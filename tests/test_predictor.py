@@ -445,16 +445,17 @@ def test_predictor_pinned_staging_switch_gives_the_same_volume(monkeypatch, dtyp
     m = UNet(in_channels=1, out_channels=2, n_blocks=2, start_filts=32, normalization='batch').cuda().eval().to(dtype)
     vol = torch.randn(1, 1, 40, 96, 130)                      # fp32 host volume, odd width (cropped rows on the way back)
     outs = []
-    for pinned in (True, False):
+    for pinned in ('rings with device twins', 'rings alone', False):        # (device twins of the slots: the default since round 6; without: torch's own temporaries)
         if pinned:
             monkeypatch.delenv('E3_PREDICTOR_NO_PINNED', raising=False)
-            monkeypatch.setattr(inference, '_RINGS', {0: (inference._PinnedRing(3 << 20), inference._PinnedRing(1 << 20))})   # small slots: several slabs per row
+            dev = torch.device('cuda:0') if pinned == 'rings with device twins' else None
+            monkeypatch.setattr(inference, '_RINGS', {0: (inference._PinnedRing(3 << 20, dev), inference._PinnedRing(1 << 20, dev))})   # small slots: several slabs per row
         else:
             monkeypatch.setenv('E3_PREDICTOR_NO_PINNED', '1')
         p = inference.Predictor(m, device='cuda', tile_shape=(20, 48, 65), overlap_shape=(8, 8, 8), out_shape=(2, 40, 96, 130), apply_softmax=True)
         assert p.dtype == dtype
         outs.append(p.predict(vol).clone())
-    assert outs[0].dtype == outs[1].dtype and torch.equal(outs[0], outs[1])
+    assert outs[0].dtype == outs[1].dtype == outs[2].dtype and torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
 
 
 @pytest.mark.gpu
