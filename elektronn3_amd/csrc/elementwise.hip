@@ -86,44 +86,46 @@ __global__ __launch_bounds__(1024) void bn_premerge_kernel(const float* __restri
 // Merges the per-tile (count, mean, M2) records of a channel in fp64, two division-free passes over the (L2-resident)
 // records:  N = sum n_i,  mu = sum n_i mean_i / N;  M2 = sum [ M2_i + n_i (mean_i - mu)^2 ].  Fixed order: deterministic.
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const BnFinalizeArgs a) {
-    __shared__ double sh[16][2];
-    __shared__ double bc[2];
+    // 256 threads for up to 256 records, 1024 beyond (launcher).  The kernel sits between a conv and the pass that applies its BatchNorm: all of its
+    // 5 - 7 us are latency on the step's critical path, 17 times per step.  Round 6: the thread's first record stays in registers for the second
+    // reduction (one trip to memory instead of two), and a reduction costs ONE barrier: every thread adds the wave sums itself, in wave order.
+    __shared__ double sh[2][16][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
     const int c = blockIdx.x;
-    auto block_sum2 = [&](double& x, double& y) {          // sums x and y over the workgroup, result in every thread
+    auto block_sum2 = [&](double& x, double& y, int which) {          // sums x and y over the workgroup, result in every thread
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { x += __shfl_xor(x, off); y += __shfl_xor(y, off); }
-        __syncthreads();                                    // (protects sh/bc against the previous use)
-        if (lane == 0) { sh[wave][0] = x; sh[wave][1] = y; }
+        if (lane == 0) { sh[which][wave][0] = x; sh[which][wave][1] = y; }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double sx = 0.0, sy = 0.0;
-            for (int w = 0; w < 16; ++w) { sx += sh[w][0]; sy += sh[w][1]; }
-            bc[0] = sx; bc[1] = sy;
-        }
-        __syncthreads();
-        x = bc[0]; y = bc[1];
+        double sx = 0.0, sy = 0.0;
+        for (int w = 0; w < nwaves; ++w) { sx += sh[which][w][0]; sy += sh[which][w][1]; }
+        x = sx; y = sy;
     };
     // group = 1: BatchNorm (statistics of channel c).  group > 1: GroupNorm -- the records of all `group` channels of c's group are
     // merged (nn.GroupNorm normalises over (C/G, D, H, W) of one sample; the caller passes one sample's records)
     const int gs = a.group > 1 ? a.group : 1;
     const int c_first = (c / gs) * gs;
     const int items = a.parts * gs;
-    double n = 0.0, s1 = 0.0;
-    for (int i = threadIdx.x; i < items; i += 1024) {
-        const float* r = a.stats + ((size_t)(i / gs) * a.C + c_first + i % gs) * 3;
+    auto record = [&](int i) { return a.stats + ((size_t)(i / gs) * a.C + c_first + i % gs) * 3; };
+    double nb0 = 0.0, mean0 = 0.0, m20 = 0.0;                          // this thread's first record
+    if ((int)threadIdx.x < items) { const float* r = record(threadIdx.x); nb0 = r[0]; mean0 = r[1]; m20 = r[2]; }
+    double n = nb0, s1 = nb0 * mean0;
+    for (int i = threadIdx.x + nthreads; i < items; i += nthreads) {
+        const float* r = record(i);
         const double nb = r[0];
         n += nb; s1 += nb * (double)r[1];
     }
-    block_sum2(n, s1);
+    block_sum2(n, s1, 0);
     const double mean = n > 0.0 ? s1 / n : 0.0;
-    double m2 = 0.0, unused = 0.0;
-    for (int i = threadIdx.x; i < items; i += 1024) {
-        const float* r = a.stats + ((size_t)(i / gs) * a.C + c_first + i % gs) * 3;
+    const double d0 = mean0 - mean;
+    double m2 = nb0 > 0.0 ? m20 + nb0 * d0 * d0 : 0.0, unused = 0.0;
+    for (int i = threadIdx.x + nthreads; i < items; i += nthreads) {
+        const float* r = record(i);
         const double nb = r[0], d = (double)r[1] - mean;
         m2 += nb > 0.0 ? (double)r[2] + nb * d * d : 0.0;
     }
-    block_sum2(m2, unused);
+    block_sum2(m2, unused, 1);
     if (threadIdx.x == 0) {
         const double var = n > 0.0 ? m2 / n : 0.0;
         const double invstd = 1.0 / sqrt(var + (double)a.eps);
@@ -851,7 +853,7 @@ int launch_bn_finalize(BnFinalizeArgs a, hipStream_t s) {
         hipLaunchKernelGGL(bn_premerge_kernel, dim3(BN_PRERED), dim3(1024), 0, s, a.stats, a.parts, a.C, a.scratch);
         a.stats = a.scratch; a.parts = BN_PRERED;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(a.parts * (a.group > 1 ? a.group : 1) <= 256 ? 256 : 1024), 0, s, a);
     E3_CHECK_HIP(hipGetLastError());
     return E3_OK;
 }
