@@ -63,3 +63,26 @@ def test_hugepage_advice_is_harmless_on_any_host_tensor(monkeypatch):
     assert int(big[0]) == 7 and int(big[-1]) == 9
     monkeypatch.setenv('E3_PREDICTOR_NO_HUGEPAGES', '1')
     inference._advise_hugepages(torch.empty(80 << 20, dtype=torch.uint8))
+
+
+def test_every_switch_of_the_gpu_switch_groups_is_read_somewhere():
+    """A switch group that sets an environment variable nobody reads would silently test the default path: every E3_* name in tests/test_switches_gpu.py's
+    groups and in README.md's switch list must occur in the library's or the package's sources."""
+    import glob
+    import re
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import test_switches_gpu as sw
+    src = ''
+    for pat in ('elektronn3_amd/csrc/*', 'elektronn3_amd/*.py', 'bench.py'):
+        for f in glob.glob(os.path.join(ROOT, pat)):
+            if os.path.isfile(f) and not f.endswith('.so'):
+                src += open(f, errors='ignore').read()
+    names = {k for env, _ in sw.GROUPS.values() for k in env}
+    missing = sorted(n for n in names if n not in src)
+    assert not missing, f'switches set by the test groups but read nowhere: {missing}'
+    readme = open(os.path.join(ROOT, 'README.md')).read()
+    start = readme.index('Switches for A/B runs')
+    listed = set(re.findall(r'`(E3_[A-Z0-9_]+)', readme[start:start + 12000]))
+    removed = readme[readme.index('Removed (alternatives'):][:1500] if 'Removed (alternatives' in readme else ''
+    stale = sorted(n for n in listed if n not in src and n not in removed)
+    assert not stale, f'switches documented in README.md but read nowhere: {stale}'
