@@ -776,7 +776,6 @@ class Predictor:
 
         row_events = []                                                   # (first, last) event of every row of tiles on the compute stream, behind its waits
         lead = {}                                                         # host time in front of the first tile (last_timing)
-        t_pool = time.perf_counter()
         with ThreadPoolExecutor(max_workers=1) as up_pool, ThreadPoolExecutor(max_workers=1) as down_pool:
             pieces = [up_pool.submit(upload_piece, j) for j in range(nty)] if zrows else []
             ups = {k: up_pool.submit(upload, k) for k in zrows[1:]}
